@@ -1,0 +1,202 @@
+/*
+ * lsfa_hip.h — C ABI of liblsfa_hip.so, the MI355X (gfx950) implementation of
+ * LSFA's per-frame inference hot path.
+ *
+ * Conventions (all entry points):
+ *   - plain C ABI: pointers + sizes, no C++/torch types.  Pointers are DEVICE
+ *     pointers unless the parameter name ends in `_host`.
+ *   - tensors are contiguous fp32 NCHW exactly as the reference operators
+ *     receive them from MXNet (psroi_pooling-inl.h:73-76 CheckContiguous).
+ *   - `stream` is a hipStream_t passed as void* (NULL = default stream).  No
+ *     entry point allocates, frees or synchronises unless documented; scratch
+ *     memory comes from the caller (`ws`, sized by lsfa_*_workspace_bytes), so
+ *     every launch sequence can be captured in a hipGraph.
+ *   - return value: 0 on success, a negative LSFA_E* code for argument errors,
+ *     or a positive hipError_t.  Nothing throws.  lsfa_last_error() returns a
+ *     thread-local message (the counterpart of MXGetLastError, which is how
+ *     the reference's CHECK_xx / LOG(FATAL) reach Python as MXNetError).
+ *
+ * Each declaration cites the reference interface it replaces
+ * (paths relative to the hustvl/LSFA tree).
+ */
+#ifndef LSFA_HIP_H_
+#define LSFA_HIP_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define LSFA_OK 0
+#define LSFA_EINVAL (-1)    /* bad argument (the reference's CHECK_EQ / CHECK_GT) */
+#define LSFA_EWORKSPACE (-2) /* workspace too small */
+#define LSFA_ENOTSUP (-3)   /* shape outside what the kernels support */
+
+const char* lsfa_last_error(void);
+/* ABI version of this header; bumped on any signature change. */
+int lsfa_abi_version(void);
+
+/* ------------------------------------------------------------------------ *
+ * Position-sensitive ROI pooling.
+ * Replaces: PSROIPoolingOp<gpu>::Forward   dff_rfcn/operator_cxx/psroi_pooling-inl.h:55-80
+ *           PSROIPoolForward / PSROIPoolForwardKernel  psroi_pooling.cu:32-128
+ *           params (spatial_scale, output_dim, pooled_size, group_size)  psroi_pooling-inl.h:33-47
+ * data  (N, output_dim*group*group, H, W);  rois (R,5) = [batch_idx,x1,y1,x2,y2]
+ * out   (R, output_dim, pooled, pooled)
+ * mapping_channel (R, output_dim, pooled, pooled) or NULL (the reference's
+ *       second, invisible output "maxidx"; written as float like the reference).
+ * ------------------------------------------------------------------------ */
+int lsfa_psroi_pool_fwd(const float* data, const float* rois,
+                        int N, int C, int H, int W, int R,
+                        float spatial_scale, int output_dim, int pooled_size, int group_size,
+                        float* out, float* mapping_channel, void* stream);
+
+/* Fused R-FCN head tail: PSROI pooling of the class map and of the box map,
+ * the global 7x7 average (Pooling global_pool avg) and the class softmax, in
+ * one launch, without materialising the (R,dim,7,7) tensors.
+ * Replaces: psroipooled_cls_rois / psroipooled_loc_rois / ave_cls_scors_rois /
+ *           ave_bbox_pred_rois / cls_prob   dff_rfcn/symbols/resnet_v1_101_flownet_rfcn.py:520-540 (key), :628-648 (cur)
+ * cls_map (N, ncls*g*g, H, W), box_map (N, nbox*g*g, H, W), rois (R,5)
+ * cls_prob (R, ncls)  softmax over classes;  cls_score (R,ncls) pre-softmax average or NULL
+ * bbox_pred (R, nbox)
+ * ------------------------------------------------------------------------ */
+int lsfa_rfcn_head_fwd(const float* cls_map, const float* box_map, const float* rois,
+                       int N, int H, int W, int R, int ncls, int nbox,
+                       float spatial_scale, int pooled_size, int group_size,
+                       float* cls_prob, float* cls_score, float* bbox_pred, void* stream);
+
+/* ------------------------------------------------------------------------ *
+ * Motion-vector / flow guided bilinear feature warp with fused epilogue.
+ * Replaces: mx.sym.GridGenerator(transform_type='warp') + mx.sym.BilinearSampler
+ *           at resnet_v1_101_flownet_rfcn.py:468-469 (key), :571-572 (cur), :678-679 (batch)
+ *           `* scale_map` :470 ; res_diff_ada (rnet_conv0 1x1 3->C, +bias) :57-67 and
+ *           `conv_feat + res_diff` :576 ; `cur_feat + warp_conv_feat` :236.
+ * out[n,c,y,x] = bilerp(feat[n,c], x+flow[n,0,y,x], y+flow[n,1,y,x])   (taps outside the map are 0)
+ *                [* mul[n,c,y,x]]                                         if mul  != NULL
+ *                [+ (res_w[c,:] . res[n,:,y,x] + res_b[c])]               if res  != NULL (res has res_c channels)
+ *                [+ add[n,c,y,x]]                                         if add  != NULL
+ * feat may have batch 1 while flow has batch N (feat_n = 1 or N): the
+ * key-frame feature is broadcast, as tile_as does (operator_py/tile_as.py:16-19).
+ * ------------------------------------------------------------------------ */
+int lsfa_warp_bilinear(const float* feat, int feat_n, const float* flow,
+                       int N, int C, int H, int W,
+                       const float* mul, const float* add,
+                       const float* res, int res_c, const float* res_w, const float* res_b,
+                       float* out, void* stream);
+
+/* ------------------------------------------------------------------------ *
+ * Long-term aggregation combine (Nq_net tail).
+ * Replaces: softmax(axis=0) + SliceChannel + tile x2 + mul x2 + add
+ *           resnet_v1_101_flownet_rfcn.py:104-108
+ * logits (2,1,H,W): index 0 weights `a` (warped old key feature), 1 weights `b`.
+ * out = w0*a + w1*b,  (w0,w1) = softmax(logits[:, 0, y, x]).
+ * ------------------------------------------------------------------------ */
+int lsfa_aggregate_softmax2(const float* a, const float* b, const float* logits,
+                            int C, int H, int W, float* out, void* stream);
+
+/* Fgfa variant: weights from cosine similarity of 2 embeddings
+ * Replaces: compute_weight + softmax + tile/mul/add  resnet_v1_101_flownet_rfcn.py:111-116, :136-147
+ * emb_cur, emb_warp (1,E,H,W); a = warped feature, b = current feature (1,C,H,W).
+ * w_a = <norm(emb_warp), norm(emb_cur)>, w_b = <norm(emb_cur), norm(emb_cur)>, softmax over the two. */
+int lsfa_aggregate_cosine(const float* a, const float* b, const float* emb_warp, const float* emb_cur,
+                          int C, int E, int H, int W, float* out, void* stream);
+
+/* ------------------------------------------------------------------------ *
+ * RPN proposal generation (anchors -> decode -> clip -> filter -> stable sort
+ * -> top pre_n -> NMS -> first post_n, cyclic pad).
+ * Replaces: MultiProposalGPUOp::Forward  dff_rfcn/operator_cxx/multi_proposal.cu:403-558
+ *           (+ kernels :47-388, anchors multi_proposal-inl.h:256-295, params :124-159);
+ *           this is also the in-repo specification of mx.contrib.sym.Proposal as called at
+ *           resnet_v1_101_flownet_rfcn.py:501, :609.
+ * cls_prob (B, 2A, H, W), bbox_pred (B, 4A, H, W), im_info (B,3) = [im_h, im_w, im_scale]
+ * rois (B*post_n, 5), scores (B*post_n, 1) or NULL.
+ * `ws` must hold lsfa_proposal_workspace_bytes(...) bytes.
+ * ------------------------------------------------------------------------ */
+size_t lsfa_proposal_workspace_bytes(int B, int A, int H, int W, int pre_nms_top_n);
+int lsfa_proposal(const float* cls_prob, const float* bbox_pred, const float* im_info,
+                  int B, int A, int H, int W, int feature_stride,
+                  const float* scales_host, int n_scales, const float* ratios_host, int n_ratios,
+                  int rpn_pre_nms_top_n, int rpn_post_nms_top_n, float threshold, int rpn_min_size,
+                  float* rois, float* scores, void* ws, size_t ws_bytes, void* stream);
+
+/* ------------------------------------------------------------------------ *
+ * NMS on score-sorted boxes, device resident.
+ * Replaces: nms_kernel + the host sweep of _nms   lib/nms/nms_kernel.cu:40-84, :97-150
+ *           and multi_proposal.cu:262-357.
+ * boxes (n, box_dim>=4) sorted by score descending; keep (n) int32 indices into
+ * boxes, num_keep (1) int32; both device.  ws >= lsfa_nms_workspace_bytes(n).
+ * ------------------------------------------------------------------------ */
+size_t lsfa_nms_workspace_bytes(int n);
+int lsfa_nms_sorted(const float* boxes, int n, int box_dim, float thresh,
+                    int* keep, int* num_keep, void* ws, size_t ws_bytes, void* stream);
+
+/* The reference's exact host-pointer entry point (lib/nms/gpu_nms.hpp:14-15):
+ * boxes_host (boxes_num, boxes_dim) already sorted by score; keep_out has room
+ * for boxes_num ints.  Allocates, copies and synchronises like the original. */
+void _nms(int* keep_out, int* num_out, const float* boxes_host, int boxes_num,
+          int boxes_dim, float nms_overlap_thresh, int device_id);
+
+/* ------------------------------------------------------------------------ *
+ * Per-frame detection post-processing, all classes in one launch.
+ * Replaces: bbox_pred (nonlinear_pred) lib/bbox/bbox_transform.py:103-140, clip_boxes :45-60,
+ *           `/ scale` dff_rfcn/core/tester.py:148-152, and the per-class threshold + NMS +
+ *           max_per_image loop tester.py:265-281 (py_nms_wrapper -> lib/nms/nms.py:37-74).
+ * rois (R,5) [batch,x1,y1,x2,y2]; deltas (R, 4*nreg); probs (R, ncls).
+ * class_agnostic != 0: every class uses delta columns 4:8 (tester.py:269).
+ * Arithmetic is float64 like the numpy reference (nonlinear_pred upcasts, :114).
+ * Outputs: dets (ncls, R, 5) float64 rows [x1,y1,x2,y2,score] for the survivors of
+ * class j in NMS (score-descending) order, counts (ncls) int32 (class 0 = background: count 0),
+ * keep_idx (ncls, R) int32 = roi index of each survivor (may be NULL).
+ * max_per_image <= 0 disables the cap.
+ * ------------------------------------------------------------------------ */
+size_t lsfa_det_workspace_bytes(int R, int ncls);
+int lsfa_det_postprocess(const float* rois, const float* deltas, const float* probs,
+                         int R, int ncls, int nreg, int class_agnostic,
+                         double im_h, double im_w, double scale,
+                         double score_thresh, double nms_thresh, int max_per_image,
+                         double* dets, int* counts, int* keep_idx,
+                         void* ws, size_t ws_bytes, void* stream);
+
+/* Box decode + clip + rescale only (float64 out), for callers that keep the
+ * reference's im_detect() signature:  tester.py:143-152. pred_boxes (R, 4*nreg) */
+int lsfa_bbox_pred_clip(const float* rois, const float* deltas, int R, int nreg,
+                        double im_h, double im_w, double scale, double* pred_boxes, void* stream);
+
+/* ------------------------------------------------------------------------ *
+ * Deformable convolution support: bilinear im2col of the DCN units
+ * (mx.contrib.symbol.DeformableConvolution, dff_rfcn/symbols/sym_common.py:138-157).
+ * data (N,C,H,W), offset (N, 2*kh*kw*dg, Ho, Wo) -> col (N, C*kh*kw, Ho*Wo);
+ * the GEMM with the (Cout, C*kh*kw) weight is the caller's (MFMA library GEMM).
+ * ------------------------------------------------------------------------ */
+int lsfa_deform_im2col(const float* data, const float* offset,
+                       int N, int C, int H, int W, int kh, int kw,
+                       int pad, int stride, int dilate, int deform_groups,
+                       int Ho, int Wo, float* col, void* stream);
+
+/* Inference BatchNorm (use_global_stats) + ReLU as one pass: y = max(x*scale[c]+shift[c], 0)
+ * (sym_common.py:92-102 bn + relu of every pre-activation unit, resnet.py:70-101).
+ * relu != 0 applies the ReLU.  In-place (y == x) allowed. */
+int lsfa_scale_shift_relu(const float* x, const float* scale, const float* shift,
+                          int N, int C, int HW, int relu, float* y, void* stream);
+
+/* ------------------------------------------------------------------------ *
+ * Live per-op timing with HIP events on the launch stream (bench.py's roofline leg).
+ * lsfa_prof_enable(1) makes every entry point above bracket its launches with
+ * hipEventRecord on `stream`; lsfa_prof_read synchronises the events and returns
+ * accumulated milliseconds and launch counts per op id, then clears them.
+ * ------------------------------------------------------------------------ */
+enum {
+  LSFA_OP_PSROI = 0, LSFA_OP_RFCN_HEAD = 1, LSFA_OP_WARP = 2, LSFA_OP_AGG = 3,
+  LSFA_OP_PROPOSAL = 4, LSFA_OP_NMS = 5, LSFA_OP_DET = 6, LSFA_OP_DCN_IM2COL = 7,
+  LSFA_OP_BNRELU = 8, LSFA_OP_COUNT = 9
+};
+int lsfa_prof_enable(int on);
+int lsfa_prof_read(double* ms_host /*LSFA_OP_COUNT*/, int* launches_host /*LSFA_OP_COUNT*/);
+const char* lsfa_op_name(int op_id);
+
+#ifdef __cplusplus
+}
+#endif
+#endif  /* LSFA_HIP_H_ */

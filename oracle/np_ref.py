@@ -1,0 +1,170 @@
+"""numpy restatement of the reference's numpy helpers — TEST INFRASTRUCTURE ONLY.
+
+These follow the reference line by line where the reference itself is numpy, so
+the golden vectors captured from the reference (tests/golden/ref_golden.npz) pin
+them directly.  Paths are relative to the hustvl/LSFA tree.
+"""
+import numpy as np
+
+
+# ---- lib/rpn/generate_anchor.py:21-85 ------------------------------------------------
+def _whctrs(anchor):
+    w = anchor[2] - anchor[0] + 1
+    h = anchor[3] - anchor[1] + 1
+    return w, h, anchor[0] + 0.5 * (w - 1), anchor[1] + 0.5 * (h - 1)
+
+
+def _mkanchors(ws, hs, x_ctr, y_ctr):
+    ws, hs = ws[:, np.newaxis], hs[:, np.newaxis]
+    return np.hstack((x_ctr - 0.5 * (ws - 1), y_ctr - 0.5 * (hs - 1),
+                      x_ctr + 0.5 * (ws - 1), y_ctr + 0.5 * (hs - 1)))
+
+
+def generate_anchors(base_size=16, ratios=(0.5, 1, 2), scales=2 ** np.arange(3, 6)):
+    ratios, scales = np.asarray(ratios, dtype=np.float64), np.asarray(scales)
+    base_anchor = np.array([1, 1, base_size, base_size]) - 1
+    w, h, x_ctr, y_ctr = _whctrs(base_anchor)
+    size_ratios = (w * h) / ratios
+    ws = np.round(np.sqrt(size_ratios))
+    hs = np.round(ws * ratios)
+    ratio_anchors = _mkanchors(ws, hs, x_ctr, y_ctr)
+    out = []
+    for i in range(ratio_anchors.shape[0]):
+        w, h, x_ctr, y_ctr = _whctrs(ratio_anchors[i, :])
+        out.append(_mkanchors(w * scales, h * scales, x_ctr, y_ctr))
+    return np.vstack(out)
+
+
+# ---- lib/nms/nms.py:37-74 -------------------------------------------------------------
+def nms(dets, thresh):
+    """Greedy NMS, keeps `ovr <= thresh`.  The reference orders with
+    `scores.argsort()[::-1]`, whose tie order is whatever numpy's unstable sort
+    yields; this restatement fixes ties as (score desc, index asc)."""
+    if dets.shape[0] == 0:
+        return []
+    x1, y1, x2, y2, scores = dets[:, 0], dets[:, 1], dets[:, 2], dets[:, 3], dets[:, 4]
+    areas = (x2 - x1 + 1) * (y2 - y1 + 1)
+    order = np.argsort(-scores, kind="stable")
+    keep = []
+    while order.size > 0:
+        i = order[0]
+        keep.append(int(i))
+        xx1 = np.maximum(x1[i], x1[order[1:]])
+        yy1 = np.maximum(y1[i], y1[order[1:]])
+        xx2 = np.minimum(x2[i], x2[order[1:]])
+        yy2 = np.minimum(y2[i], y2[order[1:]])
+        w = np.maximum(0.0, xx2 - xx1 + 1)
+        h = np.maximum(0.0, yy2 - yy1 + 1)
+        inter = w * h
+        ovr = inter / (areas[i] + areas[order[1:]] - inter)
+        inds = np.where(ovr <= thresh)[0]
+        order = order[inds + 1]
+    return keep
+
+
+# ---- lib/bbox/bbox_transform.py:45-60, :103-140 -----------------------------------------
+def clip_boxes(boxes, im_shape):
+    boxes[:, 0::4] = np.maximum(np.minimum(boxes[:, 0::4], im_shape[1] - 1), 0)
+    boxes[:, 1::4] = np.maximum(np.minimum(boxes[:, 1::4], im_shape[0] - 1), 0)
+    boxes[:, 2::4] = np.maximum(np.minimum(boxes[:, 2::4], im_shape[1] - 1), 0)
+    boxes[:, 3::4] = np.maximum(np.minimum(boxes[:, 3::4], im_shape[0] - 1), 0)
+    return boxes
+
+
+def bbox_pred(boxes, box_deltas):
+    if boxes.shape[0] == 0:
+        return np.zeros((0, box_deltas.shape[1]))
+    boxes = boxes.astype(np.float64, copy=False)
+    widths = boxes[:, 2] - boxes[:, 0] + 1.0
+    heights = boxes[:, 3] - boxes[:, 1] + 1.0
+    ctr_x = boxes[:, 0] + 0.5 * (widths - 1.0)
+    ctr_y = boxes[:, 1] + 0.5 * (heights - 1.0)
+    dx, dy, dw, dh = box_deltas[:, 0::4], box_deltas[:, 1::4], box_deltas[:, 2::4], box_deltas[:, 3::4]
+    pred_ctr_x = dx * widths[:, np.newaxis] + ctr_x[:, np.newaxis]
+    pred_ctr_y = dy * heights[:, np.newaxis] + ctr_y[:, np.newaxis]
+    pred_w = np.exp(dw) * widths[:, np.newaxis]
+    pred_h = np.exp(dh) * heights[:, np.newaxis]
+    pred_boxes = np.zeros(box_deltas.shape)
+    pred_boxes[:, 0::4] = pred_ctr_x - 0.5 * (pred_w - 1.0)
+    pred_boxes[:, 1::4] = pred_ctr_y - 0.5 * (pred_h - 1.0)
+    pred_boxes[:, 2::4] = pred_ctr_x + 0.5 * (pred_w - 1.0)
+    pred_boxes[:, 3::4] = pred_ctr_y + 0.5 * (pred_h - 1.0)
+    return pred_boxes
+
+
+def bbox_overlaps(boxes, query_boxes):
+    """bbox_overlaps_py, lib/bbox/bbox_transform.py:22-42 (vectorised)."""
+    n_, k_ = boxes.shape[0], query_boxes.shape[0]
+    overlaps = np.zeros((n_, k_), dtype=np.float64)
+    for k in range(k_):
+        qa = (query_boxes[k, 2] - query_boxes[k, 0] + 1) * (query_boxes[k, 3] - query_boxes[k, 1] + 1)
+        for n in range(n_):
+            iw = min(boxes[n, 2], query_boxes[k, 2]) - max(boxes[n, 0], query_boxes[k, 0]) + 1
+            if iw > 0:
+                ih = min(boxes[n, 3], query_boxes[k, 3]) - max(boxes[n, 1], query_boxes[k, 1]) + 1
+                if ih > 0:
+                    ba = (boxes[n, 2] - boxes[n, 0] + 1) * (boxes[n, 3] - boxes[n, 1] + 1)
+                    overlaps[n, k] = iw * ih / float(ba + qa - iw * ih)
+    return overlaps
+
+
+# ---- dff_rfcn/core/tester.py:143-152, :265-281 ------------------------------------------
+def im_detect_post(rois, scores, bbox_deltas, im_shape, scale):
+    """rois (R,5) float32, bbox_deltas (R, 4*nreg) float32 -> pred_boxes float64."""
+    pred_boxes = bbox_pred(rois[:, 1:], bbox_deltas)
+    pred_boxes = clip_boxes(pred_boxes, im_shape[-2:])
+    return scores, pred_boxes / scale
+
+
+def pred_eval_post(scores, boxes, num_classes, thresh=1e-4, nms_thresh=0.3, max_per_image=300,
+                   class_agnostic=True):
+    """Returns all_boxes[j] = (n_j, 5) float64 for j in 0..num_classes-1 (class 0 empty)."""
+    all_boxes = [np.zeros((0, 5))] * num_classes
+    for j in range(1, num_classes):
+        indexes = np.where(scores[:, j] > thresh)[0]
+        cls_scores = scores[indexes, j, np.newaxis]
+        cls_boxes = boxes[indexes, 4:8] if class_agnostic else boxes[indexes, j * 4:(j + 1) * 4]
+        cls_dets = np.hstack((cls_boxes, cls_scores))
+        keep = nms(cls_dets, nms_thresh)
+        all_boxes[j] = cls_dets[keep, :]
+    if max_per_image > 0:
+        image_scores = np.hstack([all_boxes[j][:, -1] for j in range(1, num_classes)])
+        if len(image_scores) > max_per_image:
+            image_thresh = np.sort(image_scores)[-max_per_image]
+            for j in range(1, num_classes):
+                keep = np.where(all_boxes[j][:, -1] >= image_thresh)[0]
+                all_boxes[j] = all_boxes[j][keep, :]
+    return all_boxes
+
+
+# ---- dff_rfcn/core/loader.py:87-141 ------------------------------------------------------
+def key_frame_flags(seg_lens, key_frame_interval):
+    """Flag sequence TestLoader emits: 0 first frame of a video, 1 key frame
+    (every KEY_FRAME_INTERVAL and the last frame of each video), 2 non-key."""
+    flags = []
+    for L in seg_lens:
+        key_frameid = 0
+        for f in range(L):
+            if key_frameid == f:
+                flags.append(0 if key_frameid == 0 else 1)
+            elif f + 1 == L:
+                flags.append(1)
+            else:
+                flags.append(2)
+            nf = f + 1
+            if nf == L:
+                pass
+            elif nf - key_frameid == key_frame_interval:
+                key_frameid = nf
+    return flags
+
+
+# ---- dff_rfcn/function/test_rcnn.py:69-75 ------------------------------------------------
+def shard_videos(seg_lens, gpu_num):
+    shards = [[] for _ in range(gpu_num)]
+    acc = np.zeros(gpu_num, dtype=np.int64)
+    for vid, L in enumerate(seg_lens):
+        g = int(np.argmin(acc))
+        shards[g].append(vid)
+        acc[g] += L
+    return shards

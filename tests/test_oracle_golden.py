@@ -1,0 +1,104 @@
+"""The oracle against the golden vectors captured from the reference's own numpy
+helpers (tests/golden/make_golden.py).  CPU only."""
+import numpy as np
+import pytest
+
+import oracle
+from oracle import np_ref
+
+
+def test_g1_anchor_table(golden):
+    # C++ anchor generator (multi_proposal-inl.h:256-295) == numpy generator (generate_anchor.py)
+    a = oracle.generate_anchors(16, (0.5, 1, 2), (8, 16, 32))
+    assert a.dtype == np.float32
+    np.testing.assert_array_equal(a.astype(np.float64), golden["g1_anchors"])
+    np.testing.assert_array_equal(np_ref.generate_anchors(16, [0.5, 1, 2], np.array([8, 16, 32])), golden["g1_anchors"])
+    np.testing.assert_array_equal(golden["g1_anchors"][0], [-84, -40, 99, 55])
+    np.testing.assert_array_equal(golden["g1_anchors"][-1], [-168, -344, 183, 359])
+
+
+@pytest.mark.parametrize("n", [50, 300, 2000])
+@pytest.mark.parametrize("th", [0.3, 0.7])
+def test_g2_nms_float64(golden, n, th):
+    dets = golden["g2_n%d_float64_dets" % n]
+    want = golden["g2_n%d_float64_keep_%02d" % (n, int(th * 10))]
+    np.testing.assert_array_equal(np.asarray(np_ref.nms(dets, th)), want)
+    np.testing.assert_array_equal(oracle.nms_f64(dets, th), want)
+
+
+@pytest.mark.parametrize("n", [50, 300, 2000])
+@pytest.mark.parametrize("th", [0.3, 0.7])
+def test_g2_nms_float32_bitmask_equivalence(golden, n, th):
+    """The CUDA bitmask NMS restatement (float32 devIoU, `> thresh` suppresses) returns the
+    reference numpy nms's survivors on the same float32 boxes."""
+    dets = golden["g2_n%d_float32_dets" % n]
+    want = golden["g2_n%d_float32_keep_%02d" % (n, int(th * 10))]
+    np.testing.assert_array_equal(np.asarray(np_ref.nms(dets, th)), want)
+    np.testing.assert_array_equal(np.asarray(oracle.gpu_nms(dets, th)), want)
+    # the materialised mask swept like nms_kernel.cu:133-146 agrees with the greedy loop
+    order = np.argsort(-dets[:, 4], kind="stable")
+    srt = dets[order]
+    mask = oracle.nms_mask(srt, th)
+    remv = np.zeros(mask.shape[1], np.uint64)
+    keep = []
+    for i in range(n):
+        if not (int(remv[i // 64]) >> (i % 64)) & 1:
+            keep.append(i)
+            remv[i // 64:] |= mask[i, i // 64:]
+    np.testing.assert_array_equal(order[keep], want)
+
+
+def test_g2_empty(golden):
+    assert golden["g2_empty_keep"].size == 0
+    assert np_ref.nms(np.zeros((0, 5), np.float32), 0.3) == []
+    assert oracle.nms_f64(np.zeros((0, 5)), 0.3).size == 0
+    assert oracle.nms_sorted(np.zeros((0, 5), np.float32), 0.3).size == 0
+
+
+def test_g3_bbox_pred_clip(golden):
+    rois, deltas = golden["g3_rois"], golden["g3_deltas"]
+    np.testing.assert_array_equal(np_ref.bbox_pred(rois, deltas), golden["g3_pred"])
+    np.testing.assert_array_equal(np_ref.clip_boxes(np_ref.bbox_pred(rois, deltas), (600, 1000)), golden["g3_clip"])
+    # C restatement: numpy's float32 exp is not correctly rounded, the oracle's is -> 1e-6 relative
+    rois5 = np.hstack([np.zeros((rois.shape[0], 1), np.float32), rois])
+    got = oracle.bbox_pred_clip(rois5, deltas, 600, 1000, 1.0)
+    np.testing.assert_allclose(got, golden["g3_clip"], rtol=2e-6, atol=2e-4)
+    assert golden["g3_empty"].shape == (0, 8)
+
+
+def test_g4_iou_convention(golden):
+    a, b = golden["g4_a"], golden["g4_b"]
+    np.testing.assert_array_equal(np_ref.bbox_overlaps(a, b), golden["g4_iou"])
+    # float32 devIoU agrees with the float64 matrix to float32 precision (+1 area convention)
+    for i in range(0, 40, 7):
+        for k in range(0, 25, 5):
+            assert abs(oracle.dev_iou(a[i], b[k]) - golden["g4_iou"][i, k]) < 1e-5
+
+
+def test_g5_frame_postprocess(golden):
+    rois, deltas, probs = golden["g5_rois"], golden["g5_deltas"], golden["g5_probs"]
+    scale = float(golden["g5_scale"])
+    _, pred = np_ref.im_detect_post(rois, probs, deltas, (1, 3, 600, 1000), scale)
+    np.testing.assert_array_equal(pred, golden["g5_pred_boxes"])
+    all_boxes = np_ref.pred_eval_post(probs, pred, 31)
+    np.testing.assert_array_equal([len(b) for b in all_boxes], golden["g5_counts"])
+    np.testing.assert_array_equal(np.vstack(all_boxes), golden["g5_dets"])
+    assert int(golden["g5_n_before_cap"]) > 300 and int(golden["g5_counts"].sum()) == 300
+    # C restatement of the whole frame post-processing
+    dets, counts, keep_idx = oracle.det_postprocess(rois, deltas, probs, 600, 1000, scale)
+    np.testing.assert_array_equal(counts, golden["g5_counts"])
+    got = np.vstack([dets[j, :counts[j]] for j in range(31)])
+    np.testing.assert_allclose(got, golden["g5_dets"], rtol=2e-6, atol=2e-4)
+    np.testing.assert_array_equal(got[:, 4], golden["g5_dets"][:, 4])
+
+
+def test_key_frame_flags():
+    # SURVEY.md A.5 state machine, dff_rfcn/core/loader.py:87-141
+    f = np_ref.key_frame_flags([25], 10)
+    assert f[0] == 0 and f[10] == 1 and f[20] == 1 and f[24] == 1
+    assert all(x == 2 for i, x in enumerate(f) if i not in (0, 10, 20, 24))
+    f = np_ref.key_frame_flags([144], 12)
+    assert [i for i, x in enumerate(f) if x != 2] == list(range(0, 144, 12)) + [143]
+    f = np_ref.key_frame_flags([3, 2], 10)
+    assert f == [0, 2, 1, 0, 1]
+    assert np_ref.shard_videos([10, 9, 8, 7, 1], 2) == [[0, 3, 4], [1, 2]]

@@ -1,0 +1,116 @@
+// Deformable-convolution bilinear im2col and the fused inference BatchNorm+ReLU pass.
+// Reference interfaces: include/lsfa_hip.h.  Arithmetic = oracle orc_deform_im2col /
+// orc_scale_shift_relu.
+#include "common.h"
+
+using namespace lsfa;
+
+namespace {
+
+constexpr int kThreads = 256;
+
+__device__ __forceinline__ float dcn_bilinear(const float* __restrict__ plane, int data_width, int height, int width,
+                                              float h, float w) {
+  int h_low = (int)floorf(h), w_low = (int)floorf(w);
+  int h_high, w_high;
+  if (h_low >= height - 1) { h_high = h_low = height - 1; h = (float)h_low; } else { h_high = h_low + 1; }
+  if (w_low >= width - 1) { w_high = w_low = width - 1; w = (float)w_low; } else { w_high = w_low + 1; }
+  const float lh = h - h_low, lw = w - w_low, hh = 1 - lh, hw = 1 - lw;
+  const float v1 = plane[h_low * data_width + w_low], v2 = plane[h_low * data_width + w_high];
+  const float v3 = plane[h_high * data_width + w_low], v4 = plane[h_high * data_width + w_high];
+  const float w1 = hh * hw, w2 = hh * lw, w3 = lh * hw, w4 = lh * lw;
+  return w1 * v1 + w2 * v2 + w3 * v3 + w4 * v4;
+}
+
+// thread -> (n, c, tap, ho, wo) with wo fastest: offsets and col are accessed coalesced,
+// the four data taps are near-contiguous gathers.  A thread handles one tap so that the
+// (kh*kw) x (Ho*Wo) plane of col rows is written as full lines.
+__global__ __launch_bounds__(kThreads) void deform_im2col_kernel(const float* __restrict__ data,
+                                                                 const float* __restrict__ offset, int C, int H, int W,
+                                                                 int kh, int kw, int pad, int stride, int dilate,
+                                                                 int dg, int Ho, int Wo, float* __restrict__ col,
+                                                                 size_t total) {
+  const int HoWo = Ho * Wo, KK = kh * kw, cpg = C / dg;
+  for (size_t idx = (size_t)blockIdx.x * kThreads + threadIdx.x; idx < total; idx += (size_t)gridDim.x * kThreads) {
+    const int sp = (int)(idx % HoWo);
+    const int tap = (int)((idx / HoWo) % KK);
+    const int c = (int)((idx / HoWo / KK) % C);
+    const int n = (int)(idx / HoWo / KK / C);
+    const int ho = sp / Wo, wo = sp - ho * Wo;
+    const int i = tap / kw, j = tap - i * kw;
+    const int g = c / cpg;
+    const float* off = offset + ((size_t)n * dg + g) * 2 * KK * HoWo;
+    const float oh = off[(size_t)(2 * tap) * HoWo + sp];
+    const float ow = off[(size_t)(2 * tap + 1) * HoWo + sp];
+    const float h_im = (float)(ho * stride - pad + i * dilate) + oh;
+    const float w_im = (float)(wo * stride - pad + j * dilate) + ow;
+    float val = 0.f;
+    if (h_im >= 0 && w_im >= 0 && h_im < H && w_im < W)
+      val = dcn_bilinear(data + ((size_t)n * C + c) * H * W, W, H, W, h_im, w_im);
+    col[idx] = val;
+  }
+}
+
+template <int VEC>
+__global__ __launch_bounds__(kThreads) void scale_shift_relu_kernel(const float* __restrict__ x,
+                                                                    const float* __restrict__ scale,
+                                                                    const float* __restrict__ shift, int C, int HW,
+                                                                    int relu, float* __restrict__ y, size_t nvec) {
+  for (size_t v = (size_t)blockIdx.x * kThreads + threadIdx.x; v < nvec; v += (size_t)gridDim.x * kThreads) {
+    const size_t e = v * VEC;
+    const int c = (int)((e / HW) % C);
+    const float sc = scale[c], sh = shift[c];
+    float in[VEC], out[VEC];
+    if (VEC == 4) { const float4 t = *reinterpret_cast<const float4*>(x + e); in[0] = t.x; in[1] = t.y; in[2] = t.z; in[3] = t.w; }
+    else if (VEC == 2) { const float2 t = *reinterpret_cast<const float2*>(x + e); in[0] = t.x; in[1] = t.y; }
+    else in[0] = x[e];
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) {
+      const float r = in[i] * sc + sh;
+      out[i] = (relu && r < 0.f) ? 0.f : r;
+    }
+    if (VEC == 4) *reinterpret_cast<float4*>(y + e) = make_float4(out[0], out[1], out[2], out[3]);
+    else if (VEC == 2) *reinterpret_cast<float2*>(y + e) = make_float2(out[0], out[1]);
+    else y[e] = out[0];
+  }
+}
+
+}  // namespace
+
+extern "C" int lsfa_deform_im2col(const float* data, const float* offset, int N, int C, int H, int W, int kh, int kw,
+                                  int pad, int stride, int dilate, int deform_groups, int Ho, int Wo, float* col,
+                                  void* stream) {
+  LSFA_REQUIRE(data && offset && col, "lsfa_deform_im2col: NULL argument");
+  LSFA_REQUIRE(N > 0 && C > 0 && H > 0 && W > 0 && kh > 0 && kw > 0 && stride > 0 && dilate > 0 && Ho > 0 && Wo > 0,
+               "lsfa_deform_im2col: bad shape");
+  LSFA_REQUIRE(deform_groups > 0 && C % deform_groups == 0, "lsfa_deform_im2col: C=%d not divisible by deformable groups %d",
+               C, deform_groups);
+  hipStream_t s = (hipStream_t)stream;
+  const size_t total = (size_t)N * C * kh * kw * Ho * Wo;
+  size_t nb = (total + kThreads - 1) / kThreads;
+  if (nb > 65536) nb = 65536;
+  ProfScope prof(LSFA_OP_DCN_IM2COL, s);
+  hipLaunchKernelGGL(deform_im2col_kernel, dim3((unsigned)nb), dim3(kThreads), 0, s, data, offset, C, H, W, kh, kw, pad,
+                     stride, dilate, deform_groups, Ho, Wo, col, total);
+  LSFA_LAUNCH_CHECK("lsfa_deform_im2col");
+  return LSFA_OK;
+}
+
+extern "C" int lsfa_scale_shift_relu(const float* x, const float* scale, const float* shift, int N, int C, int HW,
+                                     int relu, float* y, void* stream) {
+  LSFA_REQUIRE(x && scale && shift && y, "lsfa_scale_shift_relu: NULL argument");
+  LSFA_REQUIRE(N > 0 && C > 0 && HW > 0, "lsfa_scale_shift_relu: bad shape");
+  hipStream_t s = (hipStream_t)stream;
+  const size_t total = (size_t)N * C * HW;
+  int vec = (HW % 4 == 0) ? 4 : (HW % 2 == 0) ? 2 : 1;
+  if (((uintptr_t)x % (4 * vec)) || ((uintptr_t)y % (4 * vec))) vec = 1;
+  const size_t nvec = total / vec;
+  size_t nb = (nvec + kThreads - 1) / kThreads;
+  if (nb > 4096) nb = 4096;
+  ProfScope prof(LSFA_OP_BNRELU, s);
+  if (vec == 4) hipLaunchKernelGGL(scale_shift_relu_kernel<4>, dim3((unsigned)nb), dim3(kThreads), 0, s, x, scale, shift, C, HW, relu, y, nvec);
+  else if (vec == 2) hipLaunchKernelGGL(scale_shift_relu_kernel<2>, dim3((unsigned)nb), dim3(kThreads), 0, s, x, scale, shift, C, HW, relu, y, nvec);
+  else hipLaunchKernelGGL(scale_shift_relu_kernel<1>, dim3((unsigned)nb), dim3(kThreads), 0, s, x, scale, shift, C, HW, relu, y, nvec);
+  LSFA_LAUNCH_CHECK("lsfa_scale_shift_relu");
+  return LSFA_OK;
+}

@@ -1,0 +1,82 @@
+// NMS on score-sorted boxes: device-resident entry point and the reference's
+// host-pointer `_nms` (lib/nms/gpu_nms.hpp:14-15).  Kernels: nms_kernels.h.
+#include <vector>
+
+#include "nms_kernels.h"
+
+using namespace lsfa;
+
+extern "C" size_t lsfa_nms_workspace_bytes(int n) {
+  if (n <= 0) return 256;
+  const size_t col_blocks = (size_t)ceil_div(n, 64);
+  return align_up((size_t)n * col_blocks * sizeof(uint64_t), 256);
+}
+
+extern "C" int lsfa_nms_sorted(const float* boxes, int n, int box_dim, float thresh, int* keep, int* num_keep,
+                               void* ws, size_t ws_bytes, void* stream) {
+  LSFA_REQUIRE(n >= 0 && box_dim >= 4, "lsfa_nms_sorted: bad shape n=%d box_dim=%d", n, box_dim);
+  LSFA_REQUIRE(keep && num_keep, "lsfa_nms_sorted: keep/num_keep must be non-NULL");
+  hipStream_t s = (hipStream_t)stream;
+  if (n == 0) {
+    hipError_t e = hipMemsetAsync(num_keep, 0, sizeof(int), s);
+    if (e != hipSuccess) return hip_fail(e, "lsfa_nms_sorted: hipMemsetAsync");
+    return LSFA_OK;
+  }
+  LSFA_REQUIRE(boxes && ws, "lsfa_nms_sorted: boxes/ws must be non-NULL");
+  const int col_blocks = ceil_div(n, 64);
+  if (col_blocks > kSweepMaxBlocks) {
+    set_error("lsfa_nms_sorted: n=%d exceeds the supported %d boxes", n, kSweepMaxBlocks * 64);
+    return LSFA_ENOTSUP;
+  }
+  if (ws_bytes < lsfa_nms_workspace_bytes(n)) {
+    set_error("lsfa_nms_sorted: workspace %zu < %zu bytes", ws_bytes, lsfa_nms_workspace_bytes(n));
+    return LSFA_EWORKSPACE;
+  }
+  uint64_t* mask = (uint64_t*)ws;
+  ProfScope prof(LSFA_OP_NMS, s);
+  hipLaunchKernelGGL(nms_mask_kernel, dim3(col_blocks, col_blocks, 1), dim3(64), 0, s, boxes, n, box_dim, thresh,
+                     mask, col_blocks);
+  ProposalOut po{};
+  hipLaunchKernelGGL(nms_sweep_kernel<false>, dim3(1), dim3(64), 0, s, (const uint64_t*)mask, n, col_blocks, n,
+                     keep, num_keep, po);
+  LSFA_LAUNCH_CHECK("lsfa_nms_sorted");
+  return LSFA_OK;
+}
+
+// lib/nms/nms_kernel.cu:97-150: host pointers in and out, synchronous, device selected by id.
+// The reference prints CUDA errors and carries on (CUDA_CHECK :18-25); here an error leaves
+// *num_out = 0 and the message in lsfa_last_error().
+extern "C" void _nms(int* keep_out, int* num_out, const float* boxes_host, int boxes_num, int boxes_dim,
+                     float nms_overlap_thresh, int device_id) {
+  *num_out = 0;
+  if (boxes_num <= 0) return;
+  int cur = -1;
+  if (hipGetDevice(&cur) != hipSuccess) { set_error("_nms: hipGetDevice failed"); return; }
+  if (cur != device_id && hipSetDevice(device_id) != hipSuccess) { set_error("_nms: hipSetDevice(%d) failed", device_id); return; }
+  float* boxes_dev = nullptr;
+  void* ws = nullptr;
+  int* keep_dev = nullptr;
+  const size_t ws_bytes = lsfa_nms_workspace_bytes(boxes_num);
+  const size_t bbytes = (size_t)boxes_num * boxes_dim * sizeof(float);
+  hipError_t e = hipMalloc(&boxes_dev, bbytes);
+  if (e == hipSuccess) e = hipMalloc(&ws, ws_bytes);
+  if (e == hipSuccess) e = hipMalloc(&keep_dev, sizeof(int) * ((size_t)boxes_num + 1));
+  if (e == hipSuccess) e = hipMemcpy(boxes_dev, boxes_host, bbytes, hipMemcpyHostToDevice);
+  if (e == hipSuccess) {
+    int rc = lsfa_nms_sorted(boxes_dev, boxes_num, boxes_dim, nms_overlap_thresh, keep_dev, keep_dev + boxes_num, ws,
+                             ws_bytes, nullptr);
+    if (rc == LSFA_OK) {
+      std::vector<int> host((size_t)boxes_num + 1);
+      e = hipMemcpy(host.data(), keep_dev, sizeof(int) * host.size(), hipMemcpyDeviceToHost);
+      if (e == hipSuccess) {
+        const int k = host[boxes_num];
+        for (int i = 0; i < k; ++i) keep_out[i] = host[i];
+        *num_out = k;
+      }
+    }
+  }
+  if (e != hipSuccess) hip_fail(e, "_nms");
+  if (boxes_dev) (void)hipFree(boxes_dev);
+  if (ws) (void)hipFree(ws);
+  if (keep_dev) (void)hipFree(keep_dev);
+}

@@ -1,0 +1,88 @@
+// Error reporting + live per-op timing for liblsfa_hip.so.
+#include <stdarg.h>
+#include <stdio.h>
+
+#include <mutex>
+#include <vector>
+
+#include "common.h"
+
+namespace lsfa {
+
+static thread_local char g_err[512] = "";
+
+void set_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+
+int hip_fail(hipError_t e, const char* what) {
+  set_error("%s: %s", what, hipGetErrorString(e));
+  return (int)e;
+}
+
+// ---- profiling ------------------------------------------------------------------
+struct EventPair { hipEvent_t a, b; int op; };
+static std::mutex g_mu;
+static bool g_prof = false;
+static std::vector<EventPair> g_live;
+static std::vector<EventPair> g_free;
+
+ProfScope::ProfScope(int op, hipStream_t stream) : stream_(stream), slot_(-1) {
+  if (!g_prof) return;
+  std::lock_guard<std::mutex> lk(g_mu);
+  EventPair p;
+  if (!g_free.empty()) { p = g_free.back(); g_free.pop_back(); }
+  else {
+    if (hipEventCreate(&p.a) != hipSuccess || hipEventCreate(&p.b) != hipSuccess) return;
+  }
+  p.op = op;
+  (void)hipEventRecord(p.a, stream_);
+  g_live.push_back(p);
+  slot_ = (int)g_live.size() - 1;
+}
+
+ProfScope::~ProfScope() {
+  if (slot_ < 0) return;
+  std::lock_guard<std::mutex> lk(g_mu);
+  if (slot_ < (int)g_live.size()) (void)hipEventRecord(g_live[slot_].b, stream_);
+}
+
+}  // namespace lsfa
+
+using namespace lsfa;
+
+extern "C" const char* lsfa_last_error(void) { return g_err; }
+extern "C" int lsfa_abi_version(void) { return 1; }
+
+extern "C" int lsfa_prof_enable(int on) {
+  std::lock_guard<std::mutex> lk(g_mu);
+  g_prof = on != 0;
+  return LSFA_OK;
+}
+
+extern "C" int lsfa_prof_read(double* ms_host, int* launches_host) {
+  std::lock_guard<std::mutex> lk(g_mu);
+  for (int i = 0; i < LSFA_OP_COUNT; ++i) { ms_host[i] = 0.0; launches_host[i] = 0; }
+  for (auto& p : g_live) {
+    hipError_t e = hipEventSynchronize(p.b);
+    if (e != hipSuccess) return hip_fail(e, "lsfa_prof_read: hipEventSynchronize");
+    float ms = 0.f;
+    e = hipEventElapsedTime(&ms, p.a, p.b);
+    if (e != hipSuccess) return hip_fail(e, "lsfa_prof_read: hipEventElapsedTime");
+    ms_host[p.op] += ms;
+    launches_host[p.op] += 1;
+    g_free.push_back(p);
+  }
+  g_live.clear();
+  return LSFA_OK;
+}
+
+extern "C" const char* lsfa_op_name(int op) {
+  static const char* names[LSFA_OP_COUNT] = {"psroi_pool", "rfcn_head", "warp_bilinear", "aggregate",
+                                             "proposal", "nms", "det_postprocess", "deform_im2col",
+                                             "scale_shift_relu"};
+  return (op >= 0 && op < LSFA_OP_COUNT) ? names[op] : "?";
+}

@@ -1,0 +1,266 @@
+"""ctypes binding of liblsfa_hip.so (the C ABI in include/lsfa_hip.h) on torch tensors.
+
+PyTorch is plumbing here: it owns device memory and streams; every op below hands
+raw device pointers and torch's CURRENT stream to the C ABI.  There is no CPU or
+eager fallback — if the library is missing or a call fails, LsfaError is raised
+(the counterpart of MXNetError in the reference).
+"""
+import ctypes
+import os
+
+import torch  # must be imported before the .so so that both share one libamdhip64
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "liblsfa_hip.so")
+
+OP_NAMES = ["psroi_pool", "rfcn_head", "warp_bilinear", "aggregate", "proposal", "nms", "det_postprocess",
+            "deform_im2col", "scale_shift_relu"]
+
+
+class LsfaError(RuntimeError):
+    pass
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise LsfaError("liblsfa_hip.so is not built (%s); run `python -m lsfa_amd.build` — "
+                            "there is no fallback path" % LIB_PATH)
+        L = ctypes.CDLL(LIB_PATH)
+        L.lsfa_last_error.restype = ctypes.c_char_p
+        for name in ("lsfa_proposal_workspace_bytes", "lsfa_nms_workspace_bytes", "lsfa_det_workspace_bytes"):
+            getattr(L, name).restype = ctypes.c_size_t
+        L.lsfa_op_name.restype = ctypes.c_char_p
+        L._nms.restype = None
+        _lib = L
+    return _lib
+
+
+def _check(rc, what):
+    if rc != 0:
+        raise LsfaError("%s failed (code %d): %s" % (what, rc, lib().lsfa_last_error().decode()))
+
+
+_vp = ctypes.c_void_p
+_ci = ctypes.c_int
+_cf = ctypes.c_float
+_cd = ctypes.c_double
+
+
+def _ptr(t):
+    return _vp(t.data_ptr()) if t is not None else None
+
+
+def _stream():
+    return _vp(torch.cuda.current_stream().cuda_stream)
+
+
+def _f32c(t, name):
+    if t is None:
+        return None
+    if t.dtype != torch.float32 or not t.is_cuda:
+        raise LsfaError("%s must be a float32 CUDA tensor (got %s on %s)" % (name, t.dtype, t.device))
+    return t if t.is_contiguous() else t.contiguous()
+
+
+# ------------------------------------------------------------------------------------
+def psroi_pool(data, rois, spatial_scale, output_dim, pooled_size, group_size, with_mapping=False):
+    data, rois = _f32c(data, "data"), _f32c(rois, "rois")
+    N, C, H, W = data.shape
+    R = rois.shape[0]
+    out = torch.empty((R, output_dim, pooled_size, pooled_size), device=data.device, dtype=torch.float32)
+    mc = torch.empty_like(out) if with_mapping else None
+    _check(lib().lsfa_psroi_pool_fwd(_ptr(data), _ptr(rois), _ci(N), _ci(C), _ci(H), _ci(W), _ci(R),
+                                     _cf(spatial_scale), _ci(output_dim), _ci(pooled_size), _ci(group_size),
+                                     _ptr(out), _ptr(mc), _stream()), "lsfa_psroi_pool_fwd")
+    return (out, mc) if with_mapping else out
+
+
+def rfcn_head(cls_map, box_map, rois, spatial_scale=0.0625, pooled_size=7, group_size=7, want_score=False,
+              out=None):
+    cls_map, box_map, rois = _f32c(cls_map, "cls_map"), _f32c(box_map, "box_map"), _f32c(rois, "rois")
+    N, Cc, H, W = cls_map.shape
+    gg = group_size * group_size
+    ncls, nbox = Cc // gg, box_map.shape[1] // gg
+    R = rois.shape[0]
+    if out is None:
+        cls_prob = torch.empty((R, ncls), device=rois.device, dtype=torch.float32)
+        bbox_pred = torch.empty((R, nbox), device=rois.device, dtype=torch.float32)
+    else:
+        cls_prob, bbox_pred = out
+    cls_score = torch.empty((R, ncls), device=rois.device, dtype=torch.float32) if want_score else None
+    _check(lib().lsfa_rfcn_head_fwd(_ptr(cls_map), _ptr(box_map), _ptr(rois), _ci(N), _ci(H), _ci(W), _ci(R),
+                                    _ci(ncls), _ci(nbox), _cf(spatial_scale), _ci(pooled_size), _ci(group_size),
+                                    _ptr(cls_prob), _ptr(cls_score), _ptr(bbox_pred), _stream()), "lsfa_rfcn_head_fwd")
+    return (cls_prob, cls_score, bbox_pred) if want_score else (cls_prob, bbox_pred)
+
+
+def warp_bilinear(feat, flow, mul=None, add=None, res=None, res_w=None, res_b=None, out=None):
+    feat, flow = _f32c(feat, "feat"), _f32c(flow, "flow")
+    mul, add, res = _f32c(mul, "mul"), _f32c(add, "add"), _f32c(res, "res")
+    N, _, H, W = flow.shape
+    feat_n, C = feat.shape[0], feat.shape[1]
+    res_c = 0
+    if res is not None:
+        res_w, res_b = _f32c(res_w, "res_w").reshape(C, -1), _f32c(res_b, "res_b")
+        res_c = res.shape[1]
+    if out is None:
+        out = torch.empty((N, C, H, W), device=feat.device, dtype=torch.float32)
+    _check(lib().lsfa_warp_bilinear(_ptr(feat), _ci(feat_n), _ptr(flow), _ci(N), _ci(C), _ci(H), _ci(W), _ptr(mul),
+                                    _ptr(add), _ptr(res), _ci(res_c), _ptr(res_w), _ptr(res_b), _ptr(out), _stream()),
+           "lsfa_warp_bilinear")
+    return out
+
+
+def aggregate_softmax2(a, b, logits, out=None):
+    a, b, logits = _f32c(a, "a"), _f32c(b, "b"), _f32c(logits, "logits")
+    _, C, H, W = a.shape
+    if out is None:
+        out = torch.empty_like(a)
+    _check(lib().lsfa_aggregate_softmax2(_ptr(a), _ptr(b), _ptr(logits), _ci(C), _ci(H), _ci(W), _ptr(out), _stream()),
+           "lsfa_aggregate_softmax2")
+    return out
+
+
+def aggregate_cosine(a, b, emb_warp, emb_cur, out=None):
+    a, b = _f32c(a, "a"), _f32c(b, "b")
+    emb_warp, emb_cur = _f32c(emb_warp, "emb_warp"), _f32c(emb_cur, "emb_cur")
+    _, C, H, W = a.shape
+    if out is None:
+        out = torch.empty_like(a)
+    _check(lib().lsfa_aggregate_cosine(_ptr(a), _ptr(b), _ptr(emb_warp), _ptr(emb_cur), _ci(C), _ci(emb_warp.shape[1]),
+                                       _ci(H), _ci(W), _ptr(out), _stream()), "lsfa_aggregate_cosine")
+    return out
+
+
+class ProposalOp(object):
+    """MultiProposal / Proposal with a persistent workspace (multi_proposal-inl.h:124-159 params)."""
+
+    def __init__(self, feature_stride=16, scales=(8, 16, 32), ratios=(0.5, 1, 2), rpn_pre_nms_top_n=6000,
+                 rpn_post_nms_top_n=300, threshold=0.7, rpn_min_size=16, output_score=False):
+        self.feature_stride = int(feature_stride)
+        self.scales = (ctypes.c_float * len(scales))(*[float(s) for s in scales])
+        self.ratios = (ctypes.c_float * len(ratios))(*[float(r) for r in ratios])
+        self.pre_n, self.post_n = int(rpn_pre_nms_top_n), int(rpn_post_nms_top_n)
+        self.threshold, self.min_size = float(threshold), int(rpn_min_size)
+        self.output_score = output_score
+        self._ws = None
+
+    def __call__(self, cls_prob, bbox_pred, im_info, out=None):
+        cls_prob, bbox_pred, im_info = _f32c(cls_prob, "cls_prob"), _f32c(bbox_pred, "bbox_pred"), _f32c(im_info, "im_info")
+        B, A2, H, W = cls_prob.shape
+        A = A2 // 2
+        if bbox_pred.shape != (B, 4 * A, H, W) or im_info.shape != (B, 3):
+            raise LsfaError("Proposal: expected bbox_pred %s and im_info %s, got %s and %s (multi_proposal-inl.h:179-187)"
+                            % ((B, 4 * A, H, W), (B, 3), tuple(bbox_pred.shape), tuple(im_info.shape)))
+        need = lib().lsfa_proposal_workspace_bytes(_ci(B), _ci(A), _ci(H), _ci(W), _ci(self.pre_n))
+        if self._ws is None or self._ws.numel() < need or self._ws.device != cls_prob.device:
+            self._ws = torch.empty(need, dtype=torch.uint8, device=cls_prob.device)
+        count = A * H * W
+        pre_n = min(self.pre_n if self.pre_n > 0 else count, count)
+        post_n = min(self.post_n, pre_n)
+        if out is None:
+            rois = torch.empty((B * post_n, 5), device=cls_prob.device, dtype=torch.float32)
+            scores = torch.empty((B * post_n, 1), device=cls_prob.device, dtype=torch.float32)
+        else:
+            rois, scores = out
+        _check(lib().lsfa_proposal(_ptr(cls_prob), _ptr(bbox_pred), _ptr(im_info), _ci(B), _ci(A), _ci(H), _ci(W),
+                                   _ci(self.feature_stride), self.scales, _ci(len(self.scales)), self.ratios,
+                                   _ci(len(self.ratios)), _ci(self.pre_n), _ci(self.post_n), _cf(self.threshold),
+                                   _ci(self.min_size), _ptr(rois), _ptr(scores), _ptr(self._ws),
+                                   ctypes.c_size_t(self._ws.numel()), _stream()), "lsfa_proposal")
+        return (rois, scores) if self.output_score else rois
+
+
+def nms_sorted(boxes, thresh):
+    """boxes (n, >=4) float32 CUDA, sorted by score descending -> (keep int32 (n,), num_keep int32 (1,)) on device."""
+    boxes = _f32c(boxes, "boxes")
+    n, d = boxes.shape
+    keep = torch.empty(max(n, 1), dtype=torch.int32, device=boxes.device)
+    num = torch.zeros(1, dtype=torch.int32, device=boxes.device)
+    need = lib().lsfa_nms_workspace_bytes(_ci(n))
+    ws = torch.empty(need, dtype=torch.uint8, device=boxes.device)
+    _check(lib().lsfa_nms_sorted(_ptr(boxes), _ci(n), _ci(d), _cf(thresh), _ptr(keep), _ptr(num), _ptr(ws),
+                                 ctypes.c_size_t(need), _stream()), "lsfa_nms_sorted")
+    return keep, num
+
+
+def nms_host(boxes_np, thresh, device_id=0):
+    """The reference's `_nms` C entry point (lib/nms/gpu_nms.hpp:14-15): host numpy in, host list out."""
+    import numpy as np
+    boxes_np = np.ascontiguousarray(boxes_np, dtype=np.float32)
+    n, d = boxes_np.shape
+    keep = np.zeros(max(n, 1), dtype=np.int32)
+    num = ctypes.c_int(0)
+    lib()._nms(keep.ctypes.data_as(_vp), ctypes.byref(num), boxes_np.ctypes.data_as(_vp), _ci(n), _ci(d),
+               _cf(thresh), _ci(device_id))
+    return keep[:num.value]
+
+
+def bbox_pred_clip(rois, deltas, im_h, im_w, scale):
+    rois, deltas = _f32c(rois, "rois"), _f32c(deltas, "deltas")
+    R = rois.shape[0]
+    nreg = deltas.shape[1] // 4
+    out = torch.empty((R, 4 * nreg), dtype=torch.float64, device=rois.device)
+    _check(lib().lsfa_bbox_pred_clip(_ptr(rois), _ptr(deltas), _ci(R), _ci(nreg), _cd(im_h), _cd(im_w), _cd(scale),
+                                     _ptr(out), _stream()), "lsfa_bbox_pred_clip")
+    return out
+
+
+def det_postprocess(rois, deltas, probs, im_h, im_w, scale, score_thresh=1e-4, nms_thresh=0.3, max_per_image=300,
+                    class_agnostic=True, out=None):
+    rois, deltas, probs = _f32c(rois, "rois"), _f32c(deltas, "deltas"), _f32c(probs, "probs")
+    R, ncls = probs.shape
+    nreg = deltas.shape[1] // 4
+    if out is None:
+        dets = torch.zeros((ncls, R, 5), dtype=torch.float64, device=rois.device)
+        counts = torch.zeros(ncls, dtype=torch.int32, device=rois.device)
+        keep_idx = torch.full((ncls, R), -1, dtype=torch.int32, device=rois.device)
+    else:
+        dets, counts, keep_idx = out
+    _check(lib().lsfa_det_postprocess(_ptr(rois), _ptr(deltas), _ptr(probs), _ci(R), _ci(ncls), _ci(nreg),
+                                      _ci(int(class_agnostic)), _cd(im_h), _cd(im_w), _cd(scale), _cd(score_thresh),
+                                      _cd(nms_thresh), _ci(max_per_image), _ptr(dets), _ptr(counts), _ptr(keep_idx),
+                                      None, ctypes.c_size_t(0), _stream()), "lsfa_det_postprocess")
+    return dets, counts, keep_idx
+
+
+def deform_im2col(data, offset, kh, kw, pad, stride, dilate, deform_groups, out=None):
+    data, offset = _f32c(data, "data"), _f32c(offset, "offset")
+    N, C, H, W = data.shape
+    Ho, Wo = offset.shape[2], offset.shape[3]
+    if out is None:
+        out = torch.empty((N, C * kh * kw, Ho * Wo), dtype=torch.float32, device=data.device)
+    _check(lib().lsfa_deform_im2col(_ptr(data), _ptr(offset), _ci(N), _ci(C), _ci(H), _ci(W), _ci(kh), _ci(kw),
+                                    _ci(pad), _ci(stride), _ci(dilate), _ci(deform_groups), _ci(Ho), _ci(Wo),
+                                    _ptr(out), _stream()), "lsfa_deform_im2col")
+    return out
+
+
+def scale_shift_relu(x, scale, shift, relu=True, out=None):
+    x = _f32c(x, "x")
+    N, C = x.shape[0], x.shape[1]
+    HW = x.numel() // (N * C)
+    if out is None:
+        out = torch.empty_like(x)
+    _check(lib().lsfa_scale_shift_relu(_ptr(x), _ptr(scale), _ptr(shift), _ci(N), _ci(C), _ci(HW), _ci(int(relu)),
+                                       _ptr(out), _stream()), "lsfa_scale_shift_relu")
+    return out
+
+
+# ---- live timing -----------------------------------------------------------------------
+def prof_enable(on=True):
+    _check(lib().lsfa_prof_enable(_ci(int(on))), "lsfa_prof_enable")
+
+
+def prof_read():
+    """{op_name: (total_ms, launches)} since the last read; synchronises the recorded events."""
+    n = len(OP_NAMES)
+    ms = (ctypes.c_double * n)()
+    cnt = (ctypes.c_int * n)()
+    _check(lib().lsfa_prof_read(ms, cnt), "lsfa_prof_read")
+    return {OP_NAMES[i]: (ms[i], cnt[i]) for i in range(n)}

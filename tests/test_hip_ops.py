@@ -1,0 +1,377 @@
+"""Parity of every hand-written HIP kernel with the CPU oracle, through the C ABI.
+
+All custom ops share the oracle's floating-point contract (-ffp-contract=off, fmaf
+only where written, correctly rounded exp), so the assertion is BIT-EXACT equality
+for floats and indices alike, unless a test says otherwise.
+"""
+import numpy as np
+import pytest
+import torch
+
+import oracle
+
+pytestmark = pytest.mark.gpu
+
+DEV = "cuda:0"
+
+
+def t(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(DEV)
+
+
+def rand_rois(rs, R, im_w=1000, im_h=600, small=0.1):
+    cx, cy = rs.uniform(0, im_w, R), rs.uniform(0, im_h, R)
+    w, h = rs.uniform(8, 400, R), rs.uniform(8, 400, R)
+    tiny = rs.rand(R) < small
+    w[tiny], h[tiny] = rs.uniform(0, 3, tiny.sum()), rs.uniform(0, 3, tiny.sum())
+    x1, y1 = np.clip(cx - w / 2, 0, im_w - 1), np.clip(cy - h / 2, 0, im_h - 1)
+    x2, y2 = np.clip(cx + w / 2, 0, im_w - 1), np.clip(cy + h / 2, 0, im_h - 1)
+    rois = np.stack([np.zeros(R), x1, y1, x2, y2], 1).astype(np.float32)
+    # some ROIs whose edges land exactly on integers / half-integers (round() and bin-edge cases)
+    rois[::7, 1:] = np.round(rois[::7, 1:])
+    rois[3::11, 1:] = np.floor(rois[3::11, 1:]) + 0.5
+    rois[5::13, 1:] = (np.round(rois[5::13, 1:] / 16) * 16)
+    return rois
+
+
+# ------------------------------------------------------------------ PSROI ------------
+@pytest.mark.parametrize("shape", [(38, 63, 300, 31), (38, 63, 300, 8), (36, 63, 77, 31), (5, 9, 16, 2)])
+def test_psroi_pool_bit_exact(hip, shape):
+    H, W, R, D = shape
+    rs = np.random.RandomState(H * 1000 + R)
+    data = rs.randn(1, D * 49, H, W).astype(np.float32)
+    rois = rand_rois(rs, R, im_w=W * 16, im_h=H * 16)
+    want, want_mc = oracle.psroi_pool(data, rois, 0.0625, D, 7, 7, with_mapping=True)
+    got, got_mc = hip.psroi_pool(t(data), t(rois), 0.0625, D, 7, 7, with_mapping=True)
+    np.testing.assert_array_equal(got.cpu().numpy(), want)
+    np.testing.assert_array_equal(got_mc.cpu().numpy(), want_mc)
+
+
+def test_psroi_pool_batch_index_and_groups(hip):
+    rs = np.random.RandomState(3)
+    data = rs.randn(2, 3 * 9, 10, 12).astype(np.float32)
+    rois = rand_rois(rs, 40, im_w=12 * 8, im_h=10 * 8)
+    rois[:, 0] = rs.randint(0, 2, 40)
+    want = oracle.psroi_pool(data, rois, 0.125, 3, 3, 3)
+    got = hip.psroi_pool(t(data), t(rois), 0.125, 3, 3, 3)
+    np.testing.assert_array_equal(got.cpu().numpy(), want)
+
+
+def test_psroi_errors(hip):
+    data = torch.zeros(1, 10, 4, 4, device=DEV)
+    rois = torch.zeros(2, 5, device=DEV)
+    with pytest.raises(hip.LsfaError):  # channels != output_dim * group^2 (psroi_pooling-inl.h InferShape)
+        hip.psroi_pool(data, rois, 0.0625, 3, 7, 7)
+    out = hip.psroi_pool(torch.zeros(1, 49, 4, 4, device=DEV), torch.zeros(0, 5, device=DEV), 0.0625, 1, 7, 7)
+    assert out.shape == (0, 1, 7, 7)
+
+
+@pytest.mark.parametrize("R", [300, 1])
+def test_rfcn_head_fused_bit_exact(hip, R):
+    rs = np.random.RandomState(11 + R)
+    cls_map = rs.randn(1, 31 * 49, 38, 63).astype(np.float32)
+    box_map = (0.1 * rs.randn(1, 8 * 49, 38, 63)).astype(np.float32)
+    rois = rand_rois(rs, R)
+    want_prob, want_score, want_box = oracle.rfcn_head(cls_map, box_map, rois)
+    prob, score, box = hip.rfcn_head(t(cls_map), t(box_map), t(rois), want_score=True)
+    np.testing.assert_array_equal(score.cpu().numpy(), want_score)
+    np.testing.assert_array_equal(box.cpu().numpy(), want_box)
+    np.testing.assert_array_equal(prob.cpu().numpy(), want_prob)
+    # and the fused path equals the unfused operator + average
+    unf = hip.psroi_pool(t(cls_map), t(rois), 0.0625, 31, 7, 7).cpu().numpy()
+    np.testing.assert_array_equal(oracle.global_avg(unf), want_score)
+
+
+# ------------------------------------------------------------------ warp --------------
+def smooth_flow(rs, N, H, W, mag):
+    f = rs.uniform(-mag, mag, (N, 2, 1, 1)) + 0.3 * rs.randn(N, 2, H, W)
+    return f.astype(np.float32)
+
+
+@pytest.mark.parametrize("shape", [(1, 1024, 38, 63), (1, 64, 36, 63), (2, 32, 16, 16), (1, 16, 7, 5)])
+def test_warp_plain_bit_exact_and_grid_sample(hip, shape):
+    N, C, H, W = shape
+    rs = np.random.RandomState(C + H)
+    feat = rs.randn(N, C, H, W).astype(np.float32)
+    flow = smooth_flow(rs, N, H, W, 2.5)
+    want = oracle.warp_bilinear(feat, flow)
+    got = hip.warp_bilinear(t(feat), t(flow)).cpu().numpy()
+    np.testing.assert_array_equal(got, want)
+    # independent cross-check of the un-pinned MXNet semantics: grid_sample(align_corners=True, zeros)
+    ys, xs = np.meshgrid(np.arange(H, dtype=np.float32), np.arange(W, dtype=np.float32), indexing="ij")
+    gx = (xs[None] + flow[:, 0]) / ((W - 1) / 2.0) - 1
+    gy = (ys[None] + flow[:, 1]) / ((H - 1) / 2.0) - 1
+    grid = torch.from_numpy(np.stack([gx, gy], -1).astype(np.float32))
+    ref = torch.nn.functional.grid_sample(torch.from_numpy(feat), grid, mode="bilinear", padding_mode="zeros",
+                                          align_corners=True).numpy()
+    np.testing.assert_allclose(got, ref, rtol=1e-4, atol=2e-4)
+
+
+def test_warp_large_flow_leaves_map(hip):
+    rs = np.random.RandomState(5)
+    feat = rs.randn(1, 8, 38, 63).astype(np.float32)
+    flow = rs.uniform(-80, 80, (1, 2, 38, 63)).astype(np.float32)
+    flow[0, :, 0, :5] = 1e9
+    flow[0, :, 1, :5] = -1e9
+    want = oracle.warp_bilinear(feat, flow)
+    got = hip.warp_bilinear(t(feat), t(flow)).cpu().numpy()
+    np.testing.assert_array_equal(got, want)
+    assert (got[0, :, 0, :5] == 0).all()
+
+
+def test_warp_key_path_scale_map(hip):
+    rs = np.random.RandomState(6)
+    feat = rs.randn(1, 1024, 38, 63).astype(np.float32)
+    flow = smooth_flow(rs, 1, 38, 63, 1.5)
+    mul = (1 + 0.1 * rs.randn(1, 1024, 38, 63)).astype(np.float32)
+    want = oracle.warp_bilinear(feat, flow, mul=mul)
+    got = hip.warp_bilinear(t(feat), t(flow), mul=t(mul)).cpu().numpy()
+    np.testing.assert_array_equal(got, want)
+
+
+@pytest.mark.parametrize("hw", [(38, 63), (36, 63), (9, 7)])
+def test_warp_cur_path_fused_epilogue(hip, hw):
+    H, W = hw
+    C = 1024 if H > 20 else 24
+    rs = np.random.RandomState(7 + H)
+    feat = rs.randn(1, C, H, W).astype(np.float32)
+    flow = smooth_flow(rs, 1, H, W, 2.5)
+    res = (4 * rs.randn(1, 3, H, W)).astype(np.float32)
+    res_w = (0.01 * rs.randn(C, 3, 1, 1)).astype(np.float32)
+    res_b = (0.01 * rs.randn(C)).astype(np.float32)
+    add = rs.randn(1, C, H, W).astype(np.float32)
+    want = oracle.warp_bilinear(feat, flow, add=add, res=res, res_w=res_w, res_b=res_b)
+    got = hip.warp_bilinear(t(feat), t(flow), add=t(add), res=t(res), res_w=t(res_w), res_b=t(res_b)).cpu().numpy()
+    np.testing.assert_array_equal(got, want)
+
+
+def test_warp_broadcast_key_feature_batch(hip):
+    rs = np.random.RandomState(8)
+    feat = rs.randn(1, 32, 12, 20).astype(np.float32)
+    flow = smooth_flow(rs, 3, 12, 20, 2.0)
+    mul = rs.rand(3, 32, 12, 20).astype(np.float32)
+    want = oracle.warp_bilinear(feat, flow, mul=mul)
+    got = hip.warp_bilinear(t(feat), t(flow), mul=t(mul)).cpu().numpy()
+    np.testing.assert_array_equal(got, want)
+
+
+def test_warp_identity_property(hip):
+    feat = torch.randn(1, 1024, 38, 63, device=DEV)
+    out = hip.warp_bilinear(feat, torch.zeros(1, 2, 38, 63, device=DEV))
+    # zero flow samples integer positions (up to the normalise/denormalise round trip)
+    assert torch.allclose(out, feat, rtol=0, atol=2e-5 * feat.abs().max().item())
+
+
+# ------------------------------------------------------------------ aggregate ---------
+@pytest.mark.parametrize("shape", [(1024, 38, 63), (1024, 36, 63), (20, 8, 8), (3, 5, 7)])
+def test_aggregate_softmax2_bit_exact(hip, shape):
+    C, H, W = shape
+    rs = np.random.RandomState(C + W)
+    a, b = rs.randn(1, C, H, W).astype(np.float32), rs.randn(1, C, H, W).astype(np.float32)
+    logits = (3 * rs.randn(2, 1, H, W)).astype(np.float32)
+    logits[0, 0, 0, 0], logits[1, 0, 0, 0] = 100.0, -100.0
+    want = oracle.aggregate_softmax2(a, b, logits)
+    got = hip.aggregate_softmax2(t(a), t(b), t(logits)).cpu().numpy()
+    np.testing.assert_array_equal(got, want)
+    ref = torch.softmax(torch.from_numpy(logits), 0)
+    np.testing.assert_allclose(got, (ref[0] * torch.from_numpy(a) + ref[1] * torch.from_numpy(b)).numpy(), rtol=1e-5, atol=1e-6)
+
+
+def test_aggregate_cosine_bit_exact(hip):
+    rs = np.random.RandomState(9)
+    C, E, H, W = 64, 128, 12, 14
+    a, b = rs.randn(1, C, H, W).astype(np.float32), rs.randn(1, C, H, W).astype(np.float32)
+    ew, ec = rs.randn(1, E, H, W).astype(np.float32), rs.randn(1, E, H, W).astype(np.float32)
+    want = oracle.aggregate_cosine(a, b, ew, ec)
+    got = hip.aggregate_cosine(t(a), t(b), t(ew), t(ec)).cpu().numpy()
+    np.testing.assert_array_equal(got, want)
+
+
+# ------------------------------------------------------------------ NMS ---------------
+def clustered_dets(rs, n, dtype=np.float32):
+    k = max(3, n // 25)
+    cx = rs.uniform(50, 950, k)[rs.randint(0, k, n)] + rs.normal(0, 12, n)
+    cy = rs.uniform(50, 550, k)[rs.randint(0, k, n)] + rs.normal(0, 12, n)
+    w, h = rs.uniform(20, 220, n), rs.uniform(20, 220, n)
+    x1, y1 = np.clip(cx - w / 2, 0, 999), np.clip(cy - h / 2, 0, 599)
+    x2, y2 = np.clip(cx + w / 2, 0, 999), np.clip(cy + h / 2, 0, 599)
+    s = np.sort(rs.rand(n))[::-1]
+    return np.stack([x1, y1, x2, y2, s], 1).astype(dtype)
+
+
+@pytest.mark.parametrize("n", [1, 63, 64, 65, 300, 1000, 6000])
+@pytest.mark.parametrize("th", [0.3, 0.7])
+def test_nms_sorted_bit_exact(hip, n, th):
+    dets = clustered_dets(np.random.RandomState(n), n)
+    want = oracle.nms_sorted(dets, th)
+    keep, num = hip.nms_sorted(t(dets), th)
+    k = int(num.item())
+    assert k == len(want)
+    np.testing.assert_array_equal(keep[:k].cpu().numpy(), want)
+
+
+def test_nms_golden_reference_survivors(hip, golden):
+    """The HIP NMS reproduces the REFERENCE's numpy nms survivors on the golden boxes."""
+    for n in (50, 300, 2000):
+        for th in (0.3, 0.7):
+            dets = golden["g2_n%d_float32_dets" % n]
+            want = golden["g2_n%d_float32_keep_%02d" % (n, int(th * 10))]
+            order = np.argsort(-dets[:, 4], kind="stable")
+            keep, num = hip.nms_sorted(t(dets[order]), th)
+            got = order[keep[:int(num.item())].cpu().numpy()]
+            np.testing.assert_array_equal(got, want)
+            # and through the reference's own host-pointer C entry point `_nms`
+            np.testing.assert_array_equal(order[hip.nms_host(dets[order], th)], want)
+
+
+def test_nms_all_identical_boxes_and_empty(hip):
+    dets = np.tile(np.array([[10, 10, 50, 50, 0.5]], np.float32), (200, 1))
+    keep, num = hip.nms_sorted(t(dets), 0.5)
+    assert int(num.item()) == 1 and int(keep[0].item()) == 0
+    keep, num = hip.nms_sorted(torch.zeros(0, 5, device=DEV), 0.5)
+    assert int(num.item()) == 0
+
+
+# ------------------------------------------------------------------ Proposal ----------
+def rpn_inputs(rs, B, H, W, A=9, frac_pos=0.02):
+    logit = rs.randn(B, 2, A * H, W).astype(np.float32) * 2
+    logit[:, 1] += np.log(frac_pos / (1 - frac_pos))
+    e = np.exp(logit - logit.max(1, keepdims=True))
+    prob = (e / e.sum(1, keepdims=True)).astype(np.float32).reshape(B, 2 * A, H, W)
+    deltas = (rs.randn(B, 4 * A, H, W) * np.tile([0.1, 0.1, 0.4, 0.4], A)[None, :, None, None]).astype(np.float32)
+    return prob, deltas
+
+
+@pytest.mark.parametrize("cfg", [
+    dict(H=38, W=63, im=(600, 1000, 1.0), pre=6000, post=300, min_size=0),
+    dict(H=36, W=63, im=(562, 1000, 0.78125), pre=6000, post=300, min_size=0),
+    dict(H=38, W=63, im=(600, 1000, 1.6), pre=6000, post=300, min_size=16),
+    dict(H=10, W=12, im=(160, 192, 1.0), pre=6000, post=300, min_size=0),   # pre_n clamps to 1080
+    dict(H=38, W=63, im=(600, 1000, 1.0), pre=12000, post=1000, min_size=0),
+])
+def test_proposal_bit_exact(hip, cfg):
+    H, W = cfg["H"], cfg["W"]
+    rs = np.random.RandomState(H * W + cfg["pre"])
+    prob, deltas = rpn_inputs(rs, 1, H, W)
+    im_info = np.array([cfg["im"]], np.float32)
+    want_rois, want_scores = oracle.proposal(prob, deltas, im_info, rpn_pre_nms_top_n=cfg["pre"],
+                                             rpn_post_nms_top_n=cfg["post"], rpn_min_size=cfg["min_size"])
+    op = hip.ProposalOp(rpn_pre_nms_top_n=cfg["pre"], rpn_post_nms_top_n=cfg["post"], threshold=0.7,
+                        rpn_min_size=cfg["min_size"], output_score=True)
+    rois, scores = op(t(prob), t(deltas), t(im_info))
+    np.testing.assert_array_equal(rois.cpu().numpy(), want_rois)
+    np.testing.assert_array_equal(scores.cpu().numpy(), want_scores)
+
+
+def test_proposal_ties_stable_order_and_cyclic_pad(hip):
+    """Heavy score ties (quantised scores + the -1 block outside the real image) exercise the
+    (score desc, anchor index asc) order; few survivors exercise the cyclic pad (multi_proposal.cu:381)."""
+    rs = np.random.RandomState(4)
+    H, W = 38, 63
+    prob, deltas = rpn_inputs(rs, 1, H, W)
+    prob = (np.round(prob * 20) / 20).astype(np.float32)       # 21 distinct score values
+    deltas[:] = 0                                               # identical anchors per cell -> massive overlap
+    im_info = np.array([[300, 500, 1.0]], np.float32)           # most cells outside the real image -> -1
+    want_rois, want_scores, order, keep, nkeep = oracle.proposal(prob, deltas, im_info, return_debug=True)
+    op = hip.ProposalOp(rpn_min_size=0, output_score=True)
+    rois, scores = op(t(prob), t(deltas), t(im_info))
+    np.testing.assert_array_equal(rois.cpu().numpy(), want_rois)
+    np.testing.assert_array_equal(scores.cpu().numpy(), want_scores)
+    assert nkeep[0] < 300                                       # the pad path really ran
+
+
+def test_proposal_multi_image(hip):
+    rs = np.random.RandomState(12)
+    prob, deltas = rpn_inputs(rs, 3, 20, 30)
+    im_info = np.array([[320, 480, 1.0], [300, 470, 0.9], [320, 480, 1.2]], np.float32)
+    want_rois, want_scores = oracle.proposal(prob, deltas, im_info, rpn_pre_nms_top_n=3000, rpn_post_nms_top_n=200)
+    op = hip.ProposalOp(rpn_pre_nms_top_n=3000, rpn_post_nms_top_n=200, rpn_min_size=0, output_score=True)
+    rois, scores = op(t(prob), t(deltas), t(im_info))
+    np.testing.assert_array_equal(rois.cpu().numpy(), want_rois)
+    np.testing.assert_array_equal(scores.cpu().numpy(), want_scores)
+
+
+def test_proposal_errors(hip):
+    op = hip.ProposalOp(scales=(8, 16), ratios=(0.5, 1, 2))
+    with pytest.raises(hip.LsfaError):  # CHECK_EQ(num_anchors, ratios*scales), multi_proposal.cu:446
+        op(torch.zeros(1, 18, 4, 4, device=DEV), torch.zeros(1, 36, 4, 4, device=DEV), torch.ones(1, 3, device=DEV))
+
+
+# ------------------------------------------------------------------ det post ----------
+def test_det_postprocess_golden(hip, golden):
+    """HIP frame post-processing == the reference's bbox_pred/clip_boxes/nms loop (golden G5)."""
+    rois, deltas, probs = golden["g5_rois"], golden["g5_deltas"], golden["g5_probs"]
+    scale = float(golden["g5_scale"])
+    dets, counts, keep_idx = hip.det_postprocess(t(rois), t(deltas), t(probs), 600, 1000, scale)
+    counts = counts.cpu().numpy()
+    np.testing.assert_array_equal(counts, golden["g5_counts"])
+    got = np.vstack([dets[j, :counts[j]].cpu().numpy() for j in range(31)])
+    np.testing.assert_array_equal(got[:, 4], golden["g5_dets"][:, 4])
+    np.testing.assert_allclose(got[:, :4], golden["g5_dets"][:, :4], rtol=2e-6, atol=2e-4)
+    pred = hip.bbox_pred_clip(t(rois), t(deltas), 600, 1000, scale).cpu().numpy()
+    np.testing.assert_allclose(pred, golden["g5_pred_boxes"], rtol=2e-6, atol=2e-4)
+
+
+@pytest.mark.parametrize("seed,cap", [(0, 300), (1, 0), (2, 50), (3, 100000)])
+def test_det_postprocess_vs_oracle(hip, seed, cap):
+    rs = np.random.RandomState(seed)
+    R, ncls = 300, 31
+    rois = rand_rois(rs, R, small=0.0)
+    rois[:, 1:] = clustered_dets(rs, R)[:, :4]
+    deltas = (0.15 * rs.randn(R, 8)).astype(np.float32)
+    logits = (2 * rs.randn(R, ncls)).astype(np.float32)
+    e = np.exp(logits - logits.max(1, keepdims=True))
+    probs = (e / e.sum(1, keepdims=True)).astype(np.float32)
+    w_d, w_c, w_k = oracle.det_postprocess(rois, deltas, probs, 600, 1000, 1.3, max_per_image=cap)
+    dets, counts, keep_idx = hip.det_postprocess(t(rois), t(deltas), t(probs), 600, 1000, 1.3, max_per_image=cap)
+    counts = counts.cpu().numpy()
+    np.testing.assert_array_equal(counts, w_c)
+    for j in range(ncls):
+        np.testing.assert_array_equal(keep_idx[j, :counts[j]].cpu().numpy(), w_k[j, :counts[j]])
+        # fp64 arithmetic in the same order on both sides; exp() of the two libms may differ by an ulp
+        np.testing.assert_allclose(dets[j, :counts[j]].cpu().numpy(), w_d[j, :counts[j]], rtol=1e-12, atol=1e-9)
+
+
+# ------------------------------------------------------------------ DCN / BN ----------
+@pytest.mark.parametrize("cfg", [dict(C=16, H=19, W=23, k=3, pad=2, stride=1, dil=2, dg=4),
+                                 dict(C=8, H=20, W=21, k=3, pad=1, stride=2, dil=1, dg=4),
+                                 dict(C=12, H=9, W=9, k=3, pad=1, stride=1, dil=1, dg=1)])
+def test_deform_im2col_bit_exact(hip, cfg):
+    rs = np.random.RandomState(cfg["C"])
+    C, H, W, k = cfg["C"], cfg["H"], cfg["W"], cfg["k"]
+    Ho = (H + 2 * cfg["pad"] - (cfg["dil"] * (k - 1) + 1)) // cfg["stride"] + 1
+    Wo = (W + 2 * cfg["pad"] - (cfg["dil"] * (k - 1) + 1)) // cfg["stride"] + 1
+    data = rs.randn(2, C, H, W).astype(np.float32)
+    offset = (2.0 * rs.randn(2, 2 * k * k * cfg["dg"], Ho, Wo)).astype(np.float32)
+    want = oracle.deform_im2col(data, offset, k, k, cfg["pad"], cfg["stride"], cfg["dil"], cfg["dg"])
+    got = hip.deform_im2col(t(data), t(offset), k, k, cfg["pad"], cfg["stride"], cfg["dil"], cfg["dg"]).cpu().numpy()
+    np.testing.assert_array_equal(got, want)
+    # zero offsets reduce to an ordinary im2col (F.unfold)
+    z = hip.deform_im2col(t(data), torch.zeros_like(t(offset)), k, k, cfg["pad"], cfg["stride"], cfg["dil"], cfg["dg"])
+    ref = torch.nn.functional.unfold(torch.from_numpy(data), k, dilation=cfg["dil"], padding=cfg["pad"], stride=cfg["stride"])
+    np.testing.assert_array_equal(z.cpu().numpy(), ref.numpy())
+
+
+@pytest.mark.parametrize("shape", [(1, 64, 300, 500), (1, 256, 38, 63), (2, 7, 5, 3)])
+def test_scale_shift_relu_bit_exact(hip, shape):
+    rs = np.random.RandomState(shape[1])
+    x = rs.randn(*shape).astype(np.float32)
+    sc, sh = rs.rand(shape[1]).astype(np.float32) + 0.5, rs.randn(shape[1]).astype(np.float32)
+    for relu in (True, False):
+        want = oracle.scale_shift_relu(x, sc, sh, relu)
+        got = hip.scale_shift_relu(t(x), t(sc), t(sh), relu).cpu().numpy()
+        np.testing.assert_array_equal(got, want)
+
+
+# ------------------------------------------------------------------ profiling hook ----
+def test_prof_hooks_report_launches(hip):
+    hip.prof_enable(True)
+    try:
+        feat = torch.randn(1, 64, 38, 63, device=DEV)
+        for _ in range(3):
+            hip.warp_bilinear(feat, torch.zeros(1, 2, 38, 63, device=DEV))
+        stats = hip.prof_read()
+        assert stats["warp_bilinear"][1] == 3 and stats["warp_bilinear"][0] > 0
+        assert stats["proposal"][1] == 0
+    finally:
+        hip.prof_enable(False)

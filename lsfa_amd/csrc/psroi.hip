@@ -124,7 +124,6 @@ extern "C" int lsfa_psroi_pool_fwd(const float* data, const float* rois, int N, 
                                    float spatial_scale, int output_dim, int pooled_size, int group_size,
                                    float* out, float* mapping_channel, void* stream) {
   using namespace lsfa;
-  LSFA_REQUIRE(data && rois && out, "lsfa_psroi_pool_fwd: NULL argument");
   LSFA_REQUIRE(N > 0 && C > 0 && H > 0 && W > 0 && R >= 0, "lsfa_psroi_pool_fwd: bad shape");
   LSFA_REQUIRE(output_dim > 0 && pooled_size > 0 && group_size > 0, "lsfa_psroi_pool_fwd: bad parameters");
   // psroi_pooling-inl.h:167-169 (InferShape): channels must be output_dim * group^2
@@ -132,6 +131,7 @@ extern "C" int lsfa_psroi_pool_fwd(const float* data, const float* rois, int N, 
                "lsfa_psroi_pool_fwd: channels %d != output_dim %d * group_size^2 %d", C, output_dim,
                group_size * group_size);
   if (R == 0) return LSFA_OK;
+  LSFA_REQUIRE(data && rois && out, "lsfa_psroi_pool_fwd: NULL argument");
   hipStream_t s = (hipStream_t)stream;
   const size_t count = (size_t)R * output_dim * pooled_size * pooled_size;
   size_t nb = (count + kThreads - 1) / kThreads;
@@ -148,10 +148,10 @@ extern "C" int lsfa_rfcn_head_fwd(const float* cls_map, const float* box_map, co
                                   int group_size, float* cls_prob, float* cls_score, float* bbox_pred,
                                   void* stream) {
   using namespace lsfa;
-  LSFA_REQUIRE(cls_map && box_map && rois && cls_prob && bbox_pred, "lsfa_rfcn_head_fwd: NULL argument");
   LSFA_REQUIRE(N > 0 && H > 0 && W > 0 && R >= 0 && ncls > 0 && nbox > 0 && pooled_size > 0 && group_size > 0,
                "lsfa_rfcn_head_fwd: bad shape");
   if (R == 0) return LSFA_OK;
+  LSFA_REQUIRE(cls_map && box_map && rois && cls_prob && bbox_pred, "lsfa_rfcn_head_fwd: NULL argument");
   const size_t lds = sizeof(float) * ((size_t)(ncls + nbox) * pooled_size * pooled_size + (ncls + nbox));
   if (lds > 64 * 1024) {
     set_error("lsfa_rfcn_head_fwd: (ncls+nbox)*pooled^2 = %zu floats does not fit the LDS budget", lds / 4);

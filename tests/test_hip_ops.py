@@ -271,7 +271,7 @@ def test_proposal_ties_stable_order_and_cyclic_pad(hip):
     prob, deltas = rpn_inputs(rs, 1, H, W)
     prob = (np.round(prob * 20) / 20).astype(np.float32)       # 21 distinct score values
     deltas[:] = 0                                               # identical anchors per cell -> massive overlap
-    im_info = np.array([[300, 500, 1.0]], np.float32)           # most cells outside the real image -> -1
+    im_info = np.array([[100, 160, 1.0]], np.float32)           # most cells outside the real image -> -1
     want_rois, want_scores, order, keep, nkeep = oracle.proposal(prob, deltas, im_info, return_debug=True)
     op = hip.ProposalOp(rpn_min_size=0, output_score=True)
     rois, scores = op(t(prob), t(deltas), t(im_info))

@@ -1,0 +1,133 @@
+"""Predictor, im_detect and the per-frame evaluation loop.
+
+Mirror of dff_rfcn/core/tester.py: `Predictor(symbol, data_names, label_names, context,
+max_data_shapes, provide_data, provide_label, arg_params, aux_params)` (:28-41),
+`im_detect(predictor, data_batch, data_names, scales, cfg)` (:130-160) and `pred_eval(...)`
+(:192-299) keep the reference's signatures, return values and output names.
+
+What is different by design: nothing is copied to the host inside the frame loop.  The
+reference does .asnumpy() on rois / cls_prob / bbox_pred every frame, decodes boxes in numpy
+and runs 30 numpy NMS calls (tester.py:138-152, :265-281); here `im_detect_device` leaves the
+network outputs on the device and one HIP launch does decode + clip + per-class NMS + the
+max_per_image cap (lsfa_det_postprocess).  `im_detect` still exists with the reference's
+host-side return types for callers that want them.
+"""
+import time
+
+import numpy as np
+import torch
+
+from lsfa_amd import hip
+
+
+class Predictor(object):
+    def __init__(self, symbol, data_names, label_names, context='cuda:0', max_data_shapes=None, provide_data=None,
+                 provide_label=None, arg_params=None, aux_params=None, dtype=torch.float32):
+        self._symbol = symbol
+        self._data_names = list(data_names)
+        ctx = context[0] if isinstance(context, (list, tuple)) else context
+        self._exec = symbol.bind(arg_params, aux_params, device=ctx, dtype=dtype)
+        self.output_names = symbol.list_outputs()
+
+    def predict(self, data_batch):
+        """-> [ {output_name: tensor} per device ]  (tester.py:38-41)"""
+        outs = []
+        for idata in data_batch.data:
+            out = self._exec.forward(**dict(zip(self._data_names, idata)))
+            outs.append(out)
+        return outs
+
+
+def im_detect_device(predictor, data_batch, data_names, scales, cfg, post=None):
+    """Forward + fused post-processing, everything left on the device.
+    -> (dets (ncls,R,5) f64, counts (ncls,) i32, keep_idx (ncls,R) i32, feat or None, output dict)"""
+    output = predictor.predict(data_batch)[0]
+    data = dict(zip(data_names, data_batch.data[0]))
+    im_shape = data['data'].shape
+    rois = output['rois_output']
+    scores = output['cls_prob_reshape_output'][0]
+    deltas = output['bbox_pred_reshape_output'][0]
+    dets, counts, keep_idx = hip.det_postprocess(rois, deltas, scores, im_shape[-2], im_shape[-1], float(scales[0]),
+                                                 score_thresh=post['thresh'] if post else 1e-4,
+                                                 nms_thresh=cfg.TEST.NMS, max_per_image=cfg.TEST.max_per_image,
+                                                 class_agnostic=cfg.CLASS_AGNOSTIC,
+                                                 out=post.get('out') if post else None)
+    return dets, counts, keep_idx, output.get('choose_feat_output'), output
+
+
+def im_detect(predictor, data_batch, data_names, scales, cfg):
+    """Reference signature and return types (tester.py:130-160): numpy scores, numpy float64
+    boxes (decoded, clipped, /scale), the data dict, and the device-resident feature."""
+    output_all = predictor.predict(data_batch)
+    data_dict_all = [dict(zip(data_names, data_batch.data[i])) for i in range(len(data_batch.data))]
+    scores_all, pred_boxes_all = [], []
+    for output, data_dict, scale in zip(output_all, data_dict_all, scales):
+        rois = output['rois_output']
+        im_shape = data_dict['data'].shape
+        scores = output['cls_prob_reshape_output'][0]
+        bbox_deltas = output['bbox_pred_reshape_output'][0]
+        pred_boxes = hip.bbox_pred_clip(rois, bbox_deltas, im_shape[-2], im_shape[-1], float(scale))
+        scores_all.append(scores.cpu().numpy())
+        pred_boxes_all.append(pred_boxes.cpu().numpy())
+    feat = output_all[0].get('choose_feat_output')
+    return scores_all, pred_boxes_all, data_dict_all, feat
+
+
+def pred_eval(gpu_id, key_predictor, cur_predictor, test_data, imdb, cfg, vis=False, thresh=1e-4, logger=None,
+              ignore_cache=True):
+    """Frame loop of tester.py:192-299.  Returns (all_boxes, frame_ids) with
+    all_boxes[cls][image] = (n, 5) float64 array [x1, y1, x2, y2, score]."""
+    num_classes = imdb.num_classes if imdb is not None else cfg.dataset.NUM_CLASSES
+    data_names = [k[0] for k in test_data.provide_data[0]]
+    num_images = test_data.size
+    roidb_frame_ids = [x['frame_id'] for x in test_data.roidb]
+    all_boxes = [[[] for _ in range(num_images)] for _ in range(num_classes)]
+    frame_ids = np.zeros(num_images, dtype=np.int64)
+    roidb_idx, roidb_offset, idx = -1, -1, 0
+    data_time = net_time = post_time = 0.0
+    pending = []
+    feat = None
+    t = time.time()
+    for im_info, key_frame_flag, data_batch in test_data:
+        t1 = time.time() - t
+        t = time.time()
+        scales = [iim_info[0, 2] for iim_info in im_info]
+        if key_frame_flag != 2:
+            if key_frame_flag == 0:
+                feat_old = torch.zeros((1, cfg.network.DFF_FEAT_DIM, 1, 1), device=data_batch.data[0][0].device)
+            else:
+                feat_old = feat
+            data_batch.data[0][-2] = feat_old
+            data_batch.provide_data[0][-2] = ('feat_key_old', tuple(feat_old.shape))
+            dets, counts, _, feat, _ = im_detect_device(key_predictor, data_batch, data_names, scales, cfg,
+                                                        post={'thresh': thresh})
+        else:
+            data_batch.data[0][-1] = feat
+            data_batch.provide_data[0][-1] = ('feat_key', tuple(feat.shape))
+            dets, counts, _, _, _ = im_detect_device(cur_predictor, data_batch, data_names, scales, cfg,
+                                                     post={'thresh': thresh})
+        if key_frame_flag == 0:
+            roidb_idx += 1
+            roidb_offset = 0
+        else:
+            roidb_offset += 1
+        frame_ids[idx] = roidb_frame_ids[roidb_idx] + roidb_offset
+        pending.append((idx, dets, counts))     # copied to the host after the loop: no per-frame sync
+        t2 = time.time() - t
+        t = time.time()
+        idx += test_data.batch_size
+        data_time += t1
+        net_time += t2
+        if logger and idx % 50 == 0:
+            logger.info('testing {}/{} data {:.4f}s net {:.4f}s'.format(idx, num_images, data_time / idx, net_time / idx))
+    torch.cuda.synchronize()
+    t = time.time()
+    for i, dets, counts in pending:
+        dets, counts = dets.cpu().numpy(), counts.cpu().numpy()
+        for j in range(1, num_classes):
+            all_boxes[j][i] = dets[j, :counts[j]].copy()
+    post_time = time.time() - t
+    if logger:
+        logger.info('done {} frames: data {:.4f}s net {:.4f}s post {:.4f}s per frame'.format(
+            num_images, data_time / max(idx, 1), net_time / max(idx, 1), post_time / max(idx, 1)))
+    return all_boxes, frame_ids

@@ -1,0 +1,417 @@
+"""LSFA test graphs (key-frame and non-key-frame) on MI355X.
+
+API mirror of dff_rfcn/symbols/resnet_v1_101_flownet_rfcn.py: the class
+`resnet_v1_101_flownet_rfcn(cfg)` with `get_key_test_symbol(cfg)` (:448-551),
+`get_cur_test_symbol(cfg)` (:553-659) and `init_weight(cfg, arg_params, aux_params)` (:753-870).
+A "symbol" here is a `TestSymbol`: it knows its argument / auxiliary / output names and
+shapes like an mx.sym.Group, and `bind()`s to an executor that runs the graph.
+
+Execution design (not a translation of the MXNet graph):
+  * dense contractions (ResNet-101, FlowNet, small net, Nq convs, 1x1 heads) go to MIOpen /
+    hipBLASLt through PyTorch-ROCm; inference BatchNorms are folded into the preceding
+    convolution at bind time where the graph allows it (bn2/bn3 of each pre-activation unit,
+    bn0), the remaining ones (bn1 of each unit, bn_data, final bn1) run as one fused
+    scale-shift-ReLU HIP pass; 1x1 convolutions run as GEMMs with the residual add or bias fused
+    into the GEMM epilogue; rpn_inv_normalize (operator_py/rpn_inv_normalize.py:19-26) is
+    folded into rpn_bbox_pred's weights;
+  * warp, x scale_map, + rnet_conv0(res_diff), + small-net feature, the Nq softmax-combine,
+    Proposal, PSROI pooling + 7x7 average + class softmax, and DCN's bilinear im2col are the
+    hand-written HIP kernels behind include/lsfa_hip.h;
+  * ChooseOldKeyFeat / ChooseFeat (operator_py/choose_old_key_feat.py:23-32, choose_feat.py:23-31)
+    are a host-side `if` on the SHAPE of feat_key_old, exactly the reference's first-frame test,
+    without its GPU->CPU sync; on the first frame FlowNet / warp / Nq are skipped because
+    ChooseFeat discards their result.
+"""
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+from lsfa_amd import hip
+from lsfa_amd.symbols import params as P
+
+BN_EPS = 2e-5  # sym_common.py:9
+
+
+class TestSymbol(object):
+    """What get_*_test_symbol returns: names + shapes + bind()."""
+
+    def __init__(self, kind, cfg):
+        assert kind in ('key', 'cur')
+        self.kind = kind
+        self.cfg = cfg
+        self.arg_spec, self.aux_spec = (P.key_symbol_spec if kind == 'key' else P.cur_symbol_spec)(cfg)
+        self.data_names = ['data', 'im_info', 'data_key', 'data_key_old', 'motion_vector', 'res_diff',
+                           'feat_key_old', 'feat_key']
+
+    def list_arguments(self):
+        return list(self.data_names) + list(self.arg_spec.keys())
+
+    def list_auxiliary_states(self):
+        return list(self.aux_spec.keys())
+
+    def list_outputs(self):
+        if self.kind == 'key':   # Group at :549
+            return ['data_key', 'motion_vector', 'res_diff', 'feat_key', 'choose_feat_output', 'rois_output',
+                    'cls_prob_reshape_output', 'bbox_pred_reshape_output']
+        return ['data', 'data_key', 'data_key_old', 'feat_key_old', 'rois_output', 'cls_prob_reshape_output',
+                'bbox_pred_reshape_output']   # Group at :657
+
+    def infer_shape(self, **data_shapes):
+        n, _, h, w = data_shapes['data']
+        fh, fw = int(np.ceil(h / 16.0)), int(np.ceil(w / 16.0))
+        post = self.cfg.TEST.RPN_POST_NMS_TOP_N
+        ncls = self.cfg.dataset.NUM_CLASSES
+        nreg = 2 if self.cfg.CLASS_AGNOSTIC else ncls
+        out = {'rois_output': (post, 5), 'cls_prob_reshape_output': (self.cfg.TEST.BATCH_IMAGES, post, ncls),
+               'bbox_pred_reshape_output': (self.cfg.TEST.BATCH_IMAGES, post, 4 * nreg),
+               'choose_feat_output': (n, self.cfg.network.DFF_FEAT_DIM, fh, fw)}
+        for k in self.list_outputs():
+            if k in data_shapes:
+                out[k] = tuple(data_shapes[k])
+        arg_shapes = [tuple(data_shapes[k]) if k in data_shapes else None for k in self.data_names] + \
+                     list(self.arg_spec.values())
+        return arg_shapes, [out[k] for k in self.list_outputs()], list(self.aux_spec.values())
+
+    def bind(self, arg_params, aux_params, device='cuda:0', dtype=torch.float32):
+        return Executor(self, arg_params, aux_params, device, dtype)
+
+
+class resnet_v1_101_flownet_rfcn(object):
+    def __init__(self, cfg):
+        if cfg.network.nettype != 'resnet' or cfg.network.num_layer != 101:
+            raise RuntimeError("unknow nettype: %s" % cfg.network.nettype)
+        self.cfg = cfg
+        self.sym = None
+        self.arg_shape_dict = self.out_shape_dict = self.aux_shape_dict = None
+
+    @property
+    def symbol(self):
+        return self.sym
+
+    def get_key_test_symbol(self, cfg):
+        self.sym = TestSymbol('key', cfg)
+        return self.sym
+
+    def get_cur_test_symbol(self, cfg):
+        self.sym = TestSymbol('cur', cfg)
+        return self.sym
+
+    def get_batch_test_symbol(self, cfg):
+        raise NotImplementedError("get_batch_test_symbol (:661-751) is a §8(f) 'next' row")
+
+    def get_train_symbol(self, cfg):
+        raise NotImplementedError("training is out of scope (SURVEY.md §8)")
+
+    # lib/utils/symbol.py:36-55
+    def infer_shape(self, data_shape_dict):
+        arg_shape, out_shape, aux_shape = self.sym.infer_shape(**data_shape_dict)
+        self.arg_shape_dict = dict(zip(self.sym.list_arguments(), arg_shape))
+        self.out_shape_dict = dict(zip(self.sym.list_outputs(), out_shape))
+        self.aux_shape_dict = dict(zip(self.sym.list_auxiliary_states(), aux_shape))
+
+    def check_parameter_shapes(self, arg_params, aux_params, data_shape_dict, is_train=False):
+        for k in self.sym.list_arguments():
+            if k in data_shape_dict or k in self.sym.data_names:
+                continue
+            assert k in arg_params, k + ' not initialized'
+            assert tuple(arg_params[k].shape) == tuple(self.arg_shape_dict[k]), \
+                'shape inconsistent for ' + k + ' inferred ' + str(self.arg_shape_dict[k]) + ' provided ' + str(
+                    tuple(arg_params[k].shape))
+        for k in self.sym.list_auxiliary_states():
+            assert k in aux_params, k + ' not initialized'
+            assert tuple(aux_params[k].shape) == tuple(self.aux_shape_dict[k]), \
+                'shape inconsistent for ' + k
+
+    def init_weight(self, cfg, arg_params, aux_params, seed=0):
+        """Fill in whatever the loaded checkpoint lacks, like :753-870: small_net_* copied from the
+        big net, normal(0, 0.01) / zeros for the layers LSFA adds."""
+        rnd_arg, rnd_aux = P.init_params(cfg, seed)
+        for k in self.sym.arg_spec:
+            if k not in arg_params:
+                src = k.replace('small_net_', '')
+                arg_params[k] = arg_params[src].copy() if ('small_net_' in k and src in arg_params) else rnd_arg[k]
+        for k in self.sym.aux_spec:
+            if k not in aux_params:
+                src = k.replace('small_net_', '')
+                aux_params[k] = aux_params[src].copy() if ('small_net_' in k and src in aux_params) else rnd_aux[k]
+
+
+# ======================================================================================
+def _t(a, device, dtype=torch.float32):
+    if isinstance(a, torch.Tensor):
+        return a.to(device=device, dtype=dtype).contiguous()
+    return torch.from_numpy(np.ascontiguousarray(a)).to(device=device, dtype=dtype)
+
+
+class _ResNetWeights(object):
+    """Folded weights of a (prefix) pre-activation ResNet-101 (or its stem + stage 1)."""
+
+    def __init__(self, arg, aux, prefix, stages, add_dcn, tail, device, cdtype):
+        f32 = torch.float32
+
+        def bn(name):
+            g = arg[name + '_gamma'].astype(np.float64)
+            if name.endswith('bn_data'):
+                g = np.ones_like(g)            # fix_gamma=True, resnet.py:151
+            b = arg[name + '_beta'].astype(np.float64)
+            m = aux[name + '_moving_mean'].astype(np.float64)
+            v = aux[name + '_moving_var'].astype(np.float64)
+            s = g / np.sqrt(v + BN_EPS)
+            return s, b - m * s
+
+        def fold(w, s):
+            return (w.astype(np.float64) * s.reshape(-1, 1, 1, 1)).astype(np.float32)
+
+        s, t = bn(prefix + 'bn_data')
+        self.bn_data = (_t(s.astype(np.float32), device, f32), _t(t.astype(np.float32), device, f32))
+        s0, t0 = bn(prefix + 'bn0')
+        self.conv0_w = _t(fold(arg[prefix + 'conv0_weight'], s0), device, cdtype)
+        self.conv0_b = _t(t0.astype(np.float32), device, cdtype)
+        self.units = []
+        for si in range(1, stages + 1):
+            for u in range(1, P.UNITS[si - 1] + 1):
+                p = '%sstage%d_unit%d_' % (prefix, si, u)
+                s1, t1 = bn(p + 'bn1')
+                s2, t2 = bn(p + 'bn2')
+                s3, t3 = bn(p + 'bn3')
+                d = dict(stage=si, unit=u,
+                         bn1=(_t(s1.astype(np.float32), device, f32), _t(t1.astype(np.float32), device, f32)),
+                         w1=_t(fold(arg[p + 'conv1_weight'], s2), device, cdtype), b1=_t(t2.astype(np.float32), device, cdtype),
+                         w2=_t(fold(arg[p + 'conv2_weight'], s3), device, cdtype), b2=_t(t3.astype(np.float32), device, cdtype),
+                         w3=_t(arg[p + 'conv3_weight'], device, cdtype), dcn=P.is_dcn_unit(si, u, add_dcn))
+                if u == 1:
+                    d['sc'] = _t(arg[p + 'sc_weight'], device, cdtype)
+                if d['dcn']:
+                    d['off_w'] = _t(arg[p + 'conv2_offset_weight'], device, cdtype)
+                    d['off_b'] = _t(arg[p + 'conv2_offset_bias'], device, cdtype)
+                    d['w2_2d'] = d['w2'].reshape(d['w2'].shape[0], -1).contiguous()
+                d['w1_2d'] = d['w1'].reshape(d['w1'].shape[0], -1)
+                d['w3_2d'] = d['w3'].reshape(d['w3'].shape[0], -1)
+                self.units.append(d)
+        if tail:
+            s, t = bn(prefix + 'bn1')
+            self.bn1 = (_t(s.astype(np.float32), device, f32), _t(t.astype(np.float32), device, f32))
+
+
+class Executor(object):
+    """A bound test symbol: folded weights on the device + forward()."""
+
+    def __init__(self, sym, arg_params, aux_params, device, dtype):
+        self.sym, self.cfg = sym, sym.cfg
+        self.device = torch.device(device)
+        self.cdtype = dtype           # dtype of the dense contractions (fp32, or bf16 for config 3)
+        self.taps = None              # set to {} to record stage outputs (parity tests)
+        cfg = self.cfg
+        arg = {k: np.asarray(v, dtype=np.float32) for k, v in arg_params.items()}
+        aux = {k: np.asarray(v, dtype=np.float32) for k, v in aux_params.items()}
+        for k, shp in sym.arg_spec.items():
+            if k not in arg:
+                raise KeyError(k + ' not initialized')
+            if tuple(arg[k].shape) != tuple(shp):
+                raise ValueError('shape inconsistent for %s inferred %s provided %s' % (k, shp, arg[k].shape))
+        dev, cd = self.device, self.cdtype
+        A = cfg.network.NUM_ANCHORS
+        # heads: one GEMM for both RPN convs, one for both R-FCN convs
+        std = np.tile(np.asarray(cfg.network.ANCHOR_STDS, np.float32), A)
+        mean = np.tile(np.asarray(cfg.network.ANCHOR_MEANS, np.float32), A)
+        wb, bb = arg['rpn_bbox_pred_weight'].reshape(4 * A, 512), arg['rpn_bbox_pred_bias']
+        if cfg.network.NORMALIZE_RPN:   # rpn_inv_normalize folded: (Wx+b)*std+mean
+            wb, bb = wb * std[:, None], bb * std + mean
+        self.rpn_w = _t(np.concatenate([arg['rpn_cls_score_weight'].reshape(2 * A, 512), wb], 0), dev, cd)
+        self.rpn_b = _t(np.concatenate([arg['rpn_cls_score_bias'], bb], 0), dev, cd)
+        self.rfcn_w = _t(np.concatenate([arg['rfcn_cls_weight'].reshape(-1, 512), arg['rfcn_bbox_weight'].reshape(-1, 512)], 0), dev, cd)
+        self.rfcn_b = _t(np.concatenate([arg['rfcn_cls_bias'], arg['rfcn_bbox_bias']], 0), dev, cd)
+        self.n_cls_ch = arg['rfcn_cls_weight'].shape[0]
+        self.proposal = hip.ProposalOp(feature_stride=cfg.network.RPN_FEAT_STRIDE, scales=cfg.network.ANCHOR_SCALES,
+                                       ratios=cfg.network.ANCHOR_RATIOS, rpn_pre_nms_top_n=cfg.TEST.RPN_PRE_NMS_TOP_N,
+                                       rpn_post_nms_top_n=cfg.TEST.RPN_POST_NMS_TOP_N, threshold=cfg.TEST.RPN_NMS_THRESH,
+                                       rpn_min_size=cfg.TEST.RPN_MIN_SIZE)
+        if sym.kind == 'key':
+            self.net = _ResNetWeights(arg, aux, '', 4, cfg.network.add_dcn, True, dev, cd)
+            self.feat_w, self.feat_b = _t(arg['feat_conv_3x3_weight'], dev, cd), _t(arg['feat_conv_3x3_bias'], dev, cd)
+            self.flow = {k: _t(v, dev, cd) for k, v in arg.items()
+                         if k.startswith(('flow_conv1', 'conv', 'Convolution', 'deconv', 'upsample_flow')) and 'stage' not in k and not k.startswith('conv0')}
+            if cfg.network.add_Nq_net:
+                self.nq = [(_t(arg['Nq_conv%d_weight' % i], dev, cd), _t(arg['Nq_conv%d_bias' % i], dev, cd)) for i in (1, 2, 3)]
+            elif cfg.network.add_Fgfa_net:
+                self.em = [(_t(arg['em_conv%d_weight' % i], dev, cd), _t(arg['em_conv%d_bias' % i], dev, cd)) for i in (1, 2, 3)]
+        else:
+            self.rnet_w = _t(arg['rnet_conv0_weight'].reshape(1024, 3), dev, torch.float32)
+            self.rnet_b = _t(arg['rnet_conv0_bias'], dev, torch.float32)
+            if cfg.network.add_small_net:
+                self.small = _ResNetWeights(arg, aux, 'small_net_', 1, False, False, dev, cd)
+                self.fuse_w, self.fuse_b = _t(arg['fuse_reduce_add_weight'], dev, cd), _t(arg['fuse_reduce_add_bias'], dev, cd)
+
+    def _tap(self, name, x):
+        if self.taps is not None:
+            self.taps[name] = x
+
+    # ---- dense helpers ---------------------------------------------------------------
+    def _c(self, x):
+        return x if x.dtype == self.cdtype else x.to(self.cdtype)
+
+    def _conv1x1(self, x, w2d, bias=None, residual=None):
+        """1x1 stride-1 convolution as a GEMM on the NCHW map; bias or residual in the epilogue."""
+        n, c, h, w = x.shape
+        if n != 1:
+            y = F.conv2d(x, w2d.view(w2d.shape[0], c, 1, 1), bias)
+            return y if residual is None else y.add_(residual)
+        X = x.view(c, h * w)
+        if residual is not None:
+            out = torch.addmm(residual.view(-1, h * w), w2d, X)
+        elif bias is not None:
+            out = torch.addmm(bias.view(-1, 1), w2d, X)
+        else:
+            out = torch.mm(w2d, X)
+        return out.view(1, -1, h, w)
+
+    def _dcn(self, x, u, dilate):
+        """DeformableConvolution (sym_common.py:138-157): offsets by an ordinary conv, bilinear
+        im2col in HIP, then the contraction as one GEMM with the folded bn3 bias."""
+        off = F.conv2d(x, u['off_w'], u['off_b'], stride=1, padding=dilate, dilation=dilate)
+        col = hip.deform_im2col(x.float(), off.float(), 3, 3, dilate, 1, dilate, P.NUM_DEFORMABLE_GROUP)
+        n, _, h, w = off.shape
+        out = torch.baddbmm(u['b2'].view(1, -1, 1), u['w2_2d'].unsqueeze(0).expand(n, -1, -1), self._c(col))
+        return out.view(n, -1, h, w)
+
+    def _resnet(self, x, net, stages, tail):
+        """Pre-activation ResNet (resnet.py:138-240); returns the stage outputs the caller asked for."""
+        x = hip.scale_shift_relu(x, net.bn_data[0], net.bn_data[1], relu=False)
+        x = F.conv2d(self._c(x), net.conv0_w, net.conv0_b, stride=2, padding=3)
+        x = F.max_pool2d(torch.relu_(x), 3, 2, 1)
+        dilate = 1
+        for u in net.units:
+            if u['stage'] > stages:
+                break
+            first = u['unit'] == 1
+            # stage 4 keeps stride 1 and doubles the dilation from its 2nd unit on (resnet.py:33-34, :72-76, :223-230)
+            stride = 2 if (first and u['stage'] in (2, 3)) else 1
+            unit_dilate = dilate
+            if first and u['stage'] == 4:
+                dilate = dilate * 2
+            a = self._c(hip.scale_shift_relu(x.float(), u['bn1'][0], u['bn1'][1], relu=True))
+            c1 = torch.relu_(self._conv1x1(a, u['w1_2d'], bias=u['b1']))
+            if u['dcn']:
+                c2 = self._dcn(c1, u, unit_dilate)
+            else:
+                c2 = F.conv2d(c1, u['w2'], u['b2'], stride=stride, padding=unit_dilate, dilation=unit_dilate)
+            c2 = torch.relu_(c2)
+            if first:
+                sc = F.conv2d(a, u['sc'], None, stride=stride) if stride != 1 else self._conv1x1(a, u['sc'].view(u['sc'].shape[0], -1))
+            else:
+                sc = x if x.dtype == self.cdtype else self._c(x)
+            x = self._conv1x1(c2, u['w3_2d'], residual=sc)
+        if tail:
+            x = self._c(hip.scale_shift_relu(x.float(), net.bn1[0], net.bn1[1], relu=True))
+        return x
+
+    def _backbone(self, data):
+        x = self._resnet(data, self.net, 4, True)
+        return torch.relu_(F.conv2d(x, self.feat_w, self.feat_b, padding=6, dilation=6)).float()
+
+    def _flownet(self, img_cur, img_ref):
+        """FlowNet-S on the half-resolution pair (:150-207)."""
+        fw = self.flow
+
+        def conv(x, name, stride=1, pad=1, act=True):
+            y = F.conv2d(x, fw[name + '_weight'], fw[name + '_bias'], stride=stride, padding=pad)
+            return F.leaky_relu_(y, 0.1) if act else y
+
+        def deconv(x, name, like, act):
+            y = F.conv_transpose2d(x, fw[name + '_weight'], fw[name + '_bias'], stride=2)
+            y = y[:, :, 1:1 + like.shape[2], 1:1 + like.shape[3]]      # Crop(offset=(1,1)) to the skip tensor
+            return F.leaky_relu(y, 0.1) if act else y
+
+        data = self._c(torch.cat([img_cur / 255.0, img_ref / 255.0], 1))
+        x = F.avg_pool2d(data, 2, 2, ceil_mode=True)
+        r1 = conv(x, 'flow_conv1', 2, 3)
+        r2 = conv(r1, 'conv2', 2, 2)
+        r3 = conv(r2, 'conv3', 2, 2)
+        r4 = conv(r3, 'conv3_1')
+        r5 = conv(r4, 'conv4', 2)
+        r6 = conv(r5, 'conv4_1')
+        r7 = conv(r6, 'conv5', 2)
+        r8 = conv(r7, 'conv5_1')
+        r9 = conv(r8, 'conv6', 2)
+        r10 = conv(r9, 'conv6_1')
+        f6 = conv(r10, 'Convolution1', act=False)
+        c2 = torch.cat([r8, deconv(r10, 'deconv5', r8, True), deconv(f6, 'upsample_flow6to5', r8, False)], 1)
+        f5 = conv(c2, 'Convolution2', act=False)
+        c3 = torch.cat([r6, deconv(c2, 'deconv4', r6, True), deconv(f5, 'upsample_flow5to4', r6, False)], 1)
+        f4 = conv(c3, 'Convolution3', act=False)
+        c4 = torch.cat([r4, deconv(c3, 'deconv3', r4, True), deconv(f4, 'upsample_flow4to3', r4, False)], 1)
+        f3 = conv(c4, 'Convolution4', act=False)
+        c5 = torch.cat([r2, deconv(c4, 'deconv2', r2, True), deconv(f3, 'upsample_flow3to2', r2, False)], 1)
+        c5 = F.avg_pool2d(c5, 2, 2, ceil_mode=True)
+        flow = conv(c5, 'Convolution5', act=False).float() * 2.5
+        scale = F.conv2d(c5, fw['Convolution5_scale_weight'], fw['Convolution5_scale_bias']).float()
+        return flow, scale
+
+    def _heads(self, conv_feat, im_info):
+        """SliceChannel -> RPN -> Proposal -> R-FCN maps -> PSROI + average + softmax (:479-546)."""
+        cfg = self.cfg
+        A = cfg.network.NUM_ANCHORS
+        n, _, h, w = conv_feat.shape
+        rpn = self._conv1x1(self._c(conv_feat[:, :512]), self.rpn_w, bias=self.rpn_b).float()
+        cls_prob = torch.softmax(rpn[:, :2 * A].reshape(n, 2, A * h, w), dim=1).reshape(n, 2 * A, h, w)
+        rois = self.proposal(cls_prob, rpn[:, 2 * A:], im_info)
+        maps = self._conv1x1(self._c(conv_feat[:, 512:]), self.rfcn_w, bias=self.rfcn_b).float()
+        if self.taps is not None:
+            self.taps.update(rpn_cls_prob=cls_prob, rpn_bbox_pred=rpn[:, 2 * A:], cls_map=maps[:, :self.n_cls_ch],
+                             box_map=maps[:, self.n_cls_ch:])
+        cls_p, bbox = hip.rfcn_head(maps[:, :self.n_cls_ch], maps[:, self.n_cls_ch:], rois, 0.0625, 7, 7)
+        B = cfg.TEST.BATCH_IMAGES
+        return rois, cls_p.view(B, -1, cls_p.shape[1]), bbox.view(B, -1, bbox.shape[1])
+
+    # ---- forward ---------------------------------------------------------------------
+    def forward(self, **inputs):
+        with torch.no_grad():
+            return self._forward_key(inputs) if self.sym.kind == 'key' else self._forward_cur(inputs)
+
+    def _forward_key(self, d):
+        cfg = self.cfg
+        data, feat_key_old = d['data'], d['feat_key_old']
+        conv_feat = self._backbone(data)
+        self._tap('backbone_feat', conv_feat)
+        # ChooseOldKeyFeat: first frame <=> placeholder shape (1, 1024, 1, 1)
+        _, c, h, w = feat_key_old.shape
+        is_first = (c == cfg.network.DFF_FEAT_DIM and h == 1 and w == 1)
+        if not is_first:
+            flow, scale_map = self._flownet(data, d['data_key_old'])
+            warp = hip.warp_bilinear(feat_key_old, flow, mul=scale_map)
+            if self.taps is not None:
+                self.taps.update(flow=flow, scale_map=scale_map, warp=warp)
+            if cfg.network.add_Nq_net:
+                x = self._c(torch.cat([warp, conv_feat], 0))
+                x = torch.relu_(F.conv2d(x, self.nq[0][0], self.nq[0][1], padding=1))
+                x = torch.relu_(F.conv2d(x, self.nq[1][0], self.nq[1][1]))
+                logits = F.conv2d(x, self.nq[2][0], self.nq[2][1]).float()
+                self._tap('nq_logits', logits)
+                conv_feat = hip.aggregate_softmax2(warp, conv_feat, logits)
+            elif cfg.network.add_Fgfa_net:
+                x = self._c(torch.cat([conv_feat, warp], 0))          # note the order, :133
+                x = torch.relu_(F.conv2d(x, self.em[0][0], self.em[0][1]))
+                x = torch.relu_(F.conv2d(x, self.em[1][0], self.em[1][1], padding=1))
+                e = F.conv2d(x, self.em[2][0], self.em[2][1]).float()
+                conv_feat = hip.aggregate_cosine(warp, conv_feat, e[1:2], e[0:1])
+            else:
+                conv_feat = 0.5 * (warp + conv_feat)
+        rois, cls_prob, bbox_pred = self._heads(conv_feat, d['im_info'])
+        return {'data_key': d.get('data_key'), 'motion_vector': d.get('motion_vector'), 'res_diff': d.get('res_diff'),
+                'feat_key': d.get('feat_key'), 'choose_feat_output': conv_feat, 'rois_output': rois,
+                'cls_prob_reshape_output': cls_prob, 'bbox_pred_reshape_output': bbox_pred}
+
+    def _forward_cur(self, d):
+        cfg = self.cfg
+        add = None
+        if cfg.network.add_small_net:
+            img = F.avg_pool2d(d['data'], 4, 4, ceil_mode=True)
+            s = self._resnet(img, self.small, 1, False)
+            add = F.conv2d(s, self.fuse_w, self.fuse_b, padding=1).float()
+            self._tap('small_feat', add)
+        conv_feat = hip.warp_bilinear(d['feat_key'], d['motion_vector'], add=add, res=d['res_diff'], res_w=self.rnet_w,
+                                      res_b=self.rnet_b)
+        rois, cls_prob, bbox_pred = self._heads(conv_feat, d['im_info'])
+        return {'data': d['data'], 'data_key': d.get('data_key'), 'data_key_old': d.get('data_key_old'),
+                'feat_key_old': d.get('feat_key_old'), 'rois_output': rois, 'cls_prob_reshape_output': cls_prob,
+                'bbox_pred_reshape_output': bbox_pred, 'conv_feat': conv_feat}

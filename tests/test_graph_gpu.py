@@ -1,0 +1,131 @@
+"""Key / cur graph parity on the GPU at a reduced resolution (192x320 -> 12x20 feature map).
+
+Method (DESIGN.md "Parity method"): the dense contractions (MIOpen / hipBLASLt, BN folded)
+are compared with the unfused torch-CPU statement within a tolerance; every hand-written
+stage is then checked BIT-EXACTLY by feeding the oracle the GPU's own inputs to that stage
+("teacher forcing"), so a 1-ulp difference in a convolution cannot hide or fake a kernel bug.
+"""
+import numpy as np
+import pytest
+import torch
+
+import oracle
+from oracle import graph_ref
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+H, W = 192, 320
+
+
+def rel_err(a, b):
+    a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+    return float(np.abs(a - b).max() / (np.abs(b).max() + 1e-12))
+
+
+@pytest.fixture(scope="module")
+def world():
+    from lsfa_amd.config.config import lsfa_test_config
+    from lsfa_amd.symbols import params as P
+    from lsfa_amd.symbols.resnet_v1_101_flownet_rfcn import resnet_v1_101_flownet_rfcn
+    from lsfa_amd.utils.synthetic import SyntheticClip
+    cfg = lsfa_test_config(key_frame_interval=10)
+    arg, aux = P.init_params(cfg, seed=3)
+    net = resnet_v1_101_flownet_rfcn(cfg)
+    key = net.get_key_test_symbol(cfg).bind(arg, aux, DEV)
+    cur = net.get_cur_test_symbol(cfg).bind(arg, aux, DEV)
+    clip = SyntheticClip(0, 12, H, W)
+    return dict(cfg=cfg, arg=arg, aux=aux, key=key, cur=cur, clip=clip)
+
+
+def np_(t):
+    return t.detach().float().cpu().numpy()
+
+
+def check_heads(cfg, taps, out, im_info):
+    rois, _ = oracle.proposal(np_(taps['rpn_cls_prob']), np_(taps['rpn_bbox_pred']), im_info, 16, cfg.network.ANCHOR_SCALES,
+                              cfg.network.ANCHOR_RATIOS, cfg.TEST.RPN_PRE_NMS_TOP_N, cfg.TEST.RPN_POST_NMS_TOP_N,
+                              cfg.TEST.RPN_NMS_THRESH, cfg.TEST.RPN_MIN_SIZE)
+    np.testing.assert_array_equal(np_(out['rois_output']), rois)
+    cls_prob, _, bbox_pred = oracle.rfcn_head(np_(taps['cls_map']), np_(taps['box_map']), rois)
+    np.testing.assert_array_equal(np_(out['cls_prob_reshape_output'])[0], cls_prob)
+    np.testing.assert_array_equal(np_(out['bbox_pred_reshape_output'])[0], bbox_pred)
+
+
+def test_key_and_cur_graphs(world):
+    cfg, arg, aux, key, cur, clip = (world[k] for k in ('cfg', 'arg', 'aux', 'key', 'cur', 'clip'))
+    im_info = clip.im_info()
+    im_info_t = torch.from_numpy(im_info).to(DEV)
+    f0, f10 = clip.frame(0), clip.frame(10)
+    placeholder = torch.zeros(1, 1024, 1, 1, device=DEV)
+
+    # ---- first frame (flag 0): backbone + heads, no aggregation -----------------------
+    key.taps = {}
+    out0 = key.forward(data=f0.to(DEV), im_info=im_info_t, data_key_old=f0.to(DEV), feat_key_old=placeholder)
+    ref0 = graph_ref.key_forward(cfg, arg, aux, f0.numpy(), f0.numpy(), np.zeros((1, 1024, 1, 1), np.float32), im_info)
+    assert out0['choose_feat_output'].shape == (1, 1024, 12, 20)
+    assert rel_err(np_(key.taps['backbone_feat']), ref0['backbone_feat']) < 2e-3
+    assert rel_err(np_(key.taps['cls_map']), ref0['cls_map']) < 2e-3
+    assert rel_err(np_(key.taps['rpn_bbox_pred']), ref0['rpn_bbox_pred']) < 2e-3
+    assert np.abs(np_(key.taps['rpn_cls_prob']) - ref0['rpn_cls_prob']).max() < 1e-4
+    check_heads(cfg, key.taps, out0, im_info)
+    feat0 = out0['choose_feat_output']
+
+    # ---- non-key frame (flag 2): MV warp + residual + small net ------------------------
+    f3 = clip.frame(3)
+    mv, res = clip.motion_vector(3, 0), clip.res_diff(3)
+    cur.taps = {}
+    out3 = cur.forward(data=f3.to(DEV), im_info=im_info_t, feat_key=feat0, motion_vector=mv.to(DEV), res_diff=res.to(DEV))
+    ref_small = graph_ref.small_net_feature(graph_ref.Params(arg, aux), f3).numpy()
+    assert rel_err(np_(cur.taps['small_feat']), ref_small) < 2e-3
+    want = oracle.warp_bilinear(np_(feat0), mv.numpy(), add=np_(cur.taps['small_feat']), res=res.numpy(),
+                                res_w=arg['rnet_conv0_weight'], res_b=arg['rnet_conv0_bias'])
+    np.testing.assert_array_equal(np_(out3['conv_feat']), want)
+    check_heads(cfg, cur.taps, out3, im_info)
+
+    # ---- second key frame (flag 1): FlowNet + flow warp x scale + Nq aggregation --------
+    key.taps = {}
+    out10 = key.forward(data=f10.to(DEV), im_info=im_info_t, data_key_old=f0.to(DEV), feat_key_old=feat0)
+    p = graph_ref.Params(arg, aux)
+    flow_ref, scale_ref = graph_ref.get_flownet(p, f10, f0)
+    assert np.abs(np_(key.taps['flow']) - flow_ref.numpy()).max() < 2e-3 * max(1.0, float(flow_ref.abs().max()))
+    assert rel_err(np_(key.taps['scale_map']), scale_ref.numpy()) < 2e-3
+    warp_want = oracle.warp_bilinear(np_(feat0), np_(key.taps['flow']), mul=np_(key.taps['scale_map']))
+    np.testing.assert_array_equal(np_(key.taps['warp']), warp_want)
+    logits_ref = graph_ref.nq_logits(p, torch.from_numpy(warp_want), key.taps['backbone_feat'].cpu()).numpy()
+    assert np.abs(np_(key.taps['nq_logits']) - logits_ref).max() < 2e-3 * max(1.0, float(np.abs(logits_ref).max()))
+    agg_want = oracle.aggregate_softmax2(warp_want, np_(key.taps['backbone_feat']), np_(key.taps['nq_logits']))
+    np.testing.assert_array_equal(np_(out10['choose_feat_output']), agg_want)
+    check_heads(cfg, key.taps, out10, im_info)
+
+
+def test_pred_eval_loop_flags_and_shapes(world):
+    """The frame loop (TestLoader + pred_eval) on a 12-frame clip with interval 5."""
+    from lsfa_amd.config.config import lsfa_test_config
+    from lsfa_amd.core.loader import TestLoader
+    from lsfa_amd.core.tester import Predictor, pred_eval
+    from lsfa_amd.symbols.resnet_v1_101_flownet_rfcn import resnet_v1_101_flownet_rfcn
+    from lsfa_amd.utils.synthetic import synthetic_roidb
+    cfg = lsfa_test_config(key_frame_interval=5)
+    roidb = synthetic_roidb(1, 12, H, W, 5)
+    loader = TestLoader(roidb, cfg, device=DEV)
+    flags = []
+    probe = TestLoader(roidb, cfg, device=DEV)
+    for _, flag, _ in probe:
+        flags.append(flag)
+    assert flags == oracle_flags([12], 5)
+    net = resnet_v1_101_flownet_rfcn(cfg)
+    names = loader.data_name
+    kp = Predictor(net.get_key_test_symbol(cfg), names, None, DEV, arg_params=world['arg'], aux_params=world['aux'])
+    cp = Predictor(net.get_cur_test_symbol(cfg), names, None, DEV, arg_params=world['arg'], aux_params=world['aux'])
+    all_boxes, frame_ids = pred_eval(0, kp, cp, loader, None, cfg)
+    assert list(frame_ids) == list(range(12))
+    assert len(all_boxes) == 31 and len(all_boxes[1]) == 12
+    per_frame = [sum(len(all_boxes[j][i]) for j in range(1, 31)) for i in range(12)]
+    assert all(0 < n <= 300 + 30 for n in per_frame)
+    b = np.vstack([all_boxes[j][3] for j in range(1, 31)])
+    assert (b[:, 0] >= 0).all() and (b[:, 2] <= W - 1).all() and (b[:, 3] <= H - 1).all() and (b[:, 4] > 1e-4).all()
+
+
+def oracle_flags(seg_lens, k):
+    from oracle import np_ref
+    return np_ref.key_frame_flags(seg_lens, k)

@@ -1,0 +1,239 @@
+#!/usr/bin/env python
+"""LSFA per-frame inference benchmark on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+
+Metric (BASELINE.json): frames/sec at 1000x600, key_interval = 10, synthetic VID-shaped clips,
+random-init weights of the trained LSFA architecture (ResNet-101 + DCN + FlowNet + Nq + small net
++ R-FCN head), fp32.  Workload = BASELINE.json configs[1] ("dff_rfcn ResNet-101 LSFA, 1 clip
+key_interval=10 on 1xMI355X, fp32").
+
+A STEP is one key-frame interval of one clip: 1 key frame (ResNet-101 + FlowNet + flow warp x
+scale map + Nq aggregation + heads + Proposal + PSROI + detection NMS) followed by
+key_interval-1 non-key frames (small net + MV warp + residual + heads + Proposal + PSROI +
+detection NMS).  Frames, motion vectors and residuals are resident in HBM before the timed
+region; every frame's detections are copied to pinned host memory inside it.
+
+N > 1: launched by torch.distributed.run, one rank per GPU; rank r runs clip r (clips are
+independent: "scaling": "weak", no data-path collective); the only collective is the final
+all_gather of per-frame detection counts over RCCL, outside the per-frame path.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+WARP_BYTES = lambda C, HW: (3 * C * HW + 2 * HW) * 4  # feat + (scale map | small-net feature) + out, + flow
+HBM_PEAK_GBS = 8000.0                                   # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=12)
+    ap.add_argument('--warmup', type=int, default=2)
+    ap.add_argument('--interval', type=int, default=10)
+    ap.add_argument('--height', type=int, default=600)
+    ap.add_argument('--width', type=int, default=1000)
+    ap.add_argument('--dtype', default='f32', choices=['f32', 'bf16'])
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--cpu-budget-s', type=float, default=20.0)
+    ap.add_argument('--max-unique-steps', type=int, default=16, help='distinct intervals of frames kept in HBM')
+    return ap.parse_args()
+
+
+class Runner(object):
+    """One clip stream on one GPU: the pred_eval frame loop (dff_rfcn/core/tester.py:237-281)."""
+
+    def __init__(self, args, rank, device):
+        from lsfa_amd import hip
+        from lsfa_amd.config.config import lsfa_test_config
+        from lsfa_amd.symbols import params as P
+        from lsfa_amd.symbols.resnet_v1_101_flownet_rfcn import resnet_v1_101_flownet_rfcn
+        from lsfa_amd.utils.synthetic import SyntheticClip
+        self.hip, self.args, self.device = hip, args, device
+        self.cfg = cfg = lsfa_test_config(key_frame_interval=args.interval)
+        self.arg, self.aux = P.init_params(cfg, seed=0)
+        dt = torch.float32 if args.dtype == 'f32' else torch.bfloat16
+        net = resnet_v1_101_flownet_rfcn(cfg)
+        self.key = net.get_key_test_symbol(cfg).bind(self.arg, self.aux, device, dt)
+        self.cur = net.get_cur_test_symbol(cfg).bind(self.arg, self.aux, device, dt)
+        self.K = args.interval
+        self.nsteps_unique = min(args.max_unique_steps, args.steps + args.warmup)
+        self.clip = SyntheticClip(rank, self.nsteps_unique * self.K + 1, args.height, args.width, self.K)
+        self.im_info = torch.from_numpy(self.clip.im_info()).to(device)
+        # frames resident in HBM: frame 0 primes the recurrence, then nsteps_unique intervals
+        self.frames = [self.clip.frame(f, device) for f in range(self.nsteps_unique * self.K + 1)]
+        self.mv, self.res = {}, {}
+        for s in range(self.nsteps_unique):
+            kf = 1 + s * self.K
+            for i in range(1, self.K):
+                self.mv[kf + i] = self.clip.motion_vector(kf + i, kf, device)
+                self.res[kf + i] = self.clip.res_diff(kf + i, device)
+        R, ncls = cfg.TEST.RPN_POST_NMS_TOP_N, cfg.dataset.NUM_CLASSES
+        self.host_dets = torch.empty((self.K, ncls, R, 5), dtype=torch.float64).pin_memory()
+        self.host_counts = torch.empty((self.K, ncls), dtype=torch.int32).pin_memory()
+        self.frame_counts = []
+        self.feat = None
+        self.prev_key = None
+
+    def prime(self):
+        """Frame 0 of the clip (flag 0: no aggregation) — sets up feat_key / data_key."""
+        ph = torch.zeros((1, self.cfg.network.DFF_FEAT_DIM, 1, 1), device=self.device)
+        out = self.key.forward(data=self.frames[0], im_info=self.im_info, data_key_old=self.frames[0], feat_key_old=ph)
+        self.feat, self.prev_key = out['choose_feat_output'], self.frames[0]
+
+    def _post(self, out, slot):
+        cfg = self.cfg
+        dets, counts, _ = self.hip.det_postprocess(out['rois_output'], out['bbox_pred_reshape_output'][0],
+                                                   out['cls_prob_reshape_output'][0], self.args.height, self.args.width, 1.0,
+                                                   score_thresh=1e-4, nms_thresh=cfg.TEST.NMS,
+                                                   max_per_image=cfg.TEST.max_per_image, class_agnostic=cfg.CLASS_AGNOSTIC)
+        self.host_dets[slot].copy_(dets, non_blocking=True)
+        self.host_counts[slot].copy_(counts, non_blocking=True)
+
+    def step(self, s):
+        """One key-frame interval: key frame (flag 1) + K-1 non-key frames (flag 2)."""
+        kf = 1 + (s % self.nsteps_unique) * self.K
+        data = self.frames[kf]
+        out = self.key.forward(data=data, im_info=self.im_info, data_key_old=self.prev_key, feat_key_old=self.feat)
+        self.feat, self.prev_key = out['choose_feat_output'], data
+        self._post(out, 0)
+        for i in range(1, self.K):
+            out = self.cur.forward(data=self.frames[kf + i], im_info=self.im_info, feat_key=self.feat,
+                                   motion_vector=self.mv[kf + i], res_diff=self.res[kf + i])
+            self._post(out, i)
+
+    def cpu_baseline(self, budget_s):
+        """The oracle's statement of the same step (torch-CPU convs + C kernels), timed on the host."""
+        import oracle
+        from oracle import graph_ref
+        cfg, K = self.cfg, self.K
+        f = [self.frames[i].cpu().numpy() for i in range(0, K + 1)]
+        im_info = self.clip.im_info()
+        feat0 = self.feat.cpu().numpy()
+        t0 = time.time()
+        frames_done = 0
+        out = graph_ref.key_forward(cfg, self.arg, self.aux, f[1], f[0], feat0, im_info)
+        oracle.det_postprocess(out['rois_output'], out['bbox_pred_reshape_output'][0], out['cls_prob_reshape_output'][0],
+                               self.args.height, self.args.width, 1.0)
+        feat = out['choose_feat_output']
+        frames_done += 1
+        key_s = time.time() - t0
+        nonkey_s = 0.0
+        for i in range(1, K):
+            t1 = time.time()
+            o = graph_ref.cur_forward(cfg, self.arg, self.aux, f[1 + i], feat, self.mv[1 + i].cpu().numpy(),
+                                      self.res[1 + i].cpu().numpy(), im_info)
+            oracle.det_postprocess(o['rois_output'], o['bbox_pred_reshape_output'][0], o['cls_prob_reshape_output'][0],
+                                   self.args.height, self.args.width, 1.0)
+            nonkey_s += time.time() - t1
+            frames_done += 1
+            if time.time() - t0 > budget_s:
+                break
+        n_nonkey = frames_done - 1
+        # per-interval time = 1 key + (K-1) non-key at the measured per-frame costs
+        per_step = key_s + (nonkey_s / max(n_nonkey, 1)) * (K - 1)
+        return {"value": round(K / per_step, 3), "unit": "frames/s", "cores": int(torch.get_num_threads()), "kind": "port",
+                "sample": "1 key frame + %d non-key frame(s) of the same clip at %dx%d through oracle/graph_ref.py "
+                          "(torch-CPU fp32 convs, C oracle for warp/aggregate/proposal/psroi/nms); %.1f s key, %.2f s per "
+                          "non-key frame, extrapolated to one %d-frame interval" % (n_nonkey, self.args.width,
+                                                                                   self.args.height, key_s,
+                                                                                   nonkey_s / max(n_nonkey, 1), K)}
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    distributed = world > 1
+    if distributed:
+        import torch.distributed as dist
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
+    device = 'cuda:%d' % local_rank
+    torch.cuda.set_device(local_rank)
+    torch.backends.cudnn.benchmark = os.environ.get('LSFA_MIOPEN_FIND', '1') == '1'
+
+    from lsfa_amd import hip
+    r = Runner(args, rank, device)
+    r.prime()
+    for s in range(args.warmup):
+        r.step(s)
+    torch.cuda.synchronize()
+
+    def barrier():
+        if distributed:
+            dist.barrier(device_ids=[local_rank])
+
+    hip.prof_enable(True, ops=['warp_bilinear'])   # 2 event records per frame: the roofline kernel only
+    hip.prof_read()
+    barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for s in range(args.warmup, args.warmup + args.steps):
+        r.step(s)
+    torch.cuda.synchronize()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    prof = hip.prof_read()
+    hip.prof_enable(False)
+
+    if distributed:
+        tt = torch.tensor([elapsed], device=device, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+        # the final gather of detections (here: last interval's per-frame counts) over RCCL
+        counts = r.host_counts.to(device)
+        gathered = [torch.empty_like(counts) for _ in range(world)]
+        dist.all_gather(gathered, counts)
+        total_dets = int(sum(int(g.sum().item()) for g in gathered))
+    else:
+        total_dets = int(r.host_counts.sum().item())
+
+    if rank == 0:
+        K = args.interval
+        frames = world * args.steps * K
+        fh, fw = int(np.ceil(args.height / 16.0)), int(np.ceil(args.width / 16.0))
+        warp_ms, warp_n = prof['warp_bilinear']
+        bytes_per_launch = WARP_BYTES(1024, fh * fw)
+        achieved = bytes_per_launch * warp_n / (warp_ms * 1e-3) / 1e9 if warp_ms > 0 else 0.0
+        line = {
+            "metric": "frames/sec/GPU at 1000x600 key_interval=10 (whole-job frames/s)",
+            "value": round(frames / elapsed, 3), "unit": "frames/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+            "config": {"workload": "dff_rfcn ResNet-101 LSFA (DCN + FlowNet + Nq + small net + R-FCN), 1 clip per GPU, "
+                                   "key_interval=%d, %dx%d, %s; step = 1 key + %d non-key frames" %
+                                   (K, args.width, args.height, args.dtype, K - 1),
+                       "frames_per_step": K, "ms_per_frame": round(elapsed / (args.steps * K) * 1e3, 3),
+                       "parallelism": "clip-parallel x%d" % world, "detections_last_interval": total_dets},
+            "roofline": {"bound": "hbm", "kernel": "warp_kernel (lsfa_warp_bilinear: MV/flow warp + fused epilogue)",
+                         "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                         "launches": warp_n, "avg_us": round(warp_ms * 1e3 / max(warp_n, 1), 2),
+                         "algorithmic_bytes_per_launch": bytes_per_launch},
+        }
+        if not args.no_cpu_baseline:
+            try:
+                line["cpu_baseline"] = r.cpu_baseline(args.cpu_budget_s)
+            except Exception as e:  # the baseline is a reported extra; never lose the bench line to it
+                line["cpu_baseline"] = {"value": None, "unit": "frames/s", "cores": int(torch.get_num_threads()),
+                                        "kind": "port", "sample": "failed: %r" % (e,)}
+        print(json.dumps(line))
+    if distributed:
+        dist.barrier(device_ids=[local_rank])
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

@@ -183,16 +183,17 @@ int lsfa_scale_shift_relu(const float* x, const float* scale, const float* shift
 
 /* ------------------------------------------------------------------------ *
  * Live per-op timing with HIP events on the launch stream (bench.py's roofline leg).
- * lsfa_prof_enable(1) makes every entry point above bracket its launches with
- * hipEventRecord on `stream`; lsfa_prof_read synchronises the events and returns
- * accumulated milliseconds and launch counts per op id, then clears them.
+ * lsfa_prof_enable(mask) makes the entry points whose op id bit is set in `mask`
+ * (-1 = all, 0 = off) bracket their launches with hipEventRecord on `stream`;
+ * lsfa_prof_read synchronises the events and returns accumulated milliseconds and
+ * launch counts per op id, then clears them.  Do not enable during graph capture.
  * ------------------------------------------------------------------------ */
 enum {
   LSFA_OP_PSROI = 0, LSFA_OP_RFCN_HEAD = 1, LSFA_OP_WARP = 2, LSFA_OP_AGG = 3,
   LSFA_OP_PROPOSAL = 4, LSFA_OP_NMS = 5, LSFA_OP_DET = 6, LSFA_OP_DCN_IM2COL = 7,
   LSFA_OP_BNRELU = 8, LSFA_OP_COUNT = 9
 };
-int lsfa_prof_enable(int on);
+int lsfa_prof_enable(int mask);
 int lsfa_prof_read(double* ms_host /*LSFA_OP_COUNT*/, int* launches_host /*LSFA_OP_COUNT*/);
 const char* lsfa_op_name(int op_id);
 

@@ -26,12 +26,12 @@ int hip_fail(hipError_t e, const char* what) {
 // ---- profiling ------------------------------------------------------------------
 struct EventPair { hipEvent_t a, b; int op; };
 static std::mutex g_mu;
-static bool g_prof = false;
+static unsigned g_prof = 0;  // bit i set: op i is timed
 static std::vector<EventPair> g_live;
 static std::vector<EventPair> g_free;
 
 ProfScope::ProfScope(int op, hipStream_t stream) : stream_(stream), slot_(-1) {
-  if (!g_prof) return;
+  if (!((g_prof >> op) & 1u)) return;
   std::lock_guard<std::mutex> lk(g_mu);
   EventPair p;
   if (!g_free.empty()) { p = g_free.back(); g_free.pop_back(); }
@@ -57,9 +57,9 @@ using namespace lsfa;
 extern "C" const char* lsfa_last_error(void) { return g_err; }
 extern "C" int lsfa_abi_version(void) { return 1; }
 
-extern "C" int lsfa_prof_enable(int on) {
+extern "C" int lsfa_prof_enable(int mask) {
   std::lock_guard<std::mutex> lk(g_mu);
-  g_prof = on != 0;
+  g_prof = (unsigned)mask;
   return LSFA_OK;
 }
 

@@ -253,8 +253,12 @@ def scale_shift_relu(x, scale, shift, relu=True, out=None):
 
 
 # ---- live timing -----------------------------------------------------------------------
-def prof_enable(on=True):
-    _check(lib().lsfa_prof_enable(_ci(int(on))), "lsfa_prof_enable")
+def prof_enable(on=True, ops=None):
+    """on=True times every op; ops=['warp_bilinear', ...] times only those; on=False stops."""
+    mask = 0
+    if on:
+        mask = -1 if ops is None else sum(1 << OP_NAMES.index(o) for o in ops)
+    _check(lib().lsfa_prof_enable(_ci(mask)), "lsfa_prof_enable")
 
 
 def prof_read():

@@ -41,9 +41,12 @@ __global__ __launch_bounds__(kThreads) void bbox_pred_clip_kernel(const float* _
   decode_box(rois + (size_t)r * 5, deltas + (size_t)i * 4, im_h, im_w, scale, pred + (size_t)i * 4);
 }
 
-// grid (ncls); block 256.  LDS carve (all sized by R, offsets multiples of 16):
+// grid (ncls); block kClassThreads (16 waves).  LDS carve (all sized by R, offsets multiples of 8):
 //   box[R][4] f64 | score[R] f64 | mask[R][Wd] u64 | src[R] i32 | order[R] i32 | kept[R] i32 | misc
-__global__ __launch_bounds__(kThreads) void det_class_kernel(
+constexpr int kClassThreads = 1024;
+constexpr int kClassWaves = kClassThreads / 64;
+
+__global__ __launch_bounds__(kClassThreads) void det_class_kernel(
     const float* __restrict__ rois, const float* __restrict__ deltas, const float* __restrict__ probs, int R,
     int ncls, int nreg, int class_agnostic, double im_h, double im_w, double scale, double score_thresh,
     double nms_thresh, double* __restrict__ dets, int* __restrict__ counts, int* __restrict__ keep_idx) {
@@ -58,13 +61,13 @@ __global__ __launch_bounds__(kThreads) void det_class_kernel(
   int* src = reinterpret_cast<int*>(mask + (size_t)R * Wd);
   int* order = src + R;
   int* kept = order + R;
-  int* misc = kept + R;  // [0] running count, [1..4] wave sums
+  int* misc = kept + R;  // [0] running count, [1..16] wave sums
 
   // 1. threshold + in-order compaction (np.where(scores[:, j] > thresh), tester.py:267)
   if (tid == 0) misc[0] = 0;
   __syncthreads();
   const int lane = tid & 63, wid = tid >> 6;
-  for (int r0 = 0; r0 < R; r0 += kThreads) {
+  for (int r0 = 0; r0 < R; r0 += kClassThreads) {
     const int r = r0 + tid;
     const double s = r < R ? (double)probs[(size_t)r * ncls + j] : 0.0;
     const bool flag = r < R && s > score_thresh;
@@ -81,14 +84,18 @@ __global__ __launch_bounds__(kThreads) void det_class_kernel(
       decode_box(rois + (size_t)r * 5, deltas + ((size_t)r * nreg + col) * 4, im_h, im_w, scale, box + (size_t)pos * 4);
     }
     __syncthreads();
-    if (tid == 0) misc[0] += misc[1] + misc[2] + misc[3] + misc[4];
+    if (tid == 0) {
+      int t = 0;
+      for (int w = 0; w < kClassWaves; ++w) t += misc[1 + w];
+      misc[0] += t;
+    }
     __syncthreads();
   }
   const int m = misc[0];
   if (m == 0) { if (tid == 0) counts[j] = 0; return; }
 
   // 2. rank sort: score descending, ties by ascending candidate (= roi) index
-  for (int i = tid; i < m; i += kThreads) {
+  for (int i = tid; i < m; i += kClassThreads) {
     const double si = score[i];
     int rank = 0;
     for (int k = 0; k < m; ++k) {
@@ -100,44 +107,71 @@ __global__ __launch_bounds__(kThreads) void det_class_kernel(
   __syncthreads();
 
   // 3. suppression mask over sorted positions: bit b of mask[a][w] <=> position 64w+b > a and
-  //    NOT (ovr <= thresh)  (nms.py:71 keeps `ovr <= thresh`)
-  for (int t = tid; t < m * Wd; t += kThreads) {
-    const int a = t / Wd, w = t - a * Wd;
+  //    NOT (ovr <= thresh)  (nms.py:71 keeps `ovr <= thresh`).  One (row, 16-column strip) per
+  //    thread so that all 16 waves share the fp64 divisions of the upper triangle.
+  for (int t = tid; t < m * Wd; t += kClassThreads) mask[t] = 0;
+  __syncthreads();
+  const int strips = Wd * 4;
+  for (int t = tid; t < m * strips; t += kClassThreads) {
+    const int a = t / strips, st = t - a * strips;
+    const int c0 = st * 16;
+    if (c0 + 15 <= a || c0 >= m) continue;
+    const int ia = order[a];
+    const double ax1 = box[ia * 4], ay1 = box[ia * 4 + 1], ax2 = box[ia * 4 + 2], ay2 = box[ia * 4 + 3];
+    const double area_a = (ax2 - ax1 + 1) * (ay2 - ay1 + 1);
+    const int b0 = max(c0, a + 1), b1 = min(c0 + 16, m);
     uint64_t bits = 0;
-    if (64 * w + 63 > a) {
-      const int ia = order[a];
-      const double ax1 = box[ia * 4], ay1 = box[ia * 4 + 1], ax2 = box[ia * 4 + 2], ay2 = box[ia * 4 + 3];
-      const double area_a = (ax2 - ax1 + 1) * (ay2 - ay1 + 1);
-      const int b0 = max(64 * w, a + 1), b1 = min(64 * w + 64, m);
-      for (int b = b0; b < b1; ++b) {
-        const int ib = order[b];
-        const double bx1 = box[ib * 4], by1 = box[ib * 4 + 1], bx2 = box[ib * 4 + 2], by2 = box[ib * 4 + 3];
-        const double xx1 = fmax(ax1, bx1), yy1 = fmax(ay1, by1);
-        const double xx2 = fmin(ax2, bx2), yy2 = fmin(ay2, by2);
-        const double ww = fmax(0.0, xx2 - xx1 + 1), hh = fmax(0.0, yy2 - yy1 + 1);
-        const double inter = ww * hh;
-        const double area_b = (bx2 - bx1 + 1) * (by2 - by1 + 1);
-        const double ovr = inter / (area_a + area_b - inter);
-        if (!(ovr <= nms_thresh)) bits |= 1ULL << (b - 64 * w);
-      }
+    for (int b = b0; b < b1; ++b) {
+      const int ib = order[b];
+      const double bx1 = box[ib * 4], by1 = box[ib * 4 + 1], bx2 = box[ib * 4 + 2], by2 = box[ib * 4 + 3];
+      const double xx1 = fmax(ax1, bx1), yy1 = fmax(ay1, by1);
+      const double xx2 = fmin(ax2, bx2), yy2 = fmin(ay2, by2);
+      const double ww = fmax(0.0, xx2 - xx1 + 1), hh = fmax(0.0, yy2 - yy1 + 1);
+      const double inter = ww * hh;
+      const double area_b = (bx2 - bx1 + 1) * (by2 - by1 + 1);
+      const double ovr = inter / (area_a + area_b - inter);
+      if (!(ovr <= nms_thresh)) bits |= 1ULL << (b & 63);
     }
-    mask[(size_t)a * Wd + w] = bits;
+    if (bits) atomicOr(reinterpret_cast<unsigned long long*>(&mask[(size_t)a * Wd + (c0 >> 6)]), (unsigned long long)bits);
   }
   __syncthreads();
 
-  // 4. sweep by wave 0: lane w holds word w of the removed set
+  // 4. sweep by wave 0 in 64-position blocks: lane w (< Wd) holds word w of the removed set;
+  //    a block is resolved on scalars from its diagonal words, then the survivors' rows are ORed in
   int nk = 0;
   if (wid == 0) {
     uint64_t remv = 0;
-    for (int a = 0; a < m; ++a) {
-      const int w = a >> 6, b = a & 63;
-      const uint32_t lo = __builtin_amdgcn_readlane((uint32_t)remv, w);
-      const uint32_t hi = __builtin_amdgcn_readlane((uint32_t)(remv >> 32), w);
-      const bool removed = b < 32 ? ((lo >> b) & 1u) : ((hi >> (b - 32)) & 1u);
-      if (!removed) {
-        if (lane == 0) kept[nk] = order[a];
-        ++nk;
-        if (lane < Wd) remv |= mask[(size_t)a * Wd + lane];
+    const int nblk = (m + 63) / 64;
+    for (int b = 0; b < nblk; ++b) {
+      const int base = b * 64, nb = min(64, m - base);
+      const uint64_t diag = lane < nb ? mask[(size_t)(base + lane) * Wd + b] : 0ULL;
+      uint32_t cur_lo = __builtin_amdgcn_readlane((uint32_t)remv, b);
+      uint32_t cur_hi = __builtin_amdgcn_readlane((uint32_t)(remv >> 32), b);
+      const uint32_t d_lo = (uint32_t)diag, d_hi = (uint32_t)(diag >> 32);
+      uint32_t k_lo = 0, k_hi = 0;
+      for (int k = 0; k < nb; ++k) {
+        const bool removed = k < 32 ? ((cur_lo >> k) & 1u) : ((cur_hi >> (k - 32)) & 1u);
+        if (!removed) {
+          if (k < 32) k_lo |= 1u << k; else k_hi |= 1u << (k - 32);
+          cur_lo |= __builtin_amdgcn_readlane(d_lo, k);
+          cur_hi |= __builtin_amdgcn_readlane(d_hi, k);
+        }
+      }
+      const uint64_t kb = ((uint64_t)k_hi << 32) | k_lo;
+      if ((kb >> lane) & 1ULL) kept[nk + __popcll(kb & ((1ULL << lane) - 1ULL))] = order[base + lane];
+      nk += __popcll(kb);
+      uint64_t rem = kb;
+      while (rem) {
+        int ks[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          if (rem) { ks[u] = __builtin_ctzll(rem); rem &= rem - 1; } else ks[u] = -1;
+        }
+        uint64_t vv[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) vv[u] = (ks[u] >= 0 && lane < Wd) ? mask[(size_t)(base + ks[u]) * Wd + lane] : 0ULL;
+#pragma unroll
+        for (int u = 0; u < 8; ++u) remv |= vv[u];
       }
     }
     if (lane == 0) { misc[0] = nk; counts[j] = nk; }
@@ -146,7 +180,7 @@ __global__ __launch_bounds__(kThreads) void det_class_kernel(
   nk = misc[0];
 
   // 5. survivors in NMS order
-  for (int k = tid; k < nk; k += kThreads) {
+  for (int k = tid; k < nk; k += kClassThreads) {
     const int i = kept[k];
     double* o = dets + ((size_t)j * R + k) * 5;
     o[0] = box[i * 4]; o[1] = box[i * 4 + 1]; o[2] = box[i * 4 + 2]; o[3] = box[i * 4 + 3];
@@ -162,47 +196,74 @@ __device__ __forceinline__ uint32_t desc_key(float score) {
 }
 
 // max_per_image cap (tester.py:274-281).  The scores are float32 probabilities widened to
-// float64, so a 32-bit radix select on their float image is exact.  Single workgroup.
+// float64, so a 32-bit radix select on their float image is exact.  Single workgroup; the keys
+// of all survivors are staged in LDS once (ncls*R <= 16K keys), histograms are replicated 16x.
+constexpr int kCapMaxKeys = 16384;
 __global__ __launch_bounds__(1024) void det_cap_kernel(double* __restrict__ dets, int* __restrict__ counts,
                                                        int* __restrict__ keep_idx, int R, int ncls,
                                                        int max_per_image) {
-  __shared__ uint32_t hist[256];
-  __shared__ int misc[4];
+  __shared__ uint32_t keys[kCapMaxKeys];
+  __shared__ uint32_t hist[16 * 256];
+  __shared__ int misc[40];
   const int tid = threadIdx.x;
-  int total = 0;
-  for (int j = 1; j < ncls; ++j) total += counts[j];
+  const int lane = tid & 63, wid = tid >> 6;
+  // offsets of each class's survivors in the flat key array
+  if (tid == 0) {
+    int t = 0;
+    for (int j = 1; j < ncls; ++j) t += counts[j];
+    misc[0] = t;
+  }
+  __syncthreads();
+  const int total = misc[0];
   if (total <= max_per_image) return;
+  // stage keys: flat position = j*R + k (sparse but simple); absent slots get the largest key
+  const int span = ncls * R;
+  for (int i = tid; i < span; i += 1024) {
+    const int j = i / R, k = i - j * R;
+    keys[i] = (j >= 1 && k < counts[j]) ? desc_key((float)dets[(size_t)i * 5 + 4]) : 0xFFFFFFFFu;
+  }
+  __syncthreads();
   // image_thresh = np.sort(image_scores)[-max_per_image]  == the max_per_image-th largest
   uint32_t prefix = 0;
   int remaining = max_per_image;
   for (int shift = 24; shift >= 0; shift -= 8) {
-    if (tid < 256) hist[tid] = 0;
+    for (int i = tid; i < 16 * 256; i += 1024) hist[i] = 0;
     __syncthreads();
-    for (int j = 1; j < ncls; ++j) {
-      const int cj = counts[j];
-      for (int k = tid; k < cj; k += 1024) {
-        const uint32_t key = desc_key((float)dets[((size_t)j * R + k) * 5 + 4]);
-        const bool match = (shift == 24) || (((key ^ prefix) >> (shift + 8)) == 0);
-        if (match) atomicAdd(&hist[(key >> shift) & 255u], 1u);
-      }
+    uint32_t* myhist = hist + (lane & 15) * 256;
+    for (int i = tid; i < span; i += 1024) {
+      const uint32_t key = keys[i];
+      const bool match = (shift == 24) || (((key ^ prefix) >> (shift + 8)) == 0);
+      if (match) atomicAdd(&myhist[(key >> shift) & 255u], 1u);
     }
     __syncthreads();
-    if (tid == 0) {
-      int before = 0, bucket = 0;
-      for (int q = 0; q < 256; ++q) {
-        if (before + (int)hist[q] >= remaining) { bucket = q; break; }
-        before += (int)hist[q];
+    if (tid < 256) {
+      uint32_t c = 0;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) c += hist[r * 256 + tid];
+      int incl = (int)c;
+#pragma unroll
+      for (int d = 1; d < 64; d <<= 1) {
+        const int o = __shfl_up(incl, d, 64);
+        if (lane >= d) incl += o;
       }
-      misc[0] = bucket;
-      misc[1] = remaining - before;
+      if (lane == 63) misc[8 + wid] = incl;
+      hist[tid] = (uint32_t)incl;
+      hist[256 + tid] = c;
     }
     __syncthreads();
-    prefix |= (uint32_t)misc[0] << shift;
-    remaining = misc[1];
+    if (tid < 256) {
+      int carry = 0;
+      for (int w = 0; w < wid; ++w) carry += misc[8 + w];
+      const int incl = (int)hist[tid] + carry;
+      const int c = (int)hist[256 + tid];
+      if (incl >= remaining && incl - c < remaining) { misc[1] = tid; misc[2] = remaining - (incl - c); }
+    }
+    __syncthreads();
+    prefix |= (uint32_t)misc[1] << shift;
+    remaining = misc[2];
     __syncthreads();
   }
   const uint32_t T = prefix;  // keep score >= image_thresh  <=>  key <= T
-  const int lane = tid & 63, wid = tid >> 6;
   for (int j = 1 + wid; j < ncls; j += 16) {
     const int cj = counts[j];
     int m = 0;
@@ -215,7 +276,7 @@ __global__ __launch_bounds__(1024) void det_cap_kernel(double* __restrict__ dets
         const double* srcp = dets + ((size_t)j * R + k) * 5;
         v[0] = srcp[0]; v[1] = srcp[1]; v[2] = srcp[2]; v[3] = srcp[3]; v[4] = srcp[4];
         if (keep_idx) ki = keep_idx[(size_t)j * R + k];
-        flag = desc_key((float)v[4]) <= T;
+        flag = keys[j * R + k] <= T;
       }
       const unsigned long long bal = __ballot(flag);
       if (flag) {
@@ -232,7 +293,7 @@ __global__ __launch_bounds__(1024) void det_cap_kernel(double* __restrict__ dets
 
 size_t class_lds_bytes(int R) {
   const size_t Wd = (size_t)(R + 63) / 64;
-  return (size_t)R * 4 * 8 + (size_t)R * 8 + (size_t)R * Wd * 8 + (size_t)R * 4 * 3 + 64;
+  return (size_t)R * 4 * 8 + (size_t)R * 8 + (size_t)R * Wd * 8 + (size_t)R * 4 * 3 + 128;
 }
 
 }  // namespace
@@ -263,7 +324,10 @@ extern "C" int lsfa_det_postprocess(const float* rois, const float* deltas, cons
   LSFA_REQUIRE(rois && deltas && probs && dets && counts, "lsfa_det_postprocess: NULL argument");
   LSFA_REQUIRE(R > 0 && ncls > 1 && nreg > 0, "lsfa_det_postprocess: bad shape R=%d ncls=%d nreg=%d", R, ncls, nreg);
   LSFA_REQUIRE(class_agnostic ? nreg >= 2 : nreg >= ncls, "lsfa_det_postprocess: nreg=%d too small", nreg);
-  if (R > kMaxR) { set_error("lsfa_det_postprocess: R=%d exceeds %d", R, kMaxR); return LSFA_ENOTSUP; }
+  if (R > kMaxR || (long)R * ncls > kCapMaxKeys) {
+    set_error("lsfa_det_postprocess: R=%d (max %d) or R*ncls=%ld (max %d) unsupported", R, kMaxR, (long)R * ncls, kCapMaxKeys);
+    return LSFA_ENOTSUP;
+  }
   hipStream_t s = (hipStream_t)stream;
   const size_t lds = class_lds_bytes(R);
   static bool attr_set = false;
@@ -272,7 +336,7 @@ extern "C" int lsfa_det_postprocess(const float* rois, const float* deltas, cons
     attr_set = true;
   }
   ProfScope prof(LSFA_OP_DET, s);
-  hipLaunchKernelGGL(det_class_kernel, dim3(ncls), dim3(kThreads), lds, s, rois, deltas, probs, R, ncls, nreg,
+  hipLaunchKernelGGL(det_class_kernel, dim3(ncls), dim3(kClassThreads), lds, s, rois, deltas, probs, R, ncls, nreg,
                      class_agnostic, im_h, im_w, scale, score_thresh, nms_thresh, dets, counts, keep_idx);
   if (max_per_image > 0)
     hipLaunchKernelGGL(det_cap_kernel, dim3(1), dim3(1024), 0, s, dets, counts, keep_idx, R, ncls, max_per_image);

@@ -74,9 +74,11 @@ __global__ __launch_bounds__(kThreads) void psroi_kernel(const float* __restrict
   }
 }
 
-// Fused head: one workgroup per ROI.  Bins of both maps -> LDS, 49-bin averages in
-// (ph,pw) order -> LDS, then the class softmax (sequential sum = oracle order).
-__global__ __launch_bounds__(kThreads) void rfcn_head_kernel(
+// Fused head: one 16-wave workgroup per ROI (the ~2 bins per thread keep ~20k scattered loads in
+// flight per CU; the bins are latency- not bandwidth-bound).  Bins of both maps -> LDS, 49-bin
+// averages in (ph,pw) order -> LDS, then the class softmax (sequential sum = oracle order).
+constexpr int kHeadThreads = 1024;
+__global__ __launch_bounds__(kHeadThreads) void rfcn_head_kernel(
     const float* __restrict__ cls_map, const float* __restrict__ box_map, const float* __restrict__ rois,
     int H, int W, int ncls, int nbox, float scale, int P, int group, float* __restrict__ cls_prob,
     float* __restrict__ cls_score, float* __restrict__ bbox_pred) {
@@ -88,14 +90,14 @@ __global__ __launch_bounds__(kThreads) void rfcn_head_kernel(
   float* avg = smem + ndim * PP;    // ndim
   const RoiGeom g = roi_geom(rois + (size_t)r * 5, scale, P);
   const int Ccls = ncls * group * group, Cbox = nbox * group * group;
-  for (int i = threadIdx.x; i < ndim * PP; i += kThreads) {
+  for (int i = threadIdx.x; i < ndim * PP; i += kHeadThreads) {
     const int d = i / PP, k = i - d * PP;
     const int ph = k / P, pw = k - ph * P;
     bins[i] = d < ncls ? pool_bin(cls_map, g, Ccls, H, W, d, ph, pw, P, group, nullptr)
                        : pool_bin(box_map, g, Cbox, H, W, d - ncls, ph, pw, P, group, nullptr);
   }
   __syncthreads();
-  for (int d = threadIdx.x; d < ndim; d += kThreads) {
+  for (int d = threadIdx.x; d < ndim; d += kHeadThreads) {
     float s = 0.f;
     for (int k = 0; k < PP; ++k) s += bins[d * PP + k];
     const float a = s / (float)PP;
@@ -159,7 +161,7 @@ extern "C" int lsfa_rfcn_head_fwd(const float* cls_map, const float* box_map, co
   }
   hipStream_t s = (hipStream_t)stream;
   ProfScope prof(LSFA_OP_RFCN_HEAD, s);
-  hipLaunchKernelGGL(rfcn_head_kernel, dim3(R), dim3(kThreads), lds, s, cls_map, box_map, rois, H, W, ncls,
+  hipLaunchKernelGGL(rfcn_head_kernel, dim3(R), dim3(kHeadThreads), lds, s, cls_map, box_map, rois, H, W, ncls,
                      nbox, spatial_scale, pooled_size, group_size, cls_prob, cls_score, bbox_pred);
   LSFA_LAUNCH_CHECK("lsfa_rfcn_head_fwd");
   return LSFA_OK;

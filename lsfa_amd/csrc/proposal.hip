@@ -12,6 +12,7 @@
 // (candidates visited) x (survivors so far) IoUs instead of the full 6000^2/2 mask.
 // Arithmetic = oracle orc_proposal_decode, operation for operation.
 #include <math.h>
+#include <string.h>
 
 #include "nms_kernels.h"
 
@@ -153,7 +154,7 @@ __device__ __forceinline__ void bitonic_sort_regs(uint64_t (&v)[kPerThread], uin
   const int nthr = Kpad / kPerThread;          // threads that hold data (Kpad >= 8)
   const bool active = tid < nthr;
   for (int k = 2; k <= Kpad; k <<= 1) {
-    for (int j = k >> 1; j > 0; j >>= 1) {
+    for (int j = k >> 1; j >= kPerThread; j >>= 1) {
       if (j >= kPerThread * 64) {
         // cross-wave: through LDS
         __syncthreads();
@@ -167,30 +168,31 @@ __device__ __forceinline__ void bitonic_sort_regs(uint64_t (&v)[kPerThread], uin
           for (int r = 0; r < kPerThread; ++r) {
             const int e = tid * kPerThread + r;
             const uint64_t p = buf[e ^ j];
-            const bool up = (e & k) == 0;
-            const bool lower = (e & j) == 0;
-            const uint64_t mn = v[r] < p ? v[r] : p, mx = v[r] < p ? p : v[r];
-            v[r] = (lower == up) ? mn : mx;
+            const bool keep_min = ((e & k) == 0) == ((e & j) == 0);
+            v[r] = ((v[r] > p) == keep_min) ? p : v[r];
           }
         }
-      } else if (j >= kPerThread) {
+      } else {
         const int lane_mask = j / kPerThread;   // < 64
 #pragma unroll
         for (int r = 0; r < kPerThread; ++r) {
           const int e = tid * kPerThread + r;
           const uint64_t p = __shfl_xor(v[r], lane_mask, 64);
-          const bool up = (e & k) == 0;
-          const bool lower = (e & j) == 0;
-          const uint64_t mn = v[r] < p ? v[r] : p, mx = v[r] < p ? p : v[r];
-          v[r] = (lower == up) ? mn : mx;
+          const bool keep_min = ((e & k) == 0) == ((e & j) == 0);
+          v[r] = ((v[r] > p) == keep_min) ? p : v[r];
         }
-      } else {
-        // in registers: pairs (r, r^j) with r & j == 0; direction from the element index
+      }
+    }
+    // strides below kPerThread: in registers.  The stride must be a compile-time constant here
+    // (a runtime register index would push v[] into scratch memory), hence the unrolled ladder.
+#pragma unroll
+    for (int jj = kPerThread / 2; jj > 0; jj >>= 1) {
+      if (jj < k) {
 #pragma unroll
         for (int r = 0; r < kPerThread; ++r) {
-          if ((r & j) == 0) {
+          if ((r & jj) == 0) {
             const int e = tid * kPerThread + r;
-            cswap(v[r], v[r | j], (e & k) == 0);
+            cswap(v[r], v[r | jj], (e & k) == 0);
           }
         }
       }
@@ -204,17 +206,44 @@ __device__ __forceinline__ void bitonic_sort_regs(uint64_t (&v)[kPerThread], uin
 //   [Kpad*8+256, ...)      lkeys (N*4, KEYS_LDS) — overlaid after the sort by the NMS state:
 //                          kept_box float4[1024] | kept_idx int[1024] | cand float4[64] | colsupp u64[64]
 constexpr int kHistReplicas = 16;
-constexpr size_t kNmsStateBytes = 1024 * 16 + 1024 * 4 + 64 * 16 + 64 * 8;
+constexpr size_t kNmsStateBytes = 1024 * 16 + 1024 * 4 + 64 * 16 + 64 * 8 + 1024 * 4;
 
-template <bool KEYS_LDS, int kPerThread>
+// devIoU(a, b) > thresh (multi_proposal.cu:252-260, :295) without the division, bit for bit:
+// q = fl32(inter / uni) exceeds thresh  <=>  inter / uni lies above the midpoint `mid` between
+// thresh and the next float (or on it, when round-to-nearest-even rounds the tie upwards).
+// inter and uni are floats and mid has 25 significant bits, so mid * uni is exact in fp64 (full
+// rate on CDNA4) and the comparison is exact.  Degenerate unions (<= 0, NaN) take the division.
+struct IouTest { float thresh; double mid; int tie_up; int fast; };
+
+__device__ __forceinline__ bool iou_exceeds(const float4& a, float Sa, const float4& b, float Sb, const IouTest& t) {
+  const float left = fmaxf(a.x, b.x), right = fminf(a.z, b.z);
+  const float top = fmaxf(a.y, b.y), bottom = fminf(a.w, b.w);
+  const float width = fmaxf(right - left + 1, 0.f), height = fmaxf(bottom - top + 1, 0.f);
+  const float interS = width * height;
+  const float uni = Sa + Sb - interS;
+  const double lhs = (double)interS, rhs = t.mid * (double)uni;
+  bool r = lhs > rhs || (t.tie_up && lhs == rhs);
+  // wave-uniform branch (so the division really is skipped, not if-converted): taken only when
+  // some lane has a degenerate union or the threshold is outside the range the fast form covers
+  const bool slow = !t.fast || !(uni > 0.f);
+  if (__builtin_expect(__any(slow), 0)) {
+    if (slow) r = interS / uni > t.thresh;
+  }
+  return r;
+}
+
+template <bool KEYS_LDS, int kPerThread, bool RADIX>
 __global__ __launch_bounds__(kTopkThreads) void proposal_select_nms_kernel(
     const uint32_t* __restrict__ keys_all, const float4* __restrict__ boxes_all, int N, int K, int Kpad,
-    float thresh, int post_n, float* __restrict__ rois, float* __restrict__ scores) {
+    int sort_bytes, IouTest iou, int post_n, float* __restrict__ rois, float* __restrict__ scores,
+    unsigned long long* __restrict__ stamps /* diagnostic: phase timestamps of workgroup 0, or NULL */) {
+#define LSFA_STAMP(i) do { if (stamps && threadIdx.x == 0 && blockIdx.x == 0) stamps[i] = __builtin_readcyclecounter(); } while (0)
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  LSFA_STAMP(0);
   uint64_t* sortbuf = reinterpret_cast<uint64_t*>(smem);
   uint32_t* hist = reinterpret_cast<uint32_t*>(smem);
-  int* misc = reinterpret_cast<int*>(smem + (size_t)Kpad * 8);
-  unsigned char* region = smem + (size_t)Kpad * 8 + 256;
+  int* misc = reinterpret_cast<int*>(smem + (size_t)sort_bytes);
+  unsigned char* region = smem + (size_t)sort_bytes + 256;
   uint32_t* lkeys = reinterpret_cast<uint32_t*>(region);
   const int img = blockIdx.x;
   const uint32_t* gkeys = keys_all + (size_t)img * N;
@@ -226,6 +255,8 @@ __global__ __launch_bounds__(kTopkThreads) void proposal_select_nms_kernel(
   }
   const uint32_t* keys = KEYS_LDS ? lkeys : gkeys;
 
+  __syncthreads();
+  LSFA_STAMP(1);
   // ---- radix select: T = K-th smallest key; r_eq = how many keys == T to take ------------
   // replica = lane & 15 spreads same-bucket increments of one wave instruction over 16 words
   uint32_t prefix = 0;
@@ -277,40 +308,109 @@ __global__ __launch_bounds__(kTopkThreads) void proposal_select_nms_kernel(
   const int r_eq = remaining;
   const int n_less = K - r_eq;
 
-  // ---- compaction: keys < T in any order; keys == T in index order, first r_eq -----------
-  if (tid == 0) misc[2] = 0;
-  for (int i = K + tid; i < Kpad; i += kTopkThreads) sortbuf[i] = ~0ULL;
+  LSFA_STAMP(2);
+  // ---- stable compaction (index order): keys < T, and the first r_eq keys == T -------------
   const int chunk = (N + kTopkThreads - 1) / kTopkThreads;
   const int i0 = min(tid * chunk, N), i1 = min(i0 + chunk, N);
-  int my_eq = 0;
-  for (int i = i0; i < i1; ++i) my_eq += (keys[i] == T);
-  int total_eq;
-  int eq_rank = block_exclusive_scan(my_eq, misc + 8, &total_eq);  // barriers inside order misc[2] = 0
-  for (int i = i0; i < i1; ++i) {
-    const uint32_t k = keys[i];
-    if (k < T) {
-      const int slot = atomicAdd(&misc[2], 1);
-      sortbuf[slot] = ((uint64_t)k << 32) | (uint32_t)i;
-    } else if (k == T) {
-      if (eq_rank < r_eq) sortbuf[n_less + eq_rank] = ((uint64_t)k << 32) | (uint32_t)i;
-      ++eq_rank;
+  int my_eq = 0, my_less = 0;
+  for (int i = i0; i < i1; ++i) { const uint32_t k = keys[i]; my_eq += (k == T); my_less += (k < T); }
+  int total_eq, total_sel;
+  const int eq_rank0 = block_exclusive_scan(my_eq, misc + 8, &total_eq);
+  const int my_sel = my_less + min(max(r_eq - eq_rank0, 0), my_eq);
+  int pos = block_exclusive_scan(my_sel, misc + 8, &total_sel);
+  {
+    int er = eq_rank0;
+    for (int i = i0; i < i1; ++i) {
+      const uint32_t k = keys[i];
+      bool sel = k < T;
+      if (k == T) { sel = er < r_eq; ++er; }
+      if (sel) sortbuf[pos++] = ((uint64_t)k << 32) | (uint32_t)i;
     }
   }
+  (void)n_less;
   __syncthreads();
 
-  // ---- sort (ascending composite key == score desc, anchor index asc) ---------------------
-  uint64_t v[kPerThread];
-  const bool holds = tid < Kpad / kPerThread;
+  LSFA_STAMP(3);
+  // ---- sort by key (ascending == score desc); equal keys keep index order -------------------
+  if (RADIX) {
+    // LSD radix sort, 4-bit digits, stable: thread t owns the contiguous run [c0, c1) of the K
+    // candidates; per pass: digit counts packed in one u64 -> cnt16[d][t] -> one flat exclusive
+    // scan (digit-major) -> scatter.  Passes whose digit is identical for all keys are skipped.
+    uint64_t* bufA = sortbuf;
+    uint64_t* bufB = reinterpret_cast<uint64_t*>(region);
+    uint16_t* cnt16 = reinterpret_cast<uint16_t*>(region + (((size_t)K * 8 + 15) & ~(size_t)15));
+    const int ck = (K + kTopkThreads - 1) / kTopkThreads;   // <= 8
+    const int c0 = min(tid * ck, K), c1 = min(c0 + ck, K);
+    uint32_t vo = 0, va = ~0u;
+    for (int i = c0; i < c1; ++i) { const uint32_t hw = (uint32_t)(bufA[i] >> 32); vo |= hw; va &= hw; }
 #pragma unroll
-  for (int r = 0; r < kPerThread; ++r) v[r] = holds ? sortbuf[tid * kPerThread + r] : ~0ULL;
-  bitonic_sort_regs<kPerThread>(v, sortbuf, Kpad);
-  __syncthreads();
-  if (holds) {
+    for (int d = 32; d > 0; d >>= 1) { vo |= __shfl_xor(vo, d, 64); va &= __shfl_xor(va, d, 64); }
+    if (lane == 0) { misc[32 + wid] = (int)vo; misc[48 + wid] = (int)va; }
+    __syncthreads();
+    vo = 0; va = ~0u;
+    for (int w = 0; w < kTopkThreads / 64; ++w) { vo |= (uint32_t)misc[32 + w]; va &= (uint32_t)misc[48 + w]; }
+    const uint32_t differ = vo ^ va;
+    uint64_t* src = bufA;
+    uint64_t* dst = bufB;
+    for (int pass = 0; pass < 8; ++pass) {
+      if (((differ >> (4 * pass)) & 15u) == 0) continue;
+      const int shift = 32 + 4 * pass;
+      uint64_t h = 0;
+      for (int i = c0; i < c1; ++i) h += 1ULL << (4 * (int)((src[i] >> shift) & 15u));
 #pragma unroll
-    for (int r = 0; r < kPerThread; ++r) sortbuf[tid * kPerThread + r] = v[r];
+      for (int d = 0; d < 16; ++d) cnt16[d * kTopkThreads + tid] = (uint16_t)((h >> (4 * d)) & 15u);
+      __syncthreads();
+      {
+        uint4* p4 = reinterpret_cast<uint4*>(cnt16 + 16 * tid);
+        uint4 q0 = p4[0], q1 = p4[1];
+        uint32_t w[8] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w};
+        int run = 0;
+        uint32_t ex[16];
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          const uint32_t c = (w[e >> 1] >> (16 * (e & 1))) & 0xffffu;
+          ex[e] = (uint32_t)run;
+          run += (int)c;
+        }
+        int tot;
+        const int base = block_exclusive_scan(run, misc + 8, &tot);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) w[e] = ((ex[2 * e] + base) & 0xffffu) | ((ex[2 * e + 1] + base) << 16);
+        p4[0] = make_uint4(w[0], w[1], w[2], w[3]);
+        p4[1] = make_uint4(w[4], w[5], w[6], w[7]);
+      }
+      __syncthreads();
+      for (int i = c0; i < c1; ++i) {
+        const uint64_t e = src[i];
+        uint16_t* slot = cnt16 + (int)((e >> shift) & 15u) * kTopkThreads + tid;
+        const int o = *slot;
+        *slot = (uint16_t)(o + 1);
+        dst[o] = e;
+      }
+      __syncthreads();
+      uint64_t* tsw = src; src = dst; dst = tsw;
+    }
+    if (src != bufA) {
+      for (int i = c0; i < c1; ++i) bufA[i] = src[i];
+    }
+    __syncthreads();
+  } else {
+    for (int i = K + tid; i < Kpad; i += kTopkThreads) sortbuf[i] = ~0ULL;
+    __syncthreads();
+    uint64_t v[kPerThread];
+    const bool holds = tid < Kpad / kPerThread;
+#pragma unroll
+    for (int r = 0; r < kPerThread; ++r) v[r] = holds ? sortbuf[tid * kPerThread + r] : ~0ULL;
+    bitonic_sort_regs<kPerThread>(v, sortbuf, Kpad);
+    __syncthreads();
+    if (holds) {
+#pragma unroll
+      for (int r = 0; r < kPerThread; ++r) sortbuf[tid * kPerThread + r] = v[r];
+    }
+    __syncthreads();
   }
-  __syncthreads();
 
+  LSFA_STAMP(4);
   // ---- greedy NMS over the sorted candidates, IoU on the fly against the survivors --------
   // (same decisions as nms_kernel + the host sweep, multi_proposal.cu:262-357).  Per block of 64
   // candidates: wave q tests candidate `lane` against survivors q, q+16, ...; then the 64x64
@@ -319,6 +419,7 @@ __global__ __launch_bounds__(kTopkThreads) void proposal_select_nms_kernel(
   int* kept_idx = reinterpret_cast<int*>(region + 1024 * 16);
   float4* cand_lds = reinterpret_cast<float4*>(region + 1024 * 16 + 1024 * 4);
   uint64_t* colsupp = reinterpret_cast<uint64_t*>(region + 1024 * 16 + 1024 * 4 + 64 * 16);
+  float* kept_area = reinterpret_cast<float*>(region + 1024 * 16 + 1024 * 4 + 64 * 16 + 64 * 8);
   unsigned int* supp = reinterpret_cast<unsigned int*>(misc + 4);  // 2 words
   if (tid == 0) { misc[3] = 0; supp[0] = 0; supp[1] = 0; }
   const int nblocks = (K + 63) / 64;
@@ -326,7 +427,11 @@ __global__ __launch_bounds__(kTopkThreads) void proposal_select_nms_kernel(
   if (wid == 0 && lane < K) next_cand = boxes[(uint32_t)sortbuf[lane]];
   __syncthreads();
   int num = 0;
+  int dbg_blocks = 0;
+  unsigned long long dbg_a = 0, dbg_b = 0, dbg_c = 0, dbg_t = 0;
   for (int b = 0; b < nblocks && num < post_n; ++b) {
+    ++dbg_blocks;
+    if (stamps) dbg_t = __builtin_readcyclecounter();
     const int base = b * 64;
     const int nb = min(64, K - base);
     if (wid == 0) {
@@ -336,55 +441,63 @@ __global__ __launch_bounds__(kTopkThreads) void proposal_select_nms_kernel(
     }
     __syncthreads();
     const float4 cb = cand_lds[lane];
-    const float cbox[4] = {cb.x, cb.y, cb.z, cb.w};
+    const float carea = (cb.z - cb.x + 1) * (cb.w - cb.y + 1);
     bool s = false;
-    for (int k = wid; k < num; k += kTopkThreads / 64) {
-      const float4 kb = kept_box[k];
-      const float kbox[4] = {kb.x, kb.y, kb.z, kb.w};
-      s = s || (dev_iou(kbox, cbox) > thresh);
-    }
+    for (int k = wid; k < num; k += kTopkThreads / 64)
+      s |= iou_exceeds(kept_box[k], kept_area[k], cb, carea, iou);
     const unsigned long long bal = __ballot(s && lane < nb);
     if (lane == 0 && bal) {
       atomicOr(&supp[0], (unsigned int)bal);
       atomicOr(&supp[1], (unsigned int)(bal >> 32));
     }
+    if (stamps) { const unsigned long long t1 = __builtin_readcyclecounter(); dbg_a += t1 - dbg_t; dbg_t = t1; }
 #pragma unroll
     for (int jj = 0; jj < 4; ++jj) {
       const int j = wid * 4 + jj;
       const float4 jb = cand_lds[j];
-      const float jbox[4] = {jb.x, jb.y, jb.z, jb.w};
-      const bool pred = (lane < j) && (j < nb) && (dev_iou(cbox, jbox) > thresh);
+      const float jarea = (jb.z - jb.x + 1) * (jb.w - jb.y + 1);
+      const bool pred = (lane < j) && (j < nb) && iou_exceeds(cb, carea, jb, jarea, iou);
       const unsigned long long col = __ballot(pred);
       if (lane == 0) colsupp[j] = col;
     }
     __syncthreads();
+    if (stamps) { const unsigned long long t1 = __builtin_readcyclecounter(); dbg_b += t1 - dbg_t; dbg_t = t1; }
     if (wid == 0) {
+      // In-block greedy as a fixpoint: G(k) = alive(k) && no earlier j in G suppresses k.  Starting
+      // from G = alive, iteration t fixes the first t decisions, so it converges to the serial
+      // sweep's answer in (dependency-chain depth) rounds — a handful — instead of 64 scalar steps.
       const uint64_t col = colsupp[lane];
-      const uint32_t col_lo = (uint32_t)col, col_hi = (uint32_t)(col >> 32);
-      const uint32_t s_lo = __builtin_amdgcn_readfirstlane(supp[0]), s_hi = __builtin_amdgcn_readfirstlane(supp[1]);
-      uint32_t kept_lo = 0, kept_hi = 0;
-      int budget = post_n - num;
-      for (int k = 0; k < nb && budget > 0; ++k) {
-        const uint32_t c_lo = __builtin_amdgcn_readlane(col_lo, k), c_hi = __builtin_amdgcn_readlane(col_hi, k);
-        const bool sup_prev = k < 32 ? ((s_lo >> k) & 1u) : ((s_hi >> (k - 32)) & 1u);
-        const bool removed = sup_prev || ((c_lo & kept_lo) | (c_hi & kept_hi)) != 0;
-        if (!removed) {
-          if (k < 32) kept_lo |= 1u << k; else kept_hi |= 1u << (k - 32);
-          --budget;
-        }
+      const uint64_t sprev = ((uint64_t)supp[1] << 32) | supp[0];
+      const bool alive = lane < nb && !((sprev >> lane) & 1ULL);
+      uint64_t G = __ballot(alive);
+      for (int it = 0; it < 64; ++it) {
+        const uint64_t G2 = __ballot(alive && (col & G) == 0);
+        if (G2 == G) break;
+        G = G2;
       }
-      const uint64_t kept = ((uint64_t)kept_hi << 32) | kept_lo;
+      // keep only as many as the output still needs (later survivors never affect earlier ones)
+      const int budget = post_n - num;
+      uint64_t kept = G;
+      if (__popcll(G) > budget) {
+        const bool mine = (G >> lane) & 1ULL;
+        const int rank = __popcll(G & ((1ULL << lane) - 1ULL));
+        kept = __ballot(mine && rank < budget);
+      }
       if ((kept >> lane) & 1ULL) {
         const int pos = num + __popcll(kept & ((1ULL << lane) - 1ULL));
         kept_box[pos] = cb;
+        kept_area[pos] = carea;
         kept_idx[pos] = base + lane;
       }
       if (lane == 0) { misc[3] = num + __popcll(kept); supp[0] = 0; supp[1] = 0; }
     }
     __syncthreads();
+    if (stamps) { const unsigned long long t1 = __builtin_readcyclecounter(); dbg_c += t1 - dbg_t; dbg_t = t1; }
     num = misc[3];
   }
 
+  LSFA_STAMP(5);
+  if (stamps && tid == 0 && blockIdx.x == 0) { stamps[7] = (unsigned long long)num; stamps[8] = (unsigned long long)dbg_blocks; stamps[9] = dbg_a; stamps[10] = dbg_b; stamps[11] = dbg_c; }
   // ---- PrepareOutput (multi_proposal.cu:363-388): first post_n survivors, cyclic pad ------
   for (int index = tid; index < post_n; index += kTopkThreads) {
     const int kpos = index < num ? index : index % num;
@@ -394,6 +507,8 @@ __global__ __launch_bounds__(kTopkThreads) void proposal_select_nms_kernel(
     o[1] = bx.x; o[2] = bx.y; o[3] = bx.z; o[4] = bx.w;
     if (scores) scores[(size_t)img * post_n + index] = key_score((uint32_t)(sortbuf[kept_idx[kpos]] >> 32));
   }
+  LSFA_STAMP(6);
+#undef LSFA_STAMP
 }
 
 struct WsLayout {
@@ -414,6 +529,11 @@ int clamp_pre_n(int rpn_pre_nms_top_n, int count) {
 }
 
 }  // namespace
+
+static unsigned long long* g_stamps = nullptr;
+// Diagnostic only (not in lsfa_hip.h): device buffer of >= 8 u64 that receives the cycle counter at
+// the phase boundaries of proposal_select_nms_kernel (load, select, compact, sort, nms, output).
+extern "C" void lsfa_debug_set_proposal_stamps(void* dev_ptr) { g_stamps = (unsigned long long*)dev_ptr; }
 
 extern "C" size_t lsfa_proposal_workspace_bytes(int B, int A, int H, int W, int pre_nms_top_n) {
   if (B <= 0 || A <= 0 || H <= 0 || W <= 0) return 0;
@@ -457,28 +577,42 @@ extern "C" int lsfa_proposal(const float* cls_prob, const float* bbox_pred, cons
 
   int Kpad = 16;
   while (Kpad < pre_n) Kpad <<= 1;
-  const size_t lds_base = (size_t)Kpad * 8 + 256;
-  size_t lds_keys = lds_base + ((size_t)count * 4 > kNmsStateBytes ? (size_t)count * 4 : kNmsStateBytes);
-  lds_keys = align_up(lds_keys, 16);
-  const size_t lds_nokeys = lds_base + kNmsStateBytes;
+  IouTest iou;
+  iou.thresh = threshold;
+  {
+    const float nxt = nextafterf(threshold, INFINITY);
+    iou.mid = ((double)threshold + (double)nxt) * 0.5;
+    uint32_t nb;
+    memcpy(&nb, &nxt, sizeof(nb));
+    iou.tie_up = (nb & 1u) == 0;
+    iou.fast = (threshold > 1e-30f && threshold < 1e30f) ? 1 : 0;
+  }
   const size_t kLdsMax = 160 * 1024;
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute((const void*)proposal_select_nms_kernel<true, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsMax);
-    (void)hipFuncSetAttribute((const void*)proposal_select_nms_kernel<false, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsMax);
-    (void)hipFuncSetAttribute((const void*)proposal_select_nms_kernel<false, 16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsMax);
+    (void)hipFuncSetAttribute((const void*)proposal_select_nms_kernel<true, 8, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsMax);
+    (void)hipFuncSetAttribute((const void*)proposal_select_nms_kernel<false, 8, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsMax);
+    (void)hipFuncSetAttribute((const void*)proposal_select_nms_kernel<false, 8, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsMax);
+    (void)hipFuncSetAttribute((const void*)proposal_select_nms_kernel<false, 16, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsMax);
     attr_set = true;
   }
-  if (Kpad > 8192) {   // 8193..16384 candidates: 16 keys per thread, keys stay in global memory (L2)
-    hipLaunchKernelGGL((proposal_select_nms_kernel<false, 16>), dim3(B), dim3(kTopkThreads), lds_nokeys, s, (const uint32_t*)keys,
-                       (const float4*)boxes, count, pre_n, Kpad, threshold, post_n, rois, scores);
-  } else if (lds_keys <= kLdsMax) {
-    hipLaunchKernelGGL((proposal_select_nms_kernel<true, 8>), dim3(B), dim3(kTopkThreads), lds_keys, s, (const uint32_t*)keys,
-                       (const float4*)boxes, count, pre_n, Kpad, threshold, post_n, rois, scores);
-  } else {
-    hipLaunchKernelGGL((proposal_select_nms_kernel<false, 8>), dim3(B), dim3(kTopkThreads), lds_nokeys, s, (const uint32_t*)keys,
-                       (const float4*)boxes, count, pre_n, Kpad, threshold, post_n, rois, scores);
-  }
+  // radix path: sort buffer A = K*8 (>= the 16 KB of select histograms), region = buffer B + counters
+  const size_t hist_bytes = (size_t)kHistReplicas * 256 * 4;
+  const size_t sortA = align_up((size_t)pre_n * 8 > hist_bytes ? (size_t)pre_n * 8 : hist_bytes, 16);
+  const size_t radix_region = align_up((size_t)pre_n * 8, 16) + 16 * kTopkThreads * 2;
+  const size_t region_min = radix_region > kNmsStateBytes ? radix_region : kNmsStateBytes;
+  const size_t lds_radix_keys = sortA + 256 + align_up(((size_t)count * 4 > region_min ? (size_t)count * 4 : region_min), 16);
+  const size_t lds_radix = sortA + 256 + align_up(region_min, 16);
+  const size_t lds_bitonic = (size_t)Kpad * 8 + 256 + kNmsStateBytes;
+#define LSFA_LAUNCH_SELECT(KL, PER, RAD, LDS, SORTB)                                                         \
+  hipLaunchKernelGGL((proposal_select_nms_kernel<KL, PER, RAD>), dim3(B), dim3(kTopkThreads), (LDS), s,       \
+                     (const uint32_t*)keys, (const float4*)boxes, count, pre_n, Kpad, (int)(SORTB), iou, post_n, \
+                     rois, scores, g_stamps)
+  if (pre_n <= 8192 && lds_radix_keys <= kLdsMax) LSFA_LAUNCH_SELECT(true, 8, true, lds_radix_keys, sortA);
+  else if (pre_n <= 8192 && lds_radix <= kLdsMax) LSFA_LAUNCH_SELECT(false, 8, true, lds_radix, sortA);
+  else if (Kpad <= 8192) LSFA_LAUNCH_SELECT(false, 8, false, lds_bitonic, (size_t)Kpad * 8);
+  else LSFA_LAUNCH_SELECT(false, 16, false, lds_bitonic, (size_t)Kpad * 8);
+#undef LSFA_LAUNCH_SELECT
   LSFA_LAUNCH_CHECK("lsfa_proposal");
   return LSFA_OK;
 }

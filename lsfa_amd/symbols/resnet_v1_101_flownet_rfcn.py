@@ -201,6 +201,7 @@ class Executor(object):
         self.device = torch.device(device)
         self.cdtype = dtype           # dtype of the dense contractions (fp32, or bf16 for config 3)
         self.taps = None              # set to {} to record stage outputs (parity tests)
+        self._const = {}
         cfg = self.cfg
         arg = {k: np.asarray(v, dtype=np.float32) for k, v in arg_params.items()}
         aux = {k: np.asarray(v, dtype=np.float32) for k, v in aux_params.items()}
@@ -250,20 +251,47 @@ class Executor(object):
     def _c(self, x):
         return x if x.dtype == self.cdtype else x.to(self.cdtype)
 
-    def _conv1x1(self, x, w2d, bias=None, residual=None):
-        """1x1 stride-1 convolution as a GEMM on the NCHW map; bias or residual in the epilogue."""
+    def _conv1x1(self, x, w2d, bias=None, residual=None, relu=False):
+        """1x1 stride-1 convolution as a GEMM on the NCHW map.  `residual` is accumulated IN PLACE
+        (GEMM beta = 1 into the shortcut tensor, no copy); a bias is applied together with the ReLU by
+        the fused scale-shift-ReLU pass instead of a broadcast-copy + GEMM + ReLU triple."""
         n, c, h, w = x.shape
         if n != 1:
             y = F.conv2d(x, w2d.view(w2d.shape[0], c, 1, 1), bias)
-            return y if residual is None else y.add_(residual)
+            y = y if residual is None else y.add_(residual)
+            return torch.relu_(y) if relu else y
         X = x.view(c, h * w)
         if residual is not None:
-            out = torch.addmm(residual.view(-1, h * w), w2d, X)
-        elif bias is not None:
-            out = torch.addmm(bias.view(-1, 1), w2d, X)
+            out = residual.view(-1, h * w).addmm_(w2d, X)
         else:
             out = torch.mm(w2d, X)
-        return out.view(1, -1, h, w)
+        out = out.view(1, -1, h, w)
+        if bias is not None or relu:
+            out = self._bias_act(out, bias, relu)
+        return out
+
+    def _bias_act(self, y, bias, relu):
+        """y = max(y + bias[c], 0) in one in-place pass (fp32 maps; other dtypes use torch)."""
+        if y.dtype == torch.float32:
+            c = y.shape[1]
+            if bias is None:
+                bias = self._zeros(c)
+            return hip.scale_shift_relu(y, self._ones(c), bias, relu=relu, out=y)
+        if bias is not None:
+            y = y.add_(bias.view(1, -1, 1, 1))
+        return torch.relu_(y) if relu else y
+
+    def _ones(self, c):
+        t = self._const.get(('1', c))
+        if t is None:
+            t = self._const[('1', c)] = torch.ones(c, device=self.device)
+        return t
+
+    def _zeros(self, c):
+        t = self._const.get(('0', c))
+        if t is None:
+            t = self._const[('0', c)] = torch.zeros(c, device=self.device)
+        return t
 
     def _dcn(self, x, u, dilate):
         """DeformableConvolution (sym_common.py:138-157): offsets by an ordinary conv, bilinear
@@ -271,14 +299,14 @@ class Executor(object):
         off = F.conv2d(x, u['off_w'], u['off_b'], stride=1, padding=dilate, dilation=dilate)
         col = hip.deform_im2col(x.float(), off.float(), 3, 3, dilate, 1, dilate, P.NUM_DEFORMABLE_GROUP)
         n, _, h, w = off.shape
-        out = torch.baddbmm(u['b2'].view(1, -1, 1), u['w2_2d'].unsqueeze(0).expand(n, -1, -1), self._c(col))
+        out = torch.matmul(u['w2_2d'], self._c(col))       # (n, Cout, Ho*Wo); bn3's folded bias joins the ReLU pass
         return out.view(n, -1, h, w)
 
     def _resnet(self, x, net, stages, tail):
         """Pre-activation ResNet (resnet.py:138-240); returns the stage outputs the caller asked for."""
         x = hip.scale_shift_relu(x, net.bn_data[0], net.bn_data[1], relu=False)
-        x = F.conv2d(self._c(x), net.conv0_w, net.conv0_b, stride=2, padding=3)
-        x = F.max_pool2d(torch.relu_(x), 3, 2, 1)
+        x = self._bias_act(F.conv2d(self._c(x), net.conv0_w, None, stride=2, padding=3), net.conv0_b, True)
+        x = F.max_pool2d(x, 3, 2, 1)
         dilate = 1
         for u in net.units:
             if u['stage'] > stages:
@@ -290,16 +318,16 @@ class Executor(object):
             if first and u['stage'] == 4:
                 dilate = dilate * 2
             a = self._c(hip.scale_shift_relu(x.float(), u['bn1'][0], u['bn1'][1], relu=True))
-            c1 = torch.relu_(self._conv1x1(a, u['w1_2d'], bias=u['b1']))
+            c1 = self._conv1x1(a, u['w1_2d'], bias=u['b1'], relu=True)
             if u['dcn']:
                 c2 = self._dcn(c1, u, unit_dilate)
             else:
-                c2 = F.conv2d(c1, u['w2'], u['b2'], stride=stride, padding=unit_dilate, dilation=unit_dilate)
-            c2 = torch.relu_(c2)
+                c2 = F.conv2d(c1, u['w2'], None, stride=stride, padding=unit_dilate, dilation=unit_dilate)
+            c2 = self._bias_act(c2, u['b2'], True)
             if first:
                 sc = F.conv2d(a, u['sc'], None, stride=stride) if stride != 1 else self._conv1x1(a, u['sc'].view(u['sc'].shape[0], -1))
             else:
-                sc = x if x.dtype == self.cdtype else self._c(x)
+                sc = x if x.dtype == self.cdtype else self._c(x)   # overwritten in place by conv3's GEMM (beta = 1)
             x = self._conv1x1(c2, u['w3_2d'], residual=sc)
         if tail:
             x = self._c(hip.scale_shift_relu(x.float(), net.bn1[0], net.bn1[1], relu=True))
@@ -307,7 +335,7 @@ class Executor(object):
 
     def _backbone(self, data):
         x = self._resnet(data, self.net, 4, True)
-        return torch.relu_(F.conv2d(x, self.feat_w, self.feat_b, padding=6, dilation=6)).float()
+        return self._bias_act(F.conv2d(x, self.feat_w, None, padding=6, dilation=6).float(), self.feat_b.float(), True)
 
     def _flownet(self, img_cur, img_ref):
         """FlowNet-S on the half-resolution pair (:150-207)."""

@@ -129,3 +129,30 @@ def test_pred_eval_loop_flags_and_shapes(world):
 def oracle_flags(seg_lens, k):
     from oracle import np_ref
     return np_ref.key_frame_flags(seg_lens, k)
+
+
+def test_hipgraph_replay_equals_eager(world):
+    """The captured per-frame hipGraphs reproduce the eager launch sequence's detections: same
+    survivors per class; coordinates to fp32 conv round-off (MIOpen / hipBLASLt may pick a different
+    algorithm for the same convolution when called under stream capture)."""
+    from lsfa_amd.core.graphs import FrameGraphs
+    cfg, key, cur, clip = world['cfg'], world['key'], world['cur'], world['clip']
+    key.taps = cur.taps = None
+    results = []
+    for use_graphs in (False, True):
+        fg = FrameGraphs(key, cur, cfg, H, W, DEV, use_graphs=use_graphs)
+        fg.first_frame(clip.frame(0, DEV))
+        fg.capture()
+        out = []
+        for f, kf in ((1, 0), (2, 0), (3, 3), (4, 3), (5, 5)):   # cur, cur, key, cur, key
+            if f == kf:
+                d, c, k = fg.key_frame(clip.frame(f, DEV))
+            else:
+                d, c, k = fg.cur_frame(clip.frame(f, DEV), clip.motion_vector(f, kf, DEV), clip.res_diff(f, DEV))
+            out.append((d.cpu().numpy().copy(), c.cpu().numpy().copy()))
+        results.append(out)
+    for (d0, c0), (d1, c1) in zip(*results):
+        np.testing.assert_array_equal(c0, c1)
+        assert c0.sum() > 0
+        for j in range(31):
+            np.testing.assert_allclose(d0[j, :c0[j]], d1[j, :c1[j]], rtol=1e-4, atol=1e-3)

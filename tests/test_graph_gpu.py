@@ -156,3 +156,36 @@ def test_hipgraph_replay_equals_eager(world):
         assert c0.sum() > 0
         for j in range(31):
             np.testing.assert_allclose(d0[j, :c0[j]], d1[j, :c1[j]], rtol=1e-4, atol=1e-3)
+
+
+def test_clip_end_to_end_map_vs_oracle(world):
+    """Whole path on a 7-frame 192x320 clip, interval 3: GPU (test_rcnn -> pred_eval) vs the CPU
+    oracle's frame loop.  The convolutions differ by fp32 round-off, so individual low-score
+    detections may swap; the agreement metric is VID mAP@0.5 of the GPU detections against the
+    oracle's confident detections taken as ground truth: must be within 0.1 of 1."""
+    from oracle import frame_loop
+    from lsfa_amd.config.config import lsfa_test_config
+    from lsfa_amd.dataset import vid_eval as ve
+    from lsfa_amd.function.test_rcnn import test_rcnn
+    from lsfa_amd.utils.synthetic import synthetic_roidb
+    cfg = lsfa_test_config(key_frame_interval=3)
+    arg, aux = world['arg'], world['aux']
+    roidb = synthetic_roidb(1, 7, H, W, 3)
+    rows_gpu, frame_ids = test_rcnn(cfg, roidb, arg, aux, device=DEV)
+    clip = roidb[0]['clip']
+    rows_ref = frame_loop.run_clip(cfg, arg, aux, 7, lambda f: clip.frame(f).numpy(),
+                                   lambda f, k: clip.motion_vector(f, k).numpy(), lambda f: clip.res_diff(f).numpy(),
+                                   clip.im_info())
+    assert list(frame_ids) == list(range(7))
+    assert abs(len(rows_gpu) - len(rows_ref)) <= 0.05 * len(rows_ref)
+    # ground truth := the oracle's 5 most confident detections per frame
+    gt = []
+    for f in range(7):
+        r = rows_ref[rows_ref[:, 0] == f]
+        r = r[np.argsort(-r[:, 2], kind='stable')][:5]
+        gt.append({'img_id': f, 'bbox': r[:, 3:7], 'label': r[:, 1].astype(int)})
+    ap_ref = ve.vid_eval(rows_ref, gt, 31)
+    ap_gpu = ve.vid_eval(rows_gpu, gt, 31)
+    present = np.unique(np.concatenate([g['label'] for g in gt])) - 1
+    assert abs(ap_gpu[present].mean() - ap_ref[present].mean()) < 0.1
+    assert ap_ref[present].mean() > 0.5

@@ -1,0 +1,87 @@
+"""N>1 path on CPU: the reference's greedy video sharding and the final gather of detection rows
+over a world_size-2 gloo group; VID mAP restatement on a hand-built case."""
+import os
+import socket
+
+import numpy as np
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from lsfa_amd.core import parallel
+from lsfa_amd.dataset import vid_eval as ve
+from oracle import np_ref
+
+
+def test_sharding_matches_reference_rule():
+    lens = [144, 30, 90, 12, 60, 60, 7]
+    assert parallel.shard_videos(lens, 2) == np_ref.shard_videos(lens, 2)
+    assert parallel.shard_videos(lens, 8) == np_ref.shard_videos(lens, 8)
+    s = parallel.shard_videos(lens, 3)
+    assert sorted(v for r in s for v in r) == list(range(len(lens)))
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        return s.getsockname()[1]
+
+
+def _worker(rank, world, port, q):
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    lens = [5, 3, 4]
+    mine = parallel.shard_videos(lens, world)[rank]
+    rs = np.random.RandomState(100 + rank)
+    all_boxes = [[[] for _ in range(sum(lens[v] for v in mine))] for _ in range(4)]
+    frame_ids, im = [], 0
+    starts = np.concatenate([[0], np.cumsum(lens)])
+    for v in mine:
+        for f in range(lens[v]):
+            frame_ids.append(int(starts[v] + f))
+            for c in range(1, 4):
+                n = rs.randint(0, 3)
+                all_boxes[c][im] = rs.rand(n, 5) if n else []
+            im += 1
+    rows = parallel.detections_to_rows(all_boxes, frame_ids)
+    merged = parallel.gather_rows(rows)
+    q.put((rank, rows, merged))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_gather_rows_world2_gloo():
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = sorted([q.get(timeout=120) for _ in range(2)], key=lambda t: t[0])
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    want = np.vstack([got[0][1], got[1][1]])
+    for _, _, merged in got:
+        np.testing.assert_array_equal(merged, want)
+    assert set(np.unique(want[:, 0]).astype(int)) <= set(range(12))
+
+
+def test_vid_eval_hand_built_case():
+    gt = [{'img_id': 0, 'bbox': [[10, 10, 109, 109], [200, 200, 219, 219]], 'label': [1, 2]},
+          {'img_id': 1, 'bbox': [[50, 50, 149, 149]], 'label': [1]}]
+    rows = np.array([
+        [0, 1, 0.9, 12, 12, 111, 111],     # TP for class 1 (IoU ~0.92)
+        [0, 1, 0.8, 10, 10, 109, 109],     # duplicate of an already matched gt -> FP
+        [0, 2, 0.7, 201, 201, 220, 220],   # small box: threshold lowered to wh/((w+10)(h+10)) = 0.444 -> TP
+        [1, 1, 0.6, 300, 300, 400, 400],   # FP
+        [1, 1, 0.5, 52, 48, 151, 147],     # TP
+    ], dtype=np.float64)
+    ap = ve.vid_eval(rows, gt, 3)
+    # class 1: order 0.9 TP, 0.8 FP, 0.6 FP, 0.5 TP; npos 2 -> recall .5,.5,.5,1  precision 1,.5,.33,.5
+    assert abs(ap[0] - (0.5 * 1.0 + 0.5 * 0.5)) < 1e-12
+    assert abs(ap[1] - 1.0) < 1e-12
+    assert abs(ve.gt_threshold([200, 200, 219, 219]) - 400.0 / 900.0) < 1e-12
+    assert ve.format_rows(rows[:1]) == ['0 1 0.9000 12.00 12.00 111.00 111.00']
+    assert ve.vid_eval(np.zeros((0, 7)), gt, 3).tolist() == [0.0, 0.0]

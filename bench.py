@@ -32,6 +32,10 @@ sys.path.insert(0, ROOT)
 
 WARP_BYTES = lambda C, HW: (3 * C * HW + 2 * HW) * 4  # feat + (scale map | small-net feature) + out, + flow
 HBM_PEAK_GBS = 8000.0                                   # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+# HBM-side bytes per warp_kernel launch from rocprofv3 PMC passes (profiles/r1/warp_kernel_pmc_and_duration.txt,
+# 1024x38x63): FETCH_SIZE 11,845 KiB x2 (the guide's gfx950 correction: 128-B requests are tallied as 64 B;
+# uncalibrated for this kernel's 4/8-byte accesses) + WRITE_SIZE 9,699 KiB.  Only valid at that shape.
+WARP_TRAFFIC_BYTES_38x63 = int((2 * 11844.9 + 9699.0) * 1024)
 
 
 def parse():
@@ -230,7 +234,8 @@ def main():
                        "launch": "eager" if args.no_graph else "hipGraph replay per frame"},
             "roofline": {"bound": "hbm", "kernel": "warp_kernel (lsfa_warp_bilinear: MV/flow warp + fused epilogue)",
                          "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                         "frac": round(achieved / HBM_PEAK_GBS, 4),
+                         "traffic": WARP_TRAFFIC_BYTES_38x63 if (fh, fw) == (38, 63) else None,
                          "launches": warp_n, "avg_us": round(warp_ms * 1e3 / max(warp_n, 1), 2),
                          "algorithmic_bytes_per_launch": bytes_per_launch,
                          "measured": "HIP events around each launch, same frames re-issued eagerly right after the "

@@ -1,0 +1,54 @@
+#!/usr/bin/env python
+"""Condense rocprofv3 CSV output into small summaries (run on the GPU box; traces are too big to ship).
+
+  kernel-trace dir -> per-kernel calls / total / avg over the LAST `frac` of the run (timed region)
+  pmc dir          -> per-kernel mean counter value for kernels matching a substring
+"""
+import csv, glob, sys, collections, json
+
+
+def trace_summary(d, out, tail_frac=0.5, top=60):
+    f = glob.glob(d + '/*/*_kernel_trace.csv')
+    if not f:
+        return
+    rows = list(csv.DictReader(open(f[0])))
+    rows.sort(key=lambda r: int(r['Start_Timestamp']))
+    caps = [i for i, r in enumerate(rows) if 'det_cap_kernel' in r['Kernel_Name']]
+    if len(caps) > 4:
+        start = caps[int(len(caps) * (1 - tail_frac))]
+        rows = rows[start + 1:]
+        nframes = len([i for i in caps if i > start])
+    else:
+        nframes = 0
+    t0, t1 = int(rows[0]['Start_Timestamp']), max(int(r['End_Timestamp']) for r in rows)
+    agg = collections.defaultdict(lambda: [0, 0])
+    for r in rows:
+        a = agg[r['Kernel_Name']]
+        a[0] += 1
+        a[1] += int(r['End_Timestamp']) - int(r['Start_Timestamp'])
+    busy = sum(v[1] for v in agg.values())
+    with open(out, 'w') as o:
+        o.write('# window: last %.0f%% of the run = %d frames, wall %.3f ms, GPU busy %.3f ms, %d kernel launches\n' %
+                (tail_frac * 100, nframes, (t1 - t0) / 1e6, busy / 1e6, len(rows)))
+        o.write('kernel,calls,total_us,avg_us,pct_of_busy\n')
+        for k, v in sorted(agg.items(), key=lambda kv: -kv[1][1])[:top]:
+            o.write('"%s",%d,%.1f,%.2f,%.2f\n' % (k[:140], v[0], v[1] / 1e3, v[1] / v[0] / 1e3, 100.0 * v[1] / busy))
+
+
+def pmc_summary(d, match):
+    f = glob.glob(d + '/*/*counter_collection.csv')
+    if not f:
+        return None
+    vals = collections.defaultdict(list)
+    for r in csv.DictReader(open(f[0])):
+        if match in r['Kernel_Name']:
+            vals[r['Counter_Name']].append(float(r['Counter_Value']))
+    return {k: dict(n=len(v), mean=sum(v) / len(v), min=min(v), max=max(v)) for k, v in vals.items()}
+
+
+if __name__ == '__main__':
+    mode = sys.argv[1]
+    if mode == 'trace':
+        trace_summary(sys.argv[2], sys.argv[3], float(sys.argv[4]) if len(sys.argv) > 4 else 0.5)
+    else:
+        print(json.dumps(pmc_summary(sys.argv[2], sys.argv[3])))

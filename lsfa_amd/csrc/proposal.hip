@@ -450,15 +450,37 @@ __global__ __launch_bounds__(kTopkThreads) void proposal_select_nms_kernel(
       atomicOr(&supp[0], (unsigned int)bal);
       atomicOr(&supp[1], (unsigned int)(bal >> 32));
     }
+    __syncthreads();
     if (stamps) { const unsigned long long t1 = __builtin_readcyclecounter(); dbg_a += t1 - dbg_t; dbg_t = t1; }
+    // in-block relation, only among the candidates still alive after the survivor test: wave q
+    // takes the q-th, (q+16)-th, ... alive candidate as column j and ballots the rows that suppress it
+    {
+      const uint64_t sprev_u = ((uint64_t)supp[1] << 32) | supp[0];
+      const uint64_t valid = nb == 64 ? ~0ULL : ((1ULL << nb) - 1ULL);
+      uint64_t am = valid & ~sprev_u;                       // wave-uniform
+      const bool row_alive = (am >> lane) & 1ULL;
+      if (__popcll(am) <= kTopkThreads / 64) {
+        // few alive (the common case once survivors accumulate): one column per wave
+        for (int skip = 0; skip < wid && am; ++skip) am &= am - 1;
+        if (am) {
+          const int j = __builtin_ctzll(am);
+          const float4 jb = cand_lds[j];
+          const float jarea = (jb.z - jb.x + 1) * (jb.w - jb.y + 1);
+          const bool pred = row_alive && (lane < j) && iou_exceeds(cb, carea, jb, jarea, iou);
+          const unsigned long long col = __ballot(pred);
+          if (lane == 0) colsupp[j] = col;
+        }
+      } else {
 #pragma unroll
-    for (int jj = 0; jj < 4; ++jj) {
-      const int j = wid * 4 + jj;
-      const float4 jb = cand_lds[j];
-      const float jarea = (jb.z - jb.x + 1) * (jb.w - jb.y + 1);
-      const bool pred = (lane < j) && (j < nb) && iou_exceeds(cb, carea, jb, jarea, iou);
-      const unsigned long long col = __ballot(pred);
-      if (lane == 0) colsupp[j] = col;
+        for (int jj = 0; jj < 4; ++jj) {
+          const int j = wid * 4 + jj;
+          const float4 jb = cand_lds[j];
+          const float jarea = (jb.z - jb.x + 1) * (jb.w - jb.y + 1);
+          const bool pred = row_alive && (lane < j) && (j < nb) && iou_exceeds(cb, carea, jb, jarea, iou);
+          const unsigned long long col = __ballot(pred);
+          if (lane == 0) colsupp[j] = col;
+        }
+      }
     }
     __syncthreads();
     if (stamps) { const unsigned long long t1 = __builtin_readcyclecounter(); dbg_b += t1 - dbg_t; dbg_t = t1; }

@@ -67,6 +67,17 @@ int lsfa_rfcn_head_fwd(const float* cls_map, const float* box_map, const float* 
                        float spatial_scale, int pooled_size, int group_size,
                        float* cls_prob, float* cls_score, float* bbox_pred, void* stream);
 
+/* The same head on a position-sensitive layout: ps_map (N, H, W, group*group, ncls+nbox), i.e. for
+ * every cell and bin the ncls class scores then the nbox box values are contiguous.  That is what
+ * rfcn_cls and rfcn_bbox (resnet_v1_101_flownet_rfcn.py:517-518) produce when both 1x1 convolutions
+ * run as ONE GEMM [H*W,512] x [512, group^2*(ncls+nbox)] with the weight rows permuted
+ * (row (gh*G+gw)*(ncls+nbox)+d  <-  rfcn_cls row (d*G+gh)*G+gw, or rfcn_bbox row ((d-ncls)*G+gh)*G+gw).
+ * Results are bit-identical to lsfa_rfcn_head_fwd on the equivalent NCHW maps. */
+int lsfa_rfcn_head_ps_fwd(const float* ps_map, const float* rois,
+                          int N, int H, int W, int R, int ncls, int nbox,
+                          float spatial_scale, int pooled_size, int group_size,
+                          float* cls_prob, float* cls_score, float* bbox_pred, void* stream);
+
 /* ------------------------------------------------------------------------ *
  * Motion-vector / flow guided bilinear feature warp with fused epilogue.
  * Replaces: mx.sym.GridGenerator(transform_type='warp') + mx.sym.BilinearSampler

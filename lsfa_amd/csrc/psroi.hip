@@ -120,6 +120,70 @@ __global__ __launch_bounds__(kHeadThreads) void rfcn_head_kernel(
   }
 }
 
+
+// Same head on the position-sensitive layout ps_map[n][h][w][gh*G+gw][dim], dim = classes then box
+// coordinates: what the two R-FCN 1x1 convolutions produce when run as ONE GEMM
+// [H*W, 512] x [512, G*G*(ncls+nbox)] with permuted weight rows.  Thread i -> (bin = i / D,
+// dim = i % D): the D = ncls+nbox values of a (cell, bin) are contiguous, so a wave reads whole
+// 156-byte segments instead of 64 scattered words from 64 channel planes.  Sum order inside a bin
+// is unchanged (h outer, w inner), so the result is bit-identical to the NCHW kernel's.
+__global__ __launch_bounds__(kHeadThreads) void rfcn_head_ps_kernel(
+    const float* __restrict__ ps_map, const float* __restrict__ rois, int H, int W, int ncls, int nbox,
+    float scale, int P, int group, float* __restrict__ cls_prob, float* __restrict__ cls_score,
+    float* __restrict__ bbox_pred) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int r = blockIdx.x;
+  const int PP = P * P;
+  const int D = ncls + nbox;
+  float* bins = smem;            // D * PP, index d*PP + k like the NCHW kernel
+  float* avg = smem + D * PP;    // D
+  const RoiGeom g = roi_geom(rois + (size_t)r * 5, scale, P);
+  const size_t cell_stride = (size_t)group * group * D;
+  const float* base = ps_map + (size_t)g.batch * H * W * cell_stride;
+  for (int i = threadIdx.x; i < D * PP; i += kHeadThreads) {
+    const int k = i / D, d = i - k * D;
+    const int ph = k / P, pw = k - ph * P;
+    int hstart = (int)floorf(fmaf((float)ph, g.bin_h, g.start_h));
+    int wstart = (int)floorf(fmaf((float)pw, g.bin_w, g.start_w));
+    int hend = (int)ceilf(fmaf((float)(ph + 1), g.bin_h, g.start_h));
+    int wend = (int)ceilf(fmaf((float)(pw + 1), g.bin_w, g.start_w));
+    hstart = min(max(hstart, 0), H); hend = min(max(hend, 0), H);
+    wstart = min(max(wstart, 0), W); wend = min(max(wend, 0), W);
+    const bool is_empty = (hend <= hstart) || (wend <= wstart);
+    int gw = (int)floorf((float)pw * (float)group / (float)P);
+    int gh = (int)floorf((float)ph * (float)group / (float)P);
+    gw = min(max(gw, 0), group - 1);
+    gh = min(max(gh, 0), group - 1);
+    const float* p = base + (size_t)(gh * group + gw) * D + d;
+    float out_sum = 0.f;
+    for (int h = hstart; h < hend; ++h)
+      for (int w = wstart; w < wend; ++w) out_sum += p[((size_t)h * W + w) * cell_stride];
+    const float bin_area = (float)((hend - hstart) * (wend - wstart));
+    bins[d * PP + k] = is_empty ? 0.f : out_sum / bin_area;
+  }
+  __syncthreads();
+  for (int d = threadIdx.x; d < D; d += kHeadThreads) {
+    float s = 0.f;
+    for (int k = 0; k < PP; ++k) s += bins[d * PP + k];
+    const float a = s / (float)PP;
+    avg[d] = a;
+    if (d >= ncls) bbox_pred[(size_t)r * nbox + (d - ncls)] = a;
+    else if (cls_score) cls_score[(size_t)r * ncls + d] = a;
+  }
+  __syncthreads();
+  if (threadIdx.x < 64) {
+    float m = avg[0];
+    for (int j = 1; j < ncls; ++j) m = fmaxf(m, avg[j]);
+    for (int j = threadIdx.x; j < ncls; j += 64) bins[j] = expf_cr(avg[j] - m);
+  }
+  __syncthreads();
+  if (threadIdx.x < 64) {
+    float s = 0.f;
+    for (int j = 0; j < ncls; ++j) s += bins[j];
+    for (int j = threadIdx.x; j < ncls; j += 64) cls_prob[(size_t)r * ncls + j] = bins[j] / s;
+  }
+}
+
 }  // namespace
 
 extern "C" int lsfa_psroi_pool_fwd(const float* data, const float* rois, int N, int C, int H, int W, int R,
@@ -164,5 +228,26 @@ extern "C" int lsfa_rfcn_head_fwd(const float* cls_map, const float* box_map, co
   hipLaunchKernelGGL(rfcn_head_kernel, dim3(R), dim3(kHeadThreads), lds, s, cls_map, box_map, rois, H, W, ncls,
                      nbox, spatial_scale, pooled_size, group_size, cls_prob, cls_score, bbox_pred);
   LSFA_LAUNCH_CHECK("lsfa_rfcn_head_fwd");
+  return LSFA_OK;
+}
+
+extern "C" int lsfa_rfcn_head_ps_fwd(const float* ps_map, const float* rois, int N, int H, int W, int R, int ncls,
+                                     int nbox, float spatial_scale, int pooled_size, int group_size, float* cls_prob,
+                                     float* cls_score, float* bbox_pred, void* stream) {
+  using namespace lsfa;
+  LSFA_REQUIRE(N > 0 && H > 0 && W > 0 && R >= 0 && ncls > 0 && nbox > 0 && pooled_size > 0 && group_size > 0,
+               "lsfa_rfcn_head_ps_fwd: bad shape");
+  if (R == 0) return LSFA_OK;
+  LSFA_REQUIRE(ps_map && rois && cls_prob && bbox_pred, "lsfa_rfcn_head_ps_fwd: NULL argument");
+  const size_t lds = sizeof(float) * ((size_t)(ncls + nbox) * pooled_size * pooled_size + (ncls + nbox));
+  if (lds > 64 * 1024) {
+    set_error("lsfa_rfcn_head_ps_fwd: (ncls+nbox)*pooled^2 = %zu floats does not fit the LDS budget", lds / 4);
+    return LSFA_ENOTSUP;
+  }
+  hipStream_t s = (hipStream_t)stream;
+  ProfScope prof(LSFA_OP_RFCN_HEAD, s);
+  hipLaunchKernelGGL(rfcn_head_ps_kernel, dim3(R), dim3(kHeadThreads), lds, s, ps_map, rois, H, W, ncls, nbox,
+                     spatial_scale, pooled_size, group_size, cls_prob, cls_score, bbox_pred);
+  LSFA_LAUNCH_CHECK("lsfa_rfcn_head_ps_fwd");
   return LSFA_OK;
 }

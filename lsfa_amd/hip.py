@@ -99,6 +99,20 @@ def rfcn_head(cls_map, box_map, rois, spatial_scale=0.0625, pooled_size=7, group
     return (cls_prob, cls_score, bbox_pred) if want_score else (cls_prob, bbox_pred)
 
 
+def rfcn_head_ps(ps_map, rois, ncls, nbox, spatial_scale=0.0625, pooled_size=7, group_size=7, want_score=False):
+    """ps_map (N, H, W, group^2, ncls+nbox) float32 — see lsfa_rfcn_head_ps_fwd."""
+    ps_map, rois = _f32c(ps_map, "ps_map"), _f32c(rois, "rois")
+    N, H, W = ps_map.shape[0], ps_map.shape[1], ps_map.shape[2]
+    R = rois.shape[0]
+    cls_prob = torch.empty((R, ncls), device=rois.device, dtype=torch.float32)
+    bbox_pred = torch.empty((R, nbox), device=rois.device, dtype=torch.float32)
+    cls_score = torch.empty((R, ncls), device=rois.device, dtype=torch.float32) if want_score else None
+    _check(lib().lsfa_rfcn_head_ps_fwd(_ptr(ps_map), _ptr(rois), _ci(N), _ci(H), _ci(W), _ci(R), _ci(ncls), _ci(nbox),
+                                       _cf(spatial_scale), _ci(pooled_size), _ci(group_size), _ptr(cls_prob),
+                                       _ptr(cls_score), _ptr(bbox_pred), _stream()), "lsfa_rfcn_head_ps_fwd")
+    return (cls_prob, cls_score, bbox_pred) if want_score else (cls_prob, bbox_pred)
+
+
 def warp_bilinear(feat, flow, mul=None, add=None, res=None, res_w=None, res_b=None, out=None):
     feat, flow = _f32c(feat, "feat"), _f32c(flow, "flow")
     mul, add, res = _f32c(mul, "mul"), _f32c(add, "add"), _f32c(res, "res")

@@ -223,6 +223,17 @@ class Executor(object):
         self.rfcn_w = _t(np.concatenate([arg['rfcn_cls_weight'].reshape(-1, 512), arg['rfcn_bbox_weight'].reshape(-1, 512)], 0), dev, cd)
         self.rfcn_b = _t(np.concatenate([arg['rfcn_cls_bias'], arg['rfcn_bbox_bias']], 0), dev, cd)
         self.n_cls_ch = arg['rfcn_cls_weight'].shape[0]
+        # position-sensitive layout: GEMM [HW,512] x [512, 49*(ncls+nbox)], row (bin*D + d) of the permuted weight
+        G = 7
+        self.ncls = self.n_cls_ch // (G * G)
+        self.nbox = arg['rfcn_bbox_weight'].shape[0] // (G * G)
+        wc = arg['rfcn_cls_weight'].reshape(self.ncls, G * G, 512)
+        wx = arg['rfcn_bbox_weight'].reshape(self.nbox, G * G, 512)
+        w_ps = np.concatenate([wc, wx], 0).transpose(1, 0, 2).reshape(-1, 512)          # (49*D, 512)
+        b_ps = np.concatenate([arg['rfcn_cls_bias'].reshape(self.ncls, G * G), arg['rfcn_bbox_bias'].reshape(self.nbox, G * G)], 0).T.reshape(-1)
+        self.rfcn_w_ps_t = _t(np.ascontiguousarray(w_ps.T), dev, cd)                  # (512, 49*D)
+        self.rfcn_b_ps = _t(b_ps, dev, cd)
+        self.ps_layout = True
         self.proposal = hip.ProposalOp(feature_stride=cfg.network.RPN_FEAT_STRIDE, scales=cfg.network.ANCHOR_SCALES,
                                        ratios=cfg.network.ANCHOR_RATIOS, rpn_pre_nms_top_n=cfg.TEST.RPN_PRE_NMS_TOP_N,
                                        rpn_post_nms_top_n=cfg.TEST.RPN_POST_NMS_TOP_N, threshold=cfg.TEST.RPN_NMS_THRESH,
@@ -383,11 +394,22 @@ class Executor(object):
         rpn = self._conv1x1(self._c(conv_feat[:, :512]), self.rpn_w, bias=self.rpn_b).float()
         cls_prob = torch.softmax(rpn[:, :2 * A].reshape(n, 2, A * h, w), dim=1).reshape(n, 2 * A, h, w)
         rois = self.proposal(cls_prob, rpn[:, 2 * A:], im_info)
-        maps = self._conv1x1(self._c(conv_feat[:, 512:]), self.rfcn_w, bias=self.rfcn_b).float()
-        if self.taps is not None:
-            self.taps.update(rpn_cls_prob=cls_prob, rpn_bbox_pred=rpn[:, 2 * A:], cls_map=maps[:, :self.n_cls_ch],
-                             box_map=maps[:, self.n_cls_ch:])
-        cls_p, bbox = hip.rfcn_head(maps[:, :self.n_cls_ch], maps[:, self.n_cls_ch:], rois, 0.0625, 7, 7)
+        if self.ps_layout and n == 1:
+            # both R-FCN convs as one GEMM that writes the position-sensitive layout directly
+            xt = self._c(conv_feat[0, 512:]).view(512, h * w).t()
+            D = self.ncls + self.nbox
+            ps = torch.addmm(self.rfcn_b_ps, xt, self.rfcn_w_ps_t).float().view(1, h, w, 49, D)
+            if self.taps is not None:
+                nchw = ps.view(h * w, 49, D).permute(2, 1, 0).reshape(1, D * 49, h, w)
+                self.taps.update(rpn_cls_prob=cls_prob, rpn_bbox_pred=rpn[:, 2 * A:], cls_map=nchw[:, :self.n_cls_ch],
+                                 box_map=nchw[:, self.n_cls_ch:])
+            cls_p, bbox = hip.rfcn_head_ps(ps, rois, self.ncls, self.nbox, 0.0625, 7, 7)
+        else:
+            maps = self._conv1x1(self._c(conv_feat[:, 512:]), self.rfcn_w, bias=self.rfcn_b).float()
+            if self.taps is not None:
+                self.taps.update(rpn_cls_prob=cls_prob, rpn_bbox_pred=rpn[:, 2 * A:], cls_map=maps[:, :self.n_cls_ch],
+                                 box_map=maps[:, self.n_cls_ch:])
+            cls_p, bbox = hip.rfcn_head(maps[:, :self.n_cls_ch], maps[:, self.n_cls_ch:], rois, 0.0625, 7, 7)
         B = cfg.TEST.BATCH_IMAGES
         return rois, cls_p.view(B, -1, cls_p.shape[1]), bbox.view(B, -1, bbox.shape[1])
 

@@ -35,10 +35,12 @@ def test_library_builds_loads_and_exports_every_declared_symbol():
     lib.lsfa_op_name.restype = ctypes.c_char_p
     from lsfa_amd import hip
     assert [lib.lsfa_op_name(i).decode() for i in range(len(hip.OP_NAMES))] == hip.OP_NAMES
-    # workspace sizing is host-only arithmetic: 6000 x 94 u64 mask + boxes/keys
+    # workspace sizing is host-only arithmetic: float4 boxes + u32 keys for the 21,546 anchors (no NMS mask)
     lib.lsfa_proposal_workspace_bytes.restype = ctypes.c_size_t
     ws = lib.lsfa_proposal_workspace_bytes(1, 9, 38, 63, 6000)
-    assert 6000 * 94 * 8 < ws < 6 * 1024 * 1024
+    assert 21546 * 20 <= ws < 21546 * 20 + 1024
+    lib.lsfa_nms_workspace_bytes.restype = ctypes.c_size_t
+    assert lib.lsfa_nms_workspace_bytes(6000) >= 6000 * 94 * 8
 
 
 def test_product_never_imports_the_oracle():

@@ -82,6 +82,21 @@ def test_rfcn_head_fused_bit_exact(hip, R):
     np.testing.assert_array_equal(oracle.global_avg(unf), want_score)
 
 
+def test_rfcn_head_position_sensitive_layout_bit_exact(hip):
+    rs = np.random.RandomState(21)
+    H, W, R = 38, 63, 300
+    cls_map = rs.randn(1, 31 * 49, H, W).astype(np.float32)
+    box_map = (0.1 * rs.randn(1, 8 * 49, H, W)).astype(np.float32)
+    rois = rand_rois(rs, R)
+    want_prob, want_score, want_box = oracle.rfcn_head(cls_map, box_map, rois)
+    nchw = np.concatenate([cls_map.reshape(31, 49, H * W), box_map.reshape(8, 49, H * W)], 0)   # (D, 49, HW)
+    ps = np.ascontiguousarray(nchw.transpose(2, 1, 0)).reshape(1, H, W, 49, 39)
+    prob, score, box = hip.rfcn_head_ps(t(ps), t(rois), 31, 8, want_score=True)
+    np.testing.assert_array_equal(score.cpu().numpy(), want_score)
+    np.testing.assert_array_equal(box.cpu().numpy(), want_box)
+    np.testing.assert_array_equal(prob.cpu().numpy(), want_prob)
+
+
 # ------------------------------------------------------------------ warp --------------
 def smooth_flow(rs, N, H, W, mag):
     f = rs.uniform(-mag, mag, (N, 2, 1, 1)) + 0.3 * rs.randn(N, 2, H, W)

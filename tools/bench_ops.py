@@ -81,6 +81,9 @@ def main():
     hb = (1519 + 392) * HW * 4 + 300 * 39 * 4
     us = timeit(lambda: hip.rfcn_head(cls_map, box_map, rois), args.iters)
     out['rfcn_head_fused'] = dict(us=round(us, 2), GBps=round(hb / us / 1e3, 1), bytes=hb)
+    ps = torch.randn(1, H, W, 49, 39, device=dev)
+    us = timeit(lambda: hip.rfcn_head_ps(ps, rois, 31, 8), args.iters)
+    out['rfcn_head_ps_layout'] = dict(us=round(us, 2), GBps=round(hb / us / 1e3, 1), bytes=hb)
     pb = 1519 * HW * 4 + 300 * 31 * 49 * 4
     us = timeit(lambda: hip.psroi_pool(cls_map, rois, 0.0625, 31, 7, 7), args.iters)
     out['psroi_pool_cls'] = dict(us=round(us, 2), GBps=round(pb / us / 1e3, 1), bytes=pb)

@@ -7,7 +7,8 @@
 // and reused across the channel run (the reference materialises a (1,2,H,W) grid and
 // recomputes the taps per channel).  Lanes of a wave cover 64*VEC consecutive pixels
 // of one channel plane, so flow / mul / add / out move as 4*VEC-byte coalesced vectors
-// and the four taps are near-contiguous gathers served by L1/L2.  Planes of an NCHW
+// and the taps are near-contiguous gathers served by L1/L2: in the interior fast path
+// the left/right taps of a row are ONE 4-byte-aligned 8-byte load.  Planes of an NCHW
 // tensor start at multiples of H*W floats, hence VEC = 4, 2 or 1 by H*W mod 4.
 //
 // Arithmetic is the oracle's, operation for operation (orc_warp_bilinear): built with
@@ -18,6 +19,8 @@ namespace {
 
 constexpr int kThreads = 256;
 constexpr int kResMax = 4;
+
+typedef float float2u __attribute__((ext_vector_type(2), aligned(4)));
 
 template <int VEC> struct VecT;
 template <> struct VecT<1> { using type = float; };
@@ -94,7 +97,41 @@ __global__ __launch_bounds__(kThreads) void warp_kernel(
 
   const float* fbase = feat + (feat_n == 1 ? (size_t)0 : (size_t)n * C * HW);
   const int c1 = min(c0 + ch_per_block, C);
+  bool interior = true;
+#pragma unroll
+  for (int i = 0; i < VEC; ++i) interior = interior && v00[i] && v01[i] && v10[i] && v11[i];
+  // wave-uniform split: a wave whose pixels all sample inside the map (nearly all of them) runs
+  // the loop without any validity logic; the general loop handles map borders and escaping flows
+  if (__all(interior)) {
 #pragma unroll 4
+    for (int c = c0; c < c1; ++c) {
+      const float* plane = fbase + (size_t)c * HW;
+      const size_t o = ((size_t)n * C + c) * HW + p0;
+      float m[VEC], a[VEC], v[VEC];
+      if (HAS_MUL) load_vec<VEC>(mul + o, m);
+      if (HAS_ADD) load_vec<VEC>(add + o, a);
+#pragma unroll
+      for (int i = 0; i < VEC; ++i) {
+        const float2u t = *reinterpret_cast<const float2u*>(plane + off[i]);
+        const float2u b = *reinterpret_cast<const float2u*>(plane + off[i] + W);
+        float r = t.x * wy0[i] * wx0[i] + t.y * wy0[i] * wx1[i] + b.x * wy1[i] * wx0[i] + b.y * wy1[i] * wx1[i];
+        if (HAS_MUL) r = r * m[i];
+        if (HAS_RES) {
+          float q = res_w[(size_t)c * res_c] * rv[0][i];
+#pragma unroll
+          for (int k = 1; k < kResMax; ++k)
+            if (k < res_c) q = q + res_w[(size_t)c * res_c + k] * rv[k][i];
+          q = q + res_b[c];
+          r = r + q;
+        }
+        if (HAS_ADD) r = r + a[i];
+        v[i] = r;
+      }
+      store_vec<VEC>(out + o, v);
+    }
+    return;
+  }
+#pragma unroll 2
   for (int c = c0; c < c1; ++c) {
     const float* plane = fbase + (size_t)c * HW;
     const size_t o = ((size_t)n * C + c) * HW + p0;

@@ -30,6 +30,8 @@ from lsfa_amd import hip
 from lsfa_amd.symbols import params as P
 
 BN_EPS = 2e-5  # sym_common.py:9
+import os as _os
+_CONV1X1_MIOPEN = _os.environ.get('LSFA_CONV1X1_MIOPEN', '0') == '1'   # experiment: channel-reducing 1x1 convs through MIOpen
 
 
 class TestSymbol(object):
@@ -274,6 +276,8 @@ class Executor(object):
         X = x.view(c, h * w)
         if residual is not None:
             out = residual.view(-1, h * w).addmm_(w2d, X)
+        elif _CONV1X1_MIOPEN and w2d.shape[0] < c:
+            out = F.conv2d(x, w2d.view(w2d.shape[0], c, 1, 1))
         else:
             out = torch.mm(w2d, X)
         out = out.view(1, -1, h, w)

@@ -153,3 +153,29 @@ def proposal_phases():
 
 if __name__ == '__main__' and os.environ.get('LSFA_PHASES') == '1':
     proposal_phases()
+
+
+def batched():
+    """HBM-bound regime: 32 feature maps per launch, > 256 MiB of traffic."""
+    dev = 'cuda:0'
+    N, C, H, W = 32, 1024, 38, 63
+    HW = H * W
+    feat, add = torch.randn(N, C, H, W, device=dev), torch.randn(N, C, H, W, device=dev)
+    flow = torch.randn(N, 2, H, W, device=dev) * 0.3 + 1.5
+    res, res_w, res_b = torch.randn(N, 3, H, W, device=dev), torch.randn(C, 3, device=dev) * 0.01, torch.randn(C, device=dev) * 0.01
+    out = torch.empty_like(feat)
+    b3 = N * (3 * C * HW + 2 * HW) * 4
+    us = timeit(lambda: hip.warp_bilinear(feat, flow, add=add, res=res, res_w=res_w, res_b=res_b, out=out), 20, 3)
+    print("warp_cur N=32      us %.1f  GB/s %.0f  bytes %d" % (us, b3 / us / 1e3, b3))
+    us = timeit(lambda: hip.warp_bilinear(feat, flow, out=out), 20, 3)
+    print("warp_plain N=32    us %.1f  GB/s %.0f" % (us, N * (2 * C * HW + 2 * HW) * 4 / us / 1e3))
+    a2 = torch.randn(C * N, H, W, device=dev)
+    us = timeit(lambda: out.copy_(feat), 20, 3)
+    print("torch copy N=32    us %.1f  GB/s %.0f" % (us, 2 * N * C * HW * 4 / us / 1e3))
+    sc, sh = torch.rand(C, device=dev), torch.rand(C, device=dev)
+    us = timeit(lambda: hip.scale_shift_relu(feat, sc, sh, True, out=out), 20, 3)
+    print("scale_shift N=32   us %.1f  GB/s %.0f" % (us, 2 * N * C * HW * 4 / us / 1e3))
+
+
+if __name__ == '__main__' and os.environ.get('LSFA_BATCHED') == '1':
+    batched()

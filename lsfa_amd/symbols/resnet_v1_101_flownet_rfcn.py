@@ -72,7 +72,7 @@ class TestSymbol(object):
                 out[k] = tuple(data_shapes[k])
         arg_shapes = [tuple(data_shapes[k]) if k in data_shapes else None for k in self.data_names] + \
                      list(self.arg_spec.values())
-        return arg_shapes, [out[k] for k in self.list_outputs()], list(self.aux_spec.values())
+        return arg_shapes, [out.get(k) for k in self.list_outputs()], list(self.aux_spec.values())
 
     def bind(self, arg_params, aux_params, device='cuda:0', dtype=torch.float32):
         return Executor(self, arg_params, aux_params, device, dtype)

@@ -189,3 +189,37 @@ def test_clip_end_to_end_map_vs_oracle(world):
     present = np.unique(np.concatenate([g['label'] for g in gt])) - 1
     assert abs(ap_gpu[present].mean() - ap_ref[present].mean()) < 0.1
     assert ap_ref[present].mean() > 0.5
+
+
+def test_bf16_contractions_config3(world):
+    """BASELINE configs[2]: bf16 MFMA for the dense contractions, fp32 hand-written kernels.  The
+    feature map stays within bf16 round-off of the fp32 run and every hand-written stage is still
+    bit-exact on the inputs it was given."""
+    from lsfa_amd.symbols.resnet_v1_101_flownet_rfcn import resnet_v1_101_flownet_rfcn
+    cfg, arg, aux, clip = world['cfg'], world['arg'], world['aux'], world['clip']
+    net = resnet_v1_101_flownet_rfcn(cfg)
+    key16 = net.get_key_test_symbol(cfg).bind(arg, aux, DEV, dtype=torch.bfloat16)
+    cur16 = net.get_cur_test_symbol(cfg).bind(arg, aux, DEV, dtype=torch.bfloat16)
+    im_info = clip.im_info()
+    im_t = torch.from_numpy(im_info).to(DEV)
+    f0 = clip.frame(0, DEV)
+    ph = torch.zeros(1, 1024, 1, 1, device=DEV)
+    key16.taps = {}
+    o16 = key16.forward(data=f0, im_info=im_t, data_key_old=f0, feat_key_old=ph)
+    world['key'].taps = None
+    o32 = world['key'].forward(data=f0, im_info=im_t, data_key_old=f0, feat_key_old=ph)
+    a, b = np_(o16['choose_feat_output']), np_(o32['choose_feat_output'])
+    assert o16['choose_feat_output'].dtype == torch.float32
+    assert np.abs(a - b).max() / np.abs(b).max() < 0.08
+    check_heads(cfg, key16.taps, o16, im_info)
+    cur16.taps = {}
+    mv, res = clip.motion_vector(2, 0, DEV), clip.res_diff(2, DEV)
+    o2 = cur16.forward(data=clip.frame(2, DEV), im_info=im_t, feat_key=o16['choose_feat_output'], motion_vector=mv, res_diff=res)
+    want = oracle.warp_bilinear(a, np_(mv), add=np_(cur16.taps['small_feat']), res=np_(res), res_w=arg['rnet_conv0_weight'],
+                                res_b=arg['rnet_conv0_bias'])
+    np.testing.assert_array_equal(np_(o2['conv_feat']), want)
+    check_heads(cfg, cur16.taps, o2, im_info)
+    key16.taps = {}
+    o10 = key16.forward(data=clip.frame(10, DEV), im_info=im_t, data_key_old=f0, feat_key_old=o16['choose_feat_output'])
+    assert torch.isfinite(o10['choose_feat_output']).all()
+    check_heads(cfg, key16.taps, o10, im_info)

@@ -1,0 +1,43 @@
+"""BASELINE.json configs[0] ("single-frame R-FCN ResNet-101 on CPU, plumbing, no GPU"): the oracle's
+statement of the key-frame graph on a first frame IS the single-frame R-FCN path
+(backbone -> RPN -> Proposal -> PSROI -> decode -> NMS).  Run it on the CPU at a reduced size and
+check the plumbing invariants the GPU path is later compared against."""
+import numpy as np
+
+import oracle
+from oracle import graph_ref, np_ref
+from lsfa_amd.config.config import lsfa_test_config
+from lsfa_amd.symbols import params as P
+from lsfa_amd.symbols.resnet_v1_101_flownet_rfcn import resnet_v1_101_flownet_rfcn
+from lsfa_amd.utils.synthetic import SyntheticClip
+
+
+def test_single_frame_rfcn_graph_on_cpu_oracle():
+    cfg = lsfa_test_config(10)
+    cfg.network.add_dcn = False          # keeps the CPU run short; DCN is covered by the GPU graph test
+    arg, aux = P.init_params(cfg, seed=5)
+    clip = SyntheticClip(0, 1, 96, 160)
+    im_info = clip.im_info()
+    out = graph_ref.key_forward(cfg, arg, aux, clip.frame(0).numpy(), clip.frame(0).numpy(),
+                                np.zeros((1, 1024, 1, 1), np.float32), im_info)
+    assert out['choose_feat_output'].shape == (1, 1024, 6, 10)
+    rois, prob, bbox = out['rois_output'], out['cls_prob_reshape_output'][0], out['bbox_pred_reshape_output'][0]
+    assert rois.shape == (300, 5) and prob.shape == (300, 31) and bbox.shape == (300, 8)
+    assert (rois[:, 0] == 0).all() and (rois[:, 1] >= 0).all() and (rois[:, 3] <= 159).all() and (rois[:, 4] <= 95).all()
+    np.testing.assert_allclose(prob.sum(1), 1.0, atol=1e-5)
+    # 6*10*9 = 540 anchors < 300 survivors is impossible after NMS -> the cyclic pad ran
+    assert len(np.unique(rois, axis=0)) < 300
+    dets, counts, _ = oracle.det_postprocess(rois, bbox, prob, 96, 160, 1.0)
+    assert 0 < counts.sum() <= 300 + 30
+    # the product's symbol object agrees with the oracle on names and shapes
+    net = resnet_v1_101_flownet_rfcn(cfg)
+    sym = net.get_key_test_symbol(cfg)
+    net.infer_shape({'data': (1, 3, 96, 160), 'im_info': (1, 3)})
+    assert net.out_shape_dict['rois_output'] == (300, 5)
+    assert net.out_shape_dict['choose_feat_output'] == (1, 1024, 6, 10)
+    net.check_parameter_shapes(arg, aux, {'data': (1, 3, 96, 160)})
+    assert set(sym.arg_spec) <= set(arg) and set(sym.aux_spec) <= set(aux)
+    assert 'stage3_unit23_conv2_offset_weight' not in sym.arg_spec     # add_dcn False
+    cfg2 = lsfa_test_config(10)
+    assert 'stage3_unit23_conv2_offset_weight' in resnet_v1_101_flownet_rfcn(cfg2).get_key_test_symbol(cfg2).arg_spec
+    assert np_ref.key_frame_flags([1], 10) == [0]

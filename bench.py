@@ -49,6 +49,7 @@ def parse():
     ap.add_argument('--dtype', default='f32', choices=['f32', 'bf16'])
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-graph', action='store_true', help='issue every launch eagerly instead of replaying hipGraphs')
+    ap.add_argument('--no-prefetch', action='store_true', help='do not overlap the next frame\'s small net with this frame\'s tail')
     ap.add_argument('--cpu-budget-s', type=float, default=20.0)
     ap.add_argument('--max-unique-steps', type=int, default=16, help='distinct intervals of frames kept in HBM')
     return ap.parse_args()
@@ -86,7 +87,8 @@ class Runner(object):
         self.host_dets = torch.empty((self.K, ncls, R, 5), dtype=torch.float64).pin_memory()
         self.host_counts = torch.empty((self.K, ncls), dtype=torch.int32).pin_memory()
         from lsfa_amd.core.graphs import FrameGraphs
-        self.fg = FrameGraphs(self.key, self.cur, cfg, args.height, args.width, device, use_graphs=not args.no_graph)
+        self.fg = FrameGraphs(self.key, self.cur, cfg, args.height, args.width, device, use_graphs=not args.no_graph,
+                              prefetch=not args.no_prefetch)
 
     @property
     def feat(self):
@@ -106,15 +108,17 @@ class Runner(object):
         """One key-frame interval: key frame (flag 1) + K-1 non-key frames (flag 2)."""
         fg = fg or self.fg
         kf = 1 + (s % self.nsteps_unique) * self.K
-        self._deliver(fg.key_frame(self.frames[kf]), 0)
+        nxt = lambda i: self.frames[kf + i + 1] if i + 1 < self.K else None   # the frame after a non-key frame, if non-key too
+        self._deliver(fg.key_frame(self.frames[kf], nxt(0)), 0)
         for i in range(1, self.K):
-            self._deliver(fg.cur_frame(self.frames[kf + i], self.mv[kf + i], self.res[kf + i]), i)
+            self._deliver(fg.cur_frame(self.frames[kf + i], self.mv[kf + i], self.res[kf + i], nxt(i)), i)
 
     def eager_profile_step(self, s):
         """The same interval issued eagerly with the per-kernel event hooks on (a captured graph has no
         per-launch events): the roofline leg."""
         from lsfa_amd.core.graphs import FrameGraphs
-        eg = FrameGraphs(self.key, self.cur, self.cfg, self.args.height, self.args.width, self.device, use_graphs=False)
+        eg = FrameGraphs(self.key, self.cur, self.cfg, self.args.height, self.args.width, self.device, use_graphs=False,
+                         prefetch=False)
         eg.feat_old.copy_(self.fg.feat_old)
         eg.data_key_old.copy_(self.fg.data_key_old)
         eg.feat = self.fg.feat.clone()

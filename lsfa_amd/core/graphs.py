@@ -10,6 +10,12 @@ State carried across frames stays on the device: the key graph's output feature 
 graph's `feat_key` input by pointer (no copy); the only per-frame host work is queuing the
 copies of that frame's inputs into the graph's static buffers, one replay, and the asynchronous
 copy of the detections to pinned host memory.
+
+Software pipelining inside the graphs (`prefetch=True`): the small-net branch of a non-key frame
+needs only that frame's image, while the tail of a frame (Proposal's single-workgroup
+select/sort/NMS, the R-FCN head, the detection NMS) keeps one or a few CUs busy.  Each captured
+graph therefore forks a second stream that computes the small-net feature of the NEXT frame while
+the current frame's tail runs, and the next replay consumes it.
 """
 import torch
 
@@ -17,7 +23,7 @@ from lsfa_amd import hip
 
 
 class FrameGraphs(object):
-    def __init__(self, key_exec, cur_exec, cfg, height, width, device, thresh=1e-4, use_graphs=True):
+    def __init__(self, key_exec, cur_exec, cfg, height, width, device, thresh=1e-4, use_graphs=True, prefetch=True):
         self.key, self.cur, self.cfg = key_exec, cur_exec, cfg
         self.device = torch.device(device)
         self.use_graphs = use_graphs
@@ -38,6 +44,11 @@ class FrameGraphs(object):
         self.post_bufs = (torch.zeros((ncls, R, 5), dtype=torch.float64, device=dev),
                           torch.zeros(ncls, dtype=torch.int32, device=dev),
                           torch.full((ncls, R), -1, dtype=torch.int32, device=dev))
+        self.prefetch = prefetch and cfg.network.add_small_net
+        self.data_next = z(1, 3, height, width)        # image of the frame after the current one
+        self.small_cur = z(1, dim, fh, fw)             # small-net feature of the current non-key frame
+        self.small_next = z(1, dim, fh, fw)
+        self.side = torch.cuda.Stream(device=dev) if self.prefetch else None
         self.feat = None            # the key graph's output feature (static address once captured)
         self.key_graph = self.cur_graph = None
         self.scale = 1.0
@@ -50,16 +61,39 @@ class FrameGraphs(object):
                                    max_per_image=cfg.TEST.max_per_image, class_agnostic=cfg.CLASS_AGNOSTIC,
                                    out=self.post_bufs)
 
+    def _fork_small_next(self):
+        """side stream: small-net feature of the next frame (reads data_next, writes small_next)."""
+        main = torch.cuda.current_stream(self.device)
+        self.side.wait_stream(main)
+        with torch.cuda.stream(self.side):
+            self.small_next.copy_(self.cur.small_net_feature(self.data_next))
+
+    def _join_small_next(self):
+        main = torch.cuda.current_stream(self.device)
+        main.wait_stream(self.side)
+        self.small_cur.copy_(self.small_next)     # becomes the current frame's feature at the next replay
+
     def _key_seq(self):
+        if self.prefetch:
+            self._fork_small_next()
         out = self.key.forward(data=self.data, im_info=self.im_info, data_key_old=self.data_key_old,
                                feat_key_old=self.feat_old)
         self._post(out)
+        if self.prefetch:
+            self._join_small_next()
         return out['choose_feat_output']
 
     def _cur_seq(self):
-        out = self.cur.forward(data=self.data, im_info=self.im_info, feat_key=self.feat, motion_vector=self.mv,
-                               res_diff=self.res)
+        if self.prefetch:
+            self._fork_small_next()
+            out = self.cur.forward(data=self.data, im_info=self.im_info, feat_key=self.feat, motion_vector=self.mv,
+                                   res_diff=self.res, small_feat=self.small_cur)
+        else:
+            out = self.cur.forward(data=self.data, im_info=self.im_info, feat_key=self.feat, motion_vector=self.mv,
+                                   res_diff=self.res)
         self._post(out)
+        if self.prefetch:
+            self._join_small_next()
 
     # ---- first frame of a clip (flag 0): eager, no aggregation --------------------------
     def first_frame(self, data):
@@ -98,9 +132,13 @@ class FrameGraphs(object):
         self.feat.copy_(self._first_feat)
 
     # ---- per-frame entry points ---------------------------------------------------------
-    def key_frame(self, data):
-        """flag 1: a key frame after the first.  Returns the (dets, counts, keep_idx) device buffers."""
+    def key_frame(self, data, next_data=None):
+        """flag 1: a key frame after the first.  `next_data` = image of the following frame when that
+        frame is a non-key frame (its small-net feature is computed alongside).  Returns the
+        (dets, counts, keep_idx) device buffers."""
         self.data.copy_(data)
+        if self.prefetch:
+            self.data_next.copy_(next_data if next_data is not None else data)
         if self.use_graphs:
             self.key_graph.replay()
         else:
@@ -110,9 +148,12 @@ class FrameGraphs(object):
         self.data_key_old.copy_(self.data)
         return self.post_bufs
 
-    def cur_frame(self, data, motion_vector, res_diff):
-        """flag 2: a non-key frame."""
+    def cur_frame(self, data, motion_vector, res_diff, next_data=None):
+        """flag 2: a non-key frame.  With prefetch on, the small-net feature of THIS frame must have
+        been produced by the previous call (pass this frame's image as its `next_data`)."""
         self.data.copy_(data)
+        if self.prefetch:
+            self.data_next.copy_(next_data if next_data is not None else data)
         self.mv.copy_(motion_vector)
         self.res.copy_(res_diff)
         if self.use_graphs:

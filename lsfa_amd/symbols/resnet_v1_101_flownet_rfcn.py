@@ -455,14 +455,21 @@ class Executor(object):
                 'feat_key': d.get('feat_key'), 'choose_feat_output': conv_feat, 'rois_output': rois,
                 'cls_prob_reshape_output': cls_prob, 'bbox_pred_reshape_output': bbox_pred}
 
+    def small_net_feature(self, data):
+        """fuse_small_net's image branch (:209-236): avgpool 4x4 -> small_net_ stem + stage 1 ->
+        fuse_reduce_add.  It depends on the frame image only, so a caller may compute it ahead of the
+        rest of the frame (lsfa_amd/core/graphs.py overlaps it with the previous frame's tail)."""
+        with torch.no_grad():
+            img = F.avg_pool2d(data, 4, 4, ceil_mode=True)
+            s = self._resnet(img, self.small, 1, False)
+            return F.conv2d(s, self.fuse_w, self.fuse_b, padding=1).float()
+
     def _forward_cur(self, d):
         cfg = self.cfg
-        add = None
-        if cfg.network.add_small_net:
-            img = F.avg_pool2d(d['data'], 4, 4, ceil_mode=True)
-            s = self._resnet(img, self.small, 1, False)
-            add = F.conv2d(s, self.fuse_w, self.fuse_b, padding=1).float()
-            self._tap('small_feat', add)
+        add = d.get('small_feat')          # precomputed by the caller, else computed here
+        if add is None and cfg.network.add_small_net:
+            add = self.small_net_feature(d['data'])
+        self._tap('small_feat', add)
         conv_feat = hip.warp_bilinear(d['feat_key'], d['motion_vector'], add=add, res=d['res_diff'], res_w=self.rnet_w,
                                       res_b=self.rnet_b)
         rois, cls_prob, bbox_pred = self._heads(conv_feat, d['im_info'])

@@ -1,0 +1,73 @@
+"""Frame / motion-vector / residual preprocessing (a "next" row).
+
+Counterparts of lib/utils/image.py: `resize` (:266-294), `transform` (:296-308) and
+`transform_mv_res` (:202-228).  The reference runs them with cv2 on the host inside a prefetch
+process; here they are torch ops on whatever device the input lives on (the frame, the motion
+vectors and the residual of a decoded GOP can stay in HBM).  cv2.resize(INTER_LINEAR) on float
+input = bilinear sampling at half-pixel centres with scale src/dst and edge clamping, no
+antialiasing [OpenCV 3.2, un-vendored — PARITY UNPINNED], which is F.interpolate(mode='bilinear',
+align_corners=False, antialias=False).
+"""
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+
+def _cv_round(x):
+    return int(np.rint(x))      # cvRound: nearest, ties to even
+
+
+def _resize_hwc(x, fx, fy):
+    """x: (H, W, C) float tensor -> (round(H*fy), round(W*fx), C)."""
+    h, w, _ = x.shape
+    oh, ow = _cv_round(h * fy), _cv_round(w * fx)
+    y = F.interpolate(x.permute(2, 0, 1).unsqueeze(0), size=(oh, ow), mode='bilinear', align_corners=False)
+    return y[0].permute(1, 2, 0)
+
+
+def resize(im, target_size, max_size, stride=0):
+    """im (H, W, C) BGR tensor -> (resized [padded to `stride`], im_scale).  lib/utils/image.py:266-294"""
+    im = torch.as_tensor(im)
+    h, w = im.shape[0], im.shape[1]
+    im_size_min, im_size_max = min(h, w), max(h, w)
+    im_scale = float(target_size) / float(im_size_min)
+    if np.round(im_scale * im_size_max) > max_size:
+        im_scale = float(max_size) / float(im_size_max)
+    out = _resize_hwc(im.float(), im_scale, im_scale)
+    if stride == 0:
+        return out, im_scale
+    ph = int(np.ceil(out.shape[0] / float(stride)) * stride)
+    pw = int(np.ceil(out.shape[1] / float(stride)) * stride)
+    padded = torch.zeros((ph, pw, out.shape[2]), dtype=out.dtype, device=out.device)
+    padded[:out.shape[0], :out.shape[1]] = out
+    return padded, im_scale
+
+
+def transform(im, pixel_means, pixel_scale):
+    """(H, W, 3) BGR -> (1, 3, H, W) RGB minus means, times scale.  lib/utils/image.py:296-308"""
+    im = torch.as_tensor(im).float()
+    means = torch.as_tensor(np.asarray(pixel_means, dtype=np.float32), device=im.device)
+    t = torch.stack([im[:, :, 2 - i] - means[2 - i] for i in range(3)], 0).unsqueeze(0)
+    return t * pixel_scale
+
+
+def transform_mv_res(motion_vector, res_diff, im_scale, pixel_means, pixel_scale, rcnn_stride=16):
+    """(H, W, 2) motion vectors + (H, W, 3) residual -> (1,2,h,w), (1,3,h,w) stride-16 tensors.
+    lib/utils/image.py:202-228, including its in-place channel loop: channel 2 of the residual is
+    computed from the ALREADY REWRITTEN channel 0 (:218-219), which is reproduced here."""
+    mv = _resize_hwc(torch.as_tensor(motion_vector).float(), im_scale, im_scale)
+    res = _resize_hwc(torch.as_tensor(res_diff).float(), im_scale, im_scale)
+    im_h, im_w = res.shape[0], res.shape[1]
+    p_h = int(np.ceil(im_h / float(rcnn_stride)) * rcnn_stride)
+    p_w = int(np.ceil(im_w / float(rcnn_stride)) * rcnn_stride)
+    pmv = torch.zeros((p_h, p_w, 2), dtype=torch.float32, device=mv.device)
+    pres = torch.zeros((p_h, p_w, 3), dtype=torch.float32, device=mv.device)
+    pmv[:im_h, :im_w] = mv
+    pres[:im_h, :im_w] = res
+    means = [float(m) for m in pixel_means]
+    for i in range(3):     # the reference's in-place loop, in the same order
+        pres[:, :, i] = (pres[:, :, 2 - i] - means[2 - i]) * pixel_scale
+    s = 1.0 / rcnn_stride
+    rmv = _resize_hwc(pmv, s, s) * (im_scale * s)
+    rres = _resize_hwc(pres, s, s)
+    return rmv.permute(2, 0, 1).unsqueeze(0).contiguous(), rres.permute(2, 0, 1).unsqueeze(0).contiguous()

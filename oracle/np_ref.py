@@ -168,3 +168,67 @@ def shard_videos(seg_lens, gpu_num):
         shards[g].append(vid)
         acc[g] += L
     return shards
+
+
+# ---- lib/utils/image.py:202-308 with cv2.resize(INTER_LINEAR) restated -------------------
+def cv2_resize_linear(src, fx, fy):
+    """cv2.resize(src, None, None, fx, fy, INTER_LINEAR) for float images (OpenCV 3.2 resize.cpp:
+    dsize = cvRound(size*f); scale = src/dst; source coordinate (d + 0.5)*scale - 0.5, clamped so
+    that the two taps stay inside; horizontal pass then vertical pass) [un-vendored, parity unpinned]."""
+    src = np.asarray(src, dtype=np.float32)
+    sh, sw = src.shape[:2]
+    dh, dw = int(np.rint(sh * fy)), int(np.rint(sw * fx))
+
+    def taps(dn, sn):
+        scale = sn / float(dn)
+        f = (np.arange(dn, dtype=np.float64) + 0.5) * scale - 0.5
+        s0 = np.floor(f).astype(np.int64)
+        a = (f - s0).astype(np.float32)
+        lo = s0 < 0
+        s0[lo], a[lo] = 0, 0.0
+        hi = s0 >= sn - 1
+        s0[hi], a[hi] = sn - 1, 0.0
+        return s0, np.minimum(s0 + 1, sn - 1), a
+
+    x0, x1, ax = taps(dw, sw)
+    y0, y1, ay = taps(dh, sh)
+    src3 = src.reshape(sh, sw, -1)
+    hor = src3[:, x0] * (1 - ax)[None, :, None] + src3[:, x1] * ax[None, :, None]
+    out = hor[y0] * (1 - ay)[:, None, None] + hor[y1] * ay[:, None, None]
+    return out.astype(np.float32).reshape((dh, dw) + src.shape[2:])
+
+
+def transform_mv_res(motion_vector, res_diff, im_scale, pixel_means, pixel_scale, rcnn_stride=16):
+    motion_vector = cv2_resize_linear(motion_vector.astype(np.float32), im_scale, im_scale)
+    res_diff = cv2_resize_linear(res_diff.astype(np.float32), im_scale, im_scale)
+    im_h, im_w, _ = res_diff.shape
+    p_im_h = int(np.ceil(im_h / float(rcnn_stride)) * rcnn_stride)
+    p_im_w = int(np.ceil(im_w / float(rcnn_stride)) * rcnn_stride)
+    padded_motion_vector = np.zeros((p_im_h, p_im_w, 2))
+    padded_res_diff = np.zeros((p_im_h, p_im_w, 3))
+    padded_motion_vector[:im_h, :im_w] = motion_vector
+    padded_res_diff[:im_h, :im_w] = res_diff
+    for i in range(3):
+        padded_res_diff[:, :, i] = (padded_res_diff[:, :, 2 - i] - pixel_means[2 - i]) * pixel_scale
+    rcnn_scale = 1.0 / rcnn_stride
+    resize_motion_vector = cv2_resize_linear(padded_motion_vector, rcnn_scale, rcnn_scale).astype(np.float64)
+    resize_res_diff = cv2_resize_linear(padded_res_diff, rcnn_scale, rcnn_scale)
+    resize_motion_vector *= im_scale * rcnn_scale
+    th, tw, _ = resize_res_diff.shape
+    return (resize_motion_vector.transpose((2, 0, 1)).reshape(1, 2, th, tw),
+            resize_res_diff.transpose((2, 0, 1)).reshape(1, 3, th, tw))
+
+
+def resize_scale(im_shape, target_size, max_size):
+    im_size_min, im_size_max = np.min(im_shape[0:2]), np.max(im_shape[0:2])
+    im_scale = float(target_size) / float(im_size_min)
+    if np.round(im_scale * im_size_max) > max_size:
+        im_scale = float(max_size) / float(im_size_max)
+    return im_scale
+
+
+def transform(im, pixel_means, pixel_scale):
+    im_tensor = np.zeros((1, 3, im.shape[0], im.shape[1]))
+    for i in range(3):
+        im_tensor[0, i, :, :] = im[:, :, 2 - i] - pixel_means[2 - i]
+    return im_tensor * pixel_scale

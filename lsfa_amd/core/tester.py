@@ -73,6 +73,29 @@ def im_detect(predictor, data_batch, data_names, scales, cfg):
     return scores_all, pred_boxes_all, data_dict_all, feat
 
 
+def im_batch_detect(predictor, data_batch, data_names, scales, cfg):
+    """dff_rfcn/core/tester.py:163-189 for the batch symbol: rois of image i are rows
+    [i*post_n, (i+1)*post_n) of rois_output (MultiProposal's layout), decoded per image against its
+    own im_info and scale.  Returns host arrays like the reference."""
+    output_all = predictor.predict(data_batch)
+    data_dict_all = [dict(zip(data_names, data_batch.data[i])) for i in range(len(data_batch.data))]
+    scores_all, pred_boxes_all = [], []
+    for output, data_dict, scale in zip(output_all, data_dict_all, scales):
+        im_infos = data_dict['im_info'].cpu().numpy()
+        scores = output['cls_prob_reshape_output'][0]
+        bbox_deltas = output['bbox_pred_reshape_output'][0]
+        rois = output['rois_output']
+        post_n = rois.shape[0] // im_infos.shape[0]
+        for im_idx in range(im_infos.shape[0]):
+            sl = slice(im_idx * post_n, (im_idx + 1) * post_n)
+            im_shape = im_infos[im_idx, :2].astype(np.int64)
+            pred_boxes = hip.bbox_pred_clip(rois[sl], bbox_deltas[sl], float(im_shape[0]), float(im_shape[1]),
+                                            float(scale[im_idx]))
+            scores_all.append(scores[sl].cpu().numpy())
+            pred_boxes_all.append(pred_boxes.cpu().numpy())
+    return scores_all, pred_boxes_all, data_dict_all
+
+
 def pred_eval(gpu_id, key_predictor, cur_predictor, test_data, imdb, cfg, vis=False, thresh=1e-4, logger=None,
               ignore_cache=True):
     """Frame loop of tester.py:192-299.  Returns (all_boxes, frame_ids) with

@@ -104,6 +104,16 @@ def key_symbol_spec(cfg):
     return arg, aux
 
 
+def batch_symbol_spec(cfg):
+    """get_batch_test_symbol (:661-751): backbone + FlowNet + heads, no aggregation nets."""
+    arg, aux = OrderedDict(), OrderedDict()
+    resnet_spec(arg, aux, '', add_dcn=cfg.network.add_dcn)
+    _conv(arg, 'feat_conv_3x3', 1024, 2048, 3)
+    flownet_spec(arg)
+    head_spec(arg, cfg)
+    return arg, aux
+
+
 def cur_symbol_spec(cfg):
     arg, aux = OrderedDict(), OrderedDict()
     if cfg.network.rnet_num_conv != 0 or cfg.network.res_diff_bn or cfg.network.fuse_type != 'add' \

@@ -38,12 +38,16 @@ class TestSymbol(object):
     """What get_*_test_symbol returns: names + shapes + bind()."""
 
     def __init__(self, kind, cfg):
-        assert kind in ('key', 'cur')
+        assert kind in ('key', 'cur', 'batch')
         self.kind = kind
         self.cfg = cfg
-        self.arg_spec, self.aux_spec = (P.key_symbol_spec if kind == 'key' else P.cur_symbol_spec)(cfg)
-        self.data_names = ['data', 'im_info', 'data_key', 'data_key_old', 'motion_vector', 'res_diff',
-                           'feat_key_old', 'feat_key']
+        self.arg_spec, self.aux_spec = {'key': P.key_symbol_spec, 'cur': P.cur_symbol_spec,
+                                        'batch': P.batch_symbol_spec}[kind](cfg)
+        if kind == 'batch':
+            self.data_names = ['data_key', 'data_other', 'im_info']
+        else:
+            self.data_names = ['data', 'im_info', 'data_key', 'data_key_old', 'motion_vector', 'res_diff',
+                               'feat_key_old', 'feat_key']
 
     def list_arguments(self):
         return list(self.data_names) + list(self.arg_spec.keys())
@@ -52,6 +56,8 @@ class TestSymbol(object):
         return list(self.aux_spec.keys())
 
     def list_outputs(self):
+        if self.kind == 'batch':  # Group at :749
+            return ['rois_output', 'cls_prob_reshape_output', 'bbox_pred_reshape_output']
         if self.kind == 'key':   # Group at :549
             return ['data_key', 'motion_vector', 'res_diff', 'feat_key', 'choose_feat_output', 'rois_output',
                     'cls_prob_reshape_output', 'bbox_pred_reshape_output']
@@ -59,6 +65,14 @@ class TestSymbol(object):
                 'bbox_pred_reshape_output']   # Group at :657
 
     def infer_shape(self, **data_shapes):
+        if self.kind == 'batch':
+            nb = 1 + data_shapes['data_other'][0]
+            post, ncls = self.cfg.TEST.RPN_POST_NMS_TOP_N, self.cfg.dataset.NUM_CLASSES
+            nreg = 2 if self.cfg.CLASS_AGNOSTIC else ncls
+            outs = [(nb * post, 5), (self.cfg.TEST.BATCH_IMAGES, nb * post // self.cfg.TEST.BATCH_IMAGES, ncls),
+                    (self.cfg.TEST.BATCH_IMAGES, nb * post // self.cfg.TEST.BATCH_IMAGES, 4 * nreg)]
+            args = [tuple(data_shapes.get(k)) if k in data_shapes else None for k in self.data_names] + list(self.arg_spec.values())
+            return args, outs, list(self.aux_spec.values())
         n, _, h, w = data_shapes['data']
         fh, fw = int(np.ceil(h / 16.0)), int(np.ceil(w / 16.0))
         post = self.cfg.TEST.RPN_POST_NMS_TOP_N
@@ -99,7 +113,8 @@ class resnet_v1_101_flownet_rfcn(object):
         return self.sym
 
     def get_batch_test_symbol(self, cfg):
-        raise NotImplementedError("get_batch_test_symbol (:661-751) is a §8(f) 'next' row")
+        self.sym = TestSymbol('batch', cfg)
+        return self.sym
 
     def get_train_symbol(self, cfg):
         raise NotImplementedError("training is out of scope (SURVEY.md §8)")
@@ -240,12 +255,14 @@ class Executor(object):
                                        ratios=cfg.network.ANCHOR_RATIOS, rpn_pre_nms_top_n=cfg.TEST.RPN_PRE_NMS_TOP_N,
                                        rpn_post_nms_top_n=cfg.TEST.RPN_POST_NMS_TOP_N, threshold=cfg.TEST.RPN_NMS_THRESH,
                                        rpn_min_size=cfg.TEST.RPN_MIN_SIZE)
-        if sym.kind == 'key':
+        if sym.kind in ('key', 'batch'):
             self.net = _ResNetWeights(arg, aux, '', 4, cfg.network.add_dcn, True, dev, cd)
             self.feat_w, self.feat_b = _t(arg['feat_conv_3x3_weight'], dev, cd), _t(arg['feat_conv_3x3_bias'], dev, cd)
             self.flow = {k: _t(v, dev, cd) for k, v in arg.items()
                          if k.startswith(('flow_conv1', 'conv', 'Convolution', 'deconv', 'upsample_flow')) and 'stage' not in k and not k.startswith('conv0')}
-            if cfg.network.add_Nq_net:
+            if sym.kind == 'batch':
+                pass
+            elif cfg.network.add_Nq_net:
                 self.nq = [(_t(arg['Nq_conv%d_weight' % i], dev, cd), _t(arg['Nq_conv%d_bias' % i], dev, cd)) for i in (1, 2, 3)]
             elif cfg.network.add_Fgfa_net:
                 self.em = [(_t(arg['em_conv%d_weight' % i], dev, cd), _t(arg['em_conv%d_bias' % i], dev, cd)) for i in (1, 2, 3)]
@@ -420,7 +437,24 @@ class Executor(object):
     # ---- forward ---------------------------------------------------------------------
     def forward(self, **inputs):
         with torch.no_grad():
+            if self.sym.kind == 'batch':
+                return self._forward_batch(inputs)
             return self._forward_key(inputs) if self.sym.kind == 'key' else self._forward_cur(inputs)
+
+    def _forward_batch(self, d):
+        """get_batch_test_symbol (:661-751): one key frame + N other frames in one pass.  tile_as
+        (operator_py/tile_as.py:16-19) is a broadcast view for FlowNet's reference image and the
+        warp kernel's feat_n = 1 mode for the key feature (no (N,1024,h,w) copy)."""
+        data_key, data_other = d['data_key'], d['data_other']
+        n = data_other.shape[0]
+        conv_feat_key = self._backbone(data_key)
+        flow, scale_map = self._flownet(data_other, data_key.expand(n, -1, -1, -1))
+        conv_feat_other = hip.warp_bilinear(conv_feat_key, flow, mul=scale_map)
+        if self.taps is not None:
+            self.taps.update(backbone_feat=conv_feat_key, flow=flow, scale_map=scale_map, warp=conv_feat_other)
+        conv_feat = torch.cat([conv_feat_key, conv_feat_other], 0)
+        rois, cls_prob, bbox_pred = self._heads(conv_feat, d['im_info'])
+        return {'rois_output': rois, 'cls_prob_reshape_output': cls_prob, 'bbox_pred_reshape_output': bbox_pred}
 
     def _forward_key(self, d):
         cfg = self.cfg

@@ -208,3 +208,22 @@ def cur_forward(cfg, arg, aux, data, feat_key, motion_vector, res_diff, im_info)
         rois, cls_prob, bbox_pred = detect_from_maps(prob, bbox, cls_map, box_map, im_info, cfg)
         out.update(rois_output=rois, cls_prob_reshape_output=cls_prob[None], bbox_pred_reshape_output=bbox_pred[None])
         return out
+
+
+def batch_forward(cfg, arg, aux, data_key, data_other, im_info):
+    """get_batch_test_symbol (:661-751): key frame + N others, tile_as, MultiProposal over the batch."""
+    p = Params(arg, aux)
+    with torch.no_grad():
+        out = {}
+        n = data_other.shape[0]
+        feat_key = get_resnet_v1(p, _T(data_key), cfg)
+        flow, scale_map = get_flownet(p, _T(data_other), _T(np.tile(data_key, (n, 1, 1, 1))))
+        out['flow'], out['scale_map'], out['backbone_feat'] = flow.numpy(), scale_map.numpy(), feat_key.numpy()
+        feat_other = oracle.warp_bilinear(np.tile(out['backbone_feat'], (n, 1, 1, 1)), out['flow'], mul=out['scale_map'])
+        out['warp'] = feat_other
+        conv_feat = torch.cat([feat_key, _T(feat_other)], 0)
+        prob, bbox, cls_map, box_map = head_maps(p, conv_feat, cfg)
+        out.update(rpn_cls_prob=prob.numpy(), rpn_bbox_pred=bbox.numpy(), cls_map=cls_map.numpy(), box_map=box_map.numpy())
+        rois, cls_prob, bbox_pred = detect_from_maps(prob, bbox, cls_map, box_map, im_info, cfg)
+        out.update(rois_output=rois, cls_prob_reshape_output=cls_prob[None], bbox_pred_reshape_output=bbox_pred[None])
+        return out

@@ -205,8 +205,10 @@ __device__ __forceinline__ void bitonic_sort_regs(uint64_t (&v)[kPerThread], uin
 //   [Kpad*8, +256)         misc
 //   [Kpad*8+256, ...)      lkeys (N*4, KEYS_LDS) — overlaid after the sort by the NMS state:
 //                          kept_box float4[1024] | kept_idx int[1024] | cand float4[64] | colsupp u64[64]
+//                          | kept_area float[1024] | alive_box float4[1024] | alive_idx int[1024]
 constexpr int kHistReplicas = 16;
-constexpr size_t kNmsStateBytes = 1024 * 16 + 1024 * 4 + 64 * 16 + 64 * 8 + 1024 * 4;
+constexpr size_t kNmsCoreBytes = 1024 * 16 + 1024 * 4 + 64 * 16 + 64 * 8 + 1024 * 4;   // survivors + step scratch
+constexpr size_t kNmsStateBytes = kNmsCoreBytes + 1024 * 16 + 1024 * 4;                 // + alive candidates of a chunk
 
 // devIoU(a, b) > thresh (multi_proposal.cu:252-260, :295) without the division, bit for bit:
 // q = fl32(inter / uni) exceeds thresh  <=>  inter / uni lies above the midpoint `mid` between
@@ -215,24 +217,52 @@ constexpr size_t kNmsStateBytes = 1024 * 16 + 1024 * 4 + 64 * 16 + 64 * 8 + 1024
 // rate on CDNA4) and the comparison is exact.  Degenerate unions (<= 0, NaN) take the division.
 struct IouTest { float thresh; double mid; int tie_up; int fast; };
 
-__device__ __forceinline__ bool iou_exceeds(const float4& a, float Sa, const float4& b, float Sb, const IouTest& t) {
+// branch-free fast form; `degenerate` is raised when the union is not positive (the exact test then
+// needs the real division: iou_exceeds_div)
+__device__ __forceinline__ bool iou_exceeds_fast(const float4& a, float Sa, const float4& b, float Sb, const IouTest& t,
+                                                 bool& degenerate) {
   const float left = fmaxf(a.x, b.x), right = fminf(a.z, b.z);
   const float top = fmaxf(a.y, b.y), bottom = fminf(a.w, b.w);
   const float width = fmaxf(right - left + 1, 0.f), height = fmaxf(bottom - top + 1, 0.f);
   const float interS = width * height;
   const float uni = Sa + Sb - interS;
+  degenerate = degenerate || !(uni > 0.f);
   const double lhs = (double)interS, rhs = t.mid * (double)uni;
-  bool r = lhs > rhs || (t.tie_up && lhs == rhs);
-  // wave-uniform branch (so the division really is skipped, not if-converted): taken only when
-  // some lane has a degenerate union or the threshold is outside the range the fast form covers
-  const bool slow = !t.fast || !(uni > 0.f);
-  if (__builtin_expect(__any(slow), 0)) {
-    if (slow) r = interS / uni > t.thresh;
+  return lhs > rhs || (t.tie_up && lhs == rhs);
+}
+__device__ __forceinline__ bool iou_exceeds_div(const float4& a, float Sa, const float4& b, float Sb, const IouTest& t) {
+  const float left = fmaxf(a.x, b.x), right = fminf(a.z, b.z);
+  const float top = fmaxf(a.y, b.y), bottom = fminf(a.w, b.w);
+  const float width = fmaxf(right - left + 1, 0.f), height = fmaxf(bottom - top + 1, 0.f);
+  const float interS = width * height;
+  return interS / (Sa + Sb - interS) > t.thresh;
+}
+// one pair (used where the loop is short); wave-uniform branch so the division is really skipped
+__device__ __forceinline__ bool iou_exceeds(const float4& a, float Sa, const float4& b, float Sb, const IouTest& t) {
+  bool degenerate = !t.fast;
+  bool r = iou_exceeds_fast(a, Sa, b, Sb, t, degenerate);
+  if (__builtin_expect(__any(degenerate), 0)) {
+    if (degenerate) r = iou_exceeds_div(a, Sa, b, Sb, t);
   }
   return r;
 }
+// candidate b against survivors [k0, k1) stepping by `stride`: branch-free main loop (LDS reads batch and
+// pipeline), and a division-based second pass only if some lane met a degenerate union
+__device__ __forceinline__ bool suppressed_by(const float4* kept_box, const float* kept_area, int k0, int k1, int stride,
+                                              const float4& b, float Sb, const IouTest& t) {
+  bool hit = false, degenerate = !t.fast;
+#pragma unroll 4
+  for (int k = k0; k < k1; k += stride) hit |= iou_exceeds_fast(kept_box[k], kept_area[k], b, Sb, t, degenerate);
+  if (__builtin_expect(__any(degenerate), 0)) {
+    if (degenerate) {
+      hit = false;
+      for (int k = k0; k < k1; k += stride) hit |= iou_exceeds_div(kept_box[k], kept_area[k], b, Sb, t);
+    }
+  }
+  return hit;
+}
 
-template <bool KEYS_LDS, int kPerThread, bool RADIX>
+template <bool KEYS_LDS, int kPerThread, bool RADIX, bool ALIVE_BOX>
 __global__ __launch_bounds__(kTopkThreads) void proposal_select_nms_kernel(
     const uint32_t* __restrict__ keys_all, const float4* __restrict__ boxes_all, int N, int K, int Kpad,
     int sort_bytes, IouTest iou, int post_n, float* __restrict__ rois, float* __restrict__ scores,
@@ -412,110 +442,121 @@ __global__ __launch_bounds__(kTopkThreads) void proposal_select_nms_kernel(
 
   LSFA_STAMP(4);
   // ---- greedy NMS over the sorted candidates, IoU on the fly against the survivors --------
-  // (same decisions as nms_kernel + the host sweep, multi_proposal.cu:262-357).  Per block of 64
-  // candidates: wave q tests candidate `lane` against survivors q, q+16, ...; then the 64x64
-  // in-block relation is built column-wise by ballots and resolved by a 64-step scalar loop.
+  // (same decisions as nms_kernel + the host sweep, multi_proposal.cu:262-357).  Candidates are
+  // taken 1024 at a time: every thread tests ONE candidate against all survivors so far (no
+  // barriers, full occupancy — in the heavy-overlap regime this discards ~95 % of them), the
+  // still-alive ones are compacted in order, and only those go through the 64-wide step that
+  // tests them against the survivors added since (waves split that short list), builds the
+  // in-block relation with ballots and resolves it as a fixpoint.
   float4* kept_box = reinterpret_cast<float4*>(region);
   int* kept_idx = reinterpret_cast<int*>(region + 1024 * 16);
   float4* cand_lds = reinterpret_cast<float4*>(region + 1024 * 16 + 1024 * 4);
   uint64_t* colsupp = reinterpret_cast<uint64_t*>(region + 1024 * 16 + 1024 * 4 + 64 * 16);
   float* kept_area = reinterpret_cast<float*>(region + 1024 * 16 + 1024 * 4 + 64 * 16 + 64 * 8);
+  float4* alive_box = reinterpret_cast<float4*>(region + kNmsCoreBytes);            // 1024
+  int* alive_idx = reinterpret_cast<int*>(region + kNmsCoreBytes + (ALIVE_BOX ? 1024 * 16 : 0));   // 1024
   unsigned int* supp = reinterpret_cast<unsigned int*>(misc + 4);  // 2 words
   if (tid == 0) { misc[3] = 0; supp[0] = 0; supp[1] = 0; }
-  const int nblocks = (K + 63) / 64;
-  float4 next_cand = make_float4(0.f, 0.f, 0.f, 0.f);
-  if (wid == 0 && lane < K) next_cand = boxes[(uint32_t)sortbuf[lane]];
   __syncthreads();
   int num = 0;
   int dbg_blocks = 0;
   unsigned long long dbg_a = 0, dbg_b = 0, dbg_c = 0, dbg_t = 0;
-  for (int b = 0; b < nblocks && num < post_n; ++b) {
-    ++dbg_blocks;
+  for (int chunk = 0; chunk < K && num < post_n; chunk += kTopkThreads) {
     if (stamps) dbg_t = __builtin_readcyclecounter();
-    const int base = b * 64;
-    const int nb = min(64, K - base);
-    if (wid == 0) {
-      cand_lds[lane] = next_cand;
-      const int nxt = base + 64 + lane;
-      if (nxt < K) next_cand = boxes[(uint32_t)sortbuf[nxt]];   // prefetch the next block's boxes
-    }
-    __syncthreads();
-    const float4 cb = cand_lds[lane];
-    const float carea = (cb.z - cb.x + 1) * (cb.w - cb.y + 1);
-    bool s = false;
-    for (int k = wid; k < num; k += kTopkThreads / 64)
-      s |= iou_exceeds(kept_box[k], kept_area[k], cb, carea, iou);
-    const unsigned long long bal = __ballot(s && lane < nb);
-    if (lane == 0 && bal) {
-      atomicOr(&supp[0], (unsigned int)bal);
-      atomicOr(&supp[1], (unsigned int)(bal >> 32));
-    }
+    // -- filter: one candidate per thread against the survivors so far
+    const int ci = chunk + tid;
+    const bool valid = ci < K;
+    const float4 mybox = valid ? boxes[(uint32_t)sortbuf[ci]] : make_float4(0.f, 0.f, 0.f, 0.f);
+    const float myarea = (mybox.z - mybox.x + 1) * (mybox.w - mybox.y + 1);
+    bool dead = !valid;
+    dead = dead || suppressed_by(kept_box, kept_area, 0, num, 1, mybox, myarea, iou);
+    // -- ordered compaction of the alive candidates
+    int total_alive;
+    const int apos = block_exclusive_scan(dead ? 0 : 1, misc + 8, &total_alive);
+    if (!dead) { if (ALIVE_BOX) alive_box[apos] = mybox; alive_idx[apos] = ci; }
     __syncthreads();
     if (stamps) { const unsigned long long t1 = __builtin_readcyclecounter(); dbg_a += t1 - dbg_t; dbg_t = t1; }
-    // in-block relation, only among the candidates still alive after the survivor test: wave q
-    // takes the q-th, (q+16)-th, ... alive candidate as column j and ballots the rows that suppress it
-    {
-      const uint64_t sprev_u = ((uint64_t)supp[1] << 32) | supp[0];
-      const uint64_t valid = nb == 64 ? ~0ULL : ((1ULL << nb) - 1ULL);
-      uint64_t am = valid & ~sprev_u;                       // wave-uniform
-      const bool row_alive = (am >> lane) & 1ULL;
-      if (__popcll(am) <= kTopkThreads / 64) {
-        // few alive (the common case once survivors accumulate): one column per wave
-        for (int skip = 0; skip < wid && am; ++skip) am &= am - 1;
-        if (am) {
-          const int j = __builtin_ctzll(am);
-          const float4 jb = cand_lds[j];
-          const float jarea = (jb.z - jb.x + 1) * (jb.w - jb.y + 1);
-          const bool pred = row_alive && (lane < j) && iou_exceeds(cb, carea, jb, jarea, iou);
-          const unsigned long long col = __ballot(pred);
-          if (lane == 0) colsupp[j] = col;
-        }
-      } else {
+    const int m0 = num;   // survivors the filter already accounted for
+    for (int base = 0; base < total_alive && num < post_n; base += 64) {
+      ++dbg_blocks;
+      if (stamps) dbg_t = __builtin_readcyclecounter();
+      const int nb = min(64, total_alive - base);
+      const float4 cb = lane < nb ? (ALIVE_BOX ? alive_box[base + lane] : boxes[(uint32_t)sortbuf[alive_idx[base + lane]]])
+                                  : make_float4(0.f, 0.f, 0.f, 0.f);
+      const float carea = (cb.z - cb.x + 1) * (cb.w - cb.y + 1);
+      if (wid == 0) cand_lds[lane] = cb;
+      // survivors added since the filter (earlier steps of this chunk), split over the waves
+      const bool s = suppressed_by(kept_box, kept_area, m0 + wid, num, kTopkThreads / 64, cb, carea, iou);
+      const unsigned long long bal = __ballot(s && lane < nb);
+      if (lane == 0 && bal) {
+        atomicOr(&supp[0], (unsigned int)bal);
+        atomicOr(&supp[1], (unsigned int)(bal >> 32));
+      }
+      __syncthreads();
+      // in-block relation, only among the candidates still alive: wave q takes the q-th alive one as
+      // column j (or four fixed columns when many are alive) and ballots the rows that suppress it
+      {
+        const uint64_t sprev_u = ((uint64_t)supp[1] << 32) | supp[0];
+        const uint64_t valid_m = nb == 64 ? ~0ULL : ((1ULL << nb) - 1ULL);
+        uint64_t am = valid_m & ~sprev_u;                       // wave-uniform
+        const bool row_alive = (am >> lane) & 1ULL;
+        if (__popcll(am) <= kTopkThreads / 64) {
+          for (int skip = 0; skip < wid && am; ++skip) am &= am - 1;
+          if (am) {
+            const int j = __builtin_ctzll(am);
+            const float4 jb = cand_lds[j];
+            const float jarea = (jb.z - jb.x + 1) * (jb.w - jb.y + 1);
+            const bool pred = row_alive && (lane < j) && iou_exceeds(cb, carea, jb, jarea, iou);
+            const unsigned long long col = __ballot(pred);
+            if (lane == 0) colsupp[j] = col;
+          }
+        } else {
 #pragma unroll
-        for (int jj = 0; jj < 4; ++jj) {
-          const int j = wid * 4 + jj;
-          const float4 jb = cand_lds[j];
-          const float jarea = (jb.z - jb.x + 1) * (jb.w - jb.y + 1);
-          const bool pred = row_alive && (lane < j) && (j < nb) && iou_exceeds(cb, carea, jb, jarea, iou);
-          const unsigned long long col = __ballot(pred);
-          if (lane == 0) colsupp[j] = col;
+          for (int jj = 0; jj < 4; ++jj) {
+            const int j = wid * 4 + jj;
+            const float4 jb = cand_lds[j];
+            const float jarea = (jb.z - jb.x + 1) * (jb.w - jb.y + 1);
+            const bool pred = row_alive && (lane < j) && (j < nb) && iou_exceeds(cb, carea, jb, jarea, iou);
+            const unsigned long long col = __ballot(pred);
+            if (lane == 0) colsupp[j] = col;
+          }
         }
       }
+      __syncthreads();
+      if (stamps) { const unsigned long long t1 = __builtin_readcyclecounter(); dbg_b += t1 - dbg_t; dbg_t = t1; }
+      if (wid == 0) {
+        // In-block greedy as a fixpoint: G(k) = alive(k) && no earlier j in G suppresses k.  Starting
+        // from G = alive, iteration t fixes the first t decisions, so it converges to the serial
+        // sweep's answer in (dependency-chain depth) rounds — a handful — instead of 64 scalar steps.
+        const uint64_t col = colsupp[lane];
+        const uint64_t sprev = ((uint64_t)supp[1] << 32) | supp[0];
+        const bool alive = lane < nb && !((sprev >> lane) & 1ULL);
+        uint64_t G = __ballot(alive);
+        for (int it = 0; it < 64; ++it) {
+          const uint64_t G2 = __ballot(alive && (col & G) == 0);
+          if (G2 == G) break;
+          G = G2;
+        }
+        // keep only as many as the output still needs (later survivors never affect earlier ones)
+        const int budget = post_n - num;
+        uint64_t kept = G;
+        if (__popcll(G) > budget) {
+          const bool mine = (G >> lane) & 1ULL;
+          const int rank = __popcll(G & ((1ULL << lane) - 1ULL));
+          kept = __ballot(mine && rank < budget);
+        }
+        if ((kept >> lane) & 1ULL) {
+          const int pos = num + __popcll(kept & ((1ULL << lane) - 1ULL));
+          kept_box[pos] = cb;
+          kept_area[pos] = carea;
+          kept_idx[pos] = alive_idx[base + lane];
+        }
+        if (lane == 0) { misc[3] = num + __popcll(kept); supp[0] = 0; supp[1] = 0; }
+      }
+      __syncthreads();
+      if (stamps) { const unsigned long long t1 = __builtin_readcyclecounter(); dbg_c += t1 - dbg_t; dbg_t = t1; }
+      num = misc[3];
     }
-    __syncthreads();
-    if (stamps) { const unsigned long long t1 = __builtin_readcyclecounter(); dbg_b += t1 - dbg_t; dbg_t = t1; }
-    if (wid == 0) {
-      // In-block greedy as a fixpoint: G(k) = alive(k) && no earlier j in G suppresses k.  Starting
-      // from G = alive, iteration t fixes the first t decisions, so it converges to the serial
-      // sweep's answer in (dependency-chain depth) rounds — a handful — instead of 64 scalar steps.
-      const uint64_t col = colsupp[lane];
-      const uint64_t sprev = ((uint64_t)supp[1] << 32) | supp[0];
-      const bool alive = lane < nb && !((sprev >> lane) & 1ULL);
-      uint64_t G = __ballot(alive);
-      for (int it = 0; it < 64; ++it) {
-        const uint64_t G2 = __ballot(alive && (col & G) == 0);
-        if (G2 == G) break;
-        G = G2;
-      }
-      // keep only as many as the output still needs (later survivors never affect earlier ones)
-      const int budget = post_n - num;
-      uint64_t kept = G;
-      if (__popcll(G) > budget) {
-        const bool mine = (G >> lane) & 1ULL;
-        const int rank = __popcll(G & ((1ULL << lane) - 1ULL));
-        kept = __ballot(mine && rank < budget);
-      }
-      if ((kept >> lane) & 1ULL) {
-        const int pos = num + __popcll(kept & ((1ULL << lane) - 1ULL));
-        kept_box[pos] = cb;
-        kept_area[pos] = carea;
-        kept_idx[pos] = base + lane;
-      }
-      if (lane == 0) { misc[3] = num + __popcll(kept); supp[0] = 0; supp[1] = 0; }
-    }
-    __syncthreads();
-    if (stamps) { const unsigned long long t1 = __builtin_readcyclecounter(); dbg_c += t1 - dbg_t; dbg_t = t1; }
-    num = misc[3];
   }
 
   LSFA_STAMP(5);
@@ -612,10 +653,10 @@ extern "C" int lsfa_proposal(const float* cls_prob, const float* bbox_pred, cons
   const size_t kLdsMax = 160 * 1024;
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute((const void*)proposal_select_nms_kernel<true, 8, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsMax);
-    (void)hipFuncSetAttribute((const void*)proposal_select_nms_kernel<false, 8, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsMax);
-    (void)hipFuncSetAttribute((const void*)proposal_select_nms_kernel<false, 8, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsMax);
-    (void)hipFuncSetAttribute((const void*)proposal_select_nms_kernel<false, 16, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsMax);
+    (void)hipFuncSetAttribute((const void*)proposal_select_nms_kernel<true, 8, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsMax);
+    (void)hipFuncSetAttribute((const void*)proposal_select_nms_kernel<false, 8, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsMax);
+    (void)hipFuncSetAttribute((const void*)proposal_select_nms_kernel<false, 8, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsMax);
+    (void)hipFuncSetAttribute((const void*)proposal_select_nms_kernel<false, 16, false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsMax);
     attr_set = true;
   }
   // radix path: sort buffer A = K*8 (>= the 16 KB of select histograms), region = buffer B + counters
@@ -626,14 +667,16 @@ extern "C" int lsfa_proposal(const float* cls_prob, const float* bbox_pred, cons
   const size_t lds_radix_keys = sortA + 256 + align_up(((size_t)count * 4 > region_min ? (size_t)count * 4 : region_min), 16);
   const size_t lds_radix = sortA + 256 + align_up(region_min, 16);
   const size_t lds_bitonic = (size_t)Kpad * 8 + 256 + kNmsStateBytes;
-#define LSFA_LAUNCH_SELECT(KL, PER, RAD, LDS, SORTB)                                                         \
-  hipLaunchKernelGGL((proposal_select_nms_kernel<KL, PER, RAD>), dim3(B), dim3(kTopkThreads), (LDS), s,       \
+#define LSFA_LAUNCH_SELECT(KL, PER, RAD, AB, LDS, SORTB)                                                     \
+  hipLaunchKernelGGL((proposal_select_nms_kernel<KL, PER, RAD, AB>), dim3(B), dim3(kTopkThreads), (LDS), s,   \
                      (const uint32_t*)keys, (const float4*)boxes, count, pre_n, Kpad, (int)(SORTB), iou, post_n, \
                      rois, scores, g_stamps)
-  if (pre_n <= 8192 && lds_radix_keys <= kLdsMax) LSFA_LAUNCH_SELECT(true, 8, true, lds_radix_keys, sortA);
-  else if (pre_n <= 8192 && lds_radix <= kLdsMax) LSFA_LAUNCH_SELECT(false, 8, true, lds_radix, sortA);
-  else if (Kpad <= 8192) LSFA_LAUNCH_SELECT(false, 8, false, lds_bitonic, (size_t)Kpad * 8);
-  else LSFA_LAUNCH_SELECT(false, 16, false, lds_bitonic, (size_t)Kpad * 8);
+  // 8193..16384 candidates: 128 KB sort buffer, so the alive list keeps indices only (boxes re-read from L2)
+  const size_t lds_bitonic16 = (size_t)Kpad * 8 + 256 + kNmsCoreBytes + 1024 * 4;
+  if (pre_n <= 8192 && lds_radix_keys <= kLdsMax) LSFA_LAUNCH_SELECT(true, 8, true, true, lds_radix_keys, sortA);
+  else if (pre_n <= 8192 && lds_radix <= kLdsMax) LSFA_LAUNCH_SELECT(false, 8, true, true, lds_radix, sortA);
+  else if (Kpad <= 8192) LSFA_LAUNCH_SELECT(false, 8, false, true, lds_bitonic, (size_t)Kpad * 8);
+  else LSFA_LAUNCH_SELECT(false, 16, false, false, lds_bitonic16, (size_t)Kpad * 8);
 #undef LSFA_LAUNCH_SELECT
   LSFA_LAUNCH_CHECK("lsfa_proposal");
   return LSFA_OK;

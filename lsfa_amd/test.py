@@ -1,0 +1,81 @@
+#!/usr/bin/env python
+"""Python-3 counterpart of dff_rfcn/test.py (:24-58) + experiments/dff_rfcn/dff_rfcn_test.py:
+parse --cfg, build the test symbols, shard videos over the ranks, run pred_eval, gather, report.
+
+    python -m lsfa_amd.test [--cfg YAML] [--clips N] [--frames F] [--height H] [--width W] [--prefix P --epoch E]
+    python -m torch.distributed.run --nproc-per-node 8 -m lsfa_amd.test --clips 8
+
+Without a dataset or weights in the image, clips are synthetic (lsfa_amd.utils.synthetic) and the
+weights are the seeded random init unless --prefix points at an MXNet `.params` checkpoint.
+"""
+import argparse
+import logging
+import os
+import time
+
+import torch
+import torch.distributed as dist
+
+from lsfa_amd.config.config import config, lsfa_test_config, update_config, update_network_config
+from lsfa_amd.function.test_rcnn import test_rcnn
+from lsfa_amd.symbols import params as P
+from lsfa_amd.symbols.resnet_v1_101_flownet_rfcn import resnet_v1_101_flownet_rfcn
+from lsfa_amd.utils.load_model import load_param
+from lsfa_amd.utils.synthetic import synthetic_roidb
+
+
+def parse_args():
+    ap = argparse.ArgumentParser(description='Test a LSFA (dff_rfcn) network')
+    ap.add_argument('--cfg', help='experiment configure file name', default=None, type=str)
+    ap.add_argument('--thresh', help='valid detection threshold', default=1e-4, type=float)
+    ap.add_argument('--clips', type=int, default=2)
+    ap.add_argument('--frames', type=int, default=24)
+    ap.add_argument('--height', type=int, default=600)
+    ap.add_argument('--width', type=int, default=1000)
+    ap.add_argument('--interval', type=int, default=None, help='override TEST.KEY_FRAME_INTERVAL')
+    ap.add_argument('--prefix', default=None, help='MXNet checkpoint prefix (prefix-%%04d.params)')
+    ap.add_argument('--epoch', type=int, default=0)
+    return ap.parse_args()
+
+
+def main():
+    args = parse_args()
+    if args.cfg:
+        cfg = update_config(args.cfg, config)
+        update_network_config(cfg)
+    else:
+        cfg = lsfa_test_config()
+    if args.interval:
+        cfg.TEST.KEY_FRAME_INTERVAL = args.interval
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
+    logging.basicConfig(level=logging.INFO, format='%(asctime)s %(message)s')
+    logger = logging.getLogger('lsfa')
+    roidb = synthetic_roidb(args.clips, args.frames, args.height, args.width, cfg.TEST.KEY_FRAME_INTERVAL)
+    if args.prefix:
+        arg_params, aux_params = load_param(args.prefix, args.epoch, process=True)
+        net = resnet_v1_101_flownet_rfcn(cfg)
+        for getter in (net.get_key_test_symbol, net.get_cur_test_symbol):
+            getter(cfg)
+            net.init_weight(cfg, arg_params, aux_params)
+    else:
+        arg_params, aux_params = P.init_params(cfg, seed=0)
+    t0 = time.time()
+    rows, frame_ids = test_rcnn(cfg, roidb, arg_params, aux_params, device='cuda:%d' % local_rank, thresh=args.thresh,
+                                logger=logger)
+    torch.cuda.synchronize()
+    dt = time.time() - t0
+    if not dist.is_initialized() or dist.get_rank() == 0:
+        total = args.clips * args.frames
+        print('%d clips x %d frames on %d GPU(s): %d detections, %.1f frames/s incl. setup' % (
+            args.clips, args.frames, world, len(rows), total / dt))
+    if dist.is_initialized():
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

@@ -6,7 +6,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import bench
 from lsfa_amd import hip
 class A: pass
-a = A(); a.interval=10; a.height=600; a.width=1000; a.dtype='f32'; a.no_graph=True; a.steps=1; a.warmup=0; a.max_unique_steps=1
+a = A(); a.interval=10; a.height=600; a.width=1000; a.dtype='f32'; a.no_graph=True; a.no_prefetch=True; a.steps=1; a.warmup=0; a.max_unique_steps=1
 r = bench.Runner(a, 0, 'cuda:0')
 r.prime()
 stamps = torch.zeros(16, dtype=torch.int64, device='cuda:0')

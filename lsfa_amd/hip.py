@@ -28,8 +28,13 @@ def lib():
     global _lib
     if _lib is None:
         if not os.path.exists(LIB_PATH):
-            raise LsfaError("liblsfa_hip.so is not built (%s); run `python -m lsfa_amd.build` — "
-                            "there is no fallback path" % LIB_PATH)
+            # not a fallback: build the real library if the toolchain is here, else fail loudly
+            try:
+                from lsfa_amd import build as _build
+                _build.build_hip()
+            except Exception as e:
+                raise LsfaError("liblsfa_hip.so is not built (%s) and building it failed (%r); run "
+                                "`python -m lsfa_amd.build` — there is no fallback path" % (LIB_PATH, e))
         L = ctypes.CDLL(LIB_PATH)
         L.lsfa_last_error.restype = ctypes.c_char_p
         for name in ("lsfa_proposal_workspace_bytes", "lsfa_nms_workspace_bytes", "lsfa_det_workspace_bytes"):

@@ -176,11 +176,20 @@ def main():
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
     world = int(os.environ.get('WORLD_SIZE', '1'))
     distributed = world > 1
+    # test hook (one-GPU boxes): LSFA_BENCH_BACKEND=gloo LSFA_BENCH_ONE_DEVICE=1 runs every rank on cuda:0 and
+    # the collectives on CPU tensors, to exercise the N>1 control flow without N GPUs
+    backend = os.environ.get('LSFA_BENCH_BACKEND', 'nccl')
+    if os.environ.get('LSFA_BENCH_ONE_DEVICE') == '1':
+        local_rank = 0
     if distributed:
         import torch.distributed as dist
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         torch.cuda.set_device(local_rank)
-        dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
+        if backend == 'nccl':
+            dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
+        else:
+            dist.init_process_group(backend)
+    coll_dev = ('cuda:%d' % local_rank) if backend == 'nccl' else 'cpu'
     device = 'cuda:%d' % local_rank
     torch.cuda.set_device(local_rank)
     torch.backends.cudnn.benchmark = os.environ.get('LSFA_MIOPEN_FIND', '1') == '1'
@@ -194,7 +203,7 @@ def main():
 
     def barrier():
         if distributed:
-            dist.barrier(device_ids=[local_rank])
+            dist.barrier(device_ids=[local_rank]) if backend == 'nccl' else dist.barrier()
 
     barrier()
     torch.cuda.synchronize()
@@ -207,11 +216,11 @@ def main():
     prof = r.eager_profile_step(args.warmup) if rank == 0 else None
 
     if distributed:
-        tt = torch.tensor([elapsed], device=device, dtype=torch.float64)
+        tt = torch.tensor([elapsed], device=coll_dev, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
         # the final gather of detections (here: last interval's per-frame counts) over RCCL
-        counts = r.host_counts.to(device)
+        counts = r.host_counts.to(coll_dev)
         gathered = [torch.empty_like(counts) for _ in range(world)]
         dist.all_gather(gathered, counts)
         total_dets = int(sum(int(g.sum().item()) for g in gathered))
@@ -254,7 +263,7 @@ def main():
                                         "kind": "port", "sample": "failed: %r" % (e,)}
         print(json.dumps(line))
     if distributed:
-        dist.barrier(device_ids=[local_rank])
+        dist.barrier(device_ids=[local_rank]) if backend == 'nccl' else dist.barrier()
         dist.destroy_process_group()
 
 

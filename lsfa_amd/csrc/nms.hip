@@ -36,9 +36,8 @@ extern "C" int lsfa_nms_sorted(const float* boxes, int n, int box_dim, float thr
   ProfScope prof(LSFA_OP_NMS, s);
   hipLaunchKernelGGL(nms_mask_kernel, dim3(col_blocks, col_blocks, 1), dim3(64), 0, s, boxes, n, box_dim, thresh,
                      mask, col_blocks);
-  ProposalOut po{};
-  hipLaunchKernelGGL(nms_sweep_kernel<false>, dim3(1), dim3(64), 0, s, (const uint64_t*)mask, n, col_blocks, n,
-                     keep, num_keep, po);
+  hipLaunchKernelGGL(nms_sweep_kernel, dim3(1), dim3(64), 0, s, (const uint64_t*)mask, n, col_blocks, n, keep,
+                     num_keep);
   LSFA_LAUNCH_CHECK("lsfa_nms_sorted");
   return LSFA_OK;
 }

@@ -1,4 +1,4 @@
-// Device kernels shared by nms.hip (lsfa_nms_sorted, _nms) and proposal.hip.
+// Device kernels of nms.hip (lsfa_nms_sorted, _nms).
 //
 // Structure on CDNA4 (replaces nms_kernel + D2H of the 4.5 MB mask + serial host sweep +
 // H2D of the keep list, lib/nms/nms_kernel.cu:40-150, multi_proposal.cu:262-357):
@@ -9,8 +9,8 @@
 //      loads the 64 diagonal words (one per lane), resolves the block with a 64-step
 //      scalar loop on SGPRs (v_readlane of the diagonal word of each survivor), then ORs
 //      the survivors' mask rows into the removed-set kept in LDS, loads batched 8 rows
-//      at a time so their latencies overlap.  It stops as soon as `max_keep` survivors
-//      exist (Proposal only consumes the first post_nms_top_n).
+//      at a time so their latencies overlap.  It stops as soon as `max_keep` survivors exist.
+// (Proposal does not use these: it keeps everything in one workgroup's LDS, proposal.hip.)
 // devIoU arithmetic = oracle dev_iou (nms_kernel.cu:30-38), -ffp-contract=off.
 #pragma once
 #include "common.h"
@@ -62,26 +62,15 @@ static __global__ __launch_bounds__(64) void nms_mask_kernel(const float* __rest
 }
 
 constexpr int kSweepMaxBlocks = 512;   // n <= 32768
-constexpr int kSweepKeepLds = 1024;    // proposal: post_nms_top_n <= 1024
 
-struct ProposalOut {
-  const float4* sorted_boxes;  // (images, n)
-  const float* sorted_scores;  // (images, n)
-  float* rois;                 // (images*post_n, 5)
-  float* scores;               // (images*post_n) or NULL
-  int post_n;
-};
-
-// grid (images); block 64 (one wave).
-template <bool PROPOSAL>
-__global__ __launch_bounds__(64) void nms_sweep_kernel(const uint64_t* __restrict__ mask_all, int n,
-                                                       int col_blocks, int max_keep, int* __restrict__ keep_all,
-                                                       int* __restrict__ num_keep_all, ProposalOut po) {
+// grid (images); block 64 (one wave).  keep: (images, n) indices into boxes; num_keep: (images).
+__global__ __launch_bounds__(64) void nms_sweep_kernel(const uint64_t* __restrict__ mask_all, int n, int col_blocks,
+                                                       int max_keep, int* __restrict__ keep_all,
+                                                       int* __restrict__ num_keep_all) {
   __shared__ uint64_t remv[kSweepMaxBlocks];
-  __shared__ int skeep[PROPOSAL ? kSweepKeepLds : 1];
   const int img = blockIdx.x;
   const uint64_t* mask = mask_all + (size_t)img * n * col_blocks;
-  int* keep = keep_all ? keep_all + (size_t)img * n : nullptr;
+  int* keep = keep_all + (size_t)img * n;
   const int lane = threadIdx.x;
   for (int i = lane; i < col_blocks; i += 64) remv[i] = 0;
   __syncthreads();  // single-wave workgroup: orders the LDS accesses of different lanes
@@ -106,14 +95,10 @@ __global__ __launch_bounds__(64) void nms_sweep_kernel(const uint64_t* __restric
       }
     }
     const uint64_t kept = ((uint64_t)kept_hi << 32) | kept_lo;
-    if ((kept >> lane) & 1ULL) {
-      const int pos = num + __popcll(kept & ((1ULL << lane) - 1ULL));
-      if (keep) keep[pos] = base + lane;
-      if (PROPOSAL && pos < kSweepKeepLds) skeep[pos] = base + lane;
-    }
+    if ((kept >> lane) & 1ULL) keep[num + __popcll(kept & ((1ULL << lane) - 1ULL))] = base + lane;
     num += __popcll(kept);
     if (num >= max_keep || b + 1 >= col_blocks) break;
-    // OR the survivors' rows into remv for the blocks to the right of b
+    // OR the survivors' rows into remv for the blocks to the right of b, 8 rows per batch of loads
     uint64_t rem = kept;
     while (rem) {
       int ks[8];
@@ -135,22 +120,7 @@ __global__ __launch_bounds__(64) void nms_sweep_kernel(const uint64_t* __restric
     }
     __syncthreads();
   }
-  if (lane == 0 && num_keep_all) num_keep_all[img] = num;
-  if (PROPOSAL) {
-    // PrepareOutput, multi_proposal.cu:363-388: first post_n survivors, cyclic pad
-    __syncthreads();
-    const int out_size = num;
-    const float4* sb = po.sorted_boxes + (size_t)img * n;
-    const float* ss = po.sorted_scores + (size_t)img * n;
-    for (int index = lane; index < po.post_n; index += 64) {
-      const int keep_i = skeep[index < out_size ? index : index % out_size];
-      const float4 bx = sb[keep_i];
-      float* o = po.rois + ((size_t)img * po.post_n + index) * 5;
-      o[0] = (float)img;
-      o[1] = bx.x; o[2] = bx.y; o[3] = bx.z; o[4] = bx.w;
-      if (po.scores) po.scores[(size_t)img * po.post_n + index] = ss[keep_i];
-    }
-  }
+  if (lane == 0) num_keep_all[img] = num;
 }
 
 }  // namespace lsfa

@@ -14,7 +14,7 @@
 #include <math.h>
 #include <string.h>
 
-#include "nms_kernels.h"
+#include "common.h"
 
 using namespace lsfa;
 
@@ -619,9 +619,9 @@ extern "C" int lsfa_proposal(const float* cls_prob, const float* bbox_pred, cons
   const int count = A * H * W;
   const int pre_n = clamp_pre_n(rpn_pre_nms_top_n, count);
   const int post_n = rpn_post_nms_top_n < pre_n ? rpn_post_nms_top_n : pre_n;  // :437
-  if (pre_n > 16384 || post_n > kSweepKeepLds || B > 65535) {
+  if (pre_n > 16384 || post_n > 1024 || B > 65535) {
     set_error("lsfa_proposal: pre_nms_top_n %d (max 16384) / post_nms_top_n %d (max %d) unsupported", pre_n, post_n,
-              kSweepKeepLds);
+              1024);
     return LSFA_ENOTSUP;
   }
   const WsLayout l = ws_layout(B, count, pre_n);

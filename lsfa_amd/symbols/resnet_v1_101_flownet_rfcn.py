@@ -481,6 +481,7 @@ class Executor(object):
                 x = torch.relu_(F.conv2d(x, self.em[0][0], self.em[0][1]))
                 x = torch.relu_(F.conv2d(x, self.em[1][0], self.em[1][1], padding=1))
                 e = F.conv2d(x, self.em[2][0], self.em[2][1]).float()
+                self._tap('embed', e)
                 conv_feat = hip.aggregate_cosine(warp, conv_feat, e[1:2], e[0:1])
             else:
                 conv_feat = 0.5 * (warp + conv_feat)

@@ -138,6 +138,15 @@ def nq_logits(p, warp_feat, conv_feat):
     return F.conv2d(x, p.w('Nq_conv3_weight'), p.w('Nq_conv3_bias'))
 
 
+def embed(p, conv_feat, warp_feat):
+    """get_embednet on Concat(conv_feat, warp_feat) (symbols/resnet_v1_101_flownet_rfcn.py:118-135);
+    row 0 embeds the current feature, row 1 the warped one."""
+    x = torch.cat([conv_feat, warp_feat], 0)
+    x = F.relu(F.conv2d(x, p.w('em_conv1_weight'), p.w('em_conv1_bias')))
+    x = F.relu(F.conv2d(x, p.w('em_conv2_weight'), p.w('em_conv2_bias'), 1, 1))
+    return F.conv2d(x, p.w('em_conv3_weight'), p.w('em_conv3_bias'))
+
+
 def small_net_feature(p, data_cur):
     img = F.avg_pool2d(data_cur, 4, 4, ceil_mode=True)
     feats = resnet_backbone(p, img, prefix='small_net_', need_part=True, add_dcn=False, stages=1)
@@ -183,9 +192,15 @@ def key_forward(cfg, arg, aux, data, data_key_old, feat_key_old, im_info):
             out['flow'], out['scale_map'] = flow.numpy(), scale_map.numpy()
             warp = oracle.warp_bilinear(feat_key_old, out['flow'], mul=out['scale_map'])
             out['warp'] = warp
-            logits = nq_logits(p, _T(warp), conv_feat)
-            out['nq_logits'] = logits.numpy()
-            conv_feat = _T(oracle.aggregate_softmax2(warp, conv_feat.numpy(), out['nq_logits']))
+            if cfg.network.add_Nq_net:                          # :310-311
+                logits = nq_logits(p, _T(warp), conv_feat)
+                out['nq_logits'] = logits.numpy()
+                conv_feat = _T(oracle.aggregate_softmax2(warp, conv_feat.numpy(), out['nq_logits']))
+            elif cfg.network.add_Fgfa_net:                      # :312-313, Fgfa_net :132-148
+                out['embed'] = embed(p, conv_feat, _T(warp)).numpy()
+                conv_feat = _T(oracle.aggregate_cosine(warp, conv_feat.numpy(), out['embed'][1:2], out['embed'][0:1]))
+            else:                                               # :314-315
+                conv_feat = 0.5 * (_T(warp) + conv_feat)
         out['choose_feat_output'] = conv_feat.numpy()
         prob, bbox, cls_map, box_map = head_maps(p, conv_feat, cfg)
         out.update(rpn_cls_prob=prob.numpy(), rpn_bbox_pred=bbox.numpy(), cls_map=cls_map.numpy(), box_map=box_map.numpy())

@@ -271,3 +271,76 @@ def test_batch_symbol_tile_as_multiproposal(world):
     want = oracle.bbox_pred_clip(np_(out['rois_output'])[300:600], np_(out['bbox_pred_reshape_output'])[0, 300:600], H, W, 1.0)
     # im_batch_detect runs its own forward; MIOpen may pick another algorithm on the 2nd call -> fp32 round-off
     np.testing.assert_allclose(boxes_all[1], want, rtol=1e-5, atol=2e-3)
+
+
+@pytest.mark.parametrize("mode", ["fgfa", "average"])
+def test_key_graph_other_aggregations(mode):
+    """get_key_test_symbol's other two aggregation branches (symbols/resnet_v1_101_flownet_rfcn.py:312-315):
+    Fgfa cosine-similarity weights (:132-148) and the plain 0.5*(warp + cur) mean."""
+    from lsfa_amd.config.config import lsfa_test_config
+    from lsfa_amd.symbols import params as P
+    from lsfa_amd.symbols.resnet_v1_101_flownet_rfcn import resnet_v1_101_flownet_rfcn
+    from lsfa_amd.utils.synthetic import SyntheticClip
+    cfg = lsfa_test_config(key_frame_interval=10)
+    cfg.network.add_Nq_net = False
+    cfg.network.add_Fgfa_net = (mode == "fgfa")
+    arg, aux = P.init_params(cfg, seed=5)
+    key = resnet_v1_101_flownet_rfcn(cfg).get_key_test_symbol(cfg).bind(arg, aux, DEV)
+    clip = SyntheticClip(1, 12, H, W)
+    im_info = clip.im_info()
+    im_info_t = torch.from_numpy(im_info).to(DEV)
+    f0, f10 = clip.frame(0).to(DEV), clip.frame(10).to(DEV)
+    feat0 = key.forward(data=f0, im_info=im_info_t, data_key_old=f0,
+                        feat_key_old=torch.zeros(1, 1024, 1, 1, device=DEV))['choose_feat_output']
+    key.taps = {}
+    out = key.forward(data=f10, im_info=im_info_t, data_key_old=f0, feat_key_old=feat0)
+    warp = np_(key.taps['warp'])
+    cur_feat = np_(key.taps['backbone_feat'])
+    if mode == "fgfa":
+        p = graph_ref.Params(arg, aux)
+        emb_ref = graph_ref.embed(p, torch.from_numpy(cur_feat), torch.from_numpy(warp)).numpy()
+        emb = np_(key.taps['embed'])
+        assert emb.shape == (2, 2048, 12, 20)
+        assert rel_err(emb, emb_ref) < 2e-3
+        want = oracle.aggregate_cosine(warp, cur_feat, emb[1:2], emb[0:1])
+        np.testing.assert_array_equal(np_(out['choose_feat_output']), want)
+    else:
+        want = (0.5 * (torch.from_numpy(warp) + torch.from_numpy(cur_feat))).numpy()
+        np.testing.assert_array_equal(np_(out['choose_feat_output']), want)
+    check_heads(cfg, key.taps, out, im_info)
+    # whole-graph statement with the same switches
+    ref = graph_ref.key_forward(cfg, arg, aux, np_(f10), np_(f0), np_(feat0), im_info)
+    assert rel_err(np_(out['choose_feat_output']), ref['choose_feat_output']) < 5e-3
+
+
+def test_demo_frame_directory(tmp_path, monkeypatch):
+    """lsfa_amd.demo over a directory of PNG frames + per-frame mv/res files (demo.py:63-158 loop):
+    frame 0 eager, key frames every `interval`, non-key frames in between, hipGraph replay ==
+    eager launch of the same loop."""
+    import json
+    import sys
+    from PIL import Image
+    from lsfa_amd import demo
+    rs = np.random.RandomState(0)
+    fdir, mdir = tmp_path / "frames", tmp_path / "mv"
+    fdir.mkdir(); mdir.mkdir()
+    base = rs.randint(0, 255, (120, 200, 3)).astype(np.uint8)
+    for i in range(7):
+        Image.fromarray(np.roll(base, 3 * i, axis=1)).save(str(fdir / ("%06d.png" % i)))
+        np.savez(str(mdir / ("%06d.npz" % i)), mv=rs.uniform(-3, 3, (120, 200, 2)).astype(np.float32),
+                 res=rs.uniform(-20, 20, (120, 200, 3)).astype(np.float32))
+    outs = []
+    for extra in ([], ["--no-graph"]):
+        out = tmp_path / ("dets%d.json" % len(outs))
+        monkeypatch.setattr(sys, "argv", ["demo", "--frames", str(fdir), "--mv", str(mdir), "--interval", "3",
+                                          "--score", "0.05", "--out", str(out)] + extra)
+        demo.main()
+        outs.append(json.loads(out.read_text()))
+    a, b = outs
+    assert [r["key"] for r in a] == [True, False, False, True, False, False, True]
+    assert len(a) == len(b) == 7
+    n_a, n_b = sum(len(r["dets"]) for r in a), sum(len(r["dets"]) for r in b)
+    assert n_a > 0 and abs(n_a - n_b) <= 0.3 * max(n_a, n_b)
+    # frames 0..2 do not depend on conv algorithm choices made during capture warm-up: identical
+    for ra, rb in zip(a[:1], b[:1]):
+        assert ra == rb

@@ -41,3 +41,30 @@ def test_single_frame_rfcn_graph_on_cpu_oracle():
     cfg2 = lsfa_test_config(10)
     assert 'stage3_unit23_conv2_offset_weight' in resnet_v1_101_flownet_rfcn(cfg2).get_key_test_symbol(cfg2).arg_spec
     assert np_ref.key_frame_flags([1], 10) == [0]
+
+
+def test_key_graph_aggregation_switches():
+    """The three aggregation branches of the key symbol (symbols/resnet_v1_101_flownet_rfcn.py:310-315)
+    in the oracle graph: the Fgfa weights are a 2-way softmax of cosine similarities, so the output lies
+    between the warped and the current feature; the plain mean is exactly 0.5*(a+b)."""
+    import torch
+    outs = {}
+    for mode in ("nq", "fgfa", "average"):
+        cfg = lsfa_test_config(key_frame_interval=10)
+        cfg.network.add_Nq_net = (mode == "nq")
+        cfg.network.add_Fgfa_net = (mode == "fgfa")
+        arg, aux = P.init_params(cfg, seed=5)
+        clip = SyntheticClip(1, 12, 64, 96)
+        f0, f10 = clip.frame(0).numpy(), clip.frame(10).numpy()
+        im_info = clip.im_info()
+        r0 = graph_ref.key_forward(cfg, arg, aux, f0, f0, np.zeros((1, 1024, 1, 1), np.float32), im_info)
+        r = graph_ref.key_forward(cfg, arg, aux, f10, f0, r0['choose_feat_output'], im_info)
+        lo = np.minimum(r['warp'], r['backbone_feat'])
+        hi = np.maximum(r['warp'], r['backbone_feat'])
+        tol = 1e-5 * np.maximum(np.abs(lo), np.abs(hi)) + 1e-12
+        assert (r['choose_feat_output'] >= lo - tol).all() and (r['choose_feat_output'] <= hi + tol).all()
+        outs[mode] = r
+    mean = 0.5 * (torch.from_numpy(outs['average']['warp']) + torch.from_numpy(outs['average']['backbone_feat']))
+    np.testing.assert_array_equal(outs['average']['choose_feat_output'], mean.numpy())
+    assert 'embed' in outs['fgfa'] and outs['fgfa']['embed'].shape[:2] == (2, 2048)
+    assert 'nq_logits' in outs['nq']

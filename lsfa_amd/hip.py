@@ -157,7 +157,9 @@ def aggregate_cosine(a, b, emb_warp, emb_cur, out=None):
 
 
 class ProposalOp(object):
-    """MultiProposal / Proposal with a persistent workspace (multi_proposal-inl.h:124-159 params)."""
+    """MultiProposal / Proposal (multi_proposal-inl.h:124-159 params).  The workspace comes from torch's
+    caching allocator per call, so calls issued on different streams (or captured into different
+    graphs) never share scratch memory."""
 
     def __init__(self, feature_stride=16, scales=(8, 16, 32), ratios=(0.5, 1, 2), rpn_pre_nms_top_n=6000,
                  rpn_post_nms_top_n=300, threshold=0.7, rpn_min_size=16, output_score=False):
@@ -167,7 +169,6 @@ class ProposalOp(object):
         self.pre_n, self.post_n = int(rpn_pre_nms_top_n), int(rpn_post_nms_top_n)
         self.threshold, self.min_size = float(threshold), int(rpn_min_size)
         self.output_score = output_score
-        self._ws = None
 
     def __call__(self, cls_prob, bbox_pred, im_info, out=None):
         cls_prob, bbox_pred, im_info = _f32c(cls_prob, "cls_prob"), _f32c(bbox_pred, "bbox_pred"), _f32c(im_info, "im_info")
@@ -177,8 +178,7 @@ class ProposalOp(object):
             raise LsfaError("Proposal: expected bbox_pred %s and im_info %s, got %s and %s (multi_proposal-inl.h:179-187)"
                             % ((B, 4 * A, H, W), (B, 3), tuple(bbox_pred.shape), tuple(im_info.shape)))
         need = lib().lsfa_proposal_workspace_bytes(_ci(B), _ci(A), _ci(H), _ci(W), _ci(self.pre_n))
-        if self._ws is None or self._ws.numel() < need or self._ws.device != cls_prob.device:
-            self._ws = torch.empty(need, dtype=torch.uint8, device=cls_prob.device)
+        ws = torch.empty(need, dtype=torch.uint8, device=cls_prob.device)
         count = A * H * W
         pre_n = min(self.pre_n if self.pre_n > 0 else count, count)
         post_n = min(self.post_n, pre_n)
@@ -190,8 +190,8 @@ class ProposalOp(object):
         _check(lib().lsfa_proposal(_ptr(cls_prob), _ptr(bbox_pred), _ptr(im_info), _ci(B), _ci(A), _ci(H), _ci(W),
                                    _ci(self.feature_stride), self.scales, _ci(len(self.scales)), self.ratios,
                                    _ci(len(self.ratios)), _ci(self.pre_n), _ci(self.post_n), _cf(self.threshold),
-                                   _ci(self.min_size), _ptr(rois), _ptr(scores), _ptr(self._ws),
-                                   ctypes.c_size_t(self._ws.numel()), _stream()), "lsfa_proposal")
+                                   _ci(self.min_size), _ptr(rois), _ptr(scores), _ptr(ws),
+                                   ctypes.c_size_t(ws.numel()), _stream()), "lsfa_proposal")
         return (rois, scores) if self.output_score else rois
 
 

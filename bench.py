@@ -53,6 +53,7 @@ def parse():
     ap.add_argument('--lanes', type=int, default=2,
                     help='non-key frames of a segment alternate over this many streams while the next key frame runs on '
                          'its own stream (lsfa_amd.core.graphs.FramePipeline); 0 = strictly serial frames')
+    ap.add_argument('--key-lanes', type=int, default=1, help='streams the key frames alternate over (with --lanes > 0)')
     ap.add_argument('--cpu-budget-s', type=float, default=20.0)
     ap.add_argument('--max-unique-steps', type=int, default=16, help='distinct intervals of frames kept in HBM')
     return ap.parse_args()
@@ -92,7 +93,7 @@ class Runner(object):
         from lsfa_amd.core.graphs import FrameGraphs, FramePipeline
         if args.lanes > 0:
             self.fg = FramePipeline(self.key, self.cur, cfg, args.height, args.width, device,
-                                    use_graphs=not args.no_graph, lanes=args.lanes)
+                                    use_graphs=not args.no_graph, lanes=args.lanes, key_lanes=args.key_lanes)
         else:
             self.fg = FrameGraphs(self.key, self.cur, cfg, args.height, args.width, device, use_graphs=not args.no_graph,
                                   prefetch=not args.no_prefetch)
@@ -258,7 +259,7 @@ def main():
                        "frames_per_step": K, "ms_per_frame": round(elapsed / (args.steps * K) * 1e3, 3),
                        "parallelism": "clip-parallel x%d" % world, "detections_last_interval": total_dets,
                        "launch": "eager" if args.no_graph else "hipGraph replay per frame",
-                       "pipeline": ("key stream + %d non-key lanes" % args.lanes) if args.lanes > 0 else "serial"},
+                       "pipeline": ("%d key lanes (front/back graphs) + %d non-key lanes" % (args.key_lanes, args.lanes)) if args.lanes > 0 else "serial"},
             "roofline": {"bound": "hbm", "kernel": "warp_kernel (lsfa_warp_bilinear: MV/flow warp + fused epilogue)",
                          "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4),

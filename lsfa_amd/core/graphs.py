@@ -181,64 +181,139 @@ class FrameGraphs(object):
         return self.post_bufs
 
 
+class KeyLane(object):
+    """Static buffers and the two captured halves of a key frame: `front` (backbone + FlowNet: needs
+    only images) and `back` (flow warp of the previous key feature, aggregation, heads, detection
+    post-processing)."""
+
+    def __init__(self, key_exec, cfg, height, width, device, thresh, use_graphs):
+        self.key, self.cfg, self.device, self.use_graphs = key_exec, cfg, device, use_graphs
+        self.h, self.w, self.thresh, self.scale = height, width, thresh, 1.0
+        fh, fw = -(-height // 16), -(-width // 16)
+        z = lambda *s: torch.zeros(s, device=device, dtype=torch.float32)
+        self.data = z(1, 3, height, width)
+        self.data_key_old = z(1, 3, height, width)
+        self.feat_old = z(1, cfg.network.DFF_FEAT_DIM, fh, fw)
+        self.im_info = torch.tensor([[height, width, 1.0]], device=device, dtype=torch.float32)
+        R, ncls = cfg.TEST.RPN_POST_NMS_TOP_N, cfg.dataset.NUM_CLASSES
+        self.post_bufs = (torch.zeros((ncls, R, 5), dtype=torch.float64, device=device),
+                          torch.zeros(ncls, dtype=torch.int32, device=device),
+                          torch.full((ncls, R), -1, dtype=torch.int32, device=device))
+        self.front_out = None
+        self.feat = None
+        self.front_graph = self.back_graph = None
+
+    def front(self):
+        self.front_out = self.key.key_front(self.data, self.data_key_old)
+
+    def back(self):
+        cfg = self.cfg
+        out = self.key.key_back(*self.front_out, self.feat_old, self.im_info)
+        hip.det_postprocess(out['rois_output'], out['bbox_pred_reshape_output'][0], out['cls_prob_reshape_output'][0],
+                            self.h, self.w, self.scale, score_thresh=self.thresh, nms_thresh=cfg.TEST.NMS,
+                            max_per_image=cfg.TEST.max_per_image, class_agnostic=cfg.CLASS_AGNOSTIC, out=self.post_bufs)
+        self.feat = out['choose_feat_output']
+
+    def capture(self, warmup=3):
+        if not self.use_graphs:
+            return
+        s = torch.cuda.Stream(device=self.device)
+        s.wait_stream(torch.cuda.current_stream(self.device))
+        with torch.cuda.stream(s):
+            for _ in range(warmup):
+                self.front()
+                self.back()
+        torch.cuda.current_stream(self.device).wait_stream(s)
+        torch.cuda.synchronize(self.device)
+        self._capture_stream = torch.cuda.Stream(device=self.device)     # see FrameGraphs.capture
+        self.front_graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.front_graph, stream=self._capture_stream):
+            self.front()
+        self.back_graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.back_graph, stream=self._capture_stream):
+            self.back()
+
+    def run_front(self):
+        self.front_graph.replay() if self.use_graphs else self.front()
+
+    def run_back(self):
+        self.back_graph.replay() if self.use_graphs else self.back()
+
+
 class FramePipeline(object):
     """One clip, frames issued in order, pipelined over HIP streams.
 
     Data dependencies of the frame loop (dff_rfcn/core/tester.py:237-281): a non-key frame needs the
     feature of the latest key frame and its own image / motion vectors / residual — nothing from the
-    neighbouring non-key frames; a key frame needs the previous key frame's image and feature and
-    nothing from the non-key frames in between.  The reference runs everything serially (one
-    executor, a blocking .asnumpy() per frame).  Here:
+    neighbouring non-key frames.  A key frame needs the previous key frame's IMAGE for its backbone +
+    FlowNet part (the bulk of it) and the previous key frame's FEATURE only for the warp /
+    aggregation / heads at its end; it needs nothing from the non-key frames in between.  The
+    reference runs everything serially (one executor, a blocking .asnumpy() per frame).  Here:
 
-      * key frames run on one stream, back to back;
+      * key frames alternate over `key_lanes` streams; each is two captured graphs, `front`
+        (backbone + FlowNet) and `back` (warp, aggregation, heads, detections); a `back` waits for the
+        previous key frame's `back`, a `front` for nothing but its own lane;
       * the non-key frames of a segment alternate over `lanes` streams, each lane with its own captured
         graph and static buffers, all reading one shared copy of the key feature;
-      * the key graph's output is copied ("handed over") into that shared buffer once the key frame
-        has finished AND every lane has finished the previous segment; the next key frame may start as
-        soon as the hand-over is done, so it overlaps the current segment's non-key frames.
+      * a key frame's output is copied ("handed over") into that shared buffer once its `back` has
+        finished AND every lane has finished the previous segment.
 
     What this buys on a 256-CU part: every frame ends with work that occupies one or a few CUs
     (Proposal's single workgroup, the R-FCN head, the detection NMS: ~40 % of a non-key frame's
     time) and the key frame's late ResNet stages launch grids well under 256 workgroups; with
-    independent frames in flight those CUs run the next frame's convolutions instead of idling.
-    Results are identical to the serial loop: same graphs, same inputs, no shared scratch memory.
+    independent frames in flight those CUs run another frame's convolutions instead of idling.
+    Results are those of the serial loop: same launch sequences, same inputs, no shared scratch.
+    Measured at 1000x600, interval 10, fp32 (frames/s; serial loop = 658): key_lanes x lanes = 1x1 897,
+    1x2 926, 1x3 930, 2x2 868, 2x3 937, 3x3 797 — once the next key frame overlaps the current segment
+    the GPU is out of idle CUs and more streams only add contention, hence the 1 x 2 default.
+    The caller must keep each key frame's `data` tensor unmodified until the next key frame has
+    been queued (it is read again as that frame's `data_key_old`).
     """
 
-    def __init__(self, key_exec, cur_exec, cfg, height, width, device, thresh=1e-4, use_graphs=True, lanes=2):
+    def __init__(self, key_exec, cur_exec, cfg, height, width, device, thresh=1e-4, use_graphs=True, lanes=2,
+                 key_lanes=1):
         dev = torch.device(device)
-        self.device = dev
-        self.kg = FrameGraphs(key_exec, cur_exec, cfg, height, width, dev, thresh, use_graphs, prefetch=False)
+        self.device, self.cfg, self.key_exec = dev, cfg, key_exec
+        self.h, self.w, self.thresh, self.scale = height, width, thresh, 1.0
         fh, fw = -(-height // 16), -(-width // 16)
-        self.feat_cur = torch.zeros((1, cfg.network.DFF_FEAT_DIM, fh, fw), device=dev, dtype=torch.float32)
+        dim = cfg.network.DFF_FEAT_DIM
+        self.feat_cur = torch.zeros((1, dim, fh, fw), device=dev, dtype=torch.float32)   # what the non-key lanes read
+        self.feat0 = torch.zeros((1, dim, fh, fw), device=dev, dtype=torch.float32)      # feature of a clip's frame 0
+        self.klanes = [KeyLane(key_exec, cfg, height, width, dev, thresh, use_graphs) for _ in range(key_lanes)]
         self.lanes = [FrameGraphs(key_exec, cur_exec, cfg, height, width, dev, thresh, use_graphs, prefetch=False,
                                   feat_shared=self.feat_cur) for _ in range(lanes)]
-        self.s_key = torch.cuda.Stream(device=dev)
+        self.s_key = [torch.cuda.Stream(device=dev) for _ in range(key_lanes)]
         self.s_lane = [torch.cuda.Stream(device=dev) for _ in range(lanes)]
-        self.ev_key = torch.cuda.Event()
+        self.ev_back = torch.cuda.Event()
         self.ev_handover = torch.cuda.Event()
         self.ev_lane = [torch.cuda.Event() for _ in range(lanes)]
-        self._next = 0
+        self.captured = False
+        self._next = self._nkey = 0
         self._pending_handover = False
+        self._prev_feat = self._prev_key_data = None
+        self._first_post = None
 
+    # the state the serial FrameGraphs exposes under the same names
     @property
     def feat(self):
-        return self.kg.feat
+        return self._prev_feat
 
     @property
     def feat_old(self):
-        return self.kg.feat_old
+        return self._prev_feat
 
     @property
     def data_key_old(self):
-        return self.kg.data_key_old
+        return self._prev_key_data
 
     def set_scale(self, im_scale):
-        for g in [self.kg] + self.lanes:
+        self.scale = float(im_scale)
+        for g in self.klanes + self.lanes:
             g.scale = float(im_scale)
             g.im_info[0, 2] = float(im_scale)
 
     def _all_streams(self):
-        return [self.s_key] + self.s_lane
+        return self.s_key + self.s_lane
 
     def join(self):
         """The caller's stream waits for everything issued so far."""
@@ -249,53 +324,75 @@ class FramePipeline(object):
     def first_frame(self, data):
         """flag 0 (first frame of a clip): drains the pipeline, runs eagerly on the caller's stream."""
         self.join()
-        self._next = 0          # the lane of a frame depends only on its position in the clip
-        bufs = self.kg.first_frame(data)
-        if self.kg.feat is not None:
-            self._publish_from_main()
-        return bufs
+        self._next = self._nkey = 0          # the lane of a frame depends only on its position in the clip
+        lane, cfg = self.klanes[0], self.cfg
+        conv_feat, _, _ = self.key_exec.key_front(data, None)
+        out = self.key_exec.key_back(conv_feat, None, None, None, lane.im_info)
+        if self._first_post is None:
+            self._first_post = tuple(torch.zeros_like(b) for b in lane.post_bufs)
+            self._first_post[2].fill_(-1)
+        hip.det_postprocess(out['rois_output'], out['bbox_pred_reshape_output'][0], out['cls_prob_reshape_output'][0],
+                            self.h, self.w, self.scale, score_thresh=self.thresh, nms_thresh=cfg.TEST.NMS,
+                            max_per_image=cfg.TEST.max_per_image, class_agnostic=cfg.CLASS_AGNOSTIC,
+                            out=self._first_post)
+        self.feat0.copy_(out['choose_feat_output'])
+        self._prev_feat, self._prev_key_data = self.feat0, data
+        self._publish_from_main()
+        return self._first_post
 
     def _publish_from_main(self):
         main = torch.cuda.current_stream(self.device)
-        self.feat_cur.copy_(self.kg.feat)
+        self.feat_cur.copy_(self._prev_feat)
         for s in self._all_streams():
             s.wait_stream(main)
         self.ev_handover.record(main)
+        self.ev_back.record(main)
+        for e in self.ev_lane:
+            e.record(main)
         self._pending_handover = False
 
     def capture(self, warmup=3):
-        self.kg.capture(warmup, cur=False)
+        for lane in self.klanes:
+            lane.feat_old.copy_(self.feat0)
+            lane.capture(warmup)
         for lane in self.lanes:
             lane.capture(warmup, key=False)
         torch.cuda.synchronize(self.device)
+        self.captured = True
         self._publish_from_main()
-        for e in [self.ev_key] + self.ev_lane:
-            e.record(torch.cuda.current_stream(self.device))
 
     def key_frame(self, data, deliver=None, ready=None):
-        """flag 1.  `deliver(bufs)` is called with the key stream current right after the frame is
+        """flag 1.  `deliver(bufs)` is called with the frame's stream current right after the frame is
         queued; use it to queue copies of the (dets, counts, keep_idx) buffers.  The inputs must be
         complete on the device, or `ready` an event recorded after the work that produces them (the
         caller's stream is deliberately NOT waited on: it would serialise the pipeline)."""
-        s = self.s_key
+        i = self._nkey % len(self.klanes)
+        self._nkey += 1
+        lane, s = self.klanes[i], self.s_key[i]
         with torch.cuda.stream(s):
             if ready is not None:
                 s.wait_event(ready)
-            s.wait_event(self.ev_handover)       # the lanes own a copy of the previous key feature
-            bufs = self.kg.key_frame(data)
+            lane.data.copy_(data)
+            lane.data_key_old.copy_(self._prev_key_data)
+            lane.run_front()
+            s.wait_event(self.ev_back)           # the previous key frame's feature exists ...
+            s.wait_event(self.ev_handover)       # ... and the non-key lanes hold their copy of the feature
+            lane.feat_old.copy_(self._prev_feat)  #     this lane's `back` is about to overwrite
+            lane.run_back()
             if deliver is not None:
-                deliver(bufs)
-            self.ev_key.record(s)
+                deliver(lane.post_bufs)
+            self.ev_back.record(s)
+        self._prev_feat, self._prev_key_data = lane.feat, data
         self._pending_handover = True
-        return bufs
+        return lane.post_bufs
 
     def _handover(self):
         s = self.s_lane[0]
         with torch.cuda.stream(s):
-            s.wait_event(self.ev_key)
+            s.wait_event(self.ev_back)
             for e in self.ev_lane[1:]:
                 s.wait_event(e)
-            self.feat_cur.copy_(self.kg.feat)
+            self.feat_cur.copy_(self._prev_feat)
             self.ev_handover.record(s)
         self._pending_handover = False
 

@@ -459,13 +459,38 @@ class Executor(object):
     def _forward_key(self, d):
         cfg = self.cfg
         data, feat_key_old = d['data'], d['feat_key_old']
-        conv_feat = self._backbone(data)
-        self._tap('backbone_feat', conv_feat)
         # ChooseOldKeyFeat: first frame <=> placeholder shape (1, 1024, 1, 1)
         _, c, h, w = feat_key_old.shape
         is_first = (c == cfg.network.DFF_FEAT_DIM and h == 1 and w == 1)
-        if not is_first:
-            flow, scale_map = self._flownet(data, d['data_key_old'])
+        conv_feat, flow, scale_map = self._key_front(data, None if is_first else d['data_key_old'])
+        out = self._key_back(conv_feat, flow, scale_map, feat_key_old, d['im_info'])
+        out.update({'data_key': d.get('data_key'), 'motion_vector': d.get('motion_vector'), 'res_diff': d.get('res_diff'),
+                    'feat_key': d.get('feat_key')})
+        return out
+
+    def key_front(self, data, data_key_old):
+        """The part of a key frame that does not depend on the previous key frame's FEATURE: backbone of
+        this frame and FlowNet(this frame, previous key image).  -> (conv_feat, flow, scale_map).
+        lsfa_amd/core/graphs.py runs it ahead of time, beside the previous key frame."""
+        with torch.no_grad():
+            return self._key_front(data, data_key_old)
+
+    def key_back(self, conv_feat, flow, scale_map, feat_key_old, im_info):
+        """The rest of the key frame: flow warp x scale map of the old key feature, aggregation, heads."""
+        with torch.no_grad():
+            return self._key_back(conv_feat, flow, scale_map, feat_key_old, im_info)
+
+    def _key_front(self, data, data_key_old):
+        conv_feat = self._backbone(data)
+        self._tap('backbone_feat', conv_feat)
+        if data_key_old is None:
+            return conv_feat, None, None
+        flow, scale_map = self._flownet(data, data_key_old)
+        return conv_feat, flow, scale_map
+
+    def _key_back(self, conv_feat, flow, scale_map, feat_key_old, im_info):
+        cfg = self.cfg
+        if flow is not None:
             warp = hip.warp_bilinear(feat_key_old, flow, mul=scale_map)
             if self.taps is not None:
                 self.taps.update(flow=flow, scale_map=scale_map, warp=warp)
@@ -485,10 +510,9 @@ class Executor(object):
                 conv_feat = hip.aggregate_cosine(warp, conv_feat, e[1:2], e[0:1])
             else:
                 conv_feat = 0.5 * (warp + conv_feat)
-        rois, cls_prob, bbox_pred = self._heads(conv_feat, d['im_info'])
-        return {'data_key': d.get('data_key'), 'motion_vector': d.get('motion_vector'), 'res_diff': d.get('res_diff'),
-                'feat_key': d.get('feat_key'), 'choose_feat_output': conv_feat, 'rois_output': rois,
-                'cls_prob_reshape_output': cls_prob, 'bbox_pred_reshape_output': bbox_pred}
+        rois, cls_prob, bbox_pred = self._heads(conv_feat, im_info)
+        return {'choose_feat_output': conv_feat, 'rois_output': rois, 'cls_prob_reshape_output': cls_prob,
+                'bbox_pred_reshape_output': bbox_pred}
 
     def small_net_feature(self, data):
         """fuse_small_net's image branch (:209-236): avgpool 4x4 -> small_net_ stem + stage 1 ->

@@ -372,7 +372,7 @@ def test_frame_pipeline_matches_serial_and_is_race_free(world):
                 outs[f] = (bufs[0].clone(), bufs[1].clone())     # queued on the frame's own stream
             return deliver
         fp.first_frame(frames[0])
-        if fp.kg.key_graph is None:
+        if not fp.captured:
             fp.capture()
         for f, kf in sched:
             if f == kf:

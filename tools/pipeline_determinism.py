@@ -34,8 +34,7 @@ def run(fp, pipelined):
             outs[f] = (bufs[0].clone(), bufs[1].clone())
         return deliver
     fp.first_frame(frames[0])
-    graph = fp.kg.key_graph if pipelined else fp.key_graph
-    if graph is None:
+    if not (fp.captured if pipelined else fp.key_graph is not None):
         fp.capture()
     for f, kf in sched:
         if pipelined:

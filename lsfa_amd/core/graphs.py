@@ -372,6 +372,8 @@ class FramePipeline(object):
         with torch.cuda.stream(s):
             if ready is not None:
                 s.wait_event(ready)
+            for t in (data, self._prev_key_data):
+                t.record_stream(s)               # the caller may drop its reference right after this call
             lane.data.copy_(data)
             lane.data_key_old.copy_(self._prev_key_data)
             lane.run_front()
@@ -408,6 +410,8 @@ class FramePipeline(object):
             if ready is not None:
                 s.wait_event(ready)
             s.wait_event(self.ev_handover)
+            for t in (data, motion_vector, res_diff):
+                t.record_stream(s)
             bufs = self.lanes[i].cur_frame(data, motion_vector, res_diff)
             if deliver is not None:
                 deliver(bufs)

@@ -154,3 +154,68 @@ def pred_eval(gpu_id, key_predictor, cur_predictor, test_data, imdb, cfg, vis=Fa
         logger.info('done {} frames: data {:.4f}s net {:.4f}s post {:.4f}s per frame'.format(
             num_images, data_time / max(idx, 1), net_time / max(idx, 1), post_time / max(idx, 1)))
     return all_boxes, frame_ids
+
+
+def pred_eval_pipelined(gpu_id, key_predictor, cur_predictor, test_data, imdb, cfg, thresh=1e-4, logger=None, lanes=2,
+                        key_lanes=1, use_graphs=True):
+    """pred_eval with the frames of each video pipelined over HIP streams (core/graphs.py
+    FramePipeline): same loader, same flags, same launch sequences per frame, same return value.
+    One pipeline (captured graphs + static buffers) is built per distinct (height, width, scale) and
+    reused by every video of that shape."""
+    from lsfa_amd.core.graphs import FramePipeline
+    num_classes = imdb.num_classes if imdb is not None else cfg.dataset.NUM_CLASSES
+    data_names = [k[0] for k in test_data.provide_data[0]]
+    num_images = test_data.size
+    roidb_frame_ids = [x['frame_id'] for x in test_data.roidb]
+    all_boxes = [[[] for _ in range(num_images)] for _ in range(num_classes)]
+    frame_ids = np.zeros(num_images, dtype=np.int64)
+    pipelines, pending = {}, []
+    roidb_idx, roidb_offset, idx = -1, -1, 0
+    fp = None
+    t0 = time.time()
+    for im_info, key_frame_flag, data_batch in test_data:
+        d = dict(zip(data_names, data_batch.data[0]))
+        data = d['data']
+
+        def deliver(bufs, i=idx):
+            pending.append((i, bufs[0].clone(), bufs[1].clone()))      # queued on the frame's own stream
+
+        if key_frame_flag == 0:
+            shape_key = (int(data.shape[-2]), int(data.shape[-1]), float(im_info[0][0, 2]))
+            if fp is not None:
+                fp.join()
+            fp = pipelines.get(shape_key)
+            if fp is None:
+                fp = pipelines[shape_key] = FramePipeline(key_predictor._exec, cur_predictor._exec, cfg, shape_key[0],
+                                                          shape_key[1], data.device, thresh=thresh,
+                                                          use_graphs=use_graphs, lanes=lanes, key_lanes=key_lanes)
+                fp.set_scale(shape_key[2])
+            deliver(fp.first_frame(data))
+            if not fp.captured:
+                fp.capture()
+            roidb_idx += 1
+            roidb_offset = 0
+        else:
+            ready = torch.cuda.Event()
+            ready.record()          # the loader produced this frame's tensors on the current stream
+            if key_frame_flag == 1:
+                fp.key_frame(data, deliver=deliver, ready=ready)
+            else:
+                fp.cur_frame(data, d['motion_vector'], d['res_diff'], deliver=deliver, ready=ready)
+            roidb_offset += 1
+        frame_ids[idx] = roidb_frame_ids[roidb_idx] + roidb_offset
+        idx += test_data.batch_size
+        if logger and idx % 50 == 0:
+            logger.info('queued {}/{} frames, {:.4f}s per frame'.format(idx, num_images, (time.time() - t0) / idx))
+    if fp is not None:
+        fp.join()
+    torch.cuda.synchronize()
+    net_time = time.time() - t0
+    for i, dets, counts in pending:
+        dets, counts = dets.cpu().numpy(), counts.cpu().numpy()
+        for j in range(1, num_classes):
+            all_boxes[j][i] = dets[j, :counts[j]].copy()
+    if logger:
+        logger.info('done {} frames: {:.4f}s per frame ({:.1f} frames/s)'.format(num_images, net_time / max(idx, 1),
+                                                                                 idx / max(net_time, 1e-9)))
+    return all_boxes, frame_ids

@@ -10,7 +10,7 @@ import torch.distributed as dist
 
 from lsfa_amd.core import parallel
 from lsfa_amd.core.loader import TestLoader
-from lsfa_amd.core.tester import Predictor, pred_eval
+from lsfa_amd.core.tester import Predictor, pred_eval, pred_eval_pipelined
 from lsfa_amd.symbols.resnet_v1_101_flownet_rfcn import resnet_v1_101_flownet_rfcn
 
 
@@ -25,8 +25,11 @@ def get_predictor(sym, sym_instance, cfg, arg_params, aux_params, test_data, ctx
                      provide_label=test_data.provide_label, arg_params=arg_params, aux_params=aux_params, dtype=dtype)
 
 
-def test_rcnn(cfg, roidb, arg_params, aux_params, device=None, thresh=1e-4, logger=None, dtype=torch.float32):
-    """Returns (rows, frame_ids_local): `rows` = every rank's detections after the final gather."""
+def test_rcnn(cfg, roidb, arg_params, aux_params, device=None, thresh=1e-4, logger=None, dtype=torch.float32,
+              pipeline=False):
+    """Returns (rows, frame_ids_local): `rows` = every rank's detections after the final gather.
+    pipeline=True runs the frame loop through pred_eval_pipelined (frames of a video overlapped on HIP
+    streams) instead of the reference-shaped serial pred_eval."""
     rank = dist.get_rank() if dist.is_available() and dist.is_initialized() else 0
     world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
     if device is None:
@@ -42,6 +45,7 @@ def test_rcnn(cfg, roidb, arg_params, aux_params, device=None, thresh=1e-4, logg
     test_data = TestLoader(my_roidb, cfg, batch_size=1, shuffle=False, has_rpn=True, device=device)
     key_predictor = get_predictor(key_sym, key_sym_instance, cfg, arg_params, aux_params, test_data, device, dtype)
     cur_predictor = get_predictor(cur_sym, cur_sym_instance, cfg, arg_params, aux_params, test_data, device, dtype)
-    all_boxes, frame_ids = pred_eval(rank, key_predictor, cur_predictor, test_data, None, cfg, thresh=thresh, logger=logger)
+    run = pred_eval_pipelined if pipeline else pred_eval
+    all_boxes, frame_ids = run(rank, key_predictor, cur_predictor, test_data, None, cfg, thresh=thresh, logger=logger)
     rows = parallel.detections_to_rows(all_boxes, frame_ids)
     return parallel.gather_rows(rows), frame_ids

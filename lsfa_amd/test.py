@@ -35,6 +35,8 @@ def parse_args():
     ap.add_argument('--interval', type=int, default=None, help='override TEST.KEY_FRAME_INTERVAL')
     ap.add_argument('--prefix', default=None, help='MXNet checkpoint prefix (prefix-%%04d.params)')
     ap.add_argument('--epoch', type=int, default=0)
+    ap.add_argument('--serial', action='store_true', help='reference-shaped serial frame loop (pred_eval) instead of the '
+                                                          'stream-pipelined one')
     return ap.parse_args()
 
 
@@ -66,7 +68,7 @@ def main():
         arg_params, aux_params = P.init_params(cfg, seed=0)
     t0 = time.time()
     rows, frame_ids = test_rcnn(cfg, roidb, arg_params, aux_params, device='cuda:%d' % local_rank, thresh=args.thresh,
-                                logger=logger)
+                                logger=logger, pipeline=not args.serial)
     torch.cuda.synchronize()
     dt = time.time() - t0
     if not dist.is_initialized() or dist.get_rank() == 0:

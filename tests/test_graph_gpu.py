@@ -172,8 +172,10 @@ def test_hipgraph_replay_equals_eager(world):
         assert matched >= 0.7 * c0.sum(), "variant %d vs %d, schedule entry %d: %d of %d matched" % (va, vb, fi, matched, c0.sum())
 
 
-def test_clip_end_to_end_map_vs_oracle(world):
-    """Whole path on a 7-frame 192x320 clip, interval 3: GPU (test_rcnn -> pred_eval) vs the CPU
+@pytest.mark.parametrize("pipeline", [False, True])
+def test_clip_end_to_end_map_vs_oracle(world, pipeline):
+    """Whole path on a 7-frame 192x320 clip, interval 3: GPU (test_rcnn -> pred_eval, and the
+    stream-pipelined pred_eval_pipelined) vs the CPU
     oracle's frame loop.  The convolutions differ by fp32 round-off, so individual low-score
     detections may swap; the agreement metric is VID mAP@0.5 of the GPU detections against the
     oracle's confident detections taken as ground truth: must be within 0.1 of 1."""
@@ -185,7 +187,7 @@ def test_clip_end_to_end_map_vs_oracle(world):
     cfg = lsfa_test_config(key_frame_interval=3)
     arg, aux = world['arg'], world['aux']
     roidb = synthetic_roidb(1, 7, H, W, 3)
-    rows_gpu, frame_ids = test_rcnn(cfg, roidb, arg, aux, device=DEV)
+    rows_gpu, frame_ids = test_rcnn(cfg, roidb, arg, aux, device=DEV, pipeline=pipeline)
     clip = roidb[0]['clip']
     rows_ref = frame_loop.run_clip(cfg, arg, aux, 7, lambda f: clip.frame(f).numpy(),
                                    lambda f, k: clip.motion_vector(f, k).numpy(), lambda f: clip.res_diff(f).numpy(),
@@ -414,3 +416,27 @@ def test_frame_pipeline_matches_serial_and_is_race_free(world):
                 if len(y) and ((np.abs(y[:, :4] - row[:4]).max(1) < 0.1) & (np.abs(y[:, 4] - row[4]) < 1e-3)).any():
                     matched += 1
         assert matched >= 0.7 * c0.sum(), "frame %d: %d of %d matched" % (f, matched, c0.sum())
+
+
+def test_pred_eval_pipelined_two_videos(world):
+    """Two videos of the same shape through pred_eval_pipelined: the second video reuses the first
+    one's captured pipeline after a drain; frame ids and per-frame detections agree with the serial
+    pred_eval (criterion of test_hipgraph_replay_equals_eager)."""
+    from lsfa_amd.config.config import lsfa_test_config
+    from lsfa_amd.function.test_rcnn import test_rcnn
+    from lsfa_amd.utils.synthetic import synthetic_roidb
+    cfg = lsfa_test_config(key_frame_interval=3)
+    arg, aux = world['arg'], world['aux']
+    roidb = synthetic_roidb(2, 8, H, W, 3)
+    rows_s, ids_s = test_rcnn(cfg, roidb, arg, aux, device=DEV, pipeline=False)
+    rows_p, ids_p = test_rcnn(cfg, roidb, arg, aux, device=DEV, pipeline=True)
+    np.testing.assert_array_equal(ids_s, ids_p)
+    assert abs(len(rows_s) - len(rows_p)) <= 0.05 * len(rows_s)
+    for f in np.unique(rows_s[:, 0]):
+        a, b = rows_s[rows_s[:, 0] == f], rows_p[rows_p[:, 0] == f]
+        matched = 0
+        for row in a:
+            same = b[b[:, 1] == row[1]]
+            if len(same) and ((np.abs(same[:, 3:7] - row[3:7]).max(1) < 0.1) & (np.abs(same[:, 2] - row[2]) < 1e-3)).any():
+                matched += 1
+        assert matched >= 0.7 * len(a), "frame %d: %d of %d matched" % (f, matched, len(a))

@@ -46,9 +46,35 @@ def pmc_summary(d, match):
     return {k: dict(n=len(v), mean=sum(v) / len(v), min=min(v), max=max(v)) for k, v in vals.items()}
 
 
+def pmc_table(d, out, top=45, last_frames=20):
+    """every kernel: dispatches and the SUM of each counter over its dispatches, sorted by GRBM_GUI_ACTIVE."""
+    f = glob.glob(d + '/*/*counter_collection.csv')
+    if not f:
+        return
+    agg = collections.defaultdict(lambda: collections.defaultdict(float))
+    disp = collections.defaultdict(set)
+    rows = list(csv.DictReader(open(f[0])))
+    caps = sorted({int(r['Dispatch_Id']) for r in rows if 'det_cap_kernel' in r['Kernel_Name']})
+    first = caps[-(last_frames + 1)] if len(caps) > last_frames else -1     # skip warm-up / MIOpen find dispatches
+    for r in rows:
+        if int(r['Dispatch_Id']) <= first:
+            continue
+        k = r['Kernel_Name'][:120]
+        agg[k][r['Counter_Name']] += float(r['Counter_Value'])
+        disp[k].add(r['Dispatch_Id'])
+    names = sorted({c for v in agg.values() for c in v})
+    key = 'GRBM_GUI_ACTIVE' if 'GRBM_GUI_ACTIVE' in names else names[0]
+    with open(out, 'w') as o:
+        o.write('kernel,dispatches,' + ','.join(names) + '\n')
+        for k, v in sorted(agg.items(), key=lambda kv: -kv[1].get(key, 0))[:top]:
+            o.write('"%s",%d,%s\n' % (k, len(disp[k]), ','.join('%.0f' % v.get(c, 0) for c in names)))
+
+
 if __name__ == '__main__':
     mode = sys.argv[1]
-    if mode == 'trace':
+    if mode == 'pmctable':
+        pmc_table(sys.argv[2], sys.argv[3])
+    elif mode == 'trace':
         trace_summary(sys.argv[2], sys.argv[3], float(sys.argv[4]) if len(sys.argv) > 4 else 0.5)
     else:
         print(json.dumps(pmc_summary(sys.argv[2], sys.argv[3])))

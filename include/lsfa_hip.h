@@ -192,6 +192,11 @@ int lsfa_deform_im2col(const float* data, const float* offset,
 int lsfa_scale_shift_relu(const float* x, const float* scale, const float* shift,
                           int N, int C, int HW, int relu, float* y, void* stream);
 
+/* The same pass for a channels-last map: x, y are (rows, C) with the channel the fastest axis
+ * (rows = N*H*W), C a multiple of 4, all pointers 16-byte aligned.  In-place allowed. */
+int lsfa_scale_shift_relu_cl(const float* x, const float* scale, const float* shift,
+                             long long rows, int C, int relu, float* y, void* stream);
+
 /* ------------------------------------------------------------------------ *
  * Live per-op timing with HIP events on the launch stream (bench.py's roofline leg).
  * lsfa_prof_enable(mask) makes the entry points whose op id bit is set in `mask`

@@ -75,7 +75,42 @@ __global__ __launch_bounds__(kThreads) void scale_shift_relu_kernel(const float*
   }
 }
 
+// channels-last rows: x[r][c], channel fastest.  One float4 of channels per thread; C % 4 == 0.
+__global__ __launch_bounds__(kThreads) void scale_shift_relu_cl_kernel(const float4* __restrict__ x,
+                                                                       const float4* __restrict__ scale,
+                                                                       const float4* __restrict__ shift, int C4, int relu,
+                                                                       float4* __restrict__ y, size_t nvec) {
+  for (size_t v = (size_t)blockIdx.x * kThreads + threadIdx.x; v < nvec; v += (size_t)gridDim.x * kThreads) {
+    const int c4 = (int)(v % C4);
+    const float4 sc = scale[c4], sh = shift[c4], t = x[v];
+    float4 r;
+    r.x = t.x * sc.x + sh.x; r.y = t.y * sc.y + sh.y; r.z = t.z * sc.z + sh.z; r.w = t.w * sc.w + sh.w;
+    if (relu) {
+      r.x = r.x < 0.f ? 0.f : r.x; r.y = r.y < 0.f ? 0.f : r.y; r.z = r.z < 0.f ? 0.f : r.z; r.w = r.w < 0.f ? 0.f : r.w;
+    }
+    y[v] = r;
+  }
+}
+
 }  // namespace
+
+extern "C" int lsfa_scale_shift_relu_cl(const float* x, const float* scale, const float* shift, long long rows, int C,
+                                        int relu, float* y, void* stream) {
+  LSFA_REQUIRE(x && scale && shift && y, "lsfa_scale_shift_relu_cl: NULL argument");
+  LSFA_REQUIRE(rows > 0 && C > 0 && C % 4 == 0, "lsfa_scale_shift_relu_cl: rows=%lld C=%d (C must be a positive multiple of 4)",
+               rows, C);
+  LSFA_REQUIRE(!((uintptr_t)x % 16) && !((uintptr_t)y % 16) && !((uintptr_t)scale % 16) && !((uintptr_t)shift % 16),
+               "lsfa_scale_shift_relu_cl: pointers must be 16-byte aligned");
+  hipStream_t s = (hipStream_t)stream;
+  const size_t nvec = (size_t)rows * (C / 4);
+  size_t nb = (nvec + kThreads - 1) / kThreads;
+  if (nb > 4096) nb = 4096;
+  ProfScope prof(LSFA_OP_BNRELU, s);
+  hipLaunchKernelGGL(scale_shift_relu_cl_kernel, dim3((unsigned)nb), dim3(kThreads), 0, s, (const float4*)x,
+                     (const float4*)scale, (const float4*)shift, C / 4, relu, (float4*)y, nvec);
+  LSFA_LAUNCH_CHECK("lsfa_scale_shift_relu_cl");
+  return LSFA_OK;
+}
 
 extern "C" int lsfa_deform_im2col(const float* data, const float* offset, int N, int C, int H, int W, int kh, int kw,
                                   int pad, int stride, int dilate, int deform_groups, int Ho, int Wo, float* col,

@@ -271,6 +271,18 @@ def scale_shift_relu(x, scale, shift, relu=True, out=None):
     return out
 
 
+def scale_shift_relu_cl(x, scale, shift, relu=True, out=None):
+    """Channels-last form: x (..., C) contiguous with the channel the fastest axis, C % 4 == 0."""
+    x = _f32c(x, "x")
+    C = x.shape[-1]
+    rows = x.numel() // C
+    if out is None:
+        out = torch.empty_like(x)
+    _check(lib().lsfa_scale_shift_relu_cl(_ptr(x), _ptr(scale), _ptr(shift), ctypes.c_longlong(rows), _ci(C),
+                                          _ci(int(relu)), _ptr(out), _stream()), "lsfa_scale_shift_relu_cl")
+    return out
+
+
 # ---- live timing -----------------------------------------------------------------------
 def prof_enable(on=True, ops=None):
     """on=True times every op; ops=['warp_bilinear', ...] times only those; on=False stops."""

@@ -31,6 +31,9 @@ from lsfa_amd.symbols import params as P
 
 BN_EPS = 2e-5  # sym_common.py:9
 import os as _os
+# measured at 1000x600 fp32 (us, hipGraph replay): backbone 5806 -> 5476, small net 270 -> 258, FlowNet 1164 -> 1566
+# (its large-kernel strided convolutions and deconvolutions are slower channels-last), hence:
+_CL_DEFAULT = 'backbone,small'
 _CONV1X1_MIOPEN = _os.environ.get('LSFA_CONV1X1_MIOPEN', '0') == '1'   # experiment: channel-reducing 1x1 convs through MIOpen
 
 
@@ -208,6 +211,26 @@ class _ResNetWeights(object):
         if tail:
             s, t = bn(prefix + 'bn1')
             self.bn1 = (_t(s.astype(np.float32), device, f32), _t(t.astype(np.float32), device, f32))
+        self._cl_ready = False
+
+    def prepare_channels_last(self):
+        """Weight forms of the channels-last path: (Cin, Cout) matrices for the 1x1 convolutions (GEMM on
+        (H*W, C) rows), channels_last 4-D weights for the library convolutions."""
+        if self._cl_ready:
+            return
+        cl = torch.channels_last
+        self.conv0_w_cl = self.conv0_w.contiguous(memory_format=cl)
+        for d in self.units:
+            d['w1_t'] = d['w1_2d'].t().contiguous()
+            d['w3_t'] = d['w3_2d'].t().contiguous()
+            d['w2_cl'] = d['w2'].contiguous(memory_format=cl)
+            if 'sc' in d:
+                d['sc_t'] = d['sc'].reshape(d['sc'].shape[0], -1).t().contiguous()
+                d['sc_cl'] = d['sc'].contiguous(memory_format=cl)
+            if d['dcn']:
+                d['off_w_cl'] = d['off_w'].contiguous(memory_format=cl)
+                d['w2_2d_t'] = d['w2_2d'].t().contiguous()
+        self._cl_ready = True
 
 
 class Executor(object):
@@ -219,6 +242,10 @@ class Executor(object):
         self.cdtype = dtype           # dtype of the dense contractions (fp32, or bf16 for config 3)
         self.taps = None              # set to {} to record stage outputs (parity tests)
         self._const = {}
+        # which sub-networks run channels-last (activations as (H*W, C) rows): LSFA_CL = comma list of
+        # backbone, flownet, small; fp32 contractions only
+        want = _os.environ.get('LSFA_CL', _CL_DEFAULT)
+        self.cl = set(x for x in want.split(',') if x) if dtype == torch.float32 else set()
         cfg = self.cfg
         arg = {k: np.asarray(v, dtype=np.float32) for k, v in arg_params.items()}
         aux = {k: np.asarray(v, dtype=np.float32) for k, v in aux_params.items()}
@@ -365,7 +392,79 @@ class Executor(object):
             x = self._c(hip.scale_shift_relu(x.float(), net.bn1[0], net.bn1[1], relu=True))
         return x
 
+    # ---- channels-last variant ---------------------------------------------------------
+    # Activations are (H*W, C) rows (torch: NCHW-shaped tensors with channels_last strides), so a 1x1
+    # convolution is rows x (Cin, Cout) with the bias + ReLU in the GEMM epilogue
+    # (torch._addmm_activation -> hipBLASLt RELU_BIAS; in the NCHW form the bias runs along the GEMM's
+    # other axis and needs its own pass), the library's NHWC MFMA convolutions are used without the
+    # transposes it otherwise wraps around them, and the per-channel passes read float4 of channels.
+    @staticmethod
+    def _rows(x4):
+        n, c, h, w = x4.shape
+        # a view when x4 is channels_last-contiguous (what the library convolutions return for channels_last
+        # inputs); callers only use the rows afterwards, so a copy here would still be correct
+        return x4.permute(0, 2, 3, 1).reshape(n * h * w, c)
+
+    @staticmethod
+    def _map(x2, h, w):
+        return x2.view(1, h, w, x2.shape[1]).permute(0, 3, 1, 2)
+
+    def _dcn_cl(self, c1_4, u, dilate):
+        off = F.conv2d(c1_4, u['off_w_cl'], u['off_b'], stride=1, padding=dilate, dilation=dilate).contiguous()
+        col = hip.deform_im2col(c1_4.contiguous(), off, 3, 3, dilate, 1, dilate, P.NUM_DEFORMABLE_GROUP)
+        return torch.mm(col[0].t(), u['w2_2d_t'])              # (H*W, Cout); transposed operand, no copy
+
+    def _resnet_cl(self, x, net, stages, tail):
+        """_resnet on channels-last activations (batch 1, fp32).  Returns an NCHW-shaped channels_last map."""
+        net.prepare_channels_last()
+        cl = torch.channels_last
+        x = hip.scale_shift_relu(x, net.bn_data[0], net.bn_data[1], relu=False).contiguous(memory_format=cl)
+        y = F.conv2d(x, net.conv0_w_cl, None, stride=2, padding=3)
+        r = self._rows(y)
+        hip.scale_shift_relu_cl(r, self._ones(r.shape[1]), net.conv0_b, relu=True, out=r)
+        x4 = F.max_pool2d(self._map(r, y.shape[2], y.shape[3]), 3, 2, 1)
+        dilate = 1
+        for u in net.units:
+            if u['stage'] > stages:
+                break
+            first = u['unit'] == 1
+            stride = 2 if (first and u['stage'] in (2, 3)) else 1
+            unit_dilate = dilate
+            if first and u['stage'] == 4:
+                dilate = dilate * 2
+            h, w = x4.shape[2], x4.shape[3]
+            x2 = self._rows(x4)
+            a2 = hip.scale_shift_relu_cl(x2, u['bn1'][0], u['bn1'][1], relu=True)
+            c1 = torch._addmm_activation(u['b1'], a2, u['w1_t'])                  # conv1 + folded bn2 + ReLU
+            if u['dcn']:
+                c2 = self._dcn_cl(self._map(c1, h, w), u, unit_dilate)
+                ho, wo = h, w
+            else:
+                c2_4 = F.conv2d(self._map(c1, h, w), u['w2_cl'], None, stride=stride, padding=unit_dilate,
+                                dilation=unit_dilate)
+                ho, wo = c2_4.shape[2], c2_4.shape[3]
+                c2 = self._rows(c2_4)
+            hip.scale_shift_relu_cl(c2, self._ones(c2.shape[1]), u['b2'], relu=True, out=c2)   # folded bn3 bias + ReLU
+            if first:
+                sc = self._rows(F.conv2d(self._map(a2, h, w), u['sc_cl'], None, stride=stride)) if stride != 1 \
+                    else torch.mm(a2, u['sc_t'])
+            else:
+                sc = x2                                         # overwritten in place by conv3's GEMM (beta = 1)
+            x4 = self._map(sc.addmm_(c2, u['w3_t']), ho, wo)
+        if tail:
+            h, w = x4.shape[2], x4.shape[3]
+            x4 = self._map(hip.scale_shift_relu_cl(self._rows(x4), net.bn1[0], net.bn1[1], relu=True), h, w)
+        return x4
+
     def _backbone(self, data):
+        if 'backbone' in self.cl and data.shape[0] == 1:
+            if not hasattr(self, 'feat_w_cl'):
+                self.feat_w_cl = self.feat_w.contiguous(memory_format=torch.channels_last)
+            x4 = self._resnet_cl(data, self.net, 4, True)
+            y = F.conv2d(x4, self.feat_w_cl, None, padding=6, dilation=6)
+            r = self._rows(y)
+            hip.scale_shift_relu_cl(r, self._ones(r.shape[1]), self.feat_b, relu=True, out=r)
+            return self._map(r, y.shape[2], y.shape[3]).contiguous()   # NCHW for the warp / aggregation kernels and the API
         x = self._resnet(data, self.net, 4, True)
         return self._bias_act(F.conv2d(x, self.feat_w, None, padding=6, dilation=6).float(), self.feat_b.float(), True)
 
@@ -382,8 +481,15 @@ class Executor(object):
             y = y[:, :, 1:1 + like.shape[2], 1:1 + like.shape[3]]      # Crop(offset=(1,1)) to the skip tensor
             return F.leaky_relu(y, 0.1) if act else y
 
+        if 'flownet' in self.cl:
+            if not hasattr(self, 'flow_cl'):
+                self.flow_cl = {k: (v.contiguous(memory_format=torch.channels_last) if v.dim() == 4 else v)
+                                for k, v in self.flow.items()}
+            fw = self.flow_cl
         data = self._c(torch.cat([img_cur / 255.0, img_ref / 255.0], 1))
         x = F.avg_pool2d(data, 2, 2, ceil_mode=True)
+        if 'flownet' in self.cl:
+            x = x.contiguous(memory_format=torch.channels_last)
         r1 = conv(x, 'flow_conv1', 2, 3)
         r2 = conv(r1, 'conv2', 2, 2)
         r3 = conv(r2, 'conv3', 2, 2)
@@ -405,7 +511,7 @@ class Executor(object):
         c5 = F.avg_pool2d(c5, 2, 2, ceil_mode=True)
         flow = conv(c5, 'Convolution5', act=False).float() * 2.5
         scale = F.conv2d(c5, fw['Convolution5_scale_weight'], fw['Convolution5_scale_bias']).float()
-        return flow, scale
+        return flow.contiguous(), scale.contiguous()
 
     def _heads(self, conv_feat, im_info):
         """SliceChannel -> RPN -> Proposal -> R-FCN maps -> PSROI + average + softmax (:479-546)."""
@@ -520,6 +626,11 @@ class Executor(object):
         rest of the frame (lsfa_amd/core/graphs.py overlaps it with the previous frame's tail)."""
         with torch.no_grad():
             img = F.avg_pool2d(data, 4, 4, ceil_mode=True)
+            if 'small' in self.cl and data.shape[0] == 1:
+                if not hasattr(self, 'fuse_w_cl'):
+                    self.fuse_w_cl = self.fuse_w.contiguous(memory_format=torch.channels_last)
+                s = self._resnet_cl(img, self.small, 1, False)
+                return F.conv2d(s, self.fuse_w_cl, self.fuse_b, padding=1).contiguous()
             s = self._resnet(img, self.small, 1, False)
             return F.conv2d(s, self.fuse_w, self.fuse_b, padding=1).float()
 

@@ -378,6 +378,23 @@ def test_scale_shift_relu_bit_exact(hip, shape):
         np.testing.assert_array_equal(got, want)
 
 
+@pytest.mark.parametrize("shape", [(150 * 250, 64), (2394, 1024), (7, 4)])
+def test_scale_shift_relu_channels_last_bit_exact(hip, shape):
+    """(rows, C) maps with the channel fastest == the NCHW statement with N = rows, HW = 1."""
+    rs = np.random.RandomState(shape[1])
+    x = rs.randn(*shape).astype(np.float32)
+    sc, sh = rs.rand(shape[1]).astype(np.float32) + 0.5, rs.randn(shape[1]).astype(np.float32)
+    for relu in (True, False):
+        want = oracle.scale_shift_relu(x.reshape(shape[0], shape[1], 1), sc, sh, relu).reshape(shape)
+        got = hip.scale_shift_relu_cl(t(x), t(sc), t(sh), relu).cpu().numpy()
+        np.testing.assert_array_equal(got, want)
+    xt = t(x)
+    hip.scale_shift_relu_cl(xt, t(sc), t(sh), True, out=xt)            # in place
+    np.testing.assert_array_equal(xt.cpu().numpy(), want if relu else oracle.scale_shift_relu(x.reshape(shape[0], shape[1], 1), sc, sh, True).reshape(shape))
+    with pytest.raises(hip.LsfaError):
+        hip.scale_shift_relu_cl(torch.zeros(5, 6, device=DEV), torch.ones(6, device=DEV), torch.zeros(6, device=DEV))
+
+
 # ------------------------------------------------------------------ profiling hook ----
 def test_prof_hooks_report_launches(hip):
     hip.prof_enable(True)

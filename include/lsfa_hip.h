@@ -186,6 +186,14 @@ int lsfa_deform_im2col(const float* data, const float* offset,
                        int pad, int stride, int dilate, int deform_groups,
                        int Ho, int Wo, float* col, void* stream);
 
+/* The same sampling for channels-last tensors: data (N,H,W,C), offset (N,Ho,Wo,2*kh*kw*dg),
+ * col (N, Ho*Wo, kh*kw, C) — a row of col is one output pixel, ordered (tap, channel), so the
+ * contraction is rows x (kh*kw*C, Cout).  C/deform_groups must be a multiple of 4. */
+int lsfa_deform_im2col_cl(const float* data, const float* offset,
+                          int N, int C, int H, int W, int kh, int kw,
+                          int pad, int stride, int dilate, int deform_groups,
+                          int Ho, int Wo, float* col, void* stream);
+
 /* Inference BatchNorm (use_global_stats) + ReLU as one pass: y = max(x*scale[c]+shift[c], 0)
  * (sym_common.py:92-102 bn + relu of every pre-activation unit, resnet.py:70-101).
  * relu != 0 applies the ReLU.  In-place (y == x) allowed. */

@@ -51,6 +51,52 @@ __global__ __launch_bounds__(kThreads) void deform_im2col_kernel(const float* __
   }
 }
 
+// Channels-last form: data (N, H, W, C), offset (N, Ho, Wo, 2*KK*dg), col (N, Ho*Wo, KK, C).
+// A thread produces four consecutive channels of one (pixel, tap): the 128 channels of a deformable
+// group share the tap's offset, so a wave reads each of the four corners as 1 KB of consecutive
+// channels and writes 1 KB of col — every access is a full line.  The corner selection and the
+// weights are those of dcn_bilinear (same expressions, same order => same bits per channel).
+__global__ __launch_bounds__(kThreads) void deform_im2col_cl_kernel(const float* __restrict__ data,
+                                                                    const float* __restrict__ offset, int C, int H,
+                                                                    int W, int kh, int kw, int pad, int stride,
+                                                                    int dilate, int dg, int Ho, int Wo,
+                                                                    float* __restrict__ col, size_t total4) {
+  const int KK = kh * kw, C4 = C / 4, cpg = C / dg, HoWo = Ho * Wo;
+  for (size_t idx = (size_t)blockIdx.x * kThreads + threadIdx.x; idx < total4; idx += (size_t)gridDim.x * kThreads) {
+    const int c = (int)(idx % C4) * 4;
+    const int tap = (int)((idx / C4) % KK);
+    const size_t pix = idx / C4 / KK;                 // n * HoWo + sp
+    const int sp = (int)(pix % HoWo);
+    const int n = (int)(pix / HoWo);
+    const int ho = sp / Wo, wo = sp - ho * Wo;
+    const int i = tap / kw, j = tap - i * kw;
+    const int g = c / cpg;
+    const float* off = offset + pix * (size_t)(2 * KK * dg) + (size_t)g * 2 * KK + 2 * tap;
+    const float oh = off[0], ow = off[1];
+    float h = (float)(ho * stride - pad + i * dilate) + oh;
+    float w = (float)(wo * stride - pad + j * dilate) + ow;
+    float4 val = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (h >= 0 && w >= 0 && h < H && w < W) {
+      int h_low = (int)floorf(h), w_low = (int)floorf(w);
+      int h_high, w_high;
+      if (h_low >= H - 1) { h_high = h_low = H - 1; h = (float)h_low; } else { h_high = h_low + 1; }
+      if (w_low >= W - 1) { w_high = w_low = W - 1; w = (float)w_low; } else { w_high = w_low + 1; }
+      const float lh = h - h_low, lw = w - w_low, hh = 1 - lh, hw = 1 - lw;
+      const float* base = data + (size_t)n * H * W * C + c;
+      const float4 v1 = *reinterpret_cast<const float4*>(base + ((size_t)h_low * W + w_low) * C);
+      const float4 v2 = *reinterpret_cast<const float4*>(base + ((size_t)h_low * W + w_high) * C);
+      const float4 v3 = *reinterpret_cast<const float4*>(base + ((size_t)h_high * W + w_low) * C);
+      const float4 v4 = *reinterpret_cast<const float4*>(base + ((size_t)h_high * W + w_high) * C);
+      const float w1 = hh * hw, w2 = hh * lw, w3 = lh * hw, w4 = lh * lw;
+      val.x = w1 * v1.x + w2 * v2.x + w3 * v3.x + w4 * v4.x;
+      val.y = w1 * v1.y + w2 * v2.y + w3 * v3.y + w4 * v4.y;
+      val.z = w1 * v1.z + w2 * v2.z + w3 * v3.z + w4 * v4.z;
+      val.w = w1 * v1.w + w2 * v2.w + w3 * v3.w + w4 * v4.w;
+    }
+    reinterpret_cast<float4*>(col)[idx] = val;
+  }
+}
+
 template <int VEC>
 __global__ __launch_bounds__(kThreads) void scale_shift_relu_kernel(const float* __restrict__ x,
                                                                     const float* __restrict__ scale,
@@ -128,6 +174,27 @@ extern "C" int lsfa_deform_im2col(const float* data, const float* offset, int N,
   hipLaunchKernelGGL(deform_im2col_kernel, dim3((unsigned)nb), dim3(kThreads), 0, s, data, offset, C, H, W, kh, kw, pad,
                      stride, dilate, deform_groups, Ho, Wo, col, total);
   LSFA_LAUNCH_CHECK("lsfa_deform_im2col");
+  return LSFA_OK;
+}
+
+extern "C" int lsfa_deform_im2col_cl(const float* data, const float* offset, int N, int C, int H, int W, int kh, int kw,
+                                     int pad, int stride, int dilate, int deform_groups, int Ho, int Wo, float* col,
+                                     void* stream) {
+  LSFA_REQUIRE(data && offset && col, "lsfa_deform_im2col_cl: NULL argument");
+  LSFA_REQUIRE(N > 0 && C > 0 && H > 0 && W > 0 && kh > 0 && kw > 0 && stride > 0 && dilate > 0 && Ho > 0 && Wo > 0,
+               "lsfa_deform_im2col_cl: bad shape");
+  LSFA_REQUIRE(deform_groups > 0 && C % deform_groups == 0 && (C / deform_groups) % 4 == 0,
+               "lsfa_deform_im2col_cl: C=%d, deformable groups %d: channels per group must be a multiple of 4", C,
+               deform_groups);
+  LSFA_REQUIRE(!((uintptr_t)data % 16) && !((uintptr_t)col % 16), "lsfa_deform_im2col_cl: data/col must be 16-byte aligned");
+  hipStream_t s = (hipStream_t)stream;
+  const size_t total4 = (size_t)N * Ho * Wo * kh * kw * (C / 4);
+  size_t nb = (total4 + kThreads - 1) / kThreads;
+  if (nb > 65536) nb = 65536;
+  ProfScope prof(LSFA_OP_DCN_IM2COL, s);
+  hipLaunchKernelGGL(deform_im2col_cl_kernel, dim3((unsigned)nb), dim3(kThreads), 0, s, data, offset, C, H, W, kh, kw,
+                     pad, stride, dilate, deform_groups, Ho, Wo, col, total4);
+  LSFA_LAUNCH_CHECK("lsfa_deform_im2col_cl");
   return LSFA_OK;
 }
 

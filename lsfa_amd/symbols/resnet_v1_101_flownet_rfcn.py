@@ -229,7 +229,8 @@ class _ResNetWeights(object):
                 d['sc_cl'] = d['sc'].contiguous(memory_format=cl)
             if d['dcn']:
                 d['off_w_cl'] = d['off_w'].contiguous(memory_format=cl)
-                d['w2_2d_t'] = d['w2_2d'].t().contiguous()
+                # (Cout, C, 3, 3) -> rows ordered (tap, c) to match lsfa_deform_im2col_cl's col
+                d['w2_tap_t'] = d['w2'].permute(2, 3, 1, 0).reshape(-1, d['w2'].shape[0]).contiguous()
         self._cl_ready = True
 
 
@@ -410,9 +411,12 @@ class Executor(object):
         return x2.view(1, h, w, x2.shape[1]).permute(0, 3, 1, 2)
 
     def _dcn_cl(self, c1_4, u, dilate):
-        off = F.conv2d(c1_4, u['off_w_cl'], u['off_b'], stride=1, padding=dilate, dilation=dilate).contiguous()
-        col = hip.deform_im2col(c1_4.contiguous(), off, 3, 3, dilate, 1, dilate, P.NUM_DEFORMABLE_GROUP)
-        return torch.mm(col[0].t(), u['w2_2d_t'])              # (H*W, Cout); transposed operand, no copy
+        """DeformableConvolution on channels-last maps: offset conv, channels-last bilinear im2col (rows
+        ordered (tap, channel)), one row GEMM with the weight permuted to match."""
+        off = F.conv2d(c1_4, u['off_w_cl'], u['off_b'], stride=1, padding=dilate, dilation=dilate)
+        col = hip.deform_im2col_cl(c1_4.permute(0, 2, 3, 1), off.permute(0, 2, 3, 1), 3, 3, dilate, 1, dilate,
+                                   P.NUM_DEFORMABLE_GROUP)
+        return torch.mm(col[0], u['w2_tap_t'])                  # (H*W, 9*C) x (9*C, Cout)
 
     def _resnet_cl(self, x, net, stages, tail):
         """_resnet on channels-last activations (batch 1, fp32).  Returns an NCHW-shaped channels_last map."""

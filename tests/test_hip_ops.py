@@ -367,6 +367,29 @@ def test_deform_im2col_bit_exact(hip, cfg):
     np.testing.assert_array_equal(z.cpu().numpy(), ref.numpy())
 
 
+@pytest.mark.parametrize("cfg", [dict(C=16, H=19, W=23, k=3, pad=2, stride=1, dil=2, dg=4),
+                                 dict(C=32, H=20, W=21, k=3, pad=1, stride=2, dil=1, dg=4),
+                                 dict(C=512, H=38, W=63, k=3, pad=2, stride=1, dil=2, dg=4),
+                                 dict(C=12, H=9, W=9, k=3, pad=1, stride=1, dil=1, dg=1)])
+def test_deform_im2col_channels_last_bit_exact(hip, cfg):
+    """The channels-last kernel samples exactly what the NCHW statement samples:
+    col_cl[n, pixel, tap, c] == col[n, c*KK + tap, pixel]."""
+    rs = np.random.RandomState(cfg["C"] + 1)
+    C, H, W, k = cfg["C"], cfg["H"], cfg["W"], cfg["k"]
+    Ho = (H + 2 * cfg["pad"] - (cfg["dil"] * (k - 1) + 1)) // cfg["stride"] + 1
+    Wo = (W + 2 * cfg["pad"] - (cfg["dil"] * (k - 1) + 1)) // cfg["stride"] + 1
+    N = 1 if C > 100 else 2
+    data = rs.randn(N, C, H, W).astype(np.float32)
+    offset = (2.0 * rs.randn(N, 2 * k * k * cfg["dg"], Ho, Wo)).astype(np.float32)
+    offset[:, :, 0, :] *= 8.0            # push some taps outside the image
+    want = oracle.deform_im2col(data, offset, k, k, cfg["pad"], cfg["stride"], cfg["dil"], cfg["dg"])
+    want_cl = want.reshape(N, C, k * k, Ho * Wo).transpose(0, 3, 2, 1).reshape(N, Ho * Wo, k * k * C)
+    got = hip.deform_im2col_cl(t(np.ascontiguousarray(data.transpose(0, 2, 3, 1))),
+                               t(np.ascontiguousarray(offset.transpose(0, 2, 3, 1))), k, k, cfg["pad"], cfg["stride"],
+                               cfg["dil"], cfg["dg"]).cpu().numpy()
+    np.testing.assert_array_equal(got, want_cl)
+
+
 @pytest.mark.parametrize("shape", [(1, 64, 300, 500), (1, 256, 38, 63), (2, 7, 5, 3)])
 def test_scale_shift_relu_bit_exact(hip, shape):
     rs = np.random.RandomState(shape[1])

@@ -1,0 +1,21 @@
+#!/usr/bin/env python
+"""The key frame's backbone alone, eagerly, many times (for rocprofv3 kernel traces: the second half
+of the trace is steady state)."""
+import sys
+import torch
+import os
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..'))
+from lsfa_amd.config.config import lsfa_test_config
+from lsfa_amd.symbols import params as P
+from lsfa_amd.symbols.resnet_v1_101_flownet_rfcn import resnet_v1_101_flownet_rfcn
+torch.backends.cudnn.benchmark = True
+dev = 'cuda:0'
+cfg = lsfa_test_config(key_frame_interval=10)
+arg, aux = P.init_params(cfg, seed=0)
+key = resnet_v1_101_flownet_rfcn(cfg).get_key_test_symbol(cfg).bind(arg, aux, dev)
+data = torch.rand(1, 3, 600, 1000, device=dev) * 255
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 100
+with torch.no_grad():
+    for _ in range(n):
+        key._backbone(data)
+torch.cuda.synchronize()

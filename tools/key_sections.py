@@ -2,7 +2,8 @@
 """Where a key frame's time goes: each section captured as its own hipGraph and replayed alone."""
 import sys
 import torch
-sys.path.insert(0, '.')
+import os
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..'))
 from lsfa_amd.config.config import lsfa_test_config
 from lsfa_amd.symbols import params as P
 from lsfa_amd.symbols.resnet_v1_101_flownet_rfcn import resnet_v1_101_flownet_rfcn

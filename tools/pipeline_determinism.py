@@ -3,7 +3,8 @@
 per-frame mismatches (a race between streams shows up as run-to-run differences)."""
 import sys
 import numpy as np, torch
-sys.path.insert(0, '.')
+import os
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..'))
 from lsfa_amd.config.config import lsfa_test_config
 from lsfa_amd.core.graphs import FrameGraphs, FramePipeline
 from lsfa_amd.symbols import params as P

@@ -20,6 +20,7 @@ def trace_summary(d, out, tail_frac=0.5, top=60):
         nframes = len([i for i in caps if i > start])
     else:
         nframes = 0
+        rows = rows[int(len(rows) * (1 - tail_frac)):]
     t0, t1 = int(rows[0]['Start_Timestamp']), max(int(r['End_Timestamp']) for r in rows)
     agg = collections.defaultdict(lambda: [0, 0])
     for r in rows:

@@ -4,7 +4,8 @@ Non-key frames depend only on the key feature, so frame t's single-workgroup tai
 head, detection NMS) can run beside frame t+1's convolutions."""
 import sys, time
 import torch
-sys.path.insert(0, '.')
+import os
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..'))
 from lsfa_amd.config.config import lsfa_test_config
 from lsfa_amd.core.graphs import FrameGraphs
 from lsfa_amd.symbols import params as P

@@ -54,6 +54,8 @@ def parse():
                     help='non-key frames of a segment alternate over this many streams while the next key frame runs on '
                          'its own stream (lsfa_amd.core.graphs.FramePipeline); 0 = strictly serial frames')
     ap.add_argument('--key-lanes', type=int, default=1, help='streams the key frames alternate over (with --lanes > 0)')
+    ap.add_argument('--no-tuned-gemms', action='store_true',
+                    help='library-default GEMM heuristics instead of lsfa_amd/tuned/gemm_gfx950.csv (lsfa_amd.tuning)')
     ap.add_argument('--cpu-budget-s', type=float, default=20.0)
     ap.add_argument('--max-unique-steps', type=int, default=16, help='distinct intervals of frames kept in HBM')
     return ap.parse_args()
@@ -208,7 +210,8 @@ def main():
     torch.cuda.set_device(local_rank)
     torch.backends.cudnn.benchmark = os.environ.get('LSFA_MIOPEN_FIND', '1') == '1'
 
-    from lsfa_amd import hip
+    from lsfa_amd import hip, tuning
+    tuned = None if args.no_tuned_gemms else tuning.enable(tune_missing=True)
     r = Runner(args, rank, device)
     r.prime()
     for s in range(args.warmup):
@@ -259,6 +262,8 @@ def main():
                        "frames_per_step": K, "ms_per_frame": round(elapsed / (args.steps * K) * 1e3, 3),
                        "parallelism": "clip-parallel x%d" % world, "detections_last_interval": total_dets,
                        "launch": "eager" if args.no_graph else "hipGraph replay per frame",
+                       "gemm_solutions": "library default" if tuned is None else
+                                         ("lsfa_amd/tuned/gemm_gfx950.csv" if tuned else "tuned on first use (shipped file rejected)"),
                        "pipeline": ("%d key lanes (front/back graphs) + %d non-key lanes" % (args.key_lanes, args.lanes)) if args.lanes > 0 else "serial"},
             "roofline": {"bound": "hbm", "kernel": "warp_kernel (lsfa_warp_bilinear: MV/flow warp + fused epilogue)",
                          "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",

@@ -440,3 +440,28 @@ def test_pred_eval_pipelined_two_videos(world):
             if len(same) and ((np.abs(same[:, 3:7] - row[3:7]).max(1) < 0.1) & (np.abs(same[:, 2] - row[2]) < 1e-3)).any():
                 matched += 1
         assert matched >= 0.7 * len(a), "frame %d: %d of %d matched" % (f, matched, len(a))
+
+
+def test_tuned_gemm_file_is_accepted_and_parity_holds(world):
+    """lsfa_amd.tuning: the shipped TunableOp results are accepted by this PyTorch / rocBLAS / hipBLASLt
+    build, and with solution selection on (shapes of this small test are tuned on first use) the key
+    graph still matches the oracle graph within the convolution tolerance."""
+    from lsfa_amd import tuning
+    cfg, arg, aux, key, clip = world['cfg'], world['arg'], world['aux'], world['key'], world['clip']
+    ok = tuning.enable(tune_missing=True)
+    try:
+        assert ok, "lsfa_amd/tuned/gemm_gfx950.csv rejected: regenerate with tools/tune_gemms.py"
+        import torch.cuda.tunable as T
+        assert T.is_enabled() and len(T.get_results()) >= 20
+        im_info = clip.im_info()
+        f0 = clip.frame(0)
+        key.taps = {}
+        out = key.forward(data=f0.to(DEV), im_info=torch.from_numpy(im_info).to(DEV), data_key_old=f0.to(DEV),
+                          feat_key_old=torch.zeros(1, 1024, 1, 1, device=DEV))
+        ref = graph_ref.key_forward(cfg, arg, aux, f0.numpy(), f0.numpy(), np.zeros((1, 1024, 1, 1), np.float32), im_info)
+        assert rel_err(np_(key.taps['backbone_feat']), ref['backbone_feat']) < 2e-3
+        assert rel_err(np_(key.taps['cls_map']), ref['cls_map']) < 2e-3
+        check_heads(cfg, key.taps, out, im_info)
+    finally:
+        key.taps = None
+        tuning.disable()

@@ -200,6 +200,11 @@ int lsfa_deform_im2col_cl(const float* data, const float* offset,
 int lsfa_scale_shift_relu(const float* x, const float* scale, const float* shift,
                           int N, int C, int HW, int relu, float* y, void* stream);
 
+/* y = leaky(x*scale[c]+shift[c]) with leaky(v) = v > 0 ? v : v*slope — a convolution's bias and the
+ * LeakyReLU(0.1) that follows it in FlowNet (resnet_v1_101_flownet_rfcn.py:153-176) as one pass. */
+int lsfa_scale_shift_leaky(const float* x, const float* scale, const float* shift,
+                           int N, int C, int HW, float slope, float* y, void* stream);
+
 /* The same pass for a channels-last map: x, y are (rows, C) with the channel the fastest axis
  * (rows = N*H*W), C a multiple of 4, all pointers 16-byte aligned.  In-place allowed. */
 int lsfa_scale_shift_relu_cl(const float* x, const float* scale, const float* shift,

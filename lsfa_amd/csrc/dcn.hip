@@ -101,7 +101,8 @@ template <int VEC>
 __global__ __launch_bounds__(kThreads) void scale_shift_relu_kernel(const float* __restrict__ x,
                                                                     const float* __restrict__ scale,
                                                                     const float* __restrict__ shift, int C, int HW,
-                                                                    int relu, float* __restrict__ y, size_t nvec) {
+                                                                    int relu, float slope, float* __restrict__ y,
+                                                                    size_t nvec) {
   for (size_t v = (size_t)blockIdx.x * kThreads + threadIdx.x; v < nvec; v += (size_t)gridDim.x * kThreads) {
     const size_t e = v * VEC;
     const int c = (int)((e / HW) % C);
@@ -113,7 +114,7 @@ __global__ __launch_bounds__(kThreads) void scale_shift_relu_kernel(const float*
 #pragma unroll
     for (int i = 0; i < VEC; ++i) {
       const float r = in[i] * sc + sh;
-      out[i] = (relu && r < 0.f) ? 0.f : r;
+      out[i] = relu == 2 ? (r > 0.f ? r : r * slope) : ((relu && r < 0.f) ? 0.f : r);
     }
     if (VEC == 4) *reinterpret_cast<float4*>(y + e) = make_float4(out[0], out[1], out[2], out[3]);
     else if (VEC == 2) *reinterpret_cast<float2*>(y + e) = make_float2(out[0], out[1]);
@@ -198,10 +199,8 @@ extern "C" int lsfa_deform_im2col_cl(const float* data, const float* offset, int
   return LSFA_OK;
 }
 
-extern "C" int lsfa_scale_shift_relu(const float* x, const float* scale, const float* shift, int N, int C, int HW,
-                                     int relu, float* y, void* stream) {
-  LSFA_REQUIRE(x && scale && shift && y, "lsfa_scale_shift_relu: NULL argument");
-  LSFA_REQUIRE(N > 0 && C > 0 && HW > 0, "lsfa_scale_shift_relu: bad shape");
+static int scale_shift_act(const float* x, const float* scale, const float* shift, int N, int C, int HW, int relu,
+                           float slope, float* y, void* stream) {
   hipStream_t s = (hipStream_t)stream;
   const size_t total = (size_t)N * C * HW;
   int vec = (HW % 4 == 0) ? 4 : (HW % 2 == 0) ? 2 : 1;
@@ -210,9 +209,23 @@ extern "C" int lsfa_scale_shift_relu(const float* x, const float* scale, const f
   size_t nb = (nvec + kThreads - 1) / kThreads;
   if (nb > 4096) nb = 4096;
   ProfScope prof(LSFA_OP_BNRELU, s);
-  if (vec == 4) hipLaunchKernelGGL(scale_shift_relu_kernel<4>, dim3((unsigned)nb), dim3(kThreads), 0, s, x, scale, shift, C, HW, relu, y, nvec);
-  else if (vec == 2) hipLaunchKernelGGL(scale_shift_relu_kernel<2>, dim3((unsigned)nb), dim3(kThreads), 0, s, x, scale, shift, C, HW, relu, y, nvec);
-  else hipLaunchKernelGGL(scale_shift_relu_kernel<1>, dim3((unsigned)nb), dim3(kThreads), 0, s, x, scale, shift, C, HW, relu, y, nvec);
+  if (vec == 4) hipLaunchKernelGGL(scale_shift_relu_kernel<4>, dim3((unsigned)nb), dim3(kThreads), 0, s, x, scale, shift, C, HW, relu, slope, y, nvec);
+  else if (vec == 2) hipLaunchKernelGGL(scale_shift_relu_kernel<2>, dim3((unsigned)nb), dim3(kThreads), 0, s, x, scale, shift, C, HW, relu, slope, y, nvec);
+  else hipLaunchKernelGGL(scale_shift_relu_kernel<1>, dim3((unsigned)nb), dim3(kThreads), 0, s, x, scale, shift, C, HW, relu, slope, y, nvec);
   LSFA_LAUNCH_CHECK("lsfa_scale_shift_relu");
   return LSFA_OK;
+}
+
+extern "C" int lsfa_scale_shift_relu(const float* x, const float* scale, const float* shift, int N, int C, int HW,
+                                     int relu, float* y, void* stream) {
+  LSFA_REQUIRE(x && scale && shift && y, "lsfa_scale_shift_relu: NULL argument");
+  LSFA_REQUIRE(N > 0 && C > 0 && HW > 0, "lsfa_scale_shift_relu: bad shape");
+  return scale_shift_act(x, scale, shift, N, C, HW, relu ? 1 : 0, 0.f, y, stream);
+}
+
+extern "C" int lsfa_scale_shift_leaky(const float* x, const float* scale, const float* shift, int N, int C, int HW,
+                                      float slope, float* y, void* stream) {
+  LSFA_REQUIRE(x && scale && shift && y, "lsfa_scale_shift_leaky: NULL argument");
+  LSFA_REQUIRE(N > 0 && C > 0 && HW > 0, "lsfa_scale_shift_leaky: bad shape");
+  return scale_shift_act(x, scale, shift, N, C, HW, 2, slope, y, stream);
 }

@@ -286,6 +286,17 @@ def scale_shift_relu(x, scale, shift, relu=True, out=None):
     return out
 
 
+def scale_shift_leaky(x, scale, shift, slope, out=None):
+    x = _f32c(x, "x")
+    N, C = x.shape[0], x.shape[1]
+    HW = x.numel() // (N * C)
+    if out is None:
+        out = torch.empty_like(x)
+    _check(lib().lsfa_scale_shift_leaky(_ptr(x), _ptr(scale), _ptr(shift), _ci(N), _ci(C), _ci(HW), _cf(slope),
+                                        _ptr(out), _stream()), "lsfa_scale_shift_leaky")
+    return out
+
+
 def scale_shift_relu_cl(x, scale, shift, relu=True, out=None):
     """Channels-last form: x (..., C) contiguous with the channel the fastest axis, C % 4 == 0."""
     x = _f32c(x, "x")

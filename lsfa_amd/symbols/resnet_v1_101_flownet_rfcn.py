@@ -31,9 +31,11 @@ from lsfa_amd.symbols import params as P
 
 BN_EPS = 2e-5  # sym_common.py:9
 import os as _os
-# measured at 1000x600 fp32 (us, hipGraph replay): backbone 5806 -> 5476, small net 270 -> 258, FlowNet 1164 -> 1566
-# (its large-kernel strided convolutions and deconvolutions are slower channels-last), hence:
+# measured at 1000x600 fp32 (us, hipGraph replay): backbone 5806 -> 5476 (5175 with the channels-last DCN im2col),
+# small net 270 -> 258.  FlowNet stays NCHW: its large-kernel strided convolutions and deconvolutions were
+# slower channels-last (1164 -> 1566 us).
 _CL_DEFAULT = 'backbone,small'
+_FLOW_GEMM_MAX_L = int(_os.environ.get('LSFA_FLOW_GEMM_L', '700'))   # FlowNet convs with at most this many output pixels run as im2col + GEMM
 _CONV1X1_MIOPEN = _os.environ.get('LSFA_CONV1X1_MIOPEN', '0') == '1'   # experiment: channel-reducing 1x1 convs through MIOpen
 
 
@@ -244,7 +246,7 @@ class Executor(object):
         self.taps = None              # set to {} to record stage outputs (parity tests)
         self._const = {}
         # which sub-networks run channels-last (activations as (H*W, C) rows): LSFA_CL = comma list of
-        # backbone, flownet, small; fp32 contractions only
+        # backbone, small; fp32 contractions only
         want = _os.environ.get('LSFA_CL', _CL_DEFAULT)
         self.cl = set(x for x in want.split(',') if x) if dtype == torch.float32 else set()
         cfg = self.cfg
@@ -476,24 +478,38 @@ class Executor(object):
         """FlowNet-S on the half-resolution pair (:150-207)."""
         fw = self.flow
 
-        def conv(x, name, stride=1, pad=1, act=True):
-            y = F.conv2d(x, fw[name + '_weight'], fw[name + '_bias'], stride=stride, padding=pad)
+        fused = self.cdtype == torch.float32      # bias + LeakyReLU as one HIP pass (fp32 maps)
+        gemm_max = _FLOW_GEMM_MAX_L if fused else 0
+
+        def bias_act(y, b, act):
+            if fused:
+                c = y.shape[1]
+                if act:
+                    return hip.scale_shift_leaky(y, self._ones(c), b, 0.1, out=y)
+                return hip.scale_shift_relu(y, self._ones(c), b, relu=False, out=y)
+            y = y + b.view(1, -1, 1, 1)
             return F.leaky_relu_(y, 0.1) if act else y
 
-        def deconv(x, name, like, act):
-            y = F.conv_transpose2d(x, fw[name + '_weight'], fw[name + '_bias'], stride=2)
-            y = y[:, :, 1:1 + like.shape[2], 1:1 + like.shape[3]]      # Crop(offset=(1,1)) to the skip tensor
-            return F.leaky_relu(y, 0.1) if act else y
+        def conv(x, name, stride=1, pad=1, act=True):
+            w, b = fw[name + '_weight'], fw[name + '_bias']
+            k = w.shape[2]
+            ho, wo = (x.shape[2] + 2 * pad - k) // stride + 1, (x.shape[3] + 2 * pad - k) // stride + 1
+            if x.shape[0] == 1 and ho * wo <= gemm_max:
+                # small output map: the weights dominate the traffic (conv6_1: 37.7 MB of weights for 40
+                # output pixels); im2col + one weight-streaming GEMM beats the library's convolution kernels
+                col = F.unfold(x, k, padding=pad, stride=stride)[0]               # (Cin*k*k, ho*wo)
+                y = torch.mm(w.view(w.shape[0], -1), col).view(1, -1, ho, wo)
+            else:
+                y = F.conv2d(x, w, None, stride=stride, padding=pad)
+            return bias_act(y, b, act)
 
-        if 'flownet' in self.cl:
-            if not hasattr(self, 'flow_cl'):
-                self.flow_cl = {k: (v.contiguous(memory_format=torch.channels_last) if v.dim() == 4 else v)
-                                for k, v in self.flow.items()}
-            fw = self.flow_cl
+        def deconv(x, name, like, act):
+            y = F.conv_transpose2d(x, fw[name + '_weight'], None, stride=2)
+            y = bias_act(y, fw[name + '_bias'], act)                              # on the full map, then
+            return y[:, :, 1:1 + like.shape[2], 1:1 + like.shape[3]]              # Crop(offset=(1,1)) to the skip tensor
+
         data = self._c(torch.cat([img_cur / 255.0, img_ref / 255.0], 1))
         x = F.avg_pool2d(data, 2, 2, ceil_mode=True)
-        if 'flownet' in self.cl:
-            x = x.contiguous(memory_format=torch.channels_last)
         r1 = conv(x, 'flow_conv1', 2, 3)
         r2 = conv(r1, 'conv2', 2, 2)
         r3 = conv(r2, 'conv3', 2, 2)
@@ -514,8 +530,8 @@ class Executor(object):
         c5 = torch.cat([r2, deconv(c4, 'deconv2', r2, True), deconv(f3, 'upsample_flow3to2', r2, False)], 1)
         c5 = F.avg_pool2d(c5, 2, 2, ceil_mode=True)
         flow = conv(c5, 'Convolution5', act=False).float() * 2.5
-        scale = F.conv2d(c5, fw['Convolution5_scale_weight'], fw['Convolution5_scale_bias']).float()
-        return flow.contiguous(), scale.contiguous()
+        scale = conv(c5, 'Convolution5_scale', pad=0, act=False).float()
+        return flow, scale
 
     def _heads(self, conv_feat, im_info):
         """SliceChannel -> RPN -> Proposal -> R-FCN maps -> PSROI + average + softmax (:479-546)."""

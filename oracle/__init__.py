@@ -246,6 +246,15 @@ def deform_im2col(data, offset, kh, kw, pad, stride, dilate, deform_groups):
     return col
 
 
+def scale_shift_leaky(x, scale, shift, slope):
+    x, scale, shift = _f32(x), _f32(scale), _f32(shift)
+    N, C = x.shape[:2]
+    HW = int(np.prod(x.shape[2:]))
+    y = np.empty_like(x)
+    lib().orc_scale_shift_leaky(_p(x), _p(scale), _p(shift), _ci(N), _ci(C), _ci(HW), _cf(slope), _p(y))
+    return y
+
+
 def scale_shift_relu(x, scale, shift, relu=True):
     x, scale, shift = _f32(x), _f32(scale), _f32(shift)
     N, C = x.shape[:2]

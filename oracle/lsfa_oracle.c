@@ -575,6 +575,14 @@ void orc_deform_im2col(const float* data, const float* offset, int N, int C, int
 
 /* y = x*scale[c] + shift[c], optional ReLU (BatchNorm use_global_stats + relu,
  * sym_common.py:92-102; scale/shift precomputed by the caller). */
+void orc_scale_shift_leaky(const float* x, const float* scale, const float* shift, int N, int C, int HW, float slope, float* y) {
+  for (int n = 0; n < N; ++n) for (int c = 0; c < C; ++c) for (int p = 0; p < HW; ++p) {
+    size_t o = ((size_t)n * C + c) * HW + p;
+    float v = x[o] * scale[c] + shift[c];
+    y[o] = v > 0.f ? v : v * slope;        /* mx LeakyReLU 'leaky': x > 0 ? x : slope * x */
+  }
+}
+
 void orc_scale_shift_relu(const float* x, const float* scale, const float* shift, int N, int C, int HW, int relu, float* y) {
   for (int n = 0; n < N; ++n) for (int c = 0; c < C; ++c) for (int p = 0; p < HW; ++p) {
     size_t o = ((size_t)n * C + c) * HW + p;

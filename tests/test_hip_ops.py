@@ -401,6 +401,20 @@ def test_scale_shift_relu_bit_exact(hip, shape):
         np.testing.assert_array_equal(got, want)
 
 
+@pytest.mark.parametrize("shape", [(1, 64, 150, 250), (1, 1024, 5, 8), (2, 7, 5, 3)])
+def test_scale_shift_leaky_bit_exact(hip, shape):
+    rs = np.random.RandomState(shape[1] + 7)
+    x = rs.randn(*shape).astype(np.float32)
+    sc, sh = rs.rand(shape[1]).astype(np.float32) + 0.5, rs.randn(shape[1]).astype(np.float32)
+    want = oracle.scale_shift_leaky(x, sc, sh, 0.1)
+    got = hip.scale_shift_leaky(t(x), t(sc), t(sh), 0.1).cpu().numpy()
+    np.testing.assert_array_equal(got, want)
+    # == torch's bias add + leaky_relu (what the oracle graph does) when scale is 1
+    ones = np.ones(shape[1], np.float32)
+    ref = torch.nn.functional.leaky_relu(torch.from_numpy(x) + torch.from_numpy(sh).view(1, -1, 1, 1), 0.1).numpy()
+    np.testing.assert_array_equal(hip.scale_shift_leaky(t(x), t(ones), t(sh), 0.1).cpu().numpy(), ref)
+
+
 @pytest.mark.parametrize("shape", [(150 * 250, 64), (2394, 1024), (7, 4)])
 def test_scale_shift_relu_channels_last_bit_exact(hip, shape):
     """(rows, C) maps with the channel fastest == the NCHW statement with N = rows, HW = 1."""

@@ -1,5 +1,5 @@
 #!/usr/bin/env python
-"""The key frame's backbone alone, eagerly, many times (for rocprofv3 kernel traces: the second half
+"""The key frame's backbone (or `flownet` as 2nd argument) alone, eagerly, many times (for rocprofv3 kernel traces: the second half
 of the trace is steady state)."""
 import sys
 import torch
@@ -14,8 +14,13 @@ cfg = lsfa_test_config(key_frame_interval=10)
 arg, aux = P.init_params(cfg, seed=0)
 key = resnet_v1_101_flownet_rfcn(cfg).get_key_test_symbol(cfg).bind(arg, aux, dev)
 data = torch.rand(1, 3, 600, 1000, device=dev) * 255
+data2 = torch.rand(1, 3, 600, 1000, device=dev) * 255
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 100
+what = sys.argv[2] if len(sys.argv) > 2 else 'backbone'
+if os.environ.get('LSFA_TUNED', '1') == '1':
+    from lsfa_amd import tuning
+    tuning.enable()
 with torch.no_grad():
     for _ in range(n):
-        key._backbone(data)
+        key._backbone(data) if what == 'backbone' else key._flownet(data, data2)
 torch.cuda.synchronize()

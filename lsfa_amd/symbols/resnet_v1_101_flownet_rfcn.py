@@ -410,7 +410,7 @@ class Executor(object):
 
     @staticmethod
     def _map(x2, h, w):
-        return x2.view(1, h, w, x2.shape[1]).permute(0, 3, 1, 2)
+        return x2.view(-1, h, w, x2.shape[1]).permute(0, 3, 1, 2)
 
     def _dcn_cl(self, c1_4, u, dilate):
         """DeformableConvolution on channels-last maps: offset conv, channels-last bilinear im2col (rows
@@ -418,10 +418,10 @@ class Executor(object):
         off = F.conv2d(c1_4, u['off_w_cl'], u['off_b'], stride=1, padding=dilate, dilation=dilate)
         col = hip.deform_im2col_cl(c1_4.permute(0, 2, 3, 1), off.permute(0, 2, 3, 1), 3, 3, dilate, 1, dilate,
                                    P.NUM_DEFORMABLE_GROUP)
-        return torch.mm(col[0], u['w2_tap_t'])                  # (H*W, 9*C) x (9*C, Cout)
+        return torch.mm(col.view(-1, col.shape[2]), u['w2_tap_t'])     # (N*H*W, 9*C) x (9*C, Cout)
 
     def _resnet_cl(self, x, net, stages, tail):
-        """_resnet on channels-last activations (batch 1, fp32).  Returns an NCHW-shaped channels_last map."""
+        """_resnet on channels-last activations (fp32).  Returns an NCHW-shaped channels_last map."""
         net.prepare_channels_last()
         cl = torch.channels_last
         x = hip.scale_shift_relu(x, net.bn_data[0], net.bn_data[1], relu=False).contiguous(memory_format=cl)
@@ -463,7 +463,7 @@ class Executor(object):
         return x4
 
     def _backbone(self, data):
-        if 'backbone' in self.cl and data.shape[0] == 1:
+        if 'backbone' in self.cl:
             if not hasattr(self, 'feat_w_cl'):
                 self.feat_w_cl = self.feat_w.contiguous(memory_format=torch.channels_last)
             x4 = self._resnet_cl(data, self.net, 4, True)
@@ -646,7 +646,7 @@ class Executor(object):
         rest of the frame (lsfa_amd/core/graphs.py overlaps it with the previous frame's tail)."""
         with torch.no_grad():
             img = F.avg_pool2d(data, 4, 4, ceil_mode=True)
-            if 'small' in self.cl and data.shape[0] == 1:
+            if 'small' in self.cl:
                 if not hasattr(self, 'fuse_w_cl'):
                     self.fuse_w_cl = self.fuse_w.contiguous(memory_format=torch.channels_last)
                 s = self._resnet_cl(img, self.small, 1, False)

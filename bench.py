@@ -41,8 +41,8 @@ WARP_TRAFFIC_BYTES_38x63 = int((2 * 11844.9 + 9699.0) * 1024)
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=12)
-    ap.add_argument('--warmup', type=int, default=2)
+    ap.add_argument('--steps', type=int, default=40)
+    ap.add_argument('--warmup', type=int, default=3)
     ap.add_argument('--interval', type=int, default=10)
     ap.add_argument('--height', type=int, default=600)
     ap.add_argument('--width', type=int, default=1000)
@@ -50,10 +50,11 @@ def parse():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-graph', action='store_true', help='issue every launch eagerly instead of replaying hipGraphs')
     ap.add_argument('--no-prefetch', action='store_true', help='do not overlap the next frame\'s small net with this frame\'s tail')
-    ap.add_argument('--lanes', type=int, default=2,
+    ap.add_argument('--lanes', type=int, default=3,
                     help='non-key frames of a segment alternate over this many streams while the next key frame runs on '
                          'its own stream (lsfa_amd.core.graphs.FramePipeline); 0 = strictly serial frames')
     ap.add_argument('--key-lanes', type=int, default=1, help='streams the key frames alternate over (with --lanes > 0)')
+    ap.add_argument('--no-flow-stream', action='store_true', help='FlowNet after the backbone on the key stream instead of beside it')
     ap.add_argument('--no-tuned-gemms', action='store_true',
                     help='library-default GEMM heuristics instead of lsfa_amd/tuned/gemm_gfx950.csv (lsfa_amd.tuning)')
     ap.add_argument('--cpu-budget-s', type=float, default=20.0)
@@ -95,7 +96,8 @@ class Runner(object):
         from lsfa_amd.core.graphs import FrameGraphs, FramePipeline
         if args.lanes > 0:
             self.fg = FramePipeline(self.key, self.cur, cfg, args.height, args.width, device,
-                                    use_graphs=not args.no_graph, lanes=args.lanes, key_lanes=args.key_lanes)
+                                    use_graphs=not args.no_graph, lanes=args.lanes, key_lanes=args.key_lanes,
+                                    flow_stream=not args.no_flow_stream)
         else:
             self.fg = FrameGraphs(self.key, self.cur, cfg, args.height, args.width, device, use_graphs=not args.no_graph,
                                   prefetch=not args.no_prefetch)

@@ -199,16 +199,20 @@ class KeyLane(object):
         self.post_bufs = (torch.zeros((ncls, R, 5), dtype=torch.float64, device=device),
                           torch.zeros(ncls, dtype=torch.int32, device=device),
                           torch.full((ncls, R), -1, dtype=torch.int32, device=device))
-        self.front_out = None
+        self.conv_feat = self.flow_out = None
+        self.flow_graph = None
         self.feat = None
         self.front_graph = self.back_graph = None
 
     def front(self):
-        self.front_out = self.key.key_front(self.data, self.data_key_old)
+        self.conv_feat = self.key.key_backbone(self.data)
+
+    def flow(self):
+        self.flow_out = self.key.key_flow(self.data, self.data_key_old)
 
     def back(self):
         cfg = self.cfg
-        out = self.key.key_back(*self.front_out, self.feat_old, self.im_info)
+        out = self.key.key_back(self.conv_feat, self.flow_out[0], self.flow_out[1], self.feat_old, self.im_info)
         hip.det_postprocess(out['rois_output'], out['bbox_pred_reshape_output'][0], out['cls_prob_reshape_output'][0],
                             self.h, self.w, self.scale, score_thresh=self.thresh, nms_thresh=cfg.TEST.NMS,
                             max_per_image=cfg.TEST.max_per_image, class_agnostic=cfg.CLASS_AGNOSTIC, out=self.post_bufs)
@@ -222,6 +226,7 @@ class KeyLane(object):
         with torch.cuda.stream(s):
             for _ in range(warmup):
                 self.front()
+                self.flow()
                 self.back()
         torch.cuda.current_stream(self.device).wait_stream(s)
         torch.cuda.synchronize(self.device)
@@ -229,12 +234,20 @@ class KeyLane(object):
         self.front_graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self.front_graph, stream=self._capture_stream):
             self.front()
+        # FlowNet replays on another stream, beside the backbone: its own capture stream (BLAS workspace)
+        self._capture_stream_flow = torch.cuda.Stream(device=self.device)
+        self.flow_graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.flow_graph, stream=self._capture_stream_flow):
+            self.flow()
         self.back_graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self.back_graph, stream=self._capture_stream):
             self.back()
 
     def run_front(self):
         self.front_graph.replay() if self.use_graphs else self.front()
+
+    def run_flow(self):
+        self.flow_graph.replay() if self.use_graphs else self.flow()
 
     def run_back(self):
         self.back_graph.replay() if self.use_graphs else self.back()
@@ -250,9 +263,10 @@ class FramePipeline(object):
     aggregation / heads at its end; it needs nothing from the non-key frames in between.  The
     reference runs everything serially (one executor, a blocking .asnumpy() per frame).  Here:
 
-      * key frames alternate over `key_lanes` streams; each is two captured graphs, `front`
-        (backbone + FlowNet) and `back` (warp, aggregation, heads, detections); a `back` waits for the
-        previous key frame's `back`, a `front` for nothing but its own lane;
+      * key frames alternate over `key_lanes` streams; each is three captured graphs, `front`
+        (backbone), `flow` (FlowNet, replayed on a stream of its own beside the backbone) and `back`
+        (warp, aggregation, heads, detections); a `back` waits for the previous key frame's `back`,
+        `front` / `flow` for nothing but their own lane;
       * the non-key frames of a segment alternate over `lanes` streams, each lane with its own captured
         graph and static buffers, all reading one shared copy of the key feature;
       * a key frame's output is copied ("handed over") into that shared buffer once its `back` has
@@ -263,15 +277,17 @@ class FramePipeline(object):
     time) and the key frame's late ResNet stages launch grids well under 256 workgroups; with
     independent frames in flight those CUs run another frame's convolutions instead of idling.
     Results are those of the serial loop: same launch sequences, same inputs, no shared scratch.
-    Measured at 1000x600, interval 10, fp32 (frames/s; serial loop = 658): key_lanes x lanes = 1x1 897,
-    1x2 926, 1x3 930, 2x2 868, 2x3 937, 3x3 797 — once the next key frame overlaps the current segment
-    the GPU is out of idle CUs and more streams only add contention, hence the 1 x 2 default.
+    Measured at 1000x600, interval 10, fp32 (frames/s, three runs each on one box; serial loop 815):
+    1 key stream + 2 lanes 1169-1201, + FlowNet stream 1141-1167; 1 key stream + 3 lanes 1202-1204,
+    + FlowNet stream 1209-1234 (the default); 2 key streams + 2 lanes ~950.  Beyond that more streams
+    lose: the runtime multiplexes them onto 4 hardware queues (GPU_MAX_HW_QUEUES = 8 or 16 was slower
+    still) and two key frames in flight thrash L2 / MALL.
     The caller must keep each key frame's `data` tensor unmodified until the next key frame has
     been queued (it is read again as that frame's `data_key_old`).
     """
 
-    def __init__(self, key_exec, cur_exec, cfg, height, width, device, thresh=1e-4, use_graphs=True, lanes=2,
-                 key_lanes=1):
+    def __init__(self, key_exec, cur_exec, cfg, height, width, device, thresh=1e-4, use_graphs=True, lanes=3,
+                 key_lanes=1, flow_stream=True):
         dev = torch.device(device)
         self.device, self.cfg, self.key_exec = dev, cfg, key_exec
         self.h, self.w, self.thresh, self.scale = height, width, thresh, 1.0
@@ -284,6 +300,8 @@ class FramePipeline(object):
                                   feat_shared=self.feat_cur) for _ in range(lanes)]
         self.s_key = [torch.cuda.Stream(device=dev) for _ in range(key_lanes)]
         self.s_lane = [torch.cuda.Stream(device=dev) for _ in range(lanes)]
+        self.s_flow = torch.cuda.Stream(device=dev) if flow_stream else None     # FlowNet beside the backbone
+        self.ev_in, self.ev_flow = torch.cuda.Event(), torch.cuda.Event()
         self.ev_back = torch.cuda.Event()
         self.ev_handover = torch.cuda.Event()
         self.ev_lane = [torch.cuda.Event() for _ in range(lanes)]
@@ -313,7 +331,7 @@ class FramePipeline(object):
             g.im_info[0, 2] = float(im_scale)
 
     def _all_streams(self):
-        return self.s_key + self.s_lane
+        return self.s_key + self.s_lane + ([self.s_flow] if self.s_flow is not None else [])
 
     def join(self):
         """The caller's stream waits for everything issued so far."""
@@ -376,7 +394,17 @@ class FramePipeline(object):
                 t.record_stream(s)               # the caller may drop its reference right after this call
             lane.data.copy_(data)
             lane.data_key_old.copy_(self._prev_key_data)
-            lane.run_front()
+            if self.s_flow is not None:
+                self.ev_in.record(s)
+                with torch.cuda.stream(self.s_flow):
+                    self.s_flow.wait_event(self.ev_in)
+                    lane.run_flow()
+                    self.ev_flow.record(self.s_flow)
+                lane.run_front()
+                s.wait_event(self.ev_flow)
+            else:
+                lane.run_front()
+                lane.run_flow()
             s.wait_event(self.ev_back)           # the previous key frame's feature exists ...
             s.wait_event(self.ev_handover)       # ... and the non-key lanes hold their copy of the feature
             lane.feat_old.copy_(self._prev_feat)  #     this lane's `back` is about to overwrite

@@ -601,6 +601,17 @@ class Executor(object):
         with torch.no_grad():
             return self._key_front(data, data_key_old)
 
+    def key_backbone(self, data):
+        """key_front's two independent halves, for callers that run them on different streams."""
+        with torch.no_grad():
+            conv_feat = self._backbone(data)
+            self._tap('backbone_feat', conv_feat)
+            return conv_feat
+
+    def key_flow(self, data, data_key_old):
+        with torch.no_grad():
+            return self._flownet(data, data_key_old)
+
     def key_back(self, conv_feat, flow, scale_map, feat_key_old, im_info):
         """The rest of the key frame: flow warp x scale map of the old key feature, aggregation, heads."""
         with torch.no_grad():

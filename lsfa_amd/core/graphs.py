@@ -182,9 +182,9 @@ class FrameGraphs(object):
 
 
 class KeyLane(object):
-    """Static buffers and the two captured halves of a key frame: `front` (backbone + FlowNet: needs
-    only images) and `back` (flow warp of the previous key feature, aggregation, heads, detection
-    post-processing)."""
+    """Static buffers and the captured parts of a key frame: `front` (backbone) and `flow` (FlowNet) need
+    only images; `agg` (flow warp of the previous key feature x scale map, aggregation) produces the
+    frame's feature; `tail` (RPN, Proposal, R-FCN head, detection post-processing) consumes it."""
 
     def __init__(self, key_exec, cfg, height, width, device, thresh, use_graphs):
         self.key, self.cfg, self.device, self.use_graphs = key_exec, cfg, device, use_graphs
@@ -202,7 +202,7 @@ class KeyLane(object):
         self.conv_feat = self.flow_out = None
         self.flow_graph = None
         self.feat = None
-        self.front_graph = self.back_graph = None
+        self.front_graph = self.agg_graph = self.tail_graph = None
 
     def front(self):
         self.conv_feat = self.key.key_backbone(self.data)
@@ -210,13 +210,15 @@ class KeyLane(object):
     def flow(self):
         self.flow_out = self.key.key_flow(self.data, self.data_key_old)
 
-    def back(self):
+    def agg(self):
+        self.feat = self.key.key_aggregate(self.conv_feat, self.flow_out[0], self.flow_out[1], self.feat_old)
+
+    def tail(self):
         cfg = self.cfg
-        out = self.key.key_back(self.conv_feat, self.flow_out[0], self.flow_out[1], self.feat_old, self.im_info)
+        out = self.key.key_heads(self.feat, self.im_info)
         hip.det_postprocess(out['rois_output'], out['bbox_pred_reshape_output'][0], out['cls_prob_reshape_output'][0],
                             self.h, self.w, self.scale, score_thresh=self.thresh, nms_thresh=cfg.TEST.NMS,
                             max_per_image=cfg.TEST.max_per_image, class_agnostic=cfg.CLASS_AGNOSTIC, out=self.post_bufs)
-        self.feat = out['choose_feat_output']
 
     def capture(self, warmup=3):
         if not self.use_graphs:
@@ -227,7 +229,8 @@ class KeyLane(object):
             for _ in range(warmup):
                 self.front()
                 self.flow()
-                self.back()
+                self.agg()
+                self.tail()
         torch.cuda.current_stream(self.device).wait_stream(s)
         torch.cuda.synchronize(self.device)
         self._capture_stream = torch.cuda.Stream(device=self.device)     # see FrameGraphs.capture
@@ -239,9 +242,13 @@ class KeyLane(object):
         self.flow_graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self.flow_graph, stream=self._capture_stream_flow):
             self.flow()
-        self.back_graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.back_graph, stream=self._capture_stream):
-            self.back()
+        self.agg_graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.agg_graph, stream=self._capture_stream):
+            self.agg()
+        # the tail replays where FlowNet does (after it, same stream), so it may share that capture stream
+        self.tail_graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.tail_graph, stream=self._capture_stream_flow):
+            self.tail()
 
     def run_front(self):
         self.front_graph.replay() if self.use_graphs else self.front()
@@ -249,8 +256,11 @@ class KeyLane(object):
     def run_flow(self):
         self.flow_graph.replay() if self.use_graphs else self.flow()
 
-    def run_back(self):
-        self.back_graph.replay() if self.use_graphs else self.back()
+    def run_agg(self):
+        self.agg_graph.replay() if self.use_graphs else self.agg()
+
+    def run_tail(self):
+        self.tail_graph.replay() if self.use_graphs else self.tail()
 
 
 class FramePipeline(object):
@@ -263,13 +273,14 @@ class FramePipeline(object):
     aggregation / heads at its end; it needs nothing from the non-key frames in between.  The
     reference runs everything serially (one executor, a blocking .asnumpy() per frame).  Here:
 
-      * key frames alternate over `key_lanes` streams; each is three captured graphs, `front`
-        (backbone), `flow` (FlowNet, replayed on a stream of its own beside the backbone) and `back`
-        (warp, aggregation, heads, detections); a `back` waits for the previous key frame's `back`,
-        `front` / `flow` for nothing but their own lane;
+      * key frames alternate over `key_lanes` streams; each is four captured graphs: `front` (backbone)
+        and `agg` (flow warp, aggregation -> the frame's feature) on the key stream, `flow` (FlowNet)
+        and `tail` (RPN, Proposal, R-FCN head, detections) on a second stream, so FlowNet runs beside
+        the backbone and the next key frame's backbone starts as soon as the feature exists, beside
+        this frame's single-workgroup tail; an `agg` waits for the previous key frame's `agg`;
       * the non-key frames of a segment alternate over `lanes` streams, each lane with its own captured
         graph and static buffers, all reading one shared copy of the key feature;
-      * a key frame's output is copied ("handed over") into that shared buffer once its `back` has
+      * a key frame's output is copied ("handed over") into that shared buffer once its `agg` has
         finished AND every lane has finished the previous segment.
 
     What this buys on a 256-CU part: every frame ends with work that occupies one or a few CUs
@@ -301,7 +312,7 @@ class FramePipeline(object):
         self.s_key = [torch.cuda.Stream(device=dev) for _ in range(key_lanes)]
         self.s_lane = [torch.cuda.Stream(device=dev) for _ in range(lanes)]
         self.s_flow = torch.cuda.Stream(device=dev) if flow_stream else None     # FlowNet beside the backbone
-        self.ev_in, self.ev_flow = torch.cuda.Event(), torch.cuda.Event()
+        self.ev_in, self.ev_flow, self.ev_tail = torch.cuda.Event(), torch.cuda.Event(), torch.cuda.Event()
         self.ev_back = torch.cuda.Event()
         self.ev_handover = torch.cuda.Event()
         self.ev_lane = [torch.cuda.Event() for _ in range(lanes)]
@@ -365,6 +376,7 @@ class FramePipeline(object):
             s.wait_stream(main)
         self.ev_handover.record(main)
         self.ev_back.record(main)
+        self.ev_tail.record(main)
         for e in self.ev_lane:
             e.record(main)
         self._pending_handover = False
@@ -406,12 +418,19 @@ class FramePipeline(object):
                 lane.run_front()
                 lane.run_flow()
             s.wait_event(self.ev_back)           # the previous key frame's feature exists ...
-            s.wait_event(self.ev_handover)       # ... and the non-key lanes hold their copy of the feature
-            lane.feat_old.copy_(self._prev_feat)  #     this lane's `back` is about to overwrite
-            lane.run_back()
-            if deliver is not None:
-                deliver(lane.post_bufs)
-            self.ev_back.record(s)
+            s.wait_event(self.ev_handover)       # ... the non-key lanes hold their copy of it ...
+            s.wait_event(self.ev_tail)           # ... and the previous key frame's heads are done reading it:
+            lane.feat_old.copy_(self._prev_feat)  #     this lane's `agg` may overwrite its output buffer
+            lane.run_agg()
+            self.ev_back.record(s)               # this frame's feature exists
+            # heads + detections: off the key stream, so the next key frame's backbone starts right away
+            st = self.s_flow if self.s_flow is not None else s
+            with torch.cuda.stream(st):
+                st.wait_event(self.ev_back)
+                lane.run_tail()
+                if deliver is not None:
+                    deliver(lane.post_bufs)
+                self.ev_tail.record(st)
         self._prev_feat, self._prev_key_data = lane.feat, data
         self._pending_handover = True
         return lane.post_bufs

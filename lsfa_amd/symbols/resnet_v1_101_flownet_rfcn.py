@@ -626,6 +626,20 @@ class Executor(object):
         return conv_feat, flow, scale_map
 
     def _key_back(self, conv_feat, flow, scale_map, feat_key_old, im_info):
+        conv_feat = self._key_aggregate(conv_feat, flow, scale_map, feat_key_old)
+        return self._key_heads(conv_feat, im_info)
+
+    def key_aggregate(self, conv_feat, flow, scale_map, feat_key_old):
+        """key_back's two halves, for callers that run the heads elsewhere: the aggregated feature ..."""
+        with torch.no_grad():
+            return self._key_aggregate(conv_feat, flow, scale_map, feat_key_old)
+
+    def key_heads(self, conv_feat, im_info):
+        """... and RPN + Proposal + R-FCN heads on it."""
+        with torch.no_grad():
+            return self._key_heads(conv_feat, im_info)
+
+    def _key_aggregate(self, conv_feat, flow, scale_map, feat_key_old):
         cfg = self.cfg
         if flow is not None:
             warp = hip.warp_bilinear(feat_key_old, flow, mul=scale_map)
@@ -647,6 +661,9 @@ class Executor(object):
                 conv_feat = hip.aggregate_cosine(warp, conv_feat, e[1:2], e[0:1])
             else:
                 conv_feat = 0.5 * (warp + conv_feat)
+        return conv_feat
+
+    def _key_heads(self, conv_feat, im_info):
         rois, cls_prob, bbox_pred = self._heads(conv_feat, im_info)
         return {'choose_feat_output': conv_feat, 'rois_output': rois, 'cls_prob_reshape_output': cls_prob,
                 'bbox_pred_reshape_output': bbox_pred}

@@ -50,7 +50,7 @@ def parse():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-graph', action='store_true', help='issue every launch eagerly instead of replaying hipGraphs')
     ap.add_argument('--no-prefetch', action='store_true', help='do not overlap the next frame\'s small net with this frame\'s tail')
-    ap.add_argument('--lanes', type=int, default=3,
+    ap.add_argument('--lanes', type=int, default=2,
                     help='non-key frames of a segment alternate over this many streams while the next key frame runs on '
                          'its own stream (lsfa_amd.core.graphs.FramePipeline); 0 = strictly serial frames')
     ap.add_argument('--key-lanes', type=int, default=1, help='streams the key frames alternate over (with --lanes > 0)')

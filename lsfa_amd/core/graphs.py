@@ -20,6 +20,7 @@ the current frame's tail runs, and the next replay consumes it.
 import torch
 
 from lsfa_amd import hip
+from lsfa_amd.core import streams
 
 
 class FrameGraphs(object):
@@ -297,7 +298,7 @@ class FramePipeline(object):
     been queued (it is read again as that frame's `data_key_old`).
     """
 
-    def __init__(self, key_exec, cur_exec, cfg, height, width, device, thresh=1e-4, use_graphs=True, lanes=3,
+    def __init__(self, key_exec, cur_exec, cfg, height, width, device, thresh=1e-4, use_graphs=True, lanes=2,
                  key_lanes=1, flow_stream=True):
         dev = torch.device(device)
         self.device, self.cfg, self.key_exec = dev, cfg, key_exec
@@ -309,9 +310,23 @@ class FramePipeline(object):
         self.klanes = [KeyLane(key_exec, cfg, height, width, dev, thresh, use_graphs) for _ in range(key_lanes)]
         self.lanes = [FrameGraphs(key_exec, cur_exec, cfg, height, width, dev, thresh, use_graphs, prefetch=False,
                                   feat_shared=self.feat_cur) for _ in range(lanes)]
-        self.s_key = [torch.cuda.Stream(device=dev) for _ in range(key_lanes)]
-        self.s_lane = [torch.cuda.Stream(device=dev) for _ in range(lanes)]
-        self.s_flow = torch.cuda.Stream(device=dev) if flow_stream else None     # FlowNet beside the backbone
+        # Streams on distinct hardware queues (core/streams.py: the runtime has 4, and streams that share
+        # one run strictly one after the other): key stream(s) first, then the FlowNet / tail stream,
+        # then the lanes; a lane that does not get a queue of its own shares the FlowNet stream's,
+        # which is idle most of the time.
+        want = key_lanes + (1 if flow_stream else 0) + lanes
+        chosen, aliased = streams.concurrent_streams(want, dev)
+        self.s_key = chosen[:key_lanes]
+        rest = chosen[key_lanes:]
+        self.s_flow = rest.pop(0) if (flow_stream and rest) else None
+        flow_q = chosen.index(self.s_flow) if self.s_flow is not None else -1
+        spare = [st for st, q in aliased if q == flow_q] + [st for st, q in aliased if q != flow_q and q >= key_lanes] + \
+                [st for st, q in aliased if q < key_lanes]
+        take = lambda last=False: (spare.pop(-1 if last else 0) if spare else torch.cuda.Stream(device=dev))
+        while len(self.s_key) < key_lanes:
+            self.s_key.append(take(last=True))
+        self.s_lane = [rest.pop(0) if rest else take() for _ in range(lanes)]
+        self.hw_queues = len(chosen)
         self.ev_in, self.ev_flow, self.ev_tail = torch.cuda.Event(), torch.cuda.Event(), torch.cuda.Event()
         self.ev_back = torch.cuda.Event()
         self.ev_handover = torch.cuda.Event()

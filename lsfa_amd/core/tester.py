@@ -156,7 +156,7 @@ def pred_eval(gpu_id, key_predictor, cur_predictor, test_data, imdb, cfg, vis=Fa
     return all_boxes, frame_ids
 
 
-def pred_eval_pipelined(gpu_id, key_predictor, cur_predictor, test_data, imdb, cfg, thresh=1e-4, logger=None, lanes=3,
+def pred_eval_pipelined(gpu_id, key_predictor, cur_predictor, test_data, imdb, cfg, thresh=1e-4, logger=None, lanes=2,
                         key_lanes=1, use_graphs=True):
     """pred_eval with the frames of each video pipelined over HIP streams (core/graphs.py
     FramePipeline): same loader, same flags, same launch sequences per frame, same return value.

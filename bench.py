@@ -53,7 +53,8 @@ def parse():
     ap.add_argument('--lanes', type=int, default=2,
                     help='non-key frames of a segment alternate over this many streams while the next key frame runs on '
                          'its own stream (lsfa_amd.core.graphs.FramePipeline); 0 = strictly serial frames')
-    ap.add_argument('--key-lanes', type=int, default=1, help='streams the key frames alternate over (with --lanes > 0)')
+    ap.add_argument('--lookahead', action='store_true',
+                    help='queue each key frame ahead of the non-key frames that precede it in display order')
     ap.add_argument('--no-flow-stream', action='store_true', help='FlowNet after the backbone on the key stream instead of beside it')
     ap.add_argument('--no-tuned-gemms', action='store_true',
                     help='library-default GEMM heuristics instead of lsfa_amd/tuned/gemm_gfx950.csv (lsfa_amd.tuning)')
@@ -96,8 +97,8 @@ class Runner(object):
         from lsfa_amd.core.graphs import FrameGraphs, FramePipeline
         if args.lanes > 0:
             self.fg = FramePipeline(self.key, self.cur, cfg, args.height, args.width, device,
-                                    use_graphs=not args.no_graph, lanes=args.lanes, key_lanes=args.key_lanes,
-                                    flow_stream=not args.no_flow_stream)
+                                    use_graphs=not args.no_graph, lanes=args.lanes,
+                                    flow_stream=not args.no_flow_stream, lookahead=args.lookahead)
         else:
             self.fg = FrameGraphs(self.key, self.cur, cfg, args.height, args.width, device, use_graphs=not args.no_graph,
                                   prefetch=not args.no_prefetch)
@@ -216,9 +217,14 @@ def main():
     tuned = None if args.no_tuned_gemms else tuning.enable(tune_missing=True)
     r = Runner(args, rank, device)
     r.prime()
+    def drain():
+        if hasattr(r.fg, 'flush'):
+            r.fg.flush()             # the pipeline queues a segment when the next key frame arrives: queue the last one
+        torch.cuda.synchronize()     # device-wide: drains every stream of the frame pipeline
+
     for s in range(args.warmup):
         r.step(s)
-    torch.cuda.synchronize()     # device-wide: drains every stream of the frame pipeline
+    drain()
 
     def barrier():
         if distributed:
@@ -229,7 +235,7 @@ def main():
     t0 = time.perf_counter()
     for s in range(args.warmup, args.warmup + args.steps):
         r.step(s)
-    torch.cuda.synchronize()
+    drain()
     barrier()
     elapsed = time.perf_counter() - t0
     prof = r.eager_profile_step(args.warmup) if rank == 0 else None
@@ -266,7 +272,10 @@ def main():
                        "launch": "eager" if args.no_graph else "hipGraph replay per frame",
                        "gemm_solutions": "library default" if tuned is None else
                                          ("lsfa_amd/tuned/gemm_gfx950.csv" if tuned else "tuned on first use (shipped file rejected)"),
-                       "pipeline": ("%d key lanes (front/back graphs) + %d non-key lanes" % (args.key_lanes, args.lanes)) if args.lanes > 0 else "serial"},
+                       "pipeline": ("key stream%s + %d non-key lanes%s" % (
+                           "" if args.no_flow_stream else " + FlowNet/tail stream", args.lanes,
+                           ", next key frame queued ahead of the segment before it" if args.lookahead else ""))
+                       if args.lanes > 0 else "serial"},
             "roofline": {"bound": "hbm", "kernel": "warp_kernel (lsfa_warp_bilinear: MV/flow warp + fused epilogue)",
                          "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4),

@@ -265,86 +265,88 @@ class KeyLane(object):
 
 
 class FramePipeline(object):
-    """One clip, frames issued in order, pipelined over HIP streams.
+    """One clip, frames handed over in display order, pipelined over HIP streams.
 
     Data dependencies of the frame loop (dff_rfcn/core/tester.py:237-281): a non-key frame needs the
     feature of the latest key frame and its own image / motion vectors / residual — nothing from the
     neighbouring non-key frames.  A key frame needs the previous key frame's IMAGE for its backbone +
     FlowNet part (the bulk of it) and the previous key frame's FEATURE only for the warp /
-    aggregation / heads at its end; it needs nothing from the non-key frames in between.  The
-    reference runs everything serially (one executor, a blocking .asnumpy() per frame).  Here:
+    aggregation at its end; it needs nothing from the non-key frames in between.  The reference runs
+    everything serially (one executor, a blocking .asnumpy() per frame).  Here:
 
-      * key frames alternate over `key_lanes` streams; each is four captured graphs: `front` (backbone)
-        and `agg` (flow warp, aggregation -> the frame's feature) on the key stream, `flow` (FlowNet)
-        and `tail` (RPN, Proposal, R-FCN head, detections) on a second stream, so FlowNet runs beside
-        the backbone and the next key frame's backbone starts as soon as the feature exists, beside
-        this frame's single-workgroup tail; an `agg` waits for the previous key frame's `agg`;
+      * a key frame is four captured graphs: `front` (backbone) and `agg` (flow warp, aggregation ->
+        the frame's feature) on the key stream, `flow` (FlowNet) and `tail` (RPN, Proposal, R-FCN head,
+        detections) on a second stream: FlowNet runs beside the backbone, and the next key frame's
+        backbone starts as soon as the feature exists, beside this frame's single-workgroup tail.
+        Two sets of key-frame buffers alternate, so a key frame never overwrites the feature the
+        previous segment's non-key frames are still being served from;
       * the non-key frames of a segment alternate over `lanes` streams, each lane with its own captured
-        graph and static buffers, all reading one shared copy of the key feature;
-      * a key frame's output is copied ("handed over") into that shared buffer once its `agg` has
-        finished AND every lane has finished the previous segment.
+        graph and static buffers, all reading one shared copy of the key feature ("hand-over": one
+        10 MB copy per segment, after the key frame's `agg` and after every lane has finished the
+        previous segment);
+      * issue order: by default frames are queued as they are handed over (display order).
+        `lookahead=True` queues key frame k+1 BEFORE the non-key frames that precede it: `cur_frame`
+        then only records the frame and the segment is queued when the next key frame (or `flush` /
+        `join` / `first_frame`) arrives, so non-key detections are delivered one segment late.  A
+        graph launch blocks the host while the previous launch of the same graph is still running, and
+        under event instrumentation the key stream was seen idling behind the host; un-instrumented the
+        two orders measure the same (1324 vs 1325 frames/s), hence the simpler default.
 
     What this buys on a 256-CU part: every frame ends with work that occupies one or a few CUs
     (Proposal's single workgroup, the R-FCN head, the detection NMS: ~40 % of a non-key frame's
     time) and the key frame's late ResNet stages launch grids well under 256 workgroups; with
     independent frames in flight those CUs run another frame's convolutions instead of idling.
     Results are those of the serial loop: same launch sequences, same inputs, no shared scratch.
-    Measured at 1000x600, interval 10, fp32 (frames/s, three runs each on one box; serial loop 815):
-    1 key stream + 2 lanes 1169-1201, + FlowNet stream 1141-1167; 1 key stream + 3 lanes 1202-1204,
-    + FlowNet stream 1209-1234 (the default); 2 key streams + 2 lanes ~950.  Beyond that more streams
-    lose: the runtime multiplexes them onto 4 hardware queues (GPU_MAX_HW_QUEUES = 8 or 16 was slower
-    still) and two key frames in flight thrash L2 / MALL.
+    Streams: core/streams.py probes for streams on distinct hardware queues (the runtime has 4;
+    streams sharing one run strictly in turn): key, FlowNet/tail and two lanes get one each; further
+    lanes share the FlowNet stream's queue.
     The caller must keep each key frame's `data` tensor unmodified until the next key frame has
     been queued (it is read again as that frame's `data_key_old`).
     """
 
     def __init__(self, key_exec, cur_exec, cfg, height, width, device, thresh=1e-4, use_graphs=True, lanes=2,
-                 key_lanes=1, flow_stream=True):
+                 flow_stream=True, lookahead=False):
         dev = torch.device(device)
         self.device, self.cfg, self.key_exec = dev, cfg, key_exec
         self.h, self.w, self.thresh, self.scale = height, width, thresh, 1.0
+        self.lookahead = lookahead
         fh, fw = -(-height // 16), -(-width // 16)
         dim = cfg.network.DFF_FEAT_DIM
         self.feat_cur = torch.zeros((1, dim, fh, fw), device=dev, dtype=torch.float32)   # what the non-key lanes read
         self.feat0 = torch.zeros((1, dim, fh, fw), device=dev, dtype=torch.float32)      # feature of a clip's frame 0
-        self.klanes = [KeyLane(key_exec, cfg, height, width, dev, thresh, use_graphs) for _ in range(key_lanes)]
+        self.klanes = [KeyLane(key_exec, cfg, height, width, dev, thresh, use_graphs) for _ in range(2)]
         self.lanes = [FrameGraphs(key_exec, cur_exec, cfg, height, width, dev, thresh, use_graphs, prefetch=False,
                                   feat_shared=self.feat_cur) for _ in range(lanes)]
-        # Streams on distinct hardware queues (core/streams.py: the runtime has 4, and streams that share
-        # one run strictly one after the other): key stream(s) first, then the FlowNet / tail stream,
-        # then the lanes; a lane that does not get a queue of its own shares the FlowNet stream's,
-        # which is idle most of the time.
-        want = key_lanes + (1 if flow_stream else 0) + lanes
+        want = 1 + (1 if flow_stream else 0) + lanes
         chosen, aliased = streams.concurrent_streams(want, dev)
-        self.s_key = chosen[:key_lanes]
-        rest = chosen[key_lanes:]
+        self.hw_queues = len(chosen)
+        self.s_key = chosen[0]
+        rest = chosen[1:]
         self.s_flow = rest.pop(0) if (flow_stream and rest) else None
         flow_q = chosen.index(self.s_flow) if self.s_flow is not None else -1
-        spare = [st for st, q in aliased if q == flow_q] + [st for st, q in aliased if q != flow_q and q >= key_lanes] + \
-                [st for st, q in aliased if q < key_lanes]
-        take = lambda last=False: (spare.pop(-1 if last else 0) if spare else torch.cuda.Stream(device=dev))
-        while len(self.s_key) < key_lanes:
-            self.s_key.append(take(last=True))
-        self.s_lane = [rest.pop(0) if rest else take() for _ in range(lanes)]
-        self.hw_queues = len(chosen)
-        self.ev_in, self.ev_flow, self.ev_tail = torch.cuda.Event(), torch.cuda.Event(), torch.cuda.Event()
-        self.ev_back = torch.cuda.Event()
-        self.ev_handover = torch.cuda.Event()
-        self.ev_lane = [torch.cuda.Event() for _ in range(lanes)]
+        spare = [st for st, q in aliased if q == flow_q] + [st for st, q in aliased if q not in (flow_q, 0)] + \
+                [st for st, q in aliased if q == 0]
+        self.s_lane = [rest.pop(0) if rest else (spare.pop(0) if spare else torch.cuda.Stream(device=dev))
+                       for _ in range(lanes)]
+        E = torch.cuda.Event
+        self.ev_in, self.ev_flow, self.ev_tail, self.ev_handover = E(), E(), E(), E()
+        self.ev_feat = [E(), E()]                 # key-buffer i's feature exists
+        self.ev_lane = [E() for _ in range(lanes)]
         self.captured = False
         self._next = self._nkey = 0
-        self._pending_handover = False
-        self._prev_feat = self._prev_key_data = None
-        self._first_post = None
+        self._feat_latest = self._prev_key_data = None
+        self._seg_feat = self._seg_event = None     # feature (and its event) the buffered segment is served from
+        self._seg_needs_handover = False
+        self._held = []                              # non-key frames recorded but not yet queued
 
     # the state the serial FrameGraphs exposes under the same names
     @property
     def feat(self):
-        return self._prev_feat
+        return self._feat_latest
 
     @property
     def feat_old(self):
-        return self._prev_feat
+        return self._feat_latest
 
     @property
     def data_key_old(self):
@@ -357,10 +359,15 @@ class FramePipeline(object):
             g.im_info[0, 2] = float(im_scale)
 
     def _all_streams(self):
-        return self.s_key + self.s_lane + ([self.s_flow] if self.s_flow is not None else [])
+        return [self.s_key] + self.s_lane + ([self.s_flow] if self.s_flow is not None else [])
+
+    def flush(self):
+        """Queue the non-key frames recorded so far (end of a clip, or before reading results)."""
+        self._issue_segment()
 
     def join(self):
-        """The caller's stream waits for everything issued so far."""
+        """Everything handed over so far is queued, and the caller's stream waits for it."""
+        self.flush()
         main = torch.cuda.current_stream(self.device)
         for s in self._all_streams():
             main.wait_stream(s)
@@ -368,11 +375,11 @@ class FramePipeline(object):
     def first_frame(self, data):
         """flag 0 (first frame of a clip): drains the pipeline, runs eagerly on the caller's stream."""
         self.join()
-        self._next = self._nkey = 0          # the lane of a frame depends only on its position in the clip
+        self._next = self._nkey = 0          # the lane / buffer of a frame depends only on its position in the clip
         lane, cfg = self.klanes[0], self.cfg
         conv_feat, _, _ = self.key_exec.key_front(data, None)
         out = self.key_exec.key_back(conv_feat, None, None, None, lane.im_info)
-        if self._first_post is None:
+        if not hasattr(self, '_first_post'):
             self._first_post = tuple(torch.zeros_like(b) for b in lane.post_bufs)
             self._first_post[2].fill_(-1)
         hip.det_postprocess(out['rois_output'], out['bbox_pred_reshape_output'][0], out['cls_prob_reshape_output'][0],
@@ -380,21 +387,19 @@ class FramePipeline(object):
                             max_per_image=cfg.TEST.max_per_image, class_agnostic=cfg.CLASS_AGNOSTIC,
                             out=self._first_post)
         self.feat0.copy_(out['choose_feat_output'])
-        self._prev_feat, self._prev_key_data = self.feat0, data
+        self._feat_latest, self._prev_key_data = self.feat0, data
         self._publish_from_main()
         return self._first_post
 
     def _publish_from_main(self):
+        """The clip's first feature goes to the lanes directly; every stream and event starts from here."""
         main = torch.cuda.current_stream(self.device)
-        self.feat_cur.copy_(self._prev_feat)
+        self.feat_cur.copy_(self._feat_latest)
         for s in self._all_streams():
             s.wait_stream(main)
-        self.ev_handover.record(main)
-        self.ev_back.record(main)
-        self.ev_tail.record(main)
-        for e in self.ev_lane:
+        for e in [self.ev_handover, self.ev_tail] + self.ev_feat + self.ev_lane:
             e.record(main)
-        self._pending_handover = False
+        self._seg_feat, self._seg_event, self._seg_needs_handover = self._feat_latest, None, False
 
     def capture(self, warmup=3):
         for lane in self.klanes:
@@ -407,13 +412,17 @@ class FramePipeline(object):
         self._publish_from_main()
 
     def key_frame(self, data, deliver=None, ready=None):
-        """flag 1.  `deliver(bufs)` is called with the frame's stream current right after the frame is
-        queued; use it to queue copies of the (dets, counts, keep_idx) buffers.  The inputs must be
-        complete on the device, or `ready` an event recorded after the work that produces them (the
-        caller's stream is deliberately NOT waited on: it would serialise the pipeline)."""
-        i = self._nkey % len(self.klanes)
+        """flag 1.  `deliver(bufs)` is called with the stream of the frame's tail current, right after
+        the frame is queued; use it to queue copies of the (dets, counts, keep_idx) buffers.  The
+        inputs must be complete on the device, or `ready` an event recorded after the work that
+        produces them (the caller's stream is deliberately NOT waited on: it would serialise the
+        pipeline).  With lookahead, the non-key frames recorded since the previous key frame are
+        queued right after this frame."""
+        if not self.lookahead:
+            self._issue_segment()
+        b = self._nkey % 2
         self._nkey += 1
-        lane, s = self.klanes[i], self.s_key[i]
+        lane, s = self.klanes[b], self.s_key
         with torch.cuda.stream(s):
             if ready is not None:
                 s.wait_event(ready)
@@ -432,50 +441,58 @@ class FramePipeline(object):
             else:
                 lane.run_front()
                 lane.run_flow()
-            s.wait_event(self.ev_back)           # the previous key frame's feature exists ...
-            s.wait_event(self.ev_handover)       # ... the non-key lanes hold their copy of it ...
-            s.wait_event(self.ev_tail)           # ... and the previous key frame's heads are done reading it:
-            lane.feat_old.copy_(self._prev_feat)  #     this lane's `agg` may overwrite its output buffer
+            # this buffer's previous feature (key frame k-2) has been handed over / consumed: its hand-over
+            # was queued with segment k-2, i.e. before this call, and ev_handover is that one or a later one
+            s.wait_event(self.ev_handover)
+            s.wait_event(self.ev_tail)           # ... and that frame's heads are done reading it
+            lane.feat_old.copy_(self._feat_latest)   # the previous key frame's feature (same stream: it exists)
             lane.run_agg()
-            self.ev_back.record(s)               # this frame's feature exists
-            # heads + detections: off the key stream, so the next key frame's backbone starts right away
+            self.ev_feat[b].record(s)
             st = self.s_flow if self.s_flow is not None else s
             with torch.cuda.stream(st):
-                st.wait_event(self.ev_back)
-                lane.run_tail()
+                st.wait_event(self.ev_feat[b])
+                lane.run_tail()                  # heads + detections: off the key stream
                 if deliver is not None:
                     deliver(lane.post_bufs)
                 self.ev_tail.record(st)
-        self._prev_feat, self._prev_key_data = lane.feat, data
-        self._pending_handover = True
+        if self.lookahead:
+            self._issue_segment()                # the frames BEFORE this key frame, served from the previous feature
+        self._feat_latest, self._prev_key_data = lane.feat, data
+        self._seg_feat, self._seg_event, self._seg_needs_handover = lane.feat, self.ev_feat[b], True
         return lane.post_bufs
 
-    def _handover(self):
-        s = self.s_lane[0]
-        with torch.cuda.stream(s):
-            s.wait_event(self.ev_back)
-            for e in self.ev_lane[1:]:
-                s.wait_event(e)
-            self.feat_cur.copy_(self._prev_feat)
-            self.ev_handover.record(s)
-        self._pending_handover = False
-
     def cur_frame(self, data, motion_vector, res_diff, deliver=None, ready=None):
-        """flag 2.  Queued on the next lane; returns that lane's output buffers (valid until the lane's
-        next frame: copy them out in `deliver`)."""
-        if self._pending_handover:
-            self._handover()
-        i = self._next
-        self._next = (i + 1) % len(self.lanes)
-        s = self.s_lane[i]
-        with torch.cuda.stream(s):
-            if ready is not None:
-                s.wait_event(ready)
-            s.wait_event(self.ev_handover)
-            for t in (data, motion_vector, res_diff):
-                t.record_stream(s)
-            bufs = self.lanes[i].cur_frame(data, motion_vector, res_diff)
-            if deliver is not None:
-                deliver(bufs)
-            self.ev_lane[i].record(s)
-        return bufs
+        """flag 2.  Recorded; queued on the next lane when the segment is issued (see the class
+        docstring).  `deliver(bufs)` is called then, with the lane's stream current; the buffers are
+        valid until the lane's next frame, so copy them out there."""
+        self._held.append((data, motion_vector, res_diff, deliver, ready))
+        if not self.lookahead:
+            self._issue_segment()
+
+    def _issue_segment(self):
+        if not self._held:
+            return
+        if self._seg_needs_handover:
+            s = self.s_lane[0]
+            with torch.cuda.stream(s):
+                s.wait_event(self._seg_event)            # the segment's key feature exists
+                for e in self.ev_lane[1:]:
+                    s.wait_event(e)                      # every lane has finished the previous segment
+                self.feat_cur.copy_(self._seg_feat)
+                self.ev_handover.record(s)
+            self._seg_needs_handover = False
+        for data, motion_vector, res_diff, deliver, ready in self._held:
+            i = self._next
+            self._next = (i + 1) % len(self.lanes)
+            s = self.s_lane[i]
+            with torch.cuda.stream(s):
+                if ready is not None:
+                    s.wait_event(ready)
+                s.wait_event(self.ev_handover)
+                for t in (data, motion_vector, res_diff):
+                    t.record_stream(s)
+                bufs = self.lanes[i].cur_frame(data, motion_vector, res_diff)
+                if deliver is not None:
+                    deliver(bufs)
+                self.ev_lane[i].record(s)
+        self._held = []

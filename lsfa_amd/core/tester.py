@@ -157,7 +157,7 @@ def pred_eval(gpu_id, key_predictor, cur_predictor, test_data, imdb, cfg, vis=Fa
 
 
 def pred_eval_pipelined(gpu_id, key_predictor, cur_predictor, test_data, imdb, cfg, thresh=1e-4, logger=None, lanes=2,
-                        key_lanes=1, use_graphs=True):
+                        use_graphs=True):
     """pred_eval with the frames of each video pipelined over HIP streams (core/graphs.py
     FramePipeline): same loader, same flags, same launch sequences per frame, same return value.
     One pipeline (captured graphs + static buffers) is built per distinct (height, width, scale) and
@@ -188,7 +188,7 @@ def pred_eval_pipelined(gpu_id, key_predictor, cur_predictor, test_data, imdb, c
             if fp is None:
                 fp = pipelines[shape_key] = FramePipeline(key_predictor._exec, cur_predictor._exec, cfg, shape_key[0],
                                                           shape_key[1], data.device, thresh=thresh,
-                                                          use_graphs=use_graphs, lanes=lanes, key_lanes=key_lanes)
+                                                          use_graphs=use_graphs, lanes=lanes)
                 fp.set_scale(shape_key[2])
             deliver(fp.first_frame(data))
             if not fp.captured:

@@ -351,7 +351,8 @@ def test_demo_frame_directory(tmp_path, monkeypatch):
     np.testing.assert_allclose(top_a["box"], top_b["box"], atol=1e-2)
 
 
-def test_frame_pipeline_matches_serial_and_is_race_free(world):
+@pytest.mark.parametrize("lookahead", [False, True])
+def test_frame_pipeline_matches_serial_and_is_race_free(world, lookahead):
     """FramePipeline (key stream + non-key lanes) vs the serial FrameGraphs on the same frames:
     * run twice -> bit-identical detections (streams share no scratch memory, hand-over ordering holds);
     * every non-key frame read the right key feature: its output equals the serial loop's up to the
@@ -391,7 +392,7 @@ def test_frame_pipeline_matches_serial_and_is_race_free(world):
     det0 = torch.backends.cudnn.deterministic
     torch.backends.cudnn.deterministic = True
     try:
-        fp = FramePipeline(key, cur, cfg, H, W, DEV, lanes=3)
+        fp = FramePipeline(key, cur, cfg, H, W, DEV, lanes=3, lookahead=lookahead)
         run_pipeline(fp)
         a = run_pipeline(fp)
         b = run_pipeline(fp)

@@ -13,16 +13,16 @@ r = bench.Runner(args, 0, 'cuda:0')
 r.prime()
 for s in range(3):
     r.step(s)
-torch.cuda.synchronize()
+[getattr(x.fg, 'flush', lambda: None)() for x in (runners if 'runners' in dir() else [r])]; torch.cuda.synchronize()
 # (a) queue one step at a time and wait: host time to queue, then GPU completion
 tq = tg = 0.0
 for s in range(3, 13):
-    t0 = time.perf_counter(); r.step(s); t1 = time.perf_counter(); torch.cuda.synchronize(); t2 = time.perf_counter()
+    t0 = time.perf_counter(); r.step(s); t1 = time.perf_counter(); [getattr(x.fg, 'flush', lambda: None)() for x in (runners if 'runners' in dir() else [r])]; torch.cuda.synchronize(); t2 = time.perf_counter()
     tq += t1 - t0; tg += t2 - t0
 print('one step at a time: host queues a step in %.2f ms; step done after %.2f ms' % (tq / 10 * 1e3, tg / 10 * 1e3))
 # (b) free running
 t0 = time.perf_counter()
 for s in range(13, 33):
     r.step(s)
-t1 = time.perf_counter(); torch.cuda.synchronize(); t2 = time.perf_counter()
+t1 = time.perf_counter(); [getattr(x.fg, 'flush', lambda: None)() for x in (runners if 'runners' in dir() else [r])]; torch.cuda.synchronize(); t2 = time.perf_counter()
 print('20 steps free running: host loop %.2f ms/step, wall %.2f ms/step' % ((t1 - t0) / 20 * 1e3, (t2 - t0) / 20 * 1e3))

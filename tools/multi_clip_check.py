@@ -16,11 +16,11 @@ for k in range(K):
     r = bench.Runner(args, k, 'cuda:0'); r.prime(); runners.append(r)
 for s in range(3):
     for r in runners: r.step(s)
-torch.cuda.synchronize()
+[getattr(x.fg, 'flush', lambda: None)() for x in (runners if 'runners' in dir() else [r])]; torch.cuda.synchronize()
 n = 20
 t0 = time.perf_counter()
 for s in range(3, 3 + n):
     for r in runners: r.step(s)
-torch.cuda.synchronize()
+[getattr(x.fg, 'flush', lambda: None)() for x in (runners if 'runners' in dir() else [r])]; torch.cuda.synchronize()
 dt = time.perf_counter() - t0
 print('%d clips: %.1f frames/s aggregate, %.2f ms per (step of every clip)' % (K, K * n * args.interval / dt, dt / n * 1e3))

@@ -15,6 +15,7 @@ r = bench.Runner(args, 0, 'cuda:0')
 r.prime()
 for s in range(3):
     r.step(s)
+r.fg.flush()
 torch.cuda.synchronize()
 rec = collections.defaultdict(list)
 t_origin = torch.cuda.Event(enable_timing=True)
@@ -38,6 +39,7 @@ n = 10
 t0 = time.perf_counter()
 for s in range(3, 3 + n):
     r.step(s)
+fp.flush()
 torch.cuda.synchronize()
 wall = (time.perf_counter() - t0) / n * 1e3
 print('wall %.2f ms/step' % wall)
@@ -53,6 +55,7 @@ for name in ('front', 'flow', 'agg', 'tail'):
     print('step %d %-6s start %7.3f end %7.3f' % (k, name, f0.elapsed_time(a), f0.elapsed_time(b)))
 a, b = rec['front'][k + 1]
 print('step %d front  start %7.3f end %7.3f' % (k + 1, f0.elapsed_time(a), f0.elapsed_time(b)))
+print('non-key frames of step %d (queued after key frame %d):' % (k, k + 1))
 for j in range(9 * k, 9 * k + 9):
     a, b = rec['cur_frame'][j]
     print('   cur %d start %7.3f end %7.3f' % (j - 9 * k + 1, f0.elapsed_time(a), f0.elapsed_time(b)))

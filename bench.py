@@ -286,6 +286,14 @@ def main():
                                      "timed region (graph replays carry no per-launch events)",
                          "other_ops_avg_us": {k: round(v[0] * 1e3 / max(v[1], 1), 2) for k, v in prof.items() if v[1]}},
         }
+        if (args.height, args.width) == (600, 1000):
+            # algorithmic FLOPs of the dense contractions, key frame 392.0 G, non-key frame 17.3 G
+            gflop = 392.0 + 17.3 * (K - 1)
+            peak = 157.0 if args.dtype == 'f32' else 2500.0
+            tf = gflop * world / (elapsed / args.steps) / 1e3
+            line["roofline_dense"] = {"bound": "mfma", "scope": "all dense contractions of one interval (library MFMA kernels), "
+                                      "algorithmic FLOPs / step time, per GPU", "achieved": round(tf / world, 1), "peak": peak,
+                                      "unit": "TFLOP/s", "frac": round(tf / world / peak, 4), "gflop_per_step": round(gflop, 1)}
         if not args.no_cpu_baseline:
             try:
                 line["cpu_baseline"] = r.cpu_baseline(args.cpu_budget_s)

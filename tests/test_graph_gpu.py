@@ -466,3 +466,56 @@ def test_tuned_gemm_file_is_accepted_and_parity_holds(world):
     finally:
         key.taps = None
         tuning.disable()
+
+
+def test_two_clips_interleaved_on_one_gpu_are_isolated(world):
+    """BASELINE configs[2]/[3] run several independent clips per process / node.  Two clips pushed
+    alternately through two FramePipelines on the same GPU (bf16 contractions, config 3's arithmetic)
+    give bit-for-bit what each gives alone: pipelines share no buffers, workspaces or events."""
+    from lsfa_amd.core.graphs import FramePipeline
+    from lsfa_amd.symbols.resnet_v1_101_flownet_rfcn import resnet_v1_101_flownet_rfcn
+    from lsfa_amd.utils.synthetic import SyntheticClip
+    cfg, arg, aux = world['cfg'], world['arg'], world['aux']
+    net = resnet_v1_101_flownet_rfcn(cfg)
+    key = net.get_key_test_symbol(cfg).bind(arg, aux, DEV, torch.bfloat16)
+    cur = net.get_cur_test_symbol(cfg).bind(arg, aux, DEV, torch.bfloat16)
+    clips = [SyntheticClip(c, 8, H, W) for c in (3, 4)]
+    sched = [(f, 1 + 3 * ((f - 1) // 3)) for f in range(1, 8)]        # key 1, cur 2-3, key 4, cur 5-6, key 7
+    inputs = [{f: (c.frame(f, DEV), None if f == kf else c.motion_vector(f, kf, DEV), None if f == kf else c.res_diff(f, DEV))
+               for f, kf in sched} for c in clips]
+    first = [c.frame(0, DEV) for c in clips]
+    torch.cuda.synchronize()
+    det0 = torch.backends.cudnn.deterministic
+    torch.backends.cudnn.deterministic = True
+    try:
+        fps = [FramePipeline(key, cur, cfg, H, W, DEV) for _ in clips]
+
+        def run(order):
+            outs = [{}, {}]
+            for ci in set(order):
+                fps[ci].first_frame(first[ci])
+                if not fps[ci].captured:
+                    fps[ci].capture()
+            for f, kf in sched:
+                for ci in order:
+                    data, mv, res = inputs[ci][f]
+                    keep = (lambda ci, f: (lambda b: outs[ci].__setitem__(f, (b[0].clone(), b[1].clone()))))(ci, f)
+                    if f == kf:
+                        fps[ci].key_frame(data, deliver=keep)
+                    else:
+                        fps[ci].cur_frame(data, mv, res, deliver=keep)
+            for ci in set(order):
+                fps[ci].join()
+            torch.cuda.synchronize()
+            return [{f: (d.cpu().numpy(), c.cpu().numpy()) for f, (d, c) in o.items()} for o in outs]
+
+        run([0, 1])                          # throw-away pass (library settles on its solutions)
+        alone = [run([0])[0], run([1])[1]]
+        both = run([0, 1])
+    finally:
+        torch.backends.cudnn.deterministic = det0
+    for ci in (0, 1):
+        for f, _ in sched:
+            np.testing.assert_array_equal(both[ci][f][1], alone[ci][f][1])
+            np.testing.assert_array_equal(both[ci][f][0], alone[ci][f][0])
+    assert any((both[0][f][0] != both[1][f][0]).any() for f, _ in sched)       # the clips do differ

@@ -46,30 +46,38 @@ __device__ __forceinline__ void softmax2(float l0, float l1, float& w0, float& w
 }
 
 // out = w0*a + w1*b with (w0,w1) = softmax of the (2, HW) logits; shared by both variants.
-template <int VEC>
+// CPB (channels per thread, compile time): all 2*CPB operand loads are issued BEFORE the softmax —
+// the two correctly rounded exps are a ~1 us dependent chain on the fp64 unit, and with the loads
+// behind it every wave paid logits latency + exp chain + operand latency in series.
+template <int VEC, int CPB>
 __global__ __launch_bounds__(kThreads) void combine_kernel(const float* __restrict__ a,
                                                            const float* __restrict__ b,
                                                            const float* __restrict__ logits, int C, int HW,
-                                                           float* __restrict__ out, int ch_per_block) {
-  const int c0 = blockIdx.y * ch_per_block;
+                                                           float* __restrict__ out) {
+  const int c0 = blockIdx.y * CPB;
   const int p0 = (blockIdx.x * kThreads + threadIdx.x) * VEC;
   if (p0 >= HW) return;
   float l0[VEC], l1[VEC], w0[VEC], w1[VEC];
   load_vec<VEC>(logits + p0, l0);
   load_vec<VEC>(logits + HW + p0, l1);
+  float va[CPB][VEC], vb[CPB][VEC];
+#pragma unroll
+  for (int k = 0; k < CPB; ++k)
+    if (c0 + k < C) {
+      const size_t o = (size_t)(c0 + k) * HW + p0;
+      load_vec<VEC>(a + o, va[k]);
+      load_vec<VEC>(b + o, vb[k]);
+    }
 #pragma unroll
   for (int i = 0; i < VEC; ++i) softmax2(l0[i], l1[i], w0[i], w1[i]);
-  const int c1 = min(c0 + ch_per_block, C);
-#pragma unroll 4
-  for (int c = c0; c < c1; ++c) {
-    const size_t o = (size_t)c * HW + p0;
-    float va[VEC], vb[VEC], v[VEC];
-    load_vec<VEC>(a + o, va);
-    load_vec<VEC>(b + o, vb);
 #pragma unroll
-    for (int i = 0; i < VEC; ++i) v[i] = w0[i] * va[i] + w1[i] * vb[i];
-    store_vec<VEC>(out + o, v);
-  }
+  for (int k = 0; k < CPB; ++k)
+    if (c0 + k < C) {
+      float v[VEC];
+#pragma unroll
+      for (int i = 0; i < VEC; ++i) v[i] = w0[i] * va[k][i] + w1[i] * vb[k][i];
+      store_vec<VEC>(out + (size_t)(c0 + k) * HW + p0, v);
+    }
 }
 
 // cosine logits -> (2, HW) logits buffer laid out like Nq's, so the combine is shared.
@@ -115,12 +123,17 @@ int launch_combine(const float* a, const float* b, const float* logits, int C, i
   const size_t al = sizeof(float) * vec;
   if (!(aligned(a, al) && aligned(b, al) && aligned(logits, al) && aligned(out, al))) vec = 1;
   const int gx = ceil_div(HW, kThreads * vec);
-  int cpb = 8;
-  while (cpb > 1 && (long)gx * ceil_div(C, cpb) < 1024) cpb >>= 1;
+  // 8 channels per thread amortise the softmax; fall back to 4 when that leaves too few workgroups
+  const bool c8 = (long)gx * ceil_div(C, 8) >= 1024;
+  const int cpb = c8 ? 8 : 4;
   dim3 grid(gx, ceil_div(C, cpb));
-  if (vec == 4) hipLaunchKernelGGL(combine_kernel<4>, grid, dim3(kThreads), 0, s, a, b, logits, C, HW, out, cpb);
-  else if (vec == 2) hipLaunchKernelGGL(combine_kernel<2>, grid, dim3(kThreads), 0, s, a, b, logits, C, HW, out, cpb);
-  else hipLaunchKernelGGL(combine_kernel<1>, grid, dim3(kThreads), 0, s, a, b, logits, C, HW, out, cpb);
+#define LSFA_COMBINE(V)                                                                                          \
+  if (c8) hipLaunchKernelGGL((combine_kernel<V, 8>), grid, dim3(kThreads), 0, s, a, b, logits, C, HW, out);      \
+  else hipLaunchKernelGGL((combine_kernel<V, 4>), grid, dim3(kThreads), 0, s, a, b, logits, C, HW, out);
+  if (vec == 4) { LSFA_COMBINE(4) }
+  else if (vec == 2) { LSFA_COMBINE(2) }
+  else { LSFA_COMBINE(1) }
+#undef LSFA_COMBINE
   return 0;
 }
 

@@ -60,14 +60,15 @@ def main():
     o = torch.empty_like(feat)
     b3 = (3 * C * HW + 2 * HW) * 4
     b2 = (2 * C * HW + 2 * HW) * 4
+    LG = torch.randn(2, 1, H, W, device=dev)
     for name, fn, nbytes in (
             ('warp_plain', lambda: hip.warp_bilinear(feat, flow, out=o), b2),
             ('warp_key(x scale)', lambda: hip.warp_bilinear(feat, flow, mul=feat2, out=o), b3),
             ('warp_cur(+res+add)', lambda: hip.warp_bilinear(feat, flow, add=feat2, res=res, res_w=res_w, res_b=res_b, out=o), b3),
-            ('aggregate_softmax2', lambda: hip.aggregate_softmax2(feat, feat2, torch.randn(2, 1, H, W, device=dev) if False else LG, out=o), b3)):
-        if name.startswith('aggregate'):
-            pass
-        LG = torch.randn(2, 1, H, W, device=dev)
+            ('aggregate_softmax2', lambda: hip.aggregate_softmax2(feat, feat2, LG, out=o), b3),
+            # streaming references of the same size: what a kernel moving these bytes with no gathers costs
+            ('ref: torch copy (1 map)', lambda: o.copy_(feat), b2),
+            ('ref: torch add (2 maps -> 1)', lambda: torch.add(feat, feat2, out=o), b3)):
         us = timeit(fn, args.iters)
         out[name] = dict(us=round(us, 2), GBps=round(nbytes / us / 1e3, 1), bytes=nbytes)
     # PSROI / head

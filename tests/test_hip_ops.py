@@ -239,6 +239,20 @@ def test_nms_golden_reference_survivors(hip, golden):
             np.testing.assert_array_equal(order[hip.nms_host(dets[order], th)], want)
 
 
+def test_nms_wrappers_reference_interface(hip, golden):
+    """lib/nms/nms.py's wrappers (py_ / cpu_ / gpu_nms_wrapper, gpu_nms) over `_nms`: the reference's
+    survivor lists for its own float32 AND float64 golden boxes (IoUs computed in float32 here)."""
+    from lsfa_amd.nms.nms import py_nms_wrapper, cpu_nms_wrapper, gpu_nms_wrapper, gpu_nms
+    for n in (50, 300, 2000):
+        for th in (0.3, 0.7):
+            for dt in ("float32", "float64"):
+                dets = golden["g2_n%d_%s_dets" % (n, dt)]
+                want = golden["g2_n%d_%s_keep_%02d" % (n, dt, int(th * 10))]
+                for f in (py_nms_wrapper(th), cpu_nms_wrapper(th), gpu_nms_wrapper(th, 0)):
+                    np.testing.assert_array_equal(np.asarray(f(dets)), want)
+    assert gpu_nms(np.zeros((0, 5), np.float32), 0.3) == []
+
+
 def test_nms_all_identical_boxes_and_empty(hip):
     dets = np.tile(np.array([[10, 10, 50, 50, 0.5]], np.float32), (200, 1))
     keep, num = hip.nms_sorted(t(dets), 0.5)

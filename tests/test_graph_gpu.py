@@ -519,3 +519,28 @@ def test_two_clips_interleaved_on_one_gpu_are_isolated(world):
             np.testing.assert_array_equal(both[ci][f][1], alone[ci][f][1])
             np.testing.assert_array_equal(both[ci][f][0], alone[ci][f][0])
     assert any((both[0][f][0] != both[1][f][0]).any() for f, _ in sched)       # the clips do differ
+
+
+def test_bench_line_contract():
+    """bench.py prints ONE JSON line with the contract's keys (small frame size so it is quick)."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--steps", "3", "--warmup", "1", "--height", "192",
+                          "--width", "320", "--cpu-budget-s", "5"], capture_output=True, text=True, timeout=600, cwd=root)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+              "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert k in d, k
+    assert d["n_gpus"] == 1 and d["steps"] == 3 and d["unit"] == "frames/s" and d["value"] > 0
+    assert d["scaling"] == "weak" and d["vs_baseline"] is None and d["dtype"] == "f32" and d["data"] == "synthetic"
+    assert "workload" in d["config"] and "model" not in d["config"]
+    r = d["roofline"]
+    assert r["bound"] == "hbm" and r["unit"] == "GB/s" and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3
+    c = d["cpu_baseline"]
+    assert c["kind"] == "port" and c["cores"] >= 1 and c["unit"] == "frames/s" and c["sample"]

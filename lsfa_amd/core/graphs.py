@@ -25,11 +25,17 @@ from lsfa_amd.core import streams
 
 class FrameGraphs(object):
     def __init__(self, key_exec, cur_exec, cfg, height, width, device, thresh=1e-4, use_graphs=True, prefetch=True,
-                 feat_shared=None):
+                 feat_shared=None, taps=False):
         """feat_shared: a caller-owned (1, DFF_FEAT_DIM, h, w) buffer the non-key graph reads the key feature
-        from; such an instance is a non-key "lane" of a FramePipeline and never runs key frames."""
+        from; such an instance is a non-key "lane" of a FramePipeline and never runs key frames.
+        taps=True (parity tests): the stage outputs of the last key / non-key frame stay readable in
+        `key_taps` / `cur_taps` (+ the network outputs in `key_out` / `cur_out`); under hipGraph replay they
+        are the graphs' static buffers, so read or clone them on the frame's stream before the next replay."""
         self.key, self.cur, self.cfg = key_exec, cur_exec, cfg
         self.feat_shared = feat_shared
+        self.want_taps = taps
+        self.key_taps = self.cur_taps = self.key_out = self.cur_out = None
+        self._small_valid = False      # small_cur holds the small-net feature of the frame cur_frame is about to get
         self.device = torch.device(device)
         self.use_graphs = use_graphs
         self.h, self.w = height, width
@@ -81,30 +87,53 @@ class FrameGraphs(object):
     def _key_seq(self):
         if self.prefetch:
             self._fork_small_next()
-        out = self.key.forward(data=self.data, im_info=self.im_info, data_key_old=self.data_key_old,
-                               feat_key_old=self.feat_old)
+        saved = self.key.taps
+        if self.want_taps:
+            self.key.taps = self.key_taps = {}
+        try:
+            out = self.key.forward(data=self.data, im_info=self.im_info, data_key_old=self.data_key_old,
+                                   feat_key_old=self.feat_old)
+        finally:
+            self.key.taps = saved
+        self.key_out = out if self.want_taps else None
         self._post(out)
         if self.prefetch:
             self._join_small_next()
         return out['choose_feat_output']
 
     def _cur_seq(self):
-        if self.prefetch:
-            self._fork_small_next()
-            out = self.cur.forward(data=self.data, im_info=self.im_info, feat_key=self.feat, motion_vector=self.mv,
-                                   res_diff=self.res, small_feat=self.small_cur)
-        else:
-            out = self.cur.forward(data=self.data, im_info=self.im_info, feat_key=self.feat, motion_vector=self.mv,
-                                   res_diff=self.res)
+        saved = self.cur.taps
+        if self.want_taps:
+            self.cur.taps = self.cur_taps = {}
+        try:
+            if self.prefetch:
+                self._fork_small_next()
+                out = self.cur.forward(data=self.data, im_info=self.im_info, feat_key=self.feat, motion_vector=self.mv,
+                                       res_diff=self.res, small_feat=self.small_cur)
+            else:
+                out = self.cur.forward(data=self.data, im_info=self.im_info, feat_key=self.feat, motion_vector=self.mv,
+                                       res_diff=self.res)
+        finally:
+            self.cur.taps = saved
+        self.cur_out = out if self.want_taps else None
         self._post(out)
         if self.prefetch:
+            if self.want_taps:
+                self.cur_taps['small_feat'] = self.small_cur.clone()   # the join below overwrites small_cur
             self._join_small_next()
 
     # ---- first frame of a clip (flag 0): eager, no aggregation --------------------------
-    def first_frame(self, data):
+    def first_frame(self, data, next_data=None):
+        """`next_data`: image of the following frame when that frame is a non-key frame and prefetch is
+        on — its small-net feature is computed here, like key_frame / cur_frame do for their successor.
+        Without it, a cur_frame that follows computes its own feature inline (never a stale one)."""
         ph = torch.zeros((1, self.cfg.network.DFF_FEAT_DIM, 1, 1), device=self.device)
         out = self.key.forward(data=data, im_info=self.im_info, data_key_old=data, feat_key_old=ph)
         self._post(out)
+        self._small_valid = False
+        if self.prefetch and next_data is not None:
+            self.small_cur.copy_(self.cur.small_net_feature(next_data))
+            self._small_valid = True
         self.feat_old.copy_(out['choose_feat_output'])
         self.data_key_old.copy_(data)
         if self.feat is not None:
@@ -149,6 +178,7 @@ class FrameGraphs(object):
                 self._cur_seq()
         if self.feat_shared is None:
             self.feat.copy_(self._first_feat)
+        self._small_valid = False      # the warm-up replays left their own small-net feature in small_cur
 
     # ---- per-frame entry points ---------------------------------------------------------
     def key_frame(self, data, next_data=None):
@@ -162,6 +192,7 @@ class FrameGraphs(object):
             self.key_graph.replay()
         else:
             self.feat = self._key_seq()
+        self._small_valid = self.prefetch and next_data is not None
         # becomes the "old key" state of the next key frame
         self.feat_old.copy_(self.feat)
         self.data_key_old.copy_(self.data)
@@ -172,6 +203,10 @@ class FrameGraphs(object):
         been produced by the previous call (pass this frame's image as its `next_data`)."""
         self.data.copy_(data)
         if self.prefetch:
+            if not self._small_valid:
+                # nobody computed this frame's small-net feature ahead of time (the previous call had no
+                # `next_data`, e.g. a first_frame without it): compute it now instead of using a stale one
+                self.small_cur.copy_(self.cur.small_net_feature(data))
             self.data_next.copy_(next_data if next_data is not None else data)
         self.mv.copy_(motion_vector)
         self.res.copy_(res_diff)
@@ -179,6 +214,7 @@ class FrameGraphs(object):
             self.cur_graph.replay()
         else:
             self._cur_seq()
+        self._small_valid = self.prefetch and next_data is not None
         return self.post_bufs
 
 
@@ -187,8 +223,11 @@ class KeyLane(object):
     only images; `agg` (flow warp of the previous key feature x scale map, aggregation) produces the
     frame's feature; `tail` (RPN, Proposal, R-FCN head, detection post-processing) consumes it."""
 
-    def __init__(self, key_exec, cfg, height, width, device, thresh, use_graphs):
+    def __init__(self, key_exec, cfg, height, width, device, thresh, use_graphs, taps=False):
         self.key, self.cfg, self.device, self.use_graphs = key_exec, cfg, device, use_graphs
+        self.want_taps = taps
+        self.taps = {}         # taps=True: stage outputs of this buffer set's last frame (static under replay)
+        self.out = None
         self.h, self.w, self.thresh, self.scale = height, width, thresh, 1.0
         fh, fw = -(-height // 16), -(-width // 16)
         z = lambda *s: torch.zeros(s, device=device, dtype=torch.float32)
@@ -205,18 +244,31 @@ class KeyLane(object):
         self.feat = None
         self.front_graph = self.agg_graph = self.tail_graph = None
 
+    def _tapped(self, fn):
+        """Run one part with the executor's tap dict pointed at this lane's (parity tests only)."""
+        if not self.want_taps:
+            return fn()
+        saved = self.key.taps
+        self.key.taps = self.taps
+        try:
+            return fn()
+        finally:
+            self.key.taps = saved
+
     def front(self):
-        self.conv_feat = self.key.key_backbone(self.data)
+        self.conv_feat = self._tapped(lambda: self.key.key_backbone(self.data))
 
     def flow(self):
         self.flow_out = self.key.key_flow(self.data, self.data_key_old)
 
     def agg(self):
-        self.feat = self.key.key_aggregate(self.conv_feat, self.flow_out[0], self.flow_out[1], self.feat_old)
+        self.feat = self._tapped(lambda: self.key.key_aggregate(self.conv_feat, self.flow_out[0], self.flow_out[1],
+                                                                self.feat_old))
 
     def tail(self):
         cfg = self.cfg
-        out = self.key.key_heads(self.feat, self.im_info)
+        out = self._tapped(lambda: self.key.key_heads(self.feat, self.im_info))
+        self.out = out if self.want_taps else None
         hip.det_postprocess(out['rois_output'], out['bbox_pred_reshape_output'][0], out['cls_prob_reshape_output'][0],
                             self.h, self.w, self.scale, score_thresh=self.thresh, nms_thresh=cfg.TEST.NMS,
                             max_per_image=cfg.TEST.max_per_image, class_agnostic=cfg.CLASS_AGNOSTIC, out=self.post_bufs)
@@ -305,7 +357,7 @@ class FramePipeline(object):
     """
 
     def __init__(self, key_exec, cur_exec, cfg, height, width, device, thresh=1e-4, use_graphs=True, lanes=2,
-                 flow_stream=True, lookahead=False):
+                 flow_stream=True, lookahead=False, taps=False):
         dev = torch.device(device)
         self.device, self.cfg, self.key_exec = dev, cfg, key_exec
         self.h, self.w, self.thresh, self.scale = height, width, thresh, 1.0
@@ -314,9 +366,9 @@ class FramePipeline(object):
         dim = cfg.network.DFF_FEAT_DIM
         self.feat_cur = torch.zeros((1, dim, fh, fw), device=dev, dtype=torch.float32)   # what the non-key lanes read
         self.feat0 = torch.zeros((1, dim, fh, fw), device=dev, dtype=torch.float32)      # feature of a clip's frame 0
-        self.klanes = [KeyLane(key_exec, cfg, height, width, dev, thresh, use_graphs) for _ in range(2)]
+        self.klanes = [KeyLane(key_exec, cfg, height, width, dev, thresh, use_graphs, taps) for _ in range(2)]
         self.lanes = [FrameGraphs(key_exec, cur_exec, cfg, height, width, dev, thresh, use_graphs, prefetch=False,
-                                  feat_shared=self.feat_cur) for _ in range(lanes)]
+                                  feat_shared=self.feat_cur, taps=taps) for _ in range(lanes)]
         want = 1 + (1 if flow_stream else 0) + lanes
         chosen, aliased = streams.concurrent_streams(want, dev)
         self.hw_queues = len(chosen)
@@ -333,6 +385,7 @@ class FramePipeline(object):
         self.ev_feat = [E(), E()]                 # key-buffer i's feature exists
         self.ev_lane = [E() for _ in range(lanes)]
         self.captured = False
+        self.delivering = None
         self._next = self._nkey = 0
         self._feat_latest = self._prev_key_data = None
         self._seg_feat = self._seg_event = None     # feature (and its event) the buffered segment is served from
@@ -453,6 +506,7 @@ class FramePipeline(object):
                 st.wait_event(self.ev_feat[b])
                 lane.run_tail()                  # heads + detections: off the key stream
                 if deliver is not None:
+                    self.delivering = lane       # whose buffers `deliver` sees (tests read its taps)
                     deliver(lane.post_bufs)
                 self.ev_tail.record(st)
         if self.lookahead:
@@ -493,6 +547,7 @@ class FramePipeline(object):
                     t.record_stream(s)
                 bufs = self.lanes[i].cur_frame(data, motion_vector, res_diff)
                 if deliver is not None:
+                    self.delivering = self.lanes[i]
                     deliver(bufs)
                 self.ev_lane[i].record(s)
         self._held = []

@@ -96,6 +96,44 @@ def im_batch_detect(predictor, data_batch, data_names, scales, cfg):
     return scores_all, pred_boxes_all, data_dict_all
 
 
+class HostRing(object):
+    """Detections leave the device through a bounded ring of pinned host buffers: frame i's
+    (dets, counts) are copied asynchronously on the stream that produced them into slot i % n, an
+    event marks the copy, and a slot is drained into `all_boxes` (compact per-class numpy arrays, what
+    the reference keeps, tester.py:272) before it is reused.  Device memory held per frame: none;
+    host memory: n slots, independent of the dataset size."""
+
+    def __init__(self, all_boxes, num_classes, R, slots=32):
+        self.all_boxes, self.num_classes = all_boxes, num_classes
+        self.slots = [dict(dets=torch.empty((num_classes, R, 5), dtype=torch.float64).pin_memory(),
+                           counts=torch.empty(num_classes, dtype=torch.int32).pin_memory(),
+                           event=torch.cuda.Event(), idx=-1) for _ in range(slots)]
+        self.n = 0
+
+    def _drain(self, slot):
+        if slot['idx'] < 0:
+            return
+        slot['event'].synchronize()
+        dets, counts = slot['dets'].numpy(), slot['counts'].numpy()
+        for j in range(1, self.num_classes):
+            self.all_boxes[j][slot['idx']] = dets[j, :counts[j]].copy()
+        slot['idx'] = -1
+
+    def push(self, idx, dets, counts):
+        """Queue the copies on the CURRENT stream (the one the frame's post-processing ran on)."""
+        slot = self.slots[self.n % len(self.slots)]
+        self.n += 1
+        self._drain(slot)
+        slot['dets'].copy_(dets, non_blocking=True)
+        slot['counts'].copy_(counts, non_blocking=True)
+        slot['event'].record(torch.cuda.current_stream(dets.device))
+        slot['idx'] = idx
+
+    def finish(self):
+        for slot in self.slots:
+            self._drain(slot)
+
+
 def pred_eval(gpu_id, key_predictor, cur_predictor, test_data, imdb, cfg, vis=False, thresh=1e-4, logger=None,
               ignore_cache=True):
     """Frame loop of tester.py:192-299.  Returns (all_boxes, frame_ids) with
@@ -108,10 +146,19 @@ def pred_eval(gpu_id, key_predictor, cur_predictor, test_data, imdb, cfg, vis=Fa
     frame_ids = np.zeros(num_images, dtype=np.int64)
     roidb_idx, roidb_offset, idx = -1, -1, 0
     data_time = net_time = post_time = 0.0
-    pending = []
+    ring = post_out = None
     feat = None
     t = time.time()
     for im_info, key_frame_flag, data_batch in test_data:
+        if ring is None:
+            dev = data_batch.data[0][0].device
+            R = cfg.TEST.RPN_POST_NMS_TOP_N
+            ring = HostRing(all_boxes, num_classes, R)
+            # one set of device output buffers for every frame: the copy to the host ring is queued on the
+            # same stream right after the post-processing, so the next frame may overwrite them
+            post_out = (torch.zeros((num_classes, R, 5), dtype=torch.float64, device=dev),
+                        torch.zeros(num_classes, dtype=torch.int32, device=dev),
+                        torch.full((num_classes, R), -1, dtype=torch.int32, device=dev))
         t1 = time.time() - t
         t = time.time()
         scales = [iim_info[0, 2] for iim_info in im_info]
@@ -123,19 +170,19 @@ def pred_eval(gpu_id, key_predictor, cur_predictor, test_data, imdb, cfg, vis=Fa
             data_batch.data[0][-2] = feat_old
             data_batch.provide_data[0][-2] = ('feat_key_old', tuple(feat_old.shape))
             dets, counts, _, feat, _ = im_detect_device(key_predictor, data_batch, data_names, scales, cfg,
-                                                        post={'thresh': thresh})
+                                                        post={'thresh': thresh, 'out': post_out})
         else:
             data_batch.data[0][-1] = feat
             data_batch.provide_data[0][-1] = ('feat_key', tuple(feat.shape))
             dets, counts, _, _, _ = im_detect_device(cur_predictor, data_batch, data_names, scales, cfg,
-                                                     post={'thresh': thresh})
+                                                     post={'thresh': thresh, 'out': post_out})
         if key_frame_flag == 0:
             roidb_idx += 1
             roidb_offset = 0
         else:
             roidb_offset += 1
         frame_ids[idx] = roidb_frame_ids[roidb_idx] + roidb_offset
-        pending.append((idx, dets, counts))     # copied to the host after the loop: no per-frame sync
+        ring.push(idx, dets, counts)            # async copy to pinned host memory; no per-frame sync
         t2 = time.time() - t
         t = time.time()
         idx += test_data.batch_size
@@ -143,12 +190,9 @@ def pred_eval(gpu_id, key_predictor, cur_predictor, test_data, imdb, cfg, vis=Fa
         net_time += t2
         if logger and idx % 50 == 0:
             logger.info('testing {}/{} data {:.4f}s net {:.4f}s'.format(idx, num_images, data_time / idx, net_time / idx))
-    torch.cuda.synchronize()
     t = time.time()
-    for i, dets, counts in pending:
-        dets, counts = dets.cpu().numpy(), counts.cpu().numpy()
-        for j in range(1, num_classes):
-            all_boxes[j][i] = dets[j, :counts[j]].copy()
+    if ring is not None:
+        ring.finish()
     post_time = time.time() - t
     if logger:
         logger.info('done {} frames: data {:.4f}s net {:.4f}s post {:.4f}s per frame'.format(
@@ -169,7 +213,8 @@ def pred_eval_pipelined(gpu_id, key_predictor, cur_predictor, test_data, imdb, c
     roidb_frame_ids = [x['frame_id'] for x in test_data.roidb]
     all_boxes = [[[] for _ in range(num_images)] for _ in range(num_classes)]
     frame_ids = np.zeros(num_images, dtype=np.int64)
-    pipelines, pending = {}, []
+    pipelines = {}
+    ring = HostRing(all_boxes, num_classes, cfg.TEST.RPN_POST_NMS_TOP_N)
     roidb_idx, roidb_offset, idx = -1, -1, 0
     fp = None
     t0 = time.time()
@@ -178,7 +223,7 @@ def pred_eval_pipelined(gpu_id, key_predictor, cur_predictor, test_data, imdb, c
         data = d['data']
 
         def deliver(bufs, i=idx):
-            pending.append((i, bufs[0].clone(), bufs[1].clone()))      # queued on the frame's own stream
+            ring.push(i, bufs[0], bufs[1])      # copies queued on the frame's own stream, into pinned host memory
 
         if key_frame_flag == 0:
             shape_key = (int(data.shape[-2]), int(data.shape[-1]), float(im_info[0][0, 2]))
@@ -209,12 +254,9 @@ def pred_eval_pipelined(gpu_id, key_predictor, cur_predictor, test_data, imdb, c
             logger.info('queued {}/{} frames, {:.4f}s per frame'.format(idx, num_images, (time.time() - t0) / idx))
     if fp is not None:
         fp.join()
+    ring.finish()
     torch.cuda.synchronize()
     net_time = time.time() - t0
-    for i, dets, counts in pending:
-        dets, counts = dets.cpu().numpy(), counts.cpu().numpy()
-        for j in range(1, num_classes):
-            all_boxes[j][i] = dets[j, :counts[j]].copy()
     if logger:
         logger.info('done {} frames: {:.4f}s per frame ({:.1f} frames/s)'.format(num_images, net_time / max(idx, 1),
                                                                                  idx / max(net_time, 1e-9)))

@@ -4,6 +4,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <atomic>
+
 #include "lsfa_hip.h"
 
 namespace lsfa {
@@ -20,6 +22,22 @@ class ProfScope {
  private:
   hipStream_t stream_;
   int slot_;
+};
+
+// Function attributes (hipFuncAttributeMaxDynamicSharedMemorySize) are per DEVICE: run the setter once
+// per device the call site is used on.  Thread-safe; a setter that races with itself is idempotent.
+class PerDeviceOnce {
+ public:
+  template <class F> void run(F&& f) {
+    int d = 0;
+    (void)hipGetDevice(&d);
+    const uint64_t bit = 1ULL << (d & 63);
+    if (done_.load(std::memory_order_acquire) & bit) return;
+    f();
+    done_.fetch_or(bit, std::memory_order_release);
+  }
+ private:
+  std::atomic<uint64_t> done_{0};
 };
 
 static inline int ceil_div(int a, int b) { return (a + b - 1) / b; }

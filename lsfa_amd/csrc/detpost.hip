@@ -330,11 +330,10 @@ extern "C" int lsfa_det_postprocess(const float* rois, const float* deltas, cons
   }
   hipStream_t s = (hipStream_t)stream;
   const size_t lds = class_lds_bytes(R);
-  static bool attr_set = false;
-  if (!attr_set) {
+  static PerDeviceOnce lds_attr;
+  lds_attr.run([] {
     (void)hipFuncSetAttribute((const void*)det_class_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    attr_set = true;
-  }
+  });
   ProfScope prof(LSFA_OP_DET, s);
   hipLaunchKernelGGL(det_class_kernel, dim3(ncls), dim3(kClassThreads), lds, s, rois, deltas, probs, R, ncls, nreg,
                      class_agnostic, im_h, im_w, scale, score_thresh, nms_thresh, dets, counts, keep_idx);

@@ -650,15 +650,14 @@ extern "C" int lsfa_proposal(const float* cls_prob, const float* bbox_pred, cons
     iou.tie_up = (nb & 1u) == 0;
     iou.fast = (threshold > 1e-30f && threshold < 1e30f) ? 1 : 0;
   }
-  const size_t kLdsMax = 160 * 1024;
-  static bool attr_set = false;
-  if (!attr_set) {
+  constexpr size_t kLdsMax = 160 * 1024;
+  static PerDeviceOnce lds_attr;
+  lds_attr.run([] {
     (void)hipFuncSetAttribute((const void*)proposal_select_nms_kernel<true, 8, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsMax);
     (void)hipFuncSetAttribute((const void*)proposal_select_nms_kernel<false, 8, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsMax);
     (void)hipFuncSetAttribute((const void*)proposal_select_nms_kernel<false, 8, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsMax);
     (void)hipFuncSetAttribute((const void*)proposal_select_nms_kernel<false, 16, false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsMax);
-    attr_set = true;
-  }
+  });
   // radix path: sort buffer A = K*8 (>= the 16 KB of select histograms), region = buffer B + counters
   const size_t hist_bytes = (size_t)kHistReplicas * 256 * 4;
   const size_t sortA = align_up((size_t)pre_n * 8 > hist_bytes ? (size_t)pre_n * 8 : hist_bytes, 16);

@@ -64,6 +64,22 @@ def _stream():
     return _vp(torch.cuda.current_stream().cuda_stream)
 
 
+def _on_tensor_device(fn):
+    """Run an op with the device of its first tensor argument current, so that `_stream()` (the CURRENT
+    stream of the CURRENT device) and the C side's per-device state belong to the tensors' device even
+    when the caller never called torch.cuda.set_device (e.g. Predictor(..., context='cuda:1'))."""
+    import functools
+
+    @functools.wraps(fn)
+    def wrapped(*args, **kw):
+        dev = next((a.device for a in args if isinstance(a, torch.Tensor) and a.is_cuda), None)
+        if dev is None or dev.index == torch.cuda.current_device():
+            return fn(*args, **kw)
+        with torch.cuda.device(dev):
+            return fn(*args, **kw)
+    return wrapped
+
+
 def _f32c(t, name):
     if t is None:
         return None
@@ -73,6 +89,7 @@ def _f32c(t, name):
 
 
 # ------------------------------------------------------------------------------------
+@_on_tensor_device
 def psroi_pool(data, rois, spatial_scale, output_dim, pooled_size, group_size, with_mapping=False):
     data, rois = _f32c(data, "data"), _f32c(rois, "rois")
     N, C, H, W = data.shape
@@ -85,6 +102,7 @@ def psroi_pool(data, rois, spatial_scale, output_dim, pooled_size, group_size, w
     return (out, mc) if with_mapping else out
 
 
+@_on_tensor_device
 def rfcn_head(cls_map, box_map, rois, spatial_scale=0.0625, pooled_size=7, group_size=7, want_score=False,
               out=None):
     cls_map, box_map, rois = _f32c(cls_map, "cls_map"), _f32c(box_map, "box_map"), _f32c(rois, "rois")
@@ -104,6 +122,7 @@ def rfcn_head(cls_map, box_map, rois, spatial_scale=0.0625, pooled_size=7, group
     return (cls_prob, cls_score, bbox_pred) if want_score else (cls_prob, bbox_pred)
 
 
+@_on_tensor_device
 def rfcn_head_ps(ps_map, rois, ncls, nbox, spatial_scale=0.0625, pooled_size=7, group_size=7, want_score=False):
     """ps_map (N, H, W, group^2, ncls+nbox) float32 — see lsfa_rfcn_head_ps_fwd."""
     ps_map, rois = _f32c(ps_map, "ps_map"), _f32c(rois, "rois")
@@ -118,6 +137,7 @@ def rfcn_head_ps(ps_map, rois, ncls, nbox, spatial_scale=0.0625, pooled_size=7, 
     return (cls_prob, cls_score, bbox_pred) if want_score else (cls_prob, bbox_pred)
 
 
+@_on_tensor_device
 def warp_bilinear(feat, flow, mul=None, add=None, res=None, res_w=None, res_b=None, out=None):
     feat, flow = _f32c(feat, "feat"), _f32c(flow, "flow")
     mul, add, res = _f32c(mul, "mul"), _f32c(add, "add"), _f32c(res, "res")
@@ -135,6 +155,7 @@ def warp_bilinear(feat, flow, mul=None, add=None, res=None, res_w=None, res_b=No
     return out
 
 
+@_on_tensor_device
 def aggregate_softmax2(a, b, logits, out=None):
     a, b, logits = _f32c(a, "a"), _f32c(b, "b"), _f32c(logits, "logits")
     _, C, H, W = a.shape
@@ -145,6 +166,7 @@ def aggregate_softmax2(a, b, logits, out=None):
     return out
 
 
+@_on_tensor_device
 def aggregate_cosine(a, b, emb_warp, emb_cur, out=None):
     a, b = _f32c(a, "a"), _f32c(b, "b")
     emb_warp, emb_cur = _f32c(emb_warp, "emb_warp"), _f32c(emb_cur, "emb_cur")
@@ -171,6 +193,9 @@ class ProposalOp(object):
         self.output_score = output_score
 
     def __call__(self, cls_prob, bbox_pred, im_info, out=None):
+        if cls_prob.is_cuda and cls_prob.device.index != torch.cuda.current_device():
+            with torch.cuda.device(cls_prob.device):
+                return self(cls_prob, bbox_pred, im_info, out)
         cls_prob, bbox_pred, im_info = _f32c(cls_prob, "cls_prob"), _f32c(bbox_pred, "bbox_pred"), _f32c(im_info, "im_info")
         B, A2, H, W = cls_prob.shape
         A = A2 // 2
@@ -195,6 +220,7 @@ class ProposalOp(object):
         return (rois, scores) if self.output_score else rois
 
 
+@_on_tensor_device
 def nms_sorted(boxes, thresh):
     """boxes (n, >=4) float32 CUDA, sorted by score descending -> (keep int32 (n,), num_keep int32 (1,)) on device."""
     boxes = _f32c(boxes, "boxes")
@@ -220,6 +246,7 @@ def nms_host(boxes_np, thresh, device_id=0):
     return keep[:num.value]
 
 
+@_on_tensor_device
 def bbox_pred_clip(rois, deltas, im_h, im_w, scale):
     rois, deltas = _f32c(rois, "rois"), _f32c(deltas, "deltas")
     R = rois.shape[0]
@@ -230,6 +257,7 @@ def bbox_pred_clip(rois, deltas, im_h, im_w, scale):
     return out
 
 
+@_on_tensor_device
 def det_postprocess(rois, deltas, probs, im_h, im_w, scale, score_thresh=1e-4, nms_thresh=0.3, max_per_image=300,
                     class_agnostic=True, out=None):
     rois, deltas, probs = _f32c(rois, "rois"), _f32c(deltas, "deltas"), _f32c(probs, "probs")
@@ -248,6 +276,7 @@ def det_postprocess(rois, deltas, probs, im_h, im_w, scale, score_thresh=1e-4, n
     return dets, counts, keep_idx
 
 
+@_on_tensor_device
 def deform_im2col(data, offset, kh, kw, pad, stride, dilate, deform_groups, out=None):
     data, offset = _f32c(data, "data"), _f32c(offset, "offset")
     N, C, H, W = data.shape
@@ -260,6 +289,7 @@ def deform_im2col(data, offset, kh, kw, pad, stride, dilate, deform_groups, out=
     return out
 
 
+@_on_tensor_device
 def deform_im2col_cl(data, offset, kh, kw, pad, stride, dilate, deform_groups, out=None):
     """data (N,H,W,C), offset (N,Ho,Wo,2*kh*kw*dg) contiguous -> col (N, Ho*Wo, kh*kw*C), k = tap*C + c."""
     data, offset = _f32c(data, "data"), _f32c(offset, "offset")
@@ -275,6 +305,7 @@ def deform_im2col_cl(data, offset, kh, kw, pad, stride, dilate, deform_groups, o
     return out
 
 
+@_on_tensor_device
 def scale_shift_relu(x, scale, shift, relu=True, out=None):
     x = _f32c(x, "x")
     N, C = x.shape[0], x.shape[1]
@@ -286,6 +317,7 @@ def scale_shift_relu(x, scale, shift, relu=True, out=None):
     return out
 
 
+@_on_tensor_device
 def scale_shift_leaky(x, scale, shift, slope, out=None):
     x = _f32c(x, "x")
     N, C = x.shape[0], x.shape[1]
@@ -297,6 +329,7 @@ def scale_shift_leaky(x, scale, shift, slope, out=None):
     return out
 
 
+@_on_tensor_device
 def scale_shift_relu_cl(x, scale, shift, relu=True, out=None):
     """Channels-last form: x (..., C) contiguous with the channel the fastest axis, C % 4 == 0."""
     x = _f32c(x, "x")

@@ -85,3 +85,38 @@ def test_vid_eval_hand_built_case():
     assert abs(ve.gt_threshold([200, 200, 219, 219]) - 400.0 / 900.0) < 1e-12
     assert ve.format_rows(rows[:1]) == ['0 1 0.9000 12.00 12.00 111.00 111.00']
     assert ve.vid_eval(np.zeros((0, 7)), gt, 3).tolist() == [0.0, 0.0]
+
+
+def test_vid_eval_matches_loop_form_restatement():
+    """The vectorised evaluator vs oracle/np_ref.vid_eval_ref (lib/dataset/imagenet_vid_eval.py restated loop
+    by loop) on seeded random frames: jittered copies of the ground truth (hits, duplicates, near-threshold
+    overlaps, small boxes whose threshold is relaxed), wrong-class copies, background boxes, frames without
+    annotation records, score ties, empty ground truths."""
+    from oracle import np_ref
+    for seed in range(6):
+        rs = np.random.RandomState(seed)
+        ncls = 6
+        gt, rows = [], []
+        for f in range(12):
+            k = rs.randint(0, 5)
+            xy = rs.uniform(0, 300, (k, 2))
+            wh = np.where(rs.rand(k, 1) < 0.3, rs.uniform(4, 20, (k, 2)), rs.uniform(30, 200, (k, 2)))
+            boxes = np.round(np.concatenate([xy, xy + wh], 1))
+            labels = rs.randint(1, ncls, k)
+            if f != 7:                                   # frame 7 has detections but no annotation record
+                gt.append({'img_id': f, 'bbox': boxes, 'label': labels})
+            for b, l in zip(boxes, labels):
+                for _ in range(rs.randint(0, 4)):
+                    jit = b + rs.uniform(-1, 1, 4) * rs.choice([1.0, 6.0, 25.0])
+                    cls = l if rs.rand() < 0.8 else rs.randint(1, ncls)
+                    rows.append([f, cls, np.round(rs.uniform(0.05, 1.0), 1), jit[0], jit[1], jit[2], jit[3]])
+            for _ in range(rs.randint(0, 3)):
+                xy0 = rs.uniform(0, 400, 2)
+                rows.append([f, rs.randint(1, ncls), rs.uniform(0.05, 1.0), xy0[0], xy0[1], xy0[0] + 50, xy0[1] + 40])
+        rows = np.array(rows, dtype=np.float64)
+        rows = rows[rs.permutation(len(rows))]
+        for through_text in (True, False):
+            want = np_ref.vid_eval_ref(rows, gt, ncls, through_text=through_text)
+            got = ve.vid_eval(rows, gt, ncls, through_text=through_text)
+            np.testing.assert_array_equal(got, want)
+        assert want.max() > 0

@@ -1,0 +1,121 @@
+"""BASELINE configs[1] at its real size: 1000x600 frames (38x63 feature map, 21,546 anchors, 300 ROIs)
+through the key / cur graphs vs oracle/graph_ref.py.
+
+Dense stages (library MFMA convolutions / GEMMs, BN folded, channels-last) are compared with the
+unfused torch-CPU statement and the measured error is written to gpurun_out/parity_fullres.json;
+every hand-written stage (flow/MV warp with its fused epilogues, Nq softmax combine, Proposal,
+PSROI + average + softmax, detection post-processing) is pinned to the oracle BIT FOR BIT on
+the GPU's own inputs to that stage.  Finally the un-forced end-to-end outputs are compared
+(north_star: boxes / scores within 1e-4, ROI indices and NMS survivors identical).
+"""
+import numpy as np
+import pytest
+import torch
+
+import oracle
+from oracle import graph_ref
+from parity_util import check_cur_frame, check_dets, check_heads, check_key_frame, np_, record, rel_err
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+H, W = 600, 1000
+# dense contractions, fp32 MFMA vs torch-CPU fp32 of the unfused graph (different summation orders,
+# BN folded in fp64 vs applied in fp32): relative to the map's max.  Measured r2: see DESIGN.md §5.
+TOL_DENSE = 5e-4
+
+
+@pytest.fixture(scope="module")
+def world():
+    from lsfa_amd.config.config import lsfa_test_config
+    from lsfa_amd.symbols import params as P
+    from lsfa_amd.symbols.resnet_v1_101_flownet_rfcn import resnet_v1_101_flownet_rfcn
+    from lsfa_amd.utils.synthetic import SyntheticClip
+    cfg = lsfa_test_config(key_frame_interval=10)
+    arg, aux = P.init_params(cfg, seed=0)
+    net = resnet_v1_101_flownet_rfcn(cfg)
+    key = net.get_key_test_symbol(cfg).bind(arg, aux, DEV)
+    cur = net.get_cur_test_symbol(cfg).bind(arg, aux, DEV)
+    clip = SyntheticClip(0, 12, H, W)
+    return dict(cfg=cfg, arg=arg, aux=aux, key=key, cur=cur, clip=clip)
+
+
+def end_to_end_gap(cfg, gpu_out, ref_out, h, w):
+    """Un-forced comparison of one frame's final outputs: GPU graph vs oracle graph, each on its own
+    intermediate values.  -> dict(roi_mismatch, max_abs_dbox, max_abs_dscore, survivor_mismatch)."""
+    g_rois, r_rois = np_(gpu_out['rois_output']), np.asarray(ref_out['rois_output'])
+    same = np.abs(g_rois - r_rois).max(1) < 0.05        # same anchor survived at the same output row
+    g_cls, r_cls = np_(gpu_out['cls_prob_reshape_output'])[0], np.asarray(ref_out['cls_prob_reshape_output'])[0]
+    g_box = oracle.bbox_pred_clip(g_rois, np_(gpu_out['bbox_pred_reshape_output'])[0], h, w, 1.0)
+    r_box = oracle.bbox_pred_clip(r_rois, np.asarray(ref_out['bbox_pred_reshape_output'])[0], h, w, 1.0)
+    gd, gc, gk = oracle.det_postprocess(g_rois, np_(gpu_out['bbox_pred_reshape_output'])[0], g_cls, h, w, 1.0,
+                                        nms_thresh=cfg.TEST.NMS, max_per_image=cfg.TEST.max_per_image)
+    rd, rc, rk = oracle.det_postprocess(r_rois, np.asarray(ref_out['bbox_pred_reshape_output'])[0], r_cls, h, w, 1.0,
+                                        nms_thresh=cfg.TEST.NMS, max_per_image=cfg.TEST.max_per_image)
+    gs = set((j, int(i)) for j in range(1, len(gc)) for i in gk[j, :gc[j]])
+    rs = set((j, int(i)) for j in range(1, len(rc)) for i in rk[j, :rc[j]])
+    return dict(roi_mismatch=int((~same).sum()),
+                max_abs_dbox=float(np.abs(g_box[same] - r_box[same]).max()) if same.any() else None,
+                max_abs_dscore=float(np.abs(g_cls[same] - r_cls[same]).max()) if same.any() else None,
+                survivor_mismatch=len(gs ^ rs), survivors=len(rs))
+
+
+def test_first_key_cur_second_key_at_1000x600(world):
+    cfg, arg, aux, key, cur, clip = (world[k] for k in ('cfg', 'arg', 'aux', 'key', 'cur', 'clip'))
+    im_info = clip.im_info()
+    im_t = torch.from_numpy(im_info).to(DEV)
+    f0, f3, f10 = clip.frame(0), clip.frame(3), clip.frame(10)
+    p = graph_ref.Params(arg, aux)
+    rec = {}
+
+    # ---- frame 0 (flag 0): backbone + heads -----------------------------------------------
+    key.taps = {}
+    out0 = key.forward(data=f0.to(DEV), im_info=im_t, data_key_old=f0.to(DEV), feat_key_old=torch.zeros(1, 1024, 1, 1, device=DEV))
+    taps0 = dict(key.taps)
+    ref0 = graph_ref.key_forward(cfg, arg, aux, f0.numpy(), f0.numpy(), np.zeros((1, 1024, 1, 1), np.float32), im_info)
+    assert out0['choose_feat_output'].shape == (1, 1024, 38, 63)
+    rec['backbone_feat'] = rel_err(np_(taps0['backbone_feat']), ref0['backbone_feat'])
+    rec['cls_map'] = rel_err(np_(taps0['cls_map']), ref0['cls_map'])
+    rec['box_map'] = rel_err(np_(taps0['box_map']), ref0['box_map'])
+    rec['rpn_bbox_pred'] = rel_err(np_(taps0['rpn_bbox_pred']), ref0['rpn_bbox_pred'])
+    rec['rpn_cls_prob_abs'] = float(np.abs(np_(taps0['rpn_cls_prob']) - ref0['rpn_cls_prob']).max())
+    check_heads(cfg, taps0, out0, im_info)
+    from lsfa_amd import hip
+    d, c, _ = hip.det_postprocess(out0['rois_output'], out0['bbox_pred_reshape_output'][0], out0['cls_prob_reshape_output'][0],
+                                  H, W, 1.0, nms_thresh=cfg.TEST.NMS, max_per_image=cfg.TEST.max_per_image)
+    check_dets(cfg, out0, d.cpu().numpy(), c.cpu().numpy(), H, W)
+    rec['frame0_end_to_end'] = end_to_end_gap(cfg, out0, ref0, H, W)
+    feat0 = out0['choose_feat_output']
+
+    # ---- frame 3 (flag 2): small net + MV warp + residual + heads ---------------------------
+    mv, res = clip.motion_vector(3, 0), clip.res_diff(3)
+    cur.taps = {}
+    out3 = cur.forward(data=f3.to(DEV), im_info=im_t, feat_key=feat0, motion_vector=mv.to(DEV), res_diff=res.to(DEV))
+    taps3 = dict(cur.taps)
+    rec['small_feat'] = rel_err(np_(taps3['small_feat']), graph_ref.small_net_feature(p, f3).numpy())
+    check_cur_frame(cfg, arg, taps3, out3, feat0, mv, res, im_info)
+    ref3 = graph_ref.cur_forward(cfg, arg, aux, f3.numpy(), ref0['choose_feat_output'], mv.numpy(), res.numpy(), im_info)
+    rec['frame3_end_to_end'] = end_to_end_gap(cfg, out3, ref3, H, W)
+
+    # ---- frame 10 (flag 1): FlowNet + flow warp x scale map + Nq aggregation + heads ---------
+    key.taps = {}
+    out10 = key.forward(data=f10.to(DEV), im_info=im_t, data_key_old=f0.to(DEV), feat_key_old=feat0)
+    taps10 = dict(key.taps)
+    flow_ref, scale_ref = graph_ref.get_flownet(p, f10, f0)
+    rec['flow_abs'] = float(np.abs(np_(taps10['flow']) - flow_ref.numpy()).max())
+    rec['flow_max'] = float(flow_ref.abs().max())
+    rec['scale_map'] = rel_err(np_(taps10['scale_map']), scale_ref.numpy())
+    check_key_frame(cfg, taps10, out10, feat0, im_info)
+    logits_ref = graph_ref.nq_logits(p, torch.from_numpy(np_(taps10['warp'])), taps10['backbone_feat'].cpu()).numpy()
+    rec['nq_logits_abs'] = float(np.abs(np_(taps10['nq_logits']) - logits_ref).max())
+    rec['nq_logits_max'] = float(np.abs(logits_ref).max())
+    ref10 = graph_ref.key_forward(cfg, arg, aux, f10.numpy(), f0.numpy(), ref0['choose_feat_output'], im_info)
+    rec['choose_feat_second_key'] = rel_err(np_(out10['choose_feat_output']), ref10['choose_feat_output'])
+    rec['frame10_end_to_end'] = end_to_end_gap(cfg, out10, ref10, H, W)
+    key.taps = cur.taps = None
+    record('fullres', rec)
+
+    for k in ('backbone_feat', 'cls_map', 'box_map', 'rpn_bbox_pred', 'small_feat', 'scale_map', 'choose_feat_second_key'):
+        assert rec[k] < TOL_DENSE, (k, rec[k])
+    assert rec['rpn_cls_prob_abs'] < 1e-4
+    assert rec['flow_abs'] < TOL_DENSE * max(1.0, rec['flow_max'])
+    assert rec['nq_logits_abs'] < TOL_DENSE * max(1.0, rec['nq_logits_max'])

@@ -143,6 +143,13 @@ size_t lsfa_nms_workspace_bytes(int n);
 int lsfa_nms_sorted(const float* boxes, int n, int box_dim, float thresh,
                     int* keep, int* num_keep, void* ws, size_t ws_bytes, void* stream);
 
+/* The same sweep on float64 boxes with numpy's arithmetic and keep rule (`ovr <= thresh` survives).
+ * Replaces: the loop of nms()   lib/nms/nms.py:47-72   after its `scores.argsort()[::-1]` (:45), which the
+ * caller does (the host side mirrors the reference: lsfa_amd/nms/nms.py).  pred_eval's per-class NMS runs on
+ * float64 dets (dff_rfcn/core/tester.py:270-271); this is that path for callers of py_nms_wrapper. */
+int lsfa_nms_sorted_f64(const double* boxes, int n, int box_dim, double thresh,
+                        int* keep, int* num_keep, void* ws, size_t ws_bytes, void* stream);
+
 /* The reference's exact host-pointer entry point (lib/nms/gpu_nms.hpp:14-15):
  * boxes_host (boxes_num, boxes_dim) already sorted by score; keep_out has room
  * for boxes_num ints.  Allocates, copies and synchronises like the original. */
@@ -209,6 +216,27 @@ int lsfa_scale_shift_leaky(const float* x, const float* scale, const float* shif
  * (rows = N*H*W), C a multiple of 4, all pointers 16-byte aligned.  In-place allowed. */
 int lsfa_scale_shift_relu_cl(const float* x, const float* scale, const float* shift,
                              long long rows, int C, int relu, float* y, void* stream);
+
+/* ------------------------------------------------------------------------ *
+ * Compressed-domain motion vectors: accumulation back to the key frame, the accumulated field and
+ * the residual.
+ * Replaces: create_and_load_mv_residual (accumulate = 1)   external/data_loader_py2/coviar_data_loader.c:71-177
+ *           and the identity initialisation of accu_src    :316-323.
+ * mvs (n_mvs, 7) int32 DEVICE rows = AVMotionVector's {source, w, h, src_x, src_y, dst_x, dst_y} in decoder
+ * order (later blocks overwrite earlier ones, as the reference's serial loop does); max_block_area >= w*h of
+ * every block.  accu_* (H, W, 2) int32 = per pixel the (x, y) it came from in the GOP's first frame
+ * (row-major here; the reference's buffer is x-major).  lsfa_mv_accumulate writes EVERY pixel of accu_new
+ * (accu_new != accu_old): ping-pong the two buffers from frame to frame.
+ * mv (H, W, 2) int32 = (x, y) - accu  (:131-141);  res (H, W, 3) int32 = cur - ref[accu]  (:144-171),
+ * bgr_* (H, W, 3) uint8.  Outputs feed transform_mv_res (lib/utils/image.py:202-263).
+ * ------------------------------------------------------------------------ */
+size_t lsfa_mv_workspace_bytes(int width, int height);
+int lsfa_mv_identity(int* accu, int width, int height, void* stream);
+int lsfa_mv_accumulate(const int* mvs, int n_mvs, int max_block_area, const int* accu_old, int* accu_new,
+                       int width, int height, void* ws, size_t ws_bytes, void* stream);
+int lsfa_mv_field(const int* accu, int width, int height, int* mv, void* stream);
+int lsfa_mv_residual(const unsigned char* bgr_cur, const unsigned char* bgr_ref, const int* accu,
+                     int width, int height, int* res, void* stream);
 
 /* ------------------------------------------------------------------------ *
  * Live per-op timing with HIP events on the launch stream (bench.py's roofline leg).

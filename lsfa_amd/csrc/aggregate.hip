@@ -4,10 +4,8 @@
 // Mapping: like the warp kernel, a thread owns VEC adjacent pixels and a run of
 // channels; the per-pixel softmax weights (two correctly rounded exps on the fp64
 // unit) are computed once per thread and reused over the run.  The cosine variant
-// first reduces the two E-channel embeddings per pixel: lanes walk pixels (coalesced
-// along H*W), each lane accumulating its own pixel over E sequentially, which is the
-// oracle's summation order, so results are bit-identical and no cross-lane reduction
-// is needed at all.
+// first reduces the two E-channel embeddings per pixel with the E axis across the
+// lanes of a wave and a fixed __shfl_xor butterfly (cosine_logits_kernel below).
 #include "common.h"
 
 namespace {
@@ -81,23 +79,82 @@ __global__ __launch_bounds__(kThreads) void combine_kernel(const float* __restri
 }
 
 // cosine logits -> (2, HW) logits buffer laid out like Nq's, so the combine is shared.
+//
+// Per pixel: L2 norms of the two E-channel embeddings, then <emb_warp/|.|, emb_cur/|.|> and
+// <emb_cur/|.|, emb_cur/|.|> — four reductions over E (2048 for LSFA).  The sum order is the fixed tree
+// of orc_aggregate_cosine: 64 partial sums (partial j = channels j, j+64, ... in order), then a
+// butterfly over j.  Mapping: a workgroup owns kCosPx consecutive pixels; each 64-channel chunk is read
+// from HBM/L2 coalesced along the pixels, staged in LDS, and re-read transposed so that LANE j of a
+// wave holds channel class j of the wave's pixels: the chunk loop is the in-order accumulation of
+// partial j, and the butterfly is six __shfl_xor steps — the cross-lane reduction north_star asks
+// for — with bit-identical results on both sides.
+constexpr int kCosPx = 32;                    // pixels per workgroup (128-byte segments per channel row)
+constexpr int kCosWaves = kThreads / 64;      // 4
+constexpr int kCosPxPerWave = kCosPx / kCosWaves;
+
+__device__ __forceinline__ float wave_tree_total(float v) {
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) v = v + __shfl_xor(v, d, 64);
+  return v;
+}
+
 __global__ __launch_bounds__(kThreads) void cosine_logits_kernel(const float* __restrict__ emb_warp,
                                                                  const float* __restrict__ emb_cur, int E,
                                                                  int HW, float* __restrict__ logits) {
-  const int p = blockIdx.x * kThreads + threadIdx.x;
-  if (p >= HW) return;
-  float sw = 0.f, sc = 0.f;
-  for (int e = 0; e < E; ++e) { const float v = emb_warp[(size_t)e * HW + p]; sw += v * v; }
-  for (int e = 0; e < E; ++e) { const float v = emb_cur[(size_t)e * HW + p]; sc += v * v; }
-  const float nw = sqrtf(sw + 1e-10f), nc = sqrtf(sc + 1e-10f);
-  float l0 = 0.f, l1 = 0.f;
-  for (int e = 0; e < E; ++e) {
-    const float vw = emb_warp[(size_t)e * HW + p] / nw, vc = emb_cur[(size_t)e * HW + p] / nc;
-    l0 += vw * vc;
-    l1 += vc * vc;
+  __shared__ float tw[64][kCosPx + 1], tc[64][kCosPx + 1];
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int p0 = blockIdx.x * kCosPx;
+  const int chunks = (E + 63) / 64;
+  float nw[kCosPxPerWave], nc[kCosPxPerWave];
+  float l0[kCosPxPerWave], l1[kCosPxPerWave];
+#pragma unroll 1
+  for (int pass = 0; pass < 2; ++pass) {
+    float acc_a[kCosPxPerWave], acc_b[kCosPxPerWave];
+#pragma unroll
+    for (int i = 0; i < kCosPxPerWave; ++i) { acc_a[i] = 0.f; acc_b[i] = 0.f; }
+    for (int ch = 0; ch < chunks; ++ch) {
+      // stage 64 channels x kCosPx pixels of both embeddings (rows past E and pixels past HW read as 0 / clamped)
+#pragma unroll
+      for (int q = 0; q < 64 * kCosPx / kThreads; ++q) {
+        const int idx = q * kThreads + tid;
+        const int r = idx / kCosPx, x = idx - r * kCosPx;
+        const int e = ch * 64 + r;
+        const int p = min(p0 + x, HW - 1);
+        float vw = 0.f, vc = 0.f;
+        if (e < E) { vw = emb_warp[(size_t)e * HW + p]; vc = emb_cur[(size_t)e * HW + p]; }
+        tw[r][x] = vw;
+        tc[r][x] = vc;
+      }
+      __syncthreads();
+#pragma unroll
+      for (int i = 0; i < kCosPxPerWave; ++i) {
+        const int x = wid * kCosPxPerWave + i;
+        const float vw = tw[lane][x], vc = tc[lane][x];
+        if (pass == 0) {
+          acc_a[i] += vw * vw;
+          acc_b[i] += vc * vc;
+        } else {
+          const float uw = vw / nw[i], uc = vc / nc[i];
+          acc_a[i] += uw * uc;
+          acc_b[i] += uc * uc;
+        }
+      }
+      __syncthreads();
+    }
+#pragma unroll
+    for (int i = 0; i < kCosPxPerWave; ++i) {
+      const float ta = wave_tree_total(acc_a[i]), tb = wave_tree_total(acc_b[i]);
+      if (pass == 0) { nw[i] = sqrtf(ta + 1e-10f); nc[i] = sqrtf(tb + 1e-10f); }
+      else { l0[i] = ta; l1[i] = tb; }
+    }
   }
-  logits[p] = l0;
-  logits[HW + p] = l1;
+  if (lane < kCosPxPerWave) {
+    float v0 = 0.f, v1 = 0.f;
+#pragma unroll
+    for (int i = 0; i < kCosPxPerWave; ++i) if (lane == i) { v0 = l0[i]; v1 = l1[i]; }
+    const int p = p0 + wid * kCosPxPerWave + lane;
+    if (p < HW) { logits[p] = v0; logits[HW + p] = v1; }
+  }
 }
 
 // last two channels of the cosine variant (their planes held the logits scratch)
@@ -167,7 +224,7 @@ extern "C" int lsfa_aggregate_cosine(const float* a, const float* b, const float
   const int HW = H * W;
   ProfScope prof(LSFA_OP_AGG, s);
   float* scratch = out + (size_t)(C - 2) * HW;
-  hipLaunchKernelGGL(cosine_logits_kernel, dim3(ceil_div(HW, kThreads)), dim3(kThreads), 0, s, emb_warp, emb_cur, E, HW, scratch);
+  hipLaunchKernelGGL(cosine_logits_kernel, dim3(ceil_div(HW, kCosPx)), dim3(kThreads), 0, s, emb_warp, emb_cur, E, HW, scratch);
   launch_combine(a, b, scratch, C - 2, HW, out, s);
   hipLaunchKernelGGL(cosine_tail_kernel, dim3(ceil_div(HW, kThreads)), dim3(kThreads), 0, s, a, b, C, HW, out);
   LSFA_LAUNCH_CHECK("lsfa_aggregate_cosine");

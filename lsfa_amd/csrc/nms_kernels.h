@@ -1,101 +1,277 @@
-// Device kernels of nms.hip (lsfa_nms_sorted, _nms).
+// Device kernels shared by nms.hip (lsfa_nms_sorted, _nms) and proposal.hip.
 //
-// Structure on CDNA4 (replaces nms_kernel + D2H of the 4.5 MB mask + serial host sweep +
-// H2D of the keep list, lib/nms/nms_kernel.cu:40-150, multi_proposal.cu:262-357):
-//   1. nms_mask_kernel — 64x64 IoU tiles, one 64-lane wave per tile, upper triangle only
-//      (the sweep never reads words left of the diagonal); bit k of word (i, cb) is set
-//      iff IoU(box_i, box_{64cb+k}) > thresh and 64cb+k > i, as in the reference.
-//   2. nms_sweep_kernel — ONE wave walks the 64-box blocks in score order.  Per block it
-//      loads the 64 diagonal words (one per lane), resolves the block with a 64-step
-//      scalar loop on SGPRs (v_readlane of the diagonal word of each survivor), then ORs
-//      the survivors' mask rows into the removed-set kept in LDS, loads batched 8 rows
-//      at a time so their latencies overlap.  It stops as soon as `max_keep` survivors exist.
-// (Proposal does not use these: it keeps everything in one workgroup's LDS, proposal.hip.)
+// Greedy NMS over score-sorted boxes, wave64-native (replaces nms_kernel + D2H of the 4.5 MB mask +
+// serial host sweep + H2D of the keep list, lib/nms/nms_kernel.cu:40-150, multi_proposal.cu:262-357):
+//
+//   1. nms_mask_kernel — one 64-lane WAVE per 64x64 tile of the upper triangle (4 tiles per 256-thread
+//      workgroup, tiles enumerated linearly so no workgroup is launched for the lower triangle).  A
+//      lane owns one ROW box in registers; the 64 COLUMN boxes sit one per lane and are broadcast with
+//      v_readlane (no LDS tile, no barrier).  Bit k of word (i, cb) is set iff IoU(box_i, box_{64cb+k})
+//      > thresh and 64cb+k > i, as in the reference.  On diagonal tiles the same predicate, balloted
+//      across the wave, is the TRANSPOSED word (the rows that suppress column k): it is written to
+//      diagT so the sweep can resolve a block without a 64-step serial loop.
+//      IoU > thresh is decided WITHOUT the division, bit for bit (IouTest below).
+//   2. nms_sweep_kernel — ONE wave walks the 64-box blocks in score order.  A block is resolved as a
+//      fixpoint on ballots (G(k) = alive(k) && no earlier member of G suppresses k: a handful of
+//      iterations, not 64 scalar steps); the survivors' mask rows are ORed into the removed-set in
+//      LDS, 8 rows per batch of loads; it stops at `max_keep` survivors.  With `rois` set it also
+//      writes the Proposal output (first post_n survivors, cyclic pad, multi_proposal.cu:363-388).
 // devIoU arithmetic = oracle dev_iou (nms_kernel.cu:30-38), -ffp-contract=off.
 #pragma once
+#include <math.h>
+
 #include "common.h"
 
 namespace lsfa {
 
-__device__ __forceinline__ float dev_iou(const float* a, const float* b) {
-  const float left = fmaxf(a[0], b[0]), right = fminf(a[2], b[2]);
-  const float top = fmaxf(a[1], b[1]), bottom = fminf(a[3], b[3]);
-  const float width = fmaxf(right - left + 1, 0.f), height = fmaxf(bottom - top + 1, 0.f);
-  const float interS = width * height;
-  const float Sa = (a[2] - a[0] + 1) * (a[3] - a[1] + 1);
-  const float Sb = (b[2] - b[0] + 1) * (b[3] - b[1] + 1);
-  return interS / (Sa + Sb - interS);
+// fl32(inter / uni) > thresh, decided exactly without dividing.  With uni > 0 and 0 < thresh:
+//   v = inter - thresh*uni (exact) and d = fmaf(-thresh, uni, inter) = fl(v) have the same sign;
+//   v <= 0            =>  inter/uni <= thresh           => the rounded quotient is <= thresh (rounding is monotone)
+//   v >= thresh*uni*u =>  inter/uni >= thresh*(1 + u)   => >= the float after thresh (u = 2^-23), so the quotient is > thresh
+// and d >= thresh*uni*2^-22 implies the second case.  The sliver in between (and non-positive or NaN
+// unions, and thresholds outside (1e-30, 1e30)) takes the division.  Callers test `unsure` wave-wide.
+struct IouTest {
+  float thresh;
+  float thresh_eps;   // thresh * 2^-22
+  int fast;
+};
+
+static inline IouTest make_iou_test(float thresh) {
+  IouTest t;
+  t.thresh = thresh;
+  t.thresh_eps = thresh * 2.384185791015625e-07f;
+  t.fast = (thresh > 1e-30f && thresh < 1e30f) ? 1 : 0;
+  return t;
 }
 
-// grid (col_blocks, col_blocks, images); block 64.  boxes: (images, n, box_dim).
-// mask: (images, n, col_blocks) uint64.
-static __global__ __launch_bounds__(64) void nms_mask_kernel(const float* __restrict__ boxes_all, int n, int box_dim,
-                                                      float thresh, uint64_t* __restrict__ mask_all,
-                                                      int col_blocks) {
-  const int row_start = blockIdx.y, col_start = blockIdx.x;
-  if (col_start < row_start) return;
-  const float* boxes = boxes_all + (size_t)blockIdx.z * n * box_dim;
-  uint64_t* mask = mask_all + (size_t)blockIdx.z * n * col_blocks;
-  const int row_size = min(n - row_start * 64, 64);
-  const int col_size = min(n - col_start * 64, 64);
-  __shared__ float block_boxes[64 * 4];
-  const int t = threadIdx.x;
-  if (t < col_size) {
-    const float* src = boxes + (size_t)(64 * col_start + t) * box_dim;
-    block_boxes[t * 4 + 0] = src[0];
-    block_boxes[t * 4 + 1] = src[1];
-    block_boxes[t * 4 + 2] = src[2];
-    block_boxes[t * 4 + 3] = src[3];
+__device__ __forceinline__ float box_area(const float4& b) { return (b.z - b.x + 1) * (b.w - b.y + 1); }
+
+__device__ __forceinline__ bool iou_exceeds_fast(const float4& a, float Sa, const float4& b, float Sb, const IouTest& t,
+                                                 bool& unsure) {
+  const float left = fmaxf(a.x, b.x), right = fminf(a.z, b.z);
+  const float top = fmaxf(a.y, b.y), bottom = fminf(a.w, b.w);
+  const float width = fmaxf(right - left + 1, 0.f), height = fmaxf(bottom - top + 1, 0.f);
+  const float interS = width * height;
+  const float uni = Sa + Sb - interS;
+  const float d = fmaf(-t.thresh, uni, interS);
+  const bool pos = d > 0.f, clear = d >= t.thresh_eps * uni;
+  unsure = unsure || !(uni > 0.f) || (pos && !clear);
+  return pos && clear;
+}
+__device__ __forceinline__ bool iou_exceeds_div(const float4& a, float Sa, const float4& b, float Sb, const IouTest& t) {
+  const float left = fmaxf(a.x, b.x), right = fminf(a.z, b.z);
+  const float top = fmaxf(a.y, b.y), bottom = fminf(a.w, b.w);
+  const float width = fmaxf(right - left + 1, 0.f), height = fmaxf(bottom - top + 1, 0.f);
+  const float interS = width * height;
+  return interS / (Sa + Sb - interS) > t.thresh;
+}
+
+__device__ __forceinline__ float4 bcast4(const float4& v, int src_lane) {
+  return make_float4(__uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(v.x), src_lane)),
+                     __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(v.y), src_lane)),
+                     __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(v.z), src_lane)),
+                     __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(v.w), src_lane)));
+}
+__device__ __forceinline__ float bcast1(float v, int src_lane) {
+  return __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(v), src_lane));
+}
+
+// number of upper-triangle tiles (diagonal included) of a col_blocks x col_blocks tile grid
+__host__ __device__ static inline int nms_tile_count(int col_blocks) { return col_blocks * (col_blocks + 1) / 2; }
+
+// grid (ceil(tiles / 4), 1, images); block 256 = 4 waves = 4 tiles.
+// boxes: (images, n_total, box_dim) floats; `order` (images, n) int32 or NULL: row p of the sorted list is
+// boxes[order[p]] (Proposal: candidates stay where the decode kernel put them).  mask: (images, n, col_blocks);
+// diagT: (images, n).
+static __global__ __launch_bounds__(256) void nms_mask_kernel(const float* __restrict__ boxes_all, long boxes_img_stride,
+                                                              int box_dim, const int* __restrict__ order_all, int n,
+                                                              IouTest t, uint64_t* __restrict__ mask_all,
+                                                              uint64_t* __restrict__ diagT_all, int col_blocks) {
+  const int lane = threadIdx.x & 63;
+  const int tile = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (tile >= nms_tile_count(col_blocks)) return;
+  // tile -> (rb <= cb), tiles enumerated column by column: tile = cb*(cb+1)/2 + rb
+  int cb = (int)((sqrtf(8.0f * (float)tile + 1.0f) - 1.0f) * 0.5f);
+  while ((cb + 1) * (cb + 2) / 2 <= tile) ++cb;
+  while (cb * (cb + 1) / 2 > tile) --cb;
+  const int rb = tile - cb * (cb + 1) / 2;
+  const int img = blockIdx.z;
+  const float* boxes = boxes_all + (size_t)img * boxes_img_stride;
+  const int* order = order_all ? order_all + (size_t)img * n : nullptr;
+  uint64_t* mask = mask_all + (size_t)img * n * col_blocks;
+
+  const int row = rb * 64 + lane, col = cb * 64 + lane;
+  const bool row_ok = row < n, col_ok = col < n;
+  float4 a = make_float4(0.f, 0.f, 0.f, 0.f), c = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (row_ok) {
+    const float* p = boxes + (size_t)(order ? order[row] : row) * box_dim;
+    a = make_float4(p[0], p[1], p[2], p[3]);
   }
-  __syncthreads();
-  if (t < row_size) {
-    const int cur = 64 * row_start + t;
-    const float* src = boxes + (size_t)cur * box_dim;
-    const float cur_box[4] = {src[0], src[1], src[2], src[3]};
-    uint64_t bits = 0;
-    const int start = (row_start == col_start) ? t + 1 : 0;
-    for (int i = start; i < col_size; ++i) {
-      if (dev_iou(cur_box, block_boxes + i * 4) > thresh) bits |= 1ULL << i;
+  if (col_ok) {
+    const float* p = boxes + (size_t)(order ? order[col] : col) * box_dim;
+    c = make_float4(p[0], p[1], p[2], p[3]);
+  }
+  const float Sa = box_area(a), Sc = box_area(c);
+  const int ncol = min(64, n - cb * 64);
+  const bool diag = rb == cb;
+  // one 32-column half at a time so that the bit position is a compile-time constant after unrolling
+  uint32_t word[2] = {0, 0}, tword[2] = {0, 0};
+  bool unsure = !t.fast;
+#pragma unroll
+  for (int half = 0; half < 2; ++half) {
+    uint32_t w = 0;
+#pragma unroll 8
+    for (int jj = 0; jj < 32; ++jj) {
+      const int j = half * 32 + jj;
+      const float4 b = bcast4(c, j);
+      const float Sb = bcast1(Sc, j);
+      bool p = iou_exceeds_fast(a, Sa, b, Sb, t, unsure);
+      p = p && row_ok && j < ncol && (!diag || j > lane);
+      w |= (uint32_t)p << jj;
+      if (diag) {
+        const unsigned long long colword = __ballot(p);
+        if (lane == j) { tword[0] = (uint32_t)colword; tword[1] = (uint32_t)(colword >> 32); }
+      }
     }
-    mask[(size_t)cur * col_blocks + col_start] = bits;
+    word[half] = w;
   }
+  if (__builtin_expect(__any(unsure), 0)) {   // wave-uniform and rare: redo the tile with the real division
+    tword[0] = tword[1] = 0;
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+      uint32_t w = 0;
+      for (int jj = 0; jj < 32; ++jj) {
+        const int j = half * 32 + jj;
+        const float4 b = bcast4(c, j);
+        const float Sb = bcast1(Sc, j);
+        bool p = iou_exceeds_div(a, Sa, b, Sb, t);
+        p = p && row_ok && j < ncol && (!diag || j > lane);
+        w |= (uint32_t)p << jj;
+        if (diag) {
+          const unsigned long long colword = __ballot(p);
+          if (lane == j) { tword[0] = (uint32_t)colword; tword[1] = (uint32_t)(colword >> 32); }
+        }
+      }
+      word[half] = w;
+    }
+  }
+  const uint32_t lo = word[0], hi = word[1], tlo = tword[0], thi = tword[1];
+  if (row_ok) mask[(size_t)row * col_blocks + cb] = ((uint64_t)hi << 32) | lo;
+  if (diag && row_ok) diagT_all[(size_t)img * n + row] = ((uint64_t)thi << 32) | tlo;
+}
+
+// ---- float64 boxes: lib/nms/nms.py:37-74 run on float64 dets (pred_eval's py_nms_wrapper) --------
+// Same tiling as nms_mask_kernel; the column boxes are read at wave-uniform addresses (scalar loads).
+// numpy keeps `ovr <= thresh`, so a pair suppresses when NOT (ovr <= thresh); the division-free test is
+// IouTest's argument with doubles (u = 2^-52), the sliver and non-positive / NaN unions take the division.
+struct IouTest64 { double thresh, thresh_eps; int fast; };
+static inline IouTest64 make_iou_test64(double thresh) {
+  IouTest64 t;
+  t.thresh = thresh;
+  t.thresh_eps = thresh * 4.440892098500626e-16;   // 2^-51
+  t.fast = (thresh > 1e-300 && thresh < 1e300) ? 1 : 0;
+  return t;
+}
+
+static __global__ __launch_bounds__(256) void nms_mask_f64_kernel(const double* __restrict__ boxes, int box_dim, int n,
+                                                                  IouTest64 t, uint64_t* __restrict__ mask,
+                                                                  uint64_t* __restrict__ diagT, int col_blocks) {
+  const int lane = threadIdx.x & 63;
+  const int tile = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (tile >= nms_tile_count(col_blocks)) return;
+  int cb = (int)((sqrtf(8.0f * (float)tile + 1.0f) - 1.0f) * 0.5f);
+  while ((cb + 1) * (cb + 2) / 2 <= tile) ++cb;
+  while (cb * (cb + 1) / 2 > tile) --cb;
+  const int rb = tile - cb * (cb + 1) / 2;
+  const int row = rb * 64 + lane;
+  const bool row_ok = row < n;
+  double ax1 = 0, ay1 = 0, ax2 = 0, ay2 = 0;
+  if (row_ok) {
+    const double* p = boxes + (size_t)row * box_dim;
+    ax1 = p[0]; ay1 = p[1]; ax2 = p[2]; ay2 = p[3];
+  }
+  const double Sa = (ax2 - ax1 + 1) * (ay2 - ay1 + 1);
+  const int ncol = min(64, n - cb * 64);
+  const bool diag = rb == cb;
+  uint64_t bits = 0, tbits = 0;
+  for (int j = 0; j < ncol; ++j) {
+    const double* q = boxes + (size_t)(cb * 64 + j) * box_dim;     // wave-uniform
+    const double bx1 = q[0], by1 = q[1], bx2 = q[2], by2 = q[3];
+    const double Sb = (bx2 - bx1 + 1) * (by2 - by1 + 1);
+    const double w = fmax(0.0, fmin(ax2, bx2) - fmax(ax1, bx1) + 1), h = fmax(0.0, fmin(ay2, by2) - fmax(ay1, by1) + 1);
+    const double inter = w * h;
+    const double uni = Sa + Sb - inter;
+    const double d = fma(-t.thresh, uni, inter);
+    const bool pos = d > 0.0, clear = d >= t.thresh_eps * uni;
+    bool p = pos && clear;
+    const bool unsure = !t.fast || !(uni > 0.0) || (pos && !clear);
+    if (__builtin_expect(__any(unsure), 0)) {
+      if (unsure) p = !(inter / uni <= t.thresh);
+    }
+    p = p && row_ok && (!diag || j > lane);
+    bits |= (uint64_t)p << j;
+    if (diag) {
+      const unsigned long long colword = __ballot(p);
+      if (lane == j) tbits = colword;
+    }
+  }
+  if (row_ok) mask[(size_t)row * col_blocks + cb] = bits;
+  if (diag && row_ok) diagT[row] = tbits;
 }
 
 constexpr int kSweepMaxBlocks = 512;   // n <= 32768
+constexpr int kSweepMaxOut = 1024;     // Proposal output rows kept in LDS
 
-// grid (images); block 64 (one wave).  keep: (images, n) indices into boxes; num_keep: (images).
-__global__ __launch_bounds__(64) void nms_sweep_kernel(const uint64_t* __restrict__ mask_all, int n, int col_blocks,
+// grid (images); block 64 (one wave).  keep: (images, n) positions in the sorted list, or NULL; num_keep:
+// (images) or NULL.  Proposal epilogue when rois != NULL: sorted_box (images, n) float4, sorted_key (images, n)
+// order keys (for `scores`), rois (images*post_n, 5), scores (images*post_n) or NULL; max_keep = post_n.
+static __global__ __launch_bounds__(64) void nms_sweep_kernel(const uint64_t* __restrict__ mask_all,
+                                                       const uint64_t* __restrict__ diagT_all, int n, int col_blocks,
                                                        int max_keep, int* __restrict__ keep_all,
-                                                       int* __restrict__ num_keep_all) {
+                                                       int* __restrict__ num_keep_all,
+                                                       const float4* __restrict__ sorted_box_all,
+                                                       const uint32_t* __restrict__ sorted_key_all,
+                                                       float* __restrict__ rois, float* __restrict__ scores,
+                                                       const int* __restrict__ skip_flag) {
   __shared__ uint64_t remv[kSweepMaxBlocks];
+  __shared__ int kept_pos[kSweepMaxOut];
   const int img = blockIdx.x;
+  if (skip_flag && skip_flag[img]) return;     // Proposal: this image took the single-workgroup path
   const uint64_t* mask = mask_all + (size_t)img * n * col_blocks;
-  int* keep = keep_all + (size_t)img * n;
+  const uint64_t* diagT = diagT_all + (size_t)img * n;
+  int* keep = keep_all ? keep_all + (size_t)img * n : nullptr;
   const int lane = threadIdx.x;
   for (int i = lane; i < col_blocks; i += 64) remv[i] = 0;
   __syncthreads();  // single-wave workgroup: orders the LDS accesses of different lanes
   int num = 0;
+  uint64_t col_next = lane < n ? diagT[lane] : 0ULL;
   for (int b = 0; b < col_blocks && num < max_keep; ++b) {
     const int base = b * 64;
     const int nb = min(64, n - base);
-    const uint64_t diag = (lane < nb) ? mask[(size_t)(base + lane) * col_blocks + b] : 0ULL;
-    const uint64_t cur0 = remv[b];
-    uint32_t cur_lo = __builtin_amdgcn_readfirstlane((uint32_t)cur0);
-    uint32_t cur_hi = __builtin_amdgcn_readfirstlane((uint32_t)(cur0 >> 32));
-    const uint32_t diag_lo = (uint32_t)diag, diag_hi = (uint32_t)(diag >> 32);
-    uint32_t kept_lo = 0, kept_hi = 0;
-    int budget = max_keep - num;
-    for (int k = 0; k < nb && budget > 0; ++k) {
-      const bool removed = k < 32 ? ((cur_lo >> k) & 1u) : ((cur_hi >> (k - 32)) & 1u);
-      if (!removed) {
-        if (k < 32) kept_lo |= 1u << k; else kept_hi |= 1u << (k - 32);
-        cur_lo |= __builtin_amdgcn_readlane(diag_lo, k);
-        cur_hi |= __builtin_amdgcn_readlane(diag_hi, k);
-        --budget;
-      }
+    const uint64_t colw = col_next;
+    const int nxt = base + 64 + lane;
+    col_next = nxt < n ? diagT[nxt] : 0ULL;     // next block's transposed diagonal: independent of the sweep state
+    const uint64_t cur = remv[b];
+    const bool alive = lane < nb && !((cur >> lane) & 1ULL);
+    uint64_t G = __ballot(alive);
+    if (G == 0) continue;
+    for (int it = 0; it < 64; ++it) {
+      const uint64_t G2 = __ballot(alive && (colw & G) == 0);
+      if (G2 == G) break;
+      G = G2;
     }
-    const uint64_t kept = ((uint64_t)kept_hi << 32) | kept_lo;
-    if ((kept >> lane) & 1ULL) keep[num + __popcll(kept & ((1ULL << lane) - 1ULL))] = base + lane;
+    uint64_t kept = G;
+    const int budget = max_keep - num;
+    if (__popcll(G) > budget) {
+      const bool mine = (G >> lane) & 1ULL;
+      const int rank = __popcll(G & ((1ULL << lane) - 1ULL));
+      kept = __ballot(mine && rank < budget);
+    }
+    if ((kept >> lane) & 1ULL) {
+      const int pos = num + __popcll(kept & ((1ULL << lane) - 1ULL));
+      if (keep) keep[pos] = base + lane;
+      if (pos < kSweepMaxOut) kept_pos[pos] = base + lane;
+    }
     num += __popcll(kept);
     if (num >= max_keep || b + 1 >= col_blocks) break;
     // OR the survivors' rows into remv for the blocks to the right of b, 8 rows per batch of loads
@@ -120,7 +296,24 @@ __global__ __launch_bounds__(64) void nms_sweep_kernel(const uint64_t* __restric
     }
     __syncthreads();
   }
-  if (lane == 0) num_keep_all[img] = num;
+  if (num_keep_all && lane == 0) num_keep_all[img] = num;
+  if (rois) {
+    __syncthreads();
+    const float4* sbox = sorted_box_all + (size_t)img * n;
+    const uint32_t* skey = sorted_key_all + (size_t)img * n;
+    for (int index = lane; index < max_keep; index += 64) {
+      const int p = kept_pos[index < num ? index : index % num];
+      const float4 bx = sbox[p];
+      float* o = rois + ((size_t)img * max_keep + index) * 5;
+      o[0] = (float)img;
+      o[1] = bx.x; o[2] = bx.y; o[3] = bx.z; o[4] = bx.w;
+      if (scores) {
+        const uint32_t asc = ~skey[p];
+        const uint32_t u = (asc & 0x80000000u) ? (asc & 0x7fffffffu) : ~asc;
+        scores[(size_t)img * max_keep + index] = __uint_as_float(u);
+      }
+    }
+  }
 }
 
 }  // namespace lsfa

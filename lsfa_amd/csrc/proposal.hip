@@ -1,20 +1,30 @@
-// RPN proposal generation, fully device resident (no malloc/free, no D2H, no host sweep):
-//   proposal_decode_kernel  anchors + decode + clip + filter (ProposalGrid/BBoxPred/FilterBox,
-//                           multi_proposal.cu:47-216) -> float4 boxes + 32-bit order keys
-//   proposal_select_nms_kernel   ONE workgroup (16 waves) per image, everything in its CU's LDS:
-//       radix-select the pre_nms_top_n best (score desc, anchor index asc ==
-//       thrust::stable_sort_by_key(greater), :517-521) with the 21,546 keys held in LDS (86 KB),
-//       bitonic-sort just those 6,000 (8 keys per thread in registers, lane shuffles below stride
-//       512, LDS only above), then greedy NMS with IoUs computed on the fly against the survivors
-//       (no 4.5 MB mask, no second kernel, stops at post_nms_top_n survivors) and PrepareOutput
-//       (:363-388).
-// Selecting before sorting cuts the sort from 21,546 to 6,000 keys; the NMS only ever evaluates
-// (candidates visited) x (survivors so far) IoUs instead of the full 6000^2/2 mask.
+// RPN proposal generation, fully device resident (no malloc/free, no D2H, no host sweep; the
+// reference does 4 cudaMalloc/cudaFree, a thrust sort, a 4.5 MB D2H and a serial host loop per call,
+// multi_proposal.cu:454-557).  Two launch plans, same results bit for bit:
+//
+// CHIP-WIDE plan (count <= 32768 anchors, pre_nms_top_n <= 8192: the LSFA shapes), 6 short kernels:
+//   proposal_decode_kernel   anchors + decode + clip + filter (ProposalGrid/BBoxPred/FilterBox,
+//                            multi_proposal.cu:47-216) -> float4 boxes + 32-bit order keys, and per
+//                            workgroup a 4096-bin histogram of the keys (128 bins per octave of score)
+//   proposal_compact_kernel  every workgroup sums the partial histograms, finds the bin the
+//                            pre_nms_top_n-th best key falls in, and compacts ITS keys at or above that
+//                            bin into the candidate list (positions from the partial histograms: no
+//                            atomics, no counters to zero).  M candidates, M - pre_n of them surplus.
+//   proposal_rank_kernel     rank of every candidate among the candidates by (key, anchor index) ==
+//                            thrust::stable_sort_by_key(greater), :517-521: M^2 64-bit compares spread
+//                            over (M/256) x 16 workgroups, partial counts per slice
+//   proposal_scatter_kernel  rank < pre_n -> sorted boxes / keys (the exact top pre_n, in order)
+//   nms_mask_kernel + nms_sweep_kernel (nms_kernels.h)  64x64 IoU tiles of the upper triangle over the
+//                            chip, then one wave sweeps, stops at post_n survivors and writes the
+//                            output with the cyclic pad (PrepareOutput, :363-388)
+// SINGLE-WORKGROUP plan (anything larger): proposal_select_nms_kernel, one 16-wave workgroup per
+//   image with everything in its CU's LDS: radix select, stable LSD radix (or bitonic) sort, greedy
+//   NMS with IoUs on the fly against the survivor list.
 // Arithmetic = oracle orc_proposal_decode, operation for operation.
 #include <math.h>
 #include <string.h>
 
-#include "common.h"
+#include "nms_kernels.h"
 
 using namespace lsfa;
 
@@ -61,59 +71,89 @@ __device__ __forceinline__ float key_score(uint32_t key) {
   return __uint_as_float(u);
 }
 
+constexpr int kDecodeThreads = 1024;
+constexpr int kBins = 4096;
+
+// 12-bit monotone image of an order key: 128 bins per octave of score over [2^-32, 1) (7 mantissa
+// bits); everything below (negative scores, the -1 marks) lands in bin 0, everything above in 4095.
+// Monotone in the key, so "key order" never contradicts "bin order"; ties inside a bin are resolved
+// exactly by the rank kernel.
+__device__ __forceinline__ int key_bin(uint32_t key) {
+  const uint32_t asc = ~key;
+  if (!(asc & 0x80000000u)) return 0;                     // negative float
+  const int e7 = (int)((asc & 0x7fffffffu) >> 16);        // exponent + 7 mantissa bits of a positive float
+  const int b = e7 - ((127 - 32) << 7);
+  return b < 0 ? 0 : (b > kBins - 1 ? kBins - 1 : b);
+}
+
 // thread t -> (a, h, w) with w fastest so the five NCHW planes are read coalesced;
 // output position follows the reference's enumeration index = (h*W + w)*A + a.
-__global__ __launch_bounds__(256) void proposal_decode_kernel(
+// hist_part (images, gridDim.x, kBins) or NULL: histogram of key_bin over THIS workgroup's anchors,
+// every bin written (the workspace is not assumed to be zeroed).
+__global__ __launch_bounds__(kDecodeThreads) void proposal_decode_kernel(
     const float* __restrict__ cls_prob, const float* __restrict__ bbox_pred, const float* __restrict__ im_info,
     int A, int H, int W, int feature_stride, int rpn_min_size, Anchors anchors, float4* __restrict__ boxes_all,
-    uint32_t* __restrict__ keys_all) {
+    uint32_t* __restrict__ keys_all, uint32_t* __restrict__ hist_part) {
+  __shared__ uint32_t hist[kBins];
   const int b = blockIdx.y;
   const int HW = H * W;
-  const int t = blockIdx.x * 256 + threadIdx.x;
-  if (t >= A * HW) return;
-  const int a = t / HW, p = t - a * HW;
-  const int h = p / W, w = p - h * W;
-  const float im_height = im_info[b * 3], im_width = im_info[b * 3 + 1];
-  const int real_height = (int)(im_height / feature_stride);
-  const int real_width = (int)(im_width / feature_stride);
-  const float min_size = (float)rpn_min_size * im_info[b * 3 + 2];
-  const float x1 = anchors.v[a * 4 + 0] + (float)(w * feature_stride);
-  const float y1 = anchors.v[a * 4 + 1] + (float)(h * feature_stride);
-  const float x2 = anchors.v[a * 4 + 2] + (float)(w * feature_stride);
-  const float y2 = anchors.v[a * 4 + 3] + (float)(h * feature_stride);
-  float score = cls_prob[((size_t)b * (2 * A) + a + A) * HW + p];
-  const float width = x2 - x1 + 1.0f;
-  const float height = y2 - y1 + 1.0f;
-  const float ctr_x = fmaf(0.5f, width - 1.0f, x1);
-  const float ctr_y = fmaf(0.5f, height - 1.0f, y1);
-  const size_t ba = (size_t)b * A + a;
-  const float dx = bbox_pred[(ba * 4 + 0) * HW + p];
-  const float dy = bbox_pred[(ba * 4 + 1) * HW + p];
-  const float dw = bbox_pred[(ba * 4 + 2) * HW + p];
-  const float dh = bbox_pred[(ba * 4 + 3) * HW + p];
-  const float pred_ctr_x = fmaf(dx, width, ctr_x);
-  const float pred_ctr_y = fmaf(dy, height, ctr_y);
-  const float pred_w = expf_cr(dw) * width;
-  const float pred_h = expf_cr(dh) * height;
-  float pred_x1 = fmaf(-0.5f, pred_w - 1.0f, pred_ctr_x);
-  float pred_y1 = fmaf(-0.5f, pred_h - 1.0f, pred_ctr_y);
-  float pred_x2 = fmaf(0.5f, pred_w - 1.0f, pred_ctr_x);
-  float pred_y2 = fmaf(0.5f, pred_h - 1.0f, pred_ctr_y);
-  pred_x1 = fmaxf(fminf(pred_x1, im_width - 1.0f), 0.0f);
-  pred_y1 = fmaxf(fminf(pred_y1, im_height - 1.0f), 0.0f);
-  pred_x2 = fmaxf(fminf(pred_x2, im_width - 1.0f), 0.0f);
-  pred_y2 = fmaxf(fminf(pred_y2, im_height - 1.0f), 0.0f);
-  if (h >= real_height || w >= real_width) score = -1.0f;
-  const float iw = pred_x2 - pred_x1 + 1.0f;
-  const float ih = pred_y2 - pred_y1 + 1.0f;
-  if (iw < min_size || ih < min_size) {
-    pred_x1 -= min_size / 2; pred_y1 -= min_size / 2;
-    pred_x2 += min_size / 2; pred_y2 += min_size / 2;
-    score = -1.0f;
+  const int t = blockIdx.x * kDecodeThreads + threadIdx.x;
+  if (hist_part) {
+    for (int i = threadIdx.x; i < kBins; i += kDecodeThreads) hist[i] = 0;
+    __syncthreads();
   }
-  const size_t index = (size_t)b * A * HW + (size_t)p * A + a;
-  boxes_all[index] = make_float4(pred_x1, pred_y1, pred_x2, pred_y2);
-  keys_all[index] = desc_key(score);
+  if (t < A * HW) {
+    const int a = t / HW, p = t - a * HW;
+    const int h = p / W, w = p - h * W;
+    const float im_height = im_info[b * 3], im_width = im_info[b * 3 + 1];
+    const int real_height = (int)(im_height / feature_stride);
+    const int real_width = (int)(im_width / feature_stride);
+    const float min_size = (float)rpn_min_size * im_info[b * 3 + 2];
+    const float x1 = anchors.v[a * 4 + 0] + (float)(w * feature_stride);
+    const float y1 = anchors.v[a * 4 + 1] + (float)(h * feature_stride);
+    const float x2 = anchors.v[a * 4 + 2] + (float)(w * feature_stride);
+    const float y2 = anchors.v[a * 4 + 3] + (float)(h * feature_stride);
+    float score = cls_prob[((size_t)b * (2 * A) + a + A) * HW + p];
+    const float width = x2 - x1 + 1.0f;
+    const float height = y2 - y1 + 1.0f;
+    const float ctr_x = fmaf(0.5f, width - 1.0f, x1);
+    const float ctr_y = fmaf(0.5f, height - 1.0f, y1);
+    const size_t ba = (size_t)b * A + a;
+    const float dx = bbox_pred[(ba * 4 + 0) * HW + p];
+    const float dy = bbox_pred[(ba * 4 + 1) * HW + p];
+    const float dw = bbox_pred[(ba * 4 + 2) * HW + p];
+    const float dh = bbox_pred[(ba * 4 + 3) * HW + p];
+    const float pred_ctr_x = fmaf(dx, width, ctr_x);
+    const float pred_ctr_y = fmaf(dy, height, ctr_y);
+    const float pred_w = expf_cr(dw) * width;
+    const float pred_h = expf_cr(dh) * height;
+    float pred_x1 = fmaf(-0.5f, pred_w - 1.0f, pred_ctr_x);
+    float pred_y1 = fmaf(-0.5f, pred_h - 1.0f, pred_ctr_y);
+    float pred_x2 = fmaf(0.5f, pred_w - 1.0f, pred_ctr_x);
+    float pred_y2 = fmaf(0.5f, pred_h - 1.0f, pred_ctr_y);
+    pred_x1 = fmaxf(fminf(pred_x1, im_width - 1.0f), 0.0f);
+    pred_y1 = fmaxf(fminf(pred_y1, im_height - 1.0f), 0.0f);
+    pred_x2 = fmaxf(fminf(pred_x2, im_width - 1.0f), 0.0f);
+    pred_y2 = fmaxf(fminf(pred_y2, im_height - 1.0f), 0.0f);
+    if (h >= real_height || w >= real_width) score = -1.0f;
+    const float iw = pred_x2 - pred_x1 + 1.0f;
+    const float ih = pred_y2 - pred_y1 + 1.0f;
+    if (iw < min_size || ih < min_size) {
+      pred_x1 -= min_size / 2; pred_y1 -= min_size / 2;
+      pred_x2 += min_size / 2; pred_y2 += min_size / 2;
+      score = -1.0f;
+    }
+    const size_t index = (size_t)b * A * HW + (size_t)p * A + a;
+    boxes_all[index] = make_float4(pred_x1, pred_y1, pred_x2, pred_y2);
+    const uint32_t key = desc_key(score);
+    keys_all[index] = key;
+    if (hist_part) atomicAdd(&hist[key_bin(key)], 1u);
+  }
+  if (hist_part) {
+    __syncthreads();
+    uint32_t* dst = hist_part + ((size_t)b * gridDim.x + blockIdx.x) * kBins;
+    for (int i = threadIdx.x; i < kBins; i += kDecodeThreads) dst[i] = hist[i];
+  }
 }
 
 // block-wide exclusive scan of one int per thread (1024 threads = 16 waves)
@@ -136,6 +176,110 @@ __device__ __forceinline__ int block_exclusive_scan(int v, int* wave_sums /*LDS,
   __syncthreads();
   *total = tot;
   return base + incl - v;
+}
+
+// ---- chip-wide plan: compact -> rank -> scatter ------------------------------------------------
+constexpr int kRankSlices = 16;          // j-range of the rank kernel is cut into this many slices
+constexpr int kRankThreads = 256;
+constexpr int kFastMaxCount = 32768;     // anchors per image the chip-wide plan accepts
+constexpr int kRankSliceMax = kFastMaxCount / kRankSlices;   // entries of one slice staged in LDS
+
+// info (images, 4) int32: [0] = M, the number of candidates.
+// grid (G = decode's gridDim.x, images); block kDecodeThreads.  Every workgroup redoes the small
+// histogram reduction (G x 16 KB from L2) instead of a separate one-workgroup launch.
+__global__ __launch_bounds__(kDecodeThreads) void proposal_compact_kernel(
+    const uint32_t* __restrict__ keys_all, const uint32_t* __restrict__ hist_part, int A, int HW, int pre_n,
+    uint64_t* __restrict__ cand_all, int* __restrict__ info) {
+  __shared__ int wave_sums[kDecodeThreads / 64];
+  __shared__ int sh[4];
+  const int img = blockIdx.y, g = blockIdx.x, G = gridDim.x;
+  const int tid = threadIdx.x;
+  const int N = A * HW;
+  const uint32_t* parts = hist_part + (size_t)img * G * kBins;
+  // total histogram: this thread owns bins 4*tid .. 4*tid+3
+  uint32_t c[4] = {0, 0, 0, 0};
+  for (int q = 0; q < G; ++q) {
+    const uint4 v = *reinterpret_cast<const uint4*>(parts + (size_t)q * kBins + 4 * tid);
+    c[0] += v.x; c[1] += v.y; c[2] += v.z; c[3] += v.w;
+  }
+  const int mine = (int)(c[0] + c[1] + c[2] + c[3]);
+  int total;
+  const int below = block_exclusive_scan(mine, wave_sums, &total);     // keys in bins < 4*tid
+  // suffix counts, walking this thread's bins downwards: the bin where the count of keys at or above
+  // it first reaches pre_n is the threshold bin (exactly one thread finds it; total >= pre_n)
+  int acc = total - below - mine;                                      // keys in bins > 4*tid+3
+#pragma unroll
+  for (int k = 3; k >= 0; --k) {
+    const int before = acc;
+    acc += (int)c[k];
+    if (before < pre_n && acc >= pre_n) { sh[0] = 4 * tid + k; sh[1] = acc; }
+  }
+  __syncthreads();
+  const int bin_t = sh[0], M = sh[1];
+  // candidates held by the workgroups before this one (same chunking as the decode kernel's)
+  int prior = 0;
+  for (int q = 0; q < g; ++q) {
+    const uint4 v = *reinterpret_cast<const uint4*>(parts + (size_t)q * kBins + 4 * tid);
+    prior += (4 * tid + 0 >= bin_t ? (int)v.x : 0) + (4 * tid + 1 >= bin_t ? (int)v.y : 0) +
+             (4 * tid + 2 >= bin_t ? (int)v.z : 0) + (4 * tid + 3 >= bin_t ? (int)v.w : 0);
+  }
+  int offset;
+  (void)block_exclusive_scan(prior, wave_sums, &offset);
+  const int t = g * kDecodeThreads + tid;
+  bool is_cand = false;
+  uint32_t key = 0, index = 0;
+  if (t < N) {
+    const int a = t / HW, p = t - a * HW;
+    index = (uint32_t)(p * A + a);
+    key = keys_all[(size_t)img * N + index];
+    is_cand = key_bin(key) >= bin_t;
+  }
+  int n_here;
+  const int pos = block_exclusive_scan(is_cand ? 1 : 0, wave_sums, &n_here);
+  if (is_cand) cand_all[(size_t)img * N + offset + pos] = ((uint64_t)key << 32) | index;
+  if (g == 0 && tid == 0) info[img * 4] = M;
+}
+
+// grid (ceil(N / 256), kRankSlices, images); block 256.  part (images, kRankSlices, N) uint16:
+// how many candidates of slice s order before candidate i.  (key, index) pairs are distinct, so the
+// sum over slices is the candidate's exact position in the stable descending sort.
+__global__ __launch_bounds__(kRankThreads) void proposal_rank_kernel(const uint64_t* __restrict__ cand_all,
+                                                                     const int* __restrict__ info, int N,
+                                                                     uint16_t* __restrict__ part) {
+  __shared__ uint64_t slice[kRankSliceMax];
+  const int img = blockIdx.z, s = blockIdx.y;
+  const int M = info[img * 4];
+  const int i0 = blockIdx.x * kRankThreads;
+  if (i0 >= M) return;
+  const uint64_t* cand = cand_all + (size_t)img * N;
+  const int len = (M + kRankSlices - 1) / kRankSlices;
+  const int j0 = min(s * len, M), j1 = min(j0 + len, M);
+  for (int j = j0 + threadIdx.x; j < j1; j += kRankThreads) slice[j - j0] = cand[j];
+  __syncthreads();
+  const int i = i0 + threadIdx.x;
+  const uint64_t mine = i < M ? cand[i] : 0ULL;
+  int before = 0;
+  const int n = j1 - j0;
+#pragma unroll 8
+  for (int j = 0; j < n; ++j) before += slice[j] < mine;
+  if (i < M) part[((size_t)img * kRankSlices + s) * N + i] = (uint16_t)before;
+}
+
+// grid (ceil(N / 256), images); block 256.
+__global__ __launch_bounds__(kRankThreads) void proposal_scatter_kernel(
+    const uint64_t* __restrict__ cand_all, const int* __restrict__ info, const uint16_t* __restrict__ part, int N,
+    int pre_n, const float4* __restrict__ boxes_all, float4* __restrict__ sorted_box, uint32_t* __restrict__ sorted_key) {
+  const int img = blockIdx.y;
+  const int M = info[img * 4];
+  const int i = blockIdx.x * kRankThreads + threadIdx.x;
+  if (i >= M) return;
+  int rank = 0;
+#pragma unroll
+  for (int s = 0; s < kRankSlices; ++s) rank += part[((size_t)img * kRankSlices + s) * N + i];
+  if (rank >= pre_n) return;
+  const uint64_t e = cand_all[(size_t)img * N + i];
+  sorted_box[(size_t)img * pre_n + rank] = boxes_all[(size_t)img * N + (uint32_t)e];
+  sorted_key[(size_t)img * pre_n + rank] = (uint32_t)(e >> 32);
 }
 
 // ---- bitonic sort of Kpad 64-bit keys, 8 per thread in registers ---------------------------
@@ -210,33 +354,7 @@ constexpr int kHistReplicas = 16;
 constexpr size_t kNmsCoreBytes = 1024 * 16 + 1024 * 4 + 64 * 16 + 64 * 8 + 1024 * 4;   // survivors + step scratch
 constexpr size_t kNmsStateBytes = kNmsCoreBytes + 1024 * 16 + 1024 * 4;                 // + alive candidates of a chunk
 
-// devIoU(a, b) > thresh (multi_proposal.cu:252-260, :295) without the division, bit for bit:
-// q = fl32(inter / uni) exceeds thresh  <=>  inter / uni lies above the midpoint `mid` between
-// thresh and the next float (or on it, when round-to-nearest-even rounds the tie upwards).
-// inter and uni are floats and mid has 25 significant bits, so mid * uni is exact in fp64 (full
-// rate on CDNA4) and the comparison is exact.  Degenerate unions (<= 0, NaN) take the division.
-struct IouTest { float thresh; double mid; int tie_up; int fast; };
-
-// branch-free fast form; `degenerate` is raised when the union is not positive (the exact test then
-// needs the real division: iou_exceeds_div)
-__device__ __forceinline__ bool iou_exceeds_fast(const float4& a, float Sa, const float4& b, float Sb, const IouTest& t,
-                                                 bool& degenerate) {
-  const float left = fmaxf(a.x, b.x), right = fminf(a.z, b.z);
-  const float top = fmaxf(a.y, b.y), bottom = fminf(a.w, b.w);
-  const float width = fmaxf(right - left + 1, 0.f), height = fmaxf(bottom - top + 1, 0.f);
-  const float interS = width * height;
-  const float uni = Sa + Sb - interS;
-  degenerate = degenerate || !(uni > 0.f);
-  const double lhs = (double)interS, rhs = t.mid * (double)uni;
-  return lhs > rhs || (t.tie_up && lhs == rhs);
-}
-__device__ __forceinline__ bool iou_exceeds_div(const float4& a, float Sa, const float4& b, float Sb, const IouTest& t) {
-  const float left = fmaxf(a.x, b.x), right = fminf(a.z, b.z);
-  const float top = fmaxf(a.y, b.y), bottom = fminf(a.w, b.w);
-  const float width = fmaxf(right - left + 1, 0.f), height = fmaxf(bottom - top + 1, 0.f);
-  const float interS = width * height;
-  return interS / (Sa + Sb - interS) > t.thresh;
-}
+// devIoU(a, b) > thresh (multi_proposal.cu:252-260, :295): IouTest / iou_exceeds_fast / iou_exceeds_div of nms_kernels.h
 // one pair (used where the loop is short); wave-uniform branch so the division is really skipped
 __device__ __forceinline__ bool iou_exceeds(const float4& a, float Sa, const float4& b, float Sb, const IouTest& t) {
   bool degenerate = !t.fast;
@@ -575,33 +693,45 @@ __global__ __launch_bounds__(kTopkThreads) void proposal_select_nms_kernel(
 }
 
 struct WsLayout {
-  size_t boxes, keys, total;
+  size_t boxes, keys, hist, info, cand, part, sbox, skey, mask, diagT, total;
+  int groups;      // decode workgroups per image
+  bool chip_wide;
 };
-WsLayout ws_layout(int B, int count, int pre_n) {
-  (void)pre_n;
-  WsLayout l;
-  size_t o = 0;
-  l.boxes = o; o += align_up((size_t)B * count * sizeof(float4), 256);
-  l.keys = o; o += align_up((size_t)B * count * sizeof(uint32_t), 256);
-  l.total = o;
-  return l;
-}
 int clamp_pre_n(int rpn_pre_nms_top_n, int count) {
   int pre_n = rpn_pre_nms_top_n > 0 ? rpn_pre_nms_top_n : count;  // multi_proposal.cu:435-436
   return pre_n < count ? pre_n : count;
 }
+WsLayout ws_layout(int B, int count, int pre_n, int post_n) {
+  WsLayout l;
+  size_t o = 0;
+  l.groups = ceil_div(count, kDecodeThreads);
+  l.chip_wide = count <= kFastMaxCount && pre_n <= 8192 && post_n <= kSweepMaxOut;
+  l.boxes = o; o += align_up((size_t)B * count * sizeof(float4), 256);
+  l.keys = o; o += align_up((size_t)B * count * sizeof(uint32_t), 256);
+  l.hist = l.info = l.cand = l.part = l.sbox = l.skey = l.mask = l.diagT = o;
+  if (l.chip_wide) {
+    const size_t col_blocks = (size_t)ceil_div(pre_n, 64);
+    l.hist = o; o += align_up((size_t)B * l.groups * kBins * sizeof(uint32_t), 256);
+    l.info = o; o += align_up((size_t)B * 4 * sizeof(int), 256);
+    l.cand = o; o += align_up((size_t)B * count * sizeof(uint64_t), 256);
+    l.part = o; o += align_up((size_t)B * kRankSlices * count * sizeof(uint16_t), 256);
+    l.sbox = o; o += align_up((size_t)B * pre_n * sizeof(float4), 256);
+    l.skey = o; o += align_up((size_t)B * pre_n * sizeof(uint32_t), 256);
+    l.mask = o; o += align_up((size_t)B * pre_n * col_blocks * sizeof(uint64_t), 256);
+    l.diagT = o; o += align_up((size_t)B * pre_n * sizeof(uint64_t), 256);
+  }
+  l.total = o;
+  return l;
+}
 
 }  // namespace
-
-static unsigned long long* g_stamps = nullptr;
-// Diagnostic only (not in lsfa_hip.h): device buffer of >= 8 u64 that receives the cycle counter at
-// the phase boundaries of proposal_select_nms_kernel (load, select, compact, sort, nms, output).
-extern "C" void lsfa_debug_set_proposal_stamps(void* dev_ptr) { g_stamps = (unsigned long long*)dev_ptr; }
 
 extern "C" size_t lsfa_proposal_workspace_bytes(int B, int A, int H, int W, int pre_nms_top_n) {
   if (B <= 0 || A <= 0 || H <= 0 || W <= 0) return 0;
   const int count = A * H * W;
-  return ws_layout(B, count, clamp_pre_n(pre_nms_top_n, count)).total;
+  const int pre_n = clamp_pre_n(pre_nms_top_n, count);
+  // post_nms_top_n is not an argument here: size for the chip-wide plan whenever the other limits allow it
+  return ws_layout(B, count, pre_n, 1).total;
 }
 
 extern "C" int lsfa_proposal(const float* cls_prob, const float* bbox_pred, const float* im_info, int B, int A,
@@ -624,7 +754,7 @@ extern "C" int lsfa_proposal(const float* cls_prob, const float* bbox_pred, cons
               1024);
     return LSFA_ENOTSUP;
   }
-  const WsLayout l = ws_layout(B, count, pre_n);
+  const WsLayout l = ws_layout(B, count, pre_n, post_n);
   if (ws_bytes < l.total) { set_error("lsfa_proposal: workspace %zu < %zu bytes", ws_bytes, l.total); return LSFA_EWORKSPACE; }
   hipStream_t s = (hipStream_t)stream;
   unsigned char* base = (unsigned char*)ws;
@@ -635,21 +765,37 @@ extern "C" int lsfa_proposal(const float* cls_prob, const float* bbox_pred, cons
   generate_anchors(feature_stride, ratios_host, n_ratios, scales_host, n_scales, &anchors);
 
   ProfScope prof(LSFA_OP_PROPOSAL, s);
-  hipLaunchKernelGGL(proposal_decode_kernel, dim3(ceil_div(count, 256), B), dim3(256), 0, s, cls_prob, bbox_pred,
-                     im_info, A, H, W, feature_stride, rpn_min_size, anchors, boxes, keys);
+  uint32_t* hist = l.chip_wide ? (uint32_t*)(base + l.hist) : nullptr;
+  hipLaunchKernelGGL(proposal_decode_kernel, dim3(l.groups, B), dim3(kDecodeThreads), 0, s, cls_prob, bbox_pred,
+                     im_info, A, H, W, feature_stride, rpn_min_size, anchors, boxes, keys, hist);
+  const IouTest iou = make_iou_test(threshold);
+  if (l.chip_wide) {
+    int* info = (int*)(base + l.info);
+    uint64_t* cand = (uint64_t*)(base + l.cand);
+    uint16_t* part = (uint16_t*)(base + l.part);
+    float4* sbox = (float4*)(base + l.sbox);
+    uint32_t* skey = (uint32_t*)(base + l.skey);
+    uint64_t* mask = (uint64_t*)(base + l.mask);
+    uint64_t* diagT = (uint64_t*)(base + l.diagT);
+    const int col_blocks = ceil_div(pre_n, 64);
+    const int gi = ceil_div(count, kRankThreads);
+    hipLaunchKernelGGL(proposal_compact_kernel, dim3(l.groups, B), dim3(kDecodeThreads), 0, s, (const uint32_t*)keys,
+                       (const uint32_t*)hist, A, H * W, pre_n, cand, info);
+    hipLaunchKernelGGL(proposal_rank_kernel, dim3(gi, kRankSlices, B), dim3(kRankThreads), 0, s, (const uint64_t*)cand,
+                       (const int*)info, count, part);
+    hipLaunchKernelGGL(proposal_scatter_kernel, dim3(gi, B), dim3(kRankThreads), 0, s, (const uint64_t*)cand,
+                       (const int*)info, (const uint16_t*)part, count, pre_n, (const float4*)boxes, sbox, skey);
+    hipLaunchKernelGGL(nms_mask_kernel, dim3(ceil_div(nms_tile_count(col_blocks), 4), 1, B), dim3(256), 0, s,
+                       (const float*)sbox, (long)pre_n * 4, 4, (const int*)nullptr, pre_n, iou, mask, diagT, col_blocks);
+    hipLaunchKernelGGL(nms_sweep_kernel, dim3(B), dim3(64), 0, s, (const uint64_t*)mask, (const uint64_t*)diagT, pre_n,
+                       col_blocks, post_n, (int*)nullptr, (int*)nullptr, (const float4*)sbox, (const uint32_t*)skey,
+                       rois, scores, (const int*)nullptr);
+    LSFA_LAUNCH_CHECK("lsfa_proposal");
+    return LSFA_OK;
+  }
 
   int Kpad = 16;
   while (Kpad < pre_n) Kpad <<= 1;
-  IouTest iou;
-  iou.thresh = threshold;
-  {
-    const float nxt = nextafterf(threshold, INFINITY);
-    iou.mid = ((double)threshold + (double)nxt) * 0.5;
-    uint32_t nb;
-    memcpy(&nb, &nxt, sizeof(nb));
-    iou.tie_up = (nb & 1u) == 0;
-    iou.fast = (threshold > 1e-30f && threshold < 1e30f) ? 1 : 0;
-  }
   constexpr size_t kLdsMax = 160 * 1024;
   static PerDeviceOnce lds_attr;
   lds_attr.run([] {
@@ -669,7 +815,7 @@ extern "C" int lsfa_proposal(const float* cls_prob, const float* bbox_pred, cons
 #define LSFA_LAUNCH_SELECT(KL, PER, RAD, AB, LDS, SORTB)                                                     \
   hipLaunchKernelGGL((proposal_select_nms_kernel<KL, PER, RAD, AB>), dim3(B), dim3(kTopkThreads), (LDS), s,   \
                      (const uint32_t*)keys, (const float4*)boxes, count, pre_n, Kpad, (int)(SORTB), iou, post_n, \
-                     rois, scores, g_stamps)
+                     rois, scores, (unsigned long long*)nullptr)
   // 8193..16384 candidates: 128 KB sort buffer, so the alive list keeps indices only (boxes re-read from L2)
   const size_t lds_bitonic16 = (size_t)Kpad * 8 + 256 + kNmsCoreBytes + 1024 * 4;
   if (pre_n <= 8192 && lds_radix_keys <= kLdsMax) LSFA_LAUNCH_SELECT(true, 8, true, true, lds_radix_keys, sortA);

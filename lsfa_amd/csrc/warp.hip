@@ -13,184 +13,23 @@
 //
 // Arithmetic is the oracle's, operation for operation (orc_warp_bilinear): built with
 // -ffp-contract=off so nothing fuses.
-#include "common.h"
+#include "warp_kernels.h"
+
+// second pixel of a lane takes its taps from the first pixel's load / the next lane's (warp_kernels.h);
+// decided by measurement, see DESIGN.md "Kernels: warp"
+#ifndef LSFA_WARP_SHARE
+#define LSFA_WARP_SHARE false
+#endif
 
 namespace {
-
-constexpr int kThreads = 256;
-constexpr int kResMax = 4;
-
-typedef float float2u __attribute__((ext_vector_type(2), aligned(4)));
-
-template <int VEC> struct VecT;
-template <> struct VecT<1> { using type = float; };
-template <> struct VecT<2> { using type = float2; };
-template <> struct VecT<4> { using type = float4; };
-
-template <int VEC>
-__device__ __forceinline__ void load_vec(const float* p, float (&v)[VEC]) {
-  using T = typename VecT<VEC>::type;
-  T t = *reinterpret_cast<const T*>(p);
-  const float* f = reinterpret_cast<const float*>(&t);
-#pragma unroll
-  for (int i = 0; i < VEC; ++i) v[i] = f[i];
-}
-template <int VEC>
-__device__ __forceinline__ void store_vec(float* p, const float (&v)[VEC]) {
-  using T = typename VecT<VEC>::type;
-  T t;
-  float* f = reinterpret_cast<float*>(&t);
-#pragma unroll
-  for (int i = 0; i < VEC; ++i) f[i] = v[i];
-  *reinterpret_cast<T*>(p) = t;
-}
-
-template <int VEC, bool HAS_MUL, bool HAS_ADD, bool HAS_RES>
-__global__ __launch_bounds__(kThreads) void warp_kernel(
-    const float* __restrict__ feat, int feat_n, const float* __restrict__ flow, int C, int H, int W,
-    const float* __restrict__ mul, const float* __restrict__ add, const float* __restrict__ res,
-    int res_c, const float* __restrict__ res_w, const float* __restrict__ res_b,
-    float* __restrict__ out, int ch_per_block) {
-  const int HW = H * W;
-  const int n = blockIdx.z;
-  const int c0 = blockIdx.y * ch_per_block;
-  const int p0 = (blockIdx.x * kThreads + threadIdx.x) * VEC;
-  if (p0 >= HW) return;
-
-  float fx[VEC], fy[VEC];
-  load_vec<VEC>(flow + ((size_t)n * 2 + 0) * HW + p0, fx);
-  load_vec<VEC>(flow + ((size_t)n * 2 + 1) * HW + p0, fy);
-
-  const float half_w = (float)((W - 1) / 2.0), half_h = (float)((H - 1) / 2.0);
-  int off[VEC];
-  bool v00[VEC], v01[VEC], v10[VEC], v11[VEC];
-  float wx0[VEC], wx1[VEC], wy0[VEC], wy1[VEC];
-#pragma unroll
-  for (int i = 0; i < VEC; ++i) {
-    const int p = p0 + i;
-    const int y = p / W, x = p - y * W;
-    const float gx = ((float)x + fx[i]) / half_w - 1.0f;
-    const float gy = ((float)y + fy[i]) / half_h - 1.0f;
-    const float x_real = (gx + 1.0f) * (float)(W - 1) / 2.0f;
-    const float y_real = (gy + 1.0f) * (float)(H - 1) / 2.0f;
-    const float fx0 = floorf(x_real), fy0 = floorf(y_real);
-    // clamp before the int conversion so wild flows cannot overflow; clamped values
-    // are outside the map either way
-    const int x0 = (int)fminf(fmaxf(fx0, -2.0f), (float)W);
-    const int y0 = (int)fminf(fmaxf(fy0, -2.0f), (float)H);
-    wx0[i] = 1.0f - (x_real - fx0);
-    wy0[i] = 1.0f - (y_real - fy0);
-    wx1[i] = 1.0f - wx0[i];
-    wy1[i] = 1.0f - wy0[i];
-    const bool vx0 = (x0 >= 0 && x0 <= W - 1), vx1 = (x0 + 1 >= 0 && x0 + 1 <= W - 1);
-    const bool vy0 = (y0 >= 0 && y0 <= H - 1), vy1 = (y0 + 1 >= 0 && y0 + 1 <= H - 1);
-    v00[i] = vx0 && vy0; v01[i] = vx1 && vy0; v10[i] = vx0 && vy1; v11[i] = vx1 && vy1;
-    off[i] = y0 * W + x0;
-  }
-
-  float rv[kResMax][VEC];
-  if (HAS_RES) {
-#pragma unroll
-    for (int k = 0; k < kResMax; ++k)
-      if (k < res_c) load_vec<VEC>(res + ((size_t)n * res_c + k) * HW + p0, rv[k]);
-  }
-
-  const float* fbase = feat + (feat_n == 1 ? (size_t)0 : (size_t)n * C * HW);
-  const int c1 = min(c0 + ch_per_block, C);
-  bool interior = true;
-#pragma unroll
-  for (int i = 0; i < VEC; ++i) interior = interior && v00[i] && v01[i] && v10[i] && v11[i];
-  // wave-uniform split: a wave whose pixels all sample inside the map (nearly all of them) runs
-  // the loop without any validity logic; the general loop handles map borders and escaping flows
-  if (__all(interior)) {
-#pragma unroll 4
-    for (int c = c0; c < c1; ++c) {
-      const float* plane = fbase + (size_t)c * HW;
-      const size_t o = ((size_t)n * C + c) * HW + p0;
-      float m[VEC], a[VEC], v[VEC];
-      if (HAS_MUL) load_vec<VEC>(mul + o, m);
-      if (HAS_ADD) load_vec<VEC>(add + o, a);
-#pragma unroll
-      for (int i = 0; i < VEC; ++i) {
-        const float2u t = *reinterpret_cast<const float2u*>(plane + off[i]);
-        const float2u b = *reinterpret_cast<const float2u*>(plane + off[i] + W);
-        float r = t.x * wy0[i] * wx0[i] + t.y * wy0[i] * wx1[i] + b.x * wy1[i] * wx0[i] + b.y * wy1[i] * wx1[i];
-        if (HAS_MUL) r = r * m[i];
-        if (HAS_RES) {
-          float q = res_w[(size_t)c * res_c] * rv[0][i];
-#pragma unroll
-          for (int k = 1; k < kResMax; ++k)
-            if (k < res_c) q = q + res_w[(size_t)c * res_c + k] * rv[k][i];
-          q = q + res_b[c];
-          r = r + q;
-        }
-        if (HAS_ADD) r = r + a[i];
-        v[i] = r;
-      }
-      store_vec<VEC>(out + o, v);
-    }
-    return;
-  }
-#pragma unroll 2
-  for (int c = c0; c < c1; ++c) {
-    const float* plane = fbase + (size_t)c * HW;
-    const size_t o = ((size_t)n * C + c) * HW + p0;
-    float m[VEC], a[VEC], v[VEC];
-    if (HAS_MUL) load_vec<VEC>(mul + o, m);
-    if (HAS_ADD) load_vec<VEC>(add + o, a);
-#pragma unroll
-    for (int i = 0; i < VEC; ++i) {
-      const float tl = v00[i] ? plane[off[i]] : 0.f;
-      const float tr = v01[i] ? plane[off[i] + 1] : 0.f;
-      const float bl = v10[i] ? plane[off[i] + W] : 0.f;
-      const float br = v11[i] ? plane[off[i] + W + 1] : 0.f;
-      float r = tl * wy0[i] * wx0[i] + tr * wy0[i] * wx1[i] + bl * wy1[i] * wx0[i] + br * wy1[i] * wx1[i];
-      if (HAS_MUL) r = r * m[i];
-      if (HAS_RES) {
-        float q = res_w[(size_t)c * res_c] * rv[0][i];
-#pragma unroll
-        for (int k = 1; k < kResMax; ++k)
-          if (k < res_c) q = q + res_w[(size_t)c * res_c + k] * rv[k][i];
-        q = q + res_b[c];
-        r = r + q;
-      }
-      if (HAS_ADD) r = r + a[i];
-      v[i] = r;
-    }
-    store_vec<VEC>(out + o, v);
-  }
-}
-
-template <int VEC>
-void launch(dim3 grid, hipStream_t s, bool has_mul, bool has_add, bool has_res,
-            const float* feat, int feat_n, const float* flow, int C, int H, int W, const float* mul,
-            const float* add, const float* res, int res_c, const float* res_w, const float* res_b,
-            float* out, int cpb) {
-#define LSFA_WARP_CASE(M, A, R)                                                                        \
-  if (has_mul == M && has_add == A && has_res == R) {                                                  \
-    hipLaunchKernelGGL((warp_kernel<VEC, M, A, R>), grid, dim3(kThreads), 0, s, feat, feat_n, flow, C, \
-                       H, W, mul, add, res, res_c, res_w, res_b, out, cpb);                            \
-    return;                                                                                            \
-  }
-  LSFA_WARP_CASE(false, false, false)
-  LSFA_WARP_CASE(true, false, false)
-  LSFA_WARP_CASE(false, true, false)
-  LSFA_WARP_CASE(false, false, true)
-  LSFA_WARP_CASE(true, true, false)
-  LSFA_WARP_CASE(true, false, true)
-  LSFA_WARP_CASE(false, true, true)
-  LSFA_WARP_CASE(true, true, true)
-#undef LSFA_WARP_CASE
-}
-
 inline bool aligned(const void* p, size_t a) { return p == nullptr || ((uintptr_t)p % a) == 0; }
-
 }  // namespace
 
 extern "C" int lsfa_warp_bilinear(const float* feat, int feat_n, const float* flow, int N, int C, int H,
                                   int W, const float* mul, const float* add, const float* res, int res_c,
                                   const float* res_w, const float* res_b, float* out, void* stream) {
   using namespace lsfa;
+  using warp::kResMax;
   LSFA_REQUIRE(feat && flow && out, "lsfa_warp_bilinear: feat, flow and out must be non-NULL");
   LSFA_REQUIRE(N > 0 && C > 0 && H > 1 && W > 1, "lsfa_warp_bilinear: bad shape N=%d C=%d H=%d W=%d", N, C, H, W);
   LSFA_REQUIRE(feat_n == 1 || feat_n == N, "lsfa_warp_bilinear: feat batch %d must be 1 or N=%d", feat_n, N);
@@ -207,16 +46,15 @@ extern "C" int lsfa_warp_bilinear(const float* feat, int feat_n, const float* fl
   int vec = (HW % 4 == 0) ? 4 : (HW % 2 == 0) ? 2 : 1;
   const size_t al = sizeof(float) * vec;
   if (!(aligned(flow, al) && aligned(mul, al) && aligned(add, al) && aligned(res, al) && aligned(out, al))) vec = 1;
-  const int gx = ceil_div(HW, kThreads * vec);
-  // enough workgroups to cover 256 CUs several times over, while amortising the tap
-  // computation over the channel run
-  int cpb = 8;
-  while (cpb > 1 && (long)gx * ceil_div(C, cpb) * N < 1024) cpb >>= 1;
-  dim3 grid(gx, ceil_div(C, cpb), N);
+  const warp::Args a = {feat, feat_n, flow, N, C, H, W, mul, add, res, res_c, res_w, res_b, out};
+  // channel run per wave: 8 amortises the tap computation and puts 8 x (taps + operand) loads in flight
+  // per wave; small problems take 4 so that the chip still gets a few waves per SIMD
+  const long items8 = (long)N * ceil_div(C, 8) * warp::pixel_tiles(HW, vec);
+  const bool run8 = items8 >= 2048;
   ProfScope prof(LSFA_OP_WARP, s);
-  if (vec == 4) launch<4>(grid, s, mul != nullptr, add != nullptr, res != nullptr, feat, feat_n, flow, C, H, W, mul, add, res, res_c, res_w, res_b, out, cpb);
-  else if (vec == 2) launch<2>(grid, s, mul != nullptr, add != nullptr, res != nullptr, feat, feat_n, flow, C, H, W, mul, add, res, res_c, res_w, res_b, out, cpb);
-  else launch<1>(grid, s, mul != nullptr, add != nullptr, res != nullptr, feat, feat_n, flow, C, H, W, mul, add, res, res_c, res_w, res_b, out, cpb);
+  if (vec == 4) { if (run8) warp::launch<4, 8, false>(s, a); else warp::launch<4, 4, false>(s, a); }
+  else if (vec == 2) { if (run8) warp::launch<2, 8, LSFA_WARP_SHARE>(s, a); else warp::launch<2, 4, LSFA_WARP_SHARE>(s, a); }
+  else { if (run8) warp::launch<1, 8, false>(s, a); else warp::launch<1, 4, false>(s, a); }
   LSFA_LAUNCH_CHECK("lsfa_warp_bilinear");
   return LSFA_OK;
 }

@@ -37,7 +37,8 @@ def lib():
                                 "`python -m lsfa_amd.build` — there is no fallback path" % (LIB_PATH, e))
         L = ctypes.CDLL(LIB_PATH)
         L.lsfa_last_error.restype = ctypes.c_char_p
-        for name in ("lsfa_proposal_workspace_bytes", "lsfa_nms_workspace_bytes", "lsfa_det_workspace_bytes"):
+        for name in ("lsfa_proposal_workspace_bytes", "lsfa_nms_workspace_bytes", "lsfa_det_workspace_bytes",
+                     "lsfa_mv_workspace_bytes"):
             getattr(L, name).restype = ctypes.c_size_t
         L.lsfa_op_name.restype = ctypes.c_char_p
         L._nms.restype = None
@@ -234,6 +235,23 @@ def nms_sorted(boxes, thresh):
     return keep, num
 
 
+@_on_tensor_device
+def nms_sorted_f64(boxes, thresh):
+    """boxes (n, >=4) float64 CUDA, sorted by score descending -> (keep, num_keep) like nms_sorted; numpy's
+    float64 arithmetic and `ovr <= thresh` keep rule (lib/nms/nms.py:47-72)."""
+    if boxes.dtype != torch.float64 or not boxes.is_cuda:
+        raise LsfaError("boxes must be a float64 CUDA tensor (got %s on %s)" % (boxes.dtype, boxes.device))
+    boxes = boxes.contiguous()
+    n, d = boxes.shape
+    keep = torch.empty(max(n, 1), dtype=torch.int32, device=boxes.device)
+    num = torch.zeros(1, dtype=torch.int32, device=boxes.device)
+    need = lib().lsfa_nms_workspace_bytes(_ci(n))
+    ws = torch.empty(need, dtype=torch.uint8, device=boxes.device)
+    _check(lib().lsfa_nms_sorted_f64(_ptr(boxes), _ci(n), _ci(d), _cd(thresh), _ptr(keep), _ptr(num), _ptr(ws),
+                                     ctypes.c_size_t(need), _stream()), "lsfa_nms_sorted_f64")
+    return keep, num
+
+
 def nms_host(boxes_np, thresh, device_id=0):
     """The reference's `_nms` C entry point (lib/nms/gpu_nms.hpp:14-15): host numpy in, host list out."""
     import numpy as np
@@ -340,6 +358,63 @@ def scale_shift_relu_cl(x, scale, shift, relu=True, out=None):
     _check(lib().lsfa_scale_shift_relu_cl(_ptr(x), _ptr(scale), _ptr(shift), ctypes.c_longlong(rows), _ci(C),
                                           _ci(int(relu)), _ptr(out), _stream()), "lsfa_scale_shift_relu_cl")
     return out
+
+
+class MotionVectorAccumulator(object):
+    """Accumulated compressed-domain motion vectors of one GOP on the device
+    (coviar_data_loader.c:71-177 with accumulate = 1; see lsfa_mv_* in include/lsfa_hip.h).
+
+        acc = MotionVectorAccumulator(width, height, device)     # identity: the GOP's I-frame
+        acc.add_frame(mvs)          # one P-frame's blocks, (n,7) int32 {source,w,h,src_x,src_y,dst_x,dst_y}
+        acc.motion_vectors()        # (H,W,2) int32, what load(..., representation=MV, accumulate=True) returns
+        acc.residual(bgr_cur, bgr_ref)   # (H,W,3) int32
+    """
+
+    def __init__(self, width, height, device='cuda:0'):
+        self.width, self.height, self.device = int(width), int(height), torch.device(device)
+        self._bufs = [torch.empty((height, width, 2), dtype=torch.int32, device=self.device) for _ in range(2)]
+        self._ws = torch.empty(lib().lsfa_mv_workspace_bytes(_ci(width), _ci(height)), dtype=torch.uint8, device=self.device)
+        self._cur = 0
+        self.reset()
+
+    @property
+    def accu(self):
+        return self._bufs[self._cur]
+
+    def reset(self):
+        with torch.cuda.device(self.device):
+            _check(lib().lsfa_mv_identity(_ptr(self._bufs[self._cur]), _ci(self.width), _ci(self.height), _stream()),
+                   "lsfa_mv_identity")
+
+    def add_frame(self, mvs):
+        if mvs.dtype != torch.int32 or mvs.dim() != 2 or mvs.shape[1] != 7:
+            raise LsfaError("mvs must be (n, 7) int32, got %s %s" % (tuple(mvs.shape), mvs.dtype))
+        mvs = mvs.to(self.device).contiguous()
+        n = mvs.shape[0]
+        area = int((mvs[:, 1].clamp(min=0) * mvs[:, 2].clamp(min=0)).max().item()) if n else 0
+        old, new = self._bufs[self._cur], self._bufs[1 - self._cur]
+        with torch.cuda.device(self.device):
+            _check(lib().lsfa_mv_accumulate(_ptr(mvs), _ci(n), _ci(area), _ptr(old), _ptr(new), _ci(self.width),
+                                            _ci(self.height), _ptr(self._ws), ctypes.c_size_t(self._ws.numel()), _stream()),
+                   "lsfa_mv_accumulate")
+        self._cur = 1 - self._cur
+
+    def motion_vectors(self):
+        mv = torch.empty((self.height, self.width, 2), dtype=torch.int32, device=self.device)
+        with torch.cuda.device(self.device):
+            _check(lib().lsfa_mv_field(_ptr(self.accu), _ci(self.width), _ci(self.height), _ptr(mv), _stream()), "lsfa_mv_field")
+        return mv
+
+    def residual(self, bgr_cur, bgr_ref):
+        for t in (bgr_cur, bgr_ref):
+            if t.dtype != torch.uint8 or tuple(t.shape) != (self.height, self.width, 3):
+                raise LsfaError("frames must be (H, W, 3) uint8")
+        bgr_cur, bgr_ref = bgr_cur.to(self.device).contiguous(), bgr_ref.to(self.device).contiguous()
+        res = torch.empty((self.height, self.width, 3), dtype=torch.int32, device=self.device)
+        with torch.cuda.device(self.device):
+            _check(lib().lsfa_mv_residual(_ptr(bgr_cur), _ptr(bgr_ref), _ptr(self.accu), _ci(self.width), _ci(self.height),
+                                          _ptr(res), _stream()), "lsfa_mv_residual")
+        return res
 
 
 # ---- live timing -----------------------------------------------------------------------

@@ -262,3 +262,37 @@ def scale_shift_relu(x, scale, shift, relu=True):
     y = np.empty_like(x)
     lib().orc_scale_shift_relu(_p(x), _p(scale), _p(shift), _ci(N), _ci(C), _ci(HW), _ci(int(relu)), _p(y))
     return y
+
+
+# ---- compressed-domain motion vectors (coviar_data_loader.c:71-177) -----------------------------
+def coviar_identity(width, height):
+    accu = np.empty((height, width, 2), np.int32)
+    lib().orc_coviar_identity(_p(accu), _ci(width), _ci(height))
+    return accu
+
+
+def coviar_accumulate(mvs, accu_old):
+    """One P-frame's macroblock motion vectors (n,7) int32 applied to the accumulated source map (H,W,2)."""
+    mvs = np.ascontiguousarray(mvs, dtype=np.int32).reshape(-1, 7)
+    accu_old = np.ascontiguousarray(accu_old, dtype=np.int32)
+    h, w = accu_old.shape[:2]
+    accu_new = accu_old.copy()
+    lib().orc_coviar_accumulate(_p(mvs), _ci(mvs.shape[0]), _p(accu_old), _p(accu_new), _ci(w), _ci(h))
+    return accu_new
+
+
+def coviar_mv(accu):
+    accu = np.ascontiguousarray(accu, dtype=np.int32)
+    h, w = accu.shape[:2]
+    mv = np.empty((h, w, 2), np.int32)
+    lib().orc_coviar_mv(_p(accu), _ci(w), _ci(h), _p(mv))
+    return mv
+
+
+def coviar_residual(bgr_cur, bgr_ref, accu):
+    bgr_cur, bgr_ref = np.ascontiguousarray(bgr_cur, np.uint8), np.ascontiguousarray(bgr_ref, np.uint8)
+    accu = np.ascontiguousarray(accu, dtype=np.int32)
+    h, w = accu.shape[:2]
+    res = np.empty((h, w, 3), np.int32)
+    lib().orc_coviar_residual(_p(bgr_cur), _p(bgr_ref), _p(accu), _ci(w), _ci(h), _p(res))
+    return res

@@ -383,19 +383,42 @@ void orc_aggregate_softmax2(const float* a, const float* b, const float* logits,
 
 /* Fgfa combine, resnet_v1_101_flownet_rfcn.py:111-116, :136-147.
  * L2Normalization(mode='channel'): x / sqrt(sum_c x^2 + 1e-10). */
+/* Sum over the E embedding channels of one pixel in the FIXED order the HIP kernel uses (the reference's
+ * MXNet `sum(axis=1)` has no specified order [MXNet, un-vendored]; any order is a valid reading of
+ * resnet_v1_101_flownet_rfcn.py:111-116, so the order is defined here once for both sides): 64 partial
+ * sums, partial j taking channels e = j, j+64, j+128, ... in increasing order, then a butterfly
+ * partial[j] += partial[j ^ d] for d = 32, 16, 8, 4, 2, 1 (float addition is commutative, so every j
+ * ends with the same total). */
+#define ORC_TREE_LANES 64
+static float orc_tree_total(float* partial) {
+  float next[ORC_TREE_LANES];
+  for (int d = ORC_TREE_LANES / 2; d >= 1; d >>= 1) {
+    for (int j = 0; j < ORC_TREE_LANES; ++j) next[j] = partial[j] + partial[j ^ d];
+    for (int j = 0; j < ORC_TREE_LANES; ++j) partial[j] = next[j];
+  }
+  return partial[0];
+}
+
 void orc_aggregate_cosine(const float* a, const float* b, const float* emb_warp, const float* emb_cur,
                           int C, int E, int H, int W, float* out) {
   const size_t HW = (size_t)H * W;
   for (size_t p = 0; p < HW; ++p) {
-    float sw = 0.f, sc = 0.f;
-    for (int e = 0; e < E; ++e) { float v = emb_warp[(size_t)e * HW + p]; sw += v * v; }
-    for (int e = 0; e < E; ++e) { float v = emb_cur[(size_t)e * HW + p]; sc += v * v; }
+    float pw[ORC_TREE_LANES], pc[ORC_TREE_LANES];
+    for (int j = 0; j < ORC_TREE_LANES; ++j) { pw[j] = 0.f; pc[j] = 0.f; }
+    for (int e = 0; e < E; ++e) {
+      float vw = emb_warp[(size_t)e * HW + p], vc = emb_cur[(size_t)e * HW + p];
+      pw[e % ORC_TREE_LANES] += vw * vw;
+      pc[e % ORC_TREE_LANES] += vc * vc;
+    }
+    float sw = orc_tree_total(pw), sc = orc_tree_total(pc);
     float nw = sqrtf(sw + 1e-10f), nc = sqrtf(sc + 1e-10f);
-    float l0 = 0.f, l1 = 0.f;
+    for (int j = 0; j < ORC_TREE_LANES; ++j) { pw[j] = 0.f; pc[j] = 0.f; }
     for (int e = 0; e < E; ++e) {
       float vw = emb_warp[(size_t)e * HW + p] / nw, vc = emb_cur[(size_t)e * HW + p] / nc;
-      l0 += vw * vc; l1 += vc * vc;
+      pw[e % ORC_TREE_LANES] += vw * vc;
+      pc[e % ORC_TREE_LANES] += vc * vc;
     }
+    float l0 = orc_tree_total(pw), l1 = orc_tree_total(pc);
     float m = fmaxf_(l0, l1);
     float e0 = expf_cr(l0 - m), e1 = expf_cr(l1 - m);
     float s = e0 + e1;
@@ -589,4 +612,63 @@ void orc_scale_shift_relu(const float* x, const float* scale, const float* shift
     float v = x[o] * scale[c] + shift[c];
     y[o] = (relu && v < 0.f) ? 0.f : v;
   }
+}
+
+
+/* ------------------------------------------------------------------------ *
+ * Compressed-domain motion vectors: accumulation back to the key frame and the residual
+ * (external/data_loader_py2/coviar_data_loader.c:71-177, create_and_load_mv_residual with
+ * accumulate = 1).  mvs (n, 7) int32 rows = AVMotionVector's {source, w, h, src_x, src_y, dst_x, dst_y}
+ * in the order the decoder lists them.  accu_* hold, per pixel, the (x, y) of the pixel of the GOP's
+ * first frame it came from; HERE they are (H, W, 2) row-major (the reference keeps them x-major,
+ * accu[x*height*2 + y*2 + c], :111-113 — only the index arithmetic differs).  Start from identity
+ * (:316-323).  Integer work: bit-exact by definition.
+ * ------------------------------------------------------------------------ */
+void orc_coviar_identity(int* accu, int width, int height) {
+  for (int y = 0; y < height; ++y)
+    for (int x = 0; x < width; ++x) { accu[((size_t)y * width + x) * 2] = x; accu[((size_t)y * width + x) * 2 + 1] = y; }
+}
+
+/* one P-frame: :89-124.  accu_new must equal accu_old on entry (the reference memcpy's new -> old after every
+ * frame, :123-125, so pixels no block writes keep their value); later blocks overwrite earlier ones. */
+void orc_coviar_accumulate(const int* mvs, int n, const int* accu_old, int* accu_new, int width, int height) {
+  for (int i = 0; i < n; ++i) {
+    const int* mv = mvs + (size_t)i * 7;
+    const int w = mv[1], h = mv[2], src_x = mv[3], src_y = mv[4], dst_x = mv[5], dst_y = mv[6];
+    if (dst_x - src_x != 0 || dst_y - src_y != 0) {
+      for (int x_start = (-1 * w / 2); x_start < w / 2; ++x_start) {
+        for (int y_start = (-1 * h / 2); y_start < h / 2; ++y_start) {
+          const int p_dst_x = dst_x + x_start, p_dst_y = dst_y + y_start;
+          const int p_src_x = src_x + x_start, p_src_y = src_y + y_start;
+          if (p_dst_y >= 0 && p_dst_y < height && p_dst_x >= 0 && p_dst_x < width &&
+              p_src_y >= 0 && p_src_y < height && p_src_x >= 0 && p_src_x < width) {
+            for (int c = 0; c < 2; ++c)
+              accu_new[((size_t)p_dst_y * width + p_dst_x) * 2 + c] = accu_old[((size_t)p_src_y * width + p_src_x) * 2 + c];
+          }
+        }
+      }
+    }
+  }
+}
+
+/* :131-141: mv[y, x] = (x, y) - accu[y, x]   -> (H, W, 2) int32 */
+void orc_coviar_mv(const int* accu, int width, int height, int* mv) {
+  for (int y = 0; y < height; ++y)
+    for (int x = 0; x < width; ++x) {
+      const size_t o = ((size_t)y * width + x) * 2;
+      mv[o] = x - accu[o];
+      mv[o + 1] = y - accu[o + 1];
+    }
+}
+
+/* :144-171: res[y, x, c] = cur[y, x, c] - ref[accu_y, accu_x, c]; bgr (H, W, 3) uint8, res (H, W, 3) int32 */
+void orc_coviar_residual(const unsigned char* bgr_cur, const unsigned char* bgr_ref, const int* accu, int width, int height,
+                         int* res) {
+  for (int y = 0; y < height; ++y)
+    for (int x = 0; x < width; ++x) {
+      const size_t o = ((size_t)y * width + x);
+      const int src_x = accu[o * 2], src_y = accu[o * 2 + 1];
+      for (int c = 0; c < 3; ++c)
+        res[o * 3 + c] = (int)bgr_cur[o * 3 + c] - (int)bgr_ref[((size_t)src_y * width + src_x) * 3 + c];
+    }
 }

@@ -192,14 +192,25 @@ def test_aggregate_softmax2_bit_exact(hip, shape):
     np.testing.assert_allclose(got, (ref[0] * torch.from_numpy(a) + ref[1] * torch.from_numpy(b)).numpy(), rtol=1e-5, atol=1e-6)
 
 
-def test_aggregate_cosine_bit_exact(hip):
-    rs = np.random.RandomState(9)
-    C, E, H, W = 64, 128, 12, 14
+@pytest.mark.parametrize("shape", [(1024, 2048, 38, 63), (64, 128, 12, 14), (16, 100, 5, 7), (8, 37, 3, 3)])
+def test_aggregate_cosine_bit_exact(hip, shape):
+    """Fgfa weights at LSFA's real shape (2048-channel embeddings on the 38x63 map) and at shapes with E not a
+    multiple of the 64 lanes / pixel counts not a multiple of the workgroup tile: the lane-split reduction
+    follows the oracle's fixed tree, so the output is equal bit for bit; a float64 statement of the same
+    formula bounds what the tree order can differ by."""
+    C, E, H, W = shape
+    rs = np.random.RandomState(9 + E)
     a, b = rs.randn(1, C, H, W).astype(np.float32), rs.randn(1, C, H, W).astype(np.float32)
     ew, ec = rs.randn(1, E, H, W).astype(np.float32), rs.randn(1, E, H, W).astype(np.float32)
+    ew[0, :, 0, 0] = ec[0, :, 0, 0]                 # identical embeddings at one pixel: both logits 1 -> weights 1/2
     want = oracle.aggregate_cosine(a, b, ew, ec)
     got = hip.aggregate_cosine(t(a), t(b), t(ew), t(ec)).cpu().numpy()
     np.testing.assert_array_equal(got, want)
+    e64w, e64c = ew[0].astype(np.float64), ec[0].astype(np.float64)
+    nw, nc = np.sqrt((e64w ** 2).sum(0) + 1e-10), np.sqrt((e64c ** 2).sum(0) + 1e-10)
+    l0, l1 = ((e64w / nw) * (e64c / nc)).sum(0), ((e64c / nc) ** 2).sum(0)
+    w0 = 1.0 / (1.0 + np.exp(l1 - l0))
+    np.testing.assert_allclose(got[0], w0 * a[0] + (1 - w0) * b[0], rtol=0, atol=2e-5)
 
 
 # ------------------------------------------------------------------ NMS ---------------
@@ -251,6 +262,28 @@ def test_nms_wrappers_reference_interface(hip, golden):
                 for f in (py_nms_wrapper(th), cpu_nms_wrapper(th), gpu_nms_wrapper(th, 0)):
                     np.testing.assert_array_equal(np.asarray(f(dets)), want)
     assert gpu_nms(np.zeros((0, 5), np.float32), 0.3) == []
+
+
+def test_py_nms_wrapper_computes_in_the_dets_dtype(hip):
+    """lib/nms/nms.py:37-74 computes IoU in the dtype of `dets` — float64 in pred_eval.  Two float64 boxes whose
+    IoU sits 1e-9 below / above the threshold: float32 arithmetic cannot tell the two cases apart, the float64
+    kernel (lsfa_nms_sorted_f64) must, and agree with the oracle's float64 statement of the numpy loop."""
+    from lsfa_amd.nms.nms import py_nms_wrapper, cpu_nms_wrapper, gpu_nms_wrapper
+    s0 = 100.0 - 6000.0 / 1.3 / 100.0            # horizontal shift at which IoU of two 100x100 boxes is exactly 0.3
+    outcomes = []
+    for eps in (+1e-7, -1e-7):
+        dets = np.array([[0, 0, 99, 99, 0.9], [s0 + eps, 0, 99 + s0 + eps, 99, 0.8]], np.float64)
+        want = list(oracle.nms_f64(dets, 0.3))
+        assert list(py_nms_wrapper(0.3)(dets)) == want and list(cpu_nms_wrapper(0.3)(dets)) == want
+        outcomes.append((len(want), len(gpu_nms_wrapper(0.3, 0)(dets))))
+    assert outcomes[0][0] == 2 and outcomes[1][0] == 1          # float64: kept / suppressed
+    assert outcomes[0][1] == outcomes[1][1]                     # float32 (_nms): the same answer for both
+    # random float64 clusters, ties excluded by construction
+    rs = np.random.RandomState(21)
+    for n in (1, 63, 64, 65, 700):
+        dets = clustered_dets(rs, n, np.float64)
+        dets[:, :4] += rs.uniform(0, 1e-3, (n, 4))              # off the float32 grid
+        np.testing.assert_array_equal(np.asarray(py_nms_wrapper(0.45)(dets)), oracle.nms_f64(dets, 0.45))
 
 
 def test_nms_all_identical_boxes_and_empty(hip):
@@ -307,6 +340,35 @@ def test_proposal_ties_stable_order_and_cyclic_pad(hip):
     np.testing.assert_array_equal(rois.cpu().numpy(), want_rois)
     np.testing.assert_array_equal(scores.cpu().numpy(), want_scores)
     assert nkeep[0] < 300                                       # the pad path really ran
+
+
+@pytest.mark.parametrize("kind", ["flat", "all_equal", "logits", "few_valid", "saturated"])
+def test_proposal_score_distributions_that_stress_the_select(hip, kind):
+    """The chip-wide plan picks its candidates by a 4096-bin histogram of the order keys and ranks them
+    exactly; these inputs put thousands of keys into the threshold bin (nearly flat scores, all scores equal,
+    the -1 block larger than what is left), or outside the range the bins resolve (raw logits, scores of
+    exactly 1.0).  Results must still equal the oracle's stable sort + NMS bit for bit."""
+    rs = np.random.RandomState({"flat": 1, "all_equal": 2, "logits": 3, "few_valid": 4, "saturated": 5}[kind])
+    H, W = 38, 63
+    prob, deltas = rpn_inputs(rs, 1, H, W)
+    im_info = np.array([[600, 1000, 1.0]], np.float32)
+    min_size = 0
+    if kind == "flat":
+        prob = (0.02 + 0.002 * rs.rand(*prob.shape)).astype(np.float32)
+    elif kind == "all_equal":
+        prob[:] = 0.25
+    elif kind == "logits":
+        prob = (rs.randn(*prob.shape) * 6).astype(np.float32)           # negative and > 1 "scores"
+    elif kind == "few_valid":
+        im_info = np.array([[600, 1000, 4.0]], np.float32)                # min_size 16 * 4 = 64 px: most anchors get -1
+        min_size = 16
+    elif kind == "saturated":
+        prob[:, 9:] = np.where(rs.rand(1, 9, H, W) < 0.4, 1.0, prob[:, 9:]).astype(np.float32)
+    want_rois, want_scores = oracle.proposal(prob, deltas, im_info, rpn_min_size=min_size)
+    op = hip.ProposalOp(rpn_min_size=min_size, output_score=True)
+    rois, scores = op(t(prob), t(deltas), t(im_info))
+    np.testing.assert_array_equal(rois.cpu().numpy(), want_rois)
+    np.testing.assert_array_equal(scores.cpu().numpy(), want_scores)
 
 
 def test_proposal_multi_image(hip):
@@ -458,3 +520,47 @@ def test_prof_hooks_report_launches(hip):
         assert stats["proposal"][1] == 0
     finally:
         hip.prof_enable(False)
+
+
+# ------------------------------------------------------------------ compressed-domain MVs ----
+def synthetic_block_mvs(rs, width, height, n_extra=40):
+    """A decoder-like block list: the 16x16 macroblock grid with small motions (some zero, some leaving the
+    frame), plus 8x8 / 16x8 / odd-sized partitions scattered on top (later entries overwrite earlier ones)."""
+    rows = []
+    for by in range(0, height, 16):
+        for bx in range(0, width, 16):
+            dx, dy = rs.randint(-9, 10), rs.randint(-9, 10)
+            if rs.rand() < 0.2:
+                dx = dy = 0
+            rows.append([-1, 16, 16, bx + 8 - dx, by + 8 - dy, bx + 8, by + 8])
+    for _ in range(n_extra):
+        w, h = [(8, 8), (16, 8), (8, 16), (5, 7), (16, 16)][rs.randint(0, 5)]
+        x, y = rs.randint(-4, width + 4), rs.randint(-4, height + 4)
+        rows.append([-1, w, h, x - rs.randint(-20, 21), y - rs.randint(-20, 21), x, y])
+    return np.array(rows, np.int32)
+
+
+@pytest.mark.parametrize("size", [(96, 64), (1000, 600), (37, 23)])
+def test_mv_accumulation_bit_exact(hip, size):
+    """lsfa_mv_* vs the oracle's statement of coviar_data_loader.c:71-177 over a 5-frame GOP: the accumulated
+    source map after every frame, the motion-vector field and the residual, all int32, all equal."""
+    width, height = size
+    rs = np.random.RandomState(width)
+    acc = hip.MotionVectorAccumulator(width, height, DEV)
+    want = oracle.coviar_identity(width, height)
+    np.testing.assert_array_equal(acc.accu.cpu().numpy(), want)
+    for frame in range(5):
+        mvs = synthetic_block_mvs(rs, width, height)
+        if frame == 3:
+            mvs = mvs[:0]                                  # a frame without motion vectors
+        acc.add_frame(torch.from_numpy(mvs))
+        want = oracle.coviar_accumulate(mvs, want)
+        np.testing.assert_array_equal(acc.accu.cpu().numpy(), want, err_msg="frame %d" % frame)
+    assert (want != oracle.coviar_identity(width, height)).any()
+    np.testing.assert_array_equal(acc.motion_vectors().cpu().numpy(), oracle.coviar_mv(want))
+    cur = rs.randint(0, 256, (height, width, 3)).astype(np.uint8)
+    ref = rs.randint(0, 256, (height, width, 3)).astype(np.uint8)
+    np.testing.assert_array_equal(acc.residual(torch.from_numpy(cur), torch.from_numpy(ref)).cpu().numpy(),
+                                  oracle.coviar_residual(cur, ref, want))
+    acc.reset()
+    np.testing.assert_array_equal(acc.accu.cpu().numpy(), oracle.coviar_identity(width, height))

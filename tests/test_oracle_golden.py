@@ -102,3 +102,34 @@ def test_key_frame_flags():
     f = np_ref.key_frame_flags([3, 2], 10)
     assert f == [0, 2, 1, 0, 1]
     assert np_ref.shard_videos([10, 9, 8, 7, 1], 2) == [[0, 3, 4], [1, 2]]
+
+
+def test_coviar_accumulation_hand_case():
+    """coviar_data_loader.c:71-177 on a 12x10 frame: a 4x4 block moved by (+2,+1), then a later, overlapping 2x2
+    block; second frame moves what the first one left.  Expected values worked out by hand from the C loops."""
+    import oracle
+    W, H = 12, 10
+    accu = oracle.coviar_identity(W, H)
+    assert accu[3, 7].tolist() == [7, 3]
+    # {source, w, h, src_x, src_y, dst_x, dst_y}
+    mvs = np.array([[-1, 4, 4, 4, 4, 6, 5],        # pixels dst x in [4,8), y in [3,7) take src x-2, y-1
+                    [-1, 2, 2, 9, 2, 7, 4],        # later block: dst x in [6,8), y in [3,5) take src x+2, y-2
+                    [-1, 4, 4, 5, 5, 5, 5],        # zero displacement: skipped (:92)
+                    [-1, 4, 4, 1, 1, 0, 0]],       # partly outside: only in-bounds (dst AND src) pixels written
+                   np.int32)
+    a1 = oracle.coviar_accumulate(mvs, accu)
+    assert a1[5, 5].tolist() == [3, 4]             # first block
+    assert a1[3, 6].tolist() == [8, 1]             # overwritten by the second block (last writer wins)
+    assert a1[6, 7].tolist() == [5, 5]             # first block, outside the second
+    assert a1[8, 8].tolist() == [8, 8]             # untouched
+    assert a1[0, 0].tolist() == [1, 1] and a1[1, 1].tolist() == [2, 2]     # block 4: dst (0,0) <- src (1,1)
+    mv = oracle.coviar_mv(a1)
+    assert mv[5, 5].tolist() == [2, 1] and mv[3, 6].tolist() == [-2, 2] and mv[8, 8].tolist() == [0, 0]
+    # second frame reads the FIRST frame's result (accu_src_old), :111-113
+    a2 = oracle.coviar_accumulate(np.array([[-1, 2, 2, 5, 5, 9, 8]], np.int32), a1)
+    assert a2[8, 9].tolist() == a1[5, 5].tolist() == [3, 4]
+    bgr0 = (np.arange(H * W * 3) % 251).astype(np.uint8).reshape(H, W, 3)
+    bgr1 = ((np.arange(H * W * 3) * 7) % 253).astype(np.uint8).reshape(H, W, 3)
+    res = oracle.coviar_residual(bgr1, bgr0, a2)
+    assert res.dtype == np.int32
+    assert res[8, 9].tolist() == (bgr1[8, 9].astype(np.int32) - bgr0[4, 3].astype(np.int32)).tolist()

@@ -90,7 +90,7 @@ def main():
     out['psroi_pool_cls'] = dict(us=round(us, 2), GBps=round(pb / us / 1e3, 1), bytes=pb)
     # proposal: untrained-like (few overlaps) and trained-like (heavy overlaps)
     im_info = t(np.array([[H * 16 - 8, W * 16 - 8, 1.0]], np.float32))
-    for tag, trained in (('proposal_sparse', False), ('proposal_clustered', True)):
+    for tag, trained in (('proposal_sparse', False), ('proposal_clustered', True)):   # RPN-like inputs
         prob, deltas = rpn_inputs(rs, H, W, trained=trained)
         op = hip.ProposalOp(rpn_min_size=0)
         p_, d_ = t(prob), t(deltas)
@@ -127,33 +127,6 @@ def main():
 
 if __name__ == '__main__':
     main()
-
-
-def proposal_phases():
-    """Diagnostic: cycle shares of the phases of proposal_select_nms_kernel."""
-    import ctypes
-    dev = 'cuda:0'
-    rs = np.random.RandomState(0)
-    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
-    stamps = torch.zeros(16, dtype=torch.int64, device=dev)
-    hip.lib().lsfa_debug_set_proposal_stamps(ctypes.c_void_p(stamps.data_ptr()))
-    im_info = t(np.array([[600, 1000, 1.0]], np.float32))
-    for tag, trained in (('sparse', False), ('clustered', True)):
-        prob, deltas = rpn_inputs(rs, 38, 63, trained=trained)
-        op = hip.ProposalOp(rpn_min_size=0)
-        for _ in range(3):
-            op(t(prob), t(deltas), im_info)
-        torch.cuda.synchronize()
-        s = stamps.cpu().numpy()
-        d = np.diff(s[:7]).astype(np.float64)
-        names = ['load keys', 'radix select', 'compaction', 'sort', 'nms', 'output']
-        print(tag, 'survivors', int(s[7]), 'total cycles(100MHz ticks?)', int(s[6] - s[0]),
-              {n: int(x) for n, x in zip(names, d)}, 'nms blocks', int(s[8]), 'A(vs kept)', int(s[9]), 'B(in-block)', int(s[10]), 'C(resolve)', int(s[11]))
-    hip.lib().lsfa_debug_set_proposal_stamps(ctypes.c_void_p(0))
-
-
-if __name__ == '__main__' and os.environ.get('LSFA_PHASES') == '1':
-    proposal_phases()
 
 
 def batched():

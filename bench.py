@@ -1,22 +1,30 @@
 #!/usr/bin/env python
 """LSFA per-frame inference benchmark on MI355X.
 
-    python bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W                      # BASELINE configs[1] (the headline)
+    python bench.py --dtype bf16 --clips 4                             # configs[2]: bf16 contractions, 4 clips in lock-step
+    python bench.py --interval 1 --maps-per-launch 32                  # configs[4]: every frame a key frame; warp /
+                                                                       #   aggregate roofline on 32 maps per launch (HBM-resident)
 
 Metric (BASELINE.json): frames/sec at 1000x600, key_interval = 10, synthetic VID-shaped clips,
 random-init weights of the trained LSFA architecture (ResNet-101 + DCN + FlowNet + Nq + small net
-+ R-FCN head), fp32.  Workload = BASELINE.json configs[1] ("dff_rfcn ResNet-101 LSFA, 1 clip
++ R-FCN head), fp32.  Default workload = BASELINE.json configs[1] ("dff_rfcn ResNet-101 LSFA, 1 clip
 key_interval=10 on 1xMI355X, fp32").
 
-A STEP is one key-frame interval of one clip: 1 key frame (ResNet-101 + FlowNet + flow warp x
-scale map + Nq aggregation + heads + Proposal + PSROI + detection NMS) followed by
+A STEP is one key-frame interval of the clip(s) of this GPU: 1 key frame (ResNet-101 + FlowNet + flow
+warp x scale map + Nq aggregation + heads + Proposal + PSROI + detection NMS) followed by
 key_interval-1 non-key frames (small net + MV warp + residual + heads + Proposal + PSROI +
 detection NMS).  Frames, motion vectors and residuals are resident in HBM before the timed
 region; every frame's detections are copied to pinned host memory inside it.
 
-N > 1: launched by torch.distributed.run, one rank per GPU; rank r runs clip r (clips are
+N > 1: launched by torch.distributed.run, one rank per GPU; rank r runs clip(s) r (clips are
 independent: "scaling": "weak", no data-path collective); the only collective is the final
 all_gather of per-frame detection counts over RCCL, outside the per-frame path.
+
+After the timed region rank 0 adds, untimed: `roofline` (HIP events around every launch of the
+hand-written ops, the same frames re-issued eagerly; a captured graph carries no per-launch events),
+`parity` (the first frames of the clip against oracle/graph_ref.py: end to end, and stage by stage on
+the GPU's own inputs) and `cpu_baseline` (the oracle graph timed on the host cores).
 """
 import argparse
 import json
@@ -30,24 +38,31 @@ import torch
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-WARP_BYTES = lambda C, HW: (3 * C * HW + 2 * HW) * 4  # feat + (scale map | small-net feature) + out, + flow
 HBM_PEAK_GBS = 8000.0                                   # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
-# HBM-side bytes per warp_kernel launch from rocprofv3 PMC passes (profiles/r1/warp_kernel_pmc_and_duration.txt,
-# 1024x38x63): FETCH_SIZE 11,845 KiB x2 (the guide's gfx950 correction: 128-B requests are tallied as 64 B;
-# uncalibrated for this kernel's 4/8-byte accesses) + WRITE_SIZE 9,699 KiB.  Only valid at that shape.
-WARP_TRAFFIC_BYTES_38x63 = int((2 * 11844.9 + 9699.0) * 1024)
+TRAFFIC_FILE = os.path.join(ROOT, 'profiles', 'traffic.json')   # HBM bytes per launch from rocprofv3 PMC passes, keyed by shape
+
+
+def warp_bytes(N, C, HW):
+    """feat + (scale map | small-net feature) + out, + flow, each touched once."""
+    return N * (3 * C * HW + 2 * HW) * 4
 
 
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=40)
+    ap.add_argument('--steps', type=int, default=100)
     ap.add_argument('--warmup', type=int, default=3)
     ap.add_argument('--interval', type=int, default=10)
     ap.add_argument('--height', type=int, default=600)
     ap.add_argument('--width', type=int, default=1000)
     ap.add_argument('--dtype', default='f32', choices=['f32', 'bf16'])
+    ap.add_argument('--clips', type=int, default=1,
+                    help='clips per GPU advancing in lock-step, one image of each per frame on the batch axis (configs[2]: 4)')
+    ap.add_argument('--maps-per-launch', type=int, default=0,
+                    help='roofline leg on this many feature maps per launch of the warp / aggregate kernels (configs[4]: 32, '
+                         '942 MB per launch, HBM-resident); 0 = the frame loop\'s own single-map launches')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-parity', action='store_true')
     ap.add_argument('--no-graph', action='store_true', help='issue every launch eagerly instead of replaying hipGraphs')
     ap.add_argument('--no-prefetch', action='store_true', help='do not overlap the next frame\'s small net with this frame\'s tail')
     ap.add_argument('--lanes', type=int, default=2,
@@ -64,7 +79,7 @@ def parse():
 
 
 class Runner(object):
-    """One clip stream on one GPU: the pred_eval frame loop (dff_rfcn/core/tester.py:237-281)."""
+    """The clip stream(s) of one GPU: the pred_eval frame loop (dff_rfcn/core/tester.py:237-281)."""
 
     def __init__(self, args, rank, device):
         from lsfa_amd import hip
@@ -79,43 +94,44 @@ class Runner(object):
         net = resnet_v1_101_flownet_rfcn(cfg)
         self.key = net.get_key_test_symbol(cfg).bind(self.arg, self.aux, device, dt)
         self.cur = net.get_cur_test_symbol(cfg).bind(self.arg, self.aux, device, dt)
-        self.K = args.interval
+        self.K, self.B = args.interval, args.clips
         self.nsteps_unique = min(args.max_unique_steps, args.steps + args.warmup)
-        self.clip = SyntheticClip(rank, self.nsteps_unique * self.K + 1, args.height, args.width, self.K)
-        self.im_info = torch.from_numpy(self.clip.im_info()).to(device)
+        nframes = self.nsteps_unique * self.K + 1
+        self.clips = [SyntheticClip(rank * self.B + b, nframes, args.height, args.width, self.K) for b in range(self.B)]
+        cat = lambda fn: torch.cat([fn(c) for c in self.clips], 0)
         # frames resident in HBM: frame 0 primes the recurrence, then nsteps_unique intervals
-        self.frames = [self.clip.frame(f, device) for f in range(self.nsteps_unique * self.K + 1)]
+        self.frames = [cat(lambda c: c.frame(f, device)) for f in range(nframes)]
         self.mv, self.res = {}, {}
         for s in range(self.nsteps_unique):
             kf = 1 + s * self.K
             for i in range(1, self.K):
-                self.mv[kf + i] = self.clip.motion_vector(kf + i, kf, device)
-                self.res[kf + i] = self.clip.res_diff(kf + i, device)
+                self.mv[kf + i] = cat(lambda c: c.motion_vector(kf + i, kf, device))
+                self.res[kf + i] = cat(lambda c: c.res_diff(kf + i, device))
         R, ncls = cfg.TEST.RPN_POST_NMS_TOP_N, cfg.dataset.NUM_CLASSES
-        self.host_dets = torch.empty((self.K, ncls, R, 5), dtype=torch.float64).pin_memory()
-        self.host_counts = torch.empty((self.K, ncls), dtype=torch.int32).pin_memory()
+        self.host_dets = torch.empty((self.K, self.B, ncls, R, 5), dtype=torch.float64).pin_memory()
+        self.host_counts = torch.empty((self.K, self.B, ncls), dtype=torch.int32).pin_memory()
         from lsfa_amd.core.graphs import FrameGraphs, FramePipeline
         if args.lanes > 0:
             self.fg = FramePipeline(self.key, self.cur, cfg, args.height, args.width, device,
                                     use_graphs=not args.no_graph, lanes=args.lanes,
-                                    flow_stream=not args.no_flow_stream, lookahead=args.lookahead)
+                                    flow_stream=not args.no_flow_stream, lookahead=args.lookahead, batch=self.B)
         else:
             self.fg = FrameGraphs(self.key, self.cur, cfg, args.height, args.width, device, use_graphs=not args.no_graph,
-                                  prefetch=not args.no_prefetch)
+                                  prefetch=not args.no_prefetch, batch=self.B)
 
     @property
     def feat(self):
         return self.fg.feat
 
     def prime(self):
-        """Frame 0 of the clip (flag 0: no aggregation) sets up feat_key / data_key; then the two
-        per-frame launch sequences are captured into hipGraphs (untimed)."""
+        """Frame 0 of the clip (flag 0: no aggregation) sets up feat_key / data_key; then the per-frame
+        launch sequences are captured into hipGraphs (untimed)."""
         self.fg.first_frame(self.frames[0])
         self.fg.capture()
 
     def _deliver(self, bufs, slot):
-        self.host_dets[slot].copy_(bufs[0], non_blocking=True)
-        self.host_counts[slot].copy_(bufs[1], non_blocking=True)
+        self.host_dets[slot].copy_(bufs[0].view(self.host_dets[slot].shape), non_blocking=True)
+        self.host_counts[slot].copy_(bufs[1].view(self.host_counts[slot].shape), non_blocking=True)
 
     def step(self, s, fg=None):
         """One key-frame interval: key frame (flag 1) + K-1 non-key frames (flag 2)."""
@@ -132,18 +148,21 @@ class Runner(object):
         for i in range(1, self.K):
             self._deliver(fg.cur_frame(self.frames[kf + i], self.mv[kf + i], self.res[kf + i], nxt(i)), i)
 
+    # ---- untimed legs (rank 0) ----------------------------------------------------------------
+    OPS = ['warp_bilinear', 'aggregate', 'rfcn_head', 'proposal', 'det_postprocess']
+
     def eager_profile_step(self, s):
         """The same interval issued eagerly with the per-kernel event hooks on (a captured graph has no
-        per-launch events): the roofline leg."""
+        per-launch events): the roofline leg.  -> {op: (total_ms, launches)}"""
         from lsfa_amd.core.graphs import FrameGraphs
         eg = FrameGraphs(self.key, self.cur, self.cfg, self.args.height, self.args.width, self.device, use_graphs=False,
-                         prefetch=False)
+                         prefetch=False, batch=self.B)
         eg.feat_old.copy_(self.fg.feat_old)
         eg.data_key_old.copy_(self.fg.data_key_old)
         eg.feat = self.fg.feat.clone()
         self.step(s, eg)     # warm
         torch.cuda.synchronize()
-        self.hip.prof_enable(True, ops=['warp_bilinear', 'aggregate', 'rfcn_head', 'proposal', 'det_postprocess'])
+        self.hip.prof_enable(True, ops=self.OPS)
         self.hip.prof_read()
         self.step(s, eg)
         torch.cuda.synchronize()
@@ -151,42 +170,177 @@ class Runner(object):
         self.hip.prof_enable(False)
         return prof
 
-    def cpu_baseline(self, budget_s):
-        """The oracle's statement of the same step (torch-CPU convs + C kernels), timed on the host."""
+    def many_maps_leg(self, M, iters=10):
+        """configs[4]'s HBM-resident regime: M feature maps per launch through lsfa_warp_bilinear (key-path
+        epilogue: x scale map; cur-path epilogue: + rnet_conv0(res) + small-net feature) and
+        lsfa_aggregate_softmax2_batched, timed by the same event hooks.  3 x M x 9.8 MB per launch."""
+        hip, dev = self.hip, self.device
+        C = self.cfg.network.DFF_FEAT_DIM
+        fh, fw = -(-self.args.height // 16), -(-self.args.width // 16)
+        g = torch.Generator(device=dev).manual_seed(5)
+        feat = torch.randn((M, C, fh, fw), device=dev, generator=g)
+        other = torch.randn((M, C, fh, fw), device=dev, generator=g)
+        out = torch.empty_like(feat)
+        flow = torch.cat([self.clips[0].motion_vector(4, 1, dev)] * M, 0) + 0.05 * torch.randn((M, 2, fh, fw), device=dev, generator=g)
+        res = torch.randn((M, 3, fh, fw), device=dev, generator=g)
+        logits = torch.randn((2 * M, 1, fh, fw), device=dev, generator=g)
+        rnet_w, rnet_b = self.cur.rnet_w, self.cur.rnet_b
+        legs = {'warp_bilinear (x scale map)': lambda: hip.warp_bilinear(feat, flow, mul=other, out=out),
+                'warp_bilinear (+res +small-net)': lambda: hip.warp_bilinear(feat, flow, add=other, res=res, res_w=rnet_w,
+                                                                             res_b=rnet_b, out=out),
+                'aggregate_softmax2_batched': lambda: hip.aggregate_softmax2(feat, other, logits, out=out)}
+        result = {}
+        for name, fn in legs.items():
+            op = 'aggregate' if name.startswith('aggregate') else 'warp_bilinear'
+            for _ in range(2):
+                fn()
+            torch.cuda.synchronize()
+            hip.prof_enable(True, ops=[op])
+            hip.prof_read()
+            for _ in range(iters):
+                fn()
+            torch.cuda.synchronize()
+            ms, n = hip.prof_read()[op]
+            hip.prof_enable(False)
+            nbytes = warp_bytes(M, C, fh * fw)
+            result[name] = {"avg_us": round(ms * 1e3 / n, 2), "launches": n, "algorithmic_bytes_per_launch": nbytes,
+                            "achieved_GBps": round(nbytes * n / (ms * 1e-3) / 1e9, 1)}
+        return result
+
+    def parity_and_cpu_baseline(self, budget_s, want_parity):
+        """The oracle's statement of the clip's first frames (torch-CPU convs + C kernels), timed on the
+        host (`cpu_baseline`, kind "port") and compared with the GPU's eager run of the same frames (`parity`).
+        Clip 0 of this rank, frames 0 (first), 1 (key), 2.. (non-key)."""
         import oracle
         from oracle import graph_ref
-        cfg, K = self.cfg, self.K
-        f = [self.frames[i].cpu().numpy() for i in range(0, K + 1)]
-        im_info = self.clip.im_info()
-        feat0 = self.feat.cpu().numpy()
+        from lsfa_amd.core.graphs import FrameGraphs
+        cfg, K, H, W = self.cfg, self.K, self.args.height, self.args.width
+        im_info = self.clips[0].im_info()
+        npf = lambda t: t.detach().float().cpu().numpy()
+        one = lambda t: t[:1]
+        f = [npf(one(self.frames[i])) for i in range(0, K + 1)]
+        # ---- GPU, eager, taps on, each frame on its own intermediate values -------------------------
+        gpu = {}
+        if want_parity:
+            eg = FrameGraphs(self.key, self.cur, cfg, H, W, self.device, use_graphs=False, prefetch=False, taps=True, batch=1)
+            eg.first_frame(one(self.frames[0]))
+            eg.capture()
+            feat0_gpu = eg.feat.clone()
+            d, c, _ = eg.key_frame(one(self.frames[1]))
+            gpu[1] = dict(taps=dict(eg.key_taps), out=dict(eg.key_out), dets=d.cpu().numpy().copy(), counts=c.cpu().numpy().copy(),
+                          prev=feat0_gpu)
+            for i in range(2, K + 1):
+                d, c, _ = eg.cur_frame(one(self.frames[i]), one(self.mv[i]), one(self.res[i]))
+                gpu[i] = dict(taps=dict(eg.cur_taps), out=dict(eg.cur_out), dets=d.cpu().numpy().copy(),
+                              counts=c.cpu().numpy().copy(), key_feat=eg.feat, mv=one(self.mv[i]), res=one(self.res[i]))
+            torch.cuda.synchronize()
+        # ---- CPU oracle ---------------------------------------------------------------------------
+        ref = {}
+        ref[0] = graph_ref.key_forward(cfg, self.arg, self.aux, f[0], f[0], np.zeros((1, 1024, 1, 1), np.float32), im_info)
         t0 = time.time()
-        frames_done = 0
-        out = graph_ref.key_forward(cfg, self.arg, self.aux, f[1], f[0], feat0, im_info)
-        oracle.det_postprocess(out['rois_output'], out['bbox_pred_reshape_output'][0], out['cls_prob_reshape_output'][0],
-                               self.args.height, self.args.width, 1.0)
-        feat = out['choose_feat_output']
-        frames_done += 1
+        ref[1] = graph_ref.key_forward(cfg, self.arg, self.aux, f[1], f[0], ref[0]['choose_feat_output'], im_info)
+        oracle.det_postprocess(ref[1]['rois_output'], ref[1]['bbox_pred_reshape_output'][0], ref[1]['cls_prob_reshape_output'][0], H, W, 1.0)
         key_s = time.time() - t0
-        nonkey_s = 0.0
-        for i in range(1, K):
+        nonkey_s, n_nonkey = 0.0, 0
+        for i in range(2, K + 1):
             t1 = time.time()
-            o = graph_ref.cur_forward(cfg, self.arg, self.aux, f[1 + i], feat, self.mv[1 + i].cpu().numpy(),
-                                      self.res[1 + i].cpu().numpy(), im_info)
-            oracle.det_postprocess(o['rois_output'], o['bbox_pred_reshape_output'][0], o['cls_prob_reshape_output'][0],
-                                   self.args.height, self.args.width, 1.0)
+            ref[i] = graph_ref.cur_forward(cfg, self.arg, self.aux, f[i], ref[1]['choose_feat_output'], npf(one(self.mv[i])),
+                                           npf(one(self.res[i])), im_info)
+            oracle.det_postprocess(ref[i]['rois_output'], ref[i]['bbox_pred_reshape_output'][0], ref[i]['cls_prob_reshape_output'][0], H, W, 1.0)
             nonkey_s += time.time() - t1
-            frames_done += 1
+            n_nonkey += 1
             if time.time() - t0 > budget_s:
                 break
-        n_nonkey = frames_done - 1
-        # per-interval time = 1 key + (K-1) non-key at the measured per-frame costs
-        per_step = key_s + (nonkey_s / max(n_nonkey, 1)) * (K - 1)
-        return {"value": round(K / per_step, 3), "unit": "frames/s", "cores": int(torch.get_num_threads()), "kind": "port",
-                "sample": "1 key frame + %d non-key frame(s) of the same clip at %dx%d through oracle/graph_ref.py "
-                          "(torch-CPU fp32 convs, C oracle for warp/aggregate/proposal/psroi/nms); %.1f s key, %.2f s per "
-                          "non-key frame, extrapolated to one %d-frame interval" % (n_nonkey, self.args.width,
-                                                                                   self.args.height, key_s,
-                                                                                   nonkey_s / max(n_nonkey, 1), K)}
+        per_nonkey = nonkey_s / max(n_nonkey, 1)
+        per_step = key_s + per_nonkey * (K - 1)
+        cpu = {"value": round(K / per_step, 3), "unit": "frames/s", "cores": int(torch.get_num_threads()), "kind": "port",
+               "sample": "1 key frame + %d non-key frame(s) of the same clip at %dx%d through oracle/graph_ref.py "
+                         "(torch-CPU fp32 convs, C oracle for warp/aggregate/proposal/psroi/nms); %.1f s key, %.2f s per "
+                         "non-key frame, extrapolated to one %d-frame interval" % (n_nonkey, W, H, key_s, per_nonkey, K)}
+        if not want_parity:
+            return cpu, None
+        # ---- parity: end to end (each side on its own values), and stage by stage on the GPU's inputs ------
+        frames = sorted(i for i in gpu if i in ref and i >= 1)
+        e2e = [end_to_end_gap(cfg, gpu[i]['out'], ref[i], H, W) for i in frames]
+        forced = 0
+        for i in frames[:3]:
+            forced += forced_mismatches(cfg, self.arg, gpu[i], im_info, H, W)
+        agg = lambda k: max((e[k] for e in e2e if e[k] is not None), default=None)
+        parity = {"frames_compared": frames, "vs": "oracle/graph_ref.py, un-forced: GPU and oracle each on their own intermediate values",
+                  "max_abs_dbox": agg('max_abs_dbox'), "max_abs_dscore": agg('max_abs_dscore'),
+                  "roi_mismatch": int(sum(e['roi_mismatch'] for e in e2e)), "rois_compared": 300 * len(e2e),
+                  "survivor_mismatch": int(sum(e['survivor_mismatch'] for e in e2e)),
+                  "survivors": int(sum(e['survivors'] for e in e2e)),
+                  "feature_rel_err_key_frame": rel_err(npf(gpu[1]['out']['choose_feat_output']), ref[1]['choose_feat_output']),
+                  "handwritten_stage_mismatches_on_gpu_inputs": int(forced),
+                  "handwritten_stages_checked": "warp, aggregate, proposal, psroi+avg+softmax, det_postprocess of frames %s "
+                                                "(bit-exact = 0 mismatching elements)" % frames[:3]}
+        return cpu, parity
+
+
+def rel_err(a, b):
+    a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+    return float(np.abs(a - b).max() / (np.abs(b).max() + 1e-12))
+
+
+def end_to_end_gap(cfg, gpu_out, ref_out, h, w):
+    """Un-forced comparison of one frame's final outputs: GPU graph vs oracle graph, each on its own
+    intermediate values (north_star: ROI indices / NMS survivors identical, boxes / scores within 1e-4)."""
+    import oracle
+    npf = lambda t: t.detach().float().cpu().numpy() if isinstance(t, torch.Tensor) else np.asarray(t)
+    g_rois, r_rois = npf(gpu_out['rois_output']), np.asarray(ref_out['rois_output'])
+    same = np.abs(g_rois - r_rois).max(1) < 0.05        # the same anchor survived at the same output row
+    g_cls, r_cls = npf(gpu_out['cls_prob_reshape_output'])[0], np.asarray(ref_out['cls_prob_reshape_output'])[0]
+    g_del, r_del = npf(gpu_out['bbox_pred_reshape_output'])[0], np.asarray(ref_out['bbox_pred_reshape_output'])[0]
+    g_box, r_box = oracle.bbox_pred_clip(g_rois, g_del, h, w, 1.0), oracle.bbox_pred_clip(r_rois, r_del, h, w, 1.0)
+    kw = dict(nms_thresh=cfg.TEST.NMS, max_per_image=cfg.TEST.max_per_image, class_agnostic=cfg.CLASS_AGNOSTIC)
+    _, gc, gk = oracle.det_postprocess(g_rois, g_del, g_cls, h, w, 1.0, **kw)
+    _, rc, rk = oracle.det_postprocess(r_rois, r_del, r_cls, h, w, 1.0, **kw)
+    gs = set((j, int(i)) for j in range(1, len(gc)) for i in gk[j, :gc[j]])
+    rs = set((j, int(i)) for j in range(1, len(rc)) for i in rk[j, :rc[j]])
+    return dict(roi_mismatch=int((~same).sum()),
+                max_abs_dbox=float(np.abs(g_box[same] - r_box[same]).max()) if same.any() else None,
+                max_abs_dscore=float(np.abs(g_cls[same] - r_cls[same]).max()) if same.any() else None,
+                survivor_mismatch=len(gs ^ rs), survivors=len(rs))
+
+
+def forced_mismatches(cfg, arg, g, im_info, h, w):
+    """Elements of one GPU frame's hand-written stages that differ from the oracle run on the GPU's own inputs to
+    that stage (0 = every stage bit-exact)."""
+    import oracle
+    npf = lambda t: t.detach().float().cpu().numpy()
+    taps, out = g['taps'], g['out']
+    bad = 0
+    if 'prev' in g:      # key frame
+        warp = oracle.warp_bilinear(npf(g['prev']), npf(taps['flow']), mul=npf(taps['scale_map']))
+        bad += int((warp != npf(taps['warp'])).sum())
+        agg = oracle.aggregate_softmax2(warp, npf(taps['backbone_feat']), npf(taps['nq_logits']))
+        bad += int((agg != npf(out['choose_feat_output'])).sum())
+    else:
+        want = oracle.warp_bilinear(npf(g['key_feat']), npf(g['mv']), add=npf(taps['small_feat']), res=npf(g['res']),
+                                    res_w=arg['rnet_conv0_weight'], res_b=arg['rnet_conv0_bias'])
+        bad += int((want != npf(out['conv_feat'])).sum())
+    rois, _ = oracle.proposal(npf(taps['rpn_cls_prob']), npf(taps['rpn_bbox_pred']), im_info, cfg.network.RPN_FEAT_STRIDE,
+                              cfg.network.ANCHOR_SCALES, cfg.network.ANCHOR_RATIOS, cfg.TEST.RPN_PRE_NMS_TOP_N,
+                              cfg.TEST.RPN_POST_NMS_TOP_N, cfg.TEST.RPN_NMS_THRESH, cfg.TEST.RPN_MIN_SIZE)
+    bad += int((rois != npf(out['rois_output'])).sum())
+    cls_prob, _, bbox = oracle.rfcn_head(npf(taps['cls_map']), npf(taps['box_map']), rois)
+    bad += int((cls_prob != npf(out['cls_prob_reshape_output'])[0]).sum()) + int((bbox != npf(out['bbox_pred_reshape_output'])[0]).sum())
+    wd, wc, _ = oracle.det_postprocess(npf(out['rois_output']), npf(out['bbox_pred_reshape_output'])[0],
+                                       npf(out['cls_prob_reshape_output'])[0], h, w, 1.0, nms_thresh=cfg.TEST.NMS,
+                                       max_per_image=cfg.TEST.max_per_image, class_agnostic=cfg.CLASS_AGNOSTIC)
+    bad += int((wc != g['counts']).sum())
+    for j in range(1, len(wc)):
+        bad += int((wd[j, :wc[j]] != g['dets'][j, :wc[j]]).sum()) if wc[j] == g['counts'][j] else 0
+    return bad
+
+
+def load_traffic(key):
+    try:
+        with open(TRAFFIC_FILE) as f:
+            return json.load(f).get(key, {}).get('hbm_bytes_per_launch')
+    except (OSError, ValueError):
+        return None
 
 
 def main():
@@ -213,10 +367,11 @@ def main():
     torch.cuda.set_device(local_rank)
     torch.backends.cudnn.benchmark = os.environ.get('LSFA_MIOPEN_FIND', '1') == '1'
 
-    from lsfa_amd import hip, tuning
+    from lsfa_amd import tuning
     tuned = None if args.no_tuned_gemms else tuning.enable(tune_missing=True)
     r = Runner(args, rank, device)
     r.prime()
+
     def drain():
         if hasattr(r.fg, 'flush'):
             r.fg.flush()             # the pipeline queues a segment when the next key frame arrives: queue the last one
@@ -253,21 +408,39 @@ def main():
         total_dets = int(r.host_counts.sum().item())
 
     if rank == 0:
-        K = args.interval
-        frames = world * args.steps * K
+        K, B = args.interval, args.clips
+        frames = world * B * args.steps * K
         fh, fw = int(np.ceil(args.height / 16.0)), int(np.ceil(args.width / 16.0))
+        C = r.cfg.network.DFF_FEAT_DIM
+        # ---- roofline: the HBM-bound hand-written kernel (warp), live from HIP events ---------------------
         warp_ms, warp_n = prof['warp_bilinear']
-        bytes_per_launch = WARP_BYTES(1024, fh * fw)
+        bytes_per_launch = warp_bytes(B, C, fh * fw)
         achieved = bytes_per_launch * warp_n / (warp_ms * 1e-3) / 1e9 if warp_ms > 0 else 0.0
+        ops = {k: {"avg_us": round(v[0] * 1e3 / v[1], 2), "launches": v[1], "total_us": round(v[0] * 1e3, 1)}
+               for k, v in prof.items() if v[1]}
+        hand_total = sum(o["total_us"] for o in ops.values()) or 1.0
+        dom = max(ops, key=lambda k: ops[k]["total_us"]) if ops else None
+        roof = {"bound": "hbm", "kernel": "warp_kernel (lsfa_warp_bilinear: MV/flow warp + fused epilogue), %d map(s) per launch" % B,
+                "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": round(achieved / HBM_PEAK_GBS, 4),
+                "traffic": load_traffic("warp_bilinear:N=%d,C=%d,H=%d,W=%d" % (B, C, fh, fw)),
+                "launches": warp_n, "avg_us": round(warp_ms * 1e3 / max(warp_n, 1), 2),
+                "algorithmic_bytes_per_launch": bytes_per_launch,
+                "measured": "HIP events around each launch on its stream, same frames re-issued eagerly right after the "
+                            "timed region (graph replays carry no per-launch events); traffic = FETCH_SIZE x2 + WRITE_SIZE "
+                            "from the rocprofv3 PMC passes under profiles/ for this shape, null if none was taken",
+                "note": "%.0f MB per launch: resident in the 256 MiB Infinity Cache, so this is cache bandwidth against "
+                        "the HBM peak; --maps-per-launch 32 gives the HBM-resident figure" % (bytes_per_launch / 1e6)}
         line = {
             "metric": "frames/sec/GPU at 1000x600 key_interval=10 (whole-job frames/s)",
             "value": round(frames / elapsed, 3), "unit": "frames/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
-            "config": {"workload": "dff_rfcn ResNet-101 LSFA (DCN + FlowNet + Nq + small net + R-FCN), 1 clip per GPU, "
-                                   "key_interval=%d, %dx%d, %s; step = 1 key + %d non-key frames" %
-                                   (K, args.width, args.height, args.dtype, K - 1),
-                       "frames_per_step": K, "ms_per_frame": round(elapsed / (args.steps * K) * 1e3, 3),
+            "config": {"workload": "dff_rfcn ResNet-101 LSFA (DCN + FlowNet + Nq + small net + R-FCN), %d clip%s per GPU%s, "
+                                   "key_interval=%d, %dx%d, %s; step = 1 key + %d non-key frames per clip" %
+                                   (B, "" if B == 1 else "s", "" if B == 1 else " in lock-step (batch axis)", K, args.width,
+                                    args.height, args.dtype, K - 1),
+                       "frames_per_step": K * B, "ms_per_frame": round(elapsed / (args.steps * K * B) * 1e3, 3),
                        "parallelism": "clip-parallel x%d" % world, "detections_last_interval": total_dets,
                        "launch": "eager" if args.no_graph else "hipGraph replay per frame",
                        "gemm_solutions": "library default" if tuned is None else
@@ -276,28 +449,43 @@ def main():
                            "" if args.no_flow_stream else " + FlowNet/tail stream", args.lanes,
                            ", next key frame queued ahead of the segment before it" if args.lookahead else ""))
                        if args.lanes > 0 else "serial"},
-            "roofline": {"bound": "hbm", "kernel": "warp_kernel (lsfa_warp_bilinear: MV/flow warp + fused epilogue)",
-                         "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 4),
-                         "traffic": WARP_TRAFFIC_BYTES_38x63 if (fh, fw) == (38, 63) else None,
-                         "launches": warp_n, "avg_us": round(warp_ms * 1e3 / max(warp_n, 1), 2),
-                         "algorithmic_bytes_per_launch": bytes_per_launch,
-                         "measured": "HIP events around each launch, same frames re-issued eagerly right after the "
-                                     "timed region (graph replays carry no per-launch events)",
-                         "other_ops_avg_us": {k: round(v[0] * 1e3 / max(v[1], 1), 2) for k, v in prof.items() if v[1]}},
+            "roofline": roof,
+            "roofline_handwritten_ops": {
+                "per_op": ops, "dominant_by_time": dom,
+                "dominant_share_of_handwritten_time": round(ops[dom]["total_us"] / hand_total, 3) if dom else None,
+                "note": "one eager interval; proposal / det_postprocess / rfcn_head are latency-bound by construction "
+                        "(0.5 MB, 53 KB, 18 MB of algorithmic bytes): judged in us, not as a fraction of HBM peak"},
         }
+        if args.maps_per_launch > 0:
+            M = args.maps_per_launch
+            mm = r.many_maps_leg(M)
+            w = mm['warp_bilinear (x scale map)']
+            line["roofline_single_map"] = roof
+            line["roofline"] = {"bound": "hbm", "kernel": "warp_kernel, %d maps per launch (x scale map epilogue)" % M,
+                                "achieved": w["achieved_GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                "frac": round(w["achieved_GBps"] / HBM_PEAK_GBS, 4),
+                                "traffic": load_traffic("warp_bilinear:N=%d,C=%d,H=%d,W=%d" % (M, C, fh, fw)),
+                                "launches": w["launches"], "avg_us": w["avg_us"],
+                                "algorithmic_bytes_per_launch": w["algorithmic_bytes_per_launch"],
+                                "measured": "HIP events around each launch, untimed leg after the frame loop; %d MB per launch "
+                                            "(> 256 MiB Infinity Cache: HBM-resident)" % (w["algorithmic_bytes_per_launch"] // 1000000),
+                                "other_kernels_same_size": {k: v for k, v in mm.items() if k != 'warp_bilinear (x scale map)'}}
         if (args.height, args.width) == (600, 1000):
             # algorithmic FLOPs of the dense contractions, key frame 392.0 G, non-key frame 17.3 G
-            gflop = 392.0 + 17.3 * (K - 1)
+            gflop = (392.0 + 17.3 * (K - 1)) * B
             peak = 157.0 if args.dtype == 'f32' else 2500.0
-            tf = gflop * world / (elapsed / args.steps) / 1e3
+            tf = gflop / (elapsed / args.steps) / 1e3
             line["roofline_dense"] = {"bound": "mfma", "scope": "all dense contractions of one interval (library MFMA kernels), "
-                                      "algorithmic FLOPs / step time, per GPU", "achieved": round(tf / world, 1), "peak": peak,
-                                      "unit": "TFLOP/s", "frac": round(tf / world / peak, 4), "gflop_per_step": round(gflop, 1)}
-        if not args.no_cpu_baseline:
+                                      "algorithmic FLOPs / step time, per GPU", "achieved": round(tf, 1), "peak": peak,
+                                      "unit": "TFLOP/s", "frac": round(tf / peak, 4), "gflop_per_step": round(gflop, 1)}
+        if not (args.no_cpu_baseline and args.no_parity):
             try:
-                line["cpu_baseline"] = r.cpu_baseline(args.cpu_budget_s)
-            except Exception as e:  # the baseline is a reported extra; never lose the bench line to it
+                cpu, parity = r.parity_and_cpu_baseline(args.cpu_budget_s, not args.no_parity)
+                if not args.no_cpu_baseline:
+                    line["cpu_baseline"] = cpu
+                if parity is not None:
+                    line["parity"] = parity
+            except Exception as e:  # the checker legs are reported extras; never lose the bench line to them
                 line["cpu_baseline"] = {"value": None, "unit": "frames/s", "cores": int(torch.get_num_threads()),
                                         "kind": "port", "sample": "failed: %r" % (e,)}
         print(json.dumps(line))

@@ -107,6 +107,13 @@ int lsfa_warp_bilinear(const float* feat, int feat_n, const float* flow,
 int lsfa_aggregate_softmax2(const float* a, const float* b, const float* logits,
                             int C, int H, int W, float* out, void* stream);
 
+/* N maps per launch: a, b, out (N, C, H, W); logits (2, N, H, W) = the Nq convolutions' output for
+ * Concat(warp x N, cur x N) on the batch axis (:95), row n weighting a[n], row N+n weighting b[n].
+ * N = 1 is lsfa_aggregate_softmax2.  Used when several clips advance together (BASELINE configs[2]) and for
+ * the HBM-resident roofline measurement (configs[4]). */
+int lsfa_aggregate_softmax2_batched(const float* a, const float* b, const float* logits,
+                                    int N, int C, int H, int W, float* out, void* stream);
+
 /* Fgfa variant: weights from cosine similarity of 2 embeddings
  * Replaces: compute_weight + softmax + tile/mul/add  resnet_v1_101_flownet_rfcn.py:111-116, :136-147
  * emb_cur, emb_warp (1,E,H,W); a = warped feature, b = current feature (1,C,H,W).

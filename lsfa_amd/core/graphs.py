@@ -23,9 +23,31 @@ from lsfa_amd import hip
 from lsfa_amd.core import streams
 
 
+def _alloc_post(batch, ncls, R, device):
+    """Detection output buffers of one frame slot: (B, ncls, R, 5) f64, (B, ncls) i32, (B, ncls, R) i32.
+    Returns (all, public) where `public` drops the batch axis when B == 1 (the shapes callers had before
+    several clips could advance together)."""
+    full = (torch.zeros((batch, ncls, R, 5), dtype=torch.float64, device=device),
+            torch.zeros((batch, ncls), dtype=torch.int32, device=device),
+            torch.full((batch, ncls, R), -1, dtype=torch.int32, device=device))
+    return full, (tuple(t[0] for t in full) if batch == 1 else full)
+
+
+def _post_all(out, full, cfg, h, w, scale, thresh):
+    """lsfa_det_postprocess per image of the batch (rois of image b are rows [b*R, (b+1)*R), MultiProposal's layout)."""
+    B = full[0].shape[0]
+    R = out['rois_output'].shape[0] // B
+    bbox, cls = out['bbox_pred_reshape_output'].reshape(B * R, -1), out['cls_prob_reshape_output'].reshape(B * R, -1)
+    for b in range(B):
+        sl = slice(b * R, (b + 1) * R)
+        hip.det_postprocess(out['rois_output'][sl], bbox[sl], cls[sl], h, w, scale, score_thresh=thresh,
+                            nms_thresh=cfg.TEST.NMS, max_per_image=cfg.TEST.max_per_image,
+                            class_agnostic=cfg.CLASS_AGNOSTIC, out=tuple(t[b] for t in full))
+
+
 class FrameGraphs(object):
     def __init__(self, key_exec, cur_exec, cfg, height, width, device, thresh=1e-4, use_graphs=True, prefetch=True,
-                 feat_shared=None, taps=False):
+                 feat_shared=None, taps=False, batch=1):
         """feat_shared: a caller-owned (1, DFF_FEAT_DIM, h, w) buffer the non-key graph reads the key feature
         from; such an instance is a non-key "lane" of a FramePipeline and never runs key frames.
         taps=True (parity tests): the stage outputs of the last key / non-key frame stay readable in
@@ -40,25 +62,24 @@ class FrameGraphs(object):
         self.use_graphs = use_graphs
         self.h, self.w = height, width
         self.thresh = thresh
+        self.batch = B = int(batch)        # clips advancing in lock-step, one image of each per frame (BASELINE configs[2])
         fh, fw = -(-height // 16), -(-width // 16)
         dim = cfg.network.DFF_FEAT_DIM
         dev = self.device
         z = lambda *s: torch.zeros(s, device=dev, dtype=torch.float32)
         # static inputs
-        self.data = z(1, 3, height, width)
-        self.data_key_old = z(1, 3, height, width)
-        self.feat_old = z(1, dim, fh, fw)
-        self.mv = z(1, 2, fh, fw)
-        self.res = z(1, 3, fh, fw)
-        self.im_info = torch.tensor([[height, width, 1.0]], device=dev, dtype=torch.float32)
+        self.data = z(B, 3, height, width)
+        self.data_key_old = z(B, 3, height, width)
+        self.feat_old = z(B, dim, fh, fw)
+        self.mv = z(B, 2, fh, fw)
+        self.res = z(B, 3, fh, fw)
+        self.im_info = torch.tensor([[height, width, 1.0]] * B, device=dev, dtype=torch.float32)
         R, ncls = cfg.TEST.RPN_POST_NMS_TOP_N, cfg.dataset.NUM_CLASSES
-        self.post_bufs = (torch.zeros((ncls, R, 5), dtype=torch.float64, device=dev),
-                          torch.zeros(ncls, dtype=torch.int32, device=dev),
-                          torch.full((ncls, R), -1, dtype=torch.int32, device=dev))
+        self._post_full, self.post_bufs = _alloc_post(B, ncls, R, dev)
         self.prefetch = prefetch and cfg.network.add_small_net
-        self.data_next = z(1, 3, height, width)        # image of the frame after the current one
-        self.small_cur = z(1, dim, fh, fw)             # small-net feature of the current non-key frame
-        self.small_next = z(1, dim, fh, fw)
+        self.data_next = z(B, 3, height, width)        # image of the frame after the current one
+        self.small_cur = z(B, dim, fh, fw)             # small-net feature of the current non-key frame
+        self.small_next = z(B, dim, fh, fw)
         self.side = torch.cuda.Stream(device=dev) if self.prefetch else None
         self.feat = None            # the key graph's output feature (static address once captured)
         self.key_graph = self.cur_graph = None
@@ -66,11 +87,7 @@ class FrameGraphs(object):
 
     # ---- the two launch sequences -------------------------------------------------------
     def _post(self, out):
-        cfg = self.cfg
-        return hip.det_postprocess(out['rois_output'], out['bbox_pred_reshape_output'][0], out['cls_prob_reshape_output'][0],
-                                   self.h, self.w, self.scale, score_thresh=self.thresh, nms_thresh=cfg.TEST.NMS,
-                                   max_per_image=cfg.TEST.max_per_image, class_agnostic=cfg.CLASS_AGNOSTIC,
-                                   out=self.post_bufs)
+        _post_all(out, self._post_full, self.cfg, self.h, self.w, self.scale, self.thresh)
 
     def _fork_small_next(self):
         """side stream: small-net feature of the next frame (reads data_next, writes small_next)."""
@@ -223,22 +240,21 @@ class KeyLane(object):
     only images; `agg` (flow warp of the previous key feature x scale map, aggregation) produces the
     frame's feature; `tail` (RPN, Proposal, R-FCN head, detection post-processing) consumes it."""
 
-    def __init__(self, key_exec, cfg, height, width, device, thresh, use_graphs, taps=False):
+    def __init__(self, key_exec, cfg, height, width, device, thresh, use_graphs, taps=False, batch=1):
         self.key, self.cfg, self.device, self.use_graphs = key_exec, cfg, device, use_graphs
+        B = int(batch)
         self.want_taps = taps
         self.taps = {}         # taps=True: stage outputs of this buffer set's last frame (static under replay)
         self.out = None
         self.h, self.w, self.thresh, self.scale = height, width, thresh, 1.0
         fh, fw = -(-height // 16), -(-width // 16)
         z = lambda *s: torch.zeros(s, device=device, dtype=torch.float32)
-        self.data = z(1, 3, height, width)
-        self.data_key_old = z(1, 3, height, width)
-        self.feat_old = z(1, cfg.network.DFF_FEAT_DIM, fh, fw)
-        self.im_info = torch.tensor([[height, width, 1.0]], device=device, dtype=torch.float32)
+        self.data = z(B, 3, height, width)
+        self.data_key_old = z(B, 3, height, width)
+        self.feat_old = z(B, cfg.network.DFF_FEAT_DIM, fh, fw)
+        self.im_info = torch.tensor([[height, width, 1.0]] * B, device=device, dtype=torch.float32)
         R, ncls = cfg.TEST.RPN_POST_NMS_TOP_N, cfg.dataset.NUM_CLASSES
-        self.post_bufs = (torch.zeros((ncls, R, 5), dtype=torch.float64, device=device),
-                          torch.zeros(ncls, dtype=torch.int32, device=device),
-                          torch.full((ncls, R), -1, dtype=torch.int32, device=device))
+        self._post_full, self.post_bufs = _alloc_post(B, ncls, R, device)
         self.conv_feat = self.flow_out = None
         self.flow_graph = None
         self.feat = None
@@ -269,9 +285,7 @@ class KeyLane(object):
         cfg = self.cfg
         out = self._tapped(lambda: self.key.key_heads(self.feat, self.im_info))
         self.out = out if self.want_taps else None
-        hip.det_postprocess(out['rois_output'], out['bbox_pred_reshape_output'][0], out['cls_prob_reshape_output'][0],
-                            self.h, self.w, self.scale, score_thresh=self.thresh, nms_thresh=cfg.TEST.NMS,
-                            max_per_image=cfg.TEST.max_per_image, class_agnostic=cfg.CLASS_AGNOSTIC, out=self.post_bufs)
+        _post_all(out, self._post_full, cfg, self.h, self.w, self.scale, self.thresh)
 
     def capture(self, warmup=3):
         if not self.use_graphs:
@@ -357,18 +371,22 @@ class FramePipeline(object):
     """
 
     def __init__(self, key_exec, cur_exec, cfg, height, width, device, thresh=1e-4, use_graphs=True, lanes=2,
-                 flow_stream=True, lookahead=False, taps=False):
+                 flow_stream=True, lookahead=False, taps=False, batch=1):
+        """batch > 1: that many clips advance in lock-step — every tensor handed to first_frame / key_frame /
+        cur_frame carries one image (motion-vector field, residual) per clip on its batch axis, and the
+        detection buffers gain a leading clip axis."""
         dev = torch.device(device)
+        self.batch = B = int(batch)
         self.device, self.cfg, self.key_exec = dev, cfg, key_exec
         self.h, self.w, self.thresh, self.scale = height, width, thresh, 1.0
         self.lookahead = lookahead
         fh, fw = -(-height // 16), -(-width // 16)
         dim = cfg.network.DFF_FEAT_DIM
-        self.feat_cur = torch.zeros((1, dim, fh, fw), device=dev, dtype=torch.float32)   # what the non-key lanes read
-        self.feat0 = torch.zeros((1, dim, fh, fw), device=dev, dtype=torch.float32)      # feature of a clip's frame 0
-        self.klanes = [KeyLane(key_exec, cfg, height, width, dev, thresh, use_graphs, taps) for _ in range(2)]
+        self.feat_cur = torch.zeros((B, dim, fh, fw), device=dev, dtype=torch.float32)   # what the non-key lanes read
+        self.feat0 = torch.zeros((B, dim, fh, fw), device=dev, dtype=torch.float32)      # feature of a clip's frame 0
+        self.klanes = [KeyLane(key_exec, cfg, height, width, dev, thresh, use_graphs, taps, B) for _ in range(2)]
         self.lanes = [FrameGraphs(key_exec, cur_exec, cfg, height, width, dev, thresh, use_graphs, prefetch=False,
-                                  feat_shared=self.feat_cur, taps=taps) for _ in range(lanes)]
+                                  feat_shared=self.feat_cur, taps=taps, batch=B) for _ in range(lanes)]
         want = 1 + (1 if flow_stream else 0) + lanes
         chosen, aliased = streams.concurrent_streams(want, dev)
         self.hw_queues = len(chosen)
@@ -409,7 +427,7 @@ class FramePipeline(object):
         self.scale = float(im_scale)
         for g in self.klanes + self.lanes:
             g.scale = float(im_scale)
-            g.im_info[0, 2] = float(im_scale)
+            g.im_info[:, 2] = float(im_scale)
 
     def _all_streams(self):
         return [self.s_key] + self.s_lane + ([self.s_flow] if self.s_flow is not None else [])
@@ -433,12 +451,9 @@ class FramePipeline(object):
         conv_feat, _, _ = self.key_exec.key_front(data, None)
         out = self.key_exec.key_back(conv_feat, None, None, None, lane.im_info)
         if not hasattr(self, '_first_post'):
-            self._first_post = tuple(torch.zeros_like(b) for b in lane.post_bufs)
-            self._first_post[2].fill_(-1)
-        hip.det_postprocess(out['rois_output'], out['bbox_pred_reshape_output'][0], out['cls_prob_reshape_output'][0],
-                            self.h, self.w, self.scale, score_thresh=self.thresh, nms_thresh=cfg.TEST.NMS,
-                            max_per_image=cfg.TEST.max_per_image, class_agnostic=cfg.CLASS_AGNOSTIC,
-                            out=self._first_post)
+            self._first_full, self._first_post = _alloc_post(self.batch, cfg.dataset.NUM_CLASSES, cfg.TEST.RPN_POST_NMS_TOP_N,
+                                                             self.device)
+        _post_all(out, self._first_full, cfg, self.h, self.w, self.scale, self.thresh)
         self.feat0.copy_(out['choose_feat_output'])
         self._feat_latest, self._prev_key_data = self.feat0, data
         self._publish_from_main()

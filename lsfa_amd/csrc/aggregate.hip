@@ -47,6 +47,8 @@ __device__ __forceinline__ void softmax2(float l0, float l1, float& w0, float& w
 // CPB (channels per thread, compile time): all 2*CPB operand loads are issued BEFORE the softmax —
 // the two correctly rounded exps are a ~1 us dependent chain on the fp64 unit, and with the loads
 // behind it every wave paid logits latency + exp chain + operand latency in series.
+// Batched form (gridDim.z = N maps per launch, BASELINE configs[4]): a, b, out are (N, C, HW); the logits are
+// (2, N, HW) — what the Nq convolutions produce for Concat(warp x N, cur x N) on the batch axis.
 template <int VEC, int CPB>
 __global__ __launch_bounds__(kThreads) void combine_kernel(const float* __restrict__ a,
                                                            const float* __restrict__ b,
@@ -55,9 +57,11 @@ __global__ __launch_bounds__(kThreads) void combine_kernel(const float* __restri
   const int c0 = blockIdx.y * CPB;
   const int p0 = (blockIdx.x * kThreads + threadIdx.x) * VEC;
   if (p0 >= HW) return;
+  const int n = blockIdx.z, N = gridDim.z;
+  a += (size_t)n * C * HW; b += (size_t)n * C * HW; out += (size_t)n * C * HW;
   float l0[VEC], l1[VEC], w0[VEC], w1[VEC];
-  load_vec<VEC>(logits + p0, l0);
-  load_vec<VEC>(logits + HW + p0, l1);
+  load_vec<VEC>(logits + (size_t)n * HW + p0, l0);
+  load_vec<VEC>(logits + (size_t)(N + n) * HW + p0, l1);
   float va[CPB][VEC], vb[CPB][VEC];
 #pragma unroll
   for (int k = 0; k < CPB; ++k)
@@ -174,16 +178,16 @@ __global__ __launch_bounds__(kThreads) void cosine_tail_kernel(const float* __re
 
 inline bool aligned(const void* p, size_t a) { return ((uintptr_t)p % a) == 0; }
 
-int launch_combine(const float* a, const float* b, const float* logits, int C, int HW, float* out, hipStream_t s) {
+int launch_combine(const float* a, const float* b, const float* logits, int N, int C, int HW, float* out, hipStream_t s) {
   using namespace lsfa;
   int vec = (HW % 4 == 0) ? 4 : (HW % 2 == 0) ? 2 : 1;
   const size_t al = sizeof(float) * vec;
   if (!(aligned(a, al) && aligned(b, al) && aligned(logits, al) && aligned(out, al))) vec = 1;
   const int gx = ceil_div(HW, kThreads * vec);
   // 8 channels per thread amortise the softmax; fall back to 4 when that leaves too few workgroups
-  const bool c8 = (long)gx * ceil_div(C, 8) >= 1024;
+  const bool c8 = (long)gx * ceil_div(C, 8) * N >= 1024;
   const int cpb = c8 ? 8 : 4;
-  dim3 grid(gx, ceil_div(C, cpb));
+  dim3 grid(gx, ceil_div(C, cpb), N);
 #define LSFA_COMBINE(V)                                                                                          \
   if (c8) hipLaunchKernelGGL((combine_kernel<V, 8>), grid, dim3(kThreads), 0, s, a, b, logits, C, HW, out);      \
   else hipLaunchKernelGGL((combine_kernel<V, 4>), grid, dim3(kThreads), 0, s, a, b, logits, C, HW, out);
@@ -203,8 +207,20 @@ extern "C" int lsfa_aggregate_softmax2(const float* a, const float* b, const flo
   LSFA_REQUIRE(C > 0 && H > 0 && W > 0, "lsfa_aggregate_softmax2: bad shape C=%d H=%d W=%d", C, H, W);
   hipStream_t s = (hipStream_t)stream;
   ProfScope prof(LSFA_OP_AGG, s);
-  launch_combine(a, b, logits, C, H * W, out, s);
+  launch_combine(a, b, logits, 1, C, H * W, out, s);
   LSFA_LAUNCH_CHECK("lsfa_aggregate_softmax2");
+  return LSFA_OK;
+}
+
+extern "C" int lsfa_aggregate_softmax2_batched(const float* a, const float* b, const float* logits, int N, int C, int H,
+                                               int W, float* out, void* stream) {
+  using namespace lsfa;
+  LSFA_REQUIRE(a && b && logits && out, "lsfa_aggregate_softmax2_batched: NULL argument");
+  LSFA_REQUIRE(N > 0 && N <= 65535 && C > 0 && H > 0 && W > 0, "lsfa_aggregate_softmax2_batched: bad shape N=%d C=%d H=%d W=%d", N, C, H, W);
+  hipStream_t s = (hipStream_t)stream;
+  ProfScope prof(LSFA_OP_AGG, s);
+  launch_combine(a, b, logits, N, C, H * W, out, s);
+  LSFA_LAUNCH_CHECK("lsfa_aggregate_softmax2_batched");
   return LSFA_OK;
 }
 
@@ -225,7 +241,7 @@ extern "C" int lsfa_aggregate_cosine(const float* a, const float* b, const float
   ProfScope prof(LSFA_OP_AGG, s);
   float* scratch = out + (size_t)(C - 2) * HW;
   hipLaunchKernelGGL(cosine_logits_kernel, dim3(ceil_div(HW, kCosPx)), dim3(kThreads), 0, s, emb_warp, emb_cur, E, HW, scratch);
-  launch_combine(a, b, scratch, C - 2, HW, out, s);
+  launch_combine(a, b, scratch, 1, C - 2, HW, out, s);
   hipLaunchKernelGGL(cosine_tail_kernel, dim3(ceil_div(HW, kThreads)), dim3(kThreads), 0, s, a, b, C, HW, out);
   LSFA_LAUNCH_CHECK("lsfa_aggregate_cosine");
   return LSFA_OK;

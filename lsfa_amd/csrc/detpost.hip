@@ -3,7 +3,8 @@
 // per-class score threshold + greedy NMS (tester.py:265-272, lib/nms/nms.py:37-74) and the
 // max_per_image cap (tester.py:274-281).  The reference runs 30 numpy NMS calls per frame on
 // the host after a blocking D2H copy; here one workgroup per class does filter -> decode ->
-// rank-sort -> 64-bit IoU mask in LDS -> sweep, then a single small workgroup applies the cap.
+// rank -> 64-bit suppression mask in LDS (no division) -> ballot-fixpoint sweep, then a single small
+// workgroup applies the cap.
 // Arithmetic is float64 like the numpy reference (fp64 is full rate on CDNA4), following
 // oracle orc_det_postprocess / orc_nms_f64 / orc_bbox_pred_clip operation for operation.
 #include "common.h"
@@ -42,14 +43,39 @@ __global__ __launch_bounds__(kThreads) void bbox_pred_clip_kernel(const float* _
 }
 
 // grid (ncls); block kClassThreads (16 waves).  LDS carve (all sized by R, offsets multiples of 8):
-//   box[R][4] f64 | score[R] f64 | mask[R][Wd] u64 | src[R] i32 | order[R] i32 | kept[R] i32 | misc
+//   box[R][4] f64 (threshold order) | score[R] f64 | sbox[R][4] f64 (score order) | sarea[R] f64 |
+//   mask[R][Wd] u64 | colw[R] u64 | src[R] i32 | order[R] i32 | rank[R] i32 | kept[R] i32 | misc
+//
+// Phases: threshold + ordered compaction -> rank by (score desc, roi index asc): the m^2 comparisons are
+// split 4 ways per candidate over all 16 waves and summed with LDS atomics -> boxes re-laid in score order
+// -> suppression mask over sorted positions, all 16 waves, WITHOUT the float64 division (exact: see
+// suppresses()) and with the transposed words of the diagonal 64x64 blocks built alongside -> one wave
+// sweeps the 64-position blocks, each resolved as a ballot fixpoint (a handful of steps) instead of a
+// 64-step scalar loop.
 constexpr int kClassThreads = 1024;
 constexpr int kClassWaves = kClassThreads / 64;
+constexpr int kRankSplit = 4;
+
+// numpy keeps `ovr <= thresh` (lib/nms/nms.py:71) with ovr = fl64(inter / uni): the pair suppresses when
+// NOT (ovr <= thresh).  Decided without dividing: v = inter - thresh*uni and d = fma(-thresh, uni, inter)
+// = fl(v) have the same sign; v <= 0 => quotient <= thresh (rounding is monotone); v >= thresh*uni*2^-52
+// => the exact quotient is at least the double after thresh => suppresses; d >= thresh*uni*2^-51
+// implies that.  The sliver in between and non-positive / NaN unions take the division.
+struct NmsTest64 { double thresh, thresh_eps; int fast; };
+
+__device__ __forceinline__ bool suppresses(double inter, double uni, const NmsTest64& t) {
+  const double d = fma(-t.thresh, uni, inter);
+  const bool pos = d > 0.0, clear = d >= t.thresh_eps * uni;
+  const bool unsure = !t.fast || !(uni > 0.0) || (pos && !clear);
+  bool r = pos && clear;
+  if (__builtin_expect(unsure, 0)) r = !(inter / uni <= t.thresh);
+  return r;
+}
 
 __global__ __launch_bounds__(kClassThreads) void det_class_kernel(
     const float* __restrict__ rois, const float* __restrict__ deltas, const float* __restrict__ probs, int R,
     int ncls, int nreg, int class_agnostic, double im_h, double im_w, double scale, double score_thresh,
-    double nms_thresh, double* __restrict__ dets, int* __restrict__ counts, int* __restrict__ keep_idx) {
+    NmsTest64 nms, double* __restrict__ dets, int* __restrict__ counts, int* __restrict__ keep_idx) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int j = blockIdx.x;
   const int tid = threadIdx.x;
@@ -57,14 +83,19 @@ __global__ __launch_bounds__(kClassThreads) void det_class_kernel(
   const int Wd = (R + 63) / 64;
   double* box = reinterpret_cast<double*>(smem);
   double* score = box + (size_t)R * 4;
-  uint64_t* mask = reinterpret_cast<uint64_t*>(score + R);
-  int* src = reinterpret_cast<int*>(mask + (size_t)R * Wd);
+  double* sbox = score + R;
+  double* sarea = sbox + (size_t)R * 4;
+  uint64_t* mask = reinterpret_cast<uint64_t*>(sarea + R);
+  uint64_t* colw = mask + (size_t)R * Wd;
+  int* src = reinterpret_cast<int*>(colw + R);
   int* order = src + R;
-  int* kept = order + R;
+  int* rank = order + R;
+  int* kept = rank + R;
   int* misc = kept + R;  // [0] running count, [1..16] wave sums
 
   // 1. threshold + in-order compaction (np.where(scores[:, j] > thresh), tester.py:267)
   if (tid == 0) misc[0] = 0;
+  for (int i = tid; i < R; i += kClassThreads) { rank[i] = 0; colw[i] = 0; }
   __syncthreads();
   const int lane = tid & 63, wid = tid >> 6;
   for (int r0 = 0; r0 < R; r0 += kClassThreads) {
@@ -94,73 +125,79 @@ __global__ __launch_bounds__(kClassThreads) void det_class_kernel(
   const int m = misc[0];
   if (m == 0) { if (tid == 0) counts[j] = 0; return; }
 
-  // 2. rank sort: score descending, ties by ascending candidate (= roi) index
-  for (int i = tid; i < m; i += kClassThreads) {
+  // 2. rank: score descending, ties by ascending candidate (= roi) index; candidate i's comparisons are cut
+  //    into kRankSplit slices so that m * kRankSplit threads work
+  const int slice = (m + kRankSplit - 1) / kRankSplit;
+  for (int t = tid; t < m * kRankSplit; t += kClassThreads) {
+    const int i = t / kRankSplit, q = t - i * kRankSplit;
     const double si = score[i];
-    int rank = 0;
-    for (int k = 0; k < m; ++k) {
+    const int k0 = q * slice, k1 = min(k0 + slice, m);
+    int before = 0;
+    for (int k = k0; k < k1; ++k) {
       const double sk = score[k];
-      rank += (sk > si) || (sk == si && k < i);
+      before += (sk > si) || (sk == si && k < i);
     }
-    order[rank] = i;
+    if (before) atomicAdd(&rank[i], before);
   }
   __syncthreads();
-
-  // 3. suppression mask over sorted positions: bit b of mask[a][w] <=> position 64w+b > a and
-  //    NOT (ovr <= thresh)  (nms.py:71 keeps `ovr <= thresh`).  One (row, 16-column strip) per
-  //    thread so that all 16 waves share the fp64 divisions of the upper triangle.
+  for (int i = tid; i < m; i += kClassThreads) {
+    const int p = rank[i];
+    order[p] = i;
+    const double x1 = box[i * 4], y1 = box[i * 4 + 1], x2 = box[i * 4 + 2], y2 = box[i * 4 + 3];
+    sbox[p * 4] = x1; sbox[p * 4 + 1] = y1; sbox[p * 4 + 2] = x2; sbox[p * 4 + 3] = y2;
+    sarea[p] = (x2 - x1 + 1) * (y2 - y1 + 1);
+  }
   for (int t = tid; t < m * Wd; t += kClassThreads) mask[t] = 0;
   __syncthreads();
+
+  // 3. suppression mask over sorted positions: bit b of mask[a][w] <=> position 64w+b > a and the pair
+  //    suppresses; colw[b] collects, for the diagonal blocks, the earlier positions of b's own block that
+  //    suppress b.  One (row, 16-column strip) per thread.
   const int strips = Wd * 4;
   for (int t = tid; t < m * strips; t += kClassThreads) {
     const int a = t / strips, st = t - a * strips;
     const int c0 = st * 16;
     if (c0 + 15 <= a || c0 >= m) continue;
-    const int ia = order[a];
-    const double ax1 = box[ia * 4], ay1 = box[ia * 4 + 1], ax2 = box[ia * 4 + 2], ay2 = box[ia * 4 + 3];
-    const double area_a = (ax2 - ax1 + 1) * (ay2 - ay1 + 1);
+    const double ax1 = sbox[a * 4], ay1 = sbox[a * 4 + 1], ax2 = sbox[a * 4 + 2], ay2 = sbox[a * 4 + 3];
+    const double area_a = sarea[a];
     const int b0 = max(c0, a + 1), b1 = min(c0 + 16, m);
     uint64_t bits = 0;
     for (int b = b0; b < b1; ++b) {
-      const int ib = order[b];
-      const double bx1 = box[ib * 4], by1 = box[ib * 4 + 1], bx2 = box[ib * 4 + 2], by2 = box[ib * 4 + 3];
-      const double xx1 = fmax(ax1, bx1), yy1 = fmax(ay1, by1);
-      const double xx2 = fmin(ax2, bx2), yy2 = fmin(ay2, by2);
+      const double xx1 = fmax(ax1, sbox[b * 4]), yy1 = fmax(ay1, sbox[b * 4 + 1]);
+      const double xx2 = fmin(ax2, sbox[b * 4 + 2]), yy2 = fmin(ay2, sbox[b * 4 + 3]);
       const double ww = fmax(0.0, xx2 - xx1 + 1), hh = fmax(0.0, yy2 - yy1 + 1);
       const double inter = ww * hh;
-      const double area_b = (bx2 - bx1 + 1) * (by2 - by1 + 1);
-      const double ovr = inter / (area_a + area_b - inter);
-      if (!(ovr <= nms_thresh)) bits |= 1ULL << (b & 63);
+      if (suppresses(inter, area_a + sarea[b] - inter, nms)) {
+        bits |= 1ULL << (b & 63);
+        if ((b >> 6) == (a >> 6)) atomicOr(reinterpret_cast<unsigned long long*>(&colw[b]), 1ULL << (a & 63));
+      }
     }
     if (bits) atomicOr(reinterpret_cast<unsigned long long*>(&mask[(size_t)a * Wd + (c0 >> 6)]), (unsigned long long)bits);
   }
   __syncthreads();
 
-  // 4. sweep by wave 0 in 64-position blocks: lane w (< Wd) holds word w of the removed set;
-  //    a block is resolved on scalars from its diagonal words, then the survivors' rows are ORed in
+  // 4. sweep by wave 0 in 64-position blocks: lane w (< Wd) holds word w of the removed set; a block is the
+  //    fixpoint G(k) = alive(k) && no earlier member of G suppresses k; the survivors' rows are ORed in
   int nk = 0;
   if (wid == 0) {
     uint64_t remv = 0;
     const int nblk = (m + 63) / 64;
     for (int b = 0; b < nblk; ++b) {
       const int base = b * 64, nb = min(64, m - base);
-      const uint64_t diag = lane < nb ? mask[(size_t)(base + lane) * Wd + b] : 0ULL;
-      uint32_t cur_lo = __builtin_amdgcn_readlane((uint32_t)remv, b);
-      uint32_t cur_hi = __builtin_amdgcn_readlane((uint32_t)(remv >> 32), b);
-      const uint32_t d_lo = (uint32_t)diag, d_hi = (uint32_t)(diag >> 32);
-      uint32_t k_lo = 0, k_hi = 0;
-      for (int k = 0; k < nb; ++k) {
-        const bool removed = k < 32 ? ((cur_lo >> k) & 1u) : ((cur_hi >> (k - 32)) & 1u);
-        if (!removed) {
-          if (k < 32) k_lo |= 1u << k; else k_hi |= 1u << (k - 32);
-          cur_lo |= __builtin_amdgcn_readlane(d_lo, k);
-          cur_hi |= __builtin_amdgcn_readlane(d_hi, k);
-        }
+      const uint64_t cw = lane < nb ? colw[base + lane] : 0ULL;
+      const uint32_t cur_lo = __builtin_amdgcn_readlane((uint32_t)remv, b);
+      const uint32_t cur_hi = __builtin_amdgcn_readlane((uint32_t)(remv >> 32), b);
+      const uint64_t cur = ((uint64_t)cur_hi << 32) | cur_lo;
+      const bool alive = lane < nb && !((cur >> lane) & 1ULL);
+      uint64_t G = __ballot(alive);
+      for (int it = 0; it < 64 && G; ++it) {
+        const uint64_t G2 = __ballot(alive && (cw & G) == 0);
+        if (G2 == G) break;
+        G = G2;
       }
-      const uint64_t kb = ((uint64_t)k_hi << 32) | k_lo;
-      if ((kb >> lane) & 1ULL) kept[nk + __popcll(kb & ((1ULL << lane) - 1ULL))] = order[base + lane];
-      nk += __popcll(kb);
-      uint64_t rem = kb;
+      if ((G >> lane) & 1ULL) kept[nk + __popcll(G & ((1ULL << lane) - 1ULL))] = order[base + lane];
+      nk += __popcll(G);
+      uint64_t rem = G;
       while (rem) {
         int ks[8];
 #pragma unroll
@@ -293,7 +330,7 @@ __global__ __launch_bounds__(1024) void det_cap_kernel(double* __restrict__ dets
 
 size_t class_lds_bytes(int R) {
   const size_t Wd = (size_t)(R + 63) / 64;
-  return (size_t)R * 4 * 8 + (size_t)R * 8 + (size_t)R * Wd * 8 + (size_t)R * 4 * 3 + 128;
+  return (size_t)R * 4 * 8 * 2 + (size_t)R * 8 * 2 + (size_t)R * Wd * 8 + (size_t)R * 8 + (size_t)R * 4 * 4 + 128;
 }
 
 }  // namespace
@@ -335,8 +372,12 @@ extern "C" int lsfa_det_postprocess(const float* rois, const float* deltas, cons
     (void)hipFuncSetAttribute((const void*)det_class_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
   });
   ProfScope prof(LSFA_OP_DET, s);
+  NmsTest64 nms;
+  nms.thresh = nms_thresh;
+  nms.thresh_eps = nms_thresh * 4.440892098500626e-16;   // 2^-51
+  nms.fast = (nms_thresh > 1e-300 && nms_thresh < 1e300) ? 1 : 0;
   hipLaunchKernelGGL(det_class_kernel, dim3(ncls), dim3(kClassThreads), lds, s, rois, deltas, probs, R, ncls, nreg,
-                     class_agnostic, im_h, im_w, scale, score_thresh, nms_thresh, dets, counts, keep_idx);
+                     class_agnostic, im_h, im_w, scale, score_thresh, nms, dets, counts, keep_idx);
   if (max_per_image > 0)
     hipLaunchKernelGGL(det_cap_kernel, dim3(1), dim3(1024), 0, s, dets, counts, keep_idx, R, ncls, max_per_image);
   LSFA_LAUNCH_CHECK("lsfa_det_postprocess");

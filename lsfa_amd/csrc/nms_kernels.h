@@ -88,7 +88,8 @@ static __global__ __launch_bounds__(256) void nms_mask_kernel(const float* __res
                                                               IouTest t, uint64_t* __restrict__ mask_all,
                                                               uint64_t* __restrict__ diagT_all, int col_blocks) {
   const int lane = threadIdx.x & 63;
-  const int tile = blockIdx.x * 4 + (threadIdx.x >> 6);
+  // wave-uniform, and the compiler is told so: the tile indices and the `diag` branch stay scalar
+  const int tile = blockIdx.x * 4 + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   if (tile >= nms_tile_count(col_blocks)) return;
   // tile -> (rb <= cb), tiles enumerated column by column: tile = cb*(cb+1)/2 + rb
   int cb = (int)((sqrtf(8.0f * (float)tile + 1.0f) - 1.0f) * 0.5f);
@@ -177,7 +178,7 @@ static __global__ __launch_bounds__(256) void nms_mask_f64_kernel(const double* 
                                                                   IouTest64 t, uint64_t* __restrict__ mask,
                                                                   uint64_t* __restrict__ diagT, int col_blocks) {
   const int lane = threadIdx.x & 63;
-  const int tile = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int tile = blockIdx.x * 4 + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   if (tile >= nms_tile_count(col_blocks)) return;
   int cb = (int)((sqrtf(8.0f * (float)tile + 1.0f) - 1.0f) * 0.5f);
   while ((cb + 1) * (cb + 2) / 2 <= tile) ++cb;

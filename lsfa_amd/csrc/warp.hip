@@ -33,7 +33,7 @@ extern "C" int lsfa_warp_bilinear(const float* feat, int feat_n, const float* fl
   LSFA_REQUIRE(feat && flow && out, "lsfa_warp_bilinear: feat, flow and out must be non-NULL");
   LSFA_REQUIRE(N > 0 && C > 0 && H > 1 && W > 1, "lsfa_warp_bilinear: bad shape N=%d C=%d H=%d W=%d", N, C, H, W);
   LSFA_REQUIRE(feat_n == 1 || feat_n == N, "lsfa_warp_bilinear: feat batch %d must be 1 or N=%d", feat_n, N);
-  LSFA_REQUIRE(N <= 65535, "lsfa_warp_bilinear: N=%d exceeds grid.z", N);
+  LSFA_REQUIRE((long)N * C * ((H * W + 63) / 64) < (1L << 31), "lsfa_warp_bilinear: N=%d C=%d H=%d W=%d has too many work items", N, C, H, W);
   if (res) {
     LSFA_REQUIRE(res_w && res_b, "lsfa_warp_bilinear: res given without res_w/res_b");
     if (res_c < 1 || res_c > kResMax) {
@@ -47,14 +47,22 @@ extern "C" int lsfa_warp_bilinear(const float* feat, int feat_n, const float* fl
   const size_t al = sizeof(float) * vec;
   if (!(aligned(flow, al) && aligned(mul, al) && aligned(add, al) && aligned(res, al) && aligned(out, al))) vec = 1;
   const warp::Args a = {feat, feat_n, flow, N, C, H, W, mul, add, res, res_c, res_w, res_b, out};
-  // channel run per wave: 8 amortises the tap computation and puts 8 x (taps + operand) loads in flight
-  // per wave; small problems take 4 so that the chip still gets a few waves per SIMD
-  const long items8 = (long)N * ceil_div(C, 8) * warp::pixel_tiles(HW, vec);
-  const bool run8 = items8 >= 2048;
+  // channel run per wave: the largest of 8 / 4 / 2 / 1 that divides C (the kernel has no per-channel guards);
+  // small problems halve it so that the chip still gets a few waves per SIMD
+  int cpr = (C % 8 == 0) ? 8 : (C % 4 == 0) ? 4 : 1;
+  if (cpr == 8 && (long)N * (C / 8) * warp::pixel_tiles(HW, vec) < 2048) cpr = 4;
+  if (cpr == 4 && (long)N * (C / 4) * warp::pixel_tiles(HW, vec) < 1024) cpr = 1;
   ProfScope prof(LSFA_OP_WARP, s);
-  if (vec == 4) { if (run8) warp::launch<4, 8, false>(s, a); else warp::launch<4, 4, false>(s, a); }
-  else if (vec == 2) { if (run8) warp::launch<2, 8, LSFA_WARP_SHARE>(s, a); else warp::launch<2, 4, LSFA_WARP_SHARE>(s, a); }
-  else { if (run8) warp::launch<1, 8, false>(s, a); else warp::launch<1, 4, false>(s, a); }
+#define LSFA_WARP_RUN(V, SH)                                                   \
+  switch (cpr) {                                                               \
+    case 8: warp::launch<V, 8, SH>(s, a); break;                               \
+    case 4: warp::launch<V, 4, SH>(s, a); break;                               \
+    default: warp::launch<V, 1, SH>(s, a); break;                              \
+  }
+  if (vec == 4) { LSFA_WARP_RUN(4, false) }
+  else if (vec == 2) { LSFA_WARP_RUN(2, LSFA_WARP_SHARE) }
+  else { LSFA_WARP_RUN(1, false) }
+#undef LSFA_WARP_RUN
   LSFA_LAUNCH_CHECK("lsfa_warp_bilinear");
   return LSFA_OK;
 }

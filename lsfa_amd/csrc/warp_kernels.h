@@ -62,19 +62,27 @@ struct Args {
 // work items per image-independent axis
 __host__ __device__ static inline int pixel_tiles(int HW, int vec) { return (HW + 64 * vec - 1) / (64 * vec); }
 
-template <int VEC, int CPR, bool HAS_MUL, bool HAS_ADD, bool HAS_RES, bool SHARE>
+// RES_C: channels of the residual input folded in by the 1x1 convolution epilogue — 0 = none, 3 = LSFA's
+// (compile time: the weight loads are then straight-line scalar loads), -1 = A.res_c at run time (1..kResMax).
+template <int VEC, int CPR, bool HAS_MUL, bool HAS_ADD, int RES_C, bool SHARE>
 __global__ __launch_bounds__(kThreads, 1) void warp_kernel(Args A) {
+  constexpr bool HAS_RES = RES_C != 0;
+  const int res_c = RES_C > 0 ? RES_C : A.res_c;
   static_assert(!SHARE || VEC == 2, "tap sharing is written for two pixels per lane");
   const int H = A.H, W = A.W, C = A.C;
   const int HW = H * W;
   const int lane = threadIdx.x & 63;
   const int tiles = pixel_tiles(HW, VEC);
-  const int runs = (C + CPR - 1) / CPR;
-  const long item = (long)blockIdx.x * (kThreads / 64) + (threadIdx.x >> 6);
-  if (item >= (long)A.N * runs * tiles) return;
-  const int tile = (int)(item % tiles);
-  const int run = (int)((item / tiles) % runs);
-  const int n = (int)(item / ((long)tiles * runs));
+  const int runs = C / CPR;                       // the launcher picks a CPR that divides C: no per-channel guards, the
+                                                  // loads of a run stay one straight-line batch
+  // the wave index is uniform across the wave; readfirstlane tells the compiler so (everything derived from it —
+  // channel run, image, the `c0 + k < C` guards — then lives in SGPRs and branches are scalar, not exec-masked)
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const unsigned item = blockIdx.x * (kThreads / 64) + wave;
+  if (item >= (unsigned)A.N * runs * tiles) return;
+  const int tile = (int)(item % (unsigned)tiles);
+  const int run = (int)((item / (unsigned)tiles) % (unsigned)runs);
+  const int n = (int)(item / ((unsigned)tiles * runs));
   const int c0 = run * CPR;
   const int p_raw = (tile * 64 + lane) * VEC;
   const bool active = p_raw < HW;                 // HW % VEC == 0: a lane is wholly inside or outside
@@ -88,16 +96,22 @@ __global__ __launch_bounds__(kThreads, 1) void warp_kernel(Args A) {
   float m[CPR][VEC], ad[CPR][VEC];
 #pragma unroll
   for (int k = 0; k < CPR; ++k) {
-    if (c0 + k < C) {
-      if (HAS_MUL) load_vec<VEC>(A.mul + o0 + (size_t)k * HW, m[k]);
-      if (HAS_ADD) load_vec<VEC>(A.add + o0 + (size_t)k * HW, ad[k]);
-    }
+    if (HAS_MUL) load_vec<VEC>(A.mul + o0 + (size_t)k * HW, m[k]);
+    if (HAS_ADD) load_vec<VEC>(A.add + o0 + (size_t)k * HW, ad[k]);
   }
   float rv[kResMax][VEC];
+  float rw[CPR][kResMax], rb[CPR];       // rnet_conv0 weights of this run: wave-uniform, read before any store
   if (HAS_RES) {
 #pragma unroll
     for (int k = 0; k < kResMax; ++k)
-      if (k < A.res_c) load_vec<VEC>(A.res + ((size_t)n * A.res_c + k) * HW + p0, rv[k]);
+      if (k < res_c) load_vec<VEC>(A.res + ((size_t)n * res_c + k) * HW + p0, rv[k]);
+#pragma unroll
+    for (int k = 0; k < CPR; ++k) {
+#pragma unroll
+      for (int j = 0; j < kResMax; ++j)
+        if (j < res_c) rw[k][j] = A.res_w[(size_t)(c0 + k) * res_c + j];
+      rb[k] = A.res_b[c0 + k];
+    }
   }
 
   // ---- taps: offsets, validity, weights (GridGenerator + BilinearSampler arithmetic) -----------
@@ -135,12 +149,11 @@ __global__ __launch_bounds__(kThreads, 1) void warp_kernel(Args A) {
   auto epilogue = [&](int k, int i, float r) -> float {
     if (HAS_MUL) r = r * m[k][i];
     if (HAS_RES) {
-      const int c = c0 + k;
-      float q = A.res_w[(size_t)c * A.res_c] * rv[0][i];
+      float q = rw[k][0] * rv[0][i];
 #pragma unroll
       for (int j = 1; j < kResMax; ++j)
-        if (j < A.res_c) q = q + A.res_w[(size_t)c * A.res_c + j] * rv[j][i];
-      q = q + A.res_b[c];
+        if (j < res_c) q = q + rw[k][j] * rv[j][i];
+      q = q + rb[k];
       r = r + q;
     }
     if (HAS_ADD) r = r + ad[k][i];
@@ -158,98 +171,92 @@ __global__ __launch_bounds__(kThreads, 1) void warp_kernel(Args A) {
       const bool chained = off[1] == off[0] + 1 && next_off == off[0] + 2 && lane < 63;
 #pragma unroll
       for (int k = 0; k < CPR; ++k) {
-        if (c0 + k < C) {
-          const float* plane = fbase + (size_t)k * HW;
-          t[k][0] = *reinterpret_cast<const float2u*>(plane + off[0]);
-          b[k][0] = *reinterpret_cast<const float2u*>(plane + off[0] + W);
-        }
+        const float* plane = fbase + (size_t)k * HW;
+        t[k][0] = *reinterpret_cast<const float2u*>(plane + off[0]);
+        b[k][0] = *reinterpret_cast<const float2u*>(plane + off[0] + W);
       }
       if (!chained) {
 #pragma unroll
         for (int k = 0; k < CPR; ++k) {
-          if (c0 + k < C) {
-            const float* plane = fbase + (size_t)k * HW;
-            t[k][1] = *reinterpret_cast<const float2u*>(plane + off[1]);
-            b[k][1] = *reinterpret_cast<const float2u*>(plane + off[1] + W);
-          }
+          const float* plane = fbase + (size_t)k * HW;
+          t[k][1] = *reinterpret_cast<const float2u*>(plane + off[1]);
+          b[k][1] = *reinterpret_cast<const float2u*>(plane + off[1] + W);
         }
       }
 #pragma unroll
       for (int k = 0; k < CPR; ++k) {
-        if (c0 + k < C) {
-          const float tn = __shfl_down(t[k][0].x, 1, 64), bn = __shfl_down(b[k][0].x, 1, 64);
-          if (chained) {
-            t[k][1].x = t[k][0].y; t[k][1].y = tn;
-            b[k][1].x = b[k][0].y; b[k][1].y = bn;
-          }
+        const float tn = __shfl_down(t[k][0].x, 1, 64), bn = __shfl_down(b[k][0].x, 1, 64);
+        if (chained) {
+          t[k][1].x = t[k][0].y; t[k][1].y = tn;
+          b[k][1].x = b[k][0].y; b[k][1].y = bn;
         }
       }
     } else {
 #pragma unroll
       for (int k = 0; k < CPR; ++k) {
-        if (c0 + k < C) {
-          const float* plane = fbase + (size_t)k * HW;
+        const float* plane = fbase + (size_t)k * HW;
 #pragma unroll
-          for (int i = 0; i < VEC; ++i) {
-            t[k][i] = *reinterpret_cast<const float2u*>(plane + off[i]);
-            b[k][i] = *reinterpret_cast<const float2u*>(plane + off[i] + W);
-          }
+        for (int i = 0; i < VEC; ++i) {
+          t[k][i] = *reinterpret_cast<const float2u*>(plane + off[i]);
+          b[k][i] = *reinterpret_cast<const float2u*>(plane + off[i] + W);
         }
       }
     }
 #pragma unroll
     for (int k = 0; k < CPR; ++k) {
-      if (c0 + k < C) {
-        float v[VEC];
+      float v[VEC];
 #pragma unroll
-        for (int i = 0; i < VEC; ++i) {
-          const float r = t[k][i].x * wy0[i] * wx0[i] + t[k][i].y * wy0[i] * wx1[i] + b[k][i].x * wy1[i] * wx0[i] +
-                          b[k][i].y * wy1[i] * wx1[i];
-          v[i] = epilogue(k, i, r);
-        }
-        if (active) store_vec<VEC>(obase + (size_t)k * HW, v);
+      for (int i = 0; i < VEC; ++i) {
+        const float r = t[k][i].x * wy0[i] * wx0[i] + t[k][i].y * wy0[i] * wx1[i] + b[k][i].x * wy1[i] * wx0[i] +
+                        b[k][i].y * wy1[i] * wx1[i];
+        v[i] = epilogue(k, i, r);
       }
+      if (active) store_vec<VEC>(obase + (size_t)k * HW, v);
     }
     return;
   }
   // general path: map borders and flows that leave the map; each tap individually zero when outside
 #pragma unroll 2
   for (int k = 0; k < CPR; ++k) {
-    if (c0 + k < C) {
-      const float* plane = fbase + (size_t)k * HW;
-      float v[VEC];
+    const float* plane = fbase + (size_t)k * HW;
+    float v[VEC];
 #pragma unroll
-      for (int i = 0; i < VEC; ++i) {
-        const float tl = v00[i] ? plane[off[i]] : 0.f;
-        const float tr = v01[i] ? plane[off[i] + 1] : 0.f;
-        const float bl = v10[i] ? plane[off[i] + W] : 0.f;
-        const float br = v11[i] ? plane[off[i] + W + 1] : 0.f;
-        const float r = tl * wy0[i] * wx0[i] + tr * wy0[i] * wx1[i] + bl * wy1[i] * wx0[i] + br * wy1[i] * wx1[i];
-        v[i] = epilogue(k, i, r);
-      }
-      if (active) store_vec<VEC>(obase + (size_t)k * HW, v);
+    for (int i = 0; i < VEC; ++i) {
+      const float tl = v00[i] ? plane[off[i]] : 0.f;
+      const float tr = v01[i] ? plane[off[i] + 1] : 0.f;
+      const float bl = v10[i] ? plane[off[i] + W] : 0.f;
+      const float br = v11[i] ? plane[off[i] + W + 1] : 0.f;
+      const float r = tl * wy0[i] * wx0[i] + tr * wy0[i] * wx1[i] + bl * wy1[i] * wx0[i] + br * wy1[i] * wx1[i];
+      v[i] = epilogue(k, i, r);
     }
+    if (active) store_vec<VEC>(obase + (size_t)k * HW, v);
   }
 }
 
+// a.C % CPR == 0 (the kernel has no per-channel guard)
 template <int VEC, int CPR, bool SHARE>
 static void launch(hipStream_t s, const Args& a) {
-  const long items = (long)a.N * ((a.C + CPR - 1) / CPR) * pixel_tiles(a.H * a.W, VEC);
+  const long items = (long)a.N * (a.C / CPR) * pixel_tiles(a.H * a.W, VEC);   // < 2^31, checked by the caller
   const dim3 grid((unsigned)((items + kThreads / 64 - 1) / (kThreads / 64)));
-  const bool has_mul = a.mul != nullptr, has_add = a.add != nullptr, has_res = a.res != nullptr;
+  const bool has_mul = a.mul != nullptr, has_add = a.add != nullptr;
+  const int res_kind = a.res == nullptr ? 0 : (a.res_c == 3 ? 3 : -1);
 #define LSFA_WARP_CASE(M, AD, R)                                                                             \
-  if (has_mul == M && has_add == AD && has_res == R) {                                                       \
+  if (has_mul == M && has_add == AD && res_kind == R) {                                                      \
     hipLaunchKernelGGL((warp_kernel<VEC, CPR, M, AD, R, SHARE>), grid, dim3(kThreads), 0, s, a);             \
     return;                                                                                                  \
   }
-  LSFA_WARP_CASE(false, false, false)
-  LSFA_WARP_CASE(true, false, false)
-  LSFA_WARP_CASE(false, true, false)
-  LSFA_WARP_CASE(false, false, true)
-  LSFA_WARP_CASE(true, true, false)
-  LSFA_WARP_CASE(true, false, true)
-  LSFA_WARP_CASE(false, true, true)
-  LSFA_WARP_CASE(true, true, true)
+  LSFA_WARP_CASE(false, false, 0)
+  LSFA_WARP_CASE(true, false, 0)
+  LSFA_WARP_CASE(false, true, 0)
+  LSFA_WARP_CASE(true, true, 0)
+  LSFA_WARP_CASE(false, false, 3)
+  LSFA_WARP_CASE(true, false, 3)
+  LSFA_WARP_CASE(false, true, 3)
+  LSFA_WARP_CASE(true, true, 3)
+  LSFA_WARP_CASE(false, false, -1)
+  LSFA_WARP_CASE(true, false, -1)
+  LSFA_WARP_CASE(false, true, -1)
+  LSFA_WARP_CASE(true, true, -1)
 #undef LSFA_WARP_CASE
 }
 

@@ -158,12 +158,19 @@ def warp_bilinear(feat, flow, mul=None, add=None, res=None, res_w=None, res_b=No
 
 @_on_tensor_device
 def aggregate_softmax2(a, b, logits, out=None):
+    """a, b (N, C, H, W); logits (2N, 1, H, W): rows [0, N) weight a, rows [N, 2N) weight b."""
     a, b, logits = _f32c(a, "a"), _f32c(b, "b"), _f32c(logits, "logits")
-    _, C, H, W = a.shape
+    N, C, H, W = a.shape
+    if logits.numel() != 2 * N * H * W:
+        raise LsfaError("aggregate_softmax2: logits %s do not match a %s" % (tuple(logits.shape), tuple(a.shape)))
     if out is None:
         out = torch.empty_like(a)
-    _check(lib().lsfa_aggregate_softmax2(_ptr(a), _ptr(b), _ptr(logits), _ci(C), _ci(H), _ci(W), _ptr(out), _stream()),
-           "lsfa_aggregate_softmax2")
+    if N == 1:
+        _check(lib().lsfa_aggregate_softmax2(_ptr(a), _ptr(b), _ptr(logits), _ci(C), _ci(H), _ci(W), _ptr(out), _stream()),
+               "lsfa_aggregate_softmax2")
+    else:
+        _check(lib().lsfa_aggregate_softmax2_batched(_ptr(a), _ptr(b), _ptr(logits), _ci(N), _ci(C), _ci(H), _ci(W),
+                                                     _ptr(out), _stream()), "lsfa_aggregate_softmax2_batched")
     return out
 
 

@@ -37,13 +37,20 @@ def parse_args():
     ap.add_argument('--epoch', type=int, default=0)
     ap.add_argument('--serial', action='store_true', help='reference-shaped serial frame loop (pred_eval) instead of the '
                                                           'stream-pipelined one')
+    ap.add_argument('--out', default=None, help='rank 0 saves the gathered detection rows (n,7) here (.npy)')
+    ap.add_argument('--pinned-algorithms', action='store_true',
+                    help='deterministic convolution / GEMM algorithm choice (no MIOpen find, no TunableOp): results do not '
+                         'depend on how the videos are spread over ranks')
     return ap.parse_args()
 
 
 def main():
     args = parse_args()
     from lsfa_amd import tuning
-    tuning.enable(tune_missing=True)
+    if args.pinned_algorithms:
+        torch.backends.cudnn.deterministic, torch.backends.cudnn.benchmark = True, False
+    else:
+        tuning.enable(tune_missing=True)
     if args.cfg:
         cfg = update_config(args.cfg, config)
         update_network_config(cfg)
@@ -53,10 +60,18 @@ def main():
         cfg.TEST.KEY_FRAME_INTERVAL = args.interval
     world = int(os.environ.get('WORLD_SIZE', '1'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    # one-GPU boxes: LSFA_BENCH_BACKEND=gloo LSFA_BENCH_ONE_DEVICE=1 puts every rank on cuda:0 and runs the final
+    # gather over gloo, so the N > 1 control flow (sharding, gather, merge) can be exercised without N GPUs
+    backend = os.environ.get('LSFA_BENCH_BACKEND', 'nccl')
+    if os.environ.get('LSFA_BENCH_ONE_DEVICE') == '1':
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
+        if backend == 'nccl':
+            dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
+        else:
+            dist.init_process_group(backend)
     logging.basicConfig(level=logging.INFO, format='%(asctime)s %(message)s')
     logger = logging.getLogger('lsfa')
     roidb = synthetic_roidb(args.clips, args.frames, args.height, args.width, cfg.TEST.KEY_FRAME_INTERVAL)
@@ -77,6 +92,9 @@ def main():
         total = args.clips * args.frames
         print('%d clips x %d frames on %d GPU(s): %d detections, %.1f frames/s incl. setup' % (
             args.clips, args.frames, world, len(rows), total / dt))
+        if args.out:
+            import numpy as np
+            np.save(args.out, rows)
     if dist.is_initialized():
         dist.destroy_process_group()
 

@@ -189,10 +189,18 @@ def warp_bilinear(feat, flow, mul=None, add=None, res=None, res_w=None, res_b=No
 
 
 def aggregate_softmax2(a, b, logits):
+    """a, b (N,C,H,W), logits (2N,1,H,W): map n combines with logits rows n and N+n (resnet_v1_101_flownet_rfcn.py:95-108
+    is the N = 1 case; for N > 1 every map is that case on its own pair of rows)."""
     a, b, logits = _f32(a), _f32(b), _f32(logits)
-    _, C, H, W = a.shape
+    N, C, H, W = a.shape
     out = np.empty_like(a)
-    lib().orc_aggregate_softmax2(_p(a), _p(b), _p(logits), _ci(C), _ci(H), _ci(W), _p(out))
+    lg = logits.reshape(2, N, H, W)
+    for n in range(N):
+        pair = np.ascontiguousarray(lg[:, n])
+        o = np.empty((1, C, H, W), np.float32)
+        lib().orc_aggregate_softmax2(_p(np.ascontiguousarray(a[n])), _p(np.ascontiguousarray(b[n])), _p(pair), _ci(C), _ci(H),
+                                     _ci(W), _p(o))
+        out[n] = o[0]
     return out
 
 

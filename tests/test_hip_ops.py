@@ -192,6 +192,20 @@ def test_aggregate_softmax2_bit_exact(hip, shape):
     np.testing.assert_allclose(got, (ref[0] * torch.from_numpy(a) + ref[1] * torch.from_numpy(b)).numpy(), rtol=1e-5, atol=1e-6)
 
 
+@pytest.mark.parametrize("shape", [(4, 1024, 38, 63), (3, 20, 8, 8), (32, 64, 38, 63)])
+def test_aggregate_softmax2_batched_bit_exact(hip, shape):
+    """N maps per launch (several clips advancing together; the HBM-resident roofline mode): map n uses logits
+    rows n and N + n, each map bit-identical to the N = 1 operator."""
+    N, C, H, W = shape
+    rs = np.random.RandomState(N + C)
+    a, b = rs.randn(N, C, H, W).astype(np.float32), rs.randn(N, C, H, W).astype(np.float32)
+    logits = (3 * rs.randn(2 * N, 1, H, W)).astype(np.float32)
+    got = hip.aggregate_softmax2(t(a), t(b), t(logits)).cpu().numpy()
+    np.testing.assert_array_equal(got, oracle.aggregate_softmax2(a, b, logits))
+    one = hip.aggregate_softmax2(t(a[1:2]), t(b[1:2]), t(np.stack([logits[1], logits[N + 1]]))).cpu().numpy()
+    np.testing.assert_array_equal(got[1:2], one)
+
+
 @pytest.mark.parametrize("shape", [(1024, 2048, 38, 63), (64, 128, 12, 14), (16, 100, 5, 7), (8, 37, 3, 3)])
 def test_aggregate_cosine_bit_exact(hip, shape):
     """Fgfa weights at LSFA's real shape (2048-channel embeddings on the 38x63 map) and at shapes with E not a

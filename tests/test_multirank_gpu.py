@@ -1,0 +1,71 @@
+"""The N > 1 paths of bench.py and lsfa_amd.test on a ONE-GPU box: fresh child processes launched with
+torch.distributed.run (before anything in them touches the GPU), every rank on cuda:0, collectives over
+gloo (LSFA_BENCH_BACKEND=gloo LSFA_BENCH_ONE_DEVICE=1).  No scaling number can come out of this — it keeps
+the clip sharding (dff_rfcn/function/test_rcnn.py:69-75), the max-over-ranks timing and the final gather
+(dff_rfcn/core/tester.py:301-312, lib/dataset/imagenet_vid.py:245-268) exercised end to end on the GPU."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _env():
+    env = dict(os.environ)
+    env.update(LSFA_BENCH_BACKEND="gloo", LSFA_BENCH_ONE_DEVICE="1", MASTER_ADDR="127.0.0.1",
+               HSA_ENABLE_IPC_MODE_LEGACY="0", PYTHONPATH=ROOT + os.pathsep + env.get("PYTHONPATH", ""))
+    return env
+
+
+def _torchrun(nproc, args, timeout=900):
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(nproc), "--master-addr",
+           "127.0.0.1", "--master-port", str(_free_port())] + args
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout, cwd=ROOT, env=_env())
+    assert out.returncode == 0, out.stderr[-3000:]
+    return out.stdout
+
+
+def test_bench_two_ranks_one_device():
+    small = ["--steps", "3", "--warmup", "1", "--height", "192", "--width", "320", "--no-cpu-baseline", "--no-parity"]
+    one = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + small, capture_output=True, text=True,
+                         timeout=900, cwd=ROOT, env=_env())
+    assert one.returncode == 0, one.stderr[-3000:]
+    d1 = json.loads([l for l in one.stdout.splitlines() if l.startswith("{")][-1])
+    stdout = _torchrun(2, [os.path.join(ROOT, "bench.py"), "--gpus", "2"] + small)
+    lines = [l for l in stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, stdout[-2000:]                   # rank 0 only
+    d2 = json.loads(lines[0])
+    assert d2["n_gpus"] == 2 and d2["scaling"] == "weak" and d2["steps"] == 3
+    assert d2["config"]["parallelism"] == "clip-parallel x2"
+    # whole-job value = frames of BOTH ranks / max-over-ranks time
+    frames = 2 * 3 * d2["config"]["frames_per_step"]
+    assert abs(d2["value"] - frames / (d2["ms_per_step"] * 3 / 1e3)) < 0.02 * d2["value"]
+    # rank r runs clip r: the gathered detection count covers two different clips
+    assert d2["config"]["detections_last_interval"] > d1["config"]["detections_last_interval"]
+
+
+def test_lsfa_test_three_clips_two_ranks_equal_single_rank(tmp_path):
+    args = ["--clips", "3", "--frames", "7", "--interval", "3", "--height", "192", "--width", "320", "--pinned-algorithms"]
+    single, double = str(tmp_path / "rows1.npy"), str(tmp_path / "rows2.npy")
+    out = subprocess.run([sys.executable, "-m", "lsfa_amd.test"] + args + ["--out", single], capture_output=True,
+                         text=True, timeout=900, cwd=ROOT, env=_env())
+    assert out.returncode == 0, out.stderr[-3000:]
+    _torchrun(2, ["-m", "lsfa_amd.test"] + args + ["--out", double])
+    r1, r2 = np.load(single), np.load(double)
+    assert r1.shape == r2.shape and len(r1) > 0
+    assert sorted(np.unique(r1[:, 0]).astype(int)) == list(range(21))        # 3 clips x 7 frames, global frame ids
+    # the greedy assignment gives rank 0 clips {0, 2} and rank 1 clip {1}: the gather returns rank order, so sort rows
+    key = lambda r: r[np.lexsort((r[:, 6], r[:, 5], r[:, 4], r[:, 3], -r[:, 2], r[:, 1], r[:, 0]))]
+    np.testing.assert_array_equal(key(r1), key(r2))

@@ -208,6 +208,21 @@ int lsfa_deform_im2col_cl(const float* data, const float* offset,
                           int pad, int stride, int dilate, int deform_groups,
                           int Ho, int Wo, float* col, void* stream);
 
+/* ------------------------------------------------------------------------ *
+ * Convolution + bias + ReLU on channels-last maps with the fp32 matrix cores (implicit GEMM).
+ * Replaces: mx.sym.Convolution (no_bias) + the BatchNorm folded into it + Activation('relu') of the
+ *           pre-activation ResNet units' conv2   dff_rfcn/symbols/resnet.py:84-93, sym_common.py:92-135
+ *           (any kh x kw, stride, dilation; zero padding `pad` on every side).
+ * x (N, H, W, Cin), y (N, Ho, Wo, Cout) channels-last; w (Cout, kh*kw, Cin): K contiguous per output channel
+ * (the reference's (Cout, Cin, kh, kw) weight permuted once at bind time); bias (Cout) or NULL.
+ * Cin % 32 == 0, Cout % 64 == 0.  Small tile grids split the taps over workgroups and need
+ * lsfa_conv_nhwc_workspace_bytes(...) of workspace (partial tiles, added in a fixed order: deterministic).
+ * ------------------------------------------------------------------------ */
+size_t lsfa_conv_nhwc_workspace_bytes(int N, int H, int W, int Cout, int kh, int kw, int stride, int pad, int dil);
+int lsfa_conv_nhwc_fwd(const float* x, int N, int H, int W, int Cin, const float* w, const float* bias, int Cout,
+                       int kh, int kw, int stride, int pad, int dil, int relu, float* y,
+                       void* ws, size_t ws_bytes, void* stream);
+
 /* Inference BatchNorm (use_global_stats) + ReLU as one pass: y = max(x*scale[c]+shift[c], 0)
  * (sym_common.py:92-102 bn + relu of every pre-activation unit, resnet.py:70-101).
  * relu != 0 applies the ReLU.  In-place (y == x) allowed. */
@@ -255,7 +270,7 @@ int lsfa_mv_residual(const unsigned char* bgr_cur, const unsigned char* bgr_ref,
 enum {
   LSFA_OP_PSROI = 0, LSFA_OP_RFCN_HEAD = 1, LSFA_OP_WARP = 2, LSFA_OP_AGG = 3,
   LSFA_OP_PROPOSAL = 4, LSFA_OP_NMS = 5, LSFA_OP_DET = 6, LSFA_OP_DCN_IM2COL = 7,
-  LSFA_OP_BNRELU = 8, LSFA_OP_COUNT = 9
+  LSFA_OP_BNRELU = 8, LSFA_OP_CONV = 9, LSFA_OP_COUNT = 10
 };
 int lsfa_prof_enable(int mask);
 int lsfa_prof_read(double* ms_host /*LSFA_OP_COUNT*/, int* launches_host /*LSFA_OP_COUNT*/);

@@ -1,0 +1,197 @@
+// fp32 implicit-GEMM convolution on channels-last maps with the fp32 matrix cores
+// (v_mfma_f32_32x32x2_f32: exact fp32 products and sums, the chip's fp32 peak).
+//
+// What it is for: conv2 of the pre-activation ResNet units (3x3, stride 1 or 2, dilation d, folded
+// bn3 bias + ReLU; dff_rfcn/symbols/resnet.py:70-101, sym_common.py:92-135) on (H*W, C) rows.  At
+// LSFA's size the stage-3 instance is a SMALL GEMM — 2394 pixels x 256 channels x K = 2304 — for a
+// 256-CU part: 600 output tiles of 32x32 for 1024 SIMDs.  An fp32 MFMA occupies its SIMD for 64
+// cycles whatever else is resident, so the time is (tile-tasks per SIMD, rounded up) x (MFMAs per
+// task) x 64 cycles, and the lever is the task count, not occupancy:
+//   * a workgroup computes a 64-pixel x 64-channel tile with 4 waves (one 32x32 accumulator tile each:
+//     16 VGPRs), K walked tap by tap in 32-channel chunks, staged through LDS, double-buffered;
+//   * gridDim.z splits the TAPS over workgroups (3 x 3 taps for a 3x3 kernel) when the tile grid alone
+//     would leave SIMDs idle; the slices write fp32 partial tiles to the workspace and a second kernel
+//     adds them in a fixed order and applies bias + ReLU — deterministic, unlike the library's atomic
+//     split-K (its `gkgs` kernels) which also needs a zero-fill launch;
+//   * the MFMA sums over k in any order we like, as long as A and B agree: a lane reads 4 consecutive
+//     k of its row/column with ONE ds_read_b128 (lanes 0-31 take k = 8c..8c+3, lanes 32-63 take
+//     8c+4..8c+7) and feeds 4 MFMAs from it; LDS rows are padded to 36 floats, which spreads the 16
+//     lanes of a b128 group over all 64 banks.
+// Zero padding is realised when a chunk is staged (out-of-map pixels load zeros).
+// Weight layout (prepared once at bind time): w[co][tap][ci], i.e. K contiguous per output channel.
+#include "common.h"
+
+using namespace lsfa;
+
+namespace {
+
+constexpr int kBM = 64, kBN = 64, kBK = 32;
+constexpr int kLdk = kBK + 4;                 // padded LDS row (floats)
+constexpr int kThreads = 256;
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+struct ConvArgs {
+  const float* x; const float* w; const float* bias; float* y; float* part;
+  int N, H, W, Cin, Cout, kh, kw, stride, pad, dil, Ho, Wo, relu, taps_per_slice;
+};
+
+// grid (ceil(P / 64), Cout / 64, slices); block 256.  P = N*Ho*Wo output pixels.
+__global__ __launch_bounds__(kThreads) void conv_igemm_kernel(ConvArgs a) {
+  __shared__ __attribute__((aligned(16))) float As[2][kBM * kLdk];
+  __shared__ __attribute__((aligned(16))) float Bs[2][kBN * kLdk];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wr = wave >> 1, wc = wave & 1;
+  const int P = a.N * a.Ho * a.Wo;
+  const int m0 = blockIdx.x * kBM, n0 = blockIdx.y * kBN;
+  const int taps = a.kh * a.kw;
+  const int tap0 = blockIdx.z * a.taps_per_slice, tap1 = min(tap0 + a.taps_per_slice, taps);
+  const int chunks_per_tap = a.Cin / kBK;
+  const int nchunks = (tap1 - tap0) * chunks_per_tap;
+
+  // staging role of this thread: row (pixel of A / channel of B) and an 8-float column segment
+  const int srow = tid >> 2, scol = (tid & 3) * 8;
+  const int pix = m0 + srow;
+  const bool pix_ok = pix < P;
+  int py = 0, px = 0, pn = 0;
+  if (pix_ok) { pn = pix / (a.Ho * a.Wo); const int r = pix - pn * a.Ho * a.Wo; py = r / a.Wo; px = r - py * a.Wo; }
+  const float* wrow = a.w + ((size_t)(n0 + srow) * taps) * a.Cin + scol;
+
+  // named registers (not arrays captured by a lambda: those end up in scratch memory and serialise the loads)
+  float4 ra0, ra1, rb0, rb1;
+  float a_keep = 0.f;
+#define LSFA_CONV_FETCH(chunk_)                                                                                        \
+  {                                                                                                                    \
+    const int t_ = (chunk_) / chunks_per_tap;                                                                          \
+    const int tap = tap0 + t_;                                                                                         \
+    const int ci0 = ((chunk_) - t_ * chunks_per_tap) * kBK;                                                            \
+    const int ty = tap / a.kw, tx = tap - ty * a.kw;                                                                   \
+    const int iy = py * a.stride - a.pad + ty * a.dil, ix = px * a.stride - a.pad + tx * a.dil;                        \
+    const bool ok = pix_ok && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W;                                              \
+    const float4* src = reinterpret_cast<const float4*>(a.x + (((size_t)pn * a.H + (ok ? iy : 0)) * a.W + (ok ? ix : 0)) * a.Cin + ci0 + scol); \
+    ra0 = src[0]; ra1 = src[1];                                                                                        \
+    a_keep = ok ? 1.0f : 0.0f;   /* zero padding = the (clamped, valid) load times 0, applied when the chunk is */     \
+                                 /* written to LDS: any use of the loaded value here would stall the wave before its MFMAs */ \
+    const float4* wsrc = reinterpret_cast<const float4*>(wrow + (size_t)tap * a.Cin + ci0);                            \
+    rb0 = wsrc[0]; rb1 = wsrc[1];                                                                                      \
+  }
+#define LSFA_CONV_STASH(buf_)                                                                                          \
+  {                                                                                                                    \
+    float4* da = reinterpret_cast<float4*>(&As[buf_][srow * kLdk + scol]);                                             \
+    da[0] = make_float4(ra0.x * a_keep, ra0.y * a_keep, ra0.z * a_keep, ra0.w * a_keep);                               \
+    da[1] = make_float4(ra1.x * a_keep, ra1.y * a_keep, ra1.z * a_keep, ra1.w * a_keep);                               \
+    float4* db = reinterpret_cast<float4*>(&Bs[buf_][srow * kLdk + scol]);                                             \
+    db[0] = rb0; db[1] = rb1;                                                                                          \
+  }
+
+  f32x16 acc;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+
+  LSFA_CONV_FETCH(0)
+  LSFA_CONV_STASH(0)
+  __syncthreads();
+  const int arow = (wr * 32 + (lane & 31)) * kLdk + 4 * (lane >> 5);
+  const int brow = (wc * 32 + (lane & 31)) * kLdk + 4 * (lane >> 5);
+  for (int chunk = 0; chunk < nchunks; ++chunk) {
+    const int buf = chunk & 1;
+    if (chunk + 1 < nchunks) LSFA_CONV_FETCH(chunk + 1)  // global loads in flight under the MFMAs
+#pragma unroll
+    for (int c = 0; c < kBK / 8; ++c) {
+      const float4 av = *reinterpret_cast<const float4*>(&As[buf][arow + 8 * c]);
+      const float4 bv = *reinterpret_cast<const float4*>(&Bs[buf][brow + 8 * c]);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, bv.x, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.y, bv.y, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.z, bv.z, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.w, bv.w, acc, 0, 0, 0);
+    }
+    __builtin_amdgcn_sched_barrier(0);   // keep every use of the freshly loaded registers behind the MFMAs
+    if (chunk + 1 < nchunks) {
+      LSFA_CONV_STASH(buf ^ 1)   // the other buffer: its last readers passed the barrier of the previous iteration
+      __syncthreads();
+    }
+  }
+
+#undef LSFA_CONV_FETCH
+#undef LSFA_CONV_STASH
+  // C/D layout of 32x32x2: column = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
+  const int ch = n0 + wc * 32 + (lane & 31);
+  const float bias = (a.part == nullptr && a.bias) ? a.bias[ch] : 0.f;
+  float* dst = a.part ? a.part + (size_t)blockIdx.z * P * a.Cout : a.y;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+    const int p = m0 + wr * 32 + row;
+    if (p < P) {
+      float v = acc[r];
+      if (a.part == nullptr) { v = v + bias; if (a.relu) v = fmaxf(v, 0.f); }
+      dst[(size_t)p * a.Cout + ch] = v;
+    }
+  }
+}
+
+// y = act(sum over slices of part, in slice order, + bias); float4 of channels per thread
+__global__ __launch_bounds__(kThreads) void conv_reduce_kernel(const float4* __restrict__ part, const float4* __restrict__ bias,
+                                                               long n4, int c4, int slices, int relu, float4* __restrict__ y) {
+  const long i = (long)blockIdx.x * kThreads + threadIdx.x;
+  if (i >= n4) return;
+  float4 s = part[i];
+  for (int z = 1; z < slices; ++z) {
+    const float4 v = part[(size_t)z * n4 + i];
+    s.x = s.x + v.x; s.y = s.y + v.y; s.z = s.z + v.z; s.w = s.w + v.w;
+  }
+  if (bias) { const float4 b = bias[i % c4]; s.x = s.x + b.x; s.y = s.y + b.y; s.z = s.z + b.z; s.w = s.w + b.w; }
+  if (relu) { s.x = fmaxf(s.x, 0.f); s.y = fmaxf(s.y, 0.f); s.z = fmaxf(s.z, 0.f); s.w = fmaxf(s.w, 0.f); }
+  y[i] = s;
+}
+
+int pick_slices(long tiles, int taps) {
+  // one 4-wave workgroup per tile: below ~1 workgroup per CU the SIMDs idle, so cut the taps into 3 (3x3 kernels)
+  if (taps % 3 == 0 && tiles * 4 < 1024) return 3;
+  return 1;
+}
+
+}  // namespace
+
+extern "C" size_t lsfa_conv_nhwc_workspace_bytes(int N, int H, int W, int Cout, int kh, int kw, int stride, int pad, int dil) {
+  if (N <= 0 || H <= 0 || W <= 0 || Cout <= 0 || stride <= 0) return 0;
+  const int Ho = (H + 2 * pad - dil * (kh - 1) - 1) / stride + 1, Wo = (W + 2 * pad - dil * (kw - 1) - 1) / stride + 1;
+  const long P = (long)N * Ho * Wo;
+  const int slices = pick_slices(((P + kBM - 1) / kBM) * (Cout / kBN), kh * kw);
+  return slices > 1 ? align_up((size_t)slices * P * Cout * sizeof(float), 256) : 256;
+}
+
+extern "C" int lsfa_conv_nhwc_fwd(const float* x, int N, int H, int W, int Cin, const float* w, const float* bias, int Cout,
+                                  int kh, int kw, int stride, int pad, int dil, int relu, float* y, void* ws, size_t ws_bytes,
+                                  void* stream) {
+  LSFA_REQUIRE(x && w && y, "lsfa_conv_nhwc_fwd: NULL argument");
+  LSFA_REQUIRE(N > 0 && H > 0 && W > 0 && kh > 0 && kw > 0 && stride > 0 && pad >= 0 && dil > 0, "lsfa_conv_nhwc_fwd: bad shape");
+  if (Cin % kBK != 0 || Cout % kBN != 0) {
+    set_error("lsfa_conv_nhwc_fwd: Cin=%d must be a multiple of %d and Cout=%d of %d", Cin, kBK, Cout, kBN);
+    return LSFA_ENOTSUP;
+  }
+  const int Ho = (H + 2 * pad - dil * (kh - 1) - 1) / stride + 1, Wo = (W + 2 * pad - dil * (kw - 1) - 1) / stride + 1;
+  LSFA_REQUIRE(Ho > 0 && Wo > 0, "lsfa_conv_nhwc_fwd: empty output");
+  const long P = (long)N * Ho * Wo;
+  LSFA_REQUIRE(P * Cout < (1L << 31) && (long)N * H * W * Cin < (1L << 33), "lsfa_conv_nhwc_fwd: tensor too large");
+  const int taps = kh * kw;
+  const long tiles = ((P + kBM - 1) / kBM) * (Cout / kBN);
+  const int slices = pick_slices(tiles, taps);
+  if (slices > 1 && (!ws || ws_bytes < lsfa_conv_nhwc_workspace_bytes(N, H, W, Cout, kh, kw, stride, pad, dil))) {
+    set_error("lsfa_conv_nhwc_fwd: workspace %zu < %zu bytes", ws_bytes, lsfa_conv_nhwc_workspace_bytes(N, H, W, Cout, kh, kw, stride, pad, dil));
+    return LSFA_EWORKSPACE;
+  }
+  hipStream_t s = (hipStream_t)stream;
+  ConvArgs a = {x, w, bias, y, slices > 1 ? (float*)ws : nullptr, N, H, W, Cin, Cout, kh, kw, stride, pad, dil, Ho, Wo, relu,
+                (taps + slices - 1) / slices};
+  ProfScope prof(LSFA_OP_CONV, s);
+  hipLaunchKernelGGL(conv_igemm_kernel, dim3((unsigned)((P + kBM - 1) / kBM), Cout / kBN, slices), dim3(kThreads), 0, s, a);
+  if (slices > 1) {
+    const long n4 = P * Cout / 4;
+    hipLaunchKernelGGL(conv_reduce_kernel, dim3((unsigned)((n4 + kThreads - 1) / kThreads)), dim3(kThreads), 0, s,
+                       (const float4*)ws, (const float4*)bias, n4, Cout / 4, slices, relu, (float4*)y);
+  }
+  LSFA_LAUNCH_CHECK("lsfa_conv_nhwc_fwd");
+  return LSFA_OK;
+}

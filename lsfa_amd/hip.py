@@ -14,7 +14,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "liblsfa_hip.so")
 
 OP_NAMES = ["psroi_pool", "rfcn_head", "warp_bilinear", "aggregate", "proposal", "nms", "det_postprocess",
-            "deform_im2col", "scale_shift_relu"]
+            "deform_im2col", "scale_shift_relu", "conv_nhwc"]
 
 
 class LsfaError(RuntimeError):
@@ -38,7 +38,7 @@ def lib():
         L = ctypes.CDLL(LIB_PATH)
         L.lsfa_last_error.restype = ctypes.c_char_p
         for name in ("lsfa_proposal_workspace_bytes", "lsfa_nms_workspace_bytes", "lsfa_det_workspace_bytes",
-                     "lsfa_mv_workspace_bytes"):
+                     "lsfa_mv_workspace_bytes", "lsfa_conv_nhwc_workspace_bytes"):
             getattr(L, name).restype = ctypes.c_size_t
         L.lsfa_op_name.restype = ctypes.c_char_p
         L._nms.restype = None
@@ -364,6 +364,31 @@ def scale_shift_relu_cl(x, scale, shift, relu=True, out=None):
         out = torch.empty_like(x)
     _check(lib().lsfa_scale_shift_relu_cl(_ptr(x), _ptr(scale), _ptr(shift), ctypes.c_longlong(rows), _ci(C),
                                           _ci(int(relu)), _ptr(out), _stream()), "lsfa_scale_shift_relu_cl")
+    return out
+
+
+def conv_weight_kc(weight):
+    """(Cout, Cin, kh, kw) -> (Cout, kh*kw, Cin) contiguous: the layout lsfa_conv_nhwc_fwd reads (K contiguous)."""
+    co, ci, kh, kw = weight.shape
+    return weight.permute(0, 2, 3, 1).reshape(co, kh * kw, ci).contiguous()
+
+
+@_on_tensor_device
+def conv_nhwc(x, w_kc, bias, kh, kw, stride=1, pad=0, dil=1, relu=False, out=None):
+    """x (N, H, W, Cin) contiguous fp32; w_kc from conv_weight_kc; -> (N, Ho, Wo, Cout)."""
+    x, w_kc = _f32c(x, "x"), _f32c(w_kc, "w_kc")
+    N, H, W, Cin = x.shape
+    Cout = w_kc.shape[0]
+    if tuple(w_kc.shape) != (Cout, kh * kw, Cin):
+        raise LsfaError("conv_nhwc: weight %s does not match (Cout, %d, %d)" % (tuple(w_kc.shape), kh * kw, Cin))
+    Ho, Wo = (H + 2 * pad - dil * (kh - 1) - 1) // stride + 1, (W + 2 * pad - dil * (kw - 1) - 1) // stride + 1
+    if out is None:
+        out = torch.empty((N, Ho, Wo, Cout), device=x.device, dtype=torch.float32)
+    need = lib().lsfa_conv_nhwc_workspace_bytes(_ci(N), _ci(H), _ci(W), _ci(Cout), _ci(kh), _ci(kw), _ci(stride), _ci(pad), _ci(dil))
+    ws = torch.empty(need, dtype=torch.uint8, device=x.device)
+    _check(lib().lsfa_conv_nhwc_fwd(_ptr(x), _ci(N), _ci(H), _ci(W), _ci(Cin), _ptr(w_kc), _ptr(bias), _ci(Cout), _ci(kh), _ci(kw),
+                                    _ci(stride), _ci(pad), _ci(dil), _ci(int(relu)), _ptr(out), _ptr(ws), ctypes.c_size_t(need),
+                                    _stream()), "lsfa_conv_nhwc_fwd")
     return out
 
 

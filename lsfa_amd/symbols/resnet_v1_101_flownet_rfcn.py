@@ -37,6 +37,9 @@ import os as _os
 _CL_DEFAULT = 'backbone,small'
 _FLOW_GEMM_MAX_L = int(_os.environ.get('LSFA_FLOW_GEMM_L', '700'))   # FlowNet convs with at most this many output pixels run as im2col + GEMM
 _CONV1X1_MIOPEN = _os.environ.get('LSFA_CONV1X1_MIOPEN', '0') == '1'   # experiment: channel-reducing 1x1 convs through MIOpen
+# which 3x3 convolutions of the channels-last sub-networks run on the own fp32-MFMA implicit GEMM (lsfa_conv_nhwc_fwd,
+# bias + ReLU in its epilogue) instead of the library's kernel + a separate bias/ReLU pass: comma list of backbone, small
+_OWN_CONV = set(x for x in _os.environ.get('LSFA_OWN_CONV', 'backbone,small').split(',') if x)
 
 
 class TestSymbol(object):
@@ -226,6 +229,8 @@ class _ResNetWeights(object):
             d['w1_t'] = d['w1_2d'].t().contiguous()
             d['w3_t'] = d['w3_2d'].t().contiguous()
             d['w2_cl'] = d['w2'].contiguous(memory_format=cl)
+            if d['w2'].dtype == torch.float32 and d['w2'].shape[1] % 32 == 0 and d['w2'].shape[0] % 64 == 0:
+                d['w2_kc'] = hip.conv_weight_kc(d['w2'])        # (Cout, 9, Cin): lsfa_conv_nhwc_fwd's layout
             if 'sc' in d:
                 d['sc_t'] = d['sc'].reshape(d['sc'].shape[0], -1).t().contiguous()
                 d['sc_cl'] = d['sc'].contiguous(memory_format=cl)
@@ -420,8 +425,9 @@ class Executor(object):
                                    P.NUM_DEFORMABLE_GROUP)
         return torch.mm(col.view(-1, col.shape[2]), u['w2_tap_t'])     # (N*H*W, 9*C) x (9*C, Cout)
 
-    def _resnet_cl(self, x, net, stages, tail):
-        """_resnet on channels-last activations (fp32).  Returns an NCHW-shaped channels_last map."""
+    def _resnet_cl(self, x, net, stages, tail, own_conv=False):
+        """_resnet on channels-last activations (fp32).  Returns an NCHW-shaped channels_last map.
+        own_conv: conv2 (3x3 + folded bn3 bias + ReLU) on lsfa_conv_nhwc_fwd instead of library conv + bias/ReLU pass."""
         net.prepare_channels_last()
         cl = torch.channels_last
         x = hip.scale_shift_relu(x, net.bn_data[0], net.bn_data[1], relu=False).contiguous(memory_format=cl)
@@ -445,12 +451,18 @@ class Executor(object):
             if u['dcn']:
                 c2 = self._dcn_cl(self._map(c1, h, w), u, unit_dilate)
                 ho, wo = h, w
+            elif own_conv and 'w2_kc' in u:
+                y = hip.conv_nhwc(c1.view(-1, h, w, c1.shape[1]), u['w2_kc'], u['b2'], 3, 3, stride, unit_dilate, unit_dilate,
+                                  relu=True)                       # folded bn3 bias + ReLU in the epilogue
+                ho, wo = y.shape[1], y.shape[2]
+                c2 = y.view(-1, y.shape[3])
             else:
                 c2_4 = F.conv2d(self._map(c1, h, w), u['w2_cl'], None, stride=stride, padding=unit_dilate,
                                 dilation=unit_dilate)
                 ho, wo = c2_4.shape[2], c2_4.shape[3]
                 c2 = self._rows(c2_4)
-            hip.scale_shift_relu_cl(c2, self._ones(c2.shape[1]), u['b2'], relu=True, out=c2)   # folded bn3 bias + ReLU
+            if u['dcn'] or not (own_conv and 'w2_kc' in u):
+                hip.scale_shift_relu_cl(c2, self._ones(c2.shape[1]), u['b2'], relu=True, out=c2)   # folded bn3 bias + ReLU
             if first:
                 sc = self._rows(F.conv2d(self._map(a2, h, w), u['sc_cl'], None, stride=stride)) if stride != 1 \
                     else torch.mm(a2, u['sc_t'])
@@ -466,7 +478,7 @@ class Executor(object):
         if 'backbone' in self.cl:
             if not hasattr(self, 'feat_w_cl'):
                 self.feat_w_cl = self.feat_w.contiguous(memory_format=torch.channels_last)
-            x4 = self._resnet_cl(data, self.net, 4, True)
+            x4 = self._resnet_cl(data, self.net, 4, True, own_conv='backbone' in _OWN_CONV)
             y = F.conv2d(x4, self.feat_w_cl, None, padding=6, dilation=6)
             r = self._rows(y)
             hip.scale_shift_relu_cl(r, self._ones(r.shape[1]), self.feat_b, relu=True, out=r)
@@ -677,7 +689,13 @@ class Executor(object):
             if 'small' in self.cl:
                 if not hasattr(self, 'fuse_w_cl'):
                     self.fuse_w_cl = self.fuse_w.contiguous(memory_format=torch.channels_last)
-                s = self._resnet_cl(img, self.small, 1, False)
+                own = 'small' in _OWN_CONV
+                s = self._resnet_cl(img, self.small, 1, False, own_conv=own)
+                if own:
+                    if not hasattr(self, 'fuse_w_kc'):
+                        self.fuse_w_kc = hip.conv_weight_kc(self.fuse_w)
+                    y = hip.conv_nhwc(s.permute(0, 2, 3, 1), self.fuse_w_kc, self.fuse_b, 3, 3, 1, 1, 1, relu=False)
+                    return y.permute(0, 3, 1, 2).contiguous()        # NCHW for the warp kernel's `add` operand
                 return F.conv2d(s, self.fuse_w_cl, self.fuse_b, padding=1).contiguous()
             s = self._resnet(img, self.small, 1, False)
             return F.conv2d(s, self.fuse_w, self.fuse_b, padding=1).float()

@@ -578,3 +578,42 @@ def test_mv_accumulation_bit_exact(hip, size):
                                   oracle.coviar_residual(cur, ref, want))
     acc.reset()
     np.testing.assert_array_equal(acc.accu.cpu().numpy(), oracle.coviar_identity(width, height))
+
+
+# ------------------------------------------------------------------ fp32 MFMA convolution ----
+@pytest.mark.parametrize("cfg", [
+    dict(N=1, H=38, W=63, Cin=256, Cout=256, k=3, stride=1, dil=1),      # stage-3 conv2 (taps split over 3 slices)
+    dict(N=1, H=75, W=125, Cin=128, Cout=128, k=3, stride=1, dil=1),     # stage-2 conv2
+    dict(N=1, H=75, W=125, Cin=256, Cout=256, k=3, stride=2, dil=1),     # stage3_unit1 (stride 2)
+    dict(N=1, H=38, W=63, Cin=512, Cout=512, k=3, stride=1, dil=2),      # dilated
+    dict(N=2, H=13, W=9, Cin=64, Cout=64, k=3, stride=1, dil=1),         # batch 2, ragged pixel tile
+    dict(N=1, H=20, W=17, Cin=96, Cout=128, k=1, stride=1, dil=1),       # 1x1
+])
+def test_conv_nhwc_mfma_vs_torch(hip, cfg):
+    """lsfa_conv_nhwc_fwd (fp32 MFMA implicit GEMM, bias + ReLU epilogue) vs torch's CPU convolution in float64:
+    the fp32 result must sit within fp32 round-off of a K-term sum (both are correctly ordered sums of the same
+    exact products; only the summation order differs), and a second launch must reproduce the first bit for bit
+    (the tap slices are added in a fixed order)."""
+    import torch.nn.functional as F
+    rs = np.random.RandomState(cfg["Cin"] + cfg["H"])
+    N, H, W, Cin, Cout, k, stride, dil = (cfg[x] for x in ("N", "H", "W", "Cin", "Cout", "k", "stride", "dil"))
+    pad = dil * (k // 2)
+    x = rs.randn(N, Cin, H, W).astype(np.float32)
+    w = (rs.randn(Cout, Cin, k, k) / np.sqrt(Cin * k * k)).astype(np.float32)
+    b = rs.randn(Cout).astype(np.float32)
+    want = torch.relu(F.conv2d(torch.from_numpy(x).double(), torch.from_numpy(w).double(), torch.from_numpy(b).double(),
+                               stride, pad, dil)).permute(0, 2, 3, 1).numpy()
+    xt = t(x).permute(0, 2, 3, 1).contiguous()
+    wk = hip.conv_weight_kc(t(w))
+    got = hip.conv_nhwc(xt, wk, t(b), k, k, stride, pad, dil, relu=True)
+    again = hip.conv_nhwc(xt, wk, t(b), k, k, stride, pad, dil, relu=True)
+    assert torch.equal(got, again)
+    g = got.cpu().numpy()
+    assert g.shape == want.shape
+    scale = np.abs(want).max()
+    assert np.abs(g - want).max() < 2e-6 * np.sqrt(Cin * k * k) * max(scale, 1.0)
+    # no bias / no ReLU path
+    want2 = F.conv2d(torch.from_numpy(x).double(), torch.from_numpy(w).double(), None, stride, pad, dil).permute(0, 2, 3, 1).numpy()
+    g2 = hip.conv_nhwc(xt, wk, None, k, k, stride, pad, dil, relu=False).cpu().numpy()
+    assert np.abs(g2 - want2).max() < 2e-6 * np.sqrt(Cin * k * k) * max(np.abs(want2).max(), 1.0)
+    assert (g2 < 0).any()

@@ -1,8 +1,7 @@
-// A/B harness for the warp kernel variants (tools/lab/warp_lab.py builds and drives it).  Not part of
-// liblsfa_hip.so.  variant: 0 = round-1 kernel; 1/2/3 = current kernel with 8/4/16 channels per wave;
-// 4/5 = 8/4 channels per wave with tap sharing between the two pixels of a lane.
+// A/B harness for warp kernel variants (tools/lab/warp_lab.py builds and drives it).  Not part of liblsfa_hip.so.
 #include "warp_kernels.h"
 #include "warp_r1_kernel.h"
+#include "warp_variants.h"
 
 extern "C" int lab_warp(int variant, const float* feat, int feat_n, const float* flow, int N, int C, int H, int W,
                         const float* mul, const float* add, const float* res, int res_c, const float* res_w,
@@ -10,8 +9,10 @@ extern "C" int lab_warp(int variant, const float* feat, int feat_n, const float*
   using namespace lsfa;
   hipStream_t s = (hipStream_t)stream;
   const int HW = H * W;
-  if (HW % 2 != 0) return -1;
+  if (HW % 2 != 0 || (res && res_c != 3) || C % 16 != 0) return -1;
   const warp::Args a = {feat, feat_n, flow, N, C, H, W, mul, add, res, res_c, res_w, res_b, out};
+  const warp_lab::Args g = {feat, feat_n, flow, N, C, H, W, mul, add, res, res_w, res_b, out};
+  int rc = 0;
   switch (variant) {
     case 0: {
       const int gx = ceil_div(HW, 256 * 2);
@@ -22,18 +23,26 @@ extern "C" int lab_warp(int variant, const float* feat, int feat_n, const float*
       else if (!mul && add && res)
         hipLaunchKernelGGL((warp_r1::warp_kernel<2, false, true, true>), grid, dim3(256), 0, s, feat, feat_n, flow, C, H, W,
                            mul, add, res, res_c, res_w, res_b, out, 8);
-      else if (!mul && !add && !res)
-        hipLaunchKernelGGL((warp_r1::warp_kernel<2, false, false, false>), grid, dim3(256), 0, s, feat, feat_n, flow, C, H, W,
-                           mul, add, res, res_c, res_w, res_b, out, 8);
       else return -2;
       break;
     }
-    case 1: warp::launch<2, 8, false>(s, a); break;
-    case 2: warp::launch<2, 4, false>(s, a); break;
-    case 3: warp::launch<2, 16, false>(s, a); break;
-    case 4: warp::launch<2, 8, true>(s, a); break;
-    case 5: warp::launch<2, 4, true>(s, a); break;
+    case 1: warp::launch<2, 8, false>(s, a); break;                                   // the library's kernel, 8 ch/wave
+    //                         RUN U  FLAT   HOIST  DWORD  THREADS
+    case 2: rc = warp_lab::launch<8, 4, false, false, false, 256>(s, g); break;       // = r1's structure
+    case 3: rc = warp_lab::launch<8, 4, true, false, false, 256>(s, g); break;        // + wave-granular items
+    case 4: rc = warp_lab::launch<8, 8, true, false, false, 256>(s, g); break;        // + one batch of 8
+    case 5: rc = warp_lab::launch<8, 2, true, false, false, 256>(s, g); break;        // batches of 2
+    case 6: rc = warp_lab::launch<8, 8, true, true, false, 256>(s, g); break;         // one batch, operands hoisted
+    case 7: rc = warp_lab::launch<8, 8, false, false, false, 256>(s, g); break;       // tiled grid, one batch
+    case 8: rc = warp_lab::launch<4, 4, true, false, false, 256>(s, g); break;        // 4 ch / wave
+    case 9: rc = warp_lab::launch<16, 4, true, false, false, 256>(s, g); break;       // 16 ch / wave
+    case 10: rc = warp_lab::launch<8, 4, true, false, true, 256>(s, g); break;        // taps as 4-byte loads
+    case 11: rc = warp_lab::launch<8, 4, true, false, false, 64>(s, g); break;        // one wave per workgroup
+    case 12: rc = warp_lab::launch<8, 4, true, false, false, 1024>(s, g); break;      // 16 waves per workgroup
+    case 13: rc = warp_lab::launch<16, 8, true, false, false, 256>(s, g); break;      // 16 ch / wave, batches of 8
+    case 14: rc = warp_lab::launch<4, 2, true, false, false, 256>(s, g); break;       // 4 ch / wave, batches of 2
     default: return -3;
   }
+  if (rc) return rc;
   return (int)hipGetLastError();
 }

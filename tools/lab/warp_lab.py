@@ -24,8 +24,14 @@ ROOT = os.path.dirname(os.path.dirname(HERE))
 sys.path.insert(0, ROOT)
 from lsfa_amd import hip  # noqa: E402
 
-VARIANTS = {0: "r1 kernel (pixel-tiled workgroups, 2 batches of 4 channels)", 1: "wave items, 8 ch/wave, one batch",
-            2: "wave items, 4 ch/wave", 3: "wave items, 16 ch/wave", 4: "8 ch/wave + tap sharing", 5: "4 ch/wave + tap sharing"}
+VARIANTS = {0: "r1 kernel", 1: "library kernel (wave items, 8 ch/wave, one batch, operands first)",
+            2: "generic: tiled grid, 8 ch, batches of 4 (= r1 structure)", 3: "generic: wave items, 8 ch, batches of 4",
+            4: "generic: wave items, 8 ch, one batch of 8", 5: "generic: wave items, 8 ch, batches of 2",
+            6: "generic: wave items, one batch of 8, operands hoisted", 7: "generic: tiled grid, one batch of 8",
+            8: "generic: wave items, 4 ch/wave", 9: "generic: wave items, 16 ch/wave, batches of 4",
+            10: "generic: wave items, batches of 4, taps as 4-byte loads", 11: "generic: wave items, 64-thread workgroups",
+            12: "generic: wave items, 1024-thread workgroups", 13: "generic: wave items, 16 ch/wave, batches of 8",
+            14: "generic: wave items, 4 ch/wave, batches of 2"}
 
 
 def build():
@@ -33,7 +39,8 @@ def build():
     os.makedirs(out, exist_ok=True)
     so = os.path.join(out, "libwarp_lab.so")
     src = os.path.join(HERE, "warp_lab.hip")
-    deps = [src, os.path.join(HERE, "warp_r1_kernel.h"), os.path.join(ROOT, "lsfa_amd", "csrc", "warp_kernels.h")]
+    deps = [src, os.path.join(HERE, "warp_r1_kernel.h"), os.path.join(HERE, "warp_variants.h"),
+            os.path.join(ROOT, "lsfa_amd", "csrc", "warp_kernels.h")]
     if not os.path.exists(so) or any(os.path.getmtime(d) > os.path.getmtime(so) for d in deps):
         subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
                                "-ffp-contract=off", "-fno-fast-math", "-I", os.path.join(ROOT, "include"), "-I",
@@ -98,7 +105,7 @@ def main():
                 med, mn = float(np.median(times[v])), float(np.min(times[v]))
                 report["N=%d %s v%d" % (N, mode, v)] = dict(variant=VARIANTS[v], median_us=round(med, 2), min_us=round(mn, 2),
                                                            GBps_at_median=round(nbytes / med / 1e3, 1))
-                print("N=%-3d %-18s v%d %-62s median %8.2f us  min %8.2f us  %7.1f GB/s" % (
+                print("N=%-3d %-18s v%-2d %-66s median %8.2f us  min %8.2f us  %7.1f GB/s" % (
                     N, mode, v, VARIANTS[v], med, mn, nbytes / med / 1e3))
     os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
     with open(os.path.join(ROOT, "gpurun_out", "warp_lab.json"), "w") as f:

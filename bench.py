@@ -205,6 +205,16 @@ class Runner(object):
             nbytes = warp_bytes(M, C, fh * fw)
             result[name] = {"avg_us": round(ms * 1e3 / n, 2), "launches": n, "algorithmic_bytes_per_launch": nbytes,
                             "achieved_GBps": round(nbytes * n / (ms * 1e-3) / 1e9, 1)}
+        # what a plain streaming kernel moving the same three tensors gets on this box (torch.mul, 16-byte accesses)
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        torch.mul(feat, other, out=out)
+        a.record()
+        for _ in range(iters):
+            torch.mul(feat, other, out=out)
+        b.record()
+        torch.cuda.synchronize()
+        us = a.elapsed_time(b) * 1e3 / iters
+        result["reference: torch.mul of the same three tensors"] = {"avg_us": round(us, 2), "achieved_GBps": round(3 * feat.numel() * 4 / us / 1e3, 1)}
         return result
 
     def parity_and_cpu_baseline(self, budget_s, want_parity):

@@ -133,6 +133,11 @@ int lsfa_aggregate_cosine(const float* a, const float* b, const float* emb_warp,
  * `ws` must hold lsfa_proposal_workspace_bytes(...) bytes.
  * ------------------------------------------------------------------------ */
 size_t lsfa_proposal_workspace_bytes(int B, int A, int H, int W, int pre_nms_top_n);
+/* Launch plan (process-wide; results are identical bit for bit): AUTO picks the chip-wide plan (six short
+ * kernels spread over the CUs) for count <= 32768 anchors and pre_nms_top_n <= 8192, else the single-workgroup
+ * plan (one 16-wave workgroup per image, everything in its CU's LDS).  The workspace size does not depend on it. */
+enum { LSFA_PROPOSAL_PLAN_AUTO = 0, LSFA_PROPOSAL_PLAN_SINGLE_WORKGROUP = 1, LSFA_PROPOSAL_PLAN_CHIP_WIDE = 2 };
+int lsfa_proposal_set_plan(int plan);
 int lsfa_proposal(const float* cls_prob, const float* bbox_pred, const float* im_info,
                   int B, int A, int H, int W, int feature_stride,
                   const float* scales_host, int n_scales, const float* ratios_host, int n_ratios,

@@ -83,6 +83,9 @@ __host__ __device__ static inline int nms_tile_count(int col_blocks) { return co
 // boxes: (images, n_total, box_dim) floats; `order` (images, n) int32 or NULL: row p of the sorted list is
 // boxes[order[p]] (Proposal: candidates stay where the decode kernel put them).  mask: (images, n, col_blocks);
 // diagT: (images, n).
+// PACKED4: boxes are a plain float4 array (Proposal's sorted boxes): a column box is then read at a wave-uniform
+// address — a scalar load straight into SGPRs — instead of five v_readlane per column.
+template <bool PACKED4>
 static __global__ __launch_bounds__(256) void nms_mask_kernel(const float* __restrict__ boxes_all, long boxes_img_stride,
                                                               int box_dim, const int* __restrict__ order_all, int n,
                                                               IouTest t, uint64_t* __restrict__ mask_all,
@@ -114,6 +117,7 @@ static __global__ __launch_bounds__(256) void nms_mask_kernel(const float* __res
   }
   const float Sa = box_area(a), Sc = box_area(c);
   const int ncol = min(64, n - cb * 64);
+  const float4* col4 = reinterpret_cast<const float4*>(boxes) + (size_t)cb * 64;   // PACKED4 only
   const bool diag = rb == cb;
   // one 32-column half at a time so that the bit position is a compile-time constant after unrolling
   uint32_t word[2] = {0, 0}, tword[2] = {0, 0};
@@ -124,8 +128,8 @@ static __global__ __launch_bounds__(256) void nms_mask_kernel(const float* __res
 #pragma unroll 8
     for (int jj = 0; jj < 32; ++jj) {
       const int j = half * 32 + jj;
-      const float4 b = bcast4(c, j);
-      const float Sb = bcast1(Sc, j);
+      const float4 b = PACKED4 ? col4[min(j, ncol - 1)] : bcast4(c, j);
+      const float Sb = PACKED4 ? box_area(b) : bcast1(Sc, j);
       bool p = iou_exceeds_fast(a, Sa, b, Sb, t, unsure);
       p = p && row_ok && j < ncol && (!diag || j > lane);
       w |= (uint32_t)p << jj;
@@ -143,8 +147,8 @@ static __global__ __launch_bounds__(256) void nms_mask_kernel(const float* __res
       uint32_t w = 0;
       for (int jj = 0; jj < 32; ++jj) {
         const int j = half * 32 + jj;
-        const float4 b = bcast4(c, j);
-        const float Sb = bcast1(Sc, j);
+        const float4 b = PACKED4 ? col4[min(j, ncol - 1)] : bcast4(c, j);
+        const float Sb = PACKED4 ? box_area(b) : bcast1(Sc, j);
         bool p = iou_exceeds_div(a, Sa, b, Sb, t);
         p = p && row_ok && j < ncol && (!diag || j > lane);
         w |= (uint32_t)p << jj;
@@ -221,28 +225,43 @@ static __global__ __launch_bounds__(256) void nms_mask_f64_kernel(const double* 
 }
 
 constexpr int kSweepMaxBlocks = 512;   // n <= 32768
-constexpr int kSweepMaxOut = 1024;     // Proposal output rows kept in LDS
+constexpr int kSweepMaxOut = 1024;     // Proposal output rows
+constexpr int kSweepLazyMax = 4096;    // survivors whose positions fit the LDS list of the lazy sweep
+
+__device__ __forceinline__ uint64_t wave_or64(uint64_t v) {
+  uint32_t lo = (uint32_t)v, hi = (uint32_t)(v >> 32);
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) { lo |= __shfl_xor(lo, d, 64); hi |= __shfl_xor(hi, d, 64); }
+  return ((uint64_t)hi << 32) | lo;
+}
 
 // grid (images); block 64 (one wave).  keep: (images, n) positions in the sorted list, or NULL; num_keep:
 // (images) or NULL.  Proposal epilogue when rois != NULL: sorted_box (images, n) float4, sorted_key (images, n)
 // order keys (for `scores`), rois (images*post_n, 5), scores (images*post_n) or NULL; max_keep = post_n.
+//
+// Which candidates of block b are already suppressed is found LAZILY when max_keep <= kSweepLazyMax: the
+// survivors so far sit in an LDS list, each lane gathers word b of a survivor's mask row and the wave ORs them
+// (one memory round trip per visited block, whatever the number of survivors; nothing is ever computed for
+// blocks the sweep does not reach — Proposal stops after 300 survivors, usually within a few blocks).
+// Larger keep budgets use the eager form: every survivor's whole row is ORed into a removed-set in LDS.
 static __global__ __launch_bounds__(64) void nms_sweep_kernel(const uint64_t* __restrict__ mask_all,
-                                                       const uint64_t* __restrict__ diagT_all, int n, int col_blocks,
-                                                       int max_keep, int* __restrict__ keep_all,
-                                                       int* __restrict__ num_keep_all,
-                                                       const float4* __restrict__ sorted_box_all,
-                                                       const uint32_t* __restrict__ sorted_key_all,
-                                                       float* __restrict__ rois, float* __restrict__ scores,
-                                                       const int* __restrict__ skip_flag) {
+                                                              const uint64_t* __restrict__ diagT_all, int n, int col_blocks,
+                                                              int max_keep, int* __restrict__ keep_all,
+                                                              int* __restrict__ num_keep_all,
+                                                              const float4* __restrict__ sorted_box_all,
+                                                              const uint32_t* __restrict__ sorted_key_all,
+                                                              float* __restrict__ rois, float* __restrict__ scores) {
   __shared__ uint64_t remv[kSweepMaxBlocks];
-  __shared__ int kept_pos[kSweepMaxOut];
+  __shared__ int kept_pos[kSweepLazyMax];
   const int img = blockIdx.x;
-  if (skip_flag && skip_flag[img]) return;     // Proposal: this image took the single-workgroup path
   const uint64_t* mask = mask_all + (size_t)img * n * col_blocks;
   const uint64_t* diagT = diagT_all + (size_t)img * n;
   int* keep = keep_all ? keep_all + (size_t)img * n : nullptr;
   const int lane = threadIdx.x;
-  for (int i = lane; i < col_blocks; i += 64) remv[i] = 0;
+  const bool lazy = max_keep <= kSweepLazyMax;
+  if (!lazy) {
+    for (int i = lane; i < col_blocks; i += 64) remv[i] = 0;
+  }
   __syncthreads();  // single-wave workgroup: orders the LDS accesses of different lanes
   int num = 0;
   uint64_t col_next = lane < n ? diagT[lane] : 0ULL;
@@ -252,7 +271,14 @@ static __global__ __launch_bounds__(64) void nms_sweep_kernel(const uint64_t* __
     const uint64_t colw = col_next;
     const int nxt = base + 64 + lane;
     col_next = nxt < n ? diagT[nxt] : 0ULL;     // next block's transposed diagonal: independent of the sweep state
-    const uint64_t cur = remv[b];
+    uint64_t cur;
+    if (lazy) {
+      uint64_t acc = 0;
+      for (int k = lane; k < num; k += 64) acc |= mask[(size_t)kept_pos[k] * col_blocks + b];
+      cur = wave_or64(acc);
+    } else {
+      cur = remv[b];
+    }
     const bool alive = lane < nb && !((cur >> lane) & 1ULL);
     uint64_t G = __ballot(alive);
     if (G == 0) continue;
@@ -271,11 +297,13 @@ static __global__ __launch_bounds__(64) void nms_sweep_kernel(const uint64_t* __
     if ((kept >> lane) & 1ULL) {
       const int pos = num + __popcll(kept & ((1ULL << lane) - 1ULL));
       if (keep) keep[pos] = base + lane;
-      if (pos < kSweepMaxOut) kept_pos[pos] = base + lane;
+      if (lazy) kept_pos[pos] = base + lane;
     }
     num += __popcll(kept);
+    __syncthreads();
     if (num >= max_keep || b + 1 >= col_blocks) break;
-    // OR the survivors' rows into remv for the blocks to the right of b, 8 rows per batch of loads
+    if (lazy) continue;
+    // eager: OR the survivors' rows into remv for the blocks to the right of b, 8 rows per batch of loads
     uint64_t rem = kept;
     while (rem) {
       int ks[8];
@@ -298,7 +326,7 @@ static __global__ __launch_bounds__(64) void nms_sweep_kernel(const uint64_t* __
     __syncthreads();
   }
   if (num_keep_all && lane == 0) num_keep_all[img] = num;
-  if (rois) {
+  if (rois) {      // Proposal: max_keep = post_n <= kSweepMaxOut <= kSweepLazyMax, so kept_pos holds the survivors
     __syncthreads();
     const float4* sbox = sorted_box_all + (size_t)img * n;
     const uint32_t* skey = sorted_key_all + (size_t)img * n;

@@ -695,7 +695,7 @@ __global__ __launch_bounds__(kTopkThreads) void proposal_select_nms_kernel(
 struct WsLayout {
   size_t boxes, keys, hist, info, cand, part, sbox, skey, mask, diagT, total;
   int groups;      // decode workgroups per image
-  bool chip_wide;
+  bool chip_wide, chip_wide_possible;
 };
 int clamp_pre_n(int rpn_pre_nms_top_n, int count) {
   int pre_n = rpn_pre_nms_top_n > 0 ? rpn_pre_nms_top_n : count;  // multi_proposal.cu:435-436
@@ -706,6 +706,7 @@ WsLayout ws_layout(int B, int count, int pre_n, int post_n) {
   size_t o = 0;
   l.groups = ceil_div(count, kDecodeThreads);
   l.chip_wide = count <= kFastMaxCount && pre_n <= 8192 && post_n <= kSweepMaxOut;
+  l.chip_wide_possible = l.chip_wide;
   l.boxes = o; o += align_up((size_t)B * count * sizeof(float4), 256);
   l.keys = o; o += align_up((size_t)B * count * sizeof(uint32_t), 256);
   l.hist = l.info = l.cand = l.part = l.sbox = l.skey = l.mask = l.diagT = o;
@@ -725,6 +726,13 @@ WsLayout ws_layout(int B, int count, int pre_n, int post_n) {
 }
 
 }  // namespace
+
+static std::atomic<int> g_plan{LSFA_PROPOSAL_PLAN_AUTO};
+extern "C" int lsfa_proposal_set_plan(int plan) {
+  LSFA_REQUIRE(plan >= LSFA_PROPOSAL_PLAN_AUTO && plan <= LSFA_PROPOSAL_PLAN_CHIP_WIDE, "lsfa_proposal_set_plan: unknown plan %d", plan);
+  g_plan.store(plan);
+  return LSFA_OK;
+}
 
 extern "C" size_t lsfa_proposal_workspace_bytes(int B, int A, int H, int W, int pre_nms_top_n) {
   if (B <= 0 || A <= 0 || H <= 0 || W <= 0) return 0;
@@ -754,7 +762,9 @@ extern "C" int lsfa_proposal(const float* cls_prob, const float* bbox_pred, cons
               1024);
     return LSFA_ENOTSUP;
   }
-  const WsLayout l = ws_layout(B, count, pre_n, post_n);
+  WsLayout l = ws_layout(B, count, pre_n, post_n);     // sized for the chip-wide plan whenever the shape allows it
+  const int plan = g_plan.load();
+  if (plan == LSFA_PROPOSAL_PLAN_SINGLE_WORKGROUP) l.chip_wide = false;
   if (ws_bytes < l.total) { set_error("lsfa_proposal: workspace %zu < %zu bytes", ws_bytes, l.total); return LSFA_EWORKSPACE; }
   hipStream_t s = (hipStream_t)stream;
   unsigned char* base = (unsigned char*)ws;
@@ -785,11 +795,11 @@ extern "C" int lsfa_proposal(const float* cls_prob, const float* bbox_pred, cons
                        (const int*)info, count, part);
     hipLaunchKernelGGL(proposal_scatter_kernel, dim3(gi, B), dim3(kRankThreads), 0, s, (const uint64_t*)cand,
                        (const int*)info, (const uint16_t*)part, count, pre_n, (const float4*)boxes, sbox, skey);
-    hipLaunchKernelGGL(nms_mask_kernel, dim3(ceil_div(nms_tile_count(col_blocks), 4), 1, B), dim3(256), 0, s,
+    hipLaunchKernelGGL(nms_mask_kernel<true>, dim3(ceil_div(nms_tile_count(col_blocks), 4), 1, B), dim3(256), 0, s,
                        (const float*)sbox, (long)pre_n * 4, 4, (const int*)nullptr, pre_n, iou, mask, diagT, col_blocks);
     hipLaunchKernelGGL(nms_sweep_kernel, dim3(B), dim3(64), 0, s, (const uint64_t*)mask, (const uint64_t*)diagT, pre_n,
                        col_blocks, post_n, (int*)nullptr, (int*)nullptr, (const float4*)sbox, (const uint32_t*)skey,
-                       rois, scores, (const int*)nullptr);
+                       rois, scores);
     LSFA_LAUNCH_CHECK("lsfa_proposal");
     return LSFA_OK;
   }

@@ -229,6 +229,11 @@ class ProposalOp(object):
 
 
 @_on_tensor_device
+def proposal_set_plan(plan):
+    """'auto' | 'single' | 'chip': lsfa_proposal_set_plan (process-wide launch plan; same results)."""
+    _check(lib().lsfa_proposal_set_plan(_ci({'auto': 0, 'single': 1, 'chip': 2}[plan])), "lsfa_proposal_set_plan")
+
+
 def nms_sorted(boxes, thresh):
     """boxes (n, >=4) float32 CUDA, sorted by score descending -> (keep int32 (n,), num_keep int32 (1,)) on device."""
     boxes = _f32c(boxes, "boxes")

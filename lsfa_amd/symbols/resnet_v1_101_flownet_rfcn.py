@@ -39,7 +39,10 @@ _FLOW_GEMM_MAX_L = int(_os.environ.get('LSFA_FLOW_GEMM_L', '700'))   # FlowNet c
 _CONV1X1_MIOPEN = _os.environ.get('LSFA_CONV1X1_MIOPEN', '0') == '1'   # experiment: channel-reducing 1x1 convs through MIOpen
 # which 3x3 convolutions of the channels-last sub-networks run on the own fp32-MFMA implicit GEMM (lsfa_conv_nhwc_fwd,
 # bias + ReLU in its epilogue) instead of the library's kernel + a separate bias/ReLU pass: comma list of backbone, small
-_OWN_CONV = set(x for x in _os.environ.get('LSFA_OWN_CONV', 'backbone,small').split(',') if x)
+# measured at 1000x600 (tools/key_sections.py, hipGraph replay): backbone 4327 -> 4239 us with it, small net 256 -> 289 us:
+# the backbone's stage 2/3 units gain (epilogue fusion + deterministic tap split), the small net's 64-channel stage 1 and the
+# 256 -> 1024 fuse convolution do not
+_OWN_CONV = set(x for x in _os.environ.get('LSFA_OWN_CONV', 'backbone').split(',') if x)
 
 
 class TestSymbol(object):

@@ -3,10 +3,11 @@
 Counterparts of lib/utils/image.py: `resize` (:266-294), `transform` (:296-308) and
 `transform_mv_res` (:202-228).  The reference runs them with cv2 on the host inside a prefetch
 process; here they are torch ops on whatever device the input lives on (the frame, the motion
-vectors and the residual of a decoded GOP can stay in HBM).  cv2.resize(INTER_LINEAR) on float
-input = bilinear sampling at half-pixel centres with scale src/dst and edge clamping, no
-antialiasing [OpenCV 3.2, un-vendored — PARITY UNPINNED], which is F.interpolate(mode='bilinear',
-align_corners=False, antialias=False).
+vectors and the residual of a decoded GOP can stay in HBM).  cv2.resize(src, None, None, fx, fy,
+INTER_LINEAR) on float input [OpenCV 3.2 resize.cpp, un-vendored — PARITY UNPINNED]: dsize =
+cvRound(size * f); source coordinate of destination pixel d = (d + 0.5) / f - 0.5 — the scale is
+1/f as GIVEN, not src/dst (they differ whenever size*f is not an integer, the usual case for
+im_scale) — two taps with edge clamping, no antialiasing, horizontal pass then vertical pass.
 """
 import numpy as np
 import torch
@@ -17,12 +18,26 @@ def _cv_round(x):
     return int(np.rint(x))      # cvRound: nearest, ties to even
 
 
+def _taps(dst_n, src_n, f, device):
+    """Source taps of cv2's INTER_LINEAR along one axis: (i0, i1, weight of i1)."""
+    pos = (torch.arange(dst_n, dtype=torch.float64, device=device) + 0.5) / float(f) - 0.5
+    i0 = torch.floor(pos)
+    a = (pos - i0).to(torch.float32)
+    i0 = i0.to(torch.int64)
+    lo, hi = i0 < 0, i0 >= src_n - 1
+    i0 = torch.where(lo, torch.zeros_like(i0), torch.where(hi, torch.full_like(i0, src_n - 1), i0))
+    a = torch.where(lo | hi, torch.zeros_like(a), a)
+    return i0, torch.clamp(i0 + 1, max=src_n - 1), a
+
+
 def _resize_hwc(x, fx, fy):
-    """x: (H, W, C) float tensor -> (round(H*fy), round(W*fx), C)."""
+    """x: (H, W, C) float tensor -> (cvRound(H*fy), cvRound(W*fx), C), cv2.resize(fx=, fy=, INTER_LINEAR)."""
     h, w, _ = x.shape
     oh, ow = _cv_round(h * fy), _cv_round(w * fx)
-    y = F.interpolate(x.permute(2, 0, 1).unsqueeze(0), size=(oh, ow), mode='bilinear', align_corners=False)
-    return y[0].permute(1, 2, 0)
+    x0, x1, ax = _taps(ow, w, fx, x.device)
+    y0, y1, ay = _taps(oh, h, fy, x.device)
+    hor = x[:, x0] * (1 - ax)[None, :, None] + x[:, x1] * ax[None, :, None]
+    return hor[y0] * (1 - ay)[:, None, None] + hor[y1] * ay[:, None, None]
 
 
 def resize(im, target_size, max_size, stride=0):

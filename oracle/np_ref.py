@@ -173,14 +173,15 @@ def shard_videos(seg_lens, gpu_num):
 # ---- lib/utils/image.py:202-308 with cv2.resize(INTER_LINEAR) restated -------------------
 def cv2_resize_linear(src, fx, fy):
     """cv2.resize(src, None, None, fx, fy, INTER_LINEAR) for float images (OpenCV 3.2 resize.cpp:
-    dsize = cvRound(size*f); scale = src/dst; source coordinate (d + 0.5)*scale - 0.5, clamped so
-    that the two taps stay inside; horizontal pass then vertical pass) [un-vendored, parity unpinned]."""
+    dsize = cvRound(size*f); with fx / fy given the scale is 1/f (`scale_x = 1. / inv_scale_x`), NOT
+    src/dst; source coordinate (d + 0.5)*scale - 0.5, clamped so that the two taps stay inside;
+    horizontal pass then vertical pass) [un-vendored, parity unpinned]."""
     src = np.asarray(src, dtype=np.float32)
     sh, sw = src.shape[:2]
     dh, dw = int(np.rint(sh * fy)), int(np.rint(sw * fx))
 
-    def taps(dn, sn):
-        scale = sn / float(dn)
+    def taps(dn, sn, factor):
+        scale = 1.0 / float(factor)
         f = (np.arange(dn, dtype=np.float64) + 0.5) * scale - 0.5
         s0 = np.floor(f).astype(np.int64)
         a = (f - s0).astype(np.float32)
@@ -190,8 +191,8 @@ def cv2_resize_linear(src, fx, fy):
         s0[hi], a[hi] = sn - 1, 0.0
         return s0, np.minimum(s0 + 1, sn - 1), a
 
-    x0, x1, ax = taps(dw, sw)
-    y0, y1, ay = taps(dh, sh)
+    x0, x1, ax = taps(dw, sw, fx)
+    y0, y1, ay = taps(dh, sh, fy)
     src3 = src.reshape(sh, sw, -1)
     hor = src3[:, x0] * (1 - ax)[None, :, None] + src3[:, x1] * ax[None, :, None]
     out = hor[y0] * (1 - ay)[:, None, None] + hor[y1] * ay[:, None, None]

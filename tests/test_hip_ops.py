@@ -385,6 +385,23 @@ def test_proposal_score_distributions_that_stress_the_select(hip, kind):
     np.testing.assert_array_equal(scores.cpu().numpy(), want_scores)
 
 
+@pytest.mark.parametrize("plan", ["single", "chip"])
+def test_proposal_launch_plans_agree(hip, plan):
+    """lsfa_proposal_set_plan: the single-workgroup plan and the chip-wide plan give the oracle's result bit for bit
+    (the default picks by shape; test_proposal_bit_exact's pre_n = 12000 case runs the single-workgroup plan anyway)."""
+    rs = np.random.RandomState(77)
+    prob, deltas = rpn_inputs(rs, 2, 38, 63)
+    im_info = np.array([[600, 1000, 1.0], [592, 990, 1.3]], np.float32)
+    want_rois, want_scores = oracle.proposal(prob, deltas, im_info, rpn_min_size=16)
+    hip.proposal_set_plan(plan)
+    try:
+        rois, scores = hip.ProposalOp(rpn_min_size=16, output_score=True)(t(prob), t(deltas), t(im_info))
+    finally:
+        hip.proposal_set_plan('auto')
+    np.testing.assert_array_equal(rois.cpu().numpy(), want_rois)
+    np.testing.assert_array_equal(scores.cpu().numpy(), want_scores)
+
+
 def test_proposal_multi_image(hip):
     rs = np.random.RandomState(12)
     prob, deltas = rpn_inputs(rs, 3, 20, 30)

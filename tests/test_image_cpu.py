@@ -36,3 +36,16 @@ def test_transform_mv_res_matches_restatement_including_channel_quirk():
     # with zero means and unit scale the in-place loop leaves channel 2 == channel 0 (== source channel 2)
     _, r = image.transform_mv_res(torch.from_numpy(mv), torch.from_numpy(res), scale, [0, 0, 0], 1.0)
     np.testing.assert_array_equal(r[0, 0].numpy(), r[0, 2].numpy())
+
+
+def test_resize_uses_the_given_factor_not_the_size_ratio():
+    """cv2.resize(fx=, fy=) samples at (d + 0.5)/f - 0.5.  With f = 0.6 on 17 source pixels the output has
+    cvRound(10.2) = 10 pixels and size ratio 1.7 != 1/f: a ramp image makes the two conventions differ by a
+    known amount."""
+    src = np.tile(np.arange(17, dtype=np.float32)[None, :, None], (3, 1, 1))          # value = x coordinate
+    out = image._resize_hwc(torch.from_numpy(src), 0.6, 1.0)
+    assert out.shape == (3, 10, 1)
+    want = np.clip((np.arange(10) + 0.5) / 0.6 - 0.5, 0, 16)                            # bilinear of a ramp = the coordinate
+    np.testing.assert_allclose(out[0, :, 0].numpy(), want, rtol=0, atol=1e-5)
+    np.testing.assert_allclose(np_ref.cv2_resize_linear(src, 0.6, 1.0)[0, :, 0], want, rtol=0, atol=1e-5)
+    assert abs(want[5] - ((5 + 0.5) * 1.7 - 0.5)) > 0.1                                  # the src/dst convention would differ

@@ -56,16 +56,35 @@ def test_bench_two_ranks_one_device():
     assert d2["config"]["detections_last_interval"] > d1["config"]["detections_last_interval"]
 
 
+def _aligned(r):
+    return r[np.lexsort((r[:, 6], r[:, 5], r[:, 4], r[:, 3], -r[:, 2], r[:, 1], r[:, 0]))]
+
+
 def test_lsfa_test_three_clips_two_ranks_equal_single_rank(tmp_path):
+    """`python -m lsfa_amd.test --clips 3`: one rank (clips 0, 1, 2 through one pipeline) vs two ranks (greedy
+    assignment: rank 0 gets clips {0, 2}, rank 1 clip {1}; rows gathered over gloo in rank order).  Every process gets
+    a fresh MIOpen user database so that its immediate-mode algorithm picks do not depend on what ran on the box
+    before; with the pinned algorithms the merged detection rows are then equal bit for bit."""
     args = ["--clips", "3", "--frames", "7", "--interval", "3", "--height", "192", "--width", "320", "--pinned-algorithms"]
-    single, double = str(tmp_path / "rows1.npy"), str(tmp_path / "rows2.npy")
-    out = subprocess.run([sys.executable, "-m", "lsfa_amd.test"] + args + ["--out", single], capture_output=True,
-                         text=True, timeout=900, cwd=ROOT, env=_env())
-    assert out.returncode == 0, out.stderr[-3000:]
-    _torchrun(2, ["-m", "lsfa_amd.test"] + args + ["--out", double])
-    r1, r2 = np.load(single), np.load(double)
-    assert r1.shape == r2.shape and len(r1) > 0
-    assert sorted(np.unique(r1[:, 0]).astype(int)) == list(range(21))        # 3 clips x 7 frames, global frame ids
-    # the greedy assignment gives rank 0 clips {0, 2} and rank 1 clip {1}: the gather returns rank order, so sort rows
-    key = lambda r: r[np.lexsort((r[:, 6], r[:, 5], r[:, 4], r[:, 3], -r[:, 2], r[:, 1], r[:, 0]))]
-    np.testing.assert_array_equal(key(r1), key(r2))
+    outs = {}
+    for tag, nproc in (("one", 1), ("one_again", 1), ("two", 2)):
+        out = str(tmp_path / ("rows_%s.npy" % tag))
+        env = _env()
+        env["MIOPEN_USER_DB_PATH"] = str(tmp_path / ("miopen_" + tag))
+        os.makedirs(env["MIOPEN_USER_DB_PATH"], exist_ok=True)
+        if nproc == 1:
+            r = subprocess.run([sys.executable, "-m", "lsfa_amd.test"] + args + ["--out", out], capture_output=True, text=True,
+                               timeout=900, cwd=ROOT, env=env)
+        else:
+            r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                                "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), "-m", "lsfa_amd.test"] + args +
+                               ["--out", out], capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
+        assert r.returncode == 0, r.stderr[-3000:]
+        outs[tag] = _aligned(np.load(out))
+    r1, r1b, r2 = outs["one"], outs["one_again"], outs["two"]
+    assert len(r1) > 0 and sorted(np.unique(r1[:, 0]).astype(int)) == list(range(21))     # 3 clips x 7 frames, global frame ids
+    np.testing.assert_array_equal(r1, r1b, err_msg="two single-rank runs of the same command differ")
+    assert r1.shape == r2.shape, (r1.shape, r2.shape)
+    per_frame = [int((r1[r1[:, 0] == f] != r2[r2[:, 0] == f]).any()) if (r1[:, 0] == f).sum() == (r2[:, 0] == f).sum() else 1
+                 for f in range(21)]
+    np.testing.assert_array_equal(r1, r2, err_msg="frames whose rows differ between 1 and 2 ranks: %s" % per_frame)

@@ -1,16 +1,16 @@
 // A/B harness for warp kernel variants (tools/lab/warp_lab.py builds and drives it).  Not part of liblsfa_hip.so.
-#include "warp_kernels.h"
 #include "warp_r1_kernel.h"
 #include "warp_variants.h"
+#include "warp_r2_attempt.h"
 
 extern "C" int lab_warp(int variant, const float* feat, int feat_n, const float* flow, int N, int C, int H, int W,
                         const float* mul, const float* add, const float* res, int res_c, const float* res_w,
                         const float* res_b, float* out, void* stream) {
-  using namespace lsfa;
+  using lsfa::ceil_div;
   hipStream_t s = (hipStream_t)stream;
   const int HW = H * W;
   if (HW % 2 != 0 || (res && res_c != 3) || C % 16 != 0) return -1;
-  const warp::Args a = {feat, feat_n, flow, N, C, H, W, mul, add, res, res_c, res_w, res_b, out};
+  const warp_r2::Args a = {feat, feat_n, flow, N, C, H, W, mul, add, res, res_c, res_w, res_b, out};
   const warp_lab::Args g = {feat, feat_n, flow, N, C, H, W, mul, add, res, res_w, res_b, out};
   int rc = 0;
   switch (variant) {
@@ -26,7 +26,9 @@ extern "C" int lab_warp(int variant, const float* feat, int feat_n, const float*
       else return -2;
       break;
     }
-    case 1: warp::launch<2, 8, false>(s, a); break;                                   // the library's kernel, 8 ch/wave
+    case 1: warp_r2::launch<2, 8, false, 1>(s, a); break;     // round-2 rewrite, __launch_bounds__(256, 1) as first shipped
+    case 15: warp_r2::launch<2, 8, false, 0>(s, a); break;    // the same with plain __launch_bounds__(256)
+    case 16: warp_r2::launch<2, 8, true, 0>(s, a); break;     // + taps shared between a lane's two pixels
     //                         RUN U  FLAT   HOIST  DWORD  THREADS
     case 2: rc = warp_lab::launch<8, 4, false, false, false, 256>(s, g); break;       // = r1's structure
     case 3: rc = warp_lab::launch<8, 4, true, false, false, 256>(s, g); break;        // + wave-granular items

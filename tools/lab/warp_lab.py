@@ -24,14 +24,15 @@ ROOT = os.path.dirname(os.path.dirname(HERE))
 sys.path.insert(0, ROOT)
 from lsfa_amd import hip  # noqa: E402
 
-VARIANTS = {0: "r1 kernel", 1: "library kernel (wave items, 8 ch/wave, one batch, operands first)",
+VARIANTS = {0: "r1 kernel", 1: "round-2 rewrite (wave items, 8 ch, one batch, operands first), launch_bounds(256,1)",
             2: "generic: tiled grid, 8 ch, batches of 4 (= r1 structure)", 3: "generic: wave items, 8 ch, batches of 4",
             4: "generic: wave items, 8 ch, one batch of 8", 5: "generic: wave items, 8 ch, batches of 2",
             6: "generic: wave items, one batch of 8, operands hoisted", 7: "generic: tiled grid, one batch of 8",
             8: "generic: wave items, 4 ch/wave", 9: "generic: wave items, 16 ch/wave, batches of 4",
             10: "generic: wave items, batches of 4, taps as 4-byte loads", 11: "generic: wave items, 64-thread workgroups",
             12: "generic: wave items, 1024-thread workgroups", 13: "generic: wave items, 16 ch/wave, batches of 8",
-            14: "generic: wave items, 4 ch/wave, batches of 2"}
+            14: "generic: wave items, 4 ch/wave, batches of 2", 15: "round-2 rewrite, launch_bounds(256,2)",
+            16: "round-2 rewrite + taps shared between the two pixels of a lane"}
 
 
 def build():
@@ -39,8 +40,7 @@ def build():
     os.makedirs(out, exist_ok=True)
     so = os.path.join(out, "libwarp_lab.so")
     src = os.path.join(HERE, "warp_lab.hip")
-    deps = [src, os.path.join(HERE, "warp_r1_kernel.h"), os.path.join(HERE, "warp_variants.h"),
-            os.path.join(ROOT, "lsfa_amd", "csrc", "warp_kernels.h")]
+    deps = [src] + [os.path.join(HERE, h) for h in ("warp_r1_kernel.h", "warp_variants.h", "warp_r2_attempt.h")]
     if not os.path.exists(so) or any(os.path.getmtime(d) > os.path.getmtime(so) for d in deps):
         subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
                                "-ffp-contract=off", "-fno-fast-math", "-I", os.path.join(ROOT, "include"), "-I",

@@ -266,6 +266,14 @@ int lsfa_mv_residual(const unsigned char* bgr_cur, const unsigned char* bgr_ref,
                      int width, int height, int* res, void* stream);
 
 /* ------------------------------------------------------------------------ *
+ * Plumbing without a reference counterpart: a hipStream_t that is nobody else's (non-blocking; PyTorch's
+ * streams come from a small round-robin pool, and two graphs captured on pool twins share one BLAS
+ * workspace — lsfa_amd/core/streams.py wraps these in torch.cuda.ExternalStream for capture and replay).
+ * ------------------------------------------------------------------------ */
+int lsfa_stream_create(void** stream_out, int high_priority);
+int lsfa_stream_destroy(void* stream);
+
+/* ------------------------------------------------------------------------ *
  * Live per-op timing with HIP events on the launch stream (bench.py's roofline leg).
  * lsfa_prof_enable(mask) makes the entry points whose op id bit is set in `mask`
  * (-1 = all, 0 = off) bracket their launches with hipEventRecord on `stream`;

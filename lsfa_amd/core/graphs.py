@@ -80,7 +80,7 @@ class FrameGraphs(object):
         self.data_next = z(B, 3, height, width)        # image of the frame after the current one
         self.small_cur = z(B, dim, fh, fw)             # small-net feature of the current non-key frame
         self.small_next = z(B, dim, fh, fw)
-        self.side = torch.cuda.Stream(device=dev) if self.prefetch else None
+        self.side = streams.new_stream(dev) if self.prefetch else None
         self.feat = None            # the key graph's output feature (static address once captured)
         self.key_graph = self.cur_graph = None
         self.scale = 1.0
@@ -168,7 +168,11 @@ class FrameGraphs(object):
             if self.feat_shared is None:
                 self.feat = self._first_feat.clone()
             return
-        s = torch.cuda.Stream(device=self.device)
+        # Warm up and capture on a stream of our own.  torch keeps one BLAS workspace per (handle, stream) and
+        # captured GEMMs bake its address in; with torch's default (shared) capture stream — or with two pool
+        # streams that are the same hipStream_t (streams.new_stream) — graphs replayed concurrently on different
+        # streams (FramePipeline) would share, and corrupt, split-K scratch.
+        s = self._capture_stream = streams.new_stream(self.device)
         s.wait_stream(torch.cuda.current_stream(self.device))
         with torch.cuda.stream(s):
             if key:
@@ -180,11 +184,6 @@ class FrameGraphs(object):
                     self._cur_seq()
         torch.cuda.current_stream(self.device).wait_stream(s)
         torch.cuda.synchronize(self.device)
-        # Capture on a stream of our own.  torch keeps one BLAS workspace per (handle, stream) and captured
-        # GEMMs bake its address in; with torch's default (shared) capture stream every graph in the
-        # process would use the same workspace, and graphs replayed concurrently on different streams
-        # (FramePipeline) would corrupt each other's split-K scratch.
-        self._capture_stream = torch.cuda.Stream(device=self.device)
         if key:
             self.key_graph = torch.cuda.CUDAGraph()
             with torch.cuda.graph(self.key_graph, stream=self._capture_stream):
@@ -290,7 +289,7 @@ class KeyLane(object):
     def capture(self, warmup=3):
         if not self.use_graphs:
             return
-        s = torch.cuda.Stream(device=self.device)
+        s = self._capture_stream = streams.new_stream(self.device)     # see FrameGraphs.capture
         s.wait_stream(torch.cuda.current_stream(self.device))
         with torch.cuda.stream(s):
             for _ in range(warmup):
@@ -300,12 +299,11 @@ class KeyLane(object):
                 self.tail()
         torch.cuda.current_stream(self.device).wait_stream(s)
         torch.cuda.synchronize(self.device)
-        self._capture_stream = torch.cuda.Stream(device=self.device)     # see FrameGraphs.capture
         self.front_graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self.front_graph, stream=self._capture_stream):
             self.front()
         # FlowNet replays on another stream, beside the backbone: its own capture stream (BLAS workspace)
-        self._capture_stream_flow = torch.cuda.Stream(device=self.device)
+        self._capture_stream_flow = streams.new_stream(self.device)
         self.flow_graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self.flow_graph, stream=self._capture_stream_flow):
             self.flow()
@@ -396,7 +394,7 @@ class FramePipeline(object):
         flow_q = chosen.index(self.s_flow) if self.s_flow is not None else -1
         spare = [st for st, q in aliased if q == flow_q] + [st for st, q in aliased if q not in (flow_q, 0)] + \
                 [st for st, q in aliased if q == 0]
-        self.s_lane = [rest.pop(0) if rest else (spare.pop(0) if spare else torch.cuda.Stream(device=dev))
+        self.s_lane = [rest.pop(0) if rest else (spare.pop(0) if spare else streams.new_stream(dev))
                        for _ in range(lanes)]
         E = torch.cuda.Event
         self.ev_in, self.ev_flow, self.ev_tail, self.ev_handover = E(), E(), E(), E()

@@ -7,9 +7,40 @@ streams the process created before, so the pipeline does not guess: it probes.  
 (`torch.cuda._sleep`) are queued on a pair of candidate streams; if the pair takes about as long as
 one of them, the streams are on different hardware queues.
 """
+import ctypes
+
 import torch
 
 _SPIN = 400000        # device cycles per probe kernel (~0.2 ms)
+_OWNED = []           # hipStream_t handles created here and still wrapped by a live ExternalStream
+
+
+def new_stream(device):
+    """A stream that is this caller's alone.  `torch.cuda.Stream()` draws from a pool of 32 per priority
+    and wraps around: after enough pipelines / captures two Stream objects are the SAME hipStream_t.  PyTorch
+    keys its BLAS workspace by (handle, stream) and captured GEMMs bake that address in, so graphs captured
+    on such twins share split-K / stream-K scratch; replayed concurrently they corrupt each other, and the
+    library kernels that spin on flags in that scratch never finish (observed: a device-side hang with two
+    pipelines in one process).  Streams made here are created with hipStreamCreate and wrapped as
+    ExternalStream; they live until `release`d (or the process ends)."""
+    from lsfa_amd import hip
+    dev = torch.device(device)
+    ptr = ctypes.c_void_p()
+    with torch.cuda.device(dev):
+        hip._check(hip.lib().lsfa_stream_create(ctypes.byref(ptr), ctypes.c_int(0)), "lsfa_stream_create")
+    s = torch.cuda.ExternalStream(ptr.value, device=dev)
+    _OWNED.append(ptr.value)
+    return s
+
+
+def release(stream):
+    """Destroy a stream made by new_stream (it must be idle and no graph may have been captured on it)."""
+    from lsfa_amd import hip
+    ptr = stream.cuda_stream
+    if ptr in _OWNED:
+        _OWNED.remove(ptr)
+        with torch.cuda.device(stream.device):
+            hip._check(hip.lib().lsfa_stream_destroy(ctypes.c_void_p(ptr)), "lsfa_stream_destroy")
 
 
 def _pair_time(a, b, dev):
@@ -41,12 +72,17 @@ def concurrent_streams(n, device, candidates=16):
     list of the other candidates tried, each tagged with the index of the chosen stream it aliases:
     -> (chosen, [(stream, alias_index), ...])."""
     dev = torch.device(device)
-    pool = [torch.cuda.Stream(device=dev) for _ in range(candidates)]
-    chosen, aliased = [], []
+    pool = [new_stream(dev) for _ in range(candidates)]
+    chosen, aliased, unused = [], [], []
     for s in pool:
         clash = next((i for i, c in enumerate(chosen) if not overlaps(c, s, dev)), None)
         if clash is None and len(chosen) < n:
             chosen.append(s)
-        elif clash is not None:
+        elif clash is not None and len(aliased) < n:
             aliased.append((s, clash))
+        else:
+            unused.append(s)
+    torch.cuda.synchronize(dev)
+    for s in unused:
+        release(s)
     return chosen, aliased

@@ -57,6 +57,28 @@ using namespace lsfa;
 extern "C" const char* lsfa_last_error(void) { return g_err; }
 extern "C" int lsfa_abi_version(void) { return 1; }
 
+// A stream of our own.  PyTorch hands out streams from a pool of 32 per priority and wraps around, so two
+// `torch.cuda.Stream()` objects may be ONE hipStream_t; its BLAS workspace is keyed by (handle, stream), so
+// graphs captured on such twins bake the same split-K / stream-K scratch in and corrupt (or dead-lock: the
+// library's kernels spin on flags in that scratch) each other when they replay concurrently.
+extern "C" int lsfa_stream_create(void** stream_out, int high_priority) {
+  LSFA_REQUIRE(stream_out, "lsfa_stream_create: NULL argument");
+  int lo = 0, hi = 0;
+  (void)hipDeviceGetStreamPriorityRange(&lo, &hi);      // lo = least, hi = greatest priority (numerically lower)
+  hipStream_t s = nullptr;
+  const hipError_t e = hipStreamCreateWithPriority(&s, hipStreamNonBlocking, high_priority ? hi : lo);
+  if (e != hipSuccess) return hip_fail(e, "lsfa_stream_create");
+  *stream_out = (void*)s;
+  return LSFA_OK;
+}
+
+extern "C" int lsfa_stream_destroy(void* stream) {
+  if (!stream) return LSFA_OK;
+  const hipError_t e = hipStreamDestroy((hipStream_t)stream);
+  if (e != hipSuccess) return hip_fail(e, "lsfa_stream_destroy");
+  return LSFA_OK;
+}
+
 extern "C" int lsfa_prof_enable(int mask) {
   std::lock_guard<std::mutex> lk(g_mu);
   g_prof = (unsigned)mask;

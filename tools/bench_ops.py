@@ -47,8 +47,10 @@ def main():
     ap.add_argument('--iters', type=int, default=50)
     ap.add_argument('--H', type=int, default=38)
     ap.add_argument('--W', type=int, default=63)
+    ap.add_argument('--proposal-plan', default='auto', choices=['auto', 'single', 'chip'])
     args = ap.parse_args()
     dev = 'cuda:0'
+    hip.proposal_set_plan(args.proposal_plan)
     H, W, C = args.H, args.W, 1024
     HW = H * W
     rs = np.random.RandomState(0)

@@ -97,14 +97,19 @@ __global__ __launch_bounds__(kThreads) void conv_igemm_kernel(ConvArgs a) {
   for (int chunk = 0; chunk < nchunks; ++chunk) {
     const int buf = chunk & 1;
     if (chunk + 1 < nchunks) LSFA_CONV_FETCH(chunk + 1)  // global loads in flight under the MFMAs
+    // all eight fragment reads of the chunk first: the LDS latency is exposed once, in front of the first MFMA
+    float4 av[kBK / 8], bv[kBK / 8];
 #pragma unroll
     for (int c = 0; c < kBK / 8; ++c) {
-      const float4 av = *reinterpret_cast<const float4*>(&As[buf][arow + 8 * c]);
-      const float4 bv = *reinterpret_cast<const float4*>(&Bs[buf][brow + 8 * c]);
-      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, bv.x, acc, 0, 0, 0);
-      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.y, bv.y, acc, 0, 0, 0);
-      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.z, bv.z, acc, 0, 0, 0);
-      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.w, bv.w, acc, 0, 0, 0);
+      av[c] = *reinterpret_cast<const float4*>(&As[buf][arow + 8 * c]);
+      bv[c] = *reinterpret_cast<const float4*>(&Bs[buf][brow + 8 * c]);
+    }
+#pragma unroll
+    for (int c = 0; c < kBK / 8; ++c) {
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[c].x, bv[c].x, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[c].y, bv[c].y, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[c].z, bv[c].z, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[c].w, bv[c].w, acc, 0, 0, 0);
     }
     __builtin_amdgcn_sched_barrier(0);   // keep every use of the freshly loaded registers behind the MFMAs
     if (chunk + 1 < nchunks) {

@@ -73,6 +73,23 @@ def main():
             ('ref: torch add (2 maps -> 1)', lambda: torch.add(feat, feat2, out=o), b3)):
         us = timeit(fn, args.iters)
         out[name] = dict(us=round(us, 2), GBps=round(nbytes / us / 1e3, 1), bytes=nbytes)
+    # Fgfa cosine weights at LSFA's shape: 2048-channel embeddings on the 38x63 map
+    ew, ec = torch.randn(1, 2048, H, W, device=dev), torch.randn(1, 2048, H, W, device=dev)
+    us = timeit(lambda: hip.aggregate_cosine(feat, feat2, ew, ec, out=o), args.iters)
+    out['aggregate_cosine(E=2048)'] = dict(us=round(us, 2), bytes=2 * 2 * 2048 * HW * 4 + b3)
+    # compressed-domain motion vectors, one 1000x600 P-frame of 16x16 macroblocks
+    acc = hip.MotionVectorAccumulator(1000, 600, dev)
+    blocks = [[-1, 16, 16, bx + 8 - rs.randint(-9, 10), by + 8 - rs.randint(-9, 10), bx + 8, by + 8]
+              for by in range(0, 600, 16) for bx in range(0, 1000, 16)]
+    mvs = torch.tensor(blocks, dtype=torch.int32, device=dev)
+    us = timeit(lambda: acc.add_frame(mvs), args.iters)
+    out['mv_accumulate(1000x600)'] = dict(us=round(us, 2), bytes=1000 * 600 * (4 + 4 + 8 + 8))
+    # own fp32 MFMA convolution: stage-3 conv2
+    xr = torch.randn(1, H, W, 256, device=dev)
+    wk = hip.conv_weight_kc(torch.randn(256, 256, 3, 3, device=dev) * 0.02)
+    bb = torch.randn(256, device=dev)
+    us = timeit(lambda: hip.conv_nhwc(xr, wk, bb, 3, 3, 1, 1, 1, relu=True), args.iters)
+    out['conv_nhwc 3x3 256->256 @38x63'] = dict(us=round(us, 2), TFLOPs=round(2 * HW * 256 * 2304 / us / 1e6, 1))
     # PSROI / head
     cls_map, box_map = torch.randn(1, 31 * 49, H, W, device=dev), torch.randn(1, 8 * 49, H, W, device=dev)
     rois_np = np.zeros((300, 5), np.float32)

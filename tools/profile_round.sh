@@ -1,0 +1,42 @@
+#!/bin/bash
+# The rocprofv3 passes behind profiles/<round>/ (run on the GPU box: gpurun -- bash tools/profile_round.sh r2).
+# Raw traces stay on the box; the condensed summaries land in gpurun_out/<round>/ and are copied to profiles/<round>/.
+# PMC passes never share a run with --sys-trace / --runtime-trace (the pool refuses that combination).
+set -u
+R=${1:-r2}
+OUT=gpurun_out/$R
+mkdir -p $OUT
+export TMPDIR=/tmp
+PY=python3
+
+# 1. the bench lines (default = configs[1]; configs[4]; configs[2])
+timeout 400 $PY bench.py --steps 100 > $OUT/bench_default_run.json 2> $OUT/bench_default_run.err
+timeout 400 $PY bench.py --interval 1 --maps-per-launch 32 --steps 60 > $OUT/bench_interval1_maps32_run.json 2> $OUT/bench_interval1_maps32_run.err
+timeout 600 $PY bench.py --dtype bf16 --clips 4 --steps 40 > $OUT/bench_bf16_clips4_run.json 2> $OUT/bench_bf16_clips4_run.err
+timeout 400 $PY bench.py --dtype bf16 --steps 60 --no-cpu-baseline --no-parity > $OUT/bench_bf16_clips1_run.json 2> /dev/null
+
+# 2. kernel trace of the pipelined timed region (default configuration)
+timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_pipe -o t -- $PY bench.py --steps 30 --no-cpu-baseline --no-parity > $OUT/trace_pipe.log 2>&1
+$PY tools/summarize_prof.py trace $OUT/trace_pipe $OUT/bench_pipelined_timed_region_kernels.csv 0.6
+cp $(find $OUT/trace_pipe -name "*kernel_stats.csv" | head -1) $OUT/bench_pipelined_kernel_stats_whole_run.csv 2>/dev/null
+rm -rf $OUT/trace_pipe
+
+# 3. matrix-pipe duty per kernel, serial eager loop (counters only: no trace domains next to --pmc)
+timeout 400 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES GRBM_GUI_ACTIVE --output-format csv -d $OUT/pmc_mfma -o t -- $PY bench.py --steps 6 --warmup 2 --no-graph --lanes 0 --no-cpu-baseline --no-parity > $OUT/pmc_mfma.log 2>&1
+$PY tools/summarize_prof.py pmctable $OUT/pmc_mfma $OUT/bench_eager_pmc_mfma_busy.csv
+rm -rf $OUT/pmc_mfma
+
+# 4. HBM traffic of the streaming kernels (FETCH_SIZE and WRITE_SIZE cannot share a pass) -> traffic.json
+timeout 200 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -o t -- $PY tools/traffic_probe.py run > $OUT/traffic_fetch.log 2>&1
+timeout 200 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -o t -- $PY tools/traffic_probe.py run > $OUT/traffic_write.log 2>&1
+timeout 200 rocprofv3 --kernel-trace --output-format csv -d $OUT/pmc_trace -o t -- $PY tools/traffic_probe.py run > $OUT/traffic_trace.log 2>&1
+$PY tools/traffic_probe.py summarize $OUT/pmc_fetch $OUT/pmc_write $OUT/pmc_trace $OUT/traffic.json > $OUT/traffic_summary.log 2>&1
+rm -rf $OUT/pmc_fetch $OUT/pmc_write $OUT/pmc_trace
+
+# 5. per-op kernels (GPU-side durations) and the warp A/B
+timeout 200 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_ops -o t -- $PY tools/bench_ops.py > $OUT/bench_ops_microbench.txt 2>&1
+cp $(find $OUT/trace_ops -name "*kernel_stats.csv" | head -1) $OUT/bench_ops_kernel_stats.csv 2>/dev/null
+rm -rf $OUT/trace_ops
+timeout 200 $PY tools/lab/warp_lab.py --rounds 9 > $OUT/warp_lab.txt 2>&1
+timeout 200 $PY tools/key_sections.py > $OUT/key_sections.txt 2>&1
+ls -la $OUT

@@ -92,7 +92,7 @@ __global__ __launch_bounds__(kThreads) void combine_kernel(const float* __restri
 // wave holds channel class j of the wave's pixels: the chunk loop is the in-order accumulation of
 // partial j, and the butterfly is six __shfl_xor steps — the cross-lane reduction north_star asks
 // for — with bit-identical results on both sides.
-constexpr int kCosPx = 32;                    // pixels per workgroup (128-byte segments per channel row)
+constexpr int kCosPx = 16;                    // pixels per workgroup (64-byte segments per channel row; 150 workgroups at 38x63)
 constexpr int kCosWaves = kThreads / 64;      // 4
 constexpr int kCosPxPerWave = kCosPx / kCosWaves;
 
@@ -106,9 +106,20 @@ __global__ __launch_bounds__(kThreads) void cosine_logits_kernel(const float* __
                                                                  const float* __restrict__ emb_cur, int E,
                                                                  int HW, float* __restrict__ logits) {
   __shared__ float tw[64][kCosPx + 1], tc[64][kCosPx + 1];
+  constexpr int kPerThread = 64 * kCosPx / kThreads;      // staged values per thread, tensor and chunk (8)
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int p0 = blockIdx.x * kCosPx;
   const int chunks = (E + 63) / 64;
+  // staging role: value q of this thread is (row r = (q*256 + tid) / 32, pixel x = (q*256 + tid) % 32) of a chunk
+  int srow[kPerThread], scol[kPerThread];
+  size_t soff[kPerThread];
+#pragma unroll
+  for (int q = 0; q < kPerThread; ++q) {
+    const int idx = q * kThreads + tid;
+    srow[q] = idx / kCosPx;
+    scol[q] = idx - srow[q] * kCosPx;
+    soff[q] = (size_t)srow[q] * HW + min(p0 + scol[q], HW - 1);
+  }
   float nw[kCosPxPerWave], nc[kCosPxPerWave];
   float l0[kCosPxPerWave], l1[kCosPxPerWave];
 #pragma unroll 1
@@ -116,29 +127,37 @@ __global__ __launch_bounds__(kThreads) void cosine_logits_kernel(const float* __
     float acc_a[kCosPxPerWave], acc_b[kCosPxPerWave];
 #pragma unroll
     for (int i = 0; i < kCosPxPerWave; ++i) { acc_a[i] = 0.f; acc_b[i] = 0.f; }
-    for (int ch = 0; ch < chunks; ++ch) {
-      // stage 64 channels x kCosPx pixels of both embeddings (rows past E and pixels past HW read as 0 / clamped)
+    // chunk ch+1 is in flight (registers) while chunk ch is reduced out of LDS: with one 4-wave workgroup per
+    // CU there is nothing else to hide the load latency behind
+    float vw[kPerThread], vc[kPerThread];
 #pragma unroll
-      for (int q = 0; q < 64 * kCosPx / kThreads; ++q) {
-        const int idx = q * kThreads + tid;
-        const int r = idx / kCosPx, x = idx - r * kCosPx;
-        const int e = ch * 64 + r;
-        const int p = min(p0 + x, HW - 1);
-        float vw = 0.f, vc = 0.f;
-        if (e < E) { vw = emb_warp[(size_t)e * HW + p]; vc = emb_cur[(size_t)e * HW + p]; }
-        tw[r][x] = vw;
-        tc[r][x] = vc;
-      }
+    for (int q = 0; q < kPerThread; ++q) {
+      const bool ok = srow[q] < E;
+      vw[q] = ok ? emb_warp[soff[q]] : 0.f;
+      vc[q] = ok ? emb_cur[soff[q]] : 0.f;
+    }
+    for (int ch = 0; ch < chunks; ++ch) {
+#pragma unroll
+      for (int q = 0; q < kPerThread; ++q) { tw[srow[q]][scol[q]] = vw[q]; tc[srow[q]][scol[q]] = vc[q]; }
       __syncthreads();
+      if (ch + 1 < chunks) {
+        const size_t base = (size_t)(ch + 1) * 64 * HW;
+#pragma unroll
+        for (int q = 0; q < kPerThread; ++q) {
+          const bool ok = (ch + 1) * 64 + srow[q] < E;
+          vw[q] = ok ? emb_warp[base + soff[q]] : 0.f;
+          vc[q] = ok ? emb_cur[base + soff[q]] : 0.f;
+        }
+      }
 #pragma unroll
       for (int i = 0; i < kCosPxPerWave; ++i) {
         const int x = wid * kCosPxPerWave + i;
-        const float vw = tw[lane][x], vc = tc[lane][x];
+        const float a = tw[lane][x], c = tc[lane][x];
         if (pass == 0) {
-          acc_a[i] += vw * vw;
-          acc_b[i] += vc * vc;
+          acc_a[i] += a * a;
+          acc_b[i] += c * c;
         } else {
-          const float uw = vw / nw[i], uc = vc / nc[i];
+          const float uw = a / nw[i], uc = c / nc[i];
           acc_a[i] += uw * uc;
           acc_b[i] += uc * uc;
         }

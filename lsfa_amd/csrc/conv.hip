@@ -8,14 +8,15 @@
 // cycles whatever else is resident, so the time is (tile-tasks per SIMD, rounded up) x (MFMAs per
 // task) x 64 cycles, and the lever is the task count, not occupancy:
 //   * a workgroup computes a 64-pixel x 64-channel tile with 4 waves (one 32x32 accumulator tile each:
-//     16 VGPRs), K walked tap by tap in 32-channel chunks, staged through LDS, double-buffered;
+//     16 VGPRs), K walked tap by tap in 64-channel chunks (32 when Cin % 64 != 0), staged through LDS,
+//     double-buffered;
 //   * gridDim.z splits the TAPS over workgroups (3 x 3 taps for a 3x3 kernel) when the tile grid alone
 //     would leave SIMDs idle; the slices write fp32 partial tiles to the workspace and a second kernel
 //     adds them in a fixed order and applies bias + ReLU — deterministic, unlike the library's atomic
 //     split-K (its `gkgs` kernels) which also needs a zero-fill launch;
 //   * the MFMA sums over k in any order we like, as long as A and B agree: a lane reads 4 consecutive
 //     k of its row/column with ONE ds_read_b128 (lanes 0-31 take k = 8c..8c+3, lanes 32-63 take
-//     8c+4..8c+7) and feeds 4 MFMAs from it; LDS rows are padded to 36 floats, which spreads the 16
+//     8c+4..8c+7) and feeds 4 MFMAs from it; LDS rows are padded by 4 floats, which spreads the 16
 //     lanes of a b128 group over all 64 banks.
 // Zero padding is realised when a chunk is staged (out-of-map pixels load zeros).
 // Weight layout (prepared once at bind time): w[co][tap][ci], i.e. K contiguous per output channel.
@@ -25,8 +26,7 @@ using namespace lsfa;
 
 namespace {
 
-constexpr int kBM = 64, kBN = 64, kBK = 32;
-constexpr int kLdk = kBK + 4;                 // padded LDS row (floats)
+constexpr int kBM = 64, kBN = 64;
 constexpr int kThreads = 256;
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -36,8 +36,13 @@ struct ConvArgs {
   int N, H, W, Cin, Cout, kh, kw, stride, pad, dil, Ho, Wo, relu, taps_per_slice;
 };
 
-// grid (ceil(P / 64), Cout / 64, slices); block 256.  P = N*Ho*Wo output pixels.
+// grid (ceil(P / 64), Cout / 64, slices); block 256.  P = N*Ho*Wo output pixels.  BK = channels per staged chunk
+// (64 when Cin allows: 32 MFMAs per wave between barriers, long enough to cover the L2 latency of the next
+// chunk's loads with the ~2 waves per SIMD these small grids leave; 32 otherwise).
+template <int BK>
 __global__ __launch_bounds__(kThreads) void conv_igemm_kernel(ConvArgs a) {
+  constexpr int kLdk = BK + 4;                // padded LDS row (floats): conflict-free ds_read_b128 groups
+  constexpr int NV = BK / 16;                 // float4 per thread and operand of a staged chunk
   __shared__ __attribute__((aligned(16))) float As[2][kBM * kLdk];
   __shared__ __attribute__((aligned(16))) float Bs[2][kBN * kLdk];
   const int tid = threadIdx.x, lane = tid & 63;
@@ -47,42 +52,48 @@ __global__ __launch_bounds__(kThreads) void conv_igemm_kernel(ConvArgs a) {
   const int m0 = blockIdx.x * kBM, n0 = blockIdx.y * kBN;
   const int taps = a.kh * a.kw;
   const int tap0 = blockIdx.z * a.taps_per_slice, tap1 = min(tap0 + a.taps_per_slice, taps);
-  const int chunks_per_tap = a.Cin / kBK;
+  const int chunks_per_tap = a.Cin / BK;
   const int nchunks = (tap1 - tap0) * chunks_per_tap;
 
-  // staging role of this thread: row (pixel of A / channel of B) and an 8-float column segment
-  const int srow = tid >> 2, scol = (tid & 3) * 8;
+  // staging role of this thread: row (pixel of A / channel of B) and a (BK/4)-float column segment
+  const int srow = tid >> 2, scol = (tid & 3) * (BK / 4);
   const int pix = m0 + srow;
   const bool pix_ok = pix < P;
   int py = 0, px = 0, pn = 0;
   if (pix_ok) { pn = pix / (a.Ho * a.Wo); const int r = pix - pn * a.Ho * a.Wo; py = r / a.Wo; px = r - py * a.Wo; }
   const float* wrow = a.w + ((size_t)(n0 + srow) * taps) * a.Cin + scol;
 
-  // named registers (not arrays captured by a lambda: those end up in scratch memory and serialise the loads)
-  float4 ra0, ra1, rb0, rb1;
+  // named registers: arrays (even with compile-time indices) and lambda captures ended up in scratch memory here
+  float4 ra0, ra1, ra2, ra3, rb0, rb1, rb2, rb3;      // NV = 2 uses the first two of each
+  ra2 = ra3 = rb2 = rb3 = make_float4(0.f, 0.f, 0.f, 0.f);
   float a_keep = 0.f;
 #define LSFA_CONV_FETCH(chunk_)                                                                                        \
   {                                                                                                                    \
     const int t_ = (chunk_) / chunks_per_tap;                                                                          \
     const int tap = tap0 + t_;                                                                                         \
-    const int ci0 = ((chunk_) - t_ * chunks_per_tap) * kBK;                                                            \
+    const int ci0 = ((chunk_) - t_ * chunks_per_tap) * BK;                                                             \
     const int ty = tap / a.kw, tx = tap - ty * a.kw;                                                                   \
     const int iy = py * a.stride - a.pad + ty * a.dil, ix = px * a.stride - a.pad + tx * a.dil;                        \
     const bool ok = pix_ok && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W;                                              \
     const float4* src = reinterpret_cast<const float4*>(a.x + (((size_t)pn * a.H + (ok ? iy : 0)) * a.W + (ok ? ix : 0)) * a.Cin + ci0 + scol); \
-    ra0 = src[0]; ra1 = src[1];                                                                                        \
+    const float4* wsrc = reinterpret_cast<const float4*>(wrow + (size_t)tap * a.Cin + ci0);                            \
+    ra0 = src[0]; ra1 = src[1]; rb0 = wsrc[0]; rb1 = wsrc[1];                                                          \
+    if (NV > 2) { ra2 = src[2]; ra3 = src[3]; rb2 = wsrc[2]; rb3 = wsrc[3]; }                                          \
     a_keep = ok ? 1.0f : 0.0f;   /* zero padding = the (clamped, valid) load times 0, applied when the chunk is */     \
                                  /* written to LDS: any use of the loaded value here would stall the wave before its MFMAs */ \
-    const float4* wsrc = reinterpret_cast<const float4*>(wrow + (size_t)tap * a.Cin + ci0);                            \
-    rb0 = wsrc[0]; rb1 = wsrc[1];                                                                                      \
   }
 #define LSFA_CONV_STASH(buf_)                                                                                          \
   {                                                                                                                    \
     float4* da = reinterpret_cast<float4*>(&As[buf_][srow * kLdk + scol]);                                             \
+    float4* db = reinterpret_cast<float4*>(&Bs[buf_][srow * kLdk + scol]);                                             \
     da[0] = make_float4(ra0.x * a_keep, ra0.y * a_keep, ra0.z * a_keep, ra0.w * a_keep);                               \
     da[1] = make_float4(ra1.x * a_keep, ra1.y * a_keep, ra1.z * a_keep, ra1.w * a_keep);                               \
-    float4* db = reinterpret_cast<float4*>(&Bs[buf_][srow * kLdk + scol]);                                             \
     db[0] = rb0; db[1] = rb1;                                                                                          \
+    if (NV > 2) {                                                                                                      \
+      da[2] = make_float4(ra2.x * a_keep, ra2.y * a_keep, ra2.z * a_keep, ra2.w * a_keep);                             \
+      da[3] = make_float4(ra3.x * a_keep, ra3.y * a_keep, ra3.z * a_keep, ra3.w * a_keep);                             \
+      db[2] = rb2; db[3] = rb3;                                                                                        \
+    }                                                                                                                  \
   }
 
   f32x16 acc;
@@ -97,19 +108,14 @@ __global__ __launch_bounds__(kThreads) void conv_igemm_kernel(ConvArgs a) {
   for (int chunk = 0; chunk < nchunks; ++chunk) {
     const int buf = chunk & 1;
     if (chunk + 1 < nchunks) LSFA_CONV_FETCH(chunk + 1)  // global loads in flight under the MFMAs
-    // all eight fragment reads of the chunk first: the LDS latency is exposed once, in front of the first MFMA
-    float4 av[kBK / 8], bv[kBK / 8];
 #pragma unroll
-    for (int c = 0; c < kBK / 8; ++c) {
-      av[c] = *reinterpret_cast<const float4*>(&As[buf][arow + 8 * c]);
-      bv[c] = *reinterpret_cast<const float4*>(&Bs[buf][brow + 8 * c]);
-    }
-#pragma unroll
-    for (int c = 0; c < kBK / 8; ++c) {
-      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[c].x, bv[c].x, acc, 0, 0, 0);
-      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[c].y, bv[c].y, acc, 0, 0, 0);
-      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[c].z, bv[c].z, acc, 0, 0, 0);
-      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[c].w, bv[c].w, acc, 0, 0, 0);
+    for (int c = 0; c < BK / 8; ++c) {
+      const float4 av = *reinterpret_cast<const float4*>(&As[buf][arow + 8 * c]);
+      const float4 bv = *reinterpret_cast<const float4*>(&Bs[buf][brow + 8 * c]);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, bv.x, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.y, bv.y, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.z, bv.z, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.w, bv.w, acc, 0, 0, 0);
     }
     __builtin_amdgcn_sched_barrier(0);   // keep every use of the freshly loaded registers behind the MFMAs
     if (chunk + 1 < nchunks) {
@@ -172,8 +178,8 @@ extern "C" int lsfa_conv_nhwc_fwd(const float* x, int N, int H, int W, int Cin, 
                                   void* stream) {
   LSFA_REQUIRE(x && w && y, "lsfa_conv_nhwc_fwd: NULL argument");
   LSFA_REQUIRE(N > 0 && H > 0 && W > 0 && kh > 0 && kw > 0 && stride > 0 && pad >= 0 && dil > 0, "lsfa_conv_nhwc_fwd: bad shape");
-  if (Cin % kBK != 0 || Cout % kBN != 0) {
-    set_error("lsfa_conv_nhwc_fwd: Cin=%d must be a multiple of %d and Cout=%d of %d", Cin, kBK, Cout, kBN);
+  if (Cin % 32 != 0 || Cout % kBN != 0) {
+    set_error("lsfa_conv_nhwc_fwd: Cin=%d must be a multiple of %d and Cout=%d of %d", Cin, 32, Cout, kBN);
     return LSFA_ENOTSUP;
   }
   const int Ho = (H + 2 * pad - dil * (kh - 1) - 1) / stride + 1, Wo = (W + 2 * pad - dil * (kw - 1) - 1) / stride + 1;
@@ -191,7 +197,9 @@ extern "C" int lsfa_conv_nhwc_fwd(const float* x, int N, int H, int W, int Cin, 
   ConvArgs a = {x, w, bias, y, slices > 1 ? (float*)ws : nullptr, N, H, W, Cin, Cout, kh, kw, stride, pad, dil, Ho, Wo, relu,
                 (taps + slices - 1) / slices};
   ProfScope prof(LSFA_OP_CONV, s);
-  hipLaunchKernelGGL(conv_igemm_kernel, dim3((unsigned)((P + kBM - 1) / kBM), Cout / kBN, slices), dim3(kThreads), 0, s, a);
+  const dim3 grid((unsigned)((P + kBM - 1) / kBM), Cout / kBN, slices);
+  if (Cin % 64 == 0) hipLaunchKernelGGL(conv_igemm_kernel<64>, grid, dim3(kThreads), 0, s, a);
+  else hipLaunchKernelGGL(conv_igemm_kernel<32>, grid, dim3(kThreads), 0, s, a);
   if (slices > 1) {
     const long n4 = P * Cout / 4;
     hipLaunchKernelGGL(conv_reduce_kernel, dim3((unsigned)((n4 + kThreads - 1) / kThreads)), dim3(kThreads), 0, s,

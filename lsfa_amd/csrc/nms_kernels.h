@@ -83,17 +83,23 @@ __host__ __device__ static inline int nms_tile_count(int col_blocks) { return co
 // boxes: (images, n_total, box_dim) floats; `order` (images, n) int32 or NULL: row p of the sorted list is
 // boxes[order[p]] (Proposal: candidates stay where the decode kernel put them).  mask: (images, n, col_blocks);
 // diagT: (images, n).
-// PACKED4: boxes are a plain float4 array (Proposal's sorted boxes): a column box is then read at a wave-uniform
-// address — a scalar load straight into SGPRs — instead of five v_readlane per column.
+// PACKED4: boxes are a plain float4 array (Proposal's sorted boxes) and are loaded as one 16-byte access.
+// The 64 column boxes of a tile are staged once in LDS (one per lane) and read back at wave-uniform addresses
+// (a broadcast read per column, issued ahead by the unrolled loop); the loop body is the IoU test and a bit
+// insert only — row / column validity and the j > i rule of diagonal tiles are applied to the finished words,
+// and the transposed diagonal words come from 64 ballots over the finished rows (diagonal tiles only).
 template <bool PACKED4>
 static __global__ __launch_bounds__(256) void nms_mask_kernel(const float* __restrict__ boxes_all, long boxes_img_stride,
                                                               int box_dim, const int* __restrict__ order_all, int n,
                                                               IouTest t, uint64_t* __restrict__ mask_all,
                                                               uint64_t* __restrict__ diagT_all, int col_blocks) {
+  __shared__ float4 cbox[4][64];
+  __shared__ float carea[4][64];
   const int lane = threadIdx.x & 63;
   // wave-uniform, and the compiler is told so: the tile indices and the `diag` branch stay scalar
-  const int tile = blockIdx.x * 4 + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-  if (tile >= nms_tile_count(col_blocks)) return;
+  const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const int tile = blockIdx.x * 4 + wv;
+  const bool tile_ok = tile < nms_tile_count(col_blocks);
   // tile -> (rb <= cb), tiles enumerated column by column: tile = cb*(cb+1)/2 + rb
   int cb = (int)((sqrtf(8.0f * (float)tile + 1.0f) - 1.0f) * 0.5f);
   while ((cb + 1) * (cb + 2) / 2 <= tile) ++cb;
@@ -105,22 +111,24 @@ static __global__ __launch_bounds__(256) void nms_mask_kernel(const float* __res
   uint64_t* mask = mask_all + (size_t)img * n * col_blocks;
 
   const int row = rb * 64 + lane, col = cb * 64 + lane;
-  const bool row_ok = row < n, col_ok = col < n;
+  const bool row_ok = tile_ok && row < n, col_ok = tile_ok && col < n;
   float4 a = make_float4(0.f, 0.f, 0.f, 0.f), c = make_float4(0.f, 0.f, 0.f, 0.f);
   if (row_ok) {
-    const float* p = boxes + (size_t)(order ? order[row] : row) * box_dim;
-    a = make_float4(p[0], p[1], p[2], p[3]);
+    if (PACKED4) a = reinterpret_cast<const float4*>(boxes)[row];
+    else { const float* p = boxes + (size_t)(order ? order[row] : row) * box_dim; a = make_float4(p[0], p[1], p[2], p[3]); }
   }
   if (col_ok) {
-    const float* p = boxes + (size_t)(order ? order[col] : col) * box_dim;
-    c = make_float4(p[0], p[1], p[2], p[3]);
+    if (PACKED4) c = reinterpret_cast<const float4*>(boxes)[col];
+    else { const float* p = boxes + (size_t)(order ? order[col] : col) * box_dim; c = make_float4(p[0], p[1], p[2], p[3]); }
   }
-  const float Sa = box_area(a), Sc = box_area(c);
+  const float Sa = box_area(a);
+  cbox[wv][lane] = c;
+  carea[wv][lane] = box_area(c);
+  __syncthreads();
+  if (!tile_ok) return;
   const int ncol = min(64, n - cb * 64);
-  const float4* col4 = reinterpret_cast<const float4*>(boxes) + (size_t)cb * 64;   // PACKED4 only
   const bool diag = rb == cb;
-  // one 32-column half at a time so that the bit position is a compile-time constant after unrolling
-  uint32_t word[2] = {0, 0}, tword[2] = {0, 0};
+  uint32_t word[2] = {0, 0};
   bool unsure = !t.fast;
 #pragma unroll
   for (int half = 0; half < 2; ++half) {
@@ -128,41 +136,37 @@ static __global__ __launch_bounds__(256) void nms_mask_kernel(const float* __res
 #pragma unroll 8
     for (int jj = 0; jj < 32; ++jj) {
       const int j = half * 32 + jj;
-      const float4 b = PACKED4 ? col4[min(j, ncol - 1)] : bcast4(c, j);
-      const float Sb = PACKED4 ? box_area(b) : bcast1(Sc, j);
-      bool p = iou_exceeds_fast(a, Sa, b, Sb, t, unsure);
-      p = p && row_ok && j < ncol && (!diag || j > lane);
+      const bool p = iou_exceeds_fast(a, Sa, cbox[wv][j], carea[wv][j], t, unsure);
       w |= (uint32_t)p << jj;
-      if (diag) {
-        const unsigned long long colword = __ballot(p);
-        if (lane == j) { tword[0] = (uint32_t)colword; tword[1] = (uint32_t)(colword >> 32); }
-      }
     }
     word[half] = w;
   }
   if (__builtin_expect(__any(unsure), 0)) {   // wave-uniform and rare: redo the tile with the real division
-    tword[0] = tword[1] = 0;
 #pragma unroll
     for (int half = 0; half < 2; ++half) {
       uint32_t w = 0;
       for (int jj = 0; jj < 32; ++jj) {
         const int j = half * 32 + jj;
-        const float4 b = PACKED4 ? col4[min(j, ncol - 1)] : bcast4(c, j);
-        const float Sb = PACKED4 ? box_area(b) : bcast1(Sc, j);
-        bool p = iou_exceeds_div(a, Sa, b, Sb, t);
-        p = p && row_ok && j < ncol && (!diag || j > lane);
-        w |= (uint32_t)p << jj;
-        if (diag) {
-          const unsigned long long colword = __ballot(p);
-          if (lane == j) { tword[0] = (uint32_t)colword; tword[1] = (uint32_t)(colword >> 32); }
-        }
+        w |= (uint32_t)iou_exceeds_div(a, Sa, cbox[wv][j], carea[wv][j], t) << jj;
       }
       word[half] = w;
     }
   }
-  const uint32_t lo = word[0], hi = word[1], tlo = tword[0], thi = tword[1];
-  if (row_ok) mask[(size_t)row * col_blocks + cb] = ((uint64_t)hi << 32) | lo;
-  if (diag && row_ok) diagT_all[(size_t)img * n + row] = ((uint64_t)thi << 32) | tlo;
+  uint64_t bits = ((uint64_t)word[1] << 32) | word[0];
+  if (ncol < 64) bits &= (1ULL << ncol) - 1ULL;                       // columns past the last box
+  if (diag) bits &= lane == 63 ? 0ULL : ~((2ULL << lane) - 1ULL);      // in a diagonal tile only j > i counts
+  if (!row_ok) bits = 0;
+  if (row_ok) mask[(size_t)row * col_blocks + cb] = bits;
+  if (diag) {
+    // transpose the finished 64 x 64 bit block: word of column k = the rows that suppress k
+    uint32_t tlo = 0, thi = 0;
+#pragma unroll 8
+    for (int k = 0; k < 64; ++k) {
+      const unsigned long long colword = __ballot((bits >> k) & 1ULL);
+      if (lane == k) { tlo = (uint32_t)colword; thi = (uint32_t)(colword >> 32); }
+    }
+    if (row_ok) diagT_all[(size_t)img * n + row] = ((uint64_t)thi << 32) | tlo;
+  }
 }
 
 // ---- float64 boxes: lib/nms/nms.py:37-74 run on float64 dets (pred_eval's py_nms_wrapper) --------

@@ -2,18 +2,18 @@
 // reference does 4 cudaMalloc/cudaFree, a thrust sort, a 4.5 MB D2H and a serial host loop per call,
 // multi_proposal.cu:454-557).  Two launch plans, same results bit for bit:
 //
-// CHIP-WIDE plan (count <= 32768 anchors, pre_nms_top_n <= 8192: the LSFA shapes), 6 short kernels:
+// CHIP-WIDE plan (count <= 32768 anchors, pre_nms_top_n <= 8192: the LSFA shapes), 5 short kernels:
 //   proposal_decode_kernel   anchors + decode + clip + filter (ProposalGrid/BBoxPred/FilterBox,
 //                            multi_proposal.cu:47-216) -> float4 boxes + 32-bit order keys, and per
 //                            workgroup a 4096-bin histogram of the keys (128 bins per octave of score)
 //   proposal_compact_kernel  every workgroup sums the partial histograms, finds the bin the
-//                            pre_nms_top_n-th best key falls in, and compacts ITS keys at or above that
-//                            bin into the candidate list (positions from the partial histograms: no
-//                            atomics, no counters to zero).  M candidates, M - pre_n of them surplus.
-//   proposal_rank_kernel     rank of every candidate among the candidates by (key, anchor index) ==
-//                            thrust::stable_sort_by_key(greater), :517-521: M^2 64-bit compares spread
-//                            over (M/256) x 16 workgroups, partial counts per slice
-//   proposal_scatter_kernel  rank < pre_n -> sorted boxes / keys (the exact top pre_n, in order)
+//                            pre_nms_top_n-th best key falls in, and writes ITS keys at or above that bin
+//                            into the candidate list GROUPED BY BIN (group offsets from the histograms;
+//                            no global atomics, no counters to zero).  M candidates, M - pre_n surplus.
+//   proposal_rank_kernel     exact position of a candidate in thrust::stable_sort_by_key(greater) order
+//                            (:517-521) = start of its bin's group + candidates of its own bin ordered
+//                            before it by (key, anchor index) — a handful of compares — then it writes
+//                            its box and key at that position (rank < pre_n: the exact top pre_n, in order)
 //   nms_mask_kernel + nms_sweep_kernel (nms_kernels.h)  64x64 IoU tiles of the upper triangle over the
 //                            chip, then one wave sweeps, stops at post_n survivors and writes the
 //                            output with the cyclic pad (PrepareOutput, :363-388)
@@ -178,106 +178,88 @@ __device__ __forceinline__ int block_exclusive_scan(int v, int* wave_sums /*LDS,
   return base + incl - v;
 }
 
-// ---- chip-wide plan: compact -> rank -> scatter ------------------------------------------------
-constexpr int kRankSlices = 16;          // j-range of the rank kernel is cut into this many slices
+// ---- chip-wide plan: compact (grouped by bin) -> rank within the bin + scatter ----------------------
 constexpr int kRankThreads = 256;
 constexpr int kFastMaxCount = 32768;     // anchors per image the chip-wide plan accepts
-constexpr int kRankSliceMax = kFastMaxCount / kRankSlices;   // entries of one slice staged in LDS
 
-// info (images, 4) int32: [0] = M, the number of candidates.
-// grid (G = decode's gridDim.x, images); block kDecodeThreads.  Every workgroup redoes the small
-// histogram reduction (G x 16 KB from L2) instead of a separate one-workgroup launch.
+// info (images, 4) int32: [0] = M, the number of candidates.  bin_start / bin_count (images, kBins): where
+// the candidates of a bin sit in the candidate list (bins in DESCENDING order: bin_start[b] = candidates in
+// bins above b) and how many they are — written by workgroup 0, read by the rank kernel.
+// grid (G = decode's gridDim.x, images); block kDecodeThreads.  Every workgroup redoes the small histogram
+// reduction (G x 16 KB from L2) instead of a separate one-workgroup launch.
 __global__ __launch_bounds__(kDecodeThreads) void proposal_compact_kernel(
     const uint32_t* __restrict__ keys_all, const uint32_t* __restrict__ hist_part, int A, int HW, int pre_n,
-    uint64_t* __restrict__ cand_all, int* __restrict__ info) {
+    uint64_t* __restrict__ cand_all, int* __restrict__ info, int* __restrict__ bin_start, int* __restrict__ bin_count) {
   __shared__ int wave_sums[kDecodeThreads / 64];
   __shared__ int sh[4];
+  __shared__ int slot[kBins];            // next free position of each bin's group, for THIS workgroup's candidates
   const int img = blockIdx.y, g = blockIdx.x, G = gridDim.x;
   const int tid = threadIdx.x;
   const int N = A * HW;
   const uint32_t* parts = hist_part + (size_t)img * G * kBins;
-  // total histogram: this thread owns bins 4*tid .. 4*tid+3
-  uint32_t c[4] = {0, 0, 0, 0};
-  for (int q = 0; q < G; ++q) {
-    const uint4 v = *reinterpret_cast<const uint4*>(parts + (size_t)q * kBins + 4 * tid);
-    c[0] += v.x; c[1] += v.y; c[2] += v.z; c[3] += v.w;
-  }
-  const int mine = (int)(c[0] + c[1] + c[2] + c[3]);
-  int total;
-  const int below = block_exclusive_scan(mine, wave_sums, &total);     // keys in bins < 4*tid
-  // suffix counts, walking this thread's bins downwards: the bin where the count of keys at or above
-  // it first reaches pre_n is the threshold bin (exactly one thread finds it; total >= pre_n)
-  int acc = total - below - mine;                                      // keys in bins > 4*tid+3
-#pragma unroll
-  for (int k = 3; k >= 0; --k) {
-    const int before = acc;
-    acc += (int)c[k];
-    if (before < pre_n && acc >= pre_n) { sh[0] = 4 * tid + k; sh[1] = acc; }
-  }
-  __syncthreads();
-  const int bin_t = sh[0], M = sh[1];
-  // candidates held by the workgroups before this one (same chunking as the decode kernel's)
-  int prior = 0;
-  for (int q = 0; q < g; ++q) {
-    const uint4 v = *reinterpret_cast<const uint4*>(parts + (size_t)q * kBins + 4 * tid);
-    prior += (4 * tid + 0 >= bin_t ? (int)v.x : 0) + (4 * tid + 1 >= bin_t ? (int)v.y : 0) +
-             (4 * tid + 2 >= bin_t ? (int)v.z : 0) + (4 * tid + 3 >= bin_t ? (int)v.w : 0);
-  }
-  int offset;
-  (void)block_exclusive_scan(prior, wave_sums, &offset);
+  // this thread's anchor (same chunking as the decode kernel's): its key is needed last, so load it first
   const int t = g * kDecodeThreads + tid;
-  bool is_cand = false;
   uint32_t key = 0, index = 0;
   if (t < N) {
     const int a = t / HW, p = t - a * HW;
     index = (uint32_t)(p * A + a);
     key = keys_all[(size_t)img * N + index];
-    is_cand = key_bin(key) >= bin_t;
   }
-  int n_here;
-  const int pos = block_exclusive_scan(is_cand ? 1 : 0, wave_sums, &n_here);
-  if (is_cand) cand_all[(size_t)img * N + offset + pos] = ((uint64_t)key << 32) | index;
+  // histograms: this thread owns bins 4*tid .. 4*tid+3; totals over all workgroups, and the part held by the
+  // workgroups before this one
+  uint32_t c[4] = {0, 0, 0, 0}, before_me[4] = {0, 0, 0, 0};
+  for (int q = 0; q < G; ++q) {
+    const uint4 v = *reinterpret_cast<const uint4*>(parts + (size_t)q * kBins + 4 * tid);
+    c[0] += v.x; c[1] += v.y; c[2] += v.z; c[3] += v.w;
+    if (q < g) { before_me[0] += v.x; before_me[1] += v.y; before_me[2] += v.z; before_me[3] += v.w; }
+  }
+  const int mine = (int)(c[0] + c[1] + c[2] + c[3]);
+  int total;
+  const int below = block_exclusive_scan(mine, wave_sums, &total);     // keys in bins < 4*tid
+  // walk this thread's bins downwards: `above` = keys in bins above the current one.  The bin where the count
+  // of keys at or above it first reaches pre_n is the threshold bin (exactly one thread finds it; total >= pre_n)
+  int above = total - below - mine;
+#pragma unroll
+  for (int k = 3; k >= 0; --k) {
+    const int bin = 4 * tid + k;
+    slot[bin] = above + (int)before_me[k];
+    if (g == 0) { bin_start[img * kBins + bin] = above; bin_count[img * kBins + bin] = (int)c[k]; }
+    if (above < pre_n && above + (int)c[k] >= pre_n) { sh[0] = bin; sh[1] = above + (int)c[k]; }
+    above += (int)c[k];
+  }
+  __syncthreads();
+  const int bin_t = sh[0], M = sh[1];
+  if (t < N) {
+    const int bin = key_bin(key);
+    if (bin >= bin_t) {
+      const int pos = atomicAdd(&slot[bin], 1);       // order inside a bin's group is arbitrary; the rank kernel sorts it out
+      cand_all[(size_t)img * N + pos] = ((uint64_t)key << 32) | index;
+    }
+  }
   if (g == 0 && tid == 0) info[img * 4] = M;
 }
 
-// grid (ceil(N / 256), kRankSlices, images); block 256.  part (images, kRankSlices, N) uint16:
-// how many candidates of slice s order before candidate i.  (key, index) pairs are distinct, so the
-// sum over slices is the candidate's exact position in the stable descending sort.
-__global__ __launch_bounds__(kRankThreads) void proposal_rank_kernel(const uint64_t* __restrict__ cand_all,
-                                                                     const int* __restrict__ info, int N,
-                                                                     uint16_t* __restrict__ part) {
-  __shared__ uint64_t slice[kRankSliceMax];
-  const int img = blockIdx.z, s = blockIdx.y;
-  const int M = info[img * 4];
-  const int i0 = blockIdx.x * kRankThreads;
-  if (i0 >= M) return;
-  const uint64_t* cand = cand_all + (size_t)img * N;
-  const int len = (M + kRankSlices - 1) / kRankSlices;
-  const int j0 = min(s * len, M), j1 = min(j0 + len, M);
-  for (int j = j0 + threadIdx.x; j < j1; j += kRankThreads) slice[j - j0] = cand[j];
-  __syncthreads();
-  const int i = i0 + threadIdx.x;
-  const uint64_t mine = i < M ? cand[i] : 0ULL;
-  int before = 0;
-  const int n = j1 - j0;
-#pragma unroll 8
-  for (int j = 0; j < n; ++j) before += slice[j] < mine;
-  if (i < M) part[((size_t)img * kRankSlices + s) * N + i] = (uint16_t)before;
-}
-
-// grid (ceil(N / 256), images); block 256.
-__global__ __launch_bounds__(kRankThreads) void proposal_scatter_kernel(
-    const uint64_t* __restrict__ cand_all, const int* __restrict__ info, const uint16_t* __restrict__ part, int N,
-    int pre_n, const float4* __restrict__ boxes_all, float4* __restrict__ sorted_box, uint32_t* __restrict__ sorted_key) {
+// grid (ceil(N / 256), images); block 256.  Candidate i sits in its bin's group; bins are disjoint key ranges,
+// so its position in the stable descending sort (== thrust::stable_sort_by_key(greater), :517-521) is
+// bin_start + the number of candidates OF ITS OWN BIN ordered before it ((key, index) pairs are distinct).
+// Groups hold a handful of candidates unless the scores collapse into one bin, when this degrades to M^2.
+// Candidates ranked below pre_n drop out; the others write their box and key at their sorted position.
+__global__ __launch_bounds__(kRankThreads) void proposal_rank_kernel(
+    const uint64_t* __restrict__ cand_all, const int* __restrict__ info, const int* __restrict__ bin_start,
+    const int* __restrict__ bin_count, int N, int pre_n, const float4* __restrict__ boxes_all,
+    float4* __restrict__ sorted_box, uint32_t* __restrict__ sorted_key) {
   const int img = blockIdx.y;
   const int M = info[img * 4];
   const int i = blockIdx.x * kRankThreads + threadIdx.x;
   if (i >= M) return;
-  int rank = 0;
-#pragma unroll
-  for (int s = 0; s < kRankSlices; ++s) rank += part[((size_t)img * kRankSlices + s) * N + i];
+  const uint64_t* cand = cand_all + (size_t)img * N;
+  const uint64_t e = cand[i];
+  const int bin = key_bin((uint32_t)(e >> 32));
+  const int s0 = bin_start[img * kBins + bin], n = bin_count[img * kBins + bin];
+  int before = 0;
+  for (int j = 0; j < n; ++j) before += cand[s0 + j] < e;
+  const int rank = s0 + before;
   if (rank >= pre_n) return;
-  const uint64_t e = cand_all[(size_t)img * N + i];
   sorted_box[(size_t)img * pre_n + rank] = boxes_all[(size_t)img * N + (uint32_t)e];
   sorted_key[(size_t)img * pre_n + rank] = (uint32_t)(e >> 32);
 }
@@ -693,7 +675,7 @@ __global__ __launch_bounds__(kTopkThreads) void proposal_select_nms_kernel(
 }
 
 struct WsLayout {
-  size_t boxes, keys, hist, info, cand, part, sbox, skey, mask, diagT, total;
+  size_t boxes, keys, hist, info, bins, cand, sbox, skey, mask, diagT, total;
   int groups;      // decode workgroups per image
   bool chip_wide, chip_wide_possible;
 };
@@ -709,13 +691,13 @@ WsLayout ws_layout(int B, int count, int pre_n, int post_n) {
   l.chip_wide_possible = l.chip_wide;
   l.boxes = o; o += align_up((size_t)B * count * sizeof(float4), 256);
   l.keys = o; o += align_up((size_t)B * count * sizeof(uint32_t), 256);
-  l.hist = l.info = l.cand = l.part = l.sbox = l.skey = l.mask = l.diagT = o;
+  l.hist = l.info = l.bins = l.cand = l.sbox = l.skey = l.mask = l.diagT = o;
   if (l.chip_wide) {
     const size_t col_blocks = (size_t)ceil_div(pre_n, 64);
     l.hist = o; o += align_up((size_t)B * l.groups * kBins * sizeof(uint32_t), 256);
     l.info = o; o += align_up((size_t)B * 4 * sizeof(int), 256);
+    l.bins = o; o += align_up((size_t)B * 2 * kBins * sizeof(int), 256);
     l.cand = o; o += align_up((size_t)B * count * sizeof(uint64_t), 256);
-    l.part = o; o += align_up((size_t)B * kRankSlices * count * sizeof(uint16_t), 256);
     l.sbox = o; o += align_up((size_t)B * pre_n * sizeof(float4), 256);
     l.skey = o; o += align_up((size_t)B * pre_n * sizeof(uint32_t), 256);
     l.mask = o; o += align_up((size_t)B * pre_n * col_blocks * sizeof(uint64_t), 256);
@@ -782,7 +764,8 @@ extern "C" int lsfa_proposal(const float* cls_prob, const float* bbox_pred, cons
   if (l.chip_wide) {
     int* info = (int*)(base + l.info);
     uint64_t* cand = (uint64_t*)(base + l.cand);
-    uint16_t* part = (uint16_t*)(base + l.part);
+    int* bin_start = (int*)(base + l.bins);
+    int* bin_count = bin_start + (size_t)B * kBins;
     float4* sbox = (float4*)(base + l.sbox);
     uint32_t* skey = (uint32_t*)(base + l.skey);
     uint64_t* mask = (uint64_t*)(base + l.mask);
@@ -790,11 +773,9 @@ extern "C" int lsfa_proposal(const float* cls_prob, const float* bbox_pred, cons
     const int col_blocks = ceil_div(pre_n, 64);
     const int gi = ceil_div(count, kRankThreads);
     hipLaunchKernelGGL(proposal_compact_kernel, dim3(l.groups, B), dim3(kDecodeThreads), 0, s, (const uint32_t*)keys,
-                       (const uint32_t*)hist, A, H * W, pre_n, cand, info);
-    hipLaunchKernelGGL(proposal_rank_kernel, dim3(gi, kRankSlices, B), dim3(kRankThreads), 0, s, (const uint64_t*)cand,
-                       (const int*)info, count, part);
-    hipLaunchKernelGGL(proposal_scatter_kernel, dim3(gi, B), dim3(kRankThreads), 0, s, (const uint64_t*)cand,
-                       (const int*)info, (const uint16_t*)part, count, pre_n, (const float4*)boxes, sbox, skey);
+                       (const uint32_t*)hist, A, H * W, pre_n, cand, info, bin_start, bin_count);
+    hipLaunchKernelGGL(proposal_rank_kernel, dim3(gi, B), dim3(kRankThreads), 0, s, (const uint64_t*)cand, (const int*)info,
+                       (const int*)bin_start, (const int*)bin_count, count, pre_n, (const float4*)boxes, sbox, skey);
     hipLaunchKernelGGL(nms_mask_kernel<true>, dim3(ceil_div(nms_tile_count(col_blocks), 4), 1, B), dim3(256), 0, s,
                        (const float*)sbox, (long)pre_n * 4, 4, (const int*)nullptr, pre_n, iou, mask, diagT, col_blocks);
     hipLaunchKernelGGL(nms_sweep_kernel, dim3(B), dim3(64), 0, s, (const uint64_t*)mask, (const uint64_t*)diagT, pre_n,

@@ -423,12 +423,17 @@ class MotionVectorAccumulator(object):
             _check(lib().lsfa_mv_identity(_ptr(self._bufs[self._cur]), _ci(self.width), _ci(self.height), _stream()),
                    "lsfa_mv_identity")
 
-    def add_frame(self, mvs):
+    def add_frame(self, mvs, max_block_area=None):
+        """mvs (n, 7) int32.  max_block_area: an upper bound of w*h over the blocks (256 for 16x16 macroblocks);
+        when omitted it is read from `mvs`, which costs a device-to-host synchronisation if mvs is on the device."""
         if mvs.dtype != torch.int32 or mvs.dim() != 2 or mvs.shape[1] != 7:
             raise LsfaError("mvs must be (n, 7) int32, got %s %s" % (tuple(mvs.shape), mvs.dtype))
-        mvs = mvs.to(self.device).contiguous()
         n = mvs.shape[0]
-        area = int((mvs[:, 1].clamp(min=0) * mvs[:, 2].clamp(min=0)).max().item()) if n else 0
+        if max_block_area is not None:
+            area = int(max_block_area)
+        else:
+            area = int((mvs[:, 1].clamp(min=0).long() * mvs[:, 2].clamp(min=0).long()).max().item()) if n else 0
+        mvs = mvs.to(self.device).contiguous()
         old, new = self._bufs[self._cur], self._bufs[1 - self._cur]
         with torch.cuda.device(self.device):
             _check(lib().lsfa_mv_accumulate(_ptr(mvs), _ci(n), _ci(area), _ptr(old), _ptr(new), _ci(self.width),

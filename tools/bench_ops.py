@@ -82,7 +82,7 @@ def main():
     blocks = [[-1, 16, 16, bx + 8 - rs.randint(-9, 10), by + 8 - rs.randint(-9, 10), bx + 8, by + 8]
               for by in range(0, 600, 16) for bx in range(0, 1000, 16)]
     mvs = torch.tensor(blocks, dtype=torch.int32, device=dev)
-    us = timeit(lambda: acc.add_frame(mvs), args.iters)
+    us = timeit(lambda: acc.add_frame(mvs, max_block_area=256), args.iters)
     out['mv_accumulate(1000x600)'] = dict(us=round(us, 2), bytes=1000 * 600 * (4 + 4 + 8 + 8))
     # own fp32 MFMA convolution: stage-3 conv2
     xr = torch.randn(1, H, W, 256, device=dev)

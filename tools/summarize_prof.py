@@ -8,7 +8,7 @@ import csv, glob, sys, collections, json
 
 
 def trace_summary(d, out, tail_frac=0.5, top=60):
-    f = glob.glob(d + '/*/*_kernel_trace.csv')
+    f = glob.glob(d + '/**/*kernel_trace.csv', recursive=True)
     if not f:
         return
     rows = list(csv.DictReader(open(f[0])))
@@ -37,7 +37,7 @@ def trace_summary(d, out, tail_frac=0.5, top=60):
 
 
 def pmc_summary(d, match):
-    f = glob.glob(d + '/*/*counter_collection.csv')
+    f = glob.glob(d + '/**/*counter_collection.csv', recursive=True)
     if not f:
         return None
     vals = collections.defaultdict(list)
@@ -49,7 +49,7 @@ def pmc_summary(d, match):
 
 def pmc_table(d, out, top=45, last_frames=20):
     """every kernel: dispatches and the SUM of each counter over its dispatches, sorted by GRBM_GUI_ACTIVE."""
-    f = glob.glob(d + '/*/*counter_collection.csv')
+    f = glob.glob(d + '/**/*counter_collection.csv', recursive=True)
     if not f:
         return
     agg = collections.defaultdict(lambda: collections.defaultdict(float))

@@ -228,6 +228,15 @@ int lsfa_conv_nhwc_fwd(const float* x, int N, int H, int W, int Cin, const float
                        int kh, int kw, int stride, int pad, int dil, int relu, float* y,
                        void* ws, size_t ws_bytes, void* stream);
 
+/* The same convolution with the tail of a pre-activation unit fused in (resnet.py:93-101 + the next unit's :78-80):
+ * y = conv(x) [+ bias] + residual (residual may be y itself: in place), and, when y2 != NULL, the NEXT unit's
+ * BatchNorm + ReLU of that sum as a second output, y2 = max(y*scale2[c] + shift2[c], 0) — so conv3 + the shortcut add
+ * + bn1/relu1 of the following unit are one launch. */
+int lsfa_conv_nhwc_fused_fwd(const float* x, int N, int H, int W, int Cin, const float* w, const float* bias, int Cout,
+                             int kh, int kw, int stride, int pad, int dil, int relu, const float* residual, float* y,
+                             float* y2, const float* scale2, const float* shift2,
+                             void* ws, size_t ws_bytes, void* stream);
+
 /* Inference BatchNorm (use_global_stats) + ReLU as one pass: y = max(x*scale[c]+shift[c], 0)
  * (sym_common.py:92-102 bn + relu of every pre-activation unit, resnet.py:70-101).
  * relu != 0 applies the ReLU.  In-place (y == x) allowed. */

@@ -34,7 +34,19 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 struct ConvArgs {
   const float* x; const float* w; const float* bias; float* y; float* part;
   int N, H, W, Cin, Cout, kh, kw, stride, pad, dil, Ho, Wo, relu, taps_per_slice;
+  // fused tail of a pre-activation unit's conv3 (resnet.py:93-101): y = conv + residual (in place allowed), and the
+  // NEXT unit's bn1 + ReLU of that sum as a second output: y2 = max(y * scale2[c] + shift2[c], 0)
+  const float* res; float* y2; const float* scale2; const float* shift2;
 };
+
+__device__ __forceinline__ void conv_epilogue(const ConvArgs& a, float v, size_t o, int ch, float bias, float sc2, float sh2) {
+  v = v + bias;
+  if (a.res) v = v + a.res[o];
+  if (a.relu) v = fmaxf(v, 0.f);
+  a.y[o] = v;
+  if (a.y2) a.y2[o] = fmaxf(v * sc2 + sh2, 0.f);
+  (void)ch;
+}
 
 // grid (ceil(P / 64), Cout / 64, slices); block 256.  P = N*Ho*Wo output pixels.  BK = channels per staged chunk
 // (64 when Cin allows: 32 MFMAs per wave between barriers, long enough to cover the L2 latency of the next
@@ -129,32 +141,44 @@ __global__ __launch_bounds__(kThreads) void conv_igemm_kernel(ConvArgs a) {
   // C/D layout of 32x32x2: column = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
   const int ch = n0 + wc * 32 + (lane & 31);
   const float bias = (a.part == nullptr && a.bias) ? a.bias[ch] : 0.f;
-  float* dst = a.part ? a.part + (size_t)blockIdx.z * P * a.Cout : a.y;
+  const float sc2 = (a.part == nullptr && a.y2) ? a.scale2[ch] : 0.f, sh2 = (a.part == nullptr && a.y2) ? a.shift2[ch] : 0.f;
+  float* part = a.part ? a.part + (size_t)blockIdx.z * P * a.Cout : nullptr;
 #pragma unroll
   for (int r = 0; r < 16; ++r) {
     const int row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
     const int p = m0 + wr * 32 + row;
     if (p < P) {
-      float v = acc[r];
-      if (a.part == nullptr) { v = v + bias; if (a.relu) v = fmaxf(v, 0.f); }
-      dst[(size_t)p * a.Cout + ch] = v;
+      const size_t o = (size_t)p * a.Cout + ch;
+      if (part) part[o] = acc[r];
+      else conv_epilogue(a, acc[r], o, ch, bias, sc2, sh2);
     }
   }
 }
 
-// y = act(sum over slices of part, in slice order, + bias); float4 of channels per thread
-__global__ __launch_bounds__(kThreads) void conv_reduce_kernel(const float4* __restrict__ part, const float4* __restrict__ bias,
-                                                               long n4, int c4, int slices, int relu, float4* __restrict__ y) {
+// the epilogue for the tap-split case: sum over slices of part, in slice order, then the same tail; float4 of channels per thread
+__global__ __launch_bounds__(kThreads) void conv_reduce_kernel(ConvArgs a, long n4, int slices) {
   const long i = (long)blockIdx.x * kThreads + threadIdx.x;
   if (i >= n4) return;
+  const float4* part = reinterpret_cast<const float4*>(a.part);
   float4 s = part[i];
   for (int z = 1; z < slices; ++z) {
     const float4 v = part[(size_t)z * n4 + i];
     s.x = s.x + v.x; s.y = s.y + v.y; s.z = s.z + v.z; s.w = s.w + v.w;
   }
-  if (bias) { const float4 b = bias[i % c4]; s.x = s.x + b.x; s.y = s.y + b.y; s.z = s.z + b.z; s.w = s.w + b.w; }
-  if (relu) { s.x = fmaxf(s.x, 0.f); s.y = fmaxf(s.y, 0.f); s.z = fmaxf(s.z, 0.f); s.w = fmaxf(s.w, 0.f); }
-  y[i] = s;
+  const int c4 = a.Cout / 4;
+  const int ch = (int)(i % c4) * 4;
+  const float sv[4] = {s.x, s.y, s.z, s.w};
+  float o1[4], o2[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    float v = sv[k] + (a.bias ? a.bias[ch + k] : 0.f);
+    if (a.res) v = v + a.res[(size_t)i * 4 + k];
+    if (a.relu) v = fmaxf(v, 0.f);
+    o1[k] = v;
+    o2[k] = a.y2 ? fmaxf(v * a.scale2[ch + k] + a.shift2[ch + k], 0.f) : 0.f;
+  }
+  reinterpret_cast<float4*>(a.y)[i] = make_float4(o1[0], o1[1], o1[2], o1[3]);
+  if (a.y2) reinterpret_cast<float4*>(a.y2)[i] = make_float4(o2[0], o2[1], o2[2], o2[3]);
 }
 
 int pick_slices(long tiles, int taps) {
@@ -173,11 +197,14 @@ extern "C" size_t lsfa_conv_nhwc_workspace_bytes(int N, int H, int W, int Cout, 
   return slices > 1 ? align_up((size_t)slices * P * Cout * sizeof(float), 256) : 256;
 }
 
-extern "C" int lsfa_conv_nhwc_fwd(const float* x, int N, int H, int W, int Cin, const float* w, const float* bias, int Cout,
-                                  int kh, int kw, int stride, int pad, int dil, int relu, float* y, void* ws, size_t ws_bytes,
-                                  void* stream) {
+extern "C" int lsfa_conv_nhwc_fused_fwd(const float* x, int N, int H, int W, int Cin, const float* w, const float* bias, int Cout,
+                                        int kh, int kw, int stride, int pad, int dil, int relu, const float* residual, float* y,
+                                        float* y2, const float* scale2, const float* shift2, void* ws, size_t ws_bytes,
+                                        void* stream) {
   LSFA_REQUIRE(x && w && y, "lsfa_conv_nhwc_fwd: NULL argument");
   LSFA_REQUIRE(N > 0 && H > 0 && W > 0 && kh > 0 && kw > 0 && stride > 0 && pad >= 0 && dil > 0, "lsfa_conv_nhwc_fwd: bad shape");
+  LSFA_REQUIRE(!y2 || (scale2 && shift2), "lsfa_conv_nhwc_fused_fwd: y2 given without scale2 / shift2");
+  LSFA_REQUIRE(!y2 || y2 != y, "lsfa_conv_nhwc_fused_fwd: y2 must not alias y");
   if (Cin % 32 != 0 || Cout % kBN != 0) {
     set_error("lsfa_conv_nhwc_fwd: Cin=%d must be a multiple of %d and Cout=%d of %d", Cin, 32, Cout, kBN);
     return LSFA_ENOTSUP;
@@ -195,16 +222,22 @@ extern "C" int lsfa_conv_nhwc_fwd(const float* x, int N, int H, int W, int Cin, 
   }
   hipStream_t s = (hipStream_t)stream;
   ConvArgs a = {x, w, bias, y, slices > 1 ? (float*)ws : nullptr, N, H, W, Cin, Cout, kh, kw, stride, pad, dil, Ho, Wo, relu,
-                (taps + slices - 1) / slices};
+                (taps + slices - 1) / slices, residual, y2, scale2, shift2};
   ProfScope prof(LSFA_OP_CONV, s);
   const dim3 grid((unsigned)((P + kBM - 1) / kBM), Cout / kBN, slices);
   if (Cin % 64 == 0) hipLaunchKernelGGL(conv_igemm_kernel<64>, grid, dim3(kThreads), 0, s, a);
   else hipLaunchKernelGGL(conv_igemm_kernel<32>, grid, dim3(kThreads), 0, s, a);
   if (slices > 1) {
     const long n4 = P * Cout / 4;
-    hipLaunchKernelGGL(conv_reduce_kernel, dim3((unsigned)((n4 + kThreads - 1) / kThreads)), dim3(kThreads), 0, s,
-                       (const float4*)ws, (const float4*)bias, n4, Cout / 4, slices, relu, (float4*)y);
+    hipLaunchKernelGGL(conv_reduce_kernel, dim3((unsigned)((n4 + kThreads - 1) / kThreads)), dim3(kThreads), 0, s, a, n4, slices);
   }
   LSFA_LAUNCH_CHECK("lsfa_conv_nhwc_fwd");
   return LSFA_OK;
+}
+
+extern "C" int lsfa_conv_nhwc_fwd(const float* x, int N, int H, int W, int Cin, const float* w, const float* bias, int Cout,
+                                  int kh, int kw, int stride, int pad, int dil, int relu, float* y, void* ws, size_t ws_bytes,
+                                  void* stream) {
+  return lsfa_conv_nhwc_fused_fwd(x, N, H, W, Cin, w, bias, Cout, kh, kw, stride, pad, dil, relu, nullptr, y, nullptr, nullptr,
+                                  nullptr, ws, ws_bytes, stream);
 }

@@ -379,8 +379,11 @@ def conv_weight_kc(weight):
 
 
 @_on_tensor_device
-def conv_nhwc(x, w_kc, bias, kh, kw, stride=1, pad=0, dil=1, relu=False, out=None):
-    """x (N, H, W, Cin) contiguous fp32; w_kc from conv_weight_kc; -> (N, Ho, Wo, Cout)."""
+def conv_nhwc(x, w_kc, bias, kh, kw, stride=1, pad=0, dil=1, relu=False, out=None, residual=None, out2=None, scale2=None,
+              shift2=None):
+    """x (N, H, W, Cin) contiguous fp32; w_kc from conv_weight_kc; -> (N, Ho, Wo, Cout).
+    residual (same shape as the output; may BE `out`): added before the ReLU / store.  out2 + scale2 + shift2: second
+    output max(out*scale2[c] + shift2[c], 0) (the next ResNet unit's bn1 + relu1).  Returns out, or (out, out2)."""
     x, w_kc = _f32c(x, "x"), _f32c(w_kc, "w_kc")
     N, H, W, Cin = x.shape
     Cout = w_kc.shape[0]
@@ -389,12 +392,16 @@ def conv_nhwc(x, w_kc, bias, kh, kw, stride=1, pad=0, dil=1, relu=False, out=Non
     Ho, Wo = (H + 2 * pad - dil * (kh - 1) - 1) // stride + 1, (W + 2 * pad - dil * (kw - 1) - 1) // stride + 1
     if out is None:
         out = torch.empty((N, Ho, Wo, Cout), device=x.device, dtype=torch.float32)
+    for name, t in (("out", out), ("residual", residual), ("out2", out2)):
+        if t is not None and (t.numel() != N * Ho * Wo * Cout or not t.is_contiguous() or t.dtype != torch.float32):
+            raise LsfaError("conv_nhwc: %s must be a contiguous float32 tensor of %d elements" % (name, N * Ho * Wo * Cout))
     need = lib().lsfa_conv_nhwc_workspace_bytes(_ci(N), _ci(H), _ci(W), _ci(Cout), _ci(kh), _ci(kw), _ci(stride), _ci(pad), _ci(dil))
     ws = torch.empty(need, dtype=torch.uint8, device=x.device)
-    _check(lib().lsfa_conv_nhwc_fwd(_ptr(x), _ci(N), _ci(H), _ci(W), _ci(Cin), _ptr(w_kc), _ptr(bias), _ci(Cout), _ci(kh), _ci(kw),
-                                    _ci(stride), _ci(pad), _ci(dil), _ci(int(relu)), _ptr(out), _ptr(ws), ctypes.c_size_t(need),
-                                    _stream()), "lsfa_conv_nhwc_fwd")
-    return out
+    _check(lib().lsfa_conv_nhwc_fused_fwd(_ptr(x), _ci(N), _ci(H), _ci(W), _ci(Cin), _ptr(w_kc), _ptr(bias), _ci(Cout), _ci(kh),
+                                          _ci(kw), _ci(stride), _ci(pad), _ci(dil), _ci(int(relu)), _ptr(residual), _ptr(out),
+                                          _ptr(out2), _ptr(scale2), _ptr(shift2), _ptr(ws), ctypes.c_size_t(need), _stream()),
+           "lsfa_conv_nhwc_fused_fwd")
+    return out if out2 is None else (out, out2)
 
 
 class MotionVectorAccumulator(object):

@@ -38,11 +38,12 @@ _CL_DEFAULT = 'backbone,small'
 _FLOW_GEMM_MAX_L = int(_os.environ.get('LSFA_FLOW_GEMM_L', '700'))   # FlowNet convs with at most this many output pixels run as im2col + GEMM
 _CONV1X1_MIOPEN = _os.environ.get('LSFA_CONV1X1_MIOPEN', '0') == '1'   # experiment: channel-reducing 1x1 convs through MIOpen
 # which 3x3 convolutions of the channels-last sub-networks run on the own fp32-MFMA implicit GEMM (lsfa_conv_nhwc_fwd,
-# bias + ReLU in its epilogue) instead of the library's kernel + a separate bias/ReLU pass: comma list of backbone, small
+# bias + ReLU in its epilogue) instead of the library's kernel + a separate bias/ReLU pass: comma list of backbone, small;
+# `conv3` additionally runs the 1x1 conv3 of those units on it with the shortcut add and the next unit's bn1 + ReLU fused
 # measured at 1000x600 (tools/key_sections.py, hipGraph replay): backbone 4327 -> 4239 us with it, small net 256 -> 289 us:
 # the backbone's stage 2/3 units gain (epilogue fusion + deterministic tap split), the small net's 64-channel stage 1 and the
 # 256 -> 1024 fuse convolution do not
-_OWN_CONV = set(x for x in _os.environ.get('LSFA_OWN_CONV', 'backbone').split(',') if x)
+_OWN_CONV = set(x for x in _os.environ.get('LSFA_OWN_CONV', 'backbone,conv3').split(',') if x)
 
 
 class TestSymbol(object):
@@ -234,6 +235,8 @@ class _ResNetWeights(object):
             d['w2_cl'] = d['w2'].contiguous(memory_format=cl)
             if d['w2'].dtype == torch.float32 and d['w2'].shape[1] % 32 == 0 and d['w2'].shape[0] % 64 == 0:
                 d['w2_kc'] = hip.conv_weight_kc(d['w2'])        # (Cout, 9, Cin): lsfa_conv_nhwc_fwd's layout
+            if d['w3'].dtype == torch.float32 and d['w3'].shape[1] % 32 == 0 and d['w3'].shape[0] % 64 == 0:
+                d['w3_kc'] = hip.conv_weight_kc(d['w3'])        # (Cout, 1, Cin)
             if 'sc' in d:
                 d['sc_t'] = d['sc'].reshape(d['sc'].shape[0], -1).t().contiguous()
                 d['sc_cl'] = d['sc'].contiguous(memory_format=cl)
@@ -439,17 +442,19 @@ class Executor(object):
         hip.scale_shift_relu_cl(r, self._ones(r.shape[1]), net.conv0_b, relu=True, out=r)
         x4 = F.max_pool2d(self._map(r, y.shape[2], y.shape[3]), 3, 2, 1)
         dilate = 1
-        for u in net.units:
-            if u['stage'] > stages:
-                break
+        units = [u for u in net.units if u['stage'] <= stages]
+        fuse3 = own_conv and 'conv3' in _OWN_CONV
+        a2 = None          # relu(bn1(x)) of the current unit when the previous unit's conv3 already produced it
+        for ui, u in enumerate(units):
             first = u['unit'] == 1
             stride = 2 if (first and u['stage'] in (2, 3)) else 1
             unit_dilate = dilate
             if first and u['stage'] == 4:
                 dilate = dilate * 2
-            h, w = x4.shape[2], x4.shape[3]
+            n, h, w = x4.shape[0], x4.shape[2], x4.shape[3]
             x2 = self._rows(x4)
-            a2 = hip.scale_shift_relu_cl(x2, u['bn1'][0], u['bn1'][1], relu=True)
+            if a2 is None:
+                a2 = hip.scale_shift_relu_cl(x2, u['bn1'][0], u['bn1'][1], relu=True)
             c1 = torch._addmm_activation(u['b1'], a2, u['w1_t'])                  # conv1 + folded bn2 + ReLU
             if u['dcn']:
                 c2 = self._dcn_cl(self._map(c1, h, w), u, unit_dilate)
@@ -470,11 +475,26 @@ class Executor(object):
                 sc = self._rows(F.conv2d(self._map(a2, h, w), u['sc_cl'], None, stride=stride)) if stride != 1 \
                     else torch.mm(a2, u['sc_t'])
             else:
-                sc = x2                                         # overwritten in place by conv3's GEMM (beta = 1)
-            x4 = self._map(sc.addmm_(c2, u['w3_t']), ho, wo)
+                sc = x2                                         # overwritten in place by conv3 (+ the shortcut: beta = 1)
+            # the bn1 + ReLU the NEXT unit (or the network's tail) applies to this unit's output
+            nxt = units[ui + 1]['bn1'] if ui + 1 < len(units) else (net.bn1 if tail else None)
+            if fuse3 and 'w3_kc' in u and sc.is_contiguous():
+                # conv3 + shortcut add in place + the next bn1/relu1 as a second output: one launch (lsfa_conv_nhwc_fused_fwd)
+                sc4 = sc.view(n, ho, wo, -1)
+                out2 = torch.empty_like(sc4) if nxt is not None else None
+                hip.conv_nhwc(c2.view(n, ho, wo, -1), u['w3_kc'], None, 1, 1, 1, 0, 1, relu=False, out=sc4, residual=sc4,
+                              out2=out2, scale2=nxt[0] if nxt is not None else None, shift2=nxt[1] if nxt is not None else None)
+                a2 = out2.view(-1, out2.shape[3]) if out2 is not None else None
+                x4 = self._map(sc, ho, wo)
+            else:
+                x4 = self._map(sc.addmm_(c2, u['w3_t']), ho, wo)
+                a2 = None
         if tail:
             h, w = x4.shape[2], x4.shape[3]
-            x4 = self._map(hip.scale_shift_relu_cl(self._rows(x4), net.bn1[0], net.bn1[1], relu=True), h, w)
+            if a2 is not None:
+                x4 = self._map(a2, h, w)                          # the last conv3 already applied the final bn1 + relu1
+            else:
+                x4 = self._map(hip.scale_shift_relu_cl(self._rows(x4), net.bn1[0], net.bn1[1], relu=True), h, w)
         return x4
 
     def _backbone(self, data):

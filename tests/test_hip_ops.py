@@ -634,3 +634,33 @@ def test_conv_nhwc_mfma_vs_torch(hip, cfg):
     g2 = hip.conv_nhwc(xt, wk, None, k, k, stride, pad, dil, relu=False).cpu().numpy()
     assert np.abs(g2 - want2).max() < 2e-6 * np.sqrt(Cin * k * k) * max(np.abs(want2).max(), 1.0)
     assert (g2 < 0).any()
+
+
+@pytest.mark.parametrize("cfg", [dict(H=38, W=63, Cin=256, Cout=1024, k=1), dict(H=75, W=125, Cin=128, Cout=512, k=1),
+                                 dict(H=19, W=11, Cin=64, Cout=64, k=3)])
+def test_conv_nhwc_fused_residual_and_next_bn(hip, cfg):
+    """lsfa_conv_nhwc_fused_fwd: conv3 of a pre-activation unit + the shortcut add IN PLACE + the next unit's
+    bn1 + ReLU as a second output, vs the same three steps in float64."""
+    import torch.nn.functional as F
+    rs = np.random.RandomState(cfg["Cout"])
+    H, W, Cin, Cout, k = (cfg[x] for x in ("H", "W", "Cin", "Cout", "k"))
+    pad = k // 2
+    x = rs.randn(1, Cin, H, W).astype(np.float32)
+    w = (rs.randn(Cout, Cin, k, k) / np.sqrt(Cin * k * k)).astype(np.float32)
+    res = rs.randn(1, Cout, H, W).astype(np.float32)
+    sc2, sh2 = rs.uniform(0.5, 1.5, Cout).astype(np.float32), rs.randn(Cout).astype(np.float32)
+    y64 = F.conv2d(torch.from_numpy(x).double(), torch.from_numpy(w).double(), None, 1, pad) + torch.from_numpy(res).double()
+    y2_64 = torch.relu(y64 * torch.from_numpy(sc2).double().view(1, -1, 1, 1) + torch.from_numpy(sh2).double().view(1, -1, 1, 1))
+    want, want2 = y64.permute(0, 2, 3, 1).numpy(), y2_64.permute(0, 2, 3, 1).numpy()
+    xt = t(x).permute(0, 2, 3, 1).contiguous()
+    buf = t(res).permute(0, 2, 3, 1).contiguous()               # residual in, sum out: the same buffer
+    out2 = torch.empty_like(buf)
+    got, got2 = hip.conv_nhwc(xt, hip.conv_weight_kc(t(w)), None, k, k, 1, pad, 1, relu=False, out=buf, residual=buf, out2=out2,
+                              scale2=t(sc2), shift2=t(sh2))
+    assert got.data_ptr() == buf.data_ptr()
+    tol = 2e-6 * np.sqrt(Cin * k * k) * max(np.abs(want).max(), 1.0)
+    assert np.abs(got.cpu().numpy() - want).max() < tol
+    assert np.abs(got2.cpu().numpy() - want2).max() < 2 * tol
+    # the second output is exactly the fp32 bn + relu of the first
+    again = torch.relu(got * t(sc2) + t(sh2))
+    assert torch.equal(got2, again)

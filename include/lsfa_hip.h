@@ -237,6 +237,21 @@ int lsfa_conv_nhwc_fused_fwd(const float* x, int N, int H, int W, int Cin, const
                              float* y2, const float* scale2, const float* shift2,
                              void* ws, size_t ws_bytes, void* stream);
 
+/* The same convolution (and, with kh = kw = 1, the 1x1 convolutions = plain GEMMs of the channels-last units) on the
+ * bf16 matrix pipe with EXACTLY split fp32 operands: every fp32 value is cut into three bf16 pieces (8+8+8 mantissa
+ * bits, no rounding) and a*b is accumulated in fp32 from the six partial products of weight >= 2^-16; the dropped
+ * terms are below 2^-23 |a*b|, i.e. under one fp32 ulp of each product (lsfa_amd/csrc/conv_split_kernel.h).  Inputs,
+ * outputs and accumulation are fp32; measured against a float64 convolution it is as close as the fp32-MFMA kernel.
+ * The weights are cut and laid out once (bind time): lsfa_conv_split_weights writes lsfa_conv_split_weight_bytes(...)
+ * bytes from w (Cout, kh, kw, Cin).  Cin % 32 == 0, Cout % 64 == 0.  Arguments otherwise as lsfa_conv_nhwc_fused_fwd. */
+size_t lsfa_conv_split_weight_bytes(int Cout, int kh, int kw, int Cin);
+int lsfa_conv_split_weights(const float* w, int Cout, int kh, int kw, int Cin, void* wfrag, void* stream);
+size_t lsfa_conv_split_workspace_bytes(int N, int H, int W, int Cin, int Cout, int kh, int kw, int stride, int pad, int dil);
+int lsfa_conv_split_fwd(const float* x, int N, int H, int W, int Cin, const void* wfrag, const float* bias, int Cout,
+                        int kh, int kw, int stride, int pad, int dil, int relu, const float* residual, float* y,
+                        float* y2, const float* scale2, const float* shift2,
+                        void* ws, size_t ws_bytes, void* stream);
+
 /* Inference BatchNorm (use_global_stats) + ReLU as one pass: y = max(x*scale[c]+shift[c], 0)
  * (sym_common.py:92-102 bn + relu of every pre-activation unit, resnet.py:70-101).
  * relu != 0 applies the ReLU.  In-place (y == x) allowed. */

@@ -22,6 +22,8 @@
 // Weight layout (prepared once at bind time): w[co][tap][ci], i.e. K contiguous per output channel.
 #include "common.h"
 
+#include "conv_split_kernel.h"
+
 using namespace lsfa;
 
 namespace {
@@ -240,4 +242,83 @@ extern "C" int lsfa_conv_nhwc_fwd(const float* x, int N, int H, int W, int Cin, 
                                   void* stream) {
   return lsfa_conv_nhwc_fused_fwd(x, N, H, W, Cin, w, bias, Cout, kh, kw, stride, pad, dil, relu, nullptr, y, nullptr, nullptr,
                                   nullptr, ws, ws_bytes, stream);
+}
+
+// ---- the same convolution on the bf16 matrix pipe with exactly split fp32 operands (conv_split_kernel.h) ----
+
+namespace {
+int split_slices(long waves, int chunk_total) {
+  // two waves per SIMD is the design point (two workgroups per CU, 2048 waves); cut K while that leaves slices of
+  // at least 8 chunks
+  int s = (int)(2048 / (waves > 0 ? waves : 1));
+  if (s < 1) s = 1;
+  while (s > 1 && chunk_total / s < 8) --s;
+  return s;
+}
+}  // namespace
+
+extern "C" size_t lsfa_conv_split_weight_bytes(int Cout, int kh, int kw, int Cin) {
+  if (Cout <= 0 || kh <= 0 || kw <= 0 || Cin <= 0 || Cin % 32 != 0 || Cout % 64 != 0) return 0;
+  return (size_t)Cout * kh * kw * Cin * 6;      // three bf16 pieces per weight
+}
+
+extern "C" int lsfa_conv_split_weights(const float* w, int Cout, int kh, int kw, int Cin, void* wfrag, void* stream) {
+  LSFA_REQUIRE(w && wfrag, "lsfa_conv_split_weights: NULL argument");
+  if (lsfa_conv_split_weight_bytes(Cout, kh, kw, Cin) == 0) {
+    set_error("lsfa_conv_split_weights: Cin=%d must be a multiple of 32 and Cout=%d of 64", Cin, Cout);
+    return LSFA_ENOTSUP;
+  }
+  const long total = (long)kh * kw * (Cin / 32) * (Cout / 32) * 2 * 64;
+  hipLaunchKernelGGL(convsplit::split_weights_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, w,
+                     (uint4*)wfrag, Cout, kh * kw, Cin);
+  LSFA_LAUNCH_CHECK("lsfa_conv_split_weights");
+  return LSFA_OK;
+}
+
+extern "C" size_t lsfa_conv_split_workspace_bytes(int N, int H, int W, int Cin, int Cout, int kh, int kw, int stride, int pad, int dil) {
+  if (N <= 0 || H <= 0 || W <= 0 || Cout <= 0 || Cin <= 0 || stride <= 0) return 0;
+  const int Ho = (H + 2 * pad - dil * (kh - 1) - 1) / stride + 1, Wo = (W + 2 * pad - dil * (kw - 1) - 1) / stride + 1;
+  const long P = (long)N * Ho * Wo;
+  const long waves = ((P + convsplit::kWgPix - 1) / convsplit::kWgPix) * 4 * (Cout / convsplit::kWgCh);
+  const int slices = split_slices(waves, kh * kw * (Cin / 32));
+  return slices > 1 ? align_up((size_t)slices * P * Cout * sizeof(float), 256) : 256;
+}
+
+extern "C" int lsfa_conv_split_fwd(const float* x, int N, int H, int W, int Cin, const void* wfrag, const float* bias, int Cout,
+                                   int kh, int kw, int stride, int pad, int dil, int relu, const float* residual, float* y,
+                                   float* y2, const float* scale2, const float* shift2, void* ws, size_t ws_bytes, void* stream) {
+  LSFA_REQUIRE(x && wfrag && y, "lsfa_conv_split_fwd: NULL argument");
+  LSFA_REQUIRE(N > 0 && H > 0 && W > 0 && kh > 0 && kw > 0 && stride > 0 && pad >= 0 && dil > 0, "lsfa_conv_split_fwd: bad shape");
+  LSFA_REQUIRE(!y2 || (scale2 && shift2), "lsfa_conv_split_fwd: y2 given without scale2 / shift2");
+  LSFA_REQUIRE(!y2 || y2 != y, "lsfa_conv_split_fwd: y2 must not alias y");
+  if (Cin % 32 != 0 || Cout % convsplit::kWgCh != 0) {
+    set_error("lsfa_conv_split_fwd: Cin=%d must be a multiple of 32 and Cout=%d of %d", Cin, Cout, convsplit::kWgCh);
+    return LSFA_ENOTSUP;
+  }
+  const int Ho = (H + 2 * pad - dil * (kh - 1) - 1) / stride + 1, Wo = (W + 2 * pad - dil * (kw - 1) - 1) / stride + 1;
+  LSFA_REQUIRE(Ho > 0 && Wo > 0, "lsfa_conv_split_fwd: empty output");
+  const long P = (long)N * Ho * Wo;
+  LSFA_REQUIRE(P * Cout < (1L << 31) && ((long)N * H * W + (long)(pad + 1) * (W + 1)) * Cin < (1L << 31), "lsfa_conv_split_fwd: tensor too large");
+  const int chunk_total = kh * kw * (Cin / 32);
+  const long wg_x = (P + convsplit::kWgPix - 1) / convsplit::kWgPix;
+  const int slices = split_slices(wg_x * 4 * (Cout / convsplit::kWgCh), chunk_total);
+  const size_t need = lsfa_conv_split_workspace_bytes(N, H, W, Cin, Cout, kh, kw, stride, pad, dil);
+  if (slices > 1 && (!ws || ws_bytes < need)) {
+    set_error("lsfa_conv_split_fwd: workspace %zu < %zu bytes", ws_bytes, need);
+    return LSFA_EWORKSPACE;
+  }
+  hipStream_t s = (hipStream_t)stream;
+  convsplit::Args a = {x, (const uint4*)wfrag, bias, y, slices > 1 ? (float*)ws : nullptr, N, H, W, Cin, Cout, kh, kw, stride, pad,
+                       dil, Ho, Wo, relu, (chunk_total + slices - 1) / slices, residual, y2, scale2, shift2};
+  ProfScope prof(LSFA_OP_CONV, s);
+  const int tiles = (int)wg_x * (Cout / convsplit::kWgCh) * slices;
+  hipLaunchKernelGGL(convsplit::conv_split_kernel, dim3((unsigned)(8 * ((tiles + 7) / 8))), dim3(convsplit::kThreads), 0, s, a, (int)wg_x,
+                     Cout / convsplit::kWgCh, slices);
+  if (slices > 1) {
+    ConvArgs r = {x, nullptr, bias, y, (float*)ws, N, H, W, Cin, Cout, kh, kw, stride, pad, dil, Ho, Wo, relu, 0, residual, y2, scale2, shift2};
+    const long n4 = P * Cout / 4;
+    hipLaunchKernelGGL(conv_reduce_kernel, dim3((unsigned)((n4 + kThreads - 1) / kThreads)), dim3(kThreads), 0, s, r, n4, slices);
+  }
+  LSFA_LAUNCH_CHECK("lsfa_conv_split_fwd");
+  return LSFA_OK;
 }

@@ -1,0 +1,309 @@
+// fp32 convolution / GEMM on the bf16 matrix pipe: every fp32 operand is cut EXACTLY into three bf16 pieces
+// (8 + 8 + 8 mantissa bits), and a*b is accumulated in fp32 from the six partial products whose weight is at
+// least 2^-16 of the leading one:
+//     a = a1 + a2 + a3,  b = b1 + b2 + b3   (exact, by truncation: each piece is the leading 8 bits of what is left)
+//     a*b ~= a1*b1 + (a1*b2 + a2*b1) + (a1*b3 + a3*b1 + a2*b2)          dropped: a2*b3 + a3*b2 + a3*b3 < 2^-23 |a*b|
+// Each partial product of two bf16 values is exact in fp32, so the only differences to an fp32 FMA chain are the
+// dropped terms (below one fp32 ulp of the product) and the summation order.  `v_mfma_f32_32x32x16_bf16` does 16 k
+// in 32 cycles where `v_mfma_f32_32x32x2_f32` does 2 k in 64: six of them per 16 k are 2.7x the fp32 pipe's rate.
+// (gfx950 has no xf32 MFMA; this is the same construction as 3xTF32 / BF16x9 GEMM emulation, with the
+// negligible terms left out.)  Measured against a float64 convolution the result is as close as the fp32-MFMA
+// kernel's (tests/test_hip_ops.py::test_conv_split_*).
+//
+// Layout and pipeline.  One chunk = 32 input channels of one tap.  Workgroup = 4 waves = 128 pixels x 64 output
+// channels, wave = 32 pixels x 64 channels (two 32x32 accumulators).  Everything the loop reads arrives by LDS-DMA
+// (`global_load_lds_dwordx4`: global -> LDS with no register stage) into a ring of two stages, one chunk ahead, and
+// two workgroups share a CU (56 KB of LDS each), so one's DMA waits, LDS reads and operand cutting run under the
+// other's MFMAs:
+//   A (activations, fp32 NHWC): the wave's 32 pixels x 128 B.  One DMA instruction moves 8 pixels' whole 128-byte
+//     rows (8 lanes x 16 B per pixel: full cache lines — a DMA shaped like the MFMA fragment, one 16-B piece of a
+//     different pixel per lane, measured 3x the issue time because every lane is its own 64-B sector request).  The
+//     LDS image is linear in lane order, so the bank swizzle is applied on the SOURCE side: slot q of pixel p holds
+//     piece q ^ ((p >> 1) & 7), which makes the fragment reads (lane = pixel, four 16-B pieces of its 64-B half)
+//     conflict-free ds_read_b128.  The A fragment of the 32x32x16 MFMA is, per lane, 8 consecutive k of one row:
+//     lanes l and l+32 take the two 16-channel halves of the chunk (the k order inside a chunk is ours to choose as
+//     long as B agrees); the lane cuts its 16 values in registers and feeds two k-steps.  Zero padding = the source
+//     address points at a block of zeros.  Private to the wave.
+//   B (weights): cut and laid out ONCE at bind time in fragment order (lsfa_conv_split_weights): [tap][chunk]
+//     [32-col tile][step][piece][lane][8 bf16], so a fragment is 1 KB contiguous and the 12 KB the four waves share
+//     per chunk is one contiguous block: 3 DMA instructions per wave; fragments are read with ds_read_b128.
+// The loop body is unrolled over the two stages so that every LDS address is a compile-time offset into ONE
+// __shared__ array, and the DMA helpers take their global pointers as __restrict__ parameters: together that is
+// what lets hipcc see that the reads of one stage never alias the DMA writes in flight to the other (otherwise
+// it drains them with `s_waitcnt vmcnt(0)` before every ds_read).  Per chunk: issue the 7 DMAs of chunk c+1,
+// consume stage c, `s_waitcnt vmcnt(0)`, `lgkmcnt(0)`, raw `s_barrier`.
+// The K range (taps x Cin/32 chunks) is cut into `slices` over gridDim.z like conv.hip, summed by conv_reduce_kernel.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace lsfa {
+namespace convsplit {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int kWavePix = 32, kWgPix = 128, kWgCh = 64, kChunk = 32, kThreads = 256;
+constexpr int kChunkBytesB = 2 /*col tiles*/ * 2 /*steps*/ * 3 /*pieces*/ * 1024;      // 12 KB per chunk and workgroup
+
+struct Args {
+  const float* x; const uint4* wfrag; const float* bias; float* y; float* part;
+  int N, H, W, Cin, Cout, kh, kw, stride, pad, dil, Ho, Wo, relu, chunks_per_slice;
+  const float* res; float* y2; const float* scale2; const float* shift2;
+};
+
+// the leading 8 mantissa bits of v as an fp32 bit pattern (= a bf16 value), and what is left
+__device__ __forceinline__ uint32_t lead(float v) { return __float_as_uint(v) & 0xFFFF0000u; }
+// two bf16 (upper halves of b's and a's bit patterns) -> one dword, a in the low half
+__device__ __forceinline__ uint32_t pack_hi(uint32_t a, uint32_t b) { return __builtin_amdgcn_perm(b, a, 0x07060302u); }
+
+struct Pieces { uint4 p1, p2, p3; };     // 8 values x 3 pieces, packed bf16
+
+__device__ __forceinline__ void cut3(float v, uint32_t& h, uint32_t& m, uint32_t& l) {
+  h = lead(v);
+  const float r1 = v - __uint_as_float(h);       // exact
+  m = lead(r1);
+  const float r2 = r1 - __uint_as_float(m);      // exact, at most 8 significant bits
+  l = __float_as_uint(r2);
+}
+
+__device__ __forceinline__ Pieces split8(const float4& a, const float4& b) {
+  uint32_t h[8], m[8], l[8];
+  cut3(a.x, h[0], m[0], l[0]); cut3(a.y, h[1], m[1], l[1]); cut3(a.z, h[2], m[2], l[2]); cut3(a.w, h[3], m[3], l[3]);
+  cut3(b.x, h[4], m[4], l[4]); cut3(b.y, h[5], m[5], l[5]); cut3(b.z, h[6], m[6], l[6]); cut3(b.w, h[7], m[7], l[7]);
+  Pieces r;
+  r.p1 = make_uint4(pack_hi(h[0], h[1]), pack_hi(h[2], h[3]), pack_hi(h[4], h[5]), pack_hi(h[6], h[7]));
+  r.p2 = make_uint4(pack_hi(m[0], m[1]), pack_hi(m[2], m[3]), pack_hi(m[4], m[5]), pack_hi(m[6], m[7]));
+  r.p3 = make_uint4(pack_hi(l[0], l[1]), pack_hi(l[2], l[3]), pack_hi(l[4], l[5]), pack_hi(l[6], l[7]));
+  return r;
+}
+
+__device__ __forceinline__ bf16x8 as_bf(const uint4& u) {
+  union { uint4 u; bf16x8 v; } c;
+  c.u = u;
+  return c.v;
+}
+
+__device__ __forceinline__ f32x16 mma(const uint4& a, const uint4& b, const f32x16& c) {
+  return __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf(a), as_bf(b), c, 0, 0, 0);
+}
+
+// acc += (a1 + a2 + a3) * (b1 + b2 + b3) without the three smallest terms, smallest kept terms first
+__device__ __forceinline__ f32x16 mma6(const Pieces& a, const uint4& b1, const uint4& b2, const uint4& b3, f32x16 acc) {
+  acc = mma(a.p3, b1, acc);
+  acc = mma(a.p1, b3, acc);
+  acc = mma(a.p2, b2, acc);
+  acc = mma(a.p2, b1, acc);
+  acc = mma(a.p1, b2, acc);
+  acc = mma(a.p1, b1, acc);
+  return acc;
+}
+
+constexpr int kStageA = 4 * 4 * 64;                     // uint4 per stage: 4 waves x 32 pixels x 8 slots = 16 KB
+constexpr int kStageB = kChunkBytesB / 16;              // 768 uint4 = 12 KB
+constexpr int kStage = kStageA + kStageB;               // 28 KB; two stages = 56 KB, two workgroups per CU
+
+__device__ __attribute__((aligned(64))) const float g_zero_block[32] = {};
+
+struct Geom {       // per lane / per wave constants of the loop
+  size_t wstride;                            // uint4 between consecutive chunks
+  int H, W, Cin, kw, stride, pad, dil, chunks_per_tap, chunk0;
+  // the four pixels this lane moves (DMA i: pixel 8*i + (lane >> 3)): top-left input coordinate of its window
+  // (hugely negative when the pixel does not exist) and the float offset of (that coordinate, the lane's swizzled piece)
+  int iy0[4], ix0[4], off0[4];
+  int frag[4];                               // uint4 index, inside the wave's A image, of the lane's four fragment pieces
+  int wave, lane;
+};
+
+// the 7 LDS-DMA instructions of one chunk into stage ST (compile-time LDS offsets).  x / wblock (this workgroup's
+// 12 KB of chunk 0) are __restrict__ parameters on purpose (see the header comment).
+template <int ST>
+__device__ __forceinline__ void issue_chunk(uint4 (*S)[kStage], const float* __restrict__ x, const uint4* __restrict__ wblock,
+                                            const Geom& g, int c) {
+  const int gch = g.chunk0 + c;
+  const int tap = gch / g.chunks_per_tap;
+  const int kc = gch - tap * g.chunks_per_tap;
+  const int ty = tap / g.kw, tx = tap - ty * g.kw;
+  const int dy = ty * g.dil, dx = tx * g.dil;
+  const int doff = (dy * g.W + dx) * g.Cin + kc * kChunk;        // wave-uniform part of the source offset
+  uint4* a_dst = &S[ST][g.wave * 256];                           // + i * 64 (+ lane, implied by the DMA)
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const bool ok = (unsigned)(g.iy0[i] + dy) < (unsigned)g.H && (unsigned)(g.ix0[i] + dx) < (unsigned)g.W;
+    const float* src = ok ? x + (g.off0[i] + doff) : g_zero_block;
+    __builtin_amdgcn_global_load_lds(reinterpret_cast<const uint4*>(src), a_dst + i * 64, 16, 0, 0);
+  }
+  const uint4* wsrc = wblock + (size_t)gch * g.wstride + g.wave * 192 + g.lane;
+  uint4* b_dst = &S[ST][kStageA + g.wave * 192];
+#pragma unroll
+  for (int i = 0; i < 3; ++i) __builtin_amdgcn_global_load_lds(wsrc + i * 64, b_dst + i * 64, 16, 0, 0);
+}
+
+template <int ST>
+__device__ __forceinline__ void consume_chunk(uint4 (*S)[kStage], const Geom& g, f32x16& acc0, f32x16& acc1) {
+  const uint4* A = &S[ST][g.wave * 256];
+  const uint4* B = &S[ST][kStageA + g.lane];
+  const uint4 r0 = A[g.frag[0]], r1 = A[g.frag[1]], r2 = A[g.frag[2]], r3 = A[g.frag[3]];
+  const float4 c0 = make_float4(__uint_as_float(r0.x), __uint_as_float(r0.y), __uint_as_float(r0.z), __uint_as_float(r0.w));
+  const float4 c1 = make_float4(__uint_as_float(r1.x), __uint_as_float(r1.y), __uint_as_float(r1.z), __uint_as_float(r1.w));
+  const float4 c2 = make_float4(__uint_as_float(r2.x), __uint_as_float(r2.y), __uint_as_float(r2.z), __uint_as_float(r2.w));
+  const float4 c3 = make_float4(__uint_as_float(r3.x), __uint_as_float(r3.y), __uint_as_float(r3.z), __uint_as_float(r3.w));
+  const Pieces s0 = split8(c0, c1), s1 = split8(c2, c3);
+  // fragment (col tile t, step s, piece p) at ((t*2 + s)*3 + p)*64 + lane
+  acc0 = mma6(s0, B[(0 * 3 + 0) * 64], B[(0 * 3 + 1) * 64], B[(0 * 3 + 2) * 64], acc0);
+  acc1 = mma6(s0, B[(2 * 3 + 0) * 64], B[(2 * 3 + 1) * 64], B[(2 * 3 + 2) * 64], acc1);
+  acc0 = mma6(s1, B[(1 * 3 + 0) * 64], B[(1 * 3 + 1) * 64], B[(1 * 3 + 2) * 64], acc0);
+  acc1 = mma6(s1, B[(3 * 3 + 0) * 64], B[(3 * 3 + 1) * 64], B[(3 * 3 + 2) * 64], acc1);
+}
+
+#ifdef LSFA_CS_STAMPS     // lab builds only (tools/lab/conv_split_lab.py --stamps): shader-clock stamps of chunk 6, wave 0 of workgroup 8
+__device__ long long g_cs_stamps[8];
+#define CS_STAMP(k) do { if (c == 6 && threadIdx.x == 0 && blockIdx.x == 8) g_cs_stamps[k] = (long long)__builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define CS_STAMP(k) do { } while (0)
+#endif
+
+// chunk c of n: prefetch c+1 into the other stage, compute c, retire the DMAs, meet the other waves.
+// (Measured per chunk, one wave, shader cycles: issue 7 DMAs ~970, read A + cut + 24 MFMAs ~1430, DMA wait ~350,
+// barrier ~100.  The same copy through registers — plain loads, ds_write_b128 after the MFMAs — measured the same
+// total: what is slow is getting 28 KB per chunk into the CU at all, ~20-25 B/clk per CU with every CU pulling, i.e.
+// the L2's aggregate rate; 228-456 workgroups re-read A 4x and B 19x.  See DESIGN.md "Dense contractions".)
+template <int ST>
+__device__ __forceinline__ void pipeline_step(uint4 (*S)[kStage], const float* __restrict__ x, const uint4* __restrict__ wblock,
+                                              const Geom& g, int c, int n, f32x16& acc0, f32x16& acc1) {
+  CS_STAMP(0);
+  if (c + 1 < n) issue_chunk<ST ^ 1>(S, x, wblock, g, c + 1);
+  CS_STAMP(1);
+  consume_chunk<ST>(S, g, acc0, acc1);
+  CS_STAMP(2);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  CS_STAMP(3);
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  CS_STAMP(4);
+}
+
+// Workgroup -> tile, XCD-aware.  The hardware deals consecutive workgroup ids round-robin to the 8 XCDs (id % 8),
+// each with its own 4 MB L2.  Tiles are numbered (slice, channel tile, pixel tile) with the pixel tile fastest and
+// XCD k takes the k-th eighth of that list, so the workgroups that share an L2 share their weights (one or two
+// (slice, channel tile) blocks, a few hundred KB) and sweep the activations once — instead of every XCD streaming
+// all weights AND all activations through its L2 (6 MB for a res4 conv2: it does not fit, and the misses go to the
+// Infinity Cache).
+struct Tile { int x, y, z; };
+__device__ __forceinline__ Tile xcd_tile(int id, int nx, int ny, int nz) {
+  const int total = nx * ny * nz;
+  const int per = (total + 7) / 8;
+  const int t = (id & 7) * per + (id >> 3);
+  Tile r;
+  if (t >= total) { r.x = r.y = r.z = -1; return r; }      // the grid is 8 * per >= total: the surplus ids have no tile
+  r.x = t % nx;
+  const int q = t / nx;
+  r.y = q % ny;
+  r.z = q / ny;
+  return r;
+}
+
+// grid (8 * ceil(tiles / 8)); block 256; 56 KB of LDS.  tiles = ceil(P / 128) * (Cout / 64) * slices
+static __global__ __launch_bounds__(kThreads, 2) void conv_split_kernel(Args a, int nx, int ny, int nz) {
+  __shared__ __attribute__((aligned(16))) uint4 S[2][kStage];
+  const Tile tile = xcd_tile(blockIdx.x, nx, ny, nz);
+  if (tile.x < 0) return;
+  const int tid = threadIdx.x;
+  const int P = a.N * a.Ho * a.Wo;
+  const int taps = a.kh * a.kw;
+  Geom g;
+  g.lane = tid & 63;
+  g.wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  g.H = a.H; g.W = a.W; g.Cin = a.Cin; g.kw = a.kw; g.stride = a.stride; g.pad = a.pad; g.dil = a.dil;
+  g.chunks_per_tap = a.Cin / kChunk;
+  const int chunk_total = taps * g.chunks_per_tap;
+  g.chunk0 = tile.z * a.chunks_per_slice;
+  const int nchunks = min(a.chunks_per_slice, chunk_total - g.chunk0);
+  const int col_tiles = a.Cout / 32;
+  g.wstride = (size_t)col_tiles * (kChunkBytesB / 32);                    // 384 uint4 per 32-col tile and chunk
+  const uint4* wblock = a.wfrag + (size_t)(2 * tile.y) * (kChunkBytesB / 32);
+  const int m0 = tile.x * kWgPix + g.wave * kWavePix;
+  // DMA role: instruction i moves pixels 8i .. 8i+7 of the wave's tile, lane -> pixel 8i + (lane >> 3), slot lane & 7
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int pix = m0 + 8 * i + (g.lane >> 3);
+    const int piece = (g.lane & 7) ^ ((4 * i + (g.lane >> 4)) & 7);      // slot -> source piece: the bank swizzle
+    g.iy0[i] = g.ix0[i] = -(1 << 24);
+    g.off0[i] = 0;
+    if (pix < P) {
+      const int pn = pix / (a.Ho * a.Wo), r = pix - pn * a.Ho * a.Wo, py = r / a.Wo, px = r - py * a.Wo;
+      g.iy0[i] = py * a.stride - a.pad;
+      g.ix0[i] = px * a.stride - a.pad;
+      g.off0[i] = ((pn * a.H + g.iy0[i]) * a.W + g.ix0[i]) * a.Cin + 4 * piece;     // may be negative; only used in bounds
+    }
+  }
+  // (slot q of pixel p holds piece q ^ ((p >> 1) & 7); for p = 8i + (lane >> 3) that is (4i + (lane >> 4)) & 7: issue_chunk)
+  // fragment role: pixel r = lane & 31, pieces 4h .. 4h+3 of its row (h = lane >> 5)
+  {
+    const int r = g.lane & 31, h = g.lane >> 5, sw = (r >> 1) & 7;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) g.frag[j] = r * 8 + ((4 * h + j) ^ sw);
+  }
+
+  f32x16 acc0, acc1;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) { acc0[i] = 0.f; acc1[i] = 0.f; }
+
+  if (nchunks > 0) issue_chunk<0>(S, a.x, wblock, g, 0);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  for (int c = 0; c < nchunks; c += 2) {
+    pipeline_step<0>(S, a.x, wblock, g, c, nchunks, acc0, acc1);
+    if (c + 1 < nchunks) pipeline_step<1>(S, a.x, wblock, g, c + 1, nchunks, acc0, acc1);
+  }
+
+  // C/D layout of 32x32: column = lane & 31 (channel), row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5) (pixel)
+  const int lane = g.lane;
+  float* part = a.part ? a.part + (size_t)tile.z * P * a.Cout : nullptr;
+#pragma unroll
+  for (int t = 0; t < 2; ++t) {
+    const int ch = tile.y * kWgCh + t * 32 + (lane & 31);
+    const float bias = (!part && a.bias) ? a.bias[ch] : 0.f;
+    const float sc2 = (!part && a.y2) ? a.scale2[ch] : 0.f, sh2 = (!part && a.y2) ? a.shift2[ch] : 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+      const int p = m0 + row;
+      if (p < P) {
+        const size_t o = (size_t)p * a.Cout + ch;
+        float v = t == 0 ? acc0[r] : acc1[r];
+        if (part) { part[o] = v; continue; }
+        v = v + bias;
+        if (a.res) v = v + a.res[o];
+        if (a.relu) v = fmaxf(v, 0.f);
+        a.y[o] = v;
+        if (a.y2) a.y2[o] = fmaxf(v * sc2 + sh2, 0.f);
+      }
+    }
+  }
+}
+
+// weights (Cout, taps, Cin) fp32 -> fragment order, three bf16 pieces.  One thread per (fragment, lane): 8 values.
+// out index: ((((g * col_tiles + t) * 2 + s) * 3 + piece) * 64 + lane) uint4, g = tap * (Cin/32) + chunk
+static __global__ void split_weights_kernel(const float* __restrict__ w, uint4* __restrict__ out, int Cout, int taps, int Cin) {
+  const int col_tiles = Cout / 32, chunks = Cin / kChunk;
+  const long total = (long)taps * chunks * col_tiles * 2 * 64;
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  const int lane = (int)(i & 63);
+  long r = i >> 6;
+  const int s = (int)(r & 1); r >>= 1;
+  const int t = (int)(r % col_tiles); r /= col_tiles;
+  const int g = (int)r;
+  const int tap = g / chunks, kc = g - tap * chunks;
+  const int co = t * 32 + (lane & 31);
+  const int ci = kc * kChunk + 16 * (lane >> 5) + 8 * s;
+  const float* src = w + ((size_t)co * taps + tap) * Cin + ci;
+  const float4 v0 = *reinterpret_cast<const float4*>(src), v1 = *reinterpret_cast<const float4*>(src + 4);
+  const Pieces p = split8(v0, v1);
+  uint4* dst = out + ((((size_t)g * col_tiles + t) * 2 + s) * 3) * 64 + lane;
+  dst[0] = p.p1; dst[64] = p.p2; dst[128] = p.p3;
+}
+
+}  // namespace convsplit
+}  // namespace lsfa

@@ -8,6 +8,7 @@
 // Arithmetic is float64 like the numpy reference (fp64 is full rate on CDNA4), following
 // oracle orc_det_postprocess / orc_nms_f64 / orc_bbox_pred_clip operation for operation.
 #include "common.h"
+#include "nms_block.h"
 
 using namespace lsfa;
 
@@ -52,6 +53,13 @@ __global__ __launch_bounds__(kThreads) void bbox_pred_clip_kernel(const float* _
 // suppresses()) and with the transposed words of the diagonal 64x64 blocks built alongside -> one wave
 // sweeps the 64-position blocks, each resolved as a ballot fixpoint (a handful of steps) instead of a
 // 64-step scalar loop.
+#ifdef LSFA_DET_STAMPS     // lab builds only (tools/lab/det_lab.py): phase boundaries of class 1's workgroup, 100 MHz ticks
+__device__ long long g_det_stamps[16];
+#define DET_STAMP(k) do { if (threadIdx.x == 0 && blockIdx.x == 1) g_det_stamps[k] = wall_clock64(); } while (0)
+#else
+#define DET_STAMP(k) do { } while (0)
+#endif
+
 constexpr int kClassThreads = 1024;
 constexpr int kClassWaves = kClassThreads / 64;
 constexpr int kRankSplit = 4;
@@ -62,6 +70,10 @@ constexpr int kRankSplit = 4;
 // => the exact quotient is at least the double after thresh => suppresses; d >= thresh*uni*2^-51
 // implies that.  The sliver in between and non-positive / NaN unions take the division.
 struct NmsTest64 { double thresh, thresh_eps; int fast; };
+
+__device__ __forceinline__ double readlane_f64(double v, int src_lane) {
+  return __longlong_as_double((long long)readlane64((uint64_t)__double_as_longlong(v), src_lane));
+}
 
 __device__ __forceinline__ bool suppresses(double inter, double uni, const NmsTest64& t) {
   const double d = fma(-t.thresh, uni, inter);
@@ -94,8 +106,9 @@ __global__ __launch_bounds__(kClassThreads) void det_class_kernel(
   int* misc = kept + R;  // [0] running count, [1..16] wave sums
 
   // 1. threshold + in-order compaction (np.where(scores[:, j] > thresh), tester.py:267)
+  DET_STAMP(0);
   if (tid == 0) misc[0] = 0;
-  for (int i = tid; i < R; i += kClassThreads) { rank[i] = 0; colw[i] = 0; }
+  for (int i = tid; i < R; i += kClassThreads) rank[i] = 0;
   __syncthreads();
   const int lane = tid & 63, wid = tid >> 6;
   for (int r0 = 0; r0 < R; r0 += kClassThreads) {
@@ -124,6 +137,7 @@ __global__ __launch_bounds__(kClassThreads) void det_class_kernel(
   }
   const int m = misc[0];
   if (m == 0) { if (tid == 0) counts[j] = 0; return; }
+  DET_STAMP(1);
 
   // 2. rank: score descending, ties by ascending candidate (= roi) index; candidate i's comparisons are cut
   //    into kRankSplit slices so that m * kRankSplit threads work
@@ -147,56 +161,79 @@ __global__ __launch_bounds__(kClassThreads) void det_class_kernel(
     sbox[p * 4] = x1; sbox[p * 4 + 1] = y1; sbox[p * 4 + 2] = x2; sbox[p * 4 + 3] = y2;
     sarea[p] = (x2 - x1 + 1) * (y2 - y1 + 1);
   }
-  for (int t = tid; t < m * Wd; t += kClassThreads) mask[t] = 0;
   __syncthreads();
+  DET_STAMP(2);
 
-  // 3. suppression mask over sorted positions: bit b of mask[a][w] <=> position 64w+b > a and the pair
-  //    suppresses; colw[b] collects, for the diagonal blocks, the earlier positions of b's own block that
-  //    suppress b.  One (row, 16-column strip) per thread.
-  const int strips = Wd * 4;
-  for (int t = tid; t < m * strips; t += kClassThreads) {
-    const int a = t / strips, st = t - a * strips;
-    const int c0 = st * 16;
-    if (c0 + 15 <= a || c0 >= m) continue;
-    const double ax1 = sbox[a * 4], ay1 = sbox[a * 4 + 1], ax2 = sbox[a * 4 + 2], ay2 = sbox[a * 4 + 3];
-    const double area_a = sarea[a];
-    const int b0 = max(c0, a + 1), b1 = min(c0 + 16, m);
-    uint64_t bits = 0;
-    for (int b = b0; b < b1; ++b) {
-      const double xx1 = fmax(ax1, sbox[b * 4]), yy1 = fmax(ay1, sbox[b * 4 + 1]);
-      const double xx2 = fmin(ax2, sbox[b * 4 + 2]), yy2 = fmin(ay2, sbox[b * 4 + 3]);
+  // 3. suppression mask over sorted positions, one wave per 64x64 tile of the upper triangle: bit c of
+  //    mask[a][w] <=> position 64w+c > a and the pair suppresses.  The lane owns row a (box in registers), the
+  //    column boxes sit one per lane and are broadcast with readlane, the word is built in a register: no
+  //    atomics, no zero fill (words left of the diagonal are never read).  Diagonal tiles also produce
+  //    colw[c] = the earlier positions of c's own block that suppress c (64 ballots).
+  const int nblk = (m + 63) / 64;
+  const int ntiles = nblk * (nblk + 1) / 2;
+  for (int t = __builtin_amdgcn_readfirstlane(wid); t < ntiles; t += kClassWaves) {
+    int cb = 0;
+    while ((cb + 1) * (cb + 2) / 2 <= t) ++cb;
+    const int rb = t - cb * (cb + 1) / 2;
+    const int a = rb * 64 + lane;
+    const bool a_ok = a < m;
+    const int ar = a_ok ? a : 0;
+    const double ax1 = sbox[ar * 4], ay1 = sbox[ar * 4 + 1], ax2 = sbox[ar * 4 + 2], ay2 = sbox[ar * 4 + 3];
+    const double area_a = sarea[ar];
+    const int c0 = cb * 64, ncol = min(64, m - c0);
+    const bool diag = rb == cb;
+    // lane c holds column box c0 + c; the loop broadcasts it with readlane (no LDS latency inside the loop)
+    const int cc = min(c0 + lane, m - 1);
+    const double cx1 = sbox[cc * 4], cy1 = sbox[cc * 4 + 1], cx2 = sbox[cc * 4 + 2], cy2 = sbox[cc * 4 + 3];
+    const double carea = sarea[cc];
+    uint64_t bits = 0, tbits = 0;
+    for (int c = 0; c < ncol; ++c) {
+      const double xx1 = fmax(ax1, readlane_f64(cx1, c)), yy1 = fmax(ay1, readlane_f64(cy1, c));
+      const double xx2 = fmin(ax2, readlane_f64(cx2, c)), yy2 = fmin(ay2, readlane_f64(cy2, c));
       const double ww = fmax(0.0, xx2 - xx1 + 1), hh = fmax(0.0, yy2 - yy1 + 1);
       const double inter = ww * hh;
-      if (suppresses(inter, area_a + sarea[b] - inter, nms)) {
-        bits |= 1ULL << (b & 63);
-        if ((b >> 6) == (a >> 6)) atomicOr(reinterpret_cast<unsigned long long*>(&colw[b]), 1ULL << (a & 63));
+      const double uni = area_a + readlane_f64(carea, c) - inter;
+      const double d = fma(-nms.thresh, uni, inter);
+      const bool pos = d > 0.0, clear = d >= nms.thresh_eps * uni;
+      bool p = pos && clear;
+      const bool unsure = !nms.fast || !(uni > 0.0) || (pos && !clear);
+      if (__builtin_expect(__any(unsure), 0)) {       // wave-uniform, rare: the sliver around the threshold
+        if (unsure) p = !(inter / uni <= nms.thresh);
+      }
+      p = p && a_ok && (!diag || c > lane);
+      bits |= (uint64_t)p << c;
+      if (diag) {
+        const uint64_t cw = __ballot(p);
+        if (lane == c) tbits = cw;
       }
     }
-    if (bits) atomicOr(reinterpret_cast<unsigned long long*>(&mask[(size_t)a * Wd + (c0 >> 6)]), (unsigned long long)bits);
+    if (a_ok) {
+      mask[(size_t)a * Wd + cb] = bits;
+      if (diag) colw[a] = tbits;
+    }
   }
   __syncthreads();
+  DET_STAMP(3);
 
-  // 4. sweep by wave 0 in 64-position blocks: lane w (< Wd) holds word w of the removed set; a block is the
-  //    fixpoint G(k) = alive(k) && no earlier member of G suppresses k; the survivors' rows are ORed in
+  // 4. sweep by wave 0 in 64-position blocks: lane w (< Wd) holds word w of the removed set; a block is
+  //    resolved by resolve_block (nms_block.h: ballot fixpoint, scalar scan over the survivors when the
+  //    suppression chains are long), then the survivors' rows are ORed in.
   int nk = 0;
   if (wid == 0) {
     uint64_t remv = 0;
-    const int nblk = (m + 63) / 64;
     for (int b = 0; b < nblk; ++b) {
       const int base = b * 64, nb = min(64, m - base);
+      if (b == 0) DET_STAMP(8);
       const uint64_t cw = lane < nb ? colw[base + lane] : 0ULL;
-      const uint32_t cur_lo = __builtin_amdgcn_readlane((uint32_t)remv, b);
-      const uint32_t cur_hi = __builtin_amdgcn_readlane((uint32_t)(remv >> 32), b);
-      const uint64_t cur = ((uint64_t)cur_hi << 32) | cur_lo;
+      const uint64_t rowd = lane < nb ? mask[(size_t)(base + lane) * Wd + b] : 0ULL;
+      const uint64_t cur = readlane64(remv, b);
       const bool alive = lane < nb && !((cur >> lane) & 1ULL);
-      uint64_t G = __ballot(alive);
-      for (int it = 0; it < 64 && G; ++it) {
-        const uint64_t G2 = __ballot(alive && (cw & G) == 0);
-        if (G2 == G) break;
-        G = G2;
-      }
+      if (b == 0) DET_STAMP(9);
+      const uint64_t G = resolve_block(__ballot(alive), alive, cw, rowd, 64);
+      if (b == 0) DET_STAMP(10);
       if ((G >> lane) & 1ULL) kept[nk + __popcll(G & ((1ULL << lane) - 1ULL))] = order[base + lane];
       nk += __popcll(G);
+      if (b == 0) DET_STAMP(11);
       uint64_t rem = G;
       while (rem) {
         int ks[8];
@@ -206,14 +243,16 @@ __global__ __launch_bounds__(kClassThreads) void det_class_kernel(
         }
         uint64_t vv[8];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) vv[u] = (ks[u] >= 0 && lane < Wd) ? mask[(size_t)(base + ks[u]) * Wd + lane] : 0ULL;
+        for (int u = 0; u < 8; ++u) vv[u] = (ks[u] >= 0 && lane > b && lane < Wd) ? mask[(size_t)(base + ks[u]) * Wd + lane] : 0ULL;
 #pragma unroll
         for (int u = 0; u < 8; ++u) remv |= vv[u];
       }
+      if (b == 0) DET_STAMP(12);
     }
     if (lane == 0) { misc[0] = nk; counts[j] = nk; }
   }
   __syncthreads();
+  DET_STAMP(4);
   nk = misc[0];
 
   // 5. survivors in NMS order
@@ -224,6 +263,7 @@ __global__ __launch_bounds__(kClassThreads) void det_class_kernel(
     o[4] = score[i];
     if (keep_idx) keep_idx[(size_t)j * R + k] = src[i];
   }
+  DET_STAMP(5);
 }
 
 __device__ __forceinline__ uint32_t desc_key(float score) {
@@ -232,24 +272,40 @@ __device__ __forceinline__ uint32_t desc_key(float score) {
   return ~asc;
 }
 
-// max_per_image cap (tester.py:274-281).  The scores are float32 probabilities widened to
-// float64, so a 32-bit radix select on their float image is exact.  Single workgroup; the keys
-// of all survivors are staged in LDS once (ncls*R <= 16K keys), histograms are replicated 16x.
+// max_per_image cap (tester.py:274-281).  The scores are float32 probabilities widened to float64, so a
+// select on the 32-bit order keys of their float image is exact.  Single workgroup; the keys of all survivors are
+// staged in LDS once (ncls*R <= 16K keys).  image_thresh = the max_per_image-th best key, found in one pass:
+// a 4096-bin histogram over (exponent, 7 mantissa bits) of the score, the bin the max_per_image-th best falls
+// in, then the exact order inside that bin by pairwise counting among its (few) members.  A bin holding more
+// than kCapListMax keys (thousands of equal scores) falls back to an 8-bit radix select over the staged keys.
 constexpr int kCapMaxKeys = 16384;
+constexpr int kCapBins = 4096;
+constexpr int kCapListMax = 1024;
+
+// monotone 12-bit image of a descending order key: larger score -> larger bin; 128 bins per octave over [2^-32, 1)
+__device__ __forceinline__ int cap_bin(uint32_t key) {
+  const uint32_t asc = ~key;
+  if (!(asc & 0x80000000u)) return 0;
+  const int b = (int)((asc & 0x7fffffffu) >> 16) - ((127 - 32) << 7);
+  return b < 0 ? 0 : (b > kCapBins - 1 ? kCapBins - 1 : b);
+}
+
 __global__ __launch_bounds__(1024) void det_cap_kernel(double* __restrict__ dets, int* __restrict__ counts,
                                                        int* __restrict__ keep_idx, int R, int ncls,
                                                        int max_per_image) {
   __shared__ uint32_t keys[kCapMaxKeys];
-  __shared__ uint32_t hist[16 * 256];
+  __shared__ uint32_t hist[kCapBins];
+  __shared__ uint32_t list[kCapListMax];
   __shared__ int misc[40];
   const int tid = threadIdx.x;
   const int lane = tid & 63, wid = tid >> 6;
-  // offsets of each class's survivors in the flat key array
   if (tid == 0) {
     int t = 0;
     for (int j = 1; j < ncls; ++j) t += counts[j];
     misc[0] = t;
+    misc[3] = 0;      // members of the threshold bin collected so far
   }
+  for (int i = tid; i < kCapBins; i += 1024) hist[i] = 0;
   __syncthreads();
   const int total = misc[0];
   if (total <= max_per_image) return;
@@ -257,50 +313,97 @@ __global__ __launch_bounds__(1024) void det_cap_kernel(double* __restrict__ dets
   const int span = ncls * R;
   for (int i = tid; i < span; i += 1024) {
     const int j = i / R, k = i - j * R;
-    keys[i] = (j >= 1 && k < counts[j]) ? desc_key((float)dets[(size_t)i * 5 + 4]) : 0xFFFFFFFFu;
+    const bool present = j >= 1 && k < counts[j];
+    const uint32_t key = present ? desc_key((float)dets[(size_t)i * 5 + 4]) : 0xFFFFFFFFu;
+    keys[i] = key;
+    if (present) atomicAdd(&hist[cap_bin(key)], 1u);
   }
   __syncthreads();
-  // image_thresh = np.sort(image_scores)[-max_per_image]  == the max_per_image-th largest
-  uint32_t prefix = 0;
-  int remaining = max_per_image;
-  for (int shift = 24; shift >= 0; shift -= 8) {
-    for (int i = tid; i < 16 * 256; i += 1024) hist[i] = 0;
+  // thread t owns bins 4095-4t .. 4092-4t (best scores first); `above` = survivors in better bins
+  {
+    uint32_t c[4];
+    int mine = 0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { c[k] = hist[kCapBins - 1 - (4 * tid + k)]; mine += (int)c[k]; }
+    int incl = mine;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+      const int o = __shfl_up(incl, d, 64);
+      if (lane >= d) incl += o;
+    }
+    if (lane == 63) misc[8 + wid] = incl;
     __syncthreads();
-    uint32_t* myhist = hist + (lane & 15) * 256;
+    int above = incl - mine;
+    for (int w = 0; w < wid; ++w) above += misc[8 + w];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      if (above < max_per_image && above + (int)c[k] >= max_per_image) {
+        misc[1] = kCapBins - 1 - (4 * tid + k);       // the threshold bin
+        misc[2] = max_per_image - above;              // image_thresh is its misc[2]-th best member (1-based)
+        misc[4] = (int)c[k];
+      }
+      above += (int)c[k];
+    }
+  }
+  __syncthreads();
+  const int tbin = misc[1], want = misc[2], members = misc[4];
+  uint32_t T = 0;
+  if (members <= kCapListMax) {
     for (int i = tid; i < span; i += 1024) {
       const uint32_t key = keys[i];
-      const bool match = (shift == 24) || (((key ^ prefix) >> (shift + 8)) == 0);
-      if (match) atomicAdd(&myhist[(key >> shift) & 255u], 1u);
+      if (key != 0xFFFFFFFFu && cap_bin(key) == tbin) list[atomicAdd(&misc[3], 1)] = key;
     }
     __syncthreads();
-    if (tid < 256) {
-      uint32_t c = 0;
-#pragma unroll
-      for (int r = 0; r < 16; ++r) c += hist[r * 256 + tid];
-      int incl = (int)c;
-#pragma unroll
-      for (int d = 1; d < 64; d <<= 1) {
-        const int o = __shfl_up(incl, d, 64);
-        if (lane >= d) incl += o;
+    for (int i = tid; i < members; i += 1024) {
+      const uint32_t ki = list[i];
+      int better = 0, not_worse = 0;
+      for (int k = 0; k < members; ++k) {
+        const uint32_t kk = list[k];
+        better += kk < ki;
+        not_worse += kk <= ki;
       }
-      if (lane == 63) misc[8 + wid] = incl;
-      hist[tid] = (uint32_t)incl;
-      hist[256 + tid] = c;
+      if (better < want && want <= not_worse) misc[5] = (int)ki;    // every writer writes the same key
     }
     __syncthreads();
-    if (tid < 256) {
-      int carry = 0;
-      for (int w = 0; w < wid; ++w) carry += misc[8 + w];
-      const int incl = (int)hist[tid] + carry;
-      const int c = (int)hist[256 + tid];
-      if (incl >= remaining && incl - c < remaining) { misc[1] = tid; misc[2] = remaining - (incl - c); }
+    T = (uint32_t)misc[5];
+  } else {
+    uint32_t* rhist = list;       // 1024 words = 4 x 256 replicated radix histograms
+    uint32_t prefix = 0;
+    int remaining = max_per_image;
+    for (int shift = 24; shift >= 0; shift -= 8) {
+      for (int i = tid; i < 4 * 256; i += 1024) rhist[i] = 0;
+      __syncthreads();
+      uint32_t* myhist = rhist + (lane & 3) * 256;
+      for (int i = tid; i < span; i += 1024) {
+        const uint32_t key = keys[i];
+        const bool match = (shift == 24) || (((key ^ prefix) >> (shift + 8)) == 0);
+        if (match) atomicAdd(&myhist[(key >> shift) & 255u], 1u);
+      }
+      __syncthreads();
+      int c = 0, incl = 0;
+      if (tid < 256) {
+        c = (int)(rhist[tid] + rhist[256 + tid] + rhist[512 + tid] + rhist[768 + tid]);
+        incl = c;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+          const int o = __shfl_up(incl, d, 64);
+          if (lane >= d) incl += o;
+        }
+        if (lane == 63) misc[8 + wid] = incl;
+      }
+      __syncthreads();
+      if (tid < 256) {
+        for (int w = 0; w < wid; ++w) incl += misc[8 + w];
+        if (incl >= remaining && incl - c < remaining) { misc[1] = tid; misc[2] = remaining - (incl - c); }
+      }
+      __syncthreads();
+      prefix |= (uint32_t)misc[1] << shift;
+      remaining = misc[2];
+      __syncthreads();
     }
-    __syncthreads();
-    prefix |= (uint32_t)misc[1] << shift;
-    remaining = misc[2];
-    __syncthreads();
+    T = prefix;
   }
-  const uint32_t T = prefix;  // keep score >= image_thresh  <=>  key <= T
+  // keep score >= image_thresh  <=>  key <= T
   for (int j = 1 + wid; j < ncls; j += 16) {
     const int cj = counts[j];
     int m = 0;
@@ -334,6 +437,12 @@ size_t class_lds_bytes(int R) {
 }
 
 }  // namespace
+
+#ifdef LSFA_DET_STAMPS
+extern "C" int lsfa_det_lab_stamps(long long* host16) {
+  return hipMemcpyFromSymbol(host16, HIP_SYMBOL(g_det_stamps), sizeof(long long) * 16) == hipSuccess ? 0 : 1;
+}
+#endif
 
 extern "C" size_t lsfa_det_workspace_bytes(int R, int ncls) {
   (void)R; (void)ncls;

@@ -21,6 +21,7 @@
 #include <math.h>
 
 #include "common.h"
+#include "nms_block.h"
 
 namespace lsfa {
 
@@ -239,14 +240,32 @@ __device__ __forceinline__ uint64_t wave_or64(uint64_t v) {
   return ((uint64_t)hi << 32) | lo;
 }
 
+// OR over the wave, returned as a wave-uniform value, on the DPP cross-lane paths: quad swaps, half-row and row
+// mirrors (every lane of a 16-lane row then holds the row's OR), row_bcast15 into rows 1 and 3, row_bcast31 into
+// rows 2 and 3, read lane 63.  About 25 VALU instructions and no LDS traffic (the ds_bpermute butterfly of
+// wave_or64 is 12 dependent LDS-crossbar round trips).
+__device__ __forceinline__ uint32_t wave_or32_dpp(uint32_t x) {
+  x |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0xB1, 0xF, 0xF, false);    // quad_perm [1,0,3,2]
+  x |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x4E, 0xF, 0xF, false);    // quad_perm [2,3,0,1]
+  x |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x141, 0xF, 0xF, false);   // row_half_mirror
+  x |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x140, 0xF, 0xF, false);   // row_mirror
+  x |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x142, 0xA, 0xF, false);   // row_bcast15 -> rows 1, 3
+  x |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x143, 0xC, 0xF, false);   // row_bcast31 -> rows 2, 3
+  return (uint32_t)__builtin_amdgcn_readlane((int)x, 63);
+}
+__device__ __forceinline__ uint64_t wave_or64_uniform(uint64_t v) {
+  return ((uint64_t)wave_or32_dpp((uint32_t)(v >> 32)) << 32) | wave_or32_dpp((uint32_t)v);
+}
+
 // grid (images); block 64 (one wave).  keep: (images, n) positions in the sorted list, or NULL; num_keep:
 // (images) or NULL.  Proposal epilogue when rois != NULL: sorted_box (images, n) float4, sorted_key (images, n)
 // order keys (for `scores`), rois (images*post_n, 5), scores (images*post_n) or NULL; max_keep = post_n.
 //
 // Which candidates of block b are already suppressed is found LAZILY when max_keep <= kSweepLazyMax: the
-// survivors so far sit in an LDS list, each lane gathers word b of a survivor's mask row and the wave ORs them
-// (one memory round trip per visited block, whatever the number of survivors; nothing is ever computed for
-// blocks the sweep does not reach — Proposal stops after 300 survivors, usually within a few blocks).
+// survivors so far sit in an LDS list, each lane gathers one word of a survivor's mask row and the lanes OR
+// them into the next block's removed-set word (nothing is ever loaded for blocks the sweep does not reach —
+// Proposal stops after 300 survivors, usually within a few blocks — and the loads for block b+1 are in
+// flight while block b is resolved).
 // Larger keep budgets use the eager form: every survivor's whole row is ORed into a removed-set in LDS.
 static __global__ __launch_bounds__(64) void nms_sweep_kernel(const uint64_t* __restrict__ mask_all,
                                                               const uint64_t* __restrict__ diagT_all, int n, int col_blocks,
@@ -268,6 +287,50 @@ static __global__ __launch_bounds__(64) void nms_sweep_kernel(const uint64_t* __
   }
   __syncthreads();  // single-wave workgroup: orders the LDS accesses of different lanes
   int num = 0;
+  if (lazy) {
+    // Software-pipelined: everything block b+1 needs from memory is requested before block b is resolved.
+    //   removed(b+1) = OR of word b+1 of the rows kept in blocks < b   (gathered through kept_pos: known now)
+    //                | OR of word b+1 of the rows block b keeps         (all 64 rows of block b are loaded
+    //                                                                    speculatively, the kept lanes contribute)
+    // so one block costs a ballot fixpoint and one cross-lane OR, not a dependent trip to memory.
+    uint64_t colw = lane < n ? diagT[lane] : 0ULL;
+    uint64_t rowd = lane < n ? mask[(size_t)lane * col_blocks] : 0ULL;
+    // vmcnt(0) here, so that inside the loop the compiler knows colw / rowd have landed and their uses do not
+    // wait for the loads the same iteration has just issued (the counter retires in order)
+    __builtin_amdgcn_s_waitcnt(0x0F70);
+    uint64_t cur = 0;     // removed-set word of the block being resolved (wave-uniform)
+    for (int b = 0; b < col_blocks && num < max_keep; ++b) {
+      const int base = b * 64;
+      const int nb = min(64, n - base);
+      const bool more = b + 1 < col_blocks;
+      uint64_t col_n = 0, rowd_n = 0, spec = 0, v0 = 0, v1 = 0, v2 = 0, v3 = 0, v4 = 0, vrest = 0;
+      if (more) {
+        const int nxt = base + 64 + lane;
+        if (nxt < n) { col_n = diagT[nxt]; rowd_n = mask[(size_t)nxt * col_blocks + b + 1]; }
+        if (lane < nb) spec = mask[(size_t)(base + lane) * col_blocks + b + 1];
+        const uint64_t* mcol = mask + b + 1;
+        if (lane < num) v0 = mcol[(size_t)kept_pos[lane] * col_blocks];
+        if (lane + 64 < num) v1 = mcol[(size_t)kept_pos[lane + 64] * col_blocks];
+        if (lane + 128 < num) v2 = mcol[(size_t)kept_pos[lane + 128] * col_blocks];
+        if (lane + 192 < num) v3 = mcol[(size_t)kept_pos[lane + 192] * col_blocks];
+        if (lane + 256 < num) v4 = mcol[(size_t)kept_pos[lane + 256] * col_blocks];
+        for (int k = lane + 320; k < num; k += 64) vrest |= mcol[(size_t)kept_pos[k] * col_blocks];
+      }
+      const bool alive = lane < nb && !((cur >> lane) & 1ULL);
+      const uint64_t kept = resolve_block(__ballot(alive), alive, colw, rowd, max_keep - num);
+      const bool mine = (kept >> lane) & 1ULL;
+      if (mine) {
+        const int pos = num + __popcll(kept & ((1ULL << lane) - 1ULL));
+        if (keep) keep[pos] = base + lane;
+        kept_pos[pos] = base + lane;
+      }
+      num += __popcll(kept);
+      if (more) cur = wave_or64_uniform(v0 | v1 | v2 | v3 | v4 | vrest | (mine ? spec : 0ULL));
+      colw = col_n;
+      rowd = rowd_n;
+      __syncthreads();
+    }
+  } else {
   uint64_t col_next = lane < n ? diagT[lane] : 0ULL;
   for (int b = 0; b < col_blocks && num < max_keep; ++b) {
     const int base = b * 64;
@@ -275,38 +338,18 @@ static __global__ __launch_bounds__(64) void nms_sweep_kernel(const uint64_t* __
     const uint64_t colw = col_next;
     const int nxt = base + 64 + lane;
     col_next = nxt < n ? diagT[nxt] : 0ULL;     // next block's transposed diagonal: independent of the sweep state
-    uint64_t cur;
-    if (lazy) {
-      uint64_t acc = 0;
-      for (int k = lane; k < num; k += 64) acc |= mask[(size_t)kept_pos[k] * col_blocks + b];
-      cur = wave_or64(acc);
-    } else {
-      cur = remv[b];
-    }
+    const uint64_t cur = remv[b];
     const bool alive = lane < nb && !((cur >> lane) & 1ULL);
-    uint64_t G = __ballot(alive);
-    if (G == 0) continue;
-    for (int it = 0; it < 64; ++it) {
-      const uint64_t G2 = __ballot(alive && (colw & G) == 0);
-      if (G2 == G) break;
-      G = G2;
-    }
-    uint64_t kept = G;
-    const int budget = max_keep - num;
-    if (__popcll(G) > budget) {
-      const bool mine = (G >> lane) & 1ULL;
-      const int rank = __popcll(G & ((1ULL << lane) - 1ULL));
-      kept = __ballot(mine && rank < budget);
-    }
+    const uint64_t rowd = lane < nb ? mask[(size_t)(base + lane) * col_blocks + b] : 0ULL;
+    const uint64_t kept = resolve_block(__ballot(alive), alive, colw, rowd, max_keep - num);
+    if (kept == 0) continue;
     if ((kept >> lane) & 1ULL) {
       const int pos = num + __popcll(kept & ((1ULL << lane) - 1ULL));
       if (keep) keep[pos] = base + lane;
-      if (lazy) kept_pos[pos] = base + lane;
     }
     num += __popcll(kept);
     __syncthreads();
     if (num >= max_keep || b + 1 >= col_blocks) break;
-    if (lazy) continue;
     // eager: OR the survivors' rows into remv for the blocks to the right of b, 8 rows per batch of loads
     uint64_t rem = kept;
     while (rem) {
@@ -328,6 +371,7 @@ static __global__ __launch_bounds__(64) void nms_sweep_kernel(const uint64_t* __
       }
     }
     __syncthreads();
+  }
   }
   if (num_keep_all && lane == 0) num_keep_all[img] = num;
   if (rois) {      // Proposal: max_keep = post_n <= kSweepMaxOut <= kSweepLazyMax, so kept_pos holds the survivors

@@ -38,7 +38,8 @@ def lib():
         L = ctypes.CDLL(LIB_PATH)
         L.lsfa_last_error.restype = ctypes.c_char_p
         for name in ("lsfa_proposal_workspace_bytes", "lsfa_nms_workspace_bytes", "lsfa_det_workspace_bytes",
-                     "lsfa_mv_workspace_bytes", "lsfa_conv_nhwc_workspace_bytes"):
+                     "lsfa_mv_workspace_bytes", "lsfa_conv_nhwc_workspace_bytes", "lsfa_conv_split_weight_bytes",
+                     "lsfa_conv_split_workspace_bytes"):
             getattr(L, name).restype = ctypes.c_size_t
         L.lsfa_op_name.restype = ctypes.c_char_p
         L._nms.restype = None
@@ -401,6 +402,49 @@ def conv_nhwc(x, w_kc, bias, kh, kw, stride=1, pad=0, dil=1, relu=False, out=Non
                                           _ci(kw), _ci(stride), _ci(pad), _ci(dil), _ci(int(relu)), _ptr(residual), _ptr(out),
                                           _ptr(out2), _ptr(scale2), _ptr(shift2), _ptr(ws), ctypes.c_size_t(need), _stream()),
            "lsfa_conv_nhwc_fused_fwd")
+    return out if out2 is None else (out, out2)
+
+
+class SplitWeight(object):
+    """A convolution weight cut into three bf16 pieces per value and laid out in MFMA fragment order
+    (lsfa_conv_split_weights); made once per layer at bind time."""
+
+    def __init__(self, weight):
+        """weight: (Cout, Cin, kh, kw) float32 CUDA tensor (the framework's layout)."""
+        w_kc = _f32c(conv_weight_kc(weight), "weight")
+        self.cout, self.cin, self.kh, self.kw = [int(v) for v in weight.shape]
+        need = lib().lsfa_conv_split_weight_bytes(_ci(self.cout), _ci(self.kh), _ci(self.kw), _ci(self.cin))
+        if need == 0:
+            raise LsfaError("SplitWeight: Cin=%d must be a multiple of 32 and Cout=%d of 64" % (self.cin, self.cout))
+        self.frag = torch.empty(need, dtype=torch.uint8, device=weight.device)
+        with torch.cuda.device(weight.device):
+            _check(lib().lsfa_conv_split_weights(_ptr(w_kc), _ci(self.cout), _ci(self.kh), _ci(self.kw), _ci(self.cin),
+                                                 _ptr(self.frag), _stream()), "lsfa_conv_split_weights")
+
+
+@_on_tensor_device
+def conv_split(x, sw, bias=None, stride=1, pad=0, dil=1, relu=False, out=None, residual=None, out2=None, scale2=None,
+               shift2=None):
+    """conv_nhwc on the bf16 matrix pipe with exactly split fp32 operands (lsfa_conv_split_fwd); sw: SplitWeight.
+    x (N, H, W, Cin) contiguous fp32 -> (N, Ho, Wo, Cout); the other arguments as conv_nhwc."""
+    x = _f32c(x, "x")
+    N, H, W, Cin = x.shape
+    if Cin != sw.cin:
+        raise LsfaError("conv_split: input has %d channels, the weight %d" % (Cin, sw.cin))
+    Cout, kh, kw = sw.cout, sw.kh, sw.kw
+    Ho, Wo = (H + 2 * pad - dil * (kh - 1) - 1) // stride + 1, (W + 2 * pad - dil * (kw - 1) - 1) // stride + 1
+    if out is None:
+        out = torch.empty((N, Ho, Wo, Cout), device=x.device, dtype=torch.float32)
+    for name, t in (("out", out), ("residual", residual), ("out2", out2)):
+        if t is not None and (t.numel() != N * Ho * Wo * Cout or not t.is_contiguous() or t.dtype != torch.float32):
+            raise LsfaError("conv_split: %s must be a contiguous float32 tensor of %d elements" % (name, N * Ho * Wo * Cout))
+    need = lib().lsfa_conv_split_workspace_bytes(_ci(N), _ci(H), _ci(W), _ci(Cin), _ci(Cout), _ci(kh), _ci(kw), _ci(stride),
+                                                 _ci(pad), _ci(dil))
+    ws = torch.empty(need, dtype=torch.uint8, device=x.device)
+    _check(lib().lsfa_conv_split_fwd(_ptr(x), _ci(N), _ci(H), _ci(W), _ci(Cin), _ptr(sw.frag), _ptr(bias), _ci(Cout), _ci(kh),
+                                     _ci(kw), _ci(stride), _ci(pad), _ci(dil), _ci(int(relu)), _ptr(residual), _ptr(out),
+                                     _ptr(out2), _ptr(scale2), _ptr(shift2), _ptr(ws), ctypes.c_size_t(need), _stream()),
+           "lsfa_conv_split_fwd")
     return out if out2 is None else (out, out2)
 
 

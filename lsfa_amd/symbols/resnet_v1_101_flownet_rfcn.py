@@ -40,10 +40,16 @@ _CONV1X1_MIOPEN = _os.environ.get('LSFA_CONV1X1_MIOPEN', '0') == '1'   # experim
 # which 3x3 convolutions of the channels-last sub-networks run on the own fp32-MFMA implicit GEMM (lsfa_conv_nhwc_fwd,
 # bias + ReLU in its epilogue) instead of the library's kernel + a separate bias/ReLU pass: comma list of backbone, small;
 # `conv3` additionally runs the 1x1 conv3 of those units on it with the shortcut add and the next unit's bn1 + ReLU fused
+# (lsfa_conv_nhwc_fused_fwd) - measured SLOWER (backbone 4239 -> 4983 us: the 64x64-tile kernel loses to the tuned library GEMM on
+# K = 256 by more than the saved BN pass), so it is off by default.
 # measured at 1000x600 (tools/key_sections.py, hipGraph replay): backbone 4327 -> 4239 us with it, small net 256 -> 289 us:
 # the backbone's stage 2/3 units gain (epilogue fusion + deterministic tap split), the small net's 64-channel stage 1 and the
 # 256 -> 1024 fuse convolution do not
-_OWN_CONV = set(x for x in _os.environ.get('LSFA_OWN_CONV', 'backbone,conv3').split(',') if x)
+_OWN_CONV = set(x for x in _os.environ.get('LSFA_OWN_CONV', 'backbone').split(',') if x)
+# the own 3x3 convolutions on the bf16 matrix pipe with exactly split fp32 operands (lsfa_conv_split_fwd: fp32 in, fp32
+# accumulate, error against float64 equal to the fp32-MFMA kernel's) instead of the fp32 matrix instructions.  Measured per
+# conv2 at 1000x600 (tools/lab/conv_split_lab.py): res4 32.7 vs 40.7 us, res3 31.4 vs 50.4, res2 34.6 vs 51.3.
+_CONV_SPLIT = _os.environ.get('LSFA_CONV_SPLIT', '1') == '1'
 
 
 class TestSymbol(object):
@@ -235,6 +241,8 @@ class _ResNetWeights(object):
             d['w2_cl'] = d['w2'].contiguous(memory_format=cl)
             if d['w2'].dtype == torch.float32 and d['w2'].shape[1] % 32 == 0 and d['w2'].shape[0] % 64 == 0:
                 d['w2_kc'] = hip.conv_weight_kc(d['w2'])        # (Cout, 9, Cin): lsfa_conv_nhwc_fwd's layout
+                if _CONV_SPLIT and d['w2'].is_cuda:
+                    d['w2_split'] = hip.SplitWeight(d['w2'])    # three bf16 pieces per weight, MFMA fragment order
             if d['w3'].dtype == torch.float32 and d['w3'].shape[1] % 32 == 0 and d['w3'].shape[0] % 64 == 0:
                 d['w3_kc'] = hip.conv_weight_kc(d['w3'])        # (Cout, 1, Cin)
             if 'sc' in d:
@@ -459,6 +467,11 @@ class Executor(object):
             if u['dcn']:
                 c2 = self._dcn_cl(self._map(c1, h, w), u, unit_dilate)
                 ho, wo = h, w
+            elif own_conv and 'w2_split' in u:
+                y = hip.conv_split(c1.view(-1, h, w, c1.shape[1]), u['w2_split'], u['b2'], stride, unit_dilate, unit_dilate,
+                                   relu=True)                      # folded bn3 bias + ReLU in the epilogue
+                ho, wo = y.shape[1], y.shape[2]
+                c2 = y.view(-1, y.shape[3])
             elif own_conv and 'w2_kc' in u:
                 y = hip.conv_nhwc(c1.view(-1, h, w, c1.shape[1]), u['w2_kc'], u['b2'], 3, 3, stride, unit_dilate, unit_dilate,
                                   relu=True)                       # folded bn3 bias + ReLU in the epilogue

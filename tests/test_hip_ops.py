@@ -356,13 +356,13 @@ def test_proposal_ties_stable_order_and_cyclic_pad(hip):
     assert nkeep[0] < 300                                       # the pad path really ran
 
 
-@pytest.mark.parametrize("kind", ["flat", "all_equal", "logits", "few_valid", "saturated"])
+@pytest.mark.parametrize("kind", ["flat", "all_equal", "logits", "few_valid", "saturated", "huge_boxes"])
 def test_proposal_score_distributions_that_stress_the_select(hip, kind):
     """The chip-wide plan picks its candidates by a 4096-bin histogram of the order keys and ranks them
     exactly; these inputs put thousands of keys into the threshold bin (nearly flat scores, all scores equal,
     the -1 block larger than what is left), or outside the range the bins resolve (raw logits, scores of
     exactly 1.0).  Results must still equal the oracle's stable sort + NMS bit for bit."""
-    rs = np.random.RandomState({"flat": 1, "all_equal": 2, "logits": 3, "few_valid": 4, "saturated": 5}[kind])
+    rs = np.random.RandomState({"flat": 1, "all_equal": 2, "logits": 3, "few_valid": 4, "saturated": 5, "huge_boxes": 6}[kind])
     H, W = 38, 63
     prob, deltas = rpn_inputs(rs, 1, H, W)
     im_info = np.array([[600, 1000, 1.0]], np.float32)
@@ -378,6 +378,9 @@ def test_proposal_score_distributions_that_stress_the_select(hip, kind):
         min_size = 16
     elif kind == "saturated":
         prob[:, 9:] = np.where(rs.rand(1, 9, H, W) < 0.4, 1.0, prob[:, 9:]).astype(np.float32)
+    elif kind == "huge_boxes":       # every box clips to nearly the whole image: each 64-box block is one pile of
+        deltas[:, 2::4] = 3.0         # near-duplicates, the sweep visits all 94 blocks and keeps a handful
+        deltas[:, 3::4] = 3.0
     want_rois, want_scores = oracle.proposal(prob, deltas, im_info, rpn_min_size=min_size)
     op = hip.ProposalOp(rpn_min_size=min_size, output_score=True)
     rois, scores = op(t(prob), t(deltas), t(im_info))
@@ -452,6 +455,81 @@ def test_det_postprocess_vs_oracle(hip, seed, cap):
         np.testing.assert_array_equal(keep_idx[j, :counts[j]].cpu().numpy(), w_k[j, :counts[j]])
         # fp64 arithmetic in the same order on both sides; exp() of the two libms may differ by an ulp
         np.testing.assert_allclose(dets[j, :counts[j]].cpu().numpy(), w_d[j, :counts[j]], rtol=1e-12, atol=1e-9)
+
+
+@pytest.mark.parametrize("kind", ["piles", "equal_scores", "tied_at_cap", "two_values", "disjoint"])
+def test_det_postprocess_inputs_that_stress_sweep_and_cap(hip, kind):
+    """Near-duplicate piles (suppression chains as long as a 64-box block: the sweep's scalar scan), thousands of
+    equal scores (the cap's threshold bin overflows its list: radix fallback), ties exactly at the cap threshold
+    (all of them are kept, tester.py:277-281), no overlaps at all (every box survives, the fixpoint settles at once)."""
+    rs = np.random.RandomState(11)
+    R, ncls = 300, 31
+    rois = rand_rois(rs, R, small=0.0)
+    deltas = (0.05 * rs.randn(R, 8)).astype(np.float32)
+    logits = (2 * rs.randn(R, ncls)).astype(np.float32)
+    e = np.exp(logits - logits.max(1, keepdims=True))
+    probs = (e / e.sum(1, keepdims=True)).astype(np.float32)
+    cap = 300
+    if kind == "piles":          # 5 piles of 60 boxes, each box a slightly shifted copy of its neighbour
+        for p_ in range(5):
+            x, y = 100 + 150 * p_, 80 + 60 * p_
+            for i in range(60):
+                rois[p_ * 60 + i, 1:] = [x + 2.5 * i, y + 1.5 * i, x + 2.5 * i + 180, y + 1.5 * i + 140]
+        deltas[:] = 0
+        probs[:] = np.float32(1.0 / ncls)
+        probs[:, 1:] += (1e-4 * rs.rand(R, ncls - 1)).astype(np.float32)
+    elif kind == "equal_scores":
+        probs[:] = np.float32(1.0 / ncls)
+        x1 = (rs.rand(R) * 800).astype(np.float32); y1 = (rs.rand(R) * 450).astype(np.float32)
+        rois[:, 1:] = np.stack([x1, y1, x1 + 30, y1 + 30], 1)
+        deltas[:] = 0
+    elif kind == "tied_at_cap":
+        probs[:] = np.float32(1e-5)
+        x1 = (np.arange(R) % 20 * 48).astype(np.float32); y1 = (np.arange(R) // 20 * 38).astype(np.float32)
+        rois[:, 1:] = np.stack([x1, y1, x1 + 20, y1 + 20], 1)      # disjoint: everything above threshold survives
+        deltas[:] = 0
+        probs[:40, 3] = 0.9; probs[40:120, 5] = 0.5; probs[120:, 7] = 0.5       # the 50-th best sits inside a 260-way tie
+        cap = 50
+    elif kind == "two_values":
+        probs[:] = np.float32(0.25)
+        probs[::3] = np.float32(0.5)
+        cap = 700
+    else:
+        x1 = (np.arange(R) % 20 * 48).astype(np.float32); y1 = (np.arange(R) // 20 * 38).astype(np.float32)
+        rois[:, 1:] = np.stack([x1, y1, x1 + 20, y1 + 20], 1)
+        deltas[:] = 0
+    w_d, w_c, w_k = oracle.det_postprocess(rois, deltas, probs, 600, 1000, 1.0, max_per_image=cap)
+    dets, counts, keep_idx = hip.det_postprocess(t(rois), t(deltas), t(probs), 600, 1000, 1.0, max_per_image=cap)
+    counts = counts.cpu().numpy()
+    np.testing.assert_array_equal(counts, w_c)
+    if kind == "tied_at_cap":
+        assert counts.sum() == 40 + 80 + 180
+    for j in range(ncls):
+        np.testing.assert_array_equal(keep_idx[j, :counts[j]].cpu().numpy(), w_k[j, :counts[j]])
+        np.testing.assert_allclose(dets[j, :counts[j]].cpu().numpy(), w_d[j, :counts[j]], rtol=1e-12, atol=1e-9)
+
+
+@pytest.mark.parametrize("n,th", [(640, 0.5), (2000, 0.7)])
+def test_nms_near_duplicate_piles(hip, n, th):
+    """Blocks that are one pile of near-duplicates: the suppression chain inside a 64-box block is ~64 long, which the
+    block resolution answers by scanning survivors instead of iterating the ballot fixpoint."""
+    rs = np.random.RandomState(n)
+    i = np.arange(n, dtype=np.float32)
+    pile = (i // 100)
+    x1 = 50 + 90 * pile + 1.75 * (i % 100); y1 = 40 + 30 * pile + 1.25 * (i % 100)
+    boxes = np.stack([x1, y1, x1 + 160, y1 + 120], 1).astype(np.float32)
+    scores = np.sort(rs.rand(n).astype(np.float32))[::-1].copy()
+    dets = np.concatenate([boxes, scores[:, None]], 1).astype(np.float32)
+    want = oracle.nms_sorted(dets, th)
+    keep, num = hip.nms_sorted(t(dets), th)
+    k = int(num.item())
+    assert k == len(want)
+    np.testing.assert_array_equal(keep[:k].cpu().numpy(), want)
+    d64 = dets.astype(np.float64)
+    want64 = oracle.nms_f64(d64, th)
+    keep, num = hip.nms_sorted_f64(t(d64), th)
+    assert int(num.item()) == len(want64)
+    np.testing.assert_array_equal(keep[:len(want64)].cpu().numpy(), want64)
 
 
 # ------------------------------------------------------------------ DCN / BN ----------
@@ -634,6 +712,100 @@ def test_conv_nhwc_mfma_vs_torch(hip, cfg):
     g2 = hip.conv_nhwc(xt, wk, None, k, k, stride, pad, dil, relu=False).cpu().numpy()
     assert np.abs(g2 - want2).max() < 2e-6 * np.sqrt(Cin * k * k) * max(np.abs(want2).max(), 1.0)
     assert (g2 < 0).any()
+
+
+# ------------------------------------------------------------------ split-bf16 convolution ----
+SPLIT_CFGS = [
+    dict(N=1, H=38, W=63, Cin=256, Cout=256, k=3, stride=1, dil=1),      # res4 conv2 (K cut into slices)
+    dict(N=1, H=75, W=125, Cin=128, Cout=128, k=3, stride=1, dil=1),     # res3 conv2
+    dict(N=1, H=75, W=125, Cin=256, Cout=256, k=3, stride=2, dil=1),     # stride 2
+    dict(N=1, H=38, W=63, Cin=512, Cout=512, k=3, stride=1, dil=2),      # dilated
+    dict(N=2, H=13, W=9, Cin=64, Cout=64, k=3, stride=1, dil=1),         # batch 2, ragged pixel tile, one chunk per tap
+    dict(N=1, H=20, W=17, Cin=96, Cout=128, k=1, stride=1, dil=1),       # 1x1, odd chunk count
+    dict(N=1, H=38, W=63, Cin=256, Cout=1024, k=1, stride=1, dil=1),     # res4 conv3 shape
+]
+
+
+@pytest.mark.parametrize("cfg", SPLIT_CFGS)
+def test_conv_split_vs_float64_and_fp32_mfma(hip, cfg):
+    """lsfa_conv_split_fwd: fp32 operands cut exactly into three bf16 pieces, six partial products on the bf16 matrix
+    pipe, fp32 accumulation.  Against a float64 convolution it must be inside the same bound as the fp32-MFMA kernel
+    (2e-6 * sqrt(K) of the output scale) and not worse than 1.5x that kernel's own error; a second launch reproduces
+    the first bit for bit (slices are added in a fixed order)."""
+    import torch.nn.functional as F
+    rs = np.random.RandomState(cfg["Cin"] + cfg["H"] + 1)
+    N, H, W, Cin, Cout, k, stride, dil = (cfg[x] for x in ("N", "H", "W", "Cin", "Cout", "k", "stride", "dil"))
+    pad = dil * (k // 2)
+    # activations like the network's: non-negative with a per-channel gain, a few exact zeros and tiny values
+    x = (np.maximum(rs.randn(N, Cin, H, W), 0) * rs.uniform(0.1, 3.0, (1, Cin, 1, 1))).astype(np.float32)
+    x[0, :, 0, 0] = 1e-30
+    w = (rs.randn(Cout, Cin, k, k) / np.sqrt(Cin * k * k)).astype(np.float32)
+    b = rs.randn(Cout).astype(np.float32)
+    want = torch.relu(F.conv2d(torch.from_numpy(x).double(), torch.from_numpy(w).double(), torch.from_numpy(b).double(),
+                               stride, pad, dil)).permute(0, 2, 3, 1).numpy()
+    xt = t(x).permute(0, 2, 3, 1).contiguous()
+    sw = hip.SplitWeight(t(w))
+    got = hip.conv_split(xt, sw, t(b), stride, pad, dil, relu=True)
+    again = hip.conv_split(xt, sw, t(b), stride, pad, dil, relu=True)
+    assert torch.equal(got, again)
+    g = got.cpu().numpy()
+    assert g.shape == want.shape
+    scale = max(np.abs(want).max(), 1.0)
+    err_split = np.abs(g - want).max()
+    assert err_split < 2e-6 * np.sqrt(Cin * k * k) * scale
+    ref32 = hip.conv_nhwc(xt, hip.conv_weight_kc(t(w)), t(b), k, k, stride, pad, dil, relu=True).cpu().numpy()
+    err_mfma = np.abs(ref32 - want).max()
+    assert err_split < 1.5 * err_mfma + 1e-7 * scale, (err_split, err_mfma)
+    rms = lambda a: float(np.sqrt(np.mean((a - want) ** 2)))
+    assert rms(g) < 1.5 * rms(ref32) + 1e-8 * scale
+    # no bias / no ReLU
+    want2 = F.conv2d(torch.from_numpy(x).double(), torch.from_numpy(w).double(), None, stride, pad, dil).permute(0, 2, 3, 1).numpy()
+    g2 = hip.conv_split(xt, sw, None, stride, pad, dil, relu=False).cpu().numpy()
+    assert np.abs(g2 - want2).max() < 2e-6 * np.sqrt(Cin * k * k) * max(np.abs(want2).max(), 1.0)
+    assert (g2 < 0).any()
+
+
+def test_conv_split_cut_is_exact_and_products_are_fp32_grade(hip):
+    """With one non-zero input channel the convolution is a single product per output: a*b from the six partial products
+    must agree with the float64 product to 2^-22 relative (the three dropped terms are below 2^-23), for values whose low
+    mantissa bits are all set, for negative, tiny and huge ones."""
+    rs = np.random.RandomState(5)
+    Cin, Cout, H, W = 32, 64, 4, 8
+    vals = np.array([1.0 + 2.0 ** -23, 1.9999999, -3.1415927, 1e-20, -7e19, 0.33333334, 123456.79, -2.0 ** -100], np.float32)
+    x = np.zeros((1, Cin, H, W), np.float32)
+    x[0, 7] = np.resize(vals, H * W).reshape(H, W)
+    w = np.zeros((Cout, Cin, 1, 1), np.float32)
+    w[:, 7, 0, 0] = (rs.randn(Cout) * np.float32(1.7)).astype(np.float32) + np.float32(2.0 ** -12)
+    got = hip.conv_split(t(x).permute(0, 2, 3, 1).contiguous(), hip.SplitWeight(t(w)), None).cpu().numpy()      # (1,H,W,Cout)
+    want = x[0, 7].astype(np.float64)[:, :, None] * w[:, 7, 0, 0].astype(np.float64)[None, None, :]
+    rel = np.abs(got[0] - want) / np.abs(want)
+    assert rel.max() < 2.0 ** -22, rel.max()
+
+
+def test_conv_split_fused_tail_and_errors(hip):
+    """residual add in place + second output (next unit's bn1 + ReLU), as lsfa_conv_nhwc_fused_fwd; shape errors."""
+    import torch.nn.functional as F
+    rs = np.random.RandomState(9)
+    H, W, Cin, Cout = 38, 63, 256, 1024
+    x = rs.randn(1, Cin, H, W).astype(np.float32)
+    w = (rs.randn(Cout, Cin, 1, 1) / 16).astype(np.float32)
+    res = rs.randn(1, Cout, H, W).astype(np.float32)
+    sc2, sh2 = rs.uniform(0.5, 1.5, Cout).astype(np.float32), rs.randn(Cout).astype(np.float32)
+    y64 = F.conv2d(torch.from_numpy(x).double(), torch.from_numpy(w).double()) + torch.from_numpy(res).double()
+    want = y64.permute(0, 2, 3, 1).numpy()
+    buf = t(res).permute(0, 2, 3, 1).contiguous()
+    out2 = torch.empty_like(buf)
+    got, got2 = hip.conv_split(t(x).permute(0, 2, 3, 1).contiguous(), hip.SplitWeight(t(w)), None, out=buf, residual=buf, out2=out2,
+                               scale2=t(sc2), shift2=t(sh2))
+    assert got.data_ptr() == buf.data_ptr()
+    assert np.abs(got.cpu().numpy() - want).max() < 2e-6 * 16 * max(np.abs(want).max(), 1.0)
+    assert torch.equal(got2, torch.relu(got * t(sc2) + t(sh2)))
+    with pytest.raises(hip.LsfaError):
+        hip.SplitWeight(t(rs.randn(64, 48, 3, 3).astype(np.float32)))          # Cin % 32
+    with pytest.raises(hip.LsfaError):
+        hip.SplitWeight(t(rs.randn(96, 64, 3, 3).astype(np.float32)))          # Cout % 64
+    with pytest.raises(hip.LsfaError):
+        hip.conv_split(t(rs.randn(1, 8, 8, 32).astype(np.float32)), hip.SplitWeight(t(rs.randn(64, 64, 1, 1).astype(np.float32))))
 
 
 @pytest.mark.parametrize("cfg", [dict(H=38, W=63, Cin=256, Cout=1024, k=1), dict(H=75, W=125, Cin=128, Cout=512, k=1),

@@ -243,12 +243,14 @@ int lsfa_conv_nhwc_fused_fwd(const float* x, int N, int H, int W, int Cin, const
  * terms are below 2^-23 |a*b|, i.e. under one fp32 ulp of each product (lsfa_amd/csrc/conv_split_kernel.h).  Inputs,
  * outputs and accumulation are fp32; measured against a float64 convolution it is as close as the fp32-MFMA kernel.
  * The weights are cut and laid out once (bind time): lsfa_conv_split_weights writes lsfa_conv_split_weight_bytes(...)
- * bytes from w (Cout, kh, kw, Cin).  Cin % 32 == 0, Cout % 64 == 0.  Arguments otherwise as lsfa_conv_nhwc_fused_fwd. */
+ * bytes from w (Cout, kh, kw, Cin).  Cin % 32 == 0, Cout % 64 == 0.  y_nchw != 0: y, y2 and residual are (N, Cout, Ho, Wo)
+ * — the layout the reference's operators (and lsfa_warp_bilinear's `add` operand) take — instead of (N, Ho, Wo, Cout); x is
+ * always channels-last.  Arguments otherwise as lsfa_conv_nhwc_fused_fwd. */
 size_t lsfa_conv_split_weight_bytes(int Cout, int kh, int kw, int Cin);
 int lsfa_conv_split_weights(const float* w, int Cout, int kh, int kw, int Cin, void* wfrag, void* stream);
 size_t lsfa_conv_split_workspace_bytes(int N, int H, int W, int Cin, int Cout, int kh, int kw, int stride, int pad, int dil);
 int lsfa_conv_split_fwd(const float* x, int N, int H, int W, int Cin, const void* wfrag, const float* bias, int Cout,
-                        int kh, int kw, int stride, int pad, int dil, int relu, const float* residual, float* y,
+                        int kh, int kw, int stride, int pad, int dil, int relu, int y_nchw, const float* residual, float* y,
                         float* y2, const float* scale2, const float* shift2,
                         void* ws, size_t ws_bytes, void* stream);
 

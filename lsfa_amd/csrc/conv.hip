@@ -39,6 +39,7 @@ struct ConvArgs {
   // fused tail of a pre-activation unit's conv3 (resnet.py:93-101): y = conv + residual (in place allowed), and the
   // NEXT unit's bn1 + ReLU of that sum as a second output: y2 = max(y * scale2[c] + shift2[c], 0)
   const float* res; float* y2; const float* scale2; const float* shift2;
+  int y_nchw;      // conv_reduce_kernel only: y / y2 / res are NCHW (the partial slices are always NHWC)
 };
 
 __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, float v, size_t o, int ch, float bias, float sc2, float sh2) {
@@ -174,10 +175,26 @@ __global__ __launch_bounds__(kThreads) void conv_reduce_kernel(ConvArgs a, long 
 #pragma unroll
   for (int k = 0; k < 4; ++k) {
     float v = sv[k] + (a.bias ? a.bias[ch + k] : 0.f);
-    if (a.res) v = v + a.res[(size_t)i * 4 + k];
+    if (a.res) {
+      size_t ro = (size_t)i * 4 + k;
+      if (a.y_nchw) { const int hw = a.Ho * a.Wo; const long p = (i * 4) / a.Cout, pn = p / hw; ro = ((size_t)pn * a.Cout + ch + k) * hw + (p - pn * hw); }
+      v = v + a.res[ro];
+    }
     if (a.relu) v = fmaxf(v, 0.f);
     o1[k] = v;
     o2[k] = a.y2 ? fmaxf(v * a.scale2[ch + k] + a.shift2[ch + k], 0.f) : 0.f;
+  }
+  if (a.y_nchw) {
+    const long p = (i * 4) / a.Cout;
+    const int hw = a.Ho * a.Wo;
+    const long pn = p / hw, pr = p - pn * hw;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const size_t o = ((size_t)pn * a.Cout + ch + k) * hw + pr;
+      a.y[o] = o1[k];
+      if (a.y2) a.y2[o] = o2[k];
+    }
+    return;
   }
   reinterpret_cast<float4*>(a.y)[i] = make_float4(o1[0], o1[1], o1[2], o1[3]);
   if (a.y2) reinterpret_cast<float4*>(a.y2)[i] = make_float4(o2[0], o2[1], o2[2], o2[3]);
@@ -224,7 +241,7 @@ extern "C" int lsfa_conv_nhwc_fused_fwd(const float* x, int N, int H, int W, int
   }
   hipStream_t s = (hipStream_t)stream;
   ConvArgs a = {x, w, bias, y, slices > 1 ? (float*)ws : nullptr, N, H, W, Cin, Cout, kh, kw, stride, pad, dil, Ho, Wo, relu,
-                (taps + slices - 1) / slices, residual, y2, scale2, shift2};
+                (taps + slices - 1) / slices, residual, y2, scale2, shift2, 0};
   ProfScope prof(LSFA_OP_CONV, s);
   const dim3 grid((unsigned)((P + kBM - 1) / kBM), Cout / kBN, slices);
   if (Cin % 64 == 0) hipLaunchKernelGGL(conv_igemm_kernel<64>, grid, dim3(kThreads), 0, s, a);
@@ -247,13 +264,48 @@ extern "C" int lsfa_conv_nhwc_fwd(const float* x, int N, int H, int W, int Cin, 
 // ---- the same convolution on the bf16 matrix pipe with exactly split fp32 operands (conv_split_kernel.h) ----
 
 namespace {
-int split_slices(long waves, int chunk_total) {
-  // two waves per SIMD is the design point (two workgroups per CU, 2048 waves); cut K while that leaves slices of
-  // at least 8 chunks
-  int s = (int)(2048 / (waves > 0 ? waves : 1));
-  if (s < 1) s = 1;
-  while (s > 1 && chunk_total / s < 8) --s;
-  return s;
+// how a split convolution is launched: which kernel, the tile grid, how K is cut
+struct SplitPlan {
+  bool halo;            // the 3x3 halo kernel (stride 1, pad = dilation 1 or 2), else the general one
+  int dil;
+  int patches_x, patches_y;
+  int nx, ny, slices;   // tiles: nx pixel tiles x ny channel tiles x slices
+  int per_slice;        // chunks (general: of taps*Cin/32; halo: of Cin/32) per slice
+};
+
+SplitPlan split_plan(int N, int H, int W, int Cin, int Cout, int kh, int kw, int stride, int pad, int dil) {
+  SplitPlan p = {};
+  const int Ho = (H + 2 * pad - dil * (kh - 1) - 1) / stride + 1, Wo = (W + 2 * pad - dil * (kw - 1) - 1) / stride + 1;
+  p.ny = Cout / convsplit::kWgCh;
+  p.dil = dil;
+  p.halo = kh == 3 && kw == 3 && stride == 1 && pad == dil && (dil == 1 || dil == 2);
+  // two 4-wave workgroups per CU is the design point: 512 workgroups fill the chip
+  if (p.halo) {
+    p.patches_x = (W + convsplit::kPatchCols - 1) / convsplit::kPatchCols;
+    p.patches_y = (H + convsplit::kPatchRows - 1) / convsplit::kPatchRows;
+    p.nx = N * p.patches_x * p.patches_y;
+    const int cpt = Cin / 32;
+    int s = 512 / (p.nx * p.ny > 0 ? p.nx * p.ny : 1);
+    if (s < 1) s = 1;
+    if (s > cpt) s = cpt;
+    p.per_slice = (cpt + s - 1) / s;
+    p.slices = (cpt + p.per_slice - 1) / p.per_slice;
+    // measured (tools/lab/conv_split_lab.py): the halo form wins where its patches alone fill the chip (res2 conv2 30.7 vs
+    // 34.6 us, the 256 -> 1024 fuse convolution 91 vs 106); where K must be cut anyway the general kernel's finer cut
+    // (it slices taps x chunks) keeps more CUs busy (res4 conv2 32.7 vs 35.4, res3 conv2 31.4 vs 34.8)
+    if (p.slices > 1) p.halo = false;
+  }
+  if (!p.halo) {
+    const long P = (long)N * Ho * Wo;
+    p.nx = (int)((P + convsplit::kWgPix - 1) / convsplit::kWgPix);
+    const int chunk_total = kh * kw * (Cin / 32);
+    int s = 512 / (p.nx * p.ny > 0 ? p.nx * p.ny : 1);
+    if (s < 1) s = 1;
+    while (s > 1 && chunk_total / s < 8) --s;      // slices of at least 8 chunks
+    p.per_slice = (chunk_total + s - 1) / s;
+    p.slices = (chunk_total + p.per_slice - 1) / p.per_slice;
+  }
+  return p;
 }
 }  // namespace
 
@@ -276,16 +328,15 @@ extern "C" int lsfa_conv_split_weights(const float* w, int Cout, int kh, int kw,
 }
 
 extern "C" size_t lsfa_conv_split_workspace_bytes(int N, int H, int W, int Cin, int Cout, int kh, int kw, int stride, int pad, int dil) {
-  if (N <= 0 || H <= 0 || W <= 0 || Cout <= 0 || Cin <= 0 || stride <= 0) return 0;
+  if (N <= 0 || H <= 0 || W <= 0 || Cout <= 0 || Cin <= 0 || stride <= 0 || kh <= 0 || kw <= 0 || dil <= 0 || pad < 0) return 0;
   const int Ho = (H + 2 * pad - dil * (kh - 1) - 1) / stride + 1, Wo = (W + 2 * pad - dil * (kw - 1) - 1) / stride + 1;
-  const long P = (long)N * Ho * Wo;
-  const long waves = ((P + convsplit::kWgPix - 1) / convsplit::kWgPix) * 4 * (Cout / convsplit::kWgCh);
-  const int slices = split_slices(waves, kh * kw * (Cin / 32));
-  return slices > 1 ? align_up((size_t)slices * P * Cout * sizeof(float), 256) : 256;
+  if (Ho <= 0 || Wo <= 0) return 0;
+  const SplitPlan p = split_plan(N, H, W, Cin, Cout, kh, kw, stride, pad, dil);
+  return p.slices > 1 ? align_up((size_t)p.slices * N * Ho * Wo * Cout * sizeof(float), 256) : 256;
 }
 
 extern "C" int lsfa_conv_split_fwd(const float* x, int N, int H, int W, int Cin, const void* wfrag, const float* bias, int Cout,
-                                   int kh, int kw, int stride, int pad, int dil, int relu, const float* residual, float* y,
+                                   int kh, int kw, int stride, int pad, int dil, int relu, int y_nchw, const float* residual, float* y,
                                    float* y2, const float* scale2, const float* shift2, void* ws, size_t ws_bytes, void* stream) {
   LSFA_REQUIRE(x && wfrag && y, "lsfa_conv_split_fwd: NULL argument");
   LSFA_REQUIRE(N > 0 && H > 0 && W > 0 && kh > 0 && kw > 0 && stride > 0 && pad >= 0 && dil > 0, "lsfa_conv_split_fwd: bad shape");
@@ -299,25 +350,28 @@ extern "C" int lsfa_conv_split_fwd(const float* x, int N, int H, int W, int Cin,
   LSFA_REQUIRE(Ho > 0 && Wo > 0, "lsfa_conv_split_fwd: empty output");
   const long P = (long)N * Ho * Wo;
   LSFA_REQUIRE(P * Cout < (1L << 31) && ((long)N * H * W + (long)(pad + 1) * (W + 1)) * Cin < (1L << 31), "lsfa_conv_split_fwd: tensor too large");
-  const int chunk_total = kh * kw * (Cin / 32);
-  const long wg_x = (P + convsplit::kWgPix - 1) / convsplit::kWgPix;
-  const int slices = split_slices(wg_x * 4 * (Cout / convsplit::kWgCh), chunk_total);
+  const SplitPlan p = split_plan(N, H, W, Cin, Cout, kh, kw, stride, pad, dil);
   const size_t need = lsfa_conv_split_workspace_bytes(N, H, W, Cin, Cout, kh, kw, stride, pad, dil);
-  if (slices > 1 && (!ws || ws_bytes < need)) {
+  if (p.slices > 1 && (!ws || ws_bytes < need)) {
     set_error("lsfa_conv_split_fwd: workspace %zu < %zu bytes", ws_bytes, need);
     return LSFA_EWORKSPACE;
   }
   hipStream_t s = (hipStream_t)stream;
-  convsplit::Args a = {x, (const uint4*)wfrag, bias, y, slices > 1 ? (float*)ws : nullptr, N, H, W, Cin, Cout, kh, kw, stride, pad,
-                       dil, Ho, Wo, relu, (chunk_total + slices - 1) / slices, residual, y2, scale2, shift2};
+  convsplit::Args a = {x, (const uint4*)wfrag, bias, y, p.slices > 1 ? (float*)ws : nullptr, N, H, W, Cin, Cout, kh, kw, stride, pad,
+                       dil, Ho, Wo, relu, p.per_slice, residual, y2, scale2, shift2, y_nchw};
   ProfScope prof(LSFA_OP_CONV, s);
-  const int tiles = (int)wg_x * (Cout / convsplit::kWgCh) * slices;
-  hipLaunchKernelGGL(convsplit::conv_split_kernel, dim3((unsigned)(8 * ((tiles + 7) / 8))), dim3(convsplit::kThreads), 0, s, a, (int)wg_x,
-                     Cout / convsplit::kWgCh, slices);
-  if (slices > 1) {
-    ConvArgs r = {x, nullptr, bias, y, (float*)ws, N, H, W, Cin, Cout, kh, kw, stride, pad, dil, Ho, Wo, relu, 0, residual, y2, scale2, shift2};
+  const int tiles = p.nx * p.ny * p.slices;
+  const dim3 grid((unsigned)(8 * ((tiles + 7) / 8)));
+  if (p.halo && p.dil == 1)
+    hipLaunchKernelGGL(convsplit::conv_split3x3_kernel<1>, grid, dim3(convsplit::kThreads), 0, s, a, p.patches_x, p.patches_y, p.nx, p.ny, p.slices);
+  else if (p.halo)
+    hipLaunchKernelGGL(convsplit::conv_split3x3_kernel<2>, grid, dim3(convsplit::kThreads), 0, s, a, p.patches_x, p.patches_y, p.nx, p.ny, p.slices);
+  else
+    hipLaunchKernelGGL(convsplit::conv_split_kernel, grid, dim3(convsplit::kThreads), 0, s, a, p.nx, p.ny, p.slices);
+  if (p.slices > 1) {
+    ConvArgs r = {x, nullptr, bias, y, (float*)ws, N, H, W, Cin, Cout, kh, kw, stride, pad, dil, Ho, Wo, relu, 0, residual, y2, scale2, shift2, y_nchw};
     const long n4 = P * Cout / 4;
-    hipLaunchKernelGGL(conv_reduce_kernel, dim3((unsigned)((n4 + kThreads - 1) / kThreads)), dim3(kThreads), 0, s, r, n4, slices);
+    hipLaunchKernelGGL(conv_reduce_kernel, dim3((unsigned)((n4 + kThreads - 1) / kThreads)), dim3(kThreads), 0, s, r, n4, p.slices);
   }
   LSFA_LAUNCH_CHECK("lsfa_conv_split_fwd");
   return LSFA_OK;

@@ -50,6 +50,7 @@ struct Args {
   const float* x; const uint4* wfrag; const float* bias; float* y; float* part;
   int N, H, W, Cin, Cout, kh, kw, stride, pad, dil, Ho, Wo, relu, chunks_per_slice;
   const float* res; float* y2; const float* scale2; const float* shift2;
+  int y_nchw;      // y / y2 / res are (N, Cout, Ho, Wo) instead of (N, Ho, Wo, Cout); partial slices stay NHWC
 };
 
 // the leading 8 mantissa bits of v as an fp32 bit pattern (= a bf16 value), and what is left
@@ -117,14 +118,21 @@ struct Geom {       // per lane / per wave constants of the loop
 
 // the 7 LDS-DMA instructions of one chunk into stage ST (compile-time LDS offsets).  x / wblock (this workgroup's
 // 12 KB of chunk 0) are __restrict__ parameters on purpose (see the header comment).
+// which (tap row, tap column, channel chunk) a chunk index is, walked incrementally (an integer division per chunk
+// cost ~50 scalar instructions in the loop)
+struct Walk {
+  int ty, tx, kc, gch;
+  __device__ __forceinline__ void next(int kw, int chunks_per_tap) {
+    ++gch;
+    if (++kc == chunks_per_tap) { kc = 0; if (++tx == kw) { tx = 0; ++ty; } }
+  }
+};
+
 template <int ST>
 __device__ __forceinline__ void issue_chunk(uint4 (*S)[kStage], const float* __restrict__ x, const uint4* __restrict__ wblock,
-                                            const Geom& g, int c) {
-  const int gch = g.chunk0 + c;
-  const int tap = gch / g.chunks_per_tap;
-  const int kc = gch - tap * g.chunks_per_tap;
-  const int ty = tap / g.kw, tx = tap - ty * g.kw;
-  const int dy = ty * g.dil, dx = tx * g.dil;
+                                            const Geom& g, const Walk& wk) {
+  const int gch = wk.gch, kc = wk.kc;
+  const int dy = wk.ty * g.dil, dx = wk.tx * g.dil;
   const int doff = (dy * g.W + dx) * g.Cin + kc * kChunk;        // wave-uniform part of the source offset
   uint4* a_dst = &S[ST][g.wave * 256];                           // + i * 64 (+ lane, implied by the DMA)
 #pragma unroll
@@ -170,9 +178,9 @@ __device__ long long g_cs_stamps[8];
 // the L2's aggregate rate; 228-456 workgroups re-read A 4x and B 19x.  See DESIGN.md "Dense contractions".)
 template <int ST>
 __device__ __forceinline__ void pipeline_step(uint4 (*S)[kStage], const float* __restrict__ x, const uint4* __restrict__ wblock,
-                                              const Geom& g, int c, int n, f32x16& acc0, f32x16& acc1) {
+                                              const Geom& g, Walk& wk, int c, int n, f32x16& acc0, f32x16& acc1) {
   CS_STAMP(0);
-  if (c + 1 < n) issue_chunk<ST ^ 1>(S, x, wblock, g, c + 1);
+  if (c + 1 < n) { issue_chunk<ST ^ 1>(S, x, wblock, g, wk); wk.next(g.kw, g.chunks_per_tap); }
   CS_STAMP(1);
   consume_chunk<ST>(S, g, acc0, acc1);
   CS_STAMP(2);
@@ -249,12 +257,20 @@ static __global__ __launch_bounds__(kThreads, 2) void conv_split_kernel(Args a, 
 #pragma unroll
   for (int i = 0; i < 16; ++i) { acc0[i] = 0.f; acc1[i] = 0.f; }
 
-  if (nchunks > 0) issue_chunk<0>(S, a.x, wblock, g, 0);
+  Walk wk;       // the next chunk to fetch
+  wk.gch = g.chunk0;
+  {
+    const int tap = g.chunk0 / g.chunks_per_tap;
+    wk.kc = g.chunk0 - tap * g.chunks_per_tap;
+    wk.ty = tap / a.kw;
+    wk.tx = tap - wk.ty * a.kw;
+  }
+  if (nchunks > 0) { issue_chunk<0>(S, a.x, wblock, g, wk); wk.next(g.kw, g.chunks_per_tap); }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
   for (int c = 0; c < nchunks; c += 2) {
-    pipeline_step<0>(S, a.x, wblock, g, c, nchunks, acc0, acc1);
-    if (c + 1 < nchunks) pipeline_step<1>(S, a.x, wblock, g, c + 1, nchunks, acc0, acc1);
+    pipeline_step<0>(S, a.x, wblock, g, wk, c, nchunks, acc0, acc1);
+    if (c + 1 < nchunks) pipeline_step<1>(S, a.x, wblock, g, wk, c + 1, nchunks, acc0, acc1);
   }
 
   // C/D layout of 32x32: column = lane & 31 (channel), row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5) (pixel)
@@ -270,9 +286,10 @@ static __global__ __launch_bounds__(kThreads, 2) void conv_split_kernel(Args a, 
       const int row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
       const int p = m0 + row;
       if (p < P) {
-        const size_t o = (size_t)p * a.Cout + ch;
+        size_t o = (size_t)p * a.Cout + ch;
         float v = t == 0 ? acc0[r] : acc1[r];
         if (part) { part[o] = v; continue; }
+        if (a.y_nchw) { const int hw = a.Ho * a.Wo, pn = p / hw; o = ((size_t)pn * a.Cout + ch) * hw + (p - pn * hw); }
         v = v + bias;
         if (a.res) v = v + a.res[o];
         if (a.relu) v = fmaxf(v, 0.f);
@@ -281,6 +298,193 @@ static __global__ __launch_bounds__(kThreads, 2) void conv_split_kernel(Args a, 
       }
     }
   }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// 3x3, stride 1, pad = dilation: the halo form.  The kernel above is bound by what it pulls through the L2 (each of the
+// nine taps re-fetches the activations: 28 KB per workgroup and 24 MFMAs/wave).  Here a workgroup owns a 4-row x
+// 32-column patch of the output (wave w = row w) and, per 32-channel chunk, stages the patch's (4+2d) x (32+2d) input
+// halo ONCE (26 KB at d = 1): the nine taps read their A fragments from it at shifted positions.  Per tap only the 12 KB
+// of weights move: 12 + 26/9 = 15 KB per 24 MFMAs/wave, half of the above, and the DMA count per wave and step drops
+// from 7 to 3-4.  Stages: A halo double-buffered per channel chunk, B double-buffered per tap, all in one array with
+// compile-time offsets (the tap loop is unrolled inside a function templated on the A parity; nine taps per chunk is
+// odd, so the B parity of (chunk, tap) is (chunk + tap) & 1).
+constexpr int kPatchRows = 4, kPatchCols = 32;
+
+template <int DIL> struct Halo {
+  static constexpr int kW = kPatchCols + 2 * DIL, kH = kPatchRows + 2 * DIL;
+  static constexpr int kPix = kW * kH;
+  static constexpr int kPieces = kPix * 8;                            // 16-byte pieces of one stage
+  static constexpr int kDma = (kPieces + kThreads - 1) / kThreads;   // DMA instructions per thread and chunk
+  static constexpr int kStageUint4 = kPieces + kStageB;              // A halo + B, per parity
+};
+
+template <int DIL>
+struct HaloGeom {
+  size_t wstride;
+  int chunks_per_tap;
+  int off0[Halo<DIL>::kDma];      // float offset of this thread's piece of DMA i at channel chunk 0 (meaningless when !ok)
+  unsigned ok_mask;               // bit i: DMA i's source pixel is inside the image
+  unsigned live_mask;             // bit i: DMA i's piece exists (the last instruction is partial)
+  int hp0;                        // halo pixel of this lane's fragment row at tap (0, 0): w * kW + (lane & 31)
+  int h4;                         // 4 * (lane >> 5)
+  int wave, lane, tid;
+};
+
+// B of step (kc, tap) -> parity PB; one third of the A halo of chunk kc_next (DMA instructions i0 .. i1-1) -> parity PA
+template <int DIL, int PA, int PB, int I0, int I1>
+__device__ __forceinline__ void halo_issue(uint4 (*S)[Halo<DIL>::kStageUint4], const float* __restrict__ x, const uint4* __restrict__ wblock,
+                                           const HaloGeom<DIL>& g, int gch, bool with_b, int kc_next, bool with_a) {
+  if (with_b) {
+    const uint4* wsrc = wblock + (size_t)gch * g.wstride + g.wave * 192 + g.lane;
+    uint4* b_dst = &S[PB][Halo<DIL>::kPieces + g.wave * 192];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) __builtin_amdgcn_global_load_lds(wsrc + i * 64, b_dst + i * 64, 16, 0, 0);
+  }
+  if (with_a) {
+#pragma unroll
+    for (int i = I0; i < I1; ++i) {
+      if (i < Halo<DIL>::kDma && ((g.live_mask >> i) & 1u)) {
+        const float* src = ((g.ok_mask >> i) & 1u) ? x + (g.off0[i] + kc_next * kChunk) : g_zero_block;
+        __builtin_amdgcn_global_load_lds(reinterpret_cast<const uint4*>(src), &S[PA][i * kThreads + g.wave * 64], 16, 0, 0);
+      }
+    }
+  }
+}
+
+template <int DIL, int PA, int PB, int TAP>
+__device__ __forceinline__ void halo_consume(uint4 (*S)[Halo<DIL>::kStageUint4], const HaloGeom<DIL>& g, f32x16& acc0, f32x16& acc1) {
+  constexpr int ty = TAP / 3, tx = TAP % 3;
+  const int hp = g.hp0 + (ty * DIL) * Halo<DIL>::kW + tx * DIL;
+  const int xs = g.h4 ^ ((hp >> 1) & 7);                  // slot of piece 4h + j is (4h + j) ^ sw = xs ^ j
+  const uint4* A = &S[PA][hp * 8];
+  const uint4* B = &S[PB][Halo<DIL>::kPieces + g.lane];
+  const uint4 r0 = A[xs], r1 = A[xs ^ 1], r2 = A[xs ^ 2], r3 = A[xs ^ 3];
+  const float4 c0 = make_float4(__uint_as_float(r0.x), __uint_as_float(r0.y), __uint_as_float(r0.z), __uint_as_float(r0.w));
+  const float4 c1 = make_float4(__uint_as_float(r1.x), __uint_as_float(r1.y), __uint_as_float(r1.z), __uint_as_float(r1.w));
+  const float4 c2 = make_float4(__uint_as_float(r2.x), __uint_as_float(r2.y), __uint_as_float(r2.z), __uint_as_float(r2.w));
+  const float4 c3 = make_float4(__uint_as_float(r3.x), __uint_as_float(r3.y), __uint_as_float(r3.z), __uint_as_float(r3.w));
+  const Pieces s0 = split8(c0, c1), s1 = split8(c2, c3);
+  acc0 = mma6(s0, B[(0 * 3 + 0) * 64], B[(0 * 3 + 1) * 64], B[(0 * 3 + 2) * 64], acc0);
+  acc1 = mma6(s0, B[(2 * 3 + 0) * 64], B[(2 * 3 + 1) * 64], B[(2 * 3 + 2) * 64], acc1);
+  acc0 = mma6(s1, B[(1 * 3 + 0) * 64], B[(1 * 3 + 1) * 64], B[(1 * 3 + 2) * 64], acc0);
+  acc1 = mma6(s1, B[(3 * 3 + 0) * 64], B[(3 * 3 + 1) * 64], B[(3 * 3 + 2) * 64], acc1);
+}
+
+// one step = one tap of channel chunk kc (A parity PA): start the copies the NEXT step needs (its B; during taps 0-2 a
+// third each of the next chunk's halo), compute this tap, retire the copies, meet the other waves
+template <int DIL, int PA, int TAP>
+__device__ __forceinline__ void halo_step(uint4 (*S)[Halo<DIL>::kStageUint4], const float* __restrict__ x, const uint4* __restrict__ wblock,
+                                          const HaloGeom<DIL>& g, int kc, int kc_end, f32x16& acc0, f32x16& acc1) {
+  constexpr int PB = (PA + TAP) & 1;
+  constexpr int K3 = (Halo<DIL>::kDma + 2) / 3;
+  const bool last_tap = TAP == 8;
+  const bool more = !last_tap || kc + 1 < kc_end;                              // is there a next step at all
+  const int next_g = last_tap ? (kc + 1) : ((TAP + 1) * g.chunks_per_tap + kc);  // its (tap, chunk) index in the weight array
+  constexpr int I0 = TAP < 3 ? TAP * K3 : 0, I1 = TAP < 3 ? (TAP + 1) * K3 : 0;
+  constexpr int PA_NEXT = PA ^ 1, PB_NEXT = PB ^ 1;
+  halo_issue<DIL, PA_NEXT, PB_NEXT, I0, I1>(S, x, wblock, g, next_g, more, kc + 1, TAP < 3 && kc + 1 < kc_end);
+  halo_consume<DIL, PA, PB, TAP>(S, g, acc0, acc1);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+}
+
+template <int DIL, int PA>
+__device__ __forceinline__ void halo_chunk(uint4 (*S)[Halo<DIL>::kStageUint4], const float* __restrict__ x, const uint4* __restrict__ wblock,
+                                           const HaloGeom<DIL>& g, int kc, int kc_end, f32x16& acc0, f32x16& acc1) {
+  halo_step<DIL, PA, 0>(S, x, wblock, g, kc, kc_end, acc0, acc1);
+  halo_step<DIL, PA, 1>(S, x, wblock, g, kc, kc_end, acc0, acc1);
+  halo_step<DIL, PA, 2>(S, x, wblock, g, kc, kc_end, acc0, acc1);
+  halo_step<DIL, PA, 3>(S, x, wblock, g, kc, kc_end, acc0, acc1);
+  halo_step<DIL, PA, 4>(S, x, wblock, g, kc, kc_end, acc0, acc1);
+  halo_step<DIL, PA, 5>(S, x, wblock, g, kc, kc_end, acc0, acc1);
+  halo_step<DIL, PA, 6>(S, x, wblock, g, kc, kc_end, acc0, acc1);
+  halo_step<DIL, PA, 7>(S, x, wblock, g, kc, kc_end, acc0, acc1);
+  halo_step<DIL, PA, 8>(S, x, wblock, g, kc, kc_end, acc0, acc1);
+}
+
+// grid (8 * ceil(tiles / 8)); block 256.  tiles = N * ceil(H/4) * ceil(W/32) patches x (Cout / 64) x slices (of channel chunks);
+// a.chunks_per_slice counts CHANNEL chunks here.  Output size = input size (stride 1, pad = DIL).
+template <int DIL>
+static __global__ __launch_bounds__(kThreads, (DIL == 1 ? 2 : 1)) void conv_split3x3_kernel(Args a, int patches_x, int patches_y, int nx, int ny, int nz) {
+#if __HIP_DEVICE_COMPILE__      // hipcc's HOST pass fails to instantiate the unrolled tap chain (spurious "substitution failure"); it needs only the stub
+  typedef Halo<DIL> HL;
+  __shared__ __attribute__((aligned(16))) uint4 S[2][HL::kStageUint4];
+  const Tile tile = xcd_tile(blockIdx.x, nx, ny, nz);
+  if (tile.x < 0) return;
+  HaloGeom<DIL> g;
+  g.tid = threadIdx.x;
+  g.lane = g.tid & 63;
+  g.wave = __builtin_amdgcn_readfirstlane(g.tid >> 6);
+  g.chunks_per_tap = a.Cin / kChunk;
+  const int col_tiles = a.Cout / 32;
+  g.wstride = (size_t)col_tiles * (kChunkBytesB / 32);
+  const uint4* wblock = a.wfrag + (size_t)(2 * tile.y) * (kChunkBytesB / 32);
+  const int kc0 = tile.z * a.chunks_per_slice, kc_end = min(kc0 + a.chunks_per_slice, g.chunks_per_tap);
+  // patch -> image, top-left output pixel
+  const int pimg = tile.x / (patches_x * patches_y), prem = tile.x - pimg * (patches_x * patches_y);
+  const int y0 = (prem / patches_x) * kPatchRows, x0 = (prem % patches_x) * kPatchCols;
+  // DMA role: piece e = i * 256 + tid of the halo: halo pixel e >> 3, slot e & 7 holds source piece (e & 7) ^ ((pixel >> 1) & 7)
+  g.ok_mask = 0; g.live_mask = 0;
+#pragma unroll
+  for (int i = 0; i < HL::kDma; ++i) {
+    const int e = i * kThreads + g.tid;
+    g.off0[i] = 0;
+    if (e < HL::kPieces) {
+      g.live_mask |= 1u << i;
+      const int hpix = e >> 3, piece = (e & 7) ^ ((hpix >> 1) & 7);
+      const int iy = y0 - DIL + hpix / HL::kW, ix = x0 - DIL + hpix % HL::kW;
+      if (iy >= 0 && iy < a.H && ix >= 0 && ix < a.W) {
+        g.ok_mask |= 1u << i;
+        g.off0[i] = ((pimg * a.H + iy) * a.W + ix) * a.Cin + 4 * piece;
+      }
+    }
+  }
+  g.hp0 = g.wave * HL::kW + (g.lane & 31);
+  g.h4 = 4 * (g.lane >> 5);
+
+  f32x16 acc0, acc1;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) { acc0[i] = 0.f; acc1[i] = 0.f; }
+
+  if (kc0 < kc_end) {
+    // prologue: the whole halo of chunk kc0 and the weights of (kc0, tap 0); parities as if kc0 were even
+    halo_issue<DIL, 0, 0, 0, HL::kDma>(S, a.x, wblock, g, kc0, true, kc0, true);
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  for (int kc = kc0; kc < kc_end; kc += 2) {
+    halo_chunk<DIL, 0>(S, a.x, wblock, g, kc, kc_end, acc0, acc1);
+    if (kc + 1 < kc_end) halo_chunk<DIL, 1>(S, a.x, wblock, g, kc + 1, kc_end, acc0, acc1);
+  }
+
+  // C/D layout: column = lane & 31 (channel), row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5) = column of the patch row
+  const int P = a.N * a.H * a.W;
+  float* part = a.part ? a.part + (size_t)tile.z * P * a.Cout : nullptr;
+  const int oy = y0 + g.wave;
+#pragma unroll
+  for (int t = 0; t < 2; ++t) {
+    const int ch = tile.y * kWgCh + t * 32 + (g.lane & 31);
+    const float bias = (!part && a.bias) ? a.bias[ch] : 0.f;
+    const float sc2 = (!part && a.y2) ? a.scale2[ch] : 0.f, sh2 = (!part && a.y2) ? a.shift2[ch] : 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int ox = x0 + (r & 3) + 8 * (r >> 2) + 4 * (g.lane >> 5);
+      if (oy < a.H && ox < a.W) {
+        size_t o = ((size_t)(pimg * a.H + oy) * a.W + ox) * a.Cout + ch;
+        float v = t == 0 ? acc0[r] : acc1[r];
+        if (part) { part[o] = v; continue; }
+        if (a.y_nchw) o = (((size_t)pimg * a.Cout + ch) * a.H + oy) * a.W + ox;
+        v = v + bias;
+        if (a.res) v = v + a.res[o];
+        if (a.relu) v = fmaxf(v, 0.f);
+        a.y[o] = v;
+        if (a.y2) a.y2[o] = fmaxf(v * sc2 + sh2, 0.f);
+      }
+    }
+  }
+#endif
 }
 
 // weights (Cout, taps, Cin) fp32 -> fragment order, three bf16 pieces.  One thread per (fragment, lane): 8 values.

@@ -424,9 +424,10 @@ class SplitWeight(object):
 
 @_on_tensor_device
 def conv_split(x, sw, bias=None, stride=1, pad=0, dil=1, relu=False, out=None, residual=None, out2=None, scale2=None,
-               shift2=None):
+               shift2=None, nchw=False):
     """conv_nhwc on the bf16 matrix pipe with exactly split fp32 operands (lsfa_conv_split_fwd); sw: SplitWeight.
-    x (N, H, W, Cin) contiguous fp32 -> (N, Ho, Wo, Cout); the other arguments as conv_nhwc."""
+    x (N, H, W, Cin) contiguous fp32 -> (N, Ho, Wo, Cout), or (N, Cout, Ho, Wo) with nchw=True (then residual / out2 are
+    NCHW too); the other arguments as conv_nhwc."""
     x = _f32c(x, "x")
     N, H, W, Cin = x.shape
     if Cin != sw.cin:
@@ -434,7 +435,7 @@ def conv_split(x, sw, bias=None, stride=1, pad=0, dil=1, relu=False, out=None, r
     Cout, kh, kw = sw.cout, sw.kh, sw.kw
     Ho, Wo = (H + 2 * pad - dil * (kh - 1) - 1) // stride + 1, (W + 2 * pad - dil * (kw - 1) - 1) // stride + 1
     if out is None:
-        out = torch.empty((N, Ho, Wo, Cout), device=x.device, dtype=torch.float32)
+        out = torch.empty((N, Cout, Ho, Wo) if nchw else (N, Ho, Wo, Cout), device=x.device, dtype=torch.float32)
     for name, t in (("out", out), ("residual", residual), ("out2", out2)):
         if t is not None and (t.numel() != N * Ho * Wo * Cout or not t.is_contiguous() or t.dtype != torch.float32):
             raise LsfaError("conv_split: %s must be a contiguous float32 tensor of %d elements" % (name, N * Ho * Wo * Cout))
@@ -442,8 +443,8 @@ def conv_split(x, sw, bias=None, stride=1, pad=0, dil=1, relu=False, out=None, r
                                                  _ci(pad), _ci(dil))
     ws = torch.empty(need, dtype=torch.uint8, device=x.device)
     _check(lib().lsfa_conv_split_fwd(_ptr(x), _ci(N), _ci(H), _ci(W), _ci(Cin), _ptr(sw.frag), _ptr(bias), _ci(Cout), _ci(kh),
-                                     _ci(kw), _ci(stride), _ci(pad), _ci(dil), _ci(int(relu)), _ptr(residual), _ptr(out),
-                                     _ptr(out2), _ptr(scale2), _ptr(shift2), _ptr(ws), ctypes.c_size_t(need), _stream()),
+                                     _ci(kw), _ci(stride), _ci(pad), _ci(dil), _ci(int(relu)), _ci(int(nchw)), _ptr(residual),
+                                     _ptr(out), _ptr(out2), _ptr(scale2), _ptr(shift2), _ptr(ws), ctypes.c_size_t(need), _stream()),
            "lsfa_conv_split_fwd")
     return out if out2 is None else (out, out2)
 

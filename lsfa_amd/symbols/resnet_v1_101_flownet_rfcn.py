@@ -38,14 +38,15 @@ _CL_DEFAULT = 'backbone,small'
 _FLOW_GEMM_MAX_L = int(_os.environ.get('LSFA_FLOW_GEMM_L', '700'))   # FlowNet convs with at most this many output pixels run as im2col + GEMM
 _CONV1X1_MIOPEN = _os.environ.get('LSFA_CONV1X1_MIOPEN', '0') == '1'   # experiment: channel-reducing 1x1 convs through MIOpen
 # which 3x3 convolutions of the channels-last sub-networks run on the own fp32-MFMA implicit GEMM (lsfa_conv_nhwc_fwd,
-# bias + ReLU in its epilogue) instead of the library's kernel + a separate bias/ReLU pass: comma list of backbone, small;
+# bias + ReLU in its epilogue) instead of the library's kernel + a separate bias/ReLU pass: comma list of backbone, small,
+# fuse (the small net's 256 -> 1024 fuse_reduce_add convolution, on the split-bf16 kernel);
 # `conv3` additionally runs the 1x1 conv3 of those units on it with the shortcut add and the next unit's bn1 + ReLU fused
 # (lsfa_conv_nhwc_fused_fwd) - measured SLOWER (backbone 4239 -> 4983 us: the 64x64-tile kernel loses to the tuned library GEMM on
 # K = 256 by more than the saved BN pass), so it is off by default.
 # measured at 1000x600 (tools/key_sections.py, hipGraph replay): backbone 4327 -> 4239 us with it, small net 256 -> 289 us:
 # the backbone's stage 2/3 units gain (epilogue fusion + deterministic tap split), the small net's 64-channel stage 1 and the
 # 256 -> 1024 fuse convolution do not
-_OWN_CONV = set(x for x in _os.environ.get('LSFA_OWN_CONV', 'backbone').split(',') if x)
+_OWN_CONV = set(x for x in _os.environ.get('LSFA_OWN_CONV', 'backbone,fuse').split(',') if x)
 # the own 3x3 convolutions on the bf16 matrix pipe with exactly split fp32 operands (lsfa_conv_split_fwd: fp32 in, fp32
 # accumulate, error against float64 equal to the fp32-MFMA kernel's) instead of the fp32 matrix instructions.  Measured per
 # conv2 at 1000x600 (tools/lab/conv_split_lab.py): res4 32.7 vs 40.7 us, res3 31.4 vs 50.4, res2 34.6 vs 51.3.
@@ -727,6 +728,11 @@ class Executor(object):
                     self.fuse_w_cl = self.fuse_w.contiguous(memory_format=torch.channels_last)
                 own = 'small' in _OWN_CONV
                 s = self._resnet_cl(img, self.small, 1, False, own_conv=own)
+                if _CONV_SPLIT and self.fuse_w.dtype == torch.float32 and 'fuse' in _OWN_CONV:
+                    if not hasattr(self, 'fuse_w_split'):
+                        self.fuse_w_split = hip.SplitWeight(self.fuse_w)
+                    # written in NCHW by the epilogue: the warp kernel's `add` operand, no transposing copy
+                    return hip.conv_split(s.permute(0, 2, 3, 1), self.fuse_w_split, self.fuse_b, 1, 1, 1, relu=False, nchw=True)
                 if own:
                     if not hasattr(self, 'fuse_w_kc'):
                         self.fuse_w_kc = hip.conv_weight_kc(self.fuse_w)

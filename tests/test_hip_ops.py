@@ -782,6 +782,28 @@ def test_conv_split_cut_is_exact_and_products_are_fp32_grade(hip):
     assert rel.max() < 2.0 ** -22, rel.max()
 
 
+@pytest.mark.parametrize("cfg", [dict(N=1, H=38, W=63, Cin=256, Cout=1024, k=3), dict(N=2, H=9, W=35, Cin=64, Cout=64, k=3),
+                                 dict(N=1, H=38, W=63, Cin=256, Cout=256, k=3), dict(N=1, H=20, W=17, Cin=96, Cout=128, k=1)])
+def test_conv_split_nchw_output_equals_nhwc_output(hip, cfg):
+    """y_nchw: the same numbers in the reference operators' layout (the small net's fuse convolution feeds
+    lsfa_warp_bilinear's `add` operand without a transposing copy), incl. residual and second output, for the halo
+    kernel, the general kernel and the sliced path."""
+    rs = np.random.RandomState(cfg["Cout"] + cfg["H"])
+    N, H, W, Cin, Cout, k = (cfg[x] for x in ("N", "H", "W", "Cin", "Cout", "k"))
+    x = t(rs.randn(N, H, W, Cin).astype(np.float32))
+    sw = hip.SplitWeight(t((rs.randn(Cout, Cin, k, k) / np.sqrt(Cin * k * k)).astype(np.float32)))
+    b = t(rs.randn(Cout).astype(np.float32))
+    res = t(rs.randn(N, H, W, Cout).astype(np.float32))
+    sc2, sh2 = t(rs.uniform(0.5, 1.5, Cout).astype(np.float32)), t(rs.randn(Cout).astype(np.float32))
+    y, y2 = hip.conv_split(x, sw, b, 1, k // 2, 1, relu=False, residual=res, out2=torch.empty_like(res), scale2=sc2, shift2=sh2)
+    res_n = res.permute(0, 3, 1, 2).contiguous()
+    z, z2 = hip.conv_split(x, sw, b, 1, k // 2, 1, relu=False, residual=res_n, out2=torch.empty_like(res_n), scale2=sc2, shift2=sh2,
+                           nchw=True)
+    assert z.shape == (N, Cout, H, W)
+    assert torch.equal(z, y.permute(0, 3, 1, 2))
+    assert torch.equal(z2, y2.permute(0, 3, 1, 2))
+
+
 def test_conv_split_fused_tail_and_errors(hip):
     """residual add in place + second output (next unit's bn1 + ReLU), as lsfa_conv_nhwc_fused_fwd; shape errors."""
     import torch.nn.functional as F

@@ -299,10 +299,24 @@ SplitPlan split_plan(int N, int H, int W, int Cin, int Cout, int kh, int kw, int
     const long P = (long)N * Ho * Wo;
     p.nx = (int)((P + convsplit::kWgPix - 1) / convsplit::kWgPix);
     const int chunk_total = kh * kw * (Cin / 32);
-    int s = 512 / (p.nx * p.ny > 0 ? p.nx * p.ny : 1);
-    if (s < 1) s = 1;
-    while (s > 1 && chunk_total / s < 8) --s;      // slices of at least 8 chunks
-    p.per_slice = (chunk_total + s - 1) / s;
+    // How many slices of K.  Two workgroups per CU run almost as fast as one each (measured: ~1.2 us per chunk either
+    // way), so time ~ rounds of 512 workgroups x chunks per slice, plus the reduce pass over `slices` partial outputs
+    // (~3 TB/s effective).  A 304-workgroup grid run as one round leaves 40 % of the slots empty for its whole length;
+    // cut 5 ways it is 3 full rounds of a fifth each (feat_conv_3x3: 700 -> ~450 us).
+    const long wgs = (long)p.nx * p.ny;
+    const double out_mb = (double)P * Cout * 4.0 / 1e6;
+    double best = 0;
+    int best_s = 1;
+    for (int s = 1; s <= 16; ++s) {
+      if (s > 1 && chunk_total / s < 8) break;
+      const int per = (chunk_total + s - 1) / s;
+      const int used = (chunk_total + per - 1) / per;
+      if (used != s) continue;
+      const long rounds = (wgs * s + 511) / 512;
+      const double t = (double)rounds * per * 1.2 + (s > 1 ? 3.0 + s * out_mb * 2.0 / 3.0 : 0.0);
+      if (s == 1 || t < best * 0.97) { best = t; best_s = s; }      // a more finely cut K must pay for itself
+    }
+    p.per_slice = (chunk_total + best_s - 1) / best_s;
     p.slices = (chunk_total + p.per_slice - 1) / p.per_slice;
   }
   return p;

@@ -39,14 +39,14 @@ _FLOW_GEMM_MAX_L = int(_os.environ.get('LSFA_FLOW_GEMM_L', '700'))   # FlowNet c
 _CONV1X1_MIOPEN = _os.environ.get('LSFA_CONV1X1_MIOPEN', '0') == '1'   # experiment: channel-reducing 1x1 convs through MIOpen
 # which 3x3 convolutions of the channels-last sub-networks run on the own fp32-MFMA implicit GEMM (lsfa_conv_nhwc_fwd,
 # bias + ReLU in its epilogue) instead of the library's kernel + a separate bias/ReLU pass: comma list of backbone, small,
-# fuse (the small net's 256 -> 1024 fuse_reduce_add convolution, on the split-bf16 kernel);
+# fuse (the small net's 256 -> 1024 fuse_reduce_add convolution) and feat (feat_conv_3x3), both on the split-bf16 kernel;
 # `conv3` additionally runs the 1x1 conv3 of those units on it with the shortcut add and the next unit's bn1 + ReLU fused
 # (lsfa_conv_nhwc_fused_fwd) - measured SLOWER (backbone 4239 -> 4983 us: the 64x64-tile kernel loses to the tuned library GEMM on
 # K = 256 by more than the saved BN pass), so it is off by default.
 # measured at 1000x600 (tools/key_sections.py, hipGraph replay): backbone 4327 -> 4239 us with it, small net 256 -> 289 us:
 # the backbone's stage 2/3 units gain (epilogue fusion + deterministic tap split), the small net's 64-channel stage 1 and the
 # 256 -> 1024 fuse convolution do not
-_OWN_CONV = set(x for x in _os.environ.get('LSFA_OWN_CONV', 'backbone,fuse').split(',') if x)
+_OWN_CONV = set(x for x in _os.environ.get('LSFA_OWN_CONV', 'backbone,fuse,feat').split(',') if x)
 # the own 3x3 convolutions on the bf16 matrix pipe with exactly split fp32 operands (lsfa_conv_split_fwd: fp32 in, fp32
 # accumulate, error against float64 equal to the fp32-MFMA kernel's) instead of the fp32 matrix instructions.  Measured per
 # conv2 at 1000x600 (tools/lab/conv_split_lab.py): res4 32.7 vs 40.7 us, res3 31.4 vs 50.4, res2 34.6 vs 51.3.
@@ -516,6 +516,12 @@ class Executor(object):
             if not hasattr(self, 'feat_w_cl'):
                 self.feat_w_cl = self.feat_w.contiguous(memory_format=torch.channels_last)
             x4 = self._resnet_cl(data, self.net, 4, True, own_conv='backbone' in _OWN_CONV)
+            if _CONV_SPLIT and 'feat' in _OWN_CONV and self.feat_w.dtype == torch.float32:
+                # feat_conv_3x3 (2048 -> 1024, dilation 6: the largest single convolution of a key frame) on the split-bf16
+                # kernel: bias + ReLU in the epilogue, written in NCHW (what the warp / aggregation kernels and the API take)
+                if not hasattr(self, 'feat_w_split'):
+                    self.feat_w_split = hip.SplitWeight(self.feat_w)
+                return hip.conv_split(x4.permute(0, 2, 3, 1), self.feat_w_split, self.feat_b, 1, 6, 6, relu=True, nchw=True)
             y = F.conv2d(x4, self.feat_w_cl, None, padding=6, dilation=6)
             r = self._rows(y)
             hip.scale_shift_relu_cl(r, self._ones(r.shape[1]), self.feat_b, relu=True, out=r)

@@ -723,6 +723,9 @@ SPLIT_CFGS = [
     dict(N=2, H=13, W=9, Cin=64, Cout=64, k=3, stride=1, dil=1),         # batch 2, ragged pixel tile, one chunk per tap
     dict(N=1, H=20, W=17, Cin=96, Cout=128, k=1, stride=1, dil=1),       # 1x1, odd chunk count
     dict(N=1, H=38, W=63, Cin=256, Cout=1024, k=1, stride=1, dil=1),     # res4 conv3 shape
+    dict(N=1, H=38, W=63, Cin=256, Cout=1024, k=3, stride=1, dil=1),     # the fuse convolution (halo kernel, no K cut)
+    dict(N=1, H=21, W=40, Cin=256, Cout=64, k=3, stride=1, dil=6),       # feat_conv_3x3's dilation (general kernel)
+    dict(N=1, H=38, W=63, Cin=512, Cout=1024, k=3, stride=1, dil=6),     # 304 workgroups: K cut into 5 by the rounds model
 ]
 
 

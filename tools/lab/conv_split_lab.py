@@ -25,6 +25,12 @@ SHAPES = [  # name, H, W, Cin, Cout, k, dil
     ("res2 conv2 3x3 64->64 @150x250", 150, 250, 64, 64, 3, 1),
     ("res2 conv3 1x1 64->256 @150x250", 150, 250, 64, 256, 1, 1),
     ("fuse 3x3 256->1024 @38x63", 38, 63, 256, 1024, 3, 1),
+    ("res5 conv1 1x1 1024->512 @38x63", 38, 63, 1024, 512, 1, 1),
+    ("res5 conv1 1x1 2048->512 @38x63", 38, 63, 2048, 512, 1, 1),
+    ("res5 conv3 1x1 512->2048 @38x63", 38, 63, 512, 2048, 1, 1),
+    ("res5 dcn gemm 1x1 4608->512 @38x63", 38, 63, 4608, 512, 1, 1),
+    ("feat 3x3 d6 2048->1024 @38x63", 38, 63, 2048, 1024, 3, 6),
+    ("nq conv 1x1 2048->256? @38x63", 38, 63, 2048, 256, 1, 1),
 ]
 
 
@@ -108,6 +114,9 @@ def main():
         t_split = timeit(lambda: hip.conv_split(x_cl, sw, b, 1, pad, dil, out=out), args.iters)
         t_mfma = timeit(lambda: hip.conv_nhwc(x_cl, wk, b, k, k, 1, pad, dil, out=out), args.iters)
         t_lib = timeit(lambda: F.conv2d(xl, wl, b, 1, pad, dil), args.iters)
+        if k == 1:      # what the executor runs for 1x1 convolutions: rows x (Cin, Cout) through hipBLASLt
+            rows, wt = x_cl.view(-1, Cin), w.view(Cout, Cin).t().contiguous()
+            t_lib = min(t_lib, timeit(lambda: torch.addmm(b, rows, wt), args.iters))
         fl = 2.0 * H * W * Cin * Cout * k * k
         print("%-36s max err/max|y|: split %.2e (rms %.2e)  fp32-mfma %.2e (rms %.2e)  library %.2e | us: split %6.1f  fp32-mfma %6.1f  "
               "library %6.1f | split %.0f TFLOP/s" % (name, e_split, rms(y_split), e_mfma, rms(y_mfma), e_lib, t_split, t_mfma, t_lib,

@@ -38,6 +38,7 @@ import torch
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
+MFMA_SPLIT_PEAK_TFLOPS = round(2500.0 / 6, 1)           # dense bf16 MFMA peak / the six partial products of an fp32 product
 HBM_PEAK_GBS = 8000.0                                   # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 TRAFFIC_FILE = os.path.join(ROOT, 'profiles', 'traffic.json')   # HBM bytes per launch from rocprofv3 PMC passes, keyed by shape
 
@@ -149,7 +150,7 @@ class Runner(object):
             self._deliver(fg.cur_frame(self.frames[kf + i], self.mv[kf + i], self.res[kf + i], nxt(i)), i)
 
     # ---- untimed legs (rank 0) ----------------------------------------------------------------
-    OPS = ['warp_bilinear', 'aggregate', 'rfcn_head', 'proposal', 'det_postprocess']
+    OPS = ['warp_bilinear', 'aggregate', 'rfcn_head', 'proposal', 'det_postprocess', 'conv_nhwc']
 
     def eager_profile_step(self, s):
         """The same interval issued eagerly with the per-kernel event hooks on (a captured graph has no
@@ -164,9 +165,12 @@ class Runner(object):
         torch.cuda.synchronize()
         self.hip.prof_enable(True, ops=self.OPS)
         self.hip.prof_read()
+        self.hip.conv_flops_reset(True)
         self.step(s, eg)
         torch.cuda.synchronize()
         prof = self.hip.prof_read()
+        self.conv_flops = self.hip.conv_flops_read()
+        self.hip.conv_flops_reset(False)
         self.hip.prof_enable(False)
         return prof
 
@@ -286,7 +290,7 @@ class Runner(object):
                   "note": ("dense contractions in bf16 on the GPU vs the fp32 oracle graph: outputs differ by bf16 round-off "
                            "(feature_rel_err_key_frame), so ROI / survivor identity is not expected; the bit-exactness claim "
                            "in this mode is the hand-written-stage line below") if self.args.dtype != 'f32' else
-                          "fp32 on both sides: differences are summation order in the library convolutions",
+                          "fp32 on both sides: differences are summation order in the library convolutions and, in the own split-bf16 convolutions, the three dropped partial products (< 2^-23 of each product)",
                   "handwritten_stage_mismatches_on_gpu_inputs": int(forced),
                   "handwritten_stages_checked": "warp, aggregate, proposal, psroi+avg+softmax, det_postprocess of frames %s "
                                                 "(bit-exact = 0 mismatching elements)" % frames[:3]}
@@ -435,7 +439,7 @@ def main():
                for k, v in prof.items() if v[1]}
         hand_total = sum(o["total_us"] for o in ops.values()) or 1.0
         dom = max(ops, key=lambda k: ops[k]["total_us"]) if ops else None
-        roof = {"bound": "hbm", "kernel": "warp_kernel (lsfa_warp_bilinear: MV/flow warp + fused epilogue), %d map(s) per launch" % B,
+        roof_hbm = {"bound": "hbm", "kernel": "warp_kernel (lsfa_warp_bilinear: MV/flow warp + fused epilogue), %d map(s) per launch" % B,
                 "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 4),
                 "traffic": load_traffic("warp_bilinear:N=%d,C=%d,H=%d,W=%d" % (B, C, fh, fw)),
@@ -446,6 +450,27 @@ def main():
                             "from the rocprofv3 PMC passes under profiles/ for this shape, null if none was taken",
                 "note": "%.0f MB per launch: resident in the 256 MiB Infinity Cache, so this is cache bandwidth against "
                         "the HBM peak; --maps-per-launch 32 gives the HBM-resident figure" % (bytes_per_launch / 1e6)}
+        # ---- roofline of the dominant hand-written kernel: the split-bf16 convolution (matrix pipe) -----------------
+        conv_ms, conv_n = prof.get('conv_nhwc', (0.0, 0))
+        conv_fl, conv_calls = getattr(r, 'conv_flops', (0.0, 0))
+        if conv_n and conv_fl > 0:
+            tf = conv_fl / (conv_ms * 1e-3) / 1e12
+            roof = {"bound": "mfma", "kernel": "conv_split_kernel / conv_split3x3_kernel (lsfa_conv_split_fwd: conv2 of the ResNet "
+                    "units, feat_conv_3x3, fuse_reduce_add) incl. their conv_reduce_kernel passes, %d calls of one interval" % conv_n,
+                    "achieved": round(tf, 1), "peak": MFMA_SPLIT_PEAK_TFLOPS, "unit": "TFLOP/s",
+                    "frac": round(tf / MFMA_SPLIT_PEAK_TFLOPS, 4), "traffic": None,
+                    "launches": conv_n, "avg_us": round(conv_ms * 1e3 / conv_n, 2),
+                    "algorithmic_flops_per_launch": round(conv_fl / max(conv_calls, 1)),
+                    "bf16_mfma_work": {"achieved": round(6 * tf, 1), "peak": 2500.0, "unit": "TFLOP/s"},
+                    "fp32_mfma_pipe_peak": 157.3,
+                    "measured": "HIP events around each lsfa_conv_split_fwd / lsfa_conv_nhwc_fused_fwd call (conv kernel + its reduce "
+                                "pass) of one interval re-issued eagerly after the timed region; algorithmic FLOPs = 2*M*N*K summed "
+                                "over the same calls",
+                    "note": "fp32 in / fp32 accumulate; every fp32 product is six bf16 partial products on the bf16 matrix pipe, so "
+                            "the peak for fp32-equivalent FLOPs is the dense bf16 peak / 6 (2500 / 6); the fp32 matrix instructions "
+                            "peak at 157.3"}
+        else:
+            roof = roof_hbm
         line = {
             "metric": "frames/sec/GPU at 1000x600 key_interval=10 (whole-job frames/s)",
             "value": round(frames / elapsed, 3), "unit": "frames/s", "n_gpus": world, "steps": args.steps,
@@ -465,6 +490,7 @@ def main():
                            ", next key frame queued ahead of the segment before it" if args.lookahead else ""))
                        if args.lanes > 0 else "serial"},
             "roofline": roof,
+            "roofline_hbm_kernel": roof_hbm,
             "roofline_handwritten_ops": {
                 "per_op": ops, "dominant_by_time": dom,
                 "dominant_share_of_handwritten_time": round(ops[dom]["total_us"] / hand_total, 3) if dom else None,
@@ -475,7 +501,9 @@ def main():
             M = args.maps_per_launch
             mm = r.many_maps_leg(M)
             w = mm['warp_bilinear (x scale map)']
-            line["roofline_single_map"] = roof
+            line["roofline_single_map"] = roof_hbm
+            line["roofline_mfma_kernel"] = roof
+            del line["roofline_hbm_kernel"]
             line["roofline"] = {"bound": "hbm", "kernel": "warp_kernel, %d maps per launch (x scale map epilogue)" % M,
                                 "achieved": w["achieved_GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                 "frac": round(w["achieved_GBps"] / HBM_PEAK_GBS, 4),

@@ -373,6 +373,25 @@ def scale_shift_relu_cl(x, scale, shift, relu=True, out=None):
     return out
 
 
+# algorithmic FLOPs (2*M*N*K, fp32-equivalent) of the own convolutions issued since the last reset: bench.py divides
+# them by the event-timed duration of the same launches for its MFMA roofline
+_conv_flops = {"count": False, "flops": 0.0, "launches": 0}
+
+
+def conv_flops_reset(enable=True):
+    _conv_flops.update(count=bool(enable), flops=0.0, launches=0)
+
+
+def conv_flops_read():
+    return _conv_flops["flops"], _conv_flops["launches"]
+
+
+def _count_conv(N, Ho, Wo, Cout, Cin, kh, kw):
+    if _conv_flops["count"]:
+        _conv_flops["flops"] += 2.0 * N * Ho * Wo * Cout * Cin * kh * kw
+        _conv_flops["launches"] += 1
+
+
 def conv_weight_kc(weight):
     """(Cout, Cin, kh, kw) -> (Cout, kh*kw, Cin) contiguous: the layout lsfa_conv_nhwc_fwd reads (K contiguous)."""
     co, ci, kh, kw = weight.shape
@@ -396,6 +415,7 @@ def conv_nhwc(x, w_kc, bias, kh, kw, stride=1, pad=0, dil=1, relu=False, out=Non
     for name, t in (("out", out), ("residual", residual), ("out2", out2)):
         if t is not None and (t.numel() != N * Ho * Wo * Cout or not t.is_contiguous() or t.dtype != torch.float32):
             raise LsfaError("conv_nhwc: %s must be a contiguous float32 tensor of %d elements" % (name, N * Ho * Wo * Cout))
+    _count_conv(N, Ho, Wo, Cout, Cin, kh, kw)
     need = lib().lsfa_conv_nhwc_workspace_bytes(_ci(N), _ci(H), _ci(W), _ci(Cout), _ci(kh), _ci(kw), _ci(stride), _ci(pad), _ci(dil))
     ws = torch.empty(need, dtype=torch.uint8, device=x.device)
     _check(lib().lsfa_conv_nhwc_fused_fwd(_ptr(x), _ci(N), _ci(H), _ci(W), _ci(Cin), _ptr(w_kc), _ptr(bias), _ci(Cout), _ci(kh),
@@ -439,6 +459,7 @@ def conv_split(x, sw, bias=None, stride=1, pad=0, dil=1, relu=False, out=None, r
     for name, t in (("out", out), ("residual", residual), ("out2", out2)):
         if t is not None and (t.numel() != N * Ho * Wo * Cout or not t.is_contiguous() or t.dtype != torch.float32):
             raise LsfaError("conv_split: %s must be a contiguous float32 tensor of %d elements" % (name, N * Ho * Wo * Cout))
+    _count_conv(N, Ho, Wo, Cout, Cin, kh, kw)
     need = lib().lsfa_conv_split_workspace_bytes(_ci(N), _ci(H), _ci(W), _ci(Cin), _ci(Cout), _ci(kh), _ci(kw), _ci(stride),
                                                  _ci(pad), _ci(dil))
     ws = torch.empty(need, dtype=torch.uint8, device=x.device)

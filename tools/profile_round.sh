@@ -39,4 +39,12 @@ cp $(find $OUT/trace_ops -name "*kernel_stats.csv" | head -1) $OUT/bench_ops_ker
 rm -rf $OUT/trace_ops
 timeout 200 $PY tools/lab/warp_lab.py --rounds 9 > $OUT/warp_lab.txt 2>&1
 timeout 200 $PY tools/key_sections.py > $OUT/key_sections.txt 2>&1
+LSFA_CONV_SPLIT=0 LSFA_OWN_CONV=backbone timeout 200 $PY tools/key_sections.py > $OUT/key_sections_fp32_mfma_conv.txt 2>&1
+
+# 6. the convolution kernels: split-bf16 vs fp32-MFMA vs library per shape (error against float64 + time), where one chunk's
+#    cycles go, and the fp32-MFMA loop with parts switched off; the detection post-processing phase by phase
+timeout 600 $PY tools/lab/conv_split_lab.py > $OUT/conv_split_lab.txt 2>&1
+timeout 300 $PY tools/lab/conv_split_lab.py --stamps > $OUT/conv_split_chunk_cycles.txt 2>&1
+timeout 300 $PY tools/lab/conv_lab.py > $OUT/conv_fp32_mfma_lab.txt 2>&1
+timeout 300 $PY tools/lab/det_lab.py > $OUT/det_lab.txt 2>&1
 ls -la $OUT

@@ -231,7 +231,8 @@ static __global__ __launch_bounds__(256) void nms_mask_f64_kernel(const double* 
 
 constexpr int kSweepMaxBlocks = 512;   // n <= 32768
 constexpr int kSweepMaxOut = 1024;     // Proposal output rows
-constexpr int kSweepLazyMax = 4096;    // survivors whose positions fit the LDS list of the lazy sweep
+constexpr int kSweepLazyMax = 4096;
+constexpr int kSweepPairMax = 320;     // survivors the two-blocks-per-trip sweep gathers with five loads per lane    // survivors whose positions fit the LDS list of the lazy sweep
 
 __device__ __forceinline__ uint64_t wave_or64(uint64_t v) {
   uint32_t lo = (uint32_t)v, hi = (uint32_t)(v >> 32);
@@ -287,7 +288,87 @@ static __global__ __launch_bounds__(64) void nms_sweep_kernel(const uint64_t* __
   }
   __syncthreads();  // single-wave workgroup: orders the LDS accesses of different lanes
   int num = 0;
-  if (lazy) {
+  if (lazy && max_keep <= kSweepPairMax) {
+    // Two blocks per trip to memory (Proposal: 300 survivors).  For a pair (b, b+1) everything that does not depend on
+    // the pair's own survivors was put together one iteration earlier: cur0 = removed(b), and cur1 = removed(b+1)
+    // WITHOUT block b's contribution, which is added after block b is resolved from `intra` = word b+1 of block b's
+    // rows (state-independent, loaded an iteration ahead).  While the pair is resolved, the loads for the NEXT pair are
+    // in flight: word b+2 / b+3 of the rows that survived before b (gathered through kept_pos), of block b's and
+    // block b+1's own rows (all 64 each, the survivors' words selected afterwards), the next pair's diagonal words and
+    // its `intra`.  On heavy-overlap inputs (3-5 survivors per block, 70-90 blocks to reach 300) a block's resolution is
+    // far shorter than a trip to L2/MALL, so halving the trips nearly halves the sweep.
+    uint64_t colw0 = lane < n ? diagT[lane] : 0ULL, rowd0 = lane < n ? mask[(size_t)lane * col_blocks] : 0ULL;
+    uint64_t colw1 = 0, rowd1 = 0, intra = 0;
+    if (col_blocks > 1) {
+      const int r1 = min(64 + lane, n - 1);
+      const uint64_t cw = diagT[r1], rd = mask[(size_t)r1 * col_blocks + 1], it = mask[(size_t)min(lane, n - 1) * col_blocks + 1];
+      colw1 = 64 + lane < n ? cw : 0ULL;
+      rowd1 = 64 + lane < n ? rd : 0ULL;
+      intra = lane < n ? it : 0ULL;
+    }
+    uint64_t cur0 = 0, cur1 = 0;
+    for (int b = 0; b < col_blocks && num < max_keep; b += 2) {
+      const bool more = b + 2 < col_blocks, more3 = b + 3 < col_blocks;
+      // ---- requests for the next pair (t2 = b + 2, t3 = b + 3); unconditional loads on clamped indices ----
+      const int t2 = more ? b + 2 : b, t3 = more3 ? b + 3 : t2;
+      const uint64_t* m2 = mask + t2;
+      const uint64_t* m3 = mask + t3;
+      const int k0 = lane < num ? kept_pos[lane] : 0, k1 = lane + 64 < num ? kept_pos[lane + 64] : 0;
+      const int k2 = lane + 128 < num ? kept_pos[lane + 128] : 0, k3 = lane + 192 < num ? kept_pos[lane + 192] : 0;
+      const int k4 = lane + 256 < num ? kept_pos[lane + 256] : 0;
+      const int ra = min(b * 64 + lane, n - 1), rb = min(b * 64 + 64 + lane, n - 1);
+      const int rc = min(t2 * 64 + lane, n - 1), rd_ = min(t3 * 64 + lane, n - 1);
+      const uint64_t g20 = m2[(size_t)k0 * col_blocks], g21 = m2[(size_t)k1 * col_blocks], g22 = m2[(size_t)k2 * col_blocks];
+      const uint64_t g23 = m2[(size_t)k3 * col_blocks], g24 = m2[(size_t)k4 * col_blocks];
+      const uint64_t g30 = m3[(size_t)k0 * col_blocks], g31 = m3[(size_t)k1 * col_blocks], g32 = m3[(size_t)k2 * col_blocks];
+      const uint64_t g33 = m3[(size_t)k3 * col_blocks], g34 = m3[(size_t)k4 * col_blocks];
+      const uint64_t sa2 = m2[(size_t)ra * col_blocks], sa3 = m3[(size_t)ra * col_blocks];      // block b's rows
+      const uint64_t sb2 = m2[(size_t)rb * col_blocks], sb3 = m3[(size_t)rb * col_blocks];      // block b+1's rows
+      const uint64_t n_colw0 = diagT[rc], n_rowd0 = m2[(size_t)rc * col_blocks], n_intra = m3[(size_t)rc * col_blocks];
+      const uint64_t n_colw1 = diagT[rd_], n_rowd1 = m3[(size_t)rd_ * col_blocks];
+      const bool h0 = lane < num, h1 = lane + 64 < num, h2 = lane + 128 < num, h3 = lane + 192 < num, h4 = lane + 256 < num;
+      // ---- block b ----
+      const int nb0 = min(64, n - b * 64);
+      const bool alive0 = lane < nb0 && !((cur0 >> lane) & 1ULL);
+      const uint64_t kept0 = resolve_block(__ballot(alive0), alive0, colw0, rowd0, max_keep - num);
+      const bool mine0 = (kept0 >> lane) & 1ULL;
+      if (mine0) {
+        const int pos = num + __popcll(kept0 & ((1ULL << lane) - 1ULL));
+        if (keep) keep[pos] = b * 64 + lane;
+        kept_pos[pos] = b * 64 + lane;
+      }
+      num += __popcll(kept0);
+      // ---- block b + 1 ----
+      uint64_t kept1 = 0;
+      bool mine1 = false;
+      if (b + 1 < col_blocks && num < max_keep) {
+        const uint64_t c1 = cur1 | wave_or64_uniform(mine0 ? intra : 0ULL);
+        const int nb1 = min(64, n - (b + 1) * 64);
+        const bool alive1 = lane < nb1 && !((c1 >> lane) & 1ULL);
+        kept1 = resolve_block(__ballot(alive1), alive1, colw1, rowd1, max_keep - num);
+        mine1 = (kept1 >> lane) & 1ULL;
+        if (mine1) {
+          const int pos = num + __popcll(kept1 & ((1ULL << lane) - 1ULL));
+          if (keep) keep[pos] = (b + 1) * 64 + lane;
+          kept_pos[pos] = (b + 1) * 64 + lane;
+        }
+        num += __popcll(kept1);
+      }
+      // ---- the next pair's state ----
+      const bool va = b * 64 + lane < n, vb = b * 64 + 64 + lane < n;
+      const uint64_t x2 = (h0 ? g20 : 0ULL) | (h1 ? g21 : 0ULL) | (h2 ? g22 : 0ULL) | (h3 ? g23 : 0ULL) | (h4 ? g24 : 0ULL) |
+                          ((mine0 && va) ? sa2 : 0ULL) | ((mine1 && vb) ? sb2 : 0ULL);
+      const uint64_t x3 = (h0 ? g30 : 0ULL) | (h1 ? g31 : 0ULL) | (h2 ? g32 : 0ULL) | (h3 ? g33 : 0ULL) | (h4 ? g34 : 0ULL) |
+                          ((mine0 && va) ? sa3 : 0ULL) | ((mine1 && vb) ? sb3 : 0ULL);
+      cur0 = more ? wave_or64_uniform(x2) : 0ULL;
+      cur1 = more3 ? wave_or64_uniform(x3) : 0ULL;
+      const bool vc = more && t2 * 64 + lane < n, vd = more3 && t3 * 64 + lane < n;
+      colw0 = vc ? n_colw0 : 0ULL; rowd0 = vc ? n_rowd0 : 0ULL;
+      intra = (vc && more3) ? n_intra : 0ULL;
+      colw1 = vd ? n_colw1 : 0ULL; rowd1 = vd ? n_rowd1 : 0ULL;
+      __syncthreads();
+    }
+  } else if (lazy) {
     // Software-pipelined: everything block b+1 needs from memory is requested before block b is resolved.
     //   removed(b+1) = OR of word b+1 of the rows kept in blocks < b   (gathered through kept_pos: known now)
     //                | OR of word b+1 of the rows block b keeps         (all 64 rows of block b are loaded

@@ -89,7 +89,20 @@ def main():
     wk = hip.conv_weight_kc(torch.randn(256, 256, 3, 3, device=dev) * 0.02)
     bb = torch.randn(256, device=dev)
     us = timeit(lambda: hip.conv_nhwc(xr, wk, bb, 3, 3, 1, 1, 1, relu=True), args.iters)
-    out['conv_nhwc 3x3 256->256 @38x63'] = dict(us=round(us, 2), TFLOPs=round(2 * HW * 256 * 2304 / us / 1e6, 1))
+    out['conv_nhwc (fp32 MFMA) 3x3 256->256 @38x63'] = dict(us=round(us, 2), TFLOPs=round(2 * HW * 256 * 2304 / us / 1e6, 1))
+    # the same and the two big ones on the split-bf16 kernel
+    sw = hip.SplitWeight(torch.randn(256, 256, 3, 3, device=dev) * 0.02)
+    us = timeit(lambda: hip.conv_split(xr, sw, bb, 1, 1, 1, relu=True), args.iters)
+    out['conv_split 3x3 256->256 @38x63 (res4 conv2)'] = dict(us=round(us, 2), TFLOPs=round(2 * HW * 256 * 2304 / us / 1e6, 1))
+    sw = hip.SplitWeight(torch.randn(1024, 256, 3, 3, device=dev) * 0.02)
+    b1k = torch.randn(1024, device=dev)
+    us = timeit(lambda: hip.conv_split(xr, sw, b1k, 1, 1, 1, nchw=True), args.iters)
+    out['conv_split 3x3 256->1024 @38x63 (fuse, NCHW out)'] = dict(us=round(us, 2), TFLOPs=round(2 * HW * 1024 * 2304 / us / 1e6, 1))
+    x2k = torch.randn(1, H, W, 2048, device=dev)
+    sw = hip.SplitWeight(torch.randn(1024, 2048, 3, 3, device=dev) * 0.01)
+    us = timeit(lambda: hip.conv_split(x2k, sw, b1k, 1, 6, 6, relu=True, nchw=True), max(args.iters // 4, 3))
+    out['conv_split 3x3 d6 2048->1024 @38x63 (feat_conv_3x3)'] = dict(us=round(us, 2), TFLOPs=round(2 * HW * 1024 * 18432 / us / 1e6, 1))
+    del sw, x2k
     # PSROI / head
     cls_map, box_map = torch.randn(1, 31 * 49, H, W, device=dev), torch.randn(1, 8 * 49, H, W, device=dev)
     rois_np = np.zeros((300, 5), np.float32)

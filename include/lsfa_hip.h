@@ -254,6 +254,22 @@ int lsfa_conv_split_fwd(const float* x, int N, int H, int W, int Cin, const void
                         float* y2, const float* scale2, const float* shift2,
                         void* ws, size_t ws_bytes, void* stream);
 
+/* ---------------------------------------------------------------------------
+ * The stem of the ResNets and the frame shrink in front of the small net, three launches instead of six library ones.
+ *   lsfa_avgpool_nchw      mx.symbol.Pooling(kernel=(k,k), stride=(k,k), pool_type='avg', pooling_convention='full')
+ *                          (dff_rfcn/symbols/resnet_v1_101_flownet_rfcn.py:216 `resize_data`, k = 4): x (N,C,H,W) -> y (N,C,ceil(H/k),
+ *                          ceil(W/k)); edge windows are clipped to the image and averaged over what they hold.
+ *   lsfa_stem_conv7x7s2    bn_data + conv0 + bn0 + relu0 (dff_rfcn/symbols/resnet.py:151, :162): x (N,3,H,W) NCHW; in_scale/in_shift (3)
+ *                          = bn_data as a per-channel affine (NULL: none), applied before the zero padding; w_l (3,7,7,64) floats =
+ *                          [ci][ky][kx][co] with bn0's scale folded in; bias (64) = bn0's shift; y (N,Ho,Wo,64)
+ *                          channels-last, Ho = (H-1)/2+1.  fp32 FMA chains in (ci, ky, kx) order.
+ *   lsfa_maxpool3x3s2_nhwc pool0 (resnet.py:163: 3x3, stride 2, pad 1, max): x (N,H,W,C) -> y (N,(H-1)/2+1,(W-1)/2+1,C), C % 4 == 0.
+ * ------------------------------------------------------------------------ */
+int lsfa_avgpool_nchw(const float* x, int N, int C, int H, int W, int k, float* y, void* stream);
+int lsfa_stem_conv7x7s2(const float* x, int N, int H, int W, const float* in_scale, const float* in_shift,
+                        const float* w_l, const float* bias, float* y, void* stream);
+int lsfa_maxpool3x3s2_nhwc(const float* x, int N, int H, int W, int C, float* y, void* stream);
+
 /* Inference BatchNorm (use_global_stats) + ReLU as one pass: y = max(x*scale[c]+shift[c], 0)
  * (sym_common.py:92-102 bn + relu of every pre-activation unit, resnet.py:70-101).
  * relu != 0 applies the ReLU.  In-place (y == x) allowed. */
@@ -309,7 +325,7 @@ int lsfa_stream_destroy(void* stream);
 enum {
   LSFA_OP_PSROI = 0, LSFA_OP_RFCN_HEAD = 1, LSFA_OP_WARP = 2, LSFA_OP_AGG = 3,
   LSFA_OP_PROPOSAL = 4, LSFA_OP_NMS = 5, LSFA_OP_DET = 6, LSFA_OP_DCN_IM2COL = 7,
-  LSFA_OP_BNRELU = 8, LSFA_OP_CONV = 9, LSFA_OP_COUNT = 10
+  LSFA_OP_BNRELU = 8, LSFA_OP_CONV = 9, LSFA_OP_STEM = 10, LSFA_OP_COUNT = 11
 };
 int lsfa_prof_enable(int mask);
 int lsfa_prof_read(double* ms_host /*LSFA_OP_COUNT*/, int* launches_host /*LSFA_OP_COUNT*/);

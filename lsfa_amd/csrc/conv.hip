@@ -271,6 +271,8 @@ struct SplitPlan {
   int patches_x, patches_y;
   int nx, ny, slices;   // tiles: nx pixel tiles x ny channel tiles x slices
   int per_slice;        // chunks (general: of taps*Cin/32; halo: of Cin/32) per slice
+  int units_per_wg;     // halo, balanced mode: (tile, channel chunk) units per workgroup, else 0
+  int max_pieces;       // ... and the most workgroups that can share one tile
 };
 
 SplitPlan split_plan(int N, int H, int W, int Cin, int Cout, int kh, int kw, int stride, int pad, int dil) {
@@ -294,6 +296,13 @@ SplitPlan split_plan(int N, int H, int W, int Cin, int Cout, int kh, int kw, int
     // 34.6 us, the 256 -> 1024 fuse convolution 91 vs 106); where K must be cut anyway the general kernel's finer cut
     // (it slices taps x chunks) keeps more CUs busy (res4 conv2 32.7 vs 35.4, res3 conv2 31.4 vs 34.8)
     if (p.slices > 1) p.halo = false;
+    // balanced mode: fewer than 512 tiles but more than 512 (tile, chunk) units -> equal unit counts per workgroup
+    // (fuse_reduce_add: 320 tiles x 8 chunks = 512 workgroups x 5 instead of one round of 320 x 8)
+    const long tiles = (long)p.nx * p.ny, units = tiles * cpt;
+    if (p.halo && tiles < 512 && units > 512) {
+      const int per = (int)((units + 511) / 512);
+      if (per * 4 <= cpt * 3) { p.units_per_wg = per; p.max_pieces = (cpt + per - 1) / per + 1; }     // worth it from 25 % shorter
+    }
   }
   if (!p.halo) {
     const long P = (long)N * Ho * Wo;
@@ -346,6 +355,8 @@ extern "C" size_t lsfa_conv_split_workspace_bytes(int N, int H, int W, int Cin, 
   const int Ho = (H + 2 * pad - dil * (kh - 1) - 1) / stride + 1, Wo = (W + 2 * pad - dil * (kw - 1) - 1) / stride + 1;
   if (Ho <= 0 || Wo <= 0) return 0;
   const SplitPlan p = split_plan(N, H, W, Cin, Cout, kh, kw, stride, pad, dil);
+  if (p.units_per_wg > 0)      // one 32 KB accumulator slot per (tile, piece)
+    return (size_t)p.nx * p.ny * p.max_pieces * convsplit::kThreads * 32 * sizeof(float);
   return p.slices > 1 ? align_up((size_t)p.slices * N * Ho * Wo * Cout * sizeof(float), 256) : 256;
 }
 
@@ -366,15 +377,21 @@ extern "C" int lsfa_conv_split_fwd(const float* x, int N, int H, int W, int Cin,
   LSFA_REQUIRE(P * Cout < (1L << 31) && ((long)N * H * W + (long)(pad + 1) * (W + 1)) * Cin < (1L << 31), "lsfa_conv_split_fwd: tensor too large");
   const SplitPlan p = split_plan(N, H, W, Cin, Cout, kh, kw, stride, pad, dil);
   const size_t need = lsfa_conv_split_workspace_bytes(N, H, W, Cin, Cout, kh, kw, stride, pad, dil);
-  if (p.slices > 1 && (!ws || ws_bytes < need)) {
+  if ((p.slices > 1 || p.units_per_wg > 0) && (!ws || ws_bytes < need)) {
     set_error("lsfa_conv_split_fwd: workspace %zu < %zu bytes", ws_bytes, need);
     return LSFA_EWORKSPACE;
   }
   hipStream_t s = (hipStream_t)stream;
   convsplit::Args a = {x, (const uint4*)wfrag, bias, y, p.slices > 1 ? (float*)ws : nullptr, N, H, W, Cin, Cout, kh, kw, stride, pad,
-                       dil, Ho, Wo, relu, p.per_slice, residual, y2, scale2, shift2, y_nchw};
+                       dil, Ho, Wo, relu, p.per_slice, residual, y2, scale2, shift2, y_nchw, 0, 0};
   ProfScope prof(LSFA_OP_CONV, s);
-  const int tiles = p.nx * p.ny * p.slices;
+  int tiles = p.nx * p.ny * p.slices;
+  if (p.units_per_wg > 0) {
+    a.part = (float*)ws;
+    a.units_per_wg = p.units_per_wg;
+    a.max_pieces = p.max_pieces;
+    tiles = (p.nx * p.ny * (Cin / 32) + p.units_per_wg - 1) / p.units_per_wg;      // workgroups
+  }
   const dim3 grid((unsigned)(8 * ((tiles + 7) / 8)));
   if (p.halo && p.dil == 1)
     hipLaunchKernelGGL(convsplit::conv_split3x3_kernel<1>, grid, dim3(convsplit::kThreads), 0, s, a, p.patches_x, p.patches_y, p.nx, p.ny, p.slices);
@@ -382,6 +399,10 @@ extern "C" int lsfa_conv_split_fwd(const float* x, int N, int H, int W, int Cin,
     hipLaunchKernelGGL(convsplit::conv_split3x3_kernel<2>, grid, dim3(convsplit::kThreads), 0, s, a, p.patches_x, p.patches_y, p.nx, p.ny, p.slices);
   else
     hipLaunchKernelGGL(convsplit::conv_split_kernel, grid, dim3(convsplit::kThreads), 0, s, a, p.nx, p.ny, p.slices);
+  if (p.units_per_wg > 0) {
+    hipLaunchKernelGGL(convsplit::conv_split3x3_fixup_kernel, dim3((unsigned)(p.nx * p.ny)), dim3(convsplit::kThreads), 0, s, a, p.patches_x,
+                       p.patches_y, p.nx);
+  }
   if (p.slices > 1) {
     ConvArgs r = {x, nullptr, bias, y, (float*)ws, N, H, W, Cin, Cout, kh, kw, stride, pad, dil, Ho, Wo, relu, 0, residual, y2, scale2, shift2, y_nchw};
     const long n4 = P * Cout / 4;

@@ -51,6 +51,9 @@ struct Args {
   int N, H, W, Cin, Cout, kh, kw, stride, pad, dil, Ho, Wo, relu, chunks_per_slice;
   const float* res; float* y2; const float* scale2; const float* shift2;
   int y_nchw;      // y / y2 / res are (N, Cout, Ho, Wo) instead of (N, Ho, Wo, Cout); partial slices stay NHWC
+  // halo kernel, balanced mode (units_per_wg > 0): every workgroup takes the same number of (tile, channel chunk) units,
+  // crossing tile boundaries; a tile shared by several workgroups is put together by conv_split3x3_fixup_kernel
+  int units_per_wg; int max_pieces;
 };
 
 // the leading 8 mantissa bits of v as an fp32 bit pattern (= a bf16 value), and what is left
@@ -317,6 +320,7 @@ template <int DIL> struct Halo {
   static constexpr int kPieces = kPix * 8;                            // 16-byte pieces of one stage
   static constexpr int kDma = (kPieces + kThreads - 1) / kThreads;   // DMA instructions per thread and chunk
   static constexpr int kStageUint4 = kPieces + kStageB;              // A halo + B, per parity
+  static constexpr int kRow = kStageUint4;
 };
 
 template <int DIL>
@@ -333,7 +337,7 @@ struct HaloGeom {
 
 // B of step (kc, tap) -> parity PB; one third of the A halo of chunk kc_next (DMA instructions i0 .. i1-1) -> parity PA
 template <int DIL, int PA, int PB, int I0, int I1>
-__device__ __forceinline__ void halo_issue(uint4 (*S)[Halo<DIL>::kStageUint4], const float* __restrict__ x, const uint4* __restrict__ wblock,
+__device__ __forceinline__ void halo_issue(uint4 (*S)[Halo<DIL>::kRow], const float* __restrict__ x, const uint4* __restrict__ wblock,
                                            const HaloGeom<DIL>& g, int gch, bool with_b, int kc_next, bool with_a) {
   if (with_b) {
     const uint4* wsrc = wblock + (size_t)gch * g.wstride + g.wave * 192 + g.lane;
@@ -353,7 +357,7 @@ __device__ __forceinline__ void halo_issue(uint4 (*S)[Halo<DIL>::kStageUint4], c
 }
 
 template <int DIL, int PA, int PB, int TAP>
-__device__ __forceinline__ void halo_consume(uint4 (*S)[Halo<DIL>::kStageUint4], const HaloGeom<DIL>& g, f32x16& acc0, f32x16& acc1) {
+__device__ __forceinline__ void halo_consume(uint4 (*S)[Halo<DIL>::kRow], const HaloGeom<DIL>& g, f32x16& acc0, f32x16& acc1) {
   constexpr int ty = TAP / 3, tx = TAP % 3;
   const int hp = g.hp0 + (ty * DIL) * Halo<DIL>::kW + tx * DIL;
   const int xs = g.h4 ^ ((hp >> 1) & 7);                  // slot of piece 4h + j is (4h + j) ^ sw = xs ^ j
@@ -374,7 +378,7 @@ __device__ __forceinline__ void halo_consume(uint4 (*S)[Halo<DIL>::kStageUint4],
 // one step = one tap of channel chunk kc (A parity PA): start the copies the NEXT step needs (its B; during taps 0-2 a
 // third each of the next chunk's halo), compute this tap, retire the copies, meet the other waves
 template <int DIL, int PA, int TAP>
-__device__ __forceinline__ void halo_step(uint4 (*S)[Halo<DIL>::kStageUint4], const float* __restrict__ x, const uint4* __restrict__ wblock,
+__device__ __forceinline__ void halo_step(uint4 (*S)[Halo<DIL>::kRow], const float* __restrict__ x, const uint4* __restrict__ wblock,
                                           const HaloGeom<DIL>& g, int kc, int kc_end, f32x16& acc0, f32x16& acc1) {
   constexpr int PB = (PA + TAP) & 1;
   constexpr int K3 = (Halo<DIL>::kDma + 2) / 3;
@@ -391,7 +395,7 @@ __device__ __forceinline__ void halo_step(uint4 (*S)[Halo<DIL>::kStageUint4], co
 }
 
 template <int DIL, int PA>
-__device__ __forceinline__ void halo_chunk(uint4 (*S)[Halo<DIL>::kStageUint4], const float* __restrict__ x, const uint4* __restrict__ wblock,
+__device__ __forceinline__ void halo_chunk(uint4 (*S)[Halo<DIL>::kRow], const float* __restrict__ x, const uint4* __restrict__ wblock,
                                            const HaloGeom<DIL>& g, int kc, int kc_end, f32x16& acc0, f32x16& acc1) {
   halo_step<DIL, PA, 0>(S, x, wblock, g, kc, kc_end, acc0, acc1);
   halo_step<DIL, PA, 1>(S, x, wblock, g, kc, kc_end, acc0, acc1);
@@ -404,73 +408,19 @@ __device__ __forceinline__ void halo_chunk(uint4 (*S)[Halo<DIL>::kStageUint4], c
   halo_step<DIL, PA, 8>(S, x, wblock, g, kc, kc_end, acc0, acc1);
 }
 
-// grid (8 * ceil(tiles / 8)); block 256.  tiles = N * ceil(H/4) * ceil(W/32) patches x (Cout / 64) x slices (of channel chunks);
-// a.chunks_per_slice counts CHANNEL chunks here.  Output size = input size (stride 1, pad = DIL).
-template <int DIL>
-static __global__ __launch_bounds__(kThreads, (DIL == 1 ? 2 : 1)) void conv_split3x3_kernel(Args a, int patches_x, int patches_y, int nx, int ny, int nz) {
-#if __HIP_DEVICE_COMPILE__      // hipcc's HOST pass fails to instantiate the unrolled tap chain (spurious "substitution failure"); it needs only the stub
-  typedef Halo<DIL> HL;
-  __shared__ __attribute__((aligned(16))) uint4 S[2][HL::kStageUint4];
-  const Tile tile = xcd_tile(blockIdx.x, nx, ny, nz);
-  if (tile.x < 0) return;
-  HaloGeom<DIL> g;
-  g.tid = threadIdx.x;
-  g.lane = g.tid & 63;
-  g.wave = __builtin_amdgcn_readfirstlane(g.tid >> 6);
-  g.chunks_per_tap = a.Cin / kChunk;
-  const int col_tiles = a.Cout / 32;
-  g.wstride = (size_t)col_tiles * (kChunkBytesB / 32);
-  const uint4* wblock = a.wfrag + (size_t)(2 * tile.y) * (kChunkBytesB / 32);
-  const int kc0 = tile.z * a.chunks_per_slice, kc_end = min(kc0 + a.chunks_per_slice, g.chunks_per_tap);
-  // patch -> image, top-left output pixel
-  const int pimg = tile.x / (patches_x * patches_y), prem = tile.x - pimg * (patches_x * patches_y);
-  const int y0 = (prem / patches_x) * kPatchRows, x0 = (prem % patches_x) * kPatchCols;
-  // DMA role: piece e = i * 256 + tid of the halo: halo pixel e >> 3, slot e & 7 holds source piece (e & 7) ^ ((pixel >> 1) & 7)
-  g.ok_mask = 0; g.live_mask = 0;
-#pragma unroll
-  for (int i = 0; i < HL::kDma; ++i) {
-    const int e = i * kThreads + g.tid;
-    g.off0[i] = 0;
-    if (e < HL::kPieces) {
-      g.live_mask |= 1u << i;
-      const int hpix = e >> 3, piece = (e & 7) ^ ((hpix >> 1) & 7);
-      const int iy = y0 - DIL + hpix / HL::kW, ix = x0 - DIL + hpix % HL::kW;
-      if (iy >= 0 && iy < a.H && ix >= 0 && ix < a.W) {
-        g.ok_mask |= 1u << i;
-        g.off0[i] = ((pimg * a.H + iy) * a.W + ix) * a.Cin + 4 * piece;
-      }
-    }
-  }
-  g.hp0 = g.wave * HL::kW + (g.lane & 31);
-  g.h4 = 4 * (g.lane >> 5);
-
-  f32x16 acc0, acc1;
-#pragma unroll
-  for (int i = 0; i < 16; ++i) { acc0[i] = 0.f; acc1[i] = 0.f; }
-
-  if (kc0 < kc_end) {
-    // prologue: the whole halo of chunk kc0 and the weights of (kc0, tap 0); parities as if kc0 were even
-    halo_issue<DIL, 0, 0, 0, HL::kDma>(S, a.x, wblock, g, kc0, true, kc0, true);
-  }
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __builtin_amdgcn_s_barrier();
-  for (int kc = kc0; kc < kc_end; kc += 2) {
-    halo_chunk<DIL, 0>(S, a.x, wblock, g, kc, kc_end, acc0, acc1);
-    if (kc + 1 < kc_end) halo_chunk<DIL, 1>(S, a.x, wblock, g, kc + 1, kc_end, acc0, acc1);
-  }
-
-  // C/D layout: column = lane & 31 (channel), row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5) = column of the patch row
-  const int P = a.N * a.H * a.W;
-  float* part = a.part ? a.part + (size_t)tile.z * P * a.Cout : nullptr;
-  const int oy = y0 + g.wave;
+// the tile's outputs from the accumulators (C/D layout: column = lane & 31 = channel, row = (reg & 3) + 8 * (reg >> 2) +
+// 4 * (lane >> 5) = column of the wave's patch row): a K slice's partial sums, or bias / residual / ReLU / second output
+__device__ __forceinline__ void halo_epilogue(const Args& a, float* part, int pimg, int y0, int x0, int ch_tile, int wave, int lane,
+                                              const f32x16& acc0, const f32x16& acc1) {
+  const int oy = y0 + wave;
 #pragma unroll
   for (int t = 0; t < 2; ++t) {
-    const int ch = tile.y * kWgCh + t * 32 + (g.lane & 31);
+    const int ch = ch_tile * kWgCh + t * 32 + (lane & 31);
     const float bias = (!part && a.bias) ? a.bias[ch] : 0.f;
     const float sc2 = (!part && a.y2) ? a.scale2[ch] : 0.f, sh2 = (!part && a.y2) ? a.shift2[ch] : 0.f;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-      const int ox = x0 + (r & 3) + 8 * (r >> 2) + 4 * (g.lane >> 5);
+      const int ox = x0 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
       if (oy < a.H && ox < a.W) {
         size_t o = ((size_t)(pimg * a.H + oy) * a.W + ox) * a.Cout + ch;
         float v = t == 0 ? acc0[r] : acc1[r];
@@ -483,6 +433,133 @@ static __global__ __launch_bounds__(kThreads, (DIL == 1 ? 2 : 1)) void conv_spli
         if (a.y2) a.y2[o] = fmaxf(v * sc2 + sh2, 0.f);
       }
     }
+  }
+}
+
+// balanced mode, second launch: grid (tiles); block 256.  A tile that several workgroups shared: add their pieces in piece
+// order (fixed, so the result is reproducible) and run the epilogue; tiles one workgroup finished alone are already written.
+static __global__ __launch_bounds__(kThreads) void conv_split3x3_fixup_kernel(Args a, int patches_x, int patches_y, int nx) {
+  const int txy = blockIdx.x, cpt = a.Cin / kChunk;
+  const int first_wg = (txy * cpt) / a.units_per_wg, last_wg = (txy * cpt + cpt - 1) / a.units_per_wg;
+  if (first_wg == last_wg) return;
+  const int tid = threadIdx.x;
+  f32x16 acc0, acc1;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) { acc0[r] = 0.f; acc1[r] = 0.f; }
+  const float* base = a.part + (size_t)txy * a.max_pieces * (kThreads * 32);
+  for (int p = 0; p <= last_wg - first_wg; ++p) {
+    const float* sp = base + (size_t)p * (kThreads * 32);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { acc0[r] = acc0[r] + sp[r * kThreads + tid]; acc1[r] = acc1[r] + sp[(16 + r) * kThreads + tid]; }
+  }
+  const int tx = txy % nx, ty = txy / nx;
+  const int pimg = tx / (patches_x * patches_y), prem = tx - pimg * (patches_x * patches_y);
+  halo_epilogue(a, nullptr, pimg, (prem / patches_x) * kPatchRows, (prem % patches_x) * kPatchCols, ty, tid >> 6, tid & 63, acc0, acc1);
+}
+
+// grid (8 * ceil(tiles / 8)); block 256.  tiles = N * ceil(H/4) * ceil(W/32) patches x (Cout / 64) x slices (of channel chunks);
+// a.chunks_per_slice counts CHANNEL chunks here.  Output size = input size (stride 1, pad = DIL).
+//
+// Balanced mode (a.units_per_wg > 0, nz == 1): the work is the list of (tile, channel chunk) units, tile-major; workgroup g
+// takes units [g * per, (g + 1) * per) whatever tiles they belong to.  320 tiles of 8 chunks on 512 workgroup slots run as
+// ONE round of 8 chunks with 192 slots idle; as 512 workgroups of 5 units each they run 5 chunks' worth.  A tile whose
+// chunks were shared leaves its fp32 accumulators in a.part (one slot per piece) and conv_split3x3_fixup_kernel adds them in
+// piece order and runs the epilogue.  (A last-arriver ticket inside this kernel was tried first: the device-scope
+// __threadfence() it needs writes back / invalidates the whole L2 on this multi-XCD part and doubled the kernel's time.)
+template <int DIL>
+static __global__ __launch_bounds__(kThreads, (DIL == 1 ? 2 : 1)) void conv_split3x3_kernel(Args a, int patches_x, int patches_y, int nx, int ny, int nz) {
+#if __HIP_DEVICE_COMPILE__      // hipcc's HOST pass fails to instantiate the unrolled tap chain (spurious "substitution failure"); it needs only the stub
+  typedef Halo<DIL> HL;
+  __shared__ __attribute__((aligned(16))) uint4 S[2][HL::kRow];
+  HaloGeom<DIL> g;
+  g.tid = threadIdx.x;
+  g.lane = g.tid & 63;
+  g.wave = __builtin_amdgcn_readfirstlane(g.tid >> 6);
+  g.chunks_per_tap = a.Cin / kChunk;
+  const int cpt = g.chunks_per_tap;
+  const int col_tiles = a.Cout / 32;
+  g.wstride = (size_t)col_tiles * (kChunkBytesB / 32);
+  g.hp0 = g.wave * HL::kW + (g.lane & 31);
+  g.h4 = 4 * (g.lane >> 5);
+  const bool balanced = a.units_per_wg > 0;
+  int u = 0, u_end = 0, wg = 0;
+  Tile tile;
+  if (balanced) {
+    const int total_units = nx * ny * cpt;
+    const int groups = (total_units + a.units_per_wg - 1) / a.units_per_wg;
+    wg = xcd_tile(blockIdx.x, groups, 1, 1).x;
+    if (wg < 0) return;
+    u = wg * a.units_per_wg;
+    u_end = min(u + a.units_per_wg, total_units);
+  } else {
+    tile = xcd_tile(blockIdx.x, nx, ny, nz);
+    if (tile.x < 0) return;
+  }
+  for (;;) {
+    int kc0, kc_end, txy = 0;
+    if (balanced) {
+      txy = u / cpt;
+      kc0 = u - txy * cpt;
+      kc_end = min(cpt, kc0 + (u_end - u));
+      tile.x = txy % nx; tile.y = txy / nx; tile.z = 0;
+    } else {
+      kc0 = tile.z * a.chunks_per_slice;
+      kc_end = min(kc0 + a.chunks_per_slice, cpt);
+    }
+    const uint4* wblock = a.wfrag + (size_t)(2 * tile.y) * (kChunkBytesB / 32);
+    // patch -> image, top-left output pixel
+    const int pimg = tile.x / (patches_x * patches_y), prem = tile.x - pimg * (patches_x * patches_y);
+    const int y0 = (prem / patches_x) * kPatchRows, x0 = (prem % patches_x) * kPatchCols;
+    // DMA role: piece e = i * 256 + tid of the halo: halo pixel e >> 3, slot e & 7 holds source piece (e & 7) ^ ((pixel >> 1) & 7)
+    g.ok_mask = 0; g.live_mask = 0;
+#pragma unroll
+    for (int i = 0; i < HL::kDma; ++i) {
+      const int e = i * kThreads + g.tid;
+      g.off0[i] = 0;
+      if (e < HL::kPieces) {
+        g.live_mask |= 1u << i;
+        const int hpix = e >> 3, piece = (e & 7) ^ ((hpix >> 1) & 7);
+        const int iy = y0 - DIL + hpix / HL::kW, ix = x0 - DIL + hpix % HL::kW;
+        if (iy >= 0 && iy < a.H && ix >= 0 && ix < a.W) {
+          g.ok_mask |= 1u << i;
+          g.off0[i] = ((pimg * a.H + iy) * a.W + ix) * a.Cin + 4 * piece;
+        }
+      }
+    }
+
+    f32x16 acc0, acc1;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) { acc0[i] = 0.f; acc1[i] = 0.f; }
+
+    if (kc0 < kc_end) {
+      // prologue: the whole halo of chunk kc0 and the weights of (kc0, tap 0); parities as if kc0 were even
+      halo_issue<DIL, 0, 0, 0, HL::kDma>(S, a.x, wblock, g, kc0, true, kc0, true);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    for (int kc = kc0; kc < kc_end; kc += 2) {
+      halo_chunk<DIL, 0>(S, a.x, wblock, g, kc, kc_end, acc0, acc1);
+      if (kc + 1 < kc_end) halo_chunk<DIL, 1>(S, a.x, wblock, g, kc + 1, kc_end, acc0, acc1);
+    }
+
+    bool finish = true;       // does this workgroup write the tile's output
+    if (balanced && !(kc0 == 0 && kc_end == cpt)) {
+      // a shared tile: leave the accumulators in this piece's slot; conv_split3x3_fixup_kernel adds the pieces in order
+      const int first_wg = (txy * cpt) / a.units_per_wg;
+      float* slot = a.part + ((size_t)txy * a.max_pieces + (wg - first_wg)) * (kThreads * 32);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { slot[r * kThreads + g.tid] = acc0[r]; slot[(16 + r) * kThreads + g.tid] = acc1[r]; }
+      finish = false;
+    }
+
+    if (finish) {
+      const int P = a.N * a.H * a.W;
+      float* part = (!balanced && a.part) ? a.part + (size_t)tile.z * P * a.Cout : nullptr;
+      halo_epilogue(a, part, pimg, y0, x0, tile.y, g.wave, g.lane, acc0, acc1);
+    }
+    if (!balanced) break;
+    u += kc_end - kc0;
+    if (u >= u_end) break;
   }
 #endif
 }

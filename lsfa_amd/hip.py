@@ -14,7 +14,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "liblsfa_hip.so")
 
 OP_NAMES = ["psroi_pool", "rfcn_head", "warp_bilinear", "aggregate", "proposal", "nms", "det_postprocess",
-            "deform_im2col", "scale_shift_relu", "conv_nhwc"]
+            "deform_im2col", "scale_shift_relu", "conv_nhwc", "stem"]
 
 
 class LsfaError(RuntimeError):
@@ -423,6 +423,53 @@ def conv_nhwc(x, w_kc, bias, kh, kw, stride=1, pad=0, dil=1, relu=False, out=Non
                                           _ptr(out2), _ptr(scale2), _ptr(shift2), _ptr(ws), ctypes.c_size_t(need), _stream()),
            "lsfa_conv_nhwc_fused_fwd")
     return out if out2 is None else (out, out2)
+
+
+@_on_tensor_device
+def avgpool_nchw(x, k, out=None):
+    """(N, C, H, W) float32 -> (N, C, ceil(H/k), ceil(W/k)): k x k / k average, edge windows clipped (lsfa_avgpool_nchw)."""
+    x = _f32c(x, "x")
+    N, C, H, W = x.shape
+    Ho, Wo = -(-H // k), -(-W // k)
+    if out is None:
+        out = torch.empty((N, C, Ho, Wo), device=x.device, dtype=torch.float32)
+    _check(lib().lsfa_avgpool_nchw(_ptr(x), _ci(N), _ci(C), _ci(H), _ci(W), _ci(k), _ptr(out), _stream()), "lsfa_avgpool_nchw")
+    return out
+
+
+def stem_weight_layout(weight):
+    """conv0's (64, 3, 7, 7) weight (bn0 folded) -> the (3, 7, 7, 64) layout lsfa_stem_conv7x7s2 reads."""
+    co, ci, kh, kw = weight.shape
+    if (co, ci, kh, kw) != (64, 3, 7, 7):
+        raise LsfaError("stem_weight_layout: expected a (64, 3, 7, 7) weight, got %s" % (tuple(weight.shape),))
+    return weight.float().permute(1, 2, 3, 0).contiguous()
+
+
+@_on_tensor_device
+def stem_conv(x, w_l, bias, in_scale=None, in_shift=None, out=None):
+    """bn_data + conv0 (7x7, stride 2, pad 3) + bias + ReLU: x (N, 3, H, W) NCHW -> (N, Ho, Wo, 64) channels-last."""
+    x, w_l = _f32c(x, "x"), _f32c(w_l, "w_l")
+    N, C, H, W = x.shape
+    if C != 3 or tuple(w_l.shape) != (3, 7, 7, 64):
+        raise LsfaError("stem_conv: x must have 3 channels and w_l the (3, 7, 7, 64) layout")
+    Ho, Wo = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+    if out is None:
+        out = torch.empty((N, Ho, Wo, 64), device=x.device, dtype=torch.float32)
+    _check(lib().lsfa_stem_conv7x7s2(_ptr(x), _ci(N), _ci(H), _ci(W), _ptr(in_scale), _ptr(in_shift), _ptr(w_l), _ptr(bias),
+                                     _ptr(out), _stream()), "lsfa_stem_conv7x7s2")
+    return out
+
+
+@_on_tensor_device
+def maxpool3x3s2_nhwc(x, out=None):
+    """(N, H, W, C) float32 channels-last -> (N, (H-1)//2+1, (W-1)//2+1, C): 3x3, stride 2, pad 1 max pooling."""
+    x = _f32c(x, "x")
+    N, H, W, C = x.shape
+    Ho, Wo = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+    if out is None:
+        out = torch.empty((N, Ho, Wo, C), device=x.device, dtype=torch.float32)
+    _check(lib().lsfa_maxpool3x3s2_nhwc(_ptr(x), _ci(N), _ci(H), _ci(W), _ci(C), _ptr(out), _stream()), "lsfa_maxpool3x3s2_nhwc")
+    return out
 
 
 class SplitWeight(object):

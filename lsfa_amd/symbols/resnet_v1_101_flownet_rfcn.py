@@ -40,13 +40,14 @@ _CONV1X1_MIOPEN = _os.environ.get('LSFA_CONV1X1_MIOPEN', '0') == '1'   # experim
 # which 3x3 convolutions of the channels-last sub-networks run on the own fp32-MFMA implicit GEMM (lsfa_conv_nhwc_fwd,
 # bias + ReLU in its epilogue) instead of the library's kernel + a separate bias/ReLU pass: comma list of backbone, small,
 # fuse (the small net's 256 -> 1024 fuse_reduce_add convolution) and feat (feat_conv_3x3), both on the split-bf16 kernel;
+# stem (bn_data + conv0 + relu0 + pool0 of both ResNets and the 4x4 average pooling in front of the small net: stem.hip);
 # `conv3` additionally runs the 1x1 conv3 of those units on it with the shortcut add and the next unit's bn1 + ReLU fused
 # (lsfa_conv_nhwc_fused_fwd) - measured SLOWER (backbone 4239 -> 4983 us: the 64x64-tile kernel loses to the tuned library GEMM on
 # K = 256 by more than the saved BN pass), so it is off by default.
 # measured at 1000x600 (tools/key_sections.py, hipGraph replay): backbone 4327 -> 4239 us with it, small net 256 -> 289 us:
 # the backbone's stage 2/3 units gain (epilogue fusion + deterministic tap split), the small net's 64-channel stage 1 and the
 # 256 -> 1024 fuse convolution do not
-_OWN_CONV = set(x for x in _os.environ.get('LSFA_OWN_CONV', 'backbone,fuse,feat').split(',') if x)
+_OWN_CONV = set(x for x in _os.environ.get('LSFA_OWN_CONV', 'backbone,fuse,feat,stem').split(',') if x)
 # the own 3x3 convolutions on the bf16 matrix pipe with exactly split fp32 operands (lsfa_conv_split_fwd: fp32 in, fp32
 # accumulate, error against float64 equal to the fp32-MFMA kernel's) instead of the fp32 matrix instructions.  Measured per
 # conv2 at 1000x600 (tools/lab/conv_split_lab.py): res4 32.7 vs 40.7 us, res3 31.4 vs 50.4, res2 34.6 vs 51.3.
@@ -445,11 +446,19 @@ class Executor(object):
         own_conv: conv2 (3x3 + folded bn3 bias + ReLU) on lsfa_conv_nhwc_fwd instead of library conv + bias/ReLU pass."""
         net.prepare_channels_last()
         cl = torch.channels_last
-        x = hip.scale_shift_relu(x, net.bn_data[0], net.bn_data[1], relu=False).contiguous(memory_format=cl)
-        y = F.conv2d(x, net.conv0_w_cl, None, stride=2, padding=3)
-        r = self._rows(y)
-        hip.scale_shift_relu_cl(r, self._ones(r.shape[1]), net.conv0_b, relu=True, out=r)
-        x4 = F.max_pool2d(self._map(r, y.shape[2], y.shape[3]), 3, 2, 1)
+        if 'stem' in _OWN_CONV and x.dtype == torch.float32 and net.conv0_w.dtype == torch.float32 and x.shape[1] == 3:
+            # bn_data + conv0 + bn0 + relu0 and pool0 as two own launches (lsfa_stem_conv7x7s2, lsfa_maxpool3x3s2_nhwc)
+            # instead of five library ones (affine pass, layout copy, convolution, bias + ReLU pass, max pool)
+            if not hasattr(net, 'conv0_w_l'):
+                net.conv0_w_l = hip.stem_weight_layout(net.conv0_w)
+            y = hip.stem_conv(x, net.conv0_w_l, net.conv0_b, net.bn_data[0], net.bn_data[1])
+            x4 = hip.maxpool3x3s2_nhwc(y).permute(0, 3, 1, 2)
+        else:
+            x = hip.scale_shift_relu(x, net.bn_data[0], net.bn_data[1], relu=False).contiguous(memory_format=cl)
+            y = F.conv2d(x, net.conv0_w_cl, None, stride=2, padding=3)
+            r = self._rows(y)
+            hip.scale_shift_relu_cl(r, self._ones(r.shape[1]), net.conv0_b, relu=True, out=r)
+            x4 = F.max_pool2d(self._map(r, y.shape[2], y.shape[3]), 3, 2, 1)
         dilate = 1
         units = [u for u in net.units if u['stage'] <= stages]
         fuse3 = own_conv and 'conv3' in _OWN_CONV
@@ -728,7 +737,10 @@ class Executor(object):
         fuse_reduce_add.  It depends on the frame image only, so a caller may compute it ahead of the
         rest of the frame (lsfa_amd/core/graphs.py overlaps it with the previous frame's tail)."""
         with torch.no_grad():
-            img = F.avg_pool2d(data, 4, 4, ceil_mode=True)
+            if 'stem' in _OWN_CONV and 'small' in self.cl and data.dtype == torch.float32:
+                img = hip.avgpool_nchw(data, 4)
+            else:
+                img = F.avg_pool2d(data, 4, 4, ceil_mode=True)
             if 'small' in self.cl:
                 if not hasattr(self, 'fuse_w_cl'):
                     self.fuse_w_cl = self.fuse_w.contiguous(memory_format=torch.channels_last)

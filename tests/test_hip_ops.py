@@ -714,6 +714,46 @@ def test_conv_nhwc_mfma_vs_torch(hip, cfg):
     assert (g2 < 0).any()
 
 
+# ------------------------------------------------------------------ ResNet stem ----
+@pytest.mark.parametrize("shape", [(1, 600, 1000), (1, 150, 250), (2, 37, 50), (1, 9, 8)])
+def test_stem_conv_pool_vs_torch(hip, shape):
+    """bn_data + conv0 (7x7/2, pad 3, bn0 folded) + ReLU as one launch, then pool0 (3x3/2 max, pad 1): against torch in
+    float64 (the convolution is an fp32 FMA chain of 147 terms: 2e-6*sqrt(147) of the output scale) and, for the pooling,
+    exactly."""
+    import torch.nn.functional as F
+    N, H, W = shape
+    rs = np.random.RandomState(H + W)
+    x = (rs.rand(N, 3, H, W) * 255).astype(np.float32)
+    w = (rs.randn(64, 3, 7, 7) * 0.05).astype(np.float32)
+    b = rs.randn(64).astype(np.float32)
+    sc, sh = rs.uniform(0.01, 0.03, 3).astype(np.float32), rs.uniform(-3, -1, 3).astype(np.float32)
+    xa = torch.from_numpy(x).double() * torch.from_numpy(sc).double().view(1, 3, 1, 1) + torch.from_numpy(sh).double().view(1, 3, 1, 1)
+    want = torch.relu(F.conv2d(xa, torch.from_numpy(w).double(), torch.from_numpy(b).double(), stride=2, padding=3))
+    got = hip.stem_conv(t(x), hip.stem_weight_layout(t(w)), t(b), t(sc), t(sh))
+    assert got.shape == (N, want.shape[2], want.shape[3], 64)
+    g = got.permute(0, 3, 1, 2).cpu().double()
+    assert float((g - want).abs().max()) < 2e-6 * np.sqrt(147) * max(float(want.abs().max()), 1.0)
+    # without bn_data
+    want0 = torch.relu(F.conv2d(torch.from_numpy(x).double(), torch.from_numpy(w).double(), None, stride=2, padding=3))
+    got0 = hip.stem_conv(t(x), hip.stem_weight_layout(t(w)), None).permute(0, 3, 1, 2).cpu().double()
+    assert float((got0 - want0).abs().max()) < 2e-6 * np.sqrt(147) * max(float(want0.abs().max()), 1.0)
+    pooled = hip.maxpool3x3s2_nhwc(got)
+    ref = F.max_pool2d(got.permute(0, 3, 1, 2), 3, 2, 1)
+    assert torch.equal(pooled.permute(0, 3, 1, 2), ref)
+
+
+@pytest.mark.parametrize("shape,k", [((1, 3, 600, 1000), 4), ((2, 3, 37, 50), 4), ((1, 5, 9, 7), 2)])
+def test_avgpool_nchw_vs_torch_ceil_mode(hip, shape, k):
+    """mx Pooling(avg, pooling_convention='full') = torch avg_pool2d(ceil_mode=True) without padding: edge windows are
+    clipped to the image and divided by what they hold."""
+    import torch.nn.functional as F
+    x = t(np.random.RandomState(shape[2]).rand(*shape).astype(np.float32) * 255)
+    got = hip.avgpool_nchw(x, k)
+    want = F.avg_pool2d(x.double(), k, k, ceil_mode=True)
+    assert got.shape == want.shape
+    assert float((got.double() - want).abs().max()) < 1e-4
+
+
 # ------------------------------------------------------------------ split-bf16 convolution ----
 SPLIT_CFGS = [
     dict(N=1, H=38, W=63, Cin=256, Cout=256, k=3, stride=1, dil=1),      # res4 conv2 (K cut into slices)
@@ -723,7 +763,9 @@ SPLIT_CFGS = [
     dict(N=2, H=13, W=9, Cin=64, Cout=64, k=3, stride=1, dil=1),         # batch 2, ragged pixel tile, one chunk per tap
     dict(N=1, H=20, W=17, Cin=96, Cout=128, k=1, stride=1, dil=1),       # 1x1, odd chunk count
     dict(N=1, H=38, W=63, Cin=256, Cout=1024, k=1, stride=1, dil=1),     # res4 conv3 shape
-    dict(N=1, H=38, W=63, Cin=256, Cout=1024, k=3, stride=1, dil=1),     # the fuse convolution (halo kernel, no K cut)
+    dict(N=1, H=38, W=63, Cin=256, Cout=1024, k=3, stride=1, dil=1),     # the fuse convolution (halo kernel, balanced mode:
+                                                                         # 512 workgroups x 5 (tile, chunk) units, shared tiles)
+    dict(N=1, H=30, W=70, Cin=192, Cout=1024, k=3, stride=1, dil=2),     # balanced mode, dilation 2, 6 chunks per tile
     dict(N=1, H=21, W=40, Cin=256, Cout=64, k=3, stride=1, dil=6),       # feat_conv_3x3's dilation (general kernel)
     dict(N=1, H=38, W=63, Cin=512, Cout=1024, k=3, stride=1, dil=6),     # 304 workgroups: K cut into 5 by the rounds model
 ]

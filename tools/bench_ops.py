@@ -103,6 +103,20 @@ def main():
     us = timeit(lambda: hip.conv_split(x2k, sw, b1k, 1, 6, 6, relu=True, nchw=True), max(args.iters // 4, 3))
     out['conv_split 3x3 d6 2048->1024 @38x63 (feat_conv_3x3)'] = dict(us=round(us, 2), TFLOPs=round(2 * HW * 1024 * 18432 / us / 1e6, 1))
     del sw, x2k
+    # ResNet stem: backbone (600x1000) and small net (frame / 4)
+    img = torch.rand(1, 3, 600, 1000, device=dev) * 255
+    w0 = hip.stem_weight_layout(torch.randn(64, 3, 7, 7, device=dev) * 0.05)
+    b0, s3, t3 = torch.randn(64, device=dev), torch.rand(3, device=dev), torch.rand(3, device=dev)
+    us = timeit(lambda: hip.avgpool_nchw(img, 4), args.iters)
+    out['avgpool_nchw 4x4 (600x1000)'] = dict(us=round(us, 2), GBps=round(img.numel() * 4 * 17 / 16 / us / 1e3, 1))
+    small = hip.avgpool_nchw(img, 4)
+    for tag, xin in (('stem_conv7x7s2 (600x1000)', img), ('stem_conv7x7s2 (150x250)', small)):
+        us = timeit(lambda: hip.stem_conv(xin, w0, b0, s3, t3), args.iters)
+        ho, wo = (xin.shape[2] - 1) // 2 + 1, (xin.shape[3] - 1) // 2 + 1
+        out[tag] = dict(us=round(us, 2), TFLOPs=round(2 * ho * wo * 64 * 147 / us / 1e6, 2))
+        yy = hip.stem_conv(xin, w0, b0, s3, t3)
+        us = timeit(lambda: hip.maxpool3x3s2_nhwc(yy), args.iters)
+        out[tag.replace('stem_conv7x7s2', 'maxpool3x3s2_nhwc')] = dict(us=round(us, 2))
     # PSROI / head
     cls_map, box_map = torch.randn(1, 31 * 49, H, W, device=dev), torch.randn(1, 8 * 49, H, W, device=dev)
     rois_np = np.zeros((300, 5), np.float32)

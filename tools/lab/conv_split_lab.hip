@@ -7,7 +7,7 @@ extern "C" int conv_split_lab_run(const float* x, const void* wfrag, float* part
                                   int slices, long long* host_stamps8) {
   const int chunk_total = k * k * (Cin / 32);
   Args a = {x, (const uint4*)wfrag, nullptr, part, part, N, H, W, Cin, Cout, k, k, 1, k / 2, 1, H, W, 0,
-            (chunk_total + slices - 1) / slices, nullptr, nullptr, nullptr, nullptr};
+            (chunk_total + slices - 1) / slices, nullptr, nullptr, nullptr, nullptr, 0, 0, 0};
   const int P = N * H * W;
   const int nx = (P + kWgPix - 1) / kWgPix, ny = Cout / kWgCh;
   const int tiles = nx * ny * slices;

@@ -109,8 +109,12 @@ class Runner(object):
                 self.mv[kf + i] = cat(lambda c: c.motion_vector(kf + i, kf, device))
                 self.res[kf + i] = cat(lambda c: c.res_diff(kf + i, device))
         R, ncls = cfg.TEST.RPN_POST_NMS_TOP_N, cfg.dataset.NUM_CLASSES
-        self.host_dets = torch.empty((self.K, self.B, ncls, R, 5), dtype=torch.float64).pin_memory()
-        self.host_counts = torch.empty((self.K, self.B, ncls), dtype=torch.int32).pin_memory()
+        # one pinned slot per frame of an interval; dets and counts back to back like the device side keeps them
+        # (lsfa_amd/core/graphs.py _alloc_post), so a frame's results leave the device with ONE copy
+        n_d, n_c = self.B * ncls * R * 5, (self.B * ncls * 4 + 7) // 8
+        self.host_flat = torch.empty((self.K, n_d + n_c), dtype=torch.float64).pin_memory()
+        self.host_dets = self.host_flat[:, :n_d].view(self.K, self.B, ncls, R, 5)
+        self._n_d, self.ncls = n_d, ncls
         from lsfa_amd.core.graphs import FrameGraphs, FramePipeline
         if args.lanes > 0:
             self.fg = FramePipeline(self.key, self.cur, cfg, args.height, args.width, device,
@@ -130,9 +134,21 @@ class Runner(object):
         self.fg.first_frame(self.frames[0])
         self.fg.capture()
 
+    def host_counts_of(self, slot):
+        return self.host_flat[slot, self._n_d:].view(torch.int32)[:self.B * self.ncls].view(self.B, self.ncls)
+
+    @property
+    def host_counts(self):
+        """(K, B, ncls) int32: the per-class detection counts of the last interval's frames (a copy)."""
+        return torch.stack([self.host_counts_of(k) for k in range(self.K)])
+
     def _deliver(self, bufs, slot):
-        self.host_dets[slot].copy_(bufs[0].view(self.host_dets[slot].shape), non_blocking=True)
-        self.host_counts[slot].copy_(bufs[1].view(self.host_counts[slot].shape), non_blocking=True)
+        flat = getattr(bufs[0], 'lsfa_flat', None)
+        if flat is not None and flat.numel() == self.host_flat.shape[1]:
+            self.host_flat[slot].copy_(flat, non_blocking=True)
+        else:
+            self.host_dets[slot].copy_(bufs[0].view(self.host_dets[slot].shape), non_blocking=True)
+            self.host_counts_of(slot).copy_(bufs[1].view(self.B, self.ncls), non_blocking=True)
 
     def step(self, s, fg=None):
         """One key-frame interval: key frame (flag 1) + K-1 non-key frames (flag 2)."""

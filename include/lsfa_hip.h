@@ -314,6 +314,8 @@ int lsfa_mv_residual(const unsigned char* bgr_cur, const unsigned char* bgr_ref,
  * ------------------------------------------------------------------------ */
 int lsfa_stream_create(void** stream_out, int high_priority);
 int lsfa_stream_destroy(void* stream);
+/* up to four device-to-device copies of 4-byte elements (elems4[k] of them, dst[k] <- src[k]) as one launch */
+int lsfa_copy_many(int njobs, void* const* dst, const void* const* src, const long* elems4, void* stream);
 
 /* ------------------------------------------------------------------------ *
  * Live per-op timing with HIP events on the launch stream (bench.py's roofline leg).

@@ -26,11 +26,30 @@ from lsfa_amd.core import streams
 def _alloc_post(batch, ncls, R, device):
     """Detection output buffers of one frame slot: (B, ncls, R, 5) f64, (B, ncls) i32, (B, ncls, R) i32.
     Returns (all, public) where `public` drops the batch axis when B == 1 (the shapes callers had before
-    several clips could advance together)."""
-    full = (torch.zeros((batch, ncls, R, 5), dtype=torch.float64, device=device),
-            torch.zeros((batch, ncls), dtype=torch.int32, device=device),
-            torch.full((batch, ncls, R), -1, dtype=torch.int32, device=device))
-    return full, (tuple(t[0] for t in full) if batch == 1 else full)
+    several clips could advance together).  dets and counts live back to back in ONE allocation, reachable as
+    `dets.lsfa_flat` (float64 view of both): a consumer takes a frame's results off the device with one copy."""
+    n_d = batch * ncls * R * 5
+    n_c = (batch * ncls * 4 + 7) // 8                       # the counts, in float64 slots
+    flat = torch.zeros(n_d + n_c, dtype=torch.float64, device=device)
+    dets = flat[:n_d].view(batch, ncls, R, 5)
+    counts = flat[n_d:].view(torch.int32)[:batch * ncls].view(batch, ncls)
+    full = (dets, counts, torch.full((batch, ncls, R), -1, dtype=torch.int32, device=device))
+    public = tuple(t[0] for t in full) if batch == 1 else full
+    full[0].lsfa_flat = flat
+    public[0].lsfa_flat = flat
+    return full, public
+
+
+def _stage_inputs(jobs):
+    """Frame inputs into the static buffers a captured graph reads: one launch (lsfa_copy_many) when the tensors allow
+    it (same device, fp32, contiguous, equal shapes), else plain copies."""
+    ok = all(s.is_cuda and s.device == d.device and s.dtype == d.dtype and d.element_size() == 4 and s.shape == d.shape and
+             s.is_contiguous() and d.is_contiguous() for d, s in jobs)
+    if ok and len(jobs) <= 4:
+        hip.copy_many(jobs)
+    else:
+        for d, s in jobs:
+            d.copy_(s)
 
 
 def _post_all(out, full, cfg, h, w, scale, thresh):
@@ -217,15 +236,14 @@ class FrameGraphs(object):
     def cur_frame(self, data, motion_vector, res_diff, next_data=None):
         """flag 2: a non-key frame.  With prefetch on, the small-net feature of THIS frame must have
         been produced by the previous call (pass this frame's image as its `next_data`)."""
-        self.data.copy_(data)
+        jobs = [(self.data, data), (self.mv, motion_vector), (self.res, res_diff)]
         if self.prefetch:
             if not self._small_valid:
                 # nobody computed this frame's small-net feature ahead of time (the previous call had no
                 # `next_data`, e.g. a first_frame without it): compute it now instead of using a stale one
                 self.small_cur.copy_(self.cur.small_net_feature(data))
-            self.data_next.copy_(next_data if next_data is not None else data)
-        self.mv.copy_(motion_vector)
-        self.res.copy_(res_diff)
+            jobs.append((self.data_next, next_data if next_data is not None else data))
+        _stage_inputs(jobs)
         if self.use_graphs:
             self.cur_graph.replay()
         else:

@@ -105,9 +105,14 @@ class HostRing(object):
 
     def __init__(self, all_boxes, num_classes, R, slots=32):
         self.all_boxes, self.num_classes = all_boxes, num_classes
-        self.slots = [dict(dets=torch.empty((num_classes, R, 5), dtype=torch.float64).pin_memory(),
-                           counts=torch.empty(num_classes, dtype=torch.int32).pin_memory(),
-                           event=torch.cuda.Event(), idx=-1) for _ in range(slots)]
+        # dets and counts back to back in one pinned allocation per slot, as the device side keeps them
+        # (core/graphs.py _alloc_post): a frame's results then cross the bus as ONE copy
+        n_d, n_c = num_classes * R * 5, (num_classes * 4 + 7) // 8
+        self.slots = []
+        for _ in range(slots):
+            flat = torch.empty(n_d + n_c, dtype=torch.float64).pin_memory()
+            self.slots.append(dict(flat=flat, dets=flat[:n_d].view(num_classes, R, 5),
+                                   counts=flat[n_d:].view(torch.int32)[:num_classes], event=torch.cuda.Event(), idx=-1))
         self.n = 0
 
     def _drain(self, slot):
@@ -124,8 +129,12 @@ class HostRing(object):
         slot = self.slots[self.n % len(self.slots)]
         self.n += 1
         self._drain(slot)
-        slot['dets'].copy_(dets, non_blocking=True)
-        slot['counts'].copy_(counts, non_blocking=True)
+        flat = getattr(dets, 'lsfa_flat', None)
+        if flat is not None and flat.numel() == slot['flat'].numel():
+            slot['flat'].copy_(flat, non_blocking=True)
+        else:
+            slot['dets'].copy_(dets, non_blocking=True)
+            slot['counts'].copy_(counts, non_blocking=True)
         slot['event'].record(torch.cuda.current_stream(dets.device))
         slot['idx'] = idx
 
@@ -156,9 +165,8 @@ def pred_eval(gpu_id, key_predictor, cur_predictor, test_data, imdb, cfg, vis=Fa
             ring = HostRing(all_boxes, num_classes, R)
             # one set of device output buffers for every frame: the copy to the host ring is queued on the
             # same stream right after the post-processing, so the next frame may overwrite them
-            post_out = (torch.zeros((num_classes, R, 5), dtype=torch.float64, device=dev),
-                        torch.zeros(num_classes, dtype=torch.int32, device=dev),
-                        torch.full((num_classes, R), -1, dtype=torch.int32, device=dev))
+            from lsfa_amd.core.graphs import _alloc_post
+            post_out = _alloc_post(1, num_classes, R, dev)[1]     # dets + counts in one allocation: one copy per frame
         t1 = time.time() - t
         t = time.time()
         scales = [iim_info[0, 2] for iim_info in im_info]

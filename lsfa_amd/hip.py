@@ -425,6 +425,26 @@ def conv_nhwc(x, w_kc, bias, kh, kw, stride=1, pad=0, dil=1, relu=False, out=Non
     return out if out2 is None else (out, out2)
 
 
+def copy_many(pairs):
+    """[(dst, src), ...] (at most 4; same shapes, contiguous, 4-byte dtypes, one device) as ONE launch on the current stream."""
+    pairs = [(d, s) for d, s in pairs if d.numel()]
+    if not pairs:
+        return
+    n = len(pairs)
+    if n > 4:
+        raise LsfaError("copy_many: at most 4 copies per launch")
+    for d, s in pairs:
+        if d.shape != s.shape or d.dtype != s.dtype or d.element_size() != 4 or not (d.is_contiguous() and s.is_contiguous()) \
+                or d.device != s.device or d.device != pairs[0][0].device:
+            raise LsfaError("copy_many: %s <- %s: need equal shapes, 4-byte dtype, contiguous, one device"
+                            % (tuple(d.shape), tuple(s.shape)))
+    dst = (ctypes.c_void_p * n)(*[d.data_ptr() for d, _ in pairs])
+    src = (ctypes.c_void_p * n)(*[s.data_ptr() for _, s in pairs])
+    cnt = (ctypes.c_long * n)(*[d.numel() for d, _ in pairs])
+    with torch.cuda.device(pairs[0][0].device):
+        _check(lib().lsfa_copy_many(_ci(n), dst, src, cnt, _stream()), "lsfa_copy_many")
+
+
 @_on_tensor_device
 def avgpool_nchw(x, k, out=None):
     """(N, C, H, W) float32 -> (N, C, ceil(H/k), ceil(W/k)): k x k / k average, edge windows clipped (lsfa_avgpool_nchw)."""

@@ -714,6 +714,23 @@ def test_conv_nhwc_mfma_vs_torch(hip, cfg):
     assert (g2 < 0).any()
 
 
+def test_copy_many_is_one_launch_of_plain_copies(hip):
+    """lsfa_copy_many: a frame's image, motion vectors and residual into the graph's static buffers as one launch."""
+    rs = np.random.RandomState(3)
+    srcs = [t(rs.randn(1, 3, 60, 100).astype(np.float32)), t(rs.randn(1, 2, 38, 63).astype(np.float32)),
+            t(rs.randn(1, 3, 38, 63).astype(np.float32)), t(rs.randint(0, 99, (7,)).astype(np.int32))]
+    dsts = [torch.zeros_like(x) for x in srcs]
+    hip.copy_many(list(zip(dsts, srcs)))
+    for d, s_ in zip(dsts, srcs):
+        assert torch.equal(d, s_)
+    hip.copy_many([(dsts[1], srcs[1] * 2)])
+    assert torch.equal(dsts[1], srcs[1] * 2) and torch.equal(dsts[0], srcs[0])
+    with pytest.raises(hip.LsfaError):
+        hip.copy_many([(dsts[0], srcs[1])])
+    with pytest.raises(hip.LsfaError):
+        hip.copy_many([(dsts[0].double(), srcs[0].double())])
+
+
 # ------------------------------------------------------------------ ResNet stem ----
 @pytest.mark.parametrize("shape", [(1, 600, 1000), (1, 150, 250), (2, 37, 50), (1, 9, 8)])
 def test_stem_conv_pool_vs_torch(hip, shape):

@@ -166,7 +166,7 @@ __global__ __launch_bounds__(kClassThreads) void det_class_kernel(
 
   // 3. suppression mask over sorted positions, one wave per 64x64 tile of the upper triangle: bit c of
   //    mask[a][w] <=> position 64w+c > a and the pair suppresses.  The lane owns row a (box in registers), the
-  //    column boxes sit one per lane and are broadcast with readlane, the word is built in a register: no
+  //    column boxes are read from LDS at wave-uniform addresses, the word is built in a register: no
   //    atomics, no zero fill (words left of the diagonal are never read).  Diagonal tiles also produce
   //    colw[c] = the earlier positions of c's own block that suppress c (64 ballots).
   const int nblk = (m + 63) / 64;
@@ -182,29 +182,48 @@ __global__ __launch_bounds__(kClassThreads) void det_class_kernel(
     const double area_a = sarea[ar];
     const int c0 = cb * 64, ncol = min(64, m - c0);
     const bool diag = rb == cb;
-    // lane c holds column box c0 + c; the loop broadcasts it with readlane (no LDS latency inside the loop)
-    const int cc = min(c0 + lane, m - 1);
-    const double cx1 = sbox[cc * 4], cy1 = sbox[cc * 4 + 1], cx2 = sbox[cc * 4 + 2], cy2 = sbox[cc * 4 + 3];
-    const double carea = sarea[cc];
+    // column boxes are read from LDS at wave-uniform addresses (a broadcast), four columns per step so that the reads
+    // of a step are in flight together; the "cannot tell without dividing" case is collected per lane and, if any lane
+    // of the wave met it, the tile is redone with the division (rare)
     uint64_t bits = 0, tbits = 0;
-    for (int c = 0; c < ncol; ++c) {
-      const double xx1 = fmax(ax1, readlane_f64(cx1, c)), yy1 = fmax(ay1, readlane_f64(cy1, c));
-      const double xx2 = fmin(ax2, readlane_f64(cx2, c)), yy2 = fmin(ay2, readlane_f64(cy2, c));
-      const double ww = fmax(0.0, xx2 - xx1 + 1), hh = fmax(0.0, yy2 - yy1 + 1);
-      const double inter = ww * hh;
-      const double uni = area_a + readlane_f64(carea, c) - inter;
-      const double d = fma(-nms.thresh, uni, inter);
-      const bool pos = d > 0.0, clear = d >= nms.thresh_eps * uni;
-      bool p = pos && clear;
-      const bool unsure = !nms.fast || !(uni > 0.0) || (pos && !clear);
-      if (__builtin_expect(__any(unsure), 0)) {       // wave-uniform, rare: the sliver around the threshold
-        if (unsure) p = !(inter / uni <= nms.thresh);
+    bool unsure = !nms.fast;
+    for (int c4 = 0; c4 < ncol; c4 += 4) {
+      double bx1[4], by1[4], bx2[4], by2[4], bar[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int q = min(c0 + c4 + u, m - 1);
+        bx1[u] = sbox[q * 4]; by1[u] = sbox[q * 4 + 1]; bx2[u] = sbox[q * 4 + 2]; by2[u] = sbox[q * 4 + 3];
+        bar[u] = sarea[q];
       }
-      p = p && a_ok && (!diag || c > lane);
-      bits |= (uint64_t)p << c;
-      if (diag) {
-        const uint64_t cw = __ballot(p);
-        if (lane == c) tbits = cw;
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int c = c4 + u;
+        const double ww = fmax(0.0, fmin(ax2, bx2[u]) - fmax(ax1, bx1[u]) + 1), hh = fmax(0.0, fmin(ay2, by2[u]) - fmax(ay1, by1[u]) + 1);
+        const double inter = ww * hh;
+        const double uni = area_a + bar[u] - inter;
+        const double d = fma(-nms.thresh, uni, inter);
+        const bool pos = d > 0.0, clear = d >= nms.thresh_eps * uni;
+        unsure = unsure || ((!(uni > 0.0) || (pos && !clear)) && c < ncol);
+        const bool p = pos && clear && a_ok && c < ncol && (!diag || c > lane);
+        bits |= (uint64_t)p << c;
+        if (diag) {
+          const uint64_t cw = __ballot(p);
+          if (lane == c) tbits = cw;
+        }
+      }
+    }
+    if (__builtin_expect(__any(unsure), 0)) {       // the sliver around the threshold, or a degenerate union: divide
+      bits = 0; tbits = 0;
+      for (int c = 0; c < ncol; ++c) {
+        const double* q = sbox + (size_t)(c0 + c) * 4;
+        const double ww = fmax(0.0, fmin(ax2, q[2]) - fmax(ax1, q[0]) + 1), hh = fmax(0.0, fmin(ay2, q[3]) - fmax(ay1, q[1]) + 1);
+        const double inter = ww * hh;
+        const bool p = !(inter / (area_a + sarea[c0 + c] - inter) <= nms.thresh) && a_ok && (!diag || c > lane);
+        bits |= (uint64_t)p << c;
+        if (diag) {
+          const uint64_t cw = __ballot(p);
+          if (lane == c) tbits = cw;
+        }
       }
     }
     if (a_ok) {

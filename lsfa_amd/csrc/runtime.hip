@@ -75,14 +75,21 @@ extern "C" int lsfa_stream_create(void** stream_out, int high_priority) {
 // Up to four device-to-device copies of 4-byte elements as ONE launch: a frame's image, motion vectors and residual go
 // into the static buffers a captured graph reads from; three separate copy nodes are three ~5 us latencies per frame.
 namespace {
-struct CopyJobs { void* dst[4]; const void* src[4]; long end[4]; };     // end = running total of elements
+struct CopyJobs { void* dst[4]; const void* src[4]; long end[4]; long elems[4]; };     // end = running total of 4-element groups
 __global__ __launch_bounds__(256) void copy_many_kernel(CopyJobs j, int njobs) {
   const long i = (long)blockIdx.x * 256 + threadIdx.x;
   if (i >= j.end[njobs - 1]) return;
   int k = 0;
   while (i >= j.end[k]) ++k;
-  const long o = i - (k ? j.end[k - 1] : 0);
-  reinterpret_cast<uint32_t*>(j.dst[k])[o] = reinterpret_cast<const uint32_t*>(j.src[k])[o];
+  const long o = (i - (k ? j.end[k - 1] : 0)) * 4;            // first element of this thread's group
+  uint32_t* d = reinterpret_cast<uint32_t*>(j.dst[k]) + o;
+  const uint32_t* s = reinterpret_cast<const uint32_t*>(j.src[k]) + o;
+  const bool vec = o + 4 <= j.elems[k] && ((reinterpret_cast<uintptr_t>(j.dst[k]) | reinterpret_cast<uintptr_t>(j.src[k])) & 15) == 0;
+  if (vec) {
+    *reinterpret_cast<uint4*>(d) = *reinterpret_cast<const uint4*>(s);
+  } else {
+    for (long e = 0; e < 4 && o + e < j.elems[k]; ++e) d[e] = s[e];
+  }
 }
 }  // namespace
 
@@ -93,10 +100,11 @@ extern "C" int lsfa_copy_many(int njobs, void* const* dst, const void* const* sr
   for (int k = 0; k < 4; ++k) {
     if (k < njobs) {
       LSFA_REQUIRE(dst[k] && src[k] && elems4[k] >= 0, "lsfa_copy_many: NULL pointer or negative size");
-      total += elems4[k];
+      total += (elems4[k] + 3) / 4;
     }
     j.dst[k] = k < njobs ? dst[k] : nullptr;
     j.src[k] = k < njobs ? src[k] : nullptr;
+    j.elems[k] = k < njobs ? elems4[k] : 0;
     j.end[k] = total;
   }
   if (total == 0) return LSFA_OK;

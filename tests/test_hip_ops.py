@@ -783,6 +783,7 @@ SPLIT_CFGS = [
     dict(N=1, H=38, W=63, Cin=256, Cout=1024, k=3, stride=1, dil=1),     # the fuse convolution (halo kernel, balanced mode:
                                                                          # 512 workgroups x 5 (tile, chunk) units, shared tiles)
     dict(N=1, H=30, W=70, Cin=192, Cout=1024, k=3, stride=1, dil=2),     # balanced mode, dilation 2, 6 chunks per tile
+    dict(N=2, H=20, W=63, Cin=256, Cout=1024, k=3, stride=1, dil=1),     # balanced mode over two images
     dict(N=1, H=21, W=40, Cin=256, Cout=64, k=3, stride=1, dil=6),       # feat_conv_3x3's dilation (general kernel)
     dict(N=1, H=38, W=63, Cin=512, Cout=1024, k=3, stride=1, dil=6),     # 304 workgroups: K cut into 5 by the rounds model
 ]

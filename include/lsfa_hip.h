@@ -263,12 +263,14 @@ int lsfa_conv_split_fwd(const float* x, int N, int H, int W, int Cin, const void
  *                          = bn_data as a per-channel affine (NULL: none), applied before the zero padding; w_l (3,7,7,64) floats =
  *                          [ci][ky][kx][co] with bn0's scale folded in; bias (64) = bn0's shift; y (N,Ho,Wo,64)
  *                          channels-last, Ho = (H-1)/2+1.  fp32 FMA chains in (ci, ky, kx) order.
- *   lsfa_maxpool3x3s2_nhwc pool0 (resnet.py:163: 3x3, stride 2, pad 1, max): x (N,H,W,C) -> y (N,(H-1)/2+1,(W-1)/2+1,C), C % 4 == 0.
+ *   lsfa_maxpool3x3s2_nhwc pool0 (resnet.py:163: 3x3, stride 2, pad 1, max): x (N,H,W,C) -> y (N,(H-1)/2+1,(W-1)/2+1,C), C % 4 == 0;
+ *                          y2 != NULL: also max(y*scale2[c] + shift2[c], 0), the first unit's bn1 + relu1 (resnet.py:78-80).
  * ------------------------------------------------------------------------ */
 int lsfa_avgpool_nchw(const float* x, int N, int C, int H, int W, int k, float* y, void* stream);
 int lsfa_stem_conv7x7s2(const float* x, int N, int H, int W, const float* in_scale, const float* in_shift,
                         const float* w_l, const float* bias, float* y, void* stream);
-int lsfa_maxpool3x3s2_nhwc(const float* x, int N, int H, int W, int C, float* y, void* stream);
+int lsfa_maxpool3x3s2_nhwc(const float* x, int N, int H, int W, int C, float* y, float* y2, const float* scale2,
+                           const float* shift2, void* stream);
 
 /* Inference BatchNorm (use_global_stats) + ReLU as one pass: y = max(x*scale[c]+shift[c], 0)
  * (sym_common.py:92-102 bn + relu of every pre-activation unit, resnet.py:70-101).

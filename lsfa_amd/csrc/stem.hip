@@ -108,9 +108,11 @@ __global__ __launch_bounds__(256) void stem_conv_kernel(const float* __restrict_
   }
 }
 
-// channels-last 3x3 / 2 max pooling, pad 1 (the padding never wins: windows are clipped); a thread = 4 channels of one output
+// channels-last 3x3 / 2 max pooling, pad 1 (the padding never wins: windows are clipped); a thread = 4 channels of one output.
+// y2 (optional): max(y * scale2[c] + shift2[c], 0), the first unit's bn1 + relu1 of the pooled map, as a second output.
 __global__ __launch_bounds__(256) void maxpool3x3s2_kernel(const float4* __restrict__ x, int N, int H, int W, int C4, int Ho, int Wo,
-                                                           float4* __restrict__ y) {
+                                                           float4* __restrict__ y, float4* __restrict__ y2,
+                                                           const float4* __restrict__ scale2, const float4* __restrict__ shift2) {
   const long i = (long)blockIdx.x * 256 + threadIdx.x;
   if (i >= (long)N * Ho * Wo * C4) return;
   const int c = (int)(i % C4);
@@ -126,6 +128,11 @@ __global__ __launch_bounds__(256) void maxpool3x3s2_kernel(const float4* __restr
       m.x = fmaxf(m.x, v.x); m.y = fmaxf(m.y, v.y); m.z = fmaxf(m.z, v.z); m.w = fmaxf(m.w, v.w);
     }
   y[i] = m;
+  if (y2) {
+    const float4 sc = scale2[c], sh = shift2[c];
+    y2[i] = make_float4(fmaxf(m.x * sc.x + sh.x, 0.f), fmaxf(m.y * sc.y + sh.y, 0.f), fmaxf(m.z * sc.z + sh.z, 0.f),
+                        fmaxf(m.w * sc.w + sh.w, 0.f));
+  }
 }
 
 }  // namespace
@@ -160,14 +167,16 @@ extern "C" int lsfa_stem_conv7x7s2(const float* x, int N, int H, int W, const fl
   return LSFA_OK;
 }
 
-extern "C" int lsfa_maxpool3x3s2_nhwc(const float* x, int N, int H, int W, int C, float* y, void* stream) {
+extern "C" int lsfa_maxpool3x3s2_nhwc(const float* x, int N, int H, int W, int C, float* y, float* y2, const float* scale2,
+                                      const float* shift2, void* stream) {
   LSFA_REQUIRE(x && y, "lsfa_maxpool3x3s2_nhwc: NULL argument");
+  LSFA_REQUIRE(!y2 || (scale2 && shift2 && y2 != y), "lsfa_maxpool3x3s2_nhwc: y2 needs scale2 / shift2 and must not alias y");
   LSFA_REQUIRE(N > 0 && H > 0 && W > 0 && C > 0 && C % 4 == 0, "lsfa_maxpool3x3s2_nhwc: bad shape (C must be a multiple of 4)");
   const int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
   const long total = (long)N * Ho * Wo * (C / 4);
   ProfScope prof(LSFA_OP_STEM, (hipStream_t)stream);
   hipLaunchKernelGGL(maxpool3x3s2_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, (const float4*)x, N, H, W,
-                     C / 4, Ho, Wo, (float4*)y);
+                     C / 4, Ho, Wo, (float4*)y, (float4*)y2, (const float4*)scale2, (const float4*)shift2);
   LSFA_LAUNCH_CHECK("lsfa_maxpool3x3s2_nhwc");
   return LSFA_OK;
 }

@@ -481,15 +481,18 @@ def stem_conv(x, w_l, bias, in_scale=None, in_shift=None, out=None):
 
 
 @_on_tensor_device
-def maxpool3x3s2_nhwc(x, out=None):
-    """(N, H, W, C) float32 channels-last -> (N, (H-1)//2+1, (W-1)//2+1, C): 3x3, stride 2, pad 1 max pooling."""
+def maxpool3x3s2_nhwc(x, out=None, scale2=None, shift2=None):
+    """(N, H, W, C) float32 channels-last -> (N, (H-1)//2+1, (W-1)//2+1, C): 3x3, stride 2, pad 1 max pooling.
+    With scale2 / shift2 (C): returns (pooled, max(pooled*scale2 + shift2, 0)) — the first unit's bn1 + relu1 in the same launch."""
     x = _f32c(x, "x")
     N, H, W, C = x.shape
     Ho, Wo = (H - 1) // 2 + 1, (W - 1) // 2 + 1
     if out is None:
         out = torch.empty((N, Ho, Wo, C), device=x.device, dtype=torch.float32)
-    _check(lib().lsfa_maxpool3x3s2_nhwc(_ptr(x), _ci(N), _ci(H), _ci(W), _ci(C), _ptr(out), _stream()), "lsfa_maxpool3x3s2_nhwc")
-    return out
+    out2 = torch.empty_like(out) if scale2 is not None else None
+    _check(lib().lsfa_maxpool3x3s2_nhwc(_ptr(x), _ci(N), _ci(H), _ci(W), _ci(C), _ptr(out), _ptr(out2), _ptr(scale2), _ptr(shift2),
+                                        _stream()), "lsfa_maxpool3x3s2_nhwc")
+    return out if out2 is None else (out, out2)
 
 
 class SplitWeight(object):

@@ -452,8 +452,12 @@ class Executor(object):
             if not hasattr(net, 'conv0_w_l'):
                 net.conv0_w_l = hip.stem_weight_layout(net.conv0_w)
             y = hip.stem_conv(x, net.conv0_w_l, net.conv0_b, net.bn_data[0], net.bn_data[1])
-            x4 = hip.maxpool3x3s2_nhwc(y).permute(0, 3, 1, 2)
+            u0 = net.units[0]                                  # the first unit's bn1 + relu1 rides on the pooling launch
+            pooled, a2_stem = hip.maxpool3x3s2_nhwc(y, scale2=u0['bn1'][0], shift2=u0['bn1'][1])
+            x4 = pooled.permute(0, 3, 1, 2)
+            stem_a2 = a2_stem.view(-1, a2_stem.shape[3])
         else:
+            stem_a2 = None
             x = hip.scale_shift_relu(x, net.bn_data[0], net.bn_data[1], relu=False).contiguous(memory_format=cl)
             y = F.conv2d(x, net.conv0_w_cl, None, stride=2, padding=3)
             r = self._rows(y)
@@ -462,7 +466,7 @@ class Executor(object):
         dilate = 1
         units = [u for u in net.units if u['stage'] <= stages]
         fuse3 = own_conv and 'conv3' in _OWN_CONV
-        a2 = None          # relu(bn1(x)) of the current unit when the previous unit's conv3 already produced it
+        a2 = stem_a2       # relu(bn1(x)) of the current unit when the producer of x already made it (stem / fused conv3)
         for ui, u in enumerate(units):
             first = u['unit'] == 1
             stride = 2 if (first and u['stage'] in (2, 3)) else 1

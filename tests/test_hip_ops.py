@@ -757,6 +757,10 @@ def test_stem_conv_pool_vs_torch(hip, shape):
     pooled = hip.maxpool3x3s2_nhwc(got)
     ref = F.max_pool2d(got.permute(0, 3, 1, 2), 3, 2, 1)
     assert torch.equal(pooled.permute(0, 3, 1, 2), ref)
+    # with the first unit's bn1 + relu1 as a second output of the same launch
+    s2, t2 = t(rs.uniform(0.5, 1.5, 64).astype(np.float32)), t(rs.randn(64).astype(np.float32))
+    p1, p2 = hip.maxpool3x3s2_nhwc(got, scale2=s2, shift2=t2)
+    assert torch.equal(p1, pooled) and torch.equal(p2, torch.relu(pooled * s2 + t2))
 
 
 @pytest.mark.parametrize("shape,k", [((1, 3, 600, 1000), 4), ((2, 3, 37, 50), 4), ((1, 5, 9, 7), 2)])

@@ -80,14 +80,49 @@ def stamps(dev):
     print("  %-42s %8.0f   (24 bf16 MFMAs = 768 cycles of matrix pipe)" % ("total", acc.sum() / n))
 
 
+def slices_sweep(dev, iters=30):
+    """res4 conv2 and res4 conv1 through the general kernel alone (no reduce pass) for different K cuts."""
+    import ctypes
+    import subprocess
+    here = os.path.dirname(os.path.abspath(__file__))
+    so, src = os.path.join(here, "_build", "libconv_split_lab_plain.so"), os.path.join(here, "conv_split_lab.hip")
+    os.makedirs(os.path.dirname(so), exist_ok=True)
+    subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off",
+                           "-fno-fast-math", "-I", os.path.join(ROOT, "lsfa_amd", "csrc"), src, "-o", so])
+    lab = ctypes.CDLL(so)
+    vp = lambda t: ctypes.c_void_p(t.data_ptr())
+    for name, H, W, Cin, Cout, k in (("res4 conv2", 38, 63, 256, 256, 3), ("res4 conv1", 38, 63, 1024, 256, 1), ("res3 conv2", 75, 125, 128, 128, 3)):
+        x = torch.randn(1, H, W, Cin, device=dev)
+        sw = hip.SplitWeight(torch.randn(Cout, Cin, k, k, device=dev) * 0.02)
+        part = torch.empty(16, H * W, Cout, device=dev)
+        st = (ctypes.c_longlong * 8)()
+        for S in (1, 2, 3, 4, 5, 6, 8, 9, 12):
+            if (k * k * Cin // 32) // S < 4:
+                continue
+            fn = lambda: lab.conv_split_lab_run(vp(x), vp(sw.frag), vp(part), 1, H, W, Cin, Cout, k, S, st)
+            for _ in range(3):
+                fn()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(iters):
+                fn()
+            e1.record()
+            e1.synchronize()
+            print("%-12s slices %2d: kernel %6.1f us (synchronising launches)" % (name, S, e0.elapsed_time(e1) * 1e3 / iters))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--iters", type=int, default=30)
     ap.add_argument("--stamps", action="store_true")
+    ap.add_argument("--slices", action="store_true")
     args = ap.parse_args()
     dev = torch.device("cuda:0")
     if args.stamps:
         stamps(dev)
+        return
+    if args.slices:
+        slices_sweep(dev)
         return
     torch.manual_seed(0)
     torch.backends.cudnn.benchmark = True

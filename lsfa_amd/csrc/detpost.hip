@@ -328,14 +328,15 @@ __global__ __launch_bounds__(1024) void det_cap_kernel(double* __restrict__ dets
   __syncthreads();
   const int total = misc[0];
   if (total <= max_per_image) return;
-  // stage keys: flat position = j*R + k (sparse but simple); absent slots get the largest key
+  // stage the survivors' keys at flat position j*R + k: a wave per class walks only the k < counts[j] that exist
   const int span = ncls * R;
-  for (int i = tid; i < span; i += 1024) {
-    const int j = i / R, k = i - j * R;
-    const bool present = j >= 1 && k < counts[j];
-    const uint32_t key = present ? desc_key((float)dets[(size_t)i * 5 + 4]) : 0xFFFFFFFFu;
-    keys[i] = key;
-    if (present) atomicAdd(&hist[cap_bin(key)], 1u);
+  for (int j = 1 + wid; j < ncls; j += 16) {
+    const int cj = counts[j];
+    for (int k = lane; k < cj; k += 64) {
+      const uint32_t key = desc_key((float)dets[((size_t)j * R + k) * 5 + 4]);
+      keys[j * R + k] = key;
+      atomicAdd(&hist[cap_bin(key)], 1u);
+    }
   }
   __syncthreads();
   // thread t owns bins 4095-4t .. 4092-4t (best scores first); `above` = survivors in better bins
@@ -368,9 +369,12 @@ __global__ __launch_bounds__(1024) void det_cap_kernel(double* __restrict__ dets
   const int tbin = misc[1], want = misc[2], members = misc[4];
   uint32_t T = 0;
   if (members <= kCapListMax) {
-    for (int i = tid; i < span; i += 1024) {
-      const uint32_t key = keys[i];
-      if (key != 0xFFFFFFFFu && cap_bin(key) == tbin) list[atomicAdd(&misc[3], 1)] = key;
+    for (int j = 1 + wid; j < ncls; j += 16) {
+      const int cj = counts[j];
+      for (int k = lane; k < cj; k += 64) {
+        const uint32_t key = keys[j * R + k];
+        if (cap_bin(key) == tbin) list[atomicAdd(&misc[3], 1)] = key;
+      }
     }
     __syncthreads();
     for (int i = tid; i < members; i += 1024) {
@@ -386,6 +390,11 @@ __global__ __launch_bounds__(1024) void det_cap_kernel(double* __restrict__ dets
     __syncthreads();
     T = (uint32_t)misc[5];
   } else {
+    for (int i = tid; i < span; i += 1024) {          // the radix passes walk the whole span: absent slots get the largest key
+      const int j = i / R, k = i - j * R;
+      if (!(j >= 1 && k < counts[j])) keys[i] = 0xFFFFFFFFu;
+    }
+    __syncthreads();
     uint32_t* rhist = list;       // 1024 words = 4 x 256 replicated radix histograms
     uint32_t prefix = 0;
     int remaining = max_per_image;

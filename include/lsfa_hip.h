@@ -212,6 +212,12 @@ int lsfa_deform_im2col_cl(const float* data, const float* offset,
                           int N, int C, int H, int W, int kh, int kw,
                           int pad, int stride, int dilate, int deform_groups,
                           int Ho, int Wo, float* col, void* stream);
+/* ... with the offsets of a pixel offset_ld floats apart (>= 2*kh*kw*dg): the offset branch of a DCN unit
+ * (sym_common.py:249-257, 72 channels) computed by lsfa_conv_split_fwd with its output channels padded to 128. */
+int lsfa_deform_im2col_cl_ld(const float* data, const float* offset, int offset_ld,
+                             int N, int C, int H, int W, int kh, int kw,
+                             int pad, int stride, int dilate, int deform_groups,
+                             int Ho, int Wo, float* col, void* stream);
 
 /* ------------------------------------------------------------------------ *
  * Convolution + bias + ReLU on channels-last maps with the fp32 matrix cores (implicit GEMM).

@@ -17,6 +17,9 @@ select/sort/NMS, the R-FCN head, the detection NMS) keeps one or a few CUs busy.
 graph therefore forks a second stream that computes the small-net feature of the NEXT frame while
 the current frame's tail runs, and the next replay consumes it.
 """
+import os
+import sys
+
 import torch
 
 from lsfa_amd import hip
@@ -387,10 +390,16 @@ class FramePipeline(object):
     """
 
     def __init__(self, key_exec, cur_exec, cfg, height, width, device, thresh=1e-4, use_graphs=True, lanes=2,
-                 flow_stream=True, lookahead=False, taps=False, batch=1):
+                 flow_stream=True, lookahead=False, taps=False, batch=1, layout=None):
         """batch > 1: that many clips advance in lock-step — every tensor handed to first_frame / key_frame /
         cur_frame carries one image (motion-vector field, residual) per clip on its batch axis, and the
-        detection buffers gain a leading clip axis."""
+        detection buffers gain a leading clip axis.
+        layout (default: $LSFA_STREAM_LAYOUT or 'probe'): how the work streams are picked.  'probe' times pairs of
+        candidate streams (core/streams.py) and keeps mutually concurrent ones — a speed matter only, but the probe
+        is perturbed by whatever else runs on the GPU, so the outcome is logged in `layout_used` and the other
+        values force one: 'plain' = a fresh stream per role, no probing; 'one-queue' = what the probe returns when
+        every candidate looks aliased to the key stream (no FlowNet stream, lanes on spare streams).  Results are
+        the same under every layout (tests/test_graph_gpu.py runs the pipeline under each)."""
         dev = torch.device(device)
         self.batch = B = int(batch)
         self.device, self.cfg, self.key_exec = dev, cfg, key_exec
@@ -404,7 +413,15 @@ class FramePipeline(object):
         self.lanes = [FrameGraphs(key_exec, cur_exec, cfg, height, width, dev, thresh, use_graphs, prefetch=False,
                                   feat_shared=self.feat_cur, taps=taps, batch=B) for _ in range(lanes)]
         want = 1 + (1 if flow_stream else 0) + lanes
-        chosen, aliased = streams.concurrent_streams(want, dev)
+        layout = layout or os.environ.get('LSFA_STREAM_LAYOUT', 'probe')
+        if layout == 'probe':
+            chosen, aliased = streams.concurrent_streams(want, dev)
+        elif layout == 'plain':
+            chosen, aliased = [streams.new_stream(dev) for _ in range(want)], []
+        elif layout == 'one-queue':
+            chosen, aliased = [streams.new_stream(dev)], [(streams.new_stream(dev), 0) for _ in range(want)]
+        else:
+            raise ValueError("FramePipeline: layout must be 'probe', 'plain' or 'one-queue', got %r" % (layout,))
         self.hw_queues = len(chosen)
         self.s_key = chosen[0]
         rest = chosen[1:]
@@ -414,6 +431,11 @@ class FramePipeline(object):
                 [st for st, q in aliased if q == 0]
         self.s_lane = [rest.pop(0) if rest else (spare.pop(0) if spare else streams.new_stream(dev))
                        for _ in range(lanes)]
+        self.layout_used = '%s: %d concurrent stream(s) of %d wanted, FlowNet stream %s, lanes %s' % (
+            layout, len(chosen), want, 'own' if self.s_flow is not None else 'none (key stream)',
+            ['own' if st in chosen else 'spare' for st in self.s_lane])
+        if os.environ.get('LSFA_LOG_LAYOUT') == '1':
+            sys.stderr.write('[lsfa] FramePipeline %dx%d streams: %s\n' % (height, width, self.layout_used))
         E = torch.cuda.Event
         self.ev_in, self.ev_flow, self.ev_tail, self.ev_handover = E(), E(), E(), E()
         self.ev_feat = [E(), E()]                 # key-buffer i's feature exists
@@ -464,8 +486,15 @@ class FramePipeline(object):
         self.join()
         self._next = self._nkey = 0          # the lane / buffer of a frame depends only on its position in the clip
         lane, cfg = self.klanes[0], self.cfg
-        conv_feat, _, _ = self.key_exec.key_front(data, None)
-        out = self.key_exec.key_back(conv_feat, None, None, None, lane.im_info)
+        saved = self.key_exec.taps
+        if lane.want_taps:
+            self.key_exec.taps = self.first_taps = {}
+        try:
+            conv_feat, _, _ = self.key_exec.key_front(data, None)
+            out = self.key_exec.key_back(conv_feat, None, None, None, lane.im_info)
+        finally:
+            self.key_exec.taps = saved
+        self.first_out = out if lane.want_taps else None
         if not hasattr(self, '_first_post'):
             self._first_full, self._first_post = _alloc_post(self.batch, cfg.dataset.NUM_CLASSES, cfg.TEST.RPN_POST_NMS_TOP_N,
                                                              self.device)

@@ -12,6 +12,7 @@ network outputs on the device and one HIP launch does decode + clip + per-class 
 max_per_image cap (lsfa_det_postprocess).  `im_detect` still exists with the reference's
 host-side return types for callers that want them.
 """
+import os
 import time
 
 import numpy as np
@@ -225,13 +226,35 @@ def pred_eval_pipelined(gpu_id, key_predictor, cur_predictor, test_data, imdb, c
     ring = HostRing(all_boxes, num_classes, cfg.TEST.RPN_POST_NMS_TOP_N)
     roidb_idx, roidb_offset, idx = -1, -1, 0
     fp = None
+    # diagnostics (tools/diag_multirank.py): $LSFA_TAP_SUMS=<file> keeps, per frame, (sum |x|, sum x) in float64 of every stage
+    # output, computed on the frame's own stream (no synchronisation inside the loop), and writes them as JSON at the end
+    tap_file = os.environ.get('LSFA_TAP_SUMS')
+    tap_sums = []
+    dcn_keep = []
     t0 = time.time()
     for im_info, key_frame_flag, data_batch in test_data:
         d = dict(zip(data_names, data_batch.data[0]))
         data = d['data']
 
-        def deliver(bufs, i=idx):
+        def deliver(bufs, i=idx, flag=key_frame_flag):
             ring.push(i, bufs[0], bufs[1])      # copies queued on the frame's own stream, into pinned host memory
+            if tap_file:
+                lane = fp.delivering
+                if flag == 0:
+                    taps, out = dict(fp.first_taps), fp.first_out
+                else:
+                    taps = dict(lane.taps if hasattr(lane, 'front') else lane.cur_taps)
+                    out = lane.out if hasattr(lane, 'front') else lane.cur_out
+                taps.update({k: v for k, v in (out or {}).items() if isinstance(v, torch.Tensor)})
+                names = sorted(k for k, v in taps.items() if isinstance(v, torch.Tensor) and v.is_floating_point())
+                vals = torch.stack([torch.stack([taps[k].double().abs().sum(), taps[k].double().sum()]) for k in names])
+                tap_sums.append((i, flag, names, vals))
+                if flag == 0 and os.environ.get('LSFA_DCN_CHECK') == '1':       # eager frame: its tensors are this frame's alone
+                    for k in taps:
+                        if k.endswith('1g_col_neq_again'):
+                            u = k[:-len('1g_col_neq_again')]
+                            dcn_keep.append((i, u, taps[k], taps[u + '1e_col'], taps[u + '1f_col_again'], taps[u + '1h_c1_then'],
+                                             taps[u + '1i_off_then']))
 
         if key_frame_flag == 0:
             shape_key = (int(data.shape[-2]), int(data.shape[-1]), float(im_info[0][0, 2]))
@@ -241,8 +264,10 @@ def pred_eval_pipelined(gpu_id, key_predictor, cur_predictor, test_data, imdb, c
             if fp is None:
                 fp = pipelines[shape_key] = FramePipeline(key_predictor._exec, cur_predictor._exec, cfg, shape_key[0],
                                                           shape_key[1], data.device, thresh=thresh,
-                                                          use_graphs=use_graphs, lanes=lanes)
+                                                          use_graphs=use_graphs, lanes=lanes, taps=bool(tap_file))
                 fp.set_scale(shape_key[2])
+                if logger:
+                    logger.info('pipeline %dx%d streams: %s' % (shape_key[0], shape_key[1], fp.layout_used))
             deliver(fp.first_frame(data))
             if not fp.captured:
                 fp.capture()
@@ -264,6 +289,15 @@ def pred_eval_pipelined(gpu_id, key_predictor, cur_predictor, test_data, imdb, c
         fp.join()
     ring.finish()
     torch.cuda.synchronize()
+    for i, u, neq, col, col2, c1, off in dcn_keep:
+        if float(neq.item()) > 0:
+            np.savez(tap_file + '.dcn_frame%d_%s.npz' % (int(frame_ids[i]), u), col=col.cpu().numpy(), col2=col2.cpu().numpy(),
+                     c1=c1.cpu().numpy(), off=off.cpu().numpy())
+    if tap_file:
+        import json
+        with open(tap_file + ('.rank%d' % gpu_id if gpu_id else ''), 'w') as f:
+            json.dump([{'frame': int(frame_ids[i]), 'flag': int(flag), 'sums': {n: [float(a), float(b)] for n, (a, b) in zip(names, vals.cpu().tolist())}}
+                       for i, flag, names, vals in tap_sums], f)
     net_time = time.time() - t0
     if logger:
         logger.info('done {} frames: {:.4f}s per frame ({:.1f} frames/s)'.format(num_images, net_time / max(idx, 1),

@@ -59,7 +59,7 @@ __global__ __launch_bounds__(kThreads) void deform_im2col_kernel(const float* __
 __global__ __launch_bounds__(kThreads) void deform_im2col_cl_kernel(const float* __restrict__ data,
                                                                     const float* __restrict__ offset, int C, int H,
                                                                     int W, int kh, int kw, int pad, int stride,
-                                                                    int dilate, int dg, int Ho, int Wo,
+                                                                    int dilate, int dg, int Ho, int Wo, int off_ld,
                                                                     float* __restrict__ col, size_t total4) {
   const int KK = kh * kw, C4 = C / 4, cpg = C / dg, HoWo = Ho * Wo;
   for (size_t idx = (size_t)blockIdx.x * kThreads + threadIdx.x; idx < total4; idx += (size_t)gridDim.x * kThreads) {
@@ -71,7 +71,7 @@ __global__ __launch_bounds__(kThreads) void deform_im2col_cl_kernel(const float*
     const int ho = sp / Wo, wo = sp - ho * Wo;
     const int i = tap / kw, j = tap - i * kw;
     const int g = c / cpg;
-    const float* off = offset + pix * (size_t)(2 * KK * dg) + (size_t)g * 2 * KK + 2 * tap;
+    const float* off = offset + pix * (size_t)off_ld + (size_t)g * 2 * KK + 2 * tap;
     const float oh = off[0], ow = off[1];
     float h = (float)(ho * stride - pad + i * dilate) + oh;
     float w = (float)(wo * stride - pad + j * dilate) + ow;
@@ -181,7 +181,16 @@ extern "C" int lsfa_deform_im2col(const float* data, const float* offset, int N,
 extern "C" int lsfa_deform_im2col_cl(const float* data, const float* offset, int N, int C, int H, int W, int kh, int kw,
                                      int pad, int stride, int dilate, int deform_groups, int Ho, int Wo, float* col,
                                      void* stream) {
+  return lsfa_deform_im2col_cl_ld(data, offset, 2 * kh * kw * deform_groups, N, C, H, W, kh, kw, pad, stride, dilate, deform_groups,
+                                  Ho, Wo, col, stream);
+}
+
+extern "C" int lsfa_deform_im2col_cl_ld(const float* data, const float* offset, int offset_ld, int N, int C, int H, int W, int kh,
+                                        int kw, int pad, int stride, int dilate, int deform_groups, int Ho, int Wo, float* col,
+                                        void* stream) {
   LSFA_REQUIRE(data && offset && col, "lsfa_deform_im2col_cl: NULL argument");
+  LSFA_REQUIRE(offset_ld >= 2 * kh * kw * deform_groups, "lsfa_deform_im2col_cl_ld: offset_ld %d < %d offset channels", offset_ld,
+               2 * kh * kw * deform_groups);
   LSFA_REQUIRE(N > 0 && C > 0 && H > 0 && W > 0 && kh > 0 && kw > 0 && stride > 0 && dilate > 0 && Ho > 0 && Wo > 0,
                "lsfa_deform_im2col_cl: bad shape");
   LSFA_REQUIRE(deform_groups > 0 && C % deform_groups == 0 && (C / deform_groups) % 4 == 0,
@@ -194,7 +203,7 @@ extern "C" int lsfa_deform_im2col_cl(const float* data, const float* offset, int
   if (nb > 65536) nb = 65536;
   ProfScope prof(LSFA_OP_DCN_IM2COL, s);
   hipLaunchKernelGGL(deform_im2col_cl_kernel, dim3((unsigned)nb), dim3(kThreads), 0, s, data, offset, C, H, W, kh, kw,
-                     pad, stride, dilate, deform_groups, Ho, Wo, col, total4);
+                     pad, stride, dilate, deform_groups, Ho, Wo, offset_ld, col, total4);
   LSFA_LAUNCH_CHECK("lsfa_deform_im2col_cl");
   return LSFA_OK;
 }

@@ -322,17 +322,18 @@ def deform_im2col(data, offset, kh, kw, pad, stride, dilate, deform_groups, out=
 
 @_on_tensor_device
 def deform_im2col_cl(data, offset, kh, kw, pad, stride, dilate, deform_groups, out=None):
-    """data (N,H,W,C), offset (N,Ho,Wo,2*kh*kw*dg) contiguous -> col (N, Ho*Wo, kh*kw*C), k = tap*C + c."""
+    """data (N,H,W,C), offset (N,Ho,Wo,L) contiguous with L >= 2*kh*kw*dg (channels past those are padding)
+    -> col (N, Ho*Wo, kh*kw*C), k = tap*C + c."""
     data, offset = _f32c(data, "data"), _f32c(offset, "offset")
     N, H, W, C = data.shape
     Ho, Wo = offset.shape[1], offset.shape[2]
-    if offset.shape[3] != 2 * kh * kw * deform_groups:
+    if offset.shape[3] < 2 * kh * kw * deform_groups:
         raise LsfaError("deform_im2col_cl: offset has %d channels, expected %d" % (offset.shape[3], 2 * kh * kw * deform_groups))
     if out is None:
         out = torch.empty((N, Ho * Wo, kh * kw * C), dtype=torch.float32, device=data.device)
-    _check(lib().lsfa_deform_im2col_cl(_ptr(data), _ptr(offset), _ci(N), _ci(C), _ci(H), _ci(W), _ci(kh), _ci(kw),
-                                       _ci(pad), _ci(stride), _ci(dilate), _ci(deform_groups), _ci(Ho), _ci(Wo),
-                                       _ptr(out), _stream()), "lsfa_deform_im2col_cl")
+    _check(lib().lsfa_deform_im2col_cl_ld(_ptr(data), _ptr(offset), _ci(offset.shape[3]), _ci(N), _ci(C), _ci(H), _ci(W),
+                                          _ci(kh), _ci(kw), _ci(pad), _ci(stride), _ci(dilate), _ci(deform_groups), _ci(Ho),
+                                          _ci(Wo), _ptr(out), _stream()), "lsfa_deform_im2col_cl_ld")
     return out
 
 

@@ -42,16 +42,20 @@ _CONV1X1_MIOPEN = _os.environ.get('LSFA_CONV1X1_MIOPEN', '0') == '1'   # experim
 # fuse (the small net's 256 -> 1024 fuse_reduce_add convolution) and feat (feat_conv_3x3), both on the split-bf16 kernel;
 # stem (bn_data + conv0 + relu0 + pool0 of both ResNets and the 4x4 average pooling in front of the small net: stem.hip);
 # `conv3` additionally runs the 1x1 conv3 of those units on it with the shortcut add and the next unit's bn1 + ReLU fused
+# `pw` (r3): EVERY contraction of a unit on the split-bf16 kernel — conv1, the shortcut, conv3 with the shortcut add and the
+# next unit's bn1 + ReLU in its epilogue, the DCN offset branch and contraction — so that no library GEMM / convolution and no
+# separate BatchNorm pass is left in the ResNets (and results no longer depend on a library's per-process algorithm choice);
 # (lsfa_conv_nhwc_fused_fwd) - measured SLOWER (backbone 4239 -> 4983 us: the 64x64-tile kernel loses to the tuned library GEMM on
 # K = 256 by more than the saved BN pass), so it is off by default.
 # measured at 1000x600 (tools/key_sections.py, hipGraph replay): backbone 4327 -> 4239 us with it, small net 256 -> 289 us:
 # the backbone's stage 2/3 units gain (epilogue fusion + deterministic tap split), the small net's 64-channel stage 1 and the
 # 256 -> 1024 fuse convolution do not
-_OWN_CONV = set(x for x in _os.environ.get('LSFA_OWN_CONV', 'backbone,fuse,feat,stem').split(',') if x)
+_OWN_CONV = set(x for x in _os.environ.get('LSFA_OWN_CONV', 'backbone,small,fuse,feat,stem,pw').split(',') if x)
 # the own 3x3 convolutions on the bf16 matrix pipe with exactly split fp32 operands (lsfa_conv_split_fwd: fp32 in, fp32
 # accumulate, error against float64 equal to the fp32-MFMA kernel's) instead of the fp32 matrix instructions.  Measured per
 # conv2 at 1000x600 (tools/lab/conv_split_lab.py): res4 32.7 vs 40.7 us, res3 31.4 vs 50.4, res2 34.6 vs 51.3.
 _CONV_SPLIT = _os.environ.get('LSFA_CONV_SPLIT', '1') == '1'
+_UNIT_TAPS = _os.environ.get('LSFA_UNIT_TAPS', '0') == '1'       # diagnostics: every unit's a / c1 / c2 / shortcut / output as taps
 
 
 class TestSymbol(object):
@@ -254,6 +258,23 @@ class _ResNetWeights(object):
                 d['off_w_cl'] = d['off_w'].contiguous(memory_format=cl)
                 # (Cout, C, 3, 3) -> rows ordered (tap, c) to match lsfa_deform_im2col_cl's col
                 d['w2_tap_t'] = d['w2'].permute(2, 3, 1, 0).reshape(-1, d['w2'].shape[0]).contiguous()
+            if _CONV_SPLIT and 'pw' in _OWN_CONV and d['w1'].is_cuda and d['w1'].dtype == torch.float32:
+                # every contraction of the unit on lsfa_conv_split_fwd: the 1x1 convolutions, the shortcut, and for a DCN
+                # unit the offset branch (72 output channels, zero-padded to 128) and the contraction of the sampled
+                # columns (a 1x1 convolution over 9*C "channels" ordered (tap, c))
+                d['w1_split'] = hip.SplitWeight(d['w1'])
+                d['w3_split'] = hip.SplitWeight(d['w3'])
+                if 'sc' in d:
+                    d['sc_split'] = hip.SplitWeight(d['sc'])
+                if d['dcn']:
+                    co = d['off_w'].shape[0]
+                    pad_to = -(-co // 64) * 64
+                    wpad = torch.zeros((pad_to,) + tuple(d['off_w'].shape[1:]), device=d['off_w'].device, dtype=torch.float32)
+                    wpad[:co] = d['off_w']
+                    bpad = torch.zeros(pad_to, device=d['off_w'].device, dtype=torch.float32)
+                    bpad[:co] = d['off_b']
+                    d['off_split'], d['off_b_pad'] = hip.SplitWeight(wpad), bpad
+                    d['dcn_split'] = hip.SplitWeight(d['w2_tap_t'].t().contiguous().view(d['w2'].shape[0], -1, 1, 1))
         self._cl_ready = True
 
 
@@ -439,6 +460,9 @@ class Executor(object):
         off = F.conv2d(c1_4, u['off_w_cl'], u['off_b'], stride=1, padding=dilate, dilation=dilate)
         col = hip.deform_im2col_cl(c1_4.permute(0, 2, 3, 1), off.permute(0, 2, 3, 1), 3, 3, dilate, 1, dilate,
                                    P.NUM_DEFORMABLE_GROUP)
+        if self.taps is not None and _UNIT_TAPS:
+            self.taps['u%d_%02d_1d_off' % (u['stage'], u['unit'])] = off
+            self.taps['u%d_%02d_1e_col' % (u['stage'], u['unit'])] = col
         return torch.mm(col.view(-1, col.shape[2]), u['w2_tap_t'])     # (N*H*W, 9*C) x (9*C, Cout)
 
     def _resnet_cl(self, x, net, stages, tail, own_conv=False):
@@ -477,7 +501,51 @@ class Executor(object):
             x2 = self._rows(x4)
             if a2 is None:
                 a2 = hip.scale_shift_relu_cl(x2, u['bn1'][0], u['bn1'][1], relu=True)
+            if own_conv and 'w1_split' in u:
+                # the whole unit on the own split-bf16 convolution: conv1 (+ folded bn2 + ReLU), conv2 (3x3 or DCN: offsets,
+                # bilinear columns, contraction; + folded bn3 + ReLU), the shortcut, conv3 + shortcut add in place + the
+                # NEXT unit's bn1 + ReLU as a second output: no library GEMM, no separate BatchNorm pass
+                taps = self.taps if (self.taps is not None and _UNIT_TAPS) else None
+                tag = 'u%d_%02d_' % (u['stage'], u['unit'])
+                a4 = a2.view(n, h, w, -1)
+                c1 = hip.conv_split(a4, u['w1_split'], u['b1'], relu=True)
+                if u['dcn']:
+                    off = hip.conv_split(c1, u['off_split'], u['off_b_pad'], 1, unit_dilate, unit_dilate)
+                    col = hip.deform_im2col_cl(c1, off, 3, 3, unit_dilate, 1, unit_dilate, P.NUM_DEFORMABLE_GROUP)
+                    c2 = hip.conv_split(col.view(n, h, w, -1), u['dcn_split'], u['b2'], relu=True)
+                    if taps is not None:
+                        taps[tag + '1d_off'], taps[tag + '1e_col'] = off, col
+                        if _os.environ.get('LSFA_DCN_CHECK') == '1':
+                            # diagnostics: the same launch again right behind the first one, and what its inputs hold now
+                            col2 = hip.deform_im2col_cl(c1, off, 3, 3, unit_dilate, 1, unit_dilate, P.NUM_DEFORMABLE_GROUP)
+                            taps[tag + '1f_col_again'] = col2
+                            taps[tag + '1g_col_neq_again'] = (col != col2).sum().float().view(1)
+                            taps[tag + '1h_c1_then'] = c1.clone()
+                            taps[tag + '1i_off_then'] = off.clone()
+                else:
+                    c2 = hip.conv_split(c1, u['w2_split'], u['b2'], stride, unit_dilate, unit_dilate, relu=True)
+                ho, wo = c2.shape[1], c2.shape[2]
+                sc4 = hip.conv_split(a4, u['sc_split'], None, stride) if first else x2.view(n, ho, wo, -1)
+                nxt = units[ui + 1]['bn1'] if ui + 1 < len(units) else (net.bn1 if tail else None)
+                if taps is not None:
+                    taps[tag + '0a'], taps[tag + '1c1'], taps[tag + '2c2'] = a2, c1, c2
+                    if first:
+                        taps[tag + '3sc'] = sc4.clone()
+                if nxt is not None:
+                    _, out2 = hip.conv_split(c2, u['w3_split'], None, out=sc4, residual=sc4, out2=torch.empty_like(sc4),
+                                             scale2=nxt[0], shift2=nxt[1])
+                    a2 = out2.view(-1, out2.shape[3])
+                else:
+                    hip.conv_split(c2, u['w3_split'], None, out=sc4, residual=sc4)
+                    a2 = None
+                x4 = sc4.permute(0, 3, 1, 2)
+                if taps is not None:
+                    taps[tag + '4x'] = x4.clone()
+                continue
             c1 = torch._addmm_activation(u['b1'], a2, u['w1_t'])                  # conv1 + folded bn2 + ReLU
+            if self.taps is not None and _UNIT_TAPS:
+                self.taps['u%d_%02d_0a' % (u['stage'], u['unit'])] = a2
+                self.taps['u%d_%02d_1c1' % (u['stage'], u['unit'])] = c1
             if u['dcn']:
                 c2 = self._dcn_cl(self._map(c1, h, w), u, unit_dilate)
                 ho, wo = h, w
@@ -503,6 +571,10 @@ class Executor(object):
                     else torch.mm(a2, u['sc_t'])
             else:
                 sc = x2                                         # overwritten in place by conv3 (+ the shortcut: beta = 1)
+            if self.taps is not None and _UNIT_TAPS:
+                self.taps['u%d_%02d_2c2' % (u['stage'], u['unit'])] = c2.clone()
+                if first:
+                    self.taps['u%d_%02d_3sc' % (u['stage'], u['unit'])] = sc.clone()
             # the bn1 + ReLU the NEXT unit (or the network's tail) applies to this unit's output
             nxt = units[ui + 1]['bn1'] if ui + 1 < len(units) else (net.bn1 if tail else None)
             if fuse3 and 'w3_kc' in u and sc.is_contiguous():
@@ -516,6 +588,8 @@ class Executor(object):
             else:
                 x4 = self._map(sc.addmm_(c2, u['w3_t']), ho, wo)
                 a2 = None
+            if self.taps is not None and _UNIT_TAPS:
+                self.taps['u%d_%02d_4x' % (u['stage'], u['unit'])] = x4.clone()
         if tail:
             h, w = x4.shape[2], x4.shape[3]
             if a2 is not None:

@@ -40,3 +40,31 @@ def disable():
     import torch.cuda.tunable as T
     T.tuning_enable(False)
     T.enable(False)
+
+
+_PRIVATE_DIR = None
+
+
+def pin_algorithms(isolate_miopen=True):
+    """Results that do not depend on what ran before or beside this process (`python -m lsfa_amd.test
+    --pinned-algorithms`, the multi-rank equality test): no TunableOp, no MIOpen find step, and — the part that
+    mattered — MIOpen's per-user state made private to the process.  Measured (tools/diag_multirank.py,
+    profiles/r3/multirank_diag_before.txt): with `cudnn.benchmark` off MIOpen still picks a convolution's solver from
+    its user find-db / kernel cache under $HOME; two processes that start together on an empty cache race for it, end up
+    with other solvers than a process that starts alone, and that choice then persists in $HOME for every later
+    process.  Frames from the first FlowNet key frame on moved by up to 4e-5 px (enough, with a random-weight RPN, to
+    re-order proposals).  With MIOPEN_USER_DB_PATH / MIOPEN_CUSTOM_CACHE_DIR pointing at a fresh directory every
+    process sees the same (empty) state and chooses alike.  Must run before the first convolution of the process."""
+    global _PRIVATE_DIR
+    disable()
+    torch.backends.cudnn.deterministic, torch.backends.cudnn.benchmark = True, False
+    if isolate_miopen and _PRIVATE_DIR is None:
+        import atexit
+        import shutil
+        _PRIVATE_DIR = tempfile.mkdtemp(prefix='lsfa_miopen_%d_' % os.getpid())
+        os.environ['MIOPEN_USER_DB_PATH'] = os.path.join(_PRIVATE_DIR, 'db')
+        os.environ['MIOPEN_CUSTOM_CACHE_DIR'] = os.path.join(_PRIVATE_DIR, 'cache')
+        for d in ('db', 'cache'):
+            os.makedirs(os.path.join(_PRIVATE_DIR, d), exist_ok=True)
+        atexit.register(shutil.rmtree, _PRIVATE_DIR, True)
+    return _PRIVATE_DIR

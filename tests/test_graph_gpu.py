@@ -13,6 +13,9 @@ import oracle
 from oracle import graph_ref
 
 pytestmark = pytest.mark.gpu
+# dense stages (MFMA contractions with BN folded in float64) against the unfused torch-CPU fp32 graph, relative to the
+# map's maximum: both sides are fp32 with different summation orders; measured 1.4e-6 ... 2.6e-6
+TOL_DENSE = 2e-5
 DEV = "cuda:0"
 H, W = 192, 320
 
@@ -63,9 +66,9 @@ def test_key_and_cur_graphs(world):
     out0 = key.forward(data=f0.to(DEV), im_info=im_info_t, data_key_old=f0.to(DEV), feat_key_old=placeholder)
     ref0 = graph_ref.key_forward(cfg, arg, aux, f0.numpy(), f0.numpy(), np.zeros((1, 1024, 1, 1), np.float32), im_info)
     assert out0['choose_feat_output'].shape == (1, 1024, 12, 20)
-    assert rel_err(np_(key.taps['backbone_feat']), ref0['backbone_feat']) < 2e-3
-    assert rel_err(np_(key.taps['cls_map']), ref0['cls_map']) < 2e-3
-    assert rel_err(np_(key.taps['rpn_bbox_pred']), ref0['rpn_bbox_pred']) < 2e-3
+    assert rel_err(np_(key.taps['backbone_feat']), ref0['backbone_feat']) < TOL_DENSE
+    assert rel_err(np_(key.taps['cls_map']), ref0['cls_map']) < TOL_DENSE
+    assert rel_err(np_(key.taps['rpn_bbox_pred']), ref0['rpn_bbox_pred']) < TOL_DENSE
     assert np.abs(np_(key.taps['rpn_cls_prob']) - ref0['rpn_cls_prob']).max() < 1e-4
     check_heads(cfg, key.taps, out0, im_info)
     feat0 = out0['choose_feat_output']
@@ -76,7 +79,7 @@ def test_key_and_cur_graphs(world):
     cur.taps = {}
     out3 = cur.forward(data=f3.to(DEV), im_info=im_info_t, feat_key=feat0, motion_vector=mv.to(DEV), res_diff=res.to(DEV))
     ref_small = graph_ref.small_net_feature(graph_ref.Params(arg, aux), f3).numpy()
-    assert rel_err(np_(cur.taps['small_feat']), ref_small) < 2e-3
+    assert rel_err(np_(cur.taps['small_feat']), ref_small) < TOL_DENSE
     want = oracle.warp_bilinear(np_(feat0), mv.numpy(), add=np_(cur.taps['small_feat']), res=res.numpy(),
                                 res_w=arg['rnet_conv0_weight'], res_b=arg['rnet_conv0_bias'])
     np.testing.assert_array_equal(np_(out3['conv_feat']), want)
@@ -87,12 +90,12 @@ def test_key_and_cur_graphs(world):
     out10 = key.forward(data=f10.to(DEV), im_info=im_info_t, data_key_old=f0.to(DEV), feat_key_old=feat0)
     p = graph_ref.Params(arg, aux)
     flow_ref, scale_ref = graph_ref.get_flownet(p, f10, f0)
-    assert np.abs(np_(key.taps['flow']) - flow_ref.numpy()).max() < 2e-3 * max(1.0, float(flow_ref.abs().max()))
-    assert rel_err(np_(key.taps['scale_map']), scale_ref.numpy()) < 2e-3
+    assert np.abs(np_(key.taps['flow']) - flow_ref.numpy()).max() < TOL_DENSE * max(1.0, float(flow_ref.abs().max()))
+    assert rel_err(np_(key.taps['scale_map']), scale_ref.numpy()) < TOL_DENSE
     warp_want = oracle.warp_bilinear(np_(feat0), np_(key.taps['flow']), mul=np_(key.taps['scale_map']))
     np.testing.assert_array_equal(np_(key.taps['warp']), warp_want)
     logits_ref = graph_ref.nq_logits(p, torch.from_numpy(warp_want), key.taps['backbone_feat'].cpu()).numpy()
-    assert np.abs(np_(key.taps['nq_logits']) - logits_ref).max() < 2e-3 * max(1.0, float(np.abs(logits_ref).max()))
+    assert np.abs(np_(key.taps['nq_logits']) - logits_ref).max() < TOL_DENSE * max(1.0, float(np.abs(logits_ref).max()))
     agg_want = oracle.aggregate_softmax2(warp_want, np_(key.taps['backbone_feat']), np_(key.taps['nq_logits']))
     np.testing.assert_array_equal(np_(out10['choose_feat_output']), agg_want)
     check_heads(cfg, key.taps, out10, im_info)
@@ -272,8 +275,8 @@ def test_batch_symbol_tile_as_multiproposal(world):
     taps = pred._exec.taps
     assert out['rois_output'].shape == (900, 5) and out['cls_prob_reshape_output'].shape == (1, 900, 31)
     ref = graph_ref.batch_forward(cfg, arg, aux, data_key.cpu().numpy(), data_other.cpu().numpy(), im_info)
-    assert rel_err(np_(taps['backbone_feat']), ref['backbone_feat']) < 2e-3
-    assert np.abs(np_(taps['flow']) - ref['flow']).max() < 2e-3 * max(1.0, np.abs(ref['flow']).max())
+    assert rel_err(np_(taps['backbone_feat']), ref['backbone_feat']) < TOL_DENSE
+    assert np.abs(np_(taps['flow']) - ref['flow']).max() < TOL_DENSE * max(1.0, np.abs(ref['flow']).max())
     want_warp = oracle.warp_bilinear(np_(taps['backbone_feat']), np_(taps['flow']), mul=np_(taps['scale_map']))
     np.testing.assert_array_equal(np_(taps['warp']), want_warp)                 # feat_n = 1 broadcast == tile_as
     check_heads(cfg, taps, out, im_info)                                         # MultiProposal + PSROI over 3 images
@@ -313,7 +316,7 @@ def test_key_graph_other_aggregations(mode):
         emb_ref = graph_ref.embed(p, torch.from_numpy(cur_feat), torch.from_numpy(warp)).numpy()
         emb = np_(key.taps['embed'])
         assert emb.shape == (2, 2048, 12, 20)
-        assert rel_err(emb, emb_ref) < 2e-3
+        assert rel_err(emb, emb_ref) < TOL_DENSE
         want = oracle.aggregate_cosine(warp, cur_feat, emb[1:2], emb[0:1])
         np.testing.assert_array_equal(np_(out['choose_feat_output']), want)
     else:
@@ -322,7 +325,7 @@ def test_key_graph_other_aggregations(mode):
     check_heads(cfg, key.taps, out, im_info)
     # whole-graph statement with the same switches
     ref = graph_ref.key_forward(cfg, arg, aux, np_(f10), np_(f0), np_(feat0), im_info)
-    assert rel_err(np_(out['choose_feat_output']), ref['choose_feat_output']) < 5e-3
+    assert rel_err(np_(out['choose_feat_output']), ref['choose_feat_output']) < TOL_DENSE
 
 
 def test_demo_frame_directory(tmp_path, monkeypatch):
@@ -488,8 +491,8 @@ def test_tuned_gemm_file_is_accepted_and_parity_holds(world):
         out = key.forward(data=f0.to(DEV), im_info=torch.from_numpy(im_info).to(DEV), data_key_old=f0.to(DEV),
                           feat_key_old=torch.zeros(1, 1024, 1, 1, device=DEV))
         ref = graph_ref.key_forward(cfg, arg, aux, f0.numpy(), f0.numpy(), np.zeros((1, 1024, 1, 1), np.float32), im_info)
-        assert rel_err(np_(key.taps['backbone_feat']), ref['backbone_feat']) < 2e-3
-        assert rel_err(np_(key.taps['cls_map']), ref['cls_map']) < 2e-3
+        assert rel_err(np_(key.taps['backbone_feat']), ref['backbone_feat']) < TOL_DENSE
+        assert rel_err(np_(key.taps['cls_map']), ref['cls_map']) < TOL_DENSE
         check_heads(cfg, key.taps, out, im_info)
     finally:
         key.taps = None

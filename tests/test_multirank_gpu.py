@@ -56,29 +56,19 @@ def test_bench_two_ranks_one_device():
     assert d2["config"]["detections_last_interval"] > d1["config"]["detections_last_interval"]
 
 
-def _unmatched(a, b, box_tol=0.05, score_tol=1e-4):
-    """Rows of `a` without a counterpart in `b`: same frame and class, score within score_tol, box within box_tol px."""
-    missing = 0
-    for f in np.unique(a[:, 0]):
-        for c in np.unique(a[a[:, 0] == f][:, 1]):
-            ra, rb = a[(a[:, 0] == f) & (a[:, 1] == c)], b[(b[:, 0] == f) & (b[:, 1] == c)]
-            free = np.ones(len(rb), dtype=bool)
-            for row in ra:
-                ok = free & (np.abs(rb[:, 2] - row[2]) < score_tol) & (np.abs(rb[:, 3:] - row[3:]).max(1) < box_tol) if len(rb) else free
-                if ok.any():
-                    free[np.argmax(ok)] = False
-                else:
-                    missing += 1
-    return missing
+def _canonical(rows):
+    """Rows in an order that does not depend on which rank delivered them: by frame, class, then the values."""
+    return rows[np.lexsort(rows.T[::-1])]
 
 
 def test_lsfa_test_three_clips_two_ranks_equal_single_rank(tmp_path):
     """`python -m lsfa_amd.test --clips 3`: one rank (clips 0, 1, 2 through one pipeline) vs two ranks (greedy
-    assignment: rank 0 gets clips {0, 2}, rank 1 clip {1}; rows gathered over gloo in rank order).  Two PROCESSES
-    running the same command differ in the last bits of the library convolutions (measured here: 1e-5 px on ~1 % of
-    the coordinates between two single-rank runs, although each process reproduces itself bit for bit), so the
-    criterion is: same frames, same number of rows, and every row has a counterpart within 1e-4 in score and
-    0.05 px in every coordinate — in both directions."""
+    assignment: rank 0 gets clips {0, 2}, rank 1 clip {1}; rows gathered over gloo in rank order) must deliver the SAME
+    detection rows, bit for bit — the reference's fan-out returns the same detections however the videos are spread
+    (dff_rfcn/function/test_rcnn.py:69-75, dff_rfcn/core/tester.py:301-312).  r2 allowed a 0.2 % budget here and went
+    red on the driver's box (57 % of the rows differed); tools/diag_multirank.py traced it to MIOpen choosing solvers
+    from per-user state under $HOME that concurrently starting processes race for (profiles/r3/multirank_diag_*.txt);
+    `--pinned-algorithms` now gives every process a private, empty MIOpen state (lsfa_amd/tuning.py pin_algorithms)."""
     args = ["--clips", "3", "--frames", "7", "--interval", "3", "--height", "192", "--width", "320", "--pinned-algorithms"]
     outs = {}
     for tag, nproc in (("one", 1), ("two", 2)):
@@ -95,5 +85,7 @@ def test_lsfa_test_three_clips_two_ranks_equal_single_rank(tmp_path):
     r1, r2 = outs["one"], outs["two"]
     assert len(r1) > 0 and sorted(np.unique(r1[:, 0]).astype(int)) == list(range(21))     # 3 clips x 7 frames, global frame ids
     assert sorted(np.unique(r2[:, 0]).astype(int)) == list(range(21))
-    assert abs(len(r1) - len(r2)) <= 0.002 * len(r1), (len(r1), len(r2))
-    assert _unmatched(r1, r2) <= 0.002 * len(r1) and _unmatched(r2, r1) <= 0.002 * len(r1)
+    assert r1.shape == r2.shape, (r1.shape, r2.shape)
+    c1, c2 = _canonical(r1), _canonical(r2)
+    differing = np.flatnonzero((c1 != c2).any(1))
+    assert differing.size == 0, "%d of %d rows differ; frames %s" % (differing.size, len(c1), sorted(set(c1[differing, 0].astype(int))))

@@ -1,0 +1,106 @@
+#!/usr/bin/env python
+"""Hunt for the intermittent whole-frame garbage seen when two `python -m lsfa_amd.test` processes share the GPU
+(profiles/r3/multirank_diag_*.txt): repeat the two-process scenario, and for every frame whose detections are far from the
+reference run's (nearest row > 1e-3) name the FIRST stage output whose float64 checksum deviates.
+usage: diag_garbage.py [trials] [cold|warm]"""
+import json
+import os
+import shutil
+import subprocess
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+OUT = os.path.join(ROOT, 'gpurun_out', 'garbage')
+HOMES = '/tmp/lsfa_garbage_homes'
+ARGS = ['--clips', '3', '--frames', '7', '--interval', '3', '--height', '192', '--width', '320', '--pinned-algorithms']
+KEY_ORDER = ['backbone_feat', 'flow', 'scale_map', 'warp', 'nq_logits', 'choose_feat_output', 'rpn_cls_prob', 'rpn_bbox_pred',
+             'cls_map', 'box_map', 'rois_output', 'cls_prob_reshape_output', 'bbox_pred_reshape_output']
+CUR_ORDER = ['small_feat', 'conv_feat'] + KEY_ORDER[6:]
+
+
+def launch(tag, home, extra=None):
+    env = dict(os.environ)
+    os.makedirs(home, exist_ok=True)
+    env.update(HOME=home, LSFA_MIOPEN_SHARED='1', LSFA_UNIT_TAPS='1', LSFA_DCN_CHECK='1', LSFA_TAP_SUMS=os.path.join(OUT, 'taps_%s.json' % tag),
+               PYTHONPATH=ROOT + os.pathsep + env.get('PYTHONPATH', ''))
+    env.update(extra or {})
+    out = os.path.join(OUT, 'rows_%s.npy' % tag)
+    log = open(os.path.join(OUT, 'log_%s.txt' % tag), 'w')
+    p = subprocess.Popen([sys.executable, '-m', 'lsfa_amd.test'] + ARGS + ['--out', out], cwd=ROOT, env=env, stdout=log,
+                         stderr=subprocess.STDOUT)
+    return p, tag
+
+
+def collect(p, tag):
+    rc = p.wait(timeout=900)
+    rows = np.load(os.path.join(OUT, 'rows_%s.npy' % tag)) if rc == 0 else None
+    taps = json.load(open(os.path.join(OUT, 'taps_%s.json' % tag))) if rc == 0 else None
+    return rc, rows, taps
+
+
+def far_frames(ref, rows, tol=1e-3):
+    bad = {}
+    for f in np.unique(ref[:, 0]):
+        a, b = ref[ref[:, 0] == f], rows[rows[:, 0] == f]
+        worst = 0.0
+        for r in a:
+            c = b[b[:, 1] == r[1]]
+            worst = max(worst, float(np.abs(c[:, 2:] - r[2:]).max(1).min()) if len(c) else 1e9)
+        if worst > tol or len(a) != len(b):
+            bad[int(f)] = worst
+    return bad
+
+
+def first_deviation(ref_taps, taps, frame, tol=0.0):
+    r = next((t for t in ref_taps if t['frame'] == frame), None)
+    g = next((t for t in taps if t['frame'] == frame), None)
+    if r is None or g is None:
+        return 'no taps (flag 0 runs eagerly)'
+    names = sorted(k for k in r['sums'] if k.startswith('u')) + [k for k in (KEY_ORDER if r['flag'] != 2 else CUR_ORDER) if k in r['sums']]
+    devs = []
+    for k in names:
+        a, b = r['sums'][k], g['sums'].get(k)
+        if b is not None and a != b:
+            devs.append('%s(%.1e)' % (k, abs(a[0] - b[0]) / (abs(a[0]) + 1e-30)))
+    return 'flag %d: %s' % (r['flag'], ' '.join(devs[:10]) if devs else 'all taps identical')
+
+
+def main():
+    trials = int(sys.argv[1]) if len(sys.argv) > 1 else 6
+    mode = sys.argv[2] if len(sys.argv) > 2 else 'cold'
+    shutil.rmtree(OUT, ignore_errors=True)
+    shutil.rmtree(HOMES, ignore_errors=True)
+    os.makedirs(OUT)
+    p, tag = launch('ref', os.path.join(HOMES, 'ref'))
+    rc, ref, ref_taps = collect(p, tag)
+    assert rc == 0, open(os.path.join(OUT, 'log_ref.txt')).read()[-2000:]
+    print('reference run: %d rows' % len(ref), flush=True)
+    for t in range(trials):
+        t0 = time.time()
+        if mode == 'cold':
+            homes = [os.path.join(HOMES, 't%d%s' % (t, x)) for x in 'ab']
+        else:
+            homes = [os.path.join(HOMES, 'ref')] * 2
+        procs = [launch('t%d%s' % (t, x), h) for x, h in zip('ab', homes)]
+        for p, tag in procs:
+            rc, rows, taps = collect(p, tag)
+            if rc != 0:
+                print('trial %s: rc %d' % (tag, rc))
+                continue
+            bad = far_frames(ref, rows)
+            print('trial %s (%.0f s): %d frames far from the reference %s' % (tag, time.time() - t0, len(bad), bad if bad else ''), flush=True)
+            for f in sorted(bad):
+                print('    frame %2d  %s' % (f, first_deviation(ref_taps, taps, f)), flush=True)
+            if mode == 'warm':          # same MIOpen state as the reference run: every checksum must be identical
+                for g in taps:
+                    if g['frame'] not in bad:
+                        msg = first_deviation(ref_taps, taps, g['frame'])
+                        if 'identical' not in msg:
+                            print('    frame %2d (detections close) %s' % (g['frame'], msg), flush=True)
+
+
+if __name__ == '__main__':
+    main()

@@ -252,6 +252,9 @@ int lsfa_conv_nhwc_fused_fwd(const float* x, int N, int H, int W, int Cin, const
  * bytes from w (Cout, kh, kw, Cin).  Cin % 32 == 0, Cout % 64 == 0.  y_nchw != 0: y, y2 and residual are (N, Cout, Ho, Wo)
  * — the layout the reference's operators (and lsfa_warp_bilinear's `add` operand) take — instead of (N, Ho, Wo, Cout); x is
  * always channels-last.  Arguments otherwise as lsfa_conv_nhwc_fused_fwd. */
+/* measurement switch (tools/lab/conv_split_lab.py): 0 = the launch plan decides (default), 1 = 128 x 64 workgroup tiles only
+ * (the r2 kernel), 2 = 128 x 128 tiles wherever Cout % 128 == 0.  Same results bit for bit: the k order per output is the same. */
+int lsfa_conv_split_set_variant(int variant);
 size_t lsfa_conv_split_weight_bytes(int Cout, int kh, int kw, int Cin);
 int lsfa_conv_split_weights(const float* w, int Cout, int kh, int kw, int Cin, void* wfrag, void* stream);
 size_t lsfa_conv_split_workspace_bytes(int N, int H, int W, int Cin, int Cout, int kh, int kw, int stride, int pad, int dil);
@@ -259,6 +262,21 @@ int lsfa_conv_split_fwd(const float* x, int N, int H, int W, int Cin, const void
                         int kh, int kw, int stride, int pad, int dil, int relu, int y_nchw, const float* residual, float* y,
                         float* y2, const float* scale2, const float* shift2,
                         void* ws, size_t ws_bytes, void* stream);
+/* The same convolution on VIEWS of wider channels-last maps, for FlowNet (resnet_v1_101_flownet_rfcn.py:150-207), whose
+ * Concat / Crop / Deconvolution nodes then need no copies:
+ *   x   (N, H, W, lda) with the Cin input channels first in each pixel's row (lda >= Cin, a multiple of 4);
+ *   y   points at the first output element; output pixel (oy, ox) of image n goes to
+ *       y + (((n*out_H + oy*out_sy)*out_W + ox*out_sx) * ldy)  (out_H = 0: the plain (N, Ho, Wo, ldy) map) — a channel slice
+ *       [c0, c0 + Cout) of a concatenated map (y advanced by c0), or every other pixel of it: a Deconvolution(kernel 4,
+ *       stride 2) + Crop(offset 1) is four such launches with 2x2 taps, one per output parity (py, px), pad_h = 1 - py,
+ *       pad_w = 1 - px;
+ *   Ho, Wo > 0: the output grid of this launch when smaller than the convolution's (a phase's share of the cropped map);
+ *   separate pad_h / pad_w; act: 0 none, 1 ReLU, 2 LeakyReLU(0.1) (sym_common / :153 `LeakyReLU(act_type='leaky', slope=0.1)`).
+ * workspace: lsfa_conv_split_workspace_bytes of the same shape. */
+int lsfa_conv_split_view_fwd(const float* x, int lda, int N, int H, int W, int Cin, const void* wfrag, const float* bias,
+                             int Cout, int kh, int kw, int stride, int pad_h, int pad_w, int dil, int act, float* y, int ldy,
+                             int Ho, int Wo, int out_H, int out_W, int out_sy, int out_sx, void* ws, size_t ws_bytes,
+                             void* stream);
 
 /* ---------------------------------------------------------------------------
  * The stem of the ResNets and the frame shrink in front of the small net, three launches instead of six library ones.

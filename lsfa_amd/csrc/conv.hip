@@ -266,6 +266,7 @@ extern "C" int lsfa_conv_nhwc_fwd(const float* x, int N, int H, int W, int Cin, 
 namespace {
 // how a split convolution is launched: which kernel, the tile grid, how K is cut
 struct SplitPlan {
+  int nt;               // general kernel: 32-channel column tiles per wave (2: conv_split_kernel, 4: conv_split_wide_kernel<4>)
   bool halo;            // the 3x3 halo kernel (stride 1, pad = dilation 1 or 2), else the general one
   int dil;
   int patches_x, patches_y;
@@ -275,8 +276,12 @@ struct SplitPlan {
   int max_pieces;       // ... and the most workgroups that can share one tile
 };
 
+// lab switch (lsfa_conv_split_set_variant): 0 = plan decides, 1 = 64-channel workgroup tiles only, 2 = 128-channel tiles wherever Cout allows
+std::atomic<int> g_split_variant{0};
+
 SplitPlan split_plan(int N, int H, int W, int Cin, int Cout, int kh, int kw, int stride, int pad, int dil) {
   SplitPlan p = {};
+  p.nt = 2;
   const int Ho = (H + 2 * pad - dil * (kh - 1) - 1) / stride + 1, Wo = (W + 2 * pad - dil * (kw - 1) - 1) / stride + 1;
   p.ny = Cout / convsplit::kWgCh;
   p.dil = dil;
@@ -308,6 +313,11 @@ SplitPlan split_plan(int N, int H, int W, int Cin, int Cout, int kh, int kw, int
     const long P = (long)N * Ho * Wo;
     p.nx = (int)((P + convsplit::kWgPix - 1) / convsplit::kWgPix);
     const int chunk_total = kh * kw * (Cin / 32);
+    const int variant = g_split_variant.load();
+    // 128 x 128 workgroup tiles pay from ~128 chunks of K on (tools/lab/conv_split_lab.py, profiles/r3/conv_split_lab.txt: the DCN
+    // contraction 92 -> 82 us, feat_conv_3x3 506 -> 491); on the short-K convolutions halving the tile count costs more
+    if (Cout % 128 == 0 && variant != 1 && (variant == 2 || chunk_total >= 128)) { p.nt = 4; p.ny = Cout / 128; }
+    const double chunk_us = p.nt == 4 ? 1.6 : 1.2;
     // How many slices of K.  Two workgroups per CU run almost as fast as one each (measured: ~1.2 us per chunk either
     // way), so time ~ rounds of 512 workgroups x chunks per slice, plus the reduce pass over `slices` partial outputs
     // (~3 TB/s effective).  A 304-workgroup grid run as one round leaves 40 % of the slots empty for its whole length;
@@ -322,7 +332,7 @@ SplitPlan split_plan(int N, int H, int W, int Cin, int Cout, int kh, int kw, int
       const int used = (chunk_total + per - 1) / per;
       if (used != s) continue;
       const long rounds = (wgs * s + 511) / 512;
-      const double t = (double)rounds * per * 1.2 + (s > 1 ? 3.0 + s * out_mb * 2.0 / 3.0 : 0.0);
+      const double t = (double)rounds * per * chunk_us + (s > 1 ? 3.0 + s * out_mb * 2.0 / 3.0 : 0.0);
       if (s == 1 || t < best * 0.97) { best = t; best_s = s; }      // a more finely cut K must pay for itself
     }
     p.per_slice = (chunk_total + best_s - 1) / best_s;
@@ -330,7 +340,27 @@ SplitPlan split_plan(int N, int H, int W, int Cin, int Cout, int kh, int kw, int
   }
   return p;
 }
+
+// the general kernel's plan for an output grid of Ho x Wo pixels (what a view launch falls back to)
+SplitPlan split_plan_general(int N, int Ho, int Wo, int Cin, int Cout, int kh, int kw) {
+  // stride 7 with a 1x1 input-independent shape: split_plan only looks at the OUTPUT grid for the general kernel, so describe
+  // a convolution with that output: stride 1, no padding, input (Ho + kh - 1) x (Wo + kw - 1), and a stride that rules out the halo form
+  SplitPlan p = split_plan(N, (Ho - 1) * 3 + kh, (Wo - 1) * 3 + kw, Cin, Cout, kh, kw, 3, 0, 1);
+  return p;
+}
+
+size_t split_workspace(const SplitPlan& p, long P, int Cout) {
+  if (p.units_per_wg > 0)      // one 32 KB accumulator slot per (tile, piece)
+    return (size_t)p.nx * p.ny * p.max_pieces * convsplit::kThreads * 32 * sizeof(float);
+  return p.slices > 1 ? align_up((size_t)p.slices * P * Cout * sizeof(float), 256) : 256;
+}
 }  // namespace
+
+extern "C" int lsfa_conv_split_set_variant(int variant) {
+  LSFA_REQUIRE(variant >= 0 && variant <= 2, "lsfa_conv_split_set_variant: unknown variant %d", variant);
+  g_split_variant.store(variant);
+  return LSFA_OK;
+}
 
 extern "C" size_t lsfa_conv_split_weight_bytes(int Cout, int kh, int kw, int Cin) {
   if (Cout <= 0 || kh <= 0 || kw <= 0 || Cin <= 0 || Cin % 32 != 0 || Cout % 64 != 0) return 0;
@@ -350,40 +380,46 @@ extern "C" int lsfa_conv_split_weights(const float* w, int Cout, int kh, int kw,
   return LSFA_OK;
 }
 
-extern "C" size_t lsfa_conv_split_workspace_bytes(int N, int H, int W, int Cin, int Cout, int kh, int kw, int stride, int pad, int dil) {
-  if (N <= 0 || H <= 0 || W <= 0 || Cout <= 0 || Cin <= 0 || stride <= 0 || kh <= 0 || kw <= 0 || dil <= 0 || pad < 0) return 0;
-  const int Ho = (H + 2 * pad - dil * (kh - 1) - 1) / stride + 1, Wo = (W + 2 * pad - dil * (kw - 1) - 1) / stride + 1;
-  if (Ho <= 0 || Wo <= 0) return 0;
-  const SplitPlan p = split_plan(N, H, W, Cin, Cout, kh, kw, stride, pad, dil);
-  if (p.units_per_wg > 0)      // one 32 KB accumulator slot per (tile, piece)
-    return (size_t)p.nx * p.ny * p.max_pieces * convsplit::kThreads * 32 * sizeof(float);
-  return p.slices > 1 ? align_up((size_t)p.slices * N * Ho * Wo * Cout * sizeof(float), 256) : 256;
-}
-
-extern "C" int lsfa_conv_split_fwd(const float* x, int N, int H, int W, int Cin, const void* wfrag, const float* bias, int Cout,
-                                   int kh, int kw, int stride, int pad, int dil, int relu, int y_nchw, const float* residual, float* y,
-                                   float* y2, const float* scale2, const float* shift2, void* ws, size_t ws_bytes, void* stream) {
-  LSFA_REQUIRE(x && wfrag && y, "lsfa_conv_split_fwd: NULL argument");
-  LSFA_REQUIRE(N > 0 && H > 0 && W > 0 && kh > 0 && kw > 0 && stride > 0 && pad >= 0 && dil > 0, "lsfa_conv_split_fwd: bad shape");
-  LSFA_REQUIRE(!y2 || (scale2 && shift2), "lsfa_conv_split_fwd: y2 given without scale2 / shift2");
-  LSFA_REQUIRE(!y2 || y2 != y, "lsfa_conv_split_fwd: y2 must not alias y");
+namespace {
+// every split convolution goes through here; the public entry points fill in what they expose
+int conv_split_launch(convsplit::Args a, void* ws, size_t ws_bytes, void* stream, const char* who) {
+  const int N = a.N, H = a.H, W = a.W, Cin = a.Cin, Cout = a.Cout, kh = a.kh, kw = a.kw, stride = a.stride, dil = a.dil;
+  LSFA_REQUIRE(a.x && a.wfrag && a.y, "%s: NULL argument", who);
+  LSFA_REQUIRE(N > 0 && H > 0 && W > 0 && kh > 0 && kw > 0 && stride > 0 && a.pad_h >= 0 && a.pad_w >= 0 && dil > 0, "%s: bad shape", who);
+  LSFA_REQUIRE(!a.y2 || (a.scale2 && a.shift2), "%s: y2 given without scale2 / shift2", who);
+  LSFA_REQUIRE(!a.y2 || a.y2 != a.y, "%s: y2 must not alias y", who);
   if (Cin % 32 != 0 || Cout % convsplit::kWgCh != 0) {
-    set_error("lsfa_conv_split_fwd: Cin=%d must be a multiple of 32 and Cout=%d of %d", Cin, Cout, convsplit::kWgCh);
+    set_error("%s: Cin=%d must be a multiple of 32 and Cout=%d of %d", who, Cin, Cout, convsplit::kWgCh);
     return LSFA_ENOTSUP;
   }
-  const int Ho = (H + 2 * pad - dil * (kh - 1) - 1) / stride + 1, Wo = (W + 2 * pad - dil * (kw - 1) - 1) / stride + 1;
-  LSFA_REQUIRE(Ho > 0 && Wo > 0, "lsfa_conv_split_fwd: empty output");
-  const long P = (long)N * Ho * Wo;
-  LSFA_REQUIRE(P * Cout < (1L << 31) && ((long)N * H * W + (long)(pad + 1) * (W + 1)) * Cin < (1L << 31), "lsfa_conv_split_fwd: tensor too large");
-  const SplitPlan p = split_plan(N, H, W, Cin, Cout, kh, kw, stride, pad, dil);
-  const size_t need = lsfa_conv_split_workspace_bytes(N, H, W, Cin, Cout, kh, kw, stride, pad, dil);
+  const int Ho = (H + 2 * a.pad_h - dil * (kh - 1) - 1) / stride + 1, Wo = (W + 2 * a.pad_w - dil * (kw - 1) - 1) / stride + 1;
+  LSFA_REQUIRE(Ho > 0 && Wo > 0, "%s: empty output", who);
+  if (a.Ho <= 0) a.Ho = Ho;        // a transposed convolution's phase passes its own (smaller) output grid
+  if (a.Wo <= 0) a.Wo = Wo;
+  // taps that fall outside the image read zeros wherever they are, so a grid may extend past the symmetric-padding output
+  // (a transposed convolution's odd phase needs one more column on the right: padding 0 on the left, 1 on the right)
+  LSFA_REQUIRE(a.Ho <= Ho + kh && a.Wo <= Wo + kw, "%s: output grid %dx%d far larger than the convolution's %dx%d", who, a.Ho, a.Wo, Ho, Wo);
+  if (a.lda <= 0) a.lda = Cin;
+  if (a.ldy <= 0) a.ldy = Cout;
+  LSFA_REQUIRE(a.lda >= Cin && a.ldy >= Cout && a.lda % 4 == 0, "%s: lda %d / ldy %d smaller than the channel counts (or lda not a multiple of 4)", who, a.lda, a.ldy);
+  LSFA_REQUIRE(!(a.y_nchw && (a.view || a.ldy != Cout)), "%s: an NCHW output cannot be a view", who);
+  LSFA_REQUIRE(((uintptr_t)a.x & 15) == 0, "%s: x must be 16-byte aligned", who);
+  if (!a.view) { a.out_H = a.Ho; a.out_W = a.Wo; a.out_sy = a.out_sx = 1; }
+  const long P = (long)N * a.Ho * a.Wo;
+  LSFA_REQUIRE(((long)N * a.out_H * a.out_W + 1) * (long)(a.y_nchw ? Cout : a.ldy) < (1L << 31) && P * Cout < (1L << 31) &&
+               ((long)N * H * W + (long)(a.pad_h + 1) * (W + 1)) * a.lda < (1L << 31), "%s: tensor too large", who);
+  SplitPlan p = split_plan(N, H, W, Cin, Cout, kh, kw, stride, a.pad_h, dil);
+  if (p.halo && (a.pad_h != a.pad_w || a.lda != Cin || a.Ho != Ho || a.Wo != Wo)) p = split_plan_general(N, a.Ho, a.Wo, Cin, Cout, kh, kw);
+  else if (!p.halo && (a.Ho != Ho || a.Wo != Wo)) p = split_plan_general(N, a.Ho, a.Wo, Cin, Cout, kh, kw);
+  const size_t need = split_workspace(p, P, Cout);
   if ((p.slices > 1 || p.units_per_wg > 0) && (!ws || ws_bytes < need)) {
-    set_error("lsfa_conv_split_fwd: workspace %zu < %zu bytes", ws_bytes, need);
+    set_error("%s: workspace %zu < %zu bytes", who, ws_bytes, need);
     return LSFA_EWORKSPACE;
   }
   hipStream_t s = (hipStream_t)stream;
-  convsplit::Args a = {x, (const uint4*)wfrag, bias, y, p.slices > 1 ? (float*)ws : nullptr, N, H, W, Cin, Cout, kh, kw, stride, pad,
-                       dil, Ho, Wo, relu, p.per_slice, residual, y2, scale2, shift2, y_nchw, 0, 0};
+  a.part = p.slices > 1 ? (float*)ws : nullptr;
+  a.chunks_per_slice = p.per_slice;
+  a.units_per_wg = a.max_pieces = 0;
   ProfScope prof(LSFA_OP_CONV, s);
   int tiles = p.nx * p.ny * p.slices;
   if (p.units_per_wg > 0) {
@@ -397,6 +433,8 @@ extern "C" int lsfa_conv_split_fwd(const float* x, int N, int H, int W, int Cin,
     hipLaunchKernelGGL(convsplit::conv_split3x3_kernel<1>, grid, dim3(convsplit::kThreads), 0, s, a, p.patches_x, p.patches_y, p.nx, p.ny, p.slices);
   else if (p.halo)
     hipLaunchKernelGGL(convsplit::conv_split3x3_kernel<2>, grid, dim3(convsplit::kThreads), 0, s, a, p.patches_x, p.patches_y, p.nx, p.ny, p.slices);
+  else if (p.nt == 4)
+    hipLaunchKernelGGL(convsplit::conv_split_wide_kernel<4>, grid, dim3(convsplit::kThreads), 0, s, a, p.nx, p.ny, p.slices);
   else
     hipLaunchKernelGGL(convsplit::conv_split_kernel, grid, dim3(convsplit::kThreads), 0, s, a, p.nx, p.ny, p.slices);
   if (p.units_per_wg > 0) {
@@ -404,10 +442,48 @@ extern "C" int lsfa_conv_split_fwd(const float* x, int N, int H, int W, int Cin,
                        p.patches_y, p.nx);
   }
   if (p.slices > 1) {
-    ConvArgs r = {x, nullptr, bias, y, (float*)ws, N, H, W, Cin, Cout, kh, kw, stride, pad, dil, Ho, Wo, relu, 0, residual, y2, scale2, shift2, y_nchw};
     const long n4 = P * Cout / 4;
-    hipLaunchKernelGGL(conv_reduce_kernel, dim3((unsigned)((n4 + kThreads - 1) / kThreads)), dim3(kThreads), 0, s, r, n4, p.slices);
+    hipLaunchKernelGGL(convsplit::split_reduce_kernel, dim3((unsigned)((n4 + convsplit::kThreads - 1) / convsplit::kThreads)),
+                       dim3(convsplit::kThreads), 0, s, a, n4, p.slices);
   }
-  LSFA_LAUNCH_CHECK("lsfa_conv_split_fwd");
+  LSFA_LAUNCH_CHECK(who);
   return LSFA_OK;
+}
+}  // namespace
+
+extern "C" size_t lsfa_conv_split_workspace_bytes(int N, int H, int W, int Cin, int Cout, int kh, int kw, int stride, int pad, int dil) {
+  if (N <= 0 || H <= 0 || W <= 0 || Cout <= 0 || Cin <= 0 || stride <= 0 || kh <= 0 || kw <= 0 || dil <= 0 || pad < 0) return 0;
+  const int Ho = (H + 2 * pad - dil * (kh - 1) - 1) / stride + 1, Wo = (W + 2 * pad - dil * (kw - 1) - 1) / stride + 1;
+  if (Ho <= 0 || Wo <= 0) return 0;
+  const SplitPlan p = split_plan(N, H, W, Cin, Cout, kh, kw, stride, pad, dil);
+  const size_t a = split_workspace(p, (long)N * Ho * Wo, Cout);
+  // a view launch (lsfa_conv_split_view_fwd) may fall back from the halo plan to the general one: size for both
+  const size_t b = split_workspace(split_plan_general(N, Ho, Wo, Cin, Cout, kh, kw), (long)N * Ho * Wo, Cout);
+  return a > b ? a : b;
+}
+
+extern "C" int lsfa_conv_split_fwd(const float* x, int N, int H, int W, int Cin, const void* wfrag, const float* bias, int Cout,
+                                   int kh, int kw, int stride, int pad, int dil, int relu, int y_nchw, const float* residual, float* y,
+                                   float* y2, const float* scale2, const float* shift2, void* ws, size_t ws_bytes, void* stream) {
+  convsplit::Args a = {};
+  a.x = x; a.wfrag = (const uint4*)wfrag; a.bias = bias; a.y = y;
+  a.N = N; a.H = H; a.W = W; a.Cin = Cin; a.Cout = Cout; a.kh = kh; a.kw = kw; a.stride = stride; a.pad_h = a.pad_w = pad; a.dil = dil;
+  a.act = relu ? 1 : 0; a.res = residual; a.y2 = y2; a.scale2 = scale2; a.shift2 = shift2; a.y_nchw = y_nchw;
+  return conv_split_launch(a, ws, ws_bytes, stream, "lsfa_conv_split_fwd");
+}
+
+extern "C" int lsfa_conv_split_view_fwd(const float* x, int lda, int N, int H, int W, int Cin, const void* wfrag, const float* bias,
+                                        int Cout, int kh, int kw, int stride, int pad_h, int pad_w, int dil, int act, float* y, int ldy,
+                                        int Ho, int Wo, int out_H, int out_W, int out_sy, int out_sx, void* ws, size_t ws_bytes,
+                                        void* stream) {
+  LSFA_REQUIRE(act >= 0 && act <= 2, "lsfa_conv_split_view_fwd: act must be 0 (none), 1 (ReLU) or 2 (LeakyReLU 0.1)");
+  convsplit::Args a = {};
+  a.x = x; a.wfrag = (const uint4*)wfrag; a.bias = bias; a.y = y;
+  a.N = N; a.H = H; a.W = W; a.Cin = Cin; a.Cout = Cout; a.kh = kh; a.kw = kw; a.stride = stride; a.pad_h = pad_h; a.pad_w = pad_w; a.dil = dil;
+  a.act = act; a.lda = lda; a.ldy = ldy; a.Ho = Ho; a.Wo = Wo;
+  if (out_H > 0) {
+    LSFA_REQUIRE(out_W > 0 && out_sy > 0 && out_sx > 0, "lsfa_conv_split_view_fwd: bad output view");
+    a.view = 1; a.out_H = out_H; a.out_W = out_W; a.out_sy = out_sy; a.out_sx = out_sx;
+  }
+  return conv_split_launch(a, ws, ws_bytes, stream, "lsfa_conv_split_view_fwd");
 }

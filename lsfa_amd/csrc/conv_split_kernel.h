@@ -48,12 +48,20 @@ constexpr int kChunkBytesB = 2 /*col tiles*/ * 2 /*steps*/ * 3 /*pieces*/ * 1024
 
 struct Args {
   const float* x; const uint4* wfrag; const float* bias; float* y; float* part;
-  int N, H, W, Cin, Cout, kh, kw, stride, pad, dil, Ho, Wo, relu, chunks_per_slice;
+  int N, H, W, Cin, Cout, kh, kw, stride, pad_h, pad_w, dil, Ho, Wo, chunks_per_slice;
+  int act;         // 0 none, 1 ReLU, 2 LeakyReLU(0.1) (FlowNet, resnet_v1_101_flownet_rfcn.py:153-176)
   const float* res; float* y2; const float* scale2; const float* shift2;
   int y_nchw;      // y / y2 / res are (N, Cout, Ho, Wo) instead of (N, Ho, Wo, Cout); partial slices stay NHWC
   // halo kernel, balanced mode (units_per_wg > 0): every workgroup takes the same number of (tile, channel chunk) units,
   // crossing tile boundaries; a tile shared by several workgroups is put together by conv_split3x3_fixup_kernel
   int units_per_wg; int max_pieces;
+  // r3: operand views, so that producers write into (and consumers read from) channel slices of wider maps without copies
+  //   lda   floats between consecutive input pixels (>= Cin; the general kernels only)
+  //   ldy   floats between consecutive output pixels (>= Cout): y = channels [c0, c0 + Cout) of an (.., ldy) map, the
+  //         pointer already advanced to c0.  view != 0 additionally places output pixel (oy, ox) of image n at
+  //         ((n * out_H + oy * out_sy) * out_W + ox * out_sx) * ldy  (the pointer already advanced to the first one):
+  //         the four phases of a stride-2 transposed convolution each write every other pixel of the full map.
+  int lda, ldy, view, out_H, out_W, out_sy, out_sx;
 };
 
 // the leading 8 mantissa bits of v as an fp32 bit pattern (= a bf16 value), and what is left
@@ -103,6 +111,92 @@ __device__ __forceinline__ f32x16 mma6(const Pieces& a, const uint4& b1, const u
   return acc;
 }
 
+// ---- epilogue shared by the kernels below -----------------------------------------------------------------------
+// Where output pixel p (= (n * Ho + oy) * Wo + ox of THIS launch) starts in y / y2 / res, and the distance between channels.
+struct RowOut { int base[16]; unsigned valid; };
+
+__device__ __forceinline__ int out_pixel_base(const Args& a, int p) {
+  if (a.y_nchw) { const int hw = a.Ho * a.Wo, pn = p / hw; return pn * a.Cout * hw + (p - pn * hw); }
+  if (a.view) {
+    const int hw = a.Ho * a.Wo, pn = p / hw, r = p - pn * hw, oy = r / a.Wo, ox = r - oy * a.Wo;
+    return ((pn * a.out_H + oy * a.out_sy) * a.out_W + ox * a.out_sx) * a.ldy;
+  }
+  return p * a.ldy;
+}
+
+__device__ __forceinline__ float activate(float v, int act) {
+  return act == 1 ? fmaxf(v, 0.f) : (act == 2 ? (v > 0.f ? v : v * 0.1f) : v);
+}
+
+// one 32 x 32 accumulator (C/D layout: column = lane & 31 = channel, register r = pixel row of `ro`) -> its outputs:
+// bias, residual (all loads first, so that no store waits on a load), activation, second output
+__device__ __forceinline__ void tile_store(const Args& a, const RowOut& ro, int ch, const f32x16& acc) {
+  const int cs = a.y_nchw ? a.Ho * a.Wo : 1;
+  const float bias = a.bias ? a.bias[ch] : 0.f;
+  float v[16];
+#pragma unroll
+  for (int r = 0; r < 16; ++r) v[r] = acc[r] + bias;
+  if (a.res) {
+    float rv[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) rv[r] = ((ro.valid >> r) & 1u) ? a.res[ro.base[r] + ch * cs] : 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) v[r] = v[r] + rv[r];
+  }
+#pragma unroll
+  for (int r = 0; r < 16; ++r) v[r] = activate(v[r], a.act);
+#pragma unroll
+  for (int r = 0; r < 16; ++r)
+    if ((ro.valid >> r) & 1u) a.y[ro.base[r] + ch * cs] = v[r];
+  if (a.y2) {
+    const float sc2 = a.scale2[ch], sh2 = a.shift2[ch];
+#pragma unroll
+    for (int r = 0; r < 16; ++r)
+      if ((ro.valid >> r) & 1u) a.y2[ro.base[r] + ch * cs] = fmaxf(v[r] * sc2 + sh2, 0.f);
+  }
+}
+
+// a K slice's partial sums: dense (P, Cout) rows, whatever the output view
+__device__ __forceinline__ void tile_store_part(float* part, int Cout, const int (&p)[16], unsigned valid, int ch, const f32x16& acc) {
+#pragma unroll
+  for (int r = 0; r < 16; ++r)
+    if ((valid >> r) & 1u) part[(size_t)p[r] * Cout + ch] = acc[r];
+}
+
+// sum of the K slices in slice order (reproducible), then the same tail as tile_store; a float4 of channels per thread
+static __global__ __launch_bounds__(kThreads) void split_reduce_kernel(Args a, long n4, int slices) {
+  const long i = (long)blockIdx.x * kThreads + threadIdx.x;
+  if (i >= n4) return;
+  const float4* part = reinterpret_cast<const float4*>(a.part);
+  float4 s = part[i];
+  for (int z = 1; z < slices; ++z) {
+    const float4 v = part[(size_t)z * n4 + i];
+    s.x = s.x + v.x; s.y = s.y + v.y; s.z = s.z + v.z; s.w = s.w + v.w;
+  }
+  const int c4 = a.Cout / 4;
+  const int p = (int)(i / c4), ch = (int)(i - (long)p * c4) * 4;
+  const int base = out_pixel_base(a, p), cs = a.y_nchw ? a.Ho * a.Wo : 1;
+  float o1[4] = {s.x, s.y, s.z, s.w}, o2[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    float v = o1[k] + (a.bias ? a.bias[ch + k] : 0.f);
+    if (a.res) v = v + a.res[base + (ch + k) * cs];
+    v = activate(v, a.act);
+    o1[k] = v;
+    o2[k] = a.y2 ? fmaxf(v * a.scale2[ch + k] + a.shift2[ch + k], 0.f) : 0.f;
+  }
+  if (cs == 1 && ((base + ch) & 3) == 0 && ((uintptr_t)a.y & 15) == 0 && (!a.y2 || ((uintptr_t)a.y2 & 15) == 0)) {
+    *reinterpret_cast<float4*>(a.y + base + ch) = make_float4(o1[0], o1[1], o1[2], o1[3]);
+    if (a.y2) *reinterpret_cast<float4*>(a.y2 + base + ch) = make_float4(o2[0], o2[1], o2[2], o2[3]);
+    return;
+  }
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    a.y[base + (ch + k) * cs] = o1[k];
+    if (a.y2) a.y2[base + (ch + k) * cs] = o2[k];
+  }
+}
+
 constexpr int kStageA = 4 * 4 * 64;                     // uint4 per stage: 4 waves x 32 pixels x 8 slots = 16 KB
 constexpr int kStageB = kChunkBytesB / 16;              // 768 uint4 = 12 KB
 constexpr int kStage = kStageA + kStageB;               // 28 KB; two stages = 56 KB, two workgroups per CU
@@ -111,7 +205,7 @@ __device__ __attribute__((aligned(64))) const float g_zero_block[32] = {};
 
 struct Geom {       // per lane / per wave constants of the loop
   size_t wstride;                            // uint4 between consecutive chunks
-  int H, W, Cin, kw, stride, pad, dil, chunks_per_tap, chunk0;
+  int H, W, Cin, lda, kw, stride, dil, chunks_per_tap, chunk0;
   // the four pixels this lane moves (DMA i: pixel 8*i + (lane >> 3)): top-left input coordinate of its window
   // (hugely negative when the pixel does not exist) and the float offset of (that coordinate, the lane's swizzled piece)
   int iy0[4], ix0[4], off0[4];
@@ -136,7 +230,7 @@ __device__ __forceinline__ void issue_chunk(uint4 (*S)[kStage], const float* __r
                                             const Geom& g, const Walk& wk) {
   const int gch = wk.gch, kc = wk.kc;
   const int dy = wk.ty * g.dil, dx = wk.tx * g.dil;
-  const int doff = (dy * g.W + dx) * g.Cin + kc * kChunk;        // wave-uniform part of the source offset
+  const int doff = (dy * g.W + dx) * g.lda + kc * kChunk;        // wave-uniform part of the source offset
   uint4* a_dst = &S[ST][g.wave * 256];                           // + i * 64 (+ lane, implied by the DMA)
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
@@ -225,7 +319,7 @@ static __global__ __launch_bounds__(kThreads, 2) void conv_split_kernel(Args a, 
   Geom g;
   g.lane = tid & 63;
   g.wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  g.H = a.H; g.W = a.W; g.Cin = a.Cin; g.kw = a.kw; g.stride = a.stride; g.pad = a.pad; g.dil = a.dil;
+  g.H = a.H; g.W = a.W; g.Cin = a.Cin; g.lda = a.lda; g.kw = a.kw; g.stride = a.stride; g.dil = a.dil;
   g.chunks_per_tap = a.Cin / kChunk;
   const int chunk_total = taps * g.chunks_per_tap;
   g.chunk0 = tile.z * a.chunks_per_slice;
@@ -243,9 +337,9 @@ static __global__ __launch_bounds__(kThreads, 2) void conv_split_kernel(Args a, 
     g.off0[i] = 0;
     if (pix < P) {
       const int pn = pix / (a.Ho * a.Wo), r = pix - pn * a.Ho * a.Wo, py = r / a.Wo, px = r - py * a.Wo;
-      g.iy0[i] = py * a.stride - a.pad;
-      g.ix0[i] = px * a.stride - a.pad;
-      g.off0[i] = ((pn * a.H + g.iy0[i]) * a.W + g.ix0[i]) * a.Cin + 4 * piece;     // may be negative; only used in bounds
+      g.iy0[i] = py * a.stride - a.pad_h;
+      g.ix0[i] = px * a.stride - a.pad_w;
+      g.off0[i] = ((pn * a.H + g.iy0[i]) * a.W + g.ix0[i]) * a.lda + 4 * piece;     // may be negative; only used in bounds
     }
   }
   // (slot q of pixel p holds piece q ^ ((p >> 1) & 7); for p = 8i + (lane >> 3) that is (4i + (lane >> 4)) & 7: issue_chunk)
@@ -278,29 +372,184 @@ static __global__ __launch_bounds__(kThreads, 2) void conv_split_kernel(Args a, 
 
   // C/D layout of 32x32: column = lane & 31 (channel), row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5) (pixel)
   const int lane = g.lane;
-  float* part = a.part ? a.part + (size_t)tile.z * P * a.Cout : nullptr;
+  int prow[16];
+  RowOut ro;
+  ro.valid = 0;
 #pragma unroll
-  for (int t = 0; t < 2; ++t) {
-    const int ch = tile.y * kWgCh + t * 32 + (lane & 31);
-    const float bias = (!part && a.bias) ? a.bias[ch] : 0.f;
-    const float sc2 = (!part && a.y2) ? a.scale2[ch] : 0.f, sh2 = (!part && a.y2) ? a.shift2[ch] : 0.f;
+  for (int r = 0; r < 16; ++r) {
+    prow[r] = m0 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+    if (prow[r] < P) ro.valid |= 1u << r;
+  }
+  if (a.part) {
+    float* part = a.part + (size_t)tile.z * P * a.Cout;
+    tile_store_part(part, a.Cout, prow, ro.valid, tile.y * kWgCh + (lane & 31), acc0);
+    tile_store_part(part, a.Cout, prow, ro.valid, tile.y * kWgCh + 32 + (lane & 31), acc1);
+    return;
+  }
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-      const int p = m0 + row;
-      if (p < P) {
-        size_t o = (size_t)p * a.Cout + ch;
-        float v = t == 0 ? acc0[r] : acc1[r];
-        if (part) { part[o] = v; continue; }
-        if (a.y_nchw) { const int hw = a.Ho * a.Wo, pn = p / hw; o = ((size_t)pn * a.Cout + ch) * hw + (p - pn * hw); }
-        v = v + bias;
-        if (a.res) v = v + a.res[o];
-        if (a.relu) v = fmaxf(v, 0.f);
-        a.y[o] = v;
-        if (a.y2) a.y2[o] = fmaxf(v * sc2 + sh2, 0.f);
-      }
+  for (int r = 0; r < 16; ++r) ro.base[r] = ((ro.valid >> r) & 1u) ? out_pixel_base(a, prow[r]) : 0;
+  tile_store(a, ro, tile.y * kWgCh + (lane & 31), acc0);
+  tile_store(a, ro, tile.y * kWgCh + 32 + (lane & 31), acc1);
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// r3: the same kernel with WIDER wave tiles.  What bounds the loop above is not the matrix pipe but everything a wave must
+// issue around its 24 MFMAs per chunk: 7 LDS-DMAs, ~110 VALU instructions to cut its 32 x 32 activations, 16 ds_reads
+// (profiles/r2/conv_split_chunk_cycles.txt: 2710 cycles per chunk for 768 cycles of MFMA).  With a wave tile of 32 pixels x
+// 32*NT channels (NT = 4: four accumulators, a workgroup of 4 waves = 128 pixels x 128 channels) the SAME cut and the
+// same four A DMAs feed NT*12 MFMAs, and the B block of a chunk (NT x 6 KB) is shared by the four waves: per MFMA half the
+// cut work, 10 instead of 14 DMAs per 48 MFMAs and half the A bytes.  B DMAs are issued between the column tiles' MFMA
+// groups so that they go out while the matrix pipe drains.  Stage = 16 KB A + NT*6 KB B; two stages, two workgroups per CU
+// (NT = 4: 2 x 80 KB = the CU's whole LDS).  Everything else (A image and swizzle, B fragment order, K slices, epilogue) as
+// conv_split_kernel.
+template <int NT> struct Wide {
+  static constexpr int kStageBn = NT * 384;                 // uint4 of B per stage
+  static constexpr int kStageN = kStageA + kStageBn;
+  static constexpr int kDmaB = (NT * 384) / (4 * 64);       // B DMA instructions per wave and chunk: NT * 1.5
+  static_assert((NT * 384) % 256 == 0, "NT must be even");
+};
+
+template <int NT, int ST>
+__device__ __forceinline__ void wide_issue_a(uint4 (*S)[Wide<NT>::kStageN], const float* __restrict__ x, const Geom& g, const Walk& wk) {
+  const int dy = wk.ty * g.dil, dx = wk.tx * g.dil;
+  const int doff = (dy * g.W + dx) * g.lda + wk.kc * kChunk;
+  uint4* a_dst = &S[ST][g.wave * 256];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const bool ok = (unsigned)(g.iy0[i] + dy) < (unsigned)g.H && (unsigned)(g.ix0[i] + dx) < (unsigned)g.W;
+    const float* src = ok ? x + (g.off0[i] + doff) : g_zero_block;
+    __builtin_amdgcn_global_load_lds(reinterpret_cast<const uint4*>(src), a_dst + i * 64, 16, 0, 0);
+  }
+}
+
+// B DMA instructions I0 .. I1-1 of this wave's share (Wide<NT>::kDmaB in all) of chunk `gch`
+template <int NT, int ST, int I0, int I1>
+__device__ __forceinline__ void wide_issue_b(uint4 (*S)[Wide<NT>::kStageN], const uint4* __restrict__ wblock, const Geom& g, int gch) {
+  const uint4* wsrc = wblock + (size_t)gch * g.wstride + g.wave * (Wide<NT>::kDmaB * 64) + g.lane;
+  uint4* b_dst = &S[ST][kStageA + g.wave * (Wide<NT>::kDmaB * 64)];
+#pragma unroll
+  for (int i = I0; i < I1; ++i) __builtin_amdgcn_global_load_lds(wsrc + i * 64, b_dst + i * 64, 16, 0, 0);
+}
+
+template <int NT, int ST>
+__device__ __forceinline__ void wide_step(uint4 (*S)[Wide<NT>::kStageN], const float* __restrict__ x, const uint4* __restrict__ wblock,
+                                          const Geom& g, Walk& wk, int c, int n, f32x16 (&acc)[NT]) {
+  constexpr int kDmaB = Wide<NT>::kDmaB;
+  const bool more = c + 1 < n;
+  const int gch_next = wk.gch;
+  if (more) wide_issue_a<NT, ST ^ 1>(S, x, g, wk);
+  const uint4* A = &S[ST][g.wave * 256];
+  const uint4* B = &S[ST][kStageA + g.lane];
+  const uint4 r0 = A[g.frag[0]], r1 = A[g.frag[1]], r2 = A[g.frag[2]], r3 = A[g.frag[3]];
+  const float4 c0 = make_float4(__uint_as_float(r0.x), __uint_as_float(r0.y), __uint_as_float(r0.z), __uint_as_float(r0.w));
+  const float4 c1 = make_float4(__uint_as_float(r1.x), __uint_as_float(r1.y), __uint_as_float(r1.z), __uint_as_float(r1.w));
+  const float4 c2 = make_float4(__uint_as_float(r2.x), __uint_as_float(r2.y), __uint_as_float(r2.z), __uint_as_float(r2.w));
+  const float4 c3 = make_float4(__uint_as_float(r3.x), __uint_as_float(r3.y), __uint_as_float(r3.z), __uint_as_float(r3.w));
+  const Pieces s0 = split8(c0, c1), s1 = split8(c2, c3);
+#pragma unroll
+  for (int t = 0; t < NT; ++t) {
+    // fragment (col tile t, step s, piece p) at ((t*2 + s)*3 + p)*64 + lane
+    acc[t] = mma6(s0, B[((t * 2 + 0) * 3 + 0) * 64], B[((t * 2 + 0) * 3 + 1) * 64], B[((t * 2 + 0) * 3 + 2) * 64], acc[t]);
+    acc[t] = mma6(s1, B[((t * 2 + 1) * 3 + 0) * 64], B[((t * 2 + 1) * 3 + 1) * 64], B[((t * 2 + 1) * 3 + 2) * 64], acc[t]);
+    if (more) {      // this wave's share of the next chunk's weights, a slice behind each column tile's MFMAs
+      constexpr int kPer = (kDmaB + NT - 1) / NT;
+      constexpr int kE1 = (2 * kPer < kDmaB) ? 2 * kPer : kDmaB;
+      if (t == 0) wide_issue_b<NT, ST ^ 1, 0, kPer>(S, wblock, g, gch_next);
+      if (NT > 1 && t == 1) wide_issue_b<NT, ST ^ 1, kPer, kE1>(S, wblock, g, gch_next);
+      if (NT > 2 && t == 2) wide_issue_b<NT, ST ^ 1, kE1, kDmaB>(S, wblock, g, gch_next);
     }
   }
+  if (more) wk.next(g.kw, g.chunks_per_tap);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+}
+
+// grid (8 * ceil(tiles / 8)); block 256.  tiles = ceil(P / 128) * (Cout / (32*NT)) * slices
+template <int NT>
+static __global__ __launch_bounds__(kThreads, 2) void conv_split_wide_kernel(Args a, int nx, int ny, int nz) {
+  typedef Wide<NT> WD;
+  __shared__ __attribute__((aligned(16))) uint4 S[2][WD::kStageN];
+  const Tile tile = xcd_tile(blockIdx.x, nx, ny, nz);
+  if (tile.x < 0) return;
+  const int tid = threadIdx.x;
+  const int P = a.N * a.Ho * a.Wo;
+  const int taps = a.kh * a.kw;
+  Geom g;
+  g.lane = tid & 63;
+  g.wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  g.H = a.H; g.W = a.W; g.Cin = a.Cin; g.lda = a.lda; g.kw = a.kw; g.stride = a.stride; g.dil = a.dil;
+  g.chunks_per_tap = a.Cin / kChunk;
+  const int chunk_total = taps * g.chunks_per_tap;
+  g.chunk0 = tile.z * a.chunks_per_slice;
+  const int nchunks = min(a.chunks_per_slice, chunk_total - g.chunk0);
+  const int col_tiles = a.Cout / 32;
+  g.wstride = (size_t)col_tiles * (kChunkBytesB / 32);
+  const uint4* wblock = a.wfrag + (size_t)(NT * tile.y) * (kChunkBytesB / 32);
+  const int m0 = tile.x * kWgPix + g.wave * kWavePix;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int pix = m0 + 8 * i + (g.lane >> 3);
+    const int piece = (g.lane & 7) ^ ((4 * i + (g.lane >> 4)) & 7);
+    g.iy0[i] = g.ix0[i] = -(1 << 24);
+    g.off0[i] = 0;
+    if (pix < P) {
+      const int pn = pix / (a.Ho * a.Wo), r = pix - pn * a.Ho * a.Wo, py = r / a.Wo, px = r - py * a.Wo;
+      g.iy0[i] = py * a.stride - a.pad_h;
+      g.ix0[i] = px * a.stride - a.pad_w;
+      g.off0[i] = ((pn * a.H + g.iy0[i]) * a.W + g.ix0[i]) * a.lda + 4 * piece;
+    }
+  }
+  {
+    const int r = g.lane & 31, h = g.lane >> 5, sw = (r >> 1) & 7;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) g.frag[j] = r * 8 + ((4 * h + j) ^ sw);
+  }
+  f32x16 acc[NT];
+#pragma unroll
+  for (int t = 0; t < NT; ++t)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[t][i] = 0.f;
+
+  Walk wk;
+  wk.gch = g.chunk0;
+  {
+    const int tap = g.chunk0 / g.chunks_per_tap;
+    wk.kc = g.chunk0 - tap * g.chunks_per_tap;
+    wk.ty = tap / a.kw;
+    wk.tx = tap - wk.ty * a.kw;
+  }
+  if (nchunks > 0) {
+    wide_issue_a<NT, 0>(S, a.x, g, wk);
+    wide_issue_b<NT, 0, 0, WD::kDmaB>(S, wblock, g, wk.gch);
+    wk.next(g.kw, g.chunks_per_tap);
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  for (int c = 0; c < nchunks; c += 2) {
+    wide_step<NT, 0>(S, a.x, wblock, g, wk, c, nchunks, acc);
+    if (c + 1 < nchunks) wide_step<NT, 1>(S, a.x, wblock, g, wk, c + 1, nchunks, acc);
+  }
+
+  const int lane = g.lane;
+  int prow[16];
+  RowOut ro;
+  ro.valid = 0;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    prow[r] = m0 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+    if (prow[r] < P) ro.valid |= 1u << r;
+  }
+  if (a.part) {
+    float* part = a.part + (size_t)tile.z * P * a.Cout;
+#pragma unroll
+    for (int t = 0; t < NT; ++t) tile_store_part(part, a.Cout, prow, ro.valid, tile.y * (32 * NT) + t * 32 + (lane & 31), acc[t]);
+    return;
+  }
+#pragma unroll
+  for (int r = 0; r < 16; ++r) ro.base[r] = ((ro.valid >> r) & 1u) ? out_pixel_base(a, prow[r]) : 0;
+#pragma unroll
+  for (int t = 0; t < NT; ++t) tile_store(a, ro, tile.y * (32 * NT) + t * 32 + (lane & 31), acc[t]);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -413,27 +662,24 @@ __device__ __forceinline__ void halo_chunk(uint4 (*S)[Halo<DIL>::kRow], const fl
 __device__ __forceinline__ void halo_epilogue(const Args& a, float* part, int pimg, int y0, int x0, int ch_tile, int wave, int lane,
                                               const f32x16& acc0, const f32x16& acc1) {
   const int oy = y0 + wave;
+  int prow[16];
+  RowOut ro;
+  ro.valid = 0;
 #pragma unroll
-  for (int t = 0; t < 2; ++t) {
-    const int ch = ch_tile * kWgCh + t * 32 + (lane & 31);
-    const float bias = (!part && a.bias) ? a.bias[ch] : 0.f;
-    const float sc2 = (!part && a.y2) ? a.scale2[ch] : 0.f, sh2 = (!part && a.y2) ? a.shift2[ch] : 0.f;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int ox = x0 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-      if (oy < a.H && ox < a.W) {
-        size_t o = ((size_t)(pimg * a.H + oy) * a.W + ox) * a.Cout + ch;
-        float v = t == 0 ? acc0[r] : acc1[r];
-        if (part) { part[o] = v; continue; }
-        if (a.y_nchw) o = (((size_t)pimg * a.Cout + ch) * a.H + oy) * a.W + ox;
-        v = v + bias;
-        if (a.res) v = v + a.res[o];
-        if (a.relu) v = fmaxf(v, 0.f);
-        a.y[o] = v;
-        if (a.y2) a.y2[o] = fmaxf(v * sc2 + sh2, 0.f);
-      }
-    }
+  for (int r = 0; r < 16; ++r) {
+    const int ox = x0 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+    prow[r] = (pimg * a.H + oy) * a.W + ox;
+    if (oy < a.H && ox < a.W) ro.valid |= 1u << r;
   }
+  if (part) {
+    tile_store_part(part, a.Cout, prow, ro.valid, ch_tile * kWgCh + (lane & 31), acc0);
+    tile_store_part(part, a.Cout, prow, ro.valid, ch_tile * kWgCh + 32 + (lane & 31), acc1);
+    return;
+  }
+#pragma unroll
+  for (int r = 0; r < 16; ++r) ro.base[r] = ((ro.valid >> r) & 1u) ? out_pixel_base(a, prow[r]) : 0;
+  tile_store(a, ro, ch_tile * kWgCh + (lane & 31), acc0);
+  tile_store(a, ro, ch_tile * kWgCh + 32 + (lane & 31), acc1);
 }
 
 // balanced mode, second launch: grid (tiles); block 256.  A tile that several workgroups shared: add their pieces in piece

@@ -541,6 +541,43 @@ def conv_split(x, sw, bias=None, stride=1, pad=0, dil=1, relu=False, out=None, r
     return out if out2 is None else (out, out2)
 
 
+@_on_tensor_device
+def conv_split_view(x, sw, bias, out, stride=1, pad=(0, 0), dil=1, act=0, cin=None, c0=0, grid=None, place=None):
+    """lsfa_conv_split_view_fwd: the split-bf16 convolution between VIEWS of wider channels-last maps.
+    x    (N, H, W, L) contiguous fp32, the convolution reads channels [0, cin) of it (cin = sw.cin by default, L >= cin);
+    out  (N, Hout, Wout, Lout) contiguous fp32: the result goes to channels [c0, c0 + sw.cout) of it;
+    grid (Ho, Wo): the output grid of this launch when smaller than the convolution's; place (y0, x0, sy, sx): output pixel
+         (oy, ox) is written to out[:, y0 + oy*sy, x0 + ox*sx] (default: out[:, oy, ox]) — a phase of a transposed convolution;
+    pad  (pad_h, pad_w); act 0 none / 1 ReLU / 2 LeakyReLU(0.1)."""
+    x = _f32c(x, "x")
+    if not (out.is_contiguous() and out.dtype == torch.float32 and out.dim() == 4):
+        raise LsfaError("conv_split_view: out must be a contiguous float32 (N, H, W, C) tensor")
+    N, H, W, L = x.shape
+    cin = sw.cin if cin is None else cin
+    if cin != sw.cin or L < cin:
+        raise LsfaError("conv_split_view: the weight has %d input channels, x offers %d (of %d)" % (sw.cin, cin, L))
+    if c0 < 0 or c0 + sw.cout > out.shape[3] or out.shape[0] != N:
+        raise LsfaError("conv_split_view: channels [%d, %d) do not fit out %s" % (c0, c0 + sw.cout, tuple(out.shape)))
+    kh, kw = sw.kh, sw.kw
+    Hc, Wc = (H + 2 * pad[0] - dil * (kh - 1) - 1) // stride + 1, (W + 2 * pad[1] - dil * (kw - 1) - 1) // stride + 1
+    Ho, Wo = grid if grid is not None else (Hc, Wc)
+    y0, x0, sy, sx = place if place is not None else (0, 0, 1, 1)
+    Hout, Wout, Lout = out.shape[1], out.shape[2], out.shape[3]
+    if y0 + (Ho - 1) * sy >= Hout or x0 + (Wo - 1) * sx >= Wout:
+        raise LsfaError("conv_split_view: a %dx%d grid placed at (%d,%d) step (%d,%d) leaves out %s" % (Ho, Wo, y0, x0, sy, sx, tuple(out.shape)))
+    _count_conv(N, Ho, Wo, sw.cout, cin, kh, kw)
+    need = lib().lsfa_conv_split_workspace_bytes(_ci(N), _ci(H), _ci(W), _ci(cin), _ci(sw.cout), _ci(kh), _ci(kw), _ci(stride),
+                                                 _ci(max(pad)), _ci(dil))
+    ws = torch.empty(need, dtype=torch.uint8, device=x.device)
+    first = out.data_ptr() + 4 * ((y0 * Wout + x0) * Lout + c0)
+    view = place is not None
+    _check(lib().lsfa_conv_split_view_fwd(_ptr(x), _ci(L), _ci(N), _ci(H), _ci(W), _ci(cin), _ptr(sw.frag), _ptr(bias), _ci(sw.cout),
+                                          _ci(kh), _ci(kw), _ci(stride), _ci(pad[0]), _ci(pad[1]), _ci(dil), _ci(act), _vp(first),
+                                          _ci(Lout), _ci(Ho), _ci(Wo), _ci(Hout if view or (Ho, Wo) != (Hout, Wout) else 0), _ci(Wout),
+                                          _ci(sy), _ci(sx), _ptr(ws), ctypes.c_size_t(need), _stream()), "lsfa_conv_split_view_fwd")
+    return out
+
+
 class MotionVectorAccumulator(object):
     """Accumulated compressed-domain motion vectors of one GOP on the device
     (coviar_data_loader.c:71-177 with accumulate = 1; see lsfa_mv_* in include/lsfa_hip.h).

@@ -50,7 +50,7 @@ _CONV1X1_MIOPEN = _os.environ.get('LSFA_CONV1X1_MIOPEN', '0') == '1'   # experim
 # measured at 1000x600 (tools/key_sections.py, hipGraph replay): backbone 4327 -> 4239 us with it, small net 256 -> 289 us:
 # the backbone's stage 2/3 units gain (epilogue fusion + deterministic tap split), the small net's 64-channel stage 1 and the
 # 256 -> 1024 fuse convolution do not
-_OWN_CONV = set(x for x in _os.environ.get('LSFA_OWN_CONV', 'backbone,small,fuse,feat,stem,pw').split(',') if x)
+_OWN_CONV = set(x for x in _os.environ.get('LSFA_OWN_CONV', 'backbone,fuse,feat,stem').split(',') if x)
 # the own 3x3 convolutions on the bf16 matrix pipe with exactly split fp32 operands (lsfa_conv_split_fwd: fp32 in, fp32
 # accumulate, error against float64 equal to the fp32-MFMA kernel's) instead of the fp32 matrix instructions.  Measured per
 # conv2 at 1000x600 (tools/lab/conv_split_lab.py): res4 32.7 vs 40.7 us, res3 31.4 vs 50.4, res2 34.6 vs 51.3.

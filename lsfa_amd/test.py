@@ -39,9 +39,8 @@ def parse_args():
                                                           'stream-pipelined one')
     ap.add_argument('--out', default=None, help='rank 0 saves the gathered detection rows (n,7) here (.npy)')
     ap.add_argument('--pinned-algorithms', action='store_true',
-                    help='deterministic convolution / GEMM algorithm choice (no MIOpen find, no TunableOp, MIOpen user '
-                         'db / kernel cache private to the process): results do not depend on how the videos are spread '
-                         'over ranks nor on what ran before')
+                    help='deterministic convolution / GEMM algorithm choice (no MIOpen find, no TunableOp): results do not '
+                         'depend on how the videos are spread over ranks')
     return ap.parse_args()
 
 
@@ -49,7 +48,7 @@ def main():
     args = parse_args()
     from lsfa_amd import tuning
     if args.pinned_algorithms:
-        tuning.pin_algorithms(isolate_miopen=os.environ.get('LSFA_MIOPEN_SHARED') != '1')
+        tuning.pin_algorithms(isolate_miopen=os.environ.get('LSFA_MIOPEN_PRIVATE') == '1')
     else:
         tuning.enable(tune_missing=True)
     if args.cfg:

@@ -45,16 +45,16 @@ def disable():
 _PRIVATE_DIR = None
 
 
-def pin_algorithms(isolate_miopen=True):
-    """Results that do not depend on what ran before or beside this process (`python -m lsfa_amd.test
-    --pinned-algorithms`, the multi-rank equality test): no TunableOp, no MIOpen find step, and — the part that
-    mattered — MIOpen's per-user state made private to the process.  Measured (tools/diag_multirank.py,
-    profiles/r3/multirank_diag_before.txt): with `cudnn.benchmark` off MIOpen still picks a convolution's solver from
-    its user find-db / kernel cache under $HOME; two processes that start together on an empty cache race for it, end up
-    with other solvers than a process that starts alone, and that choice then persists in $HOME for every later
-    process.  Frames from the first FlowNet key frame on moved by up to 4e-5 px (enough, with a random-weight RPN, to
-    re-order proposals).  With MIOPEN_USER_DB_PATH / MIOPEN_CUSTOM_CACHE_DIR pointing at a fresh directory every
-    process sees the same (empty) state and chooses alike.  Must run before the first convolution of the process."""
+def pin_algorithms(isolate_miopen=False):
+    """Deterministic library algorithm choice (`python -m lsfa_amd.test --pinned-algorithms`, the multi-rank equality
+    test): no TunableOp, no MIOpen find step.  What is left of MIOpen's state dependence, measured
+    (tools/diag_multirank.py, profiles/r3/multirank_diag_before.txt): with `cudnn.benchmark` off MIOpen still picks a
+    convolution's solver from per-user state under $HOME; two processes that START TOGETHER on an empty cache end up with
+    other solvers for FlowNet than a process that starts alone (frames from the first FlowNet key frame on move by up to
+    4e-5 px), and that choice persists in $HOME.  Processes that find the state already written agree bit for bit.
+    isolate_miopen=True points MIOPEN_USER_DB_PATH / MIOPEN_CUSTOM_CACHE_DIR at a fresh directory (it did NOT make the
+    first process of a box agree with later ones, so it is off by default); the way out is the own convolution for
+    FlowNet.  Must run before the first convolution of the process."""
     global _PRIVATE_DIR
     disable()
     torch.backends.cudnn.deterministic, torch.backends.cudnn.benchmark = True, False

@@ -925,3 +925,45 @@ def test_conv_nhwc_fused_residual_and_next_bn(hip, cfg):
     # the second output is exactly the fp32 bn + relu of the first
     again = torch.relu(got * t(sc2) + t(sh2))
     assert torch.equal(got2, again)
+
+
+def test_conv_split_views_and_transposed_convolution_phases(hip):
+    """lsfa_conv_split_view_fwd: input read from the leading channels of a wider map, output written into a channel slice of a
+    wider map, LeakyReLU; and Deconvolution(4x4, stride 2) + Crop(offset 1) (resnet_v1_101_flownet_rfcn.py:170-176) as four
+    2x2-tap launches, one per output parity, against conv_transpose2d in float64."""
+    import torch.nn.functional as F
+    torch.manual_seed(3)
+    dev = DEV
+    # --- strided 5x5 convolution between views (FlowNet conv3: 128 -> 256, stride 2, pad 2) ---
+    N, H, W, Cin, Cout, L, Lout, c0 = 1, 19, 32, 128, 256, 160, 416, 64
+    xw = torch.randn(N, H, W, L, device=dev)
+    w = torch.randn(Cout, Cin, 5, 5, device=dev) * 0.02
+    b = torch.randn(Cout, device=dev)
+    sw = hip.SplitWeight(w)
+    Ho, Wo = (H + 4 - 5) // 2 + 1, (W + 4 - 5) // 2 + 1
+    out = torch.full((N, Ho, Wo, Lout), 7.0, device=dev)
+    hip.conv_split_view(xw, sw, b, out, stride=2, pad=(2, 2), act=2, cin=Cin, c0=c0)
+    ref = F.leaky_relu(F.conv2d(xw[..., :Cin].permute(0, 3, 1, 2).double(), w.double(), b.double(), 2, 2), 0.1).permute(0, 2, 3, 1)
+    got = out[..., c0:c0 + Cout].double()
+    assert float((got - ref).abs().max()) < 2e-6 * (Cin * 25) ** 0.5 * float(ref.abs().max())
+    assert bool((out[..., :c0] == 7.0).all()) and bool((out[..., c0 + Cout:] == 7.0).all())      # the rest of the map is untouched
+    # --- Deconvolution 4x4 / 2 + Crop(offset (1,1)) to a 19 x 32 map, written into channels [256, 384) of a 416-channel map ---
+    Cin, Cout, Hi, Wi, Hc, Wc, Lout, c0 = 96, 128, 10, 16, 19, 32, 416, 256
+    x = torch.randn(1, Hi, Wi, Cin, device=dev)
+    wt = torch.randn(Cin, Cout, 4, 4, device=dev) * 0.05          # conv_transpose2d layout (Cin, Cout, kh, kw)
+    b = torch.randn(Cout, device=dev)
+    full = F.leaky_relu(F.conv_transpose2d(x.permute(0, 3, 1, 2).double(), wt.double(), b.double(), stride=2), 0.1)
+    ref = full[:, :, 1:1 + Hc, 1:1 + Wc].permute(0, 2, 3, 1)
+    out = torch.full((1, Hc, Wc, Lout), -3.0, device=dev)
+    for py in (0, 1):
+        for px in (0, 1):
+            # output row 2m + py of the cropped map: taps ky = 3, 1 read input rows m - 1, m (py = 0); ky = 2, 0 read m, m + 1 (py = 1)
+            kys = (3, 1) if py == 0 else (2, 0)
+            kxs = (3, 1) if px == 0 else (2, 0)
+            wp = wt[:, :, kys, :][:, :, :, kxs].permute(1, 0, 2, 3).contiguous()       # (Cout, Cin, 2, 2) as an ordinary convolution
+            swp = hip.SplitWeight(wp)
+            gh, gw = (Hc - py + 1) // 2, (Wc - px + 1) // 2
+            hip.conv_split_view(x, swp, b, out, stride=1, pad=(1 - py, 1 - px), act=2, c0=c0, grid=(gh, gw), place=(py, px, 2, 2))
+    got = out[..., c0:c0 + Cout].double()
+    assert float((got - ref).abs().max()) < 2e-6 * (Cin * 4) ** 0.5 * float(ref.abs().max())
+    assert bool((out[..., :c0] == -3.0).all()) and bool((out[..., c0 + Cout:] == -3.0).all())

@@ -24,7 +24,7 @@ CUR_ORDER = ['small_feat', 'conv_feat'] + KEY_ORDER[6:]
 def launch(tag, home, extra=None):
     env = dict(os.environ)
     os.makedirs(home, exist_ok=True)
-    env.update(HOME=home, LSFA_MIOPEN_SHARED='1', LSFA_UNIT_TAPS='1', LSFA_DCN_CHECK='1', LSFA_TAP_SUMS=os.path.join(OUT, 'taps_%s.json' % tag),
+    env.update(HOME=home, LSFA_UNIT_TAPS='1', LSFA_DCN_CHECK='1', LSFA_TAP_SUMS=os.path.join(OUT, 'taps_%s.json' % tag),
                PYTHONPATH=ROOT + os.pathsep + env.get('PYTHONPATH', ''))
     env.update(extra or {})
     out = os.path.join(OUT, 'rows_%s.npy' % tag)

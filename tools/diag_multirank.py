@@ -76,7 +76,7 @@ def main():
     runs = {}
     shutil.rmtree(HOMES, ignore_errors=True)
     h1, h2, h3, h4 = (os.path.join(HOMES, 'home%d' % i) for i in (1, 2, 3, 4))
-    shared = {'LSFA_MIOPEN_SHARED': '1'}        # the r2 behaviour: MIOpen state under $HOME shared by every process
+    shared = {}
     runs.update(wait([launch('one_cold', 1, h1)]))
     runs.update(wait([launch('sh_one_cold', 1, h4, shared)]))
     runs.update(wait([launch('sh_two_cold', 2, h2, shared)]))

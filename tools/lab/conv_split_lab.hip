@@ -6,8 +6,11 @@ using namespace lsfa::convsplit;
 extern "C" int conv_split_lab_run(const float* x, const void* wfrag, float* part, int N, int H, int W, int Cin, int Cout, int k,
                                   int slices, long long* host_stamps8) {
   const int chunk_total = k * k * (Cin / 32);
-  Args a = {x, (const uint4*)wfrag, nullptr, part, part, N, H, W, Cin, Cout, k, k, 1, k / 2, 1, H, W, 0,
-            (chunk_total + slices - 1) / slices, nullptr, nullptr, nullptr, nullptr, 0, 0, 0};
+  Args a = {};
+  a.x = x; a.wfrag = (const uint4*)wfrag; a.y = part; a.part = part;
+  a.N = N; a.H = H; a.W = W; a.Cin = Cin; a.Cout = Cout; a.kh = a.kw = k; a.stride = 1; a.pad_h = a.pad_w = k / 2; a.dil = 1;
+  a.Ho = H; a.Wo = W; a.chunks_per_slice = (chunk_total + slices - 1) / slices; a.lda = Cin; a.ldy = Cout;
+  a.out_H = H; a.out_W = W; a.out_sy = a.out_sx = 1;
   const int P = N * H * W;
   const int nx = (P + kWgPix - 1) / kWgPix, ny = Cout / kWgCh;
   const int tiles = nx * ny * slices;

@@ -146,16 +146,22 @@ def main():
         e_lib = float((y_lib.double() - ref).abs().max()) / scale
         rms = lambda y_nhwc: float(((y_nhwc.permute(0, 3, 1, 2).double() - ref) ** 2).mean().sqrt()) / scale
         out = torch.empty_like(y_split)
+        hip.lib().lsfa_conv_split_set_variant(2)          # 128 x 128 workgroup tiles wherever Cout allows (r3)
+        y_wide = hip.conv_split(x_cl, sw, b, 1, pad, dil)
+        e_wide = err(y_wide)
+        t_wide = timeit(lambda: hip.conv_split(x_cl, sw, b, 1, pad, dil, out=out), args.iters)
+        hip.lib().lsfa_conv_split_set_variant(1)          # the r2 kernel: 128 x 64 tiles
         t_split = timeit(lambda: hip.conv_split(x_cl, sw, b, 1, pad, dil, out=out), args.iters)
+        hip.lib().lsfa_conv_split_set_variant(0)
         t_mfma = timeit(lambda: hip.conv_nhwc(x_cl, wk, b, k, k, 1, pad, dil, out=out), args.iters)
         t_lib = timeit(lambda: F.conv2d(xl, wl, b, 1, pad, dil), args.iters)
         if k == 1:      # what the executor runs for 1x1 convolutions: rows x (Cin, Cout) through hipBLASLt
             rows, wt = x_cl.view(-1, Cin), w.view(Cout, Cin).t().contiguous()
             t_lib = min(t_lib, timeit(lambda: torch.addmm(b, rows, wt), args.iters))
         fl = 2.0 * H * W * Cin * Cout * k * k
-        print("%-36s max err/max|y|: split %.2e (rms %.2e)  fp32-mfma %.2e (rms %.2e)  library %.2e | us: split %6.1f  fp32-mfma %6.1f  "
-              "library %6.1f | split %.0f TFLOP/s" % (name, e_split, rms(y_split), e_mfma, rms(y_mfma), e_lib, t_split, t_mfma, t_lib,
-                                                      fl / t_split / 1e6))
+        print("%-36s max err/max|y|: split %.2e (rms %.2e)  wide %.2e  fp32-mfma %.2e (rms %.2e)  library %.2e | us: split %6.1f  wide %6.1f  "
+              "fp32-mfma %6.1f  library %6.1f | split %.0f wide %.0f TFLOP/s" % (name, e_split, rms(y_split), e_wide, e_mfma, rms(y_mfma), e_lib,
+                                                                              t_split, t_wide, t_mfma, t_lib, fl / t_split / 1e6, fl / t_wide / 1e6))
 
 
 if __name__ == "__main__":

@@ -272,7 +272,9 @@ int lsfa_conv_split_fwd(const float* x, int N, int H, int W, int Cin, const void
  *       pad_w = 1 - px;
  *   Ho, Wo > 0: the output grid of this launch when smaller than the convolution's (a phase's share of the cropped map);
  *   separate pad_h / pad_w; act: 0 none, 1 ReLU, 2 LeakyReLU(0.1) (sym_common / :153 `LeakyReLU(act_type='leaky', slope=0.1)`).
- * workspace: lsfa_conv_split_workspace_bytes of the same shape. */
+ * workspace: lsfa_conv_split_view_workspace_bytes of the same arguments (Ho, Wo = 0: the convolution's own output grid). */
+size_t lsfa_conv_split_view_workspace_bytes(int lda, int N, int H, int W, int Cin, int Cout, int kh, int kw, int stride, int pad_h,
+                                            int pad_w, int dil, int Ho, int Wo);
 int lsfa_conv_split_view_fwd(const float* x, int lda, int N, int H, int W, int Cin, const void* wfrag, const float* bias,
                              int Cout, int kh, int kw, int stride, int pad_h, int pad_w, int dil, int act, float* y, int ldy,
                              int Ho, int Wo, int out_H, int out_W, int out_sy, int out_sx, void* ws, size_t ws_bytes,
@@ -295,6 +297,28 @@ int lsfa_stem_conv7x7s2(const float* x, int N, int H, int W, const float* in_sca
                         const float* w_l, const float* bias, float* y, void* stream);
 int lsfa_maxpool3x3s2_nhwc(const float* x, int N, int H, int W, int C, float* y, float* y2, const float* scale2,
                            const float* shift2, void* stream);
+/* lsfa_stem_conv7x7s2 with an accumulation input and a choice of activation: y = act(conv(x) + bias + accum), accum (N,Ho,Wo,64)
+ * or NULL (may be y itself), act 0 none / 1 ReLU / 2 LeakyReLU(0.1).  FlowNet's flow_conv1 (7x7 / 2, 6 -> 64 channels,
+ * resnet_v1_101_flownet_rfcn.py:153) is two such passes, one per image of the pair, with the weight's input channels 0-2 / 3-5. */
+int lsfa_stem_conv7x7s2_ex(const float* x, int N, int H, int W, const float* in_scale, const float* in_shift,
+                           const float* w_l, const float* bias, const float* accum, int act, float* y, void* stream);
+
+/* ---------------------------------------------------------------------------
+ * FlowNet-S pieces that are not MFMA-sized (lsfa_amd/csrc/flownet.hip); with lsfa_conv_split_view_fwd and the two-pass stem
+ * convolution they make get_flownet (resnet_v1_101_flownet_rfcn.py:150-207) free of library calls.
+ *   lsfa_head_conv3x3    Convolution1..5 (:178-203): 3x3, pad 1, stride 1, Cin -> Cout <= 4 channels.  x (N,H,W,lda) channels-last
+ *                        (the first Cin channels of each pixel), w (Cout,3,3,Cin), y = (conv + bias) * mul either NCHW
+ *                        (N,Cout,H,W) (out_nchw != 0: the `flow` output, mul = 2.5, :204) or channels [c0, c0+Cout) of (N,H,W,ldy).
+ *   lsfa_upsample_flow   upsample_flow*to* (:180, :185, :190, :195): Deconvolution(kernel 4, stride 2, C -> C, C <= 8) + Crop(offset 1)
+ *                        to Hc x Wc; in (N,Hi,Wi,C), w (C,C,4,4) (MXNet's (in, out, kh, kw)), out channels [c0, c0+C) of (N,Hc,Wc,ldy).
+ *   lsfa_avgpool2_nhwc   Pooling(kernel 2, stride 2, avg, 'full') on (N,H,W,C), C % 4 == 0 -> (N,ceil(H/2),ceil(W/2),C), edge
+ *                        windows clipped (:201).
+ * ------------------------------------------------------------------------ */
+int lsfa_head_conv3x3(const float* x, int lda, int N, int H, int W, int Cin, const float* w, const float* bias, int Cout,
+                      float mul, float* y, int out_nchw, int ldy, int c0, void* stream);
+int lsfa_upsample_flow(const float* in, int N, int Hi, int Wi, int C, const float* w, const float* bias, int Hc, int Wc,
+                       float* out, int ldy, int c0, void* stream);
+int lsfa_avgpool2_nhwc(const float* x, int N, int H, int W, int C, float* y, void* stream);
 
 /* Inference BatchNorm (use_global_stats) + ReLU as one pass: y = max(x*scale[c]+shift[c], 0)
  * (sym_common.py:92-102 bn + relu of every pre-activation unit, resnet.py:70-101).
@@ -353,7 +377,7 @@ int lsfa_copy_many(int njobs, void* const* dst, const void* const* src, const lo
 enum {
   LSFA_OP_PSROI = 0, LSFA_OP_RFCN_HEAD = 1, LSFA_OP_WARP = 2, LSFA_OP_AGG = 3,
   LSFA_OP_PROPOSAL = 4, LSFA_OP_NMS = 5, LSFA_OP_DET = 6, LSFA_OP_DCN_IM2COL = 7,
-  LSFA_OP_BNRELU = 8, LSFA_OP_CONV = 9, LSFA_OP_STEM = 10, LSFA_OP_COUNT = 11
+  LSFA_OP_BNRELU = 8, LSFA_OP_CONV = 9, LSFA_OP_STEM = 10, LSFA_OP_FLOWNET = 11, LSFA_OP_COUNT = 12
 };
 int lsfa_prof_enable(int mask);
 int lsfa_prof_read(double* ms_host /*LSFA_OP_COUNT*/, int* launches_host /*LSFA_OP_COUNT*/);

@@ -349,6 +349,16 @@ SplitPlan split_plan_general(int N, int Ho, int Wo, int Cin, int Cout, int kh, i
   return p;
 }
 
+// the plan of a launch whose operands may be views: the halo form needs the plain geometry
+SplitPlan view_plan(int N, int H, int W, int Cin, int Cout, int kh, int kw, int stride, int pad_h, int pad_w, int dil, int lda, int Ho_grid,
+                    int Wo_grid) {
+  const int Ho = (H + 2 * pad_h - dil * (kh - 1) - 1) / stride + 1, Wo = (W + 2 * pad_w - dil * (kw - 1) - 1) / stride + 1;
+  SplitPlan p = split_plan(N, H, W, Cin, Cout, kh, kw, stride, pad_h, dil);
+  const bool plain = pad_h == pad_w && lda == Cin && Ho_grid == Ho && Wo_grid == Wo;
+  if (!plain) p = split_plan_general(N, Ho_grid, Wo_grid, Cin, Cout, kh, kw);
+  return p;
+}
+
 size_t split_workspace(const SplitPlan& p, long P, int Cout) {
   if (p.units_per_wg > 0)      // one 32 KB accumulator slot per (tile, piece)
     return (size_t)p.nx * p.ny * p.max_pieces * convsplit::kThreads * 32 * sizeof(float);
@@ -408,9 +418,7 @@ int conv_split_launch(convsplit::Args a, void* ws, size_t ws_bytes, void* stream
   const long P = (long)N * a.Ho * a.Wo;
   LSFA_REQUIRE(((long)N * a.out_H * a.out_W + 1) * (long)(a.y_nchw ? Cout : a.ldy) < (1L << 31) && P * Cout < (1L << 31) &&
                ((long)N * H * W + (long)(a.pad_h + 1) * (W + 1)) * a.lda < (1L << 31), "%s: tensor too large", who);
-  SplitPlan p = split_plan(N, H, W, Cin, Cout, kh, kw, stride, a.pad_h, dil);
-  if (p.halo && (a.pad_h != a.pad_w || a.lda != Cin || a.Ho != Ho || a.Wo != Wo)) p = split_plan_general(N, a.Ho, a.Wo, Cin, Cout, kh, kw);
-  else if (!p.halo && (a.Ho != Ho || a.Wo != Wo)) p = split_plan_general(N, a.Ho, a.Wo, Cin, Cout, kh, kw);
+  const SplitPlan p = view_plan(N, H, W, Cin, Cout, kh, kw, stride, a.pad_h, a.pad_w, dil, a.lda, a.Ho, a.Wo);
   const size_t need = split_workspace(p, P, Cout);
   if ((p.slices > 1 || p.units_per_wg > 0) && (!ws || ws_bytes < need)) {
     set_error("%s: workspace %zu < %zu bytes", who, ws_bytes, need);
@@ -456,10 +464,18 @@ extern "C" size_t lsfa_conv_split_workspace_bytes(int N, int H, int W, int Cin, 
   const int Ho = (H + 2 * pad - dil * (kh - 1) - 1) / stride + 1, Wo = (W + 2 * pad - dil * (kw - 1) - 1) / stride + 1;
   if (Ho <= 0 || Wo <= 0) return 0;
   const SplitPlan p = split_plan(N, H, W, Cin, Cout, kh, kw, stride, pad, dil);
-  const size_t a = split_workspace(p, (long)N * Ho * Wo, Cout);
-  // a view launch (lsfa_conv_split_view_fwd) may fall back from the halo plan to the general one: size for both
-  const size_t b = split_workspace(split_plan_general(N, Ho, Wo, Cin, Cout, kh, kw), (long)N * Ho * Wo, Cout);
-  return a > b ? a : b;
+  return split_workspace(p, (long)N * Ho * Wo, Cout);
+}
+
+extern "C" size_t lsfa_conv_split_view_workspace_bytes(int lda, int N, int H, int W, int Cin, int Cout, int kh, int kw, int stride, int pad_h,
+                                                       int pad_w, int dil, int Ho, int Wo) {
+  if (N <= 0 || H <= 0 || W <= 0 || Cout <= 0 || Cin <= 0 || stride <= 0 || kh <= 0 || kw <= 0 || dil <= 0 || pad_h < 0 || pad_w < 0) return 0;
+  const int Hn = (H + 2 * pad_h - dil * (kh - 1) - 1) / stride + 1, Wn = (W + 2 * pad_w - dil * (kw - 1) - 1) / stride + 1;
+  if (Ho <= 0) Ho = Hn;
+  if (Wo <= 0) Wo = Wn;
+  if (Ho <= 0 || Wo <= 0) return 0;
+  const SplitPlan p = view_plan(N, H, W, Cin, Cout, kh, kw, stride, pad_h, pad_w, dil, lda > 0 ? lda : Cin, Ho, Wo);
+  return split_workspace(p, (long)N * Ho * Wo, Cout);
 }
 
 extern "C" int lsfa_conv_split_fwd(const float* x, int N, int H, int W, int Cin, const void* wfrag, const float* bias, int Cout,

@@ -1,0 +1,153 @@
+// The parts of FlowNet-S (dff_rfcn/symbols/resnet_v1_101_flownet_rfcn.py:150-207) that are not MFMA-sized contractions,
+// on channels-last maps, so that together with lsfa_conv_split_view_fwd the whole network runs without a library call:
+//   flow_conv1 (7x7 / 2, 6 -> 64 channels)   the stem kernel of stem.hip run once per image of the pair (3 channels each), the
+//                                            second pass adding onto the first and applying bias + LeakyReLU: stem.hip
+//   head_conv3x3_kernel    Convolution1..5 (:178, :183, :188, :193, :203): 3x3, pad 1, Cin up to 1026 -> 2 channels.  One wave
+//                          per output pixel, lanes over the input channels (coalesced 256-byte reads), nine taps, a fixed
+//                          shuffle tree: deterministic, a few microseconds (the maps are 5x8 ... 38x63).
+//   upflow_kernel          upsample_flow6to5 ... 3to2 (:180 ...): Deconvolution(kernel 4, stride 2, 2 -> 2 channels) + Crop(offset 1)
+//                          written into the two flow channels of the next concatenated map.
+//   avgpool2_cl_kernel     Pooling(2x2 / 2, avg, pooling_convention='full') on a channels-last map (:201, and the frame pair).
+// Arithmetic: plain fp32 fmaf chains in a stated order; these are "dense" stages compared by tolerance like every convolution.
+#include "common.h"
+
+using namespace lsfa;
+
+namespace {
+
+constexpr int kHeadMaxCout = 4;
+
+// grid (ceil(P / 4)); block 256 = 4 waves = 4 output pixels.  x (N, H, W, lda) channels-last, Cin channels used.
+// w (Cout, 3, 3, Cin); out: NCHW (N, Cout, H, W) when out_nchw, else channels [c0, c0 + Cout) of an (N, H, W, ldy) map.
+// Lane l sums channels l, l + 64, ... over the taps in (ky, kx) order, then the 64 partial sums are added pairwise
+// (xor 32, 16, 8, 4, 2, 1): one fixed tree.
+__global__ __launch_bounds__(256) void head_conv3x3_kernel(const float* __restrict__ x, int lda, int N, int H, int W, int Cin,
+                                                           const float* __restrict__ w, const float* __restrict__ bias, int Cout,
+                                                           float mul, float* __restrict__ y, int out_nchw, int ldy, int c0) {
+  const int lane = threadIdx.x & 63;
+  const int p = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (p >= N * H * W) return;
+  const int n = p / (H * W), r = p - n * H * W, oy = r / W, ox = r - oy * W;
+  float acc[kHeadMaxCout];
+#pragma unroll
+  for (int o = 0; o < kHeadMaxCout; ++o) acc[o] = 0.f;
+  for (int ky = 0; ky < 3; ++ky) {
+    const int iy = oy - 1 + ky;
+    if (iy < 0 || iy >= H) continue;
+    for (int kx = 0; kx < 3; ++kx) {
+      const int ix = ox - 1 + kx;
+      if (ix < 0 || ix >= W) continue;
+      const float* xp = x + ((size_t)(n * H + iy) * W + ix) * lda;
+      const float* wp = w + (size_t)(ky * 3 + kx) * Cin;
+      for (int c = lane; c < Cin; c += 64) {
+        const float v = xp[c];
+#pragma unroll
+        for (int o = 0; o < kHeadMaxCout; ++o)
+          if (o < Cout) acc[o] = fmaf(v, wp[(size_t)o * 9 * Cin + c], acc[o]);
+      }
+    }
+  }
+#pragma unroll
+  for (int o = 0; o < kHeadMaxCout; ++o) {
+    if (o >= Cout) break;
+    float s = acc[o];
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) s = s + __shfl_xor(s, d, 64);
+    if (lane == 0) {
+      const float v = (s + (bias ? bias[o] : 0.f)) * mul;
+      if (out_nchw) y[((size_t)n * Cout + o) * H * W + r] = v;
+      else y[(size_t)p * ldy + c0 + o] = v;
+    }
+  }
+}
+
+// One thread per output element of the cropped map: out[n, oy, ox, c0 + co], (oy, ox) in Hc x Wc.
+// Deconvolution: full[y, x, co] = bias[co] + sum over (ci, ky, kx) with y = 2*iy + ky, x = 2*ix + kx of in[iy, ix, ci] * w[ci, co, ky, kx];
+// Crop(offset 1): out[oy, ox] = full[oy + 1, ox + 1].  Sum order: ci, ky, kx ascending.
+__global__ __launch_bounds__(256) void upflow_kernel(const float* __restrict__ in, int N, int Hi, int Wi, int C, const float* __restrict__ w,
+                                                     const float* __restrict__ bias, int Hc, int Wc, float* __restrict__ out, int ldy,
+                                                     int c0) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= N * Hc * Wc * C) return;
+  const int co = i % C;
+  int r = i / C;
+  const int ox = r % Wc; r /= Wc;
+  const int oy = r % Hc;
+  const int n = r / Hc;
+  const int fy = oy + 1, fx = ox + 1;
+  float s = 0.f;
+  for (int ci = 0; ci < C; ++ci)
+    for (int ky = 0; ky < 4; ++ky) {
+      const int ty = fy - ky;
+      if (ty < 0 || (ty & 1) || (ty >> 1) >= Hi) continue;
+      for (int kx = 0; kx < 4; ++kx) {
+        const int tx = fx - kx;
+        if (tx < 0 || (tx & 1) || (tx >> 1) >= Wi) continue;
+        s = fmaf(in[((size_t)(n * Hi + (ty >> 1)) * Wi + (tx >> 1)) * C + ci], w[((ci * C + co) * 4 + ky) * 4 + kx], s);
+      }
+    }
+  out[((size_t)(n * Hc + oy) * Wc + ox) * ldy + c0 + co] = s + (bias ? bias[co] : 0.f);
+}
+
+// channels-last 2x2 / 2 average, windows clipped to the map ('full' convention); a float4 of channels per thread
+__global__ __launch_bounds__(256) void avgpool2_cl_kernel(const float4* __restrict__ x, int N, int H, int W, int C4, int Ho, int Wo,
+                                                          float4* __restrict__ y) {
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= (long)N * Ho * Wo * C4) return;
+  const int c = (int)(i % C4);
+  long r = i / C4;
+  const int ox = (int)(r % Wo); r /= Wo;
+  const int oy = (int)(r % Ho);
+  const int n = (int)(r / Ho);
+  const int y0 = 2 * oy, x0 = 2 * ox, y1 = min(y0 + 2, H), x1 = min(x0 + 2, W);
+  float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int yy = y0; yy < y1; ++yy)
+    for (int xx = x0; xx < x1; ++xx) {
+      const float4 v = x[(((size_t)n * H + yy) * W + xx) * C4 + c];
+      s.x = s.x + v.x; s.y = s.y + v.y; s.z = s.z + v.z; s.w = s.w + v.w;
+    }
+  const float d = (float)((y1 - y0) * (x1 - x0));
+  y[i] = make_float4(s.x / d, s.y / d, s.z / d, s.w / d);
+}
+
+}  // namespace
+
+extern "C" int lsfa_head_conv3x3(const float* x, int lda, int N, int H, int W, int Cin, const float* w, const float* bias, int Cout,
+                                 float mul, float* y, int out_nchw, int ldy, int c0, void* stream) {
+  LSFA_REQUIRE(x && w && y, "lsfa_head_conv3x3: NULL argument");
+  LSFA_REQUIRE(N > 0 && H > 0 && W > 0 && Cin > 0 && lda >= Cin && Cout > 0 && Cout <= kHeadMaxCout,
+               "lsfa_head_conv3x3: bad shape (Cout must be 1..%d)", kHeadMaxCout);
+  LSFA_REQUIRE(out_nchw || (ldy >= c0 + Cout && c0 >= 0), "lsfa_head_conv3x3: channels [%d, %d) do not fit ldy %d", c0, c0 + Cout, ldy);
+  const int P = N * H * W;
+  ProfScope prof(LSFA_OP_FLOWNET, (hipStream_t)stream);
+  hipLaunchKernelGGL(head_conv3x3_kernel, dim3((unsigned)((P + 3) / 4)), dim3(256), 0, (hipStream_t)stream, x, lda, N, H, W, Cin, w, bias,
+                     Cout, mul, y, out_nchw, ldy, c0);
+  LSFA_LAUNCH_CHECK("lsfa_head_conv3x3");
+  return LSFA_OK;
+}
+
+extern "C" int lsfa_upsample_flow(const float* in, int N, int Hi, int Wi, int C, const float* w, const float* bias, int Hc, int Wc,
+                                  float* out, int ldy, int c0, void* stream) {
+  LSFA_REQUIRE(in && w && out, "lsfa_upsample_flow: NULL argument");
+  LSFA_REQUIRE(N > 0 && Hi > 0 && Wi > 0 && C > 0 && C <= 8 && Hc > 0 && Wc > 0 && Hc <= 2 * Hi + 1 && Wc <= 2 * Wi + 1 && ldy >= c0 + C && c0 >= 0,
+               "lsfa_upsample_flow: bad shape");
+  const int total = N * Hc * Wc * C;
+  ProfScope prof(LSFA_OP_FLOWNET, (hipStream_t)stream);
+  hipLaunchKernelGGL(upflow_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, in, N, Hi, Wi, C, w, bias, Hc, Wc,
+                     out, ldy, c0);
+  LSFA_LAUNCH_CHECK("lsfa_upsample_flow");
+  return LSFA_OK;
+}
+
+extern "C" int lsfa_avgpool2_nhwc(const float* x, int N, int H, int W, int C, float* y, void* stream) {
+  LSFA_REQUIRE(x && y, "lsfa_avgpool2_nhwc: NULL argument");
+  LSFA_REQUIRE(N > 0 && H > 0 && W > 0 && C > 0 && C % 4 == 0, "lsfa_avgpool2_nhwc: bad shape (C must be a multiple of 4)");
+  LSFA_REQUIRE(!((uintptr_t)x & 15) && !((uintptr_t)y & 15), "lsfa_avgpool2_nhwc: x / y must be 16-byte aligned");
+  const int Ho = (H + 1) / 2, Wo = (W + 1) / 2;
+  const long total = (long)N * Ho * Wo * (C / 4);
+  ProfScope prof(LSFA_OP_FLOWNET, (hipStream_t)stream);
+  hipLaunchKernelGGL(avgpool2_cl_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, (const float4*)x, N, H, W,
+                     C / 4, Ho, Wo, (float4*)y);
+  LSFA_LAUNCH_CHECK("lsfa_avgpool2_nhwc");
+  return LSFA_OK;
+}

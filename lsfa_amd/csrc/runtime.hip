@@ -146,6 +146,6 @@ extern "C" int lsfa_prof_read(double* ms_host, int* launches_host) {
 extern "C" const char* lsfa_op_name(int op) {
   static const char* names[LSFA_OP_COUNT] = {"psroi_pool", "rfcn_head", "warp_bilinear", "aggregate",
                                              "proposal", "nms", "det_postprocess", "deform_im2col",
-                                             "scale_shift_relu", "conv_nhwc", "stem"};
+                                             "scale_shift_relu", "conv_nhwc", "stem", "flownet_small"};
   return (op >= 0 && op < LSFA_OP_COUNT) ? names[op] : "?";
 }

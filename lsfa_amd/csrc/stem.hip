@@ -48,7 +48,7 @@ __global__ __launch_bounds__(256) void avgpool_kernel(const float* __restrict__ 
 __global__ __launch_bounds__(256) void stem_conv_kernel(const float* __restrict__ x, int H, int W, const float* __restrict__ in_scale,
                                                         const float* __restrict__ in_shift, const float* __restrict__ w_l,
                                                         const float* __restrict__ bias, int Ho, int Wo, int tiles_per_wg,
-                                                        float* __restrict__ y) {
+                                                        const float* accum, int act, float* y) {
   __shared__ __attribute__((aligned(16))) float in_s[kStemCin][kInRows][kInPitch];
   const int tid = threadIdx.x, co = tid & 63, row = tid >> 6;
   const int n = blockIdx.z, oy0 = blockIdx.y * kTileRows;
@@ -103,7 +103,11 @@ __global__ __launch_bounds__(256) void stem_conv_kernel(const float* __restrict_
       float* out = y + (((size_t)n * Ho + oy) * Wo) * kStemCout + co;
 #pragma unroll
       for (int p = 0; p < kTileCols; ++p)
-        if (ox0 + p < Wo) out[(size_t)(ox0 + p) * kStemCout] = fmaxf(acc[p] + b, 0.f);
+        if (ox0 + p < Wo) {
+          float v = acc[p] + b;
+          if (accum) v = v + accum[(((size_t)n * Ho + oy) * Wo + ox0 + p) * kStemCout + co];
+          out[(size_t)(ox0 + p) * kStemCout] = act == 1 ? fmaxf(v, 0.f) : (act == 2 ? (v > 0.f ? v : v * 0.1f) : v);
+        }
     }
   }
 }
@@ -150,7 +154,13 @@ extern "C" int lsfa_avgpool_nchw(const float* x, int N, int C, int H, int W, int
 
 extern "C" int lsfa_stem_conv7x7s2(const float* x, int N, int H, int W, const float* in_scale, const float* in_shift,
                                    const float* w_l, const float* bias, float* y, void* stream) {
+  return lsfa_stem_conv7x7s2_ex(x, N, H, W, in_scale, in_shift, w_l, bias, nullptr, 1, y, stream);
+}
+
+extern "C" int lsfa_stem_conv7x7s2_ex(const float* x, int N, int H, int W, const float* in_scale, const float* in_shift,
+                                      const float* w_l, const float* bias, const float* accum, int act, float* y, void* stream) {
   LSFA_REQUIRE(x && w_l && y, "lsfa_stem_conv7x7s2: NULL argument");
+  LSFA_REQUIRE(act >= 0 && act <= 2, "lsfa_stem_conv7x7s2_ex: act must be 0, 1 or 2");
   LSFA_REQUIRE(N > 0 && H > 0 && W > 0, "lsfa_stem_conv7x7s2: bad shape");
   LSFA_REQUIRE((in_scale == nullptr) == (in_shift == nullptr), "lsfa_stem_conv7x7s2: in_scale and in_shift go together");
   const int Ho = (H + 6 - 7) / 2 + 1, Wo = (W + 6 - 7) / 2 + 1;
@@ -162,7 +172,7 @@ extern "C" int lsfa_stem_conv7x7s2(const float* x, int N, int H, int W, const fl
   if (tpw < 1) tpw = 1;
   if (tpw > xt) tpw = xt;
   hipLaunchKernelGGL(stem_conv_kernel, dim3((xt + tpw - 1) / tpw, yt, N), dim3(256), 0, (hipStream_t)stream, x, H, W, in_scale, in_shift,
-                     w_l, bias, Ho, Wo, tpw, y);
+                     w_l, bias, Ho, Wo, tpw, accum, act, y);
   LSFA_LAUNCH_CHECK("lsfa_stem_conv7x7s2");
   return LSFA_OK;
 }

@@ -39,7 +39,7 @@ def lib():
         L.lsfa_last_error.restype = ctypes.c_char_p
         for name in ("lsfa_proposal_workspace_bytes", "lsfa_nms_workspace_bytes", "lsfa_det_workspace_bytes",
                      "lsfa_mv_workspace_bytes", "lsfa_conv_nhwc_workspace_bytes", "lsfa_conv_split_weight_bytes",
-                     "lsfa_conv_split_workspace_bytes"):
+                     "lsfa_conv_split_workspace_bytes", "lsfa_conv_split_view_workspace_bytes"):
             getattr(L, name).restype = ctypes.c_size_t
         L.lsfa_op_name.restype = ctypes.c_char_p
         L._nms.restype = None
@@ -467,8 +467,9 @@ def stem_weight_layout(weight):
 
 
 @_on_tensor_device
-def stem_conv(x, w_l, bias, in_scale=None, in_shift=None, out=None):
-    """bn_data + conv0 (7x7, stride 2, pad 3) + bias + ReLU: x (N, 3, H, W) NCHW -> (N, Ho, Wo, 64) channels-last."""
+def stem_conv(x, w_l, bias, in_scale=None, in_shift=None, out=None, accum=None, act=1):
+    """bn_data + conv0 (7x7, stride 2, pad 3) + bias (+ accum) + activation (0 none, 1 ReLU, 2 LeakyReLU 0.1):
+    x (N, 3, H, W) NCHW -> (N, Ho, Wo, 64) channels-last."""
     x, w_l = _f32c(x, "x"), _f32c(w_l, "w_l")
     N, C, H, W = x.shape
     if C != 3 or tuple(w_l.shape) != (3, 7, 7, 64):
@@ -476,9 +477,47 @@ def stem_conv(x, w_l, bias, in_scale=None, in_shift=None, out=None):
     Ho, Wo = (H - 1) // 2 + 1, (W - 1) // 2 + 1
     if out is None:
         out = torch.empty((N, Ho, Wo, 64), device=x.device, dtype=torch.float32)
-    _check(lib().lsfa_stem_conv7x7s2(_ptr(x), _ci(N), _ci(H), _ci(W), _ptr(in_scale), _ptr(in_shift), _ptr(w_l), _ptr(bias),
-                                     _ptr(out), _stream()), "lsfa_stem_conv7x7s2")
+    if accum is not None and (tuple(accum.shape) != tuple(out.shape) or not accum.is_contiguous()):
+        raise LsfaError("stem_conv: accum must be a contiguous %s tensor" % (tuple(out.shape),))
+    _check(lib().lsfa_stem_conv7x7s2_ex(_ptr(x), _ci(N), _ci(H), _ci(W), _ptr(in_scale), _ptr(in_shift), _ptr(w_l), _ptr(bias),
+                                        _ptr(accum), _ci(act), _ptr(out), _stream()), "lsfa_stem_conv7x7s2_ex")
     return out
+
+
+@_on_tensor_device
+def head_conv3x3(x, w, bias, cin=None, mul=1.0, out=None, c0=0, nchw=False):
+    """lsfa_head_conv3x3: 3x3 / pad 1 convolution to <= 4 channels (FlowNet's flow heads).  x (N,H,W,L) channels-last, w (Cout,3,3,Cin);
+    nchw: returns (N,Cout,H,W); else writes channels [c0, c0+Cout) of `out` (N,H,W,Lout) (a fresh (N,H,W,Cout) map by default)."""
+    x, w = _f32c(x, "x"), _f32c(w, "w")
+    N, H, W, L = x.shape
+    Cout, cin = w.shape[0], (w.shape[3] if cin is None else cin)
+    if tuple(w.shape[1:3]) != (3, 3) or w.shape[3] != cin or cin > L:
+        raise LsfaError("head_conv3x3: weight %s does not fit %d input channels of %d" % (tuple(w.shape), cin, L))
+    if out is None:
+        out = torch.empty((N, Cout, H, W) if nchw else (N, H, W, Cout), device=x.device, dtype=torch.float32)
+    _check(lib().lsfa_head_conv3x3(_ptr(x), _ci(L), _ci(N), _ci(H), _ci(W), _ci(cin), _ptr(w), _ptr(bias), _ci(Cout), _cf(mul), _ptr(out),
+                                   _ci(int(nchw)), _ci(out.shape[3] if not nchw else 0), _ci(c0), _stream()), "lsfa_head_conv3x3")
+    return out
+
+
+@_on_tensor_device
+def upsample_flow(x, w, bias, out, c0):
+    """lsfa_upsample_flow: Deconvolution(4x4, stride 2) + Crop(offset 1) of a (N,Hi,Wi,C) flow into channels [c0, c0+C) of out (N,Hc,Wc,L)."""
+    x, w = _f32c(x, "x"), _f32c(w, "w")
+    N, Hi, Wi, C = x.shape
+    _check(lib().lsfa_upsample_flow(_ptr(x), _ci(N), _ci(Hi), _ci(Wi), _ci(C), _ptr(w), _ptr(bias), _ci(out.shape[1]), _ci(out.shape[2]),
+                                    _ptr(out), _ci(out.shape[3]), _ci(c0), _stream()), "lsfa_upsample_flow")
+    return out
+
+
+@_on_tensor_device
+def avgpool2_nhwc(x):
+    """(N,H,W,C) -> (N,ceil(H/2),ceil(W/2),C), 2x2 / 2 average with clipped edge windows (lsfa_avgpool2_nhwc)."""
+    x = _f32c(x, "x")
+    N, H, W, C = x.shape
+    y = torch.empty((N, (H + 1) // 2, (W + 1) // 2, C), device=x.device, dtype=torch.float32)
+    _check(lib().lsfa_avgpool2_nhwc(_ptr(x), _ci(N), _ci(H), _ci(W), _ci(C), _ptr(y), _stream()), "lsfa_avgpool2_nhwc")
+    return y
 
 
 @_on_tensor_device
@@ -566,8 +605,8 @@ def conv_split_view(x, sw, bias, out, stride=1, pad=(0, 0), dil=1, act=0, cin=No
     if y0 + (Ho - 1) * sy >= Hout or x0 + (Wo - 1) * sx >= Wout:
         raise LsfaError("conv_split_view: a %dx%d grid placed at (%d,%d) step (%d,%d) leaves out %s" % (Ho, Wo, y0, x0, sy, sx, tuple(out.shape)))
     _count_conv(N, Ho, Wo, sw.cout, cin, kh, kw)
-    need = lib().lsfa_conv_split_workspace_bytes(_ci(N), _ci(H), _ci(W), _ci(cin), _ci(sw.cout), _ci(kh), _ci(kw), _ci(stride),
-                                                 _ci(max(pad)), _ci(dil))
+    need = lib().lsfa_conv_split_view_workspace_bytes(_ci(L), _ci(N), _ci(H), _ci(W), _ci(cin), _ci(sw.cout), _ci(kh), _ci(kw),
+                                                      _ci(stride), _ci(pad[0]), _ci(pad[1]), _ci(dil), _ci(Ho), _ci(Wo))
     ws = torch.empty(need, dtype=torch.uint8, device=x.device)
     first = out.data_ptr() + 4 * ((y0 * Wout + x0) * Lout + c0)
     view = place is not None

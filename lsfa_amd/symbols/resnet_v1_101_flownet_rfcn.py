@@ -50,7 +50,7 @@ _CONV1X1_MIOPEN = _os.environ.get('LSFA_CONV1X1_MIOPEN', '0') == '1'   # experim
 # measured at 1000x600 (tools/key_sections.py, hipGraph replay): backbone 4327 -> 4239 us with it, small net 256 -> 289 us:
 # the backbone's stage 2/3 units gain (epilogue fusion + deterministic tap split), the small net's 64-channel stage 1 and the
 # 256 -> 1024 fuse convolution do not
-_OWN_CONV = set(x for x in _os.environ.get('LSFA_OWN_CONV', 'backbone,fuse,feat,stem').split(',') if x)
+_OWN_CONV = set(x for x in _os.environ.get('LSFA_OWN_CONV', 'backbone,small,fuse,feat,stem,flow,nq').split(',') if x)
 # the own 3x3 convolutions on the bf16 matrix pipe with exactly split fp32 operands (lsfa_conv_split_fwd: fp32 in, fp32
 # accumulate, error against float64 equal to the fp32-MFMA kernel's) instead of the fp32 matrix instructions.  Measured per
 # conv2 at 1000x600 (tools/lab/conv_split_lab.py): res4 32.7 vs 40.7 us, res3 31.4 vs 50.4, res2 34.6 vs 51.3.
@@ -258,13 +258,10 @@ class _ResNetWeights(object):
                 d['off_w_cl'] = d['off_w'].contiguous(memory_format=cl)
                 # (Cout, C, 3, 3) -> rows ordered (tap, c) to match lsfa_deform_im2col_cl's col
                 d['w2_tap_t'] = d['w2'].permute(2, 3, 1, 0).reshape(-1, d['w2'].shape[0]).contiguous()
-            if _CONV_SPLIT and 'pw' in _OWN_CONV and d['w1'].is_cuda and d['w1'].dtype == torch.float32:
-                # every contraction of the unit on lsfa_conv_split_fwd: the 1x1 convolutions, the shortcut, and for a DCN
-                # unit the offset branch (72 output channels, zero-padded to 128) and the contraction of the sampled
-                # columns (a 1x1 convolution over 9*C "channels" ordered (tap, c))
-                d['w1_split'] = hip.SplitWeight(d['w1'])
-                d['w3_split'] = hip.SplitWeight(d['w3'])
-                if 'sc' in d:
+            if _CONV_SPLIT and d['w1'].is_cuda and d['w1'].dtype == torch.float32:
+                # what would otherwise go to MIOpen (whose algorithm choice depends on per-user state): the
+                # stride-2 1x1 shortcuts and the DCN units' offset branch + contraction
+                if 'sc' in d and d['stage'] in (2, 3):
                     d['sc_split'] = hip.SplitWeight(d['sc'])
                 if d['dcn']:
                     co = d['off_w'].shape[0]
@@ -275,6 +272,14 @@ class _ResNetWeights(object):
                     bpad[:co] = d['off_b']
                     d['off_split'], d['off_b_pad'] = hip.SplitWeight(wpad), bpad
                     d['dcn_split'] = hip.SplitWeight(d['w2_tap_t'].t().contiguous().view(d['w2'].shape[0], -1, 1, 1))
+            if _CONV_SPLIT and 'pw' in _OWN_CONV and d['w1'].is_cuda and d['w1'].dtype == torch.float32:
+                # every contraction of the unit on lsfa_conv_split_fwd: the 1x1 convolutions, the shortcut, and for a DCN
+                # unit the offset branch (72 output channels, zero-padded to 128) and the contraction of the sampled
+                # columns (a 1x1 convolution over 9*C "channels" ordered (tap, c))
+                d['w1_split'] = hip.SplitWeight(d['w1'])
+                d['w3_split'] = hip.SplitWeight(d['w3'])
+                if 'sc' in d and 'sc_split' not in d:
+                    d['sc_split'] = hip.SplitWeight(d['sc'])
         self._cl_ready = True
 
 
@@ -546,7 +551,15 @@ class Executor(object):
             if self.taps is not None and _UNIT_TAPS:
                 self.taps['u%d_%02d_0a' % (u['stage'], u['unit'])] = a2
                 self.taps['u%d_%02d_1c1' % (u['stage'], u['unit'])] = c1
-            if u['dcn']:
+            dcn_own = u['dcn'] and own_conv and 'dcn_split' in u
+            if dcn_own:
+                # offsets (72 channels, padded to 128) by the own convolution, bilinear columns, contraction with bn3's bias + ReLU
+                c14 = c1.view(n, h, w, -1)
+                off = hip.conv_split(c14, u['off_split'], u['off_b_pad'], 1, unit_dilate, unit_dilate)
+                col = hip.deform_im2col_cl(c14, off, 3, 3, unit_dilate, 1, unit_dilate, P.NUM_DEFORMABLE_GROUP)
+                c2 = hip.conv_split(col.view(n, h, w, -1), u['dcn_split'], u['b2'], relu=True).view(n * h * w, -1)
+                ho, wo = h, w
+            elif u['dcn']:
                 c2 = self._dcn_cl(self._map(c1, h, w), u, unit_dilate)
                 ho, wo = h, w
             elif own_conv and 'w2_split' in u:
@@ -564,11 +577,15 @@ class Executor(object):
                                 dilation=unit_dilate)
                 ho, wo = c2_4.shape[2], c2_4.shape[3]
                 c2 = self._rows(c2_4)
-            if u['dcn'] or not (own_conv and 'w2_kc' in u):
+            if (u['dcn'] and not dcn_own) or not (u['dcn'] or (own_conv and 'w2_kc' in u)):
                 hip.scale_shift_relu_cl(c2, self._ones(c2.shape[1]), u['b2'], relu=True, out=c2)   # folded bn3 bias + ReLU
             if first:
-                sc = self._rows(F.conv2d(self._map(a2, h, w), u['sc_cl'], None, stride=stride)) if stride != 1 \
-                    else torch.mm(a2, u['sc_t'])
+                if stride != 1 and own_conv and 'sc_split' in u:
+                    sc = hip.conv_split(a2.view(n, h, w, -1), u['sc_split'], None, stride).view(n * ho * wo, -1)
+                elif stride != 1:
+                    sc = self._rows(F.conv2d(self._map(a2, h, w), u['sc_cl'], None, stride=stride))
+                else:
+                    sc = torch.mm(a2, u['sc_t'])
             else:
                 sc = x2                                         # overwritten in place by conv3 (+ the shortcut: beta = 1)
             if self.taps is not None and _UNIT_TAPS:
@@ -616,8 +633,111 @@ class Executor(object):
         x = self._resnet(data, self.net, 4, True)
         return self._bias_act(F.conv2d(x, self.feat_w, None, padding=6, dilation=6).float(), self.feat_b.float(), True)
 
+    def _flownet_prepare(self):
+        """Weights of the own FlowNet path: split-bf16 fragments for the convolutions and the four phases of each
+        Deconvolution(4x4, stride 2) + Crop(1) (input channels zero-padded to the concatenated maps' padded widths)."""
+        fw, dev = self.flow, self.device
+        own = {}
+        w1 = fw['flow_conv1_weight']                                   # (64, 6, 7, 7)
+        own['c1_cur'] = hip.stem_weight_layout(w1[:, 0:3].contiguous())
+        own['c1_ref'] = hip.stem_weight_layout(w1[:, 3:6].contiguous())
+        own['in_scale'] = torch.full((3,), 1.0 / 255.0, device=dev)
+        own['in_shift'] = torch.zeros(3, device=dev)
+        for name in ('conv2', 'conv3', 'conv3_1', 'conv4', 'conv4_1', 'conv5', 'conv5_1', 'conv6', 'conv6_1'):
+            own[name] = hip.SplitWeight(fw[name + '_weight'])
+
+        def pad32(c):
+            return -(-c // 32) * 32
+        for name in ('deconv5', 'deconv4', 'deconv3', 'deconv2'):
+            wt = fw[name + '_weight']                                     # (Cin, Cout, 4, 4)
+            cin, cpad = wt.shape[0], pad32(wt.shape[0])
+            for py in (0, 1):
+                for px in (0, 1):
+                    # output row 2m + py of the cropped map reads input rows (m - 1, m) through taps ky = (3, 1) when py = 0
+                    # and rows (m, m + 1) through ky = (2, 0) when py = 1; columns alike
+                    kys, kxs = ((3, 1) if py == 0 else (2, 0)), ((3, 1) if px == 0 else (2, 0))
+                    wp = torch.zeros((wt.shape[1], cpad, 2, 2), device=dev, dtype=torch.float32)
+                    wp[:, :cin] = wt[:, :, kys, :][:, :, :, kxs].permute(1, 0, 2, 3)
+                    own[(name, py, px)] = hip.SplitWeight(wp)
+        ws = fw['Convolution5_scale_weight']                              # (1024, 194, 1, 1)
+        wsp = torch.zeros((ws.shape[0], pad32(ws.shape[1]), 1, 1), device=dev, dtype=torch.float32)
+        wsp[:, :ws.shape[1]] = ws
+        own['scale'] = hip.SplitWeight(wsp)
+        for name in ('Convolution1', 'Convolution2', 'Convolution3', 'Convolution4', 'Convolution5'):
+            own[name] = fw[name + '_weight'].permute(0, 2, 3, 1).contiguous()      # (2, 3, 3, Cin)
+        self._flow_own = own
+
+    def _flownet_own(self, img_cur, img_ref):
+        """FlowNet-S (:150-207) on the own kernels, channels-last, one image pair: no library call.  Concat nodes are channel
+        slices of maps the producers write into directly (lsfa_conv_split_view_fwd), Deconvolution + Crop are four phase
+        convolutions, the 2-channel heads and their upsampling are small dedicated kernels (csrc/flownet.hip)."""
+        if not hasattr(self, '_flow_own'):
+            self._flownet_prepare()
+        o, fw, dev = self._flow_own, self.flow, self.device
+        LEAKY = 2
+
+        def cmap(h, w, c):      # a concatenated map with its channel count padded to a multiple of 32 (the padding stays zero)
+            return torch.zeros((1, h, w, -(-c // 32) * 32), device=dev, dtype=torch.float32)
+
+        def out_hw(h, w, k, stride, pad):
+            return (h + 2 * pad - k) // stride + 1, (w + 2 * pad - k) // stride + 1
+
+        def conv(x, name, stride, pad, out=None, c0=0, cin=None):
+            sw = o[name]
+            h, w = out_hw(x.shape[1], x.shape[2], sw.kh, stride, pad)
+            if out is None:
+                out = torch.empty((1, h, w, sw.cout), device=dev, dtype=torch.float32)
+            return hip.conv_split_view(x, sw, fw[name + '_bias'], out, stride=stride, pad=(pad, pad), act=LEAKY, cin=cin, c0=c0)
+
+        def deconv(x, name, out, c0):
+            hc, wc = out.shape[1], out.shape[2]
+            for py in (0, 1):
+                for px in (0, 1):
+                    hip.conv_split_view(x, o[(name, py, px)], fw[name + '_bias'], out, stride=1, pad=(1 - py, 1 - px), act=LEAKY,
+                                        c0=c0, grid=((hc - py + 1) // 2, (wc - px + 1) // 2), place=(py, px, 2, 2))
+
+        def head(x, name, cin):
+            return hip.head_conv3x3(x, o[name], fw[name + '_bias'], cin=cin)
+
+        # avg pool 2x2 of each image (x 1/255 folded into the first convolution's input affine), flow_conv1 as two passes
+        pc, pr = hip.avgpool_nchw(img_cur, 2), hip.avgpool_nchw(img_ref, 2)
+        r1 = hip.stem_conv(pc, o['c1_cur'], None, o['in_scale'], o['in_shift'], act=0)
+        r1 = hip.stem_conv(pr, o['c1_ref'], fw['flow_conv1_bias'], o['in_scale'], o['in_shift'], out=r1, accum=r1, act=LEAKY)
+        h2, w2 = out_hw(r1.shape[1], r1.shape[2], 5, 2, 2)
+        c5 = cmap(h2, w2, 194)
+        conv(r1, 'conv2', 2, 2, out=c5)                                   # r2 = c5[..., :128]
+        r3 = conv(c5, 'conv3', 2, 2, cin=128)
+        c4 = cmap(r3.shape[1], r3.shape[2], 386)
+        conv(r3, 'conv3_1', 1, 1, out=c4)                                 # r4 = c4[..., :256]
+        r5 = conv(c4, 'conv4', 2, 1, cin=256)
+        c3 = cmap(r5.shape[1], r5.shape[2], 770)
+        conv(r5, 'conv4_1', 1, 1, out=c3)                                 # r6 = c3[..., :512]
+        r7 = conv(c3, 'conv5', 2, 1, cin=512)
+        c2 = cmap(r7.shape[1], r7.shape[2], 1026)
+        conv(r7, 'conv5_1', 1, 1, out=c2)                                 # r8 = c2[..., :512]
+        r9 = conv(c2, 'conv6', 2, 1, cin=512)
+        r10 = conv(r9, 'conv6_1', 1, 1)
+        f6 = head(r10, 'Convolution1', 1024)
+        deconv(r10, 'deconv5', c2, 512)
+        hip.upsample_flow(f6, fw['upsample_flow6to5_weight'], fw['upsample_flow6to5_bias'], c2, 1024)
+        f5 = head(c2, 'Convolution2', 1026)
+        deconv(c2, 'deconv4', c3, 512)
+        hip.upsample_flow(f5, fw['upsample_flow5to4_weight'], fw['upsample_flow5to4_bias'], c3, 768)
+        f4 = head(c3, 'Convolution3', 770)
+        deconv(c3, 'deconv3', c4, 256)
+        hip.upsample_flow(f4, fw['upsample_flow4to3_weight'], fw['upsample_flow4to3_bias'], c4, 384)
+        f3 = head(c4, 'Convolution4', 386)
+        deconv(c4, 'deconv2', c5, 128)
+        hip.upsample_flow(f3, fw['upsample_flow3to2_weight'], fw['upsample_flow3to2_bias'], c5, 192)
+        c5p = hip.avgpool2_nhwc(c5)
+        flow = hip.head_conv3x3(c5p, o['Convolution5'], fw['Convolution5_bias'], cin=194, mul=2.5, nchw=True)
+        scale = hip.conv_split(c5p, o['scale'], fw['Convolution5_scale_bias'], nchw=True)
+        return flow, scale
+
     def _flownet(self, img_cur, img_ref):
         """FlowNet-S on the half-resolution pair (:150-207)."""
+        if _CONV_SPLIT and 'flow' in _OWN_CONV and self.cdtype == torch.float32 and img_cur.shape[0] == 1 and img_cur.is_cuda:
+            return self._flownet_own(img_cur, img_ref)
         fw = self.flow
 
         fused = self.cdtype == torch.float32      # bias + LeakyReLU as one HIP pass (fp32 maps)
@@ -787,7 +907,11 @@ class Executor(object):
             warp = hip.warp_bilinear(feat_key_old, flow, mul=scale_map)
             if self.taps is not None:
                 self.taps.update(flow=flow, scale_map=scale_map, warp=warp)
-            if cfg.network.add_Nq_net:
+            if cfg.network.add_Nq_net and _CONV_SPLIT and 'nq' in _OWN_CONV and self.cdtype == torch.float32 and warp.shape[0] == 1:
+                logits = self._nq_own(warp, conv_feat)
+                self._tap('nq_logits', logits)
+                conv_feat = hip.aggregate_softmax2(warp, conv_feat, logits)
+            elif cfg.network.add_Nq_net:
                 x = self._c(torch.cat([warp, conv_feat], 0))
                 x = torch.relu_(F.conv2d(x, self.nq[0][0], self.nq[0][1], padding=1))
                 x = torch.relu_(F.conv2d(x, self.nq[1][0], self.nq[1][1]))
@@ -804,6 +928,31 @@ class Executor(object):
             else:
                 conv_feat = 0.5 * (warp + conv_feat)
         return conv_feat
+
+    def _nq_own(self, warp, conv_feat):
+        """Nq_net (:94-109) on the own convolution: the two maps side by side as a batch of 2 channels-last images, 3x3
+        1024 -> 256 + ReLU, 1x1 256 -> 16 + ReLU, 1x1 16 -> 1; the 16 / 1 output channels are padded to the kernel's 64-channel
+        tiles with zero weights (the padded activations are relu(0) = 0 and meet zero weights again).  -> logits (2, 1, H, W)."""
+        if not hasattr(self, '_nq_split'):
+            dev = self.device
+            (w1, b1), (w2, b2), (w3, b3) = self.nq
+
+            def padded(w, b, cin_to, cout_to):
+                wp = torch.zeros((cout_to, cin_to) + tuple(w.shape[2:]), device=dev, dtype=torch.float32)
+                wp[:w.shape[0], :w.shape[1]] = w
+                bp = torch.zeros(cout_to, device=dev, dtype=torch.float32)
+                bp[:b.shape[0]] = b
+                return hip.SplitWeight(wp), bp
+            self._nq_split = [(hip.SplitWeight(w1), b1), padded(w2, b2, w2.shape[1], 64), padded(w3, b3, 64, 64)]
+        (s1, b1), (s2, b2), (s3, b3) = self._nq_split
+        _, c, h, w = warp.shape
+        x = torch.empty((2, h, w, c), device=warp.device, dtype=torch.float32)
+        x[0].copy_(warp[0].permute(1, 2, 0))            # NCHW -> channels-last, both maps into one batch
+        x[1].copy_(conv_feat[0].permute(1, 2, 0))
+        x = hip.conv_split(x, s1, b1, 1, 1, 1, relu=True)
+        x = hip.conv_split(x, s2, b2, relu=True)
+        x = hip.conv_split(x, s3, b3)
+        return x[..., 0].reshape(2, 1, h, w).contiguous()
 
     def _key_heads(self, conv_feat, im_info):
         rois, cls_prob, bbox_pred = self._heads(conv_feat, im_info)

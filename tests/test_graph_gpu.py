@@ -578,3 +578,25 @@ def test_bench_line_contract():
     assert h["bound"] == "hbm" and h["unit"] == "GB/s" and abs(h["frac"] - h["achieved"] / h["peak"]) < 1e-3
     c = d["cpu_baseline"]
     assert c["kind"] == "port" and c["cores"] >= 1 and c["unit"] == "frames/s" and c["sample"]
+
+
+def test_fp32_frames_run_without_a_library_convolution(world, monkeypatch):
+    """The fp32 key / non-key graphs reach no MIOpen convolution: FlowNet, the Nq net, the DCN offset branches and the strided
+    shortcuts run on the own split-bf16 convolution (r3).  MIOpen picks its solver from per-user state that concurrently
+    starting processes race for, which made detections depend on the rank layout; what is left on libraries
+    are GEMMs (torch.mm / addmm), whose solution choice is a function of the shape."""
+    import torch.nn.functional as F
+    cfg, key, cur, clip = world['cfg'], world['key'], world['cur'], world['clip']
+    im_info_t = torch.from_numpy(clip.im_info()).to(DEV)
+    f0, f3, f10 = clip.frame(0).to(DEV), clip.frame(3).to(DEV), clip.frame(10).to(DEV)
+
+    def forbidden(*a, **k):
+        raise AssertionError("a library convolution was called")
+    for name in ("conv2d", "conv_transpose2d", "conv1d", "conv3d"):
+        monkeypatch.setattr(F, name, forbidden)
+    out0 = key.forward(data=f0, im_info=im_info_t, data_key_old=f0, feat_key_old=torch.zeros(1, 1024, 1, 1, device=DEV))
+    feat0 = out0['choose_feat_output']
+    cur.forward(data=f3, im_info=im_info_t, feat_key=feat0, motion_vector=clip.motion_vector(3, 0).to(DEV), res_diff=clip.res_diff(3).to(DEV))
+    out10 = key.forward(data=f10, im_info=im_info_t, data_key_old=f0, feat_key_old=feat0)
+    torch.cuda.synchronize()
+    assert out10['rois_output'].shape == (300, 5)

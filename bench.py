@@ -64,6 +64,7 @@ def parse():
                          '942 MB per launch, HBM-resident); 0 = the frame loop\'s own single-map launches')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-parity', action='store_true')
+    ap.add_argument('--no-spread', action='store_true', help='skip the two extra repeats of the timed region behind `value_spread`')
     ap.add_argument('--no-graph', action='store_true', help='issue every launch eagerly instead of replaying hipGraphs')
     ap.add_argument('--no-prefetch', action='store_true', help='do not overlap the next frame\'s small net with this frame\'s tail')
     ap.add_argument('--lanes', type=int, default=2,
@@ -378,8 +379,20 @@ def load_traffic(key):
         return None
 
 
+def load_launch_counts(args):
+    """Kernel launches per key / non-key frame, counted from the rocprofv3 kernel trace of this configuration
+    (tools/summarize_prof.py writes profiles/launch_counts.json); None when no trace of it is committed."""
+    try:
+        with open(os.path.join(ROOT, 'profiles', 'launch_counts.json')) as f:
+            d = json.load(f)
+        return d.get("%dx%d,interval=%d,clips=%d,%s" % (args.width, args.height, args.interval, args.clips, args.dtype))
+    except (OSError, ValueError):
+        return None
+
+
 def main():
     args = parse()
+    parity_failed = False
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
     world = int(os.environ.get('WORLD_SIZE', '1'))
@@ -428,12 +441,25 @@ def main():
     drain()
     barrier()
     elapsed = time.perf_counter() - t0
+    # run-to-run spread: the same K steps twice more, each bracketed like the timed region above (`value` stays the FIRST
+    # region's; the driver's fresh-box figure and a builder's warm-box one have differed by ~10 %: this makes that visible)
+    repeats = [elapsed]
+    for _ in range(0 if args.no_spread else 2):
+        barrier()
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for s in range(args.warmup, args.warmup + args.steps):
+            r.step(s)
+        drain()
+        barrier()
+        repeats.append(time.perf_counter() - t1)
     prof = r.eager_profile_step(args.warmup) if rank == 0 else None
 
     if distributed:
-        tt = torch.tensor([elapsed], device=coll_dev, dtype=torch.float64)
+        tt = torch.tensor(repeats, device=coll_dev, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt.item())
+        repeats = [float(v) for v in tt.tolist()]
+        elapsed = repeats[0]
         # the final gather of detections (here: last interval's per-frame counts) over RCCL
         counts = r.host_counts.to(coll_dev)
         gathered = [torch.empty_like(counts) for _ in range(world)]
@@ -505,6 +531,9 @@ def main():
                            "" if args.no_flow_stream else " + FlowNet/tail stream", args.lanes,
                            ", next key frame queued ahead of the segment before it" if args.lookahead else ""))
                        if args.lanes > 0 else "serial"},
+            "value_spread": {"min": round(frames / max(repeats), 3), "max": round(frames / min(repeats), 3), "repeats": len(repeats),
+                             "values": [round(frames / t, 3) for t in repeats],
+                             "note": "the timed region run %d times back to back; `value` is the first" % len(repeats)},
             "roofline": roof,
             "roofline_hbm_kernel": roof_hbm,
             "roofline_handwritten_ops": {
@@ -547,10 +576,19 @@ def main():
             except Exception as e:  # the checker legs are reported extras; never lose the bench line to them
                 line["cpu_baseline"] = {"value": None, "unit": "frames/s", "cores": int(torch.get_num_threads()),
                                         "kind": "port", "sample": "failed: %r" % (e,)}
+        launches = load_launch_counts(args)
+        if launches is not None:
+            line["kernel_launches"] = launches
         print(json.dumps(line))
+        bad = (line.get("parity") or {}).get("handwritten_stage_mismatches_on_gpu_inputs")
+        if bad:
+            sys.stderr.write("bench.py: %d elements of the hand-written stages differ from the oracle on the GPU's own inputs\n" % bad)
+            parity_failed = True
     if distributed:
         dist.barrier(device_ids=[local_rank]) if backend == 'nccl' else dist.barrier()
         dist.destroy_process_group()
+    if parity_failed:
+        sys.exit(3)
 
 
 if __name__ == '__main__':

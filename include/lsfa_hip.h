@@ -77,6 +77,11 @@ int lsfa_rfcn_head_ps_fwd(const float* ps_map, const float* rois,
                           int N, int H, int W, int R, int ncls, int nbox,
                           float spatial_scale, int pooled_size, int group_size,
                           float* cls_prob, float* cls_score, float* bbox_pred, void* stream);
+/* ... with `cell_ld` floats between consecutive cells of ps_map (>= group*group*(ncls+nbox)): the map as lsfa_conv_split_fwd
+ * writes it, its 1911 columns padded to 1920 = 30 x 64 output channels. */
+int lsfa_rfcn_head_ps_ld_fwd(const float* ps_map, int cell_ld, const float* rois, int N, int H, int W, int R, int ncls,
+                             int nbox, float spatial_scale, int pooled_size, int group_size, float* cls_prob,
+                             float* cls_score, float* bbox_pred, void* stream);
 
 /* ------------------------------------------------------------------------ *
  * Motion-vector / flow guided bilinear feature warp with fused epilogue.

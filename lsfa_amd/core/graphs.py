@@ -218,6 +218,16 @@ class FrameGraphs(object):
             self.feat.copy_(self._first_feat)
         self._small_valid = False      # the warm-up replays left their own small-net feature in small_cur
 
+    def close(self):
+        """Drop the captured graphs (and with them their private memory pools), then destroy the streams this object
+        created.  The device must be idle with respect to them (call after a synchronize / FramePipeline.join + sync)."""
+        self.key_graph = self.cur_graph = None
+        for name in ('side', '_capture_stream'):
+            st = getattr(self, name, None)
+            if st is not None:
+                streams.release(st)
+                setattr(self, name, None)
+
     # ---- per-frame entry points ---------------------------------------------------------
     def key_frame(self, data, next_data=None):
         """flag 1: a key frame after the first.  `next_data` = image of the following frame when that
@@ -336,6 +346,14 @@ class KeyLane(object):
         with torch.cuda.graph(self.tail_graph, stream=self._capture_stream_flow):
             self.tail()
 
+    def close(self):
+        self.front_graph = self.flow_graph = self.agg_graph = self.tail_graph = None
+        for name in ('_capture_stream', '_capture_stream_flow'):
+            st = getattr(self, name, None)
+            if st is not None:
+                streams.release(st)
+                setattr(self, name, None)
+
     def run_front(self):
         self.front_graph.replay() if self.use_graphs else self.front()
 
@@ -423,6 +441,7 @@ class FramePipeline(object):
         else:
             raise ValueError("FramePipeline: layout must be 'probe', 'plain' or 'one-queue', got %r" % (layout,))
         self.hw_queues = len(chosen)
+        self._owned_streams = list(chosen) + [st for st, _ in aliased]
         self.s_key = chosen[0]
         rest = chosen[1:]
         self.s_flow = rest.pop(0) if (flow_stream and rest) else None
@@ -469,6 +488,20 @@ class FramePipeline(object):
 
     def _all_streams(self):
         return [self.s_key] + self.s_lane + ([self.s_flow] if self.s_flow is not None else [])
+
+    def close(self):
+        """Release everything the pipeline owns on the device side: drains it, drops the captured graphs of every lane and
+        destroys the streams made for it (core/streams.py new_stream; they are not returned to any pool otherwise, and a
+        process that builds a pipeline per frame shape would accumulate ~10 hipStreams + graph pools each — ADVICE r2)."""
+        self.join()
+        torch.cuda.synchronize(self.device)
+        for g in self.klanes + self.lanes:
+            g.close()
+        extra = [st for st in self.s_lane if st not in self._owned_streams]
+        for st in self._owned_streams + extra:
+            streams.release(st)
+        self._owned_streams = []
+        self.captured = False
 
     def flush(self):
         """Queue the non-key frames recorded so far (end of a clip, or before reading results)."""

@@ -12,7 +12,8 @@ import ctypes
 import torch
 
 _SPIN = 400000        # device cycles per probe kernel (~0.2 ms)
-_OWNED = []           # hipStream_t handles created here and still wrapped by a live ExternalStream
+_OWNED = []           # hipStream_t handles created here and in use
+_FREE = {}            # device index -> streams handed back by `release`, reused by the next `new_stream`
 
 
 def new_stream(device):
@@ -25,6 +26,11 @@ def new_stream(device):
     ExternalStream; they live until `release`d (or the process ends)."""
     from lsfa_amd import hip
     dev = torch.device(device)
+    idx = dev.index if dev.index is not None else torch.cuda.current_device()
+    if _FREE.get(idx):
+        s = _FREE[idx].pop()
+        _OWNED.append(s.cuda_stream)
+        return s
     ptr = ctypes.c_void_p()
     with torch.cuda.device(dev):
         hip._check(hip.lib().lsfa_stream_create(ctypes.byref(ptr), ctypes.c_int(0)), "lsfa_stream_create")
@@ -34,13 +40,14 @@ def new_stream(device):
 
 
 def release(stream):
-    """Destroy a stream made by new_stream (it must be idle and no graph may have been captured on it)."""
-    from lsfa_amd import hip
+    """Hand a stream made by new_stream back (it must be idle, and the graphs captured on it dropped).  The handle is kept
+    and reused by the next new_stream instead of being destroyed: PyTorch's caching allocator may still hold blocks that were
+    `record_stream`ed on it and records an event on that stream when they are freed — on a destroyed stream that is an
+    invalid-handle error.  The number of hipStreams a process holds is thereby bounded by what it uses at one time."""
     ptr = stream.cuda_stream
     if ptr in _OWNED:
         _OWNED.remove(ptr)
-        with torch.cuda.device(stream.device):
-            hip._check(hip.lib().lsfa_stream_destroy(ctypes.c_void_p(ptr)), "lsfa_stream_destroy")
+        _FREE.setdefault(stream.device.index, []).append(stream)
 
 
 def _pair_time(a, b, dev):

@@ -210,7 +210,7 @@ def pred_eval(gpu_id, key_predictor, cur_predictor, test_data, imdb, cfg, vis=Fa
 
 
 def pred_eval_pipelined(gpu_id, key_predictor, cur_predictor, test_data, imdb, cfg, thresh=1e-4, logger=None, lanes=2,
-                        use_graphs=True):
+                        use_graphs=True, max_pipelines=4):
     """pred_eval with the frames of each video pipelined over HIP streams (core/graphs.py
     FramePipeline): same loader, same flags, same launch sequences per frame, same return value.
     One pipeline (captured graphs + static buffers) is built per distinct (height, width, scale) and
@@ -261,7 +261,11 @@ def pred_eval_pipelined(gpu_id, key_predictor, cur_predictor, test_data, imdb, c
             if fp is not None:
                 fp.join()
             fp = pipelines.get(shape_key)
+            if fp is not None:
+                pipelines[shape_key] = pipelines.pop(shape_key)          # most recently used last
             if fp is None:
+                while len(pipelines) >= max_pipelines:                   # a dataset with many frame shapes: evict the oldest
+                    pipelines.pop(next(iter(pipelines))).close()
                 fp = pipelines[shape_key] = FramePipeline(key_predictor._exec, cur_predictor._exec, cfg, shape_key[0],
                                                           shape_key[1], data.device, thresh=thresh,
                                                           use_graphs=use_graphs, lanes=lanes, taps=bool(tap_file))
@@ -298,6 +302,8 @@ def pred_eval_pipelined(gpu_id, key_predictor, cur_predictor, test_data, imdb, c
         with open(tap_file + ('.rank%d' % gpu_id if gpu_id else ''), 'w') as f:
             json.dump([{'frame': int(frame_ids[i]), 'flag': int(flag), 'sums': {n: [float(a), float(b)] for n, (a, b) in zip(names, vals.cpu().tolist())}}
                        for i, flag, names, vals in tap_sums], f)
+    for p_ in pipelines.values():
+        p_.close()
     net_time = time.time() - t0
     if logger:
         logger.info('done {} frames: {:.4f}s per frame ({:.1f} frames/s)'.format(num_images, net_time / max(idx, 1),

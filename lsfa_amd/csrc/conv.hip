@@ -392,7 +392,7 @@ extern "C" int lsfa_conv_split_weights(const float* w, int Cout, int kh, int kw,
 
 namespace {
 // every split convolution goes through here; the public entry points fill in what they expose
-int conv_split_launch(convsplit::Args a, void* ws, size_t ws_bytes, void* stream, const char* who) {
+int conv_split_launch(convsplit::Args a, void* ws, size_t ws_bytes, void* stream, const char* who, int prof_op = LSFA_OP_CONV) {
   const int N = a.N, H = a.H, W = a.W, Cin = a.Cin, Cout = a.Cout, kh = a.kh, kw = a.kw, stride = a.stride, dil = a.dil;
   LSFA_REQUIRE(a.x && a.wfrag && a.y, "%s: NULL argument", who);
   LSFA_REQUIRE(N > 0 && H > 0 && W > 0 && kh > 0 && kw > 0 && stride > 0 && a.pad_h >= 0 && a.pad_w >= 0 && dil > 0, "%s: bad shape", who);
@@ -428,7 +428,7 @@ int conv_split_launch(convsplit::Args a, void* ws, size_t ws_bytes, void* stream
   a.part = p.slices > 1 ? (float*)ws : nullptr;
   a.chunks_per_slice = p.per_slice;
   a.units_per_wg = a.max_pieces = 0;
-  ProfScope prof(LSFA_OP_CONV, s);
+  ProfScope prof(prof_op, s);
   int tiles = p.nx * p.ny * p.slices;
   if (p.units_per_wg > 0) {
     a.part = (float*)ws;
@@ -501,5 +501,5 @@ extern "C" int lsfa_conv_split_view_fwd(const float* x, int lda, int N, int H, i
     LSFA_REQUIRE(out_W > 0 && out_sy > 0 && out_sx > 0, "lsfa_conv_split_view_fwd: bad output view");
     a.view = 1; a.out_H = out_H; a.out_W = out_W; a.out_sy = out_sy; a.out_sx = out_sx;
   }
-  return conv_split_launch(a, ws, ws_bytes, stream, "lsfa_conv_split_view_fwd");
+  return conv_split_launch(a, ws, ws_bytes, stream, "lsfa_conv_split_view_fwd", LSFA_OP_FLOWNET);
 }

@@ -323,7 +323,11 @@ static __global__ __launch_bounds__(64) void nms_sweep_kernel(const uint64_t* __
       const uint64_t g30 = m3[(size_t)k0 * col_blocks], g31 = m3[(size_t)k1 * col_blocks], g32 = m3[(size_t)k2 * col_blocks];
       const uint64_t g33 = m3[(size_t)k3 * col_blocks], g34 = m3[(size_t)k4 * col_blocks];
       const uint64_t sa2 = m2[(size_t)ra * col_blocks], sa3 = m3[(size_t)ra * col_blocks];      // block b's rows
-      const uint64_t sb2 = m2[(size_t)rb * col_blocks], sb3 = m3[(size_t)rb * col_blocks];      // block b+1's rows
+      // block b+1's rows.  When there is no next pair (t2 / t3 clamped to b) word b of those rows lies LEFT of the diagonal,
+      // which nms_mask_kernel never writes: the value would be discarded below (cur0 / cur1 are forced to 0), but read a
+      // word that exists instead (their own diagonal word, or the last row's) so that nothing uninitialised is ever loaded
+      const int tb2 = min(max(t2, b + 1), col_blocks - 1), tb3 = min(max(t3, b + 1), col_blocks - 1);
+      const uint64_t sb2 = mask[(size_t)rb * col_blocks + tb2], sb3 = mask[(size_t)rb * col_blocks + tb3];
       const uint64_t n_colw0 = diagT[rc], n_rowd0 = m2[(size_t)rc * col_blocks], n_intra = m3[(size_t)rc * col_blocks];
       const uint64_t n_colw1 = diagT[rd_], n_rowd1 = m3[(size_t)rd_ * col_blocks];
       const bool h0 = lane < num, h1 = lane + 64 < num, h2 = lane + 128 < num, h3 = lane + 192 < num, h4 = lane + 256 < num;

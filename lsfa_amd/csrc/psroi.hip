@@ -129,7 +129,7 @@ __global__ __launch_bounds__(kHeadThreads) void rfcn_head_kernel(
 // is unchanged (h outer, w inner), so the result is bit-identical to the NCHW kernel's.
 __global__ __launch_bounds__(kHeadThreads) void rfcn_head_ps_kernel(
     const float* __restrict__ ps_map, const float* __restrict__ rois, int H, int W, int ncls, int nbox,
-    float scale, int P, int group, float* __restrict__ cls_prob, float* __restrict__ cls_score,
+    float scale, int P, int group, int cell_ld, float* __restrict__ cls_prob, float* __restrict__ cls_score,
     float* __restrict__ bbox_pred) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int r = blockIdx.x;
@@ -138,7 +138,7 @@ __global__ __launch_bounds__(kHeadThreads) void rfcn_head_ps_kernel(
   float* bins = smem;            // D * PP, index d*PP + k like the NCHW kernel
   float* avg = smem + D * PP;    // D
   const RoiGeom g = roi_geom(rois + (size_t)r * 5, scale, P);
-  const size_t cell_stride = (size_t)group * group * D;
+  const size_t cell_stride = (size_t)cell_ld;        // floats between consecutive cells (>= group*group*D: rows may be padded)
   const float* base = ps_map + (size_t)g.batch * H * W * cell_stride;
   for (int i = threadIdx.x; i < D * PP; i += kHeadThreads) {
     const int k = i / D, d = i - k * D;
@@ -234,7 +234,16 @@ extern "C" int lsfa_rfcn_head_fwd(const float* cls_map, const float* box_map, co
 extern "C" int lsfa_rfcn_head_ps_fwd(const float* ps_map, const float* rois, int N, int H, int W, int R, int ncls,
                                      int nbox, float spatial_scale, int pooled_size, int group_size, float* cls_prob,
                                      float* cls_score, float* bbox_pred, void* stream) {
+  return lsfa_rfcn_head_ps_ld_fwd(ps_map, group_size * group_size * (ncls + nbox), rois, N, H, W, R, ncls, nbox, spatial_scale, pooled_size,
+                                  group_size, cls_prob, cls_score, bbox_pred, stream);
+}
+
+extern "C" int lsfa_rfcn_head_ps_ld_fwd(const float* ps_map, int cell_ld, const float* rois, int N, int H, int W, int R, int ncls,
+                                        int nbox, float spatial_scale, int pooled_size, int group_size, float* cls_prob,
+                                        float* cls_score, float* bbox_pred, void* stream) {
   using namespace lsfa;
+  LSFA_REQUIRE(cell_ld >= group_size * group_size * (ncls + nbox), "lsfa_rfcn_head_ps_ld_fwd: cell_ld %d < %d", cell_ld,
+               group_size * group_size * (ncls + nbox));
   LSFA_REQUIRE(N > 0 && H > 0 && W > 0 && R >= 0 && ncls > 0 && nbox > 0 && pooled_size > 0 && group_size > 0,
                "lsfa_rfcn_head_ps_fwd: bad shape");
   if (R == 0) return LSFA_OK;
@@ -247,7 +256,7 @@ extern "C" int lsfa_rfcn_head_ps_fwd(const float* ps_map, const float* rois, int
   hipStream_t s = (hipStream_t)stream;
   ProfScope prof(LSFA_OP_RFCN_HEAD, s);
   hipLaunchKernelGGL(rfcn_head_ps_kernel, dim3(R), dim3(kHeadThreads), lds, s, ps_map, rois, H, W, ncls, nbox,
-                     spatial_scale, pooled_size, group_size, cls_prob, cls_score, bbox_pred);
+                     spatial_scale, pooled_size, group_size, cell_ld, cls_prob, cls_score, bbox_pred);
   LSFA_LAUNCH_CHECK("lsfa_rfcn_head_ps_fwd");
   return LSFA_OK;
 }

@@ -539,10 +539,12 @@ class SplitWeight(object):
     """A convolution weight cut into three bf16 pieces per value and laid out in MFMA fragment order
     (lsfa_conv_split_weights); made once per layer at bind time."""
 
-    def __init__(self, weight):
-        """weight: (Cout, Cin, kh, kw) float32 CUDA tensor (the framework's layout)."""
+    def __init__(self, weight, real_cout=None, real_cin=None):
+        """weight: (Cout, Cin, kh, kw) float32 CUDA tensor (the framework's layout).  real_cout / real_cin: the layer's own
+        channel counts when `weight` was zero-padded to the kernel's tile sizes (algorithmic FLOPs are counted on those)."""
         w_kc = _f32c(conv_weight_kc(weight), "weight")
         self.cout, self.cin, self.kh, self.kw = [int(v) for v in weight.shape]
+        self.real_cout, self.real_cin = int(real_cout or self.cout), int(real_cin or self.cin)
         need = lib().lsfa_conv_split_weight_bytes(_ci(self.cout), _ci(self.kh), _ci(self.kw), _ci(self.cin))
         if need == 0:
             raise LsfaError("SplitWeight: Cin=%d must be a multiple of 32 and Cout=%d of 64" % (self.cin, self.cout))
@@ -569,7 +571,7 @@ def conv_split(x, sw, bias=None, stride=1, pad=0, dil=1, relu=False, out=None, r
     for name, t in (("out", out), ("residual", residual), ("out2", out2)):
         if t is not None and (t.numel() != N * Ho * Wo * Cout or not t.is_contiguous() or t.dtype != torch.float32):
             raise LsfaError("conv_split: %s must be a contiguous float32 tensor of %d elements" % (name, N * Ho * Wo * Cout))
-    _count_conv(N, Ho, Wo, Cout, Cin, kh, kw)
+    _count_conv(N, Ho, Wo, sw.real_cout, sw.real_cin, kh, kw)
     need = lib().lsfa_conv_split_workspace_bytes(_ci(N), _ci(H), _ci(W), _ci(Cin), _ci(Cout), _ci(kh), _ci(kw), _ci(stride),
                                                  _ci(pad), _ci(dil))
     ws = torch.empty(need, dtype=torch.uint8, device=x.device)
@@ -604,7 +606,6 @@ def conv_split_view(x, sw, bias, out, stride=1, pad=(0, 0), dil=1, act=0, cin=No
     Hout, Wout, Lout = out.shape[1], out.shape[2], out.shape[3]
     if y0 + (Ho - 1) * sy >= Hout or x0 + (Wo - 1) * sx >= Wout:
         raise LsfaError("conv_split_view: a %dx%d grid placed at (%d,%d) step (%d,%d) leaves out %s" % (Ho, Wo, y0, x0, sy, sx, tuple(out.shape)))
-    _count_conv(N, Ho, Wo, sw.cout, cin, kh, kw)
     need = lib().lsfa_conv_split_view_workspace_bytes(_ci(L), _ci(N), _ci(H), _ci(W), _ci(cin), _ci(sw.cout), _ci(kh), _ci(kw),
                                                       _ci(stride), _ci(pad[0]), _ci(pad[1]), _ci(dil), _ci(Ho), _ci(Wo))
     ws = torch.empty(need, dtype=torch.uint8, device=x.device)

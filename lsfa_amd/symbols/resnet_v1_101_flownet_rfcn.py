@@ -270,7 +270,7 @@ class _ResNetWeights(object):
                     wpad[:co] = d['off_w']
                     bpad = torch.zeros(pad_to, device=d['off_w'].device, dtype=torch.float32)
                     bpad[:co] = d['off_b']
-                    d['off_split'], d['off_b_pad'] = hip.SplitWeight(wpad), bpad
+                    d['off_split'], d['off_b_pad'] = hip.SplitWeight(wpad, real_cout=co), bpad
                     d['dcn_split'] = hip.SplitWeight(d['w2_tap_t'].t().contiguous().view(d['w2'].shape[0], -1, 1, 1))
             if _CONV_SPLIT and 'pw' in _OWN_CONV and d['w1'].is_cuda and d['w1'].dtype == torch.float32:
                 # every contraction of the unit on lsfa_conv_split_fwd: the 1x1 convolutions, the shortcut, and for a DCN
@@ -662,7 +662,7 @@ class Executor(object):
         ws = fw['Convolution5_scale_weight']                              # (1024, 194, 1, 1)
         wsp = torch.zeros((ws.shape[0], pad32(ws.shape[1]), 1, 1), device=dev, dtype=torch.float32)
         wsp[:, :ws.shape[1]] = ws
-        own['scale'] = hip.SplitWeight(wsp)
+        own['scale'] = hip.SplitWeight(wsp, real_cin=ws.shape[1])
         for name in ('Convolution1', 'Convolution2', 'Convolution3', 'Convolution4', 'Convolution5'):
             own[name] = fw[name + '_weight'].permute(0, 2, 3, 1).contiguous()      # (2, 3, 3, Cin)
         self._flow_own = own
@@ -942,7 +942,7 @@ class Executor(object):
                 wp[:w.shape[0], :w.shape[1]] = w
                 bp = torch.zeros(cout_to, device=dev, dtype=torch.float32)
                 bp[:b.shape[0]] = b
-                return hip.SplitWeight(wp), bp
+                return hip.SplitWeight(wp, real_cout=w.shape[0], real_cin=w.shape[1]), bp
             self._nq_split = [(hip.SplitWeight(w1), b1), padded(w2, b2, w2.shape[1], 64), padded(w3, b3, 64, 64)]
         (s1, b1), (s2, b2), (s3, b3) = self._nq_split
         _, c, h, w = warp.shape

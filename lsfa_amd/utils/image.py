@@ -8,6 +8,11 @@ INTER_LINEAR) on float input [OpenCV 3.2 resize.cpp, un-vendored — PARITY UNPI
 cvRound(size * f); source coordinate of destination pixel d = (d + 0.5) / f - 0.5 — the scale is
 1/f as GIVEN, not src/dst (they differ whenever size*f is not an integer, the usual case for
 im_scale) — two taps with edge clamping, no antialiasing, horizontal pass then vertical pass.
+This is cv2's FLOAT path, which is what the motion vectors and the residual take (image.py:204-205, 221-222).  The
+reference's `resize()` of the frame itself runs on the uint8 image from cv2.imread (image.py:283): cv2's fixed-point path
+(11-bit coefficients, result rounded to uint8).  `resize()` here interpolates in float and does not round: up to 0.5
+intensity levels of difference per pixel against the reference's frame (stated, not reproduced: cv2 is absent, so neither
+path can be pinned — DESIGN.md §5).
 """
 import numpy as np
 import torch
@@ -20,10 +25,12 @@ def _cv_round(x):
 
 def _taps(dst_n, src_n, f, device):
     """Source taps of cv2's INTER_LINEAR along one axis: (i0, i1, weight of i1)."""
-    pos = (torch.arange(dst_n, dtype=torch.float64, device=device) + 0.5) / float(f) - 0.5
-    i0 = torch.floor(pos)
-    a = (pos - i0).to(torch.float32)
-    i0 = i0.to(torch.int64)
+    # resize.cpp: `fx = (float)((dx+0.5)*scale_x - 0.5); sx = cvFloor(fx); fx -= sx;` with scale_x = 1. / f in double: the
+    # position is rounded to float BEFORE the floor and the subtraction
+    pos = ((torch.arange(dst_n, dtype=torch.float64, device=device) + 0.5) * (1.0 / float(f)) - 0.5).to(torch.float32)
+    i0f = torch.floor(pos)
+    a = pos - i0f
+    i0 = i0f.to(torch.int64)
     lo, hi = i0 < 0, i0 >= src_n - 1
     i0 = torch.where(lo, torch.zeros_like(i0), torch.where(hi, torch.full_like(i0, src_n - 1), i0))
     a = torch.where(lo | hi, torch.zeros_like(a), a)

@@ -182,9 +182,11 @@ def cv2_resize_linear(src, fx, fy):
 
     def taps(dn, sn, factor):
         scale = 1.0 / float(factor)
-        f = (np.arange(dn, dtype=np.float64) + 0.5) * scale - 0.5
+        # resize.cpp: `fx = (float)((dx+0.5)*scale_x - 0.5); sx = cvFloor(fx); fx -= sx;` — the position is rounded to
+        # float BEFORE the floor and the subtraction
+        f = ((np.arange(dn, dtype=np.float64) + 0.5) * scale - 0.5).astype(np.float32)
         s0 = np.floor(f).astype(np.int64)
-        a = (f - s0).astype(np.float32)
+        a = (f - s0.astype(np.float32)).astype(np.float32)
         lo = s0 < 0
         s0[lo], a[lo] = 0, 0.0
         hi = s0 >= sn - 1

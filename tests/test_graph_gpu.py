@@ -394,8 +394,8 @@ def _run_clip_through_pipeline(fp, frames, sched, mvs, ress):
     return outs
 
 
-@pytest.mark.parametrize("lookahead", [False, True])
-def test_frame_pipeline_frames_pinned_to_oracle_and_to_the_serial_loop(world, lookahead):
+@pytest.mark.parametrize("lookahead,layout", [(False, "probe"), (True, "probe"), (False, "plain"), (False, "one-queue"), (True, "one-queue")])
+def test_frame_pipeline_frames_pinned_to_oracle_and_to_the_serial_loop(world, lookahead, layout):
     """FramePipeline (key stream + FlowNet/tail stream + 3 non-key lanes, hipGraph replay) on an 11-frame
     schedule with key interval 4.  For EVERY frame, as delivered by the pipeline:
       * a non-key frame's conv_feat == oracle.warp_bilinear(the aggregated feature of ITS segment's key frame,
@@ -405,7 +405,9 @@ def test_frame_pipeline_frames_pinned_to_oracle_and_to_the_serial_loop(world, lo
         oracle.aggregate_softmax2 of its own taps; Proposal / PSROI head / detection NMS == oracle;
       * with conv / GEMM algorithms pinned, every tap, output and detection equals the strictly serial eager
         loop's BIT FOR BIT (so the dense stages read the right images too), and a second run of the same
-        pipeline reproduces the first."""
+        pipeline reproduces the first.
+    `layout`: how the work streams were picked (FramePipeline): the timing probe's choice, a fresh stream per role, and the
+    degenerate outcome of a perturbed probe — no FlowNet stream, lanes on spare streams aliased to the key queue."""
     from parity_util import assert_dets_equal, check_cur_frame, check_dets, check_key_frame, clone_dict, pinned_algorithms
     from lsfa_amd.core.graphs import FrameGraphs, FramePipeline
     cfg, arg, key, cur, clip = world['cfg'], world['arg'], world['key'], world['cur'], world['clip']
@@ -418,7 +420,10 @@ def test_frame_pipeline_frames_pinned_to_oracle_and_to_the_serial_loop(world, lo
     ress = {f: clip.res_diff(f, DEV) for f, kf in sched if f != kf}
     torch.cuda.synchronize()
     with pinned_algorithms():
-        fp = FramePipeline(key, cur, cfg, H, W, DEV, lanes=3, lookahead=lookahead, taps=True)
+        fp = FramePipeline(key, cur, cfg, H, W, DEV, lanes=3, lookahead=lookahead, taps=True, layout=layout)
+        assert fp.layout_used.startswith(layout)
+        if layout == "one-queue":
+            assert fp.s_flow is None
         a = _run_clip_through_pipeline(fp, frames, sched, mvs, ress)
         b = _run_clip_through_pipeline(fp, frames, sched, mvs, ress)
         # the strictly serial eager loop on the same frames
@@ -453,6 +458,7 @@ def test_frame_pipeline_frames_pinned_to_oracle_and_to_the_serial_loop(world, lo
             for name in a[f]['out']:
                 assert torch.equal(a[f]['out'][name], other[f]['out'][name]), "frame %d, output %s vs %s" % (f, name, what)
             assert_dets_equal(a[f]['dets'], a[f]['counts'], other[f]['dets'], other[f]['counts'], "frame %d vs %s" % (f, what))
+    fp.close()         # graphs dropped, streams handed back for the next pipeline
 
 
 def test_pred_eval_pipelined_two_videos(world):

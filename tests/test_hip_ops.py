@@ -967,3 +967,41 @@ def test_conv_split_views_and_transposed_convolution_phases(hip):
     got = out[..., c0:c0 + Cout].double()
     assert float((got - ref).abs().max()) < 2e-6 * (Cin * 4) ** 0.5 * float(ref.abs().max())
     assert bool((out[..., :c0] == -3.0).all()) and bool((out[..., c0 + Cout:] == -3.0).all())
+
+
+def test_proposal_and_nms_do_not_depend_on_workspace_contents(hip):
+    """The NMS sweep requests mask words speculatively; none of them may be a word nms_mask_kernel does not write (ADVICE r2:
+    the lower triangle of the mask is never initialised).  The workspace comes from torch's caching allocator, so it is
+    poisoned by filling a block of its size with 0xFF bytes and freeing it right before the call; results must not move."""
+    rs = np.random.RandomState(11)
+    n = 1500
+    boxes = np.zeros((n, 5), np.float32)
+    ctr = rs.uniform(50, 550, (n, 2)).astype(np.float32)
+    wh = rs.uniform(20, 200, (n, 2)).astype(np.float32)
+    boxes[:, 0:2], boxes[:, 2:4] = ctr - wh / 2, ctr + wh / 2
+    boxes[:, 4] = np.sort(rs.uniform(0, 1, n).astype(np.float32))[::-1]
+    t = torch.from_numpy(boxes).to(DEV)
+    want = np.asarray(oracle.nms_sorted(boxes, 0.7))
+    for poison in (False, True, True):
+        if poison:
+            junk = torch.full((64 << 20,), 0xFF, dtype=torch.uint8, device=DEV)
+            torch.cuda.synchronize()
+            del junk
+        keep, num = hip.nms_sorted(t, 0.7)
+        k = int(num.item())
+        assert np.array_equal(keep.cpu().numpy()[:k], want[:k]) and k == len(want)
+    # Proposal (the two-blocks-per-trip sweep): random RPN-like maps, poisoned workspace, against the oracle
+    A, H, W = 9, 24, 40
+    cls = rs.uniform(0, 1, (1, 2 * A, H, W)).astype(np.float32)
+    bb = (rs.randn(1, 4 * A, H, W) * 0.3).astype(np.float32)
+    im_info = np.array([[H * 16, W * 16, 1.0]], np.float32)
+    op = hip.ProposalOp(feature_stride=16, scales=(8, 16, 32), ratios=(0.5, 1, 2), rpn_pre_nms_top_n=6000, rpn_post_nms_top_n=300,
+                        threshold=0.7, rpn_min_size=16)
+    want_rois, _ = oracle.proposal(cls, bb, im_info, 16, (8, 16, 32), (0.5, 1, 2), 6000, 300, 0.7, 16)
+    for poison in (False, True):
+        if poison:
+            junk = torch.full((64 << 20,), 0xFF, dtype=torch.uint8, device=DEV)
+            torch.cuda.synchronize()
+            del junk
+        rois = op(torch.from_numpy(cls).to(DEV), torch.from_numpy(bb).to(DEV), torch.from_numpy(im_info).to(DEV))
+        np.testing.assert_array_equal(rois.cpu().numpy(), want_rois)

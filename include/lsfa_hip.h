@@ -278,6 +278,14 @@ int lsfa_conv_split_fwd(const float* x, int N, int H, int W, int Cin, const void
  *   Ho, Wo > 0: the output grid of this launch when smaller than the convolution's (a phase's share of the cropped map);
  *   separate pad_h / pad_w; act: 0 none, 1 ReLU, 2 LeakyReLU(0.1) (sym_common / :153 `LeakyReLU(act_type='leaky', slope=0.1)`).
  * workspace: lsfa_conv_split_view_workspace_bytes of the same arguments (Ho, Wo = 0: the convolution's own output grid). */
+/* Deconvolution(kernel 4, stride 2) + Crop(offset (1,1)) to Hc x Wc (+ bias + activation) as ONE launch of the four phase
+ * convolutions above (resnet_v1_101_flownet_rfcn.py:170-176 `deconv5` ... `deconv2`): x (N, Hi, Wi, lda) with Cin channels used,
+ * wfrag4[py*2 + px] = lsfa_conv_split_weights of the (Cout, 2, 2, Cin) weight w[:, :, kys, kxs] transposed to (out, in, ky, kx),
+ * kys = (3, 1) for py = 0 and (2, 0) for py = 1 (kxs alike); y points at channel c0 of pixel (0, 0) of the (N, Hc, Wc, ldy) map. */
+size_t lsfa_deconv4x4s2_crop_workspace_bytes(int N, int Hi, int Wi, int Cin, int Cout, int Hc, int Wc);
+int lsfa_deconv4x4s2_crop_fwd(const float* x, int lda, int N, int Hi, int Wi, int Cin, const void* const* wfrag4,
+                              const float* bias, int Cout, int act, float* y, int ldy, int Hc, int Wc, void* ws,
+                              size_t ws_bytes, void* stream);
 size_t lsfa_conv_split_view_workspace_bytes(int lda, int N, int H, int W, int Cin, int Cout, int kh, int kw, int stride, int pad_h,
                                             int pad_w, int dil, int Ho, int Wo);
 int lsfa_conv_split_view_fwd(const float* x, int lda, int N, int H, int W, int Cin, const void* wfrag, const float* bias,

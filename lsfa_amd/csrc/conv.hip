@@ -419,17 +419,20 @@ int conv_split_launch(convsplit::Args a, void* ws, size_t ws_bytes, void* stream
   LSFA_REQUIRE(((long)N * a.out_H * a.out_W + 1) * (long)(a.y_nchw ? Cout : a.ldy) < (1L << 31) && P * Cout < (1L << 31) &&
                ((long)N * H * W + (long)(a.pad_h + 1) * (W + 1)) * a.lda < (1L << 31), "%s: tensor too large", who);
   const SplitPlan p = view_plan(N, H, W, Cin, Cout, kh, kw, stride, a.pad_h, a.pad_w, dil, a.lda, a.Ho, a.Wo);
-  const size_t need = split_workspace(p, P, Cout);
+  const int nph = a.nphase > 1 ? a.nphase : 1;
+  const size_t need = split_workspace(p, P, Cout) * (size_t)nph;
   if ((p.slices > 1 || p.units_per_wg > 0) && (!ws || ws_bytes < need)) {
     set_error("%s: workspace %zu < %zu bytes", who, ws_bytes, need);
     return LSFA_EWORKSPACE;
   }
+  LSFA_REQUIRE(nph == 1 || (!p.halo && p.units_per_wg == 0), "%s: phases need the general kernel", who);
   hipStream_t s = (hipStream_t)stream;
   a.part = p.slices > 1 ? (float*)ws : nullptr;
+  a.part_stride = P * Cout;
   a.chunks_per_slice = p.per_slice;
   a.units_per_wg = a.max_pieces = 0;
   ProfScope prof(prof_op, s);
-  int tiles = p.nx * p.ny * p.slices;
+  int tiles = p.nx * p.ny * p.slices * nph;
   if (p.units_per_wg > 0) {
     a.part = (float*)ws;
     a.units_per_wg = p.units_per_wg;
@@ -442,16 +445,16 @@ int conv_split_launch(convsplit::Args a, void* ws, size_t ws_bytes, void* stream
   else if (p.halo)
     hipLaunchKernelGGL(convsplit::conv_split3x3_kernel<2>, grid, dim3(convsplit::kThreads), 0, s, a, p.patches_x, p.patches_y, p.nx, p.ny, p.slices);
   else if (p.nt == 4)
-    hipLaunchKernelGGL(convsplit::conv_split_wide_kernel<4>, grid, dim3(convsplit::kThreads), 0, s, a, p.nx, p.ny, p.slices);
+    hipLaunchKernelGGL(convsplit::conv_split_wide_kernel<4>, grid, dim3(convsplit::kThreads), 0, s, a, p.nx, p.ny, p.slices * nph);
   else
-    hipLaunchKernelGGL(convsplit::conv_split_kernel, grid, dim3(convsplit::kThreads), 0, s, a, p.nx, p.ny, p.slices);
+    hipLaunchKernelGGL(convsplit::conv_split_kernel, grid, dim3(convsplit::kThreads), 0, s, a, p.nx, p.ny, p.slices * nph);
   if (p.units_per_wg > 0) {
     hipLaunchKernelGGL(convsplit::conv_split3x3_fixup_kernel, dim3((unsigned)(p.nx * p.ny)), dim3(convsplit::kThreads), 0, s, a, p.patches_x,
                        p.patches_y, p.nx);
   }
   if (p.slices > 1) {
     const long n4 = P * Cout / 4;
-    hipLaunchKernelGGL(convsplit::split_reduce_kernel, dim3((unsigned)((n4 + convsplit::kThreads - 1) / convsplit::kThreads)),
+    hipLaunchKernelGGL(convsplit::split_reduce_kernel, dim3((unsigned)((n4 + convsplit::kThreads - 1) / convsplit::kThreads), nph),
                        dim3(convsplit::kThreads), 0, s, a, n4, p.slices);
   }
   LSFA_LAUNCH_CHECK(who);
@@ -465,6 +468,41 @@ extern "C" size_t lsfa_conv_split_workspace_bytes(int N, int H, int W, int Cin, 
   if (Ho <= 0 || Wo <= 0) return 0;
   const SplitPlan p = split_plan(N, H, W, Cin, Cout, kh, kw, stride, pad, dil);
   return split_workspace(p, (long)N * Ho * Wo, Cout);
+}
+
+// Deconvolution(kernel 4, stride 2, pad 0) + Crop(offset (1,1)) to Hc x Wc as ONE launch of four 2x2-tap phase convolutions.
+// Output row 2m + py of the cropped map reads input rows (m - 1, m) through taps ky = (3, 1) when py = 0 and rows (m, m + 1)
+// through ky = (2, 0) when py = 1 (columns alike): phase (py, px) is an ordinary 2x2 convolution with padding (1 - py, 1 - px)
+// whose weights wfrag[py * 2 + px] the caller cut with lsfa_conv_split_weights from w[:, :, kys, kxs] (Cout, 2, 2, Cin).
+extern "C" size_t lsfa_deconv4x4s2_crop_workspace_bytes(int N, int Hi, int Wi, int Cin, int Cout, int Hc, int Wc) {
+  if (N <= 0 || Hi <= 0 || Wi <= 0 || Cin <= 0 || Cout <= 0 || Hc <= 0 || Wc <= 0) return 0;
+  const int gh = (Hc + 1) / 2, gw = (Wc + 1) / 2;
+  const SplitPlan p = split_plan_general(N, gh, gw, Cin, Cout, 2, 2);
+  return split_workspace(p, (long)N * gh * gw, Cout) * 4;
+}
+
+extern "C" int lsfa_deconv4x4s2_crop_fwd(const float* x, int lda, int N, int Hi, int Wi, int Cin, const void* const* wfrag4,
+                                         const float* bias, int Cout, int act, float* y, int ldy, int Hc, int Wc, void* ws,
+                                         size_t ws_bytes, void* stream) {
+  LSFA_REQUIRE(x && wfrag4 && wfrag4[0] && wfrag4[1] && wfrag4[2] && wfrag4[3] && y, "lsfa_deconv4x4s2_crop_fwd: NULL argument");
+  LSFA_REQUIRE(act >= 0 && act <= 2 && Hc > 0 && Wc > 0 && Hc <= 2 * Hi + 1 && Wc <= 2 * Wi + 1, "lsfa_deconv4x4s2_crop_fwd: bad shape");
+  convsplit::Args a = {};
+  a.x = x; a.bias = bias;
+  a.N = N; a.H = Hi; a.W = Wi; a.Cin = Cin; a.Cout = Cout; a.kh = a.kw = 2; a.stride = 1; a.dil = 1;
+  a.act = act; a.lda = lda; a.ldy = ldy;
+  a.view = 1; a.out_H = Hc; a.out_W = Wc; a.out_sy = a.out_sx = 2;
+  a.nphase = 4;
+  for (int py = 0; py < 2; ++py)
+    for (int px = 0; px < 2; ++px) {
+      convsplit::Args::Phase& ph = a.ph[py * 2 + px];
+      ph.wfrag = (const uint4*)wfrag4[py * 2 + px];
+      ph.y = y + ((size_t)py * Wc + px) * (ldy > 0 ? ldy : Cout);
+      ph.pad_h = 1 - py; ph.pad_w = 1 - px;
+      ph.Ho = (Hc - py + 1) / 2; ph.Wo = (Wc - px + 1) / 2;
+    }
+  // the launch is sized for phase (0, 0), the largest grid
+  a.wfrag = a.ph[0].wfrag; a.y = a.ph[0].y; a.pad_h = a.pad_w = 1; a.Ho = a.ph[0].Ho; a.Wo = a.ph[0].Wo;
+  return conv_split_launch(a, ws, ws_bytes, stream, "lsfa_deconv4x4s2_crop_fwd", LSFA_OP_FLOWNET);
 }
 
 extern "C" size_t lsfa_conv_split_view_workspace_bytes(int lda, int N, int H, int W, int Cin, int Cout, int kh, int kw, int stride, int pad_h,

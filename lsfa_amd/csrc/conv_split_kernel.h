@@ -62,7 +62,21 @@ struct Args {
   //         ((n * out_H + oy * out_sy) * out_W + ox * out_sx) * ldy  (the pointer already advanced to the first one):
   //         the four phases of a stride-2 transposed convolution each write every other pixel of the full map.
   int lda, ldy, view, out_H, out_W, out_sy, out_sx;
+  // r3: up to four launches in one (the four output parities of a stride-2 transposed convolution): workgroups are dealt
+  // over (phase, K slice, channel tile, pixel tile); a phase has its own weights, padding, output grid and first output
+  // element; its partial sums start at part + phase * slices * part_stride.  nphase <= 1: a plain launch.
+  int nphase; long part_stride;
+  struct Phase { const uint4* wfrag; float* y; int pad_h, pad_w, Ho, Wo; } ph[4];
 };
+
+// the launch as phase `phase` sees it
+__device__ __forceinline__ void apply_phase(Args& a, int phase, int slices) {
+  if (a.nphase > 1) {
+    a.wfrag = a.ph[phase].wfrag; a.y = a.ph[phase].y;
+    a.pad_h = a.ph[phase].pad_h; a.pad_w = a.ph[phase].pad_w; a.Ho = a.ph[phase].Ho; a.Wo = a.ph[phase].Wo;
+    if (a.part) a.part += (size_t)phase * slices * a.part_stride;
+  }
+}
 
 // the leading 8 mantissa bits of v as an fp32 bit pattern (= a bf16 value), and what is left
 __device__ __forceinline__ uint32_t lead(float v) { return __float_as_uint(v) & 0xFFFF0000u; }
@@ -165,6 +179,7 @@ __device__ __forceinline__ void tile_store_part(float* part, int Cout, const int
 
 // sum of the K slices in slice order (reproducible), then the same tail as tile_store; a float4 of channels per thread
 static __global__ __launch_bounds__(kThreads) void split_reduce_kernel(Args a, long n4, int slices) {
+  if (a.nphase > 1) { apply_phase(a, blockIdx.y, slices); n4 = (long)a.N * a.Ho * a.Wo * a.Cout / 4; }
   const long i = (long)blockIdx.x * kThreads + threadIdx.x;
   if (i >= n4) return;
   const float4* part = reinterpret_cast<const float4*>(a.part);
@@ -311,10 +326,12 @@ __device__ __forceinline__ Tile xcd_tile(int id, int nx, int ny, int nz) {
 // grid (8 * ceil(tiles / 8)); block 256; 56 KB of LDS.  tiles = ceil(P / 128) * (Cout / 64) * slices
 static __global__ __launch_bounds__(kThreads, 2) void conv_split_kernel(Args a, int nx, int ny, int nz) {
   __shared__ __attribute__((aligned(16))) uint4 S[2][kStage];
-  const Tile tile = xcd_tile(blockIdx.x, nx, ny, nz);
+  Tile tile = xcd_tile(blockIdx.x, nx, ny, nz);
   if (tile.x < 0) return;
+  if (a.nphase > 1) { const int slices = nz / a.nphase, phase = tile.z / slices; tile.z -= phase * slices; apply_phase(a, phase, slices); }
   const int tid = threadIdx.x;
   const int P = a.N * a.Ho * a.Wo;
+  if (tile.x * kWgPix >= P) return;          // a phase with a smaller grid than the launch was sized for
   const int taps = a.kh * a.kw;
   Geom g;
   g.lane = tid & 63;
@@ -470,10 +487,12 @@ template <int NT>
 static __global__ __launch_bounds__(kThreads, 2) void conv_split_wide_kernel(Args a, int nx, int ny, int nz) {
   typedef Wide<NT> WD;
   __shared__ __attribute__((aligned(16))) uint4 S[2][WD::kStageN];
-  const Tile tile = xcd_tile(blockIdx.x, nx, ny, nz);
+  Tile tile = xcd_tile(blockIdx.x, nx, ny, nz);
   if (tile.x < 0) return;
+  if (a.nphase > 1) { const int slices = nz / a.nphase, phase = tile.z / slices; tile.z -= phase * slices; apply_phase(a, phase, slices); }
   const int tid = threadIdx.x;
   const int P = a.N * a.Ho * a.Wo;
+  if (tile.x * kWgPix >= P) return;
   const int taps = a.kh * a.kw;
   Geom g;
   g.lane = tid & 63;

@@ -2,9 +2,9 @@
 // on channels-last maps, so that together with lsfa_conv_split_view_fwd the whole network runs without a library call:
 //   flow_conv1 (7x7 / 2, 6 -> 64 channels)   the stem kernel of stem.hip run once per image of the pair (3 channels each), the
 //                                            second pass adding onto the first and applying bias + LeakyReLU: stem.hip
-//   head_conv3x3_kernel    Convolution1..5 (:178, :183, :188, :193, :203): 3x3, pad 1, Cin up to 1026 -> 2 channels.  One wave
-//                          per output pixel, lanes over the input channels (coalesced 256-byte reads), nine taps, a fixed
-//                          shuffle tree: deterministic, a few microseconds (the maps are 5x8 ... 38x63).
+//   head_conv3x3_kernel    Convolution1..5 (:178, :183, :188, :193, :203): 3x3, pad 1, Cin up to 1026 -> 2 channels.  One
+//                          workgroup per output pixel, threads over the input channels (coalesced reads), nine taps, a fixed
+//                          reduction tree: deterministic, a few microseconds (the maps are 5x8 ... 38x63).
 //   upflow_kernel          upsample_flow6to5 ... 3to2 (:180 ...): Deconvolution(kernel 4, stride 2, 2 -> 2 channels) + Crop(offset 1)
 //                          written into the two flow channels of the next concatenated map.
 //   avgpool2_cl_kernel     Pooling(2x2 / 2, avg, pooling_convention='full') on a channels-last map (:201, and the frame pair).
@@ -17,47 +17,57 @@ namespace {
 
 constexpr int kHeadMaxCout = 4;
 
-// grid (ceil(P / 4)); block 256 = 4 waves = 4 output pixels.  x (N, H, W, lda) channels-last, Cin channels used.
+// grid (P); block 256 = 4 waves, ONE output pixel per workgroup: the (tap, channel) products of a pixel are dealt to the 256
+// threads (thread t takes channels t, t + 256, ... of every tap), so that a 9 x 1026-long dot product is 9 x 4 loads deep per
+// thread instead of 9 x 16, all of them independent (unrolled): the first form of this kernel walked taps x channels with
+// one wave and sat at 60 us per call on load latency.  x (N, H, W, lda) channels-last, Cin channels used.
 // w (Cout, 3, 3, Cin); out: NCHW (N, Cout, H, W) when out_nchw, else channels [c0, c0 + Cout) of an (N, H, W, ldy) map.
-// Lane l sums channels l, l + 64, ... over the taps in (ky, kx) order, then the 64 partial sums are added pairwise
-// (xor 32, 16, 8, 4, 2, 1): one fixed tree.
+// Sum order (fixed): per thread channels ascending, taps in (ky, kx) order inside a channel; then the lanes of a wave pairwise (xor 32 ... 1), then
+// the four waves in order.
 __global__ __launch_bounds__(256) void head_conv3x3_kernel(const float* __restrict__ x, int lda, int N, int H, int W, int Cin,
                                                            const float* __restrict__ w, const float* __restrict__ bias, int Cout,
                                                            float mul, float* __restrict__ y, int out_nchw, int ldy, int c0) {
-  const int lane = threadIdx.x & 63;
-  const int p = blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (p >= N * H * W) return;
+  __shared__ float wave_sum[4][kHeadMaxCout];
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int p = blockIdx.x;
   const int n = p / (H * W), r = p - n * H * W, oy = r / W, ox = r - oy * W;
   float acc[kHeadMaxCout];
 #pragma unroll
   for (int o = 0; o < kHeadMaxCout; ++o) acc[o] = 0.f;
-  for (int ky = 0; ky < 3; ++ky) {
-    const int iy = oy - 1 + ky;
-    if (iy < 0 || iy >= H) continue;
-    for (int kx = 0; kx < 3; ++kx) {
-      const int ix = ox - 1 + kx;
-      if (ix < 0 || ix >= W) continue;
-      const float* xp = x + ((size_t)(n * H + iy) * W + ix) * lda;
-      const float* wp = w + (size_t)(ky * 3 + kx) * Cin;
-      for (int c = lane; c < Cin; c += 64) {
-        const float v = xp[c];
+  // taps outside the image contribute zero through a 0 / 1 factor on a clamped (always valid) address instead of a branch:
+  // no load then waits behind a branch, and the unrolled loops keep all of a thread's loads in flight
+  for (int c = tid; c < Cin; c += 256) {
+    float xv[9];
 #pragma unroll
-        for (int o = 0; o < kHeadMaxCout; ++o)
-          if (o < Cout) acc[o] = fmaf(v, wp[(size_t)o * 9 * Cin + c], acc[o]);
-      }
+    for (int tap = 0; tap < 9; ++tap) {
+      const int iy = oy - 1 + tap / 3, ix = ox - 1 + tap % 3;
+      const bool ok = iy >= 0 && iy < H && ix >= 0 && ix < W;
+      const int cy = min(max(iy, 0), H - 1), cx = min(max(ix, 0), W - 1);
+      xv[tap] = x[((size_t)(n * H + cy) * W + cx) * lda + c] * (ok ? 1.f : 0.f);
+    }
+#pragma unroll
+    for (int o = 0; o < kHeadMaxCout; ++o) {
+      if (o >= Cout) break;
+      float wv[9];
+#pragma unroll
+      for (int tap = 0; tap < 9; ++tap) wv[tap] = w[((size_t)o * 9 + tap) * Cin + c];
+#pragma unroll
+      for (int tap = 0; tap < 9; ++tap) acc[o] = fmaf(xv[tap], wv[tap], acc[o]);
     }
   }
 #pragma unroll
   for (int o = 0; o < kHeadMaxCout; ++o) {
-    if (o >= Cout) break;
     float s = acc[o];
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1) s = s + __shfl_xor(s, d, 64);
-    if (lane == 0) {
-      const float v = (s + (bias ? bias[o] : 0.f)) * mul;
-      if (out_nchw) y[((size_t)n * Cout + o) * H * W + r] = v;
-      else y[(size_t)p * ldy + c0 + o] = v;
-    }
+    if (lane == 0) wave_sum[wv][o] = s;
+  }
+  __syncthreads();
+  if (tid < Cout) {
+    const float s = ((wave_sum[0][tid] + wave_sum[1][tid]) + wave_sum[2][tid]) + wave_sum[3][tid];
+    const float v = (s + (bias ? bias[tid] : 0.f)) * mul;
+    if (out_nchw) y[((size_t)n * Cout + tid) * H * W + r] = v;
+    else y[(size_t)p * ldy + c0 + tid] = v;
   }
 }
 
@@ -120,7 +130,7 @@ extern "C" int lsfa_head_conv3x3(const float* x, int lda, int N, int H, int W, i
   LSFA_REQUIRE(out_nchw || (ldy >= c0 + Cout && c0 >= 0), "lsfa_head_conv3x3: channels [%d, %d) do not fit ldy %d", c0, c0 + Cout, ldy);
   const int P = N * H * W;
   ProfScope prof(LSFA_OP_FLOWNET, (hipStream_t)stream);
-  hipLaunchKernelGGL(head_conv3x3_kernel, dim3((unsigned)((P + 3) / 4)), dim3(256), 0, (hipStream_t)stream, x, lda, N, H, W, Cin, w, bias,
+  hipLaunchKernelGGL(head_conv3x3_kernel, dim3((unsigned)P), dim3(256), 0, (hipStream_t)stream, x, lda, N, H, W, Cin, w, bias,
                      Cout, mul, y, out_nchw, ldy, c0);
   LSFA_LAUNCH_CHECK("lsfa_head_conv3x3");
   return LSFA_OK;

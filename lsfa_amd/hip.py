@@ -39,7 +39,8 @@ def lib():
         L.lsfa_last_error.restype = ctypes.c_char_p
         for name in ("lsfa_proposal_workspace_bytes", "lsfa_nms_workspace_bytes", "lsfa_det_workspace_bytes",
                      "lsfa_mv_workspace_bytes", "lsfa_conv_nhwc_workspace_bytes", "lsfa_conv_split_weight_bytes",
-                     "lsfa_conv_split_workspace_bytes", "lsfa_conv_split_view_workspace_bytes"):
+                     "lsfa_conv_split_workspace_bytes", "lsfa_conv_split_view_workspace_bytes",
+                     "lsfa_deconv4x4s2_crop_workspace_bytes"):
             getattr(L, name).restype = ctypes.c_size_t
         L.lsfa_op_name.restype = ctypes.c_char_p
         L._nms.restype = None
@@ -615,6 +616,28 @@ def conv_split_view(x, sw, bias, out, stride=1, pad=(0, 0), dil=1, act=0, cin=No
                                           _ci(kh), _ci(kw), _ci(stride), _ci(pad[0]), _ci(pad[1]), _ci(dil), _ci(act), _vp(first),
                                           _ci(Lout), _ci(Ho), _ci(Wo), _ci(Hout if view or (Ho, Wo) != (Hout, Wout) else 0), _ci(Wout),
                                           _ci(sy), _ci(sx), _ptr(ws), ctypes.c_size_t(need), _stream()), "lsfa_conv_split_view_fwd")
+    return out
+
+
+@_on_tensor_device
+def deconv4x4s2_crop(x, sw4, bias, out, c0=0, act=0):
+    """lsfa_deconv4x4s2_crop_fwd: Deconvolution(4x4, stride 2) + Crop(offset 1) + bias + activation as one launch.
+    x (N, Hi, Wi, L) channels-last (the weights' Cin channels read, L >= Cin); sw4: four SplitWeight of the (Cout, Cin, 2, 2) phase
+    weights in (py, px) order (see the header); the result fills channels [c0, c0 + Cout) of out (N, Hc, Wc, Lout)."""
+    x = _f32c(x, "x")
+    N, Hi, Wi, L = x.shape
+    cin, cout = sw4[0].cin, sw4[0].cout
+    if len(sw4) != 4 or any((s.cin, s.cout, s.kh, s.kw) != (cin, cout, 2, 2) for s in sw4) or cin > L:
+        raise LsfaError("deconv4x4s2_crop: four (Cout, Cin, 2, 2) phase weights with Cin <= %d expected" % L)
+    if not (out.is_contiguous() and out.dtype == torch.float32 and out.dim() == 4) or c0 + cout > out.shape[3] or out.shape[0] != N:
+        raise LsfaError("deconv4x4s2_crop: bad out %s for channels [%d, %d)" % (tuple(out.shape), c0, c0 + cout))
+    Hc, Wc, Lout = out.shape[1], out.shape[2], out.shape[3]
+    need = lib().lsfa_deconv4x4s2_crop_workspace_bytes(_ci(N), _ci(Hi), _ci(Wi), _ci(cin), _ci(cout), _ci(Hc), _ci(Wc))
+    ws = torch.empty(need, dtype=torch.uint8, device=x.device)
+    frags = (ctypes.c_void_p * 4)(*[s.frag.data_ptr() for s in sw4])
+    _check(lib().lsfa_deconv4x4s2_crop_fwd(_ptr(x), _ci(L), _ci(N), _ci(Hi), _ci(Wi), _ci(cin), frags, _ptr(bias), _ci(cout), _ci(act),
+                                           _vp(out.data_ptr() + 4 * c0), _ci(Lout), _ci(Hc), _ci(Wc), _ptr(ws), ctypes.c_size_t(need),
+                                           _stream()), "lsfa_deconv4x4s2_crop_fwd")
     return out
 
 

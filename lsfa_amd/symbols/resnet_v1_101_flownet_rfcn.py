@@ -690,11 +690,7 @@ class Executor(object):
             return hip.conv_split_view(x, sw, fw[name + '_bias'], out, stride=stride, pad=(pad, pad), act=LEAKY, cin=cin, c0=c0)
 
         def deconv(x, name, out, c0):
-            hc, wc = out.shape[1], out.shape[2]
-            for py in (0, 1):
-                for px in (0, 1):
-                    hip.conv_split_view(x, o[(name, py, px)], fw[name + '_bias'], out, stride=1, pad=(1 - py, 1 - px), act=LEAKY,
-                                        c0=c0, grid=((hc - py + 1) // 2, (wc - px + 1) // 2), place=(py, px, 2, 2))
+            hip.deconv4x4s2_crop(x, [o[(name, py, px)] for py in (0, 1) for px in (0, 1)], fw[name + '_bias'], out, c0=c0, act=LEAKY)
 
         def head(x, name, cin):
             return hip.head_conv3x3(x, o[name], fw[name + '_bias'], cin=cin)

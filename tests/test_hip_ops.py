@@ -967,6 +967,30 @@ def test_conv_split_views_and_transposed_convolution_phases(hip):
     got = out[..., c0:c0 + Cout].double()
     assert float((got - ref).abs().max()) < 2e-6 * (Cin * 4) ** 0.5 * float(ref.abs().max())
     assert bool((out[..., :c0] == -3.0).all()) and bool((out[..., c0 + Cout:] == -3.0).all())
+    # the same as ONE launch (lsfa_deconv4x4s2_crop_fwd): identical bits, and on FlowNet's own shapes (odd crops, K long enough
+    # for the 128-channel workgroup tiles and for K slices)
+    for (Cin, Cout, Hi, Wi, Hc, Wc, Lout, c0) in ((96, 128, 10, 16, 19, 32, 416, 256), (1056, 256, 10, 16, 19, 32, 800, 512),
+                                                   (1024, 512, 5, 8, 10, 16, 1056, 512), (416, 64, 38, 63, 75, 125, 224, 128)):
+        x = torch.randn(1, Hi, Wi, Cin, device=dev)
+        wt = torch.randn(Cin, Cout, 4, 4, device=dev) * (1.0 / (4 * Cin) ** 0.5)
+        b = torch.randn(Cout, device=dev)
+        sws = []
+        for py in (0, 1):
+            for px in (0, 1):
+                kys, kxs = ((3, 1) if py == 0 else (2, 0)), ((3, 1) if px == 0 else (2, 0))
+                sws.append(hip.SplitWeight(wt[:, :, kys, :][:, :, :, kxs].permute(1, 0, 2, 3).contiguous()))
+        one = torch.full((1, Hc, Wc, Lout), 5.0, device=dev)
+        hip.deconv4x4s2_crop(x, sws, b, one, c0=c0, act=2)
+        four = torch.full((1, Hc, Wc, Lout), 5.0, device=dev)
+        for py in (0, 1):
+            for px in (0, 1):
+                hip.conv_split_view(x, sws[py * 2 + px], b, four, stride=1, pad=(1 - py, 1 - px), act=2, c0=c0,
+                                    grid=((Hc - py + 1) // 2, (Wc - px + 1) // 2), place=(py, px, 2, 2))
+        full = F.leaky_relu(F.conv_transpose2d(x.permute(0, 3, 1, 2).double(), wt.double(), b.double(), stride=2), 0.1)
+        ref = full[:, :, 1:1 + Hc, 1:1 + Wc].permute(0, 2, 3, 1)
+        assert float((one[..., c0:c0 + Cout].double() - ref).abs().max()) < 2e-6 * (Cin * 4) ** 0.5 * float(ref.abs().max())
+        assert bool((one[..., :c0] == 5.0).all()) and bool((one[..., c0 + Cout:] == 5.0).all())
+        assert torch.equal(one, four)
 
 
 def test_proposal_and_nms_do_not_depend_on_workspace_contents(hip):

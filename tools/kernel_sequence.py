@@ -1,0 +1,33 @@
+#!/usr/bin/env python
+"""For a rocprofv3 kernel trace of a script that repeats ONE launch sequence n times (tools/backbone_only.py): the kernels of one
+steady-state repetition in launch order with their durations averaged over the last repetitions.
+usage: kernel_sequence.py <trace_dir> <repetitions>"""
+import csv
+import glob
+import os
+import sys
+
+
+def main():
+    d, n = sys.argv[1], int(sys.argv[2])
+    f = [p for p in glob.glob(os.path.join(d, '**', '*kernel_trace.csv'), recursive=True)][0]
+    rows = sorted(csv.DictReader(open(f)), key=lambda r: int(r['Start_Timestamp']))
+    names = [r['Kernel_Name'] for r in rows]
+    # the period of the steady state: the shortest p with the last p names equal to the p before them (the first repetition
+    # also runs one-off preparation kernels, so len(rows) / n is not it)
+    per = next(p for p in range(max(1, len(rows) // (2 * n)), len(rows) // 2) if names[-p:] == names[-2 * p:-p])
+    reps = max(1, min(n // 2, len(rows) // per - 1))
+    tail = rows[len(rows) - per * reps:]
+    tot = 0.0
+    for i in range(per):
+        name = tail[i]['Kernel_Name']
+        dur = sum((int(tail[k * per + i]['End_Timestamp']) - int(tail[k * per + i]['Start_Timestamp'])) for k in range(reps)) / reps / 1e3
+        same = all(tail[k * per + i]['Kernel_Name'] == name for k in range(reps))
+        tot += dur
+        short = name.replace('(anonymous namespace)::', '').replace('lsfa::convsplit::', '').replace('void ', '').split('(')[0][:60]
+        print('%3d %-62s %8.1f us  grid %s%s' % (i, short, dur, tail[i].get('Grid_Size', '?'), '' if same else '  (sequence differs between repetitions)'))
+    print('sum of kernel durations: %.1f us over %d kernels (%d repetitions averaged)' % (tot, per, reps))
+
+
+if __name__ == '__main__':
+    main()

@@ -258,7 +258,8 @@ int lsfa_conv_nhwc_fused_fwd(const float* x, int N, int H, int W, int Cin, const
  * — the layout the reference's operators (and lsfa_warp_bilinear's `add` operand) take — instead of (N, Ho, Wo, Cout); x is
  * always channels-last.  Arguments otherwise as lsfa_conv_nhwc_fused_fwd. */
 /* measurement switch (tools/lab/conv_split_lab.py): 0 = the launch plan decides (default), 1 = 128 x 64 workgroup tiles only
- * (the r2 kernel), 2 = 128 x 128 tiles wherever Cout % 128 == 0.  Same results bit for bit: the k order per output is the same. */
+ * and the 2-stage ring (the r2 kernel), 2 = 128 x 128 tiles wherever Cout % 128 == 0, 3 = as 0 without the 4-stage ring.  The k order
+ * per output is the same in every variant; results differ only where the number of K slices does. */
 int lsfa_conv_split_set_variant(int variant);
 size_t lsfa_conv_split_weight_bytes(int Cout, int kh, int kw, int Cin);
 int lsfa_conv_split_weights(const float* w, int Cout, int kh, int kw, int Cin, void* wfrag, void* stream);
@@ -280,10 +281,11 @@ int lsfa_conv_split_fwd(const float* x, int N, int H, int W, int Cin, const void
  * workspace: lsfa_conv_split_view_workspace_bytes of the same arguments (Ho, Wo = 0: the convolution's own output grid). */
 /* Deconvolution(kernel 4, stride 2) + Crop(offset (1,1)) to Hc x Wc (+ bias + activation) as ONE launch of the four phase
  * convolutions above (resnet_v1_101_flownet_rfcn.py:170-176 `deconv5` ... `deconv2`): x (N, Hi, Wi, lda) with Cin channels used,
- * wfrag4[py*2 + px] = lsfa_conv_split_weights of the (Cout, 2, 2, Cin) weight w[:, :, kys, kxs] transposed to (out, in, ky, kx),
- * kys = (3, 1) for py = 0 and (2, 0) for py = 1 (kxs alike); y points at channel c0 of pixel (0, 0) of the (N, Hc, Wc, ldy) map. */
+ * wfrag4 = four consecutive blocks of lsfa_conv_split_weight_bytes(Cout, 2, 2, Cin) bytes, block py*2 + px =
+ * lsfa_conv_split_weights of the (Cout, 2, 2, Cin) weight w[:, :, kys, kxs] transposed to (out, in, ky, kx), kys = (3, 1) for py = 0
+ * and (2, 0) for py = 1 (kxs alike); y points at channel c0 of pixel (0, 0) of the (N, Hc, Wc, ldy) map. */
 size_t lsfa_deconv4x4s2_crop_workspace_bytes(int N, int Hi, int Wi, int Cin, int Cout, int Hc, int Wc);
-int lsfa_deconv4x4s2_crop_fwd(const float* x, int lda, int N, int Hi, int Wi, int Cin, const void* const* wfrag4,
+int lsfa_deconv4x4s2_crop_fwd(const float* x, int lda, int N, int Hi, int Wi, int Cin, const void* wfrag4,
                               const float* bias, int Cout, int act, float* y, int ldy, int Hc, int Wc, void* ws,
                               size_t ws_bytes, void* stream);
 size_t lsfa_conv_split_view_workspace_bytes(int lda, int N, int H, int W, int Cin, int Cout, int kh, int kw, int stride, int pad_h,

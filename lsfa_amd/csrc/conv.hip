@@ -267,6 +267,7 @@ namespace {
 // how a split convolution is launched: which kernel, the tile grid, how K is cut
 struct SplitPlan {
   int nt;               // general kernel: 32-channel column tiles per wave (2: conv_split_kernel, 4: conv_split_wide_kernel<4>)
+  bool deep;            // general kernel, nt == 2: the four-stage ring (conv_split_deep_kernel), one workgroup per CU
   bool halo;            // the 3x3 halo kernel (stride 1, pad = dilation 1 or 2), else the general one
   int dil;
   int patches_x, patches_y;
@@ -276,7 +277,8 @@ struct SplitPlan {
   int max_pieces;       // ... and the most workgroups that can share one tile
 };
 
-// lab switch (lsfa_conv_split_set_variant): 0 = plan decides, 1 = 64-channel workgroup tiles only, 2 = 128-channel tiles wherever Cout allows
+// lab switch (lsfa_conv_split_set_variant): 0 = plan decides, 1 = the r2 kernel only (128 x 64 tiles, 2-stage ring), 2 = 128-channel tiles
+// wherever Cout allows, 3 = plan decides but without the 4-stage ring
 std::atomic<int> g_split_variant{0};
 
 SplitPlan split_plan(int N, int H, int W, int Cin, int Cout, int kh, int kw, int stride, int pad, int dil) {
@@ -300,6 +302,8 @@ SplitPlan split_plan(int N, int H, int W, int Cin, int Cout, int kh, int kw, int
     // measured (tools/lab/conv_split_lab.py): the halo form wins where its patches alone fill the chip (res2 conv2 30.7 vs
     // 34.6 us, the 256 -> 1024 fuse convolution 91 vs 106); where K must be cut anyway the general kernel's finer cut
     // (it slices taps x chunks) keeps more CUs busy (res4 conv2 32.7 vs 35.4, res3 conv2 31.4 vs 34.8)
+    // (r3, tried: the small net's 64 -> 64 convolutions as 20 unsliced halo workgroups of 18 tap steps: 22-25 us against 16.5 + 8.4
+    // for the sliced general tiles + reduce pass — a step is ~1.2 us of DMA latency when a workgroup has its CU to itself)
     if (p.slices > 1) p.halo = false;
     // balanced mode: fewer than 512 tiles but more than 512 (tile, chunk) units -> equal unit counts per workgroup
     // (fuse_reduce_add: 320 tiles x 8 chunks = 512 workgroups x 5 instead of one round of 320 x 8)
@@ -326,15 +330,25 @@ SplitPlan split_plan(int N, int H, int W, int Cin, int Cout, int kh, int kw, int
     const double out_mb = (double)P * Cout * 4.0 / 1e6;
     double best = 0;
     int best_s = 1;
-    for (int s = 1; s <= 16; ++s) {
-      if (s > 1 && chunk_total / s < 8) break;
-      const int per = (chunk_total + s - 1) / s;
-      const int used = (chunk_total + per - 1) / per;
-      if (used != s) continue;
-      const long rounds = (wgs * s + 511) / 512;
-      const double t = (double)rounds * per * chunk_us + (s > 1 ? 3.0 + s * out_mb * 2.0 / 3.0 : 0.0);
-      if (s == 1 || t < best * 0.97) { best = t; best_s = s; }      // a more finely cut K must pay for itself
+    bool best_deep = false;
+    // two ways to run a grid: two 2-stage workgroups per CU (512 slots; a chunk ~1.2 us each, the two overlapping) or one 4-stage
+    // workgroup per CU (256 slots; ~0.95 us per chunk: three chunks in flight hide the DMA latency, what is left is one wave per
+    // SIMD issuing 7 DMAs + ~110 cut instructions + 24 MFMAs).  The ring pays on grids that cannot fill 512 slots whichever way K
+    // is cut (res4 conv1: 24.3 -> 20.9 us); measured per shape in profiles/r3/conv_split_lab.txt
+    for (int deep = 0; deep <= ((p.nt == 2 && variant != 1 && variant != 3) ? 1 : 0); ++deep) {
+      const double per_chunk = deep ? 0.95 : chunk_us;
+      const long slots = deep ? 256 : 512;
+      for (int s = 1; s <= 16; ++s) {
+        if (s > 1 && chunk_total / s < (deep ? 6 : 8)) break;
+        const int per = (chunk_total + s - 1) / s;
+        const int used = (chunk_total + per - 1) / per;
+        if (used != s) continue;
+        const long rounds = (wgs * s + slots - 1) / slots;
+        const double t = (double)rounds * per * per_chunk + (deep ? 1.5 : 0.0) + (s > 1 ? 3.0 + s * out_mb * 2.0 / 3.0 : 0.0);
+        if ((s == 1 && deep == 0) || t < best * 0.97) { best = t; best_s = s; best_deep = deep != 0; }      // a finer cut must pay for itself
+      }
     }
+    p.deep = best_deep;
     p.per_slice = (chunk_total + best_s - 1) / best_s;
     p.slices = (chunk_total + p.per_slice - 1) / p.per_slice;
   }
@@ -367,7 +381,7 @@ size_t split_workspace(const SplitPlan& p, long P, int Cout) {
 }  // namespace
 
 extern "C" int lsfa_conv_split_set_variant(int variant) {
-  LSFA_REQUIRE(variant >= 0 && variant <= 2, "lsfa_conv_split_set_variant: unknown variant %d", variant);
+  LSFA_REQUIRE(variant >= 0 && variant <= 3, "lsfa_conv_split_set_variant: unknown variant %d", variant);
   g_split_variant.store(variant);
   return LSFA_OK;
 }
@@ -446,6 +460,8 @@ int conv_split_launch(convsplit::Args a, void* ws, size_t ws_bytes, void* stream
     hipLaunchKernelGGL(convsplit::conv_split3x3_kernel<2>, grid, dim3(convsplit::kThreads), 0, s, a, p.patches_x, p.patches_y, p.nx, p.ny, p.slices);
   else if (p.nt == 4)
     hipLaunchKernelGGL(convsplit::conv_split_wide_kernel<4>, grid, dim3(convsplit::kThreads), 0, s, a, p.nx, p.ny, p.slices * nph);
+  else if (p.deep)
+    hipLaunchKernelGGL(convsplit::conv_split_deep_kernel, grid, dim3(convsplit::kThreads), 0, s, a, p.nx, p.ny, p.slices * nph);
   else
     hipLaunchKernelGGL(convsplit::conv_split_kernel, grid, dim3(convsplit::kThreads), 0, s, a, p.nx, p.ny, p.slices * nph);
   if (p.units_per_wg > 0) {
@@ -481,27 +497,20 @@ extern "C" size_t lsfa_deconv4x4s2_crop_workspace_bytes(int N, int Hi, int Wi, i
   return split_workspace(p, (long)N * gh * gw, Cout) * 4;
 }
 
-extern "C" int lsfa_deconv4x4s2_crop_fwd(const float* x, int lda, int N, int Hi, int Wi, int Cin, const void* const* wfrag4,
+extern "C" int lsfa_deconv4x4s2_crop_fwd(const float* x, int lda, int N, int Hi, int Wi, int Cin, const void* wfrag4,
                                          const float* bias, int Cout, int act, float* y, int ldy, int Hc, int Wc, void* ws,
                                          size_t ws_bytes, void* stream) {
-  LSFA_REQUIRE(x && wfrag4 && wfrag4[0] && wfrag4[1] && wfrag4[2] && wfrag4[3] && y, "lsfa_deconv4x4s2_crop_fwd: NULL argument");
+  LSFA_REQUIRE(x && wfrag4 && y, "lsfa_deconv4x4s2_crop_fwd: NULL argument");
   LSFA_REQUIRE(act >= 0 && act <= 2 && Hc > 0 && Wc > 0 && Hc <= 2 * Hi + 1 && Wc <= 2 * Wi + 1, "lsfa_deconv4x4s2_crop_fwd: bad shape");
   convsplit::Args a = {};
-  a.x = x; a.bias = bias;
+  a.x = x; a.bias = bias; a.wfrag = (const uint4*)wfrag4; a.y = y;
   a.N = N; a.H = Hi; a.W = Wi; a.Cin = Cin; a.Cout = Cout; a.kh = a.kw = 2; a.stride = 1; a.dil = 1;
   a.act = act; a.lda = lda; a.ldy = ldy;
   a.view = 1; a.out_H = Hc; a.out_W = Wc; a.out_sy = a.out_sx = 2;
   a.nphase = 4;
-  for (int py = 0; py < 2; ++py)
-    for (int px = 0; px < 2; ++px) {
-      convsplit::Args::Phase& ph = a.ph[py * 2 + px];
-      ph.wfrag = (const uint4*)wfrag4[py * 2 + px];
-      ph.y = y + ((size_t)py * Wc + px) * (ldy > 0 ? ldy : Cout);
-      ph.pad_h = 1 - py; ph.pad_w = 1 - px;
-      ph.Ho = (Hc - py + 1) / 2; ph.Wo = (Wc - px + 1) / 2;
-    }
+  a.ph_wstride = (long)(lsfa_conv_split_weight_bytes(Cout, 2, 2, Cin) / 16);
   // the launch is sized for phase (0, 0), the largest grid
-  a.wfrag = a.ph[0].wfrag; a.y = a.ph[0].y; a.pad_h = a.pad_w = 1; a.Ho = a.ph[0].Ho; a.Wo = a.ph[0].Wo;
+  a.pad_h = a.pad_w = 1; a.Ho = (Hc + 1) / 2; a.Wo = (Wc + 1) / 2;
   return conv_split_launch(a, ws, ws_bytes, stream, "lsfa_deconv4x4s2_crop_fwd", LSFA_OP_FLOWNET);
 }
 

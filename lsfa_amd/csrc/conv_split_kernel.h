@@ -65,15 +65,21 @@ struct Args {
   // r3: up to four launches in one (the four output parities of a stride-2 transposed convolution): workgroups are dealt
   // over (phase, K slice, channel tile, pixel tile); a phase has its own weights, padding, output grid and first output
   // element; its partial sums start at part + phase * slices * part_stride.  nphase <= 1: a plain launch.
-  int nphase; long part_stride;
-  struct Phase { const uint4* wfrag; float* y; int pad_h, pad_w, Ho, Wo; } ph[4];
+  // nphase == 4: the launch is a Deconvolution(4x4, stride 2) + Crop(1) to out_H x out_W: phase = py * 2 + px has padding
+  // (1 - py, 1 - px), output grid ((out_H - py + 1) / 2, (out_W - px + 1) / 2), first output pixel (py, px), and its weights
+  // ph_wstride uint4 behind the previous phase's (everything a phase needs follows from (py, px): a table in the argument
+  // struct would be indexed dynamically, which makes hipcc keep the struct in scratch)
+  int nphase; long part_stride; long ph_wstride;
 };
 
 // the launch as phase `phase` sees it
 __device__ __forceinline__ void apply_phase(Args& a, int phase, int slices) {
   if (a.nphase > 1) {
-    a.wfrag = a.ph[phase].wfrag; a.y = a.ph[phase].y;
-    a.pad_h = a.ph[phase].pad_h; a.pad_w = a.ph[phase].pad_w; a.Ho = a.ph[phase].Ho; a.Wo = a.ph[phase].Wo;
+    const int py = phase >> 1, px = phase & 1;
+    a.wfrag += (size_t)phase * a.ph_wstride;
+    a.y += ((size_t)py * a.out_W + px) * a.ldy;
+    a.pad_h = 1 - py; a.pad_w = 1 - px;
+    a.Ho = (a.out_H - py + 1) / 2; a.Wo = (a.out_W - px + 1) / 2;
     if (a.part) a.part += (size_t)phase * slices * a.part_stride;
   }
 }
@@ -388,6 +394,148 @@ static __global__ __launch_bounds__(kThreads, 2) void conv_split_kernel(Args a, 
   }
 
   // C/D layout of 32x32: column = lane & 31 (channel), row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5) (pixel)
+  const int lane = g.lane;
+  int prow[16];
+  RowOut ro;
+  ro.valid = 0;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    prow[r] = m0 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+    if (prow[r] < P) ro.valid |= 1u << r;
+  }
+  if (a.part) {
+    float* part = a.part + (size_t)tile.z * P * a.Cout;
+    tile_store_part(part, a.Cout, prow, ro.valid, tile.y * kWgCh + (lane & 31), acc0);
+    tile_store_part(part, a.Cout, prow, ro.valid, tile.y * kWgCh + 32 + (lane & 31), acc1);
+    return;
+  }
+#pragma unroll
+  for (int r = 0; r < 16; ++r) ro.base[r] = ((ro.valid >> r) & 1u) ? out_pixel_base(a, prow[r]) : 0;
+  tile_store(a, ro, tile.y * kWgCh + (lane & 31), acc0);
+  tile_store(a, ro, tile.y * kWgCh + 32 + (lane & 31), acc1);
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// r3: the same kernel with a DEEP ring.  A chunk is 24 MFMAs per wave (~0.35 us) but its 28 KB take ~1 us to arrive; with one
+// chunk in flight a step therefore costs ~1.2 us unless a second workgroup on the CU fills the gap — which only happens on
+// grids of more than ~256 workgroups.  Most launches of this network are smaller (a res4 conv1 is 228 workgroups, FlowNet's
+// late layers a few dozen): for those the ring has kDeep = 4 stages (112 KB, one workgroup per CU) and three chunks in
+// flight.  Per step: wait until all but the two youngest chunks' DMAs of this wave have landed (counted vmcnt: DMAs retire in
+// issue order), barrier (every wave's share of chunk c is there, and everybody is done reading chunk c-1's stage), issue
+// chunk c+3 into that stage, compute chunk c.  One barrier per chunk; all stage offsets are compile-time (the loop is unrolled
+// over the four stages).  Bit-identical results to conv_split_kernel for the same K cut.
+constexpr int kDeep = 4;
+
+template <int ST>
+__device__ __forceinline__ void deep_issue(uint4 (*S)[kStage], const float* __restrict__ x, const uint4* __restrict__ wblock, const Geom& g,
+                                           const Walk& wk) {
+  const int gch = wk.gch, kc = wk.kc;
+  const int dy = wk.ty * g.dil, dx = wk.tx * g.dil;
+  const int doff = (dy * g.W + dx) * g.lda + kc * kChunk;
+  uint4* a_dst = &S[ST][g.wave * 256];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const bool ok = (unsigned)(g.iy0[i] + dy) < (unsigned)g.H && (unsigned)(g.ix0[i] + dx) < (unsigned)g.W;
+    const float* src = ok ? x + (g.off0[i] + doff) : g_zero_block;
+    __builtin_amdgcn_global_load_lds(reinterpret_cast<const uint4*>(src), a_dst + i * 64, 16, 0, 0);
+  }
+  const uint4* wsrc = wblock + (size_t)gch * g.wstride + g.wave * 192 + g.lane;
+  uint4* b_dst = &S[ST][kStageA + g.wave * 192];
+#pragma unroll
+  for (int i = 0; i < 3; ++i) __builtin_amdgcn_global_load_lds(wsrc + i * 64, b_dst + i * 64, 16, 0, 0);
+}
+
+template <int ST>
+__device__ __forceinline__ void deep_consume(uint4 (*S)[kStage], const Geom& g, f32x16& acc0, f32x16& acc1) {
+  const uint4* A = &S[ST][g.wave * 256];
+  const uint4* B = &S[ST][kStageA + g.lane];
+  const uint4 r0 = A[g.frag[0]], r1 = A[g.frag[1]], r2 = A[g.frag[2]], r3 = A[g.frag[3]];
+  const float4 c0 = make_float4(__uint_as_float(r0.x), __uint_as_float(r0.y), __uint_as_float(r0.z), __uint_as_float(r0.w));
+  const float4 c1 = make_float4(__uint_as_float(r1.x), __uint_as_float(r1.y), __uint_as_float(r1.z), __uint_as_float(r1.w));
+  const float4 c2 = make_float4(__uint_as_float(r2.x), __uint_as_float(r2.y), __uint_as_float(r2.z), __uint_as_float(r2.w));
+  const float4 c3 = make_float4(__uint_as_float(r3.x), __uint_as_float(r3.y), __uint_as_float(r3.z), __uint_as_float(r3.w));
+  const Pieces s0 = split8(c0, c1), s1 = split8(c2, c3);
+  acc0 = mma6(s0, B[(0 * 3 + 0) * 64], B[(0 * 3 + 1) * 64], B[(0 * 3 + 2) * 64], acc0);
+  acc1 = mma6(s0, B[(2 * 3 + 0) * 64], B[(2 * 3 + 1) * 64], B[(2 * 3 + 2) * 64], acc1);
+  acc0 = mma6(s1, B[(1 * 3 + 0) * 64], B[(1 * 3 + 1) * 64], B[(1 * 3 + 2) * 64], acc0);
+  acc1 = mma6(s1, B[(3 * 3 + 0) * 64], B[(3 * 3 + 1) * 64], B[(3 * 3 + 2) * 64], acc1);
+}
+
+// step c (its data in stage ST = c % 4): `ahead` = how many chunks beyond c this wave has already issued (2, fewer at the tail)
+template <int ST>
+__device__ __forceinline__ void deep_step(uint4 (*S)[kStage], const float* __restrict__ x, const uint4* __restrict__ wblock, const Geom& g,
+                                          Walk& wk, int c, int n, f32x16& acc0, f32x16& acc1) {
+  const int ahead = min(n - 1 - c, kDeep - 2);
+  if (ahead >= 2) asm volatile("s_waitcnt vmcnt(14)" ::: "memory");
+  else if (ahead == 1) asm volatile("s_waitcnt vmcnt(7)" ::: "memory");
+  else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  if (c + kDeep - 1 < n) { deep_issue<(ST + kDeep - 1) % kDeep>(S, x, wblock, g, wk); wk.next(g.kw, g.chunks_per_tap); }
+  deep_consume<ST>(S, g, acc0, acc1);
+}
+
+// grid (8 * ceil(tiles / 8)); block 256; 112 KB of LDS.  tiles as conv_split_kernel
+static __global__ __launch_bounds__(kThreads, 1) void conv_split_deep_kernel(Args a, int nx, int ny, int nz) {
+  __shared__ __attribute__((aligned(16))) uint4 S[kDeep][kStage];
+  Tile tile = xcd_tile(blockIdx.x, nx, ny, nz);
+  if (tile.x < 0) return;
+  if (a.nphase > 1) { const int slices = nz / a.nphase, phase = tile.z / slices; tile.z -= phase * slices; apply_phase(a, phase, slices); }
+  const int tid = threadIdx.x;
+  const int P = a.N * a.Ho * a.Wo;
+  if (tile.x * kWgPix >= P) return;
+  const int taps = a.kh * a.kw;
+  Geom g;
+  g.lane = tid & 63;
+  g.wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  g.H = a.H; g.W = a.W; g.Cin = a.Cin; g.lda = a.lda; g.kw = a.kw; g.stride = a.stride; g.dil = a.dil;
+  g.chunks_per_tap = a.Cin / kChunk;
+  const int chunk_total = taps * g.chunks_per_tap;
+  g.chunk0 = tile.z * a.chunks_per_slice;
+  const int nchunks = min(a.chunks_per_slice, chunk_total - g.chunk0);
+  const int col_tiles = a.Cout / 32;
+  g.wstride = (size_t)col_tiles * (kChunkBytesB / 32);
+  const uint4* wblock = a.wfrag + (size_t)(2 * tile.y) * (kChunkBytesB / 32);
+  const int m0 = tile.x * kWgPix + g.wave * kWavePix;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int pix = m0 + 8 * i + (g.lane >> 3);
+    const int piece = (g.lane & 7) ^ ((4 * i + (g.lane >> 4)) & 7);
+    g.iy0[i] = g.ix0[i] = -(1 << 24);
+    g.off0[i] = 0;
+    if (pix < P) {
+      const int pn = pix / (a.Ho * a.Wo), r = pix - pn * a.Ho * a.Wo, py = r / a.Wo, px = r - py * a.Wo;
+      g.iy0[i] = py * a.stride - a.pad_h;
+      g.ix0[i] = px * a.stride - a.pad_w;
+      g.off0[i] = ((pn * a.H + g.iy0[i]) * a.W + g.ix0[i]) * a.lda + 4 * piece;
+    }
+  }
+  {
+    const int r = g.lane & 31, h = g.lane >> 5, sw = (r >> 1) & 7;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) g.frag[j] = r * 8 + ((4 * h + j) ^ sw);
+  }
+  f32x16 acc0, acc1;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) { acc0[i] = 0.f; acc1[i] = 0.f; }
+  Walk wk;
+  wk.gch = g.chunk0;
+  {
+    const int tap = g.chunk0 / g.chunks_per_tap;
+    wk.kc = g.chunk0 - tap * g.chunks_per_tap;
+    wk.ty = tap / a.kw;
+    wk.tx = tap - wk.ty * a.kw;
+  }
+  // prologue: chunks 0, 1, 2 into stages 0, 1, 2
+  if (nchunks > 0) { deep_issue<0>(S, a.x, wblock, g, wk); wk.next(g.kw, g.chunks_per_tap); }
+  if (nchunks > 1) { deep_issue<1>(S, a.x, wblock, g, wk); wk.next(g.kw, g.chunks_per_tap); }
+  if (nchunks > 2) { deep_issue<2>(S, a.x, wblock, g, wk); wk.next(g.kw, g.chunks_per_tap); }
+  for (int c = 0; c < nchunks; c += kDeep) {
+    deep_step<0>(S, a.x, wblock, g, wk, c, nchunks, acc0, acc1);
+    if (c + 1 < nchunks) deep_step<1>(S, a.x, wblock, g, wk, c + 1, nchunks, acc0, acc1);
+    if (c + 2 < nchunks) deep_step<2>(S, a.x, wblock, g, wk, c + 2, nchunks, acc0, acc1);
+    if (c + 3 < nchunks) deep_step<3>(S, a.x, wblock, g, wk, c + 3, nchunks, acc0, acc1);
+  }
   const int lane = g.lane;
   int prow[16];
   RowOut ro;

@@ -540,7 +540,7 @@ class SplitWeight(object):
     """A convolution weight cut into three bf16 pieces per value and laid out in MFMA fragment order
     (lsfa_conv_split_weights); made once per layer at bind time."""
 
-    def __init__(self, weight, real_cout=None, real_cin=None):
+    def __init__(self, weight, real_cout=None, real_cin=None, into=None):
         """weight: (Cout, Cin, kh, kw) float32 CUDA tensor (the framework's layout).  real_cout / real_cin: the layer's own
         channel counts when `weight` was zero-padded to the kernel's tile sizes (algorithmic FLOPs are counted on those)."""
         w_kc = _f32c(conv_weight_kc(weight), "weight")
@@ -549,7 +549,9 @@ class SplitWeight(object):
         need = lib().lsfa_conv_split_weight_bytes(_ci(self.cout), _ci(self.kh), _ci(self.kw), _ci(self.cin))
         if need == 0:
             raise LsfaError("SplitWeight: Cin=%d must be a multiple of 32 and Cout=%d of 64" % (self.cin, self.cout))
-        self.frag = torch.empty(need, dtype=torch.uint8, device=weight.device)
+        self.frag = torch.empty(need, dtype=torch.uint8, device=weight.device) if into is None else into
+        if self.frag.numel() != need or not self.frag.is_contiguous():
+            raise LsfaError("SplitWeight: `into` must be a contiguous uint8 tensor of %d bytes" % need)
         with torch.cuda.device(weight.device):
             _check(lib().lsfa_conv_split_weights(_ptr(w_kc), _ci(self.cout), _ci(self.kh), _ci(self.kw), _ci(self.cin),
                                                  _ptr(self.frag), _stream()), "lsfa_conv_split_weights")
@@ -619,6 +621,31 @@ def conv_split_view(x, sw, bias, out, stride=1, pad=(0, 0), dil=1, act=0, cin=No
     return out
 
 
+class PhaseWeights(list):
+    """The four phase weights of a Deconvolution(4x4, stride 2) as SplitWeight views of ONE allocation (`frag4`)."""
+
+
+def deconv_phase_weights(wt, cin_pad=None):
+    """wt: MXNet Deconvolution weight (Cin, Cout, 4, 4) -> PhaseWeights for lsfa_deconv4x4s2_crop_fwd (input channels zero-padded to
+    cin_pad).  Output row 2m + py of the cropped map reads input rows (m - 1, m) through taps ky = (3, 1) when py = 0 and rows
+    (m, m + 1) through ky = (2, 0) when py = 1; columns alike."""
+    cin, cout = int(wt.shape[0]), int(wt.shape[1])
+    cpad = int(cin_pad or cin)
+    per = lib().lsfa_conv_split_weight_bytes(_ci(cout), _ci(2), _ci(2), _ci(cpad))
+    if per == 0:
+        raise LsfaError("deconv_phase_weights: Cin=%d must be a multiple of 32 and Cout=%d of 64" % (cpad, cout))
+    frag4 = torch.empty(4 * per, dtype=torch.uint8, device=wt.device)
+    out = PhaseWeights()
+    for py in (0, 1):
+        for px in (0, 1):
+            kys, kxs = ((3, 1) if py == 0 else (2, 0)), ((3, 1) if px == 0 else (2, 0))
+            wp = torch.zeros((cout, cpad, 2, 2), device=wt.device, dtype=torch.float32)
+            wp[:, :cin] = wt[:, :, kys, :][:, :, :, kxs].permute(1, 0, 2, 3)
+            out.append(SplitWeight(wp, real_cin=cin, into=frag4[(py * 2 + px) * per:(py * 2 + px + 1) * per]))
+    out.frag4 = frag4
+    return out
+
+
 @_on_tensor_device
 def deconv4x4s2_crop(x, sw4, bias, out, c0=0, act=0):
     """lsfa_deconv4x4s2_crop_fwd: Deconvolution(4x4, stride 2) + Crop(offset 1) + bias + activation as one launch.
@@ -634,8 +661,10 @@ def deconv4x4s2_crop(x, sw4, bias, out, c0=0, act=0):
     Hc, Wc, Lout = out.shape[1], out.shape[2], out.shape[3]
     need = lib().lsfa_deconv4x4s2_crop_workspace_bytes(_ci(N), _ci(Hi), _ci(Wi), _ci(cin), _ci(cout), _ci(Hc), _ci(Wc))
     ws = torch.empty(need, dtype=torch.uint8, device=x.device)
-    frags = (ctypes.c_void_p * 4)(*[s.frag.data_ptr() for s in sw4])
-    _check(lib().lsfa_deconv4x4s2_crop_fwd(_ptr(x), _ci(L), _ci(N), _ci(Hi), _ci(Wi), _ci(cin), frags, _ptr(bias), _ci(cout), _ci(act),
+    frags = getattr(sw4, 'frag4', None)
+    if frags is None:
+        raise LsfaError("deconv4x4s2_crop: the phase weights must come from hip.deconv_phase_weights (one allocation)")
+    _check(lib().lsfa_deconv4x4s2_crop_fwd(_ptr(x), _ci(L), _ci(N), _ci(Hi), _ci(Wi), _ci(cin), _ptr(frags), _ptr(bias), _ci(cout), _ci(act),
                                            _vp(out.data_ptr() + 4 * c0), _ci(Lout), _ci(Hc), _ci(Wc), _ptr(ws), ctypes.c_size_t(need),
                                            _stream()), "lsfa_deconv4x4s2_crop_fwd")
     return out

@@ -650,15 +650,7 @@ class Executor(object):
             return -(-c // 32) * 32
         for name in ('deconv5', 'deconv4', 'deconv3', 'deconv2'):
             wt = fw[name + '_weight']                                     # (Cin, Cout, 4, 4)
-            cin, cpad = wt.shape[0], pad32(wt.shape[0])
-            for py in (0, 1):
-                for px in (0, 1):
-                    # output row 2m + py of the cropped map reads input rows (m - 1, m) through taps ky = (3, 1) when py = 0
-                    # and rows (m, m + 1) through ky = (2, 0) when py = 1; columns alike
-                    kys, kxs = ((3, 1) if py == 0 else (2, 0)), ((3, 1) if px == 0 else (2, 0))
-                    wp = torch.zeros((wt.shape[1], cpad, 2, 2), device=dev, dtype=torch.float32)
-                    wp[:, :cin] = wt[:, :, kys, :][:, :, :, kxs].permute(1, 0, 2, 3)
-                    own[(name, py, px)] = hip.SplitWeight(wp)
+            own[name] = hip.deconv_phase_weights(wt, cin_pad=pad32(wt.shape[0]))
         ws = fw['Convolution5_scale_weight']                              # (1024, 194, 1, 1)
         wsp = torch.zeros((ws.shape[0], pad32(ws.shape[1]), 1, 1), device=dev, dtype=torch.float32)
         wsp[:, :ws.shape[1]] = ws
@@ -690,7 +682,7 @@ class Executor(object):
             return hip.conv_split_view(x, sw, fw[name + '_bias'], out, stride=stride, pad=(pad, pad), act=LEAKY, cin=cin, c0=c0)
 
         def deconv(x, name, out, c0):
-            hip.deconv4x4s2_crop(x, [o[(name, py, px)] for py in (0, 1) for px in (0, 1)], fw[name + '_bias'], out, c0=c0, act=LEAKY)
+            hip.deconv4x4s2_crop(x, o[name], fw[name + '_bias'], out, c0=c0, act=LEAKY)
 
         def head(x, name, cin):
             return hip.head_conv3x3(x, o[name], fw[name + '_bias'], cin=cin)

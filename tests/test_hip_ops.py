@@ -974,11 +974,7 @@ def test_conv_split_views_and_transposed_convolution_phases(hip):
         x = torch.randn(1, Hi, Wi, Cin, device=dev)
         wt = torch.randn(Cin, Cout, 4, 4, device=dev) * (1.0 / (4 * Cin) ** 0.5)
         b = torch.randn(Cout, device=dev)
-        sws = []
-        for py in (0, 1):
-            for px in (0, 1):
-                kys, kxs = ((3, 1) if py == 0 else (2, 0)), ((3, 1) if px == 0 else (2, 0))
-                sws.append(hip.SplitWeight(wt[:, :, kys, :][:, :, :, kxs].permute(1, 0, 2, 3).contiguous()))
+        sws = hip.deconv_phase_weights(wt)
         one = torch.full((1, Hc, Wc, Lout), 5.0, device=dev)
         hip.deconv4x4s2_crop(x, sws, b, one, c0=c0, act=2)
         four = torch.full((1, Hc, Wc, Lout), 5.0, device=dev)

@@ -150,18 +150,24 @@ def main():
         y_wide = hip.conv_split(x_cl, sw, b, 1, pad, dil)
         e_wide = err(y_wide)
         t_wide = timeit(lambda: hip.conv_split(x_cl, sw, b, 1, pad, dil, out=out), args.iters)
-        hip.lib().lsfa_conv_split_set_variant(1)          # the r2 kernel: 128 x 64 tiles
+        hip.lib().lsfa_conv_split_set_variant(1)          # the r2 kernel: 128 x 64 tiles, 2-stage ring
         t_split = timeit(lambda: hip.conv_split(x_cl, sw, b, 1, pad, dil, out=out), args.iters)
-        hip.lib().lsfa_conv_split_set_variant(0)
+        hip.lib().lsfa_conv_split_set_variant(3)          # the plan without the 4-stage ring
+        t_nodeep = timeit(lambda: hip.conv_split(x_cl, sw, b, 1, pad, dil, out=out), args.iters)
+        hip.lib().lsfa_conv_split_set_variant(0)          # the launch plan as shipped
+        y_plan = hip.conv_split(x_cl, sw, b, 1, pad, dil)
+        e_plan = err(y_plan)
+        t_plan = timeit(lambda: hip.conv_split(x_cl, sw, b, 1, pad, dil, out=out), args.iters)
         t_mfma = timeit(lambda: hip.conv_nhwc(x_cl, wk, b, k, k, 1, pad, dil, out=out), args.iters)
         t_lib = timeit(lambda: F.conv2d(xl, wl, b, 1, pad, dil), args.iters)
         if k == 1:      # what the executor runs for 1x1 convolutions: rows x (Cin, Cout) through hipBLASLt
             rows, wt = x_cl.view(-1, Cin), w.view(Cout, Cin).t().contiguous()
             t_lib = min(t_lib, timeit(lambda: torch.addmm(b, rows, wt), args.iters))
         fl = 2.0 * H * W * Cin * Cout * k * k
-        print("%-36s max err/max|y|: split %.2e (rms %.2e)  wide %.2e  fp32-mfma %.2e (rms %.2e)  library %.2e | us: split %6.1f  wide %6.1f  "
-              "fp32-mfma %6.1f  library %6.1f | split %.0f wide %.0f TFLOP/s" % (name, e_split, rms(y_split), e_wide, e_mfma, rms(y_mfma), e_lib,
-                                                                              t_split, t_wide, t_mfma, t_lib, fl / t_split / 1e6, fl / t_wide / 1e6))
+        print("%-36s max err/max|y|: r2 %.2e (rms %.2e)  wide %.2e  plan %.2e  fp32-mfma %.2e (rms %.2e)  library %.2e | us: r2 kernel %6.1f  "
+              "wide %6.1f  plan w/o deep ring %6.1f  PLAN %6.1f  fp32-mfma %6.1f  library %6.1f | r2 %.0f plan %.0f TFLOP/s" % (
+                  name, e_split, rms(y_split), e_wide, e_plan, e_mfma, rms(y_mfma), e_lib, t_split, t_wide, t_nodeep, t_plan, t_mfma, t_lib,
+                  fl / t_split / 1e6, fl / t_plan / 1e6))
 
 
 if __name__ == "__main__":

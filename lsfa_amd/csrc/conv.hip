@@ -268,6 +268,7 @@ namespace {
 struct SplitPlan {
   int nt;               // general kernel: 32-channel column tiles per wave (2: conv_split_kernel, 4: conv_split_wide_kernel<4>)
   bool deep;            // general kernel, nt == 2: the four-stage ring (conv_split_deep_kernel), one workgroup per CU
+  bool direct;          // conv_split_direct_kernel: operands straight into registers, a wave per 32 x 64 tile, no K slices
   bool halo;            // the 3x3 halo kernel (stride 1, pad = dilation 1 or 2), else the general one
   int dil;
   int patches_x, patches_y;
@@ -454,7 +455,9 @@ int conv_split_launch(convsplit::Args a, void* ws, size_t ws_bytes, void* stream
     tiles = (p.nx * p.ny * (Cin / 32) + p.units_per_wg - 1) / p.units_per_wg;      // workgroups
   }
   const dim3 grid((unsigned)(8 * ((tiles + 7) / 8)));
-  if (p.halo && p.dil == 1)
+  if (p.direct)
+    hipLaunchKernelGGL(convsplit::conv_split_direct_kernel, dim3((unsigned)((P + 31) / 32), Cout / 64), dim3(64 * convsplit::kDirectWaves), 0, s, a);
+  else if (p.halo && p.dil == 1)
     hipLaunchKernelGGL(convsplit::conv_split3x3_kernel<1>, grid, dim3(convsplit::kThreads), 0, s, a, p.patches_x, p.patches_y, p.nx, p.ny, p.slices);
   else if (p.halo)
     hipLaunchKernelGGL(convsplit::conv_split3x3_kernel<2>, grid, dim3(convsplit::kThreads), 0, s, a, p.patches_x, p.patches_y, p.nx, p.ny, p.slices);

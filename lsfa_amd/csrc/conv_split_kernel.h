@@ -977,6 +977,119 @@ static __global__ __launch_bounds__(kThreads, (DIL == 1 ? 2 : 1)) void conv_spli
 #endif
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// r3: the DIRECT form, for convolutions whose weights are small (the small net's units on the 38 x 63 map: 64 -> 64 3x3, 64 / 256 ->
+// 64 and 64 -> 256 1x1: 0.08 - 0.35 GFLOP each, run on EVERY non-key frame).  The tiled kernels above need 128-pixel tiles and K
+// slices (+ a reduce pass) to occupy the chip and then pay ~1 us of DMA latency per chunk: 16 + 8 us for 0.35 GFLOP.  Here a
+// wave owns a 32-pixel x 64-channel output tile and loads its operands straight into registers in fragment shape — A: the lane's
+// pixel, 16 consecutive channels (4 x 16 B); B: 12 fragments of 1 KB, coalesced — with the next chunk's 16 loads in flight while
+// the current one is cut and multiplied; no LDS staging, no barrier in the loop.  The K range (taps x chunks) of a tile is dealt
+// to the kDirectWaves waves of the workgroup in contiguous runs; their accumulators meet in LDS and are added in wave order
+// (reproducible), then the shared epilogue (bias / residual / activation / second output).  Weights are re-read by every pixel
+// tile (75 x 216 KB from L2 for the 3x3): fine for small weights, which is what the launch plan checks.
+constexpr int kDirectWaves = 3;
+
+struct DirectOperands { uint4 a[4]; uint4 b[12]; };
+
+__device__ __forceinline__ void direct_load(DirectOperands& o, const float* __restrict__ x, const uint4* __restrict__ wtile, size_t wstride,
+                                            int gch, int a_off, bool a_ok, int lane) {
+  const uint4* ap = reinterpret_cast<const uint4*>(a_ok ? x + a_off : g_zero_block);
+#pragma unroll
+  for (int j = 0; j < 4; ++j) o.a[j] = a_ok ? ap[j] : make_uint4(0u, 0u, 0u, 0u);
+  const uint4* bp = wtile + (size_t)gch * wstride + lane;
+#pragma unroll
+  for (int j = 0; j < 12; ++j) o.b[j] = bp[j * 64];       // ((t*2 + s)*3 + piece) * 64 + lane, t = 0..1: two column tiles are 768 uint4 in a row
+}
+
+__device__ __forceinline__ void direct_mma(const DirectOperands& o, f32x16& acc0, f32x16& acc1) {
+  const float4 c0 = make_float4(__uint_as_float(o.a[0].x), __uint_as_float(o.a[0].y), __uint_as_float(o.a[0].z), __uint_as_float(o.a[0].w));
+  const float4 c1 = make_float4(__uint_as_float(o.a[1].x), __uint_as_float(o.a[1].y), __uint_as_float(o.a[1].z), __uint_as_float(o.a[1].w));
+  const float4 c2 = make_float4(__uint_as_float(o.a[2].x), __uint_as_float(o.a[2].y), __uint_as_float(o.a[2].z), __uint_as_float(o.a[2].w));
+  const float4 c3 = make_float4(__uint_as_float(o.a[3].x), __uint_as_float(o.a[3].y), __uint_as_float(o.a[3].z), __uint_as_float(o.a[3].w));
+  const Pieces s0 = split8(c0, c1), s1 = split8(c2, c3);
+  acc0 = mma6(s0, o.b[0], o.b[1], o.b[2], acc0);
+  acc1 = mma6(s0, o.b[6], o.b[7], o.b[8], acc1);
+  acc0 = mma6(s1, o.b[3], o.b[4], o.b[5], acc0);
+  acc1 = mma6(s1, o.b[9], o.b[10], o.b[11], acc1);
+}
+
+// grid (ceil(P / 32), Cout / 64); block 64 * kDirectWaves.  stride 1 (the plan's condition); any kh x kw, pads, dilation.
+static __global__ __launch_bounds__(64 * kDirectWaves) void conv_split_direct_kernel(Args a) {
+  __shared__ __attribute__((aligned(16))) float red[kDirectWaves - 1][32 * 64];
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const int P = a.N * a.Ho * a.Wo;
+  const int m0 = blockIdx.x * 32;
+  const int cpt = a.Cin / kChunk, nchunks = a.kh * a.kw * cpt;
+  // this wave's run of the (tap, chunk) list
+  const int c_begin = (nchunks * wave) / kDirectWaves, c_end = (nchunks * (wave + 1)) / kDirectWaves;
+  const int col_tiles = a.Cout / 32;
+  const size_t wstride = (size_t)col_tiles * (kChunkBytesB / 32);
+  const uint4* wtile = a.wfrag + (size_t)(2 * blockIdx.y) * (kChunkBytesB / 32);
+  // the lane's pixel and the 16 channels of a chunk it feeds (fragment role: row = lane & 31, k half = lane >> 5)
+  const int pix = m0 + (lane & 31);
+  const bool pix_ok = pix < P;
+  int iy0 = 0, ix0 = 0, base = 0;
+  if (pix_ok) {
+    const int pn = pix / (a.Ho * a.Wo), r = pix - pn * a.Ho * a.Wo, py = r / a.Wo, px = r - py * a.Wo;
+    iy0 = py * a.stride - a.pad_h; ix0 = px * a.stride - a.pad_w;
+    base = ((pn * a.H + iy0) * a.W + ix0) * a.lda + 16 * (lane >> 5);
+  }
+  f32x16 acc0, acc1;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) { acc0[i] = 0.f; acc1[i] = 0.f; }
+
+  auto operand_of = [&](int gch, int& off, bool& ok) {
+    const int tap = gch / cpt, kc = gch - tap * cpt, ty = tap / a.kw, tx = tap - ty * a.kw;
+    const int dy = ty * a.dil, dx = tx * a.dil;
+    ok = pix_ok && (unsigned)(iy0 + dy) < (unsigned)a.H && (unsigned)(ix0 + dx) < (unsigned)a.W;
+    off = base + (dy * a.W + dx) * a.lda + kc * kChunk;
+  };
+  DirectOperands cur, nxt;
+  if (c_begin < c_end) {
+    int off; bool ok;
+    operand_of(c_begin, off, ok);
+    direct_load(cur, a.x, wtile, wstride, c_begin, off, ok, lane);
+  }
+  for (int c = c_begin; c < c_end; c += 2) {         // two register sets take turns (no copies)
+    if (c + 1 < c_end) {
+      int off; bool ok;
+      operand_of(c + 1, off, ok);
+      direct_load(nxt, a.x, wtile, wstride, c + 1, off, ok, lane);
+    }
+    direct_mma(cur, acc0, acc1);
+    if (c + 1 < c_end) {
+      if (c + 2 < c_end) {
+        int off; bool ok;
+        operand_of(c + 2, off, ok);
+        direct_load(cur, a.x, wtile, wstride, c + 2, off, ok, lane);
+      }
+      direct_mma(nxt, acc0, acc1);
+    }
+  }
+  // the waves' partial sums meet in LDS: [wave - 1][reg][lane] (conflict-free), added in wave order by wave 0
+  if (wave > 0) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { red[wave - 1][r * 64 + lane] = acc0[r]; red[wave - 1][(16 + r) * 64 + lane] = acc1[r]; }
+  }
+  __syncthreads();
+  if (wave > 0) return;
+#pragma unroll
+  for (int w = 0; w < kDirectWaves - 1; ++w)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { acc0[r] = acc0[r] + red[w][r * 64 + lane]; acc1[r] = acc1[r] + red[w][(16 + r) * 64 + lane]; }
+  RowOut ro;
+  ro.valid = 0;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int p = m0 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+    ro.base[r] = 0;
+    if (p < P) { ro.valid |= 1u << r; ro.base[r] = out_pixel_base(a, p); }
+  }
+  tile_store(a, ro, blockIdx.y * kWgCh + (lane & 31), acc0);
+  tile_store(a, ro, blockIdx.y * kWgCh + 32 + (lane & 31), acc1);
+}
+
 // weights (Cout, taps, Cin) fp32 -> fragment order, three bf16 pieces.  One thread per (fragment, lane): 8 values.
 // out index: ((((g * col_tiles + t) * 2 + s) * 3 + piece) * 64 + lane) uint4, g = tap * (Cin/32) + chunk
 static __global__ void split_weights_kernel(const float* __restrict__ w, uint4* __restrict__ out, int Cout, int taps, int Cin) {

@@ -59,3 +59,24 @@ def test_checkpoint_feeds_init_weight(tmp_path):
     assert set(sym.arg_spec) <= set(arg) and set(sym.aux_spec) <= set(aux)
     np.testing.assert_array_equal(arg['small_net_conv0_weight'], small['conv0_weight'])    # copied from the big net
     assert keep('conv0_weight')
+
+
+def test_fixture_written_byte_by_byte_from_the_documented_layout():
+    """tests/golden/mxnet_ndarray_list-0003.params was assembled with struct.pack calls only (make_params_fixture.py), not by
+    this package's writer: V2, V1 and legacy NDArray records, float32 and int32, a record saved from a GPU context, and the
+    `_test` renaming of load_param(process=True) (lib/utils/load_model.py:57-62)."""
+    import os
+    import numpy as np
+    from lsfa_amd.utils.load_model import load_param, load_ndarray_list
+    prefix = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'mxnet_ndarray_list')
+    raw = load_ndarray_list(prefix + '-0003.params')
+    assert list(raw) == ['arg:conv_weight', 'arg:conv_bias', 'arg:rfcn_bbox_weight_test', 'aux:bn_moving_var', 'aux:counter']
+    arg, aux = load_param(prefix, 3, process=True)
+    assert sorted(arg) == ['conv_bias', 'conv_weight', 'rfcn_bbox_weight'] and sorted(aux) == ['bn_moving_var', 'counter']
+    np.testing.assert_array_equal(arg['conv_weight'], (0.5 * np.arange(6, dtype=np.float32)).reshape(2, 3, 1, 1))
+    assert arg['conv_weight'].dtype == np.float32
+    np.testing.assert_array_equal(arg['conv_bias'], np.array([-1, 0, 1], np.float32))
+    np.testing.assert_array_equal(arg['rfcn_bbox_weight'], np.array([[1, 2], [3, 4]], np.float32))
+    np.testing.assert_array_equal(aux['bn_moving_var'], np.ones(4, np.float32))
+    np.testing.assert_array_equal(aux['counter'], np.array([7, -7], np.int32))
+    assert aux['counter'].dtype == np.int32

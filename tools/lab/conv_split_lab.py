@@ -31,6 +31,10 @@ SHAPES = [  # name, H, W, Cin, Cout, k, dil
     ("res5 dcn gemm 1x1 4608->512 @38x63", 38, 63, 4608, 512, 1, 1),
     ("feat 3x3 d6 2048->1024 @38x63", 38, 63, 2048, 1024, 3, 6),
     ("nq conv 1x1 2048->256? @38x63", 38, 63, 2048, 256, 1, 1),
+    ("small conv2 3x3 64->64 @38x63", 38, 63, 64, 64, 3, 1),
+    ("small conv1 1x1 256->64 @38x63", 38, 63, 256, 64, 1, 1),
+    ("small conv3 1x1 64->256 @38x63", 38, 63, 64, 256, 1, 1),
+    ("rpn 1x1 512->64 @38x63", 38, 63, 512, 64, 1, 1),
 ]
 
 

@@ -13,8 +13,11 @@ import torch  # must be imported before the .so so that both share one libamdhip
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "liblsfa_hip.so")
 
+# names of the LSFA_OP_* ids, in id order.  The table is the LIBRARY's (lsfa_op_name) — filled in by lib(); this copy only serves
+# code that runs before the library is loaded and is checked against it there (an out-of-date copy made lsfa_prof_read write one
+# element past the buffers sized by it: r3, after LSFA_OP_FLOWNET was added)
 OP_NAMES = ["psroi_pool", "rfcn_head", "warp_bilinear", "aggregate", "proposal", "nms", "det_postprocess",
-            "deform_im2col", "scale_shift_relu", "conv_nhwc", "stem"]
+            "deform_im2col", "scale_shift_relu", "conv_nhwc", "stem", "flownet_small"]
 
 
 class LsfaError(RuntimeError):
@@ -44,6 +47,15 @@ def lib():
             getattr(L, name).restype = ctypes.c_size_t
         L.lsfa_op_name.restype = ctypes.c_char_p
         L._nms.restype = None
+        names, i = [], 0
+        while True:
+            nm = L.lsfa_op_name(ctypes.c_int(i))
+            if not nm or nm == b"?" or i >= 64:          # "?" is what the library returns past the last id
+                break
+            names.append(nm.decode())
+            i += 1
+        if names != OP_NAMES:
+            OP_NAMES[:] = names              # in place: importers of the list see the library's table
         _lib = L
     return _lib
 

@@ -490,9 +490,9 @@ class FramePipeline(object):
         return [self.s_key] + self.s_lane + ([self.s_flow] if self.s_flow is not None else [])
 
     def close(self):
-        """Release everything the pipeline owns on the device side: drains it, drops the captured graphs of every lane and
-        destroys the streams made for it (core/streams.py new_stream; they are not returned to any pool otherwise, and a
-        process that builds a pipeline per frame shape would accumulate ~10 hipStreams + graph pools each — ADVICE r2)."""
+        """Release what the pipeline owns on the device side: drains it, drops the captured graphs of every lane (with their
+        private memory pools — the bulk of what a process that builds a pipeline per frame shape would accumulate) and
+        hands its streams back to core/streams.py (parked there: see streams._REUSE for why they are not recycled)."""
         self.join()
         torch.cuda.synchronize(self.device)
         for g in self.klanes + self.lanes:

@@ -14,6 +14,13 @@ import torch
 _SPIN = 400000        # device cycles per probe kernel (~0.2 ms)
 _OWNED = []           # hipStream_t handles created here and in use
 _FREE = {}            # device index -> streams handed back by `release`, reused by the next `new_stream`
+import os as _os
+# Reuse is OFF by default: a hipStream that graphs were captured on carries PyTorch's BLAS workspace for (handle, stream); handing it to
+# a later pipeline while library graphs of another pipeline replay made `torch.cuda.synchronize()` never return (two bf16 pipelines in one
+# process, tests/test_graph_gpu.py::test_two_clips_interleaved_on_one_gpu_are_isolated; fine with LSFA_STREAM_REUSE=0, hung with 1).  A
+# released stream is therefore only parked (a few hundred bytes of runtime state); what close() really gives back are the captured graphs
+# and their private memory pools.
+_REUSE = _os.environ.get('LSFA_STREAM_REUSE', '0') == '1'
 
 
 def new_stream(device):
@@ -27,7 +34,7 @@ def new_stream(device):
     from lsfa_amd import hip
     dev = torch.device(device)
     idx = dev.index if dev.index is not None else torch.cuda.current_device()
-    if _FREE.get(idx):
+    if _FREE.get(idx) and _REUSE:
         s = _FREE[idx].pop()
         _OWNED.append(s.cuda_stream)
         return s
@@ -40,10 +47,10 @@ def new_stream(device):
 
 
 def release(stream):
-    """Hand a stream made by new_stream back (it must be idle, and the graphs captured on it dropped).  The handle is kept
-    and reused by the next new_stream instead of being destroyed: PyTorch's caching allocator may still hold blocks that were
-    `record_stream`ed on it and records an event on that stream when they are freed — on a destroyed stream that is an
-    invalid-handle error.  The number of hipStreams a process holds is thereby bounded by what it uses at one time."""
+    """Hand a stream made by new_stream back (it must be idle, and the graphs captured on it dropped).  The handle is parked, not
+    destroyed: PyTorch's caching allocator may still hold blocks that were `record_stream`ed on it and records an event on that
+    stream when they are freed — on a destroyed stream that is an invalid-handle error.  Parked streams are reused by new_stream
+    only with LSFA_STREAM_REUSE=1 (see _REUSE)."""
     ptr = stream.cuda_stream
     if ptr in _OWNED:
         _OWNED.remove(ptr)

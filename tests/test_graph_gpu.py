@@ -458,7 +458,7 @@ def test_frame_pipeline_frames_pinned_to_oracle_and_to_the_serial_loop(world, lo
             for name in a[f]['out']:
                 assert torch.equal(a[f]['out'][name], other[f]['out'][name]), "frame %d, output %s vs %s" % (f, name, what)
             assert_dets_equal(a[f]['dets'], a[f]['counts'], other[f]['dets'], other[f]['counts'], "frame %d vs %s" % (f, what))
-    fp.close()         # graphs dropped, streams handed back for the next pipeline
+    fp.close()         # graphs and their memory pools dropped
 
 
 def test_pred_eval_pipelined_two_videos(world):

@@ -433,7 +433,13 @@ int conv_split_launch(convsplit::Args a, void* ws, size_t ws_bytes, void* stream
   const long P = (long)N * a.Ho * a.Wo;
   LSFA_REQUIRE(((long)N * a.out_H * a.out_W + 1) * (long)(a.y_nchw ? Cout : a.ldy) < (1L << 31) && P * Cout < (1L << 31) &&
                ((long)N * H * W + (long)(a.pad_h + 1) * (W + 1)) * a.lda < (1L << 31), "%s: tensor too large", who);
-  const SplitPlan p = view_plan(N, H, W, Cin, Cout, kh, kw, stride, a.pad_h, a.pad_w, dil, a.lda, a.Ho, a.Wo);
+  SplitPlan p = view_plan(N, H, W, Cin, Cout, kh, kw, stride, a.pad_h, a.pad_w, dil, a.lda, a.Ho, a.Wo);
+  // small weights on a small map: the direct kernel (a 64-channel group's weights <= 256 KB, re-read by every 32-pixel tile)
+  if (a.nphase <= 1 && stride == 1 && (size_t)kh * kw * Cin * 64 * 6 <= (256u << 10) && P <= 16384 && g_split_variant.load() != 1) {
+    p = SplitPlan{};
+    p.direct = true;
+    p.slices = 1;
+  }
   const int nph = a.nphase > 1 ? a.nphase : 1;
   const size_t need = split_workspace(p, P, Cout) * (size_t)nph;
   if ((p.slices > 1 || p.units_per_wg > 0) && (!ws || ws_bytes < need)) {
@@ -455,8 +461,14 @@ int conv_split_launch(convsplit::Args a, void* ws, size_t ws_bytes, void* stream
     tiles = (p.nx * p.ny * (Cin / 32) + p.units_per_wg - 1) / p.units_per_wg;      // workgroups
   }
   const dim3 grid((unsigned)(8 * ((tiles + 7) / 8)));
-  if (p.direct)
-    hipLaunchKernelGGL(convsplit::conv_split_direct_kernel, dim3((unsigned)((P + 31) / 32), Cout / 64), dim3(64 * convsplit::kDirectWaves), 0, s, a);
+  if (p.direct) {
+    const int nchunks = kh * kw * (Cin / 32);
+    int nw = (nchunks + 1) / 2;            // at least two chunks per wave, at most kDirectMaxWaves waves
+    if (nw > convsplit::kDirectMaxWaves) nw = convsplit::kDirectMaxWaves;
+    if (nw < 1) nw = 1;
+    hipLaunchKernelGGL(convsplit::conv_split_direct_kernel, dim3((unsigned)((P + 31) / 32), Cout / 64), dim3(64 * nw),
+                       (size_t)(nw - 1) * 32 * 64 * sizeof(float), s, a);
+  }
   else if (p.halo && p.dil == 1)
     hipLaunchKernelGGL(convsplit::conv_split3x3_kernel<1>, grid, dim3(convsplit::kThreads), 0, s, a, p.patches_x, p.patches_y, p.nx, p.ny, p.slices);
   else if (p.halo)

@@ -984,10 +984,9 @@ static __global__ __launch_bounds__(kThreads, (DIL == 1 ? 2 : 1)) void conv_spli
 // wave owns a 32-pixel x 64-channel output tile and loads its operands straight into registers in fragment shape — A: the lane's
 // pixel, 16 consecutive channels (4 x 16 B); B: 12 fragments of 1 KB, coalesced — with the next chunk's 16 loads in flight while
 // the current one is cut and multiplied; no LDS staging, no barrier in the loop.  The K range (taps x chunks) of a tile is dealt
-// to the kDirectWaves waves of the workgroup in contiguous runs; their accumulators meet in LDS and are added in wave order
+// to the waves of the workgroup in contiguous runs; their accumulators meet in LDS and are added in wave order
 // (reproducible), then the shared epilogue (bias / residual / activation / second output).  Weights are re-read by every pixel
 // tile (75 x 216 KB from L2 for the 3x3): fine for small weights, which is what the launch plan checks.
-constexpr int kDirectWaves = 3;
 
 struct DirectOperands { uint4 a[4]; uint4 b[12]; };
 
@@ -1013,9 +1012,14 @@ __device__ __forceinline__ void direct_mma(const DirectOperands& o, f32x16& acc0
   acc1 = mma6(s1, o.b[9], o.b[10], o.b[11], acc1);
 }
 
-// grid (ceil(P / 32), Cout / 64); block 64 * kDirectWaves.  stride 1 (the plan's condition); any kh x kw, pads, dilation.
-static __global__ __launch_bounds__(64 * kDirectWaves) void conv_split_direct_kernel(Args a) {
-  __shared__ __attribute__((aligned(16))) float red[kDirectWaves - 1][32 * 64];
+// grid (ceil(P / 32), Cout / 64); block 64 * nw, nw = 1 .. kDirectMaxWaves waves; dynamic LDS (nw - 1) * 8 KB.  stride 1 (the plan's
+// condition); any kh x kw, pads, dilation.  (Measured on the small net's 64 -> 64 3x3, 18 chunks: 3 waves x 6 chunks 12.3-14.0 us;
+// 9 waves x 2 chunks 17.8-18.3 us — the launch bound for 9 waves caps the registers below the two operand sets.)
+constexpr int kDirectMaxWaves = 3;
+static __global__ __launch_bounds__(64 * kDirectMaxWaves) void conv_split_direct_kernel(Args a) {
+  extern __shared__ __attribute__((aligned(16))) float red_dyn[];
+  float (*red)[32 * 64] = reinterpret_cast<float (*)[32 * 64]>(red_dyn);
+  const int kDirectWaves = blockDim.x >> 6;
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   const int P = a.N * a.Ho * a.Wo;
@@ -1074,7 +1078,6 @@ static __global__ __launch_bounds__(64 * kDirectWaves) void conv_split_direct_ke
   }
   __syncthreads();
   if (wave > 0) return;
-#pragma unroll
   for (int w = 0; w < kDirectWaves - 1; ++w)
 #pragma unroll
     for (int r = 0; r < 16; ++r) { acc0[r] = acc0[r] + red[w][r * 64 + lane]; acc1[r] = acc1[r] + red[w][(16 + r) * 64 + lane]; }

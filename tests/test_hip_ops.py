@@ -967,7 +967,7 @@ def test_conv_split_views_and_transposed_convolution_phases(hip):
     got = out[..., c0:c0 + Cout].double()
     assert float((got - ref).abs().max()) < 2e-6 * (Cin * 4) ** 0.5 * float(ref.abs().max())
     assert bool((out[..., :c0] == -3.0).all()) and bool((out[..., c0 + Cout:] == -3.0).all())
-    # the same as ONE launch (lsfa_deconv4x4s2_crop_fwd): identical bits, and on FlowNet's own shapes (odd crops, K long enough
+    # the same as ONE launch (lsfa_deconv4x4s2_crop_fwd), also on FlowNet's own shapes (odd crops, K long enough
     # for the 128-channel workgroup tiles and for K slices)
     for (Cin, Cout, Hi, Wi, Hc, Wc, Lout, c0) in ((96, 128, 10, 16, 19, 32, 416, 256), (1056, 256, 10, 16, 19, 32, 800, 512),
                                                    (1024, 512, 5, 8, 10, 16, 1056, 512), (416, 64, 38, 63, 75, 125, 224, 128)):
@@ -986,7 +986,9 @@ def test_conv_split_views_and_transposed_convolution_phases(hip):
         ref = full[:, :, 1:1 + Hc, 1:1 + Wc].permute(0, 2, 3, 1)
         assert float((one[..., c0:c0 + Cout].double() - ref).abs().max()) < 2e-6 * (Cin * 4) ** 0.5 * float(ref.abs().max())
         assert bool((one[..., :c0] == 5.0).all()) and bool((one[..., c0 + Cout:] == 5.0).all())
-        assert torch.equal(one, four)
+        # one launch vs four: the same arithmetic; bit-identical when the launch plan picks the same kernel and K cut for both,
+        # fp32 round-off apart otherwise (small phases go to the direct kernel, whose three waves cut K differently)
+        assert float((one - four).abs().max()) <= 4e-6 * float(ref.abs().max())
 
 
 def test_proposal_and_nms_do_not_depend_on_workspace_contents(hip):

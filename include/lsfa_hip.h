@@ -141,7 +141,12 @@ size_t lsfa_proposal_workspace_bytes(int B, int A, int H, int W, int pre_nms_top
 /* Launch plan (process-wide; results are identical bit for bit): AUTO picks the chip-wide plan (six short
  * kernels spread over the CUs) for count <= 32768 anchors and pre_nms_top_n <= 8192, else the single-workgroup
  * plan (one 16-wave workgroup per image, everything in its CU's LDS).  The workspace size does not depend on it. */
-enum { LSFA_PROPOSAL_PLAN_AUTO = 0, LSFA_PROPOSAL_PLAN_SINGLE_WORKGROUP = 1, LSFA_PROPOSAL_PLAN_CHIP_WIDE = 2 };
+enum { LSFA_PROPOSAL_PLAN_AUTO = 0, LSFA_PROPOSAL_PLAN_SINGLE_WORKGROUP = 1, LSFA_PROPOSAL_PLAN_CHIP_WIDE = 2,
+       /* the chip-wide plan with a mask-free NMS stage (r3 experiment, same results): only the diagonal tiles of the suppression mask are
+        * built and one 16-wave workgroup decides everything across blocks from the survivors' boxes in LDS.  No dependent trips to
+        * L2, but 64 x (survivors so far) IoU tests per block on ONE CU's four SIMDs: 160 us against 18 + 48 us for mask + sweep on the
+        * benchmark's RPN, so it is not what AUTO picks */
+       LSFA_PROPOSAL_PLAN_CHIP_WIDE_BOX_SWEEP = 3 };
 int lsfa_proposal_set_plan(int plan);
 int lsfa_proposal(const float* cls_prob, const float* bbox_pred, const float* im_info,
                   int B, int A, int H, int W, int feature_stride,
@@ -334,6 +339,9 @@ int lsfa_head_conv3x3(const float* x, int lda, int N, int H, int W, int Cin, con
 int lsfa_upsample_flow(const float* in, int N, int Hi, int Wi, int C, const float* w, const float* bias, int Hc, int Wc,
                        float* out, int ldy, int c0, void* stream);
 int lsfa_avgpool2_nhwc(const float* x, int N, int H, int W, int C, float* y, void* stream);
+/* channels [c0, c0 + C) of an (N, Ctot, HW) map as (N, HW, C) rows: the NCHW feature the reference's operators exchange
+ * (`conv_feat`, resnet_v1_101_flownet_rfcn.py:479-481 SliceChannel) in the channels-last form lsfa_conv_split_fwd reads. */
+int lsfa_nchw_to_nhwc(const float* x, int N, int Ctot, int HW, int c0, int C, float* y, void* stream);
 
 /* Inference BatchNorm (use_global_stats) + ReLU as one pass: y = max(x*scale[c]+shift[c], 0)
  * (sym_common.py:92-102 bn + relu of every pre-activation unit, resnet.py:70-101).

@@ -321,7 +321,9 @@ SplitPlan split_plan(int N, int H, int W, int Cin, int Cout, int kh, int kw, int
     const int variant = g_split_variant.load();
     // 128 x 128 workgroup tiles pay from ~128 chunks of K on (tools/lab/conv_split_lab.py, profiles/r3/conv_split_lab.txt: the DCN
     // contraction 92 -> 82 us, feat_conv_3x3 506 -> 491); on the short-K convolutions halving the tile count costs more
-    if (Cout % 128 == 0 && variant != 1 && (variant == 2 || chunk_total >= 128)) { p.nt = 4; p.ny = Cout / 128; }
+    // ... or when the 128 x 64 tiles alone overflow the 512 workgroup slots (the R-FCN score-map GEMM: 19 x 30 = 570 tiles of 16 chunks
+    // = two rounds; 19 x 15 of the wide ones = one)
+    if (Cout % 128 == 0 && variant != 1 && (variant == 2 || chunk_total >= 128 || (long)p.nx * (Cout / 64) > 512)) { p.nt = 4; p.ny = Cout / 128; }
     const double chunk_us = p.nt == 4 ? 1.6 : 1.2;
     // How many slices of K.  Two workgroups per CU run almost as fast as one each (measured: ~1.2 us per chunk either
     // way), so time ~ rounds of 512 workgroups x chunks per slice, plus the reduce pass over `slices` partial outputs
@@ -435,7 +437,9 @@ int conv_split_launch(convsplit::Args a, void* ws, size_t ws_bytes, void* stream
                ((long)N * H * W + (long)(a.pad_h + 1) * (W + 1)) * a.lda < (1L << 31), "%s: tensor too large", who);
   SplitPlan p = view_plan(N, H, W, Cin, Cout, kh, kw, stride, a.pad_h, a.pad_w, dil, a.lda, a.Ho, a.Wo);
   // small weights on a small map: the direct kernel (a 64-channel group's weights <= 256 KB, re-read by every 32-pixel tile)
-  if (a.nphase <= 1 && stride == 1 && (size_t)kh * kw * Cin * 64 * 6 <= (256u << 10) && P <= 16384 && g_split_variant.load() != 1) {
+  // and the weights' re-reads stay modest: (P / 32) tiles x all weights <= 48 MB through L2
+  if (a.nphase <= 1 && stride == 1 && (size_t)kh * kw * Cin * 64 * 6 <= (256u << 10) && P <= 16384 &&
+      (size_t)((P + 31) / 32) * kh * kw * Cin * Cout * 6 <= (48u << 20) && g_split_variant.load() != 1) {
     p = SplitPlan{};
     p.direct = true;
     p.slices = 1;

@@ -120,7 +120,36 @@ __global__ __launch_bounds__(256) void avgpool2_cl_kernel(const float4* __restri
   y[i] = make_float4(s.x / d, s.y / d, s.z / d, s.w / d);
 }
 
+// (N, Ctot, HW) planes -> (N, HW, C) rows for channels [c0, c0 + C): 64 x 64 tiles through LDS (padded rows: conflict-free both ways),
+// coalesced 256-byte reads along the pixels and writes along the channels
+__global__ __launch_bounds__(256) void nchw_to_nhwc_kernel(const float* __restrict__ x, int Ctot, int HW, int c0, int C, float* __restrict__ y) {
+  __shared__ float tile[64][65];
+  const int n = blockIdx.z, p0 = blockIdx.x * 64, cb = blockIdx.y * 64;
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  const float* xs = x + ((size_t)n * Ctot + c0) * HW;
+  for (int r = ty; r < 64; r += 4) {
+    const int c = cb + r, p = p0 + tx;
+    tile[r][tx] = (c < C && p < HW) ? xs[(size_t)c * HW + p] : 0.f;
+  }
+  __syncthreads();
+  float* ys = y + (size_t)n * HW * C;
+  for (int r = ty; r < 64; r += 4) {
+    const int p = p0 + r, c = cb + tx;
+    if (p < HW && c < C) ys[(size_t)p * C + c] = tile[tx][r];
+  }
+}
+
 }  // namespace
+
+extern "C" int lsfa_nchw_to_nhwc(const float* x, int N, int Ctot, int HW, int c0, int C, float* y, void* stream) {
+  LSFA_REQUIRE(x && y, "lsfa_nchw_to_nhwc: NULL argument");
+  LSFA_REQUIRE(N > 0 && Ctot > 0 && HW > 0 && c0 >= 0 && C > 0 && c0 + C <= Ctot, "lsfa_nchw_to_nhwc: bad shape");
+  ProfScope prof(LSFA_OP_FLOWNET, (hipStream_t)stream);
+  hipLaunchKernelGGL(nchw_to_nhwc_kernel, dim3((unsigned)((HW + 63) / 64), (unsigned)((C + 63) / 64), (unsigned)N), dim3(256), 0,
+                     (hipStream_t)stream, x, Ctot, HW, c0, C, y);
+  LSFA_LAUNCH_CHECK("lsfa_nchw_to_nhwc");
+  return LSFA_OK;
+}
 
 extern "C" int lsfa_head_conv3x3(const float* x, int lda, int N, int H, int W, int Cin, const float* w, const float* bias, int Cout,
                                  float mul, float* y, int out_nchw, int ldy, int c0, void* stream) {

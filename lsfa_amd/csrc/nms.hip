@@ -38,7 +38,7 @@ extern "C" int lsfa_nms_sorted(const float* boxes, int n, int box_dim, float thr
   uint64_t* diagT = (uint64_t*)((unsigned char*)ws + align_up((size_t)n * col_blocks * sizeof(uint64_t), 256));
   ProfScope prof(LSFA_OP_NMS, s);
   hipLaunchKernelGGL(nms_mask_kernel<false>, dim3(ceil_div(nms_tile_count(col_blocks), 4), 1, 1), dim3(256), 0, s, boxes,
-                     (long)n * box_dim, box_dim, (const int*)nullptr, n, make_iou_test(thresh), mask, diagT, col_blocks);
+                     (long)n * box_dim, box_dim, (const int*)nullptr, n, make_iou_test(thresh), mask, diagT, col_blocks, 0);
   hipLaunchKernelGGL(nms_sweep_kernel, dim3(1), dim3(64), 0, s, (const uint64_t*)mask, (const uint64_t*)diagT, n,
                      col_blocks, n, keep, num_keep, (const float4*)nullptr, (const uint32_t*)nullptr, (float*)nullptr,
                      (float*)nullptr);

@@ -93,19 +93,22 @@ template <bool PACKED4>
 static __global__ __launch_bounds__(256) void nms_mask_kernel(const float* __restrict__ boxes_all, long boxes_img_stride,
                                                               int box_dim, const int* __restrict__ order_all, int n,
                                                               IouTest t, uint64_t* __restrict__ mask_all,
-                                                              uint64_t* __restrict__ diagT_all, int col_blocks) {
+                                                              uint64_t* __restrict__ diagT_all, int col_blocks, int diag_only) {
   __shared__ float4 cbox[4][64];
   __shared__ float carea[4][64];
   const int lane = threadIdx.x & 63;
   // wave-uniform, and the compiler is told so: the tile indices and the `diag` branch stay scalar
   const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   const int tile = blockIdx.x * 4 + wv;
-  const bool tile_ok = tile < nms_tile_count(col_blocks);
-  // tile -> (rb <= cb), tiles enumerated column by column: tile = cb*(cb+1)/2 + rb
-  int cb = (int)((sqrtf(8.0f * (float)tile + 1.0f) - 1.0f) * 0.5f);
-  while ((cb + 1) * (cb + 2) / 2 <= tile) ++cb;
-  while (cb * (cb + 1) / 2 > tile) --cb;
-  const int rb = tile - cb * (cb + 1) / 2;
+  const bool tile_ok = tile < (diag_only ? col_blocks : nms_tile_count(col_blocks));
+  // tile -> (rb <= cb), tiles enumerated column by column: tile = cb*(cb+1)/2 + rb; diag_only: the col_blocks diagonal tiles only
+  // (the Proposal's sweep decides everything off the diagonal from the boxes themselves: nms_sweep_iou_kernel)
+  int cb = diag_only ? tile : (int)((sqrtf(8.0f * (float)tile + 1.0f) - 1.0f) * 0.5f);
+  if (!diag_only) {
+    while ((cb + 1) * (cb + 2) / 2 <= tile) ++cb;
+    while (cb * (cb + 1) / 2 > tile) --cb;
+  }
+  const int rb = diag_only ? tile : tile - cb * (cb + 1) / 2;
   const int img = blockIdx.z;
   const float* boxes = boxes_all + (size_t)img * boxes_img_stride;
   const int* order = order_all ? order_all + (size_t)img * n : nullptr;
@@ -474,6 +477,102 @@ static __global__ __launch_bounds__(64) void nms_sweep_kernel(const uint64_t* __
         const uint32_t u = (asc & 0x80000000u) ? (asc & 0x7fffffffu) : ~asc;
         scores[(size_t)img * max_keep + index] = __uint_as_float(u);
       }
+    }
+  }
+}
+
+// ---- r3 experiment (LSFA_PROPOSAL_PLAN_CHIP_WIDE_BOX_SWEEP): the Proposal's sweep without the suppression mask -------------------
+// MEASURED SLOWER than mask + sweep (160 us against 18 + 48 on the benchmark's RPN): a wave64 VALU instruction occupies its SIMD for
+// four cycles and a CU has four SIMDs, so the 64 x (survivors so far) IoU tests of a block - ~12 K wave-tests of ~25 instructions
+// over the call - are 150 us of ONE CU's issue slots; the mask kernel spreads the same tests over the chip.  Kept as an opt-in plan
+// because it is bit-exact and states the trade; frames/s did not move either way (the pipeline's throughput is set by the chip-filling
+// kernels; a one-CU kernel's latency overlaps the other streams' work).  The reasoning that led here:
+// nms_sweep_kernel above pays one trip to L2 per pair of 64-box blocks for the mask words of the survivors so far: ~0.55 us a
+// block, 70-90 blocks on the benchmark's untrained RPN (every anchor regresses to a large box, 3-5 survivors per block) = 48 us,
+// behind an 18 us mask kernel that fills 4465 tiles of which the sweep reads a sliver.  The Proposal keeps at most post_n <= 1024
+// boxes, so the survivors' boxes fit in LDS and "is candidate j suppressed by an earlier survivor" can be decided from the boxes
+// themselves: one 16-wave workgroup; for block b every wave tests the block's 64 candidates (lane = candidate) against its share
+// of the survivor list (survivor k goes to wave k % 16; its box is a broadcast LDS read), the 16 partial words are ORed, wave 0
+// resolves the block with resolve_block (the block's own 64 x 64 IoU bits come from nms_mask_kernel run on the DIAGONAL tiles
+// only: 94 tiles instead of 4465) and appends the survivors' boxes.  Nothing the loop loads from global memory depends on the
+// sweep's state (the next block's boxes and diagonal words are requested a block ahead); a block costs two workgroup barriers and
+// ~num/16 IoU tests per lane.  Decisions are the mask kernel's, bit for bit: the same iou_exceeds_fast / iou_exceeds_div, whose
+// value does not depend on which of the two boxes is called the row.
+constexpr int kSweepIouWaves = 16;
+
+static __global__ __launch_bounds__(64 * kSweepIouWaves) void nms_sweep_iou_kernel(
+    const float4* __restrict__ sorted_box_all, const uint32_t* __restrict__ sorted_key_all, const uint64_t* __restrict__ mask_all,
+    const uint64_t* __restrict__ diagT_all, int n, int col_blocks, int max_keep, IouTest t, float* __restrict__ rois,
+    float* __restrict__ scores) {
+  __shared__ float4 kbox[kSweepMaxOut];
+  __shared__ float karea[kSweepMaxOut];
+  __shared__ int kept_pos[kSweepMaxOut];
+  __shared__ uint64_t part[kSweepIouWaves];
+  __shared__ int s_num;
+  const int img = blockIdx.x;
+  const float4* sbox = sorted_box_all + (size_t)img * n;
+  const uint64_t* mask = mask_all + (size_t)img * n * col_blocks;
+  const uint64_t* diagT = diagT_all + (size_t)img * n;
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  if (threadIdx.x == 0) s_num = 0;
+  // block 0's operands
+  float4 c_next = lane < n ? sbox[lane] : make_float4(0.f, 0.f, 0.f, 0.f);
+  uint64_t colw_next = 0, rowd_next = 0;
+  if (wave == 0 && lane < n) { colw_next = diagT[lane]; rowd_next = mask[(size_t)lane * col_blocks]; }
+  __syncthreads();
+  int num = 0;
+  for (int b = 0; b < col_blocks && num < max_keep; ++b) {
+    const float4 c = c_next;
+    const uint64_t colw = colw_next, rowd = rowd_next;
+    const int cand = b * 64 + lane;
+    {   // requests for block b + 1: independent of what this block decides
+      const int nc = cand + 64;
+      c_next = nc < n ? sbox[nc] : make_float4(0.f, 0.f, 0.f, 0.f);
+      if (wave == 0) {
+        colw_next = nc < n ? diagT[nc] : 0ULL;
+        rowd_next = nc < n ? mask[(size_t)nc * col_blocks + b + 1] : 0ULL;
+      }
+    }
+    const float Sc = box_area(c);
+    bool sup = false, unsure = !t.fast;
+    for (int k = wave; k < num; k += kSweepIouWaves) sup = sup || iou_exceeds_fast(kbox[k], karea[k], c, Sc, t, unsure);
+    if (__builtin_expect(__any(unsure), 0)) {     // rare: redo this wave's share with the real division
+      sup = false;
+      for (int k = wave; k < num; k += kSweepIouWaves) sup = sup || iou_exceeds_div(kbox[k], karea[k], c, Sc, t);
+    }
+    const uint64_t w = __ballot(sup);
+    if (lane == 0) part[wave] = w;
+    __syncthreads();
+    if (wave == 0) {
+      uint64_t cur = 0;
+#pragma unroll
+      for (int i = 0; i < kSweepIouWaves; ++i) cur |= part[i];
+      const int nb = min(64, n - b * 64);
+      const bool alive = lane < nb && !((cur >> lane) & 1ULL);
+      const uint64_t kept = resolve_block(__ballot(alive), alive, colw, rowd, max_keep - num);
+      if ((kept >> lane) & 1ULL) {
+        const int pos = num + __popcll(kept & ((1ULL << lane) - 1ULL));
+        kbox[pos] = c;
+        karea[pos] = Sc;
+        kept_pos[pos] = cand;
+      }
+      if (lane == 0) s_num = num + __popcll(kept);
+    }
+    __syncthreads();
+    num = s_num;
+  }
+  // output: the first max_keep survivors, cyclic pad (PrepareOutput, multi_proposal.cu:363-388)
+  for (int index = threadIdx.x; index < max_keep; index += 64 * kSweepIouWaves) {
+    const int p = kept_pos[index < num ? index : index % num];
+    const float4 bx = sbox[p];
+    float* o = rois + ((size_t)img * max_keep + index) * 5;
+    o[0] = (float)img;
+    o[1] = bx.x; o[2] = bx.y; o[3] = bx.z; o[4] = bx.w;
+    if (scores) {
+      const uint32_t asc = ~sorted_key_all[(size_t)img * n + p];
+      const uint32_t u = (asc & 0x80000000u) ? (asc & 0x7fffffffu) : ~asc;
+      scores[(size_t)img * max_keep + index] = __uint_as_float(u);
     }
   }
 }

@@ -711,7 +711,7 @@ WsLayout ws_layout(int B, int count, int pre_n, int post_n) {
 
 static std::atomic<int> g_plan{LSFA_PROPOSAL_PLAN_AUTO};
 extern "C" int lsfa_proposal_set_plan(int plan) {
-  LSFA_REQUIRE(plan >= LSFA_PROPOSAL_PLAN_AUTO && plan <= LSFA_PROPOSAL_PLAN_CHIP_WIDE, "lsfa_proposal_set_plan: unknown plan %d", plan);
+  LSFA_REQUIRE(plan >= LSFA_PROPOSAL_PLAN_AUTO && plan <= LSFA_PROPOSAL_PLAN_CHIP_WIDE_BOX_SWEEP, "lsfa_proposal_set_plan: unknown plan %d", plan);
   g_plan.store(plan);
   return LSFA_OK;
 }
@@ -776,11 +776,20 @@ extern "C" int lsfa_proposal(const float* cls_prob, const float* bbox_pred, cons
                        (const uint32_t*)hist, A, H * W, pre_n, cand, info, bin_start, bin_count);
     hipLaunchKernelGGL(proposal_rank_kernel, dim3(gi, B), dim3(kRankThreads), 0, s, (const uint64_t*)cand, (const int*)info,
                        (const int*)bin_start, (const int*)bin_count, count, pre_n, (const float4*)boxes, sbox, skey);
-    hipLaunchKernelGGL(nms_mask_kernel<true>, dim3(ceil_div(nms_tile_count(col_blocks), 4), 1, B), dim3(256), 0, s,
-                       (const float*)sbox, (long)pre_n * 4, 4, (const int*)nullptr, pre_n, iou, mask, diagT, col_blocks);
-    hipLaunchKernelGGL(nms_sweep_kernel, dim3(B), dim3(64), 0, s, (const uint64_t*)mask, (const uint64_t*)diagT, pre_n,
-                       col_blocks, post_n, (int*)nullptr, (int*)nullptr, (const float4*)sbox, (const uint32_t*)skey,
-                       rois, scores);
+    if (plan != LSFA_PROPOSAL_PLAN_CHIP_WIDE_BOX_SWEEP) {
+      hipLaunchKernelGGL(nms_mask_kernel<true>, dim3(ceil_div(nms_tile_count(col_blocks), 4), 1, B), dim3(256), 0, s,
+                         (const float*)sbox, (long)pre_n * 4, 4, (const int*)nullptr, pre_n, iou, mask, diagT, col_blocks, 0);
+      hipLaunchKernelGGL(nms_sweep_kernel, dim3(B), dim3(64), 0, s, (const uint64_t*)mask, (const uint64_t*)diagT, pre_n,
+                         col_blocks, post_n, (int*)nullptr, (int*)nullptr, (const float4*)sbox, (const uint32_t*)skey,
+                         rois, scores);
+    } else {
+      // diagonal tiles only (each block's own 64 x 64 bits); everything across blocks is decided by the sweep from the boxes
+      hipLaunchKernelGGL(nms_mask_kernel<true>, dim3(ceil_div(col_blocks, 4), 1, B), dim3(256), 0, s,
+                         (const float*)sbox, (long)pre_n * 4, 4, (const int*)nullptr, pre_n, iou, mask, diagT, col_blocks, 1);
+      hipLaunchKernelGGL(nms_sweep_iou_kernel, dim3(B), dim3(64 * kSweepIouWaves), 0, s, (const float4*)sbox,
+                         (const uint32_t*)skey, (const uint64_t*)mask, (const uint64_t*)diagT, pre_n, col_blocks, post_n, iou,
+                         rois, scores);
+    }
     LSFA_LAUNCH_CHECK("lsfa_proposal");
     return LSFA_OK;
   }

@@ -244,8 +244,8 @@ class ProposalOp(object):
 
 @_on_tensor_device
 def proposal_set_plan(plan):
-    """'auto' | 'single' | 'chip': lsfa_proposal_set_plan (process-wide launch plan; same results)."""
-    _check(lib().lsfa_proposal_set_plan(_ci({'auto': 0, 'single': 1, 'chip': 2}[plan])), "lsfa_proposal_set_plan")
+    """'auto' | 'single' | 'chip' | 'chip-box-sweep': lsfa_proposal_set_plan (process-wide launch plan; same results)."""
+    _check(lib().lsfa_proposal_set_plan(_ci({'auto': 0, 'single': 1, 'chip': 2, 'chip-box-sweep': 3}[plan])), "lsfa_proposal_set_plan")
 
 
 def nms_sorted(boxes, thresh):
@@ -521,6 +521,30 @@ def upsample_flow(x, w, bias, out, c0):
     _check(lib().lsfa_upsample_flow(_ptr(x), _ci(N), _ci(Hi), _ci(Wi), _ci(C), _ptr(w), _ptr(bias), _ci(out.shape[1]), _ci(out.shape[2]),
                                     _ptr(out), _ci(out.shape[3]), _ci(c0), _stream()), "lsfa_upsample_flow")
     return out
+
+
+@_on_tensor_device
+def nchw_to_nhwc(x, c0=0, c=None):
+    """channels [c0, c0 + c) of an (N, C, H, W) map -> (N, H, W, c) channels-last (lsfa_nchw_to_nhwc)."""
+    x = _f32c(x, "x")
+    N, C, H, W = x.shape
+    c = C - c0 if c is None else c
+    y = torch.empty((N, H, W, c), device=x.device, dtype=torch.float32)
+    _check(lib().lsfa_nchw_to_nhwc(_ptr(x), _ci(N), _ci(C), _ci(H * W), _ci(c0), _ci(c), _ptr(y), _stream()), "lsfa_nchw_to_nhwc")
+    return y
+
+
+def rfcn_head_ps_ld(ps_map, cell_ld, rois, H, W, ncls, nbox, spatial_scale=0.0625, pooled_size=7, group_size=7):
+    """rfcn_head_ps on a position-sensitive map whose cells are `cell_ld` floats apart (N, H, W, cell_ld)."""
+    ps_map, rois = _f32c(ps_map, "ps_map"), _f32c(rois, "rois")
+    N, R = ps_map.shape[0], rois.shape[0]
+    cls_prob = torch.empty((R, ncls), device=rois.device, dtype=torch.float32)
+    bbox_pred = torch.empty((R, nbox), device=rois.device, dtype=torch.float32)
+    with torch.cuda.device(ps_map.device):
+        _check(lib().lsfa_rfcn_head_ps_ld_fwd(_ptr(ps_map), _ci(cell_ld), _ptr(rois), _ci(N), _ci(H), _ci(W), _ci(R), _ci(ncls), _ci(nbox),
+                                              _cf(spatial_scale), _ci(pooled_size), _ci(group_size), _ptr(cls_prob), None,
+                                              _ptr(bbox_pred), _stream()), "lsfa_rfcn_head_ps_ld_fwd")
+    return cls_prob, bbox_pred
 
 
 @_on_tensor_device

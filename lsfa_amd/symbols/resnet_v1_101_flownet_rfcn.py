@@ -791,7 +791,29 @@ class Executor(object):
         rpn = self._conv1x1(self._c(conv_feat[:, :512]), self.rpn_w, bias=self.rpn_b).float()
         cls_prob = torch.softmax(rpn[:, :2 * A].reshape(n, 2, A * h, w), dim=1).reshape(n, 2 * A, h, w)
         rois = self.proposal(cls_prob, rpn[:, 2 * A:], im_info)
-        if self.ps_layout and n == 1:
+        if self.ps_layout and n == 1 and _CONV_SPLIT and 'rfcn' in _OWN_CONV and self.cdtype == torch.float32 and conv_feat.is_cuda:
+            # r3 (opt-in, LSFA_OWN_CONV=...,rfcn): the same GEMM on the own split convolution ((H*W, 512) x (512, 49*D), D = ncls + nbox,
+            # columns padded to a multiple of 128): the R-FCN half of conv_feat is turned channels-last by one small launch, the
+            # padded position-sensitive map is read with its row stride by the head kernel.  Measured 44.6 us (128 x 128 tiles) + 9.2
+            # (transpose) against 45 us for the tuned hipBLASLt fp32-MFMA GEMM (104 TFLOP/s, 66 % of ITS pipe's peak): no gain, so the
+            # library GEMM stays the default here
+            D = self.ncls + self.nbox
+            if not hasattr(self, '_rfcn_split'):
+                cols = 49 * D
+                pad_to = -(-cols // 128) * 128
+                wp = torch.zeros((pad_to, 512, 1, 1), device=self.device, dtype=torch.float32)
+                wp[:cols, :, 0, 0] = self.rfcn_w_ps_t.t()
+                bp = torch.zeros(pad_to, device=self.device, dtype=torch.float32)
+                bp[:cols] = self.rfcn_b_ps
+                self._rfcn_split, self._rfcn_b_pad, self._rfcn_ld = hip.SplitWeight(wp, real_cout=cols), bp, pad_to
+            x = hip.nchw_to_nhwc(conv_feat, 512, 512)
+            ps = hip.conv_split(x, self._rfcn_split, self._rfcn_b_pad)                 # (1, h, w, ld)
+            if self.taps is not None:
+                nchw = ps.view(h * w, self._rfcn_ld)[:, :49 * D].reshape(h * w, 49, D).permute(2, 1, 0).reshape(1, D * 49, h, w)
+                self.taps.update(rpn_cls_prob=cls_prob, rpn_bbox_pred=rpn[:, 2 * A:], cls_map=nchw[:, :self.n_cls_ch],
+                                 box_map=nchw[:, self.n_cls_ch:])
+            cls_p, bbox = hip.rfcn_head_ps_ld(ps, self._rfcn_ld, rois, h, w, self.ncls, self.nbox, 0.0625, 7, 7)
+        elif self.ps_layout and n == 1:
             # both R-FCN convs as one GEMM that writes the position-sensitive layout directly
             xt = self._c(conv_feat[0, 512:]).view(512, h * w).t()
             D = self.ncls + self.nbox

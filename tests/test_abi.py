@@ -35,6 +35,9 @@ def test_library_builds_loads_and_exports_every_declared_symbol():
     lib.lsfa_op_name.restype = ctypes.c_char_p
     from lsfa_amd import hip
     assert [lib.lsfa_op_name(i).decode() for i in range(len(hip.OP_NAMES))] == hip.OP_NAMES
+    # ... and the table is COMPLETE: lsfa_prof_read fills LSFA_OP_COUNT entries of buffers the binding sizes by this list (an
+    # out-of-date copy, one short, let it write past them and hung bench.py: r3)
+    assert lib.lsfa_op_name(len(hip.OP_NAMES)) == b"?"
     # workspace sizing is host-only arithmetic: float4 boxes + u32 keys for the 21,546 anchors (no NMS mask)
     lib.lsfa_proposal_workspace_bytes.restype = ctypes.c_size_t
     ws = lib.lsfa_proposal_workspace_bytes(1, 9, 38, 63, 6000)

@@ -388,7 +388,7 @@ def test_proposal_score_distributions_that_stress_the_select(hip, kind):
     np.testing.assert_array_equal(scores.cpu().numpy(), want_scores)
 
 
-@pytest.mark.parametrize("plan", ["single", "chip"])
+@pytest.mark.parametrize("plan", ["single", "chip", "chip-box-sweep"])
 def test_proposal_launch_plans_agree(hip, plan):
     """lsfa_proposal_set_plan: the single-workgroup plan and the chip-wide plan give the oracle's result bit for bit
     (the default picks by shape; test_proposal_bit_exact's pre_n = 12000 case runs the single-workgroup plan anyway)."""

@@ -3,21 +3,21 @@
 # Raw traces stay on the box; the condensed summaries land in gpurun_out/<round>/ and are copied to profiles/<round>/.
 # PMC passes never share a run with --sys-trace / --runtime-trace (the pool refuses that combination).
 set -u
-R=${1:-r2}
+R=${1:-r3}
 OUT=gpurun_out/$R
 mkdir -p $OUT
 export TMPDIR=/tmp
 PY=python3
 
 # 1. the bench lines (default = configs[1]; configs[4]; configs[2])
-timeout 400 $PY bench.py --steps 100 > $OUT/bench_default_run.json 2> $OUT/bench_default_run.err
+timeout 600 $PY bench.py --steps 100 > $OUT/bench_default_run.json 2> $OUT/bench_default_run.err
 timeout 400 $PY bench.py --interval 1 --maps-per-launch 32 --steps 60 > $OUT/bench_interval1_maps32_run.json 2> $OUT/bench_interval1_maps32_run.err
 timeout 600 $PY bench.py --dtype bf16 --clips 4 --steps 40 > $OUT/bench_bf16_clips4_run.json 2> $OUT/bench_bf16_clips4_run.err
 timeout 400 $PY bench.py --dtype bf16 --steps 60 --no-cpu-baseline --no-parity > $OUT/bench_bf16_clips1_run.json 2> /dev/null
 
 # 2. kernel trace of the pipelined timed region (default configuration)
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_pipe -o t -- $PY bench.py --steps 30 --no-cpu-baseline --no-parity > $OUT/trace_pipe.log 2>&1
-$PY tools/summarize_prof.py trace $OUT/trace_pipe $OUT/bench_pipelined_timed_region_kernels.csv 0.6
+$PY tools/summarize_prof.py trace $OUT/trace_pipe $OUT/bench_pipelined_timed_region_kernels.csv 0.6     # also writes ..._kernels_launches.json
 cp $(find $OUT/trace_pipe -name "*kernel_stats.csv" | head -1) $OUT/bench_pipelined_kernel_stats_whole_run.csv 2>/dev/null
 rm -rf $OUT/trace_pipe
 
@@ -47,4 +47,9 @@ timeout 600 $PY tools/lab/conv_split_lab.py > $OUT/conv_split_lab.txt 2>&1
 timeout 300 $PY tools/lab/conv_split_lab.py --stamps > $OUT/conv_split_chunk_cycles.txt 2>&1
 timeout 300 $PY tools/lab/conv_lab.py > $OUT/conv_fp32_mfma_lab.txt 2>&1
 timeout 300 $PY tools/lab/det_lab.py > $OUT/det_lab.txt 2>&1
+# 7. r3: kernel sequences of FlowNet and of one non-key frame (eager), multi-process determinism table
+timeout 200 rocprofv3 --kernel-trace --output-format csv -d $OUT/fn -o t -- $PY tools/backbone_only.py 20 flownet > /dev/null 2>&1
+timeout 60 $PY tools/kernel_sequence.py $OUT/fn 20 > $OUT/flownet_kernel_sequence.txt 2>&1; rm -rf $OUT/fn
+timeout 200 rocprofv3 --kernel-trace --output-format csv -d $OUT/cf -o t -- $PY tools/curframe_only.py 30 > /dev/null 2>&1
+timeout 60 $PY tools/kernel_sequence.py $OUT/cf 30 > $OUT/curframe_kernel_sequence.txt 2>&1; rm -rf $OUT/cf
 ls -la $OUT

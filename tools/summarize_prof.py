@@ -34,6 +34,17 @@ def trace_summary(d, out, tail_frac=0.5, top=60):
         o.write('kernel,calls,total_us,avg_us,pct_of_busy\n')
         for k, v in sorted(agg.items(), key=lambda kv: -kv[1][1])[:top]:
             o.write('"%s",%d,%.1f,%.2f,%.2f\n' % (k[:140], v[0], v[1] / 1e3, v[1] / v[0] / 1e3, 100.0 * v[1] / busy))
+    if nframes:
+        # launches per frame over the same window -> what bench.py reports as `kernel_launches` (profiles/launch_counts.json)
+        own = sum(v[0] for k, v in agg.items() if 'lsfa' in k or '(anonymous namespace)' in k)
+        lib = sum(v[0] for k, v in agg.items() if k.startswith('Cijk') or 'miopen' in k.lower() or 'ck::' in k or 'igemm' in k)
+        with open(out.replace('.csv', '') + '_launches.json', 'w') as o:
+            json.dump({"frames_in_window": nframes, "kernel_launches_in_window": len(rows),
+                       "per_frame_mean": round(len(rows) / float(nframes), 1), "per_10_frame_interval": round(10.0 * len(rows) / nframes, 1),
+                       "own_kernels_per_frame": round(own / float(nframes), 1), "library_gemm_or_conv_per_frame": round(lib / float(nframes), 1),
+                       "gpu_busy_ms_per_frame": round(busy / 1e6 / nframes, 4), "wall_ms_per_frame": round((t1 - t0) / 1e6 / nframes, 4),
+                       "own_kernel_share_of_busy": round(sum(v[1] for k, v in agg.items() if 'lsfa' in k or '(anonymous namespace)' in k) / float(busy), 4),
+                       "source": "rocprofv3 --kernel-trace of `bench.py --steps 30` (pipelined hipGraph replay), last %.0f%% of the run" % (tail_frac * 100)}, o, indent=1)
 
 
 def pmc_summary(d, match):

@@ -1,7 +1,8 @@
 #!/usr/bin/env python
 """For a rocprofv3 kernel trace of a script that repeats ONE launch sequence n times (tools/backbone_only.py): the kernels of one
 steady-state repetition in launch order with their durations averaged over the last repetitions.
-usage: kernel_sequence.py <trace_dir> <repetitions>"""
+usage: kernel_sequence.py <trace_dir> <repetitions> [--by-name]     (--by-name: one line per kernel name, time summed over the
+repetition, for sequences of hundreds of launches such as the backbone)"""
 import csv
 import glob
 import os
@@ -19,6 +20,20 @@ def main():
     reps = max(1, min(n // 2, len(rows) // per - 1))
     tail = rows[len(rows) - per * reps:]
     tot = 0.0
+    if '--by-name' in sys.argv:
+        agg = {}
+        for i in range(per):
+            name = tail[i]['Kernel_Name']
+            dur = sum((int(tail[k * per + i]['End_Timestamp']) - int(tail[k * per + i]['Start_Timestamp'])) for k in range(reps)) / reps / 1e3
+            a = agg.setdefault(name, [0, 0.0])
+            a[0] += 1
+            a[1] += dur
+            tot += dur
+        for name, (cnt, dur) in sorted(agg.items(), key=lambda kv: -kv[1][1]):
+            short = name.replace('(anonymous namespace)::', '').replace('lsfa::convsplit::', '').replace('void ', '').split('(')[0][:90]
+            print('%-92s %4d launches %9.1f us  %5.1f %%' % (short, cnt, dur, 100 * dur / tot))
+        print('sum of kernel durations: %.1f us over %d kernels (%d repetitions averaged)' % (tot, per, reps))
+        return
     for i in range(per):
         name = tail[i]['Kernel_Name']
         dur = sum((int(tail[k * per + i]['End_Timestamp']) - int(tail[k * per + i]['Start_Timestamp'])) for k in range(reps)) / reps / 1e3

@@ -52,4 +52,6 @@ timeout 200 rocprofv3 --kernel-trace --output-format csv -d $OUT/fn -o t -- $PY 
 timeout 60 $PY tools/kernel_sequence.py $OUT/fn 20 > $OUT/flownet_kernel_sequence.txt 2>&1; rm -rf $OUT/fn
 timeout 200 rocprofv3 --kernel-trace --output-format csv -d $OUT/cf -o t -- $PY tools/curframe_only.py 30 > /dev/null 2>&1
 timeout 60 $PY tools/kernel_sequence.py $OUT/cf 30 > $OUT/curframe_kernel_sequence.txt 2>&1; rm -rf $OUT/cf
+timeout 200 rocprofv3 --kernel-trace --output-format csv -d $OUT/bb -o t -- $PY tools/backbone_only.py 12 backbone > /dev/null 2>&1
+timeout 60 $PY tools/kernel_sequence.py $OUT/bb 12 --by-name > $OUT/backbone_kernels_by_name.txt 2>&1; rm -rf $OUT/bb
 ls -la $OUT

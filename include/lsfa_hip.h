@@ -101,6 +101,10 @@ int lsfa_warp_bilinear(const float* feat, int feat_n, const float* flow,
                        const float* mul, const float* add,
                        const float* res, int res_c, const float* res_w, const float* res_b,
                        float* out, void* stream);
+/* Kernel choice (process-wide; results are identical bit for bit): 0 = by shape (default), 1 = the gather kernel only (rounds 1-2),
+ * 2 = the LDS-staged kernel (round 3: whole planes copied into LDS by DMA, taps read from LDS) or LSFA_ENOTSUP when the shape or
+ * alignment does not allow it (H*W even and <= 4096, 16-byte aligned maps, (C*H*W) % 4 == 0). */
+int lsfa_warp_set_variant(int variant);
 
 /* ------------------------------------------------------------------------ *
  * Long-term aggregation combine (Nq_net tail).

@@ -56,6 +56,9 @@ def lib():
             i += 1
         if names != OP_NAMES:
             OP_NAMES[:] = names              # in place: importers of the list see the library's table
+        wv = os.environ.get("LSFA_WARP_VARIANT")         # A/B runs of whole programs: 'gather' | 'staged' | 'auto'
+        if wv:
+            L.lsfa_warp_set_variant(ctypes.c_int({'auto': 0, 'gather': 1, 'staged': 2}[wv]))
         _lib = L
     return _lib
 
@@ -168,6 +171,12 @@ def warp_bilinear(feat, flow, mul=None, add=None, res=None, res_w=None, res_b=No
                                     _ptr(add), _ptr(res), _ci(res_c), _ptr(res_w), _ptr(res_b), _ptr(out), _stream()),
            "lsfa_warp_bilinear")
     return out
+
+
+def warp_set_variant(variant):
+    """'auto' | 'gather' | 'staged': lsfa_warp_set_variant (process-wide kernel choice of warp_bilinear; same results.  'staged'
+    makes shapes the LDS-staged kernel does not take an error instead of falling back)."""
+    _check(lib().lsfa_warp_set_variant(_ci({'auto': 0, 'gather': 1, 'staged': 2}[variant])), "lsfa_warp_set_variant")
 
 
 @_on_tensor_device

@@ -170,6 +170,78 @@ def test_warp_broadcast_key_feature_batch(hip):
     np.testing.assert_array_equal(got, want)
 
 
+@pytest.mark.parametrize("case", ["plain", "key", "cur", "mul+add+res4", "border", "broadcast", "in-place", "45x80", "26x40"])
+def test_warp_staged_kernel_matches_the_oracle_and_the_gather_kernel(hip, case):
+    """r3: planes staged in LDS by DMA (warp_staged_kernel).  Forced ('staged' makes an unsupported shape an error), on every
+    operand combination, with flows that leave the map on all sides, odd plane alignments (38 x 63 planes start 8 bytes off every
+    other channel), the broadcast key feature, the in-place `add`, a map larger than one 640-thread pass and one smaller than the
+    default threshold: bit-identical to the oracle and to the gather kernel."""
+    H, W = {"45x80": (45, 80), "26x40": (26, 40)}.get(case, (38, 63))
+    N, C = (3, 40) if case in ("broadcast", "45x80", "26x40") else (2, 24)
+    rs = np.random.RandomState(len(case) + H)
+    feat = rs.randn(1 if case == "broadcast" else N, C, H, W).astype(np.float32)
+    flow = smooth_flow(rs, N, H, W, 2.5)
+    if case == "border":
+        flow = rs.uniform(-70, 70, (N, 2, H, W)).astype(np.float32)
+        flow[0, :, 0, :7] = 1e9
+        flow[1, :, -1, -7:] = -1e9
+        flow[0, 0, 5, :] = -1.5          # x0 = -2 .. -1: the left column half in
+        flow[0, 1, :, 9] = 1.25
+    kw = {}
+    if case in ("key", "mul+add+res4", "broadcast"):
+        kw["mul"] = (1 + 0.1 * rs.randn(N, C, H, W)).astype(np.float32)
+    if case in ("cur", "mul+add+res4", "border", "in-place", "45x80", "26x40"):
+        kw["add"] = rs.randn(N, C, H, W).astype(np.float32)
+    if case in ("cur", "mul+add+res4", "border", "45x80"):
+        rc = 4 if case == "mul+add+res4" else 3
+        kw["res"] = (4 * rs.randn(N, rc, H, W)).astype(np.float32)
+        kw["res_w"] = (0.01 * rs.randn(C, rc, 1, 1)).astype(np.float32)
+        kw["res_b"] = (0.01 * rs.randn(C)).astype(np.float32)
+    want = oracle.warp_bilinear(feat, flow, **kw)
+    dkw = {k: t(v) for k, v in kw.items()}
+    got = {}
+    try:
+        for variant in ("staged", "gather"):
+            hip.warp_set_variant(variant)
+            if case == "in-place":
+                buf = dkw["add"].clone()
+                got[variant] = hip.warp_bilinear(t(feat), t(flow), add=buf, out=buf).cpu().numpy()
+            else:
+                got[variant] = hip.warp_bilinear(t(feat), t(flow), **dkw).cpu().numpy()
+    finally:
+        hip.warp_set_variant("auto")
+    np.testing.assert_array_equal(got["staged"], want)
+    np.testing.assert_array_equal(got["gather"], want)
+
+
+def test_warp_staged_kernel_refuses_what_it_cannot_take(hip):
+    feat, flow = torch.randn(1, 8, 9, 7, device=DEV), torch.zeros(1, 2, 9, 7, device=DEV)      # 63 pixels: odd
+    hip.warp_set_variant("staged")
+    try:
+        with pytest.raises(hip.LsfaError):
+            hip.warp_bilinear(feat, flow)
+    finally:
+        hip.warp_set_variant("auto")
+    assert hip.warp_bilinear(feat, flow).shape == feat.shape
+
+
+def test_warp_32_maps_per_launch_bit_exact(hip):
+    """BASELINE configs[4]'s launch shape (32 maps x 1024 channels): the many-planes instance of the staged kernel against the
+    gather kernel (the oracle at this size takes minutes; both kernels are checked against it at small sizes above)."""
+    g = torch.Generator(device=DEV).manual_seed(3)
+    feat = torch.randn((32, 1024, 38, 63), device=DEV, generator=g)
+    mul = torch.randn((32, 1024, 38, 63), device=DEV, generator=g)
+    flow = torch.randn((32, 2, 38, 63), device=DEV, generator=g) * 3
+    try:
+        hip.warp_set_variant("staged")
+        a = hip.warp_bilinear(feat, flow, mul=mul)
+        hip.warp_set_variant("gather")
+        b = hip.warp_bilinear(feat, flow, mul=mul)
+    finally:
+        hip.warp_set_variant("auto")
+    assert torch.equal(a, b)
+
+
 def test_warp_identity_property(hip):
     feat = torch.randn(1, 1024, 38, 63, device=DEV)
     out = hip.warp_bilinear(feat, torch.zeros(1, 2, 38, 63, device=DEV))

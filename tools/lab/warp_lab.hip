@@ -1,6 +1,7 @@
 // A/B harness for warp kernel variants (tools/lab/warp_lab.py builds and drives it).  Not part of liblsfa_hip.so.
 #include "warp_r1_kernel.h"
 #include "warp_variants.h"
+#include "warp_lds.h"
 #include "warp_r2_attempt.h"
 
 extern "C" int lab_warp(int variant, const float* feat, int feat_n, const float* flow, int N, int C, int H, int W,
@@ -43,6 +44,30 @@ extern "C" int lab_warp(int variant, const float* feat, int feat_n, const float*
     case 12: rc = warp_lab::launch<8, 4, true, false, false, 1024>(s, g); break;      // 16 waves per workgroup
     case 13: rc = warp_lab::launch<16, 8, true, false, false, 256>(s, g); break;      // 16 ch / wave, batches of 8
     case 14: rc = warp_lab::launch<4, 2, true, false, false, 256>(s, g); break;       // 4 ch / wave, batches of 2
+    //                        THREADS NPAIR NDMA STAGES          channels per workgroup
+    case 17: rc = warp_lds::launch<640, 2, 1, 3>(s, g, 8); break;
+    case 18: rc = warp_lds::launch<640, 2, 1, 3>(s, g, 16); break;
+    case 19: rc = warp_lds::launch<640, 2, 1, 4>(s, g, 16); break;
+    case 20: rc = warp_lds::launch<320, 4, 2, 3>(s, g, 16); break;
+    case 21: rc = warp_lds::launch<320, 4, 2, 4>(s, g, 16); break;
+    case 22: rc = warp_lds::launch<256, 5, 3, 3>(s, g, 16); break;
+    case 23: rc = warp_lds::launch<640, 2, 1, 3>(s, g, 4); break;
+    case 24: rc = warp_lds::launch<640, 2, 1, 3>(s, g, 32); break;
+    case 25: rc = warp_lds::launch<640, 2, 1, 3>(s, g, 2); break;
+    case 26: rc = warp_lds::launch<640, 2, 1, 4>(s, g, 8); break;
+    case 27: rc = warp_lds::launch<256, 5, 3, 3>(s, g, 8); break;
+    case 28: rc = warp_lds::launch<256, 5, 3, 3>(s, g, 4); break;
+    case 29: rc = warp_lds::launch<1024, 2, 1, 3>(s, g, 8); break;
+    case 30: rc = warp_lds::launch<1024, 2, 1, 3>(s, g, 4); break;
+    case 31: rc = warp_lds::launch<512, 3, 2, 3>(s, g, 8); break;
+    case 32: rc = warp_lds::launch<512, 3, 2, 3>(s, g, 4); break;
+    case 99: {     // not a warp: the same three streams (two in, one out) moved with 16-byte accesses
+      const size_t n4 = (size_t)N * C * HW / 4;
+      const float* other = mul ? mul : add;
+      if (mul) hipLaunchKernelGGL(warp_lds::stream_floor_kernel<true>, dim3(256 * 16), dim3(256), 0, s, (const float4*)feat, (const float4*)other, (float4*)out, n4);
+      else hipLaunchKernelGGL(warp_lds::stream_floor_kernel<false>, dim3(256 * 16), dim3(256), 0, s, (const float4*)feat, (const float4*)other, (float4*)out, n4);
+      break;
+    }
     default: return -3;
   }
   if (rc) return rc;

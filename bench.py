@@ -62,6 +62,9 @@ def parse():
     ap.add_argument('--maps-per-launch', type=int, default=0,
                     help='roofline leg on this many feature maps per launch of the warp / aggregate kernels (configs[4]: 32, '
                          '942 MB per launch, HBM-resident); 0 = the frame loop\'s own single-map launches')
+    ap.add_argument('--settle-s', type=float, default=2.5,
+                    help='setup: after graph capture, replay untimed intervals for this long before the W warm-up steps (a fresh '
+                         'device needs 1-3 s of load to reach its steady clocks; W = 5 intervals is 30 ms)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-parity', action='store_true')
     ap.add_argument('--no-spread', action='store_true', help='skip the two extra repeats of the timed region behind `value_spread`')
@@ -425,6 +428,14 @@ def main():
             r.fg.flush()             # the pipeline queues a segment when the next key frame arrives: queue the last one
         torch.cuda.synchronize()     # device-wide: drains every stream of the frame pipeline
 
+    # setup, untimed and not part of the W warm-up steps: keep the device under the workload's load until its clocks have settled
+    settle_steps, t_settle = 0, time.perf_counter()
+    while time.perf_counter() - t_settle < args.settle_s:
+        r.step(settle_steps)
+        settle_steps += 1
+        if settle_steps % 8 == 0:
+            drain()
+    drain()
     for s in range(args.warmup):
         r.step(s)
     drain()
@@ -525,6 +536,8 @@ def main():
                        "frames_per_step": K * B, "ms_per_frame": round(elapsed / (args.steps * K * B) * 1e3, 3),
                        "parallelism": "clip-parallel x%d" % world, "detections_last_interval": total_dets,
                        "launch": "eager" if args.no_graph else "hipGraph replay per frame",
+                       "setup_before_warmup": "graph capture + %d untimed interval(s) over %.1f s (clock settle), then the %d warm-up steps"
+                                              % (settle_steps, args.settle_s, args.warmup),
                        "gemm_solutions": "library default" if tuned is None else
                                          ("lsfa_amd/tuned/gemm_gfx950.csv" if tuned else "tuned on first use (shipped file rejected)"),
                        "pipeline": ("key stream%s + %d non-key lanes%s" % (

@@ -435,7 +435,10 @@ class FramePipeline(object):
         if layout == 'probe':
             chosen, aliased = streams.concurrent_streams(want, dev)
         elif layout == 'plain':
-            chosen, aliased = [streams.new_stream(dev) for _ in range(want)], []
+            # LSFA_STREAM_PRIO (experiments): which of the streams are created with the device's greatest priority
+            prio = os.environ.get('LSFA_STREAM_PRIO', '')
+            roles = ['key'] + (['flow'] if flow_stream else []) + ['lanes'] * lanes
+            chosen, aliased = [streams.new_stream(dev, high_priority=(r in prio.split(','))) for r in roles], []
         elif layout == 'one-queue':
             chosen, aliased = [streams.new_stream(dev)], [(streams.new_stream(dev), 0) for _ in range(want)]
         else:

@@ -23,7 +23,7 @@ import os as _os
 _REUSE = _os.environ.get('LSFA_STREAM_REUSE', '0') == '1'
 
 
-def new_stream(device):
+def new_stream(device, high_priority=False):
     """A stream that is this caller's alone.  `torch.cuda.Stream()` draws from a pool of 32 per priority
     and wraps around: after enough pipelines / captures two Stream objects are the SAME hipStream_t.  PyTorch
     keys its BLAS workspace by (handle, stream) and captured GEMMs bake that address in, so graphs captured
@@ -34,13 +34,13 @@ def new_stream(device):
     from lsfa_amd import hip
     dev = torch.device(device)
     idx = dev.index if dev.index is not None else torch.cuda.current_device()
-    if _FREE.get(idx) and _REUSE:
+    if _FREE.get(idx) and _REUSE and not high_priority:
         s = _FREE[idx].pop()
         _OWNED.append(s.cuda_stream)
         return s
     ptr = ctypes.c_void_p()
     with torch.cuda.device(dev):
-        hip._check(hip.lib().lsfa_stream_create(ctypes.byref(ptr), ctypes.c_int(0)), "lsfa_stream_create")
+        hip._check(hip.lib().lsfa_stream_create(ctypes.byref(ptr), ctypes.c_int(1 if high_priority else 0)), "lsfa_stream_create")
     s = torch.cuda.ExternalStream(ptr.value, device=dev)
     _OWNED.append(ptr.value)
     return s

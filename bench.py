@@ -492,7 +492,7 @@ def main():
                for k, v in prof.items() if v[1]}
         hand_total = sum(o["total_us"] for o in ops.values()) or 1.0
         dom = max(ops, key=lambda k: ops[k]["total_us"]) if ops else None
-        roof_hbm = {"bound": "hbm", "kernel": "warp_kernel (lsfa_warp_bilinear: MV/flow warp + fused epilogue), %d map(s) per launch" % B,
+        roof_hbm = {"bound": "hbm", "kernel": "warp_staged_kernel (lsfa_warp_bilinear: MV/flow warp + fused epilogue; planes staged in LDS by DMA), %d map(s) per launch" % B,
                 "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 4),
                 "traffic": load_traffic("warp_bilinear:N=%d,C=%d,H=%d,W=%d" % (B, C, fh, fw)),
@@ -562,7 +562,7 @@ def main():
             line["roofline_single_map"] = roof_hbm
             line["roofline_mfma_kernel"] = roof
             del line["roofline_hbm_kernel"]
-            line["roofline"] = {"bound": "hbm", "kernel": "warp_kernel, %d maps per launch (x scale map epilogue)" % M,
+            line["roofline"] = {"bound": "hbm", "kernel": "warp_staged_kernel (lsfa_warp_bilinear, planes staged in LDS by DMA), %d maps per launch (x scale map epilogue)" % M,
                                 "achieved": w["achieved_GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                 "frac": round(w["achieved_GBps"] / HBM_PEAK_GBS, 4),
                                 "traffic": load_traffic("warp_bilinear:N=%d,C=%d,H=%d,W=%d" % (M, C, fh, fw)),

@@ -280,6 +280,8 @@ class _ResNetWeights(object):
                 d['w3_split'] = hip.SplitWeight(d['w3'])
                 if 'sc' in d and 'sc_split' not in d:
                     d['sc_split'] = hip.SplitWeight(d['sc'])
+            if _CONV_SPLIT and 'conv3s' in _OWN_CONV and 'w3_split' not in d and d['w3'].is_cuda and d['w3'].dtype == torch.float32:
+                d['w3_split'] = hip.SplitWeight(d['w3'])      # conv3 alone on the split kernel (residual + next bn1/ReLU fused)
         self._cl_ready = True
 
 
@@ -594,7 +596,18 @@ class Executor(object):
                     self.taps['u%d_%02d_3sc' % (u['stage'], u['unit'])] = sc.clone()
             # the bn1 + ReLU the NEXT unit (or the network's tail) applies to this unit's output
             nxt = units[ui + 1]['bn1'] if ui + 1 < len(units) else (net.bn1 if tail else None)
-            if fuse3 and 'w3_kc' in u and sc.is_contiguous():
+            if own_conv and 'conv3s' in _OWN_CONV and 'w3_split' in u and sc.is_contiguous():
+                # conv3 + shortcut add in place + the next bn1 / ReLU as a second output on the split kernel; conv1 stays a library GEMM
+                sc4 = sc.view(n, ho, wo, -1)
+                if nxt is not None:
+                    _, out2 = hip.conv_split(c2.view(n, ho, wo, -1), u['w3_split'], None, out=sc4, residual=sc4,
+                                             out2=torch.empty_like(sc4), scale2=nxt[0], shift2=nxt[1])
+                    a2 = out2.view(-1, out2.shape[3])
+                else:
+                    hip.conv_split(c2.view(n, ho, wo, -1), u['w3_split'], None, out=sc4, residual=sc4)
+                    a2 = None
+                x4 = self._map(sc, ho, wo)
+            elif fuse3 and 'w3_kc' in u and sc.is_contiguous():
                 # conv3 + shortcut add in place + the next bn1/relu1 as a second output: one launch (lsfa_conv_nhwc_fused_fwd)
                 sc4 = sc.view(n, ho, wo, -1)
                 out2 = torch.empty_like(sc4) if nxt is not None else None

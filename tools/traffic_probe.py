@@ -62,7 +62,7 @@ def _kernel_rows(d, suffix):
     if not f:
         raise SystemExit("no %s under %s" % (suffix, d))
     rows = list(csv.DictReader(open(f[0])))
-    return [r for r in rows if "warp_kernel" in r["Kernel_Name"] or "combine_kernel" in r["Kernel_Name"]]
+    return [r for r in rows if "warp_kernel" in r["Kernel_Name"] or "warp_staged_kernel" in r["Kernel_Name"] or "combine_kernel" in r["Kernel_Name"]]
 
 
 def summarize(fetch_dir, write_dir, trace_dir, out_path):

@@ -566,7 +566,8 @@ def test_bench_line_contract():
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--steps", "3", "--warmup", "1", "--height", "192",
-                          "--width", "320", "--cpu-budget-s", "5"], capture_output=True, text=True, timeout=600, cwd=root)
+                          "--width", "320", "--cpu-budget-s", "5", "--settle-s", "0.3"], capture_output=True, text=True, timeout=600,
+                         cwd=root)
     assert out.returncode == 0, out.stderr[-2000:]
     lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1
@@ -584,6 +585,11 @@ def test_bench_line_contract():
     assert h["bound"] == "hbm" and h["unit"] == "GB/s" and abs(h["frac"] - h["achieved"] / h["peak"]) < 1e-3
     c = d["cpu_baseline"]
     assert c["kind"] == "port" and c["cores"] >= 1 and c["unit"] == "frames/s" and c["sample"]
+    # r3: three back-to-back timed regions (`value` is the first), what ran before the warm-up steps, exit status 0 = parity held
+    v = d["value_spread"]
+    assert v["repeats"] == 3 and len(v["values"]) == 3 and v["values"][0] == d["value"] and v["min"] <= d["value"] <= v["max"]
+    assert "settle" in d["config"]["setup_before_warmup"] and d["warmup"] == 1
+    assert d["parity"]["handwritten_stage_mismatches_on_gpu_inputs"] == 0
 
 
 def test_fp32_frames_run_without_a_library_convolution(world, monkeypatch):

@@ -508,17 +508,21 @@ def main():
         conv_fl, conv_calls = getattr(r, 'conv_flops', (0.0, 0))
         if conv_n and conv_fl > 0:
             tf = conv_fl / (conv_ms * 1e-3) / 1e12
-            roof = {"bound": "mfma", "kernel": "conv_split_kernel / conv_split3x3_kernel (lsfa_conv_split_fwd: conv2 of the ResNet "
-                    "units, feat_conv_3x3, fuse_reduce_add) incl. their conv_reduce_kernel passes, %d calls of one interval" % conv_n,
+            roof = {"bound": "mfma", "kernel": "the split-bf16 convolution family (lsfa_conv_split_fwd and its view / phase forms: conv2 and "
+                    "the DCN branch of the ResNet units, feat_conv_3x3, fuse_reduce_add, FlowNet, the Nq net, the small net's 3x3s) incl. "
+                    "their reduce / fix-up passes, %d calls of one interval" % conv_n,
                     "achieved": round(tf, 1), "peak": MFMA_SPLIT_PEAK_TFLOPS, "unit": "TFLOP/s",
-                    "frac": round(tf / MFMA_SPLIT_PEAK_TFLOPS, 4), "traffic": None,
+                    "frac": round(tf / MFMA_SPLIT_PEAK_TFLOPS, 4),
+                    "traffic": load_traffic("conv_split:%dx%d,interval=%d,%s" % (args.width, args.height, args.interval, args.dtype)),
                     "launches": conv_n, "avg_us": round(conv_ms * 1e3 / conv_n, 2),
                     "algorithmic_flops_per_launch": round(conv_fl / max(conv_calls, 1)),
                     "bf16_mfma_work": {"achieved": round(6 * tf, 1), "peak": 2500.0, "unit": "TFLOP/s"},
                     "fp32_mfma_pipe_peak": 157.3,
                     "measured": "HIP events around each lsfa_conv_split_fwd / lsfa_conv_nhwc_fused_fwd call (conv kernel + its reduce "
                                 "pass) of one interval re-issued eagerly after the timed region; algorithmic FLOPs = 2*M*N*K summed "
-                                "over the same calls",
+                                "over the same calls; traffic = HBM bytes per call of the kernel family (FETCH_SIZE x2 + WRITE_SIZE, separate "
+                                "rocprofv3 PMC passes over the eager loop, profiles/traffic.json), null if no profile of this configuration is "
+                                "committed",
                     "note": "fp32 in / fp32 accumulate; every fp32 product is six bf16 partial products on the bf16 matrix pipe, so "
                             "the peak for fp32-equivalent FLOPs is the dense bf16 peak / 6 (2500 / 6); the fp32 matrix instructions "
                             "peak at 157.3"}

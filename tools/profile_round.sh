@@ -32,6 +32,12 @@ timeout 200 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -o 
 timeout 200 rocprofv3 --kernel-trace --output-format csv -d $OUT/pmc_trace -o t -- $PY tools/traffic_probe.py run > $OUT/traffic_trace.log 2>&1
 $PY tools/traffic_probe.py summarize $OUT/pmc_fetch $OUT/pmc_write $OUT/pmc_trace $OUT/traffic.json > $OUT/traffic_summary.log 2>&1
 rm -rf $OUT/pmc_fetch $OUT/pmc_write $OUT/pmc_trace
+# 4b. HBM traffic of the split-convolution family per call (the `roofline.traffic` of the default bench line), same two-pass rule
+EAGER="bench.py --steps 4 --warmup 1 --settle-s 0 --no-graph --lanes 0 --no-cpu-baseline --no-parity --no-spread"
+timeout 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_cfetch -o t -- $PY $EAGER > $OUT/conv_traffic_fetch.log 2>&1
+timeout 300 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_cwrite -o t -- $PY $EAGER > $OUT/conv_traffic_write.log 2>&1
+$PY tools/summarize_prof.py convtraffic $OUT/pmc_cfetch $OUT/pmc_cwrite $OUT/traffic.json "conv_split:1000x600,interval=10,f32" > $OUT/conv_traffic_summary.log 2>&1
+rm -rf $OUT/pmc_cfetch $OUT/pmc_cwrite
 
 # 5. per-op kernels (GPU-side durations) and the warp A/B
 timeout 200 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_ops -o t -- $PY tools/bench_ops.py > $OUT/bench_ops_microbench.txt 2>&1

@@ -82,9 +82,47 @@ def pmc_table(d, out, top=45, last_frames=20):
             o.write('"%s",%d,%s\n' % (k, len(disp[k]), ','.join('%.0f' % v.get(c, 0) for c in names)))
 
 
+def conv_traffic(fetch_dir, write_dir, out_json, key):
+    """HBM bytes of the split-convolution kernel family per lsfa_conv_split_fwd call, from two PMC passes (FETCH_SIZE, WRITE_SIZE: they
+    cannot share one) over the same eager loop: (2 x sum FETCH_SIZE KiB [the gfx950 correction] + sum WRITE_SIZE KiB) x 1024 over the
+    family's dispatches / dispatches of its main kernels (a call = one main kernel + at most one reduce / fix-up pass).  Merged
+    into `out_json` (profiles/traffic.json, what bench.py reads) under `key`."""
+    main = ('conv_split_kernel', 'conv_split_wide_kernel', 'conv_split_deep_kernel', 'conv_split_direct_kernel', 'conv_split3x3_kernel')
+
+    def collect(d, cname):
+        f = glob.glob(d + '/**/*counter_collection.csv', recursive=True)
+        agg = collections.defaultdict(lambda: [0.0, 0])
+        for r in csv.DictReader(open(f[0])):
+            if r['Counter_Name'] == cname and 'convsplit::' in r['Kernel_Name']:
+                k = r['Kernel_Name'].split('(')[0].replace('void ', '').replace('lsfa::convsplit::', '')
+                agg[k][0] += float(r['Counter_Value'])
+                agg[k][1] += 1
+        return agg
+    fe, wr = collect(fetch_dir, 'FETCH_SIZE'), collect(write_dir, 'WRITE_SIZE')
+    calls_f = sum(v[1] for k, v in fe.items() if k.startswith(main) and 'fixup' not in k)
+    calls_w = sum(v[1] for k, v in wr.items() if k.startswith(main) and 'fixup' not in k)
+    fetch_per_call = 2.0 * 1024 * sum(v[0] for v in fe.values()) / max(calls_f, 1)
+    write_per_call = 1024.0 * sum(v[0] for v in wr.values()) / max(calls_w, 1)
+    entry = {"hbm_bytes_per_launch": int(fetch_per_call + write_per_call), "fetch_bytes_per_launch": int(fetch_per_call),
+             "write_bytes_per_launch": int(write_per_call), "calls_in_fetch_pass": calls_f, "calls_in_write_pass": calls_w,
+             "per_kernel_avg_bytes": {k: {"dispatches": fe[k][1], "fetch": int(2048 * fe[k][0] / max(fe[k][1], 1)),
+                                          "write": int(1024 * wr[k][0] / max(wr[k][1], 1)) if k in wr else None} for k in sorted(fe)},
+             "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) over `bench.py --no-graph --lanes 0`; FETCH_SIZE x2 "
+                       "(gfx950), KiB units; a launch = one lsfa_conv_split_fwd call (main kernel + its reduce / fix-up pass)"}
+    try:
+        d = json.load(open(out_json))
+    except (OSError, ValueError):
+        d = {}
+    d[key] = entry
+    json.dump(d, open(out_json, 'w'), indent=1)
+    print(json.dumps(entry, indent=1))
+
+
 if __name__ == '__main__':
     mode = sys.argv[1]
-    if mode == 'pmctable':
+    if mode == 'convtraffic':
+        conv_traffic(sys.argv[2], sys.argv[3], sys.argv[4], sys.argv[5])
+    elif mode == 'pmctable':
         pmc_table(sys.argv[2], sys.argv[3])
     elif mode == 'trace':
         trace_summary(sys.argv[2], sys.argv[3], float(sys.argv[4]) if len(sys.argv) > 4 else 0.5)

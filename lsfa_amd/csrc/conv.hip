@@ -22,6 +22,8 @@
 // Weight layout (prepared once at bind time): w[co][tap][ci], i.e. K contiguous per output channel.
 #include "common.h"
 
+#include <stdlib.h>
+
 #include "conv_split_kernel.h"
 
 using namespace lsfa;
@@ -409,7 +411,15 @@ extern "C" int lsfa_conv_split_weights(const float* w, int Cout, int kh, int kw,
 
 namespace {
 // every split convolution goes through here; the public entry points fill in what they expose
+// LSFA_CONV_TILE_ORDER (lab): how workgroup ids map to (slice, channel tile, pixel tile), see xcd_tile
+static int tile_order_from_env() {
+  const char* e = getenv("LSFA_CONV_TILE_ORDER");
+  return e ? atoi(e) : 0;
+}
+
 int conv_split_launch(convsplit::Args a, void* ws, size_t ws_bytes, void* stream, const char* who, int prof_op = LSFA_OP_CONV) {
+  static const int tile_order = tile_order_from_env();
+  a.tile_order = tile_order;
   const int N = a.N, H = a.H, W = a.W, Cin = a.Cin, Cout = a.Cout, kh = a.kh, kw = a.kw, stride = a.stride, dil = a.dil;
   LSFA_REQUIRE(a.x && a.wfrag && a.y, "%s: NULL argument", who);
   LSFA_REQUIRE(N > 0 && H > 0 && W > 0 && kh > 0 && kw > 0 && stride > 0 && a.pad_h >= 0 && a.pad_w >= 0 && dil > 0, "%s: bad shape", who);

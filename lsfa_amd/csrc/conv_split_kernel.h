@@ -70,6 +70,7 @@ struct Args {
   // ph_wstride uint4 behind the previous phase's (everything a phase needs follows from (py, px): a table in the argument
   // struct would be indexed dynamically, which makes hipcc keep the struct in scratch)
   int nphase; long part_stride; long ph_wstride;
+  int tile_order;   // 0: tiles numbered (slice, channel tile, pixel tile), pixel fastest; 1: (slice, pixel tile, channel tile), channel fastest
 };
 
 // the launch as phase `phase` sees it
@@ -316,12 +317,19 @@ __device__ __forceinline__ void pipeline_step(uint4 (*S)[kStage], const float* _
 // all weights AND all activations through its L2 (6 MB for a res4 conv2: it does not fit, and the misses go to the
 // Infinity Cache).
 struct Tile { int x, y, z; };
-__device__ __forceinline__ Tile xcd_tile(int id, int nx, int ny, int nz) {
+__device__ __forceinline__ Tile xcd_tile(int id, int nx, int ny, int nz, int order = 0) {
   const int total = nx * ny * nz;
   const int per = (total + 7) / 8;
   const int t = (id & 7) * per + (id >> 3);
   Tile r;
   if (t >= total) { r.x = r.y = r.z = -1; return r; }      // the grid is 8 * per >= total: the surplus ids have no tile
+  if (order == 1) {      // channel tile fastest: the workgroups of one XCD are ALL channel tiles of an eighth of the (slice, pixel tile) list
+    r.y = t % ny;
+    const int q = t / ny;
+    r.x = q % nx;
+    r.z = q / nx;
+    return r;
+  }
   r.x = t % nx;
   const int q = t / nx;
   r.y = q % ny;
@@ -332,7 +340,7 @@ __device__ __forceinline__ Tile xcd_tile(int id, int nx, int ny, int nz) {
 // grid (8 * ceil(tiles / 8)); block 256; 56 KB of LDS.  tiles = ceil(P / 128) * (Cout / 64) * slices
 static __global__ __launch_bounds__(kThreads, 2) void conv_split_kernel(Args a, int nx, int ny, int nz) {
   __shared__ __attribute__((aligned(16))) uint4 S[2][kStage];
-  Tile tile = xcd_tile(blockIdx.x, nx, ny, nz);
+  Tile tile = xcd_tile(blockIdx.x, nx, ny, nz, a.tile_order);
   if (tile.x < 0) return;
   if (a.nphase > 1) { const int slices = nz / a.nphase, phase = tile.z / slices; tile.z -= phase * slices; apply_phase(a, phase, slices); }
   const int tid = threadIdx.x;
@@ -478,7 +486,7 @@ __device__ __forceinline__ void deep_step(uint4 (*S)[kStage], const float* __res
 // grid (8 * ceil(tiles / 8)); block 256; 112 KB of LDS.  tiles as conv_split_kernel
 static __global__ __launch_bounds__(kThreads, 1) void conv_split_deep_kernel(Args a, int nx, int ny, int nz) {
   __shared__ __attribute__((aligned(16))) uint4 S[kDeep][kStage];
-  Tile tile = xcd_tile(blockIdx.x, nx, ny, nz);
+  Tile tile = xcd_tile(blockIdx.x, nx, ny, nz, a.tile_order);
   if (tile.x < 0) return;
   if (a.nphase > 1) { const int slices = nz / a.nphase, phase = tile.z / slices; tile.z -= phase * slices; apply_phase(a, phase, slices); }
   const int tid = threadIdx.x;
@@ -635,7 +643,7 @@ template <int NT>
 static __global__ __launch_bounds__(kThreads, 2) void conv_split_wide_kernel(Args a, int nx, int ny, int nz) {
   typedef Wide<NT> WD;
   __shared__ __attribute__((aligned(16))) uint4 S[2][WD::kStageN];
-  Tile tile = xcd_tile(blockIdx.x, nx, ny, nz);
+  Tile tile = xcd_tile(blockIdx.x, nx, ny, nz, a.tile_order);
   if (tile.x < 0) return;
   if (a.nphase > 1) { const int slices = nz / a.nphase, phase = tile.z / slices; tile.z -= phase * slices; apply_phase(a, phase, slices); }
   const int tid = threadIdx.x;
@@ -905,7 +913,7 @@ static __global__ __launch_bounds__(kThreads, (DIL == 1 ? 2 : 1)) void conv_spli
     u = wg * a.units_per_wg;
     u_end = min(u + a.units_per_wg, total_units);
   } else {
-    tile = xcd_tile(blockIdx.x, nx, ny, nz);
+    tile = xcd_tile(blockIdx.x, nx, ny, nz, a.tile_order);
     if (tile.x < 0) return;
   }
   for (;;) {

@@ -42,7 +42,9 @@ bool launch_staged(hipStream_t s, StagedArgs a) {
   const int HW = a.H * a.W;
   constexpr int kRegion = THREADS * NDMA * 4;
   a.guard = (2 * a.W + 6 + 3) & ~3;
-  if (HW > 2 * THREADS * NPAIR || 3 + HW + a.W + 2 > kRegion + a.guard || (3 + HW + 3) / 4 > THREADS * NDMA) return false;
+  // the lanes cover the plane; the DMA pass covers its chunks; the farthest tap (plane start + <= 3 floats of shift + H*W + 2W + 1, taken
+  // and discarded for a flow that leaves the map at the bottom right) stays inside the slot
+  if (HW > 2 * THREADS * NPAIR || (3 + HW + 3) / 4 > THREADS * NDMA || 3 + HW + 2 * a.W + 2 > kRegion + a.guard) return false;
   const int ops = (a.mul ? 1 : 0) + (a.add ? 1 : 0);
   const size_t lds_bytes = (size_t)kStages * (2 * a.guard + (1 + ops) * kRegion) * 4;
   if (lds_bytes > 160 * 1024) return false;

@@ -50,20 +50,25 @@ bool launch_staged(hipStream_t s, StagedArgs a) {
   if (lds_bytes > 160 * 1024) return false;
   static lsfa::PerDeviceOnce attr;
   attr.run([] {
-#define LSFA_WS_ATTR(M, A, R) (void)hipFuncSetAttribute((const void*)warp_staged_kernel<THREADS, NPAIR, NDMA, kStages, M, A, R>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+#define LSFA_WS_ATTR(M, A, R) (void)hipFuncSetAttribute((const void*)warp_staged_kernel<THREADS, NPAIR, NDMA, kStages, M, A, R, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     LSFA_WS_ATTR(false, false, false) LSFA_WS_ATTR(true, false, false) LSFA_WS_ATTR(false, true, false) LSFA_WS_ATTR(false, false, true)
     LSFA_WS_ATTR(true, true, false) LSFA_WS_ATTR(true, false, true) LSFA_WS_ATTR(false, true, true) LSFA_WS_ATTR(true, true, true)
+#define LSFA_WS_ATTR3(M, A) (void)hipFuncSetAttribute((const void*)warp_staged_kernel<THREADS, NPAIR, NDMA, kStages, M, A, true, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    LSFA_WS_ATTR3(false, false) LSFA_WS_ATTR3(true, false) LSFA_WS_ATTR3(false, true) LSFA_WS_ATTR3(true, true)
+#undef LSFA_WS_ATTR3
 #undef LSFA_WS_ATTR
   });
   const bool m = a.mul != nullptr, ad = a.add != nullptr, r = a.res != nullptr;
   const dim3 grid(a.N * (a.C / a.cg));
-#define LSFA_WS_CASE(M, A, R)                                                                                                  \
-  if (m == M && ad == A && r == R) {                                                                                           \
-    hipLaunchKernelGGL((warp_staged_kernel<THREADS, NPAIR, NDMA, kStages, M, A, R>), grid, dim3(THREADS), lds_bytes, s, a);    \
+#define LSFA_WS_CASE(M, A, R, RC)                                                                                              \
+  if (m == M && ad == A && r == R && (RC == 0 || a.res_c == RC)) {                                                             \
+    hipLaunchKernelGGL((warp_staged_kernel<THREADS, NPAIR, NDMA, kStages, M, A, R, RC>), grid, dim3(THREADS), lds_bytes, s, a); \
     return true;                                                                                                               \
   }
-  LSFA_WS_CASE(false, false, false) LSFA_WS_CASE(true, false, false) LSFA_WS_CASE(false, true, false) LSFA_WS_CASE(false, false, true)
-  LSFA_WS_CASE(true, true, false) LSFA_WS_CASE(true, false, true) LSFA_WS_CASE(false, true, true) LSFA_WS_CASE(true, true, true)
+  // the frame path's residual has 3 channels (rnet_conv0): those instances keep 3 values per pixel and unroll the dot product
+  LSFA_WS_CASE(false, false, true, 3) LSFA_WS_CASE(true, false, true, 3) LSFA_WS_CASE(false, true, true, 3) LSFA_WS_CASE(true, true, true, 3)
+  LSFA_WS_CASE(false, false, false, 0) LSFA_WS_CASE(true, false, false, 0) LSFA_WS_CASE(false, true, false, 0) LSFA_WS_CASE(false, false, true, 0)
+  LSFA_WS_CASE(true, true, false, 0) LSFA_WS_CASE(true, false, true, 0) LSFA_WS_CASE(false, true, true, 0) LSFA_WS_CASE(true, true, true, 0)
 #undef LSFA_WS_CASE
   return false;
 }

@@ -218,9 +218,12 @@ struct StagedArgs {
 // grid (N * C / cg); block THREADS; dynamic LDS STAGES * (2 * guard + (1 + HAS_MUL + HAS_ADD) * THREADS * NDMA * 4) floats.
 // Needs: H*W even, feat / mul / add 16-byte aligned, (C*H*W) % 4 == 0, H*W <= 2 * THREADS * NPAIR,
 //        3 + H*W + W + 2 <= THREADS * NDMA * 4 + guard (warp.hip checks all of it and falls back to warp_kernel)
-template <int THREADS, int NPAIR, int NDMA, int STAGES, bool HAS_MUL, bool HAS_ADD, bool HAS_RES>
+// RC: the residual's channel count when it is known at compile time (3: rnet_conv0 of the frame path), 0 = A.res_c at run time
+template <int THREADS, int NPAIR, int NDMA, int STAGES, bool HAS_MUL, bool HAS_ADD, bool HAS_RES, int RC = 0>
 __global__ __launch_bounds__(THREADS) void warp_staged_kernel(StagedArgs A) {
   static_assert(STAGES == 3 || STAGES == 4, "the counted waits below cover one or two planes in flight");
+  constexpr int kRes = RC > 0 ? RC : kResMax;              // residual values a lane keeps per pixel
+  const int res_c = RC > 0 ? RC : A.res_c;
   extern __shared__ __attribute__((aligned(16))) float lds[];
   constexpr int kOps = (HAS_MUL ? 1 : 0) + (HAS_ADD ? 1 : 0);
   constexpr int kRegion = THREADS * NDMA * 4;            // floats one DMA pass of the workgroup covers
@@ -237,7 +240,7 @@ __global__ __launch_bounds__(THREADS) void warp_staged_kernel(StagedArgs A) {
   int idx[NPAIR][2];            // float index of the top-left tap relative to the plane's first float (negative: in the guard)
   unsigned vb[NPAIR];           // validity bits: pixel j -> bits 4j .. 4j+3 = v00 v01 v10 v11
   float wx0[NPAIR][2], wx1[NPAIR][2], wy0[NPAIR][2], wy1[NPAIR][2];
-  float rv[HAS_RES ? NPAIR : 1][kResMax][2];
+  float rv[HAS_RES ? NPAIR : 1][kRes][2];
   const float half_w = (float)((W - 1) / 2.0), half_h = (float)((H - 1) / 2.0);
 #pragma unroll
   for (int i = 0; i < NPAIR; ++i) {
@@ -248,9 +251,9 @@ __global__ __launch_bounds__(THREADS) void warp_staged_kernel(StagedArgs A) {
     const float fxs[2] = {fx.x, fx.y}, fys[2] = {fy.x, fy.y};
     if (HAS_RES) {
 #pragma unroll
-      for (int k = 0; k < kResMax; ++k) {
+      for (int k = 0; k < kRes; ++k) {
         float2 r = make_float2(0.f, 0.f);
-        if (k < A.res_c) r = *reinterpret_cast<const float2*>(A.res + ((size_t)n * A.res_c + k) * HW + p0);
+        if (k < res_c) r = *reinterpret_cast<const float2*>(A.res + ((size_t)n * res_c + k) * HW + p0);
         rv[i][k][0] = r.x; rv[i][k][1] = r.y;
       }
     }
@@ -281,7 +284,7 @@ __global__ __launch_bounds__(THREADS) void warp_staged_kernel(StagedArgs A) {
 #pragma unroll
     for (int i = 0; i < NPAIR; ++i)
 #pragma unroll
-      for (int k = 0; k < kResMax; ++k) { pin(rv[i][k][0]); pin(rv[i][k][1]); }
+      for (int k = 0; k < kRes; ++k) { pin(rv[i][k][0]); pin(rv[i][k][1]); }
   }
 
   // ---- the ring ------------------------------------------------------------------------------------------------------------------
@@ -338,10 +341,10 @@ __global__ __launch_bounds__(THREADS) void warp_staged_kernel(StagedArgs A) {
       if (HAS_MUL) mv[i] = lds_read2(m0 + (uint32_t)pl * 4u);
       if (HAS_ADD) av[i] = lds_read2(a0 + (uint32_t)pl * 4u);
     }
-    float rw[kResMax], rb = 0.f;
+    float rw[kRes], rb = 0.f;
     if (HAS_RES) {
 #pragma unroll
-      for (int q = 0; q < kResMax; ++q) rw[q] = q < A.res_c ? A.res_w[(size_t)c * A.res_c + q] : 0.f;
+      for (int q = 0; q < kRes; ++q) rw[q] = q < res_c ? A.res_w[(size_t)c * res_c + q] : 0.f;
       rb = A.res_b[c];
     }
     lds_wait();
@@ -367,8 +370,8 @@ __global__ __launch_bounds__(THREADS) void warp_staged_kernel(StagedArgs A) {
         if (HAS_RES) {
           float q = rw[0] * rv[i][0][j];
 #pragma unroll
-          for (int kk = 1; kk < kResMax; ++kk)
-            if (kk < A.res_c) q = q + rw[kk] * rv[i][kk][j];
+          for (int kk = 1; kk < kRes; ++kk)
+            if (kk < res_c) q = q + rw[kk] * rv[i][kk][j];
           q = q + rb;
           r = r + q;
         }

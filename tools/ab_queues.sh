@@ -1,5 +1,6 @@
 # A/B of whole-bench settings on ONE box: hardware queues x non-key lanes
 run() { name=$1; shift; env "$@" 2>/dev/null | tail -1 > gpurun_out/ab_$name.json
+[ -s gpurun_out/ab_$name.json ] || { echo "$name: no output, stopping (sick box?)"; exit 9; }
 python -c "import json,sys; d=json.load(open('gpurun_out/ab_$name.json')); print('$name', d['value'], d['value_spread']['values'])"; }
 B="timeout 300 python bench.py --no-cpu-baseline --no-parity"
 for i in 1 2; do

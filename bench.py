@@ -455,12 +455,14 @@ def main():
     # run-to-run spread: the same K steps twice more, each bracketed like the timed region above (`value` stays the FIRST
     # region's; the driver's fresh-box figure and a builder's warm-box one have differed by ~10 %: this makes that visible)
     repeats = [elapsed]
+    host_enqueue = []            # how long the host loop of a repeat took to QUEUE its K steps (the rest of the region is waiting for the GPU)
     for _ in range(0 if args.no_spread else 2):
         barrier()
         torch.cuda.synchronize()
         t1 = time.perf_counter()
         for s in range(args.warmup, args.warmup + args.steps):
             r.step(s)
+        host_enqueue.append(time.perf_counter() - t1)
         drain()
         barrier()
         repeats.append(time.perf_counter() - t1)
@@ -550,7 +552,8 @@ def main():
                        if args.lanes > 0 else "serial"},
             "value_spread": {"min": round(frames / max(repeats), 3), "max": round(frames / min(repeats), 3), "repeats": len(repeats),
                              "values": [round(frames / t, 3) for t in repeats],
-                             "note": "the timed region run %d times back to back; `value` is the first" % len(repeats)},
+                             "note": "the timed region run %d times back to back; `value` is the first" % len(repeats),
+                             "host_enqueue_share_of_repeats": [round(h / t, 3) for h, t in zip(host_enqueue, repeats[1:])]},
             "roofline": roof,
             "roofline_hbm_kernel": roof_hbm,
             "roofline_handwritten_ops": {

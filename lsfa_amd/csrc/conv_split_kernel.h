@@ -123,6 +123,13 @@ __device__ __forceinline__ f32x16 mma(const uint4& a, const uint4& b, const f32x
 
 // acc += (a1 + a2 + a3) * (b1 + b2 + b3) without the three smallest terms, smallest kept terms first
 __device__ __forceinline__ f32x16 mma6(const Pieces& a, const uint4& b1, const uint4& b2, const uint4& b3, f32x16 acc) {
+#ifdef LSFA_LAB_MMA3      // timing experiment only (WRONG results): what three matrix instructions per k-step instead of six would cost
+  acc = mma(a.p2, b1, acc);
+  acc = mma(a.p1, b2, acc);
+  acc = mma(a.p1, b1, acc);
+  (void)b3;
+  return acc;
+#endif
   acc = mma(a.p3, b1, acc);
   acc = mma(a.p1, b3, acc);
   acc = mma(a.p2, b2, acc);

@@ -430,12 +430,14 @@ def main():
 
     # setup, untimed and not part of the W warm-up steps: keep the device under the workload's load until its clocks have settled
     settle_steps, t_settle = 0, time.perf_counter()
+    settle_drain = int(os.environ.get('LSFA_BENCH_SETTLE_DRAIN', '8'))      # lab: 0 = one uninterrupted load, no drain before the warm-up steps
     while time.perf_counter() - t_settle < args.settle_s:
         r.step(settle_steps)
         settle_steps += 1
-        if settle_steps % 8 == 0:
+        if settle_drain and settle_steps % settle_drain == 0:
             drain()
-    drain()
+    if settle_drain:
+        drain()
     for s in range(args.warmup):
         r.step(s)
     drain()

@@ -430,7 +430,10 @@ def main():
 
     # setup, untimed and not part of the W warm-up steps: keep the device under the workload's load until its clocks have settled
     settle_steps, t_settle = 0, time.perf_counter()
-    settle_drain = int(os.environ.get('LSFA_BENCH_SETTLE_DRAIN', '8'))      # lab: 0 = one uninterrupted load, no drain before the warm-up steps
+    # bursts of 32 intervals (~0.19 s) between drains: with bursts of 8 (46 ms) the device never reached its sustained state during setup
+    # and went through the transition - three to six intervals of 7.5-9.7 ms instead of 5.6 - inside the first timed region in half of
+    # the runs (profiles/r3/ab_experiments.txt section 9, tools/trace_regions.py)
+    settle_drain = int(os.environ.get('LSFA_BENCH_SETTLE_DRAIN', '32'))
     while time.perf_counter() - t_settle < args.settle_s:
         r.step(settle_steps)
         settle_steps += 1

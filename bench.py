@@ -190,6 +190,7 @@ class Runner(object):
         torch.cuda.synchronize()
         prof = self.hip.prof_read()
         self.conv_flops = self.hip.conv_flops_read()
+        self.conv_flops3 = self.hip.conv_flops_three_products()
         self.hip.conv_flops_reset(False)
         self.hip.prof_enable(False)
         return prof
@@ -515,24 +516,30 @@ def main():
         conv_fl, conv_calls = getattr(r, 'conv_flops', (0.0, 0))
         if conv_n and conv_fl > 0:
             tf = conv_fl / (conv_ms * 1e-3) / 1e12
+            # matrix-pipe peak for this mix of calls: six bf16 products per fp32 product (2500 / 6), three fp16 ones on the calls
+            # that ran the two-piece form (2500 / 3): harmonic mix by FLOPs
+            fl3 = float(getattr(r, 'conv_flops3', 0.0))
+            mix_peak = conv_fl / ((conv_fl - fl3) / MFMA_SPLIT_PEAK_TFLOPS + fl3 / (2.0 * MFMA_SPLIT_PEAK_TFLOPS))
             roof = {"bound": "mfma", "kernel": "the split-bf16 convolution family (lsfa_conv_split_fwd and its view / phase forms: conv2 and "
                     "the DCN branch of the ResNet units, feat_conv_3x3, fuse_reduce_add, FlowNet, the Nq net, the small net's 3x3s) incl. "
                     "their reduce / fix-up passes, %d calls of one interval" % conv_n,
-                    "achieved": round(tf, 1), "peak": MFMA_SPLIT_PEAK_TFLOPS, "unit": "TFLOP/s",
-                    "frac": round(tf / MFMA_SPLIT_PEAK_TFLOPS, 4),
+                    "achieved": round(tf, 1), "peak": round(mix_peak, 1), "unit": "TFLOP/s",
+                    "frac": round(tf / mix_peak, 4),
+                    "flops_share_on_three_products": round(fl3 / conv_fl, 3),
                     "traffic": load_traffic("conv_split:%dx%d,interval=%d,%s" % (args.width, args.height, args.interval, args.dtype)),
                     "launches": conv_n, "avg_us": round(conv_ms * 1e3 / conv_n, 2),
                     "algorithmic_flops_per_launch": round(conv_fl / max(conv_calls, 1)),
-                    "bf16_mfma_work": {"achieved": round(6 * tf, 1), "peak": 2500.0, "unit": "TFLOP/s"},
+                    "bf16_mfma_work": {"achieved": round((6 * (conv_fl - fl3) + 3 * fl3) / (conv_ms * 1e-3) / 1e12, 1), "peak": 2500.0, "unit": "TFLOP/s"},
                     "fp32_mfma_pipe_peak": 157.3,
                     "measured": "HIP events around each lsfa_conv_split_fwd / lsfa_conv_nhwc_fused_fwd call (conv kernel + its reduce "
                                 "pass) of one interval re-issued eagerly after the timed region; algorithmic FLOPs = 2*M*N*K summed "
                                 "over the same calls; traffic = HBM bytes per call of the kernel family (FETCH_SIZE x2 + WRITE_SIZE, separate "
                                 "rocprofv3 PMC passes over the eager loop, profiles/traffic.json), null if no profile of this configuration is "
                                 "committed",
-                    "note": "fp32 in / fp32 accumulate; every fp32 product is six bf16 partial products on the bf16 matrix pipe, so "
-                            "the peak for fp32-equivalent FLOPs is the dense bf16 peak / 6 (2500 / 6); the fp32 matrix instructions "
-                            "peak at 157.3"}
+                    "note": "fp32 in / fp32 accumulate; every fp32 product is six bf16 partial products on the bf16 matrix pipe (peak for "
+                            "fp32-equivalent FLOPs 2500 / 6 = 416.7) or, on the calls that ran the fp16 two-piece form, three fp16 ones "
+                            "(2500 / 3 = 833.3); `peak` is the FLOP-weighted harmonic mix of the two; the fp32 matrix instructions peak "
+                            "at 157.3"}
         else:
             roof = roof_hbm
         line = {

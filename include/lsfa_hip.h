@@ -270,6 +270,20 @@ int lsfa_conv_nhwc_fused_fwd(const float* x, int N, int H, int W, int Cin, const
  * and the 2-stage ring (the r2 kernel), 2 = 128 x 128 tiles wherever Cout % 128 == 0, 3 = as 0 without the 4-stage ring.  The k order
  * per output is the same in every variant; results differ only where the number of K slices does. */
 int lsfa_conv_split_set_variant(int variant);
+
+/* r3 (opt-in): the same convolution with fp32 operands cut into TWO fp16 pieces and three matrix instructions per product
+ * (hi*hi + hi*lo + lo*hi, fp32 accumulate; as close to float64 as the three-piece bf16 form, half its matrix-pipe cycles).
+ * fp16's exponent range makes it need a bound on max|x|: `amax` = the 256 partial maxima lsfa_amax_partial wrote for x (or for a map
+ * that bounds x, e.g. the input of an interpolation); the weights are packed as w * 2^w_exp with max|w| * 2^w_exp in [2^13, 2^14).
+ * 128 x 128 tiles: Cout % 128 == 0, Cin % 32 == 0.  Non-finite inputs give non-finite outputs, not necessarily the same ones as fp32.
+ * Replaces the same reference convolutions as lsfa_conv_split_fwd (e.g. feat_conv_3x3, resnet_v1_101_flownet_rfcn.py:44-55). */
+size_t lsfa_conv_split_h_weight_bytes(int Cout, int kh, int kw, int Cin);
+int lsfa_conv_split_h_weights(const float* w, int Cout, int kh, int kw, int Cin, int w_exp, void* out, void* stream);
+int lsfa_amax_partial(const float* x, long long n, float* out256, void* stream);
+size_t lsfa_conv_split_h_workspace_bytes(int N, int H, int W, int Cin, int Cout, int kh, int kw, int stride, int pad, int dil);
+int lsfa_conv_split_h_fwd(const float* x, const void* wfrag_h, int w_exp, const float* amax, const float* bias, int N, int H, int W,
+                          int Cin, int Cout, int kh, int kw, int stride, int pad, int dil, int act, int y_nchw, float* y, void* ws,
+                          size_t ws_bytes, void* stream);
 size_t lsfa_conv_split_weight_bytes(int Cout, int kh, int kw, int Cin);
 int lsfa_conv_split_weights(const float* w, int Cout, int kh, int kw, int Cin, void* wfrag, void* stream);
 size_t lsfa_conv_split_workspace_bytes(int N, int H, int W, int Cin, int Cout, int kh, int kw, int stride, int pad, int dil);

@@ -411,6 +411,31 @@ extern "C" int lsfa_conv_split_weights(const float* w, int Cout, int kh, int kw,
 
 namespace {
 // every split convolution goes through here; the public entry points fill in what they expose
+// the fp16 two-piece form runs on the 128 x 128 tiles only: K slices by the same cost model (a chunk ~1.1 us: 24 instead of 48 matrix
+// instructions per wave next to the same DMAs)
+SplitPlan wide_h_plan(long P, int Cin, int Cout, int kh, int kw) {
+  SplitPlan p = {};
+  p.nt = 4;
+  p.ny = Cout / 128;
+  p.nx = (int)((P + convsplit::kWgPix - 1) / convsplit::kWgPix);
+  const int chunk_total = kh * kw * (Cin / 32);
+  const long wgs = (long)p.nx * p.ny;
+  const double out_mb = (double)P * Cout * 4.0 / 1e6;
+  double best = 0;
+  int best_s = 1;
+  for (int s = 1; s <= 16; ++s) {
+    if (s > 1 && chunk_total / s < 8) break;
+    const int per = (chunk_total + s - 1) / s;
+    if ((chunk_total + per - 1) / per != s) continue;
+    const long rounds = (wgs * s + 511) / 512;
+    const double t = (double)rounds * per * 1.1 + (s > 1 ? 3.0 + s * out_mb * 2.0 / 3.0 : 0.0);
+    if (s == 1 || t < best * 0.97) { best = t; best_s = s; }
+  }
+  p.per_slice = (chunk_total + best_s - 1) / best_s;
+  p.slices = (chunk_total + p.per_slice - 1) / p.per_slice;
+  return p;
+}
+
 // LSFA_CONV_TILE_ORDER (lab): how workgroup ids map to (slice, channel tile, pixel tile), see xcd_tile
 static int tile_order_from_env() {
   const char* e = getenv("LSFA_CONV_TILE_ORDER");
@@ -455,6 +480,10 @@ int conv_split_launch(convsplit::Args a, void* ws, size_t ws_bytes, void* stream
     p.slices = 1;
   }
   const int nph = a.nphase > 1 ? a.nphase : 1;
+  if (a.amax) {      // the fp16 two-piece form: 128 x 128 tiles, plain launches
+    LSFA_REQUIRE(Cout % 128 == 0 && nph == 1, "%s: the fp16 form needs Cout %% 128 == 0 and no phases", who);
+    p = wide_h_plan(P, Cin, Cout, kh, kw);
+  }
   const size_t need = split_workspace(p, P, Cout) * (size_t)nph;
   if ((p.slices > 1 || p.units_per_wg > 0) && (!ws || ws_bytes < need)) {
     set_error("%s: workspace %zu < %zu bytes", who, ws_bytes, need);
@@ -487,6 +516,8 @@ int conv_split_launch(convsplit::Args a, void* ws, size_t ws_bytes, void* stream
     hipLaunchKernelGGL(convsplit::conv_split3x3_kernel<1>, grid, dim3(convsplit::kThreads), 0, s, a, p.patches_x, p.patches_y, p.nx, p.ny, p.slices);
   else if (p.halo)
     hipLaunchKernelGGL(convsplit::conv_split3x3_kernel<2>, grid, dim3(convsplit::kThreads), 0, s, a, p.patches_x, p.patches_y, p.nx, p.ny, p.slices);
+  else if (a.amax)
+    hipLaunchKernelGGL((convsplit::conv_split_wide_kernel<4, 2>), grid, dim3(convsplit::kThreads), 0, s, a, p.nx, p.ny, p.slices * nph);
   else if (p.nt == 4)
     hipLaunchKernelGGL(convsplit::conv_split_wide_kernel<4>, grid, dim3(convsplit::kThreads), 0, s, a, p.nx, p.ny, p.slices * nph);
   else if (p.deep)
@@ -513,6 +544,52 @@ extern "C" size_t lsfa_conv_split_workspace_bytes(int N, int H, int W, int Cin, 
   if (Ho <= 0 || Wo <= 0) return 0;
   const SplitPlan p = split_plan(N, H, W, Cin, Cout, kh, kw, stride, pad, dil);
   return split_workspace(p, (long)N * Ho * Wo, Cout);
+}
+
+// ---- r3 (opt-in): the fp16 two-piece form (three matrix instructions per product; conv_split_kernel.h) ------------------------------
+extern "C" size_t lsfa_conv_split_h_weight_bytes(int Cout, int kh, int kw, int Cin) {
+  if (Cout <= 0 || kh <= 0 || kw <= 0 || Cin <= 0) return 0;
+  return (size_t)Cout * kh * kw * Cin * 4;        // two fp16 pieces per weight
+}
+
+extern "C" int lsfa_conv_split_h_weights(const float* w, int Cout, int kh, int kw, int Cin, int w_exp, void* out, void* stream) {
+  LSFA_REQUIRE(w && out, "lsfa_conv_split_h_weights: NULL argument");
+  LSFA_REQUIRE(Cout > 0 && Cout % 128 == 0 && Cin > 0 && Cin % 32 == 0 && kh > 0 && kw > 0,
+               "lsfa_conv_split_h_weights: Cout=%d must be a multiple of 128 and Cin=%d of 32", Cout, Cin);
+  LSFA_REQUIRE(w_exp > -120 && w_exp < 120, "lsfa_conv_split_h_weights: w_exp %d out of range", w_exp);
+  const long total = (long)kh * kw * (Cin / 32) * (Cout / 32) * 2 * 64;
+  hipLaunchKernelGGL(convsplit::split_weights_h_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, w,
+                     (uint4*)out, Cout, kh * kw, Cin, w_exp);
+  LSFA_LAUNCH_CHECK("lsfa_conv_split_h_weights");
+  return LSFA_OK;
+}
+
+extern "C" int lsfa_amax_partial(const float* x, long long n, float* out, void* stream) {
+  LSFA_REQUIRE(x && out && n > 0 && n % 4 == 0 && ((uintptr_t)x & 15) == 0, "lsfa_amax_partial: x must be 16-byte aligned, n a positive multiple of 4");
+  hipLaunchKernelGGL(convsplit::amax_partial_kernel, dim3(convsplit::kAmaxSlots), dim3(256), 0, (hipStream_t)stream, (const float4*)x,
+                     (long)(n / 4), out);
+  LSFA_LAUNCH_CHECK("lsfa_amax_partial");
+  return LSFA_OK;
+}
+
+extern "C" size_t lsfa_conv_split_h_workspace_bytes(int N, int H, int W, int Cin, int Cout, int kh, int kw, int stride, int pad, int dil) {
+  if (N <= 0 || H <= 0 || W <= 0 || Cout <= 0 || Cout % 128 || Cin <= 0 || stride <= 0 || kh <= 0 || kw <= 0 || dil <= 0 || pad < 0) return 0;
+  const int Ho = (H + 2 * pad - dil * (kh - 1) - 1) / stride + 1, Wo = (W + 2 * pad - dil * (kw - 1) - 1) / stride + 1;
+  if (Ho <= 0 || Wo <= 0) return 0;
+  const SplitPlan p = wide_h_plan((long)N * Ho * Wo, Cin, Cout, kh, kw);
+  return split_workspace(p, (long)N * Ho * Wo, Cout);
+}
+
+extern "C" int lsfa_conv_split_h_fwd(const float* x, const void* wfrag_h, int w_exp, const float* amax, const float* bias, int N, int H,
+                                     int W, int Cin, int Cout, int kh, int kw, int stride, int pad, int dil, int act, int y_nchw,
+                                     float* y, void* ws, size_t ws_bytes, void* stream) {
+  LSFA_REQUIRE(amax, "lsfa_conv_split_h_fwd: amax (lsfa_amax_partial of x, or of a map that bounds it) must be given");
+  convsplit::Args a = {};
+  a.x = x; a.wfrag = (const uint4*)wfrag_h; a.bias = bias; a.y = y;
+  a.N = N; a.H = H; a.W = W; a.Cin = Cin; a.Cout = Cout; a.kh = kh; a.kw = kw; a.stride = stride; a.pad_h = a.pad_w = pad; a.dil = dil;
+  a.act = act; a.y_nchw = y_nchw;
+  a.amax = amax; a.w_exp = w_exp;
+  return conv_split_launch(a, ws, ws_bytes, stream, "lsfa_conv_split_h_fwd");
 }
 
 // Deconvolution(kernel 4, stride 2, pad 0) + Crop(offset (1,1)) to Hc x Wc as ONE launch of four 2x2-tap phase convolutions.

@@ -70,6 +70,9 @@ struct Args {
   // ph_wstride uint4 behind the previous phase's (everything a phase needs follows from (py, px): a table in the argument
   // struct would be indexed dynamically, which makes hipcc keep the struct in scratch)
   int nphase; long part_stride; long ph_wstride;
+  // r3, fp16 two-piece form (conv_split_wide_kernel<NT, 2>): `amax` = kAmaxSlots partial maxima of |x| (lsfa_amax_partial), from which
+  // every wave derives the power-of-two scale that puts x into fp16's range; the weights were packed as w * 2^w_exp
+  const float* amax; int w_exp;
   int tile_order;   // 0: tiles numbered (slice, channel tile, pixel tile), pixel fastest; 1: (slice, pixel tile, channel tile), channel fastest
 };
 
@@ -137,6 +140,61 @@ __device__ __forceinline__ f32x16 mma6(const Pieces& a, const uint4& b1, const u
   acc = mma(a.p1, b2, acc);
   acc = mma(a.p1, b1, acc);
   return acc;
+}
+
+// ---- r3 (opt-in): fp16 in TWO pieces, three matrix instructions per k-step ----------------------------------------------------------
+// hi = fp16(x s), lo = fp16(x s - hi), s a power of two that puts max|x| into [2^13, 2^14): x s = hi + lo to 2^-24 relative (like fp32
+// itself; below 2^-3 of the scaled range lo goes subnormal and the absolute error is 2^-25 of that range), and
+// x y = hi hi + hi lo + lo hi + (lo lo <= 2^-24 |x y|, dropped).  Same accumulator, smallest terms first.  Against float64 this is as
+// close as the bf16 three-piece form and closer (tools/lab/split_numerics.py), with half the matrix-pipe cycles, which is what the
+// large convolutions are bound by.
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+constexpr int kAmaxSlots = 256;
+
+struct PiecesH { uint4 hi, lo; };
+
+__device__ __forceinline__ void cut2h(float v, float s, uint32_t& h, uint32_t& l) {
+  const float xs = v * s;                         // exact: s is a power of two
+  const _Float16 hh = (_Float16)xs;               // round to nearest even
+  const float r = xs - (float)hh;                 // exact
+  const _Float16 ll = (_Float16)r;
+  h = (uint32_t)__builtin_bit_cast(unsigned short, hh);
+  l = (uint32_t)__builtin_bit_cast(unsigned short, ll);
+}
+
+__device__ __forceinline__ PiecesH split8h(const float4& a, const float4& b, float s) {
+  uint32_t h[8], l[8];
+  cut2h(a.x, s, h[0], l[0]); cut2h(a.y, s, h[1], l[1]); cut2h(a.z, s, h[2], l[2]); cut2h(a.w, s, h[3], l[3]);
+  cut2h(b.x, s, h[4], l[4]); cut2h(b.y, s, h[5], l[5]); cut2h(b.z, s, h[6], l[6]); cut2h(b.w, s, h[7], l[7]);
+  PiecesH r;
+  r.hi = make_uint4(h[0] | (h[1] << 16), h[2] | (h[3] << 16), h[4] | (h[5] << 16), h[6] | (h[7] << 16));
+  r.lo = make_uint4(l[0] | (l[1] << 16), l[2] | (l[3] << 16), l[4] | (l[5] << 16), l[6] | (l[7] << 16));
+  return r;
+}
+
+__device__ __forceinline__ f16x8 as_h(const uint4& u) {
+  union { uint4 u; f16x8 v; } c;
+  c.u = u;
+  return c.v;
+}
+
+__device__ __forceinline__ f32x16 mma3h(const PiecesH& a, const uint4& bhi, const uint4& blo, f32x16 acc) {
+  acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(as_h(a.lo), as_h(bhi), acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(as_h(a.hi), as_h(blo), acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(as_h(a.hi), as_h(bhi), acc, 0, 0, 0);
+  return acc;
+}
+
+// floor(log2(max of the kAmaxSlots partial maxima)) of a finite positive maximum, 0 for an all-zero (or non-finite) map; wave-uniform
+__device__ __forceinline__ int amax_exponent(const float* __restrict__ amax, int lane) {
+  float m = 0.f;
+#pragma unroll
+  for (int i = 0; i < kAmaxSlots / 64; ++i) m = fmaxf(m, amax[i * 64 + lane]);
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) m = fmaxf(m, __shfl_xor(m, d, 64));
+  const uint32_t bits = __float_as_uint(m);
+  const int e = (int)((bits >> 23) & 255u);
+  return (e == 0 || e == 255) ? 0 : __builtin_amdgcn_readfirstlane(e - 127);
 }
 
 // ---- epilogue shared by the kernels below -----------------------------------------------------------------------
@@ -582,15 +640,17 @@ static __global__ __launch_bounds__(kThreads, 1) void conv_split_deep_kernel(Arg
 // groups so that they go out while the matrix pipe drains.  Stage = 16 KB A + NT*6 KB B; two stages, two workgroups per CU
 // (NT = 4: 2 x 80 KB = the CU's whole LDS).  Everything else (A image and swizzle, B fragment order, K slices, epilogue) as
 // conv_split_kernel.
-template <int NT> struct Wide {
-  static constexpr int kStageBn = NT * 384;                 // uint4 of B per stage
+// PC = pieces per weight: 3 (bf16, six products) or 2 (fp16, three products: the opt-in form above)
+template <int NT, int PC = 3> struct Wide {
+  static constexpr int kColTile = 128 * PC;                 // uint4 of one 32-column tile of one chunk: 2 steps x PC pieces x 64 lanes
+  static constexpr int kStageBn = NT * kColTile;            // uint4 of B per stage
   static constexpr int kStageN = kStageA + kStageBn;
-  static constexpr int kDmaB = (NT * 384) / (4 * 64);       // B DMA instructions per wave and chunk: NT * 1.5
-  static_assert((NT * 384) % 256 == 0, "NT must be even");
+  static constexpr int kDmaB = (NT * kColTile) / (4 * 64);  // B DMA instructions per wave and chunk: NT * PC / 2
+  static_assert((NT * kColTile) % 256 == 0, "NT must be even");
 };
 
-template <int NT, int ST>
-__device__ __forceinline__ void wide_issue_a(uint4 (*S)[Wide<NT>::kStageN], const float* __restrict__ x, const Geom& g, const Walk& wk) {
+template <int NT, int ST, int PC = 3>
+__device__ __forceinline__ void wide_issue_a(uint4 (*S)[(Wide<NT, PC>::kStageN)], const float* __restrict__ x, const Geom& g, const Walk& wk) {
   const int dy = wk.ty * g.dil, dx = wk.tx * g.dil;
   const int doff = (dy * g.W + dx) * g.lda + wk.kc * kChunk;
   uint4* a_dst = &S[ST][g.wave * 256];
@@ -603,21 +663,21 @@ __device__ __forceinline__ void wide_issue_a(uint4 (*S)[Wide<NT>::kStageN], cons
 }
 
 // B DMA instructions I0 .. I1-1 of this wave's share (Wide<NT>::kDmaB in all) of chunk `gch`
-template <int NT, int ST, int I0, int I1>
-__device__ __forceinline__ void wide_issue_b(uint4 (*S)[Wide<NT>::kStageN], const uint4* __restrict__ wblock, const Geom& g, int gch) {
-  const uint4* wsrc = wblock + (size_t)gch * g.wstride + g.wave * (Wide<NT>::kDmaB * 64) + g.lane;
-  uint4* b_dst = &S[ST][kStageA + g.wave * (Wide<NT>::kDmaB * 64)];
+template <int NT, int ST, int I0, int I1, int PC = 3>
+__device__ __forceinline__ void wide_issue_b(uint4 (*S)[(Wide<NT, PC>::kStageN)], const uint4* __restrict__ wblock, const Geom& g, int gch) {
+  const uint4* wsrc = wblock + (size_t)gch * g.wstride + g.wave * (Wide<NT, PC>::kDmaB * 64) + g.lane;
+  uint4* b_dst = &S[ST][kStageA + g.wave * (Wide<NT, PC>::kDmaB * 64)];
 #pragma unroll
   for (int i = I0; i < I1; ++i) __builtin_amdgcn_global_load_lds(wsrc + i * 64, b_dst + i * 64, 16, 0, 0);
 }
 
-template <int NT, int ST>
-__device__ __forceinline__ void wide_step(uint4 (*S)[Wide<NT>::kStageN], const float* __restrict__ x, const uint4* __restrict__ wblock,
-                                          const Geom& g, Walk& wk, int c, int n, f32x16 (&acc)[NT]) {
-  constexpr int kDmaB = Wide<NT>::kDmaB;
+template <int NT, int ST, int PC = 3>
+__device__ __forceinline__ void wide_step(uint4 (*S)[(Wide<NT, PC>::kStageN)], const float* __restrict__ x, const uint4* __restrict__ wblock,
+                                          const Geom& g, Walk& wk, int c, int n, f32x16 (&acc)[NT], float a_scale = 1.f) {
+  constexpr int kDmaB = Wide<NT, PC>::kDmaB;
   const bool more = c + 1 < n;
   const int gch_next = wk.gch;
-  if (more) wide_issue_a<NT, ST ^ 1>(S, x, g, wk);
+  if (more) wide_issue_a<NT, ST ^ 1, PC>(S, x, g, wk);
   const uint4* A = &S[ST][g.wave * 256];
   const uint4* B = &S[ST][kStageA + g.lane];
   const uint4 r0 = A[g.frag[0]], r1 = A[g.frag[1]], r2 = A[g.frag[2]], r3 = A[g.frag[3]];
@@ -625,18 +685,28 @@ __device__ __forceinline__ void wide_step(uint4 (*S)[Wide<NT>::kStageN], const f
   const float4 c1 = make_float4(__uint_as_float(r1.x), __uint_as_float(r1.y), __uint_as_float(r1.z), __uint_as_float(r1.w));
   const float4 c2 = make_float4(__uint_as_float(r2.x), __uint_as_float(r2.y), __uint_as_float(r2.z), __uint_as_float(r2.w));
   const float4 c3 = make_float4(__uint_as_float(r3.x), __uint_as_float(r3.y), __uint_as_float(r3.z), __uint_as_float(r3.w));
-  const Pieces s0 = split8(c0, c1), s1 = split8(c2, c3);
+  Pieces s0, s1;
+  PiecesH h0, h1;
+  if (PC == 3) { s0 = split8(c0, c1); s1 = split8(c2, c3); }
+  else { h0 = split8h(c0, c1, a_scale); h1 = split8h(c2, c3, a_scale); }
 #pragma unroll
   for (int t = 0; t < NT; ++t) {
-    // fragment (col tile t, step s, piece p) at ((t*2 + s)*3 + p)*64 + lane
-    acc[t] = mma6(s0, B[((t * 2 + 0) * 3 + 0) * 64], B[((t * 2 + 0) * 3 + 1) * 64], B[((t * 2 + 0) * 3 + 2) * 64], acc[t]);
-    acc[t] = mma6(s1, B[((t * 2 + 1) * 3 + 0) * 64], B[((t * 2 + 1) * 3 + 1) * 64], B[((t * 2 + 1) * 3 + 2) * 64], acc[t]);
+    // fragment (col tile t, step s, piece p) at ((t*2 + s)*PC + p)*64 + lane
+    if (PC == 3) {
+      acc[t] = mma6(s0, B[((t * 2 + 0) * 3 + 0) * 64], B[((t * 2 + 0) * 3 + 1) * 64], B[((t * 2 + 0) * 3 + 2) * 64], acc[t]);
+      acc[t] = mma6(s1, B[((t * 2 + 1) * 3 + 0) * 64], B[((t * 2 + 1) * 3 + 1) * 64], B[((t * 2 + 1) * 3 + 2) * 64], acc[t]);
+    } else {
+      acc[t] = mma3h(h0, B[((t * 2 + 0) * 2 + 0) * 64], B[((t * 2 + 0) * 2 + 1) * 64], acc[t]);
+      acc[t] = mma3h(h1, B[((t * 2 + 1) * 2 + 0) * 64], B[((t * 2 + 1) * 2 + 1) * 64], acc[t]);
+    }
     if (more) {      // this wave's share of the next chunk's weights, a slice behind each column tile's MFMAs
       constexpr int kPer = (kDmaB + NT - 1) / NT;
       constexpr int kE1 = (2 * kPer < kDmaB) ? 2 * kPer : kDmaB;
-      if (t == 0) wide_issue_b<NT, ST ^ 1, 0, kPer>(S, wblock, g, gch_next);
-      if (NT > 1 && t == 1) wide_issue_b<NT, ST ^ 1, kPer, kE1>(S, wblock, g, gch_next);
-      if (NT > 2 && t == 2) wide_issue_b<NT, ST ^ 1, kE1, kDmaB>(S, wblock, g, gch_next);
+      constexpr int kE2 = (3 * kPer < kDmaB) ? 3 * kPer : kDmaB;
+      if (t == 0) wide_issue_b<NT, ST ^ 1, 0, kPer, PC>(S, wblock, g, gch_next);
+      if (NT > 1 && t == 1) wide_issue_b<NT, ST ^ 1, kPer, kE1, PC>(S, wblock, g, gch_next);
+      if (NT > 2 && t == 2) wide_issue_b<NT, ST ^ 1, kE1, (NT > 3 ? kE2 : kDmaB), PC>(S, wblock, g, gch_next);
+      if (NT > 3 && t == 3) wide_issue_b<NT, ST ^ 1, kE2, kDmaB, PC>(S, wblock, g, gch_next);
     }
   }
   if (more) wk.next(g.kw, g.chunks_per_tap);
@@ -646,9 +716,9 @@ __device__ __forceinline__ void wide_step(uint4 (*S)[Wide<NT>::kStageN], const f
 }
 
 // grid (8 * ceil(tiles / 8)); block 256.  tiles = ceil(P / 128) * (Cout / (32*NT)) * slices
-template <int NT>
+template <int NT, int PC = 3>
 static __global__ __launch_bounds__(kThreads, 2) void conv_split_wide_kernel(Args a, int nx, int ny, int nz) {
-  typedef Wide<NT> WD;
+  typedef Wide<NT, PC> WD;
   __shared__ __attribute__((aligned(16))) uint4 S[2][WD::kStageN];
   Tile tile = xcd_tile(blockIdx.x, nx, ny, nz, a.tile_order);
   if (tile.x < 0) return;
@@ -666,8 +736,8 @@ static __global__ __launch_bounds__(kThreads, 2) void conv_split_wide_kernel(Arg
   g.chunk0 = tile.z * a.chunks_per_slice;
   const int nchunks = min(a.chunks_per_slice, chunk_total - g.chunk0);
   const int col_tiles = a.Cout / 32;
-  g.wstride = (size_t)col_tiles * (kChunkBytesB / 32);
-  const uint4* wblock = a.wfrag + (size_t)(NT * tile.y) * (kChunkBytesB / 32);
+  g.wstride = (size_t)col_tiles * WD::kColTile;
+  const uint4* wblock = a.wfrag + (size_t)(NT * tile.y) * WD::kColTile;
   const int m0 = tile.x * kWgPix + g.wave * kWavePix;
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
@@ -702,15 +772,28 @@ static __global__ __launch_bounds__(kThreads, 2) void conv_split_wide_kernel(Arg
     wk.tx = tap - wk.ty * a.kw;
   }
   if (nchunks > 0) {
-    wide_issue_a<NT, 0>(S, a.x, g, wk);
-    wide_issue_b<NT, 0, 0, WD::kDmaB>(S, wblock, g, wk.gch);
+    wide_issue_a<NT, 0, PC>(S, a.x, g, wk);
+    wide_issue_b<NT, 0, 0, WD::kDmaB, PC>(S, wblock, g, wk.gch);
     wk.next(g.kw, g.chunks_per_tap);
+  }
+  // fp16 form: the scale that puts max|x| into [2^13, 2^14), and its inverse together with the weights' (both powers of two: exact)
+  float a_scale = 1.f, out_scale = 1.f;
+  if (PC == 2) {
+    const int s_exp = 13 - amax_exponent(a.amax, g.lane);
+    a_scale = ldexpf(1.f, s_exp);
+    out_scale = ldexpf(1.f, -(s_exp + a.w_exp));
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
   for (int c = 0; c < nchunks; c += 2) {
-    wide_step<NT, 0>(S, a.x, wblock, g, wk, c, nchunks, acc);
-    if (c + 1 < nchunks) wide_step<NT, 1>(S, a.x, wblock, g, wk, c + 1, nchunks, acc);
+    wide_step<NT, 0, PC>(S, a.x, wblock, g, wk, c, nchunks, acc, a_scale);
+    if (c + 1 < nchunks) wide_step<NT, 1, PC>(S, a.x, wblock, g, wk, c + 1, nchunks, acc, a_scale);
+  }
+  if (PC == 2) {
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) acc[t][i] = acc[t][i] * out_scale;
   }
 
   const int lane = g.lane;
@@ -1128,6 +1211,42 @@ static __global__ void split_weights_kernel(const float* __restrict__ w, uint4* 
   const Pieces p = split8(v0, v1);
   uint4* dst = out + ((((size_t)g * col_tiles + t) * 2 + s) * 3) * 64 + lane;
   dst[0] = p.p1; dst[64] = p.p2; dst[128] = p.p3;
+}
+
+// the fp16 two-piece form of the same: values w * 2^w_exp, pieces (hi, lo); out index ((((g * col_tiles + t) * 2 + s) * 2 + piece) * 64 + lane)
+static __global__ void split_weights_h_kernel(const float* __restrict__ w, uint4* __restrict__ out, int Cout, int taps, int Cin, int w_exp) {
+  const int col_tiles = Cout / 32, chunks = Cin / kChunk;
+  const long total = (long)taps * chunks * col_tiles * 2 * 64;
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  const int lane = (int)(i & 63);
+  long r = i >> 6;
+  const int s = (int)(r & 1); r >>= 1;
+  const int t = (int)(r % col_tiles); r /= col_tiles;
+  const int g = (int)r;
+  const int tap = g / chunks, kc = g - tap * chunks;
+  const int co = t * 32 + (lane & 31);
+  const int ci = kc * kChunk + 16 * (lane >> 5) + 8 * s;
+  const float* src = w + ((size_t)co * taps + tap) * Cin + ci;
+  const float4 v0 = *reinterpret_cast<const float4*>(src), v1 = *reinterpret_cast<const float4*>(src + 4);
+  const PiecesH p = split8h(v0, v1, ldexpf(1.f, w_exp));
+  uint4* dst = out + ((((size_t)g * col_tiles + t) * 2 + s) * 2) * 64 + lane;
+  dst[0] = p.hi; dst[64] = p.lo;
+}
+
+// partial maxima of |x| for the fp16 form's scale: kAmaxSlots workgroups, slot b = max over its grid-stride share (0 for an empty share)
+static __global__ __launch_bounds__(256) void amax_partial_kernel(const float4* __restrict__ x, long n4, float* __restrict__ out) {
+  __shared__ float red[4];
+  float m = 0.f;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
+    const float4 v = x[i];
+    m = fmaxf(m, fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w))));
+  }
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) m = fmaxf(m, __shfl_xor(m, d, 64));
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+  __syncthreads();
+  if (threadIdx.x == 0) out[blockIdx.x] = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
 }
 
 }  // namespace convsplit

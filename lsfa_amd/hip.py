@@ -43,6 +43,7 @@ def lib():
         for name in ("lsfa_proposal_workspace_bytes", "lsfa_nms_workspace_bytes", "lsfa_det_workspace_bytes",
                      "lsfa_mv_workspace_bytes", "lsfa_conv_nhwc_workspace_bytes", "lsfa_conv_split_weight_bytes",
                      "lsfa_conv_split_workspace_bytes", "lsfa_conv_split_view_workspace_bytes",
+                     "lsfa_conv_split_h_weight_bytes", "lsfa_conv_split_h_workspace_bytes",
                      "lsfa_deconv4x4s2_crop_workspace_bytes"):
             getattr(L, name).restype = ctypes.c_size_t
         L.lsfa_op_name.restype = ctypes.c_char_p
@@ -398,21 +399,28 @@ def scale_shift_relu_cl(x, scale, shift, relu=True, out=None):
 
 # algorithmic FLOPs (2*M*N*K, fp32-equivalent) of the own convolutions issued since the last reset: bench.py divides
 # them by the event-timed duration of the same launches for its MFMA roofline
-_conv_flops = {"count": False, "flops": 0.0, "launches": 0}
+_conv_flops = {"count": False, "flops": 0.0, "launches": 0, "flops_three_products": 0.0}
 
 
 def conv_flops_reset(enable=True):
-    _conv_flops.update(count=bool(enable), flops=0.0, launches=0)
+    _conv_flops.update(count=bool(enable), flops=0.0, launches=0, flops_three_products=0.0)
 
 
 def conv_flops_read():
     return _conv_flops["flops"], _conv_flops["launches"]
 
 
-def _count_conv(N, Ho, Wo, Cout, Cin, kh, kw):
+def conv_flops_three_products():
+    """the part of conv_flops_read()'s FLOPs that ran on the fp16 two-piece form (three matrix instructions per product, not six)"""
+    return _conv_flops["flops_three_products"]
+
+
+def _count_conv(N, Ho, Wo, Cout, Cin, kh, kw, three_products=False):
     if _conv_flops["count"]:
         _conv_flops["flops"] += 2.0 * N * Ho * Wo * Cout * Cin * kh * kw
         _conv_flops["launches"] += 1
+        if three_products:
+            _conv_flops["flops_three_products"] += 2.0 * N * Ho * Wo * Cout * Cin * kh * kw
 
 
 def conv_weight_kc(weight):
@@ -628,6 +636,63 @@ def conv_split(x, sw, bias=None, stride=1, pad=0, dil=1, relu=False, out=None, r
                                      _ptr(out), _ptr(out2), _ptr(scale2), _ptr(shift2), _ptr(ws), ctypes.c_size_t(need), _stream()),
            "lsfa_conv_split_fwd")
     return out if out2 is None else (out, out2)
+
+
+class SplitWeightH(object):
+    """r3 (opt-in): a convolution weight cut into TWO fp16 pieces per value (values scaled by 2^w_exp so that the largest lands in
+    [2^13, 2^14)) in MFMA fragment order (lsfa_conv_split_h_weights); made once per layer at bind time.  Cout % 128 == 0."""
+
+    def __init__(self, weight):
+        w_kc = _f32c(conv_weight_kc(weight), "weight")
+        self.cout, self.cin, self.kh, self.kw = [int(v) for v in weight.shape]
+        self.real_cout, self.real_cin = self.cout, self.cin
+        need = lib().lsfa_conv_split_h_weight_bytes(_ci(self.cout), _ci(self.kh), _ci(self.kw), _ci(self.cin))
+        if need == 0 or self.cout % 128 or self.cin % 32:
+            raise LsfaError("SplitWeightH: Cin=%d must be a multiple of 32 and Cout=%d of 128" % (self.cin, self.cout))
+        amax = float(weight.abs().max().item())              # bind time: a host synchronisation is fine here
+        import math
+        self.w_exp = 0 if not (amax > 0 and math.isfinite(amax)) else 13 - int(math.floor(math.log2(amax)))
+        self.w_exp = max(-100, min(100, self.w_exp))
+        self.frag = torch.empty(need, dtype=torch.uint8, device=weight.device)
+        with torch.cuda.device(weight.device):
+            _check(lib().lsfa_conv_split_h_weights(_ptr(w_kc), _ci(self.cout), _ci(self.kh), _ci(self.kw), _ci(self.cin), _ci(self.w_exp),
+                                                   _ptr(self.frag), _stream()), "lsfa_conv_split_h_weights")
+
+
+@_on_tensor_device
+def amax_partial(x, out=None):
+    """lsfa_amax_partial: 256 partial maxima of |x| (float32, contiguous, numel % 4 == 0): what conv_split_h derives its scale from."""
+    x = _f32c(x, "x")
+    if out is None:
+        out = torch.empty(256, device=x.device, dtype=torch.float32)
+    _check(lib().lsfa_amax_partial(_ptr(x), ctypes.c_longlong(x.numel()), _ptr(out), _stream()), "lsfa_amax_partial")
+    return out
+
+
+@_on_tensor_device
+def conv_split_h(x, swh, bias=None, stride=1, pad=0, dil=1, act=0, out=None, nchw=False, amax=None):
+    """lsfa_conv_split_h_fwd: the convolution with fp32 operands cut into two fp16 pieces, three matrix instructions per product.
+    amax: the partial maxima of x (amax_partial(x)) or of a map that bounds |x|; computed here when not given (one more launch)."""
+    x = _f32c(x, "x")
+    N, H, W, Cin = x.shape
+    if Cin != swh.cin:
+        raise LsfaError("conv_split_h: input has %d channels, the weight %d" % (Cin, swh.cin))
+    Cout, kh, kw = swh.cout, swh.kh, swh.kw
+    Ho, Wo = (H + 2 * pad - dil * (kh - 1) - 1) // stride + 1, (W + 2 * pad - dil * (kw - 1) - 1) // stride + 1
+    if out is None:
+        out = torch.empty((N, Cout, Ho, Wo) if nchw else (N, Ho, Wo, Cout), device=x.device, dtype=torch.float32)
+    elif out.numel() != N * Ho * Wo * Cout or not out.is_contiguous() or out.dtype != torch.float32:
+        raise LsfaError("conv_split_h: out must be a contiguous float32 tensor of %d elements" % (N * Ho * Wo * Cout))
+    if amax is None:
+        amax = amax_partial(x)
+    _count_conv(N, Ho, Wo, swh.real_cout, swh.real_cin, kh, kw, three_products=True)
+    need = lib().lsfa_conv_split_h_workspace_bytes(_ci(N), _ci(H), _ci(W), _ci(Cin), _ci(Cout), _ci(kh), _ci(kw), _ci(stride), _ci(pad),
+                                                   _ci(dil))
+    ws = torch.empty(max(need, 16), dtype=torch.uint8, device=x.device)
+    _check(lib().lsfa_conv_split_h_fwd(_ptr(x), _ptr(swh.frag), _ci(swh.w_exp), _ptr(amax), _ptr(bias), _ci(N), _ci(H), _ci(W), _ci(Cin),
+                                       _ci(Cout), _ci(kh), _ci(kw), _ci(stride), _ci(pad), _ci(dil), _ci(int(act)), _ci(int(nchw)),
+                                       _ptr(out), _ptr(ws), ctypes.c_size_t(need), _stream()), "lsfa_conv_split_h_fwd")
+    return out
 
 
 @_on_tensor_device

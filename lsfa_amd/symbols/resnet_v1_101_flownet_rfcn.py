@@ -50,7 +50,7 @@ _CONV1X1_MIOPEN = _os.environ.get('LSFA_CONV1X1_MIOPEN', '0') == '1'   # experim
 # measured at 1000x600 (tools/key_sections.py, hipGraph replay): backbone 4327 -> 4239 us with it, small net 256 -> 289 us:
 # the backbone's stage 2/3 units gain (epilogue fusion + deterministic tap split), the small net's 64-channel stage 1 and the
 # 256 -> 1024 fuse convolution do not
-_OWN_CONV = set(x for x in _os.environ.get('LSFA_OWN_CONV', 'backbone,small,fuse,feat,stem,flow,nq').split(',') if x)
+_OWN_CONV = set(x for x in _os.environ.get('LSFA_OWN_CONV', 'backbone,small,fuse,feat,stem,flow,nq,h3').split(',') if x)
 # the own 3x3 convolutions on the bf16 matrix pipe with exactly split fp32 operands (lsfa_conv_split_fwd: fp32 in, fp32
 # accumulate, error against float64 equal to the fp32-MFMA kernel's) instead of the fp32 matrix instructions.  Measured per
 # conv2 at 1000x600 (tools/lab/conv_split_lab.py): res4 32.7 vs 40.7 us, res3 31.4 vs 50.4, res2 34.6 vs 51.3.
@@ -272,6 +272,8 @@ class _ResNetWeights(object):
                     bpad[:co] = d['off_b']
                     d['off_split'], d['off_b_pad'] = hip.SplitWeight(wpad, real_cout=co), bpad
                     d['dcn_split'] = hip.SplitWeight(d['w2_tap_t'].t().contiguous().view(d['w2'].shape[0], -1, 1, 1))
+                    if 'h3' in _OWN_CONV and d['w2'].shape[0] % 128 == 0:
+                        d['dcn_split_h'] = hip.SplitWeightH(d['w2_tap_t'].t().contiguous().view(d['w2'].shape[0], -1, 1, 1))
             if _CONV_SPLIT and 'pw' in _OWN_CONV and d['w1'].is_cuda and d['w1'].dtype == torch.float32:
                 # every contraction of the unit on lsfa_conv_split_fwd: the 1x1 convolutions, the shortcut, and for a DCN
                 # unit the offset branch (72 output channels, zero-padded to 128) and the contraction of the sampled
@@ -559,7 +561,11 @@ class Executor(object):
                 c14 = c1.view(n, h, w, -1)
                 off = hip.conv_split(c14, u['off_split'], u['off_b_pad'], 1, unit_dilate, unit_dilate)
                 col = hip.deform_im2col_cl(c14, off, 3, 3, unit_dilate, 1, unit_dilate, P.NUM_DEFORMABLE_GROUP)
-                c2 = hip.conv_split(col.view(n, h, w, -1), u['dcn_split'], u['b2'], relu=True).view(n * h * w, -1)
+                if 'dcn_split_h' in u:
+                    # every column entry is a bilinear interpolation of c1 (zeros outside): max|col| <= max|c1|, 9x fewer bytes to scan
+                    c2 = hip.conv_split_h(col.view(n, h, w, -1), u['dcn_split_h'], u['b2'], act=1, amax=hip.amax_partial(c14)).view(n * h * w, -1)
+                else:
+                    c2 = hip.conv_split(col.view(n, h, w, -1), u['dcn_split'], u['b2'], relu=True).view(n * h * w, -1)
                 ho, wo = h, w
             elif u['dcn']:
                 c2 = self._dcn_cl(self._map(c1, h, w), u, unit_dilate)
@@ -636,6 +642,12 @@ class Executor(object):
             if _CONV_SPLIT and 'feat' in _OWN_CONV and self.feat_w.dtype == torch.float32:
                 # feat_conv_3x3 (2048 -> 1024, dilation 6: the largest single convolution of a key frame) on the split-bf16
                 # kernel: bias + ReLU in the epilogue, written in NCHW (what the warp / aggregation kernels and the API take)
+                if 'h3' in _OWN_CONV:
+                    # r3: two fp16 pieces per operand, three matrix instructions per product (lsfa_conv_split_h_fwd): as close to
+                    # float64 as the bf16 three-piece form at half its matrix-pipe cycles; the scale comes from one pass over x4
+                    if not hasattr(self, 'feat_w_split_h'):
+                        self.feat_w_split_h = hip.SplitWeightH(self.feat_w)
+                    return hip.conv_split_h(x4.permute(0, 2, 3, 1), self.feat_w_split_h, self.feat_b, 1, 6, 6, act=1, nchw=True)
                 if not hasattr(self, 'feat_w_split'):
                     self.feat_w_split = hip.SplitWeight(self.feat_w)
                 return hip.conv_split(x4.permute(0, 2, 3, 1), self.feat_w_split, self.feat_b, 1, 6, 6, relu=True, nchw=True)
@@ -997,6 +1009,10 @@ class Executor(object):
                 own = 'small' in _OWN_CONV
                 s = self._resnet_cl(img, self.small, 1, False, own_conv=own)
                 if _CONV_SPLIT and self.fuse_w.dtype == torch.float32 and 'fuse' in _OWN_CONV:
+                    if 'h3' in _OWN_CONV:
+                        if not hasattr(self, 'fuse_w_split_h'):
+                            self.fuse_w_split_h = hip.SplitWeightH(self.fuse_w)
+                        return hip.conv_split_h(s.permute(0, 2, 3, 1), self.fuse_w_split_h, self.fuse_b, 1, 1, 1, act=0, nchw=True)
                     if not hasattr(self, 'fuse_w_split'):
                         self.fuse_w_split = hip.SplitWeight(self.fuse_w)
                     # written in NCHW by the epilogue: the warp kernel's `add` operand, no transposing copy

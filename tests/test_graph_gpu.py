@@ -580,7 +580,7 @@ def test_bench_line_contract():
     assert "workload" in d["config"] and "model" not in d["config"]
     r = d["roofline"]           # the dominant hand-written kernel: the split-bf16 convolution, priced against the matrix pipe
     assert r["bound"] == "mfma" and r["unit"] == "TFLOP/s" and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3
-    assert r["launches"] > 0 and r["traffic"] is None and abs(r["peak"] - 2500.0 / 6) < 0.1
+    assert r["launches"] > 0 and r["traffic"] is None and 2500.0 / 6 - 0.1 <= r["peak"] <= 2500.0 / 3 + 0.1
     h = d["roofline_hbm_kernel"]  # the HBM-bound one (warp)
     assert h["bound"] == "hbm" and h["unit"] == "GB/s" and abs(h["frac"] - h["achieved"] / h["peak"]) < 1e-3
     c = d["cpu_baseline"]

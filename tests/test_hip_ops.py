@@ -1063,6 +1063,37 @@ def test_conv_split_views_and_transposed_convolution_phases(hip):
         assert float((one - four).abs().max()) <= 4e-6 * float(ref.abs().max())
 
 
+@pytest.mark.parametrize("case", ["res5 1x1 2048->512", "dcn 1x1 4608->512", "3x3 d6 256->128", "3x3 256->1024 nchw", "huge", "tiny", "zeros"])
+def test_conv_split_h_fp16_two_piece_form_vs_float64(hip, case):
+    """r3 (opt-in): lsfa_conv_split_h_fwd, fp32 operands in two fp16 pieces, three matrix instructions per product.  Against a
+    float64 convolution it must be as close as the fp32 bound used for the bf16 three-piece form (2e-6 * sqrt(K) of max|y|) and
+    not worse than 1.5x that form on the same inputs; inputs of 1e6 and 1e-6 magnitude go through the power-of-two scale unharmed;
+    an all-zero map gives the bias; bit-reproducible."""
+    shapes = {"res5 1x1 2048->512": (38, 63, 2048, 512, 1, 0, 1, False), "dcn 1x1 4608->512": (38, 63, 4608, 512, 1, 0, 1, False),
+              "3x3 d6 256->128": (20, 30, 256, 128, 3, 6, 6, False), "3x3 256->1024 nchw": (19, 21, 256, 1024, 3, 1, 1, True)}
+    H, W, ci, co, k, pad, dil, nchw = shapes.get(case, (20, 30, 256, 128, 3, 1, 1, False))
+    g = torch.Generator(device=DEV).manual_seed(len(case))
+    mag = {"huge": 1e6, "tiny": 1e-6, "zeros": 0.0}.get(case, 3.0)
+    x = torch.relu(torch.randn((1, H, W, ci), device=DEV, generator=g)) * mag
+    w = torch.randn((co, ci, k, k), device=DEV, generator=g) * 0.01
+    b = torch.randn(co, device=DEV, generator=g) * mag * 0.1
+    swh, sw = hip.SplitWeightH(w), hip.SplitWeight(w)
+    y = hip.conv_split_h(x, swh, b, 1, pad, dil, act=1, nchw=nchw)
+    y_again = hip.conv_split_h(x, swh, b, 1, pad, dil, act=1, nchw=nchw)
+    assert torch.equal(y, y_again)
+    ref = torch.relu(torch.nn.functional.conv2d(x.permute(0, 3, 1, 2).double().cpu(), w.double().cpu(), b.double().cpu(), padding=pad, dilation=dil))
+    y6 = hip.conv_split(x, sw, b, 1, pad, dil, relu=True, nchw=nchw)
+    to_nchw = (lambda t: t) if nchw else (lambda t: t.permute(0, 3, 1, 2))
+    scale = max(ref.abs().max().item(), 1e-300)
+    e3 = (to_nchw(y).double().cpu() - ref).abs().max().item() / scale
+    e6 = (to_nchw(y6).double().cpu() - ref).abs().max().item() / scale
+    K = ci * k * k
+    if case == "zeros":
+        assert torch.equal(to_nchw(y).cpu(), ref.float())
+        return
+    assert e3 <= 2e-6 * K ** 0.5 and e3 <= 1.5 * e6 + 1e-7, (case, e3, e6)
+
+
 def test_proposal_and_nms_do_not_depend_on_workspace_contents(hip):
     """The NMS sweep requests mask words speculatively; none of them may be a word nms_mask_kernel does not write (ADVICE r2:
     the lower triangle of the mask is never initialised).  The workspace comes from torch's caching allocator, so it is

@@ -47,19 +47,39 @@ def world():
 
 
 def end_to_end_gap(cfg, gpu_out, ref_out, h, w):
-    """Un-forced comparison of one frame's final outputs: GPU graph vs oracle graph, each on its own
-    intermediate values.  -> dict(roi_mismatch, max_abs_dbox, max_abs_dscore, survivor_mismatch)."""
+    """Un-forced comparison of one frame's final outputs: GPU graph vs oracle graph, each on its own intermediate values.
+    -> dict(roi_mismatch, roi_displaced, roi_max_shift, unstable_rois, max_abs_dbox, max_abs_dscore, survivor_mismatch, survivors).
+
+    ROIs are compared as a SET first: every GPU row must be an oracle row (`roi_mismatch` = rows without a counterpart).  Their ORDER
+    is the order of fp32 RPN scores that the two sides computed with different summation orders: two proposals whose scores agree
+    to the last bits may come out swapped (observed: rows 283 / 284 of frame 0 when feat_conv_3x3 moved to the fp16 two-piece form,
+    which is CLOSER to float64 than what it replaced).  Such rows are counted (`roi_displaced`, `roi_max_shift` = how far a row
+    moved) and matched to their counterpart before boxes, scores and NMS survivors are compared.  The Proposal stage itself is
+    asserted bit-exact on identical inputs by check_heads in the same test."""
     g_rois, r_rois = np_(gpu_out['rois_output']), np.asarray(ref_out['rois_output'])
-    same = np.abs(g_rois - r_rois).max(1) < 0.05        # same anchor survived at the same output row
+    R = g_rois.shape[0]
+    eq = lambda a, b: np.abs(a - b).max() < 0.05
+    perm = -np.ones(R, np.int64)            # perm[i] = the oracle row that GPU row i is
+    used = np.zeros(R, bool)
+    for i in range(R):
+        if eq(g_rois[i], r_rois[i]):
+            perm[i], used[i] = i, True
+    for i in np.nonzero(perm < 0)[0]:       # displaced rows: the nearest unused oracle row with the same box (the cyclic pad repeats rows)
+        cand = [j for j in np.argsort(np.abs(np.arange(R) - i)) if not used[j] and eq(g_rois[i], r_rois[j])]
+        if cand:
+            perm[i], used[cand[0]] = cand[0], True
+    matched = perm >= 0
+    displaced = matched & (perm != np.arange(R))
+    pm = np.where(matched, perm, 0)
+    r_rois_m = r_rois[pm]
     # PSROI pooling rounds the ROI corners (psroi_pooling.cu:56-59 `round(x1)`): a corner that sits within the two sides'
     # 1e-4 px of a .5 boundary falls into different bins on the two sides, a discontinuity of the REFERENCE's own map and
     # not a numerical error.  Such ROIs are counted (`unstable_rois`, ~0.2 expected per frame) and left out of the box /
     # score distances.
     half_away = lambda v: np.sign(v) * np.floor(np.abs(v) + 0.5)
-    stable = (half_away(g_rois[:, 1:].astype(np.float64)) == half_away(r_rois[:, 1:].astype(np.float64))).all(1)
-    unstable = int((same & ~stable).sum())
-    same_all = same
-    same = same & stable
+    stable = (half_away(g_rois[:, 1:].astype(np.float64)) == half_away(r_rois_m[:, 1:].astype(np.float64))).all(1)
+    unstable = int((matched & ~stable).sum())
+    same = matched & stable
     g_cls, r_cls = np_(gpu_out['cls_prob_reshape_output'])[0], np.asarray(ref_out['cls_prob_reshape_output'])[0]
     g_box = oracle.bbox_pred_clip(g_rois, np_(gpu_out['bbox_pred_reshape_output'])[0], h, w, 1.0)
     r_box = oracle.bbox_pred_clip(r_rois, np.asarray(ref_out['bbox_pred_reshape_output'])[0], h, w, 1.0)
@@ -67,11 +87,15 @@ def end_to_end_gap(cfg, gpu_out, ref_out, h, w):
                                         nms_thresh=cfg.TEST.NMS, max_per_image=cfg.TEST.max_per_image)
     rd, rc, rk = oracle.det_postprocess(r_rois, np.asarray(ref_out['bbox_pred_reshape_output'])[0], r_cls, h, w, 1.0,
                                         nms_thresh=cfg.TEST.NMS, max_per_image=cfg.TEST.max_per_image)
+    inv = {int(perm[i]): i for i in range(R) if matched[i]}            # oracle row -> GPU row
     gs = set((j, int(i)) for j in range(1, len(gc)) for i in gk[j, :gc[j]])
-    rs = set((j, int(i)) for j in range(1, len(rc)) for i in rk[j, :rc[j]])
-    return dict(roi_mismatch=int((~same_all).sum()), unstable_rois=unstable,
-                max_abs_dbox=float(np.abs(g_box[same] - r_box[same]).max()) if same.any() else None,
-                max_abs_dscore=float(np.abs(g_cls[same] - r_cls[same]).max()) if same.any() else None,
+    rs = set((j, inv.get(int(i), -1 - int(i))) for j in range(1, len(rc)) for i in rk[j, :rc[j]])
+    detail = [dict(row=int(i), oracle_row=int(perm[i]), box=[round(float(v), 3) for v in g_rois[i]]) for i in np.nonzero(displaced | ~matched)[0][:8]]
+    return dict(roi_mismatch=int((~matched).sum()), roi_displaced=int(displaced.sum()),
+                roi_max_shift=int(np.abs(perm - np.arange(R))[matched].max()) if matched.any() else 0, roi_rows=detail,
+                unstable_rois=unstable,
+                max_abs_dbox=float(np.abs(g_box[same] - r_box[pm][same]).max()) if same.any() else None,
+                max_abs_dscore=float(np.abs(g_cls[same] - r_cls[pm][same]).max()) if same.any() else None,
                 survivor_mismatch=len(gs ^ rs), survivors=len(rs))
 
 
@@ -137,9 +161,12 @@ def test_first_key_cur_second_key_at_1000x600(world):
     assert rec['nq_logits_abs'] < TOL_DENSE * max(1.0, rec['nq_logits_max'])
     for k in ('frame0_end_to_end', 'frame3_end_to_end', 'frame10_end_to_end'):
         e = rec[k]
-        assert e['roi_mismatch'] == 0, (k, e)                   # the same 300 anchors survive Proposal, in the same order
+        assert e['roi_mismatch'] == 0, (k, e)                   # the same 300 anchors survive Proposal ...
+        # ... in the same order, up to swaps of NEIGHBOURS whose fp32 scores tie to the last bits (at most two swaps per frame)
+        assert e['roi_displaced'] <= 4 and e['roi_max_shift'] <= 1, (k, e)
         assert e['unstable_rois'] <= 3, (k, e)                  # corners on a rounding boundary of PSROI's round(): see end_to_end_gap
-        # the same (class, ROI) pairs survive the NMS (an unstable ROI may change the survivors of its classes)
+        # the same (class, ROI) pairs survive the NMS (an unstable ROI may change the survivors of its classes; a swapped pair,
+        # being compared by identity, does not)
         assert e['survivor_mismatch'] <= 8 * e['unstable_rois'] and e['survivors'] > 0, (k, e)
         assert e['max_abs_dscore'] <= TOL_SCORE, (k, e)
         assert e['max_abs_dbox'] <= TOL_BOX_PX, (k, e)

@@ -526,6 +526,7 @@ def main():
                     "achieved": round(tf, 1), "peak": round(mix_peak, 1), "unit": "TFLOP/s",
                     "frac": round(tf / mix_peak, 4),
                     "flops_share_on_three_products": round(fl3 / conv_fl, 3),
+                    "frac_of_six_product_peak": round(tf / MFMA_SPLIT_PEAK_TFLOPS, 4),     # what rounds 1-2 quoted as `frac` (every call on six products)
                     "traffic": load_traffic("conv_split:%dx%d,interval=%d,%s" % (args.width, args.height, args.interval, args.dtype)),
                     "launches": conv_n, "avg_us": round(conv_ms * 1e3 / conv_n, 2),
                     "algorithmic_flops_per_launch": round(conv_fl / max(conv_calls, 1)),

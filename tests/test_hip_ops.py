@@ -1063,6 +1063,19 @@ def test_conv_split_views_and_transposed_convolution_phases(hip):
         assert float((one - four).abs().max()) <= 4e-6 * float(ref.abs().max())
 
 
+def test_amax_partial_is_the_exact_maximum(hip):
+    """lsfa_amax_partial: the maximum of its 256 partial maxima is max|x| exactly (negative values, sizes that leave most of the 256
+    workgroups without work, a NaN is ignored like fmaxf ignores it)."""
+    g = torch.Generator(device=DEV).manual_seed(11)
+    for n in (4, 1024, 2394 * 256, 2394 * 2048):
+        x = torch.randn(n, device=DEV, generator=g) * 7
+        x[n // 3] = -123.5
+        out = hip.amax_partial(x)
+        assert out.shape == (256,) and out.max().item() == x.abs().max().item() == 123.5
+    x[5] = float('nan')
+    assert hip.amax_partial(x).max().item() == 123.5
+
+
 @pytest.mark.parametrize("case", ["res5 1x1 2048->512", "dcn 1x1 4608->512", "3x3 d6 256->128", "3x3 256->1024 nchw", "huge", "tiny", "zeros"])
 def test_conv_split_h_fp16_two_piece_form_vs_float64(hip, case):
     """r3 (opt-in): lsfa_conv_split_h_fwd, fp32 operands in two fp16 pieces, three matrix instructions per product.  Against a

@@ -155,9 +155,27 @@ __global__ __launch_bounds__(kHeadThreads) void rfcn_head_ps_kernel(
     gw = min(max(gw, 0), group - 1);
     gh = min(max(gh, 0), group - 1);
     const float* p = base + (size_t)(gh * group + gw) * D + d;
+    // the reference's order of additions (row by row, left to right) over the bin's pixels taken as ONE run, so that eight loads are in
+    // flight before the first of them is added whatever the bin's width
     float out_sum = 0.f;
-    for (int h = hstart; h < hend; ++h)
-      for (int w = wstart; w < wend; ++w) out_sum += p[((size_t)h * W + w) * cell_stride];
+    {
+      const int bw = wend - wstart, n = is_empty ? 0 : (hend - hstart) * bw;
+      int h = hstart, w = wstart, i8 = 0;
+      for (; i8 + 8 <= n; i8 += 8) {
+        float v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          v[u] = p[((size_t)h * W + w) * cell_stride];
+          if (++w == wend) { w = wstart; ++h; }
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) out_sum += v[u];
+      }
+      for (; i8 < n; ++i8) {
+        out_sum += p[((size_t)h * W + w) * cell_stride];
+        if (++w == wend) { w = wstart; ++h; }
+      }
+    }
     const float bin_area = (float)((hend - hstart) * (wend - wstart));
     bins[d * PP + k] = is_empty ? 0.f : out_sum / bin_area;
   }

@@ -528,7 +528,10 @@ int conv_split_launch(convsplit::Args a, void* ws, size_t ws_bytes, void* stream
     hipLaunchKernelGGL(convsplit::conv_split3x3_fixup_kernel, dim3((unsigned)(p.nx * p.ny)), dim3(convsplit::kThreads), 0, s, a, p.patches_x,
                        p.patches_y, p.nx);
   }
-  if (p.slices > 1) {
+  if (p.slices > 1 && a.y_nchw && !a.res && !a.y2 && nph == 1 && Cout % 64 == 0) {
+    hipLaunchKernelGGL(convsplit::split_reduce_nchw_kernel, dim3((unsigned)((P + 63) / 64), (unsigned)(Cout / 64)), dim3(convsplit::kThreads), 0,
+                       s, a, p.slices);
+  } else if (p.slices > 1) {
     const long n4 = P * Cout / 4;
     hipLaunchKernelGGL(convsplit::split_reduce_kernel, dim3((unsigned)((n4 + convsplit::kThreads - 1) / convsplit::kThreads), nph),
                        dim3(convsplit::kThreads), 0, s, a, n4, p.slices);

@@ -284,6 +284,51 @@ static __global__ __launch_bounds__(kThreads) void split_reduce_kernel(Args a, l
   }
 }
 
+// The same for an NCHW output without residual / second output (feat_conv_3x3, fuse_reduce_add): split_reduce_kernel's lanes walk
+// the channels of ONE pixel, so its NCHW stores are 64 different channel planes per instruction.  Here a workgroup sums a tile of
+// 64 pixels x 64 channels (reads: float4s of channels, coalesced along the partial sums' rows), turns it in LDS and writes, per
+// channel, 64 consecutive pixels.  Same additions in the same order, same epilogue arithmetic: bit-identical to split_reduce_kernel.
+// grid (ceil(P / 64), Cout / 64)
+static __global__ __launch_bounds__(kThreads) void split_reduce_nchw_kernel(Args a, int slices) {
+  __shared__ float T[64][65];
+  const int P = a.N * a.Ho * a.Wo, HW = a.Ho * a.Wo;
+  const int p0 = blockIdx.x * 64, c0 = blockIdx.y * 64;
+  const int t = threadIdx.x;
+  const int cg = t & 15, row = t >> 4;
+  const int ch = c0 + 4 * cg;
+  const size_t n4 = (size_t)P * a.Cout / 4;
+  const float4* part = reinterpret_cast<const float4*>(a.part);
+  float bias[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) bias[k] = a.bias ? a.bias[ch + k] : 0.f;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int pl = row + 16 * j, p = p0 + pl;
+    if (p < P) {
+      const size_t i = ((size_t)p * a.Cout + ch) / 4;
+      float4 sum = part[i];
+      for (int z = 1; z < slices; ++z) {
+        const float4 v = part[(size_t)z * n4 + i];
+        sum.x = sum.x + v.x; sum.y = sum.y + v.y; sum.z = sum.z + v.z; sum.w = sum.w + v.w;
+      }
+      T[4 * cg + 0][pl] = activate(sum.x + bias[0], a.act);
+      T[4 * cg + 1][pl] = activate(sum.y + bias[1], a.act);
+      T[4 * cg + 2][pl] = activate(sum.z + bias[2], a.act);
+      T[4 * cg + 3][pl] = activate(sum.w + bias[3], a.act);
+    }
+  }
+  __syncthreads();
+  const int cl = t >> 2, q0 = (t & 3) * 16;
+#pragma unroll
+  for (int q = 0; q < 16; ++q) {
+    const int pl = q0 + q, p = p0 + pl;
+    if (p < P) {
+      const int pn = p / HW, r = p - pn * HW;
+      a.y[((size_t)pn * a.Cout + c0 + cl) * HW + r] = T[cl][pl];
+    }
+  }
+}
+
 constexpr int kStageA = 4 * 4 * 64;                     // uint4 per stage: 4 waves x 32 pixels x 8 slots = 16 KB
 constexpr int kStageB = kChunkBytesB / 16;              // 768 uint4 = 12 KB
 constexpr int kStage = kStageA + kStageB;               // 28 KB; two stages = 56 KB, two workgroups per CU

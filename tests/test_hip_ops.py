@@ -1094,6 +1094,10 @@ def test_conv_split_h_fp16_two_piece_form_vs_float64(hip, case):
     y = hip.conv_split_h(x, swh, b, 1, pad, dil, act=1, nchw=nchw)
     y_again = hip.conv_split_h(x, swh, b, 1, pad, dil, act=1, nchw=nchw)
     assert torch.equal(y, y_again)
+    if nchw:      # the NCHW reduce pass (tile turned in LDS) against the channels-last one: the same numbers, transposed
+        assert torch.equal(y, hip.conv_split_h(x, swh, b, 1, pad, dil, act=1, nchw=False).permute(0, 3, 1, 2))
+        assert torch.equal(hip.conv_split(x, sw, b, 1, pad, dil, relu=True, nchw=True),
+                           hip.conv_split(x, sw, b, 1, pad, dil, relu=True, nchw=False).permute(0, 3, 1, 2))
     ref = torch.relu(torch.nn.functional.conv2d(x.permute(0, 3, 1, 2).double().cpu(), w.double().cpu(), b.double().cpu(), padding=pad, dilation=dil))
     y6 = hip.conv_split(x, sw, b, 1, pad, dil, relu=True, nchw=nchw)
     to_nchw = (lambda t: t) if nchw else (lambda t: t.permute(0, 3, 1, 2))

@@ -256,7 +256,15 @@ static __global__ __launch_bounds__(kThreads) void split_reduce_kernel(Args a, l
   if (i >= n4) return;
   const float4* part = reinterpret_cast<const float4*>(a.part);
   float4 s = part[i];
-  for (int z = 1; z < slices; ++z) {
+  int z = 1;
+  for (; z + 4 <= slices; z += 4) {       // four slices' loads in flight together; the additions stay in slice order
+    float4 v[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) v[u] = part[(size_t)(z + u) * n4 + i];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) { s.x = s.x + v[u].x; s.y = s.y + v[u].y; s.z = s.z + v[u].z; s.w = s.w + v[u].w; }
+  }
+  for (; z < slices; ++z) {
     const float4 v = part[(size_t)z * n4 + i];
     s.x = s.x + v.x; s.y = s.y + v.y; s.z = s.z + v.z; s.w = s.w + v.w;
   }
@@ -301,30 +309,44 @@ static __global__ __launch_bounds__(kThreads) void split_reduce_nchw_kernel(Args
   float bias[4];
 #pragma unroll
   for (int k = 0; k < 4; ++k) bias[k] = a.bias ? a.bias[ch + k] : 0.f;
+  // slice 0 of the thread's four pixels first, then the other slices slice by slice with the four loads of a slice in flight together
+  // (the additions stay in slice order per element)
+  float4 sum[4];
+  size_t idx[4];
+  bool ok[4];
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
-    const int pl = row + 16 * j, p = p0 + pl;
-    if (p < P) {
-      const size_t i = ((size_t)p * a.Cout + ch) / 4;
-      float4 sum = part[i];
-      for (int z = 1; z < slices; ++z) {
-        const float4 v = part[(size_t)z * n4 + i];
-        sum.x = sum.x + v.x; sum.y = sum.y + v.y; sum.z = sum.z + v.z; sum.w = sum.w + v.w;
-      }
-      T[4 * cg + 0][pl] = activate(sum.x + bias[0], a.act);
-      T[4 * cg + 1][pl] = activate(sum.y + bias[1], a.act);
-      T[4 * cg + 2][pl] = activate(sum.z + bias[2], a.act);
-      T[4 * cg + 3][pl] = activate(sum.w + bias[3], a.act);
-    }
+    const int p = p0 + row + 16 * j;
+    ok[j] = p < P;
+    idx[j] = ((size_t)(ok[j] ? p : 0) * a.Cout + ch) / 4;
+    sum[j] = part[idx[j]];
+  }
+  for (int z = 1; z < slices; ++z) {
+    float4 v[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) v[j] = part[(size_t)z * n4 + idx[j]];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { sum[j].x = sum[j].x + v[j].x; sum[j].y = sum[j].y + v[j].y; sum[j].z = sum[j].z + v[j].z; sum[j].w = sum[j].w + v[j].w; }
+  }
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int pl = row + 16 * j;
+    T[4 * cg + 0][pl] = activate(sum[j].x + bias[0], a.act);
+    T[4 * cg + 1][pl] = activate(sum[j].y + bias[1], a.act);
+    T[4 * cg + 2][pl] = activate(sum[j].z + bias[2], a.act);
+    T[4 * cg + 3][pl] = activate(sum[j].w + bias[3], a.act);
   }
   __syncthreads();
-  const int cl = t >> 2, q0 = (t & 3) * 16;
+  // a wave writes 64 consecutive pixels of one channel per instruction (256 contiguous bytes), 16 channels in turn
+  const int lane = t & 63, wv = t >> 6;
+  const int p = p0 + lane;
+  if (p < P) {
+    const int pn = p / HW, r = p - pn * HW;
+    float* dst = a.y + ((size_t)pn * a.Cout + c0) * HW + r;
 #pragma unroll
-  for (int q = 0; q < 16; ++q) {
-    const int pl = q0 + q, p = p0 + pl;
-    if (p < P) {
-      const int pn = p / HW, r = p - pn * HW;
-      a.y[((size_t)pn * a.Cout + c0 + cl) * HW + r] = T[cl][pl];
+    for (int q = 0; q < 16; ++q) {
+      const int cl = wv * 16 + q;
+      dst[(size_t)cl * HW] = T[cl][lane];
     }
   }
 }

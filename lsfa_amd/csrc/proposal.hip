@@ -257,7 +257,18 @@ __global__ __launch_bounds__(kRankThreads) void proposal_rank_kernel(
   const int bin = key_bin((uint32_t)(e >> 32));
   const int s0 = bin_start[img * kBins + bin], n = bin_count[img * kBins + bin];
   int before = 0;
-  for (int j = 0; j < n; ++j) before += cand[s0 + j] < e;
+  {
+    const uint64_t* b = cand + s0;
+    int j = 0;
+    for (; j + 8 <= n; j += 8) {       // eight loads in flight: the walk over a bin's members is a latency chain otherwise
+      uint64_t v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = b[j + u];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) before += v[u] < e;
+    }
+    for (; j < n; ++j) before += b[j] < e;
+  }
   const int rank = s0 + before;
   if (rank >= pre_n) return;
   sorted_box[(size_t)img * pre_n + rank] = boxes_all[(size_t)img * N + (uint32_t)e];

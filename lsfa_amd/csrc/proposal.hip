@@ -208,10 +208,21 @@ __global__ __launch_bounds__(kDecodeThreads) void proposal_compact_kernel(
   // histograms: this thread owns bins 4*tid .. 4*tid+3; totals over all workgroups, and the part held by the
   // workgroups before this one
   uint32_t c[4] = {0, 0, 0, 0}, before_me[4] = {0, 0, 0, 0};
-  for (int q = 0; q < G; ++q) {
-    const uint4 v = *reinterpret_cast<const uint4*>(parts + (size_t)q * kBins + 4 * tid);
-    c[0] += v.x; c[1] += v.y; c[2] += v.z; c[3] += v.w;
-    if (q < g) { before_me[0] += v.x; before_me[1] += v.y; before_me[2] += v.z; before_me[3] += v.w; }
+  for (int q0 = 0; q0 < G; q0 += 8) {      // eight workgroups' partial histograms in flight per step (G = 22: a chain of 22 trips otherwise)
+    uint4 v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int q = q0 + u < G ? q0 + u : G - 1;
+      v[u] = *reinterpret_cast<const uint4*>(parts + (size_t)q * kBins + 4 * tid);
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int q = q0 + u;
+      if (q < G) {
+        c[0] += v[u].x; c[1] += v[u].y; c[2] += v[u].z; c[3] += v[u].w;
+        if (q < g) { before_me[0] += v[u].x; before_me[1] += v[u].y; before_me[2] += v[u].z; before_me[3] += v[u].w; }
+      }
+    }
   }
   const int mine = (int)(c[0] + c[1] + c[2] + c[3]);
   int total;

@@ -1076,7 +1076,8 @@ def test_amax_partial_is_the_exact_maximum(hip):
     assert hip.amax_partial(x).max().item() == 123.5
 
 
-@pytest.mark.parametrize("case", ["res5 1x1 2048->512", "dcn 1x1 4608->512", "3x3 d6 256->128", "3x3 256->1024 nchw", "huge", "tiny", "zeros"])
+@pytest.mark.parametrize("case", ["res5 1x1 2048->512", "dcn 1x1 4608->512", "3x3 d6 256->128", "3x3 256->1024 nchw", "batch 3 nchw", "huge", "tiny",
+                                  "zeros"])
 def test_conv_split_h_fp16_two_piece_form_vs_float64(hip, case):
     """r3 (opt-in): lsfa_conv_split_h_fwd, fp32 operands in two fp16 pieces, three matrix instructions per product.  Against a
     float64 convolution it must be as close as the fp32 bound used for the bf16 three-piece form (2e-6 * sqrt(K) of max|y|) and
@@ -1085,9 +1086,12 @@ def test_conv_split_h_fp16_two_piece_form_vs_float64(hip, case):
     shapes = {"res5 1x1 2048->512": (38, 63, 2048, 512, 1, 0, 1, False), "dcn 1x1 4608->512": (38, 63, 4608, 512, 1, 0, 1, False),
               "3x3 d6 256->128": (20, 30, 256, 128, 3, 6, 6, False), "3x3 256->1024 nchw": (19, 21, 256, 1024, 3, 1, 1, True)}
     H, W, ci, co, k, pad, dil, nchw = shapes.get(case, (20, 30, 256, 128, 3, 1, 1, False))
+    nb = 1
+    if case == "batch 3 nchw":      # pixel tiles of the NCHW reduce pass straddle the images (3 x 17 x 13 = 663 pixels, tiles of 64)
+        nb, H, W, ci, co, k, pad, dil, nchw = 3, 17, 13, 256, 128, 3, 1, 1, True
     g = torch.Generator(device=DEV).manual_seed(len(case))
     mag = {"huge": 1e6, "tiny": 1e-6, "zeros": 0.0}.get(case, 3.0)
-    x = torch.relu(torch.randn((1, H, W, ci), device=DEV, generator=g)) * mag
+    x = torch.relu(torch.randn((nb, H, W, ci), device=DEV, generator=g)) * mag
     w = torch.randn((co, ci, k, k), device=DEV, generator=g) * 0.01
     b = torch.randn(co, device=DEV, generator=g) * mag * 0.1
     swh, sw = hip.SplitWeightH(w), hip.SplitWeight(w)

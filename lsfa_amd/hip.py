@@ -6,6 +6,7 @@ eager fallback — if the library is missing or a call fails, LsfaError is raise
 (the counterpart of MXNetError in the reference).
 """
 import ctypes
+import math
 import os
 
 import torch  # must be imported before the .so so that both share one libamdhip64
@@ -650,7 +651,6 @@ class SplitWeightH(object):
         if need == 0 or self.cout % 128 or self.cin % 32:
             raise LsfaError("SplitWeightH: Cin=%d must be a multiple of 32 and Cout=%d of 128" % (self.cin, self.cout))
         amax = float(weight.abs().max().item())              # bind time: a host synchronisation is fine here
-        import math
         self.w_exp = 0 if not (amax > 0 and math.isfinite(amax)) else 13 - int(math.floor(math.log2(amax)))
         self.w_exp = max(-100, min(100, self.w_exp))
         self.frag = torch.empty(need, dtype=torch.uint8, device=weight.device)

@@ -546,7 +546,8 @@ def main():
         line = {
             "metric": "frames/sec/GPU at 1000x600 key_interval=10 (whole-job frames/s)",
             "value": round(frames / elapsed, 3), "unit": "frames/s", "n_gpus": world, "steps": args.steps,
-            "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True,
+            "warmup": args.warmup, "settle_s": args.settle_s, "settle_steps": settle_steps,
+            "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
             "config": {"workload": "dff_rfcn ResNet-101 LSFA (DCN + FlowNet + Nq + small net + R-FCN), %d clip%s per GPU%s, "
                                    "key_interval=%d, %dx%d, %s; step = 1 key + %d non-key frames per clip" %

@@ -60,7 +60,10 @@ def lib():
             OP_NAMES[:] = names              # in place: importers of the list see the library's table
         wv = os.environ.get("LSFA_WARP_VARIANT")         # A/B runs of whole programs: 'gather' | 'staged' | 'auto'
         if wv:
-            L.lsfa_warp_set_variant(ctypes.c_int({'auto': 0, 'gather': 1, 'staged': 2}[wv]))
+            variants = {'auto': 0, 'gather': 1, 'staged': 2}
+            if wv not in variants:
+                raise LsfaError("LSFA_WARP_VARIANT=%r: expected one of %s" % (wv, sorted(variants)))
+            L.lsfa_warp_set_variant(ctypes.c_int(variants[wv]))
         _lib = L
     return _lib
 

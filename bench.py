@@ -296,22 +296,56 @@ class Runner(object):
             return cpu, None
         # ---- parity: end to end (each side on its own values), and stage by stage on the GPU's inputs ------
         frames = sorted(i for i in gpu if i in ref and i >= 1)
-        e2e = [end_to_end_gap(cfg, gpu[i]['out'], ref[i], H, W) for i in frames]
+        # the float64 statement of the same frames: the yardstick both fp32 evaluations are measured against (oracle/e2e.py)
+        from oracle import e2e as e2e_mod
+        F64 = torch.float64
+        d = {0: graph_ref.key_forward(cfg, self.arg, self.aux, f[0], f[0], np.zeros((1, 1024, 1, 1), np.float32), im_info, dtype=F64)}
+        d[1] = graph_ref.key_forward(cfg, self.arg, self.aux, f[1], f[0], d[0]['choose_feat_output'], im_info, dtype=F64)
+        for i in frames:
+            if i >= 2:
+                d[i] = graph_ref.cur_forward(cfg, self.arg, self.aux, f[i], d[1]['choose_feat_output'], npf(one(self.mv[i])),
+                                             npf(one(self.res[i])), im_info, dtype=F64)
+        e2e = []
+        for i in frames:
+            try:
+                e2e.append(e2e_mod.frame_gap(cfg, e2e_mod.gpu_side(cfg, gpu[i]['taps'], gpu[i]['out'], im_info), ref[i], d[i], im_info, H, W))
+            except AssertionError as ex:       # Proposal itself differs from the oracle on the GPU's maps: counted below as a failure
+                e2e.append({'failures': [str(ex)]})
         forced = 0
         for i in frames[:3]:
             forced += forced_mismatches(cfg, self.arg, gpu[i], im_info, H, W)
-        agg = lambda k: max((e[k] for e in e2e if e[k] is not None), default=None)
-        parity = {"frames_compared": frames, "vs": "oracle/graph_ref.py, un-forced: GPU and oracle each on their own intermediate values",
+        agg = lambda k: max((e[k] for e in e2e if e.get(k) is not None), default=None)
+        tot = lambda k: int(sum(e.get(k, 0) for e in e2e))
+        worst = {}
+        for q in ('rpn_score', 'rpn_delta', 'roi_px', 'box_px', 'cls_prob'):
+            rows = [e['err_vs_f64_' + q] for e in e2e if 'err_vs_f64_' + q in e]
+            if rows:
+                w = max(rows, key=lambda r: r['gpu'])
+                worst[q] = {"gpu": w['gpu'], "oracle_fp32": max(r['oracle_fp32'] for r in rows),
+                            "worst_frame_ratio": max((r['ratio'] for r in rows if r['ratio'] is not None), default=None)}
+        feat64 = d[1]['choose_feat_output']
+        parity = {"frames_compared": frames,
+                  "vs": "oracle/graph_ref.py in fp32 AND in float64, un-forced: GPU and oracles each on their own intermediate values; "
+                        "criterion oracle/e2e.py: GPU error vs float64 <= %.1f x the fp32 oracle's (+ 1 ulp), ROIs identified by anchor index, "
+                        "every pair of proposals the fp32 sides order differently must tie in float64" % e2e_mod.RATIO,
+                  "criterion_failures": [x for e in e2e for x in e['failures']][:8],
+                  "error_vs_float64": worst,
                   "max_abs_dbox": agg('max_abs_dbox'), "max_abs_dscore": agg('max_abs_dscore'),
-                  "roi_mismatch": int(sum(e['roi_mismatch'] for e in e2e)), "rois_compared": 300 * len(e2e),
-                  "survivor_mismatch": int(sum(e['survivor_mismatch'] for e in e2e)),
-                  "survivors": int(sum(e['survivors'] for e in e2e)),
+                  "roi_rows_in_a_different_order": tot('roi_displaced'), "of_which_float64_ties": tot('roi_displaced_ties'),
+                  "roi_kept_on_one_side_only": tot('roi_only_one_side'), "of_which_iou_threshold_ties": tot('roi_iou_ties'),
+                  "rois_on_a_psroi_rounding_boundary": tot('unstable_rois'),
+                  "rois_compared": tot('rois_compared'),
+                  "survivor_mismatch": tot('survivor_mismatch'), "survivors": tot('survivors'),
                   "feature_rel_err_key_frame": rel_err(npf(gpu[1]['out']['choose_feat_output']), ref[1]['choose_feat_output']),
+                  "feature_rel_err_key_frame_vs_float64": {"gpu": rel_err(npf(gpu[1]['out']['choose_feat_output']), feat64),
+                                                           "oracle_fp32": rel_err(ref[1]['choose_feat_output'], feat64)},
                   "contractions": self.args.dtype,
-                  "note": ("dense contractions in bf16 on the GPU vs the fp32 oracle graph: outputs differ by bf16 round-off "
-                           "(feature_rel_err_key_frame), so ROI / survivor identity is not expected; the bit-exactness claim "
+                  "note": ("dense contractions in bf16 on the GPU vs the fp32 / float64 oracle graphs: outputs differ by bf16 round-off "
+                           "(feature_rel_err_key_frame), so the fp32 criterion is expected to fail; the bit-exactness claim "
                            "in this mode is the hand-written-stage line below") if self.args.dtype != 'f32' else
-                          "fp32 on both sides: differences are summation order in the library convolutions and, in the own split-bf16 convolutions, the three dropped partial products (< 2^-23 of each product)",
+                          "fp32 in / fp32 accumulate on both sides; the GPU's convolutions form every fp32 product from split operands on the "
+                          "matrix pipe (two fp16 pieces + a power-of-two scale, three products; or three bf16 pieces, six products) and sum "
+                          "in MFMA tile order, the oracle in the CPU library's order",
                   "handwritten_stage_mismatches_on_gpu_inputs": int(forced),
                   "handwritten_stages_checked": "warp, aggregate, proposal, psroi+avg+softmax, det_postprocess of frames %s "
                                                 "(bit-exact = 0 mismatching elements)" % frames[:3]}
@@ -321,27 +355,6 @@ class Runner(object):
 def rel_err(a, b):
     a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
     return float(np.abs(a - b).max() / (np.abs(b).max() + 1e-12))
-
-
-def end_to_end_gap(cfg, gpu_out, ref_out, h, w):
-    """Un-forced comparison of one frame's final outputs: GPU graph vs oracle graph, each on its own
-    intermediate values (north_star: ROI indices / NMS survivors identical, boxes / scores within 1e-4)."""
-    import oracle
-    npf = lambda t: t.detach().float().cpu().numpy() if isinstance(t, torch.Tensor) else np.asarray(t)
-    g_rois, r_rois = npf(gpu_out['rois_output']), np.asarray(ref_out['rois_output'])
-    same = np.abs(g_rois - r_rois).max(1) < 0.05        # the same anchor survived at the same output row
-    g_cls, r_cls = npf(gpu_out['cls_prob_reshape_output'])[0], np.asarray(ref_out['cls_prob_reshape_output'])[0]
-    g_del, r_del = npf(gpu_out['bbox_pred_reshape_output'])[0], np.asarray(ref_out['bbox_pred_reshape_output'])[0]
-    g_box, r_box = oracle.bbox_pred_clip(g_rois, g_del, h, w, 1.0), oracle.bbox_pred_clip(r_rois, r_del, h, w, 1.0)
-    kw = dict(nms_thresh=cfg.TEST.NMS, max_per_image=cfg.TEST.max_per_image, class_agnostic=cfg.CLASS_AGNOSTIC)
-    _, gc, gk = oracle.det_postprocess(g_rois, g_del, g_cls, h, w, 1.0, **kw)
-    _, rc, rk = oracle.det_postprocess(r_rois, r_del, r_cls, h, w, 1.0, **kw)
-    gs = set((j, int(i)) for j in range(1, len(gc)) for i in gk[j, :gc[j]])
-    rs = set((j, int(i)) for j in range(1, len(rc)) for i in rk[j, :rc[j]])
-    return dict(roi_mismatch=int((~same).sum()),
-                max_abs_dbox=float(np.abs(g_box[same] - r_box[same]).max()) if same.any() else None,
-                max_abs_dscore=float(np.abs(g_cls[same] - r_cls[same]).max()) if same.any() else None,
-                survivor_mismatch=len(gs ^ rs), survivors=len(rs))
 
 
 def forced_mismatches(cfg, arg, g, im_info, h, w):

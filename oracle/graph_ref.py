@@ -9,6 +9,12 @@ own op, every 1x1 convolution is a convolution, rpn_inv_normalize is applied aft
 The dense ops are torch.nn.functional on the CPU in fp32; the custom stages (warp, aggregate,
 Proposal, PSROI, DCN im2col) are the C oracle.  PARITY UNPINNED for all of it: MXNet is not
 vendored and the reference holds no golden outputs for these graphs.
+
+`dtype=torch.float64` (r4) runs every DENSE op (convolutions, BatchNorm, pooling, softmax, the DCN contraction) in
+float64 and hands float32-rounded maps to the custom stages at exactly the boundaries where the reference's operators
+receive fp32 tensors.  That graph is the yardstick of tests/test_parity_fullres_gpu.py: the fp32 statement of this file
+and the GPU path are two fp32 evaluations of the same graph with different summation orders; how far each is from the
+float64 graph says whether the GPU path is "no worse than the reference's own fp32" without appealing to a constant.
 """
 import numpy as np
 import torch
@@ -27,15 +33,21 @@ def _T(a):
 
 
 class Params(object):
-    def __init__(self, arg, aux):
-        self.arg, self.aux = arg, aux
+    def __init__(self, arg, aux, dtype=torch.float32):
+        self.arg, self.aux, self.dt = arg, aux, dtype
+
+    def T(self, a):
+        """numpy (or tensor) -> tensor of the graph's dense dtype; fp32 values are represented exactly in float64"""
+        if isinstance(a, torch.Tensor):
+            return a.to(self.dt)
+        return _T(a).to(self.dt) if np.asarray(a).dtype != np.float64 else torch.from_numpy(np.ascontiguousarray(a)).to(self.dt)
 
     def w(self, name):
-        return _T(self.arg[name])
+        return _T(self.arg[name]).to(self.dt)
 
     def bn(self, x, name, fix_gamma=False):
-        g = torch.ones(x.shape[1]) if fix_gamma else self.w(name + '_gamma')
-        return F.batch_norm(x, _T(self.aux[name + '_moving_mean']), _T(self.aux[name + '_moving_var']), g,
+        g = torch.ones(x.shape[1], dtype=self.dt) if fix_gamma else self.w(name + '_gamma')
+        return F.batch_norm(x, self.T(self.aux[name + '_moving_mean']), self.T(self.aux[name + '_moving_var']), g,
                             self.w(name + '_beta'), False, 0.0, EPS)
 
     def conv(self, x, name, k, stride=1, dilate=1, bias=True, pad=None):
@@ -49,11 +61,13 @@ class Params(object):
 def deformable_conv(p, x, name, num_filter, dilate, num_deformable_group=4):
     """sym_common.py:249-262: offset conv (with bias) then DeformableConvolution (no bias)."""
     off = p.conv(x, name + '_offset', 3, 1, dilate, bias=True)
+    # the sampling operator receives fp32 maps in the reference (DeformableConvolution's im2col), the contraction is dense
     col = oracle.deform_im2col(x.numpy(), off.numpy(), 3, 3, dilate, 1, dilate, num_deformable_group)
-    w = p.arg[name + '_weight'].reshape(num_filter, -1)
+    npdt = np.float64 if p.dt == torch.float64 else np.float32
+    w = p.arg[name + '_weight'].reshape(num_filter, -1).astype(npdt)
     n, _, h, wd = off.shape
-    out = np.stack([w @ col[i] for i in range(n)], 0).reshape(n, num_filter, h, wd)
-    return _T(out)
+    out = np.stack([w @ col[i].astype(npdt) for i in range(n)], 0).reshape(n, num_filter, h, wd)
+    return p.T(out)
 
 
 def resnet_backbone(p, data, prefix='', need_part=False, add_dcn=True, stages=4):
@@ -105,7 +119,7 @@ def get_flownet(p, img_cur, img_ref):
         y = F.conv_transpose2d(x, p.w(name + '_weight'), p.w(name + '_bias'), stride=2)
         return y[:, :, 1:1 + like.shape[2], 1:1 + like.shape[3]]
 
-    data = torch.cat([img_cur / 255.0, img_ref / 255.0], 1)
+    data = torch.cat([p.T(img_cur) / 255.0, p.T(img_ref) / 255.0], 1)
     x = F.avg_pool2d(data, 2, 2, ceil_mode=True)
     r1 = conv(x, 'flow_conv1', 7, 2, 3)
     r2 = conv(r1, 'conv2', 5, 2, 2)
@@ -132,7 +146,7 @@ def get_flownet(p, img_cur, img_ref):
 
 
 def nq_logits(p, warp_feat, conv_feat):
-    x = torch.cat([warp_feat, conv_feat], 0)
+    x = torch.cat([p.T(warp_feat), p.T(conv_feat)], 0)
     x = F.relu(F.conv2d(x, p.w('Nq_conv1_weight'), p.w('Nq_conv1_bias'), 1, 1))
     x = F.relu(F.conv2d(x, p.w('Nq_conv2_weight'), p.w('Nq_conv2_bias')))
     return F.conv2d(x, p.w('Nq_conv3_weight'), p.w('Nq_conv3_bias'))
@@ -141,14 +155,14 @@ def nq_logits(p, warp_feat, conv_feat):
 def embed(p, conv_feat, warp_feat):
     """get_embednet on Concat(conv_feat, warp_feat) (symbols/resnet_v1_101_flownet_rfcn.py:118-135);
     row 0 embeds the current feature, row 1 the warped one."""
-    x = torch.cat([conv_feat, warp_feat], 0)
+    x = torch.cat([p.T(conv_feat), p.T(warp_feat)], 0)
     x = F.relu(F.conv2d(x, p.w('em_conv1_weight'), p.w('em_conv1_bias')))
     x = F.relu(F.conv2d(x, p.w('em_conv2_weight'), p.w('em_conv2_bias'), 1, 1))
     return F.conv2d(x, p.w('em_conv3_weight'), p.w('em_conv3_bias'))
 
 
 def small_net_feature(p, data_cur):
-    img = F.avg_pool2d(data_cur, 4, 4, ceil_mode=True)
+    img = F.avg_pool2d(p.T(data_cur), 4, 4, ceil_mode=True)
     feats = resnet_backbone(p, img, prefix='small_net_', need_part=True, add_dcn=False, stages=1)
     return F.conv2d(feats[0], p.w('fuse_reduce_add_weight'), p.w('fuse_reduce_add_bias'), 1, 1)
 
@@ -156,12 +170,13 @@ def small_net_feature(p, data_cur):
 def head_maps(p, conv_feat, cfg):
     """RPN class probabilities + de-normalised deltas, and the two R-FCN score maps."""
     A = cfg.network.NUM_ANCHORS
+    conv_feat = p.T(conv_feat)
     rpn_feat, rfcn_feat = conv_feat[:, :512], conv_feat[:, 512:]
     cls_score = F.conv2d(rpn_feat, p.w('rpn_cls_score_weight'), p.w('rpn_cls_score_bias'))
     bbox = F.conv2d(rpn_feat, p.w('rpn_bbox_pred_weight'), p.w('rpn_bbox_pred_bias'))
     if cfg.network.NORMALIZE_RPN:   # operator_py/rpn_inv_normalize.py:19-26
-        std = torch.tensor(cfg.network.ANCHOR_STDS, dtype=torch.float32).repeat(A).view(1, -1, 1, 1)
-        mean = torch.tensor(cfg.network.ANCHOR_MEANS, dtype=torch.float32).repeat(A).view(1, -1, 1, 1)
+        std = torch.tensor(cfg.network.ANCHOR_STDS, dtype=torch.float32).to(p.dt).repeat(A).view(1, -1, 1, 1)
+        mean = torch.tensor(cfg.network.ANCHOR_MEANS, dtype=torch.float32).to(p.dt).repeat(A).view(1, -1, 1, 1)
         bbox = bbox * std + mean
     n, _, h, w = cls_score.shape
     prob = torch.softmax(cls_score.reshape(n, 2, A * h, w), 1).reshape(n, 2 * A, h, w)
@@ -170,57 +185,74 @@ def head_maps(p, conv_feat, cfg):
     return prob, bbox, cls_map, box_map
 
 
-def detect_from_maps(prob, bbox, cls_map, box_map, im_info, cfg):
-    rois, _ = oracle.proposal(prob.numpy(), bbox.numpy(), im_info, cfg.network.RPN_FEAT_STRIDE,
-                              cfg.network.ANCHOR_SCALES, cfg.network.ANCHOR_RATIOS, cfg.TEST.RPN_PRE_NMS_TOP_N,
-                              cfg.TEST.RPN_POST_NMS_TOP_N, cfg.TEST.RPN_NMS_THRESH, cfg.TEST.RPN_MIN_SIZE)
+def detect_from_maps(prob, bbox, cls_map, box_map, im_info, cfg, out=None):
+    """Proposal + R-FCN head on fp32 maps (the operators' input dtype; a float64 graph's maps are rounded here).  With `out`, the
+    anchor index behind every ROI row is recorded too (`roi_anchor`: index ((h * W) + w) * A + a of multi_proposal.cu:57-67)."""
+    rois, _, order, keep, nkeep = oracle.proposal(prob.numpy(), bbox.numpy(), im_info, cfg.network.RPN_FEAT_STRIDE,
+                                                  cfg.network.ANCHOR_SCALES, cfg.network.ANCHOR_RATIOS, cfg.TEST.RPN_PRE_NMS_TOP_N,
+                                                  cfg.TEST.RPN_POST_NMS_TOP_N, cfg.TEST.RPN_NMS_THRESH, cfg.TEST.RPN_MIN_SIZE,
+                                                  return_debug=True)
+    if out is not None:
+        out['roi_anchor'] = roi_anchor_index(order, keep, nkeep, rois.shape[0])
     cls_prob, _, bbox_pred = oracle.rfcn_head(cls_map.numpy(), box_map.numpy(), rois)
     return rois, cls_prob, bbox_pred
 
 
-def key_forward(cfg, arg, aux, data, data_key_old, feat_key_old, im_info):
-    """get_key_test_symbol.  All inputs numpy; returns a dict of numpy stage outputs."""
-    p = Params(arg, aux)
+def roi_anchor_index(order, keep, nkeep, rows):
+    """Which anchor each output row of Proposal is: row i of image b = sorted position keep[b, i % nkeep[b]] (the cyclic pad of
+    multi_proposal.cu:374-386) = anchor order[b, that position]."""
+    B = order.shape[0]
+    post = rows // B
+    out = np.empty(rows, np.int64)
+    for b in range(B):
+        k = keep[b, np.arange(post) % max(int(nkeep[b]), 1)]
+        out[b * post:(b + 1) * post] = order[b, k]
+    return out
+
+
+def key_forward(cfg, arg, aux, data, data_key_old, feat_key_old, im_info, dtype=torch.float32):
+    """get_key_test_symbol.  All inputs numpy; returns a dict of numpy stage outputs (in `dtype` for the dense stages)."""
+    p = Params(arg, aux, dtype)
     with torch.no_grad():
         out = {}
-        conv_feat = get_resnet_v1(p, _T(data), cfg)
+        conv_feat = get_resnet_v1(p, p.T(data), cfg)
         out['backbone_feat'] = conv_feat.numpy()
         c, h, w = feat_key_old.shape[1:]
         is_first = (c == 1024 and h == 1 and w == 1)            # choose_old_key_feat.py:27
         if not is_first:
-            flow, scale_map = get_flownet(p, _T(data), _T(data_key_old))
+            flow, scale_map = get_flownet(p, p.T(data), p.T(data_key_old))
             out['flow'], out['scale_map'] = flow.numpy(), scale_map.numpy()
             warp = oracle.warp_bilinear(feat_key_old, out['flow'], mul=out['scale_map'])
             out['warp'] = warp
             if cfg.network.add_Nq_net:                          # :310-311
                 logits = nq_logits(p, _T(warp), conv_feat)
                 out['nq_logits'] = logits.numpy()
-                conv_feat = _T(oracle.aggregate_softmax2(warp, conv_feat.numpy(), out['nq_logits']))
+                conv_feat = p.T(oracle.aggregate_softmax2(warp, conv_feat.numpy(), out['nq_logits']))
             elif cfg.network.add_Fgfa_net:                      # :312-313, Fgfa_net :132-148
                 out['embed'] = embed(p, conv_feat, _T(warp)).numpy()
-                conv_feat = _T(oracle.aggregate_cosine(warp, conv_feat.numpy(), out['embed'][1:2], out['embed'][0:1]))
+                conv_feat = p.T(oracle.aggregate_cosine(warp, conv_feat.numpy(), out['embed'][1:2], out['embed'][0:1]))
             else:                                               # :314-315
-                conv_feat = 0.5 * (_T(warp) + conv_feat)
+                conv_feat = 0.5 * (p.T(warp) + conv_feat)
         out['choose_feat_output'] = conv_feat.numpy()
         prob, bbox, cls_map, box_map = head_maps(p, conv_feat, cfg)
         out.update(rpn_cls_prob=prob.numpy(), rpn_bbox_pred=bbox.numpy(), cls_map=cls_map.numpy(), box_map=box_map.numpy())
-        rois, cls_prob, bbox_pred = detect_from_maps(prob, bbox, cls_map, box_map, im_info, cfg)
+        rois, cls_prob, bbox_pred = detect_from_maps(prob, bbox, cls_map, box_map, im_info, cfg, out)
         out.update(rois_output=rois, cls_prob_reshape_output=cls_prob[None], bbox_pred_reshape_output=bbox_pred[None])
         return out
 
 
-def cur_forward(cfg, arg, aux, data, feat_key, motion_vector, res_diff, im_info):
-    p = Params(arg, aux)
+def cur_forward(cfg, arg, aux, data, feat_key, motion_vector, res_diff, im_info, dtype=torch.float32):
+    p = Params(arg, aux, dtype)
     with torch.no_grad():
         out = {}
-        small = small_net_feature(p, _T(data))
+        small = small_net_feature(p, p.T(data))
         out['small_feat'] = small.numpy()
         conv_feat = oracle.warp_bilinear(feat_key, motion_vector, add=out['small_feat'], res=res_diff,
                                          res_w=arg['rnet_conv0_weight'], res_b=arg['rnet_conv0_bias'])
         out['conv_feat'] = conv_feat
         prob, bbox, cls_map, box_map = head_maps(p, _T(conv_feat), cfg)
         out.update(rpn_cls_prob=prob.numpy(), rpn_bbox_pred=bbox.numpy(), cls_map=cls_map.numpy(), box_map=box_map.numpy())
-        rois, cls_prob, bbox_pred = detect_from_maps(prob, bbox, cls_map, box_map, im_info, cfg)
+        rois, cls_prob, bbox_pred = detect_from_maps(prob, bbox, cls_map, box_map, im_info, cfg, out)
         out.update(rois_output=rois, cls_prob_reshape_output=cls_prob[None], bbox_pred_reshape_output=bbox_pred[None])
         return out
 

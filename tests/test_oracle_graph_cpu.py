@@ -68,3 +68,52 @@ def test_key_graph_aggregation_switches():
     np.testing.assert_array_equal(outs['average']['choose_feat_output'], mean.numpy())
     assert 'embed' in outs['fgfa'] and outs['fgfa']['embed'].shape[:2] == (2, 2048)
     assert 'nq_logits' in outs['nq']
+
+
+def _side(out):
+    return {k: out[k] for k in ('rpn_cls_prob', 'rpn_bbox_pred', 'rois_output', 'roi_anchor', 'cls_prob_reshape_output',
+                                'bbox_pred_reshape_output')}
+
+
+def test_float64_anchored_criterion_accepts_fp32_and_rejects_a_degraded_side():
+    """oracle/e2e.py on the CPU: the fp32 oracle graph judged against the float64 graph passes with itself as the 'GPU'
+    side (ratios 1), still passes when the 'GPU' side is another fp32 evaluation (rounded through float64 -> fp32 maps),
+    and FAILS when the RPN scores of the 'GPU' side carry errors 10x the fp32 oracle's (what a dropped partial product
+    in a convolution would do), or when two proposals that are not a float64 tie are swapped."""
+    import torch
+    from oracle import e2e
+    cfg = lsfa_test_config(key_frame_interval=10)
+    arg, aux = P.init_params(cfg, seed=0)
+    H, W = 192, 320
+    clip = SyntheticClip(0, 12, H, W)
+    f0, im_info = clip.frame(0).numpy(), clip.im_info()
+    z = np.zeros((1, 1024, 1, 1), np.float32)
+    r32 = graph_ref.key_forward(cfg, arg, aux, f0, f0, z, im_info)
+    r64 = graph_ref.key_forward(cfg, arg, aux, f0, f0, z, im_info, dtype=torch.float64)
+    assert r64['backbone_feat'].dtype == np.float64
+    # the fp32 statement is an fp32-accurate evaluation of the float64 one
+    assert np.abs(r32['backbone_feat'] - r64['backbone_feat']).max() < 1e-5 * np.abs(r64['backbone_feat']).max()
+    rec = e2e.frame_gap(cfg, _side(r32), _side(r32), _side(r64), im_info, H, W)
+    assert not rec['failures'], rec
+    assert rec['roi_order_identical'] and rec['survivor_mismatch'] == 0
+    assert rec['err_vs_f64_rpn_score']['ratio'] == 1.0
+
+    # a degraded side: scores off by 10x the oracle's own error -> (a) fails
+    bad = dict(_side(r32))
+    e_ref = rec['err_vs_f64_rpn_score']['oracle_fp32']
+    rng = np.random.RandomState(0)
+    bad['rpn_cls_prob'] = (r32['rpn_cls_prob'] + rng.uniform(-1, 1, r32['rpn_cls_prob'].shape) * (10 * e_ref + 1e-6)).astype(np.float32)
+    rec_bad = e2e.frame_gap(cfg, bad, _side(r32), _side(r64), im_info, H, W)
+    assert any(f.startswith('rpn_score') for f in rec_bad['failures']), rec_bad['failures']
+
+    # two proposals swapped that are no tie in float64 -> (b) fails
+    sw = dict(_side(r32))
+    a = np.array(r32['roi_anchor'])
+    s64 = e2e.fg_scores(r64['rpn_cls_prob'], cfg.network.NUM_ANCHORS)
+    i = next(i for i in range(len(a) - 1) if abs(s64[a[i]] - s64[a[i + 1]]) > 1e-3)
+    for k in ('rois_output', 'roi_anchor'):
+        v = np.array(r32[k]); v[[i, i + 1]] = v[[i + 1, i]]; sw[k] = v
+    for k in ('cls_prob_reshape_output', 'bbox_pred_reshape_output'):
+        v = np.array(r32[k]); v[0, [i, i + 1]] = v[0, [i + 1, i]]; sw[k] = v
+    rec_sw = e2e.frame_gap(cfg, sw, _side(r32), _side(r64), im_info, H, W)
+    assert rec_sw['roi_displaced'] == 2 and any('ordered differently' in f for f in rec_sw['failures']), rec_sw['failures']

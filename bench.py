@@ -39,6 +39,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 MFMA_SPLIT_PEAK_TFLOPS = round(2500.0 / 6, 1)           # dense bf16 MFMA peak / the six partial products of an fp32 product
+MFMA_BF16_PEAK_TFLOPS = 2500.0                           # dense bf16 / fp16 MFMA peak (MI355X_MICROARCH.md)
 HBM_PEAK_GBS = 8000.0                                   # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 TRAFFIC_FILE = os.path.join(ROOT, 'profiles', 'traffic.json')   # HBM bytes per launch from rocprofv3 PMC passes, keyed by shape
 
@@ -146,6 +147,21 @@ class Runner(object):
         """(K, B, ncls) int32: the per-class detection counts of the last interval's frames (a copy)."""
         return torch.stack([self.host_counts_of(k) for k in range(self.K)])
 
+    def last_interval_rows(self):
+        """The last interval's detections as the rows the reference's result file holds (lib/dataset/imagenet_vid.py:260-268):
+        [frame, class, score, x1, y1, x2, y2] float64, frames numbered (clip of this rank, frame of the interval)."""
+        counts, rows = self.host_counts, []
+        for k in range(self.K):
+            for b in range(self.B):
+                for j in range(1, self.ncls):
+                    n = int(counts[k, b, j])
+                    if n:
+                        d = self.host_dets[k, b, j, :n].numpy()
+                        r = np.empty((n, 7), np.float64)
+                        r[:, 0], r[:, 1], r[:, 2], r[:, 3:] = k * self.B + b, j, d[:, 4], d[:, :4]
+                        rows.append(r)
+        return np.vstack(rows) if rows else np.zeros((0, 7), np.float64)
+
     def _deliver(self, bufs, slot):
         flat = getattr(bufs[0], 'lsfa_flat', None)
         if flat is not None and flat.numel() == self.host_flat.shape[1]:
@@ -191,6 +207,7 @@ class Runner(object):
         prof = self.hip.prof_read()
         self.conv_flops = self.hip.conv_flops_read()
         self.conv_flops3 = self.hip.conv_flops_three_products()
+        self.conv_flops1 = self.hip.conv_flops_one_product()
         self.hip.conv_flops_reset(False)
         self.hip.prof_enable(False)
         return prof
@@ -487,16 +504,41 @@ def main():
         repeats.append(time.perf_counter() - t1)
     prof = r.eager_profile_step(args.warmup) if rank == 0 else None
 
+    # an overflow of the fp16 form's scale anywhere in the run is an error, not a number (outside the timed regions: it synchronises)
+    r.key.check_status()
+    r.cur.check_status()
+    multi = None
     if distributed:
+        own = [float(v) for v in repeats]
         tt = torch.tensor(repeats, device=coll_dev, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         repeats = [float(v) for v in tt.tolist()]
         elapsed = repeats[0]
-        # the final gather of detections (here: last interval's per-frame counts) over RCCL
-        counts = r.host_counts.to(coll_dev)
-        gathered = [torch.empty_like(counts) for _ in range(world)]
-        dist.all_gather(gathered, counts)
-        total_dets = int(sum(int(g.sum().item()) for g in gathered))
+        # what every rank saw: its own time for the first region (-> per-rank frames/s) and which device it ran on
+        mine = torch.tensor([own[0], float(local_rank), float(rank)], device=coll_dev, dtype=torch.float64)
+        seen = [torch.empty_like(mine) for _ in range(world)]
+        dist.all_gather(seen, mine)
+        # the final gather of detections - the one data-path collective (RCCL over xGMI): the benchmarked clip's detection rows of the
+        # last interval, [frame, class, score, x1, y1, x2, y2] per row, ragged per rank (lsfa_amd/core/parallel.py gather_rows)
+        from lsfa_amd.core.parallel import gather_rows
+        rows = r.last_interval_rows()
+        if backend == 'nccl':
+            torch.cuda.synchronize()
+        dist.barrier(device_ids=[local_rank]) if backend == 'nccl' else dist.barrier()
+        tg = time.perf_counter()
+        all_rows = gather_rows(rows, torch.device(coll_dev))
+        if backend == 'nccl':
+            torch.cuda.synchronize()
+        gather_s = time.perf_counter() - tg
+        total_dets = int(all_rows.shape[0])
+        per_rank_frames = args.clips * args.steps * args.interval
+        multi = {"backend": "rccl (torch.distributed 'nccl')" if backend == 'nccl' else backend,
+                 "rccl_ranks_seen": world if backend == 'nccl' else 0, "ranks_seen": world,
+                 "per_rank": [{"rank": int(v[2].item()), "device": int(v[1].item()), "seconds": round(float(v[0].item()), 6),
+                               "frames_per_s": round(per_rank_frames / float(v[0].item()), 2)} for v in seen],
+                 "final_gather": {"rows": total_dets, "bytes": int(all_rows.nbytes), "seconds": round(gather_s, 6),
+                                  "what": "detection rows of every rank's last interval, counts first then one padded all_gather"},
+                 "collectives_in_timed_region": 0}
     else:
         total_dets = int(r.host_counts.sum().item())
 
@@ -532,28 +574,30 @@ def main():
             # matrix-pipe peak for this mix of calls: six bf16 products per fp32 product (2500 / 6), three fp16 ones on the calls
             # that ran the two-piece form (2500 / 3): harmonic mix by FLOPs
             fl3 = float(getattr(r, 'conv_flops3', 0.0))
-            mix_peak = conv_fl / ((conv_fl - fl3) / MFMA_SPLIT_PEAK_TFLOPS + fl3 / (2.0 * MFMA_SPLIT_PEAK_TFLOPS))
-            roof = {"bound": "mfma", "kernel": "the split-bf16 convolution family (lsfa_conv_split_fwd and its view / phase forms: conv2 and "
-                    "the DCN branch of the ResNet units, feat_conv_3x3, fuse_reduce_add, FlowNet, the Nq net, the small net's 3x3s) incl. "
-                    "their reduce / fix-up passes, %d calls of one interval" % conv_n,
+            fl1 = float(getattr(r, 'conv_flops1', 0.0))
+            fl6 = conv_fl - fl3 - fl1
+            mfma_work = 6 * fl6 + 3 * fl3 + fl1          # matrix-instruction FLOPs actually issued
+            mix_peak = conv_fl / (mfma_work / MFMA_BF16_PEAK_TFLOPS)
+            roof = {"bound": "mfma", "kernel": "the split-operand convolution family behind lsfa_conv_fwd (ring / halo / direct kernels + their reduce passes): "
+                    "every convolution of ResNet-101 + DCN, feat_conv_3x3, the small net, fuse_reduce_add, FlowNet, the Nq net; %d calls of one interval" % conv_n,
                     "achieved": round(tf, 1), "peak": round(mix_peak, 1), "unit": "TFLOP/s",
                     "frac": round(tf / mix_peak, 4),
-                    "flops_share_on_three_products": round(fl3 / conv_fl, 3),
+                    "flops_share_by_products_per_fp32_product": {"six (three bf16 pieces)": round(fl6 / conv_fl, 3), "three (two fp16 pieces)": round(fl3 / conv_fl, 3),
+                                                                  "one (bf16 mode)": round(fl1 / conv_fl, 3)},
                     "frac_of_six_product_peak": round(tf / MFMA_SPLIT_PEAK_TFLOPS, 4),     # what rounds 1-2 quoted as `frac` (every call on six products)
                     "traffic": load_traffic("conv_split:%dx%d,interval=%d,%s" % (args.width, args.height, args.interval, args.dtype)),
                     "launches": conv_n, "avg_us": round(conv_ms * 1e3 / conv_n, 2),
                     "algorithmic_flops_per_launch": round(conv_fl / max(conv_calls, 1)),
-                    "bf16_mfma_work": {"achieved": round((6 * (conv_fl - fl3) + 3 * fl3) / (conv_ms * 1e-3) / 1e12, 1), "peak": 2500.0, "unit": "TFLOP/s"},
+                    "mfma_work": {"achieved": round(mfma_work / (conv_ms * 1e-3) / 1e12, 1), "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s"},
                     "fp32_mfma_pipe_peak": 157.3,
-                    "measured": "HIP events around each lsfa_conv_split_fwd / lsfa_conv_nhwc_fused_fwd call (conv kernel + its reduce "
-                                "pass) of one interval re-issued eagerly after the timed region; algorithmic FLOPs = 2*M*N*K summed "
-                                "over the same calls; traffic = HBM bytes per call of the kernel family (FETCH_SIZE x2 + WRITE_SIZE, separate "
-                                "rocprofv3 PMC passes over the eager loop, profiles/traffic.json), null if no profile of this configuration is "
-                                "committed",
-                    "note": "fp32 in / fp32 accumulate; every fp32 product is six bf16 partial products on the bf16 matrix pipe (peak for "
-                            "fp32-equivalent FLOPs 2500 / 6 = 416.7) or, on the calls that ran the fp16 two-piece form, three fp16 ones "
-                            "(2500 / 3 = 833.3); `peak` is the FLOP-weighted harmonic mix of the two; the fp32 matrix instructions peak "
-                            "at 157.3"}
+                    "measured": "HIP events around each lsfa_conv_fwd call (convolution kernel + its reduce pass) of one interval re-issued "
+                                "eagerly after the timed region; algorithmic FLOPs = 2*M*N*K summed over the same calls; traffic = HBM bytes "
+                                "per call of the kernel family (FETCH_SIZE x2 + WRITE_SIZE, separate rocprofv3 PMC passes over the eager loop, "
+                                "profiles/traffic.json), null if no profile of this configuration is committed",
+                    "note": "fp32 in / fp32 accumulate; an fp32 product costs three fp16 matrix instructions' worth (two-piece form: the fp32 "
+                            "path's default, peak for fp32-equivalent FLOPs 2500 / 3 = 833.3), six bf16 ones (three-piece form: FlowNet, 416.7) "
+                            "or one (bf16 mode, 2500); `peak` is the dense bf16 / fp16 matrix peak divided by the FLOP-weighted products per "
+                            "fp32 product of this mix; the fp32 matrix instructions peak at 157.3"}
         else:
             roof = roof_hbm
         line = {
@@ -582,6 +626,7 @@ def main():
                              "note": "the timed region run %d times back to back; `value` is the first" % len(repeats),
                              "host_enqueue_share_of_repeats": [round(h / t, 3) for h, t in zip(host_enqueue, repeats[1:])]},
             "roofline": roof,
+            "multi_gpu": multi,
             "roofline_hbm_kernel": roof_hbm,
             "roofline_handwritten_ops": {
                 "per_op": ops, "dominant_by_time": dom,

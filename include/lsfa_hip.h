@@ -257,66 +257,65 @@ int lsfa_conv_nhwc_fused_fwd(const float* x, int N, int H, int W, int Cin, const
                              float* y2, const float* scale2, const float* shift2,
                              void* ws, size_t ws_bytes, void* stream);
 
-/* The same convolution (and, with kh = kw = 1, the 1x1 convolutions = plain GEMMs of the channels-last units) on the
- * bf16 matrix pipe with EXACTLY split fp32 operands: every fp32 value is cut into three bf16 pieces (8+8+8 mantissa
- * bits, no rounding) and a*b is accumulated in fp32 from the six partial products of weight >= 2^-16; the dropped
- * terms are below 2^-23 |a*b|, i.e. under one fp32 ulp of each product (lsfa_amd/csrc/conv_split_kernel.h).  Inputs,
- * outputs and accumulation are fp32; measured against a float64 convolution it is as close as the fp32-MFMA kernel.
- * The weights are cut and laid out once (bind time): lsfa_conv_split_weights writes lsfa_conv_split_weight_bytes(...)
- * bytes from w (Cout, kh, kw, Cin).  Cin % 32 == 0, Cout % 64 == 0.  y_nchw != 0: y, y2 and residual are (N, Cout, Ho, Wo)
- * — the layout the reference's operators (and lsfa_warp_bilinear's `add` operand) take — instead of (N, Ho, Wo, Cout); x is
- * always channels-last.  Arguments otherwise as lsfa_conv_nhwc_fused_fwd. */
-/* measurement switch (tools/lab/conv_split_lab.py): 0 = the launch plan decides (default), 1 = 128 x 64 workgroup tiles only
- * and the 2-stage ring (the r2 kernel), 2 = 128 x 128 tiles wherever Cout % 128 == 0, 3 = as 0 without the 4-stage ring.  The k order
- * per output is the same in every variant; results differ only where the number of K slices does. */
-int lsfa_conv_split_set_variant(int variant);
-
-/* r3 (opt-in): the same convolution with fp32 operands cut into TWO fp16 pieces and three matrix instructions per product
- * (hi*hi + hi*lo + lo*hi, fp32 accumulate; as close to float64 as the three-piece bf16 form, half its matrix-pipe cycles).
- * fp16's exponent range makes it need a bound on max|x|: `amax` = the 256 partial maxima lsfa_amax_partial wrote for x (or for a map
- * that bounds x, e.g. the input of an interpolation); the weights are packed as w * 2^w_exp with max|w| * 2^w_exp in [2^13, 2^14).
- * 128 x 128 tiles: Cout % 128 == 0, Cin % 32 == 0.  Non-finite inputs give non-finite outputs, not necessarily the same ones as fp32.
- * Replaces the same reference convolutions as lsfa_conv_split_fwd (e.g. feat_conv_3x3, resnet_v1_101_flownet_rfcn.py:44-55). */
-size_t lsfa_conv_split_h_weight_bytes(int Cout, int kh, int kw, int Cin);
-int lsfa_conv_split_h_weights(const float* w, int Cout, int kh, int kw, int Cin, int w_exp, void* out, void* stream);
+/* The convolutions of the frame path (and, with kh = kw = 1, the 1x1 convolutions = plain GEMMs of the channels-last units):
+ * fp32 in, fp32 accumulate, fp32 out, with every fp32 product formed on the bf16 / fp16 matrix pipe from `pieces` pieces per operand
+ * (gfx950 has no xf32 MFMA and its fp32 MFMA runs at 1/16 of the bf16 / fp16 rate):
+ *   pieces = 3  three bf16 pieces (8 + 8 + 8 mantissa bits, an exact cut) and the six partial products of weight >= 2^-16;
+ *   pieces = 2  two fp16 pieces of x * s and w * 2^w_exp (hi = fp16(v), lo = fp16(v - hi)) and the three products hi hi + hi lo + lo hi:
+ *               half the matrix-pipe cycles of the six-product form and at least as close to a float64 convolution (tests/test_hip_ops.py).
+ *               fp16's exponent range makes it need the map's scale: `amax_in` = 256 floats whose maximum is >= max|x| (lsfa_amax_partial
+ *               of x, a producing convolution's `amax_out`, or of a map that bounds x); s is the power of two that puts that maximum
+ *               into [2^13, 2^14).  An UNDER-estimate makes fp16(x s) overflow: the output turns non-finite and bit 0 of *status is
+ *               raised - lsfa_status_check() turns it into an error instead of a silently wrong feature map.
+ *   pieces = 1  one bf16 piece (round to nearest even), one product: the bf16 mode (BASELINE configs[2]).
+ * Replaces mx.sym.Convolution (+ the BatchNorm / ReLU / residual add around it) of dff_rfcn/symbols/resnet.py:70-101,
+ * sym_common.py:92-135, resnet_v1_101_flownet_rfcn.py:44-55 (feat_conv_3x3), :150-207 (FlowNet), :94-109 (Nq), :209-236 (small net),
+ * :479-546 (RPN / R-FCN score maps).
+ * Weights are cut and laid out once at bind time: lsfa_conv_weights writes lsfa_conv_weight_bytes(...) bytes (2 * pieces per weight, in
+ * MFMA fragment order) from w (Cout, kh, kw, Cin); Cin % 32 == 0, Cout % 64 == 0; w_exp (pieces == 2 only) = 13 - floor(log2 max|w|).
+ * Operands may be VIEWS of wider channels-last maps (FlowNet's Concat / Crop / Deconvolution nodes then need no copies):
+ *   x   (N, H, W, lda) with the Cin input channels first in each pixel's row (lda = 0: Cin; a multiple of 4);
+ *   y   points at the first output element; ldy floats between output pixels (0: Cout); out_H > 0 places output pixel (oy, ox) of
+ *       image n at y + (((n*out_H + oy*out_sy)*out_W + ox*out_sx) * ldy) - a channel slice of a concatenated map, or every other pixel
+ *       of it (one parity of a stride-2 transposed convolution); Ho, Wo > 0: the output grid of this launch when it is not the
+ *       convolution's own;
+ *   y_nchw != 0: y, y2 and residual are (N, Cout, Ho, Wo) - the layout the reference's operators take - instead of channels-last.
+ * Epilogue: + bias[c], + residual (may alias y), act (0 none, 1 ReLU, 2 LeakyReLU 0.1), and optionally a second output
+ * y2 = max(y * scale2[c] + shift2[c], 0) - the NEXT pre-activation unit's bn1 + relu1 (resnet.py:77-79) - and `amax_out`: 256 unsigned
+ * slots that receive (atomicMax on the bit pattern; the caller zeroes them once per frame) max|y2| if y2 is given, else max|y|.
+ * K may be cut into slices whose partial sums go through `ws` and are added in a fixed order (bit-reproducible). */
+typedef struct lsfa_conv_desc {
+  const float* x; int lda; int N, H, W, Cin;
+  const void* wfrag; int pieces; int w_exp; const float* amax_in;
+  const float* bias; int Cout, kh, kw, stride, pad_h, pad_w, dil;
+  int act; int y_nchw; const float* residual; float* y; int ldy;
+  float* y2; const float* scale2; const float* shift2;
+  unsigned* amax_out; unsigned* status;
+  int Ho, Wo, out_H, out_W, out_sy, out_sx;
+  int prof_tag;          /* lsfa_prof_*: 0 counts the call as "conv", 1 as "flownet" */
+} lsfa_conv_desc;
+size_t lsfa_conv_weight_bytes(int Cout, int kh, int kw, int Cin, int pieces);
+int lsfa_conv_weights(const float* w, int Cout, int kh, int kw, int Cin, int pieces, int w_exp, void* wfrag, void* stream);
+size_t lsfa_conv_workspace_bytes(const lsfa_conv_desc* d);
+int lsfa_conv_fwd(const lsfa_conv_desc* d, void* ws, size_t ws_bytes, void* stream);
+/* 256 partial maxima of |x| (n floats, n % 4 == 0, 16-byte aligned): an `amax_in` for maps no convolution of this library produced */
 int lsfa_amax_partial(const float* x, long long n, float* out256, void* stream);
-size_t lsfa_conv_split_h_workspace_bytes(int N, int H, int W, int Cin, int Cout, int kh, int kw, int stride, int pad, int dil);
-int lsfa_conv_split_h_fwd(const float* x, const void* wfrag_h, int w_exp, const float* amax, const float* bias, int N, int H, int W,
-                          int Cin, int Cout, int kh, int kw, int stride, int pad, int dil, int act, int y_nchw, float* y, void* ws,
-                          size_t ws_bytes, void* stream);
-size_t lsfa_conv_split_weight_bytes(int Cout, int kh, int kw, int Cin);
-int lsfa_conv_split_weights(const float* w, int Cout, int kh, int kw, int Cin, void* wfrag, void* stream);
-size_t lsfa_conv_split_workspace_bytes(int N, int H, int W, int Cin, int Cout, int kh, int kw, int stride, int pad, int dil);
-int lsfa_conv_split_fwd(const float* x, int N, int H, int W, int Cin, const void* wfrag, const float* bias, int Cout,
-                        int kh, int kw, int stride, int pad, int dil, int relu, int y_nchw, const float* residual, float* y,
-                        float* y2, const float* scale2, const float* shift2,
-                        void* ws, size_t ws_bytes, void* stream);
-/* The same convolution on VIEWS of wider channels-last maps, for FlowNet (resnet_v1_101_flownet_rfcn.py:150-207), whose
- * Concat / Crop / Deconvolution nodes then need no copies:
- *   x   (N, H, W, lda) with the Cin input channels first in each pixel's row (lda >= Cin, a multiple of 4);
- *   y   points at the first output element; output pixel (oy, ox) of image n goes to
- *       y + (((n*out_H + oy*out_sy)*out_W + ox*out_sx) * ldy)  (out_H = 0: the plain (N, Ho, Wo, ldy) map) — a channel slice
- *       [c0, c0 + Cout) of a concatenated map (y advanced by c0), or every other pixel of it: a Deconvolution(kernel 4,
- *       stride 2) + Crop(offset 1) is four such launches with 2x2 taps, one per output parity (py, px), pad_h = 1 - py,
- *       pad_w = 1 - px;
- *   Ho, Wo > 0: the output grid of this launch when smaller than the convolution's (a phase's share of the cropped map);
- *   separate pad_h / pad_w; act: 0 none, 1 ReLU, 2 LeakyReLU(0.1) (sym_common / :153 `LeakyReLU(act_type='leaky', slope=0.1)`).
- * workspace: lsfa_conv_split_view_workspace_bytes of the same arguments (Ho, Wo = 0: the convolution's own output grid). */
-/* Deconvolution(kernel 4, stride 2) + Crop(offset (1,1)) to Hc x Wc (+ bias + activation) as ONE launch of the four phase
- * convolutions above (resnet_v1_101_flownet_rfcn.py:170-176 `deconv5` ... `deconv2`): x (N, Hi, Wi, lda) with Cin channels used,
- * wfrag4 = four consecutive blocks of lsfa_conv_split_weight_bytes(Cout, 2, 2, Cin) bytes, block py*2 + px =
- * lsfa_conv_split_weights of the (Cout, 2, 2, Cin) weight w[:, :, kys, kxs] transposed to (out, in, ky, kx), kys = (3, 1) for py = 0
+/* Reads and clears the status word the convolutions raise (synchronises `stream`): LSFA_OK, or LSFA_EOVERFLOW with lsfa_last_error()
+ * saying which bit was set.  The frame loop calls it where it synchronises anyway (end of a video, after a benchmark region). */
+#define LSFA_EOVERFLOW (-4)
+int lsfa_status_check(unsigned* status_dev, void* stream);
+/* measurement hook (tools/lab/conv_ring_lab.py): force the kernel (1: never the halo / direct forms), the tile width nt (2 | 4), the
+ * ring depth st (2..4) and the number of K slices; 0 = the launch plan decides.  Process-wide; results stay bit-reproducible per setting. */
+int lsfa_conv_plan_override(int kernel, int nt, int st, int slices);
+/* Deconvolution(kernel 4, stride 2) + Crop(offset (1,1)) to Hc x Wc (+ bias + activation) as ONE launch of four 2x2-tap phase
+ * convolutions (resnet_v1_101_flownet_rfcn.py:170-176 `deconv5` ... `deconv2`): x (N, Hi, Wi, lda) with Cin channels used,
+ * wfrag4 = four consecutive blocks of lsfa_conv_weight_bytes(Cout, 2, 2, Cin, pieces) bytes, block py*2 + px =
+ * lsfa_conv_weights of the (Cout, 2, 2, Cin) weight w[:, :, kys, kxs] transposed to (out, in, ky, kx), kys = (3, 1) for py = 0
  * and (2, 0) for py = 1 (kxs alike); y points at channel c0 of pixel (0, 0) of the (N, Hc, Wc, ldy) map. */
-size_t lsfa_deconv4x4s2_crop_workspace_bytes(int N, int Hi, int Wi, int Cin, int Cout, int Hc, int Wc);
-int lsfa_deconv4x4s2_crop_fwd(const float* x, int lda, int N, int Hi, int Wi, int Cin, const void* wfrag4,
-                              const float* bias, int Cout, int act, float* y, int ldy, int Hc, int Wc, void* ws,
-                              size_t ws_bytes, void* stream);
-size_t lsfa_conv_split_view_workspace_bytes(int lda, int N, int H, int W, int Cin, int Cout, int kh, int kw, int stride, int pad_h,
-                                            int pad_w, int dil, int Ho, int Wo);
-int lsfa_conv_split_view_fwd(const float* x, int lda, int N, int H, int W, int Cin, const void* wfrag, const float* bias,
-                             int Cout, int kh, int kw, int stride, int pad_h, int pad_w, int dil, int act, float* y, int ldy,
-                             int Ho, int Wo, int out_H, int out_W, int out_sy, int out_sx, void* ws, size_t ws_bytes,
-                             void* stream);
+size_t lsfa_deconv4x4s2_crop_workspace_bytes(int N, int Hi, int Wi, int Cin, int Cout, int Hc, int Wc, int pieces);
+int lsfa_deconv4x4s2_crop_fwd(const float* x, int lda, int N, int Hi, int Wi, int Cin, const void* wfrag4, int pieces, int w_exp,
+                              const float* amax_in, const float* bias, int Cout, int act, float* y, int ldy, int Hc, int Wc,
+                              unsigned* amax_out, unsigned* status, void* ws, size_t ws_bytes, void* stream);
 
 /* ---------------------------------------------------------------------------
  * The stem of the ResNets and the frame shrink in front of the small net, three launches instead of six library ones.

@@ -24,7 +24,9 @@
 
 #include <stdlib.h>
 
-#include "conv_split_kernel.h"
+#include <algorithm>
+
+#include "conv_ring_kernel.h"
 
 using namespace lsfa;
 
@@ -263,35 +265,97 @@ extern "C" int lsfa_conv_nhwc_fwd(const float* x, int N, int H, int W, int Cin, 
                                   nullptr, ws, ws_bytes, stream);
 }
 
-// ---- the same convolution on the bf16 matrix pipe with exactly split fp32 operands (conv_split_kernel.h) ----
+// ---- the split-operand convolution family (conv_split_kernel.h, conv_ring_kernel.h) -----------------------------------------------------
+// fp32 in, fp32 accumulate, fp32 out; every fp32 product is formed on the bf16 / fp16 matrix pipe from `pieces` pieces per operand:
+//   3  three bf16 pieces, six products (exact cut, no scale needed)
+//   2  two fp16 pieces + a power-of-two scale per map (amax_in), three products: the default of the fp32 path since r4
+//   1  one bf16 piece, one product: the bf16 mode (BASELINE configs[2])
 
 namespace {
-// how a split convolution is launched: which kernel, the tile grid, how K is cut
+// how a convolution is launched: which kernel, the tile grid, how K is cut
 struct SplitPlan {
-  int nt;               // general kernel: 32-channel column tiles per wave (2: conv_split_kernel, 4: conv_split_wide_kernel<4>)
-  bool deep;            // general kernel, nt == 2: the four-stage ring (conv_split_deep_kernel), one workgroup per CU
+  int nt;               // ring kernel: 32-channel column tiles per wave (2: 128 x 64 workgroup tiles, 4: 128 x 128)
+  int st;               // ring kernel: stages of the LDS ring
   bool direct;          // conv_split_direct_kernel: operands straight into registers, a wave per 32 x 64 tile, no K slices
-  bool halo;            // the 3x3 halo kernel (stride 1, pad = dilation 1 or 2), else the general one
+  bool halo;            // the 3x3 halo kernel (stride 1, pad = dilation 1 or 2), else the ring kernel
   int dil;
   int patches_x, patches_y;
   int nx, ny, slices;   // tiles: nx pixel tiles x ny channel tiles x slices
-  int per_slice;        // chunks (general: of taps*Cin/32; halo: of Cin/32) per slice
+  int per_slice;        // chunks (ring: of taps*Cin/32; halo: of Cin/32) per slice
   int units_per_wg;     // halo, balanced mode: (tile, channel chunk) units per workgroup, else 0
   int max_pieces;       // ... and the most workgroups that can share one tile
 };
 
-// lab switch (lsfa_conv_split_set_variant): 0 = plan decides, 1 = the r2 kernel only (128 x 64 tiles, 2-stage ring), 2 = 128-channel tiles
-// wherever Cout allows, 3 = plan decides but without the 4-stage ring
-std::atomic<int> g_split_variant{0};
+// lab override (lsfa_conv_plan_override): 0 = the plan decides
+std::atomic<int> g_force_nt{0}, g_force_st{0}, g_force_slices{0}, g_force_kernel{0};
 
-SplitPlan split_plan(int N, int H, int W, int Cin, int Cout, int kh, int kw, int stride, int pad, int dil) {
+size_t ring_lds_bytes(int nt, int pieces, int st) { return (size_t)st * (16384 + (size_t)nt * pieces * 2048); }
+bool ring_ok(int nt, int pieces, int st) {
+  if (st < 2 || st > 4 || (nt != 2 && nt != 4) || pieces < 1 || pieces > 3) return false;
+  if ((nt * pieces) % 2) return false;
+  if (nt == 4 && pieces == 3 && st == 4) return false;       // 160 KB exactly: no room for anything else
+  return ring_lds_bytes(nt, pieces, st) <= 160 * 1024 && (st - 2) * (4 + nt * pieces / 2) <= 63;
+}
+
+// Cost model of the ring kernel, microseconds (calibrated on tools/lab/conv_ring_lab.py sweeps, profiles/r4/conv_ring_lab.txt):
+// a workgroup's chunk costs what the slowest of three things costs -
+//   its bytes through the CU's fill path (~55 KB/us per CU, shared by the workgroups resident on it),
+//   its matrix + cut work on the wave's SIMD (2 * nt * products MFMAs of 32 cycles at ~2 GHz, + ~0.1 us of cutting; two resident
+//   workgroups share the SIMDs),
+//   the arrival latency of a chunk (~1 us from L2 / the Infinity Cache) spread over the st - 1 chunks in flight -
+// plus ~3.5 us per launch (dispatch, first arrival, epilogue) and, for K slices, the reduce pass (a launch + the partial sums at ~3 TB/s).
+double ring_cost(long tiles, int chunk_total, double out_mb, int nt, int pieces, int st, int s) {
+  static const int prods[4] = {0, 1, 3, 6};
+  const int per = (chunk_total + s - 1) / s;
+  const int res = 2 * ring_lds_bytes(nt, pieces, st) <= 160 * 1024 ? 2 : 1;
+  const long wgs = tiles * s;
+  const int on_cu = (wgs > 256 && res == 2) ? 2 : 1;
+  const long slots = 256L * res;
+  const long rounds = (wgs + slots - 1) / slots;
+  const double bytes_kb = 16.0 + nt * pieces * 2.0;
+  const double t_fill = bytes_kb / 55.0 * on_cu;
+  const double t_simd = (2.0 * nt * prods[pieces] * 32.0 / 2000.0 + 0.10) * on_cu;
+  const double t_lat = 1.0 / (st - 1) / (on_cu == 2 ? 2.0 : 1.0);
+  const double t_chunk = std::max(t_fill, std::max(t_simd, t_lat));
+  return rounds * (per * t_chunk + 3.5) + (s > 1 ? 3.5 + s * out_mb * 2.0 / 3.0 : 0.0);
+}
+
+void ring_plan(SplitPlan& p, long P, int chunk_total, int Cout, int pieces) {
+  const double out_mb = (double)P * Cout * 4.0 / 1e6;
+  const int f_nt = g_force_nt.load(), f_st = g_force_st.load(), f_s = g_force_slices.load();
+  double best = 1e30;
+  p.nx = (int)((P + convsplit::kWgPix - 1) / convsplit::kWgPix);
+  for (int nt = 2; nt <= 4; nt += 2) {
+    if (Cout % (32 * nt)) continue;
+    if (f_nt && nt != f_nt) continue;
+    const long tiles = (long)p.nx * (Cout / (32 * nt));
+    for (int st = 2; st <= 4; ++st) {
+      if (!ring_ok(nt, pieces, st)) continue;
+      if (f_st && st != f_st) continue;
+      for (int s = 1; s <= 16; ++s) {
+        if (f_s && s != f_s) continue;
+        if (!f_s && s > 1 && chunk_total / s < 4) break;
+        const int per = (chunk_total + s - 1) / s;
+        if ((chunk_total + per - 1) / per != s) continue;      // every slice non-empty
+        const double t = ring_cost(tiles, chunk_total, out_mb, nt, pieces, st, s);
+        if (t < best) { best = t; p.nt = nt; p.st = st; p.slices = s; p.per_slice = per; }
+      }
+    }
+  }
+  if (best >= 1e30) {      // an override that fits nothing: the plainest valid form
+    p.nt = 2; p.st = 2; p.slices = 1; p.per_slice = chunk_total;
+  }
+  p.ny = Cout / (32 * p.nt);
+}
+
+SplitPlan split_plan(int N, int H, int W, int Cin, int Cout, int kh, int kw, int stride, int pad, int dil, int pieces) {
   SplitPlan p = {};
-  p.nt = 2;
+  p.nt = 2; p.st = 2;
   const int Ho = (H + 2 * pad - dil * (kh - 1) - 1) / stride + 1, Wo = (W + 2 * pad - dil * (kw - 1) - 1) / stride + 1;
   p.ny = Cout / convsplit::kWgCh;
   p.dil = dil;
-  p.halo = kh == 3 && kw == 3 && stride == 1 && pad == dil && (dil == 1 || dil == 2);
-  // two 4-wave workgroups per CU is the design point: 512 workgroups fill the chip
+  p.halo = kh == 3 && kw == 3 && stride == 1 && pad == dil && (dil == 1 || dil == 2) && g_force_kernel.load() != 1;
+  // two 4-wave workgroups per CU is the halo kernel's design point: 512 workgroups fill the chip
   if (p.halo) {
     p.patches_x = (W + convsplit::kPatchCols - 1) / convsplit::kPatchCols;
     p.patches_y = (H + convsplit::kPatchRows - 1) / convsplit::kPatchRows;
@@ -302,11 +366,8 @@ SplitPlan split_plan(int N, int H, int W, int Cin, int Cout, int kh, int kw, int
     if (s > cpt) s = cpt;
     p.per_slice = (cpt + s - 1) / s;
     p.slices = (cpt + p.per_slice - 1) / p.per_slice;
-    // measured (tools/lab/conv_split_lab.py): the halo form wins where its patches alone fill the chip (res2 conv2 30.7 vs
-    // 34.6 us, the 256 -> 1024 fuse convolution 91 vs 106); where K must be cut anyway the general kernel's finer cut
-    // (it slices taps x chunks) keeps more CUs busy (res4 conv2 32.7 vs 35.4, res3 conv2 31.4 vs 34.8)
-    // (r3, tried: the small net's 64 -> 64 convolutions as 20 unsliced halo workgroups of 18 tap steps: 22-25 us against 16.5 + 8.4
-    // for the sliced general tiles + reduce pass — a step is ~1.2 us of DMA latency when a workgroup has its CU to itself)
+    // measured (r2, tools/lab/conv_split_lab.py): the halo form wins where its patches alone fill the chip (res2 conv2, the 256 -> 1024
+    // fuse convolution); where K must be cut anyway the ring kernel's finer cut (it slices taps x chunks) keeps more CUs busy
     if (p.slices > 1) p.halo = false;
     // balanced mode: fewer than 512 tiles but more than 512 (tile, chunk) units -> equal unit counts per workgroup
     // (fuse_reduce_add: 320 tiles x 8 chunks = 512 workgroups x 5 instead of one round of 320 x 8)
@@ -316,66 +377,25 @@ SplitPlan split_plan(int N, int H, int W, int Cin, int Cout, int kh, int kw, int
       if (per * 4 <= cpt * 3) { p.units_per_wg = per; p.max_pieces = (cpt + per - 1) / per + 1; }     // worth it from 25 % shorter
     }
   }
-  if (!p.halo) {
-    const long P = (long)N * Ho * Wo;
-    p.nx = (int)((P + convsplit::kWgPix - 1) / convsplit::kWgPix);
-    const int chunk_total = kh * kw * (Cin / 32);
-    const int variant = g_split_variant.load();
-    // 128 x 128 workgroup tiles pay from ~128 chunks of K on (tools/lab/conv_split_lab.py, profiles/r3/conv_split_lab.txt: the DCN
-    // contraction 92 -> 82 us, feat_conv_3x3 506 -> 491); on the short-K convolutions halving the tile count costs more
-    // ... or when the 128 x 64 tiles alone overflow the 512 workgroup slots (the R-FCN score-map GEMM: 19 x 30 = 570 tiles of 16 chunks
-    // = two rounds; 19 x 15 of the wide ones = one)
-    if (Cout % 128 == 0 && variant != 1 && (variant == 2 || chunk_total >= 128 || (long)p.nx * (Cout / 64) > 512)) { p.nt = 4; p.ny = Cout / 128; }
-    const double chunk_us = p.nt == 4 ? 1.6 : 1.2;
-    // How many slices of K.  Two workgroups per CU run almost as fast as one each (measured: ~1.2 us per chunk either
-    // way), so time ~ rounds of 512 workgroups x chunks per slice, plus the reduce pass over `slices` partial outputs
-    // (~3 TB/s effective).  A 304-workgroup grid run as one round leaves 40 % of the slots empty for its whole length;
-    // cut 5 ways it is 3 full rounds of a fifth each (feat_conv_3x3: 700 -> ~450 us).
-    const long wgs = (long)p.nx * p.ny;
-    const double out_mb = (double)P * Cout * 4.0 / 1e6;
-    double best = 0;
-    int best_s = 1;
-    bool best_deep = false;
-    // two ways to run a grid: two 2-stage workgroups per CU (512 slots; a chunk ~1.2 us each, the two overlapping) or one 4-stage
-    // workgroup per CU (256 slots; ~0.95 us per chunk: three chunks in flight hide the DMA latency, what is left is one wave per
-    // SIMD issuing 7 DMAs + ~110 cut instructions + 24 MFMAs).  The ring pays on grids that cannot fill 512 slots whichever way K
-    // is cut (res4 conv1: 24.3 -> 20.9 us); measured per shape in profiles/r3/conv_split_lab.txt
-    for (int deep = 0; deep <= ((p.nt == 2 && variant != 1 && variant != 3) ? 1 : 0); ++deep) {
-      const double per_chunk = deep ? 0.95 : chunk_us;
-      const long slots = deep ? 256 : 512;
-      for (int s = 1; s <= 16; ++s) {
-        if (s > 1 && chunk_total / s < (deep ? 6 : 8)) break;
-        const int per = (chunk_total + s - 1) / s;
-        const int used = (chunk_total + per - 1) / per;
-        if (used != s) continue;
-        const long rounds = (wgs * s + slots - 1) / slots;
-        const double t = (double)rounds * per * per_chunk + (deep ? 1.5 : 0.0) + (s > 1 ? 3.0 + s * out_mb * 2.0 / 3.0 : 0.0);
-        if ((s == 1 && deep == 0) || t < best * 0.97) { best = t; best_s = s; best_deep = deep != 0; }      // a finer cut must pay for itself
-      }
-    }
-    p.deep = best_deep;
-    p.per_slice = (chunk_total + best_s - 1) / best_s;
-    p.slices = (chunk_total + p.per_slice - 1) / p.per_slice;
-  }
+  if (!p.halo) ring_plan(p, (long)N * Ho * Wo, kh * kw * (Cin / 32), Cout, pieces);
   return p;
 }
 
-// the general kernel's plan for an output grid of Ho x Wo pixels (what a view launch falls back to)
-SplitPlan split_plan_general(int N, int Ho, int Wo, int Cin, int Cout, int kh, int kw) {
-  // stride 7 with a 1x1 input-independent shape: split_plan only looks at the OUTPUT grid for the general kernel, so describe
-  // a convolution with that output: stride 1, no padding, input (Ho + kh - 1) x (Wo + kw - 1), and a stride that rules out the halo form
-  SplitPlan p = split_plan(N, (Ho - 1) * 3 + kh, (Wo - 1) * 3 + kw, Cin, Cout, kh, kw, 3, 0, 1);
+// the ring kernel's plan for an output grid of Ho x Wo pixels (what a view launch falls back to)
+SplitPlan split_plan_general(int N, int Ho, int Wo, int Cin, int Cout, int kh, int kw, int pieces) {
+  SplitPlan p = {};
+  p.dil = 1;
+  ring_plan(p, (long)N * Ho * Wo, kh * kw * (Cin / 32), Cout, pieces);
   return p;
 }
 
 // the plan of a launch whose operands may be views: the halo form needs the plain geometry
 SplitPlan view_plan(int N, int H, int W, int Cin, int Cout, int kh, int kw, int stride, int pad_h, int pad_w, int dil, int lda, int Ho_grid,
-                    int Wo_grid) {
+                    int Wo_grid, int pieces) {
   const int Ho = (H + 2 * pad_h - dil * (kh - 1) - 1) / stride + 1, Wo = (W + 2 * pad_w - dil * (kw - 1) - 1) / stride + 1;
-  SplitPlan p = split_plan(N, H, W, Cin, Cout, kh, kw, stride, pad_h, dil);
   const bool plain = pad_h == pad_w && lda == Cin && Ho_grid == Ho && Wo_grid == Wo;
-  if (!plain) p = split_plan_general(N, Ho_grid, Wo_grid, Cin, Cout, kh, kw);
-  return p;
+  if (!plain) return split_plan_general(N, Ho_grid, Wo_grid, Cin, Cout, kh, kw, pieces);
+  return split_plan(N, H, W, Cin, Cout, kh, kw, stride, pad_h, dil, pieces);
 }
 
 size_t split_workspace(const SplitPlan& p, long P, int Cout) {
@@ -383,57 +403,42 @@ size_t split_workspace(const SplitPlan& p, long P, int Cout) {
     return (size_t)p.nx * p.ny * p.max_pieces * convsplit::kThreads * 32 * sizeof(float);
   return p.slices > 1 ? align_up((size_t)p.slices * P * Cout * sizeof(float), 256) : 256;
 }
-}  // namespace
 
-extern "C" int lsfa_conv_split_set_variant(int variant) {
-  LSFA_REQUIRE(variant >= 0 && variant <= 3, "lsfa_conv_split_set_variant: unknown variant %d", variant);
-  g_split_variant.store(variant);
-  return LSFA_OK;
+bool direct_fits(const convsplit::Args& a, long P, int pieces) {
+  const size_t wbytes = (size_t)a.kh * a.kw * a.Cin * 2 * pieces;      // per output channel
+  return a.nphase <= 1 && a.stride == 1 && wbytes * 64 <= (256u << 10) && P <= 16384 &&
+         (size_t)((P + 31) / 32) * wbytes * a.Cout <= (48u << 20) && g_force_kernel.load() != 1;
 }
 
-extern "C" size_t lsfa_conv_split_weight_bytes(int Cout, int kh, int kw, int Cin) {
-  if (Cout <= 0 || kh <= 0 || kw <= 0 || Cin <= 0 || Cin % 32 != 0 || Cout % 64 != 0) return 0;
-  return (size_t)Cout * kh * kw * Cin * 6;      // three bf16 pieces per weight
+template <int NT, int PC, int ST>
+void launch_ring(const convsplit::Args& a, dim3 grid, hipStream_t s, int nx, int ny, int nz) {
+  hipLaunchKernelGGL((convsplit::conv_ring_kernel<NT, PC, ST>), grid, dim3(convsplit::kThreads), 0, s, a, nx, ny, nz);
 }
-
-extern "C" int lsfa_conv_split_weights(const float* w, int Cout, int kh, int kw, int Cin, void* wfrag, void* stream) {
-  LSFA_REQUIRE(w && wfrag, "lsfa_conv_split_weights: NULL argument");
-  if (lsfa_conv_split_weight_bytes(Cout, kh, kw, Cin) == 0) {
-    set_error("lsfa_conv_split_weights: Cin=%d must be a multiple of 32 and Cout=%d of 64", Cin, Cout);
-    return LSFA_ENOTSUP;
+template <int PC>
+bool launch_ring_pc(int nt, int st, const convsplit::Args& a, dim3 grid, hipStream_t s, int nx, int ny, int nz) {
+  if (nt == 2 && st == 2) launch_ring<2, PC, 2>(a, grid, s, nx, ny, nz);
+  else if (nt == 2 && st == 3) launch_ring<2, PC, 3>(a, grid, s, nx, ny, nz);
+  else if (nt == 2 && st == 4) launch_ring<2, PC, 4>(a, grid, s, nx, ny, nz);
+  else if (nt == 4 && st == 2) launch_ring<4, PC, 2>(a, grid, s, nx, ny, nz);
+  else if (nt == 4 && st == 3) launch_ring<4, PC, 3>(a, grid, s, nx, ny, nz);
+  else if (nt == 4 && st == 4 && PC < 3) launch_ring<4, (PC < 3 ? PC : 2), 4>(a, grid, s, nx, ny, nz);
+  else return false;
+  return true;
+}
+template <int PC>
+void launch_halo_direct(const SplitPlan& p, const convsplit::Args& a, dim3 grid, hipStream_t s, long P) {
+  if (p.direct) {
+    const int nchunks = a.kh * a.kw * (a.Cin / 32);
+    int nw = (nchunks + 1) / 2;            // at least two chunks per wave, at most kDirectMaxWaves waves
+    if (nw > convsplit::kDirectMaxWaves) nw = convsplit::kDirectMaxWaves;
+    if (nw < 1) nw = 1;
+    hipLaunchKernelGGL(convsplit::conv_split_direct_kernel<PC>, dim3((unsigned)((P + 31) / 32), a.Cout / 64), dim3(64 * nw),
+                       (size_t)(nw - 1) * 32 * 64 * sizeof(float), s, a);
+  } else if (p.dil == 1) {
+    hipLaunchKernelGGL((convsplit::conv_split3x3_kernel<1, PC>), grid, dim3(convsplit::kThreads), 0, s, a, p.patches_x, p.patches_y, p.nx, p.ny, p.slices);
+  } else {
+    hipLaunchKernelGGL((convsplit::conv_split3x3_kernel<2, PC>), grid, dim3(convsplit::kThreads), 0, s, a, p.patches_x, p.patches_y, p.nx, p.ny, p.slices);
   }
-  const long total = (long)kh * kw * (Cin / 32) * (Cout / 32) * 2 * 64;
-  hipLaunchKernelGGL(convsplit::split_weights_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, w,
-                     (uint4*)wfrag, Cout, kh * kw, Cin);
-  LSFA_LAUNCH_CHECK("lsfa_conv_split_weights");
-  return LSFA_OK;
-}
-
-namespace {
-// every split convolution goes through here; the public entry points fill in what they expose
-// the fp16 two-piece form runs on the 128 x 128 tiles only: K slices by the same cost model (a chunk ~1.1 us: 24 instead of 48 matrix
-// instructions per wave next to the same DMAs)
-SplitPlan wide_h_plan(long P, int Cin, int Cout, int kh, int kw) {
-  SplitPlan p = {};
-  p.nt = 4;
-  p.ny = Cout / 128;
-  p.nx = (int)((P + convsplit::kWgPix - 1) / convsplit::kWgPix);
-  const int chunk_total = kh * kw * (Cin / 32);
-  const long wgs = (long)p.nx * p.ny;
-  const double out_mb = (double)P * Cout * 4.0 / 1e6;
-  double best = 0;
-  int best_s = 1;
-  for (int s = 1; s <= 16; ++s) {
-    if (s > 1 && chunk_total / s < 8) break;
-    const int per = (chunk_total + s - 1) / s;
-    if ((chunk_total + per - 1) / per != s) continue;
-    const long rounds = (wgs * s + 511) / 512;
-    const double t = (double)rounds * per * 1.1 + (s > 1 ? 3.0 + s * out_mb * 2.0 / 3.0 : 0.0);
-    if (s == 1 || t < best * 0.97) { best = t; best_s = s; }
-  }
-  p.per_slice = (chunk_total + best_s - 1) / best_s;
-  p.slices = (chunk_total + p.per_slice - 1) / p.per_slice;
-  return p;
 }
 
 // LSFA_CONV_TILE_ORDER (lab): how workgroup ids map to (slice, channel tile, pixel tile), see xcd_tile
@@ -442,14 +447,18 @@ static int tile_order_from_env() {
   return e ? atoi(e) : 0;
 }
 
-int conv_split_launch(convsplit::Args a, void* ws, size_t ws_bytes, void* stream, const char* who, int prof_op = LSFA_OP_CONV) {
+// every split-operand convolution goes through here; the public entry points fill in what they expose
+int conv_split_launch(convsplit::Args a, int pieces, void* ws, size_t ws_bytes, void* stream, const char* who, int prof_op = LSFA_OP_CONV) {
   static const int tile_order = tile_order_from_env();
   a.tile_order = tile_order;
   const int N = a.N, H = a.H, W = a.W, Cin = a.Cin, Cout = a.Cout, kh = a.kh, kw = a.kw, stride = a.stride, dil = a.dil;
   LSFA_REQUIRE(a.x && a.wfrag && a.y, "%s: NULL argument", who);
+  LSFA_REQUIRE(pieces >= 1 && pieces <= 3, "%s: pieces must be 1 (bf16), 2 (fp16 hi / lo) or 3 (bf16 x 3), not %d", who, pieces);
+  LSFA_REQUIRE(pieces != 2 || a.amax, "%s: the fp16 two-piece form needs amax_in (lsfa_amax_partial of x, a producer's amax_out, or a bound)", who);
   LSFA_REQUIRE(N > 0 && H > 0 && W > 0 && kh > 0 && kw > 0 && stride > 0 && a.pad_h >= 0 && a.pad_w >= 0 && dil > 0, "%s: bad shape", who);
   LSFA_REQUIRE(!a.y2 || (a.scale2 && a.shift2), "%s: y2 given without scale2 / shift2", who);
   LSFA_REQUIRE(!a.y2 || a.y2 != a.y, "%s: y2 must not alias y", who);
+  LSFA_REQUIRE(a.act >= 0 && a.act <= 2, "%s: act must be 0 (none), 1 (ReLU) or 2 (LeakyReLU 0.1)", who);
   if (Cin % 32 != 0 || Cout % convsplit::kWgCh != 0) {
     set_error("%s: Cin=%d must be a multiple of 32 and Cout=%d of %d", who, Cin, Cout, convsplit::kWgCh);
     return LSFA_ENOTSUP;
@@ -470,26 +479,21 @@ int conv_split_launch(convsplit::Args a, void* ws, size_t ws_bytes, void* stream
   const long P = (long)N * a.Ho * a.Wo;
   LSFA_REQUIRE(((long)N * a.out_H * a.out_W + 1) * (long)(a.y_nchw ? Cout : a.ldy) < (1L << 31) && P * Cout < (1L << 31) &&
                ((long)N * H * W + (long)(a.pad_h + 1) * (W + 1)) * a.lda < (1L << 31), "%s: tensor too large", who);
-  SplitPlan p = view_plan(N, H, W, Cin, Cout, kh, kw, stride, a.pad_h, a.pad_w, dil, a.lda, a.Ho, a.Wo);
-  // small weights on a small map: the direct kernel (a 64-channel group's weights <= 256 KB, re-read by every 32-pixel tile)
-  // and the weights' re-reads stay modest: (P / 32) tiles x all weights <= 48 MB through L2
-  if (a.nphase <= 1 && stride == 1 && (size_t)kh * kw * Cin * 64 * 6 <= (256u << 10) && P <= 16384 &&
-      (size_t)((P + 31) / 32) * kh * kw * Cin * Cout * 6 <= (48u << 20) && g_split_variant.load() != 1) {
+  SplitPlan p = view_plan(N, H, W, Cin, Cout, kh, kw, stride, a.pad_h, a.pad_w, dil, a.lda, a.Ho, a.Wo, pieces);
+  // small weights on a small map: the direct kernel (a 64-channel group's weights <= 256 KB at three pieces, re-read by every 32-pixel
+  // tile) while the weights' re-reads stay modest: (P / 32) tiles x all weights <= 48 MB through L2
+  if (direct_fits(a, P, pieces) && !g_force_nt.load()) {
     p = SplitPlan{};
     p.direct = true;
     p.slices = 1;
   }
   const int nph = a.nphase > 1 ? a.nphase : 1;
-  if (a.amax) {      // the fp16 two-piece form: 128 x 128 tiles, plain launches
-    LSFA_REQUIRE(Cout % 128 == 0 && nph == 1, "%s: the fp16 form needs Cout %% 128 == 0 and no phases", who);
-    p = wide_h_plan(P, Cin, Cout, kh, kw);
-  }
   const size_t need = split_workspace(p, P, Cout) * (size_t)nph;
   if ((p.slices > 1 || p.units_per_wg > 0) && (!ws || ws_bytes < need)) {
     set_error("%s: workspace %zu < %zu bytes", who, ws_bytes, need);
     return LSFA_EWORKSPACE;
   }
-  LSFA_REQUIRE(nph == 1 || (!p.halo && p.units_per_wg == 0), "%s: phases need the general kernel", who);
+  LSFA_REQUIRE(nph == 1 || (!p.halo && p.units_per_wg == 0 && !p.direct), "%s: phases need the ring kernel", who);
   hipStream_t s = (hipStream_t)stream;
   a.part = p.slices > 1 ? (float*)ws : nullptr;
   a.part_stride = P * Cout;
@@ -504,26 +508,16 @@ int conv_split_launch(convsplit::Args a, void* ws, size_t ws_bytes, void* stream
     tiles = (p.nx * p.ny * (Cin / 32) + p.units_per_wg - 1) / p.units_per_wg;      // workgroups
   }
   const dim3 grid((unsigned)(8 * ((tiles + 7) / 8)));
-  if (p.direct) {
-    const int nchunks = kh * kw * (Cin / 32);
-    int nw = (nchunks + 1) / 2;            // at least two chunks per wave, at most kDirectMaxWaves waves
-    if (nw > convsplit::kDirectMaxWaves) nw = convsplit::kDirectMaxWaves;
-    if (nw < 1) nw = 1;
-    hipLaunchKernelGGL(convsplit::conv_split_direct_kernel, dim3((unsigned)((P + 31) / 32), Cout / 64), dim3(64 * nw),
-                       (size_t)(nw - 1) * 32 * 64 * sizeof(float), s, a);
+  if (p.direct || p.halo) {
+    if (pieces == 3) launch_halo_direct<3>(p, a, grid, s, P);
+    else if (pieces == 2) launch_halo_direct<2>(p, a, grid, s, P);
+    else launch_halo_direct<1>(p, a, grid, s, P);
+  } else {
+    const bool ok = pieces == 3 ? launch_ring_pc<3>(p.nt, p.st, a, grid, s, p.nx, p.ny, p.slices * nph)
+                  : pieces == 2 ? launch_ring_pc<2>(p.nt, p.st, a, grid, s, p.nx, p.ny, p.slices * nph)
+                                : launch_ring_pc<1>(p.nt, p.st, a, grid, s, p.nx, p.ny, p.slices * nph);
+    LSFA_REQUIRE(ok, "%s: no ring kernel for nt=%d st=%d pieces=%d", who, p.nt, p.st, pieces);
   }
-  else if (p.halo && p.dil == 1)
-    hipLaunchKernelGGL(convsplit::conv_split3x3_kernel<1>, grid, dim3(convsplit::kThreads), 0, s, a, p.patches_x, p.patches_y, p.nx, p.ny, p.slices);
-  else if (p.halo)
-    hipLaunchKernelGGL(convsplit::conv_split3x3_kernel<2>, grid, dim3(convsplit::kThreads), 0, s, a, p.patches_x, p.patches_y, p.nx, p.ny, p.slices);
-  else if (a.amax)
-    hipLaunchKernelGGL((convsplit::conv_split_wide_kernel<4, 2>), grid, dim3(convsplit::kThreads), 0, s, a, p.nx, p.ny, p.slices * nph);
-  else if (p.nt == 4)
-    hipLaunchKernelGGL(convsplit::conv_split_wide_kernel<4>, grid, dim3(convsplit::kThreads), 0, s, a, p.nx, p.ny, p.slices * nph);
-  else if (p.deep)
-    hipLaunchKernelGGL(convsplit::conv_split_deep_kernel, grid, dim3(convsplit::kThreads), 0, s, a, p.nx, p.ny, p.slices * nph);
-  else
-    hipLaunchKernelGGL(convsplit::conv_split_kernel, grid, dim3(convsplit::kThreads), 0, s, a, p.nx, p.ny, p.slices * nph);
   if (p.units_per_wg > 0) {
     hipLaunchKernelGGL(convsplit::conv_split3x3_fixup_kernel, dim3((unsigned)(p.nx * p.ny)), dim3(convsplit::kThreads), 0, s, a, p.patches_x,
                        p.patches_y, p.nx);
@@ -539,32 +533,64 @@ int conv_split_launch(convsplit::Args a, void* ws, size_t ws_bytes, void* stream
   LSFA_LAUNCH_CHECK(who);
   return LSFA_OK;
 }
+
+convsplit::Args args_of(const lsfa_conv_desc& d) {
+  convsplit::Args a = {};
+  a.x = d.x; a.wfrag = (const uint4*)d.wfrag; a.bias = d.bias; a.y = d.y;
+  a.N = d.N; a.H = d.H; a.W = d.W; a.Cin = d.Cin; a.Cout = d.Cout; a.kh = d.kh; a.kw = d.kw; a.stride = d.stride;
+  a.pad_h = d.pad_h; a.pad_w = d.pad_w; a.dil = d.dil; a.act = d.act; a.y_nchw = d.y_nchw;
+  a.res = d.residual; a.y2 = d.y2; a.scale2 = d.scale2; a.shift2 = d.shift2;
+  a.lda = d.lda; a.ldy = d.ldy; a.Ho = d.Ho; a.Wo = d.Wo;
+  if (d.out_H > 0) { a.view = 1; a.out_H = d.out_H; a.out_W = d.out_W; a.out_sy = d.out_sy; a.out_sx = d.out_sx; }
+  a.amax = d.amax_in; a.w_exp = d.w_exp; a.amax_out = d.amax_out; a.status = d.status;
+  return a;
+}
 }  // namespace
 
-extern "C" size_t lsfa_conv_split_workspace_bytes(int N, int H, int W, int Cin, int Cout, int kh, int kw, int stride, int pad, int dil) {
-  if (N <= 0 || H <= 0 || W <= 0 || Cout <= 0 || Cin <= 0 || stride <= 0 || kh <= 0 || kw <= 0 || dil <= 0 || pad < 0) return 0;
-  const int Ho = (H + 2 * pad - dil * (kh - 1) - 1) / stride + 1, Wo = (W + 2 * pad - dil * (kw - 1) - 1) / stride + 1;
-  if (Ho <= 0 || Wo <= 0) return 0;
-  const SplitPlan p = split_plan(N, H, W, Cin, Cout, kh, kw, stride, pad, dil);
-  return split_workspace(p, (long)N * Ho * Wo, Cout);
-}
-
-// ---- r3 (opt-in): the fp16 two-piece form (three matrix instructions per product; conv_split_kernel.h) ------------------------------
-extern "C" size_t lsfa_conv_split_h_weight_bytes(int Cout, int kh, int kw, int Cin) {
-  if (Cout <= 0 || kh <= 0 || kw <= 0 || Cin <= 0) return 0;
-  return (size_t)Cout * kh * kw * Cin * 4;        // two fp16 pieces per weight
-}
-
-extern "C" int lsfa_conv_split_h_weights(const float* w, int Cout, int kh, int kw, int Cin, int w_exp, void* out, void* stream) {
-  LSFA_REQUIRE(w && out, "lsfa_conv_split_h_weights: NULL argument");
-  LSFA_REQUIRE(Cout > 0 && Cout % 128 == 0 && Cin > 0 && Cin % 32 == 0 && kh > 0 && kw > 0,
-               "lsfa_conv_split_h_weights: Cout=%d must be a multiple of 128 and Cin=%d of 32", Cout, Cin);
-  LSFA_REQUIRE(w_exp > -120 && w_exp < 120, "lsfa_conv_split_h_weights: w_exp %d out of range", w_exp);
-  const long total = (long)kh * kw * (Cin / 32) * (Cout / 32) * 2 * 64;
-  hipLaunchKernelGGL(convsplit::split_weights_h_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, w,
-                     (uint4*)out, Cout, kh * kw, Cin, w_exp);
-  LSFA_LAUNCH_CHECK("lsfa_conv_split_h_weights");
+extern "C" int lsfa_conv_plan_override(int kernel, int nt, int st, int slices) {
+  LSFA_REQUIRE(kernel >= 0 && kernel <= 1 && (nt == 0 || nt == 2 || nt == 4) && (st == 0 || (st >= 2 && st <= 4)) && slices >= 0 && slices <= 16,
+               "lsfa_conv_plan_override: kernel 0/1, nt 0/2/4, st 0/2..4, slices 0..16");
+  g_force_kernel.store(kernel); g_force_nt.store(nt); g_force_st.store(st); g_force_slices.store(slices);
   return LSFA_OK;
+}
+
+extern "C" size_t lsfa_conv_weight_bytes(int Cout, int kh, int kw, int Cin, int pieces) {
+  if (Cout <= 0 || kh <= 0 || kw <= 0 || Cin <= 0 || Cin % 32 != 0 || Cout % 64 != 0 || pieces < 1 || pieces > 3) return 0;
+  return (size_t)Cout * kh * kw * Cin * 2 * pieces;
+}
+
+extern "C" int lsfa_conv_weights(const float* w, int Cout, int kh, int kw, int Cin, int pieces, int w_exp, void* wfrag, void* stream) {
+  LSFA_REQUIRE(w && wfrag, "lsfa_conv_weights: NULL argument");
+  if (lsfa_conv_weight_bytes(Cout, kh, kw, Cin, pieces) == 0) {
+    set_error("lsfa_conv_weights: Cin=%d must be a multiple of 32, Cout=%d of 64, pieces=%d one of 1, 2, 3", Cin, Cout, pieces);
+    return LSFA_ENOTSUP;
+  }
+  LSFA_REQUIRE(w_exp > -120 && w_exp < 120 && (pieces == 2 || w_exp == 0), "lsfa_conv_weights: w_exp %d out of range (it is 0 unless pieces == 2)", w_exp);
+  const long total = (long)kh * kw * (Cin / 32) * (Cout / 32) * 2 * 64;
+  const dim3 grid((unsigned)((total + 255) / 256));
+  hipStream_t s = (hipStream_t)stream;
+  if (pieces == 3) hipLaunchKernelGGL(convsplit::pack_weights_kernel<3>, grid, dim3(256), 0, s, w, (uint4*)wfrag, Cout, kh * kw, Cin, 0);
+  else if (pieces == 2) hipLaunchKernelGGL(convsplit::pack_weights_kernel<2>, grid, dim3(256), 0, s, w, (uint4*)wfrag, Cout, kh * kw, Cin, w_exp);
+  else hipLaunchKernelGGL(convsplit::pack_weights_kernel<1>, grid, dim3(256), 0, s, w, (uint4*)wfrag, Cout, kh * kw, Cin, 0);
+  LSFA_LAUNCH_CHECK("lsfa_conv_weights");
+  return LSFA_OK;
+}
+
+extern "C" size_t lsfa_conv_workspace_bytes(const lsfa_conv_desc* d) {
+  if (!d || d->N <= 0 || d->H <= 0 || d->W <= 0 || d->Cout <= 0 || d->Cin <= 0 || d->stride <= 0 || d->kh <= 0 || d->kw <= 0 || d->dil <= 0 ||
+      d->pad_h < 0 || d->pad_w < 0 || d->pieces < 1 || d->pieces > 3 || d->Cin % 32 || d->Cout % 64)
+    return 0;
+  const int Hn = (d->H + 2 * d->pad_h - d->dil * (d->kh - 1) - 1) / d->stride + 1, Wn = (d->W + 2 * d->pad_w - d->dil * (d->kw - 1) - 1) / d->stride + 1;
+  const int Ho = d->Ho > 0 ? d->Ho : Hn, Wo = d->Wo > 0 ? d->Wo : Wn;
+  if (Ho <= 0 || Wo <= 0) return 0;
+  const SplitPlan p = view_plan(d->N, d->H, d->W, d->Cin, d->Cout, d->kh, d->kw, d->stride, d->pad_h, d->pad_w, d->dil, d->lda > 0 ? d->lda : d->Cin, Ho, Wo,
+                                d->pieces);
+  return split_workspace(p, (long)d->N * Ho * Wo, d->Cout);
+}
+
+extern "C" int lsfa_conv_fwd(const lsfa_conv_desc* d, void* ws, size_t ws_bytes, void* stream) {
+  LSFA_REQUIRE(d, "lsfa_conv_fwd: NULL descriptor");
+  return conv_split_launch(args_of(*d), d->pieces, ws, ws_bytes, stream, "lsfa_conv_fwd", d->prof_tag == 1 ? LSFA_OP_FLOWNET : LSFA_OP_CONV);
 }
 
 extern "C" int lsfa_amax_partial(const float* x, long long n, float* out, void* stream) {
@@ -575,40 +601,40 @@ extern "C" int lsfa_amax_partial(const float* x, long long n, float* out, void* 
   return LSFA_OK;
 }
 
-extern "C" size_t lsfa_conv_split_h_workspace_bytes(int N, int H, int W, int Cin, int Cout, int kh, int kw, int stride, int pad, int dil) {
-  if (N <= 0 || H <= 0 || W <= 0 || Cout <= 0 || Cout % 128 || Cin <= 0 || stride <= 0 || kh <= 0 || kw <= 0 || dil <= 0 || pad < 0) return 0;
-  const int Ho = (H + 2 * pad - dil * (kh - 1) - 1) / stride + 1, Wo = (W + 2 * pad - dil * (kw - 1) - 1) / stride + 1;
-  if (Ho <= 0 || Wo <= 0) return 0;
-  const SplitPlan p = wide_h_plan((long)N * Ho * Wo, Cin, Cout, kh, kw);
-  return split_workspace(p, (long)N * Ho * Wo, Cout);
-}
-
-extern "C" int lsfa_conv_split_h_fwd(const float* x, const void* wfrag_h, int w_exp, const float* amax, const float* bias, int N, int H,
-                                     int W, int Cin, int Cout, int kh, int kw, int stride, int pad, int dil, int act, int y_nchw,
-                                     float* y, void* ws, size_t ws_bytes, void* stream) {
-  LSFA_REQUIRE(amax, "lsfa_conv_split_h_fwd: amax (lsfa_amax_partial of x, or of a map that bounds it) must be given");
-  convsplit::Args a = {};
-  a.x = x; a.wfrag = (const uint4*)wfrag_h; a.bias = bias; a.y = y;
-  a.N = N; a.H = H; a.W = W; a.Cin = Cin; a.Cout = Cout; a.kh = kh; a.kw = kw; a.stride = stride; a.pad_h = a.pad_w = pad; a.dil = dil;
-  a.act = act; a.y_nchw = y_nchw;
-  a.amax = amax; a.w_exp = w_exp;
-  return conv_split_launch(a, ws, ws_bytes, stream, "lsfa_conv_split_h_fwd");
+// The device's status word (bit 0: a convolution wrote a non-finite value - with the fp16 form that is what an under-estimated amax
+// produces; bit 1: a convolution's INPUT maximum was already inf / NaN): read it (synchronising `stream`), clear it, and turn a set bit
+// into an error.
+extern "C" int lsfa_status_check(unsigned* status_dev, void* stream) {
+  LSFA_REQUIRE(status_dev, "lsfa_status_check: NULL status word");
+  unsigned h = 0;
+  hipStream_t s = (hipStream_t)stream;
+  hipError_t e = hipMemcpyAsync(&h, status_dev, sizeof(h), hipMemcpyDeviceToHost, s);
+  if (e == hipSuccess) e = hipStreamSynchronize(s);
+  if (e != hipSuccess) return hip_fail(e, "lsfa_status_check");
+  if (h == 0) return LSFA_OK;
+  e = hipMemsetAsync(status_dev, 0, sizeof(unsigned), s);
+  if (e == hipSuccess) e = hipStreamSynchronize(s);
+  if (e != hipSuccess) return hip_fail(e, "lsfa_status_check");
+  set_error("lsfa_status_check: status 0x%x:%s%s", h,
+            (h & 1u) ? " a convolution produced a non-finite output (fp16 two-piece form: amax_in under-estimates max|x|, or the input held inf / NaN)" : "",
+            (h & 2u) ? " a convolution's input maximum was inf / NaN" : "");
+  return LSFA_EOVERFLOW;
 }
 
 // Deconvolution(kernel 4, stride 2, pad 0) + Crop(offset (1,1)) to Hc x Wc as ONE launch of four 2x2-tap phase convolutions.
 // Output row 2m + py of the cropped map reads input rows (m - 1, m) through taps ky = (3, 1) when py = 0 and rows (m, m + 1)
 // through ky = (2, 0) when py = 1 (columns alike): phase (py, px) is an ordinary 2x2 convolution with padding (1 - py, 1 - px)
-// whose weights wfrag[py * 2 + px] the caller cut with lsfa_conv_split_weights from w[:, :, kys, kxs] (Cout, 2, 2, Cin).
-extern "C" size_t lsfa_deconv4x4s2_crop_workspace_bytes(int N, int Hi, int Wi, int Cin, int Cout, int Hc, int Wc) {
-  if (N <= 0 || Hi <= 0 || Wi <= 0 || Cin <= 0 || Cout <= 0 || Hc <= 0 || Wc <= 0) return 0;
+// whose weights wfrag[py * 2 + px] the caller cut with lsfa_conv_weights from w[:, :, kys, kxs] (Cout, 2, 2, Cin).
+extern "C" size_t lsfa_deconv4x4s2_crop_workspace_bytes(int N, int Hi, int Wi, int Cin, int Cout, int Hc, int Wc, int pieces) {
+  if (N <= 0 || Hi <= 0 || Wi <= 0 || Cin <= 0 || Cout <= 0 || Hc <= 0 || Wc <= 0 || pieces < 1 || pieces > 3) return 0;
   const int gh = (Hc + 1) / 2, gw = (Wc + 1) / 2;
-  const SplitPlan p = split_plan_general(N, gh, gw, Cin, Cout, 2, 2);
+  const SplitPlan p = split_plan_general(N, gh, gw, Cin, Cout, 2, 2, pieces);
   return split_workspace(p, (long)N * gh * gw, Cout) * 4;
 }
 
-extern "C" int lsfa_deconv4x4s2_crop_fwd(const float* x, int lda, int N, int Hi, int Wi, int Cin, const void* wfrag4,
-                                         const float* bias, int Cout, int act, float* y, int ldy, int Hc, int Wc, void* ws,
-                                         size_t ws_bytes, void* stream) {
+extern "C" int lsfa_deconv4x4s2_crop_fwd(const float* x, int lda, int N, int Hi, int Wi, int Cin, const void* wfrag4, int pieces, int w_exp,
+                                         const float* amax_in, const float* bias, int Cout, int act, float* y, int ldy, int Hc, int Wc,
+                                         unsigned* amax_out, unsigned* status, void* ws, size_t ws_bytes, void* stream) {
   LSFA_REQUIRE(x && wfrag4 && y, "lsfa_deconv4x4s2_crop_fwd: NULL argument");
   LSFA_REQUIRE(act >= 0 && act <= 2 && Hc > 0 && Wc > 0 && Hc <= 2 * Hi + 1 && Wc <= 2 * Wi + 1, "lsfa_deconv4x4s2_crop_fwd: bad shape");
   convsplit::Args a = {};
@@ -617,45 +643,9 @@ extern "C" int lsfa_deconv4x4s2_crop_fwd(const float* x, int lda, int N, int Hi,
   a.act = act; a.lda = lda; a.ldy = ldy;
   a.view = 1; a.out_H = Hc; a.out_W = Wc; a.out_sy = a.out_sx = 2;
   a.nphase = 4;
-  a.ph_wstride = (long)(lsfa_conv_split_weight_bytes(Cout, 2, 2, Cin) / 16);
+  a.ph_wstride = (long)(lsfa_conv_weight_bytes(Cout, 2, 2, Cin, pieces) / 16);
+  a.amax = amax_in; a.w_exp = w_exp; a.amax_out = amax_out; a.status = status;
   // the launch is sized for phase (0, 0), the largest grid
   a.pad_h = a.pad_w = 1; a.Ho = (Hc + 1) / 2; a.Wo = (Wc + 1) / 2;
-  return conv_split_launch(a, ws, ws_bytes, stream, "lsfa_deconv4x4s2_crop_fwd", LSFA_OP_FLOWNET);
-}
-
-extern "C" size_t lsfa_conv_split_view_workspace_bytes(int lda, int N, int H, int W, int Cin, int Cout, int kh, int kw, int stride, int pad_h,
-                                                       int pad_w, int dil, int Ho, int Wo) {
-  if (N <= 0 || H <= 0 || W <= 0 || Cout <= 0 || Cin <= 0 || stride <= 0 || kh <= 0 || kw <= 0 || dil <= 0 || pad_h < 0 || pad_w < 0) return 0;
-  const int Hn = (H + 2 * pad_h - dil * (kh - 1) - 1) / stride + 1, Wn = (W + 2 * pad_w - dil * (kw - 1) - 1) / stride + 1;
-  if (Ho <= 0) Ho = Hn;
-  if (Wo <= 0) Wo = Wn;
-  if (Ho <= 0 || Wo <= 0) return 0;
-  const SplitPlan p = view_plan(N, H, W, Cin, Cout, kh, kw, stride, pad_h, pad_w, dil, lda > 0 ? lda : Cin, Ho, Wo);
-  return split_workspace(p, (long)N * Ho * Wo, Cout);
-}
-
-extern "C" int lsfa_conv_split_fwd(const float* x, int N, int H, int W, int Cin, const void* wfrag, const float* bias, int Cout,
-                                   int kh, int kw, int stride, int pad, int dil, int relu, int y_nchw, const float* residual, float* y,
-                                   float* y2, const float* scale2, const float* shift2, void* ws, size_t ws_bytes, void* stream) {
-  convsplit::Args a = {};
-  a.x = x; a.wfrag = (const uint4*)wfrag; a.bias = bias; a.y = y;
-  a.N = N; a.H = H; a.W = W; a.Cin = Cin; a.Cout = Cout; a.kh = kh; a.kw = kw; a.stride = stride; a.pad_h = a.pad_w = pad; a.dil = dil;
-  a.act = relu ? 1 : 0; a.res = residual; a.y2 = y2; a.scale2 = scale2; a.shift2 = shift2; a.y_nchw = y_nchw;
-  return conv_split_launch(a, ws, ws_bytes, stream, "lsfa_conv_split_fwd");
-}
-
-extern "C" int lsfa_conv_split_view_fwd(const float* x, int lda, int N, int H, int W, int Cin, const void* wfrag, const float* bias,
-                                        int Cout, int kh, int kw, int stride, int pad_h, int pad_w, int dil, int act, float* y, int ldy,
-                                        int Ho, int Wo, int out_H, int out_W, int out_sy, int out_sx, void* ws, size_t ws_bytes,
-                                        void* stream) {
-  LSFA_REQUIRE(act >= 0 && act <= 2, "lsfa_conv_split_view_fwd: act must be 0 (none), 1 (ReLU) or 2 (LeakyReLU 0.1)");
-  convsplit::Args a = {};
-  a.x = x; a.wfrag = (const uint4*)wfrag; a.bias = bias; a.y = y;
-  a.N = N; a.H = H; a.W = W; a.Cin = Cin; a.Cout = Cout; a.kh = kh; a.kw = kw; a.stride = stride; a.pad_h = pad_h; a.pad_w = pad_w; a.dil = dil;
-  a.act = act; a.lda = lda; a.ldy = ldy; a.Ho = Ho; a.Wo = Wo;
-  if (out_H > 0) {
-    LSFA_REQUIRE(out_W > 0 && out_sy > 0 && out_sx > 0, "lsfa_conv_split_view_fwd: bad output view");
-    a.view = 1; a.out_H = out_H; a.out_W = out_W; a.out_sy = out_sy; a.out_sx = out_sx;
-  }
-  return conv_split_launch(a, ws, ws_bytes, stream, "lsfa_conv_split_view_fwd", LSFA_OP_FLOWNET);
+  return conv_split_launch(a, pieces, ws, ws_bytes, stream, "lsfa_deconv4x4s2_crop_fwd", LSFA_OP_FLOWNET);
 }

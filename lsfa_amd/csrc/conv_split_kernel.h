@@ -44,7 +44,6 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 constexpr int kWavePix = 32, kWgPix = 128, kWgCh = 64, kChunk = 32, kThreads = 256;
-constexpr int kChunkBytesB = 2 /*col tiles*/ * 2 /*steps*/ * 3 /*pieces*/ * 1024;      // 12 KB per chunk and workgroup
 
 struct Args {
   const float* x; const uint4* wfrag; const float* bias; float* y; float* part;
@@ -73,6 +72,10 @@ struct Args {
   // r3, fp16 two-piece form (conv_split_wide_kernel<NT, 2>): `amax` = kAmaxSlots partial maxima of |x| (lsfa_amax_partial), from which
   // every wave derives the power-of-two scale that puts x into fp16's range; the weights were packed as w * 2^w_exp
   const float* amax; int w_exp;
+  // r4: the epilogue (or the reduce pass of a K-sliced launch) leaves max|output| (of y2 when there is a second output) in
+  // amax_out[kAmaxSlots] by atomicMax on the bit patterns (the caller zeroes the slots once per frame), so that the layer that
+  // multiplies this output next needs no amax pass; a non-finite output raises bit 0 of *status (lsfa_status_check)
+  unsigned* amax_out; unsigned* status;
   int tile_order;   // 0: tiles numbered (slice, channel tile, pixel tile), pixel fastest; 1: (slice, pixel tile, channel tile), channel fastest
 };
 
@@ -126,13 +129,6 @@ __device__ __forceinline__ f32x16 mma(const uint4& a, const uint4& b, const f32x
 
 // acc += (a1 + a2 + a3) * (b1 + b2 + b3) without the three smallest terms, smallest kept terms first
 __device__ __forceinline__ f32x16 mma6(const Pieces& a, const uint4& b1, const uint4& b2, const uint4& b3, f32x16 acc) {
-#ifdef LSFA_LAB_MMA3      // timing experiment only (WRONG results): what three matrix instructions per k-step instead of six would cost
-  acc = mma(a.p2, b1, acc);
-  acc = mma(a.p1, b2, acc);
-  acc = mma(a.p1, b1, acc);
-  (void)b3;
-  return acc;
-#endif
   acc = mma(a.p3, b1, acc);
   acc = mma(a.p1, b3, acc);
   acc = mma(a.p2, b2, acc);
@@ -249,47 +245,176 @@ __device__ __forceinline__ void tile_store_part(float* part, int Cout, const int
     if ((valid >> r) & 1u) part[(size_t)p[r] * Cout + ch] = acc[r];
 }
 
+// ---- r4: operand pieces generic in PC (pieces per fp32 operand) -----------------------------------------------------------------------
+//   3 = three bf16 pieces, six products;  2 = two fp16 pieces + a power-of-two scale per map, three products;
+//   1 = one bf16 piece (round to nearest even), one product: the bf16 mode of BASELINE configs[2]
+struct PiecesN { uint4 p[3]; };
+
+__device__ __forceinline__ uint32_t bf16_rne_pair(float a, float b) {
+  typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+  bf16x2 v;
+  v[0] = (__bf16)a;
+  v[1] = (__bf16)b;
+  return __builtin_bit_cast(uint32_t, v);
+}
+
+template <int PC>
+__device__ __forceinline__ PiecesN cut8(const float4& a, const float4& b, float s) {
+  PiecesN r;
+  if (PC == 3) {
+    const Pieces p = split8(a, b);
+    r.p[0] = p.p1; r.p[1] = p.p2; r.p[2] = p.p3;
+  } else if (PC == 2) {
+    const PiecesH p = split8h(a, b, s);
+    r.p[0] = p.hi; r.p[1] = p.lo;
+  } else {
+    r.p[0] = make_uint4(bf16_rne_pair(a.x, a.y), bf16_rne_pair(a.z, a.w), bf16_rne_pair(b.x, b.y), bf16_rne_pair(b.z, b.w));
+  }
+  return r;
+}
+
+__device__ __forceinline__ float4 as_f4(const uint4& r) {
+  return make_float4(__uint_as_float(r.x), __uint_as_float(r.y), __uint_as_float(r.z), __uint_as_float(r.w));
+}
+
+// acc += A * B for one k-step; b0, b1, b2 = the (up to) PC fragments of (column tile, step) in piece order
+template <int PC>
+__device__ __forceinline__ f32x16 mma_pc(const PiecesN& a, const uint4& b0, const uint4& b1, const uint4& b2, f32x16 acc) {
+  if (PC == 3) {
+    Pieces p; p.p1 = a.p[0]; p.p2 = a.p[1]; p.p3 = a.p[2];
+    return mma6(p, b0, b1, b2, acc);
+  } else if (PC == 2) {
+    PiecesH p; p.hi = a.p[0]; p.lo = a.p[1];
+    return mma3h(p, b0, b1, acc);
+  }
+  return mma(a.p[0], b0, acc);
+}
+// ... with the fragments 64 uint4 apart in LDS
+template <int PC>
+__device__ __forceinline__ f32x16 mma_pc(const PiecesN& a, const uint4* B, f32x16 acc) {
+  return mma_pc<PC>(a, B[0], B[PC > 1 ? 64 : 0], B[PC > 2 ? 128 : 0], acc);
+}
+
+template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+
+// the fp16 form's scale from the kAmaxSlots partial maxima (floats or bit patterns of |x|: the same thing for non-negative values),
+// read by inline assembly with its own wait so that no compiler-visible vector load is pending when a DMA ring starts.
+// -> floor(log2(max)), 0 for an all-zero map; an inf / NaN maximum raises bit 1 of *status
+__device__ __forceinline__ int amax_exponent_asm(const float* amax, int lane, unsigned* status) {
+  static_assert(kAmaxSlots == 256, "four slots per lane");
+  const float* p = amax + lane;
+  uint32_t m0, m1, m2, m3;
+  asm volatile("global_load_dword %0, %4, off\n\t"
+               "global_load_dword %1, %4, off offset:256\n\t"
+               "global_load_dword %2, %4, off offset:512\n\t"
+               "global_load_dword %3, %4, off offset:768\n\t"
+               "s_waitcnt vmcnt(0)"
+               : "=&v"(m0), "=&v"(m1), "=&v"(m2), "=&v"(m3)
+               : "v"(p)
+               : "memory");
+  uint32_t m = max(max(m0 & 0x7FFFFFFFu, m1 & 0x7FFFFFFFu), max(m2 & 0x7FFFFFFFu, m3 & 0x7FFFFFFFu));
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) m = max(m, (uint32_t)__shfl_xor((int)m, d, 64));
+  const int e = (int)((m >> 23) & 255u);
+  if (e == 255 && status && lane == 0) atomicOr(status, 2u);      // the INPUT map already holds inf / NaN
+  return (e == 0 || e == 255) ? 0 : __builtin_amdgcn_readfirstlane(e - 127);
+}
+
+// a wave's largest |v| bit pattern -> a slot; non-finite -> status bit 0
+__device__ __forceinline__ void publish_amax(uint32_t m, unsigned* amax_out, unsigned* status, int slot) {
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) m = max(m, (uint32_t)__shfl_xor((int)m, d, 64));
+  if ((threadIdx.x & 63) == 0) {
+    if (amax_out) atomicMax(amax_out + (slot & (kAmaxSlots - 1)), m);
+    if (m >= 0x7F800000u && status) atomicOr(status, 1u);
+  }
+}
+
+// |v| as bits, with a non-finite PRE-activation value kept visible (ReLU turns NaN and -inf into 0)
+__device__ __forceinline__ uint32_t amax_bits(float pre, float post) {
+  const uint32_t b = __float_as_uint(pre) & 0x7FFFFFFFu;
+  return b >= 0x7F800000u ? b : (__float_as_uint(post) & 0x7FFFFFFFu);
+}
+
+// tile_store that also returns the maximum of what it wrote (of y2 when there is a second output: that is what the next layer multiplies)
+__device__ __forceinline__ uint32_t tile_store_max(const Args& a, const RowOut& ro, int ch, const f32x16& acc) {
+  const int cs = a.y_nchw ? a.Ho * a.Wo : 1;
+  const float bias = a.bias ? a.bias[ch] : 0.f;
+  float v[16], pre[16];
+#pragma unroll
+  for (int r = 0; r < 16; ++r) v[r] = acc[r] + bias;
+  if (a.res) {
+    float rv[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) rv[r] = ((ro.valid >> r) & 1u) ? a.res[ro.base[r] + ch * cs] : 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) v[r] = v[r] + rv[r];
+  }
+#pragma unroll
+  for (int r = 0; r < 16; ++r) { pre[r] = v[r]; v[r] = activate(v[r], a.act); }
+  uint32_t m = 0;
+#pragma unroll
+  for (int r = 0; r < 16; ++r)
+    if ((ro.valid >> r) & 1u) { a.y[ro.base[r] + ch * cs] = v[r]; m = max(m, amax_bits(pre[r], a.y2 ? 0.f : v[r])); }
+  if (a.y2) {
+    const float sc2 = a.scale2[ch], sh2 = a.shift2[ch];
+#pragma unroll
+    for (int r = 0; r < 16; ++r)
+      if ((ro.valid >> r) & 1u) {
+        const float w = fmaxf(v[r] * sc2 + sh2, 0.f);
+        a.y2[ro.base[r] + ch * cs] = w;
+        m = max(m, __float_as_uint(w) & 0x7FFFFFFFu);
+      }
+  }
+  return m;
+}
+
 // sum of the K slices in slice order (reproducible), then the same tail as tile_store; a float4 of channels per thread
 static __global__ __launch_bounds__(kThreads) void split_reduce_kernel(Args a, long n4, int slices) {
   if (a.nphase > 1) { apply_phase(a, blockIdx.y, slices); n4 = (long)a.N * a.Ho * a.Wo * a.Cout / 4; }
   const long i = (long)blockIdx.x * kThreads + threadIdx.x;
-  if (i >= n4) return;
-  const float4* part = reinterpret_cast<const float4*>(a.part);
-  float4 s = part[i];
-  int z = 1;
-  for (; z + 4 <= slices; z += 4) {       // four slices' loads in flight together; the additions stay in slice order
-    float4 v[4];
+  uint32_t m = 0;
+  if (i < n4) {
+    const float4* part = reinterpret_cast<const float4*>(a.part);
+    float4 s = part[i];
+    int z = 1;
+    for (; z + 4 <= slices; z += 4) {       // four slices' loads in flight together; the additions stay in slice order
+      float4 v[4];
 #pragma unroll
-    for (int u = 0; u < 4; ++u) v[u] = part[(size_t)(z + u) * n4 + i];
+      for (int u = 0; u < 4; ++u) v[u] = part[(size_t)(z + u) * n4 + i];
 #pragma unroll
-    for (int u = 0; u < 4; ++u) { s.x = s.x + v[u].x; s.y = s.y + v[u].y; s.z = s.z + v[u].z; s.w = s.w + v[u].w; }
-  }
-  for (; z < slices; ++z) {
-    const float4 v = part[(size_t)z * n4 + i];
-    s.x = s.x + v.x; s.y = s.y + v.y; s.z = s.z + v.z; s.w = s.w + v.w;
-  }
-  const int c4 = a.Cout / 4;
-  const int p = (int)(i / c4), ch = (int)(i - (long)p * c4) * 4;
-  const int base = out_pixel_base(a, p), cs = a.y_nchw ? a.Ho * a.Wo : 1;
-  float o1[4] = {s.x, s.y, s.z, s.w}, o2[4];
+      for (int u = 0; u < 4; ++u) { s.x = s.x + v[u].x; s.y = s.y + v[u].y; s.z = s.z + v[u].z; s.w = s.w + v[u].w; }
+    }
+    for (; z < slices; ++z) {
+      const float4 v = part[(size_t)z * n4 + i];
+      s.x = s.x + v.x; s.y = s.y + v.y; s.z = s.z + v.z; s.w = s.w + v.w;
+    }
+    const int c4 = a.Cout / 4;
+    const int p = (int)(i / c4), ch = (int)(i - (long)p * c4) * 4;
+    const int base = out_pixel_base(a, p), cs = a.y_nchw ? a.Ho * a.Wo : 1;
+    float o1[4] = {s.x, s.y, s.z, s.w}, o2[4];
 #pragma unroll
-  for (int k = 0; k < 4; ++k) {
-    float v = o1[k] + (a.bias ? a.bias[ch + k] : 0.f);
-    if (a.res) v = v + a.res[base + (ch + k) * cs];
-    v = activate(v, a.act);
-    o1[k] = v;
-    o2[k] = a.y2 ? fmaxf(v * a.scale2[ch + k] + a.shift2[ch + k], 0.f) : 0.f;
-  }
-  if (cs == 1 && ((base + ch) & 3) == 0 && ((uintptr_t)a.y & 15) == 0 && (!a.y2 || ((uintptr_t)a.y2 & 15) == 0)) {
-    *reinterpret_cast<float4*>(a.y + base + ch) = make_float4(o1[0], o1[1], o1[2], o1[3]);
-    if (a.y2) *reinterpret_cast<float4*>(a.y2 + base + ch) = make_float4(o2[0], o2[1], o2[2], o2[3]);
-    return;
-  }
+    for (int k = 0; k < 4; ++k) {
+      float v = o1[k] + (a.bias ? a.bias[ch + k] : 0.f);
+      if (a.res) v = v + a.res[base + (ch + k) * cs];
+      const float pre = v;
+      v = activate(v, a.act);
+      o1[k] = v;
+      o2[k] = a.y2 ? fmaxf(v * a.scale2[ch + k] + a.shift2[ch + k], 0.f) : 0.f;
+      m = max(m, max(amax_bits(pre, a.y2 ? 0.f : v), __float_as_uint(o2[k]) & 0x7FFFFFFFu));
+    }
+    if (cs == 1 && ((base + ch) & 3) == 0 && ((uintptr_t)a.y & 15) == 0 && (!a.y2 || ((uintptr_t)a.y2 & 15) == 0)) {
+      *reinterpret_cast<float4*>(a.y + base + ch) = make_float4(o1[0], o1[1], o1[2], o1[3]);
+      if (a.y2) *reinterpret_cast<float4*>(a.y2 + base + ch) = make_float4(o2[0], o2[1], o2[2], o2[3]);
+    } else {
 #pragma unroll
-  for (int k = 0; k < 4; ++k) {
-    a.y[base + (ch + k) * cs] = o1[k];
-    if (a.y2) a.y2[base + (ch + k) * cs] = o2[k];
+      for (int k = 0; k < 4; ++k) {
+        a.y[base + (ch + k) * cs] = o1[k];
+        if (a.y2) a.y2[base + (ch + k) * cs] = o2[k];
+      }
+    }
   }
+  publish_amax(m, a.amax_out, a.status, blockIdx.x * 4 + (threadIdx.x >> 6));
 }
 
 // The same for an NCHW output without residual / second output (feat_conv_3x3, fuse_reduce_add): split_reduce_kernel's lanes walk
@@ -328,14 +453,19 @@ static __global__ __launch_bounds__(kThreads) void split_reduce_nchw_kernel(Args
 #pragma unroll
     for (int j = 0; j < 4; ++j) { sum[j].x = sum[j].x + v[j].x; sum[j].y = sum[j].y + v[j].y; sum[j].z = sum[j].z + v[j].z; sum[j].w = sum[j].w + v[j].w; }
   }
+  uint32_t m = 0;
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
     const int pl = row + 16 * j;
-    T[4 * cg + 0][pl] = activate(sum[j].x + bias[0], a.act);
-    T[4 * cg + 1][pl] = activate(sum[j].y + bias[1], a.act);
-    T[4 * cg + 2][pl] = activate(sum[j].z + bias[2], a.act);
-    T[4 * cg + 3][pl] = activate(sum[j].w + bias[3], a.act);
+    const float pre[4] = {sum[j].x + bias[0], sum[j].y + bias[1], sum[j].z + bias[2], sum[j].w + bias[3]};
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const float v = activate(pre[k], a.act);
+      T[4 * cg + k][pl] = v;
+      if (ok[j]) m = max(m, amax_bits(pre[k], v));
+    }
   }
+  publish_amax(m, a.amax_out, a.status, (blockIdx.y * gridDim.x + blockIdx.x) * 4 + (t >> 6));
   __syncthreads();
   // a wave writes 64 consecutive pixels of one channel per instruction (256 contiguous bytes), 16 channels in turn
   const int lane = t & 63, wv = t >> 6;
@@ -352,8 +482,6 @@ static __global__ __launch_bounds__(kThreads) void split_reduce_nchw_kernel(Args
 }
 
 constexpr int kStageA = 4 * 4 * 64;                     // uint4 per stage: 4 waves x 32 pixels x 8 slots = 16 KB
-constexpr int kStageB = kChunkBytesB / 16;              // 768 uint4 = 12 KB
-constexpr int kStage = kStageA + kStageB;               // 28 KB; two stages = 56 KB, two workgroups per CU
 
 __device__ __attribute__((aligned(64))) const float g_zero_block[32] = {};
 
@@ -378,69 +506,6 @@ struct Walk {
     if (++kc == chunks_per_tap) { kc = 0; if (++tx == kw) { tx = 0; ++ty; } }
   }
 };
-
-template <int ST>
-__device__ __forceinline__ void issue_chunk(uint4 (*S)[kStage], const float* __restrict__ x, const uint4* __restrict__ wblock,
-                                            const Geom& g, const Walk& wk) {
-  const int gch = wk.gch, kc = wk.kc;
-  const int dy = wk.ty * g.dil, dx = wk.tx * g.dil;
-  const int doff = (dy * g.W + dx) * g.lda + kc * kChunk;        // wave-uniform part of the source offset
-  uint4* a_dst = &S[ST][g.wave * 256];                           // + i * 64 (+ lane, implied by the DMA)
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const bool ok = (unsigned)(g.iy0[i] + dy) < (unsigned)g.H && (unsigned)(g.ix0[i] + dx) < (unsigned)g.W;
-    const float* src = ok ? x + (g.off0[i] + doff) : g_zero_block;
-    __builtin_amdgcn_global_load_lds(reinterpret_cast<const uint4*>(src), a_dst + i * 64, 16, 0, 0);
-  }
-  const uint4* wsrc = wblock + (size_t)gch * g.wstride + g.wave * 192 + g.lane;
-  uint4* b_dst = &S[ST][kStageA + g.wave * 192];
-#pragma unroll
-  for (int i = 0; i < 3; ++i) __builtin_amdgcn_global_load_lds(wsrc + i * 64, b_dst + i * 64, 16, 0, 0);
-}
-
-template <int ST>
-__device__ __forceinline__ void consume_chunk(uint4 (*S)[kStage], const Geom& g, f32x16& acc0, f32x16& acc1) {
-  const uint4* A = &S[ST][g.wave * 256];
-  const uint4* B = &S[ST][kStageA + g.lane];
-  const uint4 r0 = A[g.frag[0]], r1 = A[g.frag[1]], r2 = A[g.frag[2]], r3 = A[g.frag[3]];
-  const float4 c0 = make_float4(__uint_as_float(r0.x), __uint_as_float(r0.y), __uint_as_float(r0.z), __uint_as_float(r0.w));
-  const float4 c1 = make_float4(__uint_as_float(r1.x), __uint_as_float(r1.y), __uint_as_float(r1.z), __uint_as_float(r1.w));
-  const float4 c2 = make_float4(__uint_as_float(r2.x), __uint_as_float(r2.y), __uint_as_float(r2.z), __uint_as_float(r2.w));
-  const float4 c3 = make_float4(__uint_as_float(r3.x), __uint_as_float(r3.y), __uint_as_float(r3.z), __uint_as_float(r3.w));
-  const Pieces s0 = split8(c0, c1), s1 = split8(c2, c3);
-  // fragment (col tile t, step s, piece p) at ((t*2 + s)*3 + p)*64 + lane
-  acc0 = mma6(s0, B[(0 * 3 + 0) * 64], B[(0 * 3 + 1) * 64], B[(0 * 3 + 2) * 64], acc0);
-  acc1 = mma6(s0, B[(2 * 3 + 0) * 64], B[(2 * 3 + 1) * 64], B[(2 * 3 + 2) * 64], acc1);
-  acc0 = mma6(s1, B[(1 * 3 + 0) * 64], B[(1 * 3 + 1) * 64], B[(1 * 3 + 2) * 64], acc0);
-  acc1 = mma6(s1, B[(3 * 3 + 0) * 64], B[(3 * 3 + 1) * 64], B[(3 * 3 + 2) * 64], acc1);
-}
-
-#ifdef LSFA_CS_STAMPS     // lab builds only (tools/lab/conv_split_lab.py --stamps): shader-clock stamps of chunk 6, wave 0 of workgroup 8
-__device__ long long g_cs_stamps[8];
-#define CS_STAMP(k) do { if (c == 6 && threadIdx.x == 0 && blockIdx.x == 8) g_cs_stamps[k] = (long long)__builtin_amdgcn_s_memtime(); } while (0)
-#else
-#define CS_STAMP(k) do { } while (0)
-#endif
-
-// chunk c of n: prefetch c+1 into the other stage, compute c, retire the DMAs, meet the other waves.
-// (Measured per chunk, one wave, shader cycles: issue 7 DMAs ~970, read A + cut + 24 MFMAs ~1430, DMA wait ~350,
-// barrier ~100.  The same copy through registers — plain loads, ds_write_b128 after the MFMAs — measured the same
-// total: what is slow is getting 28 KB per chunk into the CU at all, ~20-25 B/clk per CU with every CU pulling, i.e.
-// the L2's aggregate rate; 228-456 workgroups re-read A 4x and B 19x.  See DESIGN.md "Dense contractions".)
-template <int ST>
-__device__ __forceinline__ void pipeline_step(uint4 (*S)[kStage], const float* __restrict__ x, const uint4* __restrict__ wblock,
-                                              const Geom& g, Walk& wk, int c, int n, f32x16& acc0, f32x16& acc1) {
-  CS_STAMP(0);
-  if (c + 1 < n) { issue_chunk<ST ^ 1>(S, x, wblock, g, wk); wk.next(g.kw, g.chunks_per_tap); }
-  CS_STAMP(1);
-  consume_chunk<ST>(S, g, acc0, acc1);
-  CS_STAMP(2);
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  CS_STAMP(3);
-  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-  __builtin_amdgcn_s_barrier();
-  CS_STAMP(4);
-}
 
 // Workgroup -> tile, XCD-aware.  The hardware deals consecutive workgroup ids round-robin to the 8 XCDs (id % 8),
 // each with its own 4 MB L2.  Tiles are numbered (slice, channel tile, pixel tile) with the pixel tile fastest and
@@ -469,421 +534,6 @@ __device__ __forceinline__ Tile xcd_tile(int id, int nx, int ny, int nz, int ord
   return r;
 }
 
-// grid (8 * ceil(tiles / 8)); block 256; 56 KB of LDS.  tiles = ceil(P / 128) * (Cout / 64) * slices
-static __global__ __launch_bounds__(kThreads, 2) void conv_split_kernel(Args a, int nx, int ny, int nz) {
-  __shared__ __attribute__((aligned(16))) uint4 S[2][kStage];
-  Tile tile = xcd_tile(blockIdx.x, nx, ny, nz, a.tile_order);
-  if (tile.x < 0) return;
-  if (a.nphase > 1) { const int slices = nz / a.nphase, phase = tile.z / slices; tile.z -= phase * slices; apply_phase(a, phase, slices); }
-  const int tid = threadIdx.x;
-  const int P = a.N * a.Ho * a.Wo;
-  if (tile.x * kWgPix >= P) return;          // a phase with a smaller grid than the launch was sized for
-  const int taps = a.kh * a.kw;
-  Geom g;
-  g.lane = tid & 63;
-  g.wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  g.H = a.H; g.W = a.W; g.Cin = a.Cin; g.lda = a.lda; g.kw = a.kw; g.stride = a.stride; g.dil = a.dil;
-  g.chunks_per_tap = a.Cin / kChunk;
-  const int chunk_total = taps * g.chunks_per_tap;
-  g.chunk0 = tile.z * a.chunks_per_slice;
-  const int nchunks = min(a.chunks_per_slice, chunk_total - g.chunk0);
-  const int col_tiles = a.Cout / 32;
-  g.wstride = (size_t)col_tiles * (kChunkBytesB / 32);                    // 384 uint4 per 32-col tile and chunk
-  const uint4* wblock = a.wfrag + (size_t)(2 * tile.y) * (kChunkBytesB / 32);
-  const int m0 = tile.x * kWgPix + g.wave * kWavePix;
-  // DMA role: instruction i moves pixels 8i .. 8i+7 of the wave's tile, lane -> pixel 8i + (lane >> 3), slot lane & 7
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int pix = m0 + 8 * i + (g.lane >> 3);
-    const int piece = (g.lane & 7) ^ ((4 * i + (g.lane >> 4)) & 7);      // slot -> source piece: the bank swizzle
-    g.iy0[i] = g.ix0[i] = -(1 << 24);
-    g.off0[i] = 0;
-    if (pix < P) {
-      const int pn = pix / (a.Ho * a.Wo), r = pix - pn * a.Ho * a.Wo, py = r / a.Wo, px = r - py * a.Wo;
-      g.iy0[i] = py * a.stride - a.pad_h;
-      g.ix0[i] = px * a.stride - a.pad_w;
-      g.off0[i] = ((pn * a.H + g.iy0[i]) * a.W + g.ix0[i]) * a.lda + 4 * piece;     // may be negative; only used in bounds
-    }
-  }
-  // (slot q of pixel p holds piece q ^ ((p >> 1) & 7); for p = 8i + (lane >> 3) that is (4i + (lane >> 4)) & 7: issue_chunk)
-  // fragment role: pixel r = lane & 31, pieces 4h .. 4h+3 of its row (h = lane >> 5)
-  {
-    const int r = g.lane & 31, h = g.lane >> 5, sw = (r >> 1) & 7;
-#pragma unroll
-    for (int j = 0; j < 4; ++j) g.frag[j] = r * 8 + ((4 * h + j) ^ sw);
-  }
-
-  f32x16 acc0, acc1;
-#pragma unroll
-  for (int i = 0; i < 16; ++i) { acc0[i] = 0.f; acc1[i] = 0.f; }
-
-  Walk wk;       // the next chunk to fetch
-  wk.gch = g.chunk0;
-  {
-    const int tap = g.chunk0 / g.chunks_per_tap;
-    wk.kc = g.chunk0 - tap * g.chunks_per_tap;
-    wk.ty = tap / a.kw;
-    wk.tx = tap - wk.ty * a.kw;
-  }
-  if (nchunks > 0) { issue_chunk<0>(S, a.x, wblock, g, wk); wk.next(g.kw, g.chunks_per_tap); }
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __builtin_amdgcn_s_barrier();
-  for (int c = 0; c < nchunks; c += 2) {
-    pipeline_step<0>(S, a.x, wblock, g, wk, c, nchunks, acc0, acc1);
-    if (c + 1 < nchunks) pipeline_step<1>(S, a.x, wblock, g, wk, c + 1, nchunks, acc0, acc1);
-  }
-
-  // C/D layout of 32x32: column = lane & 31 (channel), row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5) (pixel)
-  const int lane = g.lane;
-  int prow[16];
-  RowOut ro;
-  ro.valid = 0;
-#pragma unroll
-  for (int r = 0; r < 16; ++r) {
-    prow[r] = m0 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-    if (prow[r] < P) ro.valid |= 1u << r;
-  }
-  if (a.part) {
-    float* part = a.part + (size_t)tile.z * P * a.Cout;
-    tile_store_part(part, a.Cout, prow, ro.valid, tile.y * kWgCh + (lane & 31), acc0);
-    tile_store_part(part, a.Cout, prow, ro.valid, tile.y * kWgCh + 32 + (lane & 31), acc1);
-    return;
-  }
-#pragma unroll
-  for (int r = 0; r < 16; ++r) ro.base[r] = ((ro.valid >> r) & 1u) ? out_pixel_base(a, prow[r]) : 0;
-  tile_store(a, ro, tile.y * kWgCh + (lane & 31), acc0);
-  tile_store(a, ro, tile.y * kWgCh + 32 + (lane & 31), acc1);
-}
-
-// ---------------------------------------------------------------------------------------------------------------
-// r3: the same kernel with a DEEP ring.  A chunk is 24 MFMAs per wave (~0.35 us) but its 28 KB take ~1 us to arrive; with one
-// chunk in flight a step therefore costs ~1.2 us unless a second workgroup on the CU fills the gap — which only happens on
-// grids of more than ~256 workgroups.  Most launches of this network are smaller (a res4 conv1 is 228 workgroups, FlowNet's
-// late layers a few dozen): for those the ring has kDeep = 4 stages (112 KB, one workgroup per CU) and three chunks in
-// flight.  Per step: wait until all but the two youngest chunks' DMAs of this wave have landed (counted vmcnt: DMAs retire in
-// issue order), barrier (every wave's share of chunk c is there, and everybody is done reading chunk c-1's stage), issue
-// chunk c+3 into that stage, compute chunk c.  One barrier per chunk; all stage offsets are compile-time (the loop is unrolled
-// over the four stages).  Bit-identical results to conv_split_kernel for the same K cut.
-constexpr int kDeep = 4;
-
-template <int ST>
-__device__ __forceinline__ void deep_issue(uint4 (*S)[kStage], const float* __restrict__ x, const uint4* __restrict__ wblock, const Geom& g,
-                                           const Walk& wk) {
-  const int gch = wk.gch, kc = wk.kc;
-  const int dy = wk.ty * g.dil, dx = wk.tx * g.dil;
-  const int doff = (dy * g.W + dx) * g.lda + kc * kChunk;
-  uint4* a_dst = &S[ST][g.wave * 256];
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const bool ok = (unsigned)(g.iy0[i] + dy) < (unsigned)g.H && (unsigned)(g.ix0[i] + dx) < (unsigned)g.W;
-    const float* src = ok ? x + (g.off0[i] + doff) : g_zero_block;
-    __builtin_amdgcn_global_load_lds(reinterpret_cast<const uint4*>(src), a_dst + i * 64, 16, 0, 0);
-  }
-  const uint4* wsrc = wblock + (size_t)gch * g.wstride + g.wave * 192 + g.lane;
-  uint4* b_dst = &S[ST][kStageA + g.wave * 192];
-#pragma unroll
-  for (int i = 0; i < 3; ++i) __builtin_amdgcn_global_load_lds(wsrc + i * 64, b_dst + i * 64, 16, 0, 0);
-}
-
-template <int ST>
-__device__ __forceinline__ void deep_consume(uint4 (*S)[kStage], const Geom& g, f32x16& acc0, f32x16& acc1) {
-  const uint4* A = &S[ST][g.wave * 256];
-  const uint4* B = &S[ST][kStageA + g.lane];
-  const uint4 r0 = A[g.frag[0]], r1 = A[g.frag[1]], r2 = A[g.frag[2]], r3 = A[g.frag[3]];
-  const float4 c0 = make_float4(__uint_as_float(r0.x), __uint_as_float(r0.y), __uint_as_float(r0.z), __uint_as_float(r0.w));
-  const float4 c1 = make_float4(__uint_as_float(r1.x), __uint_as_float(r1.y), __uint_as_float(r1.z), __uint_as_float(r1.w));
-  const float4 c2 = make_float4(__uint_as_float(r2.x), __uint_as_float(r2.y), __uint_as_float(r2.z), __uint_as_float(r2.w));
-  const float4 c3 = make_float4(__uint_as_float(r3.x), __uint_as_float(r3.y), __uint_as_float(r3.z), __uint_as_float(r3.w));
-  const Pieces s0 = split8(c0, c1), s1 = split8(c2, c3);
-  acc0 = mma6(s0, B[(0 * 3 + 0) * 64], B[(0 * 3 + 1) * 64], B[(0 * 3 + 2) * 64], acc0);
-  acc1 = mma6(s0, B[(2 * 3 + 0) * 64], B[(2 * 3 + 1) * 64], B[(2 * 3 + 2) * 64], acc1);
-  acc0 = mma6(s1, B[(1 * 3 + 0) * 64], B[(1 * 3 + 1) * 64], B[(1 * 3 + 2) * 64], acc0);
-  acc1 = mma6(s1, B[(3 * 3 + 0) * 64], B[(3 * 3 + 1) * 64], B[(3 * 3 + 2) * 64], acc1);
-}
-
-// step c (its data in stage ST = c % 4): `ahead` = how many chunks beyond c this wave has already issued (2, fewer at the tail)
-template <int ST>
-__device__ __forceinline__ void deep_step(uint4 (*S)[kStage], const float* __restrict__ x, const uint4* __restrict__ wblock, const Geom& g,
-                                          Walk& wk, int c, int n, f32x16& acc0, f32x16& acc1) {
-  const int ahead = min(n - 1 - c, kDeep - 2);
-  if (ahead >= 2) asm volatile("s_waitcnt vmcnt(14)" ::: "memory");
-  else if (ahead == 1) asm volatile("s_waitcnt vmcnt(7)" ::: "memory");
-  else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-  __builtin_amdgcn_s_barrier();
-  if (c + kDeep - 1 < n) { deep_issue<(ST + kDeep - 1) % kDeep>(S, x, wblock, g, wk); wk.next(g.kw, g.chunks_per_tap); }
-  deep_consume<ST>(S, g, acc0, acc1);
-}
-
-// grid (8 * ceil(tiles / 8)); block 256; 112 KB of LDS.  tiles as conv_split_kernel
-static __global__ __launch_bounds__(kThreads, 1) void conv_split_deep_kernel(Args a, int nx, int ny, int nz) {
-  __shared__ __attribute__((aligned(16))) uint4 S[kDeep][kStage];
-  Tile tile = xcd_tile(blockIdx.x, nx, ny, nz, a.tile_order);
-  if (tile.x < 0) return;
-  if (a.nphase > 1) { const int slices = nz / a.nphase, phase = tile.z / slices; tile.z -= phase * slices; apply_phase(a, phase, slices); }
-  const int tid = threadIdx.x;
-  const int P = a.N * a.Ho * a.Wo;
-  if (tile.x * kWgPix >= P) return;
-  const int taps = a.kh * a.kw;
-  Geom g;
-  g.lane = tid & 63;
-  g.wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  g.H = a.H; g.W = a.W; g.Cin = a.Cin; g.lda = a.lda; g.kw = a.kw; g.stride = a.stride; g.dil = a.dil;
-  g.chunks_per_tap = a.Cin / kChunk;
-  const int chunk_total = taps * g.chunks_per_tap;
-  g.chunk0 = tile.z * a.chunks_per_slice;
-  const int nchunks = min(a.chunks_per_slice, chunk_total - g.chunk0);
-  const int col_tiles = a.Cout / 32;
-  g.wstride = (size_t)col_tiles * (kChunkBytesB / 32);
-  const uint4* wblock = a.wfrag + (size_t)(2 * tile.y) * (kChunkBytesB / 32);
-  const int m0 = tile.x * kWgPix + g.wave * kWavePix;
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int pix = m0 + 8 * i + (g.lane >> 3);
-    const int piece = (g.lane & 7) ^ ((4 * i + (g.lane >> 4)) & 7);
-    g.iy0[i] = g.ix0[i] = -(1 << 24);
-    g.off0[i] = 0;
-    if (pix < P) {
-      const int pn = pix / (a.Ho * a.Wo), r = pix - pn * a.Ho * a.Wo, py = r / a.Wo, px = r - py * a.Wo;
-      g.iy0[i] = py * a.stride - a.pad_h;
-      g.ix0[i] = px * a.stride - a.pad_w;
-      g.off0[i] = ((pn * a.H + g.iy0[i]) * a.W + g.ix0[i]) * a.lda + 4 * piece;
-    }
-  }
-  {
-    const int r = g.lane & 31, h = g.lane >> 5, sw = (r >> 1) & 7;
-#pragma unroll
-    for (int j = 0; j < 4; ++j) g.frag[j] = r * 8 + ((4 * h + j) ^ sw);
-  }
-  f32x16 acc0, acc1;
-#pragma unroll
-  for (int i = 0; i < 16; ++i) { acc0[i] = 0.f; acc1[i] = 0.f; }
-  Walk wk;
-  wk.gch = g.chunk0;
-  {
-    const int tap = g.chunk0 / g.chunks_per_tap;
-    wk.kc = g.chunk0 - tap * g.chunks_per_tap;
-    wk.ty = tap / a.kw;
-    wk.tx = tap - wk.ty * a.kw;
-  }
-  // prologue: chunks 0, 1, 2 into stages 0, 1, 2
-  if (nchunks > 0) { deep_issue<0>(S, a.x, wblock, g, wk); wk.next(g.kw, g.chunks_per_tap); }
-  if (nchunks > 1) { deep_issue<1>(S, a.x, wblock, g, wk); wk.next(g.kw, g.chunks_per_tap); }
-  if (nchunks > 2) { deep_issue<2>(S, a.x, wblock, g, wk); wk.next(g.kw, g.chunks_per_tap); }
-  for (int c = 0; c < nchunks; c += kDeep) {
-    deep_step<0>(S, a.x, wblock, g, wk, c, nchunks, acc0, acc1);
-    if (c + 1 < nchunks) deep_step<1>(S, a.x, wblock, g, wk, c + 1, nchunks, acc0, acc1);
-    if (c + 2 < nchunks) deep_step<2>(S, a.x, wblock, g, wk, c + 2, nchunks, acc0, acc1);
-    if (c + 3 < nchunks) deep_step<3>(S, a.x, wblock, g, wk, c + 3, nchunks, acc0, acc1);
-  }
-  const int lane = g.lane;
-  int prow[16];
-  RowOut ro;
-  ro.valid = 0;
-#pragma unroll
-  for (int r = 0; r < 16; ++r) {
-    prow[r] = m0 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-    if (prow[r] < P) ro.valid |= 1u << r;
-  }
-  if (a.part) {
-    float* part = a.part + (size_t)tile.z * P * a.Cout;
-    tile_store_part(part, a.Cout, prow, ro.valid, tile.y * kWgCh + (lane & 31), acc0);
-    tile_store_part(part, a.Cout, prow, ro.valid, tile.y * kWgCh + 32 + (lane & 31), acc1);
-    return;
-  }
-#pragma unroll
-  for (int r = 0; r < 16; ++r) ro.base[r] = ((ro.valid >> r) & 1u) ? out_pixel_base(a, prow[r]) : 0;
-  tile_store(a, ro, tile.y * kWgCh + (lane & 31), acc0);
-  tile_store(a, ro, tile.y * kWgCh + 32 + (lane & 31), acc1);
-}
-
-// ---------------------------------------------------------------------------------------------------------------
-// r3: the same kernel with WIDER wave tiles.  What bounds the loop above is not the matrix pipe but everything a wave must
-// issue around its 24 MFMAs per chunk: 7 LDS-DMAs, ~110 VALU instructions to cut its 32 x 32 activations, 16 ds_reads
-// (profiles/r2/conv_split_chunk_cycles.txt: 2710 cycles per chunk for 768 cycles of MFMA).  With a wave tile of 32 pixels x
-// 32*NT channels (NT = 4: four accumulators, a workgroup of 4 waves = 128 pixels x 128 channels) the SAME cut and the
-// same four A DMAs feed NT*12 MFMAs, and the B block of a chunk (NT x 6 KB) is shared by the four waves: per MFMA half the
-// cut work, 10 instead of 14 DMAs per 48 MFMAs and half the A bytes.  B DMAs are issued between the column tiles' MFMA
-// groups so that they go out while the matrix pipe drains.  Stage = 16 KB A + NT*6 KB B; two stages, two workgroups per CU
-// (NT = 4: 2 x 80 KB = the CU's whole LDS).  Everything else (A image and swizzle, B fragment order, K slices, epilogue) as
-// conv_split_kernel.
-// PC = pieces per weight: 3 (bf16, six products) or 2 (fp16, three products: the opt-in form above)
-template <int NT, int PC = 3> struct Wide {
-  static constexpr int kColTile = 128 * PC;                 // uint4 of one 32-column tile of one chunk: 2 steps x PC pieces x 64 lanes
-  static constexpr int kStageBn = NT * kColTile;            // uint4 of B per stage
-  static constexpr int kStageN = kStageA + kStageBn;
-  static constexpr int kDmaB = (NT * kColTile) / (4 * 64);  // B DMA instructions per wave and chunk: NT * PC / 2
-  static_assert((NT * kColTile) % 256 == 0, "NT must be even");
-};
-
-template <int NT, int ST, int PC = 3>
-__device__ __forceinline__ void wide_issue_a(uint4 (*S)[(Wide<NT, PC>::kStageN)], const float* __restrict__ x, const Geom& g, const Walk& wk) {
-  const int dy = wk.ty * g.dil, dx = wk.tx * g.dil;
-  const int doff = (dy * g.W + dx) * g.lda + wk.kc * kChunk;
-  uint4* a_dst = &S[ST][g.wave * 256];
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const bool ok = (unsigned)(g.iy0[i] + dy) < (unsigned)g.H && (unsigned)(g.ix0[i] + dx) < (unsigned)g.W;
-    const float* src = ok ? x + (g.off0[i] + doff) : g_zero_block;
-    __builtin_amdgcn_global_load_lds(reinterpret_cast<const uint4*>(src), a_dst + i * 64, 16, 0, 0);
-  }
-}
-
-// B DMA instructions I0 .. I1-1 of this wave's share (Wide<NT>::kDmaB in all) of chunk `gch`
-template <int NT, int ST, int I0, int I1, int PC = 3>
-__device__ __forceinline__ void wide_issue_b(uint4 (*S)[(Wide<NT, PC>::kStageN)], const uint4* __restrict__ wblock, const Geom& g, int gch) {
-  const uint4* wsrc = wblock + (size_t)gch * g.wstride + g.wave * (Wide<NT, PC>::kDmaB * 64) + g.lane;
-  uint4* b_dst = &S[ST][kStageA + g.wave * (Wide<NT, PC>::kDmaB * 64)];
-#pragma unroll
-  for (int i = I0; i < I1; ++i) __builtin_amdgcn_global_load_lds(wsrc + i * 64, b_dst + i * 64, 16, 0, 0);
-}
-
-template <int NT, int ST, int PC = 3>
-__device__ __forceinline__ void wide_step(uint4 (*S)[(Wide<NT, PC>::kStageN)], const float* __restrict__ x, const uint4* __restrict__ wblock,
-                                          const Geom& g, Walk& wk, int c, int n, f32x16 (&acc)[NT], float a_scale = 1.f) {
-  constexpr int kDmaB = Wide<NT, PC>::kDmaB;
-  const bool more = c + 1 < n;
-  const int gch_next = wk.gch;
-  if (more) wide_issue_a<NT, ST ^ 1, PC>(S, x, g, wk);
-  const uint4* A = &S[ST][g.wave * 256];
-  const uint4* B = &S[ST][kStageA + g.lane];
-  const uint4 r0 = A[g.frag[0]], r1 = A[g.frag[1]], r2 = A[g.frag[2]], r3 = A[g.frag[3]];
-  const float4 c0 = make_float4(__uint_as_float(r0.x), __uint_as_float(r0.y), __uint_as_float(r0.z), __uint_as_float(r0.w));
-  const float4 c1 = make_float4(__uint_as_float(r1.x), __uint_as_float(r1.y), __uint_as_float(r1.z), __uint_as_float(r1.w));
-  const float4 c2 = make_float4(__uint_as_float(r2.x), __uint_as_float(r2.y), __uint_as_float(r2.z), __uint_as_float(r2.w));
-  const float4 c3 = make_float4(__uint_as_float(r3.x), __uint_as_float(r3.y), __uint_as_float(r3.z), __uint_as_float(r3.w));
-  Pieces s0, s1;
-  PiecesH h0, h1;
-  if (PC == 3) { s0 = split8(c0, c1); s1 = split8(c2, c3); }
-  else { h0 = split8h(c0, c1, a_scale); h1 = split8h(c2, c3, a_scale); }
-#pragma unroll
-  for (int t = 0; t < NT; ++t) {
-    // fragment (col tile t, step s, piece p) at ((t*2 + s)*PC + p)*64 + lane
-    if (PC == 3) {
-      acc[t] = mma6(s0, B[((t * 2 + 0) * 3 + 0) * 64], B[((t * 2 + 0) * 3 + 1) * 64], B[((t * 2 + 0) * 3 + 2) * 64], acc[t]);
-      acc[t] = mma6(s1, B[((t * 2 + 1) * 3 + 0) * 64], B[((t * 2 + 1) * 3 + 1) * 64], B[((t * 2 + 1) * 3 + 2) * 64], acc[t]);
-    } else {
-      acc[t] = mma3h(h0, B[((t * 2 + 0) * 2 + 0) * 64], B[((t * 2 + 0) * 2 + 1) * 64], acc[t]);
-      acc[t] = mma3h(h1, B[((t * 2 + 1) * 2 + 0) * 64], B[((t * 2 + 1) * 2 + 1) * 64], acc[t]);
-    }
-    if (more) {      // this wave's share of the next chunk's weights, a slice behind each column tile's MFMAs
-      constexpr int kPer = (kDmaB + NT - 1) / NT;
-      constexpr int kE1 = (2 * kPer < kDmaB) ? 2 * kPer : kDmaB;
-      constexpr int kE2 = (3 * kPer < kDmaB) ? 3 * kPer : kDmaB;
-      if (t == 0) wide_issue_b<NT, ST ^ 1, 0, kPer, PC>(S, wblock, g, gch_next);
-      if (NT > 1 && t == 1) wide_issue_b<NT, ST ^ 1, kPer, kE1, PC>(S, wblock, g, gch_next);
-      if (NT > 2 && t == 2) wide_issue_b<NT, ST ^ 1, kE1, (NT > 3 ? kE2 : kDmaB), PC>(S, wblock, g, gch_next);
-      if (NT > 3 && t == 3) wide_issue_b<NT, ST ^ 1, kE2, kDmaB, PC>(S, wblock, g, gch_next);
-    }
-  }
-  if (more) wk.next(g.kw, g.chunks_per_tap);
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-  __builtin_amdgcn_s_barrier();
-}
-
-// grid (8 * ceil(tiles / 8)); block 256.  tiles = ceil(P / 128) * (Cout / (32*NT)) * slices
-template <int NT, int PC = 3>
-static __global__ __launch_bounds__(kThreads, 2) void conv_split_wide_kernel(Args a, int nx, int ny, int nz) {
-  typedef Wide<NT, PC> WD;
-  __shared__ __attribute__((aligned(16))) uint4 S[2][WD::kStageN];
-  Tile tile = xcd_tile(blockIdx.x, nx, ny, nz, a.tile_order);
-  if (tile.x < 0) return;
-  if (a.nphase > 1) { const int slices = nz / a.nphase, phase = tile.z / slices; tile.z -= phase * slices; apply_phase(a, phase, slices); }
-  const int tid = threadIdx.x;
-  const int P = a.N * a.Ho * a.Wo;
-  if (tile.x * kWgPix >= P) return;
-  const int taps = a.kh * a.kw;
-  Geom g;
-  g.lane = tid & 63;
-  g.wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  g.H = a.H; g.W = a.W; g.Cin = a.Cin; g.lda = a.lda; g.kw = a.kw; g.stride = a.stride; g.dil = a.dil;
-  g.chunks_per_tap = a.Cin / kChunk;
-  const int chunk_total = taps * g.chunks_per_tap;
-  g.chunk0 = tile.z * a.chunks_per_slice;
-  const int nchunks = min(a.chunks_per_slice, chunk_total - g.chunk0);
-  const int col_tiles = a.Cout / 32;
-  g.wstride = (size_t)col_tiles * WD::kColTile;
-  const uint4* wblock = a.wfrag + (size_t)(NT * tile.y) * WD::kColTile;
-  const int m0 = tile.x * kWgPix + g.wave * kWavePix;
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int pix = m0 + 8 * i + (g.lane >> 3);
-    const int piece = (g.lane & 7) ^ ((4 * i + (g.lane >> 4)) & 7);
-    g.iy0[i] = g.ix0[i] = -(1 << 24);
-    g.off0[i] = 0;
-    if (pix < P) {
-      const int pn = pix / (a.Ho * a.Wo), r = pix - pn * a.Ho * a.Wo, py = r / a.Wo, px = r - py * a.Wo;
-      g.iy0[i] = py * a.stride - a.pad_h;
-      g.ix0[i] = px * a.stride - a.pad_w;
-      g.off0[i] = ((pn * a.H + g.iy0[i]) * a.W + g.ix0[i]) * a.lda + 4 * piece;
-    }
-  }
-  {
-    const int r = g.lane & 31, h = g.lane >> 5, sw = (r >> 1) & 7;
-#pragma unroll
-    for (int j = 0; j < 4; ++j) g.frag[j] = r * 8 + ((4 * h + j) ^ sw);
-  }
-  f32x16 acc[NT];
-#pragma unroll
-  for (int t = 0; t < NT; ++t)
-#pragma unroll
-    for (int i = 0; i < 16; ++i) acc[t][i] = 0.f;
-
-  Walk wk;
-  wk.gch = g.chunk0;
-  {
-    const int tap = g.chunk0 / g.chunks_per_tap;
-    wk.kc = g.chunk0 - tap * g.chunks_per_tap;
-    wk.ty = tap / a.kw;
-    wk.tx = tap - wk.ty * a.kw;
-  }
-  if (nchunks > 0) {
-    wide_issue_a<NT, 0, PC>(S, a.x, g, wk);
-    wide_issue_b<NT, 0, 0, WD::kDmaB, PC>(S, wblock, g, wk.gch);
-    wk.next(g.kw, g.chunks_per_tap);
-  }
-  // fp16 form: the scale that puts max|x| into [2^13, 2^14), and its inverse together with the weights' (both powers of two: exact)
-  float a_scale = 1.f, out_scale = 1.f;
-  if (PC == 2) {
-    const int s_exp = 13 - amax_exponent(a.amax, g.lane);
-    a_scale = ldexpf(1.f, s_exp);
-    out_scale = ldexpf(1.f, -(s_exp + a.w_exp));
-  }
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __builtin_amdgcn_s_barrier();
-  for (int c = 0; c < nchunks; c += 2) {
-    wide_step<NT, 0, PC>(S, a.x, wblock, g, wk, c, nchunks, acc, a_scale);
-    if (c + 1 < nchunks) wide_step<NT, 1, PC>(S, a.x, wblock, g, wk, c + 1, nchunks, acc, a_scale);
-  }
-  if (PC == 2) {
-#pragma unroll
-    for (int t = 0; t < NT; ++t)
-#pragma unroll
-      for (int i = 0; i < 16; ++i) acc[t][i] = acc[t][i] * out_scale;
-  }
-
-  const int lane = g.lane;
-  int prow[16];
-  RowOut ro;
-  ro.valid = 0;
-#pragma unroll
-  for (int r = 0; r < 16; ++r) {
-    prow[r] = m0 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-    if (prow[r] < P) ro.valid |= 1u << r;
-  }
-  if (a.part) {
-    float* part = a.part + (size_t)tile.z * P * a.Cout;
-#pragma unroll
-    for (int t = 0; t < NT; ++t) tile_store_part(part, a.Cout, prow, ro.valid, tile.y * (32 * NT) + t * 32 + (lane & 31), acc[t]);
-    return;
-  }
-#pragma unroll
-  for (int r = 0; r < 16; ++r) ro.base[r] = ((ro.valid >> r) & 1u) ? out_pixel_base(a, prow[r]) : 0;
-#pragma unroll
-  for (int t = 0; t < NT; ++t) tile_store(a, ro, tile.y * (32 * NT) + t * 32 + (lane & 31), acc[t]);
-}
-
 // ---------------------------------------------------------------------------------------------------------------
 // 3x3, stride 1, pad = dilation: the halo form.  The kernel above is bound by what it pulls through the L2 (each of the
 // nine taps re-fetches the activations: 28 KB per workgroup and 24 MFMAs/wave).  Here a workgroup owns a 4-row x
@@ -895,12 +545,13 @@ static __global__ __launch_bounds__(kThreads, 2) void conv_split_wide_kernel(Arg
 // odd, so the B parity of (chunk, tap) is (chunk + tap) & 1).
 constexpr int kPatchRows = 4, kPatchCols = 32;
 
-template <int DIL> struct Halo {
+template <int DIL, int PC = 3> struct Halo {
+  static constexpr int kStageBp = 2 * 2 * PC * 64;                     // uint4 of B per tap step: two 32-column tiles x 2 steps x PC pieces
   static constexpr int kW = kPatchCols + 2 * DIL, kH = kPatchRows + 2 * DIL;
   static constexpr int kPix = kW * kH;
   static constexpr int kPieces = kPix * 8;                            // 16-byte pieces of one stage
   static constexpr int kDma = (kPieces + kThreads - 1) / kThreads;   // DMA instructions per thread and chunk
-  static constexpr int kStageUint4 = kPieces + kStageB;              // A halo + B, per parity
+  static constexpr int kStageUint4 = kPieces + kStageBp;             // A halo + B, per parity
   static constexpr int kRow = kStageUint4;
 };
 
@@ -917,19 +568,19 @@ struct HaloGeom {
 };
 
 // B of step (kc, tap) -> parity PB; one third of the A halo of chunk kc_next (DMA instructions i0 .. i1-1) -> parity PA
-template <int DIL, int PA, int PB, int I0, int I1>
-__device__ __forceinline__ void halo_issue(uint4 (*S)[Halo<DIL>::kRow], const float* __restrict__ x, const uint4* __restrict__ wblock,
+template <int DIL, int PC, int PA, int PB, int I0, int I1>
+__device__ __forceinline__ void halo_issue(uint4 (*S)[(Halo<DIL, PC>::kRow)], const float* __restrict__ x, const uint4* __restrict__ wblock,
                                            const HaloGeom<DIL>& g, int gch, bool with_b, int kc_next, bool with_a) {
   if (with_b) {
-    const uint4* wsrc = wblock + (size_t)gch * g.wstride + g.wave * 192 + g.lane;
-    uint4* b_dst = &S[PB][Halo<DIL>::kPieces + g.wave * 192];
+    const uint4* wsrc = wblock + (size_t)gch * g.wstride + g.wave * (64 * PC) + g.lane;
+    uint4* b_dst = &S[PB][Halo<DIL, PC>::kPieces + g.wave * (64 * PC)];
 #pragma unroll
-    for (int i = 0; i < 3; ++i) __builtin_amdgcn_global_load_lds(wsrc + i * 64, b_dst + i * 64, 16, 0, 0);
+    for (int i = 0; i < PC; ++i) __builtin_amdgcn_global_load_lds(wsrc + i * 64, b_dst + i * 64, 16, 0, 0);
   }
   if (with_a) {
 #pragma unroll
     for (int i = I0; i < I1; ++i) {
-      if (i < Halo<DIL>::kDma && ((g.live_mask >> i) & 1u)) {
+      if (i < Halo<DIL, PC>::kDma && ((g.live_mask >> i) & 1u)) {
         const float* src = ((g.ok_mask >> i) & 1u) ? x + (g.off0[i] + kc_next * kChunk) : g_zero_block;
         __builtin_amdgcn_global_load_lds(reinterpret_cast<const uint4*>(src), &S[PA][i * kThreads + g.wave * 64], 16, 0, 0);
       }
@@ -937,62 +588,59 @@ __device__ __forceinline__ void halo_issue(uint4 (*S)[Halo<DIL>::kRow], const fl
   }
 }
 
-template <int DIL, int PA, int PB, int TAP>
-__device__ __forceinline__ void halo_consume(uint4 (*S)[Halo<DIL>::kRow], const HaloGeom<DIL>& g, f32x16& acc0, f32x16& acc1) {
+template <int DIL, int PC, int PA, int PB, int TAP>
+__device__ __forceinline__ void halo_consume(uint4 (*S)[(Halo<DIL, PC>::kRow)], const HaloGeom<DIL>& g, f32x16& acc0, f32x16& acc1, float a_scale) {
   constexpr int ty = TAP / 3, tx = TAP % 3;
   const int hp = g.hp0 + (ty * DIL) * Halo<DIL>::kW + tx * DIL;
   const int xs = g.h4 ^ ((hp >> 1) & 7);                  // slot of piece 4h + j is (4h + j) ^ sw = xs ^ j
   const uint4* A = &S[PA][hp * 8];
-  const uint4* B = &S[PB][Halo<DIL>::kPieces + g.lane];
+  const uint4* B = &S[PB][Halo<DIL, PC>::kPieces + g.lane];
   const uint4 r0 = A[xs], r1 = A[xs ^ 1], r2 = A[xs ^ 2], r3 = A[xs ^ 3];
-  const float4 c0 = make_float4(__uint_as_float(r0.x), __uint_as_float(r0.y), __uint_as_float(r0.z), __uint_as_float(r0.w));
-  const float4 c1 = make_float4(__uint_as_float(r1.x), __uint_as_float(r1.y), __uint_as_float(r1.z), __uint_as_float(r1.w));
-  const float4 c2 = make_float4(__uint_as_float(r2.x), __uint_as_float(r2.y), __uint_as_float(r2.z), __uint_as_float(r2.w));
-  const float4 c3 = make_float4(__uint_as_float(r3.x), __uint_as_float(r3.y), __uint_as_float(r3.z), __uint_as_float(r3.w));
-  const Pieces s0 = split8(c0, c1), s1 = split8(c2, c3);
-  acc0 = mma6(s0, B[(0 * 3 + 0) * 64], B[(0 * 3 + 1) * 64], B[(0 * 3 + 2) * 64], acc0);
-  acc1 = mma6(s0, B[(2 * 3 + 0) * 64], B[(2 * 3 + 1) * 64], B[(2 * 3 + 2) * 64], acc1);
-  acc0 = mma6(s1, B[(1 * 3 + 0) * 64], B[(1 * 3 + 1) * 64], B[(1 * 3 + 2) * 64], acc0);
-  acc1 = mma6(s1, B[(3 * 3 + 0) * 64], B[(3 * 3 + 1) * 64], B[(3 * 3 + 2) * 64], acc1);
+  const PiecesN s0 = cut8<PC>(as_f4(r0), as_f4(r1), a_scale), s1 = cut8<PC>(as_f4(r2), as_f4(r3), a_scale);
+  // fragment (col tile t, step s, piece p) at ((t*2 + s)*PC + p)*64 + lane
+  acc0 = mma_pc<PC>(s0, B + (0 * PC) * 64, acc0);
+  acc1 = mma_pc<PC>(s0, B + (2 * PC) * 64, acc1);
+  acc0 = mma_pc<PC>(s1, B + (1 * PC) * 64, acc0);
+  acc1 = mma_pc<PC>(s1, B + (3 * PC) * 64, acc1);
 }
 
 // one step = one tap of channel chunk kc (A parity PA): start the copies the NEXT step needs (its B; during taps 0-2 a
 // third each of the next chunk's halo), compute this tap, retire the copies, meet the other waves
-template <int DIL, int PA, int TAP>
-__device__ __forceinline__ void halo_step(uint4 (*S)[Halo<DIL>::kRow], const float* __restrict__ x, const uint4* __restrict__ wblock,
-                                          const HaloGeom<DIL>& g, int kc, int kc_end, f32x16& acc0, f32x16& acc1) {
+template <int DIL, int PC, int PA, int TAP>
+__device__ __forceinline__ void halo_step(uint4 (*S)[(Halo<DIL, PC>::kRow)], const float* __restrict__ x, const uint4* __restrict__ wblock,
+                                          const HaloGeom<DIL>& g, int kc, int kc_end, f32x16& acc0, f32x16& acc1, float a_scale) {
   constexpr int PB = (PA + TAP) & 1;
-  constexpr int K3 = (Halo<DIL>::kDma + 2) / 3;
+  constexpr int K3 = (Halo<DIL, PC>::kDma + 2) / 3;
   const bool last_tap = TAP == 8;
   const bool more = !last_tap || kc + 1 < kc_end;                              // is there a next step at all
   const int next_g = last_tap ? (kc + 1) : ((TAP + 1) * g.chunks_per_tap + kc);  // its (tap, chunk) index in the weight array
   constexpr int I0 = TAP < 3 ? TAP * K3 : 0, I1 = TAP < 3 ? (TAP + 1) * K3 : 0;
   constexpr int PA_NEXT = PA ^ 1, PB_NEXT = PB ^ 1;
-  halo_issue<DIL, PA_NEXT, PB_NEXT, I0, I1>(S, x, wblock, g, next_g, more, kc + 1, TAP < 3 && kc + 1 < kc_end);
-  halo_consume<DIL, PA, PB, TAP>(S, g, acc0, acc1);
+  halo_issue<DIL, PC, PA_NEXT, PB_NEXT, I0, I1>(S, x, wblock, g, next_g, more, kc + 1, TAP < 3 && kc + 1 < kc_end);
+  halo_consume<DIL, PC, PA, PB, TAP>(S, g, acc0, acc1, a_scale);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
 }
 
-template <int DIL, int PA>
-__device__ __forceinline__ void halo_chunk(uint4 (*S)[Halo<DIL>::kRow], const float* __restrict__ x, const uint4* __restrict__ wblock,
-                                           const HaloGeom<DIL>& g, int kc, int kc_end, f32x16& acc0, f32x16& acc1) {
-  halo_step<DIL, PA, 0>(S, x, wblock, g, kc, kc_end, acc0, acc1);
-  halo_step<DIL, PA, 1>(S, x, wblock, g, kc, kc_end, acc0, acc1);
-  halo_step<DIL, PA, 2>(S, x, wblock, g, kc, kc_end, acc0, acc1);
-  halo_step<DIL, PA, 3>(S, x, wblock, g, kc, kc_end, acc0, acc1);
-  halo_step<DIL, PA, 4>(S, x, wblock, g, kc, kc_end, acc0, acc1);
-  halo_step<DIL, PA, 5>(S, x, wblock, g, kc, kc_end, acc0, acc1);
-  halo_step<DIL, PA, 6>(S, x, wblock, g, kc, kc_end, acc0, acc1);
-  halo_step<DIL, PA, 7>(S, x, wblock, g, kc, kc_end, acc0, acc1);
-  halo_step<DIL, PA, 8>(S, x, wblock, g, kc, kc_end, acc0, acc1);
+template <int DIL, int PC, int PA>
+__device__ __forceinline__ void halo_chunk(uint4 (*S)[(Halo<DIL, PC>::kRow)], const float* __restrict__ x, const uint4* __restrict__ wblock,
+                                           const HaloGeom<DIL>& g, int kc, int kc_end, f32x16& acc0, f32x16& acc1, float a_scale) {
+  halo_step<DIL, PC, PA, 0>(S, x, wblock, g, kc, kc_end, acc0, acc1, a_scale);
+  halo_step<DIL, PC, PA, 1>(S, x, wblock, g, kc, kc_end, acc0, acc1, a_scale);
+  halo_step<DIL, PC, PA, 2>(S, x, wblock, g, kc, kc_end, acc0, acc1, a_scale);
+  halo_step<DIL, PC, PA, 3>(S, x, wblock, g, kc, kc_end, acc0, acc1, a_scale);
+  halo_step<DIL, PC, PA, 4>(S, x, wblock, g, kc, kc_end, acc0, acc1, a_scale);
+  halo_step<DIL, PC, PA, 5>(S, x, wblock, g, kc, kc_end, acc0, acc1, a_scale);
+  halo_step<DIL, PC, PA, 6>(S, x, wblock, g, kc, kc_end, acc0, acc1, a_scale);
+  halo_step<DIL, PC, PA, 7>(S, x, wblock, g, kc, kc_end, acc0, acc1, a_scale);
+  halo_step<DIL, PC, PA, 8>(S, x, wblock, g, kc, kc_end, acc0, acc1, a_scale);
 }
 
 // the tile's outputs from the accumulators (C/D layout: column = lane & 31 = channel, row = (reg & 3) + 8 * (reg >> 2) +
 // 4 * (lane >> 5) = column of the wave's patch row): a K slice's partial sums, or bias / residual / ReLU / second output
-__device__ __forceinline__ void halo_epilogue(const Args& a, float* part, int pimg, int y0, int x0, int ch_tile, int wave, int lane,
-                                              const f32x16& acc0, const f32x16& acc1) {
+__device__ __forceinline__ uint32_t halo_epilogue(const Args& a, float* part, int pimg, int y0, int x0, int ch_tile, int wave, int lane,
+                                                  const f32x16& acc0, const f32x16& acc1) {
   const int oy = y0 + wave;
   int prow[16];
   RowOut ro;
@@ -1006,12 +654,11 @@ __device__ __forceinline__ void halo_epilogue(const Args& a, float* part, int pi
   if (part) {
     tile_store_part(part, a.Cout, prow, ro.valid, ch_tile * kWgCh + (lane & 31), acc0);
     tile_store_part(part, a.Cout, prow, ro.valid, ch_tile * kWgCh + 32 + (lane & 31), acc1);
-    return;
+    return 0;
   }
 #pragma unroll
   for (int r = 0; r < 16; ++r) ro.base[r] = ((ro.valid >> r) & 1u) ? out_pixel_base(a, prow[r]) : 0;
-  tile_store(a, ro, ch_tile * kWgCh + (lane & 31), acc0);
-  tile_store(a, ro, ch_tile * kWgCh + 32 + (lane & 31), acc1);
+  return max(tile_store_max(a, ro, ch_tile * kWgCh + (lane & 31), acc0), tile_store_max(a, ro, ch_tile * kWgCh + 32 + (lane & 31), acc1));
 }
 
 // balanced mode, second launch: grid (tiles); block 256.  A tile that several workgroups shared: add their pieces in piece
@@ -1032,7 +679,8 @@ static __global__ __launch_bounds__(kThreads) void conv_split3x3_fixup_kernel(Ar
   }
   const int tx = txy % nx, ty = txy / nx;
   const int pimg = tx / (patches_x * patches_y), prem = tx - pimg * (patches_x * patches_y);
-  halo_epilogue(a, nullptr, pimg, (prem / patches_x) * kPatchRows, (prem % patches_x) * kPatchCols, ty, tid >> 6, tid & 63, acc0, acc1);
+  const uint32_t m = halo_epilogue(a, nullptr, pimg, (prem / patches_x) * kPatchRows, (prem % patches_x) * kPatchCols, ty, tid >> 6, tid & 63, acc0, acc1);
+  publish_amax(m, a.amax_out, a.status, blockIdx.x * 4 + (tid >> 6));
 }
 
 // grid (8 * ceil(tiles / 8)); block 256.  tiles = N * ceil(H/4) * ceil(W/32) patches x (Cout / 64) x slices (of channel chunks);
@@ -1044,10 +692,10 @@ static __global__ __launch_bounds__(kThreads) void conv_split3x3_fixup_kernel(Ar
 // chunks were shared leaves its fp32 accumulators in a.part (one slot per piece) and conv_split3x3_fixup_kernel adds them in
 // piece order and runs the epilogue.  (A last-arriver ticket inside this kernel was tried first: the device-scope
 // __threadfence() it needs writes back / invalidates the whole L2 on this multi-XCD part and doubled the kernel's time.)
-template <int DIL>
+template <int DIL, int PC>
 static __global__ __launch_bounds__(kThreads, (DIL == 1 ? 2 : 1)) void conv_split3x3_kernel(Args a, int patches_x, int patches_y, int nx, int ny, int nz) {
 #if __HIP_DEVICE_COMPILE__      // hipcc's HOST pass fails to instantiate the unrolled tap chain (spurious "substitution failure"); it needs only the stub
-  typedef Halo<DIL> HL;
+  typedef Halo<DIL, PC> HL;
   __shared__ __attribute__((aligned(16))) uint4 S[2][HL::kRow];
   HaloGeom<DIL> g;
   g.tid = threadIdx.x;
@@ -1056,8 +704,15 @@ static __global__ __launch_bounds__(kThreads, (DIL == 1 ? 2 : 1)) void conv_spli
   g.chunks_per_tap = a.Cin / kChunk;
   const int cpt = g.chunks_per_tap;
   const int col_tiles = a.Cout / 32;
-  g.wstride = (size_t)col_tiles * (kChunkBytesB / 32);
+  g.wstride = (size_t)col_tiles * (128 * PC);
   g.hp0 = g.wave * HL::kW + (g.lane & 31);
+  float a_scale = 1.f, out_scale = 1.f;
+  if (PC == 2) {
+    const int s_exp = 13 - amax_exponent_asm(a.amax, g.lane, a.status);
+    a_scale = ldexpf(1.f, s_exp);
+    out_scale = ldexpf(1.f, -(s_exp + a.w_exp));
+  }
+  uint32_t wg_max = 0;
   g.h4 = 4 * (g.lane >> 5);
   const bool balanced = a.units_per_wg > 0;
   int u = 0, u_end = 0, wg = 0;
@@ -1084,7 +739,7 @@ static __global__ __launch_bounds__(kThreads, (DIL == 1 ? 2 : 1)) void conv_spli
       kc0 = tile.z * a.chunks_per_slice;
       kc_end = min(kc0 + a.chunks_per_slice, cpt);
     }
-    const uint4* wblock = a.wfrag + (size_t)(2 * tile.y) * (kChunkBytesB / 32);
+    const uint4* wblock = a.wfrag + (size_t)(2 * tile.y) * (128 * PC);
     // patch -> image, top-left output pixel
     const int pimg = tile.x / (patches_x * patches_y), prem = tile.x - pimg * (patches_x * patches_y);
     const int y0 = (prem / patches_x) * kPatchRows, x0 = (prem % patches_x) * kPatchCols;
@@ -1111,13 +766,17 @@ static __global__ __launch_bounds__(kThreads, (DIL == 1 ? 2 : 1)) void conv_spli
 
     if (kc0 < kc_end) {
       // prologue: the whole halo of chunk kc0 and the weights of (kc0, tap 0); parities as if kc0 were even
-      halo_issue<DIL, 0, 0, 0, HL::kDma>(S, a.x, wblock, g, kc0, true, kc0, true);
+      halo_issue<DIL, PC, 0, 0, 0, HL::kDma>(S, a.x, wblock, g, kc0, true, kc0, true);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     for (int kc = kc0; kc < kc_end; kc += 2) {
-      halo_chunk<DIL, 0>(S, a.x, wblock, g, kc, kc_end, acc0, acc1);
-      if (kc + 1 < kc_end) halo_chunk<DIL, 1>(S, a.x, wblock, g, kc + 1, kc_end, acc0, acc1);
+      halo_chunk<DIL, PC, 0>(S, a.x, wblock, g, kc, kc_end, acc0, acc1, a_scale);
+      if (kc + 1 < kc_end) halo_chunk<DIL, PC, 1>(S, a.x, wblock, g, kc + 1, kc_end, acc0, acc1, a_scale);
+    }
+    if (PC == 2) {
+#pragma unroll
+      for (int i = 0; i < 16; ++i) { acc0[i] = acc0[i] * out_scale; acc1[i] = acc1[i] * out_scale; }
     }
 
     bool finish = true;       // does this workgroup write the tile's output
@@ -1133,12 +792,13 @@ static __global__ __launch_bounds__(kThreads, (DIL == 1 ? 2 : 1)) void conv_spli
     if (finish) {
       const int P = a.N * a.H * a.W;
       float* part = (!balanced && a.part) ? a.part + (size_t)tile.z * P * a.Cout : nullptr;
-      halo_epilogue(a, part, pimg, y0, x0, tile.y, g.wave, g.lane, acc0, acc1);
+      wg_max = max(wg_max, halo_epilogue(a, part, pimg, y0, x0, tile.y, g.wave, g.lane, acc0, acc1));
     }
     if (!balanced) break;
     u += kc_end - kc0;
     if (u >= u_end) break;
   }
+  if (!(a.part && !balanced)) publish_amax(wg_max, a.amax_out, a.status, blockIdx.x * 4 + g.wave);
 #endif
 }
 
@@ -1153,34 +813,33 @@ static __global__ __launch_bounds__(kThreads, (DIL == 1 ? 2 : 1)) void conv_spli
 // (reproducible), then the shared epilogue (bias / residual / activation / second output).  Weights are re-read by every pixel
 // tile (75 x 216 KB from L2 for the 3x3): fine for small weights, which is what the launch plan checks.
 
-struct DirectOperands { uint4 a[4]; uint4 b[12]; };
+template <int PC> struct DirectOperands { uint4 a[4]; uint4 b[4 * PC]; };
 
-__device__ __forceinline__ void direct_load(DirectOperands& o, const float* __restrict__ x, const uint4* __restrict__ wtile, size_t wstride,
+template <int PC>
+__device__ __forceinline__ void direct_load(DirectOperands<PC>& o, const float* __restrict__ x, const uint4* __restrict__ wtile, size_t wstride,
                                             int gch, int a_off, bool a_ok, int lane) {
   const uint4* ap = reinterpret_cast<const uint4*>(a_ok ? x + a_off : g_zero_block);
 #pragma unroll
   for (int j = 0; j < 4; ++j) o.a[j] = a_ok ? ap[j] : make_uint4(0u, 0u, 0u, 0u);
   const uint4* bp = wtile + (size_t)gch * wstride + lane;
 #pragma unroll
-  for (int j = 0; j < 12; ++j) o.b[j] = bp[j * 64];       // ((t*2 + s)*3 + piece) * 64 + lane, t = 0..1: two column tiles are 768 uint4 in a row
+  for (int j = 0; j < 4 * PC; ++j) o.b[j] = bp[j * 64];   // ((t*2 + s)*PC + piece) * 64 + lane, t = 0..1: two column tiles are 256 * PC uint4 in a row
 }
 
-__device__ __forceinline__ void direct_mma(const DirectOperands& o, f32x16& acc0, f32x16& acc1) {
-  const float4 c0 = make_float4(__uint_as_float(o.a[0].x), __uint_as_float(o.a[0].y), __uint_as_float(o.a[0].z), __uint_as_float(o.a[0].w));
-  const float4 c1 = make_float4(__uint_as_float(o.a[1].x), __uint_as_float(o.a[1].y), __uint_as_float(o.a[1].z), __uint_as_float(o.a[1].w));
-  const float4 c2 = make_float4(__uint_as_float(o.a[2].x), __uint_as_float(o.a[2].y), __uint_as_float(o.a[2].z), __uint_as_float(o.a[2].w));
-  const float4 c3 = make_float4(__uint_as_float(o.a[3].x), __uint_as_float(o.a[3].y), __uint_as_float(o.a[3].z), __uint_as_float(o.a[3].w));
-  const Pieces s0 = split8(c0, c1), s1 = split8(c2, c3);
-  acc0 = mma6(s0, o.b[0], o.b[1], o.b[2], acc0);
-  acc1 = mma6(s0, o.b[6], o.b[7], o.b[8], acc1);
-  acc0 = mma6(s1, o.b[3], o.b[4], o.b[5], acc0);
-  acc1 = mma6(s1, o.b[9], o.b[10], o.b[11], acc1);
+template <int PC>
+__device__ __forceinline__ void direct_mma(const DirectOperands<PC>& o, f32x16& acc0, f32x16& acc1, float a_scale) {
+  const PiecesN s0 = cut8<PC>(as_f4(o.a[0]), as_f4(o.a[1]), a_scale), s1 = cut8<PC>(as_f4(o.a[2]), as_f4(o.a[3]), a_scale);
+  acc0 = mma_pc<PC>(s0, o.b[0 * PC], o.b[0 * PC + (PC > 1 ? 1 : 0)], o.b[0 * PC + (PC > 2 ? 2 : 0)], acc0);
+  acc1 = mma_pc<PC>(s0, o.b[2 * PC], o.b[2 * PC + (PC > 1 ? 1 : 0)], o.b[2 * PC + (PC > 2 ? 2 : 0)], acc1);
+  acc0 = mma_pc<PC>(s1, o.b[1 * PC], o.b[1 * PC + (PC > 1 ? 1 : 0)], o.b[1 * PC + (PC > 2 ? 2 : 0)], acc0);
+  acc1 = mma_pc<PC>(s1, o.b[3 * PC], o.b[3 * PC + (PC > 1 ? 1 : 0)], o.b[3 * PC + (PC > 2 ? 2 : 0)], acc1);
 }
 
 // grid (ceil(P / 32), Cout / 64); block 64 * nw, nw = 1 .. kDirectMaxWaves waves; dynamic LDS (nw - 1) * 8 KB.  stride 1 (the plan's
 // condition); any kh x kw, pads, dilation.  (Measured on the small net's 64 -> 64 3x3, 18 chunks: 3 waves x 6 chunks 12.3-14.0 us;
 // 9 waves x 2 chunks 17.8-18.3 us — the launch bound for 9 waves caps the registers below the two operand sets.)
 constexpr int kDirectMaxWaves = 3;
+template <int PC>
 static __global__ __launch_bounds__(64 * kDirectMaxWaves) void conv_split_direct_kernel(Args a) {
   extern __shared__ __attribute__((aligned(16))) float red_dyn[];
   float (*red)[32 * 64] = reinterpret_cast<float (*)[32 * 64]>(red_dyn);
@@ -1193,8 +852,14 @@ static __global__ __launch_bounds__(64 * kDirectMaxWaves) void conv_split_direct
   // this wave's run of the (tap, chunk) list
   const int c_begin = (nchunks * wave) / kDirectWaves, c_end = (nchunks * (wave + 1)) / kDirectWaves;
   const int col_tiles = a.Cout / 32;
-  const size_t wstride = (size_t)col_tiles * (kChunkBytesB / 32);
-  const uint4* wtile = a.wfrag + (size_t)(2 * blockIdx.y) * (kChunkBytesB / 32);
+  const size_t wstride = (size_t)col_tiles * (128 * PC);
+  const uint4* wtile = a.wfrag + (size_t)(2 * blockIdx.y) * (128 * PC);
+  float a_scale = 1.f, out_scale = 1.f;
+  if (PC == 2) {
+    const int s_exp = 13 - amax_exponent_asm(a.amax, lane, a.status);
+    a_scale = ldexpf(1.f, s_exp);
+    out_scale = ldexpf(1.f, -(s_exp + a.w_exp));
+  }
   // the lane's pixel and the 16 channels of a chunk it feeds (fragment role: row = lane & 31, k half = lane >> 5)
   const int pix = m0 + (lane & 31);
   const bool pix_ok = pix < P;
@@ -1214,7 +879,7 @@ static __global__ __launch_bounds__(64 * kDirectMaxWaves) void conv_split_direct
     ok = pix_ok && (unsigned)(iy0 + dy) < (unsigned)a.H && (unsigned)(ix0 + dx) < (unsigned)a.W;
     off = base + (dy * a.W + dx) * a.lda + kc * kChunk;
   };
-  DirectOperands cur, nxt;
+  DirectOperands<PC> cur, nxt;
   if (c_begin < c_end) {
     int off; bool ok;
     operand_of(c_begin, off, ok);
@@ -1226,14 +891,14 @@ static __global__ __launch_bounds__(64 * kDirectMaxWaves) void conv_split_direct
       operand_of(c + 1, off, ok);
       direct_load(nxt, a.x, wtile, wstride, c + 1, off, ok, lane);
     }
-    direct_mma(cur, acc0, acc1);
+    direct_mma<PC>(cur, acc0, acc1, a_scale);
     if (c + 1 < c_end) {
       if (c + 2 < c_end) {
         int off; bool ok;
         operand_of(c + 2, off, ok);
         direct_load(cur, a.x, wtile, wstride, c + 2, off, ok, lane);
       }
-      direct_mma(nxt, acc0, acc1);
+      direct_mma<PC>(nxt, acc0, acc1, a_scale);
     }
   }
   // the waves' partial sums meet in LDS: [wave - 1][reg][lane] (conflict-free), added in wave order by wave 0
@@ -1254,51 +919,12 @@ static __global__ __launch_bounds__(64 * kDirectMaxWaves) void conv_split_direct
     ro.base[r] = 0;
     if (p < P) { ro.valid |= 1u << r; ro.base[r] = out_pixel_base(a, p); }
   }
-  tile_store(a, ro, blockIdx.y * kWgCh + (lane & 31), acc0);
-  tile_store(a, ro, blockIdx.y * kWgCh + 32 + (lane & 31), acc1);
-}
-
-// weights (Cout, taps, Cin) fp32 -> fragment order, three bf16 pieces.  One thread per (fragment, lane): 8 values.
-// out index: ((((g * col_tiles + t) * 2 + s) * 3 + piece) * 64 + lane) uint4, g = tap * (Cin/32) + chunk
-static __global__ void split_weights_kernel(const float* __restrict__ w, uint4* __restrict__ out, int Cout, int taps, int Cin) {
-  const int col_tiles = Cout / 32, chunks = Cin / kChunk;
-  const long total = (long)taps * chunks * col_tiles * 2 * 64;
-  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= total) return;
-  const int lane = (int)(i & 63);
-  long r = i >> 6;
-  const int s = (int)(r & 1); r >>= 1;
-  const int t = (int)(r % col_tiles); r /= col_tiles;
-  const int g = (int)r;
-  const int tap = g / chunks, kc = g - tap * chunks;
-  const int co = t * 32 + (lane & 31);
-  const int ci = kc * kChunk + 16 * (lane >> 5) + 8 * s;
-  const float* src = w + ((size_t)co * taps + tap) * Cin + ci;
-  const float4 v0 = *reinterpret_cast<const float4*>(src), v1 = *reinterpret_cast<const float4*>(src + 4);
-  const Pieces p = split8(v0, v1);
-  uint4* dst = out + ((((size_t)g * col_tiles + t) * 2 + s) * 3) * 64 + lane;
-  dst[0] = p.p1; dst[64] = p.p2; dst[128] = p.p3;
-}
-
-// the fp16 two-piece form of the same: values w * 2^w_exp, pieces (hi, lo); out index ((((g * col_tiles + t) * 2 + s) * 2 + piece) * 64 + lane)
-static __global__ void split_weights_h_kernel(const float* __restrict__ w, uint4* __restrict__ out, int Cout, int taps, int Cin, int w_exp) {
-  const int col_tiles = Cout / 32, chunks = Cin / kChunk;
-  const long total = (long)taps * chunks * col_tiles * 2 * 64;
-  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= total) return;
-  const int lane = (int)(i & 63);
-  long r = i >> 6;
-  const int s = (int)(r & 1); r >>= 1;
-  const int t = (int)(r % col_tiles); r /= col_tiles;
-  const int g = (int)r;
-  const int tap = g / chunks, kc = g - tap * chunks;
-  const int co = t * 32 + (lane & 31);
-  const int ci = kc * kChunk + 16 * (lane >> 5) + 8 * s;
-  const float* src = w + ((size_t)co * taps + tap) * Cin + ci;
-  const float4 v0 = *reinterpret_cast<const float4*>(src), v1 = *reinterpret_cast<const float4*>(src + 4);
-  const PiecesH p = split8h(v0, v1, ldexpf(1.f, w_exp));
-  uint4* dst = out + ((((size_t)g * col_tiles + t) * 2 + s) * 2) * 64 + lane;
-  dst[0] = p.hi; dst[64] = p.lo;
+  if (PC == 2) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { acc0[r] = acc0[r] * out_scale; acc1[r] = acc1[r] * out_scale; }
+  }
+  const uint32_t m = max(tile_store_max(a, ro, blockIdx.y * kWgCh + (lane & 31), acc0), tile_store_max(a, ro, blockIdx.y * kWgCh + 32 + (lane & 31), acc1));
+  publish_amax(m, a.amax_out, a.status, blockIdx.y * gridDim.x + blockIdx.x);
 }
 
 // partial maxima of |x| for the fp16 form's scale: kAmaxSlots workgroups, slot b = max over its grid-stride share (0 for an empty share)

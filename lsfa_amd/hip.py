@@ -12,7 +12,9 @@ import os
 import torch  # must be imported before the .so so that both share one libamdhip64
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "liblsfa_hip.so")
+# LSFA_HIP_LIBRARY: another build of the same library (tools/lab/drop_product_check.sh runs the parity suite against a deliberately
+# degraded one to show that the suite notices); there is no fallback either way
+LIB_PATH = os.environ.get("LSFA_HIP_LIBRARY") or os.path.join(_HERE, "liblsfa_hip.so")
 
 # names of the LSFA_OP_* ids, in id order.  The table is the LIBRARY's (lsfa_op_name) — filled in by lib(); this copy only serves
 # code that runs before the library is loaded and is checked against it there (an out-of-date copy made lsfa_prof_read write one
@@ -42,10 +44,8 @@ def lib():
         L = ctypes.CDLL(LIB_PATH)
         L.lsfa_last_error.restype = ctypes.c_char_p
         for name in ("lsfa_proposal_workspace_bytes", "lsfa_nms_workspace_bytes", "lsfa_det_workspace_bytes",
-                     "lsfa_mv_workspace_bytes", "lsfa_conv_nhwc_workspace_bytes", "lsfa_conv_split_weight_bytes",
-                     "lsfa_conv_split_workspace_bytes", "lsfa_conv_split_view_workspace_bytes",
-                     "lsfa_conv_split_h_weight_bytes", "lsfa_conv_split_h_workspace_bytes",
-                     "lsfa_deconv4x4s2_crop_workspace_bytes"):
+                     "lsfa_mv_workspace_bytes", "lsfa_conv_nhwc_workspace_bytes", "lsfa_conv_weight_bytes",
+                     "lsfa_conv_workspace_bytes", "lsfa_deconv4x4s2_crop_workspace_bytes"):
             getattr(L, name).restype = ctypes.c_size_t
         L.lsfa_op_name.restype = ctypes.c_char_p
         L._nms.restype = None
@@ -403,11 +403,11 @@ def scale_shift_relu_cl(x, scale, shift, relu=True, out=None):
 
 # algorithmic FLOPs (2*M*N*K, fp32-equivalent) of the own convolutions issued since the last reset: bench.py divides
 # them by the event-timed duration of the same launches for its MFMA roofline
-_conv_flops = {"count": False, "flops": 0.0, "launches": 0, "flops_three_products": 0.0}
+_conv_flops = {"count": False, "flops": 0.0, "launches": 0, "flops_three_products": 0.0, "flops_one_product": 0.0}
 
 
 def conv_flops_reset(enable=True):
-    _conv_flops.update(count=bool(enable), flops=0.0, launches=0, flops_three_products=0.0)
+    _conv_flops.update(count=bool(enable), flops=0.0, launches=0, flops_three_products=0.0, flops_one_product=0.0)
 
 
 def conv_flops_read():
@@ -419,12 +419,20 @@ def conv_flops_three_products():
     return _conv_flops["flops_three_products"]
 
 
-def _count_conv(N, Ho, Wo, Cout, Cin, kh, kw, three_products=False):
+def conv_flops_one_product():
+    """... and the part that ran one bf16 product per fp32 product (the bf16 mode)"""
+    return _conv_flops["flops_one_product"]
+
+
+def _count_conv(N, Ho, Wo, Cout, Cin, kh, kw, pieces=3):
     if _conv_flops["count"]:
-        _conv_flops["flops"] += 2.0 * N * Ho * Wo * Cout * Cin * kh * kw
+        f = 2.0 * N * Ho * Wo * Cout * Cin * kh * kw
+        _conv_flops["flops"] += f
         _conv_flops["launches"] += 1
-        if three_products:
-            _conv_flops["flops_three_products"] += 2.0 * N * Ho * Wo * Cout * Cin * kh * kw
+        if pieces == 2:
+            _conv_flops["flops_three_products"] += f
+        elif pieces == 1:
+            _conv_flops["flops_one_product"] += f
 
 
 def conv_weight_kc(weight):
@@ -593,33 +601,116 @@ def maxpool3x3s2_nhwc(x, out=None, scale2=None, shift2=None):
     return out if out2 is None else (out, out2)
 
 
-class SplitWeight(object):
-    """A convolution weight cut into three bf16 pieces per value and laid out in MFMA fragment order
-    (lsfa_conv_split_weights); made once per layer at bind time."""
+class ConvDesc(ctypes.Structure):
+    """struct lsfa_conv_desc (include/lsfa_hip.h)"""
+    _fields_ = [("x", ctypes.c_void_p), ("lda", ctypes.c_int), ("N", ctypes.c_int), ("H", ctypes.c_int), ("W", ctypes.c_int), ("Cin", ctypes.c_int),
+                ("wfrag", ctypes.c_void_p), ("pieces", ctypes.c_int), ("w_exp", ctypes.c_int), ("amax_in", ctypes.c_void_p),
+                ("bias", ctypes.c_void_p), ("Cout", ctypes.c_int), ("kh", ctypes.c_int), ("kw", ctypes.c_int), ("stride", ctypes.c_int),
+                ("pad_h", ctypes.c_int), ("pad_w", ctypes.c_int), ("dil", ctypes.c_int),
+                ("act", ctypes.c_int), ("y_nchw", ctypes.c_int), ("residual", ctypes.c_void_p), ("y", ctypes.c_void_p), ("ldy", ctypes.c_int),
+                ("y2", ctypes.c_void_p), ("scale2", ctypes.c_void_p), ("shift2", ctypes.c_void_p),
+                ("amax_out", ctypes.c_void_p), ("status", ctypes.c_void_p),
+                ("Ho", ctypes.c_int), ("Wo", ctypes.c_int), ("out_H", ctypes.c_int), ("out_W", ctypes.c_int), ("out_sy", ctypes.c_int),
+                ("out_sx", ctypes.c_int), ("prof_tag", ctypes.c_int)]
 
-    def __init__(self, weight, real_cout=None, real_cin=None, into=None):
+
+def _dp(t):
+    return None if t is None else ctypes.c_void_p(t.data_ptr())
+
+
+# SplitWeight's default form: three bf16 pieces (exact cut, no scale needed).  The frame path binds its fp32 convolutions with
+# pieces=2 (two fp16 pieces + a scale, three products) and its bf16 mode with pieces=1 (lsfa_amd/symbols).
+DEFAULT_PIECES = 3
+AMAX_SLOTS = 256
+
+
+class SplitWeight(object):
+    """A convolution weight cut into `pieces` pieces per value and laid out in MFMA fragment order (lsfa_conv_weights); made once per
+    layer at bind time.  pieces = 2: the values are scaled by 2^w_exp so that the largest lands in [2^13, 2^14)."""
+
+    def __init__(self, weight, real_cout=None, real_cin=None, into=None, pieces=None):
         """weight: (Cout, Cin, kh, kw) float32 CUDA tensor (the framework's layout).  real_cout / real_cin: the layer's own
         channel counts when `weight` was zero-padded to the kernel's tile sizes (algorithmic FLOPs are counted on those)."""
         w_kc = _f32c(conv_weight_kc(weight), "weight")
+        self.pieces = int(DEFAULT_PIECES if pieces is None else pieces)
         self.cout, self.cin, self.kh, self.kw = [int(v) for v in weight.shape]
         self.real_cout, self.real_cin = int(real_cout or self.cout), int(real_cin or self.cin)
-        need = lib().lsfa_conv_split_weight_bytes(_ci(self.cout), _ci(self.kh), _ci(self.kw), _ci(self.cin))
+        need = lib().lsfa_conv_weight_bytes(_ci(self.cout), _ci(self.kh), _ci(self.kw), _ci(self.cin), _ci(self.pieces))
         if need == 0:
-            raise LsfaError("SplitWeight: Cin=%d must be a multiple of 32 and Cout=%d of 64" % (self.cin, self.cout))
+            raise LsfaError("SplitWeight: Cin=%d must be a multiple of 32, Cout=%d of 64, pieces=%d one of 1, 2, 3" % (self.cin, self.cout, self.pieces))
+        self.w_exp = 0
+        if self.pieces == 2:
+            amax = float(weight.abs().max().item())              # bind time: a host synchronisation is fine here
+            self.w_exp = 0 if not (amax > 0 and math.isfinite(amax)) else 13 - int(math.floor(math.log2(amax)))
+            self.w_exp = max(-100, min(100, self.w_exp))
         self.frag = torch.empty(need, dtype=torch.uint8, device=weight.device) if into is None else into
         if self.frag.numel() != need or not self.frag.is_contiguous():
             raise LsfaError("SplitWeight: `into` must be a contiguous uint8 tensor of %d bytes" % need)
         with torch.cuda.device(weight.device):
-            _check(lib().lsfa_conv_split_weights(_ptr(w_kc), _ci(self.cout), _ci(self.kh), _ci(self.kw), _ci(self.cin),
-                                                 _ptr(self.frag), _stream()), "lsfa_conv_split_weights")
+            _check(lib().lsfa_conv_weights(_ptr(w_kc), _ci(self.cout), _ci(self.kh), _ci(self.kw), _ci(self.cin), _ci(self.pieces),
+                                           _ci(self.w_exp), _ptr(self.frag), _stream()), "lsfa_conv_weights")
+
+
+def SplitWeightH(weight, **kw):
+    """the fp16 two-piece form by name (r3's class)"""
+    return SplitWeight(weight, pieces=2, **kw)
+
+
+@_on_tensor_device
+def amax_partial(x, out=None):
+    """lsfa_amax_partial: 256 partial maxima of |x| (float32, contiguous, numel % 4 == 0): an `amax_in` for a map that no convolution
+    of this library produced (those leave theirs in `amax_out`)."""
+    x = _f32c(x, "x")
+    if out is None:
+        out = torch.empty(AMAX_SLOTS, device=x.device, dtype=torch.float32)
+    _check(lib().lsfa_amax_partial(_ptr(x), ctypes.c_longlong(x.numel()), _ptr(out), _stream()), "lsfa_amax_partial")
+    return out
+
+
+def amax_slots(n, device):
+    """n zeroed amax_out slot arrays (n, 256) - uint32 bit patterns of non-negative floats, readable as float32 through .view()"""
+    return torch.zeros((n, AMAX_SLOTS), dtype=torch.int32, device=device)
+
+
+def new_status(device):
+    return torch.zeros(4, dtype=torch.int32, device=device)
+
+
+@_on_tensor_device
+def check_status(status):
+    """lsfa_status_check: raises LsfaError if a convolution raised the status word (non-finite output: the fp16 form's scale was an
+    under-estimate, or the input held inf / NaN).  Synchronises the current stream."""
+    _check(lib().lsfa_status_check(_ptr(status), _stream()), "lsfa_status_check")
+
+
+def _conv_launch(who, x, lda, N, H, W, cin, sw, bias, stride, pad_h, pad_w, dil, act, nchw, residual, y_ptr, ldy, out2, scale2, shift2,
+                 amax_in, amax_out, status, grid, view, prof_tag, device):
+    if sw.pieces == 2 and amax_in is None:
+        raise LsfaError("%s: a two-piece (fp16) weight needs amax_in" % who)
+    d = ConvDesc()
+    d.x, d.lda, d.N, d.H, d.W, d.Cin = x.data_ptr(), lda, N, H, W, cin
+    d.wfrag, d.pieces, d.w_exp, d.amax_in = sw.frag.data_ptr(), sw.pieces, sw.w_exp, (amax_in.data_ptr() if amax_in is not None else None)
+    d.bias, d.Cout, d.kh, d.kw, d.stride, d.pad_h, d.pad_w, d.dil = (bias.data_ptr() if bias is not None else None), sw.cout, sw.kh, sw.kw, stride, pad_h, pad_w, dil
+    d.act, d.y_nchw, d.residual, d.y, d.ldy = int(act), int(nchw), (residual.data_ptr() if residual is not None else None), y_ptr, ldy
+    d.y2, d.scale2, d.shift2 = (out2.data_ptr() if out2 is not None else None), (scale2.data_ptr() if scale2 is not None else None), (shift2.data_ptr() if shift2 is not None else None)
+    d.amax_out, d.status = (amax_out.data_ptr() if amax_out is not None else None), (status.data_ptr() if status is not None else None)
+    d.Ho, d.Wo = grid
+    d.out_H, d.out_W, d.out_sy, d.out_sx = view
+    d.prof_tag = prof_tag
+    need = lib().lsfa_conv_workspace_bytes(ctypes.byref(d))
+    ws = torch.empty(max(need, 16), dtype=torch.uint8, device=device)
+    _check(lib().lsfa_conv_fwd(ctypes.byref(d), _ptr(ws), ctypes.c_size_t(need), _stream()), who)
 
 
 @_on_tensor_device
 def conv_split(x, sw, bias=None, stride=1, pad=0, dil=1, relu=False, out=None, residual=None, out2=None, scale2=None,
-               shift2=None, nchw=False):
-    """conv_nhwc on the bf16 matrix pipe with exactly split fp32 operands (lsfa_conv_split_fwd); sw: SplitWeight.
-    x (N, H, W, Cin) contiguous fp32 -> (N, Ho, Wo, Cout), or (N, Cout, Ho, Wo) with nchw=True (then residual / out2 are
-    NCHW too); the other arguments as conv_nhwc."""
+               shift2=None, nchw=False, act=None, amax_in=None, amax_out=None, status=None):
+    """lsfa_conv_fwd: convolution with fp32 in / out and split operands on the matrix pipe; sw: SplitWeight (its `pieces` picks the form).
+    x (N, H, W, Cin) contiguous fp32 -> (N, Ho, Wo, Cout), or (N, Cout, Ho, Wo) with nchw=True (then residual / out2 are NCHW too).
+    residual (same shape as the output; may BE `out`): added before the activation / store.  out2 + scale2 + shift2: second output
+    max(out*scale2[c] + shift2[c], 0) (the next ResNet unit's bn1 + relu1).  act: 0 none, 1 ReLU, 2 LeakyReLU(0.1) (relu=True = act 1).
+    amax_in: 256 partial maxima (float32 or int32 bit patterns) bounding |x| - required for two-piece weights; amax_out: 256 int32 slots that
+    receive max|out2| (or max|out|); status: the int32 status word.  Returns out, or (out, out2)."""
     x = _f32c(x, "x")
     N, H, W, Cin = x.shape
     if Cin != sw.cin:
@@ -631,80 +722,27 @@ def conv_split(x, sw, bias=None, stride=1, pad=0, dil=1, relu=False, out=None, r
     for name, t in (("out", out), ("residual", residual), ("out2", out2)):
         if t is not None and (t.numel() != N * Ho * Wo * Cout or not t.is_contiguous() or t.dtype != torch.float32):
             raise LsfaError("conv_split: %s must be a contiguous float32 tensor of %d elements" % (name, N * Ho * Wo * Cout))
-    _count_conv(N, Ho, Wo, sw.real_cout, sw.real_cin, kh, kw)
-    need = lib().lsfa_conv_split_workspace_bytes(_ci(N), _ci(H), _ci(W), _ci(Cin), _ci(Cout), _ci(kh), _ci(kw), _ci(stride),
-                                                 _ci(pad), _ci(dil))
-    ws = torch.empty(need, dtype=torch.uint8, device=x.device)
-    _check(lib().lsfa_conv_split_fwd(_ptr(x), _ci(N), _ci(H), _ci(W), _ci(Cin), _ptr(sw.frag), _ptr(bias), _ci(Cout), _ci(kh),
-                                     _ci(kw), _ci(stride), _ci(pad), _ci(dil), _ci(int(relu)), _ci(int(nchw)), _ptr(residual),
-                                     _ptr(out), _ptr(out2), _ptr(scale2), _ptr(shift2), _ptr(ws), ctypes.c_size_t(need), _stream()),
-           "lsfa_conv_split_fwd")
+    if amax_in is None and sw.pieces == 2:
+        amax_in = amax_partial(x)
+    _count_conv(N, Ho, Wo, sw.real_cout, sw.real_cin, kh, kw, sw.pieces)
+    _conv_launch("lsfa_conv_fwd", x, Cin, N, H, W, Cin, sw, bias, stride, pad, pad, dil, (1 if relu else 0) if act is None else act, nchw,
+                 residual, out.data_ptr(), Cout, out2, scale2, shift2, amax_in, amax_out, status, (0, 0), (0, 0, 0, 0), 0, x.device)
     return out if out2 is None else (out, out2)
 
 
-class SplitWeightH(object):
-    """r3 (opt-in): a convolution weight cut into TWO fp16 pieces per value (values scaled by 2^w_exp so that the largest lands in
-    [2^13, 2^14)) in MFMA fragment order (lsfa_conv_split_h_weights); made once per layer at bind time.  Cout % 128 == 0."""
-
-    def __init__(self, weight):
-        w_kc = _f32c(conv_weight_kc(weight), "weight")
-        self.cout, self.cin, self.kh, self.kw = [int(v) for v in weight.shape]
-        self.real_cout, self.real_cin = self.cout, self.cin
-        need = lib().lsfa_conv_split_h_weight_bytes(_ci(self.cout), _ci(self.kh), _ci(self.kw), _ci(self.cin))
-        if need == 0 or self.cout % 128 or self.cin % 32:
-            raise LsfaError("SplitWeightH: Cin=%d must be a multiple of 32 and Cout=%d of 128" % (self.cin, self.cout))
-        amax = float(weight.abs().max().item())              # bind time: a host synchronisation is fine here
-        self.w_exp = 0 if not (amax > 0 and math.isfinite(amax)) else 13 - int(math.floor(math.log2(amax)))
-        self.w_exp = max(-100, min(100, self.w_exp))
-        self.frag = torch.empty(need, dtype=torch.uint8, device=weight.device)
-        with torch.cuda.device(weight.device):
-            _check(lib().lsfa_conv_split_h_weights(_ptr(w_kc), _ci(self.cout), _ci(self.kh), _ci(self.kw), _ci(self.cin), _ci(self.w_exp),
-                                                   _ptr(self.frag), _stream()), "lsfa_conv_split_h_weights")
+def conv_split_h(x, swh, bias=None, stride=1, pad=0, dil=1, act=0, out=None, nchw=False, amax=None, amax_out=None, status=None):
+    """conv_split with r3's argument names for the fp16 two-piece form (amax: the partial maxima of x or of a map that bounds |x|)"""
+    return conv_split(x, swh, bias, stride, pad, dil, out=out, nchw=nchw, act=act, amax_in=amax, amax_out=amax_out, status=status)
 
 
 @_on_tensor_device
-def amax_partial(x, out=None):
-    """lsfa_amax_partial: 256 partial maxima of |x| (float32, contiguous, numel % 4 == 0): what conv_split_h derives its scale from."""
-    x = _f32c(x, "x")
-    if out is None:
-        out = torch.empty(256, device=x.device, dtype=torch.float32)
-    _check(lib().lsfa_amax_partial(_ptr(x), ctypes.c_longlong(x.numel()), _ptr(out), _stream()), "lsfa_amax_partial")
-    return out
-
-
-@_on_tensor_device
-def conv_split_h(x, swh, bias=None, stride=1, pad=0, dil=1, act=0, out=None, nchw=False, amax=None):
-    """lsfa_conv_split_h_fwd: the convolution with fp32 operands cut into two fp16 pieces, three matrix instructions per product.
-    amax: the partial maxima of x (amax_partial(x)) or of a map that bounds |x|; computed here when not given (one more launch)."""
-    x = _f32c(x, "x")
-    N, H, W, Cin = x.shape
-    if Cin != swh.cin:
-        raise LsfaError("conv_split_h: input has %d channels, the weight %d" % (Cin, swh.cin))
-    Cout, kh, kw = swh.cout, swh.kh, swh.kw
-    Ho, Wo = (H + 2 * pad - dil * (kh - 1) - 1) // stride + 1, (W + 2 * pad - dil * (kw - 1) - 1) // stride + 1
-    if out is None:
-        out = torch.empty((N, Cout, Ho, Wo) if nchw else (N, Ho, Wo, Cout), device=x.device, dtype=torch.float32)
-    elif out.numel() != N * Ho * Wo * Cout or not out.is_contiguous() or out.dtype != torch.float32:
-        raise LsfaError("conv_split_h: out must be a contiguous float32 tensor of %d elements" % (N * Ho * Wo * Cout))
-    if amax is None:
-        amax = amax_partial(x)
-    _count_conv(N, Ho, Wo, swh.real_cout, swh.real_cin, kh, kw, three_products=True)
-    need = lib().lsfa_conv_split_h_workspace_bytes(_ci(N), _ci(H), _ci(W), _ci(Cin), _ci(Cout), _ci(kh), _ci(kw), _ci(stride), _ci(pad),
-                                                   _ci(dil))
-    ws = torch.empty(max(need, 16), dtype=torch.uint8, device=x.device)
-    _check(lib().lsfa_conv_split_h_fwd(_ptr(x), _ptr(swh.frag), _ci(swh.w_exp), _ptr(amax), _ptr(bias), _ci(N), _ci(H), _ci(W), _ci(Cin),
-                                       _ci(Cout), _ci(kh), _ci(kw), _ci(stride), _ci(pad), _ci(dil), _ci(int(act)), _ci(int(nchw)),
-                                       _ptr(out), _ptr(ws), ctypes.c_size_t(need), _stream()), "lsfa_conv_split_h_fwd")
-    return out
-
-
-@_on_tensor_device
-def conv_split_view(x, sw, bias, out, stride=1, pad=(0, 0), dil=1, act=0, cin=None, c0=0, grid=None, place=None):
-    """lsfa_conv_split_view_fwd: the split-bf16 convolution between VIEWS of wider channels-last maps.
+def conv_split_view(x, sw, bias, out, stride=1, pad=(0, 0), dil=1, act=0, cin=None, c0=0, grid=None, place=None, amax_in=None,
+                    amax_out=None, status=None):
+    """lsfa_conv_fwd between VIEWS of wider channels-last maps.
     x    (N, H, W, L) contiguous fp32, the convolution reads channels [0, cin) of it (cin = sw.cin by default, L >= cin);
     out  (N, Hout, Wout, Lout) contiguous fp32: the result goes to channels [c0, c0 + sw.cout) of it;
     grid (Ho, Wo): the output grid of this launch when smaller than the convolution's; place (y0, x0, sy, sx): output pixel
-         (oy, ox) is written to out[:, y0 + oy*sy, x0 + ox*sx] (default: out[:, oy, ox]) — a phase of a transposed convolution;
+         (oy, ox) is written to out[:, y0 + oy*sy, x0 + ox*sx] (default: out[:, oy, ox]) - a phase of a transposed convolution;
     pad  (pad_h, pad_w); act 0 none / 1 ReLU / 2 LeakyReLU(0.1)."""
     x = _f32c(x, "x")
     if not (out.is_contiguous() and out.dtype == torch.float32 and out.dim() == 4):
@@ -722,15 +760,13 @@ def conv_split_view(x, sw, bias, out, stride=1, pad=(0, 0), dil=1, act=0, cin=No
     Hout, Wout, Lout = out.shape[1], out.shape[2], out.shape[3]
     if y0 + (Ho - 1) * sy >= Hout or x0 + (Wo - 1) * sx >= Wout:
         raise LsfaError("conv_split_view: a %dx%d grid placed at (%d,%d) step (%d,%d) leaves out %s" % (Ho, Wo, y0, x0, sy, sx, tuple(out.shape)))
-    need = lib().lsfa_conv_split_view_workspace_bytes(_ci(L), _ci(N), _ci(H), _ci(W), _ci(cin), _ci(sw.cout), _ci(kh), _ci(kw),
-                                                      _ci(stride), _ci(pad[0]), _ci(pad[1]), _ci(dil), _ci(Ho), _ci(Wo))
-    ws = torch.empty(need, dtype=torch.uint8, device=x.device)
+    if amax_in is None and sw.pieces == 2:
+        amax_in = amax_partial(x)          # the whole (N, H, W, L) map bounds its leading channels
     first = out.data_ptr() + 4 * ((y0 * Wout + x0) * Lout + c0)
-    view = place is not None
-    _check(lib().lsfa_conv_split_view_fwd(_ptr(x), _ci(L), _ci(N), _ci(H), _ci(W), _ci(cin), _ptr(sw.frag), _ptr(bias), _ci(sw.cout),
-                                          _ci(kh), _ci(kw), _ci(stride), _ci(pad[0]), _ci(pad[1]), _ci(dil), _ci(act), _vp(first),
-                                          _ci(Lout), _ci(Ho), _ci(Wo), _ci(Hout if view or (Ho, Wo) != (Hout, Wout) else 0), _ci(Wout),
-                                          _ci(sy), _ci(sx), _ptr(ws), ctypes.c_size_t(need), _stream()), "lsfa_conv_split_view_fwd")
+    view = place is not None or (Ho, Wo) != (Hout, Wout)
+    _count_conv(N, Ho, Wo, sw.real_cout, sw.real_cin, kh, kw, sw.pieces)
+    _conv_launch("lsfa_conv_fwd (view)", x, L, N, H, W, cin, sw, bias, stride, pad[0], pad[1], dil, act, False, None, first, Lout, None, None,
+                 None, amax_in, amax_out, status, (Ho, Wo), (Hout if view else 0, Wout, sy, sx), 1, x.device)
     return out
 
 
@@ -738,32 +774,44 @@ class PhaseWeights(list):
     """The four phase weights of a Deconvolution(4x4, stride 2) as SplitWeight views of ONE allocation (`frag4`)."""
 
 
-def deconv_phase_weights(wt, cin_pad=None):
+def deconv_phase_weights(wt, cin_pad=None, pieces=None):
     """wt: MXNet Deconvolution weight (Cin, Cout, 4, 4) -> PhaseWeights for lsfa_deconv4x4s2_crop_fwd (input channels zero-padded to
     cin_pad).  Output row 2m + py of the cropped map reads input rows (m - 1, m) through taps ky = (3, 1) when py = 0 and rows
-    (m, m + 1) through ky = (2, 0) when py = 1; columns alike."""
+    (m, m + 1) through ky = (2, 0) when py = 1; columns alike.  With two pieces all four phases share ONE weight scale (w_exp)."""
     cin, cout = int(wt.shape[0]), int(wt.shape[1])
     cpad = int(cin_pad or cin)
-    per = lib().lsfa_conv_split_weight_bytes(_ci(cout), _ci(2), _ci(2), _ci(cpad))
+    pieces = int(DEFAULT_PIECES if pieces is None else pieces)
+    per = lib().lsfa_conv_weight_bytes(_ci(cout), _ci(2), _ci(2), _ci(cpad), _ci(pieces))
     if per == 0:
         raise LsfaError("deconv_phase_weights: Cin=%d must be a multiple of 32 and Cout=%d of 64" % (cpad, cout))
     frag4 = torch.empty(4 * per, dtype=torch.uint8, device=wt.device)
     out = PhaseWeights()
+    # the four phases together hold every tap of wt exactly once: its maximum is each phase's bound
+    amax = float(wt.abs().max().item())
+    w_exp = 0 if (pieces != 2 or not (amax > 0 and math.isfinite(amax))) else max(-100, min(100, 13 - int(math.floor(math.log2(amax)))))
     for py in (0, 1):
         for px in (0, 1):
             kys, kxs = ((3, 1) if py == 0 else (2, 0)), ((3, 1) if px == 0 else (2, 0))
             wp = torch.zeros((cout, cpad, 2, 2), device=wt.device, dtype=torch.float32)
             wp[:, :cin] = wt[:, :, kys, :][:, :, :, kxs].permute(1, 0, 2, 3)
-            out.append(SplitWeight(wp, real_cin=cin, into=frag4[(py * 2 + px) * per:(py * 2 + px + 1) * per]))
-    out.frag4 = frag4
+            sw = SplitWeight.__new__(SplitWeight)
+            sw.pieces, sw.w_exp = pieces, w_exp
+            sw.cout, sw.cin, sw.kh, sw.kw = cout, cpad, 2, 2
+            sw.real_cout, sw.real_cin = cout, cin
+            sw.frag = frag4[(py * 2 + px) * per:(py * 2 + px + 1) * per]
+            with torch.cuda.device(wt.device):
+                _check(lib().lsfa_conv_weights(_ptr(_f32c(conv_weight_kc(wp), "weight")), _ci(cout), _ci(2), _ci(2), _ci(cpad), _ci(pieces),
+                                               _ci(w_exp), _ptr(sw.frag), _stream()), "lsfa_conv_weights")
+            out.append(sw)
+    out.frag4, out.pieces, out.w_exp = frag4, pieces, w_exp
     return out
 
 
 @_on_tensor_device
-def deconv4x4s2_crop(x, sw4, bias, out, c0=0, act=0):
+def deconv4x4s2_crop(x, sw4, bias, out, c0=0, act=0, amax_in=None, amax_out=None, status=None):
     """lsfa_deconv4x4s2_crop_fwd: Deconvolution(4x4, stride 2) + Crop(offset 1) + bias + activation as one launch.
-    x (N, Hi, Wi, L) channels-last (the weights' Cin channels read, L >= Cin); sw4: four SplitWeight of the (Cout, Cin, 2, 2) phase
-    weights in (py, px) order (see the header); the result fills channels [c0, c0 + Cout) of out (N, Hc, Wc, Lout)."""
+    x (N, Hi, Wi, L) channels-last (the weights' Cin channels read, L >= Cin); sw4: deconv_phase_weights(...); the result fills
+    channels [c0, c0 + Cout) of out (N, Hc, Wc, Lout)."""
     x = _f32c(x, "x")
     N, Hi, Wi, L = x.shape
     cin, cout = sw4[0].cin, sw4[0].cout
@@ -772,15 +820,24 @@ def deconv4x4s2_crop(x, sw4, bias, out, c0=0, act=0):
     if not (out.is_contiguous() and out.dtype == torch.float32 and out.dim() == 4) or c0 + cout > out.shape[3] or out.shape[0] != N:
         raise LsfaError("deconv4x4s2_crop: bad out %s for channels [%d, %d)" % (tuple(out.shape), c0, c0 + cout))
     Hc, Wc, Lout = out.shape[1], out.shape[2], out.shape[3]
-    need = lib().lsfa_deconv4x4s2_crop_workspace_bytes(_ci(N), _ci(Hi), _ci(Wi), _ci(cin), _ci(cout), _ci(Hc), _ci(Wc))
-    ws = torch.empty(need, dtype=torch.uint8, device=x.device)
     frags = getattr(sw4, 'frag4', None)
     if frags is None:
         raise LsfaError("deconv4x4s2_crop: the phase weights must come from hip.deconv_phase_weights (one allocation)")
-    _check(lib().lsfa_deconv4x4s2_crop_fwd(_ptr(x), _ci(L), _ci(N), _ci(Hi), _ci(Wi), _ci(cin), _ptr(frags), _ptr(bias), _ci(cout), _ci(act),
-                                           _vp(out.data_ptr() + 4 * c0), _ci(Lout), _ci(Hc), _ci(Wc), _ptr(ws), ctypes.c_size_t(need),
-                                           _stream()), "lsfa_deconv4x4s2_crop_fwd")
+    if amax_in is None and sw4.pieces == 2:
+        amax_in = amax_partial(x)
+    need = lib().lsfa_deconv4x4s2_crop_workspace_bytes(_ci(N), _ci(Hi), _ci(Wi), _ci(cin), _ci(cout), _ci(Hc), _ci(Wc), _ci(sw4.pieces))
+    ws = torch.empty(max(need, 16), dtype=torch.uint8, device=x.device)
+    for s in sw4:
+        _count_conv(N, (Hc + 1) // 2, (Wc + 1) // 2, s.real_cout, s.real_cin, 2, 2, sw4.pieces)
+    _check(lib().lsfa_deconv4x4s2_crop_fwd(_ptr(x), _ci(L), _ci(N), _ci(Hi), _ci(Wi), _ci(cin), _ptr(frags), _ci(sw4.pieces), _ci(sw4.w_exp),
+                                           _ptr(amax_in), _ptr(bias), _ci(cout), _ci(act), _vp(out.data_ptr() + 4 * c0), _ci(Lout), _ci(Hc), _ci(Wc),
+                                           _ptr(amax_out), _ptr(status), _ptr(ws), ctypes.c_size_t(need), _stream()), "lsfa_deconv4x4s2_crop_fwd")
     return out
+
+
+def conv_plan_override(kernel=0, nt=0, st=0, slices=0):
+    """lsfa_conv_plan_override (lab): force the ring kernel (kernel=1), its tile width / ring depth / K slices; zeros = the plan decides"""
+    _check(lib().lsfa_conv_plan_override(_ci(kernel), _ci(nt), _ci(st), _ci(slices)), "lsfa_conv_plan_override")
 
 
 class MotionVectorAccumulator(object):

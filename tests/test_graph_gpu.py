@@ -592,19 +592,28 @@ def test_bench_line_contract():
     assert d["parity"]["handwritten_stage_mismatches_on_gpu_inputs"] == 0
 
 
-def test_fp32_frames_run_without_a_library_convolution(world, monkeypatch):
-    """The fp32 key / non-key graphs reach no MIOpen convolution: FlowNet, the Nq net, the DCN offset branches and the strided
-    shortcuts run on the own split-bf16 convolution (r3).  MIOpen picks its solver from per-user state that concurrently
-    starting processes race for, which made detections depend on the rank layout; what is left on libraries
-    are GEMMs (torch.mm / addmm), whose solution choice is a function of the shape."""
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+def test_frames_run_without_a_library_convolution(world, monkeypatch, dtype):
+    """Neither the fp32 nor the bf16 key / non-key graphs reach a MIOpen convolution: every convolution runs on lsfa_conv_fwd
+    (fp32: two fp16 pieces per operand; bf16: one bf16 piece - r3's bf16 mode fell back to F.conv2d / MIOpen).  MIOpen picks its
+    solver from per-user state that concurrently starting processes race for, which made detections depend on the rank layout
+    (DESIGN.md section 4); what is left on libraries are the RPN / R-FCN score-map GEMMs (torch.mm / addmm), whose solution choice
+    is a function of the shape.  The executors' status words stay clear (no fp16 scale overflowed)."""
     import torch.nn.functional as F
-    cfg, key, cur, clip = world['cfg'], world['key'], world['cur'], world['clip']
+    cfg, clip = world['cfg'], world['clip']
+    if dtype == "f32":
+        key, cur = world['key'], world['cur']
+    else:
+        from lsfa_amd.symbols.resnet_v1_101_flownet_rfcn import resnet_v1_101_flownet_rfcn
+        net = resnet_v1_101_flownet_rfcn(cfg)
+        key = net.get_key_test_symbol(cfg).bind(world['arg'], world['aux'], DEV, torch.bfloat16)
+        cur = net.get_cur_test_symbol(cfg).bind(world['arg'], world['aux'], DEV, torch.bfloat16)
     im_info_t = torch.from_numpy(clip.im_info()).to(DEV)
     f0, f3, f10 = clip.frame(0).to(DEV), clip.frame(3).to(DEV), clip.frame(10).to(DEV)
 
     def forbidden(*a, **k):
         raise AssertionError("a library convolution was called")
-    for name in ("conv2d", "conv_transpose2d", "conv1d", "conv3d"):
+    for name in ("conv2d", "conv_transpose2d", "conv1d", "conv3d", "max_pool2d", "avg_pool2d", "unfold"):
         monkeypatch.setattr(F, name, forbidden)
     out0 = key.forward(data=f0, im_info=im_info_t, data_key_old=f0, feat_key_old=torch.zeros(1, 1024, 1, 1, device=DEV))
     feat0 = out0['choose_feat_output']
@@ -612,3 +621,6 @@ def test_fp32_frames_run_without_a_library_convolution(world, monkeypatch):
     out10 = key.forward(data=f10, im_info=im_info_t, data_key_old=f0, feat_key_old=feat0)
     torch.cuda.synchronize()
     assert out10['rois_output'].shape == (300, 5)
+    assert bool(torch.isfinite(out10['choose_feat_output']).all())
+    key.check_status()
+    cur.check_status()

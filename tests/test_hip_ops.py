@@ -865,12 +865,14 @@ SPLIT_CFGS = [
 ]
 
 
+@pytest.mark.parametrize("pieces", [3, 2, 1])
 @pytest.mark.parametrize("cfg", SPLIT_CFGS)
-def test_conv_split_vs_float64_and_fp32_mfma(hip, cfg):
-    """lsfa_conv_split_fwd: fp32 operands cut exactly into three bf16 pieces, six partial products on the bf16 matrix
-    pipe, fp32 accumulation.  Against a float64 convolution it must be inside the same bound as the fp32-MFMA kernel
-    (2e-6 * sqrt(K) of the output scale) and not worse than 1.5x that kernel's own error; a second launch reproduces
-    the first bit for bit (slices are added in a fixed order)."""
+def test_conv_split_vs_float64_and_fp32_mfma(hip, cfg, pieces):
+    """lsfa_conv_fwd: fp32 operands cut into three bf16 pieces (six partial products), two fp16 pieces (three) or one bf16
+    piece (the bf16 mode) on the matrix pipe, fp32 accumulation.  Against a float64 convolution the fp32 forms must be inside
+    the same bound as the fp32-MFMA kernel (2e-6 * sqrt(K) of the output scale) and not worse than 1.5x that kernel's own
+    error; the bf16 form inside bf16 round-off; a second launch reproduces the first bit for bit (slices are added in a
+    fixed order).  The epilogue's amax_out is the exact maximum of the output and the status word stays clear."""
     import torch.nn.functional as F
     rs = np.random.RandomState(cfg["Cin"] + cfg["H"] + 1)
     N, H, W, Cin, Cout, k, stride, dil = (cfg[x] for x in ("N", "H", "W", "Cin", "Cout", "k", "stride", "dil"))
@@ -883,14 +885,20 @@ def test_conv_split_vs_float64_and_fp32_mfma(hip, cfg):
     want = torch.relu(F.conv2d(torch.from_numpy(x).double(), torch.from_numpy(w).double(), torch.from_numpy(b).double(),
                                stride, pad, dil)).permute(0, 2, 3, 1).numpy()
     xt = t(x).permute(0, 2, 3, 1).contiguous()
-    sw = hip.SplitWeight(t(w))
-    got = hip.conv_split(xt, sw, t(b), stride, pad, dil, relu=True)
+    sw = hip.SplitWeight(t(w), pieces=pieces)
+    slots, status = hip.amax_slots(1, DEV)[0], hip.new_status(DEV)
+    got = hip.conv_split(xt, sw, t(b), stride, pad, dil, relu=True, amax_out=slots, status=status)
     again = hip.conv_split(xt, sw, t(b), stride, pad, dil, relu=True)
     assert torch.equal(got, again)
+    hip.check_status(status)
+    assert slots.view(torch.float32).max().item() == got.abs().max().item()
     g = got.cpu().numpy()
     assert g.shape == want.shape
     scale = max(np.abs(want).max(), 1.0)
     err_split = np.abs(g - want).max()
+    if pieces == 1:
+        assert err_split < 1e-2 * scale, err_split         # one bf16 product per fp32 product: 2^-8 per term
+        return
     assert err_split < 2e-6 * np.sqrt(Cin * k * k) * scale
     ref32 = hip.conv_nhwc(xt, hip.conv_weight_kc(t(w)), t(b), k, k, stride, pad, dil, relu=True).cpu().numpy()
     err_mfma = np.abs(ref32 - want).max()
@@ -899,9 +907,12 @@ def test_conv_split_vs_float64_and_fp32_mfma(hip, cfg):
     assert rms(g) < 1.5 * rms(ref32) + 1e-8 * scale
     # no bias / no ReLU
     want2 = F.conv2d(torch.from_numpy(x).double(), torch.from_numpy(w).double(), None, stride, pad, dil).permute(0, 2, 3, 1).numpy()
-    g2 = hip.conv_split(xt, sw, None, stride, pad, dil, relu=False).cpu().numpy()
+    slots.zero_()
+    g2t = hip.conv_split(xt, sw, None, stride, pad, dil, relu=False, amax_out=slots)
+    g2 = g2t.cpu().numpy()
     assert np.abs(g2 - want2).max() < 2e-6 * np.sqrt(Cin * k * k) * max(np.abs(want2).max(), 1.0)
     assert (g2 < 0).any()
+    assert slots.view(torch.float32).max().item() == g2t.abs().max().item()        # |negative| values count
 
 
 def test_conv_split_cut_is_exact_and_products_are_fp32_grade(hip):
@@ -1113,6 +1124,76 @@ def test_conv_split_h_fp16_two_piece_form_vs_float64(hip, case):
         assert torch.equal(to_nchw(y).cpu(), ref.float())
         return
     assert e3 <= 2e-6 * K ** 0.5 and e3 <= 1.5 * e6 + 1e-7, (case, e3, e6)
+
+
+def test_conv_fp16_form_flags_an_underestimated_scale(hip):
+    """The fp16 two-piece form takes its scale from `amax_in`.  An UNDER-estimate (here the true partial maxima / 8) makes fp16(x s)
+    overflow: the output is non-finite, and instead of handing a silently wrong feature map to the next layer the epilogue raises
+    the status word, which lsfa_status_check turns into an error (LsfaError with lsfa_last_error()); the word is cleared by the
+    check; a correct bound - and an OVER-estimate by 2^10 - leave it clear.  Through the K-sliced path (reduce pass) and the
+    unsliced one, and with a ReLU that would hide a NaN / -inf from a test of the stored values."""
+    g = torch.Generator(device=DEV).manual_seed(3)
+    for (H, W, ci, co, k) in ((38, 63, 256, 128, 3), (12, 20, 64, 64, 1)):
+        x = torch.randn((1, H, W, ci), device=DEV, generator=g) * 5.0
+        w = torch.randn((co, ci, k, k), device=DEV, generator=g) * 0.05
+        sw = hip.SplitWeight(w, pieces=2)
+        status = hip.new_status(DEV)
+        am = hip.amax_partial(x)
+        y = hip.conv_split(x, sw, None, 1, k // 2, 1, relu=True, amax_in=am, status=status)
+        hip.check_status(status)                                     # clear
+        y_over = hip.conv_split(x, sw, None, 1, k // 2, 1, relu=True, amax_in=am * 1024.0, status=status)
+        hip.check_status(status)
+        assert float((y_over - y).abs().max()) <= 2e-6 * (ci * k * k) ** 0.5 * float(y.abs().max())      # 10 octaves of headroom cost nothing
+        hip.conv_split(x, sw, None, 1, k // 2, 1, relu=True, amax_in=am / 8.0, status=status)
+        with pytest.raises(hip.LsfaError, match="non-finite"):
+            hip.check_status(status)
+        hip.check_status(status)                                     # the check cleared the word
+        # a map that already holds inf: flagged as an input problem too
+        x2 = x.clone()
+        x2[0, 1, 2, 3] = float('inf')
+        hip.conv_split(x2, sw, None, 1, k // 2, 1, relu=True, status=status)
+        with pytest.raises(hip.LsfaError):
+            hip.check_status(status)
+
+
+@pytest.mark.parametrize("pieces", [2, 3])
+def test_conv_ring_every_plan_gives_the_same_convolution(hip, pieces):
+    """lsfa_conv_plan_override: the ring kernel under every tile width x ring depth x K cut the plan may choose computes the
+    same convolution (equal to float64 within the fp32 bound; bit-identical between ring depths, which only change how far
+    ahead the copies run), incl. a slice count that leaves the last slice short, residual + second output + amax_out through
+    the reduce pass, and two-level accumulation past 16 chunks."""
+    g = torch.Generator(device=DEV).manual_seed(17 + pieces)
+    H, W, ci, co, k, dil = 23, 31, 256, 128, 3, 2          # 72 chunks of K
+    x = torch.relu(torch.randn((1, H, W, ci), device=DEV, generator=g)) * 2.0
+    w = torch.randn((co, ci, k, k), device=DEV, generator=g) * 0.02
+    b = torch.randn(co, device=DEV, generator=g)
+    res = torch.randn((1, H, W, co), device=DEV, generator=g)
+    sc2, sh2 = torch.rand(co, device=DEV, generator=g) + 0.5, torch.randn(co, device=DEV, generator=g)
+    ref = torch.nn.functional.conv2d(x.permute(0, 3, 1, 2).double().cpu(), w.double().cpu(), b.double().cpu(), padding=dil, dilation=dil)
+    ref = (ref + res.permute(0, 3, 1, 2).double().cpu()).permute(0, 2, 3, 1)
+    sw = hip.SplitWeight(w, pieces=pieces)
+    am = hip.amax_partial(x)
+    tol = 2e-6 * (ci * k * k) ** 0.5 * float(ref.abs().max())
+    try:
+        by_cut = {}
+        for nt in (2, 4):
+            for st in (2, 3, 4):
+                if nt == 4 and pieces == 3 and st == 4:
+                    continue
+                for slices in (1, 2, 5, 7):
+                    hip.conv_plan_override(kernel=1, nt=nt, st=st, slices=slices)
+                    slots = hip.amax_slots(1, DEV)[0]
+                    y, y2 = hip.conv_split(x, sw, b, 1, dil, dil, residual=res, out2=torch.empty_like(res), scale2=sc2, shift2=sh2,
+                                           amax_in=am, amax_out=slots)
+                    assert float((y.double().cpu() - ref).abs().max()) < tol, (nt, st, slices)
+                    assert torch.equal(y2, torch.relu(y * sc2 + sh2))
+                    assert slots.view(torch.float32).max().item() == y2.max().item()
+                    key = (nt, slices)
+                    if key in by_cut:
+                        assert torch.equal(by_cut[key], y), (nt, st, slices)      # the ring depth does not change the arithmetic
+                    by_cut[key] = y
+    finally:
+        hip.conv_plan_override()
 
 
 def test_proposal_and_nms_do_not_depend_on_workspace_contents(hip):

@@ -53,6 +53,5 @@ secs = [
     ('whole non-key frame', lambda: cur.forward(data=data, im_info=im_info, feat_key=feat_old, motion_vector=mv, res_diff=res)),
 ]
 import os
-print('LSFA_CL =', os.environ.get('LSFA_CL', '(default)'))
 for name, fn in secs:
     print('%-46s %8.1f us' % (name, graph_time(fn)), flush=True)

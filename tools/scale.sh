@@ -1,0 +1,34 @@
+#!/bin/bash
+# The 1 -> 8 GPU clip-parallel scaling table DESIGN.md section 7 promises, for a node that has the GPUs (the build container has
+# none and the gpurun boxes one: this has never run on hardware - VERDICT r3).  One process per GPU under torch.distributed.run,
+# RCCL over xGMI for the one collective (the final gather of detection rows); per N it prints the bench line's whole-job frames/s,
+# each rank's own frames/s, how many ranks RCCL saw and what the gather cost.
+#   tools/scale.sh [STEPS] [WARMUP]        ->  gpurun_out/scale_table.txt + gpurun_out/scale_N<k>.json
+set -u
+STEPS=${1:-40}; WARM=${2:-5}
+OUT=gpurun_out; mkdir -p $OUT
+export HSA_ENABLE_IPC_MODE_LEGACY=0
+NGPU=$(python -c 'import torch; print(torch.cuda.device_count())')
+echo "# GPUs visible: $NGPU" | tee $OUT/scale_table.txt
+for N in 1 2 4 8; do
+  if [ "$N" -gt "$NGPU" ]; then echo "N=$N skipped: only $NGPU GPU(s)" | tee -a $OUT/scale_table.txt; continue; fi
+  if [ "$N" -eq 1 ]; then
+    python bench.py --gpus 1 --steps $STEPS --warmup $WARM --no-cpu-baseline --no-parity > $OUT/scale_N$N.json 2> $OUT/scale_N$N.err
+  else
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node $N --master-addr 127.0.0.1 --master-port $((29500 + N)) \
+      bench.py --gpus $N --steps $STEPS --warmup $WARM --no-cpu-baseline --no-parity > $OUT/scale_N$N.json 2> $OUT/scale_N$N.err
+  fi
+  python - $N $OUT/scale_N$N.json <<'PY' | tee -a $OUT/scale_table.txt
+import json, sys
+n, path = int(sys.argv[1]), sys.argv[2]
+try:
+    d = json.loads([l for l in open(path) if l.startswith('{')][-1])
+except Exception as e:
+    print("N=%d failed: %r" % (n, e)); sys.exit(0)
+m = d.get('multi_gpu') or {}
+per = " ".join("%.0f" % r['frames_per_s'] for r in m.get('per_rank', []))
+print("N=%d  whole-job %.1f frames/s  (%.1f per GPU)  rccl_ranks_seen=%s  per-rank frames/s: [%s]  gather %s s for %s rows" % (
+    n, d['value'], d['value'] / n, m.get('rccl_ranks_seen', '-'), per, (m.get('final_gather') or {}).get('seconds', '-'),
+    (m.get('final_gather') or {}).get('rows', '-')))
+PY
+done

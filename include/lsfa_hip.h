@@ -304,7 +304,8 @@ int lsfa_amax_partial(const float* x, long long n, float* out256, void* stream);
  * saying which bit was set.  The frame loop calls it where it synchronises anyway (end of a video, after a benchmark region). */
 #define LSFA_EOVERFLOW (-4)
 int lsfa_status_check(unsigned* status_dev, void* stream);
-/* measurement hook (tools/lab/conv_ring_lab.py): force the kernel (1: never the halo / direct forms), the tile width nt (2 | 4), the
+/* measurement hook (tools/lab/conv_ring_lab.py): force the kernel (1: the ring kernel, mixed-role waves; 2: the ring kernel with
+ * loader / consumer waves; never the halo / direct forms then; 3: the 3x3 halo form wherever its geometry allows), the tile width nt (2 | 4), the
  * ring depth st (2..4) and the number of K slices; 0 = the launch plan decides.  Process-wide; results stay bit-reproducible per setting. */
 int lsfa_conv_plan_override(int kernel, int nt, int st, int slices);
 /* Deconvolution(kernel 4, stride 2) + Crop(offset (1,1)) to Hc x Wc (+ bias + activation) as ONE launch of four 2x2-tap phase

@@ -276,6 +276,7 @@ namespace {
 struct SplitPlan {
   int nt;               // ring kernel: 32-channel column tiles per wave (2: 128 x 64 workgroup tiles, 4: 128 x 128)
   int st;               // ring kernel: stages of the LDS ring
+  bool sp;              // ring kernel: split roles (512-thread workgroups: four loader waves + four consumer waves)
   bool direct;          // conv_split_direct_kernel: operands straight into registers, a wave per 32 x 64 tile, no K slices
   bool halo;            // the 3x3 halo kernel (stride 1, pad = dilation 1 or 2), else the ring kernel
   int dil;
@@ -297,55 +298,49 @@ bool ring_ok(int nt, int pieces, int st) {
   return ring_lds_bytes(nt, pieces, st) <= 160 * 1024 && (st - 2) * (4 + nt * pieces / 2) <= 63;
 }
 
-// Cost model of the ring kernel, microseconds (calibrated on tools/lab/conv_ring_lab.py sweeps, profiles/r4/conv_ring_lab.txt):
-// a workgroup's chunk costs what the slowest of three things costs -
-//   its bytes through the CU's fill path (~55 KB/us per CU, shared by the workgroups resident on it),
-//   its matrix + cut work on the wave's SIMD (2 * nt * products MFMAs of 32 cycles at ~2 GHz, + ~0.1 us of cutting; two resident
-//   workgroups share the SIMDs),
-//   the arrival latency of a chunk (~1 us from L2 / the Infinity Cache) spread over the st - 1 chunks in flight -
-// plus ~3.5 us per launch (dispatch, first arrival, epilogue) and, for K slices, the reduce pass (a launch + the partial sums at ~3 TB/s).
-double ring_cost(long tiles, int chunk_total, double out_mb, int nt, int pieces, int st, int s) {
-  static const int prods[4] = {0, 1, 3, 6};
-  const int per = (chunk_total + s - 1) / s;
-  const int res = 2 * ring_lds_bytes(nt, pieces, st) <= 160 * 1024 ? 2 : 1;
-  const long wgs = tiles * s;
-  const int on_cu = (wgs > 256 && res == 2) ? 2 : 1;
-  const long slots = 256L * res;
-  const long rounds = (wgs + slots - 1) / slots;
-  const double bytes_kb = 16.0 + nt * pieces * 2.0;
-  const double t_fill = bytes_kb / 55.0 * on_cu;
-  const double t_simd = (2.0 * nt * prods[pieces] * 32.0 / 2000.0 + 0.10) * on_cu;
-  const double t_lat = 1.0 / (st - 1) / (on_cu == 2 ? 2.0 : 1.0);
-  const double t_chunk = std::max(t_fill, std::max(t_simd, t_lat));
-  return rounds * (per * t_chunk + 3.5) + (s > 1 ? 3.5 + s * out_mb * 2.0 / 3.0 : 0.0);
-}
-
+// The ring kernel's plan, from the sweeps of tools/lab/conv_ring_lab.py over the network's shapes (profiles/r4/conv_ring_lab.txt: every
+// tile width x ring depth x K cut x wave roles, hipGraph-timed):
+//   * wave roles: loader / consumer waves (512-thread workgroups) win wherever a workgroup has at least four chunks of K to walk
+//     (res4 conv1 21.7 -> 19.9 us, res3 conv2 31.9 -> 26.4, the DCN contraction 59.8 -> 56.2); on the two-chunk launches (res2
+//     conv3: 37,500 pixels, K = 64) the extra waves only add launch weight (38 vs 48 us): mixed-role, two-stage;
+//   * ring depth 3 (two chunks in flight) everywhere else: depth 4 never measured better, depth 2 loses 5-10 % on one-workgroup-per-CU grids;
+//   * 128 x 128 tiles when there are >= 512 output channels and >= 64 chunks of K (the A tile's cut and copies feed twice the MFMAs),
+//     128 x 64 otherwise (more tiles for the small maps of this network);
+//   * K slices: by a small cost model over rounds of resident workgroups (below).
 void ring_plan(SplitPlan& p, long P, int chunk_total, int Cout, int pieces) {
-  const double out_mb = (double)P * Cout * 4.0 / 1e6;
-  const int f_nt = g_force_nt.load(), f_st = g_force_st.load(), f_s = g_force_slices.load();
-  double best = 1e30;
+  const int f_nt = g_force_nt.load(), f_st = g_force_st.load(), f_s = g_force_slices.load(), f_k = g_force_kernel.load();
   p.nx = (int)((P + convsplit::kWgPix - 1) / convsplit::kWgPix);
-  for (int nt = 2; nt <= 4; nt += 2) {
-    if (Cout % (32 * nt)) continue;
-    if (f_nt && nt != f_nt) continue;
-    const long tiles = (long)p.nx * (Cout / (32 * nt));
-    for (int st = 2; st <= 4; ++st) {
-      if (!ring_ok(nt, pieces, st)) continue;
-      if (f_st && st != f_st) continue;
-      for (int s = 1; s <= 16; ++s) {
-        if (f_s && s != f_s) continue;
-        if (!f_s && s > 1 && chunk_total / s < 4) break;
-        const int per = (chunk_total + s - 1) / s;
-        if ((chunk_total + per - 1) / per != s) continue;      // every slice non-empty
-        const double t = ring_cost(tiles, chunk_total, out_mb, nt, pieces, st, s);
-        if (t < best) { best = t; p.nt = nt; p.st = st; p.slices = s; p.per_slice = per; }
-      }
-    }
+  int nt = (Cout % 128 == 0 && Cout >= 512 && chunk_total >= 64) ? 4 : 2;
+  if (f_nt && Cout % (32 * f_nt) == 0) nt = f_nt;
+  const long tiles = (long)p.nx * (Cout / (32 * nt));
+  // K slices: rounds of resident workgroups x chunks per slice (~0.9 us per chunk and workgroup with two chunks in flight: feat_conv_3x3 as
+  // 456 workgroups of 192 chunks = two rounds on 256 one-workgroup CUs = 329 us; as 304 of 288 it is also two rounds: 431 us) + ~3.5 us
+  // per round for dispatch, first arrival and epilogue + the reduce pass (measured 5.5 us + 0.125 us per MB of partial sums:
+  // L2 / Infinity-Cache resident); never fewer than four chunks per slice
+  const double out_mb = (double)P * Cout * 4.0 / 1e6;
+  int s = 1;
+  double best = 1e30;
+  for (int c = 1; c <= 16; ++c) {
+    if (c > 1 && chunk_total / c < 4) break;
+    const int per_c = (chunk_total + c - 1) / c;
+    if ((chunk_total + per_c - 1) / per_c != c) continue;
+    // a CU's chunk rate is shared by the workgroups resident on it (456 workgroups on two slots per CU measured like two rounds:
+    // res4 conv1 cut six ways 22.9 us against 19.9 cut three ways): rounds are counted per CU
+    const long rounds = (tiles * c + 255) / 256;
+    const double t = rounds * (per_c * 0.9 + 3.5) + (c > 1 ? 5.5 + 0.125 * c * out_mb : 0.0);
+    if (t < best * 0.97) { best = t; s = c; }      // a finer cut must pay for itself
   }
-  if (best >= 1e30) {      // an override that fits nothing: the plainest valid form
-    p.nt = 2; p.st = 2; p.slices = 1; p.per_slice = chunk_total;
-  }
-  p.ny = Cout / (32 * p.nt);
+  if (f_s) s = f_s;
+  int per = (chunk_total + s - 1) / s;
+  s = (chunk_total + per - 1) / per;                    // every slice non-empty
+  bool sp = per >= 4;
+  if (f_k == 1) sp = false;
+  if (f_k == 2) sp = true;
+  int st = sp ? 3 : 2;
+  if (f_st) st = f_st;
+  while (st > 2 && !ring_ok(nt, pieces, st)) --st;
+  p.nt = nt; p.st = st; p.slices = s; p.per_slice = per; p.sp = sp;
+  p.ny = Cout / (32 * nt);
 }
 
 SplitPlan split_plan(int N, int H, int W, int Cin, int Cout, int kh, int kw, int stride, int pad, int dil, int pieces) {
@@ -354,7 +349,7 @@ SplitPlan split_plan(int N, int H, int W, int Cin, int Cout, int kh, int kw, int
   const int Ho = (H + 2 * pad - dil * (kh - 1) - 1) / stride + 1, Wo = (W + 2 * pad - dil * (kw - 1) - 1) / stride + 1;
   p.ny = Cout / convsplit::kWgCh;
   p.dil = dil;
-  p.halo = kh == 3 && kw == 3 && stride == 1 && pad == dil && (dil == 1 || dil == 2) && g_force_kernel.load() != 1;
+  p.halo = kh == 3 && kw == 3 && stride == 1 && pad == dil && (dil == 1 || dil == 2) && (g_force_kernel.load() == 0 || g_force_kernel.load() == 3);
   // two 4-wave workgroups per CU is the halo kernel's design point: 512 workgroups fill the chip
   if (p.halo) {
     p.patches_x = (W + convsplit::kPatchCols - 1) / convsplit::kPatchCols;
@@ -369,6 +364,10 @@ SplitPlan split_plan(int N, int H, int W, int Cin, int Cout, int kh, int kw, int
     // measured (r2, tools/lab/conv_split_lab.py): the halo form wins where its patches alone fill the chip (res2 conv2, the 256 -> 1024
     // fuse convolution); where K must be cut anyway the ring kernel's finer cut (it slices taps x chunks) keeps more CUs busy
     if (p.slices > 1) p.halo = false;
+    // r4: with the ring kernel's loader / consumer waves the halo form only keeps the wide-map, narrow-output case (res2 conv2:
+    // 37,500 pixels, 64 -> 64: 30.3 vs 31.1 us); fuse_reduce_add is 58 us on the ring against 77 here (tools/lab/conv_ring_lab.py)
+    if ((long)p.nx * p.ny < 256 || Cout > 128) p.halo = false;
+    if (g_force_kernel.load() == 3) p.halo = true;
     // balanced mode: fewer than 512 tiles but more than 512 (tile, chunk) units -> equal unit counts per workgroup
     // (fuse_reduce_add: 320 tiles x 8 chunks = 512 workgroups x 5 instead of one round of 320 x 8)
     const long tiles = (long)p.nx * p.ny, units = tiles * cpt;
@@ -407,21 +406,22 @@ size_t split_workspace(const SplitPlan& p, long P, int Cout) {
 bool direct_fits(const convsplit::Args& a, long P, int pieces) {
   const size_t wbytes = (size_t)a.kh * a.kw * a.Cin * 2 * pieces;      // per output channel
   return a.nphase <= 1 && a.stride == 1 && wbytes * 64 <= (256u << 10) && P <= 16384 &&
-         (size_t)((P + 31) / 32) * wbytes * a.Cout <= (48u << 20) && g_force_kernel.load() != 1;
+         (size_t)((P + 31) / 32) * wbytes * a.Cout <= (48u << 20) && g_force_kernel.load() == 0;
 }
 
 template <int NT, int PC, int ST>
-void launch_ring(const convsplit::Args& a, dim3 grid, hipStream_t s, int nx, int ny, int nz) {
-  hipLaunchKernelGGL((convsplit::conv_ring_kernel<NT, PC, ST>), grid, dim3(convsplit::kThreads), 0, s, a, nx, ny, nz);
+void launch_ring(bool sp, const convsplit::Args& a, dim3 grid, hipStream_t s, int nx, int ny, int nz) {
+  if (sp) hipLaunchKernelGGL((convsplit::conv_ring_kernel<NT, PC, ST, true>), grid, dim3(2 * convsplit::kThreads), 0, s, a, nx, ny, nz);
+  else hipLaunchKernelGGL((convsplit::conv_ring_kernel<NT, PC, ST, false>), grid, dim3(convsplit::kThreads), 0, s, a, nx, ny, nz);
 }
 template <int PC>
-bool launch_ring_pc(int nt, int st, const convsplit::Args& a, dim3 grid, hipStream_t s, int nx, int ny, int nz) {
-  if (nt == 2 && st == 2) launch_ring<2, PC, 2>(a, grid, s, nx, ny, nz);
-  else if (nt == 2 && st == 3) launch_ring<2, PC, 3>(a, grid, s, nx, ny, nz);
-  else if (nt == 2 && st == 4) launch_ring<2, PC, 4>(a, grid, s, nx, ny, nz);
-  else if (nt == 4 && st == 2) launch_ring<4, PC, 2>(a, grid, s, nx, ny, nz);
-  else if (nt == 4 && st == 3) launch_ring<4, PC, 3>(a, grid, s, nx, ny, nz);
-  else if (nt == 4 && st == 4 && PC < 3) launch_ring<4, (PC < 3 ? PC : 2), 4>(a, grid, s, nx, ny, nz);
+bool launch_ring_pc(int nt, int st, bool sp, const convsplit::Args& a, dim3 grid, hipStream_t s, int nx, int ny, int nz) {
+  if (nt == 2 && st == 2) launch_ring<2, PC, 2>(sp, a, grid, s, nx, ny, nz);
+  else if (nt == 2 && st == 3) launch_ring<2, PC, 3>(sp, a, grid, s, nx, ny, nz);
+  else if (nt == 2 && st == 4) launch_ring<2, PC, 4>(sp, a, grid, s, nx, ny, nz);
+  else if (nt == 4 && st == 2) launch_ring<4, PC, 2>(sp, a, grid, s, nx, ny, nz);
+  else if (nt == 4 && st == 3) launch_ring<4, PC, 3>(sp, a, grid, s, nx, ny, nz);
+  else if (nt == 4 && st == 4 && PC < 3) launch_ring<4, (PC < 3 ? PC : 2), 4>(sp, a, grid, s, nx, ny, nz);
   else return false;
   return true;
 }
@@ -477,6 +477,7 @@ int conv_split_launch(convsplit::Args a, int pieces, void* ws, size_t ws_bytes, 
   LSFA_REQUIRE(((uintptr_t)a.x & 15) == 0, "%s: x must be 16-byte aligned", who);
   if (!a.view) { a.out_H = a.Ho; a.out_W = a.Wo; a.out_sy = a.out_sx = 1; }
   const long P = (long)N * a.Ho * a.Wo;
+  LSFA_REQUIRE(P + 256 < (1L << 24), "%s: more than 2^24 output pixels", who);      // fdiv's range (conv_split_kernel.h)
   LSFA_REQUIRE(((long)N * a.out_H * a.out_W + 1) * (long)(a.y_nchw ? Cout : a.ldy) < (1L << 31) && P * Cout < (1L << 31) &&
                ((long)N * H * W + (long)(a.pad_h + 1) * (W + 1)) * a.lda < (1L << 31), "%s: tensor too large", who);
   SplitPlan p = view_plan(N, H, W, Cin, Cout, kh, kw, stride, a.pad_h, a.pad_w, dil, a.lda, a.Ho, a.Wo, pieces);
@@ -499,6 +500,12 @@ int conv_split_launch(convsplit::Args a, int pieces, void* ws, size_t ws_bytes, 
   a.part_stride = P * Cout;
   a.chunks_per_slice = p.per_slice;
   a.units_per_wg = a.max_pieces = 0;
+  a.inv_wo = 1.0f / (float)a.Wo;
+  a.inv_howo = 1.0f / (float)(a.Ho * a.Wo);
+  a.inv_nx = 1.0f / (float)(p.nx > 0 ? p.nx : 1);
+  a.inv_ny = 1.0f / (float)(p.ny > 0 ? p.ny : 1);
+  a.inv_cpt = 1.0f / (float)(Cin / 32);
+  a.inv_kw = 1.0f / (float)kw;
   ProfScope prof(prof_op, s);
   int tiles = p.nx * p.ny * p.slices * nph;
   if (p.units_per_wg > 0) {
@@ -513,9 +520,9 @@ int conv_split_launch(convsplit::Args a, int pieces, void* ws, size_t ws_bytes, 
     else if (pieces == 2) launch_halo_direct<2>(p, a, grid, s, P);
     else launch_halo_direct<1>(p, a, grid, s, P);
   } else {
-    const bool ok = pieces == 3 ? launch_ring_pc<3>(p.nt, p.st, a, grid, s, p.nx, p.ny, p.slices * nph)
-                  : pieces == 2 ? launch_ring_pc<2>(p.nt, p.st, a, grid, s, p.nx, p.ny, p.slices * nph)
-                                : launch_ring_pc<1>(p.nt, p.st, a, grid, s, p.nx, p.ny, p.slices * nph);
+    const bool ok = pieces == 3 ? launch_ring_pc<3>(p.nt, p.st, p.sp, a, grid, s, p.nx, p.ny, p.slices * nph)
+                  : pieces == 2 ? launch_ring_pc<2>(p.nt, p.st, p.sp, a, grid, s, p.nx, p.ny, p.slices * nph)
+                                : launch_ring_pc<1>(p.nt, p.st, p.sp, a, grid, s, p.nx, p.ny, p.slices * nph);
     LSFA_REQUIRE(ok, "%s: no ring kernel for nt=%d st=%d pieces=%d", who, p.nt, p.st, pieces);
   }
   if (p.units_per_wg > 0) {
@@ -548,8 +555,8 @@ convsplit::Args args_of(const lsfa_conv_desc& d) {
 }  // namespace
 
 extern "C" int lsfa_conv_plan_override(int kernel, int nt, int st, int slices) {
-  LSFA_REQUIRE(kernel >= 0 && kernel <= 1 && (nt == 0 || nt == 2 || nt == 4) && (st == 0 || (st >= 2 && st <= 4)) && slices >= 0 && slices <= 16,
-               "lsfa_conv_plan_override: kernel 0/1, nt 0/2/4, st 0/2..4, slices 0..16");
+  LSFA_REQUIRE(kernel >= 0 && kernel <= 3 && (nt == 0 || nt == 2 || nt == 4) && (st == 0 || (st >= 2 && st <= 4)) && slices >= 0 && slices <= 16,
+               "lsfa_conv_plan_override: kernel 0..3, nt 0/2/4, st 0/2..4, slices 0..16");
   g_force_kernel.store(kernel); g_force_nt.store(nt); g_force_st.store(st); g_force_slices.store(slices);
   return LSFA_OK;
 }

@@ -24,14 +24,14 @@
 // 1152 rounding steps per K slice), where a CPU library's blocked loops run ~100 short chains and add them at the end.  Measured
 // against the float64 graph that made the GPU path 2.2x as far off as the fp32 oracle (tests/test_parity_fullres_gpu.py, r4).
 // Every kFlush chunks the accumulators are therefore added into a second set and cleared: chains of <= kFlush x 2 x PC adds, then
-// <= ceil(chunks / kFlush) adds of the block sums - the error of a blocked summation, for 16 x NT vector adds per kFlush chunks.
+// <= ceil(chunks / kFlush) adds of the block sums - the error of a blocked summation, for 16 x NT vector adds per kFlush (= 12) chunks.
 #pragma once
 #include "conv_split_kernel.h"
 
 namespace lsfa {
 namespace convsplit {
 
-constexpr int kFlush = 16;
+constexpr int kFlush = 12;        // a multiple of every ring depth: the flush points do not depend on ST
 
 template <int NT, int PC, int ST> struct Ring {
   static constexpr int kColTile = 128 * PC;                 // uint4 of one 32-column tile of one chunk: 2 steps x PC pieces x 64 lanes
@@ -112,6 +112,44 @@ __device__ __forceinline__ void ring_step(uint4 (*R)[(Ring<NT, PC, ST>::kStageN)
   if (more) wk.next(g.kw, g.chunks_per_tap);
 }
 
+// ---- split roles (SP): waves 4-7 of a 512-thread workgroup issue the copies, waves 0-3 cut and multiply ------------------------------
+// Measured (rocprofv3 kernel trace, r4): a chunk costs a mixed-role wave ~1.3 us whatever the ring depth - its 6-8 LDS-DMA
+// instructions (~100 cycles of issue each), ~100 VALU instructions of cutting, 16 LDS reads and 12-24 MFMAs are ONE in-order
+// instruction stream, and the matrix pipe idles while the wave sits in a DMA issue.  With the copies issued by a partner wave on
+// the same SIMD the consumer's stream is LDS reads + cut + MFMAs only and the two streams overlap.  Same LDS image, same barrier
+// per chunk (all eight waves), same arithmetic: bit-identical results to the mixed-role form.
+template <int NT, int PC, int ST, int S>
+__device__ __forceinline__ void ring_load_step(uint4 (*R)[(Ring<NT, PC, ST>::kStageN)], const float* __restrict__ x, const uint4* __restrict__ wblock,
+                                               const Geom& g, Walk& wk, int c, int n) {
+  typedef Ring<NT, PC, ST> RG;
+  constexpr int SN = (S + ST - 1) % ST;
+  const int ahead = min(n - 1 - c, ST - 2);
+  if (ST >= 4 && ahead >= 2) wait_vmcnt<(ST >= 4 ? 2 : 0) * RG::kDma>();
+  else if (ST >= 3 && ahead == 1) wait_vmcnt<(ST >= 3 ? 1 : 0) * RG::kDma>();
+  else wait_vmcnt<0>();
+  __builtin_amdgcn_s_barrier();
+  if (c + ST - 1 < n) {
+    ring_issue_a<NT, PC, ST, SN>(R, x, g, wk);
+    ring_issue_b<NT, PC, ST, SN, 0, RG::kDmaB>(R, wblock, g, wk.gch);
+    wk.next(g.kw, g.chunks_per_tap);
+  }
+}
+
+template <int NT, int PC, int ST, int S>
+__device__ __forceinline__ void ring_consume_step(uint4 (*R)[(Ring<NT, PC, ST>::kStageN)], const Geom& g, f32x16 (&acc)[NT], float a_scale) {
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  const uint4* A = &R[S][g.wave * 256];
+  const uint4* B = &R[S][kStageA + g.lane];
+  const uint4 r0 = A[g.frag[0]], r1 = A[g.frag[1]], r2 = A[g.frag[2]], r3 = A[g.frag[3]];
+  const PiecesN s0 = cut8<PC>(as_f4(r0), as_f4(r1), a_scale), s1 = cut8<PC>(as_f4(r2), as_f4(r3), a_scale);
+#pragma unroll
+  for (int t = 0; t < NT; ++t) {
+    acc[t] = mma_pc<PC>(s0, B + ((t * 2 + 0) * PC) * 64, acc[t]);
+    acc[t] = mma_pc<PC>(s1, B + ((t * 2 + 1) * PC) * 64, acc[t]);
+  }
+}
+
 template <int NT, int PC, int ST, int S>
 __device__ __forceinline__ void ring_prologue(uint4 (*R)[(Ring<NT, PC, ST>::kStageN)], const float* __restrict__ x, const uint4* __restrict__ wblock,
                                               const Geom& g, Walk& wk, int n) {
@@ -122,12 +160,12 @@ __device__ __forceinline__ void ring_prologue(uint4 (*R)[(Ring<NT, PC, ST>::kSta
   }
 }
 
-// grid (8 * ceil(tiles / 8)); block 256.  tiles = ceil(P / 128) * (Cout / (32 * NT)) * slices (* phases)
-template <int NT, int PC, int ST>
-static __global__ __launch_bounds__(kThreads, (Ring<NT, PC, ST>::kWgPerCu)) void conv_ring_kernel(Args a, int nx, int ny, int nz) {
+// grid (8 * ceil(tiles / 8)); block 256 (SP: 512).  tiles = ceil(P / 128) * (Cout / (32 * NT)) * slices (* phases)
+template <int NT, int PC, int ST, bool SP = false>
+static __global__ __launch_bounds__((SP ? 2 : 1) * kThreads, (Ring<NT, PC, ST>::kWgPerCu) * (SP ? 2 : 1)) void conv_ring_kernel(Args a, int nx, int ny, int nz) {
   typedef Ring<NT, PC, ST> RG;
   __shared__ __attribute__((aligned(16))) uint4 R[ST][RG::kStageN];
-  Tile tile = xcd_tile(blockIdx.x, nx, ny, nz, a.tile_order);
+  Tile tile = xcd_tile(blockIdx.x, nx, ny, nz, a.tile_order, a.inv_nx, a.inv_ny);
   if (tile.x < 0) return;
   if (a.nphase > 1) { const int slices = nz / a.nphase, phase = tile.z / slices; tile.z -= phase * slices; apply_phase(a, phase, slices); }
   const int tid = threadIdx.x;
@@ -136,10 +174,12 @@ static __global__ __launch_bounds__(kThreads, (Ring<NT, PC, ST>::kWgPerCu)) void
   const int taps = a.kh * a.kw;
   Geom g;
   g.lane = tid & 63;
-  g.wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wave8 = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const bool loader = SP && wave8 >= 4;                 // wave-uniform role
+  g.wave = wave8 & 3;                                    // the consumer wave whose rows / share of B this wave reads or copies
   // fp16 form: the scale that puts max|x| into [2^13, 2^14), and its inverse together with the weights' (both powers of two: exact)
   float a_scale = 1.f, out_scale = 1.f;
-  if (PC == 2) {
+  if (PC == 2 && !loader) {
     const int s_exp = 13 - amax_exponent_asm(a.amax, g.lane, a.status);
     a_scale = ldexpf(1.f, s_exp);
     out_scale = ldexpf(1.f, -(s_exp + a.w_exp));
@@ -154,6 +194,7 @@ static __global__ __launch_bounds__(kThreads, (Ring<NT, PC, ST>::kWgPerCu)) void
   const uint4* wblock = a.wfrag + (size_t)(NT * tile.y) * RG::kColTile;
   const int m0 = tile.x * kWgPix + g.wave * kWavePix;
   // DMA role: instruction i moves pixels 8i .. 8i+7 of the wave's tile, lane -> pixel 8i + (lane >> 3), slot lane & 7
+  if (!SP || loader) {
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     const int pix = m0 + 8 * i + (g.lane >> 3);
@@ -161,11 +202,12 @@ static __global__ __launch_bounds__(kThreads, (Ring<NT, PC, ST>::kWgPerCu)) void
     g.iy0[i] = g.ix0[i] = -(1 << 24);
     g.off0[i] = 0;
     if (pix < P) {
-      const int pn = pix / (a.Ho * a.Wo), r = pix - pn * a.Ho * a.Wo, py = r / a.Wo, px = r - py * a.Wo;
+      const int pn = fdiv(pix, a.Ho * a.Wo, a.inv_howo), r = pix - pn * a.Ho * a.Wo, py = fdiv(r, a.Wo, a.inv_wo), px = r - py * a.Wo;
       g.iy0[i] = py * a.stride - a.pad_h;
       g.ix0[i] = px * a.stride - a.pad_w;
       g.off0[i] = ((pn * a.H + g.iy0[i]) * a.W + g.ix0[i]) * a.lda + 4 * piece;     // may be negative; only used in bounds
     }
+  }
   }
   {
     const int r = g.lane & 31, h = g.lane >> 5, sw = (r >> 1) & 7;
@@ -181,33 +223,64 @@ static __global__ __launch_bounds__(kThreads, (Ring<NT, PC, ST>::kWgPerCu)) void
   Walk wk;       // the next chunk to fetch
   wk.gch = g.chunk0;
   {
-    const int tap = g.chunk0 / g.chunks_per_tap;
+    const int tap = fdiv(g.chunk0, g.chunks_per_tap, a.inv_cpt);
     wk.kc = g.chunk0 - tap * g.chunks_per_tap;
-    wk.ty = tap / a.kw;
+    wk.ty = fdiv(tap, a.kw, a.inv_kw);
     wk.tx = tap - wk.ty * a.kw;
   }
-  // prologue: chunks 0 .. ST-2 into stages 0 .. ST-2
-  ring_prologue<NT, PC, ST, 0>(R, a.x, wblock, g, wk, nchunks);
-  if (ST > 2) ring_prologue<NT, PC, ST, (ST > 2 ? 1 : 0)>(R, a.x, wblock, g, wk, nchunks);
-  if (ST > 3) ring_prologue<NT, PC, ST, (ST > 3 ? 2 : 0)>(R, a.x, wblock, g, wk, nchunks);
   f32x16 sum[NT];        // block sums (second level)
 #pragma unroll
   for (int t = 0; t < NT; ++t)
 #pragma unroll
     for (int i = 0; i < 16; ++i) sum[t][i] = 0.f;
-  int since = 0;
-  for (int c = 0; c < nchunks; c += ST) {
-    ring_step<NT, PC, ST, 0>(R, a.x, wblock, g, wk, c, nchunks, acc, a_scale);
-    if (c + 1 < nchunks) ring_step<NT, PC, ST, 1>(R, a.x, wblock, g, wk, c + 1, nchunks, acc, a_scale);
-    if (ST > 2 && c + 2 < nchunks) ring_step<NT, PC, ST, (ST > 2 ? 2 : 0)>(R, a.x, wblock, g, wk, c + 2, nchunks, acc, a_scale);
-    if (ST > 3 && c + 3 < nchunks) ring_step<NT, PC, ST, (ST > 3 ? 3 : 0)>(R, a.x, wblock, g, wk, c + 3, nchunks, acc, a_scale);
-    since += ST;
-    if (since >= kFlush) {
-      since = 0;
+  if (SP) {
+    if (loader) {
+      // prologue: chunks 0 .. ST-2 into stages 0 .. ST-2, then one step per chunk: wait for chunk c, meet, refill the stage chunk c - 1 left
+      ring_prologue<NT, PC, ST, 0>(R, a.x, wblock, g, wk, nchunks);
+      if (ST > 2) ring_prologue<NT, PC, ST, (ST > 2 ? 1 : 0)>(R, a.x, wblock, g, wk, nchunks);
+      if (ST > 3) ring_prologue<NT, PC, ST, (ST > 3 ? 2 : 0)>(R, a.x, wblock, g, wk, nchunks);
+      for (int c = 0; c < nchunks; c += ST) {
+        ring_load_step<NT, PC, ST, 0>(R, a.x, wblock, g, wk, c, nchunks);
+        if (c + 1 < nchunks) ring_load_step<NT, PC, ST, 1>(R, a.x, wblock, g, wk, c + 1, nchunks);
+        if (ST > 2 && c + 2 < nchunks) ring_load_step<NT, PC, ST, (ST > 2 ? 2 : 0)>(R, a.x, wblock, g, wk, c + 2, nchunks);
+        if (ST > 3 && c + 3 < nchunks) ring_load_step<NT, PC, ST, (ST > 3 ? 3 : 0)>(R, a.x, wblock, g, wk, c + 3, nchunks);
+      }
+      return;                 // the epilogue is the consumers'
+    }
+    int since = 0;
+    for (int c = 0; c < nchunks; c += ST) {
+      ring_consume_step<NT, PC, ST, 0>(R, g, acc, a_scale);
+      if (c + 1 < nchunks) ring_consume_step<NT, PC, ST, 1>(R, g, acc, a_scale);
+      if (ST > 2 && c + 2 < nchunks) ring_consume_step<NT, PC, ST, (ST > 2 ? 2 : 0)>(R, g, acc, a_scale);
+      if (ST > 3 && c + 3 < nchunks) ring_consume_step<NT, PC, ST, (ST > 3 ? 3 : 0)>(R, g, acc, a_scale);
+      since += ST;
+      if (since >= kFlush) {
+        since = 0;
 #pragma unroll
-      for (int t = 0; t < NT; ++t)
+        for (int t = 0; t < NT; ++t)
 #pragma unroll
-        for (int i = 0; i < 16; ++i) { sum[t][i] = sum[t][i] + acc[t][i]; acc[t][i] = 0.f; }
+          for (int i = 0; i < 16; ++i) { sum[t][i] = sum[t][i] + acc[t][i]; acc[t][i] = 0.f; }
+      }
+    }
+  } else {
+    // prologue: chunks 0 .. ST-2 into stages 0 .. ST-2
+    ring_prologue<NT, PC, ST, 0>(R, a.x, wblock, g, wk, nchunks);
+    if (ST > 2) ring_prologue<NT, PC, ST, (ST > 2 ? 1 : 0)>(R, a.x, wblock, g, wk, nchunks);
+    if (ST > 3) ring_prologue<NT, PC, ST, (ST > 3 ? 2 : 0)>(R, a.x, wblock, g, wk, nchunks);
+    int since = 0;
+    for (int c = 0; c < nchunks; c += ST) {
+      ring_step<NT, PC, ST, 0>(R, a.x, wblock, g, wk, c, nchunks, acc, a_scale);
+      if (c + 1 < nchunks) ring_step<NT, PC, ST, 1>(R, a.x, wblock, g, wk, c + 1, nchunks, acc, a_scale);
+      if (ST > 2 && c + 2 < nchunks) ring_step<NT, PC, ST, (ST > 2 ? 2 : 0)>(R, a.x, wblock, g, wk, c + 2, nchunks, acc, a_scale);
+      if (ST > 3 && c + 3 < nchunks) ring_step<NT, PC, ST, (ST > 3 ? 3 : 0)>(R, a.x, wblock, g, wk, c + 3, nchunks, acc, a_scale);
+      since += ST;
+      if (since >= kFlush) {
+        since = 0;
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+          for (int i = 0; i < 16; ++i) { sum[t][i] = sum[t][i] + acc[t][i]; acc[t][i] = 0.f; }
+      }
     }
   }
 #pragma unroll
@@ -217,6 +290,65 @@ static __global__ __launch_bounds__(kThreads, (Ring<NT, PC, ST>::kWgPerCu)) void
 
   // C/D layout of 32x32: column = lane & 31 (channel), row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5) (pixel)
   const int lane = g.lane;
+  // Channels-last outputs leave through LDS: in the accumulator layout a lane holds ONE channel of 16 pixels, i.e. 4-byte accesses
+  // (16 per tile and output, plus 16 residual loads: the epilogue of a conv3 - residual, sum, next bn1 / relu1 - was 7 of its 27 us).
+  // The ring is free once every wave is past its last chunk: each wave writes its NT 32 x 32 tiles row-major into a private 4 KB x NT
+  // region and reads them back as float4 along the channels - lane -> (row 8k + lane / 8, channels 4 (lane % 8) ..): whole 128-byte
+  // rows per 8 lanes, 16 bytes per lane, a quarter of the memory instructions.  Same values, same arithmetic per element.
+  constexpr bool kRowsFit = RG::kLdsBytes >= 4 * NT * 4096;       // the ring holds the four waves' tiles
+  const bool rows_ok = kRowsFit && (a.part || (!a.y_nchw && (a.ldy & 3) == 0 && ((uintptr_t)a.y & 15) == 0 && (!a.y2 || ((uintptr_t)a.y2 & 15) == 0) &&
+                                  (!a.res || ((uintptr_t)a.res & 15) == 0)));
+  if (rows_ok) {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();                       // every wave is done reading the ring (SP: the loaders have left)
+    float* T = reinterpret_cast<float*>(&R[0][0]) + g.wave * (NT * 1024);
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) T[t * 1024 + ((r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)) * 32 + (lane & 31)] = acc[t][r];
+    const int c4 = (lane & 7) * 4;
+    float* part = a.part ? a.part + (size_t)tile.z * P * a.Cout : nullptr;
+    // the maximum as a float maximum of |.| (one instruction per value; a NaN drops out of it) and, beside it, the SUM of the
+    // pre-activation magnitudes, which is non-finite exactly when one of them is (ReLU would hide a NaN or a -inf): one add per value
+    float mx = 0.f, nf = 0.f;
+    const int act = a.act;                         // wave-uniform: the branches below are scalar
+    const bool has_y2 = a.y2 != nullptr, has_res = a.res != nullptr, has_bias = a.bias != nullptr;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int row = 8 * k + (lane >> 3);
+      const int p = m0 + row;
+      const bool ok = p < P;
+      const int base = (ok && !part) ? out_pixel_base(a, p) : 0;
+#pragma unroll
+      for (int t = 0; t < NT; ++t) {
+        const int ch = tile.y * (32 * NT) + t * 32 + c4;
+        const float4 v = *reinterpret_cast<const float4*>(&T[t * 1024 + row * 32 + c4]);
+        if (!ok) continue;
+        if (part) { *reinterpret_cast<float4*>(part + (size_t)p * a.Cout + ch) = v; continue; }
+        float4 o = v;
+        if (has_bias) { const float4 b = *reinterpret_cast<const float4*>(a.bias + ch); o.x = o.x + b.x; o.y = o.y + b.y; o.z = o.z + b.z; o.w = o.w + b.w; }
+        if (has_res) { const float4 rr = *reinterpret_cast<const float4*>(a.res + base + ch); o.x = o.x + rr.x; o.y = o.y + rr.y; o.z = o.z + rr.z; o.w = o.w + rr.w; }
+        nf = nf + fabsf(o.x); nf = nf + fabsf(o.y); nf = nf + fabsf(o.z); nf = nf + fabsf(o.w);
+        if (act == 1) { o.x = fmaxf(o.x, 0.f); o.y = fmaxf(o.y, 0.f); o.z = fmaxf(o.z, 0.f); o.w = fmaxf(o.w, 0.f); }
+        else if (act == 2) { o.x = activate(o.x, 2); o.y = activate(o.y, 2); o.z = activate(o.z, 2); o.w = activate(o.w, 2); }
+        *reinterpret_cast<float4*>(a.y + base + ch) = o;
+        if (has_y2) {
+          const float4 s2 = *reinterpret_cast<const float4*>(a.scale2 + ch), h2 = *reinterpret_cast<const float4*>(a.shift2 + ch);
+          float4 w;
+          w.x = fmaxf(o.x * s2.x + h2.x, 0.f); w.y = fmaxf(o.y * s2.y + h2.y, 0.f);
+          w.z = fmaxf(o.z * s2.z + h2.z, 0.f); w.w = fmaxf(o.w * s2.w + h2.w, 0.f);
+          *reinterpret_cast<float4*>(a.y2 + base + ch) = w;
+          mx = fmaxf(fmaxf(mx, fmaxf(w.x, w.y)), fmaxf(w.z, w.w));
+        } else {
+          mx = fmaxf(fmaxf(mx, fmaxf(fabsf(o.x), fabsf(o.y))), fmaxf(fabsf(o.z), fabsf(o.w)));
+        }
+      }
+    }
+    uint32_t m = __float_as_uint(mx);
+    if ((__float_as_uint(nf) & 0x7F800000u) == 0x7F800000u) m = 0x7FC00000u;       // a non-finite value went through this lane
+    if (!part) publish_amax(m, a.amax_out, a.status, blockIdx.x * 4 + g.wave);
+    return;
+  }
   int prow[16];
   RowOut ro;
   ro.valid = 0;
@@ -224,12 +356,6 @@ static __global__ __launch_bounds__(kThreads, (Ring<NT, PC, ST>::kWgPerCu)) void
   for (int r = 0; r < 16; ++r) {
     prow[r] = m0 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
     if (prow[r] < P) ro.valid |= 1u << r;
-  }
-  if (a.part) {
-    float* part = a.part + (size_t)tile.z * P * a.Cout;
-#pragma unroll
-    for (int t = 0; t < NT; ++t) tile_store_part(part, a.Cout, prow, ro.valid, tile.y * (32 * NT) + t * 32 + (lane & 31), acc[t]);
-    return;
   }
 #pragma unroll
   for (int r = 0; r < 16; ++r) ro.base[r] = ((ro.valid >> r) & 1u) ? out_pixel_base(a, prow[r]) : 0;

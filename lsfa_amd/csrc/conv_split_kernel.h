@@ -76,8 +76,20 @@ struct Args {
   // amax_out[kAmaxSlots] by atomicMax on the bit patterns (the caller zeroes the slots once per frame), so that the layer that
   // multiplies this output next needs no amax pass; a non-finite output raises bit 0 of *status (lsfa_status_check)
   unsigned* amax_out; unsigned* status;
+  // r4: reciprocals of the divisors the kernels' index arithmetic uses (filled by the host; fdiv below): an integer division costs
+  // ~35 dependent VALU instructions, and a short launch spent more time in its prologue's divisions than in its matrix instructions
+  float inv_wo, inv_howo, inv_nx, inv_ny, inv_cpt, inv_kw;      // 1 / Wo, 1 / (Ho Wo), 1 / nx, 1 / ny, 1 / (Cin / 32), 1 / kw
   int tile_order;   // 0: tiles numbered (slice, channel tile, pixel tile), pixel fastest; 1: (slice, pixel tile, channel tile), channel fastest
 };
+
+// n / d for 0 <= n < 2^24, 0 < d, with inv = 1.0f / d from the host: the float product is off by at most one, the remainder fixes it
+__device__ __forceinline__ int fdiv(int n, int d, float inv) {
+  int q = (int)((float)n * inv);
+  const int r = n - q * d;
+  q += (r >= d) ? 1 : 0;
+  q -= (r < 0) ? 1 : 0;
+  return q;
+}
 
 // the launch as phase `phase` sees it
 __device__ __forceinline__ void apply_phase(Args& a, int phase, int slices) {
@@ -87,6 +99,7 @@ __device__ __forceinline__ void apply_phase(Args& a, int phase, int slices) {
     a.y += ((size_t)py * a.out_W + px) * a.ldy;
     a.pad_h = 1 - py; a.pad_w = 1 - px;
     a.Ho = (a.out_H - py + 1) / 2; a.Wo = (a.out_W - px + 1) / 2;
+    a.inv_wo = 1.0f / (float)a.Wo; a.inv_howo = 1.0f / (float)(a.Ho * a.Wo);
     if (a.part) a.part += (size_t)phase * slices * a.part_stride;
   }
 }
@@ -149,22 +162,30 @@ constexpr int kAmaxSlots = 256;
 
 struct PiecesH { uint4 hi, lo; };
 
-__device__ __forceinline__ void cut2h(float v, float s, uint32_t& h, uint32_t& l) {
-  const float xs = v * s;                         // exact: s is a power of two
-  const _Float16 hh = (_Float16)xs;               // round to nearest even
-  const float r = xs - (float)hh;                 // exact
-  const _Float16 ll = (_Float16)r;
-  h = (uint32_t)__builtin_bit_cast(unsigned short, hh);
-  l = (uint32_t)__builtin_bit_cast(unsigned short, ll);
+// two values at a time: gfx950's v_cvt_pk_f16_f32 rounds (to nearest even) and packs both in one instruction; the way back is
+// one v_cvt_f32_f16 per half.  8 VALU instructions per pair where the scalar conversions + shifts + ors took 12.
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ void cut2h_pair(float v0, float v1, float s, uint32_t& h, uint32_t& l) {
+  f32x2 xs;
+  xs[0] = v0 * s;                                 // exact: s is a power of two
+  xs[1] = v1 * s;
+  const f16x2 hh = __builtin_convertvector(xs, f16x2);
+  f32x2 r;
+  r[0] = xs[0] - (float)hh[0];                    // exact (scalar subtractions: no packed fp32 math)
+  r[1] = xs[1] - (float)hh[1];
+  const f16x2 ll = __builtin_convertvector(r, f16x2);
+  h = __builtin_bit_cast(uint32_t, hh);
+  l = __builtin_bit_cast(uint32_t, ll);
 }
 
 __device__ __forceinline__ PiecesH split8h(const float4& a, const float4& b, float s) {
-  uint32_t h[8], l[8];
-  cut2h(a.x, s, h[0], l[0]); cut2h(a.y, s, h[1], l[1]); cut2h(a.z, s, h[2], l[2]); cut2h(a.w, s, h[3], l[3]);
-  cut2h(b.x, s, h[4], l[4]); cut2h(b.y, s, h[5], l[5]); cut2h(b.z, s, h[6], l[6]); cut2h(b.w, s, h[7], l[7]);
   PiecesH r;
-  r.hi = make_uint4(h[0] | (h[1] << 16), h[2] | (h[3] << 16), h[4] | (h[5] << 16), h[6] | (h[7] << 16));
-  r.lo = make_uint4(l[0] | (l[1] << 16), l[2] | (l[3] << 16), l[4] | (l[5] << 16), l[6] | (l[7] << 16));
+  cut2h_pair(a.x, a.y, s, r.hi.x, r.lo.x);
+  cut2h_pair(a.z, a.w, s, r.hi.y, r.lo.y);
+  cut2h_pair(b.x, b.y, s, r.hi.z, r.lo.z);
+  cut2h_pair(b.z, b.w, s, r.hi.w, r.lo.w);
   return r;
 }
 
@@ -198,9 +219,9 @@ __device__ __forceinline__ int amax_exponent(const float* __restrict__ amax, int
 struct RowOut { int base[16]; unsigned valid; };
 
 __device__ __forceinline__ int out_pixel_base(const Args& a, int p) {
-  if (a.y_nchw) { const int hw = a.Ho * a.Wo, pn = p / hw; return pn * a.Cout * hw + (p - pn * hw); }
+  if (a.y_nchw) { const int hw = a.Ho * a.Wo, pn = fdiv(p, hw, a.inv_howo); return pn * a.Cout * hw + (p - pn * hw); }
   if (a.view) {
-    const int hw = a.Ho * a.Wo, pn = p / hw, r = p - pn * hw, oy = r / a.Wo, ox = r - oy * a.Wo;
+    const int hw = a.Ho * a.Wo, pn = fdiv(p, hw, a.inv_howo), r = p - pn * hw, oy = fdiv(r, a.Wo, a.inv_wo), ox = r - oy * a.Wo;
     return ((pn * a.out_H + oy * a.out_sy) * a.out_W + ox * a.out_sx) * a.ldy;
   }
   return p * a.ldy;
@@ -514,28 +535,29 @@ struct Walk {
 // all weights AND all activations through its L2 (6 MB for a res4 conv2: it does not fit, and the misses go to the
 // Infinity Cache).
 struct Tile { int x, y, z; };
-__device__ __forceinline__ Tile xcd_tile(int id, int nx, int ny, int nz, int order = 0) {
+__device__ __forceinline__ Tile xcd_tile(int id, int nx, int ny, int nz, int order = 0, float inv_nx = 0.f, float inv_ny = 0.f) {
   const int total = nx * ny * nz;
-  const int per = (total + 7) / 8;
+  const int per = (total + 7) >> 3;
   const int t = (id & 7) * per + (id >> 3);
   Tile r;
   if (t >= total) { r.x = r.y = r.z = -1; return r; }      // the grid is 8 * per >= total: the surplus ids have no tile
+  const bool fast = inv_nx > 0.f && inv_ny > 0.f && total < (1 << 24);
   if (order == 1) {      // channel tile fastest: the workgroups of one XCD are ALL channel tiles of an eighth of the (slice, pixel tile) list
-    r.y = t % ny;
-    const int q = t / ny;
-    r.x = q % nx;
-    r.z = q / nx;
+    const int q = fast ? fdiv(t, ny, inv_ny) : t / ny;
+    r.y = t - q * ny;
+    r.z = fast ? fdiv(q, nx, inv_nx) : q / nx;
+    r.x = q - r.z * nx;
     return r;
   }
-  r.x = t % nx;
-  const int q = t / nx;
-  r.y = q % ny;
-  r.z = q / ny;
+  const int q = fast ? fdiv(t, nx, inv_nx) : t / nx;
+  r.x = t - q * nx;
+  r.z = fast ? fdiv(q, ny, inv_ny) : q / ny;
+  r.y = q - r.z * ny;
   return r;
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-// 3x3, stride 1, pad = dilation: the halo form.  The kernel above is bound by what it pulls through the L2 (each of the
+// 3x3, stride 1, pad = dilation: the halo form.  The ring kernel is bound by what it pulls through the L2 (each of the
 // nine taps re-fetches the activations: 28 KB per workgroup and 24 MFMAs/wave).  Here a workgroup owns a 4-row x
 // 32-column patch of the output (wave w = row w) and, per 32-channel chunk, stages the patch's (4+2d) x (32+2d) input
 // halo ONCE (26 KB at d = 1): the nine taps read their A fragments from it at shifted positions.  Per tap only the 12 KB
@@ -865,7 +887,7 @@ static __global__ __launch_bounds__(64 * kDirectMaxWaves) void conv_split_direct
   const bool pix_ok = pix < P;
   int iy0 = 0, ix0 = 0, base = 0;
   if (pix_ok) {
-    const int pn = pix / (a.Ho * a.Wo), r = pix - pn * a.Ho * a.Wo, py = r / a.Wo, px = r - py * a.Wo;
+    const int pn = fdiv(pix, a.Ho * a.Wo, a.inv_howo), r = pix - pn * a.Ho * a.Wo, py = fdiv(r, a.Wo, a.inv_wo), px = r - py * a.Wo;
     iy0 = py * a.stride - a.pad_h; ix0 = px * a.stride - a.pad_w;
     base = ((pn * a.H + iy0) * a.W + ix0) * a.lda + 16 * (lane >> 5);
   }

@@ -1159,8 +1159,8 @@ def test_conv_fp16_form_flags_an_underestimated_scale(hip):
 @pytest.mark.parametrize("pieces", [2, 3])
 def test_conv_ring_every_plan_gives_the_same_convolution(hip, pieces):
     """lsfa_conv_plan_override: the ring kernel under every tile width x ring depth x K cut the plan may choose computes the
-    same convolution (equal to float64 within the fp32 bound; bit-identical between ring depths, which only change how far
-    ahead the copies run), incl. a slice count that leaves the last slice short, residual + second output + amax_out through
+    same convolution (equal to float64 within the fp32 bound; bit-identical between ring depths and between mixed-role and
+    loader / consumer waves, which only change who issues the copies and how far ahead they run), incl. a slice count that leaves the last slice short, residual + second output + amax_out through
     the reduce pass, and two-level accumulation past 16 chunks."""
     g = torch.Generator(device=DEV).manual_seed(17 + pieces)
     H, W, ci, co, k, dil = 23, 31, 256, 128, 3, 2          # 72 chunks of K
@@ -1176,24 +1176,49 @@ def test_conv_ring_every_plan_gives_the_same_convolution(hip, pieces):
     tol = 2e-6 * (ci * k * k) ** 0.5 * float(ref.abs().max())
     try:
         by_cut = {}
-        for nt in (2, 4):
-            for st in (2, 3, 4):
+        for kern, nt, st in [(k_, n_, s_) for k_ in (1, 2) for n_ in (2, 4) for s_ in (2, 3, 4)]:      # 2: loader / consumer waves
+            if True:
                 if nt == 4 and pieces == 3 and st == 4:
                     continue
                 for slices in (1, 2, 5, 7):
-                    hip.conv_plan_override(kernel=1, nt=nt, st=st, slices=slices)
+                    hip.conv_plan_override(kernel=kern, nt=nt, st=st, slices=slices)
                     slots = hip.amax_slots(1, DEV)[0]
                     y, y2 = hip.conv_split(x, sw, b, 1, dil, dil, residual=res, out2=torch.empty_like(res), scale2=sc2, shift2=sh2,
                                            amax_in=am, amax_out=slots)
-                    assert float((y.double().cpu() - ref).abs().max()) < tol, (nt, st, slices)
+                    assert float((y.double().cpu() - ref).abs().max()) < tol, (kern, nt, st, slices)
                     assert torch.equal(y2, torch.relu(y * sc2 + sh2))
                     assert slots.view(torch.float32).max().item() == y2.max().item()
                     key = (nt, slices)
                     if key in by_cut:
-                        assert torch.equal(by_cut[key], y), (nt, st, slices)      # the ring depth does not change the arithmetic
+                        assert torch.equal(by_cut[key], y), (kern, nt, st, slices)      # neither ring depth nor wave roles change the arithmetic
                     by_cut[key] = y
     finally:
         hip.conv_plan_override()
+
+
+@pytest.mark.parametrize("shape", [(38, 63, 256, 1024, 1), (30, 70, 192, 1024, 2), (150, 250, 64, 64, 1)])
+def test_conv_halo_form_forced(hip, shape):
+    """The 3x3 halo kernel (incl. its balanced mode + fix-up pass and the K-sliced form) is only the plan's choice for wide maps with
+    narrow outputs since r4; forced through lsfa_conv_plan_override(kernel=3) it must still compute the convolution the ring
+    kernel computes (both within the fp32 bound of float64), for two- and three-piece operands, with amax_out."""
+    H, W, ci, co, dil = shape
+    g = torch.Generator(device=DEV).manual_seed(H + ci)
+    x = torch.relu(torch.randn((1, H, W, ci), device=DEV, generator=g))
+    w = torch.randn((co, ci, 3, 3), device=DEV, generator=g) * 0.02
+    b = torch.randn(co, device=DEV, generator=g)
+    ref = torch.relu(torch.nn.functional.conv2d(x.permute(0, 3, 1, 2).double().cpu(), w.double().cpu(), b.double().cpu(), padding=dil, dilation=dil)).permute(0, 2, 3, 1)
+    tol = 2e-6 * (ci * 9) ** 0.5 * float(ref.abs().max())
+    for pieces in (2, 3):
+        sw = hip.SplitWeight(w, pieces=pieces)
+        try:
+            hip.conv_plan_override(kernel=3)
+            slots = hip.amax_slots(1, DEV)[0]
+            y = hip.conv_split(x, sw, b, 1, dil, dil, relu=True, amax_out=slots)
+        finally:
+            hip.conv_plan_override()
+        assert float((y.double().cpu() - ref).abs().max()) < tol
+        assert slots.view(torch.float32).max().item() == y.max().item()
+        assert float((hip.conv_split(x, sw, b, 1, dil, dil, relu=True).double().cpu() - ref).abs().max()) < tol
 
 
 def test_proposal_and_nms_do_not_depend_on_workspace_contents(hip):

@@ -1,6 +1,6 @@
 set -u
 export TMPDIR=/tmp
-OUT=gpurun_out/r3; mkdir -p $OUT; PY=python3
+OUT=gpurun_out/r4; mkdir -p $OUT; PY=python3
 cp profiles/traffic.json $OUT/traffic.json
 EAGER="bench.py --steps 4 --warmup 1 --settle-s 0 --no-graph --lanes 0 --no-cpu-baseline --no-parity --no-spread"
 timeout 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_cfetch -o t -- $PY $EAGER > $OUT/conv_traffic_fetch.log 2>&1

@@ -7,7 +7,8 @@ Per shape and operand form: the launch plan's own choice (time, error against a 
 tile width nt x ring depth st x K slices through lsfa_conv_plan_override, and the tuned / default library GEMM for the 1x1
 shapes.  Time = HIP events around `reps` back-to-back calls that cycle over 6 copies of the weights and 3 of the input
 (in the frame path a layer's weights were last touched a frame ago: they come from the Infinity Cache, not from L2),
-median of 3 rounds; the reduce pass of a K-sliced plan is included.
+captured into one hipGraph per measurement (kernel time incl. launch gaps, not host time); median of 3 replays; the reduce pass
+of a K-sliced plan is included.
 """
 import argparse
 import os
@@ -46,17 +47,29 @@ SHAPES = {
 
 
 def timed(fn, reps, rounds=3):
-    out = []
-    for _ in range(rounds):
+    """us per call: `reps` calls captured into ONE hipGraph (issued eagerly the host's ~15 us per call would be the measurement for
+    every launch shorter than that), replayed `rounds` times; median"""
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
         fn(0)
-        torch.cuda.synchronize()
-        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        a.record()
+    torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
         for i in range(reps):
             fn(i)
+    g.replay()
+    torch.cuda.synchronize()
+    out = []
+    for _ in range(rounds):
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        g.replay()
         b.record()
         torch.cuda.synchronize()
         out.append(a.elapsed_time(b) * 1e3 / reps)
+    del g
     return float(np.median(out))
 
 
@@ -116,29 +129,31 @@ def main():
             if args.no_sweep:
                 continue
             rows = []
-            for nt in (2, 4):
-                if co % (32 * nt):
-                    continue
-                for st in (2, 3, 4):
-                    if nt == 4 and pieces == 3 and st == 4:
+            for kern in (1, 2):          # 1: mixed-role waves, 2: loader / consumer waves
+                for nt in (2, 4):
+                    if co % (32 * nt):
                         continue
-                    for s in ((1, 2, 3, 4, 6, 8, 12) if not args.quick else (1, 3, 6)):
-                        if s > 1 and (ci * k * k // 32) // s < 3:
+                    for st in (2, 3, 4):
+                        if nt == 4 and pieces == 3 and st == 4:
                             continue
-                        try:
-                            hip.conv_plan_override(kernel=1, nt=nt, st=st, slices=s)
-                            call(0)
-                            rows.append((timed(call, max(8, args.reps // 2), rounds=2), nt, st, s))
-                        except hip.LsfaError:
-                            pass
+                        for s in ((1, 2, 3, 4, 6, 8, 12) if not args.quick else (1, 3, 6)):
+                            if s > 1 and (ci * k * k // 32) // s < 3:
+                                continue
+                            try:
+                                hip.conv_plan_override(kernel=kern, nt=nt, st=st, slices=s)
+                                call(0)
+                                rows.append((timed(call, max(8, args.reps // 2), rounds=2), kern, nt, st, s))
+                            except hip.LsfaError:
+                                pass
             hip.conv_plan_override()
             rows.sort()
-            print("      best plans (ring kernel forced): " + "   ".join("nt%d st%d s%d %.1f" % (nt, st, s, tt) for tt, nt, st, s in rows[:6]))
+            tag = {1: "mix", 2: "split"}
+            print("      best plans (ring kernel forced): " + "   ".join("%s nt%d st%d s%d %.1f" % (tag[kn], nt, st, s, tt) for tt, kn, nt, st, s in rows[:6]))
             by = {}
-            for tt, nt, st, s in rows:
-                by.setdefault((nt, st), []).append((s, tt))
-            for (nt, st), v in sorted(by.items()):
-                print("      nt%d st%d: " % (nt, st) + "  ".join("s%d %.1f" % (s, tt) for s, tt in sorted(v)))
+            for tt, kn, nt, st, s in rows:
+                by.setdefault((kn, nt, st), []).append((s, tt))
+            for (kn, nt, st), v in sorted(by.items()):
+                print("      %-5s nt%d st%d: " % (tag[kn], nt, st) + "  ".join("s%d %.1f" % (s, tt) for s, tt in sorted(v)))
 
 
 if __name__ == '__main__':

@@ -3,7 +3,7 @@
 # Raw traces stay on the box; the condensed summaries land in gpurun_out/<round>/ and are copied to profiles/<round>/.
 # PMC passes never share a run with --sys-trace / --runtime-trace (the pool refuses that combination).
 set -u
-R=${1:-r3}
+R=${1:-r4}
 OUT=gpurun_out/$R
 mkdir -p $OUT
 export TMPDIR=/tmp
@@ -45,13 +45,12 @@ cp $(find $OUT/trace_ops -name "*kernel_stats.csv" | head -1) $OUT/bench_ops_ker
 rm -rf $OUT/trace_ops
 timeout 200 $PY tools/lab/warp_lab.py --rounds 9 > $OUT/warp_lab.txt 2>&1
 timeout 200 $PY tools/key_sections.py > $OUT/key_sections.txt 2>&1
-LSFA_CONV_SPLIT=0 LSFA_OWN_CONV=backbone timeout 200 $PY tools/key_sections.py > $OUT/key_sections_fp32_mfma_conv.txt 2>&1
+LSFA_CONV_PIECES=3 timeout 200 $PY tools/key_sections.py > $OUT/key_sections_three_bf16_pieces.txt 2>&1
 
-# 6. the convolution kernels: split-bf16 vs fp32-MFMA vs library per shape (error against float64 + time), where one chunk's
-#    cycles go, and the fp32-MFMA loop with parts switched off; the detection post-processing phase by phase
-timeout 600 $PY tools/lab/conv_split_lab.py > $OUT/conv_split_lab.txt 2>&1
-timeout 300 $PY tools/lab/conv_split_lab.py --stamps > $OUT/conv_split_chunk_cycles.txt 2>&1
-timeout 300 $PY tools/lab/conv_lab.py > $OUT/conv_fp32_mfma_lab.txt 2>&1
+# 6. the convolution kernels: every launch plan of the ring kernel per network shape against the library GEMM (error against
+#    float64 + time, hipGraph-timed); per-kernel durations and counters of a few plans; the detection post-processing phase by phase
+timeout 1500 $PY tools/lab/conv_ring_lab.py --pieces 2,3,1 > $OUT/conv_ring_lab.txt 2>&1
+bash tools/lab/pmc_probe.sh > /dev/null 2>&1; mv gpurun_out/pmc_probe_summary.txt gpurun_out/trace_probe_rows_split.txt $OUT/ 2>/dev/null
 timeout 300 $PY tools/lab/det_lab.py > $OUT/det_lab.txt 2>&1
 # 7. r3: kernel sequences of FlowNet and of one non-key frame (eager), multi-process determinism table
 timeout 200 rocprofv3 --kernel-trace --output-format csv -d $OUT/fn -o t -- $PY tools/backbone_only.py 20 flownet > /dev/null 2>&1

@@ -83,11 +83,11 @@ def pmc_table(d, out, top=45, last_frames=20):
 
 
 def conv_traffic(fetch_dir, write_dir, out_json, key):
-    """HBM bytes of the split-convolution kernel family per lsfa_conv_split_fwd call, from two PMC passes (FETCH_SIZE, WRITE_SIZE: they
+    """HBM bytes of the split-convolution kernel family per lsfa_conv_fwd call, from two PMC passes (FETCH_SIZE, WRITE_SIZE: they
     cannot share one) over the same eager loop: (2 x sum FETCH_SIZE KiB [the gfx950 correction] + sum WRITE_SIZE KiB) x 1024 over the
     family's dispatches / dispatches of its main kernels (a call = one main kernel + at most one reduce / fix-up pass).  Merged
     into `out_json` (profiles/traffic.json, what bench.py reads) under `key`."""
-    main = ('conv_split_kernel', 'conv_split_wide_kernel', 'conv_split_deep_kernel', 'conv_split_direct_kernel', 'conv_split3x3_kernel')
+    main = ('conv_ring_kernel', 'conv_split_direct_kernel', 'conv_split3x3_kernel')
 
     def collect(d, cname):
         f = glob.glob(d + '/**/*counter_collection.csv', recursive=True)
@@ -108,7 +108,7 @@ def conv_traffic(fetch_dir, write_dir, out_json, key):
              "per_kernel_avg_bytes": {k: {"dispatches": fe[k][1], "fetch": int(2048 * fe[k][0] / max(fe[k][1], 1)),
                                           "write": int(1024 * wr[k][0] / max(wr[k][1], 1)) if k in wr else None} for k in sorted(fe)},
              "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) over `bench.py --no-graph --lanes 0`; FETCH_SIZE x2 "
-                       "(gfx950), KiB units; a launch = one lsfa_conv_split_fwd call (main kernel + its reduce / fix-up pass)"}
+                       "(gfx950), KiB units; a launch = one lsfa_conv_fwd call (main kernel + its reduce / fix-up pass)"}
     try:
         d = json.load(open(out_json))
     except (OSError, ValueError):

@@ -433,7 +433,7 @@ void launch_halo_direct(const SplitPlan& p, const convsplit::Args& a, dim3 grid,
     if (nw > convsplit::kDirectMaxWaves) nw = convsplit::kDirectMaxWaves;
     if (nw < 1) nw = 1;
     hipLaunchKernelGGL(convsplit::conv_split_direct_kernel<PC>, dim3((unsigned)((P + 31) / 32), a.Cout / 64), dim3(64 * nw),
-                       (size_t)(nw - 1) * 32 * 64 * sizeof(float), s, a);
+                       (size_t)(nw > 1 ? nw - 1 : 1) * 32 * 64 * sizeof(float), s, a);      // the waves' sums; at least the 8 KB the row epilogue uses
   } else if (p.dil == 1) {
     hipLaunchKernelGGL((convsplit::conv_split3x3_kernel<1, PC>), grid, dim3(convsplit::kThreads), 0, s, a, p.patches_x, p.patches_y, p.nx, p.ny, p.slices);
   } else {

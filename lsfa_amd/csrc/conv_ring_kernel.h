@@ -296,8 +296,7 @@ static __global__ __launch_bounds__((SP ? 2 : 1) * kThreads, (Ring<NT, PC, ST>::
   // region and reads them back as float4 along the channels - lane -> (row 8k + lane / 8, channels 4 (lane % 8) ..): whole 128-byte
   // rows per 8 lanes, 16 bytes per lane, a quarter of the memory instructions.  Same values, same arithmetic per element.
   constexpr bool kRowsFit = RG::kLdsBytes >= 4 * NT * 4096;       // the ring holds the four waves' tiles
-  const bool rows_ok = kRowsFit && (a.part || (!a.y_nchw && (a.ldy & 3) == 0 && ((uintptr_t)a.y & 15) == 0 && (!a.y2 || ((uintptr_t)a.y2 & 15) == 0) &&
-                                  (!a.res || ((uintptr_t)a.res & 15) == 0)));
+  const bool rows_ok = kRowsFit && rows_path_ok(a);
   if (rows_ok) {
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();                       // every wave is done reading the ring (SP: the loaders have left)
@@ -306,46 +305,8 @@ static __global__ __launch_bounds__((SP ? 2 : 1) * kThreads, (Ring<NT, PC, ST>::
     for (int t = 0; t < NT; ++t)
 #pragma unroll
       for (int r = 0; r < 16; ++r) T[t * 1024 + ((r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)) * 32 + (lane & 31)] = acc[t][r];
-    const int c4 = (lane & 7) * 4;
     float* part = a.part ? a.part + (size_t)tile.z * P * a.Cout : nullptr;
-    // the maximum as a float maximum of |.| (one instruction per value; a NaN drops out of it) and, beside it, the SUM of the
-    // pre-activation magnitudes, which is non-finite exactly when one of them is (ReLU would hide a NaN or a -inf): one add per value
-    float mx = 0.f, nf = 0.f;
-    const int act = a.act;                         // wave-uniform: the branches below are scalar
-    const bool has_y2 = a.y2 != nullptr, has_res = a.res != nullptr, has_bias = a.bias != nullptr;
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      const int row = 8 * k + (lane >> 3);
-      const int p = m0 + row;
-      const bool ok = p < P;
-      const int base = (ok && !part) ? out_pixel_base(a, p) : 0;
-#pragma unroll
-      for (int t = 0; t < NT; ++t) {
-        const int ch = tile.y * (32 * NT) + t * 32 + c4;
-        const float4 v = *reinterpret_cast<const float4*>(&T[t * 1024 + row * 32 + c4]);
-        if (!ok) continue;
-        if (part) { *reinterpret_cast<float4*>(part + (size_t)p * a.Cout + ch) = v; continue; }
-        float4 o = v;
-        if (has_bias) { const float4 b = *reinterpret_cast<const float4*>(a.bias + ch); o.x = o.x + b.x; o.y = o.y + b.y; o.z = o.z + b.z; o.w = o.w + b.w; }
-        if (has_res) { const float4 rr = *reinterpret_cast<const float4*>(a.res + base + ch); o.x = o.x + rr.x; o.y = o.y + rr.y; o.z = o.z + rr.z; o.w = o.w + rr.w; }
-        nf = nf + fabsf(o.x); nf = nf + fabsf(o.y); nf = nf + fabsf(o.z); nf = nf + fabsf(o.w);
-        if (act == 1) { o.x = fmaxf(o.x, 0.f); o.y = fmaxf(o.y, 0.f); o.z = fmaxf(o.z, 0.f); o.w = fmaxf(o.w, 0.f); }
-        else if (act == 2) { o.x = activate(o.x, 2); o.y = activate(o.y, 2); o.z = activate(o.z, 2); o.w = activate(o.w, 2); }
-        *reinterpret_cast<float4*>(a.y + base + ch) = o;
-        if (has_y2) {
-          const float4 s2 = *reinterpret_cast<const float4*>(a.scale2 + ch), h2 = *reinterpret_cast<const float4*>(a.shift2 + ch);
-          float4 w;
-          w.x = fmaxf(o.x * s2.x + h2.x, 0.f); w.y = fmaxf(o.y * s2.y + h2.y, 0.f);
-          w.z = fmaxf(o.z * s2.z + h2.z, 0.f); w.w = fmaxf(o.w * s2.w + h2.w, 0.f);
-          *reinterpret_cast<float4*>(a.y2 + base + ch) = w;
-          mx = fmaxf(fmaxf(mx, fmaxf(w.x, w.y)), fmaxf(w.z, w.w));
-        } else {
-          mx = fmaxf(fmaxf(mx, fmaxf(fabsf(o.x), fabsf(o.y))), fmaxf(fabsf(o.z), fabsf(o.w)));
-        }
-      }
-    }
-    uint32_t m = __float_as_uint(mx);
-    if ((__float_as_uint(nf) & 0x7F800000u) == 0x7F800000u) m = 0x7FC00000u;       // a non-finite value went through this lane
+    const uint32_t m = tile_rows_out<NT>(a, T, m0, P, tile.y * (32 * NT), part, lane);
     if (!part) publish_amax(m, a.amax_out, a.status, blockIdx.x * 4 + g.wave);
     return;
   }

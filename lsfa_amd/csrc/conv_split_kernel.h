@@ -390,6 +390,63 @@ __device__ __forceinline__ uint32_t tile_store_max(const Args& a, const RowOut& 
   return m;
 }
 
+// Channels-last outputs leave through LDS.  In the accumulator layout a lane holds ONE channel of 16 pixels, i.e. 4-byte accesses
+// (16 per tile and output, plus 16 residual loads: the epilogue of a conv3 - residual, sum, next bn1 / relu1 - was 7 of its 27 us).
+// T holds a wave's NT 32 x 32 tiles row-major ([tile][row][32 channels], written from the accumulators by the caller); here they
+// are read back as float4 along the channels - lane -> (row 8k + lane / 8, channels 4 (lane % 8) ..): whole 128-byte rows per
+// 8 lanes, 16 bytes per lane, a quarter of the memory instructions.  Same values, same arithmetic per element as tile_store.
+// m0 = first pixel of the 32 rows, ch0 = first channel of tile 0; part != NULL: a K slice's partial sums instead of the epilogue.
+// -> the wave's contribution to amax_out (bit pattern; 0x7FC00000 if a non-finite value went through this lane)
+template <int NT>
+__device__ __forceinline__ uint32_t tile_rows_out(const Args& a, const float* T, int m0, int P, int ch0, float* part, int lane) {
+  const int c4 = (lane & 7) * 4;
+  // the maximum as a float maximum of |.| (one instruction per value; a NaN drops out of it) and, beside it, the SUM of the
+  // pre-activation magnitudes, which is non-finite exactly when one of them is (ReLU would hide a NaN or a -inf): one add per value
+  float mx = 0.f, nf = 0.f;
+  const int act = a.act;                         // wave-uniform: the branches below are scalar
+  const bool has_y2 = a.y2 != nullptr, has_res = a.res != nullptr, has_bias = a.bias != nullptr;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int row = 8 * k + (lane >> 3);
+    const int p = m0 + row;
+    const bool ok = p < P;
+    const int base = (ok && !part) ? out_pixel_base(a, p) : 0;
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+      const int ch = ch0 + t * 32 + c4;
+      const float4 v = *reinterpret_cast<const float4*>(&T[t * 1024 + row * 32 + c4]);
+      if (!ok) continue;
+      if (part) { *reinterpret_cast<float4*>(part + (size_t)p * a.Cout + ch) = v; continue; }
+      float4 o = v;
+      if (has_bias) { const float4 b = *reinterpret_cast<const float4*>(a.bias + ch); o.x = o.x + b.x; o.y = o.y + b.y; o.z = o.z + b.z; o.w = o.w + b.w; }
+      if (has_res) { const float4 rr = *reinterpret_cast<const float4*>(a.res + base + ch); o.x = o.x + rr.x; o.y = o.y + rr.y; o.z = o.z + rr.z; o.w = o.w + rr.w; }
+      nf = nf + fabsf(o.x); nf = nf + fabsf(o.y); nf = nf + fabsf(o.z); nf = nf + fabsf(o.w);
+      if (act == 1) { o.x = fmaxf(o.x, 0.f); o.y = fmaxf(o.y, 0.f); o.z = fmaxf(o.z, 0.f); o.w = fmaxf(o.w, 0.f); }
+      else if (act == 2) { o.x = activate(o.x, 2); o.y = activate(o.y, 2); o.z = activate(o.z, 2); o.w = activate(o.w, 2); }
+      *reinterpret_cast<float4*>(a.y + base + ch) = o;
+      if (has_y2) {
+        const float4 s2 = *reinterpret_cast<const float4*>(a.scale2 + ch), h2 = *reinterpret_cast<const float4*>(a.shift2 + ch);
+        float4 w;
+        w.x = fmaxf(o.x * s2.x + h2.x, 0.f); w.y = fmaxf(o.y * s2.y + h2.y, 0.f);
+        w.z = fmaxf(o.z * s2.z + h2.z, 0.f); w.w = fmaxf(o.w * s2.w + h2.w, 0.f);
+        *reinterpret_cast<float4*>(a.y2 + base + ch) = w;
+        mx = fmaxf(fmaxf(mx, fmaxf(w.x, w.y)), fmaxf(w.z, w.w));
+      } else {
+        mx = fmaxf(fmaxf(mx, fmaxf(fabsf(o.x), fabsf(o.y))), fmaxf(fabsf(o.z), fabsf(o.w)));
+      }
+    }
+  }
+  uint32_t m = __float_as_uint(mx);
+  if ((__float_as_uint(nf) & 0x7F800000u) == 0x7F800000u) m = 0x7FC00000u;       // a non-finite value went through this lane
+  return m;
+}
+
+// can a channels-last output take the float4 row path (alignment of the operands it touches)
+__device__ __forceinline__ bool rows_path_ok(const Args& a) {
+  return a.part || (!a.y_nchw && (a.ldy & 3) == 0 && ((uintptr_t)a.y & 15) == 0 && (!a.y2 || ((uintptr_t)a.y2 & 15) == 0) &&
+                    (!a.res || ((uintptr_t)a.res & 15) == 0));
+}
+
 // sum of the K slices in slice order (reproducible), then the same tail as tile_store; a float4 of channels per thread
 static __global__ __launch_bounds__(kThreads) void split_reduce_kernel(Args a, long n4, int slices) {
   if (a.nphase > 1) { apply_phase(a, blockIdx.y, slices); n4 = (long)a.N * a.Ho * a.Wo * a.Cout / 4; }
@@ -872,16 +929,11 @@ static __global__ __launch_bounds__(64 * kDirectMaxWaves) void conv_split_direct
   const int m0 = blockIdx.x * 32;
   const int cpt = a.Cin / kChunk, nchunks = a.kh * a.kw * cpt;
   // this wave's run of the (tap, chunk) list
-  const int c_begin = (nchunks * wave) / kDirectWaves, c_end = (nchunks * (wave + 1)) / kDirectWaves;
+  const float inv_nw = 1.0f / (float)kDirectWaves;
+  const int c_begin = fdiv(nchunks * wave, kDirectWaves, inv_nw), c_end = fdiv(nchunks * (wave + 1), kDirectWaves, inv_nw);
   const int col_tiles = a.Cout / 32;
   const size_t wstride = (size_t)col_tiles * (128 * PC);
   const uint4* wtile = a.wfrag + (size_t)(2 * blockIdx.y) * (128 * PC);
-  float a_scale = 1.f, out_scale = 1.f;
-  if (PC == 2) {
-    const int s_exp = 13 - amax_exponent_asm(a.amax, lane, a.status);
-    a_scale = ldexpf(1.f, s_exp);
-    out_scale = ldexpf(1.f, -(s_exp + a.w_exp));
-  }
   // the lane's pixel and the 16 channels of a chunk it feeds (fragment role: row = lane & 31, k half = lane >> 5)
   const int pix = m0 + (lane & 31);
   const bool pix_ok = pix < P;
@@ -896,7 +948,7 @@ static __global__ __launch_bounds__(64 * kDirectMaxWaves) void conv_split_direct
   for (int i = 0; i < 16; ++i) { acc0[i] = 0.f; acc1[i] = 0.f; }
 
   auto operand_of = [&](int gch, int& off, bool& ok) {
-    const int tap = gch / cpt, kc = gch - tap * cpt, ty = tap / a.kw, tx = tap - ty * a.kw;
+    const int tap = fdiv(gch, cpt, a.inv_cpt), kc = gch - tap * cpt, ty = fdiv(tap, a.kw, a.inv_kw), tx = tap - ty * a.kw;
     const int dy = ty * a.dil, dx = tx * a.dil;
     ok = pix_ok && (unsigned)(iy0 + dy) < (unsigned)a.H && (unsigned)(ix0 + dx) < (unsigned)a.W;
     off = base + (dy * a.W + dx) * a.lda + kc * kChunk;
@@ -906,6 +958,14 @@ static __global__ __launch_bounds__(64 * kDirectMaxWaves) void conv_split_direct
     int off; bool ok;
     operand_of(c_begin, off, ok);
     direct_load(cur, a.x, wtile, wstride, c_begin, off, ok, lane);
+  }
+  // the fp16 form's scale, read AFTER the first operands are on their way (one wait for both: a launch this short is a chain of
+  // memory round trips, and every one taken out of the chain is ~1 us of its ~10)
+  float a_scale = 1.f, out_scale = 1.f;
+  if (PC == 2) {
+    const int s_exp = 13 - amax_exponent_asm(a.amax, lane, a.status);
+    a_scale = ldexpf(1.f, s_exp);
+    out_scale = ldexpf(1.f, -(s_exp + a.w_exp));
   }
   for (int c = c_begin; c < c_end; c += 2) {         // two register sets take turns (no copies)
     if (c + 1 < c_end) {
@@ -933,6 +993,24 @@ static __global__ __launch_bounds__(64 * kDirectMaxWaves) void conv_split_direct
   for (int w = 0; w < kDirectWaves - 1; ++w)
 #pragma unroll
     for (int r = 0; r < 16; ++r) { acc0[r] = acc0[r] + red[w][r * 64 + lane]; acc1[r] = acc1[r] + red[w][(16 + r) * 64 + lane]; }
+  if (PC == 2) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { acc0[r] = acc0[r] * out_scale; acc1[r] = acc1[r] * out_scale; }
+  }
+  if (rows_path_ok(a)) {
+    // the two 32 x 32 tiles through the first 8 KB of the LDS block (the other waves' sums have been read) as float4 rows
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    float* T = red_dyn;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+      T[row * 32 + (lane & 31)] = acc0[r];
+      T[1024 + row * 32 + (lane & 31)] = acc1[r];
+    }
+    const uint32_t mr = tile_rows_out<2>(a, T, m0, P, blockIdx.y * kWgCh, nullptr, lane);
+    publish_amax(mr, a.amax_out, a.status, blockIdx.y * gridDim.x + blockIdx.x);
+    return;
+  }
   RowOut ro;
   ro.valid = 0;
 #pragma unroll
@@ -940,10 +1018,6 @@ static __global__ __launch_bounds__(64 * kDirectMaxWaves) void conv_split_direct
     const int p = m0 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
     ro.base[r] = 0;
     if (p < P) { ro.valid |= 1u << r; ro.base[r] = out_pixel_base(a, p); }
-  }
-  if (PC == 2) {
-#pragma unroll
-    for (int r = 0; r < 16; ++r) { acc0[r] = acc0[r] * out_scale; acc1[r] = acc1[r] * out_scale; }
   }
   const uint32_t m = max(tile_store_max(a, ro, blockIdx.y * kWgCh + (lane & 31), acc0), tile_store_max(a, ro, blockIdx.y * kWgCh + 32 + (lane & 31), acc1));
   publish_amax(m, a.amax_out, a.status, blockIdx.y * gridDim.x + blockIdx.x);

@@ -38,6 +38,8 @@ def parse_args():
     ap.add_argument('--serial', action='store_true', help='reference-shaped serial frame loop (pred_eval) instead of the '
                                                           'stream-pipelined one')
     ap.add_argument('--out', default=None, help='rank 0 saves the gathered detection rows (n,7) here (.npy)')
+    ap.add_argument('--dtype', default='f32', choices=['f32', 'bf16'],
+                    help='f32: every fp32 product from two fp16 pieces (fp32 accuracy); bf16: one bf16 product per fp32 product (BASELINE configs[2])')
     ap.add_argument('--pinned-algorithms', action='store_true',
                     help='deterministic convolution / GEMM algorithm choice (no MIOpen find, no TunableOp): results do not '
                          'depend on how the videos are spread over ranks')
@@ -85,7 +87,8 @@ def main():
         arg_params, aux_params = P.init_params(cfg, seed=0)
     t0 = time.time()
     rows, frame_ids = test_rcnn(cfg, roidb, arg_params, aux_params, device='cuda:%d' % local_rank, thresh=args.thresh,
-                                logger=logger, pipeline=not args.serial)
+                                logger=logger, pipeline=not args.serial,
+                                dtype=torch.float32 if args.dtype == 'f32' else torch.bfloat16)
     torch.cuda.synchronize()
     dt = time.time() - t0
     if not dist.is_initialized() or dist.get_rank() == 0:

@@ -75,14 +75,27 @@ def test_config3_bf16_four_clips_in_lockstep(world):
                    'cls_prob_reshape_output': out['cls_prob_reshape_output'][:, sl]}
             check_dets(cfg, one, d[b], c[b], H, W)
     assert (np_(kfeat)[0] != np_(kfeat)[1]).any()                  # the clips do differ
-    # ---- clip 2 alone (batch 1) through the same executors: bf16 contractions may pick other kernels for another
-    #      batch size, so agreement is to bf16 round-off of the feature map, not bit for bit
+    # ---- clip 2 alone (batch 1) through the same executors.  r4: the bf16 mode runs the own kernels, whose operands are rounded
+    #      to bf16 the same way whatever the batch; only the launch plan (K slices) and with it the fp32 summation order may differ
+    #      between batch 1 and batch 4: agreement to fp32 round-off of the feature map (r3, library kernels: 0.05)
     solo = FrameGraphs(key, cur, cfg, H, W, DEV, use_graphs=False, prefetch=False, taps=False, batch=1)
     solo.first_frame(f0[2:3])
     solo.capture()
     solo.key_frame(f1[2:3])
     a, b = np_(solo.feat)[0], np_(kfeat)[2]
-    assert np.abs(a - b).max() / np.abs(b).max() < 0.05
+    assert np.abs(a - b).max() / np.abs(b).max() < 1e-4
+    # ---- the end-to-end criterion of the bf16 mode.  north_star words it as "mAP within 0.1 of the reference"; with the random
+    #      weights of this test (no checkpoint in the image) RPN scores are near-ties by construction and ROI / mAP identity with an
+    #      fp32 run is not a meaningful quantity (bench.py's parity block reports it: ~all 3000 ROIs differ).  What IS asserted:
+    #      every hand-written stage bit-exact on the bf16 run's own inputs (above), no overflow flag, and the dense features of the
+    #      first key frame within bf16 round-off of the fp32 oracle graph: the aggregated feature to 3 % of its maximum (one bf16
+    #      rounding per operand is 2^-9 = 0.2 %; ~100 layers compound it), the RPN probabilities to 0.02 absolute.
+    from oracle import graph_ref
+    ref = graph_ref.key_forward(cfg, arg, aux, np_(f0[2:3]), np_(f0[2:3]), np.zeros((1, 1024, 1, 1), np.float32), clips[2].im_info())
+    rel = np.abs(np_(feat0)[2] - ref['choose_feat_output'][0]).max() / np.abs(ref['choose_feat_output']).max()
+    assert rel < 0.03, rel
+    key.check_status()
+    cur.check_status()
 
 
 def test_config5_many_maps_per_launch_bit_exact():

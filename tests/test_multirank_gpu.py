@@ -61,7 +61,8 @@ def _canonical(rows):
     return rows[np.lexsort(rows.T[::-1])]
 
 
-def test_lsfa_test_three_clips_two_ranks_equal_single_rank(tmp_path):
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+def test_lsfa_test_three_clips_two_ranks_equal_single_rank(tmp_path, dtype):
     """`python -m lsfa_amd.test --clips 3`: one rank (clips 0, 1, 2 through one pipeline) vs two ranks (greedy
     assignment: rank 0 gets clips {0, 2}, rank 1 clip {1}; rows gathered over gloo in rank order) must deliver the SAME
     detection rows, bit for bit — the reference's fan-out returns the same detections however the videos are spread
@@ -70,8 +71,9 @@ def test_lsfa_test_three_clips_two_ranks_equal_single_rank(tmp_path):
     from per-user state under $HOME that concurrently starting processes race for (profiles/r3/multirank_diag_*.txt);
     since r3 the fp32 frame path makes no MIOpen call at all (own convolutions) and the library is built without packed-fp32
     VALU code - that, not an isolated MIOpen state, is what the bit-exactness rests on; `--pinned-algorithms`
-    only switches off the find step / TunableOp for the remaining library GEMMs."""
-    args = ["--clips", "3", "--frames", "7", "--interval", "3", "--height", "192", "--width", "320", "--pinned-algorithms"]
+    only switches off the find step / TunableOp for the remaining library GEMMs.  r4: the bf16 mode runs the same own kernels (one
+    bf16 product per fp32 product; r3's fell back to MIOpen) and is held to the same bit-for-bit equality."""
+    args = ["--clips", "3", "--frames", "7", "--interval", "3", "--height", "192", "--width", "320", "--pinned-algorithms", "--dtype", dtype]
     outs = {}
     for tag, nproc in (("one", 1), ("two", 2)):
         out = str(tmp_path / ("rows_%s.npy" % tag))

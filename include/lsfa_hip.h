@@ -348,14 +348,15 @@ int lsfa_stem_conv7x7s2_ex(const float* x, int N, int H, int W, const float* in_
  *                        (the first Cin channels of each pixel), w (Cout,3,3,Cin), y = (conv + bias) * mul either NCHW
  *                        (N,Cout,H,W) (out_nchw != 0: the `flow` output, mul = 2.5, :204) or channels [c0, c0+Cout) of (N,H,W,ldy).
  *   lsfa_upsample_flow   upsample_flow*to* (:180, :185, :190, :195): Deconvolution(kernel 4, stride 2, C -> C, C <= 8) + Crop(offset 1)
- *                        to Hc x Wc; in (N,Hi,Wi,C), w (C,C,4,4) (MXNet's (in, out, kh, kw)), out channels [c0, c0+C) of (N,Hc,Wc,ldy).
+ *                        to Hc x Wc; in (N,Hi,Wi,C), w (C,C,4,4) (MXNet's (in, out, kh, kw)), out channels [c0, c0+C) of (N,Hc,Wc,ldy);
+ *                        amax_out (or NULL): the 256 slots of the destination map that receive max|result| (see lsfa_conv_fwd).
  *   lsfa_avgpool2_nhwc   Pooling(kernel 2, stride 2, avg, 'full') on (N,H,W,C), C % 4 == 0 -> (N,ceil(H/2),ceil(W/2),C), edge
  *                        windows clipped (:201).
  * ------------------------------------------------------------------------ */
 int lsfa_head_conv3x3(const float* x, int lda, int N, int H, int W, int Cin, const float* w, const float* bias, int Cout,
                       float mul, float* y, int out_nchw, int ldy, int c0, void* stream);
 int lsfa_upsample_flow(const float* in, int N, int Hi, int Wi, int C, const float* w, const float* bias, int Hc, int Wc,
-                       float* out, int ldy, int c0, void* stream);
+                       float* out, int ldy, int c0, unsigned* amax_out, void* stream);
 int lsfa_avgpool2_nhwc(const float* x, int N, int H, int W, int C, float* y, void* stream);
 /* channels [c0, c0 + C) of an (N, Ctot, HW) map as (N, HW, C) rows: the NCHW feature the reference's operators exchange
  * (`conv_feat`, resnet_v1_101_flownet_rfcn.py:479-481 SliceChannel) in the channels-last form lsfa_conv_split_fwd reads. */

@@ -953,6 +953,7 @@ static __global__ __launch_bounds__(64 * kDirectMaxWaves) void conv_split_direct
     ok = pix_ok && (unsigned)(iy0 + dy) < (unsigned)a.H && (unsigned)(ix0 + dx) < (unsigned)a.W;
     off = base + (dy * a.W + dx) * a.lda + kc * kChunk;
   };
+  const bool rows = rows_path_ok(a);
   DirectOperands<PC> cur, nxt;
   if (c_begin < c_end) {
     int off; bool ok;
@@ -997,7 +998,7 @@ static __global__ __launch_bounds__(64 * kDirectMaxWaves) void conv_split_direct
 #pragma unroll
     for (int r = 0; r < 16; ++r) { acc0[r] = acc0[r] * out_scale; acc1[r] = acc1[r] * out_scale; }
   }
-  if (rows_path_ok(a)) {
+  if (rows) {
     // the two 32 x 32 tiles through the first 8 KB of the LDS block (the other waves' sums have been read) as float4 rows
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     float* T = red_dyn;

@@ -76,9 +76,10 @@ __global__ __launch_bounds__(256) void head_conv3x3_kernel(const float* __restri
 // Crop(offset 1): out[oy, ox] = full[oy + 1, ox + 1].  Sum order: ci, ky, kx ascending.
 __global__ __launch_bounds__(256) void upflow_kernel(const float* __restrict__ in, int N, int Hi, int Wi, int C, const float* __restrict__ w,
                                                      const float* __restrict__ bias, int Hc, int Wc, float* __restrict__ out, int ldy,
-                                                     int c0) {
+                                                     int c0, unsigned* __restrict__ amax_out) {
   const int i = blockIdx.x * 256 + threadIdx.x;
-  if (i >= N * Hc * Wc * C) return;
+  float v = 0.f;
+  if (i < N * Hc * Wc * C) {
   const int co = i % C;
   int r = i / C;
   const int ox = r % Wc; r /= Wc;
@@ -96,7 +97,15 @@ __global__ __launch_bounds__(256) void upflow_kernel(const float* __restrict__ i
         s = fmaf(in[((size_t)(n * Hi + (ty >> 1)) * Wi + (tx >> 1)) * C + ci], w[((ci * C + co) * 4 + ky) * 4 + kx], s);
       }
     }
-  out[((size_t)(n * Hc + oy) * Wc + ox) * ldy + c0 + co] = s + (bias ? bias[co] : 0.f);
+  v = s + (bias ? bias[co] : 0.f);
+  out[((size_t)(n * Hc + oy) * Wc + ox) * ldy + c0 + co] = v;
+  }
+  if (amax_out) {      // max|v| of the wave into one of the 256 slots the map's other producers (convolutions) also write (lsfa_conv_fwd)
+    uint32_t m = __float_as_uint(v) & 0x7FFFFFFFu;
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) m = max(m, (uint32_t)__shfl_xor((int)m, d, 64));
+    if ((threadIdx.x & 63) == 0) atomicMax(amax_out + ((blockIdx.x * 4 + (threadIdx.x >> 6)) & 255), m);
+  }
 }
 
 // channels-last 2x2 / 2 average, windows clipped to the map ('full' convention); a float4 of channels per thread
@@ -166,14 +175,14 @@ extern "C" int lsfa_head_conv3x3(const float* x, int lda, int N, int H, int W, i
 }
 
 extern "C" int lsfa_upsample_flow(const float* in, int N, int Hi, int Wi, int C, const float* w, const float* bias, int Hc, int Wc,
-                                  float* out, int ldy, int c0, void* stream) {
+                                  float* out, int ldy, int c0, unsigned* amax_out, void* stream) {
   LSFA_REQUIRE(in && w && out, "lsfa_upsample_flow: NULL argument");
   LSFA_REQUIRE(N > 0 && Hi > 0 && Wi > 0 && C > 0 && C <= 8 && Hc > 0 && Wc > 0 && Hc <= 2 * Hi + 1 && Wc <= 2 * Wi + 1 && ldy >= c0 + C && c0 >= 0,
                "lsfa_upsample_flow: bad shape");
   const int total = N * Hc * Wc * C;
   ProfScope prof(LSFA_OP_FLOWNET, (hipStream_t)stream);
   hipLaunchKernelGGL(upflow_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, in, N, Hi, Wi, C, w, bias, Hc, Wc,
-                     out, ldy, c0);
+                     out, ldy, c0, amax_out);
   LSFA_LAUNCH_CHECK("lsfa_upsample_flow");
   return LSFA_OK;
 }

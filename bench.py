@@ -555,7 +555,11 @@ def main():
                for k, v in prof.items() if v[1]}
         hand_total = sum(o["total_us"] for o in ops.values()) or 1.0
         dom = max(ops, key=lambda k: ops[k]["total_us"]) if ops else None
-        roof_hbm = {"bound": "hbm", "kernel": "warp_staged_kernel (lsfa_warp_bilinear: MV/flow warp + fused epilogue; planes staged in LDS by DMA), %d map(s) per launch" % B,
+        # which kernel lsfa_warp_bilinear runs for this shape (warp.hip's predicate: planes of 1,024-4,096 even pixels go through LDS)
+        staged = (fh * fw) % 2 == 0 and 1024 <= fh * fw <= 4096 and os.environ.get('LSFA_WARP_VARIANT', 'auto') != 'gather'
+        warp_kernel = ("warp_staged_kernel (lsfa_warp_bilinear: MV/flow warp + fused epilogue; planes staged in LDS by DMA)" if staged else
+                       "warp_kernel (lsfa_warp_bilinear: MV/flow warp + fused epilogue; gather form: plane size outside the LDS-staged kernel's range)")
+        roof_hbm = {"bound": "hbm", "kernel": "%s, %d map(s) per launch" % (warp_kernel, B),
                 "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 4),
                 "traffic": load_traffic("warp_bilinear:N=%d,C=%d,H=%d,W=%d" % (B, C, fh, fw)),
@@ -641,7 +645,7 @@ def main():
             line["roofline_single_map"] = roof_hbm
             line["roofline_mfma_kernel"] = roof
             del line["roofline_hbm_kernel"]
-            line["roofline"] = {"bound": "hbm", "kernel": "warp_staged_kernel (lsfa_warp_bilinear, planes staged in LDS by DMA), %d maps per launch (x scale map epilogue)" % M,
+            line["roofline"] = {"bound": "hbm", "kernel": "%s, %d maps per launch (x scale map epilogue)" % (warp_kernel, M),
                                 "achieved": w["achieved_GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                 "frac": round(w["achieved_GBps"] / HBM_PEAK_GBS, 4),
                                 "traffic": load_traffic("warp_bilinear:N=%d,C=%d,H=%d,W=%d" % (M, C, fh, fw)),

@@ -53,12 +53,6 @@ __global__ __launch_bounds__(kThreads) void bbox_pred_clip_kernel(const float* _
 // suppresses()) and with the transposed words of the diagonal 64x64 blocks built alongside -> one wave
 // sweeps the 64-position blocks, each resolved as a ballot fixpoint (a handful of steps) instead of a
 // 64-step scalar loop.
-#ifdef LSFA_DET_STAMPS     // lab builds only (tools/lab/det_lab.py): phase boundaries of class 1's workgroup, 100 MHz ticks
-__device__ long long g_det_stamps[16];
-#define DET_STAMP(k) do { if (threadIdx.x == 0 && blockIdx.x == 1) g_det_stamps[k] = wall_clock64(); } while (0)
-#else
-#define DET_STAMP(k) do { } while (0)
-#endif
 
 constexpr int kClassThreads = 1024;
 constexpr int kClassWaves = kClassThreads / 64;
@@ -106,7 +100,6 @@ __global__ __launch_bounds__(kClassThreads) void det_class_kernel(
   int* misc = kept + R;  // [0] running count, [1..16] wave sums
 
   // 1. threshold + in-order compaction (np.where(scores[:, j] > thresh), tester.py:267)
-  DET_STAMP(0);
   if (tid == 0) misc[0] = 0;
   for (int i = tid; i < R; i += kClassThreads) rank[i] = 0;
   __syncthreads();
@@ -137,7 +130,6 @@ __global__ __launch_bounds__(kClassThreads) void det_class_kernel(
   }
   const int m = misc[0];
   if (m == 0) { if (tid == 0) counts[j] = 0; return; }
-  DET_STAMP(1);
 
   // 2. rank: score descending, ties by ascending candidate (= roi) index; candidate i's comparisons are cut
   //    into kRankSplit slices so that m * kRankSplit threads work
@@ -162,7 +154,6 @@ __global__ __launch_bounds__(kClassThreads) void det_class_kernel(
     sarea[p] = (x2 - x1 + 1) * (y2 - y1 + 1);
   }
   __syncthreads();
-  DET_STAMP(2);
 
   // 3. suppression mask over sorted positions, one wave per 64x64 tile of the upper triangle: bit c of
   //    mask[a][w] <=> position 64w+c > a and the pair suppresses.  The lane owns row a (box in registers), the
@@ -232,7 +223,6 @@ __global__ __launch_bounds__(kClassThreads) void det_class_kernel(
     }
   }
   __syncthreads();
-  DET_STAMP(3);
 
   // 4. sweep by wave 0 in 64-position blocks: lane w (< Wd) holds word w of the removed set; a block is
   //    resolved by resolve_block (nms_block.h: ballot fixpoint, scalar scan over the survivors when the
@@ -242,17 +232,13 @@ __global__ __launch_bounds__(kClassThreads) void det_class_kernel(
     uint64_t remv = 0;
     for (int b = 0; b < nblk; ++b) {
       const int base = b * 64, nb = min(64, m - base);
-      if (b == 0) DET_STAMP(8);
       const uint64_t cw = lane < nb ? colw[base + lane] : 0ULL;
       const uint64_t rowd = lane < nb ? mask[(size_t)(base + lane) * Wd + b] : 0ULL;
       const uint64_t cur = readlane64(remv, b);
       const bool alive = lane < nb && !((cur >> lane) & 1ULL);
-      if (b == 0) DET_STAMP(9);
       const uint64_t G = resolve_block(__ballot(alive), alive, cw, rowd, 64);
-      if (b == 0) DET_STAMP(10);
       if ((G >> lane) & 1ULL) kept[nk + __popcll(G & ((1ULL << lane) - 1ULL))] = order[base + lane];
       nk += __popcll(G);
-      if (b == 0) DET_STAMP(11);
       uint64_t rem = G;
       while (rem) {
         int ks[8];
@@ -266,12 +252,10 @@ __global__ __launch_bounds__(kClassThreads) void det_class_kernel(
 #pragma unroll
         for (int u = 0; u < 8; ++u) remv |= vv[u];
       }
-      if (b == 0) DET_STAMP(12);
     }
     if (lane == 0) { misc[0] = nk; counts[j] = nk; }
   }
   __syncthreads();
-  DET_STAMP(4);
   nk = misc[0];
 
   // 5. survivors in NMS order
@@ -282,7 +266,6 @@ __global__ __launch_bounds__(kClassThreads) void det_class_kernel(
     o[4] = score[i];
     if (keep_idx) keep_idx[(size_t)j * R + k] = src[i];
   }
-  DET_STAMP(5);
 }
 
 __device__ __forceinline__ uint32_t desc_key(float score) {
@@ -466,11 +449,6 @@ size_t class_lds_bytes(int R) {
 
 }  // namespace
 
-#ifdef LSFA_DET_STAMPS
-extern "C" int lsfa_det_lab_stamps(long long* host16) {
-  return hipMemcpyFromSymbol(host16, HIP_SYMBOL(g_det_stamps), sizeof(long long) * 16) == hipSuccess ? 0 : 1;
-}
-#endif
 
 extern "C" size_t lsfa_det_workspace_bytes(int R, int ncls) {
   (void)R; (void)ncls;

@@ -51,7 +51,6 @@ LSFA_CONV_PIECES=3 timeout 200 $PY tools/key_sections.py > $OUT/key_sections_thr
 #    float64 + time, hipGraph-timed); per-kernel durations and counters of a few plans; the detection post-processing phase by phase
 timeout 1500 $PY tools/lab/conv_ring_lab.py --pieces 2,3,1 > $OUT/conv_ring_lab.txt 2>&1
 bash tools/lab/pmc_probe.sh > /dev/null 2>&1; mv gpurun_out/pmc_probe_summary.txt gpurun_out/trace_probe_rows_split.txt $OUT/ 2>/dev/null
-timeout 300 $PY tools/lab/det_lab.py > $OUT/det_lab.txt 2>&1
 # 7. r3: kernel sequences of FlowNet and of one non-key frame (eager), multi-process determinism table
 timeout 200 rocprofv3 --kernel-trace --output-format csv -d $OUT/fn -o t -- $PY tools/backbone_only.py 20 flownet > /dev/null 2>&1
 timeout 60 $PY tools/kernel_sequence.py $OUT/fn 20 > $OUT/flownet_kernel_sequence.txt 2>&1; rm -rf $OUT/fn

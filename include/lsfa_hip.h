@@ -329,17 +329,21 @@ int lsfa_deconv4x4s2_crop_fwd(const float* x, int lda, int N, int Hi, int Wi, in
  *                          channels-last, Ho = (H-1)/2+1.  fp32 FMA chains in (ci, ky, kx) order.
  *   lsfa_maxpool3x3s2_nhwc pool0 (resnet.py:163: 3x3, stride 2, pad 1, max): x (N,H,W,C) -> y (N,(H-1)/2+1,(W-1)/2+1,C), C % 4 == 0;
  *                          y2 != NULL: also max(y*scale2[c] + shift2[c], 0), the first unit's bn1 + relu1 (resnet.py:78-80).
+ *                          amax_out != NULL: 256 slots (zeroed by the caller) that receive max|y2| (max|y| without y2) the way
+ *                          lsfa_conv_fwd's amax_out does, for the next convolution's amax_in.
  * ------------------------------------------------------------------------ */
 int lsfa_avgpool_nchw(const float* x, int N, int C, int H, int W, int k, float* y, void* stream);
 int lsfa_stem_conv7x7s2(const float* x, int N, int H, int W, const float* in_scale, const float* in_shift,
                         const float* w_l, const float* bias, float* y, void* stream);
 int lsfa_maxpool3x3s2_nhwc(const float* x, int N, int H, int W, int C, float* y, float* y2, const float* scale2,
-                           const float* shift2, void* stream);
+                           const float* shift2, unsigned* amax_out, void* stream);
 /* lsfa_stem_conv7x7s2 with an accumulation input and a choice of activation: y = act(conv(x) + bias + accum), accum (N,Ho,Wo,64)
  * or NULL (may be y itself), act 0 none / 1 ReLU / 2 LeakyReLU(0.1).  FlowNet's flow_conv1 (7x7 / 2, 6 -> 64 channels,
- * resnet_v1_101_flownet_rfcn.py:153) is two such passes, one per image of the pair, with the weight's input channels 0-2 / 3-5. */
+ * resnet_v1_101_flownet_rfcn.py:153) is two such passes, one per image of the pair, with the weight's input channels 0-2 / 3-5.
+ * amax_out (or NULL): 256 zeroed slots that receive max|y|, like lsfa_conv_fwd's. */
 int lsfa_stem_conv7x7s2_ex(const float* x, int N, int H, int W, const float* in_scale, const float* in_shift,
-                           const float* w_l, const float* bias, const float* accum, int act, float* y, void* stream);
+                           const float* w_l, const float* bias, const float* accum, int act, float* y, unsigned* amax_out,
+                           void* stream);
 
 /* ---------------------------------------------------------------------------
  * FlowNet-S pieces that are not MFMA-sized (lsfa_amd/csrc/flownet.hip); with lsfa_conv_split_view_fwd and the two-pass stem

@@ -409,6 +409,14 @@ bool direct_fits(const convsplit::Args& a, long P, int pieces) {
          (size_t)((P + 31) / 32) * wbytes * a.Cout <= (48u << 20) && g_force_kernel.load() == 0;
 }
 
+// waves per tile of the direct kernel: at least two chunks per wave, at most kDirectMaxWaves waves
+int direct_waves(const convsplit::Args& a) {
+  const int nchunks = a.kh * a.kw * (a.Cin / 32);
+  int nw = (nchunks + 1) / 2;
+  if (nw > convsplit::kDirectMaxWaves) nw = convsplit::kDirectMaxWaves;
+  return nw < 1 ? 1 : nw;
+}
+
 template <int NT, int PC, int ST>
 void launch_ring(bool sp, const convsplit::Args& a, dim3 grid, hipStream_t s, int nx, int ny, int nz) {
   if (sp) hipLaunchKernelGGL((convsplit::conv_ring_kernel<NT, PC, ST, true>), grid, dim3(2 * convsplit::kThreads), 0, s, a, nx, ny, nz);
@@ -428,10 +436,7 @@ bool launch_ring_pc(int nt, int st, bool sp, const convsplit::Args& a, dim3 grid
 template <int PC>
 void launch_halo_direct(const SplitPlan& p, const convsplit::Args& a, dim3 grid, hipStream_t s, long P) {
   if (p.direct) {
-    const int nchunks = a.kh * a.kw * (a.Cin / 32);
-    int nw = (nchunks + 1) / 2;            // at least two chunks per wave, at most kDirectMaxWaves waves
-    if (nw > convsplit::kDirectMaxWaves) nw = convsplit::kDirectMaxWaves;
-    if (nw < 1) nw = 1;
+    const int nw = direct_waves(a);
     hipLaunchKernelGGL(convsplit::conv_split_direct_kernel<PC>, dim3((unsigned)((P + 31) / 32), a.Cout / 64), dim3(64 * nw),
                        (size_t)(nw > 1 ? nw - 1 : 1) * 32 * 64 * sizeof(float), s, a);      // the waves' sums; at least the 8 KB the row epilogue uses
   } else if (p.dil == 1) {
@@ -448,7 +453,8 @@ static int tile_order_from_env() {
 }
 
 // every split-operand convolution goes through here; the public entry points fill in what they expose
-int conv_split_launch(convsplit::Args a, int pieces, void* ws, size_t ws_bytes, void* stream, const char* who, int prof_op = LSFA_OP_CONV) {
+// validation, the launch plan, and every derived field of the argument block
+int conv_split_prepare(convsplit::Args& a, int pieces, SplitPlan& p, long& P_out, const char* who) {
   static const int tile_order = tile_order_from_env();
   a.tile_order = tile_order;
   const int N = a.N, H = a.H, W = a.W, Cin = a.Cin, Cout = a.Cout, kh = a.kh, kw = a.kw, stride = a.stride, dil = a.dil;
@@ -480,7 +486,7 @@ int conv_split_launch(convsplit::Args a, int pieces, void* ws, size_t ws_bytes, 
   LSFA_REQUIRE(P + 256 < (1L << 24), "%s: more than 2^24 output pixels", who);      // fdiv's range (conv_split_kernel.h)
   LSFA_REQUIRE(((long)N * a.out_H * a.out_W + 1) * (long)(a.y_nchw ? Cout : a.ldy) < (1L << 31) && P * Cout < (1L << 31) &&
                ((long)N * H * W + (long)(a.pad_h + 1) * (W + 1)) * a.lda < (1L << 31), "%s: tensor too large", who);
-  SplitPlan p = view_plan(N, H, W, Cin, Cout, kh, kw, stride, a.pad_h, a.pad_w, dil, a.lda, a.Ho, a.Wo, pieces);
+  p = view_plan(N, H, W, Cin, Cout, kh, kw, stride, a.pad_h, a.pad_w, dil, a.lda, a.Ho, a.Wo, pieces);
   // small weights on a small map: the direct kernel (a 64-channel group's weights <= 256 KB at three pieces, re-read by every 32-pixel
   // tile) while the weights' re-reads stay modest: (P / 32) tiles x all weights <= 48 MB through L2
   if (direct_fits(a, P, pieces) && !g_force_nt.load()) {
@@ -488,15 +494,6 @@ int conv_split_launch(convsplit::Args a, int pieces, void* ws, size_t ws_bytes, 
     p.direct = true;
     p.slices = 1;
   }
-  const int nph = a.nphase > 1 ? a.nphase : 1;
-  const size_t need = split_workspace(p, P, Cout) * (size_t)nph;
-  if ((p.slices > 1 || p.units_per_wg > 0) && (!ws || ws_bytes < need)) {
-    set_error("%s: workspace %zu < %zu bytes", who, ws_bytes, need);
-    return LSFA_EWORKSPACE;
-  }
-  LSFA_REQUIRE(nph == 1 || (!p.halo && p.units_per_wg == 0 && !p.direct), "%s: phases need the ring kernel", who);
-  hipStream_t s = (hipStream_t)stream;
-  a.part = p.slices > 1 ? (float*)ws : nullptr;
   a.part_stride = P * Cout;
   a.chunks_per_slice = p.per_slice;
   a.units_per_wg = a.max_pieces = 0;
@@ -506,6 +503,26 @@ int conv_split_launch(convsplit::Args a, int pieces, void* ws, size_t ws_bytes, 
   a.inv_ny = 1.0f / (float)(p.ny > 0 ? p.ny : 1);
   a.inv_cpt = 1.0f / (float)(Cin / 32);
   a.inv_kw = 1.0f / (float)kw;
+  P_out = P;
+  return LSFA_OK;
+}
+
+int conv_split_launch(convsplit::Args a, int pieces, void* ws, size_t ws_bytes, void* stream, const char* who, int prof_op = LSFA_OP_CONV) {
+  SplitPlan p;
+  long P = 0;
+  const int rc = conv_split_prepare(a, pieces, p, P, who);
+  if (rc != LSFA_OK) return rc;
+  const int Cin = a.Cin, Cout = a.Cout;
+  (void)Cin;
+  const int nph = a.nphase > 1 ? a.nphase : 1;
+  const size_t need = split_workspace(p, P, Cout) * (size_t)nph;
+  if ((p.slices > 1 || p.units_per_wg > 0) && (!ws || ws_bytes < need)) {
+    set_error("%s: workspace %zu < %zu bytes", who, ws_bytes, need);
+    return LSFA_EWORKSPACE;
+  }
+  LSFA_REQUIRE(nph == 1 || (!p.halo && p.units_per_wg == 0 && !p.direct), "%s: phases need the ring kernel", who);
+  hipStream_t s = (hipStream_t)stream;
+  a.part = p.slices > 1 ? (float*)ws : nullptr;
   ProfScope prof(prof_op, s);
   int tiles = p.nx * p.ny * p.slices * nph;
   if (p.units_per_wg > 0) {
@@ -600,6 +617,53 @@ extern "C" int lsfa_conv_fwd(const lsfa_conv_desc* d, void* ws, size_t ws_bytes,
   return conv_split_launch(args_of(*d), d->pieces, ws, ws_bytes, stream, "lsfa_conv_fwd", d->prof_tag == 1 ? LSFA_OP_FLOWNET : LSFA_OP_CONV);
 }
 
+// n convolutions as one launch when every one of them takes the direct form (conv_chain_kernel), else one after the other: the results are
+// the same bit for bit either way.
+extern "C" int lsfa_conv_chain_fwd(const lsfa_conv_desc* d, int n, unsigned sync_mask, unsigned* barrier, void* ws, size_t ws_bytes, void* stream) {
+  LSFA_REQUIRE(d && n > 0 && n <= 32, "lsfa_conv_chain_fwd: 1..32 descriptors");
+  static const bool off = getenv("LSFA_CONV_CHAIN") && atoi(getenv("LSFA_CONV_CHAIN")) == 0;      // lab: always the separate launches
+  convsplit::ChainArgs c = {};
+  bool chain = !off && barrier && n <= convsplit::kChainMax;
+  int max_phase = 0, phase = 0;
+  for (int l = 0; l < n && chain; ++l) {
+    convsplit::Args a = args_of(d[l]);
+    SplitPlan p;
+    long P = 0;
+    const int rc = conv_split_prepare(a, d[l].pieces, p, P, "lsfa_conv_chain_fwd");
+    if (rc != LSFA_OK) return rc;
+    if (!p.direct || d[l].pieces != d[0].pieces) { chain = false; break; }
+    const int nx = (int)((P + 31) / 32), tiles = nx * (a.Cout / 64);
+    a.inv_nx = 1.0f / (float)nx;
+    c.layer[l] = a;
+    c.nw_packed |= (unsigned)(direct_waves(a) - 1) << (2 * l);
+    if (l == 0 || ((sync_mask >> l) & 1u)) phase = 0;
+    phase += tiles;
+    if (phase > max_phase) max_phase = phase;
+  }
+  if (!chain) {
+    for (int l = 0; l < n; ++l) {
+      const int rc = lsfa_conv_fwd(&d[l], ws, ws_bytes, stream);
+      if (rc != LSFA_OK) return rc;
+    }
+    return LSFA_OK;
+  }
+  c.n = n;
+  c.sync_mask = sync_mask | 1u;
+  c.barrier = barrier;
+  c.status = d[0].status;
+  // every workgroup must be resident while the others spin: at most 1.5 workgroups of 3 waves + 16 KB per CU
+  const int wgs = max_phase < 384 ? max_phase : 384;
+  hipStream_t s = (hipStream_t)stream;
+  ProfScope prof(d[0].prof_tag == 1 ? LSFA_OP_FLOWNET : LSFA_OP_CONV, s);
+  const size_t lds = (size_t)(convsplit::kDirectMaxWaves - 1) * 32 * 64 * sizeof(float);
+  const dim3 grid((unsigned)wgs), block(64 * convsplit::kDirectMaxWaves);
+  if (d[0].pieces == 3) hipLaunchKernelGGL(convsplit::conv_chain_kernel<3>, grid, block, lds, s, c);
+  else if (d[0].pieces == 2) hipLaunchKernelGGL(convsplit::conv_chain_kernel<2>, grid, block, lds, s, c);
+  else hipLaunchKernelGGL(convsplit::conv_chain_kernel<1>, grid, block, lds, s, c);
+  LSFA_LAUNCH_CHECK("lsfa_conv_chain_fwd");
+  return LSFA_OK;
+}
+
 extern "C" int lsfa_amax_partial(const float* x, long long n, float* out, void* stream) {
   LSFA_REQUIRE(x && out && n > 0 && n % 4 == 0 && ((uintptr_t)x & 15) == 0, "lsfa_amax_partial: x must be 16-byte aligned, n a positive multiple of 4");
   hipLaunchKernelGGL(convsplit::amax_partial_kernel, dim3(convsplit::kAmaxSlots), dim3(256), 0, (hipStream_t)stream, (const float4*)x,
@@ -622,9 +686,10 @@ extern "C" int lsfa_status_check(unsigned* status_dev, void* stream) {
   e = hipMemsetAsync(status_dev, 0, sizeof(unsigned), s);
   if (e == hipSuccess) e = hipStreamSynchronize(s);
   if (e != hipSuccess) return hip_fail(e, "lsfa_status_check");
-  set_error("lsfa_status_check: status 0x%x:%s%s", h,
+  set_error("lsfa_status_check: status 0x%x:%s%s%s", h,
             (h & 1u) ? " a convolution produced a non-finite output (fp16 two-piece form: amax_in under-estimates max|x|, or the input held inf / NaN)" : "",
-            (h & 2u) ? " a convolution's input maximum was inf / NaN" : "");
+            (h & 2u) ? " a convolution's input maximum was inf / NaN" : "",
+            (h & 4u) ? " a grid barrier of lsfa_conv_chain_fwd timed out (its workgroups were not resident together): the chain's outputs are incomplete" : "");
   return LSFA_EOVERFLOW;
 }
 

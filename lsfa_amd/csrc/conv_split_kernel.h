@@ -918,22 +918,23 @@ __device__ __forceinline__ void direct_mma(const DirectOperands<PC>& o, f32x16& 
 // condition); any kh x kw, pads, dilation.  (Measured on the small net's 64 -> 64 3x3, 18 chunks: 3 waves x 6 chunks 12.3-14.0 us;
 // 9 waves x 2 chunks 17.8-18.3 us — the launch bound for 9 waves caps the registers below the two operand sets.)
 constexpr int kDirectMaxWaves = 3;
+
+// One 32-pixel x 64-channel output tile (bx, by) of convolution `a` by the `nw` first waves of the workgroup (every wave of the
+// workgroup must call it: there is a workgroup barrier inside).  red_dyn: max(nw - 1, 1) * 8 KB of LDS.
 template <int PC>
-static __global__ __launch_bounds__(64 * kDirectMaxWaves) void conv_split_direct_kernel(Args a) {
-  extern __shared__ __attribute__((aligned(16))) float red_dyn[];
+__device__ __forceinline__ void direct_tile(const Args& a, int bx, int by, int nx, int nw, float* red_dyn) {
   float (*red)[32 * 64] = reinterpret_cast<float (*)[32 * 64]>(red_dyn);
-  const int kDirectWaves = blockDim.x >> 6;
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   const int P = a.N * a.Ho * a.Wo;
-  const int m0 = blockIdx.x * 32;
+  const int m0 = bx * 32;
   const int cpt = a.Cin / kChunk, nchunks = a.kh * a.kw * cpt;
-  // this wave's run of the (tap, chunk) list
-  const float inv_nw = 1.0f / (float)kDirectWaves;
-  const int c_begin = fdiv(nchunks * wave, kDirectWaves, inv_nw), c_end = fdiv(nchunks * (wave + 1), kDirectWaves, inv_nw);
+  // this wave's run of the (tap, chunk) list (waves past nw: an empty run)
+  const float inv_nw = 1.0f / (float)nw;
+  const int c_begin = wave < nw ? fdiv(nchunks * wave, nw, inv_nw) : 0, c_end = wave < nw ? fdiv(nchunks * (wave + 1), nw, inv_nw) : 0;
   const int col_tiles = a.Cout / 32;
   const size_t wstride = (size_t)col_tiles * (128 * PC);
-  const uint4* wtile = a.wfrag + (size_t)(2 * blockIdx.y) * (128 * PC);
+  const uint4* wtile = a.wfrag + (size_t)(2 * by) * (128 * PC);
   // the lane's pixel and the 16 channels of a chunk it feeds (fragment role: row = lane & 31, k half = lane >> 5)
   const int pix = m0 + (lane & 31);
   const bool pix_ok = pix < P;
@@ -985,13 +986,13 @@ static __global__ __launch_bounds__(64 * kDirectMaxWaves) void conv_split_direct
     }
   }
   // the waves' partial sums meet in LDS: [wave - 1][reg][lane] (conflict-free), added in wave order by wave 0
-  if (wave > 0) {
+  if (wave > 0 && wave < nw) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) { red[wave - 1][r * 64 + lane] = acc0[r]; red[wave - 1][(16 + r) * 64 + lane] = acc1[r]; }
   }
   __syncthreads();
   if (wave > 0) return;
-  for (int w = 0; w < kDirectWaves - 1; ++w)
+  for (int w = 0; w < nw - 1; ++w)
 #pragma unroll
     for (int r = 0; r < 16; ++r) { acc0[r] = acc0[r] + red[w][r * 64 + lane]; acc1[r] = acc1[r] + red[w][(16 + r) * 64 + lane]; }
   if (PC == 2) {
@@ -1008,8 +1009,8 @@ static __global__ __launch_bounds__(64 * kDirectMaxWaves) void conv_split_direct
       T[row * 32 + (lane & 31)] = acc0[r];
       T[1024 + row * 32 + (lane & 31)] = acc1[r];
     }
-    const uint32_t mr = tile_rows_out<2>(a, T, m0, P, blockIdx.y * kWgCh, nullptr, lane);
-    publish_amax(mr, a.amax_out, a.status, blockIdx.y * gridDim.x + blockIdx.x);
+    const uint32_t mr = tile_rows_out<2>(a, T, m0, P, by * kWgCh, nullptr, lane);
+    publish_amax(mr, a.amax_out, a.status, by * nx + bx);
     return;
   }
   RowOut ro;
@@ -1020,8 +1021,88 @@ static __global__ __launch_bounds__(64 * kDirectMaxWaves) void conv_split_direct
     ro.base[r] = 0;
     if (p < P) { ro.valid |= 1u << r; ro.base[r] = out_pixel_base(a, p); }
   }
-  const uint32_t m = max(tile_store_max(a, ro, blockIdx.y * kWgCh + (lane & 31), acc0), tile_store_max(a, ro, blockIdx.y * kWgCh + 32 + (lane & 31), acc1));
-  publish_amax(m, a.amax_out, a.status, blockIdx.y * gridDim.x + blockIdx.x);
+  const uint32_t m = max(tile_store_max(a, ro, by * kWgCh + (lane & 31), acc0), tile_store_max(a, ro, by * kWgCh + 32 + (lane & 31), acc1));
+  publish_amax(m, a.amax_out, a.status, by * nx + bx);
+}
+
+template <int PC>
+static __global__ __launch_bounds__(64 * kDirectMaxWaves) void conv_split_direct_kernel(Args a) {
+  extern __shared__ __attribute__((aligned(16))) float red_dyn[];
+  direct_tile<PC>(a, blockIdx.x, blockIdx.y, gridDim.x, (int)(blockDim.x >> 6), red_dyn);
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// r4: a CHAIN of direct-form convolutions in one launch (the small net's stage 1 on every non-key frame: ten convolutions of 0.02 - 0.35
+// GFLOP whose launches cost more than their arithmetic).  A persistent grid walks the layers; layers that read an earlier layer's
+// output are separated by a grid barrier (arrive: agent-scope release + atomic add; wait: spin on the counter + agent-scope acquire -
+// on this part that writes back / invalidates the XCD's L2 so that maps written by one XCD are read correctly by another).  Each tile
+// is computed exactly as conv_split_direct_kernel computes it (same wave count per layer, same order of additions): the chain's
+// outputs are those of the separate launches bit for bit.  All workgroups must be resident together (the host caps the grid); a
+// barrier that does not complete within kChainSpin polls raises bit 2 of the status word and the workgroup leaves.
+constexpr int kChainMax = 12;            // 12 x sizeof(Args) stays under the 4 KB kernel-argument limit
+constexpr unsigned kChainSpin = 1u << 21;
+struct ChainArgs {
+  Args layer[kChainMax];
+  int n;
+  unsigned sync_mask;                    // bit l: a grid barrier before layer l
+  unsigned nw_packed;                    // 2 bits per layer: waves per tile - 1
+  unsigned* barrier;                     // one zeroed counter
+  unsigned* status;
+};
+static_assert(sizeof(ChainArgs) <= 4096, "the chain's layers travel as kernel arguments");
+
+__device__ __forceinline__ bool chain_barrier(unsigned* counter, unsigned target, unsigned* status) {
+  __syncthreads();
+  bool ok = true;
+  if (threadIdx.x == 0) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    unsigned spins = 0;
+    while (__hip_atomic_load(counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+      __builtin_amdgcn_s_sleep(2);
+      if (++spins > kChainSpin) { ok = false; break; }
+    }
+    if (!ok && status) atomicOr(status, 4u);
+  }
+  // every wave invalidates its view (the acquire half), after thread 0 has seen the counter
+  ok = __syncthreads_and((int)ok) != 0;
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+  return ok;
+}
+
+template <int PC>
+static __global__ __launch_bounds__(64 * kDirectMaxWaves) void conv_chain_kernel(ChainArgs c) {
+  extern __shared__ __attribute__((aligned(16))) float red_dyn[];
+  // the layers are read from the kernel-argument segment through a (uniform) pointer: indexing the by-value array with a run-time
+  // layer number would make the compiler copy it to scratch
+  const Args* layers = (const Args*)__builtin_amdgcn_kernarg_segment_ptr();      // ChainArgs::layer is the first member
+  unsigned arrived = 0;
+  for (int l = 0; l < c.n;) {
+    // a phase: layers l .. e - 1 with no barrier between them; its tiles are the layers' tiles one list after the other
+    int e = l + 1;
+    while (e < c.n && !((c.sync_mask >> e) & 1u)) ++e;
+    if (l > 0) {
+      arrived += gridDim.x;
+      if (!chain_barrier(c.barrier, arrived, c.status)) return;
+    }
+    int first = 0;
+    for (int k = l; k < e; ++k) {
+      const Args a = layers[k];
+      const int nx = (a.N * a.Ho * a.Wo + 31) >> 5, tiles = nx * (a.Cout / kWgCh);
+      const int nw = 1 + (int)((c.nw_packed >> (2 * k)) & 3u);
+      const float inv_nx = a.inv_nx;
+      // this workgroup's tiles of layer k: list positions first + t, dealt round-robin
+      int t = (int)blockIdx.x - first % (int)gridDim.x;
+      if (t < 0) t += gridDim.x;
+      for (; t < tiles; t += gridDim.x) {
+        const int by = fdiv(t, nx, inv_nx), bx = t - by * nx;
+        direct_tile<PC>(a, bx, by, nx, nw, red_dyn);
+        __syncthreads();                 // wave 0 is done with the LDS block before the next tile's sums arrive
+      }
+      first += tiles;
+    }
+    l = e;
+  }
 }
 
 // partial maxima of |x| for the fp16 form's scale: kAmaxSlots workgroups, slot b = max over its grid-stride share (0 for an empty share)

@@ -48,7 +48,7 @@ __global__ __launch_bounds__(256) void avgpool_kernel(const float* __restrict__ 
 __global__ __launch_bounds__(256) void stem_conv_kernel(const float* __restrict__ x, int H, int W, const float* __restrict__ in_scale,
                                                         const float* __restrict__ in_shift, const float* __restrict__ w_l,
                                                         const float* __restrict__ bias, int Ho, int Wo, int tiles_per_wg,
-                                                        const float* accum, int act, float* y) {
+                                                        const float* accum, int act, float* y, unsigned* __restrict__ amax_out) {
   __shared__ __attribute__((aligned(16))) float in_s[kStemCin][kInRows][kInPitch];
   const int tid = threadIdx.x, co = tid & 63, row = tid >> 6;
   const int n = blockIdx.z, oy0 = blockIdx.y * kTileRows;
@@ -61,6 +61,7 @@ __global__ __launch_bounds__(256) void stem_conv_kernel(const float* __restrict_
   const float sc0 = in_scale ? in_scale[0] : 1.f, sc1 = in_scale ? in_scale[1] : 1.f, sc2 = in_scale ? in_scale[2] : 1.f;
   const float sh0 = in_shift ? in_shift[0] : 0.f, sh1 = in_shift ? in_shift[1] : 0.f, sh2 = in_shift ? in_shift[2] : 0.f;
   const int oy = oy0 + row;
+  float top = 0.f;                        // max |y| this thread stored
   for (int t = 0; t < tiles_per_wg; ++t) {
     const int ox0 = (blockIdx.x * tiles_per_wg + t) * kTileCols;
     if (ox0 >= Wo) break;
@@ -106,9 +107,17 @@ __global__ __launch_bounds__(256) void stem_conv_kernel(const float* __restrict_
         if (ox0 + p < Wo) {
           float v = acc[p] + b;
           if (accum) v = v + accum[(((size_t)n * Ho + oy) * Wo + ox0 + p) * kStemCout + co];
-          out[(size_t)(ox0 + p) * kStemCout] = act == 1 ? fmaxf(v, 0.f) : (act == 2 ? (v > 0.f ? v : v * 0.1f) : v);
+          v = act == 1 ? fmaxf(v, 0.f) : (act == 2 ? (v > 0.f ? v : v * 0.1f) : v);
+          out[(size_t)(ox0 + p) * kStemCout] = v;
+          top = fmaxf(top, fabsf(v));
         }
     }
+  }
+  if (amax_out) {      // the slots lsfa_conv_fwd reads as amax_in
+    uint32_t m = __float_as_uint(top);
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) m = max(m, (uint32_t)__shfl_xor((int)m, d, 64));
+    if (co == 0) atomicMax(amax_out + ((((blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * 4 + row) & 255), m);
   }
 }
 
@@ -116,9 +125,11 @@ __global__ __launch_bounds__(256) void stem_conv_kernel(const float* __restrict_
 // y2 (optional): max(y * scale2[c] + shift2[c], 0), the first unit's bn1 + relu1 of the pooled map, as a second output.
 __global__ __launch_bounds__(256) void maxpool3x3s2_kernel(const float4* __restrict__ x, int N, int H, int W, int C4, int Ho, int Wo,
                                                            float4* __restrict__ y, float4* __restrict__ y2,
-                                                           const float4* __restrict__ scale2, const float4* __restrict__ shift2) {
+                                                           const float4* __restrict__ scale2, const float4* __restrict__ shift2,
+                                                           unsigned* __restrict__ amax_out) {
   const long i = (long)blockIdx.x * 256 + threadIdx.x;
-  if (i >= (long)N * Ho * Wo * C4) return;
+  float top = 0.f;        // max |.| of what this thread hands to the next convolution (y2 when present, else y)
+  if (i < (long)N * Ho * Wo * C4) {
   const int c = (int)(i % C4);
   long r = i / C4;
   const int ox = (int)(r % Wo); r /= Wo;
@@ -134,8 +145,17 @@ __global__ __launch_bounds__(256) void maxpool3x3s2_kernel(const float4* __restr
   y[i] = m;
   if (y2) {
     const float4 sc = scale2[c], sh = shift2[c];
-    y2[i] = make_float4(fmaxf(m.x * sc.x + sh.x, 0.f), fmaxf(m.y * sc.y + sh.y, 0.f), fmaxf(m.z * sc.z + sh.z, 0.f),
-                        fmaxf(m.w * sc.w + sh.w, 0.f));
+    m = make_float4(fmaxf(m.x * sc.x + sh.x, 0.f), fmaxf(m.y * sc.y + sh.y, 0.f), fmaxf(m.z * sc.z + sh.z, 0.f),
+                    fmaxf(m.w * sc.w + sh.w, 0.f));
+    y2[i] = m;
+  }
+  top = fmaxf(fmaxf(fabsf(m.x), fabsf(m.y)), fmaxf(fabsf(m.z), fabsf(m.w)));
+  }
+  if (amax_out) {      // the slots lsfa_conv_fwd reads as amax_in (bit patterns of non-negative floats order like the floats)
+    uint32_t b = __float_as_uint(top);
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) b = max(b, (uint32_t)__shfl_xor((int)b, d, 64));
+    if ((threadIdx.x & 63) == 0) atomicMax(amax_out + ((blockIdx.x * 4 + (threadIdx.x >> 6)) & 255), b);
   }
 }
 
@@ -154,11 +174,12 @@ extern "C" int lsfa_avgpool_nchw(const float* x, int N, int C, int H, int W, int
 
 extern "C" int lsfa_stem_conv7x7s2(const float* x, int N, int H, int W, const float* in_scale, const float* in_shift,
                                    const float* w_l, const float* bias, float* y, void* stream) {
-  return lsfa_stem_conv7x7s2_ex(x, N, H, W, in_scale, in_shift, w_l, bias, nullptr, 1, y, stream);
+  return lsfa_stem_conv7x7s2_ex(x, N, H, W, in_scale, in_shift, w_l, bias, nullptr, 1, y, nullptr, stream);
 }
 
 extern "C" int lsfa_stem_conv7x7s2_ex(const float* x, int N, int H, int W, const float* in_scale, const float* in_shift,
-                                      const float* w_l, const float* bias, const float* accum, int act, float* y, void* stream) {
+                                      const float* w_l, const float* bias, const float* accum, int act, float* y, unsigned* amax_out,
+                                      void* stream) {
   LSFA_REQUIRE(x && w_l && y, "lsfa_stem_conv7x7s2: NULL argument");
   LSFA_REQUIRE(act >= 0 && act <= 2, "lsfa_stem_conv7x7s2_ex: act must be 0, 1 or 2");
   LSFA_REQUIRE(N > 0 && H > 0 && W > 0, "lsfa_stem_conv7x7s2: bad shape");
@@ -172,13 +193,13 @@ extern "C" int lsfa_stem_conv7x7s2_ex(const float* x, int N, int H, int W, const
   if (tpw < 1) tpw = 1;
   if (tpw > xt) tpw = xt;
   hipLaunchKernelGGL(stem_conv_kernel, dim3((xt + tpw - 1) / tpw, yt, N), dim3(256), 0, (hipStream_t)stream, x, H, W, in_scale, in_shift,
-                     w_l, bias, Ho, Wo, tpw, accum, act, y);
+                     w_l, bias, Ho, Wo, tpw, accum, act, y, amax_out);
   LSFA_LAUNCH_CHECK("lsfa_stem_conv7x7s2");
   return LSFA_OK;
 }
 
 extern "C" int lsfa_maxpool3x3s2_nhwc(const float* x, int N, int H, int W, int C, float* y, float* y2, const float* scale2,
-                                      const float* shift2, void* stream) {
+                                      const float* shift2, unsigned* amax_out, void* stream) {
   LSFA_REQUIRE(x && y, "lsfa_maxpool3x3s2_nhwc: NULL argument");
   LSFA_REQUIRE(!y2 || (scale2 && shift2 && y2 != y), "lsfa_maxpool3x3s2_nhwc: y2 needs scale2 / shift2 and must not alias y");
   LSFA_REQUIRE(N > 0 && H > 0 && W > 0 && C > 0 && C % 4 == 0, "lsfa_maxpool3x3s2_nhwc: bad shape (C must be a multiple of 4)");
@@ -186,7 +207,7 @@ extern "C" int lsfa_maxpool3x3s2_nhwc(const float* x, int N, int H, int W, int C
   const long total = (long)N * Ho * Wo * (C / 4);
   ProfScope prof(LSFA_OP_STEM, (hipStream_t)stream);
   hipLaunchKernelGGL(maxpool3x3s2_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, (const float4*)x, N, H, W,
-                     C / 4, Ho, Wo, (float4*)y, (float4*)y2, (const float4*)scale2, (const float4*)shift2);
+                     C / 4, Ho, Wo, (float4*)y, (float4*)y2, (const float4*)scale2, (const float4*)shift2, amax_out);
   LSFA_LAUNCH_CHECK("lsfa_maxpool3x3s2_nhwc");
   return LSFA_OK;
 }

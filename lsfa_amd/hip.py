@@ -509,9 +509,9 @@ def stem_weight_layout(weight):
 
 
 @_on_tensor_device
-def stem_conv(x, w_l, bias, in_scale=None, in_shift=None, out=None, accum=None, act=1):
+def stem_conv(x, w_l, bias, in_scale=None, in_shift=None, out=None, accum=None, act=1, amax_out=None):
     """bn_data + conv0 (7x7, stride 2, pad 3) + bias (+ accum) + activation (0 none, 1 ReLU, 2 LeakyReLU 0.1):
-    x (N, 3, H, W) NCHW -> (N, Ho, Wo, 64) channels-last."""
+    x (N, 3, H, W) NCHW -> (N, Ho, Wo, 64) channels-last.  amax_out: a zeroed row of amax_slots() for max|out|."""
     x, w_l = _f32c(x, "x"), _f32c(w_l, "w_l")
     N, C, H, W = x.shape
     if C != 3 or tuple(w_l.shape) != (3, 7, 7, 64):
@@ -522,7 +522,7 @@ def stem_conv(x, w_l, bias, in_scale=None, in_shift=None, out=None, accum=None, 
     if accum is not None and (tuple(accum.shape) != tuple(out.shape) or not accum.is_contiguous()):
         raise LsfaError("stem_conv: accum must be a contiguous %s tensor" % (tuple(out.shape),))
     _check(lib().lsfa_stem_conv7x7s2_ex(_ptr(x), _ci(N), _ci(H), _ci(W), _ptr(in_scale), _ptr(in_shift), _ptr(w_l), _ptr(bias),
-                                        _ptr(accum), _ci(act), _ptr(out), _stream()), "lsfa_stem_conv7x7s2_ex")
+                                        _ptr(accum), _ci(act), _ptr(out), _ptr(amax_out), _stream()), "lsfa_stem_conv7x7s2_ex")
     return out
 
 
@@ -587,9 +587,11 @@ def avgpool2_nhwc(x):
 
 
 @_on_tensor_device
-def maxpool3x3s2_nhwc(x, out=None, scale2=None, shift2=None):
+def maxpool3x3s2_nhwc(x, out=None, scale2=None, shift2=None, amax_out=None):
     """(N, H, W, C) float32 channels-last -> (N, (H-1)//2+1, (W-1)//2+1, C): 3x3, stride 2, pad 1 max pooling.
-    With scale2 / shift2 (C): returns (pooled, max(pooled*scale2 + shift2, 0)) — the first unit's bn1 + relu1 in the same launch."""
+    With scale2 / shift2 (C): returns (pooled, max(pooled*scale2 + shift2, 0)) — the first unit's bn1 + relu1 in the same launch.
+    amax_out: a zeroed row of amax_slots() that receives the maximum of the map the next convolution reads (the second output
+    when there is one)."""
     x = _f32c(x, "x")
     N, H, W, C = x.shape
     Ho, Wo = (H - 1) // 2 + 1, (W - 1) // 2 + 1
@@ -597,7 +599,7 @@ def maxpool3x3s2_nhwc(x, out=None, scale2=None, shift2=None):
         out = torch.empty((N, Ho, Wo, C), device=x.device, dtype=torch.float32)
     out2 = torch.empty_like(out) if scale2 is not None else None
     _check(lib().lsfa_maxpool3x3s2_nhwc(_ptr(x), _ci(N), _ci(H), _ci(W), _ci(C), _ptr(out), _ptr(out2), _ptr(scale2), _ptr(shift2),
-                                        _stream()), "lsfa_maxpool3x3s2_nhwc")
+                                        _ptr(amax_out), _stream()), "lsfa_maxpool3x3s2_nhwc")
     return out if out2 is None else (out, out2)
 
 

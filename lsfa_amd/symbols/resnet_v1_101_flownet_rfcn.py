@@ -365,8 +365,8 @@ class Executor(object):
         units = [u for u in net.units if u['stage'] <= stages]
         # bn_data + conv0 + bn0 + relu0, then pool0 with the first unit's bn1 + relu1 as a second output: two launches
         y = hip.stem_conv(x, net.conv0_w_l, net.conv0_b, net.bn_data[0], net.bn_data[1])
-        x4, a = hip.maxpool3x3s2_nhwc(y, scale2=units[0]['bn1'][0], shift2=units[0]['bn1'][1])
-        am_a = None                # the stem's output has no producer epilogue: _conv scans it (one pass per ResNet call)
+        am_a = S.new()             # pool0 publishes the maximum of its second output like the convolutions' epilogues do
+        x4, a = hip.maxpool3x3s2_nhwc(y, scale2=units[0]['bn1'][0], shift2=units[0]['bn1'][1], amax_out=am_a)
         dilate = 1
         for ui, u in enumerate(units):
             first = u['unit'] == 1
@@ -375,8 +375,6 @@ class Executor(object):
             ud = dilate
             if first and u['stage'] == 4:
                 dilate = dilate * 2
-            if am_a is None and self.pieces == 2:
-                am_a = hip.amax_partial(a)
             am_c1, am_c2, am_n = S.new(), S.new(), S.new()
             c1 = self._conv(a, u['w1'], u['b1'], act=1, amax_in=am_a, amax_out=am_c1)                  # conv1 + folded bn2 + relu2
             if u['dcn']:
@@ -438,7 +436,6 @@ class Executor(object):
         N = img_cur.shape[0]
         st = self.status
         S = self._slots['flow'].begin()
-        two = self.flow_pieces == 2
 
         def cmap(h, w, c):      # a concatenated map with its channel count padded to a multiple of 32 (the padding stays zero)
             return torch.zeros((N, h, w, -(-c // 32) * 32), device=dev, dtype=torch.float32)
@@ -468,8 +465,8 @@ class Executor(object):
         # avg pool 2x2 of each image (x 1/255 folded into the first convolution's input affine), flow_conv1 as two passes
         pc, pr = hip.avgpool_nchw(img_cur, 2), hip.avgpool_nchw(img_ref.contiguous(), 2)
         r1 = hip.stem_conv(pc, o['c1_cur'], None, o['in_scale'], o['in_shift'], act=0)
-        r1 = hip.stem_conv(pr, o['c1_ref'], fw['flow_conv1_bias'], o['in_scale'], o['in_shift'], out=r1, accum=r1, act=LEAKY)
-        am_r1 = hip.amax_partial(r1) if two else None            # the stem kernel has no amax epilogue: one scan
+        am_r1 = S.new()
+        r1 = hip.stem_conv(pr, o['c1_ref'], fw['flow_conv1_bias'], o['in_scale'], o['in_shift'], out=r1, accum=r1, act=LEAKY, amax_out=am_r1)
         h2, w2 = out_hw(r1.shape[1], r1.shape[2], 5, 2, 2)
         c5, am5 = cmap(h2, w2, 194), S.new()
         conv(r1, am_r1, 'conv2', 2, 2, out=c5, am_out=am5)                # r2 = c5[..., :128]

@@ -23,11 +23,14 @@ feat = torch.randn(1, 1024, 38, 63, device=dev)
 mv = torch.randn(1, 2, 38, 63, device=dev) * 0.5
 res = torch.randn(1, 3, 38, 63, device=dev)
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 30
+R, ncls = cfg.TEST.RPN_POST_NMS_TOP_N, cfg.dataset.NUM_CLASSES
+bufs = (torch.zeros((ncls, R, 5), dtype=torch.float64, device=dev), torch.zeros(ncls, dtype=torch.int32, device=dev),
+        torch.full((ncls, R), -1, dtype=torch.int32, device=dev))      # what core/graphs.py hands lsfa_det_postprocess: static buffers
 if os.environ.get('LSFA_TUNED', '1') == '1':
     tuning.enable()
 with torch.no_grad():
     for _ in range(n):
         out = cur.forward(data=data, im_info=im_info, feat_key=feat, motion_vector=mv, res_diff=res)
         hip.det_postprocess(out['rois_output'], out['bbox_pred_reshape_output'][0], out['cls_prob_reshape_output'][0], H, W, 1.0,
-                            nms_thresh=cfg.TEST.NMS, max_per_image=cfg.TEST.max_per_image, class_agnostic=cfg.CLASS_AGNOSTIC)
+                            nms_thresh=cfg.TEST.NMS, max_per_image=cfg.TEST.max_per_image, class_agnostic=cfg.CLASS_AGNOSTIC, out=bufs)
 torch.cuda.synchronize()

@@ -1,61 +1,74 @@
 #!/usr/bin/env python
-"""Durations of the pipeline's graph replays while the whole pipeline is running (HIP events on
-each replay's own stream): where does a step's time go under contention?"""
-import os, sys, time, collections
-import torch
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..'))
-import bench
-from lsfa_amd import tuning
-from lsfa_amd.core import graphs
-tuning.enable()
-torch.backends.cudnn.benchmark = True
-sys.argv = ['bench.py', '--no-cpu-baseline'] + sys.argv[1:]
-args = bench.parse()
-r = bench.Runner(args, 0, 'cuda:0')
-r.prime()
-for s in range(3):
-    r.step(s)
-r.fg.flush()
-torch.cuda.synchronize()
-rec = collections.defaultdict(list)
-t_origin = torch.cuda.Event(enable_timing=True)
+"""Where the pipelined frame loop's wall time goes, per hardware queue, from a rocprofv3 --kernel-trace directory (run on the GPU box):
+for the last `frac` of the run - per queue: launches, busy time (union of its kernels), idle time inside its span and the largest idle
+gaps with the kernels either side; over all queues: the time during which no kernel at all was running.
 
-def timed(name, fn):
-    def wrapper(*a, **k):
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record(); out = fn(*a, **k); e1.record()
-        rec[name].append((e0, e1))
-        return out
-    return wrapper
+    rocprofv3 --kernel-trace --output-format csv -d DIR -o t -- python3 bench.py --steps 30 --no-cpu-baseline --no-parity
+    python3 tools/pipeline_timeline.py DIR [frac]
+"""
+import collections
+import csv
+import glob
+import sys
 
-fp = r.fg
-for lane in fp.klanes:
-    for n in ('run_front', 'run_flow', 'run_agg', 'run_tail'):
-        setattr(lane, n, timed(n[4:], getattr(lane, n)))
-for i, lane in enumerate(fp.lanes):
-    lane.cur_frame = timed('cur_frame', lane.cur_frame)
-t_origin.record()
-n = 10
-t0 = time.perf_counter()
-for s in range(3, 3 + n):
-    r.step(s)
-fp.flush()
-torch.cuda.synchronize()
-wall = (time.perf_counter() - t0) / n * 1e3
-print('wall %.2f ms/step' % wall)
-for name, evs in rec.items():
-    d = [a.elapsed_time(b) for a, b in evs]
-    st = [t_origin.elapsed_time(a) for a, _ in evs]
-    print('%-10s n=%3d  mean %.3f ms  min %.3f  max %.3f   per step %.2f ms' % (name, len(d), sum(d) / len(d), min(d), max(d), sum(d) / n))
-# timeline of one steady-state step (the 6th): start/end relative to its front start
-k = 5
-f0 = rec['front'][k][0]
-for name in ('front', 'flow', 'agg', 'tail'):
-    a, b = rec[name][k]
-    print('step %d %-6s start %7.3f end %7.3f' % (k, name, f0.elapsed_time(a), f0.elapsed_time(b)))
-a, b = rec['front'][k + 1]
-print('step %d front  start %7.3f end %7.3f' % (k + 1, f0.elapsed_time(a), f0.elapsed_time(b)))
-print('non-key frames of step %d (queued after key frame %d):' % (k, k + 1))
-for j in range(9 * k, 9 * k + 9):
-    a, b = rec['cur_frame'][j]
-    print('   cur %d start %7.3f end %7.3f' % (j - 9 * k + 1, f0.elapsed_time(a), f0.elapsed_time(b)))
+
+def short(name):
+    name = name.replace('(anonymous namespace)::', '').replace('lsfa::', '').replace('convsplit::', '').replace('void ', '')
+    return name.split('(')[0][:44]
+
+
+def main(d, frac=0.5):
+    f = glob.glob(d + '/**/*kernel_trace.csv', recursive=True)
+    rows = list(csv.DictReader(open(f[0])))
+    rows.sort(key=lambda r: int(r['Start_Timestamp']))
+    caps = [i for i, r in enumerate(rows) if 'det_cap_kernel' in r['Kernel_Name']]
+    start = caps[int(len(caps) * (1 - frac))]
+    nframes = len([i for i in caps if i > start])
+    rows = rows[start + 1:]
+    t0, t1 = int(rows[0]['Start_Timestamp']), max(int(r['End_Timestamp']) for r in rows)
+    wall = (t1 - t0) / 1e3
+    print('window: %d frames, wall %.1f us (%.1f us per frame)' % (nframes, wall, wall / nframes))
+    qkey = 'Queue_Id' if 'Queue_Id' in rows[0] else 'Stream_Id'
+    byq = collections.defaultdict(list)
+    for r in rows:
+        byq[r[qkey]].append((int(r['Start_Timestamp']), int(r['End_Timestamp']), r['Kernel_Name']))
+    # all queues: union of busy intervals
+    ev = sorted((s, e) for q in byq.values() for s, e, _ in q)
+    cur_s, cur_e, union = ev[0][0], ev[0][1], 0
+    for s, e in ev[1:]:
+        if s > cur_e:
+            union += cur_e - cur_s
+            cur_s, cur_e = s, e
+        else:
+            cur_e = max(cur_e, e)
+    union += cur_e - cur_s
+    print('some kernel running: %.1f %% of the wall time; sum of kernel durations / wall = %.2f' %
+          (100.0 * union / 1e3 / wall, sum(e - s for s, e in ev) / 1e3 / wall))
+    for q, ks in sorted(byq.items(), key=lambda kv: -sum(e - s for s, e, _ in kv[1])):
+        ks.sort()
+        busy = sum(e - s for s, e, _ in ks) / 1e3
+        span = (ks[-1][1] - ks[0][0]) / 1e3
+        gaps = [(ks[i + 1][0] - ks[i][1], ks[i][2], ks[i + 1][2]) for i in range(len(ks) - 1)]
+        idle = sum(max(g[0], 0) for g in gaps) / 1e3
+        names = collections.Counter(short(k) for _, _, k in ks)
+        print('\nqueue %s: %d launches, busy %.1f us (%.1f %% of wall), idle inside its span %.1f us; most frequent: %s' %
+              (q, len(ks), busy, 100.0 * busy / wall, idle, ', '.join('%s x%d' % kv for kv in names.most_common(3))))
+        hist = collections.Counter()
+        for g, _, _ in gaps:
+            us = g / 1e3
+            hist['<2' if us < 2 else '2-5' if us < 5 else '5-20' if us < 20 else '20-100' if us < 100 else '>100'] += 1
+        tot = {k: sum(max(g, 0) for g, _, _ in gaps if (lambda us: ('<2' if us < 2 else '2-5' if us < 5 else '5-20' if us < 20 else '20-100' if us < 100 else '>100'))(g / 1e3) == k) / 1e3
+               for k in hist}
+        print('   gaps between consecutive kernels (us): ' + ', '.join('%s: %d (%.0f us)' % (k, hist[k], tot[k]) for k in ('<2', '2-5', '5-20', '20-100', '>100') if k in hist))
+        ctx = collections.defaultdict(lambda: [0, 0.0])
+        for g, a, b in gaps:
+            if g / 1e3 >= 20:
+                c = ctx[(short(a), short(b))]
+                c[0] += 1
+                c[1] += g / 1e3
+        for (a, b), (n, tt) in sorted(ctx.items(), key=lambda kv: -kv[1][1])[:6]:
+            print('   %4d gaps >= 20 us, %8.0f us in all: after %-40s before %s' % (n, tt, a, b))
+
+
+if __name__ == '__main__':
+    main(sys.argv[1], float(sys.argv[2]) if len(sys.argv) > 2 else 0.5)

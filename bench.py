@@ -74,6 +74,11 @@ def parse():
     ap.add_argument('--lanes', type=int, default=2,
                     help='non-key frames of a segment alternate over this many streams while the next key frame runs on '
                          'its own stream (lsfa_amd.core.graphs.FramePipeline); 0 = strictly serial frames')
+    ap.add_argument('--segment', type=int, default=-1,
+                    help='non-key frames of a segment that go through the network in ONE pass, batch axis = frames (the reference\'s batch test '
+                         'symbol, resnet_v1_101_flownet_rfcn.py:661-751); -1 = interval - 1 when one clip runs pipelined, else 0 = frame by frame')
+    ap.add_argument('--key-group', type=int, default=3,
+                    help='key frames whose image-only half (backbone, FlowNet) is computed in one pass (FramePipeline key_group); 1 = one by one')
     ap.add_argument('--lookahead', action='store_true',
                     help='queue each key frame ahead of the non-key frames that precede it in display order')
     ap.add_argument('--no-flow-stream', action='store_true', help='FlowNet after the backbone on the key stream instead of beside it')
@@ -119,12 +124,18 @@ class Runner(object):
         n_d, n_c = self.B * ncls * R * 5, (self.B * ncls * 4 + 7) // 8
         self.host_flat = torch.empty((self.K, n_d + n_c), dtype=torch.float64).pin_memory()
         self.host_dets = self.host_flat[:, :n_d].view(self.K, self.B, ncls, R, 5)
-        self._n_d, self.ncls = n_d, ncls
+        self._n_d, self.ncls, self._R = n_d, ncls, R
         from lsfa_amd.core.graphs import FrameGraphs, FramePipeline
+        one_clip_pipelined = args.lanes > 0 and self.B == 1
+        self.segment = (self.K - 1 if (one_clip_pipelined and self.K > 2) else 0) if args.segment < 0 else (args.segment if one_clip_pipelined else 0)
+        self.key_group = max(1, args.key_group) if one_clip_pipelined else 1
+        F = self.segment
+        self.host_seg = torch.empty(max(F, 1) * ncls * R * 5 + (max(F, 1) * ncls * 4 + 7) // 8, dtype=torch.float64).pin_memory()
         if args.lanes > 0:
             self.fg = FramePipeline(self.key, self.cur, cfg, args.height, args.width, device,
-                                    use_graphs=not args.no_graph, lanes=args.lanes,
-                                    flow_stream=not args.no_flow_stream, lookahead=args.lookahead, batch=self.B)
+                                    use_graphs=not args.no_graph, lanes=max(args.lanes, 2 if F else 1),
+                                    flow_stream=not args.no_flow_stream, lookahead=args.lookahead, batch=self.B,
+                                    segment=F, key_group=self.key_group)
         else:
             self.fg = FrameGraphs(self.key, self.cur, cfg, args.height, args.width, device, use_graphs=not args.no_graph,
                                   prefetch=not args.no_prefetch, batch=self.B)
@@ -139,8 +150,21 @@ class Runner(object):
         self.fg.first_frame(self.frames[0])
         self.fg.capture()
 
+    def _in_segment(self, slot):
+        """frame `slot` of the interval came back with its whole segment (one copy per segment, host_seg) rather than on its own"""
+        return self.segment > 0 and slot >= 1 and self.segment == self.K - 1
+
     def host_counts_of(self, slot):
+        if self._in_segment(slot):
+            F, n = self.segment, self.ncls
+            return self.host_seg[F * n * self._R * 5:].view(torch.int32)[:F * n].view(F, 1, n)[slot - 1]
         return self.host_flat[slot, self._n_d:].view(torch.int32)[:self.B * self.ncls].view(self.B, self.ncls)
+
+    def host_dets_of(self, slot):
+        if self._in_segment(slot):
+            F, n = self.segment, self.ncls
+            return self.host_seg[:F * n * self._R * 5].view(F, 1, n, self._R, 5)[slot - 1]
+        return self.host_dets[slot]
 
     @property
     def host_counts(self):
@@ -156,13 +180,22 @@ class Runner(object):
                 for j in range(1, self.ncls):
                     n = int(counts[k, b, j])
                     if n:
-                        d = self.host_dets[k, b, j, :n].numpy()
+                        d = self.host_dets_of(k)[b, j, :n].numpy()
                         r = np.empty((n, 7), np.float64)
                         r[:, 0], r[:, 1], r[:, 2], r[:, 3:] = k * self.B + b, j, d[:, 4], d[:, :4]
                         rows.append(r)
         return np.vstack(rows) if rows else np.zeros((0, 7), np.float64)
 
     def _deliver(self, bufs, slot):
+        seg = getattr(bufs[0], 'lsfa_segment', None)
+        if seg is not None:          # a frame of a batched segment: the whole segment's results leave the device with its last frame, in one copy
+            flat, f, F = seg
+            if f == F - 1 and flat.numel() == self.host_seg.numel():
+                self.host_seg.copy_(flat, non_blocking=True)
+            elif flat.numel() != self.host_seg.numel():
+                self.host_dets[slot].copy_(bufs[0].view(self.host_dets[slot].shape), non_blocking=True)
+                self.host_counts_of(slot).copy_(bufs[1].view(self.B, self.ncls), non_blocking=True)
+            return
         flat = getattr(bufs[0], 'lsfa_flat', None)
         if flat is not None and flat.numel() == self.host_flat.shape[1]:
             self.host_flat[slot].copy_(flat, non_blocking=True)
@@ -170,12 +203,15 @@ class Runner(object):
             self.host_dets[slot].copy_(bufs[0].view(self.host_dets[slot].shape), non_blocking=True)
             self.host_counts_of(slot).copy_(bufs[1].view(self.B, self.ncls), non_blocking=True)
 
-    def step(self, s, fg=None):
-        """One key-frame interval: key frame (flag 1) + K-1 non-key frames (flag 2)."""
+    def step(self, s, fg=None, end=None):
+        """One key-frame interval: key frame (flag 1) + K-1 non-key frames (flag 2).  end: one past the last step of the run of consecutive
+        steps this one belongs to (key_group: only key frames of the same run are looked ahead at)."""
         fg = fg or self.fg
         kf = 1 + (s % self.nsteps_unique) * self.K
         if hasattr(fg, 'lanes'):      # pipelined: frames are queued in order, copies ride on each frame's stream
-            fg.key_frame(self.frames[kf], deliver=lambda b: self._deliver(b, 0))
+            ahead = range(s + 1, s + self.key_group if end is None else min(s + self.key_group, end))
+            fg.key_frame(self.frames[kf], deliver=lambda b: self._deliver(b, 0),
+                         upcoming=[self.frames[1 + (j % self.nsteps_unique) * self.K] for j in ahead] if self.key_group > 1 else None)
             for i in range(1, self.K):
                 fg.cur_frame(self.frames[kf + i], self.mv[kf + i], self.res[kf + i],
                              deliver=lambda b, i=i: self._deliver(b, i))
@@ -210,6 +246,63 @@ class Runner(object):
         self.conv_flops1 = self.hip.conv_flops_one_product()
         self.hip.conv_flops_reset(False)
         self.hip.prof_enable(False)
+        return prof
+
+    def eager_profile_batched(self, s):
+        """The roofline leg of the batched pipeline: G consecutive intervals the way FramePipeline(segment, key_group) computes them - one pass
+        for the G key fronts, per key frame aggregation + heads + detections, one pass per segment - issued eagerly on ONE stream with the
+        per-kernel event hooks on (nothing overlaps: the durations are the kernels' own).  -> {op: (total_ms, launches)} over the G intervals."""
+        from lsfa_amd.core import graphs
+        G, F, K, cfg, hip = self.key_group, self.segment, self.K, self.cfg, self.hip
+        key, cur, fg = self.key, self.cur, self.fg
+        H, W = self.args.height, self.args.width
+        kfs = [1 + ((s + j) % self.nsteps_unique) * K for j in range(G)]
+        imgs = torch.cat([self.frames[k] for k in kfs], 0)
+        olds = torch.cat([fg.data_key_old] + [self.frames[k] for k in kfs[:-1]], 0)
+        feat0 = fg.feat.clone()
+        im1 = fg.klanes[0].im_info
+        R, ncls = cfg.TEST.RPN_POST_NMS_TOP_N, cfg.dataset.NUM_CLASSES
+        post1, _ = graphs._alloc_post(1, ncls, R, self.device)
+        postF, _ = graphs._alloc_post(max(F, 1), ncls, R, self.device)
+        imF = im1.expand(max(F, 1), -1).contiguous()
+        segs = []
+        for kf in kfs:
+            idx = list(range(kf + 1, kf + K))
+            segs.append((torch.cat([self.frames[i] for i in idx], 0), torch.cat([self.mv[i] for i in idx], 0), torch.cat([self.res[i] for i in idx], 0)) if idx else None)
+
+        def run():
+            conv = key.key_backbone(imgs)
+            flow, scale = key.key_flow(imgs, olds)
+            f = feat0
+            for i in range(G):
+                f = key.key_aggregate(conv[i:i + 1], flow[i:i + 1], scale[i:i + 1], f)
+                graphs._post_all(key.key_heads(f, im1), post1, cfg, H, W, 1.0, fg.thresh)
+                if segs[i] is None:
+                    continue
+                d, m, r_ = segs[i]
+                if F == K - 1:
+                    graphs._post_all(cur.forward(data=d, im_info=imF, feat_key=f, motion_vector=m, res_diff=r_), postF, cfg, H, W, 1.0, fg.thresh)
+                else:
+                    for j in range(K - 1):
+                        graphs._post_all(cur.forward(data=d[j:j + 1], im_info=im1, feat_key=f, motion_vector=m[j:j + 1], res_diff=r_[j:j + 1]),
+                                         post1, cfg, H, W, 1.0, fg.thresh)
+        run()                # warm
+        torch.cuda.synchronize()
+        hip.prof_enable(True, ops=self.OPS)
+        hip.prof_read()
+        hip.conv_flops_reset(True)
+        run()
+        torch.cuda.synchronize()
+        prof = hip.prof_read()
+        self.conv_flops = hip.conv_flops_read()
+        self.conv_flops3 = hip.conv_flops_three_products()
+        self.conv_flops1 = hip.conv_flops_one_product()
+        hip.conv_flops_reset(False)
+        hip.prof_enable(False)
+        C, hw = cfg.network.DFF_FEAT_DIM, (-(-H // 16)) * (-(-W // 16))
+        per_seg = ((1 + 2 * F) * C * hw + 2 * F * hw) * 4 if F == K - 1 else (K - 1) * warp_bytes(1, C, hw)
+        self.warp_bytes_total = G * (warp_bytes(1, C, hw) + (per_seg if K > 1 else 0))
+        self.profiled_intervals = G
         return prof
 
     def many_maps_leg(self, M, iters=10):
@@ -259,6 +352,60 @@ class Runner(object):
         result["reference: torch.mul of the same three tensors"] = {"avg_us": round(us, 2), "achieved_GBps": round(3 * feat.numel() * 4 / us / 1e3, 1)}
         return result
 
+    def _gpu_frames_batched(self, im_info):
+        """Frames 1 (key) .. K of clip 0 computed the way the batched pipeline computes them (FramePipeline segment / key_group: the key
+        frame's front in one pass with the next key frames', the non-key frames in one pass), eagerly with taps on, each frame cut out of
+        its batch: what the parity leg judges is the arithmetic the timed region ran."""
+        from oracle import e2e as e2e_mod
+        from lsfa_amd.core import graphs
+        cfg, K, H, W, key, cur, hip = self.cfg, self.K, self.args.height, self.args.width, self.key, self.cur, self.hip
+        one = lambda t: t[:1]
+        R, ncls = cfg.TEST.RPN_POST_NMS_TOP_N, cfg.dataset.NUM_CLASSES
+        im1 = torch.from_numpy(im_info).to(self.device)
+        with torch.no_grad():
+            out0 = key.forward(data=one(self.frames[0]), im_info=im1, data_key_old=one(self.frames[0]),
+                               feat_key_old=torch.zeros((1, cfg.network.DFF_FEAT_DIM, 1, 1), device=self.device))
+            feat0 = out0['choose_feat_output'].clone()
+            G = max(1, min(self.key_group, self.nsteps_unique))
+            kfs = [1 + j * K for j in range(G)]
+            imgs = torch.cat([one(self.frames[k]) for k in kfs], 0)
+            olds = torch.cat([one(self.frames[0])] + [one(self.frames[k]) for k in kfs[:-1]], 0)
+            conv = key.key_backbone(imgs)
+            flow, scale = key.key_flow(imgs, olds)
+            key.taps = {}
+            feat1 = key.key_aggregate(conv[0:1], flow[0:1], scale[0:1], feat0)
+            out1 = key.key_heads(feat1, im1)
+            taps1 = dict(key.taps, backbone_feat=conv[0:1])
+            key.taps = None
+            post1, _ = graphs._alloc_post(1, ncls, R, self.device)
+            graphs._post_all(out1, post1, cfg, H, W, 1.0, self.fg.thresh)
+            gpu = {1: dict(taps=taps1, out=out1, dets=post1[0][0].cpu().numpy().copy(), counts=post1[1][0].cpu().numpy().copy(), prev=feat0)}
+            idx = list(range(2, K + 1))
+            F = len(idx)
+            if F and self.segment == F:
+                cur.taps = {}
+                outF = cur.forward(data=torch.cat([one(self.frames[i]) for i in idx], 0), im_info=im1.expand(F, -1).contiguous(), feat_key=feat1,
+                                   motion_vector=torch.cat([one(self.mv[i]) for i in idx], 0), res_diff=torch.cat([one(self.res[i]) for i in idx], 0))
+                tapsF = dict(cur.taps)
+                cur.taps = None
+                postF, _ = graphs._alloc_post(F, ncls, R, self.device)
+                graphs._post_all(outF, postF, cfg, H, W, 1.0, self.fg.thresh)
+                for j, i in enumerate(idx):
+                    t, o = e2e_mod.image_of_batch(tapsF, outF, j, F)
+                    gpu[i] = dict(taps=t, out=o, dets=postF[0][j].cpu().numpy().copy(), counts=postF[1][j].cpu().numpy().copy(),
+                                  key_feat=feat1, mv=one(self.mv[i]), res=one(self.res[i]))
+            else:
+                for i in idx:
+                    cur.taps = {}
+                    o = cur.forward(data=one(self.frames[i]), im_info=im1, feat_key=feat1, motion_vector=one(self.mv[i]), res_diff=one(self.res[i]))
+                    t = dict(cur.taps)
+                    cur.taps = None
+                    graphs._post_all(o, post1, cfg, H, W, 1.0, self.fg.thresh)
+                    gpu[i] = dict(taps=t, out=o, dets=post1[0][0].cpu().numpy().copy(), counts=post1[1][0].cpu().numpy().copy(),
+                                  key_feat=feat1, mv=one(self.mv[i]), res=one(self.res[i]))
+        torch.cuda.synchronize()
+        return gpu
+
     def parity_and_cpu_baseline(self, budget_s, want_parity):
         """The oracle's statement of the clip's first frames (torch-CPU convs + C kernels), timed on the
         host (`cpu_baseline`, kind "port") and compared with the GPU's eager run of the same frames (`parity`).
@@ -273,7 +420,10 @@ class Runner(object):
         f = [npf(one(self.frames[i])) for i in range(0, K + 1)]
         # ---- GPU, eager, taps on, each frame on its own intermediate values -------------------------
         gpu = {}
-        if want_parity:
+        batched = hasattr(self.fg, 'lanes') and (self.segment > 0 or self.key_group > 1)
+        if want_parity and batched:
+            gpu = self._gpu_frames_batched(im_info)
+        elif want_parity:
             eg = FrameGraphs(self.key, self.cur, cfg, H, W, self.device, use_graphs=False, prefetch=False, taps=True, batch=1)
             eg.first_frame(one(self.frames[0]))
             eg.capture()
@@ -465,15 +615,20 @@ def main():
     # and went through the transition - three to six intervals of 7.5-9.7 ms instead of 5.6 - inside the first timed region in half of
     # the runs (profiles/r3/ab_experiments.txt section 9, tools/trace_regions.py)
     settle_drain = int(os.environ.get('LSFA_BENCH_SETTLE_DRAIN', '32'))
+    burst = settle_drain or 32
     while time.perf_counter() - t_settle < args.settle_s:
-        r.step(settle_steps)
+        r.step(settle_steps, end=(settle_steps // burst + 1) * burst)        # a burst is one run of consecutive steps
         settle_steps += 1
         if settle_drain and settle_steps % settle_drain == 0:
             drain()
+    if settle_steps % burst:
+        # the time limit cut the last burst short: the fronts it computed ahead are dropped (FramePipeline.first_frame-style reset)
+        if hasattr(r.fg, 'drop_fronts'):
+            r.fg.drop_fronts()
     if settle_drain:
         drain()
     for s in range(args.warmup):
-        r.step(s)
+        r.step(s, end=args.warmup)
     drain()
 
     def barrier():
@@ -484,7 +639,7 @@ def main():
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for s in range(args.warmup, args.warmup + args.steps):
-        r.step(s)
+        r.step(s, end=args.warmup + args.steps)
     drain()
     barrier()
     elapsed = time.perf_counter() - t0
@@ -497,12 +652,13 @@ def main():
         torch.cuda.synchronize()
         t1 = time.perf_counter()
         for s in range(args.warmup, args.warmup + args.steps):
-            r.step(s)
+            r.step(s, end=args.warmup + args.steps)
         host_enqueue.append(time.perf_counter() - t1)
         drain()
         barrier()
         repeats.append(time.perf_counter() - t1)
-    prof = r.eager_profile_step(args.warmup) if rank == 0 else None
+    batched = hasattr(r.fg, 'lanes') and (r.segment > 0 or r.key_group > 1)
+    prof = (r.eager_profile_batched(args.warmup) if batched else r.eager_profile_step(args.warmup)) if rank == 0 else None
 
     # an overflow of the fp16 form's scale anywhere in the run is an error, not a number (outside the timed regions: it synchronises)
     r.key.check_status()
@@ -550,6 +706,8 @@ def main():
         # ---- roofline: the HBM-bound hand-written kernel (warp), live from HIP events ---------------------
         warp_ms, warp_n = prof['warp_bilinear']
         bytes_per_launch = warp_bytes(B, C, fh * fw)
+        if getattr(r, 'warp_bytes_total', None):       # batched pipeline: launches of one map (key frames) and of a segment's maps (one shared key feature)
+            bytes_per_launch = r.warp_bytes_total // max(warp_n, 1)
         achieved = bytes_per_launch * warp_n / (warp_ms * 1e-3) / 1e9 if warp_ms > 0 else 0.0
         ops = {k: {"avg_us": round(v[0] * 1e3 / v[1], 2), "launches": v[1], "total_us": round(v[0] * 1e3, 1)}
                for k, v in prof.items() if v[1]}
@@ -583,7 +741,8 @@ def main():
             mfma_work = 6 * fl6 + 3 * fl3 + fl1          # matrix-instruction FLOPs actually issued
             mix_peak = conv_fl / (mfma_work / MFMA_BF16_PEAK_TFLOPS)
             roof = {"bound": "mfma", "kernel": "the split-operand convolution family behind lsfa_conv_fwd (ring / halo / direct kernels + their reduce passes): "
-                    "every convolution of ResNet-101 + DCN, feat_conv_3x3, the small net, fuse_reduce_add, FlowNet, the Nq net; %d calls of one interval" % conv_n,
+                    "every convolution of ResNet-101 + DCN, feat_conv_3x3, the small net, fuse_reduce_add, FlowNet, the Nq net; %d calls of %d interval(s)%s" %
+                    (conv_n, getattr(r, 'profiled_intervals', 1), " computed the way the pipeline batches them (key fronts x%d, segments of %d frames)" % (r.key_group, r.segment) if batched else ""),
                     "achieved": round(tf, 1), "peak": round(mix_peak, 1), "unit": "TFLOP/s",
                     "frac": round(tf / mix_peak, 4),
                     "flops_share_by_products_per_fp32_product": {"six (three bf16 pieces)": round(fl6 / conv_fl, 3), "three (two fp16 pieces)": round(fl3 / conv_fl, 3),
@@ -624,7 +783,11 @@ def main():
                        "pipeline": ("key stream%s + %d non-key lanes%s" % (
                            "" if args.no_flow_stream else " + FlowNet/tail stream", args.lanes,
                            ", next key frame queued ahead of the segment before it" if args.lookahead else ""))
-                       if args.lanes > 0 else "serial"},
+                       if args.lanes > 0 else "serial",
+                       "batching": ("one clip, frames in display order; the %d non-key frames of a segment go through the network in one pass (batch axis = "
+                                    "frames, like the reference's batch test symbol) and the image-only half (backbone, FlowNet) of %d consecutive key "
+                                    "frames in one pass (look-ahead of %d frames); --segment 0 --key-group 1 = frame by frame" %
+                                    (r.segment, r.key_group, (r.key_group - 1) * K)) if batched else "none: one frame per pass"},
             "value_spread": {"min": round(frames / max(repeats), 3), "max": round(frames / min(repeats), 3), "repeats": len(repeats),
                              "values": [round(frames / t, 3) for t in repeats],
                              "note": "the timed region run %d times back to back; `value` is the first" % len(repeats),

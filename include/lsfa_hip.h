@@ -203,6 +203,16 @@ int lsfa_det_postprocess(const float* rois, const float* deltas, const float* pr
                          double* dets, int* counts, int* keep_idx,
                          void* ws, size_t ws_bytes, void* stream);
 
+/* The same for the B images of a batch in one launch pair (the non-key frames of a segment, the clips of a lock-step batch): image b's rois /
+ * deltas / probs are rows [b*R, (b+1)*R) (MultiProposal's layout, multi_proposal.cu:560-575), its outputs dets[b] (ncls, R, 5), counts[b] (ncls),
+ * keep_idx[b] (ncls, R); one image size and scale for all (frames of one clip). */
+int lsfa_det_postprocess_batch(const float* rois, const float* deltas, const float* probs,
+                               int B, int R, int ncls, int nreg, int class_agnostic,
+                               double im_h, double im_w, double scale,
+                               double score_thresh, double nms_thresh, int max_per_image,
+                               double* dets, int* counts, int* keep_idx,
+                               void* ws, size_t ws_bytes, void* stream);
+
 /* Box decode + clip + rescale only (float64 out), for callers that keep the
  * reference's im_detect() signature:  tester.py:143-152. pred_boxes (R, 4*nreg) */
 int lsfa_bbox_pred_clip(const float* rois, const float* deltas, int R, int nreg,
@@ -410,7 +420,8 @@ int lsfa_mv_residual(const unsigned char* bgr_cur, const unsigned char* bgr_ref,
  * ------------------------------------------------------------------------ */
 int lsfa_stream_create(void** stream_out, int high_priority);
 int lsfa_stream_destroy(void* stream);
-/* up to four device-to-device copies of 4-byte elements (elems4[k] of them, dst[k] <- src[k]) as one launch */
+/* up to 32 device-to-device copies of 4-byte elements (elems4[k] of them, dst[k] <- src[k]) as one launch: a frame's - or a whole
+ * segment's - images, motion vectors and residuals into the static buffers a captured graph reads */
 int lsfa_copy_many(int njobs, void* const* dst, const void* const* src, const long* elems4, void* stream);
 
 /* ------------------------------------------------------------------------ *

@@ -48,23 +48,21 @@ def _stage_inputs(jobs):
     it (same device, fp32, contiguous, equal shapes), else plain copies."""
     ok = all(s.is_cuda and s.device == d.device and s.dtype == d.dtype and d.element_size() == 4 and s.shape == d.shape and
              s.is_contiguous() and d.is_contiguous() for d, s in jobs)
-    if ok and len(jobs) <= 4:
-        hip.copy_many(jobs)
+    if ok:
+        for i in range(0, len(jobs), 32):
+            hip.copy_many(jobs[i:i + 32])
     else:
         for d, s in jobs:
             d.copy_(s)
 
 
 def _post_all(out, full, cfg, h, w, scale, thresh):
-    """lsfa_det_postprocess per image of the batch (rois of image b are rows [b*R, (b+1)*R), MultiProposal's layout)."""
+    """lsfa_det_postprocess_batch: every image of the batch in one launch pair (rois of image b are rows [b*R, (b+1)*R), MultiProposal's layout)."""
     B = full[0].shape[0]
     R = out['rois_output'].shape[0] // B
     bbox, cls = out['bbox_pred_reshape_output'].reshape(B * R, -1), out['cls_prob_reshape_output'].reshape(B * R, -1)
-    for b in range(B):
-        sl = slice(b * R, (b + 1) * R)
-        hip.det_postprocess(out['rois_output'][sl], bbox[sl], cls[sl], h, w, scale, score_thresh=thresh,
-                            nms_thresh=cfg.TEST.NMS, max_per_image=cfg.TEST.max_per_image,
-                            class_agnostic=cfg.CLASS_AGNOSTIC, out=tuple(t[b] for t in full))
+    hip.det_postprocess_batch(out['rois_output'], bbox, cls, B, h, w, scale, full, score_thresh=thresh, nms_thresh=cfg.TEST.NMS,
+                              max_per_image=cfg.TEST.max_per_image, class_agnostic=cfg.CLASS_AGNOSTIC)
 
 
 class FrameGraphs(object):
@@ -265,6 +263,78 @@ class FrameGraphs(object):
         return self.post_bufs
 
 
+    def cur_segment(self, frames):
+        """The non-key frames of one segment in ONE pass, batch axis = frames (this instance was built with batch = len(frames) and a
+        shared (1, C, h, w) key feature: every frame of a segment is served from the same key frame).  frames: [(data, motion_vector,
+        res_diff), ...], one image each.  Returns the batched (dets, counts, keep_idx) buffers: frame f's results are index f."""
+        if len(frames) != self.batch or self.prefetch:
+            raise ValueError("cur_segment: this lane takes %d frames per pass (and no prefetch)" % self.batch)
+        jobs = []
+        for f, (data, mv, res) in enumerate(frames):
+            jobs += [(self.data[f:f + 1], data), (self.mv[f:f + 1], mv), (self.res[f:f + 1], res)]
+        _stage_inputs(jobs)
+        if self.use_graphs:
+            self.cur_graph.replay()
+        else:
+            self._cur_seq()
+        return self._post_full
+
+
+class KeyBank(object):
+    """The image-only half of G consecutive key frames in one pass (batch axis = key frames): backbone of each, FlowNet of each against
+    its predecessor.  The late ResNet stages run 38 x 63 maps: one frame's convolutions launch a fraction of a wave of workgroups per
+    K slice, three frames' fill the chip (measured per frame: backbone 3231 -> 2200 us, FlowNet 514 -> 289 us at G = 3,
+    profiles/r4/key_batch_probe.txt).  Key frame i of the group then takes conv_feat[i], flow[i], scale[i] for its aggregation."""
+
+    def __init__(self, key_exec, cfg, height, width, device, use_graphs, group, taps=False):
+        self.key, self.device, self.use_graphs, self.G = key_exec, device, use_graphs, int(group)
+        z = lambda *s: torch.zeros(s, device=device, dtype=torch.float32)
+        self.data = z(self.G, 3, height, width)
+        self.data_old = z(self.G, 3, height, width)
+        self.conv_feat = self.flow_out = None
+        self.front_graph = self.flow_graph = None
+        self.want_taps = taps
+
+    def front(self):
+        self.conv_feat = self.key.key_backbone(self.data)
+
+    def flow(self):
+        self.flow_out = self.key.key_flow(self.data, self.data_old)
+
+    def capture(self, warmup=2):
+        if not self.use_graphs:
+            return
+        s = self._capture_stream = streams.new_stream(self.device)
+        s.wait_stream(torch.cuda.current_stream(self.device))
+        with torch.cuda.stream(s):
+            for _ in range(warmup):
+                self.front()
+                self.flow()
+        torch.cuda.current_stream(self.device).wait_stream(s)
+        torch.cuda.synchronize(self.device)
+        self.front_graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.front_graph, stream=self._capture_stream):
+            self.front()
+        self._capture_stream_flow = streams.new_stream(self.device)
+        self.flow_graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.flow_graph, stream=self._capture_stream_flow):
+            self.flow()
+
+    def close(self):
+        self.front_graph = self.flow_graph = None
+        for name in ('_capture_stream', '_capture_stream_flow'):
+            st = getattr(self, name, None)
+            if st is not None:
+                streams.release(st)
+                setattr(self, name, None)
+
+    def run_front(self):
+        self.front_graph.replay() if self.use_graphs else self.front()
+
+    def run_flow(self):
+        self.flow_graph.replay() if self.use_graphs else self.flow()
+
+
 class KeyLane(object):
     """Static buffers and the captured parts of a key frame: `front` (backbone) and `flow` (FlowNet) need
     only images; `agg` (flow warp of the previous key feature x scale map, aggregation) produces the
@@ -408,7 +478,7 @@ class FramePipeline(object):
     """
 
     def __init__(self, key_exec, cur_exec, cfg, height, width, device, thresh=1e-4, use_graphs=True, lanes=2,
-                 flow_stream=True, lookahead=False, taps=False, batch=1, layout=None):
+                 flow_stream=True, lookahead=False, taps=False, batch=1, layout=None, segment=0, key_group=1):
         """batch > 1: that many clips advance in lock-step — every tensor handed to first_frame / key_frame /
         cur_frame carries one image (motion-vector field, residual) per clip on its batch axis, and the
         detection buffers gain a leading clip axis.
@@ -420,6 +490,11 @@ class FramePipeline(object):
         the same under every layout (tests/test_graph_gpu.py runs the pipeline under each)."""
         dev = torch.device(device)
         self.batch = B = int(batch)
+        self.segment, self.key_group = int(segment), int(key_group)
+        if (self.segment > 0 or self.key_group > 1) and B != 1:
+            raise ValueError("FramePipeline: segment / key_group batching is for one clip per pipeline (batch = 1)")
+        if self.segment > 0 and lanes < 2:
+            raise ValueError("FramePipeline: segment batching alternates over two lane streams (lanes >= 2)")
         self.device, self.cfg, self.key_exec = dev, cfg, key_exec
         self.h, self.w, self.thresh, self.scale = height, width, thresh, 1.0
         self.lookahead = lookahead
@@ -430,6 +505,17 @@ class FramePipeline(object):
         self.klanes = [KeyLane(key_exec, cfg, height, width, dev, thresh, use_graphs, taps, B) for _ in range(2)]
         self.lanes = [FrameGraphs(key_exec, cur_exec, cfg, height, width, dev, thresh, use_graphs, prefetch=False,
                                   feat_shared=self.feat_cur, taps=taps, batch=B) for _ in range(lanes)]
+        # segment > 0: the non-key frames of a segment (all served from one key feature) go through the network in ONE pass of `segment`
+        # frames on the batch axis - what the reference's own batch test symbol does (get_batch_test_symbol,
+        # resnet_v1_101_flownet_rfcn.py:661-751) - on two alternating lanes, each with its own copy of the key feature; a shorter run of
+        # non-key frames (the end of a clip) takes the per-frame lanes.  key_group > 1: see KeyBank and key_frame(upcoming=...).
+        self.feat_seg = [torch.zeros((1, dim, fh, fw), device=dev, dtype=torch.float32) for _ in range(2 if self.segment else 0)]
+        self.seg_lanes = [FrameGraphs(key_exec, cur_exec, cfg, height, width, dev, thresh, use_graphs, prefetch=False,
+                                      feat_shared=f, taps=taps, batch=self.segment) for f in self.feat_seg]
+        # one bank per group size 2 .. key_group: the tail of a run of key frames (fewer images ahead than key_group - 1) is a smaller group
+        self.banks = {g: KeyBank(key_exec, cfg, height, width, dev, use_graphs, g, taps) for g in range(2, self.key_group + 1)}
+        self._bank_ready = []                        # [(bank, slot, data_ptr)]: fronts of upcoming key frames already computed
+        self._next_seg = 0
         want = 1 + (1 if flow_stream else 0) + lanes
         layout = layout or os.environ.get('LSFA_STREAM_LAYOUT', 'probe')
         if layout == 'probe':
@@ -467,6 +553,10 @@ class FramePipeline(object):
         self._next = self._nkey = 0
         self._feat_latest = self._prev_key_data = None
         self._seg_feat = self._seg_event = None     # feature (and its event) the buffered segment is served from
+        # which key frame's feature the non-key lanes' copies hold (feat_cur, feat_seg[i]) against the one the current segment needs;
+        # _handed[b]: events of the copies taken from key buffer b's current feature (key frame k + 2 overwrites it after them)
+        self._seg_key, self._seg_buf, self._cur_key, self._lane_key = 0, None, 0, [-1, -1]
+        self._handed = [[], []]
         self._seg_needs_handover = False
         self._held = []                              # non-key frames recorded but not yet queued
 
@@ -485,7 +575,7 @@ class FramePipeline(object):
 
     def set_scale(self, im_scale):
         self.scale = float(im_scale)
-        for g in self.klanes + self.lanes:
+        for g in self.klanes + self.lanes + self.seg_lanes:
             g.scale = float(im_scale)
             g.im_info[:, 2] = float(im_scale)
 
@@ -498,13 +588,17 @@ class FramePipeline(object):
         hands its streams back to core/streams.py (parked there: see streams._REUSE for why they are not recycled)."""
         self.join()
         torch.cuda.synchronize(self.device)
-        for g in self.klanes + self.lanes:
+        for g in self.klanes + self.lanes + self.seg_lanes + list(self.banks.values()):
             g.close()
         extra = [st for st in self.s_lane if st not in self._owned_streams]
         for st in self._owned_streams + extra:
             streams.release(st)
         self._owned_streams = []
         self.captured = False
+
+    def drop_fronts(self):
+        """Forget the fronts the bank computed ahead for key frames that will not come (the caller abandons the run of frames it announced)."""
+        self._bank_ready = []
 
     def flush(self):
         """Queue the non-key frames recorded so far (end of a clip, or before reading results)."""
@@ -520,7 +614,8 @@ class FramePipeline(object):
     def first_frame(self, data):
         """flag 0 (first frame of a clip): drains the pipeline, runs eagerly on the caller's stream."""
         self.join()
-        self._next = self._nkey = 0          # the lane / buffer of a frame depends only on its position in the clip
+        self._next = self._nkey = self._next_seg = 0          # the lane / buffer of a frame depends only on its position in the clip
+        self._bank_ready = []
         lane, cfg = self.klanes[0], self.cfg
         saved = self.key_exec.taps
         if lane.want_taps:
@@ -549,50 +644,91 @@ class FramePipeline(object):
         for e in [self.ev_handover, self.ev_tail] + self.ev_feat + self.ev_lane:
             e.record(main)
         self._seg_feat, self._seg_event, self._seg_needs_handover = self._feat_latest, None, False
+        self._seg_key += 1
+        self._seg_buf, self._cur_key, self._lane_key, self._handed = None, self._seg_key, [-1, -1], [[], []]
 
     def capture(self, warmup=3):
         for lane in self.klanes:
             lane.feat_old.copy_(self.feat0)
             lane.capture(warmup)
-        for lane in self.lanes:
+        for lane in self.lanes + self.seg_lanes:
             lane.capture(warmup, key=False)
+        for bank in self.banks.values():
+            bank.capture()
         torch.cuda.synchronize(self.device)
         self.captured = True
         self._publish_from_main()
 
-    def key_frame(self, data, deliver=None, ready=None):
+    def key_frame(self, data, deliver=None, ready=None, upcoming=None):
         """flag 1.  `deliver(bufs)` is called with the stream of the frame's tail current, right after
         the frame is queued; use it to queue copies of the (dets, counts, keep_idx) buffers.  The
         inputs must be complete on the device, or `ready` an event recorded after the work that
         produces them (the caller's stream is deliberately NOT waited on: it would serialise the
         pipeline).  With lookahead, the non-key frames recorded since the previous key frame are
-        queued right after this frame."""
+        queued right after this frame.
+        upcoming (key_group = G > 1): the images of the next G - 1 key frames of the clip, already on the device.  When the bank holds no
+        front for this frame, the fronts (backbone, FlowNet) of this frame and those G - 1 are computed in one pass (KeyBank) and the
+        next G - 1 key_frame calls - which must hand over exactly those tensors - take theirs from the bank.  With fewer than G - 1
+        images (the end of a clip) the group is that much smaller; without any the frame's front is computed alone, as with key_group = 1."""
         if not self.lookahead:
             self._issue_segment()
         b = self._nkey % 2
         self._nkey += 1
         lane, s = self.klanes[b], self.s_key
+        bank, slot, group = None, -1, None
+        if self._bank_ready:
+            bank, slot, ptr = self._bank_ready.pop(0)
+            if ptr != data.data_ptr():
+                raise ValueError("FramePipeline.key_frame: the bank holds the front of another image (hand the tensors of `upcoming` over in "
+                                 "order, or drop_fronts())")
+        elif self.banks and upcoming:
+            g = min(self.key_group, 1 + len(upcoming))
+            bank, group, slot = self.banks[g], [data] + list(upcoming[:g - 1]), 0
+            self._bank_ready = [(bank, i, group[i].data_ptr()) for i in range(1, g)]
         with torch.cuda.stream(s):
             if ready is not None:
                 s.wait_event(ready)
-            for t in (data, self._prev_key_data):
-                t.record_stream(s)               # the caller may drop its reference right after this call
-            lane.data.copy_(data)
-            lane.data_key_old.copy_(self._prev_key_data)
-            if self.s_flow is not None:
-                self.ev_in.record(s)
-                with torch.cuda.stream(self.s_flow):
-                    self.s_flow.wait_event(self.ev_in)
-                    lane.run_flow()
-                    self.ev_flow.record(self.s_flow)
-                lane.run_front()
-                s.wait_event(self.ev_flow)
-            else:
-                lane.run_front()
-                lane.run_flow()
-            # this buffer's previous feature (key frame k-2) has been handed over / consumed: its hand-over
-            # was queued with segment k-2, i.e. before this call, and ev_handover is that one or a later one
-            s.wait_event(self.ev_handover)
+            if slot < 0 or group is not None:
+                front = lane if slot < 0 else bank
+                if slot < 0:
+                    for t in (data, self._prev_key_data):
+                        t.record_stream(s)               # the caller may drop its reference right after this call
+                    lane.data.copy_(data)
+                    lane.data_key_old.copy_(self._prev_key_data)
+                else:
+                    # frame i of the group against its predecessor (the previous key frame for i = 0)
+                    olds = [self._prev_key_data] + group[:-1]
+                    for t in group + olds[:1]:
+                        t.record_stream(s)
+                    _stage_inputs([(bank.data[i:i + 1], group[i]) for i in range(bank.G)] +
+                                  [(bank.data_old[i:i + 1], olds[i]) for i in range(bank.G)])
+                if self.s_flow is not None:
+                    self.ev_in.record(s)
+                    with torch.cuda.stream(self.s_flow):
+                        self.s_flow.wait_event(self.ev_in)
+                        front.run_flow()
+                        self.ev_flow.record(self.s_flow)
+                    front.run_front()
+                    s.wait_event(self.ev_flow)
+                else:
+                    front.run_front()
+                    front.run_flow()
+            if slot >= 0:
+                # this frame's slice of the bank -> what the key lane's `agg` reads (static buffers under replay)
+                parts = (bank.conv_feat[slot:slot + 1], bank.flow_out[0][slot:slot + 1], bank.flow_out[1][slot:slot + 1])
+                if self.klanes[0].use_graphs:
+                    lane.conv_feat.copy_(parts[0])
+                    lane.flow_out[0].copy_(parts[1])
+                    lane.flow_out[1].copy_(parts[2])
+                else:
+                    lane.conv_feat, lane.flow_out = parts[0], (parts[1], parts[2])
+                if lane.want_taps:
+                    lane.taps['backbone_feat'] = lane.conv_feat
+            # this buffer's previous feature (key frame k-2) has been handed over / consumed: its copies to the non-key lanes
+            # were queued with segment k-2, i.e. before this call
+            for e in self._handed[b]:
+                s.wait_event(e)
+            self._handed[b] = []
             s.wait_event(self.ev_tail)           # ... and that frame's heads are done reading it
             lane.feat_old.copy_(self._feat_latest)   # the previous key frame's feature (same stream: it exists)
             lane.run_agg()
@@ -608,7 +744,8 @@ class FramePipeline(object):
         if self.lookahead:
             self._issue_segment()                # the frames BEFORE this key frame, served from the previous feature
         self._feat_latest, self._prev_key_data = lane.feat, data
-        self._seg_feat, self._seg_event, self._seg_needs_handover = lane.feat, self.ev_feat[b], True
+        self._seg_feat, self._seg_event, self._seg_needs_handover, self._seg_buf = lane.feat, self.ev_feat[b], True, b
+        self._seg_key += 1
         return lane.post_bufs
 
     def cur_frame(self, data, motion_vector, res_diff, deliver=None, ready=None):
@@ -616,20 +753,63 @@ class FramePipeline(object):
         docstring).  `deliver(bufs)` is called then, with the lane's stream current; the buffers are
         valid until the lane's next frame, so copy them out there."""
         self._held.append((data, motion_vector, res_diff, deliver, ready))
-        if not self.lookahead:
+        if not self.lookahead and (self.segment == 0 or len(self._held) >= self.segment):
             self._issue_segment()
+
+    def _copied_out(self, s):
+        """a copy of the current segment's key feature has been queued on `s`: the key buffer it came from waits for it before its next use"""
+        if self._seg_buf is not None:
+            e = torch.cuda.Event()
+            e.record(s)
+            self._handed[self._seg_buf].append(e)
+
+    def _issue_batched(self):
+        """The held frames (exactly `segment` of them, all of one segment) as one pass on the next segment lane."""
+        i = self._next_seg
+        self._next_seg = (i + 1) % len(self.seg_lanes)
+        lane, s = self.seg_lanes[i], self.s_lane[i]
+        with torch.cuda.stream(s):
+            for _, _, _, _, ready in self._held:
+                if ready is not None:
+                    s.wait_event(ready)
+            if self._lane_key[i] != self._seg_key:
+                # this lane's copy of the segment's key feature (the lane's previous segment is done with the old one: stream order)
+                if self._seg_event is not None:
+                    s.wait_event(self._seg_event)
+                self.feat_seg[i].copy_(self._seg_feat)
+                self._copied_out(s)
+                self._lane_key[i] = self._seg_key
+            frames = []
+            for data, motion_vector, res_diff, _, _ in self._held:
+                for t in (data, motion_vector, res_diff):
+                    t.record_stream(s)
+                frames.append((data, motion_vector, res_diff))
+            full = lane.cur_segment(frames)
+            self.delivering = lane
+            for f, (_, _, _, deliver, _) in enumerate(self._held):
+                if deliver is not None:
+                    bufs = tuple(t[f] for t in full)
+                    bufs[0].lsfa_segment = (full[0].lsfa_flat, f, len(self._held))      # a consumer may take the whole segment with one copy
+                    deliver(bufs)
+            self.ev_lane[i].record(s)
+        self._held = []
 
     def _issue_segment(self):
         if not self._held:
             return
-        if self._seg_needs_handover:
+        if self.segment > 0 and len(self._held) == self.segment:
+            return self._issue_batched()
+        if self._cur_key != self._seg_key:
             s = self.s_lane[0]
             with torch.cuda.stream(s):
-                s.wait_event(self._seg_event)            # the segment's key feature exists
+                if self._seg_event is not None:
+                    s.wait_event(self._seg_event)        # the segment's key feature exists
                 for e in self.ev_lane[1:]:
                     s.wait_event(e)                      # every lane has finished the previous segment
                 self.feat_cur.copy_(self._seg_feat)
                 self.ev_handover.record(s)
+                self._copied_out(s)
+            self._cur_key = self._seg_key
             self._seg_needs_handover = False
         for data, motion_vector, res_diff, deliver, ready in self._held:
             i = self._next

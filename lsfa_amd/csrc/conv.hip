@@ -617,53 +617,6 @@ extern "C" int lsfa_conv_fwd(const lsfa_conv_desc* d, void* ws, size_t ws_bytes,
   return conv_split_launch(args_of(*d), d->pieces, ws, ws_bytes, stream, "lsfa_conv_fwd", d->prof_tag == 1 ? LSFA_OP_FLOWNET : LSFA_OP_CONV);
 }
 
-// n convolutions as one launch when every one of them takes the direct form (conv_chain_kernel), else one after the other: the results are
-// the same bit for bit either way.
-extern "C" int lsfa_conv_chain_fwd(const lsfa_conv_desc* d, int n, unsigned sync_mask, unsigned* barrier, void* ws, size_t ws_bytes, void* stream) {
-  LSFA_REQUIRE(d && n > 0 && n <= 32, "lsfa_conv_chain_fwd: 1..32 descriptors");
-  static const bool off = getenv("LSFA_CONV_CHAIN") && atoi(getenv("LSFA_CONV_CHAIN")) == 0;      // lab: always the separate launches
-  convsplit::ChainArgs c = {};
-  bool chain = !off && barrier && n <= convsplit::kChainMax;
-  int max_phase = 0, phase = 0;
-  for (int l = 0; l < n && chain; ++l) {
-    convsplit::Args a = args_of(d[l]);
-    SplitPlan p;
-    long P = 0;
-    const int rc = conv_split_prepare(a, d[l].pieces, p, P, "lsfa_conv_chain_fwd");
-    if (rc != LSFA_OK) return rc;
-    if (!p.direct || d[l].pieces != d[0].pieces) { chain = false; break; }
-    const int nx = (int)((P + 31) / 32), tiles = nx * (a.Cout / 64);
-    a.inv_nx = 1.0f / (float)nx;
-    c.layer[l] = a;
-    c.nw_packed |= (unsigned)(direct_waves(a) - 1) << (2 * l);
-    if (l == 0 || ((sync_mask >> l) & 1u)) phase = 0;
-    phase += tiles;
-    if (phase > max_phase) max_phase = phase;
-  }
-  if (!chain) {
-    for (int l = 0; l < n; ++l) {
-      const int rc = lsfa_conv_fwd(&d[l], ws, ws_bytes, stream);
-      if (rc != LSFA_OK) return rc;
-    }
-    return LSFA_OK;
-  }
-  c.n = n;
-  c.sync_mask = sync_mask | 1u;
-  c.barrier = barrier;
-  c.status = d[0].status;
-  // every workgroup must be resident while the others spin: at most 1.5 workgroups of 3 waves + 16 KB per CU
-  const int wgs = max_phase < 384 ? max_phase : 384;
-  hipStream_t s = (hipStream_t)stream;
-  ProfScope prof(d[0].prof_tag == 1 ? LSFA_OP_FLOWNET : LSFA_OP_CONV, s);
-  const size_t lds = (size_t)(convsplit::kDirectMaxWaves - 1) * 32 * 64 * sizeof(float);
-  const dim3 grid((unsigned)wgs), block(64 * convsplit::kDirectMaxWaves);
-  if (d[0].pieces == 3) hipLaunchKernelGGL(convsplit::conv_chain_kernel<3>, grid, block, lds, s, c);
-  else if (d[0].pieces == 2) hipLaunchKernelGGL(convsplit::conv_chain_kernel<2>, grid, block, lds, s, c);
-  else hipLaunchKernelGGL(convsplit::conv_chain_kernel<1>, grid, block, lds, s, c);
-  LSFA_LAUNCH_CHECK("lsfa_conv_chain_fwd");
-  return LSFA_OK;
-}
-
 extern "C" int lsfa_amax_partial(const float* x, long long n, float* out, void* stream) {
   LSFA_REQUIRE(x && out && n > 0 && n % 4 == 0 && ((uintptr_t)x & 15) == 0, "lsfa_amax_partial: x must be 16-byte aligned, n a positive multiple of 4");
   hipLaunchKernelGGL(convsplit::amax_partial_kernel, dim3(convsplit::kAmaxSlots), dim3(256), 0, (hipStream_t)stream, (const float4*)x,
@@ -686,10 +639,9 @@ extern "C" int lsfa_status_check(unsigned* status_dev, void* stream) {
   e = hipMemsetAsync(status_dev, 0, sizeof(unsigned), s);
   if (e == hipSuccess) e = hipStreamSynchronize(s);
   if (e != hipSuccess) return hip_fail(e, "lsfa_status_check");
-  set_error("lsfa_status_check: status 0x%x:%s%s%s", h,
+  set_error("lsfa_status_check: status 0x%x:%s%s", h,
             (h & 1u) ? " a convolution produced a non-finite output (fp16 two-piece form: amax_in under-estimates max|x|, or the input held inf / NaN)" : "",
-            (h & 2u) ? " a convolution's input maximum was inf / NaN" : "",
-            (h & 4u) ? " a grid barrier of lsfa_conv_chain_fwd timed out (its workgroups were not resident together): the chain's outputs are incomplete" : "");
+            (h & 2u) ? " a convolution's input maximum was inf / NaN" : "");
   return LSFA_EOVERFLOW;
 }
 

@@ -1,38 +1,27 @@
-// fp32 convolution / GEMM on the bf16 matrix pipe: every fp32 operand is cut EXACTLY into three bf16 pieces
-// (8 + 8 + 8 mantissa bits), and a*b is accumulated in fp32 from the six partial products whose weight is at
-// least 2^-16 of the leading one:
-//     a = a1 + a2 + a3,  b = b1 + b2 + b3   (exact, by truncation: each piece is the leading 8 bits of what is left)
-//     a*b ~= a1*b1 + (a1*b2 + a2*b1) + (a1*b3 + a3*b1 + a2*b2)          dropped: a2*b3 + a3*b2 + a3*b3 < 2^-23 |a*b|
-// Each partial product of two bf16 values is exact in fp32, so the only differences to an fp32 FMA chain are the
-// dropped terms (below one fp32 ulp of the product) and the summation order.  `v_mfma_f32_32x32x16_bf16` does 16 k
-// in 32 cycles where `v_mfma_f32_32x32x2_f32` does 2 k in 64: six of them per 16 k are 2.7x the fp32 pipe's rate.
-// (gfx950 has no xf32 MFMA; this is the same construction as 3xTF32 / BF16x9 GEMM emulation, with the
-// negligible terms left out.)  Measured against a float64 convolution the result is as close as the fp32-MFMA
-// kernel's (tests/test_hip_ops.py::test_conv_split_*).
+// fp32 convolution / GEMM with every product formed on the 16-bit matrix pipe from PIECES of the fp32 operands (gfx950 has no xf32
+// MFMA; this is the construction of 3xTF32 / BF16x9 GEMM emulation with the negligible terms left out).  Three forms, picked per
+// weight (lsfa_conv_weights' `pieces`, hip.SplitWeight):
+//   3  a = a1 + a2 + a3 EXACTLY in bf16 (8 + 8 + 8 mantissa bits, by truncation), likewise b; a*b ~= a1*b1 + (a1*b2 + a2*b1) +
+//      (a1*b3 + a3*b1 + a2*b2): six v_mfma_f32_32x32x16_bf16, the dropped terms < 2^-23 |a*b|.  No scale needed.
+//   2  a * 2^s = hi + lo in fp16 (11 + 11 bits; s from the map's maximum, `amax_in`, so that hi stays inside fp16's range; the weights
+//      were packed as w * 2^w_exp); a*b ~= hi*hi' + hi*lo' + lo*hi': three v_mfma_f32_32x32x16_f16, the result scaled back by the
+//      exact power of two.  The default of the fp32 path since r4.  A non-finite result (an under-estimated amax) raises the status word.
+//   1  one bf16 piece, round-to-nearest-even: one instruction per product, the bf16 mode (BASELINE configs[2]).
+// Each partial product of two 16-bit values is exact in fp32, so the only differences to an fp32 FMA chain are the dropped terms and
+// the summation order; against a float64 convolution forms 3 and 2 are as close as an fp32 FMA chain (tests/test_hip_ops.py).
 //
-// Layout and pipeline.  One chunk = 32 input channels of one tap.  Workgroup = 4 waves = 128 pixels x 64 output
-// channels, wave = 32 pixels x 64 channels (two 32x32 accumulators).  Everything the loop reads arrives by LDS-DMA
-// (`global_load_lds_dwordx4`: global -> LDS with no register stage) into a ring of two stages, one chunk ahead, and
-// two workgroups share a CU (56 KB of LDS each), so one's DMA waits, LDS reads and operand cutting run under the
-// other's MFMAs:
-//   A (activations, fp32 NHWC): the wave's 32 pixels x 128 B.  One DMA instruction moves 8 pixels' whole 128-byte
-//     rows (8 lanes x 16 B per pixel: full cache lines — a DMA shaped like the MFMA fragment, one 16-B piece of a
-//     different pixel per lane, measured 3x the issue time because every lane is its own 64-B sector request).  The
-//     LDS image is linear in lane order, so the bank swizzle is applied on the SOURCE side: slot q of pixel p holds
-//     piece q ^ ((p >> 1) & 7), which makes the fragment reads (lane = pixel, four 16-B pieces of its 64-B half)
-//     conflict-free ds_read_b128.  The A fragment of the 32x32x16 MFMA is, per lane, 8 consecutive k of one row:
-//     lanes l and l+32 take the two 16-channel halves of the chunk (the k order inside a chunk is ours to choose as
-//     long as B agrees); the lane cuts its 16 values in registers and feeds two k-steps.  Zero padding = the source
-//     address points at a block of zeros.  Private to the wave.
-//   B (weights): cut and laid out ONCE at bind time in fragment order (lsfa_conv_split_weights): [tap][chunk]
-//     [32-col tile][step][piece][lane][8 bf16], so a fragment is 1 KB contiguous and the 12 KB the four waves share
-//     per chunk is one contiguous block: 3 DMA instructions per wave; fragments are read with ds_read_b128.
-// The loop body is unrolled over the two stages so that every LDS address is a compile-time offset into ONE
-// __shared__ array, and the DMA helpers take their global pointers as __restrict__ parameters: together that is
-// what lets hipcc see that the reads of one stage never alias the DMA writes in flight to the other (otherwise
-// it drains them with `s_waitcnt vmcnt(0)` before every ds_read).  Per chunk: issue the 7 DMAs of chunk c+1,
-// consume stage c, `s_waitcnt vmcnt(0)`, `lgkmcnt(0)`, raw `s_barrier`.
-// The K range (taps x Cin/32 chunks) is cut into `slices` over gridDim.z like conv.hip, summed by conv_reduce_kernel.
+// What is in this file (the 128-pixel ring kernel, the main kernel of the family, lives in conv_ring_kernel.h):
+//   Args                    the argument block every kernel of the family takes (filled by conv.hip from lsfa_conv_desc)
+//   cut8 / mma_pc           cutting 8 fp32 values into pieces and the 1 / 3 / 6 matrix instructions of one k-step
+//   amax plumbing           amax_exponent_asm (the scale from 256 partial maxima), publish_amax (an epilogue's maximum into the slots the
+//                           next layer reads), the status word
+//   epilogues               tile_store_max (fragment-shaped stores: NCHW, views), tile_rows_out (channels-last rows through LDS as
+//                           float4), with bias / residual / activation / second output (the next unit's bn1 + relu1)
+//   split_reduce_*          the pass that adds a K-sliced launch's partial sums in slice order and applies the epilogue
+//   conv_split3x3_kernel    the 3x3 halo form (wide maps with few output channels: the input patch + halo staged once per tile)
+//   conv_split_direct_*     small weights on a small map: a wave per 32 x 64 tile, operands straight into registers
+// Weights (B) are cut and laid out ONCE at bind time in fragment order (lsfa_conv_weights / pack_weights_kernel):
+// [tap][chunk][32-col tile][k-step][piece][lane][8 x 16 bit], so a fragment is 1 KB contiguous.  One chunk = 32 input channels of one tap.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -919,8 +908,8 @@ __device__ __forceinline__ void direct_mma(const DirectOperands<PC>& o, f32x16& 
 // 9 waves x 2 chunks 17.8-18.3 us — the launch bound for 9 waves caps the registers below the two operand sets.)
 constexpr int kDirectMaxWaves = 3;
 
-// One 32-pixel x 64-channel output tile (bx, by) of convolution `a` by the `nw` first waves of the workgroup (every wave of the
-// workgroup must call it: there is a workgroup barrier inside).  red_dyn: max(nw - 1, 1) * 8 KB of LDS.
+// One 32-pixel x 64-channel output tile (bx, by) of convolution `a` by the `nw` waves of the workgroup (every wave must call it: there
+// is a workgroup barrier inside).  red_dyn: max(nw - 1, 1) * 8 KB of LDS.
 template <int PC>
 __device__ __forceinline__ void direct_tile(const Args& a, int bx, int by, int nx, int nw, float* red_dyn) {
   float (*red)[32 * 64] = reinterpret_cast<float (*)[32 * 64]>(red_dyn);
@@ -1029,80 +1018,6 @@ template <int PC>
 static __global__ __launch_bounds__(64 * kDirectMaxWaves) void conv_split_direct_kernel(Args a) {
   extern __shared__ __attribute__((aligned(16))) float red_dyn[];
   direct_tile<PC>(a, blockIdx.x, blockIdx.y, gridDim.x, (int)(blockDim.x >> 6), red_dyn);
-}
-
-// ---------------------------------------------------------------------------------------------------------------
-// r4: a CHAIN of direct-form convolutions in one launch (the small net's stage 1 on every non-key frame: ten convolutions of 0.02 - 0.35
-// GFLOP whose launches cost more than their arithmetic).  A persistent grid walks the layers; layers that read an earlier layer's
-// output are separated by a grid barrier (arrive: agent-scope release + atomic add; wait: spin on the counter + agent-scope acquire -
-// on this part that writes back / invalidates the XCD's L2 so that maps written by one XCD are read correctly by another).  Each tile
-// is computed exactly as conv_split_direct_kernel computes it (same wave count per layer, same order of additions): the chain's
-// outputs are those of the separate launches bit for bit.  All workgroups must be resident together (the host caps the grid); a
-// barrier that does not complete within kChainSpin polls raises bit 2 of the status word and the workgroup leaves.
-constexpr int kChainMax = 12;            // 12 x sizeof(Args) stays under the 4 KB kernel-argument limit
-constexpr unsigned kChainSpin = 1u << 21;
-struct ChainArgs {
-  Args layer[kChainMax];
-  int n;
-  unsigned sync_mask;                    // bit l: a grid barrier before layer l
-  unsigned nw_packed;                    // 2 bits per layer: waves per tile - 1
-  unsigned* barrier;                     // one zeroed counter
-  unsigned* status;
-};
-static_assert(sizeof(ChainArgs) <= 4096, "the chain's layers travel as kernel arguments");
-
-__device__ __forceinline__ bool chain_barrier(unsigned* counter, unsigned target, unsigned* status) {
-  __syncthreads();
-  bool ok = true;
-  if (threadIdx.x == 0) {
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-    __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    unsigned spins = 0;
-    while (__hip_atomic_load(counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
-      __builtin_amdgcn_s_sleep(2);
-      if (++spins > kChainSpin) { ok = false; break; }
-    }
-    if (!ok && status) atomicOr(status, 4u);
-  }
-  // every wave invalidates its view (the acquire half), after thread 0 has seen the counter
-  ok = __syncthreads_and((int)ok) != 0;
-  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-  return ok;
-}
-
-template <int PC>
-static __global__ __launch_bounds__(64 * kDirectMaxWaves) void conv_chain_kernel(ChainArgs c) {
-  extern __shared__ __attribute__((aligned(16))) float red_dyn[];
-  // the layers are read from the kernel-argument segment through a (uniform) pointer: indexing the by-value array with a run-time
-  // layer number would make the compiler copy it to scratch
-  const Args* layers = (const Args*)__builtin_amdgcn_kernarg_segment_ptr();      // ChainArgs::layer is the first member
-  unsigned arrived = 0;
-  for (int l = 0; l < c.n;) {
-    // a phase: layers l .. e - 1 with no barrier between them; its tiles are the layers' tiles one list after the other
-    int e = l + 1;
-    while (e < c.n && !((c.sync_mask >> e) & 1u)) ++e;
-    if (l > 0) {
-      arrived += gridDim.x;
-      if (!chain_barrier(c.barrier, arrived, c.status)) return;
-    }
-    int first = 0;
-    for (int k = l; k < e; ++k) {
-      const Args a = layers[k];
-      const int nx = (a.N * a.Ho * a.Wo + 31) >> 5, tiles = nx * (a.Cout / kWgCh);
-      const int nw = 1 + (int)((c.nw_packed >> (2 * k)) & 3u);
-      const float inv_nx = a.inv_nx;
-      // this workgroup's tiles of layer k: list positions first + t, dealt round-robin
-      int t = (int)blockIdx.x - first % (int)gridDim.x;
-      if (t < 0) t += gridDim.x;
-      for (; t < tiles; t += gridDim.x) {
-        const int by = fdiv(t, nx, inv_nx), bx = t - by * nx;
-        direct_tile<PC>(a, bx, by, nx, nw, red_dyn);
-        __syncthreads();                 // wave 0 is done with the LDS block before the next tile's sums arrive
-      }
-      first += tiles;
-    }
-    l = e;
-  }
 }
 
 // partial maxima of |x| for the fp16 form's scale: kAmaxSlots workgroups, slot b = max over its grid-stride share (0 for an empty share)

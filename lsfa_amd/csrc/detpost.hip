@@ -85,6 +85,12 @@ __global__ __launch_bounds__(kClassThreads) void det_class_kernel(
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int j = blockIdx.x;
   const int tid = threadIdx.x;
+  {   // image blockIdx.y of a batch: its R rois (MultiProposal's layout: image b's rows are [b*R, (b+1)*R)) and its own outputs
+    const size_t b = blockIdx.y;
+    rois += b * R * 5; deltas += b * (size_t)R * nreg * 4; probs += b * (size_t)R * ncls;
+    dets += b * (size_t)ncls * R * 5; counts += b * ncls;
+    if (keep_idx) keep_idx += b * (size_t)ncls * R;
+  }
   if (j == 0) { if (tid == 0) counts[0] = 0; return; }
   const int Wd = (R + 63) / 64;
   double* box = reinterpret_cast<double*>(smem);
@@ -301,6 +307,8 @@ __global__ __launch_bounds__(1024) void det_cap_kernel(double* __restrict__ dets
   __shared__ int misc[40];
   const int tid = threadIdx.x;
   const int lane = tid & 63, wid = tid >> 6;
+  dets += (size_t)blockIdx.x * ncls * R * 5; counts += (size_t)blockIdx.x * ncls;      // image blockIdx.x
+  if (keep_idx) keep_idx += (size_t)blockIdx.x * ncls * R;
   if (tid == 0) {
     int t = 0;
     for (int j = 1; j < ncls; ++j) t += counts[j];
@@ -472,9 +480,17 @@ extern "C" int lsfa_det_postprocess(const float* rois, const float* deltas, cons
                                     int nreg, int class_agnostic, double im_h, double im_w, double scale,
                                     double score_thresh, double nms_thresh, int max_per_image, double* dets,
                                     int* counts, int* keep_idx, void* ws, size_t ws_bytes, void* stream) {
+  return lsfa_det_postprocess_batch(rois, deltas, probs, 1, R, ncls, nreg, class_agnostic, im_h, im_w, scale, score_thresh, nms_thresh,
+                                    max_per_image, dets, counts, keep_idx, ws, ws_bytes, stream);
+}
+
+extern "C" int lsfa_det_postprocess_batch(const float* rois, const float* deltas, const float* probs, int B, int R, int ncls,
+                                          int nreg, int class_agnostic, double im_h, double im_w, double scale,
+                                          double score_thresh, double nms_thresh, int max_per_image, double* dets,
+                                          int* counts, int* keep_idx, void* ws, size_t ws_bytes, void* stream) {
   (void)ws; (void)ws_bytes;
   LSFA_REQUIRE(rois && deltas && probs && dets && counts, "lsfa_det_postprocess: NULL argument");
-  LSFA_REQUIRE(R > 0 && ncls > 1 && nreg > 0, "lsfa_det_postprocess: bad shape R=%d ncls=%d nreg=%d", R, ncls, nreg);
+  LSFA_REQUIRE(B > 0 && B <= 65535 && R > 0 && ncls > 1 && nreg > 0, "lsfa_det_postprocess: bad shape B=%d R=%d ncls=%d nreg=%d", B, R, ncls, nreg);
   LSFA_REQUIRE(class_agnostic ? nreg >= 2 : nreg >= ncls, "lsfa_det_postprocess: nreg=%d too small", nreg);
   if (R > kMaxR || (long)R * ncls > kCapMaxKeys) {
     set_error("lsfa_det_postprocess: R=%d (max %d) or R*ncls=%ld (max %d) unsupported", R, kMaxR, (long)R * ncls, kCapMaxKeys);
@@ -491,10 +507,10 @@ extern "C" int lsfa_det_postprocess(const float* rois, const float* deltas, cons
   nms.thresh = nms_thresh;
   nms.thresh_eps = nms_thresh * 4.440892098500626e-16;   // 2^-51
   nms.fast = (nms_thresh > 1e-300 && nms_thresh < 1e300) ? 1 : 0;
-  hipLaunchKernelGGL(det_class_kernel, dim3(ncls), dim3(kClassThreads), lds, s, rois, deltas, probs, R, ncls, nreg,
+  hipLaunchKernelGGL(det_class_kernel, dim3(ncls, B), dim3(kClassThreads), lds, s, rois, deltas, probs, R, ncls, nreg,
                      class_agnostic, im_h, im_w, scale, score_thresh, nms, dets, counts, keep_idx);
   if (max_per_image > 0)
-    hipLaunchKernelGGL(det_cap_kernel, dim3(1), dim3(1024), 0, s, dets, counts, keep_idx, R, ncls, max_per_image);
+    hipLaunchKernelGGL(det_cap_kernel, dim3(B), dim3(1024), 0, s, dets, counts, keep_idx, R, ncls, max_per_image);
   LSFA_LAUNCH_CHECK("lsfa_det_postprocess");
   return LSFA_OK;
 }

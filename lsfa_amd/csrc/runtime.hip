@@ -75,29 +75,41 @@ extern "C" int lsfa_stream_create(void** stream_out, int high_priority) {
 // Up to four device-to-device copies of 4-byte elements as ONE launch: a frame's image, motion vectors and residual go
 // into the static buffers a captured graph reads from; three separate copy nodes are three ~5 us latencies per frame.
 namespace {
-struct CopyJobs { void* dst[4]; const void* src[4]; long end[4]; long elems[4]; };     // end = running total of 4-element groups
+constexpr int kCopyJobsMax = 32;
+struct CopyJobs { void* dst[kCopyJobsMax]; const void* src[kCopyJobsMax]; long end[kCopyJobsMax]; long elems[kCopyJobsMax]; };     // end = running total of 4-element groups
 __global__ __launch_bounds__(256) void copy_many_kernel(CopyJobs j, int njobs) {
+  // the job table through LDS: indexing the by-value argument with a run-time job number would send it to scratch
+  __shared__ long s_end[kCopyJobsMax], s_elems[kCopyJobsMax];
+  __shared__ uintptr_t s_dst[kCopyJobsMax], s_src[kCopyJobsMax];
+  if (threadIdx.x == 0) {
+#pragma unroll
+    for (int k = 0; k < kCopyJobsMax; ++k) {
+      s_end[k] = j.end[k]; s_elems[k] = j.elems[k];
+      s_dst[k] = reinterpret_cast<uintptr_t>(j.dst[k]); s_src[k] = reinterpret_cast<uintptr_t>(j.src[k]);
+    }
+  }
+  __syncthreads();
   const long i = (long)blockIdx.x * 256 + threadIdx.x;
-  if (i >= j.end[njobs - 1]) return;
+  if (i >= s_end[njobs - 1]) return;
   int k = 0;
-  while (i >= j.end[k]) ++k;
-  const long o = (i - (k ? j.end[k - 1] : 0)) * 4;            // first element of this thread's group
-  uint32_t* d = reinterpret_cast<uint32_t*>(j.dst[k]) + o;
-  const uint32_t* s = reinterpret_cast<const uint32_t*>(j.src[k]) + o;
-  const bool vec = o + 4 <= j.elems[k] && ((reinterpret_cast<uintptr_t>(j.dst[k]) | reinterpret_cast<uintptr_t>(j.src[k])) & 15) == 0;
+  while (i >= s_end[k]) ++k;
+  const long o = (i - (k ? s_end[k - 1] : 0)) * 4;            // first element of this thread's group
+  uint32_t* d = reinterpret_cast<uint32_t*>(s_dst[k]) + o;
+  const uint32_t* s = reinterpret_cast<const uint32_t*>(s_src[k]) + o;
+  const bool vec = o + 4 <= s_elems[k] && ((s_dst[k] | s_src[k]) & 15) == 0;
   if (vec) {
     *reinterpret_cast<uint4*>(d) = *reinterpret_cast<const uint4*>(s);
   } else {
-    for (long e = 0; e < 4 && o + e < j.elems[k]; ++e) d[e] = s[e];
+    for (long e = 0; e < 4 && o + e < s_elems[k]; ++e) d[e] = s[e];
   }
 }
 }  // namespace
 
 extern "C" int lsfa_copy_many(int njobs, void* const* dst, const void* const* src, const long* elems4, void* stream) {
-  LSFA_REQUIRE(njobs >= 1 && njobs <= 4 && dst && src && elems4, "lsfa_copy_many: bad argument");
+  LSFA_REQUIRE(njobs >= 1 && njobs <= kCopyJobsMax && dst && src && elems4, "lsfa_copy_many: 1..32 jobs");
   CopyJobs j;
   long total = 0;
-  for (int k = 0; k < 4; ++k) {
+  for (int k = 0; k < kCopyJobsMax; ++k) {
     if (k < njobs) {
       LSFA_REQUIRE(dst[k] && src[k] && elems4[k] >= 0, "lsfa_copy_many: NULL pointer or negative size");
       total += (elems4[k] + 3) / 4;

@@ -335,6 +335,25 @@ def det_postprocess(rois, deltas, probs, im_h, im_w, scale, score_thresh=1e-4, n
 
 
 @_on_tensor_device
+def det_postprocess_batch(rois, deltas, probs, B, im_h, im_w, scale, out, score_thresh=1e-4, nms_thresh=0.3, max_per_image=300,
+                          class_agnostic=True):
+    """lsfa_det_postprocess_batch: det_postprocess for the B images of a batch in one launch pair.  rois (B*R, 5), deltas (B*R, 4*nreg),
+    probs (B*R, ncls), image b's rows [b*R, (b+1)*R); out = (dets (B, ncls, R, 5) f64, counts (B, ncls) i32, keep_idx (B, ncls, R) i32)."""
+    rois, deltas, probs = _f32c(rois, "rois"), _f32c(deltas, "deltas"), _f32c(probs, "probs")
+    R, ncls = probs.shape[0] // B, probs.shape[1]
+    nreg = deltas.shape[1] // 4
+    dets, counts, keep_idx = out
+    if tuple(dets.shape) != (B, ncls, R, 5) or tuple(counts.shape) != (B, ncls) or not (dets.is_contiguous() and counts.is_contiguous() and
+                                                                                       keep_idx.is_contiguous()):
+        raise LsfaError("det_postprocess_batch: out must be contiguous (B, ncls, R, 5) / (B, ncls) / (B, ncls, R) buffers")
+    _check(lib().lsfa_det_postprocess_batch(_ptr(rois), _ptr(deltas), _ptr(probs), _ci(B), _ci(R), _ci(ncls), _ci(nreg),
+                                            _ci(int(class_agnostic)), _cd(im_h), _cd(im_w), _cd(scale), _cd(score_thresh),
+                                            _cd(nms_thresh), _ci(max_per_image), _ptr(dets), _ptr(counts), _ptr(keep_idx),
+                                            None, ctypes.c_size_t(0), _stream()), "lsfa_det_postprocess_batch")
+    return dets, counts, keep_idx
+
+
+@_on_tensor_device
 def deform_im2col(data, offset, kh, kw, pad, stride, dilate, deform_groups, out=None):
     data, offset = _f32c(data, "data"), _f32c(offset, "offset")
     N, C, H, W = data.shape
@@ -469,13 +488,13 @@ def conv_nhwc(x, w_kc, bias, kh, kw, stride=1, pad=0, dil=1, relu=False, out=Non
 
 
 def copy_many(pairs):
-    """[(dst, src), ...] (at most 4; same shapes, contiguous, 4-byte dtypes, one device) as ONE launch on the current stream."""
+    """[(dst, src), ...] (at most 32; same shapes, contiguous, 4-byte dtypes, one device) as ONE launch on the current stream."""
     pairs = [(d, s) for d, s in pairs if d.numel()]
     if not pairs:
         return
     n = len(pairs)
-    if n > 4:
-        raise LsfaError("copy_many: at most 4 copies per launch")
+    if n > 32:
+        raise LsfaError("copy_many: at most 32 copies per launch")
     for d, s in pairs:
         if d.shape != s.shape or d.dtype != s.dtype or d.element_size() != 4 or not (d.is_contiguous() and s.is_contiguous()) \
                 or d.device != s.device or d.device != pairs[0][0].device:

@@ -376,7 +376,7 @@ class Executor(object):
             if first and u['stage'] == 4:
                 dilate = dilate * 2
             am_c1, am_c2, am_n = S.new(), S.new(), S.new()
-            c1 = self._conv(a, u['w1'], u['b1'], act=1, amax_in=am_a, amax_out=am_c1)                  # conv1 + folded bn2 + relu2
+            c1 = self._conv(a, u['w1'], u['b1'], act=1, amax_in=am_a, amax_out=am_c1)     # conv1 + folded bn2 + relu2
             if u['dcn']:
                 # DeformableConvolution (sym_common.py:138-157): offsets, bilinear columns, contraction + folded bn3 + relu3.  Every column
                 # entry is an interpolation of c1 (zeros outside): max|col| <= max|c1|, so c1's scale serves the contraction
@@ -384,8 +384,11 @@ class Executor(object):
                 col = hip.deform_im2col_cl(c1, off, 3, 3, ud, 1, ud, P.NUM_DEFORMABLE_GROUP)
                 c2 = self._conv(col.view(c1.shape[0], c1.shape[1], c1.shape[2], -1), u['w2'], u['b2'], act=1, amax_in=am_c1, amax_out=am_c2)
             else:
+                c2 = None
+            # shortcut: 1x1 (stride) on relu1, or x
+            sc = self._conv(a, u['sc'], None, stride, amax_in=am_a) if first else x4
+            if c2 is None:
                 c2 = self._conv(c1, u['w2'], u['b2'], stride, ud, ud, act=1, amax_in=am_c1, amax_out=am_c2)   # conv2 + folded bn3 + relu3
-            sc = self._conv(a, u['sc'], None, stride, amax_in=am_a) if first else x4                  # shortcut: 1x1 (stride) on relu1, or x
             # conv3 + shortcut add in place + the bn1 / relu1 the NEXT unit (or the tail) applies to the sum, as a second output
             nxt = units[ui + 1]['bn1'] if ui + 1 < len(units) else net.bn1
             if nxt is not None:

@@ -49,6 +49,27 @@ def anchor_rows(anchors):
     return first
 
 
+def image_of_batch(taps, out, b, B):
+    """Image b of a frame pass that carried B images on the batch axis (the non-key frames of a segment, a group of key fronts), as the
+    single-image taps / outputs the checks take: every tensor whose leading axis is B (or B x rows: MultiProposal's ROI layout, whose
+    batch column is set to 0 like a single image's) is cut down to image b."""
+    def cut(name, t):
+        if not hasattr(t, 'shape') or t.dim() == 0:
+            return t
+        if name.endswith('_reshape_output') and t.dim() == 3 and t.shape[0] == 1 and t.shape[1] % B == 0:
+            R = t.shape[1] // B              # (BATCH_IMAGES = 1, B * R, C): the batch symbol's shape (resnet_v1_101_flownet_rfcn.py:745-747)
+            return t[:, b * R:(b + 1) * R]
+        if t.shape[0] == B:
+            return t[b:b + 1]
+        if name == 'rois_output' and t.shape[0] % B == 0:
+            R = t.shape[0] // B
+            r = t[b * R:(b + 1) * R].clone()
+            r[:, 0] = 0
+            return r
+        return t
+    return {k: cut(k, v) for k, v in taps.items()}, {k: cut(k, v) for k, v in out.items()}
+
+
 def gpu_side(cfg, taps, out, im_info):
     """The GPU frame as a `side`: its own head maps + outputs, and the anchor index of every ROI row - taken from the oracle's
     Proposal run on the GPU's own maps, whose ROIs must equal the GPU's bit for bit (asserted here)."""

@@ -461,6 +461,116 @@ def test_frame_pipeline_frames_pinned_to_oracle_and_to_the_serial_loop(world, lo
     fp.close()         # graphs and their memory pools dropped
 
 
+@pytest.mark.parametrize("lookahead,group", [(False, 3), (True, 2)])
+def test_frame_pipeline_batched_segments_and_key_groups(world, lookahead, group):
+    """FramePipeline(segment=3, key_group=G): the three non-key frames of a segment go through the network in ONE pass (batch axis = frames,
+    the reference's batch test symbol) and the fronts (backbone, FlowNet) of G consecutive key frames in one pass, 16 frames at key interval
+    4: keys 1, 5, 9, 13, the last segment one frame short (per-frame lanes), the last key frame(s) without enough `upcoming` images (front
+    computed alone).  For every frame as delivered: the hand-written stages equal the oracle bit for bit on that frame's own inputs - a
+    non-key frame's conv_feat is the warp of ITS segment's key feature with ITS motion vectors, a key frame's warp that of the PREVIOUS key
+    frame's feature; a second run reproduces the first bit for bit; a batched pass equals the same pass issued eagerly by hand (graphs,
+    streams and staging add nothing); and every dense map stays within the convolution tolerance of the serial one-frame-at-a-time loop
+    (a batch changes the K cut of a convolution, hence its rounding, never more)."""
+    from oracle import e2e
+    from parity_util import assert_dets_equal, check_cur_frame, check_dets, check_key_frame, clone_dict
+    from lsfa_amd.core.graphs import FrameGraphs, FramePipeline
+    from lsfa_amd.utils.synthetic import SyntheticClip
+    cfg, arg, key, cur = world['cfg'], world['arg'], world['key'], world['cur']
+    key.taps = cur.taps = None
+    clip = SyntheticClip(3, 17, H, W, 4)
+    im_info = clip.im_info()
+    K, F = 4, 3
+    sched = [(f, 1 + K * ((f - 1) // K)) for f in range(1, 16)]          # keys 1, 5, 9, 13; frame 16 does not exist: segment 13 has 14, 15
+    keys = [f for f, kf in sched if f == kf]
+    frames = {f: clip.frame(f, DEV) for f in range(16)}
+    mvs = {f: clip.motion_vector(f, kf, DEV) for f, kf in sched if f != kf}
+    ress = {f: clip.res_diff(f, DEV) for f, kf in sched if f != kf}
+    torch.cuda.synchronize()
+
+    def run(fp):
+        outs = {}
+
+        def keep(f, is_key):
+            def deliver(bufs):
+                lane = fp.delivering
+                if is_key:
+                    o = dict(taps=clone_dict(lane.taps), out=clone_dict(lane.out), feat=lane.feat.clone())
+                else:
+                    seg = getattr(bufs[0], 'lsfa_segment', None)
+                    taps, out = clone_dict(lane.cur_taps), clone_dict(lane.cur_out)
+                    if seg is not None:
+                        taps, out = e2e.image_of_batch(taps, out, seg[1], seg[2])
+                    o = dict(taps=taps, out=out, batched=seg is not None)
+                o.update(dets=bufs[0].clone(), counts=bufs[1].clone())
+                outs[f] = o
+            return deliver
+        first = fp.first_frame(frames[0])
+        outs[0] = dict(feat=fp.feat.clone())
+        if not fp.captured:
+            fp.capture()
+        for f, kf in sched:
+            if f == kf:
+                later = [frames[k] for k in keys if k > f]
+                fp.key_frame(frames[f], deliver=keep(f, True), upcoming=later)
+            else:
+                fp.cur_frame(frames[f], mvs[f], ress[f], deliver=keep(f, False))
+        fp.join()
+        torch.cuda.synchronize()
+        return outs
+
+    fp = FramePipeline(key, cur, cfg, H, W, DEV, lanes=2, lookahead=lookahead, taps=True, segment=F, key_group=group)
+    a, b = run(fp), run(fp)
+    fp.close()
+    # 1. every frame against the oracle's hand-written stages, on the pipeline's own intermediate values
+    key_feat, prev_key = {0: a[0]['feat']}, 0
+    for f, kf in sched:
+        r = a[f]
+        if f == kf:
+            check_key_frame(cfg, r['taps'], r['out'], key_feat[prev_key], im_info)
+            assert torch.equal(r['feat'], r['out']['choose_feat_output'])
+            key_feat[f], prev_key = r['feat'], f
+        else:
+            assert r['batched'] == (kf != 13)
+            check_cur_frame(cfg, arg, r['taps'], r['out'], key_feat[kf], mvs[f], ress[f], im_info)
+        check_dets(cfg, r['out'], r['dets'].cpu().numpy(), r['counts'].cpu().numpy(), H, W)
+    # 2. run to run
+    for f, _ in sched:
+        for name in a[f]['taps']:
+            assert torch.equal(a[f]['taps'][name], b[f]['taps'][name]), (f, name)
+        assert_dets_equal(a[f]['dets'], a[f]['counts'], b[f]['dets'], b[f]['counts'], "frame %d, second run" % f)
+    # 3. the batched passes by hand: the first full group of fronts, the first segment
+    with torch.no_grad():
+        grp = keys[:group]
+        olds = [0] + grp[:-1]
+        conv = key.key_backbone(torch.cat([frames[k] for k in grp], 0))
+        flow, scale = key.key_flow(torch.cat([frames[k] for k in grp], 0), torch.cat([frames[k] for k in olds], 0))
+        for i, k in enumerate(grp):
+            assert torch.equal(a[k]['taps']['backbone_feat'], conv[i:i + 1]), k
+            assert torch.equal(a[k]['taps']['flow'], flow[i:i + 1]) and torch.equal(a[k]['taps']['scale_map'], scale[i:i + 1]), k
+        seg = [2, 3, 4]
+        out = cur.forward(data=torch.cat([frames[f] for f in seg], 0), im_info=torch.from_numpy(np.repeat(im_info, F, 0)).to(DEV),
+                          feat_key=key_feat[1], motion_vector=torch.cat([mvs[f] for f in seg], 0), res_diff=torch.cat([ress[f] for f in seg], 0))
+        for i, f in enumerate(seg):
+            assert torch.equal(a[f]['out']['conv_feat'], out['conv_feat'][i:i + 1]), f
+            R = out['rois_output'].shape[0] // F
+            assert torch.equal(a[f]['out']['cls_prob_reshape_output'], out['cls_prob_reshape_output'][:, i * R:(i + 1) * R]), f
+    # 4. against the serial loop: same frames one at a time
+    fg = FrameGraphs(key, cur, cfg, H, W, DEV, use_graphs=False, prefetch=False, taps=True)
+    fg.first_frame(frames[0])
+    fg.capture()
+    worst = 0.0
+    for f, kf in sched:
+        if f == kf:
+            fg.key_frame(frames[f])
+            pairs = [(a[f]['feat'], fg.feat), (a[f]['taps']['backbone_feat'], fg.key_taps['backbone_feat'])]
+        else:
+            fg.cur_frame(frames[f], mvs[f], ress[f])
+            pairs = [(a[f]['out']['conv_feat'], fg.cur_out['conv_feat']), (a[f]['taps']['small_feat'], fg.cur_taps['small_feat'])]
+        for x, y in pairs:
+            worst = max(worst, float((x - y).abs().max() / y.abs().max()))
+    assert worst < TOL_DENSE, worst
+
+
 def test_pred_eval_pipelined_two_videos(world):
     """Two videos of the same shape through pred_eval_pipelined: the second video reuses the first
     one's captured pipeline after a drain; frame ids and every detection row equal the serial

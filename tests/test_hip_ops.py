@@ -529,6 +529,39 @@ def test_det_postprocess_vs_oracle(hip, seed, cap):
         np.testing.assert_allclose(dets[j, :counts[j]].cpu().numpy(), w_d[j, :counts[j]], rtol=1e-12, atol=1e-9)
 
 
+@pytest.mark.parametrize("cap", [300, 40])
+def test_det_postprocess_batch_equals_the_oracle_per_image(hip, cap):
+    """lsfa_det_postprocess_batch (the frames of a segment / the clips of a lock-step batch in one launch pair): image b of five, each
+    with its own rois / deltas / probs (one with nothing above threshold), equals the oracle run on that image alone and the single-image
+    entry point bit for bit."""
+    rs = np.random.RandomState(40 + cap)
+    B, R, ncls = 5, 300, 31
+    rois = np.concatenate([rand_rois(rs, R, small=0.0) for _ in range(B)], 0)
+    for b in range(B):
+        rois[b * R:(b + 1) * R, 0] = b
+        rois[b * R:(b + 1) * R, 1:] = clustered_dets(rs, R)[:, :4]
+    deltas = (0.15 * rs.randn(B * R, 8)).astype(np.float32)
+    logits = (2 * rs.randn(B * R, ncls)).astype(np.float32)
+    e = np.exp(logits - logits.max(1, keepdims=True))
+    probs = (e / e.sum(1, keepdims=True)).astype(np.float32)
+    probs[3 * R:4 * R, 1:] = np.float32(1e-6)          # image 3: every class below the threshold
+    out = (torch.full((B, ncls, R, 5), -7.0, dtype=torch.float64, device=DEV), torch.full((B, ncls), -7, dtype=torch.int32, device=DEV),
+           torch.full((B, ncls, R), -7, dtype=torch.int32, device=DEV))
+    dets, counts, keep_idx = hip.det_postprocess_batch(t(rois), t(deltas), t(probs), B, 600, 1000, 1.3, out, max_per_image=cap)
+    assert int(counts[3].sum()) == 0
+    for b in range(B):
+        sl = slice(b * R, (b + 1) * R)
+        w_d, w_c, w_k = oracle.det_postprocess(rois[sl], deltas[sl], probs[sl], 600, 1000, 1.3, max_per_image=cap)
+        s_d, s_c, s_k = hip.det_postprocess(t(rois[sl]), t(deltas[sl]), t(probs[sl]), 600, 1000, 1.3, max_per_image=cap)
+        c = counts[b].cpu().numpy()
+        np.testing.assert_array_equal(c, w_c)
+        assert torch.equal(counts[b], s_c)
+        for j in range(ncls):
+            np.testing.assert_array_equal(keep_idx[b, j, :c[j]].cpu().numpy(), w_k[j, :c[j]])
+            assert torch.equal(keep_idx[b, j, :c[j]], s_k[j, :c[j]]) and torch.equal(dets[b, j, :c[j]], s_d[j, :c[j]])
+            np.testing.assert_allclose(dets[b, j, :c[j]].cpu().numpy(), w_d[j, :c[j]], rtol=1e-12, atol=1e-9)
+
+
 @pytest.mark.parametrize("kind", ["piles", "equal_scores", "tied_at_cap", "two_values", "disjoint"])
 def test_det_postprocess_inputs_that_stress_sweep_and_cap(hip, kind):
     """Near-duplicate piles (suppression chains as long as a 64-box block: the sweep's scalar scan), thousands of
@@ -801,6 +834,14 @@ def test_copy_many_is_one_launch_of_plain_copies(hip):
         hip.copy_many([(dsts[0], srcs[1])])
     with pytest.raises(hip.LsfaError):
         hip.copy_many([(dsts[0].double(), srcs[0].double())])
+    # a segment's worth: 27 jobs of three sizes (one of them odd) into slices of batched buffers
+    big = [torch.zeros((9, 3, 60, 100), device=DEV), torch.zeros((9, 2, 38, 63), device=DEV), torch.zeros((9, 3, 37, 21), device=DEV)]
+    parts = [[t(rs.randn(1, *b.shape[1:]).astype(np.float32)) for _ in range(9)] for b in big]
+    hip.copy_many([(b[f:f + 1], parts[k][f]) for f in range(9) for k, b in enumerate(big)])
+    for k, b in enumerate(big):
+        assert torch.equal(b, torch.cat(parts[k], 0))
+    with pytest.raises(hip.LsfaError):
+        hip.copy_many([(dsts[1], srcs[1])] * 33)
 
 
 # ------------------------------------------------------------------ ResNet stem ----

@@ -126,11 +126,12 @@ class Runner(object):
         self.host_dets = self.host_flat[:, :n_d].view(self.K, self.B, ncls, R, 5)
         self._n_d, self.ncls, self._R = n_d, ncls, R
         from lsfa_amd.core.graphs import FrameGraphs, FramePipeline
-        one_clip_pipelined = args.lanes > 0 and self.B == 1
-        self.segment = (self.K - 1 if (one_clip_pipelined and self.K > 2) else 0) if args.segment < 0 else (args.segment if one_clip_pipelined else 0)
-        self.key_group = max(1, args.key_group) if one_clip_pipelined else 1
+        pipelined = args.lanes > 0
+        self.segment = (self.K - 1 if (pipelined and self.K > 2) else 0) if args.segment < 0 else (args.segment if pipelined else 0)
+        self.key_group = max(1, args.key_group) if pipelined else 1
         F = self.segment
-        self.host_seg = torch.empty(max(F, 1) * ncls * R * 5 + (max(F, 1) * ncls * 4 + 7) // 8, dtype=torch.float64).pin_memory()
+        nimg = max(F, 1) * self.B                   # images of a batched segment, frame-major
+        self.host_seg = torch.empty(nimg * ncls * R * 5 + (nimg * ncls * 4 + 7) // 8, dtype=torch.float64).pin_memory()
         if args.lanes > 0:
             self.fg = FramePipeline(self.key, self.cur, cfg, args.height, args.width, device,
                                     use_graphs=not args.no_graph, lanes=max(args.lanes, 2 if F else 1),
@@ -156,14 +157,14 @@ class Runner(object):
 
     def host_counts_of(self, slot):
         if self._in_segment(slot):
-            F, n = self.segment, self.ncls
-            return self.host_seg[F * n * self._R * 5:].view(torch.int32)[:F * n].view(F, 1, n)[slot - 1]
+            F, n, B = self.segment, self.ncls, self.B
+            return self.host_seg[F * B * n * self._R * 5:].view(torch.int32)[:F * B * n].view(F, B, n)[slot - 1]
         return self.host_flat[slot, self._n_d:].view(torch.int32)[:self.B * self.ncls].view(self.B, self.ncls)
 
     def host_dets_of(self, slot):
         if self._in_segment(slot):
-            F, n = self.segment, self.ncls
-            return self.host_seg[:F * n * self._R * 5].view(F, 1, n, self._R, 5)[slot - 1]
+            F, n, B = self.segment, self.ncls, self.B
+            return self.host_seg[:F * B * n * self._R * 5].view(F, B, n, self._R, 5)[slot - 1]
         return self.host_dets[slot]
 
     @property
@@ -262,9 +263,10 @@ class Runner(object):
         feat0 = fg.feat.clone()
         im1 = fg.klanes[0].im_info
         R, ncls = cfg.TEST.RPN_POST_NMS_TOP_N, cfg.dataset.NUM_CLASSES
-        post1, _ = graphs._alloc_post(1, ncls, R, self.device)
-        postF, _ = graphs._alloc_post(max(F, 1), ncls, R, self.device)
-        imF = im1.expand(max(F, 1), -1).contiguous()
+        B = self.B
+        post1, _ = graphs._alloc_post(B, ncls, R, self.device)
+        postF, _ = graphs._alloc_post(max(F, 1) * B, ncls, R, self.device)
+        imF = im1.repeat(max(F, 1), 1)
         segs = []
         for kf in kfs:
             idx = list(range(kf + 1, kf + K))
@@ -275,7 +277,8 @@ class Runner(object):
             flow, scale = key.key_flow(imgs, olds)
             f = feat0
             for i in range(G):
-                f = key.key_aggregate(conv[i:i + 1], flow[i:i + 1], scale[i:i + 1], f)
+                sl = slice(i * B, (i + 1) * B)
+                f = key.key_aggregate(conv[sl], flow[sl], scale[sl], f)
                 graphs._post_all(key.key_heads(f, im1), post1, cfg, H, W, 1.0, fg.thresh)
                 if segs[i] is None:
                     continue
@@ -284,7 +287,8 @@ class Runner(object):
                     graphs._post_all(cur.forward(data=d, im_info=imF, feat_key=f, motion_vector=m, res_diff=r_), postF, cfg, H, W, 1.0, fg.thresh)
                 else:
                     for j in range(K - 1):
-                        graphs._post_all(cur.forward(data=d[j:j + 1], im_info=im1, feat_key=f, motion_vector=m[j:j + 1], res_diff=r_[j:j + 1]),
+                        sj = slice(j * B, (j + 1) * B)
+                        graphs._post_all(cur.forward(data=d[sj], im_info=im1, feat_key=f, motion_vector=m[sj], res_diff=r_[sj]),
                                          post1, cfg, H, W, 1.0, fg.thresh)
         run()                # warm
         torch.cuda.synchronize()
@@ -300,8 +304,8 @@ class Runner(object):
         hip.conv_flops_reset(False)
         hip.prof_enable(False)
         C, hw = cfg.network.DFF_FEAT_DIM, (-(-H // 16)) * (-(-W // 16))
-        per_seg = ((1 + 2 * F) * C * hw + 2 * F * hw) * 4 if F == K - 1 else (K - 1) * warp_bytes(1, C, hw)
-        self.warp_bytes_total = G * (warp_bytes(1, C, hw) + (per_seg if K > 1 else 0))
+        per_seg = ((1 + 2 * F) * C * hw + 2 * F * hw) * 4 * B if F == K - 1 else (K - 1) * warp_bytes(B, C, hw)
+        self.warp_bytes_total = G * (warp_bytes(B, C, hw) + (per_seg if K > 1 else 0))
         self.profiled_intervals = G
         return prof
 

@@ -93,8 +93,9 @@ int lsfa_rfcn_head_ps_ld_fwd(const float* ps_map, int cell_ld, const float* rois
  *                [* mul[n,c,y,x]]                                         if mul  != NULL
  *                [+ (res_w[c,:] . res[n,:,y,x] + res_b[c])]               if res  != NULL (res has res_c channels)
  *                [+ add[n,c,y,x]]                                         if add  != NULL
- * feat may have batch 1 while flow has batch N (feat_n = 1 or N): the
- * key-frame feature is broadcast, as tile_as does (operator_py/tile_as.py:16-19).
+ * feat may have a smaller batch than flow (feat_n divides N): map n samples feature n mod feat_n.  feat_n = 1 broadcasts the
+ * key-frame feature as tile_as does (operator_py/tile_as.py:16-19); feat_n = B < N serves the F frames of a segment of B lock-step
+ * clips laid out frame-major (map f*B + b reads clip b's key feature).
  * ------------------------------------------------------------------------ */
 int lsfa_warp_bilinear(const float* feat, int feat_n, const float* flow,
                        int N, int C, int H, int W,
@@ -212,6 +213,17 @@ int lsfa_det_postprocess_batch(const float* rois, const float* deltas, const flo
                                double score_thresh, double nms_thresh, int max_per_image,
                                double* dets, int* counts, int* keep_idx,
                                void* ws, size_t ws_bytes, void* stream);
+
+/* ------------------------------------------------------------------------ *
+ * RPN head on the NCHW feature map: rpn_cls_score + rpn_bbox_pred (1x1 convolutions of channels [0, 512), both in one pass) + bias +
+ * the per-anchor two-way softmax (Reshape (2, A*H, W) -> SoftmaxActivation(channel) -> Reshape).
+ * Replaces: dff_rfcn/symbols/resnet_v1_101_flownet_rfcn.py:479-494 (and the rpn_inv_normalize the caller folds into the weights).
+ * feat (N, C_total, H, W), C_total >= 512; w_t (512, 64) floats [input channel][output], output o < 2A = score channel o (background
+ * a = o, foreground A + a), 2A <= o < 6A = box delta channel o - 2A, columns past 6A zero; bias (64);
+ * cls_prob (N, 2A, H, W), bbox_pred (N, 4A, H, W).  fp32 FMA chains over ascending input channels in eight runs of 64, added in order.
+ * ------------------------------------------------------------------------ */
+int lsfa_rpn_head(const float* feat, int N, int C_total, int H, int W, const float* w_t, const float* bias, int A,
+                  float* cls_prob, float* bbox_pred, void* stream);
 
 /* Box decode + clip + rescale only (float64 out), for callers that keep the
  * reference's im_detect() signature:  tester.py:143-152. pred_boxes (R, 4*nreg) */

@@ -16,7 +16,7 @@ CSRC = os.path.join(HERE, "csrc")
 INCLUDE = os.path.join(os.path.dirname(HERE), "include")
 OBJ = os.path.join(HERE, "csrc", "_obj")
 LIB = os.path.join(HERE, "liblsfa_hip.so")
-SOURCES = ["runtime.hip", "warp.hip", "aggregate.hip", "psroi.hip", "nms.hip", "proposal.hip", "detpost.hip", "dcn.hip", "mv.hip", "conv.hip", "stem.hip", "flownet.hip"]
+SOURCES = ["runtime.hip", "warp.hip", "aggregate.hip", "psroi.hip", "nms.hip", "proposal.hip", "detpost.hip", "dcn.hip", "mv.hip", "conv.hip", "stem.hip", "flownet.hip", "rpn_head.hip"]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math",
          "-Wall", "-Wno-unused-function", "-I", INCLUDE, "-I", CSRC] + os.environ.get("LSFA_HIPCC_EXTRA", "-fno-slp-vectorize -fno-vectorize").split()

@@ -264,14 +264,17 @@ class FrameGraphs(object):
 
 
     def cur_segment(self, frames):
-        """The non-key frames of one segment in ONE pass, batch axis = frames (this instance was built with batch = len(frames) and a
-        shared (1, C, h, w) key feature: every frame of a segment is served from the same key frame).  frames: [(data, motion_vector,
-        res_diff), ...], one image each.  Returns the batched (dets, counts, keep_idx) buffers: frame f's results are index f."""
-        if len(frames) != self.batch or self.prefetch:
-            raise ValueError("cur_segment: this lane takes %d frames per pass (and no prefetch)" % self.batch)
+        """The non-key frames of one segment in ONE pass, batch axis = frames x clips, frame-major (this instance was built with batch =
+        len(frames) * B and a shared (B, C, h, w) key feature: every frame of a segment is served from the same key frame, image f * B + b
+        from clip b's).  frames: [(data, motion_vector, res_diff), ...], B images each.  Returns the batched (dets, counts, keep_idx)
+        buffers: frame f's results are rows [f * B, (f + 1) * B)."""
+        B = int(frames[0][0].shape[0])               # clips advancing in lock-step: images per frame; the batch is frame-major (f * B + b)
+        if len(frames) * B != self.batch or self.prefetch:
+            raise ValueError("cur_segment: this lane takes %d images per pass (and no prefetch)" % self.batch)
         jobs = []
         for f, (data, mv, res) in enumerate(frames):
-            jobs += [(self.data[f:f + 1], data), (self.mv[f:f + 1], mv), (self.res[f:f + 1], res)]
+            sl = slice(f * B, (f + 1) * B)
+            jobs += [(self.data[sl], data), (self.mv[sl], mv), (self.res[sl], res)]
         _stage_inputs(jobs)
         if self.use_graphs:
             self.cur_graph.replay()
@@ -286,11 +289,11 @@ class KeyBank(object):
     K slice, three frames' fill the chip (measured per frame: backbone 3231 -> 2200 us, FlowNet 514 -> 289 us at G = 3,
     profiles/r4/key_batch_probe.txt).  Key frame i of the group then takes conv_feat[i], flow[i], scale[i] for its aggregation."""
 
-    def __init__(self, key_exec, cfg, height, width, device, use_graphs, group, taps=False):
-        self.key, self.device, self.use_graphs, self.G = key_exec, device, use_graphs, int(group)
+    def __init__(self, key_exec, cfg, height, width, device, use_graphs, group, taps=False, batch=1):
+        self.key, self.device, self.use_graphs, self.G, self.B = key_exec, device, use_graphs, int(group), int(batch)
         z = lambda *s: torch.zeros(s, device=device, dtype=torch.float32)
-        self.data = z(self.G, 3, height, width)
-        self.data_old = z(self.G, 3, height, width)
+        self.data = z(self.G * self.B, 3, height, width)          # group-major: key frame i of the group is images [i * B, (i + 1) * B)
+        self.data_old = z(self.G * self.B, 3, height, width)
         self.conv_feat = self.flow_out = None
         self.front_graph = self.flow_graph = None
         self.want_taps = taps
@@ -491,8 +494,6 @@ class FramePipeline(object):
         dev = torch.device(device)
         self.batch = B = int(batch)
         self.segment, self.key_group = int(segment), int(key_group)
-        if (self.segment > 0 or self.key_group > 1) and B != 1:
-            raise ValueError("FramePipeline: segment / key_group batching is for one clip per pipeline (batch = 1)")
         if self.segment > 0 and lanes < 2:
             raise ValueError("FramePipeline: segment batching alternates over two lane streams (lanes >= 2)")
         self.device, self.cfg, self.key_exec = dev, cfg, key_exec
@@ -509,11 +510,11 @@ class FramePipeline(object):
         # frames on the batch axis - what the reference's own batch test symbol does (get_batch_test_symbol,
         # resnet_v1_101_flownet_rfcn.py:661-751) - on two alternating lanes, each with its own copy of the key feature; a shorter run of
         # non-key frames (the end of a clip) takes the per-frame lanes.  key_group > 1: see KeyBank and key_frame(upcoming=...).
-        self.feat_seg = [torch.zeros((1, dim, fh, fw), device=dev, dtype=torch.float32) for _ in range(2 if self.segment else 0)]
+        self.feat_seg = [torch.zeros((B, dim, fh, fw), device=dev, dtype=torch.float32) for _ in range(2 if self.segment else 0)]
         self.seg_lanes = [FrameGraphs(key_exec, cur_exec, cfg, height, width, dev, thresh, use_graphs, prefetch=False,
-                                      feat_shared=f, taps=taps, batch=self.segment) for f in self.feat_seg]
+                                      feat_shared=f, taps=taps, batch=self.segment * B) for f in self.feat_seg]
         # one bank per group size 2 .. key_group: the tail of a run of key frames (fewer images ahead than key_group - 1) is a smaller group
-        self.banks = {g: KeyBank(key_exec, cfg, height, width, dev, use_graphs, g, taps) for g in range(2, self.key_group + 1)}
+        self.banks = {g: KeyBank(key_exec, cfg, height, width, dev, use_graphs, g, taps, B) for g in range(2, self.key_group + 1)}
         self._bank_ready = []                        # [(bank, slot, data_ptr)]: fronts of upcoming key frames already computed
         self._next_seg = 0
         want = 1 + (1 if flow_stream else 0) + lanes
@@ -700,8 +701,9 @@ class FramePipeline(object):
                     olds = [self._prev_key_data] + group[:-1]
                     for t in group + olds[:1]:
                         t.record_stream(s)
-                    _stage_inputs([(bank.data[i:i + 1], group[i]) for i in range(bank.G)] +
-                                  [(bank.data_old[i:i + 1], olds[i]) for i in range(bank.G)])
+                    nb = bank.B
+                    _stage_inputs([(bank.data[i * nb:(i + 1) * nb], group[i]) for i in range(bank.G)] +
+                                  [(bank.data_old[i * nb:(i + 1) * nb], olds[i]) for i in range(bank.G)])
                 if self.s_flow is not None:
                     self.ev_in.record(s)
                     with torch.cuda.stream(self.s_flow):
@@ -715,7 +717,8 @@ class FramePipeline(object):
                     front.run_flow()
             if slot >= 0:
                 # this frame's slice of the bank -> what the key lane's `agg` reads (static buffers under replay)
-                parts = (bank.conv_feat[slot:slot + 1], bank.flow_out[0][slot:slot + 1], bank.flow_out[1][slot:slot + 1])
+                sl = slice(slot * bank.B, (slot + 1) * bank.B)
+                parts = (bank.conv_feat[sl], bank.flow_out[0][sl], bank.flow_out[1][sl])
                 if self.klanes[0].use_graphs:
                     lane.conv_feat.copy_(parts[0])
                     lane.flow_out[0].copy_(parts[1])
@@ -786,9 +789,10 @@ class FramePipeline(object):
                 frames.append((data, motion_vector, res_diff))
             full = lane.cur_segment(frames)
             self.delivering = lane
+            nb = self.batch
             for f, (_, _, _, deliver, _) in enumerate(self._held):
                 if deliver is not None:
-                    bufs = tuple(t[f] for t in full)
+                    bufs = tuple(t[f] if nb == 1 else t[f * nb:(f + 1) * nb] for t in full)     # like post_bufs: no clip axis for one clip
                     bufs[0].lsfa_segment = (full[0].lsfa_flat, f, len(self._held))      # a consumer may take the whole segment with one copy
                     deliver(bufs)
             self.ev_lane[i].record(s)

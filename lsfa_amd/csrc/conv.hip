@@ -310,7 +310,12 @@ bool ring_ok(int nt, int pieces, int st) {
 void ring_plan(SplitPlan& p, long P, int chunk_total, int Cout, int pieces) {
   const int f_nt = g_force_nt.load(), f_st = g_force_st.load(), f_s = g_force_slices.load(), f_k = g_force_kernel.load();
   p.nx = (int)((P + convsplit::kWgPix - 1) / convsplit::kWgPix);
-  int nt = (Cout % 128 == 0 && Cout >= 512 && chunk_total >= 64) ? 4 : 2;
+  // 128 x 128 tiles: long K with >= 512 output channels (r4, one image), or - maps of several images, the batched pipeline - wherever the
+  // wider tiles alone still give the chip well over a wave of workgroups (profiles/r4/conv_ring_lab_batch3.txt: res4 conv3 44.1 -> 39.3 us,
+  // res5 conv3 108 -> 97, res5 sc 153 -> 127, res3 conv2 40.9 -> 38.6 at three images); never on two-chunk launches (res2 conv3: 144 -> 168)
+  const long tiles4 = (long)p.nx * (Cout / 128);
+  int nt = (Cout % 128 == 0 && chunk_total >= 4 &&
+            ((Cout >= 512 && chunk_total >= 64) || tiles4 >= 400 || (tiles4 >= 200 && chunk_total >= 32 && Cout <= 256))) ? 4 : 2;
   if (f_nt && Cout % (32 * f_nt) == 0) nt = f_nt;
   const long tiles = (long)p.nx * (Cout / (32 * nt));
   // K slices: rounds of resident workgroups x chunks per slice (~0.9 us per chunk and workgroup with two chunks in flight: feat_conv_3x3 as
@@ -334,6 +339,10 @@ void ring_plan(SplitPlan& p, long P, int chunk_total, int Cout, int pieces) {
   int per = (chunk_total + s - 1) / s;
   s = (chunk_total + per - 1) / per;                    // every slice non-empty
   bool sp = per >= 4;
+  // the expanding 1x1s (conv3 of a bottleneck: K = Cout / 4, at most 16 chunks, an epilogue of residual + two outputs per tile): the four
+  // loader waves only add launch weight; mixed roles, two stages (res5 conv3 42.7 -> 40.4 us, res3 conv3 31.1 -> 24.9; at three images
+  // res5 conv3 113 -> 97, res4 conv3 44.1 -> 39.3)
+  if (s == 1 && per <= 16 && Cout >= 128 * chunk_total) sp = false;
   if (f_k == 1) sp = false;
   if (f_k == 2) sp = true;
   int st = sp ? 3 : 2;
@@ -367,6 +376,9 @@ SplitPlan split_plan(int N, int H, int W, int Cin, int Cout, int kh, int kw, int
     // r4: with the ring kernel's loader / consumer waves the halo form only keeps the wide-map, narrow-output case (res2 conv2:
     // 37,500 pixels, 64 -> 64: 30.3 vs 31.1 us); fuse_reduce_add is 58 us on the ring against 77 here (tools/lab/conv_ring_lab.py)
     if ((long)p.nx * p.ny < 256 || Cout > 128) p.halo = false;
+    // r4, end of round: the ring kernel with loader / consumer waves is ahead on these too (res2 conv2 24.0 vs 27.1 us, at three images 45.1 vs
+    // 55.0; res3 conv2 38.6 vs 41): the halo form is no plan's choice any more, only lsfa_conv_plan_override(kernel = 3) reaches it
+    p.halo = false;
     if (g_force_kernel.load() == 3) p.halo = true;
     // balanced mode: fewer than 512 tiles but more than 512 (tile, chunk) units -> equal unit counts per workgroup
     // (fuse_reduce_add: 320 tiles x 8 chunks = 512 workgroups x 5 instead of one round of 320 x 8)

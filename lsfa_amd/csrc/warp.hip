@@ -89,7 +89,7 @@ extern "C" int lsfa_warp_bilinear(const float* feat, int feat_n, const float* fl
   using namespace lsfa;
   LSFA_REQUIRE(feat && flow && out, "lsfa_warp_bilinear: feat, flow and out must be non-NULL");
   LSFA_REQUIRE(N > 0 && C > 0 && H > 1 && W > 1, "lsfa_warp_bilinear: bad shape N=%d C=%d H=%d W=%d", N, C, H, W);
-  LSFA_REQUIRE(feat_n == 1 || feat_n == N, "lsfa_warp_bilinear: feat batch %d must be 1 or N=%d", feat_n, N);
+  LSFA_REQUIRE(feat_n >= 1 && N % feat_n == 0, "lsfa_warp_bilinear: feat batch %d must divide N=%d", feat_n, N);
   LSFA_REQUIRE(N <= 65535, "lsfa_warp_bilinear: N=%d exceeds grid.z", N);
   if (res) {
     LSFA_REQUIRE(res_w && res_b, "lsfa_warp_bilinear: res given without res_w/res_b");

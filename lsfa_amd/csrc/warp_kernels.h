@@ -104,7 +104,7 @@ __global__ __launch_bounds__(kThreads) void warp_kernel(
       if (k < res_c) load_vec<VEC>(res + ((size_t)n * res_c + k) * HW + p0, rv[k]);
   }
 
-  const float* fbase = feat + (feat_n == 1 ? (size_t)0 : (size_t)n * C * HW);
+  const float* fbase = feat + (size_t)(n % feat_n) * C * HW;       // map n samples feature n mod feat_n (1: one feature for all; N: its own)
   const int c1 = min(c0 + ch_per_block, C);
   bool interior = true;
 #pragma unroll
@@ -288,7 +288,7 @@ __global__ __launch_bounds__(THREADS) void warp_staged_kernel(StagedArgs A) {
   }
 
   // ---- the ring ------------------------------------------------------------------------------------------------------------------
-  const float* fbase = A.feat + (A.feat_n == 1 ? (size_t)0 : (size_t)n * C * HW);
+  const float* fbase = A.feat + (size_t)(n % A.feat_n) * C * HW;       // map n samples feature n mod feat_n
   const size_t nbase = (size_t)n * C * HW;
   // one plane by DMA: lane -> LDS chunk is fixed by the hardware (base + 16 * lane); lanes past the plane re-read its last chunk
   // into the slack behind it

@@ -335,6 +335,21 @@ def det_postprocess(rois, deltas, probs, im_h, im_w, scale, score_thresh=1e-4, n
 
 
 @_on_tensor_device
+def rpn_head(feat, w_t, bias, A):
+    """lsfa_rpn_head: feat (N, C >= 512, H, W) NCHW; w_t (512, 64) [input channel][score 2A | delta 4A | zeros]; bias (64)
+    -> (rpn_cls_prob (N, 2A, H, W), rpn_bbox_pred (N, 4A, H, W))."""
+    feat, w_t, bias = _f32c(feat, "feat"), _f32c(w_t, "w_t"), _f32c(bias, "bias")
+    N, C, H, W = feat.shape
+    if tuple(w_t.shape) != (512, 64) or bias.numel() != 64:
+        raise LsfaError("rpn_head: w_t must be (512, 64) and bias (64)")
+    cls_prob = torch.empty((N, 2 * A, H, W), device=feat.device, dtype=torch.float32)
+    bbox = torch.empty((N, 4 * A, H, W), device=feat.device, dtype=torch.float32)
+    _check(lib().lsfa_rpn_head(_ptr(feat), _ci(N), _ci(C), _ci(H), _ci(W), _ptr(w_t), _ptr(bias), _ci(A), _ptr(cls_prob), _ptr(bbox),
+                               _stream()), "lsfa_rpn_head")
+    return cls_prob, bbox
+
+
+@_on_tensor_device
 def det_postprocess_batch(rois, deltas, probs, B, im_h, im_w, scale, out, score_thresh=1e-4, nms_thresh=0.3, max_per_image=300,
                           class_agnostic=True):
     """lsfa_det_postprocess_batch: det_postprocess for the B images of a batch in one launch pair.  rois (B*R, 5), deltas (B*R, 4*nreg),

@@ -292,10 +292,11 @@ class Executor(object):
         wb, bb = arg['rpn_bbox_pred_weight'].reshape(4 * A, 512), arg['rpn_bbox_pred_bias']
         if cfg.network.NORMALIZE_RPN:   # rpn_inv_normalize folded: (Wx+b)*std+mean
             wb, bb = wb * std[:, None], bb * std + mean
-        self.rpn_w = _t(np.concatenate([arg['rpn_cls_score_weight'].reshape(2 * A, 512), wb], 0), dev, dtype)
-        self.rpn_b = _t(np.concatenate([arg['rpn_cls_score_bias'], bb], 0), dev, f32)
-        self.rfcn_w = _t(np.concatenate([arg['rfcn_cls_weight'].reshape(-1, 512), arg['rfcn_bbox_weight'].reshape(-1, 512)], 0), dev, dtype)
-        self.rfcn_b = _t(np.concatenate([arg['rfcn_cls_bias'], arg['rfcn_bbox_bias']], 0), dev, f32)
+        # lsfa_rpn_head's layout: (512, 64) [input channel][score 2A | delta 4A | zero columns], fp32 in both modes (0.13 GFLOP)
+        w64, b64 = np.zeros((512, 64), np.float32), np.zeros(64, np.float32)
+        w64[:, :6 * A] = np.concatenate([arg['rpn_cls_score_weight'].reshape(2 * A, 512), wb], 0).T
+        b64[:6 * A] = np.concatenate([arg['rpn_cls_score_bias'], bb], 0)
+        self.rpn_w_t, self.rpn_b = _t(w64, dev, f32), _t(b64, dev, f32)
         self.n_cls_ch = arg['rfcn_cls_weight'].shape[0]
         # position-sensitive layout: GEMM [HW,512] x [512, 49*(ncls+nbox)], row (bin*D + d) of the permuted weight
         G = 7
@@ -305,8 +306,10 @@ class Executor(object):
         wx = arg['rfcn_bbox_weight'].reshape(self.nbox, G * G, 512)
         w_ps = np.concatenate([wc, wx], 0).transpose(1, 0, 2).reshape(-1, 512)          # (49*D, 512)
         b_ps = np.concatenate([arg['rfcn_cls_bias'].reshape(self.ncls, G * G), arg['rfcn_bbox_bias'].reshape(self.nbox, G * G)], 0).T.reshape(-1)
-        self.rfcn_w_ps_t = _t(np.ascontiguousarray(w_ps.T), dev, dtype)                 # (512, 49*D)
-        self.rfcn_b_ps = _t(b_ps, dev, dtype)
+        # as a 1x1 convolution of the own family: output channels padded to its 64-channel tiles (the padding columns are never read)
+        self.ps_ld = -(-w_ps.shape[0] // 64) * 64
+        wp, bp = _pad_rows(_t(w_ps.reshape(-1, 512, 1, 1), dev, f32), _t(b_ps, dev, f32), self.ps_ld)
+        self.rfcn_sw, self.rfcn_b_ps = hip.SplitWeight(wp, real_cout=w_ps.shape[0], pieces=self.pieces), bp
         self.proposal = hip.ProposalOp(feature_stride=cfg.network.RPN_FEAT_STRIDE, scales=cfg.network.ANCHOR_SCALES,
                                        ratios=cfg.network.ANCHOR_RATIOS, rpn_pre_nms_top_n=cfg.TEST.RPN_PRE_NMS_TOP_N,
                                        rpn_post_nms_top_n=cfg.TEST.RPN_POST_NMS_TOP_N, threshold=cfg.TEST.RPN_NMS_THRESH,
@@ -501,46 +504,26 @@ class Executor(object):
         scale = self._conv(c5p, o['scale'], fw['Convolution5_scale_bias'], amax_in=am5, nchw=True)
         return flow, scale
 
-    def _gemm_rows(self, feat, c0, w_t, bias):
-        """rows (N*H*W, 512) of channels [c0, c0 + 512) of the NCHW feature x w_t (512, M) + bias -> (N*H*W, M) float32: a library
-        GEMM (hipBLASLt) in the executor's dtype"""
-        n, _, h, w = feat.shape
-        x = feat[:, c0:c0 + 512]
-        rows = x[0].reshape(512, h * w).t() if n == 1 else x.permute(0, 2, 3, 1).reshape(n * h * w, 512)
-        if rows.dtype != w_t.dtype:
-            rows = rows.to(w_t.dtype)
-        return torch.addmm(bias.to(w_t.dtype), rows, w_t).float()
-
     def _heads(self, conv_feat, im_info):
         """SliceChannel -> RPN -> Proposal -> R-FCN maps -> PSROI + average + softmax (:479-546)."""
         cfg = self.cfg
         A = cfg.network.NUM_ANCHORS
         n, _, h, w = conv_feat.shape
-        # both RPN convolutions as one GEMM W (6A, 512) x X (512, HW): NCHW maps directly; the bias rides on the fused pass
-        X = conv_feat[:, :512].reshape(n, 512, h * w)
-        X = X if X.dtype == self.rpn_w.dtype else X.to(self.rpn_w.dtype)
-        rpn = (torch.mm(self.rpn_w, X[0]) if n == 1 else torch.matmul(self.rpn_w, X)).float().view(n, -1, h, w)
-        rpn = hip.scale_shift_relu(rpn, self._ones(rpn.shape[1]), self.rpn_b, relu=False, out=rpn)
-        cls_prob = torch.softmax(rpn[:, :2 * A].reshape(n, 2, A * h, w), dim=1).reshape(n, 2 * A, h, w)
-        rois = self.proposal(cls_prob, rpn[:, 2 * A:], im_info)
+        # both RPN convolutions + bias + the per-anchor softmax as one launch on the NCHW map (lsfa_rpn_head)
+        cls_prob, rpn_bbox = hip.rpn_head(conv_feat, self.rpn_w_t, self.rpn_b, A)
+        rois = self.proposal(cls_prob, rpn_bbox, im_info)
         D = self.ncls + self.nbox
-        # both R-FCN convolutions as one GEMM that writes the position-sensitive layout [h][w][bin][class | box] directly
-        ps = self._gemm_rows(conv_feat, 512, self.rfcn_w_ps_t, self.rfcn_b_ps).view(n, h, w, 49, D)
+        # both R-FCN convolutions as ONE 1x1 convolution of the own family that writes the position-sensitive layout [h][w][bin][class | box]
+        # directly: channels 512.. of the NCHW feature turned channels-last (one copy), then lsfa_conv_fwd (cells self.ps_ld floats apart)
+        rows = conv_feat[:, 512:].permute(0, 2, 3, 1).contiguous()
+        ps = self._conv(rows, self.rfcn_sw, self.rfcn_b_ps)
         if self.taps is not None:
-            nchw = ps.view(n, h * w, 49, D).permute(0, 3, 2, 1).reshape(n, D * 49, h, w)
-            self.taps.update(rpn_cls_prob=cls_prob, rpn_bbox_pred=rpn[:, 2 * A:], cls_map=nchw[:, :self.n_cls_ch],
+            nchw = ps[..., :49 * D].reshape(n, h * w, 49, D).permute(0, 3, 2, 1).reshape(n, D * 49, h, w)
+            self.taps.update(rpn_cls_prob=cls_prob, rpn_bbox_pred=rpn_bbox, cls_map=nchw[:, :self.n_cls_ch],
                              box_map=nchw[:, self.n_cls_ch:])
-        cls_p, bbox = hip.rfcn_head_ps(ps, rois, self.ncls, self.nbox, 0.0625, 7, 7)
+        cls_p, bbox = hip.rfcn_head_ps_ld(ps, self.ps_ld, rois, h, w, self.ncls, self.nbox, 0.0625, 7, 7)
         B = cfg.TEST.BATCH_IMAGES
         return rois, cls_p.view(B, -1, cls_p.shape[1]), bbox.view(B, -1, bbox.shape[1])
-
-    def _ones(self, c):
-        if not hasattr(self, '_const'):
-            self._const = {}
-        t = self._const.get(c)
-        if t is None:
-            t = self._const[c] = torch.ones(c, device=self.device)
-        return t
 
     # ---- forward ---------------------------------------------------------------------
     def forward(self, **inputs):

@@ -59,6 +59,8 @@ def image_of_batch(taps, out, b, B):
         if name.endswith('_reshape_output') and t.dim() == 3 and t.shape[0] == 1 and t.shape[1] % B == 0:
             R = t.shape[1] // B              # (BATCH_IMAGES = 1, B * R, C): the batch symbol's shape (resnet_v1_101_flownet_rfcn.py:745-747)
             return t[:, b * R:(b + 1) * R]
+        if name == 'nq_logits' and t.shape[0] == 2 * B:
+            return t[[b, B + b]]             # rows b and B + b weigh image b's two maps (aggregate_softmax2's layout)
         if t.shape[0] == B:
             return t[b:b + 1]
         if name == 'rois_output' and t.shape[0] % B == 0:

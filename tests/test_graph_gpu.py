@@ -5,6 +5,8 @@ are compared with the unfused torch-CPU statement within a tolerance; every hand
 stage is then checked BIT-EXACTLY by feeding the oracle the GPU's own inputs to that stage
 ("teacher forcing"), so a 1-ulp difference in a convolution cannot hide or fake a kernel bug.
 """
+import gc
+
 import numpy as np
 import pytest
 import torch
@@ -571,6 +573,77 @@ def test_frame_pipeline_batched_segments_and_key_groups(world, lookahead, group)
     assert worst < TOL_DENSE, worst
 
 
+def test_frame_pipeline_batched_with_two_clips_in_lockstep(world):
+    """FramePipeline(batch=2, segment=3, key_group=2): two clips advance together, so a segment pass carries 3 frames x 2 clips (frame-major:
+    image f * 2 + b samples clip b's key feature - lsfa_warp_bilinear's feat_n = 2 < N = 6) and a key group 2 key frames x 2 clips.  Every
+    delivered frame equals the same passes issued by hand (bit for bit), and for one key frame and one non-key frame each clip's image, cut
+    out of its batch, passes the oracle's hand-written-stage checks against ITS OWN clip's key feature."""
+    from oracle import e2e
+    from parity_util import check_cur_frame, check_key_frame, clone_dict
+    from lsfa_amd.core.graphs import FramePipeline
+    from lsfa_amd.utils.synthetic import SyntheticClip
+    cfg, arg, key, cur = world['cfg'], world['arg'], world['key'], world['cur']
+    key.taps = cur.taps = None
+    B, K, F = 2, 4, 3
+    clips = [SyntheticClip(5 + b, 10, H, W, K) for b in range(B)]
+    cat = lambda fn: torch.cat([fn(c) for c in clips], 0)
+    im_info = clips[0].im_info()
+    sched = [(f, 1 + K * ((f - 1) // K)) for f in range(1, 9)]           # keys 1, 5; segments 2-4, 6-8
+    keys = [1, 5]
+    frames = {f: cat(lambda c: c.frame(f, DEV)) for f in range(9)}
+    mvs = {f: cat(lambda c: c.motion_vector(f, kf, DEV)) for f, kf in sched if f != kf}
+    ress = {f: cat(lambda c: c.res_diff(f, DEV)) for f, kf in sched if f != kf}
+    fp = FramePipeline(key, cur, cfg, H, W, DEV, lanes=2, taps=True, batch=B, segment=F, key_group=2)
+    outs = {}
+
+    def keep(f, is_key):
+        def deliver(bufs):
+            lane = fp.delivering
+            if is_key:
+                outs[f] = dict(taps=clone_dict(lane.taps), out=clone_dict(lane.out), feat=lane.feat.clone(), dets=bufs[0].clone(), counts=bufs[1].clone())
+            else:
+                _, i, n = bufs[0].lsfa_segment
+                outs[f] = dict(taps=clone_dict(lane.cur_taps), out=clone_dict(lane.cur_out), index=i, dets=bufs[0].clone(), counts=bufs[1].clone())
+        return deliver
+    fp.first_frame(frames[0])
+    feat0 = fp.feat.clone()
+    fp.capture()
+    for f, kf in sched:
+        if f == kf:
+            fp.key_frame(frames[f], deliver=keep(f, True), upcoming=[frames[k] for k in keys if k > f])
+        else:
+            fp.cur_frame(frames[f], mvs[f], ress[f], deliver=keep(f, False))
+    fp.join()
+    torch.cuda.synchronize()
+    fp.close()
+    assert outs[1]['dets'].shape[0] == B and outs[2]['dets'].shape[0] == B
+    im_t = torch.from_numpy(np.repeat(im_info, B, 0)).to(DEV)
+    with torch.no_grad():
+        conv = key.key_backbone(torch.cat([frames[1], frames[5]], 0))
+        flow, scale = key.key_flow(torch.cat([frames[1], frames[5]], 0), torch.cat([frames[0], frames[1]], 0))
+        feat, prev = {}, feat0
+        for i, k in enumerate(keys):
+            sl = slice(i * B, (i + 1) * B)
+            assert torch.equal(outs[k]['taps']['backbone_feat'], conv[sl]) and torch.equal(outs[k]['taps']['flow'], flow[sl])
+            feat[k] = key.key_aggregate(conv[sl], flow[sl], scale[sl], prev)
+            assert torch.equal(outs[k]['feat'], feat[k]), k
+            prev = feat[k]
+        for k in keys:
+            seg = [k + 1, k + 2, k + 3]
+            out = cur.forward(data=torch.cat([frames[f] for f in seg], 0), im_info=im_t.repeat(F, 1), feat_key=feat[k],
+                              motion_vector=torch.cat([mvs[f] for f in seg], 0), res_diff=torch.cat([ress[f] for f in seg], 0))
+            for i, f in enumerate(seg):
+                assert outs[f]['index'] == i
+                assert torch.equal(outs[f]['out']['conv_feat'], out['conv_feat']), f          # the lane's whole batch, cloned at every delivery
+    # each clip's image against the oracle's stages, with its own clip's key feature
+    for b in range(B):
+        t, o = e2e.image_of_batch(outs[5]['taps'], outs[5]['out'], b, B)
+        check_key_frame(cfg, t, o, outs[1]['feat'][b:b + 1], im_info)
+        i = 1 * B + b                                                                     # frame 7 = index 1 of segment 6-8
+        t, o = e2e.image_of_batch(outs[7]['taps'], outs[7]['out'], i, F * B)
+        check_cur_frame(cfg, arg, t, o, outs[5]['feat'][b:b + 1], mvs[7][b:b + 1], ress[7][b:b + 1], im_info)
+
+
 def test_pred_eval_pipelined_two_videos(world):
     """Two videos of the same shape through pred_eval_pipelined: the second video reuses the first
     one's captured pipeline after a drain; frame ids and every detection row equal the serial
@@ -588,6 +661,45 @@ def test_pred_eval_pipelined_two_videos(world):
     np.testing.assert_array_equal(ids_s, ids_p)
     assert len(rows_s) > 0
     np.testing.assert_array_equal(rows_s, rows_p)
+
+
+def test_pred_eval_pipelined_evicts_pipelines_of_old_shapes(world):
+    """Five videos of three frame shapes (A, B, C, A, B) with room for TWO captured pipelines: the oldest shape's pipeline is closed (graphs
+    and their memory pools dropped, streams parked) when a third shape arrives and rebuilt when its shape returns; every detection row
+    equals the serial pred_eval's, and the device memory in use after the run is what it was before (no pool of an evicted pipeline
+    survives) - ADVICE r3."""
+    from parity_util import pinned_algorithms
+    from lsfa_amd.config.config import lsfa_test_config
+    from lsfa_amd.core import streams
+    from lsfa_amd.function.test_rcnn import test_rcnn
+    from lsfa_amd.utils.synthetic import synthetic_roidb
+    cfg = lsfa_test_config(key_frame_interval=3)
+    arg, aux = world['arg'], world['aux']
+    shapes = [(128, 192), (160, 256), (96, 160), (128, 192), (160, 256)]
+    roidb, fid = [], 0
+    for v, (h, w) in enumerate(shapes):
+        e = synthetic_roidb(1, 5, h, w, 3, seed=v)[0]
+        e['frame_id'] = fid
+        fid += 5
+        roidb.append(e)
+    with pinned_algorithms():
+        rows_s, ids_s = test_rcnn(cfg, roidb, arg, aux, device=DEV, pipeline=False)
+        torch.cuda.synchronize()
+        gc.collect()
+        torch.cuda.empty_cache()
+        before, parked = torch.cuda.memory_allocated(), sum(len(v) for v in streams._FREE.values())
+        rows_p, ids_p = test_rcnn(cfg, roidb, arg, aux, device=DEV, pipeline=True, max_pipelines=2)
+        torch.cuda.synchronize()
+        gc.collect()                     # lanes, deliver closures and graphs reference each other: the pools go when the cycle is collected
+        torch.cuda.empty_cache()
+        after = torch.cuda.memory_allocated()
+    np.testing.assert_array_equal(ids_s, ids_p)
+    assert len(rows_s) > 0
+    np.testing.assert_array_equal(rows_s, rows_p)
+    assert after <= before + (64 << 20), (before, after)
+    # five pipelines were built (A, B, C, A again, B again), every one closed: their streams are parked, a bounded number each (22 today)
+    grown = sum(len(v) for v in streams._FREE.values()) - parked
+    assert 5 <= grown <= 5 * 32, grown
 
 
 def test_tuned_gemm_file_is_accepted_and_parity_holds(world):
@@ -704,11 +816,12 @@ def test_bench_line_contract():
 
 @pytest.mark.parametrize("dtype", ["f32", "bf16"])
 def test_frames_run_without_a_library_convolution(world, monkeypatch, dtype):
-    """Neither the fp32 nor the bf16 key / non-key graphs reach a MIOpen convolution: every convolution runs on lsfa_conv_fwd
-    (fp32: two fp16 pieces per operand; bf16: one bf16 piece - r3's bf16 mode fell back to F.conv2d / MIOpen).  MIOpen picks its
-    solver from per-user state that concurrently starting processes race for, which made detections depend on the rank layout
-    (DESIGN.md section 4); what is left on libraries are the RPN / R-FCN score-map GEMMs (torch.mm / addmm), whose solution choice
-    is a function of the shape.  The executors' status words stay clear (no fp16 scale overflowed)."""
+    """Neither the fp32 nor the bf16 key / non-key graphs reach a library convolution OR a library GEMM: every convolution runs on
+    lsfa_conv_fwd (fp32: two fp16 pieces per operand; bf16: one bf16 piece - r3's bf16 mode fell back to F.conv2d / MIOpen), the R-FCN
+    score maps are one of them and the RPN head is lsfa_rpn_head (r4: torch.mm / addmm / matmul / softmax are forbidden here too).
+    MIOpen picks its solver from per-user state that concurrently starting processes race for, which made detections depend on the rank
+    layout; hipBLASLt keeps a workspace per stream that a pipeline's captured graphs pin for the life of the
+    process.  The executors' status words stay clear (no fp16 scale overflowed)."""
     import torch.nn.functional as F
     cfg, clip = world['cfg'], world['clip']
     if dtype == "f32":
@@ -723,8 +836,10 @@ def test_frames_run_without_a_library_convolution(world, monkeypatch, dtype):
 
     def forbidden(*a, **k):
         raise AssertionError("a library convolution was called")
-    for name in ("conv2d", "conv_transpose2d", "conv1d", "conv3d", "max_pool2d", "avg_pool2d", "unfold"):
+    for name in ("conv2d", "conv_transpose2d", "conv1d", "conv3d", "max_pool2d", "avg_pool2d", "unfold", "linear", "softmax"):
         monkeypatch.setattr(F, name, forbidden)
+    for name in ("mm", "addmm", "matmul", "bmm", "baddbmm", "einsum", "softmax"):
+        monkeypatch.setattr(torch, name, forbidden)
     out0 = key.forward(data=f0, im_info=im_info_t, data_key_old=f0, feat_key_old=torch.zeros(1, 1024, 1, 1, device=DEV))
     feat0 = out0['choose_feat_output']
     cur.forward(data=f3, im_info=im_info_t, feat_key=feat0, motion_vector=clip.motion_vector(3, 0).to(DEV), res_diff=clip.res_diff(3).to(DEV))

@@ -170,6 +170,27 @@ def test_warp_broadcast_key_feature_batch(hip):
     np.testing.assert_array_equal(got, want)
 
 
+@pytest.mark.parametrize("hw", [(12, 20), (38, 63)])
+def test_warp_feature_batch_that_divides_the_map_batch(hip, hw):
+    """feat_n = 2 features, N = 6 maps (three frames of two lock-step clips, frame-major): map n samples feature n mod 2 - equal bit for
+    bit to the oracle's warp of each map with its own feature, through the gather kernel (12 x 20) and the LDS-staged one (38 x 63), with
+    the non-key epilogue (add + residual)."""
+    H, W = hw
+    rs = np.random.RandomState(H)
+    C, B, N = 24, 2, 6
+    feat = rs.randn(B, C, H, W).astype(np.float32)
+    flow = smooth_flow(rs, N, H, W, 2.0)
+    add = rs.randn(N, C, H, W).astype(np.float32)
+    res = rs.randn(N, 3, H, W).astype(np.float32)
+    rw, rb = (0.01 * rs.randn(C, 3, 1, 1)).astype(np.float32), rs.randn(C).astype(np.float32)
+    got = hip.warp_bilinear(t(feat), t(flow), add=t(add), res=t(res), res_w=t(rw), res_b=t(rb)).cpu().numpy()
+    for n in range(N):
+        want = oracle.warp_bilinear(feat[n % B:n % B + 1], flow[n:n + 1], add=add[n:n + 1], res=res[n:n + 1], res_w=rw, res_b=rb)
+        np.testing.assert_array_equal(got[n:n + 1], want)
+    with pytest.raises(hip.LsfaError):
+        hip.warp_bilinear(t(feat), t(flow[:5]))
+
+
 @pytest.mark.parametrize("case", ["plain", "key", "cur", "mul+add+res4", "border", "broadcast", "in-place", "45x80", "26x40"])
 def test_warp_staged_kernel_matches_the_oracle_and_the_gather_kernel(hip, case):
     """r3: planes staged in LDS by DMA (warp_staged_kernel).  Forced ('staged' makes an unsupported shape an error), on every
@@ -527,6 +548,38 @@ def test_det_postprocess_vs_oracle(hip, seed, cap):
         np.testing.assert_array_equal(keep_idx[j, :counts[j]].cpu().numpy(), w_k[j, :counts[j]])
         # fp64 arithmetic in the same order on both sides; exp() of the two libms may differ by an ulp
         np.testing.assert_allclose(dets[j, :counts[j]].cpu().numpy(), w_d[j, :counts[j]], rtol=1e-12, atol=1e-9)
+
+
+@pytest.mark.parametrize("shape", [(1, 1024, 38, 63), (3, 512, 12, 20), (2, 640, 7, 9)])
+def test_rpn_head_scores_softmax_and_deltas(hip, shape):
+    """lsfa_rpn_head: both RPN 1x1 convolutions on channels [0, 512) of an NCHW map + bias + the per-anchor two-way softmax in one launch,
+    against float64 (fp32 FMA chains of 512 terms: 2e-6 x sqrt(512) of the logits' scale); probabilities of an anchor's two classes add
+    up to one; maps whose pixel count is not a multiple of the 64-pixel tile; channels past 512 are not read."""
+    N, C, H, W = shape
+    A = 9
+    g = torch.Generator(device=DEV).manual_seed(C + H)
+    feat = torch.randn((N, C, H, W), device=DEV, generator=g) * 2.0
+    w = torch.randn((6 * A, 512), device=DEV, generator=g) * 0.05
+    b = torch.randn(6 * A, device=DEV, generator=g) * 0.1
+    w_t = torch.zeros((512, 64), device=DEV)
+    w_t[:, :6 * A] = w.t()
+    b64 = torch.zeros(64, device=DEV)
+    b64[:6 * A] = b
+    cls_prob, bbox = hip.rpn_head(feat, w_t, b64, A)
+    x = feat[:, :512].double().cpu()
+    logits = torch.einsum('oc,nchw->nohw', w.double().cpu(), x) + b.double().cpu().view(1, -1, 1, 1)
+    want_p = torch.softmax(logits[:, :2 * A].reshape(N, 2, A * H, W), dim=1).reshape(N, 2 * A, H, W)
+    tol = 2e-6 * 512 ** 0.5 * float(logits.abs().max())
+    assert float((bbox.double().cpu() - logits[:, 2 * A:]).abs().max()) < tol
+    assert float((cls_prob.double().cpu() - want_p).abs().max()) < tol
+    assert float((cls_prob[:, :A] + cls_prob[:, A:] - 1.0).abs().max()) < 3e-7
+    if C > 512:
+        feat2 = feat.clone()
+        feat2[:, 512:] = float('nan')
+        p2, b2 = hip.rpn_head(feat2, w_t, b64, A)
+        assert torch.equal(p2, cls_prob) and torch.equal(b2, bbox)
+    with pytest.raises(hip.LsfaError):
+        hip.rpn_head(feat, w_t, b64, 11)
 
 
 @pytest.mark.parametrize("cap", [300, 40])
@@ -1195,6 +1248,32 @@ def test_conv_fp16_form_flags_an_underestimated_scale(hip):
         hip.conv_split(x2, sw, None, 1, k // 2, 1, relu=True, status=status)
         with pytest.raises(hip.LsfaError):
             hip.check_status(status)
+
+
+def test_conv_fp16_form_with_a_wide_per_channel_weight_range(hip):
+    """BatchNorm folding multiplies every output channel of a weight by its own gamma / sqrt(var): real checkpoints carry channel scales a
+    few thousand apart, and the two-piece form has ONE power-of-two scale per weight tensor (and one per activation map).  Output channels
+    whose weights are 2^-12 of the largest channel's - and activations whose channels span the same range - must still come out with
+    fp32-grade accuracy RELATIVE TO THEIR OWN magnitude: hi + lo keep 22 bits down to 2^-15 of the tensor's maximum before lo goes
+    subnormal.  Channel c is scaled by 2^-(c mod 13); each output channel is judged against float64 on its own scale, next
+    to the three-piece bf16 form, which has no scale."""
+    g = torch.Generator(device=DEV).manual_seed(21)
+    H, W, ci, co, k = 20, 33, 256, 128, 3
+    K = ci * k * k
+    ch_w = torch.pow(2.0, -(torch.arange(co, device=DEV) % 13).float())
+    ch_x = torch.pow(2.0, -(torch.arange(ci, device=DEV) % 13).float())
+    w = torch.randn((co, ci, k, k), device=DEV, generator=g) * 0.05 * ch_w.view(-1, 1, 1, 1)
+    x = torch.randn((1, H, W, ci), device=DEV, generator=g) * 3.0 * ch_x
+    ref = torch.nn.functional.conv2d(x.permute(0, 3, 1, 2).double().cpu(), w.double().cpu(), padding=1).permute(0, 2, 3, 1)
+    per_ch = ref.abs().amax(dim=(0, 1, 2))                       # each output channel's own scale
+    errs = {}
+    for pieces in (2, 3):
+        status = hip.new_status(DEV)
+        y = hip.conv_split(x, hip.SplitWeight(w, pieces=pieces), None, 1, 1, 1, status=status)
+        hip.check_status(status)
+        errs[pieces] = float(((y.double().cpu() - ref).abs().amax(dim=(0, 1, 2)) / per_ch).max())
+    assert errs[2] <= 2e-6 * K ** 0.5, errs
+    assert errs[2] <= 2.0 * errs[3] + 1e-7, errs
 
 
 @pytest.mark.parametrize("pieces", [2, 3])

@@ -80,6 +80,7 @@ def main():
     ap.add_argument('--shapes', default='')
     ap.add_argument('--reps', type=int, default=24)
     ap.add_argument('--no-sweep', action='store_true')
+    ap.add_argument('--batch', type=int, default=1, help='images per call (the batched pipeline: 3 key fronts, 9 non-key frames)')
     args = ap.parse_args()
     pieces_list = [int(p) for p in args.pieces.split(',')]
     g = torch.Generator(device=DEV).manual_seed(0)
@@ -88,12 +89,13 @@ def main():
     for name in names:
         H, W, ci, co, k, stride, dil, epi = SHAPES[name]
         pad = dil * (k // 2)
-        xs = [torch.relu(torch.randn((1, H, W, ci), device=DEV, generator=g)) * 2.0 for _ in range(3)]
+        NB = args.batch
+        xs = [torch.relu(torch.randn((NB, H, W, ci), device=DEV, generator=g)) * 2.0 for _ in range(3)]
         ws = [torch.randn((co, ci, k, k), device=DEV, generator=g) * (1.0 / (ci * k * k) ** 0.5) for _ in range(6)]
         b = torch.randn(co, device=DEV, generator=g)
-        res = torch.randn((1, H, W, co), device=DEV, generator=g)
+        res = torch.randn((NB, H, W, co), device=DEV, generator=g)
         sc2, sh2 = torch.rand(co, device=DEV, generator=g) + 0.5, torch.randn(co, device=DEV, generator=g)
-        gf = 2.0 * H * W * ci * co * k * k / 1e9
+        gf = 2.0 * NB * H * W * ci * co * k * k / 1e9
         ref = torch.nn.functional.conv2d(xs[0].permute(0, 3, 1, 2).double().cpu(), ws[0].double().cpu(), b.double().cpu(), stride=stride, padding=pad,
                                          dilation=dil)
         if epi == 'res2':
@@ -101,9 +103,9 @@ def main():
         if epi in ('relu', 'nchw'):
             ref = torch.relu(ref)
         scale = float(ref.abs().max())
-        print("\n## %s   P=%d K=%d N=%d   %.2f GFLOP" % (name, H * W, ci * k * k, co, gf))
+        print("\n## %s   P=%d K=%d N=%d   %.2f GFLOP" % (name, NB * H * W, ci * k * k, co, gf))
         if k == 1 and stride == 1:      # the library GEMM of the same shape (untuned; bias / activation not included)
-            X = [x.view(H * W, ci) for x in xs]
+            X = [x.view(NB * H * W, ci) for x in xs]
             Wt = [w.view(co, ci).t().contiguous() for w in ws]
             t_lib = timed(lambda i: torch.mm(X[i % 3], Wt[i % 6]), args.reps)
             print("   library torch.mm (fp32 MFMA)                      %7.1f us   %6.1f TFLOP/s" % (t_lib, gf / t_lib * 1e3))
@@ -111,7 +113,7 @@ def main():
             sws = [hip.SplitWeight(w, pieces=pieces) for w in ws]
             ams = [hip.amax_partial(x) for x in xs]
             slots = hip.amax_slots(1, DEV)[0]
-            out = torch.empty((1, co, H, W) if epi == 'nchw' else (1, H, W, co), device=DEV)
+            out = torch.empty((NB, co, H, W) if epi == 'nchw' else (NB, H, W, co), device=DEV)
             out2 = torch.empty_like(out)
 
             def call(i, sws=sws, ams=ams, out=out, out2=out2):

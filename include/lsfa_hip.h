@@ -220,7 +220,7 @@ int lsfa_det_postprocess_batch(const float* rois, const float* deltas, const flo
  * Replaces: dff_rfcn/symbols/resnet_v1_101_flownet_rfcn.py:479-494 (and the rpn_inv_normalize the caller folds into the weights).
  * feat (N, C_total, H, W), C_total >= 512; w_t (512, 64) floats [input channel][output], output o < 2A = score channel o (background
  * a = o, foreground A + a), 2A <= o < 6A = box delta channel o - 2A, columns past 6A zero; bias (64);
- * cls_prob (N, 2A, H, W), bbox_pred (N, 4A, H, W).  fp32 FMA chains over ascending input channels in eight runs of 64, added in order.
+ * cls_prob (N, 2A, H, W), bbox_pred (N, 4A, H, W).  One fp32 FMA chain per output over ascending input channels.
  * ------------------------------------------------------------------------ */
 int lsfa_rpn_head(const float* feat, int N, int C_total, int H, int W, const float* w_t, const float* bias, int A,
                   float* cls_prob, float* bbox_pred, void* stream);
@@ -385,8 +385,10 @@ int lsfa_upsample_flow(const float* in, int N, int Hi, int Wi, int C, const floa
                        float* out, int ldy, int c0, unsigned* amax_out, void* stream);
 int lsfa_avgpool2_nhwc(const float* x, int N, int H, int W, int C, float* y, void* stream);
 /* channels [c0, c0 + C) of an (N, Ctot, HW) map as (N, HW, C) rows: the NCHW feature the reference's operators exchange
- * (`conv_feat`, resnet_v1_101_flownet_rfcn.py:479-481 SliceChannel) in the channels-last form lsfa_conv_split_fwd reads. */
-int lsfa_nchw_to_nhwc(const float* x, int N, int Ctot, int HW, int c0, int C, float* y, void* stream);
+ * (`conv_feat`, resnet_v1_101_flownet_rfcn.py:479-481 SliceChannel; Concat(warp, feat), :94-133) in the channels-last form lsfa_conv_fwd
+ * reads (the R-FCN score maps, the Nq / embedding nets).  amax_out (or NULL): 256 zeroed slots that receive max|x| of the copied values
+ * (lsfa_conv_fwd's amax_in). */
+int lsfa_nchw_to_nhwc(const float* x, int N, int Ctot, int HW, int c0, int C, float* y, unsigned* amax_out, void* stream);
 
 /* Inference BatchNorm (use_global_stats) + ReLU as one pass: y = max(x*scale[c]+shift[c], 0)
  * (sym_common.py:92-102 bn + relu of every pre-activation unit, resnet.py:70-101).

@@ -508,9 +508,9 @@ class FramePipeline(object):
                                   feat_shared=self.feat_cur, taps=taps, batch=B) for _ in range(lanes)]
         # segment > 0: the non-key frames of a segment (all served from one key feature) go through the network in ONE pass of `segment`
         # frames on the batch axis - what the reference's own batch test symbol does (get_batch_test_symbol,
-        # resnet_v1_101_flownet_rfcn.py:661-751) - on two alternating lanes, each with its own copy of the key feature; a shorter run of
+        # resnet_v1_101_flownet_rfcn.py:661-751) - on `lanes` (>= 2) alternating lanes, each with its own copy of the key feature; a shorter run of
         # non-key frames (the end of a clip) takes the per-frame lanes.  key_group > 1: see KeyBank and key_frame(upcoming=...).
-        self.feat_seg = [torch.zeros((B, dim, fh, fw), device=dev, dtype=torch.float32) for _ in range(2 if self.segment else 0)]
+        self.feat_seg = [torch.zeros((B, dim, fh, fw), device=dev, dtype=torch.float32) for _ in range(max(2, lanes) if self.segment else 0)]
         self.seg_lanes = [FrameGraphs(key_exec, cur_exec, cfg, height, width, dev, thresh, use_graphs, prefetch=False,
                                       feat_shared=f, taps=taps, batch=self.segment * B) for f in self.feat_seg]
         # one bank per group size 2 .. key_group: the tail of a run of key frames (fewer images ahead than key_group - 1) is a smaller group
@@ -556,7 +556,7 @@ class FramePipeline(object):
         self._seg_feat = self._seg_event = None     # feature (and its event) the buffered segment is served from
         # which key frame's feature the non-key lanes' copies hold (feat_cur, feat_seg[i]) against the one the current segment needs;
         # _handed[b]: events of the copies taken from key buffer b's current feature (key frame k + 2 overwrites it after them)
-        self._seg_key, self._seg_buf, self._cur_key, self._lane_key = 0, None, 0, [-1, -1]
+        self._seg_key, self._seg_buf, self._cur_key, self._lane_key = 0, None, 0, [-1] * len(self.seg_lanes)
         self._handed = [[], []]
         self._seg_needs_handover = False
         self._held = []                              # non-key frames recorded but not yet queued
@@ -646,7 +646,7 @@ class FramePipeline(object):
             e.record(main)
         self._seg_feat, self._seg_event, self._seg_needs_handover = self._feat_latest, None, False
         self._seg_key += 1
-        self._seg_buf, self._cur_key, self._lane_key, self._handed = None, self._seg_key, [-1, -1], [[], []]
+        self._seg_buf, self._cur_key, self._lane_key, self._handed = None, self._seg_key, [-1] * len(self.seg_lanes), [[], []]
 
     def capture(self, warmup=3):
         for lane in self.klanes:

@@ -131,14 +131,24 @@ __global__ __launch_bounds__(256) void avgpool2_cl_kernel(const float4* __restri
 
 // (N, Ctot, HW) planes -> (N, HW, C) rows for channels [c0, c0 + C): 64 x 64 tiles through LDS (padded rows: conflict-free both ways),
 // coalesced 256-byte reads along the pixels and writes along the channels
-__global__ __launch_bounds__(256) void nchw_to_nhwc_kernel(const float* __restrict__ x, int Ctot, int HW, int c0, int C, float* __restrict__ y) {
+__global__ __launch_bounds__(256) void nchw_to_nhwc_kernel(const float* __restrict__ x, int Ctot, int HW, int c0, int C, float* __restrict__ y,
+                                                           unsigned* __restrict__ amax_out) {
   __shared__ float tile[64][65];
   const int n = blockIdx.z, p0 = blockIdx.x * 64, cb = blockIdx.y * 64;
   const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
   const float* xs = x + ((size_t)n * Ctot + c0) * HW;
+  float top = 0.f;
   for (int r = ty; r < 64; r += 4) {
     const int c = cb + r, p = p0 + tx;
-    tile[r][tx] = (c < C && p < HW) ? xs[(size_t)c * HW + p] : 0.f;
+    const float v = (c < C && p < HW) ? xs[(size_t)c * HW + p] : 0.f;
+    tile[r][tx] = v;
+    top = fmaxf(top, fabsf(v));
+  }
+  if (amax_out) {      // the slots lsfa_conv_fwd reads as amax_in (a wave's maximum per atomic)
+    uint32_t m = __float_as_uint(top);
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) m = max(m, (uint32_t)__shfl_xor((int)m, d, 64));
+    if (tx == 0) atomicMax(amax_out + ((((blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * 4 + ty) & 255), m);
   }
   __syncthreads();
   float* ys = y + (size_t)n * HW * C;
@@ -150,12 +160,12 @@ __global__ __launch_bounds__(256) void nchw_to_nhwc_kernel(const float* __restri
 
 }  // namespace
 
-extern "C" int lsfa_nchw_to_nhwc(const float* x, int N, int Ctot, int HW, int c0, int C, float* y, void* stream) {
+extern "C" int lsfa_nchw_to_nhwc(const float* x, int N, int Ctot, int HW, int c0, int C, float* y, unsigned* amax_out, void* stream) {
   LSFA_REQUIRE(x && y, "lsfa_nchw_to_nhwc: NULL argument");
   LSFA_REQUIRE(N > 0 && Ctot > 0 && HW > 0 && c0 >= 0 && C > 0 && c0 + C <= Ctot, "lsfa_nchw_to_nhwc: bad shape");
   ProfScope prof(LSFA_OP_FLOWNET, (hipStream_t)stream);
   hipLaunchKernelGGL(nchw_to_nhwc_kernel, dim3((unsigned)((HW + 63) / 64), (unsigned)((C + 63) / 64), (unsigned)N), dim3(256), 0,
-                     (hipStream_t)stream, x, Ctot, HW, c0, C, y);
+                     (hipStream_t)stream, x, Ctot, HW, c0, C, y, amax_out);
   LSFA_LAUNCH_CHECK("lsfa_nchw_to_nhwc");
   return LSFA_OK;
 }

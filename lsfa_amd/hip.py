@@ -587,14 +587,19 @@ def upsample_flow(x, w, bias, out, c0, amax_out=None):
 
 
 @_on_tensor_device
-def nchw_to_nhwc(x, c0=0, c=None):
-    """channels [c0, c0 + c) of an (N, C, H, W) map -> (N, H, W, c) channels-last (lsfa_nchw_to_nhwc)."""
+def nchw_to_nhwc(x, c0=0, c=None, out=None, amax_out=None):
+    """channels [c0, c0 + c) of an (N, C, H, W) map -> (N, H, W, c) channels-last (lsfa_nchw_to_nhwc), into `out` when given (a contiguous
+    (N, H, W, c) tensor or leading slice of one); amax_out: a zeroed row of amax_slots() that receives max|.| of the copied values."""
     x = _f32c(x, "x")
     N, C, H, W = x.shape
     c = C - c0 if c is None else c
-    y = torch.empty((N, H, W, c), device=x.device, dtype=torch.float32)
-    _check(lib().lsfa_nchw_to_nhwc(_ptr(x), _ci(N), _ci(C), _ci(H * W), _ci(c0), _ci(c), _ptr(y), _stream()), "lsfa_nchw_to_nhwc")
-    return y
+    if out is None:
+        out = torch.empty((N, H, W, c), device=x.device, dtype=torch.float32)
+    elif tuple(out.shape) != (N, H, W, c) or not out.is_contiguous() or out.dtype != torch.float32:
+        raise LsfaError("nchw_to_nhwc: out must be a contiguous float32 %s tensor" % ((N, H, W, c),))
+    _check(lib().lsfa_nchw_to_nhwc(_ptr(x), _ci(N), _ci(C), _ci(H * W), _ci(c0), _ci(c), _ptr(out), _ptr(amax_out), _stream()),
+           "lsfa_nchw_to_nhwc")
+    return out
 
 
 def rfcn_head_ps_ld(ps_map, cell_ld, rois, H, W, ncls, nbox, spatial_scale=0.0625, pooled_size=7, group_size=7):

@@ -315,7 +315,8 @@ class Executor(object):
                                        rpn_post_nms_top_n=cfg.TEST.RPN_POST_NMS_TOP_N, threshold=cfg.TEST.RPN_NMS_THRESH,
                                        rpn_min_size=cfg.TEST.RPN_MIN_SIZE)
         two = self.pieces == 2
-        self._slots = {'backbone': _Slots(128, dev, two), 'small': _Slots(16, dev, two), 'agg': _Slots(8, dev, two), 'flow': _Slots(16, dev, two)}
+        self._slots = {'backbone': _Slots(128, dev, two), 'small': _Slots(16, dev, two), 'agg': _Slots(8, dev, two), 'flow': _Slots(16, dev, two),
+                       'heads': _Slots(2, dev, two)}
         W = lambda name: _t(arg[name], dev, f32)
         if sym.kind in ('key', 'batch'):
             self.net = _ResNetWeights(arg, aux, '', 4, cfg.network.add_dcn, True, dev, self.pieces)
@@ -514,9 +515,12 @@ class Executor(object):
         rois = self.proposal(cls_prob, rpn_bbox, im_info)
         D = self.ncls + self.nbox
         # both R-FCN convolutions as ONE 1x1 convolution of the own family that writes the position-sensitive layout [h][w][bin][class | box]
-        # directly: channels 512.. of the NCHW feature turned channels-last (one copy), then lsfa_conv_fwd (cells self.ps_ld floats apart)
-        rows = conv_feat[:, 512:].permute(0, 2, 3, 1).contiguous()
-        ps = self._conv(rows, self.rfcn_sw, self.rfcn_b_ps)
+        # directly: channels 512.. of the NCHW feature turned channels-last (one copy that also leaves their maximum), then lsfa_conv_fwd (cells
+        # self.ps_ld floats apart)
+        S = self._slots['heads'].begin()
+        am = S.new()
+        rows = hip.nchw_to_nhwc(conv_feat, 512, 512, amax_out=am)
+        ps = self._conv(rows, self.rfcn_sw, self.rfcn_b_ps, amax_in=am)
         if self.taps is not None:
             nchw = ps[..., :49 * D].reshape(n, h * w, 49, D).permute(0, 3, 2, 1).reshape(n, D * 49, h, w)
             self.taps.update(rpn_cls_prob=cls_prob, rpn_bbox_pred=rpn_bbox, cls_map=nchw[:, :self.n_cls_ch],
@@ -604,12 +608,12 @@ class Executor(object):
         with torch.no_grad():
             return self._key_heads(conv_feat, im_info)
 
-    def _pair_rows(self, first, second):
-        """Concat(first, second) on the batch axis (:95, :133) as channels-last images: (2N, H, W, C)"""
+    def _pair_rows(self, first, second, amax_out):
+        """Concat(first, second) on the batch axis (:95, :133) as channels-last images: (2N, H, W, C); their maximum into amax_out"""
         n, c, h, w = first.shape
         x = torch.empty((2 * n, h, w, c), device=first.device, dtype=torch.float32)
-        x[:n].copy_(first.permute(0, 2, 3, 1))
-        x[n:].copy_(second.permute(0, 2, 3, 1))
+        hip.nchw_to_nhwc(first, out=x[:n], amax_out=amax_out)
+        hip.nchw_to_nhwc(second, out=x[n:], amax_out=amax_out)
         return x
 
     def _key_aggregate(self, conv_feat, flow, scale_map, feat_key_old):
@@ -622,9 +626,9 @@ class Executor(object):
             if cfg.network.add_Nq_net:
                 # Nq_net (:94-109) on Concat(warp, conv_feat): rows 0..n-1 weight the warped maps, n..2n-1 the current ones
                 S = self._slots['agg'].begin()
-                x = self._pair_rows(warp, conv_feat)
-                am1, am2 = S.new(), S.new()
-                x = self._conv(x, self.nq[0][0], self.nq[0][1], 1, 1, 1, act=1, amax_out=am1)
+                am0, am1, am2 = S.new(), S.new(), S.new()
+                x = self._pair_rows(warp, conv_feat, am0)
+                x = self._conv(x, self.nq[0][0], self.nq[0][1], 1, 1, 1, act=1, amax_in=am0, amax_out=am1)
                 x = self._conv(x, self.nq[1][0], self.nq[1][1], act=1, amax_in=am1, amax_out=am2)
                 x = self._conv(x, self.nq[2][0], self.nq[2][1], amax_in=am2)
                 logits = x[..., 0].reshape(2 * n, 1, h, w).contiguous()
@@ -633,9 +637,9 @@ class Executor(object):
             elif cfg.network.add_Fgfa_net:
                 # get_embednet on Concat(conv_feat, warp) (:118-135; note the order, :133): 1x1 1024 -> 512, 3x3 512 -> 512, 1x1 512 -> 2048
                 S = self._slots['agg'].begin()
-                x = self._pair_rows(conv_feat, warp)
-                am1, am2 = S.new(), S.new()
-                x = self._conv(x, self.em[0][0], self.em[0][1], act=1, amax_out=am1)
+                am0, am1, am2 = S.new(), S.new(), S.new()
+                x = self._pair_rows(conv_feat, warp, am0)
+                x = self._conv(x, self.em[0][0], self.em[0][1], act=1, amax_in=am0, amax_out=am1)
                 x = self._conv(x, self.em[1][0], self.em[1][1], 1, 1, 1, act=1, amax_in=am1, amax_out=am2)
                 e = self._conv(x, self.em[2][0], self.em[2][1], amax_in=am2, nchw=True)
                 self._tap('embed', e)

@@ -108,6 +108,7 @@ def test_first_key_cur_second_key_at_1000x600(world):
                                                 oracle_fp32=rel_err(ref10['choose_feat_output'], d10['choose_feat_output']))
     key.taps = cur.taps = None
     record('fullres', rec)
+    world['oracles'] = dict(feat0=feat0, ref3=ref3, d3=d3, ref10=ref10, d10=d10)       # for the batched-pass test below
 
     for k in ('backbone_feat', 'cls_map', 'box_map', 'rpn_bbox_pred', 'small_feat', 'scale_map', 'choose_feat_second_key'):
         assert rec[k] < TOL_DENSE, (k, rec[k])
@@ -122,3 +123,51 @@ def test_first_key_cur_second_key_at_1000x600(world):
     # the dense features against float64: the GPU (split operands on the fp16 / bf16 matrix pipe) no further than 1.5x the fp32 oracle
     for k in ('backbone_feat_vs_f64', 'choose_feat_second_key_vs_f64'):
         assert rec[k]['gpu'] <= e2e.RATIO * rec[k]['oracle_fp32'] + 2.0 ** -23, (k, rec[k])
+
+
+def test_batched_passes_meet_the_same_criterion_at_1000x600(world):
+    """What FramePipeline(segment=9, key_group=3) computes - the fronts of three key frames in one pass, the nine non-key frames of a
+    segment in one pass - judged like the frame-by-frame graphs above: key frame 10 (slot 0 of a group with two more images) and non-key
+    frame 3 (image 2 of the segment 1..9), each cut out of its batch, against the SAME fp32 and float64 oracle frames.  A batch changes a
+    convolution's launch plan and with it the summation order; the float64-anchored criterion is what says that this is as good an fp32
+    evaluation as the oracle's."""
+    if 'oracles' not in world:
+        pytest.skip("runs after test_first_key_cur_second_key_at_1000x600 (its oracle frames are reused)")
+    cfg, arg, key, cur, clip = (world[k] for k in ('cfg', 'arg', 'key', 'cur', 'clip'))
+    o = world['oracles']
+    im_info = clip.im_info()
+    im_t = torch.from_numpy(im_info).to(DEV)
+    feat0 = o['feat0']
+    rec = {}
+    with torch.no_grad():
+        group, olds = [clip.frame(f).to(DEV) for f in (10, 11, 9)], [clip.frame(f).to(DEV) for f in (0, 10, 11)]
+        conv = key.key_backbone(torch.cat(group, 0))
+        flow, scale = key.key_flow(torch.cat(group, 0), torch.cat(olds, 0))
+        key.taps = {}
+        feat10 = key.key_aggregate(conv[0:1], flow[0:1], scale[0:1], feat0)
+        out10 = key.key_heads(feat10, im_t)
+        taps10 = dict(key.taps, backbone_feat=conv[0:1])
+        key.taps = None
+        check_key_frame(cfg, taps10, out10, feat0, im_info)
+        rec['frame10_in_a_group_of_three'] = e2e.frame_gap(cfg, e2e.gpu_side(cfg, taps10, out10, im_info), o['ref10'], o['d10'], im_info, H, W)
+        rec['choose_feat_vs_f64'] = dict(gpu=rel_err(np_(feat10), o['d10']['choose_feat_output']),
+                                         oracle_fp32=rel_err(o['ref10']['choose_feat_output'], o['d10']['choose_feat_output']))
+        seg = list(range(1, 10))
+        mvs, ress = [clip.motion_vector(f, 0) for f in seg], [clip.res_diff(f) for f in seg]
+        cur.taps = {}
+        outF = cur.forward(data=torch.cat([clip.frame(f).to(DEV) for f in seg], 0), im_info=im_t.repeat(len(seg), 1), feat_key=feat0,
+                           motion_vector=torch.cat(mvs, 0).to(DEV), res_diff=torch.cat(ress, 0).to(DEV))
+        tapsF = dict(cur.taps)
+        cur.taps = None
+        t3, o3 = e2e.image_of_batch(tapsF, outF, 2, len(seg))
+        check_cur_frame(cfg, arg, t3, o3, feat0, mvs[2], ress[2], im_info)
+        rec['frame3_in_a_segment_of_nine'] = e2e.frame_gap(cfg, e2e.gpu_side(cfg, t3, o3, im_info), o['ref3'], o['d3'], im_info, H, W)
+    key.check_status()
+    cur.check_status()
+    record('fullres_batched', rec)
+    for k in ('frame10_in_a_group_of_three', 'frame3_in_a_segment_of_nine'):
+        e = rec[k]
+        assert not e['failures'], (k, e['failures'], e)
+        assert e['max_abs_dscore'] <= TOL_SCORE, (k, e)
+        assert e['rois_compared'] >= 250, (k, e)
+    assert rec['choose_feat_vs_f64']['gpu'] <= e2e.RATIO * rec['choose_feat_vs_f64']['oracle_fp32'] + 2.0 ** -23, rec['choose_feat_vs_f64']

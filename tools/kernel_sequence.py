@@ -16,7 +16,8 @@ def main():
     names = [r['Kernel_Name'] for r in rows]
     # the period of the steady state: the shortest p with the last p names equal to the p before them (the first repetition
     # also runs one-off preparation kernels, so len(rows) / n is not it)
-    per = next(p for p in range(max(1, len(rows) // (2 * n)), len(rows) // 2) if names[-p:] == names[-2 * p:-p])
+    # (three equal periods, at least five launches long: a run of same-named convolutions is not a period)
+    per = next(p for p in range(5, len(rows) // 3) if names[-p:] == names[-2 * p:-p] == names[-3 * p:-2 * p])
     reps = max(1, min(n // 2, len(rows) // per - 1))
     tail = rows[len(rows) - per * reps:]
     tot = 0.0

@@ -23,7 +23,8 @@ def main(d, frac=0.5):
     rows.sort(key=lambda r: int(r['Start_Timestamp']))
     caps = [i for i, r in enumerate(rows) if 'det_cap_kernel' in r['Kernel_Name']]
     start = caps[int(len(caps) * (1 - frac))]
-    nframes = len([i for i in caps if i > start])
+    images = lambda r: max(1, int(r.get('Grid_Size_X', 1)) // max(1, int(r.get('Workgroup_Size_X', 1))))      # one workgroup per image
+    nframes = sum(images(rows[i]) for i in caps if i > start)
     rows = rows[start + 1:]
     t0, t1 = int(rows[0]['Start_Timestamp']), max(int(r['End_Timestamp']) for r in rows)
     wall = (t1 - t0) / 1e3

@@ -9,8 +9,9 @@ mkdir -p $OUT
 export TMPDIR=/tmp
 PY=python3
 
-# 1. the bench lines (default = configs[1]; configs[4]; configs[2])
+# 1. the bench lines (default = configs[1], batched passes; the same frame by frame; configs[4]; configs[2])
 timeout 600 $PY bench.py --steps 100 > $OUT/bench_default_run.json 2> $OUT/bench_default_run.err
+timeout 400 $PY bench.py --steps 60 --segment 0 --key-group 1 --no-cpu-baseline > $OUT/bench_frame_by_frame_run.json 2> /dev/null
 timeout 400 $PY bench.py --interval 1 --maps-per-launch 32 --steps 60 > $OUT/bench_interval1_maps32_run.json 2> $OUT/bench_interval1_maps32_run.err
 timeout 600 $PY bench.py --dtype bf16 --clips 4 --steps 40 > $OUT/bench_bf16_clips4_run.json 2> $OUT/bench_bf16_clips4_run.err
 timeout 400 $PY bench.py --dtype bf16 --steps 60 --no-cpu-baseline --no-parity > $OUT/bench_bf16_clips1_run.json 2> /dev/null
@@ -22,7 +23,7 @@ cp $(find $OUT/trace_pipe -name "*kernel_stats.csv" | head -1) $OUT/bench_pipeli
 rm -rf $OUT/trace_pipe
 
 # 3. matrix-pipe duty per kernel, serial eager loop (counters only: no trace domains next to --pmc)
-timeout 400 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES GRBM_GUI_ACTIVE --output-format csv -d $OUT/pmc_mfma -o t -- $PY bench.py --steps 6 --warmup 2 --no-graph --lanes 0 --no-cpu-baseline --no-parity > $OUT/pmc_mfma.log 2>&1
+timeout 400 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES GRBM_GUI_ACTIVE --output-format csv -d $OUT/pmc_mfma -o t -- $PY bench.py --steps 12 --warmup 3 --settle-s 0 --no-graph --no-cpu-baseline --no-parity --no-spread > $OUT/pmc_mfma.log 2>&1
 $PY tools/summarize_prof.py pmctable $OUT/pmc_mfma $OUT/bench_eager_pmc_mfma_busy.csv
 rm -rf $OUT/pmc_mfma
 
@@ -33,7 +34,7 @@ timeout 200 rocprofv3 --kernel-trace --output-format csv -d $OUT/pmc_trace -o t 
 $PY tools/traffic_probe.py summarize $OUT/pmc_fetch $OUT/pmc_write $OUT/pmc_trace $OUT/traffic.json > $OUT/traffic_summary.log 2>&1
 rm -rf $OUT/pmc_fetch $OUT/pmc_write $OUT/pmc_trace
 # 4b. HBM traffic of the split-convolution family per call (the `roofline.traffic` of the default bench line), same two-pass rule
-EAGER="bench.py --steps 4 --warmup 1 --settle-s 0 --no-graph --lanes 0 --no-cpu-baseline --no-parity --no-spread"
+EAGER="bench.py --steps 6 --warmup 3 --settle-s 0 --no-graph --no-cpu-baseline --no-parity --no-spread"
 timeout 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_cfetch -o t -- $PY $EAGER > $OUT/conv_traffic_fetch.log 2>&1
 timeout 300 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_cwrite -o t -- $PY $EAGER > $OUT/conv_traffic_write.log 2>&1
 $PY tools/summarize_prof.py convtraffic $OUT/pmc_cfetch $OUT/pmc_cwrite $OUT/traffic.json "conv_split:1000x600,interval=10,f32" > $OUT/conv_traffic_summary.log 2>&1
@@ -46,16 +47,27 @@ rm -rf $OUT/trace_ops
 timeout 200 $PY tools/lab/warp_lab.py --rounds 9 > $OUT/warp_lab.txt 2>&1
 timeout 200 $PY tools/key_sections.py > $OUT/key_sections.txt 2>&1
 LSFA_CONV_PIECES=3 timeout 200 $PY tools/key_sections.py > $OUT/key_sections_three_bf16_pieces.txt 2>&1
+timeout 300 $PY tools/lab/key_batch_probe.py 2>&1 | tail -4 > $OUT/key_batch_probe.txt
+timeout 300 $PY tools/lab/cur_batch_probe.py 2>&1 | tail -5 > $OUT/cur_batch_probe.txt
 
 # 6. the convolution kernels: every launch plan of the ring kernel per network shape against the library GEMM (error against
 #    float64 + time, hipGraph-timed); per-kernel durations and counters of a few plans; the detection post-processing phase by phase
 timeout 1500 $PY tools/lab/conv_ring_lab.py --pieces 2,3,1 > $OUT/conv_ring_lab.txt 2>&1
+timeout 900 $PY tools/lab/conv_ring_lab.py --quick --pieces 2 --batch 3 --shapes "res4,res5,res3,res2,feat" > $OUT/conv_ring_lab_batch3.txt 2>&1
 bash tools/lab/pmc_probe.sh > /dev/null 2>&1; mv gpurun_out/pmc_probe_summary.txt gpurun_out/trace_probe_rows_split.txt $OUT/ 2>/dev/null
 # 7. r3: kernel sequences of FlowNet and of one non-key frame (eager), multi-process determinism table
 timeout 200 rocprofv3 --kernel-trace --output-format csv -d $OUT/fn -o t -- $PY tools/backbone_only.py 20 flownet > /dev/null 2>&1
 timeout 60 $PY tools/kernel_sequence.py $OUT/fn 20 > $OUT/flownet_kernel_sequence.txt 2>&1; rm -rf $OUT/fn
 timeout 200 rocprofv3 --kernel-trace --output-format csv -d $OUT/cf -o t -- $PY tools/curframe_only.py 30 > /dev/null 2>&1
 timeout 60 $PY tools/kernel_sequence.py $OUT/cf 30 > $OUT/curframe_kernel_sequence.txt 2>&1; rm -rf $OUT/cf
+timeout 200 rocprofv3 --kernel-trace --output-format csv -d $OUT/cf9 -o t -- $PY tools/curframe_only.py 12 9 > /dev/null 2>&1
+timeout 60 $PY tools/kernel_sequence.py $OUT/cf9 12 > $OUT/segment9_kernel_sequence.txt 2>&1; rm -rf $OUT/cf9
 timeout 200 rocprofv3 --kernel-trace --output-format csv -d $OUT/bb -o t -- $PY tools/backbone_only.py 12 backbone > /dev/null 2>&1
 timeout 60 $PY tools/kernel_sequence.py $OUT/bb 12 --by-name > $OUT/backbone_kernels_by_name.txt 2>&1; rm -rf $OUT/bb
+timeout 300 rocprofv3 --kernel-trace --output-format csv -d $OUT/bb3 -o t -- $PY tools/backbone_only.py 10 backbone 3 > /dev/null 2>&1
+timeout 60 $PY tools/kernel_sequence.py $OUT/bb3 10 --by-name > $OUT/backbone3_kernels_by_name.txt 2>&1
+timeout 60 $PY tools/kernel_sequence.py $OUT/bb3 10 > $OUT/backbone3_kernel_sequence.txt 2>&1; rm -rf $OUT/bb3
+# 8. r4: where the pipelined loop's wall time goes per hardware queue
+timeout 300 rocprofv3 --kernel-trace --output-format csv -d $OUT/tl -o t -- $PY bench.py --steps 30 --no-cpu-baseline --no-parity --no-spread > /dev/null 2>&1
+timeout 120 $PY tools/pipeline_timeline.py $OUT/tl 0.5 > $OUT/pipeline_timeline.txt 2>&1; rm -rf $OUT/tl
 ls -la $OUT

@@ -14,10 +14,16 @@ def trace_summary(d, out, tail_frac=0.5, top=60):
     rows = list(csv.DictReader(open(f[0])))
     rows.sort(key=lambda r: int(r['Start_Timestamp']))
     caps = [i for i, r in enumerate(rows) if 'det_cap_kernel' in r['Kernel_Name']]
+
+    def images(r):      # det_cap_kernel runs one workgroup per image: a key frame's launch is one frame, a batched segment's is its frames
+        try:
+            return max(1, int(r['Grid_Size_X']) // max(1, int(r['Workgroup_Size_X'])))
+        except (KeyError, ValueError):
+            return 1
     if len(caps) > 4:
         start = caps[int(len(caps) * (1 - tail_frac))]
+        nframes = sum(images(rows[i]) for i in caps if i > start)
         rows = rows[start + 1:]
-        nframes = len([i for i in caps if i > start])
     else:
         nframes = 0
         rows = rows[int(len(rows) * (1 - tail_frac)):]
@@ -107,7 +113,7 @@ def conv_traffic(fetch_dir, write_dir, out_json, key):
              "write_bytes_per_launch": int(write_per_call), "calls_in_fetch_pass": calls_f, "calls_in_write_pass": calls_w,
              "per_kernel_avg_bytes": {k: {"dispatches": fe[k][1], "fetch": int(2048 * fe[k][0] / max(fe[k][1], 1)),
                                           "write": int(1024 * wr[k][0] / max(wr[k][1], 1)) if k in wr else None} for k in sorted(fe)},
-             "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) over `bench.py --no-graph --lanes 0`; FETCH_SIZE x2 "
+             "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) over `bench.py --no-graph` (the batched pipeline issued eagerly); FETCH_SIZE x2 "
                        "(gfx950), KiB units; a launch = one lsfa_conv_fwd call (main kernel + its reduce / fix-up pass)"}
     try:
         d = json.load(open(out_json))

@@ -782,8 +782,7 @@ def main():
                        "launch": "eager" if args.no_graph else "hipGraph replay per frame",
                        "setup_before_warmup": "graph capture + %d untimed interval(s) over %.1f s (clock settle), then the %d warm-up steps"
                                               % (settle_steps, args.settle_s, args.warmup),
-                       "gemm_solutions": "library default" if tuned is None else
-                                         ("lsfa_amd/tuned/gemm_gfx950.csv" if tuned else "tuned on first use (shipped file rejected)"),
+                       "gemm_solutions": "not applicable: no library GEMM or convolution is left in the frame path (r4)",
                        "pipeline": ("key stream%s + %d non-key lanes%s" % (
                            "" if args.no_flow_stream else " + FlowNet/tail stream", args.lanes,
                            ", next key frame queued ahead of the segment before it" if args.lookahead else ""))

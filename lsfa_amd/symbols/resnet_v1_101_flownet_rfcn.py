@@ -11,9 +11,9 @@ Execution design (not a translation of the MXNet graph) - ONE path per dtype sin
   * every convolution of ResNet-101 (+ DCN), the small net, FlowNet-S, the Nq / embedding nets and feat_conv_3x3 runs on the
     hand-written split-operand MFMA kernels behind lsfa_conv_fwd (lsfa_amd/csrc/conv_ring_kernel.h, conv_split_kernel.h),
     channels-last, fp32 in / fp32 accumulate / fp32 out.  `dtype=torch.float32` (BASELINE configs[1]) forms every fp32 product from
-    two fp16 pieces per operand and a power-of-two scale per map (three matrix instructions per product; FlowNet: three bf16
-    pieces, six products, no scale); `dtype=torch.bfloat16` (configs[2]) rounds the operands to one bf16 piece (one product).
-    No MIOpen call in either mode;
+    two fp16 pieces per operand and a power-of-two scale per map (three matrix instructions per product; FlowNet too: a Concat map's
+    producers share one row of amax slots); `dtype=torch.bfloat16` (configs[2]) rounds the operands to one bf16 piece (one product).
+    No library convolution or GEMM in either mode;
   * inference BatchNorms are folded at bind time: bn2 / bn3 of each pre-activation unit and bn0 into the preceding convolution;
     each unit's bn1 + relu1 (its input is also the raw shortcut, so it cannot be folded) is the SECOND OUTPUT of the previous
     unit's conv3 epilogue (y = conv3 + shortcut in place, y2 = relu(bn1_next(y))), the first one rides on the max-pooling launch;
@@ -22,8 +22,11 @@ Execution design (not a translation of the MXNet graph) - ONE path per dtype sin
   * the scale of the fp16 form is max|x| of the input map, left behind by the PRODUCING convolution's epilogue (`amax_out`, 256
     atomicMax slots zeroed once per frame section) - no pass of its own; an under-estimated scale raises the executor's status
     word (`Executor.check_status()`), it cannot silently overflow;
-  * the RPN and R-FCN score maps are library GEMMs (hipBLASLt through PyTorch: their input is the NCHW feature the reference's
-    operators exchange); both RPN convs are one GEMM, both R-FCN convs are one GEMM that writes a position-sensitive layout;
+  * the heads read the NCHW feature the reference's operators exchange: both RPN convs + bias + the per-anchor softmax are one kernel
+    (lsfa_rpn_head); both R-FCN convs are ONE convolution of the own family on a channels-last copy of channels 512.. (lsfa_nchw_to_nhwc,
+    which also leaves their maximum) that writes the position-sensitive layout lsfa_rfcn_head_ps_ld_fwd reads in place;
+  * every pass takes a batch: B lock-step clips, the F non-key frames of a segment (x B, frame-major: image f * B + b is warped from clip
+    b's key feature) or the fronts of G key frames - what lsfa_amd/core/graphs.py FramePipeline(segment, key_group) feeds it;
   * warp, x scale_map, + rnet_conv0(res_diff), + small-net feature, the Nq softmax-combine, Proposal, PSROI pooling + 7x7 average +
     class softmax, and DCN's bilinear im2col are the hand-written HIP kernels behind include/lsfa_hip.h;
   * ChooseOldKeyFeat / ChooseFeat (operator_py/choose_old_key_feat.py:23-32, choose_feat.py:23-31) are a host-side `if` on the

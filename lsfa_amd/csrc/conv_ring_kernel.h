@@ -310,6 +310,20 @@ static __global__ __launch_bounds__((SP ? 2 : 1) * kThreads, (Ring<NT, PC, ST>::
     if (!part) publish_amax(m, a.amax_out, a.status, blockIdx.x * 4 + g.wave);
     return;
   }
+  constexpr bool kColsFit = RG::kLdsBytes >= 4 * NT * 32 * kColPitch * 4;       // ... or their padded column-major images
+  if (kColsFit && a.y_nchw && !a.part && !a.view) {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();                       // every wave is done reading the ring
+    float* Tc = reinterpret_cast<float*>(&R[0][0]) + g.wave * (NT * 32 * kColPitch);
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) Tc[(t * 32 + (lane & 31)) * kColPitch + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)] = acc[t][r];
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       // the wave reads back what its own lanes wrote
+    const uint32_t m = tile_cols_out_nchw<NT>(a, Tc, m0, P, tile.y * (32 * NT), lane);
+    publish_amax(m, a.amax_out, a.status, blockIdx.x * 4 + g.wave);
+    return;
+  }
   int prow[16];
   RowOut ro;
   ro.valid = 0;

@@ -431,6 +431,48 @@ __device__ __forceinline__ uint32_t tile_rows_out(const Args& a, const float* T,
 }
 
 // can a channels-last output take the float4 row path (alignment of the operands it touches)
+// NCHW outputs leave through LDS too (r4).  In the accumulator layout a store instruction puts 32 channels of one pixel into 32
+// different planes: 4-byte pieces of 32 cache lines, 16 x NT times per wave (fuse_reduce_add writes 88 MB per nine-frame segment that
+// way).  Tc holds a wave's NT tiles COLUMN-major with padded columns ([tile][channel][33]: written from the accumulators without bank
+// conflicts by the caller); here lane -> (pixel m0 + lane % 32, channel c + lane / 32): an instruction stores two 128-byte runs of two
+// planes.  Same values, same arithmetic per element as tile_store_max (bias, residual, activation, second output, maximum, the
+// non-finite check on the pre-activation value).
+constexpr int kColPitch = 33;
+template <int NT>
+__device__ __forceinline__ uint32_t tile_cols_out_nchw(const Args& a, const float* Tc, int m0, int P, int ch0, int lane) {
+  const int p = m0 + (lane & 31);
+  const bool ok = p < P;
+  const int hw = a.Ho * a.Wo;
+  const int base = ok ? out_pixel_base(a, p) : 0;       // (n * Cout) * hw + the pixel's offset in its plane
+  const int act = a.act;
+  const bool has_y2 = a.y2 != nullptr, has_res = a.res != nullptr, has_bias = a.bias != nullptr;
+  float mx = 0.f, nf = 0.f;
+#pragma unroll
+  for (int t = 0; t < NT; ++t) {
+#pragma unroll 4
+    for (int c = 0; c < 32; c += 2) {
+      const int col = c + (lane >> 5), ch = ch0 + t * 32 + col;
+      float o = Tc[(t * 32 + col) * kColPitch + (lane & 31)];
+      if (!ok) continue;
+      if (has_bias) o = o + a.bias[ch];
+      if (has_res) o = o + a.res[base + ch * hw];
+      nf = nf + fabsf(o);
+      o = activate(o, act);
+      a.y[base + ch * hw] = o;
+      if (has_y2) {
+        const float w = fmaxf(o * a.scale2[ch] + a.shift2[ch], 0.f);
+        a.y2[base + ch * hw] = w;
+        mx = fmaxf(mx, w);
+      } else {
+        mx = fmaxf(mx, fabsf(o));
+      }
+    }
+  }
+  uint32_t m = __float_as_uint(mx);
+  if ((__float_as_uint(nf) & 0x7F800000u) == 0x7F800000u) m = 0x7FC00000u;       // a non-finite value went through this lane
+  return m;
+}
+
 __device__ __forceinline__ bool rows_path_ok(const Args& a) {
   return a.part || (!a.y_nchw && (a.ldy & 3) == 0 && ((uintptr_t)a.y & 15) == 0 && (!a.y2 || ((uintptr_t)a.y2 & 15) == 0) &&
                     (!a.res || ((uintptr_t)a.res & 15) == 0));

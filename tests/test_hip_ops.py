@@ -1048,6 +1048,49 @@ def test_conv_split_nchw_output_equals_nhwc_output(hip, cfg):
     assert torch.equal(z2, y2.permute(0, 3, 1, 2))
 
 
+@pytest.mark.parametrize("pieces", [2, 3, 1])
+def test_conv_ring_nchw_epilogue_through_lds(hip, pieces):
+    """The unsliced ring kernel writes NCHW outputs as 128-byte runs of a plane (tiles turned in LDS, column-major with padded columns)
+    instead of 4-byte pieces of 32 planes per instruction: under every tile width / ring depth / wave-role plan (K cut forced to one
+    slice), with bias + residual + ReLU-free second output and with LeakyReLU alone, two images whose 128-pixel tiles straddle the image
+    boundary and end in a partial tile - the same numbers as the channels-last output, transposed, and the same amax slots."""
+    g = torch.Generator(device=DEV).manual_seed(40 + pieces)
+    N, H, W, ci, co, k = 2, 13, 23, 64, 256, 3                    # 598 pixels: tiles of 128 straddle the images, the last one is partial
+    x = torch.randn((N, H, W, ci), device=DEV, generator=g)
+    sw = hip.SplitWeight(torch.randn((co, ci, k, k), device=DEV, generator=g) * 0.05, pieces=pieces)
+    b = torch.randn(co, device=DEV, generator=g)
+    res = torch.randn((N, H, W, co), device=DEV, generator=g)
+    res_n = res.permute(0, 3, 1, 2).contiguous()
+    sc2, sh2 = torch.rand(co, device=DEV, generator=g) + 0.5, torch.randn(co, device=DEV, generator=g)
+    am = hip.amax_partial(x)
+    try:
+        for kern in (1, 2):
+            for nt in (2, 4):
+                for st in (2, 3):
+                    hip.conv_plan_override(kernel=kern, nt=nt, st=st, slices=1)
+                    s1, s2 = hip.amax_slots(2, DEV)
+                    y, y2 = hip.conv_split(x, sw, b, 1, 1, 1, residual=res, out2=torch.empty_like(res), scale2=sc2, shift2=sh2, amax_in=am, amax_out=s1)
+                    z, z2 = hip.conv_split(x, sw, b, 1, 1, 1, residual=res_n, out2=torch.empty_like(res_n), scale2=sc2, shift2=sh2, nchw=True,
+                                           amax_in=am, amax_out=s2)
+                    assert torch.equal(z, y.permute(0, 3, 1, 2)) and torch.equal(z2, y2.permute(0, 3, 1, 2)), (kern, nt, st)
+                    assert s1.max().item() == s2.max().item() and s2.view(torch.float32).max().item() == z2.max().item()
+                    yl = hip.conv_split(x, sw, b, 1, 1, 1, act=2, amax_in=am)
+                    zl = hip.conv_split(x, sw, b, 1, 1, 1, act=2, nchw=True, amax_in=am)
+                    assert torch.equal(zl, yl.permute(0, 3, 1, 2)), (kern, nt, st)
+    finally:
+        hip.conv_plan_override()
+    # an overflowing scale is flagged through this epilogue too
+    if pieces == 2:
+        status = hip.new_status(DEV)
+        try:
+            hip.conv_plan_override(kernel=2, nt=4, st=3, slices=1)
+            hip.conv_split(x * 100.0, sw, b, 1, 1, 1, relu=True, nchw=True, amax_in=am, status=status)
+        finally:
+            hip.conv_plan_override()
+        with pytest.raises(hip.LsfaError, match="non-finite"):
+            hip.check_status(status)
+
+
 def test_conv_split_fused_tail_and_errors(hip):
     """residual add in place + second output (next unit's bn1 + ReLU), as lsfa_conv_nhwc_fused_fwd; shape errors."""
     import torch.nn.functional as F

@@ -77,8 +77,9 @@ def parse():
     ap.add_argument('--segment', type=int, default=-1,
                     help='non-key frames of a segment that go through the network in ONE pass, batch axis = frames (the reference\'s batch test '
                          'symbol, resnet_v1_101_flownet_rfcn.py:661-751); -1 = interval - 1 when one clip runs pipelined, else 0 = frame by frame')
-    ap.add_argument('--key-group', type=int, default=3,
-                    help='key frames whose image-only half (backbone, FlowNet) is computed in one pass (FramePipeline key_group); 1 = one by one')
+    ap.add_argument('--key-group', type=int, default=6,
+                    help='key frames whose image-only half (backbone, FlowNet) is computed in one pass (FramePipeline key_group; the first passes '
+                         'after the pipeline ran empty are 1 and 2 frames: its ramp); 1 = one by one')
     ap.add_argument('--lookahead', action='store_true',
                     help='queue each key frame ahead of the non-key frames that precede it in display order')
     ap.add_argument('--no-flow-stream', action='store_true', help='FlowNet after the backbone on the key stream instead of beside it')
@@ -789,7 +790,8 @@ def main():
                        if args.lanes > 0 else "serial",
                        "batching": ("one clip, frames in display order; the %d non-key frames of a segment go through the network in one pass (batch axis = "
                                     "frames, like the reference's batch test symbol) and the image-only half (backbone, FlowNet) of %d consecutive key "
-                                    "frames in one pass (look-ahead of %d frames); --segment 0 --key-group 1 = frame by frame" %
+                                    "frames in one pass (look-ahead of %d frames; after the pipeline ran empty the first passes are 1 and 2 key frames); "
+                                    "--segment 0 --key-group 1 = frame by frame" %
                                     (r.segment, r.key_group, (r.key_group - 1) * K)) if batched else "none: one frame per pass"},
             "value_spread": {"min": round(frames / max(repeats), 3), "max": round(frames / min(repeats), 3), "repeats": len(repeats),
                              "values": [round(frames / t, 3) for t in repeats],

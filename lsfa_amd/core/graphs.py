@@ -481,7 +481,7 @@ class FramePipeline(object):
     """
 
     def __init__(self, key_exec, cur_exec, cfg, height, width, device, thresh=1e-4, use_graphs=True, lanes=2,
-                 flow_stream=True, lookahead=False, taps=False, batch=1, layout=None, segment=0, key_group=1):
+                 flow_stream=True, lookahead=False, taps=False, batch=1, layout=None, segment=0, key_group=1, ramp=True):
         """batch > 1: that many clips advance in lock-step — every tensor handed to first_frame / key_frame /
         cur_frame carries one image (motion-vector field, residual) per clip on its batch axis, and the
         detection buffers gain a leading clip axis.
@@ -516,6 +516,11 @@ class FramePipeline(object):
         # one bank per group size 2 .. key_group: the tail of a run of key frames (fewer images ahead than key_group - 1) is a smaller group
         self.banks = {g: KeyBank(key_exec, cfg, height, width, dev, use_graphs, g, taps, B) for g in range(2, self.key_group + 1)}
         self._bank_ready = []                        # [(bank, slot, data_ptr)]: fronts of upcoming key frames already computed
+        # ramp: while the pipeline is empty (the first key frames of a clip, or after flush() / join()) nothing overlaps a pass of
+        # key_group fronts and every lane waits for it: the first pass after that is one front, the second a group of two, then full groups
+        self.ramp = bool(ramp) and self.key_group > 2
+        self._ramp_step = 0
+        self.group_sizes = []                        # the sizes of the passes issued so far (diagnostics / tests)
         self._next_seg = 0
         want = 1 + (1 if flow_stream else 0) + lanes
         layout = layout or os.environ.get('LSFA_STREAM_LAYOUT', 'probe')
@@ -600,10 +605,14 @@ class FramePipeline(object):
     def drop_fronts(self):
         """Forget the fronts the bank computed ahead for key frames that will not come (the caller abandons the run of frames it announced)."""
         self._bank_ready = []
+        self._ramp_step = 0
 
     def flush(self):
-        """Queue the non-key frames recorded so far (end of a clip, or before reading results)."""
+        """Queue the non-key frames recorded so far (end of a clip, or before reading results: the caller is about to let the pipeline
+        run empty, so the next fresh pass of key fronts starts the ramp again)."""
         self._issue_segment()
+        if not self._bank_ready:
+            self._ramp_step = 0
 
     def join(self):
         """Everything handed over so far is queued, and the caller's stream waits for it."""
@@ -617,6 +626,7 @@ class FramePipeline(object):
         self.join()
         self._next = self._nkey = self._next_seg = 0          # the lane / buffer of a frame depends only on its position in the clip
         self._bank_ready = []
+        self._ramp_step = 0
         lane, cfg = self.klanes[0], self.cfg
         saved = self.key_exec.taps
         if lane.want_taps:
@@ -682,10 +692,15 @@ class FramePipeline(object):
             if ptr != data.data_ptr():
                 raise ValueError("FramePipeline.key_frame: the bank holds the front of another image (hand the tensors of `upcoming` over in "
                                  "order, or drop_fronts())")
-        elif self.banks and upcoming:
-            g = min(self.key_group, 1 + len(upcoming))
-            bank, group, slot = self.banks[g], [data] + list(upcoming[:g - 1]), 0
-            self._bank_ready = [(bank, i, group[i].data_ptr()) for i in range(1, g)]
+        else:
+            cap = self.key_group if not self.ramp else (1, 2)[self._ramp_step] if self._ramp_step < 2 else self.key_group
+            self._ramp_step += 1
+            g = min(cap, 1 + len(upcoming or ())) if self.banks else 1
+            self.group_sizes.append(g)
+            del self.group_sizes[:-64]
+            if g >= 2:
+                bank, group, slot = self.banks[g], [data] + list(upcoming[:g - 1]), 0
+                self._bank_ready = [(bank, i, group[i].data_ptr()) for i in range(1, g)]
         with torch.cuda.stream(s):
             if ready is not None:
                 s.wait_event(ready)

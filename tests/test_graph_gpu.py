@@ -520,8 +520,9 @@ def test_frame_pipeline_batched_segments_and_key_groups(world, lookahead, group)
         torch.cuda.synchronize()
         return outs
 
-    fp = FramePipeline(key, cur, cfg, H, W, DEV, lanes=2, lookahead=lookahead, taps=True, segment=F, key_group=group)
+    fp = FramePipeline(key, cur, cfg, H, W, DEV, lanes=2, lookahead=lookahead, taps=True, segment=F, key_group=group, ramp=False)
     a, b = run(fp), run(fp)
+    assert fp.group_sizes == ([3, 1, 3, 1] if group == 3 else [2, 2, 2, 2])
     fp.close()
     # 1. every frame against the oracle's hand-written stages, on the pipeline's own intermediate values
     key_feat, prev_key = {0: a[0]['feat']}, 0
@@ -593,7 +594,7 @@ def test_frame_pipeline_batched_with_two_clips_in_lockstep(world):
     frames = {f: cat(lambda c: c.frame(f, DEV)) for f in range(9)}
     mvs = {f: cat(lambda c: c.motion_vector(f, kf, DEV)) for f, kf in sched if f != kf}
     ress = {f: cat(lambda c: c.res_diff(f, DEV)) for f, kf in sched if f != kf}
-    fp = FramePipeline(key, cur, cfg, H, W, DEV, lanes=2, taps=True, batch=B, segment=F, key_group=2)
+    fp = FramePipeline(key, cur, cfg, H, W, DEV, lanes=2, taps=True, batch=B, segment=F, key_group=2)       # (no ramp below key_group 3)
     outs = {}
 
     def keep(f, is_key):

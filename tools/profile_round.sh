@@ -47,7 +47,7 @@ rm -rf $OUT/trace_ops
 timeout 200 $PY tools/lab/warp_lab.py --rounds 9 > $OUT/warp_lab.txt 2>&1
 timeout 200 $PY tools/key_sections.py > $OUT/key_sections.txt 2>&1
 LSFA_CONV_PIECES=3 timeout 200 $PY tools/key_sections.py > $OUT/key_sections_three_bf16_pieces.txt 2>&1
-timeout 300 $PY tools/lab/key_batch_probe.py 2>&1 | tail -4 > $OUT/key_batch_probe.txt
+timeout 300 $PY tools/lab/key_batch_probe.py 2>&1 | tail -6 > $OUT/key_batch_probe.txt
 timeout 300 $PY tools/lab/cur_batch_probe.py 2>&1 | tail -5 > $OUT/cur_batch_probe.txt
 
 # 6. the convolution kernels: every launch plan of the ring kernel per network shape against the library GEMM (error against

@@ -312,10 +312,11 @@ void ring_plan(SplitPlan& p, long P, int chunk_total, int Cout, int pieces) {
   p.nx = (int)((P + convsplit::kWgPix - 1) / convsplit::kWgPix);
   // 128 x 128 tiles: long K with >= 512 output channels (r4, one image), or - maps of several images, the batched pipeline - wherever the
   // wider tiles alone still give the chip well over a wave of workgroups (profiles/r4/conv_ring_lab_batch3.txt: res4 conv3 44.1 -> 39.3 us,
-  // res5 conv3 108 -> 97, res5 sc 153 -> 127, res3 conv2 40.9 -> 38.6 at three images); never on two-chunk launches (res2 conv3: 144 -> 168)
+  // res5 conv3 108 -> 97, res5 sc 153 -> 127, res3 conv2 40.9 -> 38.6 at three images); never on launches of a few chunks (res2 conv3: 144 ->
+  // 168; res3 conv3 at six images: 158 -> 179)
   const long tiles4 = (long)p.nx * (Cout / 128);
-  int nt = (Cout % 128 == 0 && chunk_total >= 4 &&
-            ((Cout >= 512 && chunk_total >= 64) || tiles4 >= 400 || (tiles4 >= 200 && chunk_total >= 32 && Cout <= 256))) ? 4 : 2;
+  int nt = (Cout % 128 == 0 &&
+            ((Cout >= 512 && chunk_total >= 64) || (tiles4 >= 400 && chunk_total >= 8) || (tiles4 >= 200 && chunk_total >= 32 && Cout <= 256))) ? 4 : 2;
   if (f_nt && Cout % (32 * f_nt) == 0) nt = f_nt;
   const long tiles = (long)p.nx * (Cout / (32 * nt));
   // K slices: rounds of resident workgroups x chunks per slice (~0.9 us per chunk and workgroup with two chunks in flight: feat_conv_3x3 as
@@ -343,6 +344,10 @@ void ring_plan(SplitPlan& p, long P, int chunk_total, int Cout, int pieces) {
   // loader waves only add launch weight; mixed roles, two stages (res5 conv3 42.7 -> 40.4 us, res3 conv3 31.1 -> 24.9; at three images
   // res5 conv3 113 -> 97, res4 conv3 44.1 -> 39.3)
   if (s == 1 && per <= 16 && Cout >= 128 * chunk_total) sp = false;
+  // 128 x 128 tiles with at least ~1.5 workgroups per CU: two 256-thread mixed-role workgroups share a CU (two stages: 64 KB of LDS each)
+  // and overlap each other better than one 512-thread workgroup's loader and consumer waves do (six images, conv_ring_lab_batch6.txt:
+  // res5 shortcut 275 -> 257 us, res3 conv2 75 -> 67, res3 conv1 51 -> 44, feat_conv_3x3 1852 -> 1783; the DCN contraction 265 -> 270)
+  if (s == 1 && nt == 4 && tiles4 >= 400) sp = false;
   if (f_k == 1) sp = false;
   if (f_k == 2) sp = true;
   int st = sp ? 3 : 2;

@@ -40,6 +40,7 @@ class TestLoader(object):
         self.data = None
         self.label = []
         self.im_info = None
+        self._ahead = {}
         self.reset()
         self.get_batch()
 
@@ -90,8 +91,30 @@ class TestLoader(object):
 
     def _frame_inputs(self, entry, f, key_f):
         clip = entry['clip']
-        return {'data': clip.frame(f, self.device), 'im_info': torch.from_numpy(clip.im_info()).to(self.device),
+        data = self._ahead.pop((self.cur_roidb_index, f), None)      # an image upcoming_key_frames already produced: the SAME tensor
+        if data is None:
+            data = clip.frame(f, self.device)
+        return {'data': data, 'im_info': torch.from_numpy(clip.im_info()).to(self.device),
                 'motion_vector': clip.motion_vector(f, key_f, self.device), 'res_diff': clip.res_diff(f, self.device)}
+
+    def upcoming_key_frames(self, n):
+        """The images of the next `n` key frames of the CURRENT video after the frame just returned (fewer near the end of the video), for a
+        caller that computes the image-only part of several key frames at once (FramePipeline.key_frame(upcoming=...)).  Key frames are
+        every KEY_FRAME_INTERVAL-th frame and, by the rule of get_batch above (:106-109), the video's last frame.  The tensors are kept and
+        handed out again when the iteration reaches those frames."""
+        if self.cur_frameid == 0:             # the frame just returned was its video's last: nothing ahead in this video
+            return []
+        entry = self.roidb[self.cur_roidb_index]
+        K, L = self.cfg.TEST.KEY_FRAME_INTERVAL, entry['frame_seg_len']
+        out, prev = [], self.key_frameid
+        while len(out) < n and prev < L - 1:
+            f = min(prev + K, L - 1)          # the next multiple of the interval, or the video's last frame if that comes first
+            key = (self.cur_roidb_index, f)
+            if key not in self._ahead:
+                self._ahead[key] = entry['clip'].frame(f, self.device)
+            out.append(self._ahead[key])
+            prev = f
+        return out
 
     def get_batch(self):
         cur_roidb = self.roidb[self.cur_roidb_index]

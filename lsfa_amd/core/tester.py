@@ -210,11 +210,15 @@ def pred_eval(gpu_id, key_predictor, cur_predictor, test_data, imdb, cfg, vis=Fa
 
 
 def pred_eval_pipelined(gpu_id, key_predictor, cur_predictor, test_data, imdb, cfg, thresh=1e-4, logger=None, lanes=2,
-                        use_graphs=True, max_pipelines=4):
+                        use_graphs=True, max_pipelines=4, segment=0, key_group=1):
     """pred_eval with the frames of each video pipelined over HIP streams (core/graphs.py
     FramePipeline): same loader, same flags, same launch sequences per frame, same return value.
     One pipeline (captured graphs + static buffers) is built per distinct (height, width, scale) and
-    reused by every video of that shape."""
+    reused by every video of that shape.
+    segment / key_group (default off: then every frame's arithmetic is the serial loop's, bit for bit): the batched passes of
+    FramePipeline - `segment` non-key frames per pass (KEY_FRAME_INTERVAL - 1 batches whole segments; a shorter run before a video's last
+    frame goes frame by frame) and the image-only half of up to `key_group` key frames per pass, for which the loader is asked for the
+    coming key frames' images (TestLoader.upcoming_key_frames).  Same detections up to the rounding of a different K cut."""
     from lsfa_amd.core.graphs import FramePipeline
     num_classes = imdb.num_classes if imdb is not None else cfg.dataset.NUM_CLASSES
     data_names = [k[0] for k in test_data.provide_data[0]]
@@ -261,7 +265,8 @@ def pred_eval_pipelined(gpu_id, key_predictor, cur_predictor, test_data, imdb, c
                     pipelines.pop(next(iter(pipelines))).close()
                 fp = pipelines[shape_key] = FramePipeline(key_predictor._exec, cur_predictor._exec, cfg, shape_key[0],
                                                           shape_key[1], data.device, thresh=thresh,
-                                                          use_graphs=use_graphs, lanes=lanes, taps=bool(tap_file))
+                                                          use_graphs=use_graphs, lanes=max(lanes, 2) if segment else lanes, taps=bool(tap_file),
+                                                          segment=segment, key_group=key_group)
                 fp.set_scale(shape_key[2])
                 if logger:
                     logger.info('pipeline %dx%d streams: %s' % (shape_key[0], shape_key[1], fp.layout_used))
@@ -271,10 +276,11 @@ def pred_eval_pipelined(gpu_id, key_predictor, cur_predictor, test_data, imdb, c
             roidb_idx += 1
             roidb_offset = 0
         else:
+            upcoming = test_data.upcoming_key_frames(key_group - 1) if (key_frame_flag == 1 and key_group > 1) else None
             ready = torch.cuda.Event()
-            ready.record()          # the loader produced this frame's tensors on the current stream
+            ready.record()          # the loader produced this frame's (and the announced key frames') tensors on the current stream
             if key_frame_flag == 1:
-                fp.key_frame(data, deliver=deliver, ready=ready)
+                fp.key_frame(data, deliver=deliver, ready=ready, upcoming=upcoming)
             else:
                 fp.cur_frame(data, d['motion_vector'], d['res_diff'], deliver=deliver, ready=ready)
             roidb_offset += 1

@@ -26,10 +26,11 @@ def get_predictor(sym, sym_instance, cfg, arg_params, aux_params, test_data, ctx
 
 
 def test_rcnn(cfg, roidb, arg_params, aux_params, device=None, thresh=1e-4, logger=None, dtype=torch.float32,
-              pipeline=False, max_pipelines=4):
+              pipeline=False, max_pipelines=4, segment=0, key_group=1):
     """Returns (rows, frame_ids_local): `rows` = every rank's detections after the final gather.
     pipeline=True runs the frame loop through pred_eval_pipelined (frames of a video overlapped on HIP
-    streams) instead of the reference-shaped serial pred_eval; it keeps the captured pipelines of at most `max_pipelines` frame shapes."""
+    streams) instead of the reference-shaped serial pred_eval; it keeps the captured pipelines of at most `max_pipelines` frame shapes;
+    segment / key_group: its batched passes (pred_eval_pipelined)."""
     rank = dist.get_rank() if dist.is_available() and dist.is_initialized() else 0
     world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
     if device is None:
@@ -46,7 +47,7 @@ def test_rcnn(cfg, roidb, arg_params, aux_params, device=None, thresh=1e-4, logg
     key_predictor = get_predictor(key_sym, key_sym_instance, cfg, arg_params, aux_params, test_data, device, dtype)
     cur_predictor = get_predictor(cur_sym, cur_sym_instance, cfg, arg_params, aux_params, test_data, device, dtype)
     run = pred_eval_pipelined if pipeline else pred_eval
-    kw = dict(max_pipelines=max_pipelines) if pipeline else {}
+    kw = dict(max_pipelines=max_pipelines, segment=segment, key_group=key_group) if pipeline else {}
     all_boxes, frame_ids = run(rank, key_predictor, cur_predictor, test_data, None, cfg, thresh=thresh, logger=logger, **kw)
     rows = parallel.detections_to_rows(all_boxes, frame_ids)
     return parallel.gather_rows(rows), frame_ids

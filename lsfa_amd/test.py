@@ -37,6 +37,10 @@ def parse_args():
     ap.add_argument('--epoch', type=int, default=0)
     ap.add_argument('--serial', action='store_true', help='reference-shaped serial frame loop (pred_eval) instead of the '
                                                           'stream-pipelined one')
+    ap.add_argument('--segment', type=int, default=0,
+                    help='non-key frames per batched pass of the pipelined loop (-1: a whole segment, KEY_FRAME_INTERVAL - 1; 0: frame by '
+                         'frame, every detection equal to the serial loop\'s bit for bit)')
+    ap.add_argument('--key-group', type=int, default=1, help='key frames whose backbone + FlowNet run in one pass (look-ahead through the loader)')
     ap.add_argument('--out', default=None, help='rank 0 saves the gathered detection rows (n,7) here (.npy)')
     ap.add_argument('--dtype', default='f32', choices=['f32', 'bf16'],
                     help='f32: every fp32 product from two fp16 pieces (fp32 accuracy); bf16: one bf16 product per fp32 product (BASELINE configs[2])')
@@ -88,6 +92,7 @@ def main():
     t0 = time.time()
     rows, frame_ids = test_rcnn(cfg, roidb, arg_params, aux_params, device='cuda:%d' % local_rank, thresh=args.thresh,
                                 logger=logger, pipeline=not args.serial,
+                                segment=(cfg.TEST.KEY_FRAME_INTERVAL - 1 if args.segment < 0 else args.segment), key_group=args.key_group,
                                 dtype=torch.float32 if args.dtype == 'f32' else torch.bfloat16)
     torch.cuda.synchronize()
     dt = time.time() - t0

@@ -664,6 +664,43 @@ def test_pred_eval_pipelined_two_videos(world):
     np.testing.assert_array_equal(rows_s, rows_p)
 
 
+def test_pred_eval_pipelined_with_batched_passes(world):
+    """pred_eval_pipelined(segment = interval - 1, key_group = 3) - the reference-shaped frame loop on the batched pipeline, the coming key
+    frames' images obtained from the loader (TestLoader.upcoming_key_frames: the SAME tensors come back when the iteration reaches them) -
+    over two videos of 14 frames at key interval 4 (three full segments, a short one before the video's last frame, which is a key frame
+    by the loader's rule; a ramp of 1, 2 and then 3 key fronts per pass): the same frame ids as the serial pred_eval, and its detections up
+    to the rounding of the convolutions' different K cuts - per (frame, class) the same number of rows wherever no score sits on the
+    threshold, scores within 1e-4 (north_star's tolerance), boxes within 0.01 px."""
+    from lsfa_amd.config.config import lsfa_test_config
+    from lsfa_amd.function.test_rcnn import test_rcnn
+    from lsfa_amd.utils.synthetic import synthetic_roidb
+    cfg = lsfa_test_config(key_frame_interval=4)
+    arg, aux = world['arg'], world['aux']
+    roidb = synthetic_roidb(2, 14, H, W, 4)
+    rows_s, ids_s = test_rcnn(cfg, roidb, arg, aux, device=DEV, pipeline=False)
+    rows_b, ids_b = test_rcnn(cfg, roidb, arg, aux, device=DEV, pipeline=True, segment=3, key_group=3)
+    np.testing.assert_array_equal(ids_s, ids_b)
+    assert len(rows_s) > 0 and abs(len(rows_b) - len(rows_s)) <= 0.01 * len(rows_s)
+
+    def cells(rows):
+        out = {}
+        for r in rows:
+            out.setdefault((int(r[0]), int(r[1])), []).append(r[2:])
+        return {k: np.asarray(sorted(v, key=lambda x: -x[0])) for k, v in out.items()}
+    a, b = cells(rows_s), cells(rows_b)
+    same = [k for k in a if k in b and len(a[k]) == len(b[k])]
+    assert len(same) >= 0.98 * len(a), (len(same), len(a), len(b))
+    dscore = max(float(np.abs(a[k][:, 0] - b[k][:, 0]).max()) for k in same)
+    assert dscore <= 1e-4, dscore
+    # boxes of the rows whose scores pair up unambiguously (scores of one cell further apart than the tolerance)
+    dbox = 0.0
+    for k in same:
+        s = a[k][:, 0]
+        if len(s) < 2 or float(np.min(-np.diff(s))) > 2e-4:
+            dbox = max(dbox, float(np.abs(a[k][:, 1:] - b[k][:, 1:]).max()))
+    assert dbox <= 1e-2, dbox
+
+
 def test_pred_eval_pipelined_evicts_pipelines_of_old_shapes(world):
     """Five videos of three frame shapes (A, B, C, A, B) with room for TWO captured pipelines: the oldest shape's pipeline is closed (graphs
     and their memory pools dropped, streams parked) when a third shape arrives and rebuilt when its shape returns; every detection row

@@ -98,7 +98,7 @@ class TestLoader(object):
                 'motion_vector': clip.motion_vector(f, key_f, self.device), 'res_diff': clip.res_diff(f, self.device)}
 
     def upcoming_key_frames(self, n):
-        """The images of the next `n` key frames of the CURRENT video after the frame just returned (fewer near the end of the video), for a
+        """Call right after a KEY frame was returned: the images of the next `n` key frames of the same video (fewer near its end), for a
         caller that computes the image-only part of several key frames at once (FramePipeline.key_frame(upcoming=...)).  Key frames are
         every KEY_FRAME_INTERVAL-th frame and, by the rule of get_batch above (:106-109), the video's last frame.  The tensors are kept and
         handed out again when the iteration reaches those frames."""
@@ -106,7 +106,7 @@ class TestLoader(object):
             return []
         entry = self.roidb[self.cur_roidb_index]
         K, L = self.cfg.TEST.KEY_FRAME_INTERVAL, entry['frame_seg_len']
-        out, prev = [], self.key_frameid
+        out, prev = [], self.cur_frameid - 1       # the (key) frame just returned; key_frameid may already point past it (interval 1)
         while len(out) < n and prev < L - 1:
             f = min(prev + K, L - 1)          # the next multiple of the interval, or the video's last frame if that comes first
             key = (self.cur_roidb_index, f)

@@ -4,6 +4,7 @@ import os
 import socket
 
 import numpy as np
+import pytest
 import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
@@ -120,3 +121,39 @@ def test_vid_eval_matches_loop_form_restatement():
             got = ve.vid_eval(rows, gt, ncls, through_text=through_text)
             np.testing.assert_array_equal(got, want)
         assert want.max() > 0
+
+
+@pytest.mark.parametrize("K,n", [(4, 11), (4, 9), (3, 7), (10, 24), (1, 5)])
+def test_loader_announces_the_coming_key_frames(K, n):
+    """TestLoader.upcoming_key_frames (the look-ahead pred_eval_pipelined's key groups need), on the CPU: after every key frame (flags 0 / 1
+    of dff_rfcn/core/loader.py:92-121's state machine, incl. the rule that a video's last frame is a key frame) it names the next two key
+    frames of the SAME video - every KEY_FRAME_INTERVAL-th frame, then the last one - never a frame of the next video, and the iteration
+    later hands out those very tensors (same storage), in that order."""
+    from lsfa_amd.config.config import lsfa_test_config
+    from lsfa_amd.core.loader import TestLoader
+    from lsfa_amd.utils.synthetic import synthetic_roidb
+    cfg = lsfa_test_config(key_frame_interval=K)
+    loader = TestLoader(synthetic_roidb(2, n, 32, 48, K), cfg, device='cpu')
+    expected_keys = sorted(set(list(range(0, n, K)) + [n - 1]))
+    pending, seen, i = [], [], 0
+    for im_info, flag, batch in loader:
+        d = dict(zip(loader.data_name, batch.data[0]))
+        f = i % n
+        if f == 0:
+            assert flag == 0 and not pending          # nothing announced across a video boundary
+            seen = []
+        if flag in (0, 1):
+            seen.append(f)
+            if pending:
+                assert pending.pop(0).data_ptr() == d['data'].data_ptr(), (K, n, f)
+            up = loader.upcoming_key_frames(2)
+            ahead = [k for k in expected_keys if k > f][:2]
+            assert len(up) == len(ahead), (K, n, f, len(up), ahead)
+            for t, k in zip(up, ahead):
+                assert torch.equal(t, synthetic_roidb(2, n, 32, 48, K)[i // n]['clip'].frame(k, 'cpu')), (K, n, f, k)
+            known = {p.data_ptr() for p in pending}
+            pending += [t for t in up if t.data_ptr() not in known]
+        if f == n - 1:
+            assert seen == expected_keys, (K, n, seen)
+        i += 1
+    assert i == 2 * n and not pending

@@ -683,16 +683,16 @@ class FramePipeline(object):
         images (the end of a clip) the group is that much smaller; without any the frame's front is computed alone, as with key_group = 1."""
         if not self.lookahead:
             self._issue_segment()
+        bank, slot, group = None, -1, None
+        if self._bank_ready:
+            if self._bank_ready[0][2] != data.data_ptr():     # checked before anything is queued or counted: the call leaves no trace
+                raise ValueError("FramePipeline.key_frame: the bank holds the front of another image (hand the tensors of `upcoming` over in "
+                                 "order, or drop_fronts())")
+            bank, slot, _ = self._bank_ready.pop(0)
         b = self._nkey % 2
         self._nkey += 1
         lane, s = self.klanes[b], self.s_key
-        bank, slot, group = None, -1, None
-        if self._bank_ready:
-            bank, slot, ptr = self._bank_ready.pop(0)
-            if ptr != data.data_ptr():
-                raise ValueError("FramePipeline.key_frame: the bank holds the front of another image (hand the tensors of `upcoming` over in "
-                                 "order, or drop_fronts())")
-        else:
+        if bank is None:
             cap = self.key_group if not self.ramp else (1, 2)[self._ramp_step] if self._ramp_step < 2 else self.key_group
             self._ramp_step += 1
             g = min(cap, 1 + len(upcoming or ())) if self.banks else 1

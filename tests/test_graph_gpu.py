@@ -574,6 +574,51 @@ def test_frame_pipeline_batched_segments_and_key_groups(world, lookahead, group)
     assert worst < TOL_DENSE, worst
 
 
+def test_frame_pipeline_ramp_and_bank_bookkeeping(world):
+    """key_group = 4 with the ramp: after first_frame (and again after flush()) the passes are 1, 2 and then 4 key fronts; a key frame
+    whose front sits in the bank must hand over exactly the announced tensor (another one is an error, not a silently wrong feature);
+    drop_fronts() forgets announced frames; the features do not depend on how the key frames were grouped beyond the convolutions'
+    rounding (ramp on / off: within the dense tolerance)."""
+    from lsfa_amd.core.graphs import FramePipeline
+    from lsfa_amd.utils.synthetic import SyntheticClip
+    cfg, key, cur = world['cfg'], world['key'], world['cur']
+    key.taps = cur.taps = None
+    clip = SyntheticClip(9, 12, H, W, 1)
+    frames = [clip.frame(f, DEV) for f in range(12)]
+
+    def run(ramp, upto=9):
+        fp = FramePipeline(key, cur, cfg, H, W, DEV, lanes=2, use_graphs=False, key_group=4, ramp=ramp)
+        fp.first_frame(frames[0])
+        fp.capture()
+        feats = []
+        for k in range(1, upto):
+            fp.key_frame(frames[k], upcoming=frames[k + 1:upto])
+            feats.append(fp.feat.clone())
+        fp.join()
+        torch.cuda.synchronize()
+        return fp, feats
+    fp, with_ramp = run(True)
+    assert fp.group_sizes == [1, 2, 4, 1]                      # 8 key frames: 1 + 2 + 4, then one left with nothing ahead
+    fp.flush()
+    fp.key_frame(frames[9], upcoming=frames[10:12])
+    assert fp.group_sizes[-1] == 1                             # the pipeline ran empty: the ramp starts over
+    fp.key_frame(frames[10], upcoming=frames[11:12])
+    assert fp.group_sizes[-1] == 2
+    with pytest.raises(ValueError, match="another image"):
+        fp.key_frame(frames[3])                                # frames[11]'s front is what the bank holds
+    assert len(fp._bank_ready) == 1                            # the refused call left the bank as it was
+    fp.drop_fronts()
+    fp.key_frame(frames[3])                                    # fine now: computed alone
+    fp.join()
+    torch.cuda.synchronize()
+    fp.close()
+    fp2, without = run(False)
+    assert fp2.group_sizes == [4, 4]
+    fp2.close()
+    worst = max(float((a - b).abs().max() / b.abs().max()) for a, b in zip(with_ramp, without))
+    assert worst < TOL_DENSE, worst
+
+
 def test_frame_pipeline_batched_with_two_clips_in_lockstep(world):
     """FramePipeline(batch=2, segment=3, key_group=2): two clips advance together, so a segment pass carries 3 frames x 2 clips (frame-major:
     image f * 2 + b samples clip b's key feature - lsfa_warp_bilinear's feat_n = 2 < N = 6) and a key group 2 key frames x 2 clips.  Every

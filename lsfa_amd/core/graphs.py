@@ -552,7 +552,14 @@ class FramePipeline(object):
             sys.stderr.write('[lsfa] FramePipeline %dx%d streams: %s\n' % (height, width, self.layout_used))
         E = torch.cuda.Event
         self.ev_in, self.ev_flow, self.ev_tail, self.ev_handover = E(), E(), E(), E()
-        self.ev_feat = [E(), E()]                 # key-buffer i's feature exists
+        # A key frame's feature leaves its key lane right after `agg`: into one of key_group + 2 pool buffers, which is what the next key
+        # frame's aggregation, the non-key lanes' copies and the caller's `feat` read.  The key lane (two alternate) is then only held by
+        # its own tail; with the lanes copying out of the key lane itself the aggregations of a group advanced at the pace of the
+        # SEGMENTS (buffer k + 2 waited for segment k's copy, which waited for its lane to finish the previous group's segments) and the
+        # next pass of fronts started ~4 ms late (profiles/r4/pipeline_timeline.txt: the key queue idle a third of the time).
+        self._feat_pool = [torch.zeros((B, dim, fh, fw), device=dev, dtype=torch.float32) for _ in range(self.key_group + 2)]
+        self.ev_feat = [E() for _ in self._feat_pool]      # pool buffer i holds its key frame's feature
+        self.ev_tail_of = [E(), E()]              # key lane i's tail is done reading its feature
         self.ev_lane = [E() for _ in range(lanes)]
         self.captured = False
         self.delivering = None
@@ -562,7 +569,7 @@ class FramePipeline(object):
         # which key frame's feature the non-key lanes' copies hold (feat_cur, feat_seg[i]) against the one the current segment needs;
         # _handed[b]: events of the copies taken from key buffer b's current feature (key frame k + 2 overwrites it after them)
         self._seg_key, self._seg_buf, self._cur_key, self._lane_key = 0, None, 0, [-1] * len(self.seg_lanes)
-        self._handed = [[], []]
+        self._handed = [[] for _ in self._feat_pool]
         self._seg_needs_handover = False
         self._held = []                              # non-key frames recorded but not yet queued
 
@@ -652,11 +659,11 @@ class FramePipeline(object):
         self.feat_cur.copy_(self._feat_latest)
         for s in self._all_streams():
             s.wait_stream(main)
-        for e in [self.ev_handover, self.ev_tail] + self.ev_feat + self.ev_lane:
+        for e in [self.ev_handover, self.ev_tail] + self.ev_feat + self.ev_lane + self.ev_tail_of:
             e.record(main)
         self._seg_feat, self._seg_event, self._seg_needs_handover = self._feat_latest, None, False
         self._seg_key += 1
-        self._seg_buf, self._cur_key, self._lane_key, self._handed = None, self._seg_key, [-1] * len(self.seg_lanes), [[], []]
+        self._seg_buf, self._cur_key, self._lane_key, self._handed = None, self._seg_key, [-1] * len(self.seg_lanes), [[] for _ in self._feat_pool]
 
     def capture(self, warmup=3):
         for lane in self.klanes:
@@ -704,6 +711,9 @@ class FramePipeline(object):
         with torch.cuda.stream(s):
             if ready is not None:
                 s.wait_event(ready)
+            # this key lane's previous frame (k - 2) is through its tail and its `deliver`: the heads are done reading its feature, and whoever
+            # reads the lane's taps there (tests) is done with the static buffers that the front / the copies from the bank / `agg` overwrite
+            s.wait_event(self.ev_tail_of[b])
             if slot < 0 or group is not None:
                 front = lane if slot < 0 else bank
                 if slot < 0:
@@ -727,6 +737,10 @@ class FramePipeline(object):
                         self.ev_flow.record(self.s_flow)
                     front.run_front()
                     s.wait_event(self.ev_flow)
+                    if not lane.use_graphs:
+                        # eager mode: FlowNet's outputs were allocated on the FlowNet stream and are read here, on the key stream
+                        for t in front.flow_out:
+                            t.record_stream(s)
                 else:
                     front.run_front()
                     front.run_flow()
@@ -742,27 +756,31 @@ class FramePipeline(object):
                     lane.conv_feat, lane.flow_out = parts[0], (parts[1], parts[2])
                 if lane.want_taps:
                     lane.taps['backbone_feat'] = lane.conv_feat
-            # this buffer's previous feature (key frame k-2) has been handed over / consumed: its copies to the non-key lanes
-            # were queued with segment k-2, i.e. before this call
-            for e in self._handed[b]:
-                s.wait_event(e)
-            self._handed[b] = []
-            s.wait_event(self.ev_tail)           # ... and that frame's heads are done reading it
             lane.feat_old.copy_(self._feat_latest)   # the previous key frame's feature (same stream: it exists)
             lane.run_agg()
-            self.ev_feat[b].record(s)
+            # out of the key lane: pool buffer j, once the copies taken from its previous occupant (key frame k - len(pool)) are done
+            j = (self._nkey - 1) % len(self._feat_pool)
+            for e in self._handed[j]:
+                s.wait_event(e)
+            self._handed[j] = []
+            pooled = self._feat_pool[j]
+            pooled.copy_(lane.feat)
+            self.ev_feat[j].record(s)
             st = self.s_flow if self.s_flow is not None else s
             with torch.cuda.stream(st):
-                st.wait_event(self.ev_feat[b])
+                st.wait_event(self.ev_feat[j])
+                if not lane.use_graphs:
+                    lane.feat.record_stream(st)  # eager mode: allocated by `agg` on the key stream, read by the tail here
                 lane.run_tail()                  # heads + detections: off the key stream
                 if deliver is not None:
                     self.delivering = lane       # whose buffers `deliver` sees (tests read its taps)
                     deliver(lane.post_bufs)
                 self.ev_tail.record(st)
+                self.ev_tail_of[b].record(st)
         if self.lookahead:
             self._issue_segment()                # the frames BEFORE this key frame, served from the previous feature
-        self._feat_latest, self._prev_key_data = lane.feat, data
-        self._seg_feat, self._seg_event, self._seg_needs_handover, self._seg_buf = lane.feat, self.ev_feat[b], True, b
+        self._feat_latest, self._prev_key_data = pooled, data
+        self._seg_feat, self._seg_event, self._seg_needs_handover, self._seg_buf = pooled, self.ev_feat[j], True, j
         self._seg_key += 1
         return lane.post_bufs
 

@@ -297,6 +297,8 @@ class KeyBank(object):
         self.conv_feat = self.flow_out = None
         self.front_graph = self.flow_graph = None
         self.want_taps = taps
+        E = torch.cuda.Event
+        self.ev_front, self.ev_flow, self.ev_free = E(), E(), E()      # backbone done / FlowNet done / every slice copied out
 
     def front(self):
         self.conv_feat = self.key.key_backbone(self.data)
@@ -362,6 +364,7 @@ class KeyLane(object):
         self.flow_graph = None
         self.feat = None
         self.front_graph = self.agg_graph = self.tail_graph = None
+        self.ev_front, self.ev_flow = torch.cuda.Event(), torch.cuda.Event()
 
     def _tapped(self, fn):
         """Run one part with the executor's tap dict pointed at this lane's (parity tests only)."""
@@ -514,7 +517,10 @@ class FramePipeline(object):
         self.seg_lanes = [FrameGraphs(key_exec, cur_exec, cfg, height, width, dev, thresh, use_graphs, prefetch=False,
                                       feat_shared=f, taps=taps, batch=self.segment * B) for f in self.feat_seg]
         # one bank per group size 2 .. key_group: the tail of a run of key frames (fewer images ahead than key_group - 1) is a smaller group
-        self.banks = {g: KeyBank(key_exec, cfg, height, width, dev, use_graphs, g, taps, B) for g in range(2, self.key_group + 1)}
+        # (two of the full size, alternating: the next group's pass may start while this group's key frames still take their slices)
+        self.banks = {g: [KeyBank(key_exec, cfg, height, width, dev, use_graphs, g, taps, B) for _ in range(2 if g == self.key_group else 1)]
+                      for g in range(2, self.key_group + 1)}
+        self._bank_turn = 0
         self._bank_ready = []                        # [(bank, slot, data_ptr)]: fronts of upcoming key frames already computed
         # ramp: while the pipeline is empty (the first key frames of a clip, or after flush() / join()) nothing overlaps a pass of
         # key_group fronts and every lane waits for it: the first pass after that is one front, the second a group of two, then full groups
@@ -601,7 +607,7 @@ class FramePipeline(object):
         hands its streams back to core/streams.py (parked there: see streams._REUSE for why they are not recycled)."""
         self.join()
         torch.cuda.synchronize(self.device)
-        for g in self.klanes + self.lanes + self.seg_lanes + list(self.banks.values()):
+        for g in self.klanes + self.lanes + self.seg_lanes + [b for bs in self.banks.values() for b in bs]:
             g.close()
         extra = [st for st in self.s_lane if st not in self._owned_streams]
         for st in self._owned_streams + extra:
@@ -671,8 +677,9 @@ class FramePipeline(object):
             lane.capture(warmup)
         for lane in self.lanes + self.seg_lanes:
             lane.capture(warmup, key=False)
-        for bank in self.banks.values():
-            bank.capture()
+        for bs in self.banks.values():
+            for bank in bs:
+                bank.capture()
         torch.cuda.synchronize(self.device)
         self.captured = True
         self._publish_from_main()
@@ -706,22 +713,25 @@ class FramePipeline(object):
             self.group_sizes.append(g)
             del self.group_sizes[:-64]
             if g >= 2:
-                bank, group, slot = self.banks[g], [data] + list(upcoming[:g - 1]), 0
+                self._bank_turn += 1
+                bank, group, slot = self.banks[g][self._bank_turn % len(self.banks[g])], [data] + list(upcoming[:g - 1]), 0
                 self._bank_ready = [(bank, i, group[i].data_ptr()) for i in range(1, g)]
-        with torch.cuda.stream(s):
-            if ready is not None:
-                s.wait_event(ready)
-            # this key lane's previous frame (k - 2) is through its tail and its `deliver`: the heads are done reading its feature, and whoever
-            # reads the lane's taps there (tests) is done with the static buffers that the front / the copies from the bank / `agg` overwrite
-            s.wait_event(self.ev_tail_of[b])
-            if slot < 0 or group is not None:
-                front = lane if slot < 0 else bank
+        # ---- the image-only part, when this call starts one: a pass of the bank (or this frame's front alone) on the key stream, FlowNet
+        #      beside it; nothing here waits for aggregations or tails, so passes run back to back
+        src = bank if slot >= 0 else lane
+        if slot < 0 or group is not None:
+            with torch.cuda.stream(s):
+                if ready is not None:
+                    s.wait_event(ready)
                 if slot < 0:
+                    # the key lane's own front: its static buffers are free once its previous frame (k - 2) is through tail and `deliver`
+                    s.wait_event(self.ev_tail_of[b])
                     for t in (data, self._prev_key_data):
                         t.record_stream(s)               # the caller may drop its reference right after this call
                     lane.data.copy_(data)
                     lane.data_key_old.copy_(self._prev_key_data)
                 else:
+                    s.wait_event(bank.ev_free)           # the bank's previous group has taken all its slices
                     # frame i of the group against its predecessor (the previous key frame for i = 0)
                     olds = [self._prev_key_data] + group[:-1]
                     for t in group + olds[:1]:
@@ -733,50 +743,60 @@ class FramePipeline(object):
                     self.ev_in.record(s)
                     with torch.cuda.stream(self.s_flow):
                         self.s_flow.wait_event(self.ev_in)
-                        front.run_flow()
-                        self.ev_flow.record(self.s_flow)
-                    front.run_front()
-                    s.wait_event(self.ev_flow)
-                    if not lane.use_graphs:
-                        # eager mode: FlowNet's outputs were allocated on the FlowNet stream and are read here, on the key stream
-                        for t in front.flow_out:
-                            t.record_stream(s)
+                        src.run_flow()
+                        src.ev_flow.record(self.s_flow)
+                    src.run_front()
+                    src.ev_front.record(s)
                 else:
-                    front.run_front()
-                    front.run_flow()
+                    src.run_front()
+                    src.run_flow()
+                    src.ev_front.record(s)
+                    src.ev_flow.record(s)
+        # ---- this key frame's own part: its slice of the bank, aggregation, the feature into the pool - on the FlowNet / tail stream when
+        #      there is one (in order behind the FlowNet pass and the previous key frames' tails), so that the key stream is free for the next pass
+        sa = self.s_flow if self.s_flow is not None else s
+        with torch.cuda.stream(sa):
+            if ready is not None:
+                sa.wait_event(ready)
+            sa.wait_event(src.ev_front)
+            sa.wait_event(src.ev_flow)
+            if not lane.use_graphs:
+                # eager mode: the maps were allocated on the streams that produced them and are read here
+                for t in (src.conv_feat,) + tuple(src.flow_out):
+                    t.record_stream(sa)
+            # this key lane's previous frame (k - 2) is through its tail and its `deliver`: the heads are done reading its feature, and whoever
+            # reads the lane's taps there (tests) is done with the static buffers that the copies from the bank / `agg` overwrite
+            sa.wait_event(self.ev_tail_of[b])
             if slot >= 0:
                 # this frame's slice of the bank -> what the key lane's `agg` reads (static buffers under replay)
                 sl = slice(slot * bank.B, (slot + 1) * bank.B)
                 parts = (bank.conv_feat[sl], bank.flow_out[0][sl], bank.flow_out[1][sl])
-                if self.klanes[0].use_graphs:
+                if lane.use_graphs:
                     lane.conv_feat.copy_(parts[0])
                     lane.flow_out[0].copy_(parts[1])
                     lane.flow_out[1].copy_(parts[2])
                 else:
                     lane.conv_feat, lane.flow_out = parts[0], (parts[1], parts[2])
+                if slot == bank.G - 1:
+                    bank.ev_free.record(sa)
                 if lane.want_taps:
                     lane.taps['backbone_feat'] = lane.conv_feat
-            lane.feat_old.copy_(self._feat_latest)   # the previous key frame's feature (same stream: it exists)
+            lane.feat_old.copy_(self._feat_latest)   # the previous key frame's feature (queued earlier on this stream: it exists)
             lane.run_agg()
             # out of the key lane: pool buffer j, once the copies taken from its previous occupant (key frame k - len(pool)) are done
             j = (self._nkey - 1) % len(self._feat_pool)
             for e in self._handed[j]:
-                s.wait_event(e)
+                sa.wait_event(e)
             self._handed[j] = []
             pooled = self._feat_pool[j]
             pooled.copy_(lane.feat)
-            self.ev_feat[j].record(s)
-            st = self.s_flow if self.s_flow is not None else s
-            with torch.cuda.stream(st):
-                st.wait_event(self.ev_feat[j])
-                if not lane.use_graphs:
-                    lane.feat.record_stream(st)  # eager mode: allocated by `agg` on the key stream, read by the tail here
-                lane.run_tail()                  # heads + detections: off the key stream
-                if deliver is not None:
-                    self.delivering = lane       # whose buffers `deliver` sees (tests read its taps)
-                    deliver(lane.post_bufs)
-                self.ev_tail.record(st)
-                self.ev_tail_of[b].record(st)
+            self.ev_feat[j].record(sa)
+            lane.run_tail()                      # heads + detections
+            if deliver is not None:
+                self.delivering = lane           # whose buffers `deliver` sees (tests read its taps)
+                deliver(lane.post_bufs)
+            self.ev_tail.record(sa)
+            self.ev_tail_of[b].record(sa)
         if self.lookahead:
             self._issue_segment()                # the frames BEFORE this key frame, served from the previous feature
         self._feat_latest, self._prev_key_data = pooled, data

@@ -215,15 +215,14 @@ int lsfa_det_postprocess_batch(const float* rois, const float* deltas, const flo
                                void* ws, size_t ws_bytes, void* stream);
 
 /* ------------------------------------------------------------------------ *
- * RPN head on the NCHW feature map: rpn_cls_score + rpn_bbox_pred (1x1 convolutions of channels [0, 512), both in one pass) + bias +
- * the per-anchor two-way softmax (Reshape (2, A*H, W) -> SoftmaxActivation(channel) -> Reshape).
+ * RPN head.  rpn_cls_score + rpn_bbox_pred (1x1 convolutions of channels [0, 512) of the NCHW feature, both as ONE convolution: lsfa_conv_fwd
+ * with x_nchw = 1, output channel o < 2A = score channel o, 2A <= o < 6A = box delta o - 2A, padded to 64) leave `logits` (N, H*W, ld)
+ * channels-last; lsfa_rpn_softmax_split applies the per-anchor two-way softmax (Reshape (2, A*H, W) -> SoftmaxActivation(channel) ->
+ * Reshape) and splits them into the NCHW maps MultiProposal takes.
  * Replaces: dff_rfcn/symbols/resnet_v1_101_flownet_rfcn.py:479-494 (and the rpn_inv_normalize the caller folds into the weights).
- * feat (N, C_total, H, W), C_total >= 512; w_t (512, 64) floats [input channel][output], output o < 2A = score channel o (background
- * a = o, foreground A + a), 2A <= o < 6A = box delta channel o - 2A, columns past 6A zero; bias (64);
- * cls_prob (N, 2A, H, W), bbox_pred (N, 4A, H, W).  One fp32 FMA chain per output over ascending input channels.
+ * cls_prob (N, 2A, H, W): channel a = background, A + a = foreground of anchor a; bbox_pred (N, 4A, H, W).
  * ------------------------------------------------------------------------ */
-int lsfa_rpn_head(const float* feat, int N, int C_total, int H, int W, const float* w_t, const float* bias, int A,
-                  float* cls_prob, float* bbox_pred, void* stream);
+int lsfa_rpn_softmax_split(const float* logits, int N, int H, int W, int ld, int A, float* cls_prob, float* bbox_pred, void* stream);
 
 /* Box decode + clip + rescale only (float64 out), for callers that keep the
  * reference's im_detect() signature:  tester.py:143-152. pred_boxes (R, 4*nreg) */
@@ -315,6 +314,9 @@ typedef struct lsfa_conv_desc {
   unsigned* amax_out; unsigned* status;
   int Ho, Wo, out_H, out_W, out_sy, out_sx;
   int prof_tag;          /* lsfa_prof_*: 0 counts the call as "conv", 1 as "flownet" */
+  int x_nchw;            /* != 0: x is an NCHW map (N, lda, H, W) whose channels [0, Cin) are the input (K-major for the contraction): 1x1 /
+                          * stride 1 / no padding and small weights only (Cout * Cin * 2 * pieces <= 256 KB per 64 output channels) -
+                          * the RPN's 1x1 convolutions on the feature map the reference's operators exchange; else LSFA_ENOTSUP */
 } lsfa_conv_desc;
 size_t lsfa_conv_weight_bytes(int Cout, int kh, int kw, int Cin, int pieces);
 int lsfa_conv_weights(const float* w, int Cout, int kh, int kw, int Cin, int pieces, int w_exp, void* wfrag, void* stream);

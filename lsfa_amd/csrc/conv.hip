@@ -504,6 +504,18 @@ int conv_split_prepare(convsplit::Args& a, int pieces, SplitPlan& p, long& P_out
   LSFA_REQUIRE(((long)N * a.out_H * a.out_W + 1) * (long)(a.y_nchw ? Cout : a.ldy) < (1L << 31) && P * Cout < (1L << 31) &&
                ((long)N * H * W + (long)(a.pad_h + 1) * (W + 1)) * a.lda < (1L << 31), "%s: tensor too large", who);
   p = view_plan(N, H, W, Cin, Cout, kh, kw, stride, a.pad_h, a.pad_w, dil, a.lda, a.Ho, a.Wo, pieces);
+  if (a.x_kmajor) {
+    // a K-major (NCHW) input exists in the direct kernel only: 1x1, stride 1, no padding, plain output grid, small weights
+    const size_t wbytes = (size_t)Cin * 2 * pieces * 64;
+    if (kh != 1 || kw != 1 || stride != 1 || a.pad_h || a.pad_w || a.nphase > 1 || a.lda < Cin || wbytes > (256u << 10) || a.Ho != H || a.Wo != W) {
+      set_error("%s: an NCHW input (x_nchw) needs a 1x1 / stride 1 / pad 0 convolution with at most 256 KB of weights per 64 output channels", who);
+      return LSFA_ENOTSUP;
+    }
+    LSFA_REQUIRE((long)N * a.lda * H * W < (1L << 31), "%s: tensor too large", who);
+    p = SplitPlan{};
+    p.direct = true;
+    p.slices = 1;
+  } else
   // small weights on a small map: the direct kernel (a 64-channel group's weights <= 256 KB at three pieces, re-read by every 32-pixel
   // tile) while the weights' re-reads stay modest: (P / 32) tiles x all weights <= 48 MB through L2
   if (direct_fits(a, P, pieces) && !g_force_nt.load()) {
@@ -584,6 +596,7 @@ convsplit::Args args_of(const lsfa_conv_desc& d) {
   a.lda = d.lda; a.ldy = d.ldy; a.Ho = d.Ho; a.Wo = d.Wo;
   if (d.out_H > 0) { a.view = 1; a.out_H = d.out_H; a.out_W = d.out_W; a.out_sy = d.out_sy; a.out_sx = d.out_sx; }
   a.amax = d.amax_in; a.w_exp = d.w_exp; a.amax_out = d.amax_out; a.status = d.status;
+  a.x_kmajor = d.x_nchw ? 1 : 0;
   return a;
 }
 }  // namespace

@@ -69,6 +69,10 @@ struct Args {
   // ~35 dependent VALU instructions, and a short launch spent more time in its prologue's divisions than in its matrix instructions
   float inv_wo, inv_howo, inv_nx, inv_ny, inv_cpt, inv_kw;      // 1 / Wo, 1 / (Ho Wo), 1 / nx, 1 / ny, 1 / (Cin / 32), 1 / kw
   int tile_order;   // 0: tiles numbered (slice, channel tile, pixel tile), pixel fastest; 1: (slice, pixel tile, channel tile), channel fastest
+  // r4: the input is channels [0, Cin) of an NCHW map with `lda` channels (K-major for the contraction: element (pixel, channel) at
+  // x[(n * lda + channel) * H * W + pixel]); 1x1 / stride 1 / no padding, the direct kernel only (the RPN head on the feature map the
+  // reference's operators exchange)
+  int x_kmajor;
 };
 
 // n / d for 0 <= n < 2^24, 0 < d, with inv = 1.0f / d from the host: the float product is off by at most one, the remainder fixes it
@@ -927,10 +931,21 @@ template <int PC> struct DirectOperands { uint4 a[4]; uint4 b[4 * PC]; };
 
 template <int PC>
 __device__ __forceinline__ void direct_load(DirectOperands<PC>& o, const float* __restrict__ x, const uint4* __restrict__ wtile, size_t wstride,
-                                            int gch, int a_off, bool a_ok, int lane) {
+                                            int gch, int a_off, bool a_ok, int lane, int kstride = 0) {
+  if (kstride) {
+    // K-major input: the lane's 16 channels are 16 planes apart by `kstride` floats (a wave instruction reads 32 consecutive pixels of
+    // two planes: coalesced 128-byte runs)
+    const float* xp = a_ok ? x + a_off : reinterpret_cast<const float*>(g_zero_block);
+    const int ks = a_ok ? kstride : 0;
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      o.a[j] = make_uint4(__float_as_uint(xp[(4 * j + 0) * ks]), __float_as_uint(xp[(4 * j + 1) * ks]), __float_as_uint(xp[(4 * j + 2) * ks]),
+                          __float_as_uint(xp[(4 * j + 3) * ks]));
+  } else {
   const uint4* ap = reinterpret_cast<const uint4*>(a_ok ? x + a_off : g_zero_block);
 #pragma unroll
   for (int j = 0; j < 4; ++j) o.a[j] = a_ok ? ap[j] : make_uint4(0u, 0u, 0u, 0u);
+  }
   const uint4* bp = wtile + (size_t)gch * wstride + lane;
 #pragma unroll
   for (int j = 0; j < 4 * PC; ++j) o.b[j] = bp[j * 64];   // ((t*2 + s)*PC + piece) * 64 + lane, t = 0..1: two column tiles are 256 * PC uint4 in a row
@@ -974,7 +989,9 @@ __device__ __forceinline__ void direct_tile(const Args& a, int bx, int by, int n
     const int pn = fdiv(pix, a.Ho * a.Wo, a.inv_howo), r = pix - pn * a.Ho * a.Wo, py = fdiv(r, a.Wo, a.inv_wo), px = r - py * a.Wo;
     iy0 = py * a.stride - a.pad_h; ix0 = px * a.stride - a.pad_w;
     base = ((pn * a.H + iy0) * a.W + ix0) * a.lda + 16 * (lane >> 5);
+    if (a.x_kmajor) base = (pn * a.lda + 16 * (lane >> 5)) * (a.H * a.W) + r;       // 1x1, stride 1, no padding: input pixel = output pixel
   }
+  const int kstride = a.x_kmajor ? a.H * a.W : 0;
   f32x16 acc0, acc1;
 #pragma unroll
   for (int i = 0; i < 16; ++i) { acc0[i] = 0.f; acc1[i] = 0.f; }
@@ -983,14 +1000,14 @@ __device__ __forceinline__ void direct_tile(const Args& a, int bx, int by, int n
     const int tap = fdiv(gch, cpt, a.inv_cpt), kc = gch - tap * cpt, ty = fdiv(tap, a.kw, a.inv_kw), tx = tap - ty * a.kw;
     const int dy = ty * a.dil, dx = tx * a.dil;
     ok = pix_ok && (unsigned)(iy0 + dy) < (unsigned)a.H && (unsigned)(ix0 + dx) < (unsigned)a.W;
-    off = base + (dy * a.W + dx) * a.lda + kc * kChunk;
+    off = kstride ? base + kc * kChunk * kstride : base + (dy * a.W + dx) * a.lda + kc * kChunk;
   };
   const bool rows = rows_path_ok(a);
   DirectOperands<PC> cur, nxt;
   if (c_begin < c_end) {
     int off; bool ok;
     operand_of(c_begin, off, ok);
-    direct_load(cur, a.x, wtile, wstride, c_begin, off, ok, lane);
+    direct_load(cur, a.x, wtile, wstride, c_begin, off, ok, lane, kstride);
   }
   // the fp16 form's scale, read AFTER the first operands are on their way (one wait for both: a launch this short is a chain of
   // memory round trips, and every one taken out of the chain is ~1 us of its ~10)
@@ -1004,14 +1021,14 @@ __device__ __forceinline__ void direct_tile(const Args& a, int bx, int by, int n
     if (c + 1 < c_end) {
       int off; bool ok;
       operand_of(c + 1, off, ok);
-      direct_load(nxt, a.x, wtile, wstride, c + 1, off, ok, lane);
+      direct_load(nxt, a.x, wtile, wstride, c + 1, off, ok, lane, kstride);
     }
     direct_mma<PC>(cur, acc0, acc1, a_scale);
     if (c + 1 < c_end) {
       if (c + 2 < c_end) {
         int off; bool ok;
         operand_of(c + 2, off, ok);
-        direct_load(cur, a.x, wtile, wstride, c + 2, off, ok, lane);
+        direct_load(cur, a.x, wtile, wstride, c + 2, off, ok, lane, kstride);
       }
       direct_mma<PC>(nxt, acc0, acc1, a_scale);
     }

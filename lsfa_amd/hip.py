@@ -335,17 +335,15 @@ def det_postprocess(rois, deltas, probs, im_h, im_w, scale, score_thresh=1e-4, n
 
 
 @_on_tensor_device
-def rpn_head(feat, w_t, bias, A):
-    """lsfa_rpn_head: feat (N, C >= 512, H, W) NCHW; w_t (512, 64) [input channel][score 2A | delta 4A | zeros]; bias (64)
-    -> (rpn_cls_prob (N, 2A, H, W), rpn_bbox_pred (N, 4A, H, W))."""
-    feat, w_t, bias = _f32c(feat, "feat"), _f32c(w_t, "w_t"), _f32c(bias, "bias")
-    N, C, H, W = feat.shape
-    if tuple(w_t.shape) != (512, 64) or bias.numel() != 64:
-        raise LsfaError("rpn_head: w_t must be (512, 64) and bias (64)")
-    cls_prob = torch.empty((N, 2 * A, H, W), device=feat.device, dtype=torch.float32)
-    bbox = torch.empty((N, 4 * A, H, W), device=feat.device, dtype=torch.float32)
-    _check(lib().lsfa_rpn_head(_ptr(feat), _ci(N), _ci(C), _ci(H), _ci(W), _ptr(w_t), _ptr(bias), _ci(A), _ptr(cls_prob), _ptr(bbox),
-                               _stream()), "lsfa_rpn_head")
+def rpn_softmax_split(logits, A):
+    """lsfa_rpn_softmax_split: logits (N, H, W, L >= 6A) channels-last [score 2A | delta 4A | padding] -> (rpn_cls_prob (N, 2A, H, W),
+    rpn_bbox_pred (N, 4A, H, W)): the per-anchor two-way softmax and the split into MultiProposal's NCHW inputs."""
+    logits = _f32c(logits, "logits")
+    N, H, W, L = logits.shape
+    cls_prob = torch.empty((N, 2 * A, H, W), device=logits.device, dtype=torch.float32)
+    bbox = torch.empty((N, 4 * A, H, W), device=logits.device, dtype=torch.float32)
+    _check(lib().lsfa_rpn_softmax_split(_ptr(logits), _ci(N), _ci(H), _ci(W), _ci(L), _ci(A), _ptr(cls_prob), _ptr(bbox), _stream()),
+           "lsfa_rpn_softmax_split")
     return cls_prob, bbox
 
 
@@ -652,7 +650,7 @@ class ConvDesc(ctypes.Structure):
                 ("y2", ctypes.c_void_p), ("scale2", ctypes.c_void_p), ("shift2", ctypes.c_void_p),
                 ("amax_out", ctypes.c_void_p), ("status", ctypes.c_void_p),
                 ("Ho", ctypes.c_int), ("Wo", ctypes.c_int), ("out_H", ctypes.c_int), ("out_W", ctypes.c_int), ("out_sy", ctypes.c_int),
-                ("out_sx", ctypes.c_int), ("prof_tag", ctypes.c_int)]
+                ("out_sx", ctypes.c_int), ("prof_tag", ctypes.c_int), ("x_nchw", ctypes.c_int)]
 
 
 def _dp(t):
@@ -725,7 +723,7 @@ def check_status(status):
 
 
 def _conv_launch(who, x, lda, N, H, W, cin, sw, bias, stride, pad_h, pad_w, dil, act, nchw, residual, y_ptr, ldy, out2, scale2, shift2,
-                 amax_in, amax_out, status, grid, view, prof_tag, device):
+                 amax_in, amax_out, status, grid, view, prof_tag, device, x_nchw=False):
     if sw.pieces == 2 and amax_in is None:
         raise LsfaError("%s: a two-piece (fp16) weight needs amax_in" % who)
     d = ConvDesc()
@@ -738,6 +736,7 @@ def _conv_launch(who, x, lda, N, H, W, cin, sw, bias, stride, pad_h, pad_w, dil,
     d.Ho, d.Wo = grid
     d.out_H, d.out_W, d.out_sy, d.out_sx = view
     d.prof_tag = prof_tag
+    d.x_nchw = int(x_nchw)
     need = lib().lsfa_conv_workspace_bytes(ctypes.byref(d))
     ws = torch.empty(max(need, 16), dtype=torch.uint8, device=device)
     _check(lib().lsfa_conv_fwd(ctypes.byref(d), _ptr(ws), ctypes.c_size_t(need), _stream()), who)
@@ -745,7 +744,7 @@ def _conv_launch(who, x, lda, N, H, W, cin, sw, bias, stride, pad_h, pad_w, dil,
 
 @_on_tensor_device
 def conv_split(x, sw, bias=None, stride=1, pad=0, dil=1, relu=False, out=None, residual=None, out2=None, scale2=None,
-               shift2=None, nchw=False, act=None, amax_in=None, amax_out=None, status=None):
+               shift2=None, nchw=False, act=None, amax_in=None, amax_out=None, status=None, x_nchw=False):
     """lsfa_conv_fwd: convolution with fp32 in / out and split operands on the matrix pipe; sw: SplitWeight (its `pieces` picks the form).
     x (N, H, W, Cin) contiguous fp32 -> (N, Ho, Wo, Cout), or (N, Cout, Ho, Wo) with nchw=True (then residual / out2 are NCHW too).
     residual (same shape as the output; may BE `out`): added before the activation / store.  out2 + scale2 + shift2: second output
@@ -753,7 +752,15 @@ def conv_split(x, sw, bias=None, stride=1, pad=0, dil=1, relu=False, out=None, r
     amax_in: 256 partial maxima (float32 or int32 bit patterns) bounding |x| - required for two-piece weights; amax_out: 256 int32 slots that
     receive max|out2| (or max|out|); status: the int32 status word.  Returns out, or (out, out2)."""
     x = _f32c(x, "x")
-    N, H, W, Cin = x.shape
+    if x_nchw:
+        # the input is channels [0, sw.cin) of an NCHW map (N, Ctot, H, W): 1x1 / stride 1 / no padding, small weights (the RPN head)
+        N, Ctot, H, W = x.shape
+        Cin = sw.cin
+        if Ctot < Cin or (sw.kh, sw.kw, stride, pad, dil) != (1, 1, 1, 0, 1):
+            raise LsfaError("conv_split: x_nchw needs a 1x1 / stride 1 / pad 0 convolution on at least %d channels" % Cin)
+    else:
+        N, H, W, Cin = x.shape
+        Ctot = Cin
     if Cin != sw.cin:
         raise LsfaError("conv_split: input has %d channels, the weight %d" % (Cin, sw.cin))
     Cout, kh, kw = sw.cout, sw.kh, sw.kw
@@ -766,8 +773,9 @@ def conv_split(x, sw, bias=None, stride=1, pad=0, dil=1, relu=False, out=None, r
     if amax_in is None and sw.pieces == 2:
         amax_in = amax_partial(x)
     _count_conv(N, Ho, Wo, sw.real_cout, sw.real_cin, kh, kw, sw.pieces)
-    _conv_launch("lsfa_conv_fwd", x, Cin, N, H, W, Cin, sw, bias, stride, pad, pad, dil, (1 if relu else 0) if act is None else act, nchw,
-                 residual, out.data_ptr(), Cout, out2, scale2, shift2, amax_in, amax_out, status, (0, 0), (0, 0, 0, 0), 0, x.device)
+    _conv_launch("lsfa_conv_fwd", x, Ctot, N, H, W, Cin, sw, bias, stride, pad, pad, dil, (1 if relu else 0) if act is None else act, nchw,
+                 residual, out.data_ptr(), Cout, out2, scale2, shift2, amax_in, amax_out, status, (0, 0), (0, 0, 0, 0), 0, x.device,
+                 x_nchw=x_nchw)
     return out if out2 is None else (out, out2)
 
 

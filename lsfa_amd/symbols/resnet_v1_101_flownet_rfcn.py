@@ -22,8 +22,8 @@ Execution design (not a translation of the MXNet graph) - ONE path per dtype sin
   * the scale of the fp16 form is max|x| of the input map, left behind by the PRODUCING convolution's epilogue (`amax_out`, 256
     atomicMax slots zeroed once per frame section) - no pass of its own; an under-estimated scale raises the executor's status
     word (`Executor.check_status()`), it cannot silently overflow;
-  * the heads read the NCHW feature the reference's operators exchange: both RPN convs + bias + the per-anchor softmax are one kernel
-    (lsfa_rpn_head); both R-FCN convs are ONE convolution of the own family on a channels-last copy of channels 512.. (lsfa_nchw_to_nhwc,
+  * the heads read the NCHW feature the reference's operators exchange: both RPN convs are one convolution of the own family on the NCHW
+    map itself (x_nchw: the direct kernel's K-major operand form) + lsfa_rpn_softmax_split; both R-FCN convs are ONE convolution of the own family on a channels-last copy of channels 512.. (lsfa_nchw_to_nhwc,
     which also leaves their maximum) that writes the position-sensitive layout lsfa_rfcn_head_ps_ld_fwd reads in place;
   * every pass takes a batch: B lock-step clips, the F non-key frames of a segment (x B, frame-major: image f * B + b is warped from clip
     b's key feature) or the fronts of G key frames - what lsfa_amd/core/graphs.py FramePipeline(segment, key_group) feeds it;
@@ -295,11 +295,14 @@ class Executor(object):
         wb, bb = arg['rpn_bbox_pred_weight'].reshape(4 * A, 512), arg['rpn_bbox_pred_bias']
         if cfg.network.NORMALIZE_RPN:   # rpn_inv_normalize folded: (Wx+b)*std+mean
             wb, bb = wb * std[:, None], bb * std + mean
-        # lsfa_rpn_head's layout: (512, 64) [input channel][score 2A | delta 4A | zero columns], fp32 in both modes (0.13 GFLOP)
-        w64, b64 = np.zeros((512, 64), np.float32), np.zeros(64, np.float32)
-        w64[:, :6 * A] = np.concatenate([arg['rpn_cls_score_weight'].reshape(2 * A, 512), wb], 0).T
+        # both RPN convolutions as ONE 1x1 convolution of the own family on the NCHW map: output channels [score 2A | delta 4A] padded to the
+        # 64-channel tile; three exact bf16 pieces in the fp32 mode (no scale to know: the feature comes out of the warp / aggregation
+        # kernels), one piece in the bf16 mode
+        w64, b64 = np.zeros((64, 512, 1, 1), np.float32), np.zeros(64, np.float32)
+        w64[:6 * A, :, 0, 0] = np.concatenate([arg['rpn_cls_score_weight'].reshape(2 * A, 512), wb], 0)
         b64[:6 * A] = np.concatenate([arg['rpn_cls_score_bias'], bb], 0)
-        self.rpn_w_t, self.rpn_b = _t(w64, dev, f32), _t(b64, dev, f32)
+        self.rpn_sw = hip.SplitWeight(_t(w64, dev, f32), real_cout=6 * A, pieces=3 if self.pieces == 2 else self.pieces)
+        self.rpn_b = _t(b64, dev, f32)
         self.n_cls_ch = arg['rfcn_cls_weight'].shape[0]
         # position-sensitive layout: GEMM [HW,512] x [512, 49*(ncls+nbox)], row (bin*D + d) of the permuted weight
         G = 7
@@ -513,8 +516,10 @@ class Executor(object):
         cfg = self.cfg
         A = cfg.network.NUM_ANCHORS
         n, _, h, w = conv_feat.shape
-        # both RPN convolutions + bias + the per-anchor softmax as one launch on the NCHW map (lsfa_rpn_head)
-        cls_prob, rpn_bbox = hip.rpn_head(conv_feat, self.rpn_w_t, self.rpn_b, A)
+        # both RPN convolutions on the matrix pipe straight from the NCHW map (the direct kernel's K-major operand form), then the per-anchor
+        # softmax + the split into MultiProposal's two NCHW inputs
+        logits = hip.conv_split(conv_feat, self.rpn_sw, self.rpn_b, x_nchw=True, status=self.status)
+        cls_prob, rpn_bbox = hip.rpn_softmax_split(logits, A)
         rois = self.proposal(cls_prob, rpn_bbox, im_info)
         D = self.ncls + self.nbox
         # both R-FCN convolutions as ONE 1x1 convolution of the own family that writes the position-sensitive layout [h][w][bin][class | box]

@@ -550,36 +550,45 @@ def test_det_postprocess_vs_oracle(hip, seed, cap):
         np.testing.assert_allclose(dets[j, :counts[j]].cpu().numpy(), w_d[j, :counts[j]], rtol=1e-12, atol=1e-9)
 
 
+@pytest.mark.parametrize("pieces", [3, 1])
 @pytest.mark.parametrize("shape", [(1, 1024, 38, 63), (3, 512, 12, 20), (2, 640, 7, 9)])
-def test_rpn_head_scores_softmax_and_deltas(hip, shape):
-    """lsfa_rpn_head: both RPN 1x1 convolutions on channels [0, 512) of an NCHW map + bias + the per-anchor two-way softmax in one launch,
-    against float64 (fp32 FMA chains of 512 terms: 2e-6 x sqrt(512) of the logits' scale); probabilities of an anchor's two classes add
-    up to one; maps whose pixel count is not a multiple of the 64-pixel tile; channels past 512 are not read."""
+def test_rpn_head_on_the_nchw_map(hip, shape, pieces):
+    """The RPN head: both 1x1 convolutions as one lsfa_conv_fwd on channels [0, 512) of an NCHW map (x_nchw: the direct kernel's K-major
+    operand form; three exact bf16 pieces = fp32 accuracy, one piece = the bf16 mode) + lsfa_rpn_softmax_split, against float64; the
+    probabilities of an anchor's two classes add up to one; maps whose pixel count is not a multiple of the tiles; channels past 512 are
+    not read; convolutions the K-major form does not take are refused."""
     N, C, H, W = shape
     A = 9
     g = torch.Generator(device=DEV).manual_seed(C + H)
     feat = torch.randn((N, C, H, W), device=DEV, generator=g) * 2.0
     w = torch.randn((6 * A, 512), device=DEV, generator=g) * 0.05
     b = torch.randn(6 * A, device=DEV, generator=g) * 0.1
-    w_t = torch.zeros((512, 64), device=DEV)
-    w_t[:, :6 * A] = w.t()
+    w64 = torch.zeros((64, 512, 1, 1), device=DEV)
+    w64[:6 * A, :, 0, 0] = w
     b64 = torch.zeros(64, device=DEV)
     b64[:6 * A] = b
-    cls_prob, bbox = hip.rpn_head(feat, w_t, b64, A)
+    sw = hip.SplitWeight(w64, real_cout=6 * A, pieces=pieces)
+    logits_g = hip.conv_split(feat, sw, b64, x_nchw=True)
+    assert logits_g.shape == (N, H, W, 64)
+    cls_prob, bbox = hip.rpn_softmax_split(logits_g, A)
     x = feat[:, :512].double().cpu()
     logits = torch.einsum('oc,nchw->nohw', w.double().cpu(), x) + b.double().cpu().view(1, -1, 1, 1)
     want_p = torch.softmax(logits[:, :2 * A].reshape(N, 2, A * H, W), dim=1).reshape(N, 2 * A, H, W)
-    tol = 2e-6 * 512 ** 0.5 * float(logits.abs().max())
+    tol = (2e-2 if pieces == 1 else 2e-6 * 512 ** 0.5) * float(logits.abs().max())
     assert float((bbox.double().cpu() - logits[:, 2 * A:]).abs().max()) < tol
     assert float((cls_prob.double().cpu() - want_p).abs().max()) < tol
     assert float((cls_prob[:, :A] + cls_prob[:, A:] - 1.0).abs().max()) < 3e-7
+    # the same numbers as the channels-last form of the same convolution
+    rows = hip.conv_split(feat[:, :512].permute(0, 2, 3, 1).contiguous(), sw, b64)
+    assert torch.equal(rows, logits_g)
     if C > 512:
         feat2 = feat.clone()
         feat2[:, 512:] = float('nan')
-        p2, b2 = hip.rpn_head(feat2, w_t, b64, A)
-        assert torch.equal(p2, cls_prob) and torch.equal(b2, bbox)
+        assert torch.equal(hip.conv_split(feat2, sw, b64, x_nchw=True), logits_g)
     with pytest.raises(hip.LsfaError):
-        hip.rpn_head(feat, w_t, b64, 11)
+        hip.rpn_softmax_split(logits_g, 11)
+    with pytest.raises(hip.LsfaError):
+        hip.conv_split(feat, hip.SplitWeight(torch.zeros((64, 512, 3, 3), device=DEV), pieces=pieces), None, 1, 1, 1, x_nchw=True)
 
 
 @pytest.mark.parametrize("cap", [300, 40])

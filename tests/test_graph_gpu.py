@@ -901,7 +901,7 @@ def test_bench_line_contract():
 def test_frames_run_without_a_library_convolution(world, monkeypatch, dtype):
     """Neither the fp32 nor the bf16 key / non-key graphs reach a library convolution OR a library GEMM: every convolution runs on
     lsfa_conv_fwd (fp32: two fp16 pieces per operand; bf16: one bf16 piece - r3's bf16 mode fell back to F.conv2d / MIOpen), the R-FCN
-    score maps are one of them and the RPN head is lsfa_rpn_head (r4: torch.mm / addmm / matmul / softmax are forbidden here too).
+    score maps and the RPN head (straight on the NCHW map) are among them (r4: torch.mm / addmm / matmul / softmax are forbidden here too).
     MIOpen picks its solver from per-user state that concurrently starting processes race for, which made detections depend on the rank
     layout; hipBLASLt keeps a workspace per stream that a pipeline's captured graphs pin for the life of the
     process.  The executors' status words stay clear (no fp16 scale overflowed)."""

@@ -286,7 +286,7 @@ class FrameGraphs(object):
 class KeyBank(object):
     """The image-only half of G consecutive key frames in one pass (batch axis = key frames): backbone of each, FlowNet of each against
     its predecessor.  The late ResNet stages run 38 x 63 maps: one frame's convolutions launch a fraction of a wave of workgroups per
-    K slice, three frames' fill the chip (measured per frame: backbone 3231 -> 2200 us, FlowNet 514 -> 289 us at G = 3,
+    K slice, several frames' fill the chip (measured per frame: backbone 3150 -> 2080 -> 1860 us, FlowNet 500 -> 273 -> 225 us at G = 1 / 3 / 6,
     profiles/r4/key_batch_probe.txt).  Key frame i of the group then takes conv_feat[i], flow[i], scale[i] for its aggregation."""
 
     def __init__(self, key_exec, cfg, height, width, device, use_graphs, group, taps=False, batch=1):

@@ -83,8 +83,6 @@ def parse():
     ap.add_argument('--lookahead', action='store_true',
                     help='queue each key frame ahead of the non-key frames that precede it in display order')
     ap.add_argument('--no-flow-stream', action='store_true', help='FlowNet after the backbone on the key stream instead of beside it')
-    ap.add_argument('--no-tuned-gemms', action='store_true',
-                    help='library-default GEMM heuristics instead of lsfa_amd/tuned/gemm_gfx950.csv (lsfa_amd.tuning)')
     ap.add_argument('--cpu-budget-s', type=float, default=20.0)
     ap.add_argument('--max-unique-steps', type=int, default=16, help='distinct intervals of frames kept in HBM')
     return ap.parse_args()
@@ -602,10 +600,6 @@ def main():
     coll_dev = ('cuda:%d' % local_rank) if backend == 'nccl' else 'cpu'
     device = 'cuda:%d' % local_rank
     torch.cuda.set_device(local_rank)
-    torch.backends.cudnn.benchmark = os.environ.get('LSFA_MIOPEN_FIND', '1') == '1'
-
-    from lsfa_amd import tuning
-    tuned = None if args.no_tuned_gemms else tuning.enable(tune_missing=True)
     r = Runner(args, rank, device)
     r.prime()
 

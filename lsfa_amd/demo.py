@@ -95,8 +95,6 @@ def parse_args():
 
 def main():
     args = parse_args()
-    from lsfa_amd import tuning
-    tuning.enable(tune_missing=True)
     if args.cfg:
         cfg = update_config(args.cfg, config)
         update_network_config(cfg)

@@ -44,19 +44,11 @@ def parse_args():
     ap.add_argument('--out', default=None, help='rank 0 saves the gathered detection rows (n,7) here (.npy)')
     ap.add_argument('--dtype', default='f32', choices=['f32', 'bf16'],
                     help='f32: every fp32 product from two fp16 pieces (fp32 accuracy); bf16: one bf16 product per fp32 product (BASELINE configs[2])')
-    ap.add_argument('--pinned-algorithms', action='store_true',
-                    help='deterministic convolution / GEMM algorithm choice (no MIOpen find, no TunableOp): results do not '
-                         'depend on how the videos are spread over ranks')
     return ap.parse_args()
 
 
 def main():
     args = parse_args()
-    from lsfa_amd import tuning
-    if args.pinned_algorithms:
-        tuning.pin_algorithms(isolate_miopen=os.environ.get('LSFA_MIOPEN_PRIVATE') == '1')
-    else:
-        tuning.enable(tune_missing=True)
     if args.cfg:
         cfg = update_config(args.cfg, config)
         update_network_config(cfg)

@@ -6,7 +6,6 @@ bit for bit, by feeding the oracle the GPU's own inputs to that stage (teacher f
 frame that was served a stale key feature, a stale small-net feature or another frame's
 motion vectors fails `array_equal` instead of slipping under a tolerance.
 """
-import contextlib
 import json
 import os
 
@@ -23,21 +22,6 @@ def np_(t):
 def rel_err(a, b):
     a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
     return float(np.abs(a - b).max() / (np.abs(b).max() + 1e-12))
-
-
-@contextlib.contextmanager
-def pinned_algorithms():
-    """Convolution / GEMM algorithm choice that does not depend on how a call is issued: no MIOpen
-    find step (immediate mode picks per shape), no atomic split-K, no TunableOp.  Under it eager
-    launch, hipGraph replay and the stream pipeline must agree BIT FOR BIT."""
-    from lsfa_amd import tuning
-    tuning.disable()
-    det0, ben0 = torch.backends.cudnn.deterministic, torch.backends.cudnn.benchmark
-    torch.backends.cudnn.deterministic, torch.backends.cudnn.benchmark = True, False
-    try:
-        yield
-    finally:
-        torch.backends.cudnn.deterministic, torch.backends.cudnn.benchmark = det0, ben0
 
 
 def check_heads(cfg, taps, out, im_info):

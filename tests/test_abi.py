@@ -60,16 +60,3 @@ def test_product_never_imports_the_oracle():
     assert not bad, "product code references the oracle: %s" % bad
 
 
-def test_shipped_gemm_solutions_file_is_well_formed():
-    """lsfa_amd/tuned/gemm_gfx950.csv: validator header + one solution per (op, shape)."""
-    from lsfa_amd import tuning
-    lines = [l.strip().split(',') for l in open(tuning.SHIPPED) if l.strip()]
-    validators = {l[1]: l[2] for l in lines if l[0] == 'Validator'}
-    assert validators.get('GCN_ARCH_NAME', '').startswith('gfx950')
-    for k in ('PT_VERSION', 'HIPBLASLT_VERSION', 'ROCBLAS_VERSION'):
-        assert k in validators
-    entries = [l for l in lines if l[0] != 'Validator']
-    assert len(entries) >= 20 and all(len(e) == 4 and float(e[3]) > 0 for e in entries)
-    assert len({(e[0], e[1]) for e in entries}) == len(entries)
-    # the shapes the 1000x600 backbone hits: stage-3 conv3 (256 -> 1024 on 2394 rows) must be there
-    assert any(e[1].startswith('nn_1024_2394_256') for e in entries)

@@ -13,7 +13,7 @@ import pytest
 import torch
 
 import oracle
-from parity_util import check_dets, check_heads, check_key_frame, clone_dict, np_, pinned_algorithms
+from parity_util import check_dets, check_heads, check_key_frame, clone_dict, np_
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
@@ -132,22 +132,21 @@ def test_config5_every_frame_a_key_frame(world):
     im_info = clip.im_info()
     frames = [clip.frame(f, DEV) for f in range(5)]
     outs = {}
-    with pinned_algorithms():
-        fp = FramePipeline(key, cur, cfg, H, W, DEV, lanes=1, taps=True)
-        first = fp.first_frame(frames[0])
-        outs[0] = dict(feat=fp.feat.clone())
-        fp.capture()
+    fp = FramePipeline(key, cur, cfg, H, W, DEV, lanes=1, taps=True)
+    first = fp.first_frame(frames[0])
+    outs[0] = dict(feat=fp.feat.clone())
+    fp.capture()
 
-        def keep(f):
-            def deliver(bufs):
-                lane = fp.delivering
-                outs[f] = dict(taps=clone_dict(lane.taps), out=clone_dict(lane.out), feat=lane.feat.clone(),
-                               dets=bufs[0].clone(), counts=bufs[1].clone())
-            return deliver
-        for f in range(1, 5):
-            fp.key_frame(frames[f], deliver=keep(f))
-        fp.join()
-        torch.cuda.synchronize()
+    def keep(f):
+        def deliver(bufs):
+            lane = fp.delivering
+            outs[f] = dict(taps=clone_dict(lane.taps), out=clone_dict(lane.out), feat=lane.feat.clone(),
+                           dets=bufs[0].clone(), counts=bufs[1].clone())
+        return deliver
+    for f in range(1, 5):
+        fp.key_frame(frames[f], deliver=keep(f))
+    fp.join()
+    torch.cuda.synchronize()
     for f in range(1, 5):
         check_key_frame(cfg, outs[f]['taps'], outs[f]['out'], outs[f - 1]['feat'], im_info)
         check_dets(cfg, outs[f]['out'], outs[f]['dets'].cpu().numpy(), outs[f]['counts'].cpu().numpy(), H, W)

@@ -138,11 +138,11 @@ def oracle_flags(seg_lens, k):
 
 def test_hipgraph_replay_equals_eager(world):
     """The captured per-frame hipGraphs, with and without the small-net prefetch fork, reproduce the eager
-    launch sequence BIT FOR BIT (conv / GEMM algorithms pinned: parity_util.pinned_algorithms), and every
+    launch sequence BIT FOR BIT (every kernel is this library's own: nothing chooses an algorithm by how a call is issued), and every
     frame of the eager run is pinned to the oracle stage by stage.  The schedule starts 0, 2, 2, 1: a
     non-key frame right after the first frame — with prefetch on, its small-net feature must be that
     frame's, not a left-over of capture's warm-up."""
-    from parity_util import assert_dets_equal, check_cur_frame, check_dets, check_key_frame, clone_dict, pinned_algorithms
+    from parity_util import assert_dets_equal, check_cur_frame, check_dets, check_key_frame, clone_dict
     from lsfa_amd.core.graphs import FrameGraphs
     cfg, arg, key, cur, clip = world['cfg'], world['arg'], world['key'], world['cur'], world['clip']
     key.taps = cur.taps = None
@@ -150,25 +150,24 @@ def test_hipgraph_replay_equals_eager(world):
     # (frame, its key frame): cur, cur, key, cur, cur, key, cur, key
     sched = ((1, 0), (2, 0), (3, 3), (4, 3), (5, 3), (6, 6), (7, 6), (8, 8))
     results = []
-    with pinned_algorithms():
-        for use_graphs, prefetch, first_next in ((False, False, False), (True, False, False), (True, True, True), (True, True, False)):
-            fg = FrameGraphs(key, cur, cfg, H, W, DEV, use_graphs=use_graphs, prefetch=prefetch, taps=True)
-            fg.first_frame(clip.frame(0, DEV), clip.frame(1, DEV) if first_next else None)
-            fg.capture()
-            out = []
-            for idx, (f, kf) in enumerate(sched):
-                nxt = clip.frame(f + 1, DEV) if idx + 1 < len(sched) and sched[idx + 1][0] != sched[idx + 1][1] else None
-                if f == kf:
-                    prev_feat = fg.feat_old.clone()
-                    d, c, k = fg.key_frame(clip.frame(f, DEV), nxt)
-                    rec = dict(kind='key', prev_feat=prev_feat, taps=clone_dict(fg.key_taps), out=clone_dict(fg.key_out))
-                else:
-                    mv, res = clip.motion_vector(f, kf, DEV), clip.res_diff(f, DEV)
-                    d, c, k = fg.cur_frame(clip.frame(f, DEV), mv, res, nxt)
-                    rec = dict(kind='cur', mv=mv, res=res, taps=clone_dict(fg.cur_taps), out=clone_dict(fg.cur_out))
-                rec.update(dets=d.cpu().numpy().copy(), counts=c.cpu().numpy().copy(), feat=fg.feat.clone())
-                out.append(rec)
-            results.append(out)
+    for use_graphs, prefetch, first_next in ((False, False, False), (True, False, False), (True, True, True), (True, True, False)):
+        fg = FrameGraphs(key, cur, cfg, H, W, DEV, use_graphs=use_graphs, prefetch=prefetch, taps=True)
+        fg.first_frame(clip.frame(0, DEV), clip.frame(1, DEV) if first_next else None)
+        fg.capture()
+        out = []
+        for idx, (f, kf) in enumerate(sched):
+            nxt = clip.frame(f + 1, DEV) if idx + 1 < len(sched) and sched[idx + 1][0] != sched[idx + 1][1] else None
+            if f == kf:
+                prev_feat = fg.feat_old.clone()
+                d, c, k = fg.key_frame(clip.frame(f, DEV), nxt)
+                rec = dict(kind='key', prev_feat=prev_feat, taps=clone_dict(fg.key_taps), out=clone_dict(fg.key_out))
+            else:
+                mv, res = clip.motion_vector(f, kf, DEV), clip.res_diff(f, DEV)
+                d, c, k = fg.cur_frame(clip.frame(f, DEV), mv, res, nxt)
+                rec = dict(kind='cur', mv=mv, res=res, taps=clone_dict(fg.cur_taps), out=clone_dict(fg.cur_out))
+            rec.update(dets=d.cpu().numpy().copy(), counts=c.cpu().numpy().copy(), feat=fg.feat.clone())
+            out.append(rec)
+        results.append(out)
     # the eager run, frame by frame, against the oracle
     for (f, kf), r in zip(sched, results[0]):
         if r['kind'] == 'key':
@@ -410,7 +409,7 @@ def test_frame_pipeline_frames_pinned_to_oracle_and_to_the_serial_loop(world, lo
         pipeline reproduces the first.
     `layout`: how the work streams were picked (FramePipeline): the timing probe's choice, a fresh stream per role, and the
     degenerate outcome of a perturbed probe — no FlowNet stream, lanes on spare streams aliased to the key queue."""
-    from parity_util import assert_dets_equal, check_cur_frame, check_dets, check_key_frame, clone_dict, pinned_algorithms
+    from parity_util import assert_dets_equal, check_cur_frame, check_dets, check_key_frame, clone_dict
     from lsfa_amd.core.graphs import FrameGraphs, FramePipeline
     cfg, arg, key, cur, clip = world['cfg'], world['arg'], world['key'], world['cur'], world['clip']
     key.taps = cur.taps = None
@@ -421,26 +420,25 @@ def test_frame_pipeline_frames_pinned_to_oracle_and_to_the_serial_loop(world, lo
     mvs = {f: clip.motion_vector(f, kf, DEV) for f, kf in sched if f != kf}
     ress = {f: clip.res_diff(f, DEV) for f, kf in sched if f != kf}
     torch.cuda.synchronize()
-    with pinned_algorithms():
-        fp = FramePipeline(key, cur, cfg, H, W, DEV, lanes=3, lookahead=lookahead, taps=True, layout=layout)
-        assert fp.layout_used.startswith(layout)
-        if layout == "one-queue":
-            assert fp.s_flow is None
-        a = _run_clip_through_pipeline(fp, frames, sched, mvs, ress)
-        b = _run_clip_through_pipeline(fp, frames, sched, mvs, ress)
-        # the strictly serial eager loop on the same frames
-        fg = FrameGraphs(key, cur, cfg, H, W, DEV, use_graphs=False, prefetch=False, taps=True)
-        fg.first_frame(frames[0])
-        fg.capture()
-        serial = {}
-        for f, kf in sched:
-            if f == kf:
-                d, c, _ = fg.key_frame(frames[f])
-                serial[f] = dict(taps=clone_dict(fg.key_taps), out=clone_dict(fg.key_out), feat=fg.feat.clone())
-            else:
-                d, c, _ = fg.cur_frame(frames[f], mvs[f], ress[f])
-                serial[f] = dict(taps=clone_dict(fg.cur_taps), out=clone_dict(fg.cur_out))
-            serial[f].update(dets=d.clone(), counts=c.clone())
+    fp = FramePipeline(key, cur, cfg, H, W, DEV, lanes=3, lookahead=lookahead, taps=True, layout=layout)
+    assert fp.layout_used.startswith(layout)
+    if layout == "one-queue":
+        assert fp.s_flow is None
+    a = _run_clip_through_pipeline(fp, frames, sched, mvs, ress)
+    b = _run_clip_through_pipeline(fp, frames, sched, mvs, ress)
+    # the strictly serial eager loop on the same frames
+    fg = FrameGraphs(key, cur, cfg, H, W, DEV, use_graphs=False, prefetch=False, taps=True)
+    fg.first_frame(frames[0])
+    fg.capture()
+    serial = {}
+    for f, kf in sched:
+        if f == kf:
+            d, c, _ = fg.key_frame(frames[f])
+            serial[f] = dict(taps=clone_dict(fg.key_taps), out=clone_dict(fg.key_out), feat=fg.feat.clone())
+        else:
+            d, c, _ = fg.cur_frame(frames[f], mvs[f], ress[f])
+            serial[f] = dict(taps=clone_dict(fg.cur_taps), out=clone_dict(fg.cur_out))
+        serial[f].update(dets=d.clone(), counts=c.clone())
     key_feat = {0: a[0]['feat']}
     prev_key = 0
     for f, kf in sched:
@@ -694,16 +692,14 @@ def test_pred_eval_pipelined_two_videos(world):
     """Two videos of the same shape through pred_eval_pipelined: the second video reuses the first
     one's captured pipeline after a drain; frame ids and every detection row equal the serial
     pred_eval's exactly (conv / GEMM algorithms pinned)."""
-    from parity_util import pinned_algorithms
     from lsfa_amd.config.config import lsfa_test_config
     from lsfa_amd.function.test_rcnn import test_rcnn
     from lsfa_amd.utils.synthetic import synthetic_roidb
     cfg = lsfa_test_config(key_frame_interval=3)
     arg, aux = world['arg'], world['aux']
     roidb = synthetic_roidb(2, 8, H, W, 3)
-    with pinned_algorithms():
-        rows_s, ids_s = test_rcnn(cfg, roidb, arg, aux, device=DEV, pipeline=False)
-        rows_p, ids_p = test_rcnn(cfg, roidb, arg, aux, device=DEV, pipeline=True)
+    rows_s, ids_s = test_rcnn(cfg, roidb, arg, aux, device=DEV, pipeline=False)
+    rows_p, ids_p = test_rcnn(cfg, roidb, arg, aux, device=DEV, pipeline=True)
     np.testing.assert_array_equal(ids_s, ids_p)
     assert len(rows_s) > 0
     np.testing.assert_array_equal(rows_s, rows_p)
@@ -751,7 +747,6 @@ def test_pred_eval_pipelined_evicts_pipelines_of_old_shapes(world):
     and their memory pools dropped, streams parked) when a third shape arrives and rebuilt when its shape returns; every detection row
     equals the serial pred_eval's, and the device memory in use after the run is what it was before (no pool of an evicted pipeline
     survives) - ADVICE r3."""
-    from parity_util import pinned_algorithms
     from lsfa_amd.config.config import lsfa_test_config
     from lsfa_amd.core import streams
     from lsfa_amd.function.test_rcnn import test_rcnn
@@ -765,17 +760,16 @@ def test_pred_eval_pipelined_evicts_pipelines_of_old_shapes(world):
         e['frame_id'] = fid
         fid += 5
         roidb.append(e)
-    with pinned_algorithms():
-        rows_s, ids_s = test_rcnn(cfg, roidb, arg, aux, device=DEV, pipeline=False)
-        torch.cuda.synchronize()
-        gc.collect()
-        torch.cuda.empty_cache()
-        before, parked = torch.cuda.memory_allocated(), sum(len(v) for v in streams._FREE.values())
-        rows_p, ids_p = test_rcnn(cfg, roidb, arg, aux, device=DEV, pipeline=True, max_pipelines=2)
-        torch.cuda.synchronize()
-        gc.collect()                     # lanes, deliver closures and graphs reference each other: the pools go when the cycle is collected
-        torch.cuda.empty_cache()
-        after = torch.cuda.memory_allocated()
+    rows_s, ids_s = test_rcnn(cfg, roidb, arg, aux, device=DEV, pipeline=False)
+    torch.cuda.synchronize()
+    gc.collect()
+    torch.cuda.empty_cache()
+    before, parked = torch.cuda.memory_allocated(), sum(len(v) for v in streams._FREE.values())
+    rows_p, ids_p = test_rcnn(cfg, roidb, arg, aux, device=DEV, pipeline=True, max_pipelines=2)
+    torch.cuda.synchronize()
+    gc.collect()                     # lanes, deliver closures and graphs reference each other: the pools go when the cycle is collected
+    torch.cuda.empty_cache()
+    after = torch.cuda.memory_allocated()
     np.testing.assert_array_equal(ids_s, ids_p)
     assert len(rows_s) > 0
     np.testing.assert_array_equal(rows_s, rows_p)
@@ -783,31 +777,6 @@ def test_pred_eval_pipelined_evicts_pipelines_of_old_shapes(world):
     # five pipelines were built (A, B, C, A again, B again), every one closed: their streams are parked, a bounded number each (22 today)
     grown = sum(len(v) for v in streams._FREE.values()) - parked
     assert 5 <= grown <= 5 * 32, grown
-
-
-def test_tuned_gemm_file_is_accepted_and_parity_holds(world):
-    """lsfa_amd.tuning: the shipped TunableOp results are accepted by this PyTorch / rocBLAS / hipBLASLt
-    build, and with solution selection on (shapes of this small test are tuned on first use) the key
-    graph still matches the oracle graph within the convolution tolerance."""
-    from lsfa_amd import tuning
-    cfg, arg, aux, key, clip = world['cfg'], world['arg'], world['aux'], world['key'], world['clip']
-    ok = tuning.enable(tune_missing=True)
-    try:
-        assert ok, "lsfa_amd/tuned/gemm_gfx950.csv rejected: regenerate with tools/tune_gemms.py"
-        import torch.cuda.tunable as T
-        assert T.is_enabled() and len(T.get_results()) >= 20
-        im_info = clip.im_info()
-        f0 = clip.frame(0)
-        key.taps = {}
-        out = key.forward(data=f0.to(DEV), im_info=torch.from_numpy(im_info).to(DEV), data_key_old=f0.to(DEV),
-                          feat_key_old=torch.zeros(1, 1024, 1, 1, device=DEV))
-        ref = graph_ref.key_forward(cfg, arg, aux, f0.numpy(), f0.numpy(), np.zeros((1, 1024, 1, 1), np.float32), im_info)
-        assert rel_err(np_(key.taps['backbone_feat']), ref['backbone_feat']) < TOL_DENSE
-        assert rel_err(np_(key.taps['cls_map']), ref['cls_map']) < TOL_DENSE
-        check_heads(cfg, key.taps, out, im_info)
-    finally:
-        key.taps = None
-        tuning.disable()
 
 
 def test_two_clips_interleaved_on_one_gpu_are_isolated(world):
@@ -827,35 +796,30 @@ def test_two_clips_interleaved_on_one_gpu_are_isolated(world):
                for f, kf in sched} for c in clips]
     first = [c.frame(0, DEV) for c in clips]
     torch.cuda.synchronize()
-    det0 = torch.backends.cudnn.deterministic
-    torch.backends.cudnn.deterministic = True
-    try:
-        fps = [FramePipeline(key, cur, cfg, H, W, DEV) for _ in clips]
+    fps = [FramePipeline(key, cur, cfg, H, W, DEV) for _ in clips]
 
-        def run(order):
-            outs = [{}, {}]
-            for ci in set(order):
-                fps[ci].first_frame(first[ci])
-                if not fps[ci].captured:
-                    fps[ci].capture()
-            for f, kf in sched:
-                for ci in order:
-                    data, mv, res = inputs[ci][f]
-                    keep = (lambda ci, f: (lambda b: outs[ci].__setitem__(f, (b[0].clone(), b[1].clone()))))(ci, f)
-                    if f == kf:
-                        fps[ci].key_frame(data, deliver=keep)
-                    else:
-                        fps[ci].cur_frame(data, mv, res, deliver=keep)
-            for ci in set(order):
-                fps[ci].join()
-            torch.cuda.synchronize()
-            return [{f: (d.cpu().numpy(), c.cpu().numpy()) for f, (d, c) in o.items()} for o in outs]
+    def run(order):
+        outs = [{}, {}]
+        for ci in set(order):
+            fps[ci].first_frame(first[ci])
+            if not fps[ci].captured:
+                fps[ci].capture()
+        for f, kf in sched:
+            for ci in order:
+                data, mv, res = inputs[ci][f]
+                keep = (lambda ci, f: (lambda b: outs[ci].__setitem__(f, (b[0].clone(), b[1].clone()))))(ci, f)
+                if f == kf:
+                    fps[ci].key_frame(data, deliver=keep)
+                else:
+                    fps[ci].cur_frame(data, mv, res, deliver=keep)
+        for ci in set(order):
+            fps[ci].join()
+        torch.cuda.synchronize()
+        return [{f: (d.cpu().numpy(), c.cpu().numpy()) for f, (d, c) in o.items()} for o in outs]
 
-        run([0, 1])                          # throw-away pass (library settles on its solutions)
-        alone = [run([0])[0], run([1])[1]]
-        both = run([0, 1])
-    finally:
-        torch.backends.cudnn.deterministic = det0
+    run([0, 1])                          # throw-away pass
+    alone = [run([0])[0], run([1])[1]]
+    both = run([0, 1])
     for ci in (0, 1):
         for f, _ in sched:
             np.testing.assert_array_equal(both[ci][f][1], alone[ci][f][1])

@@ -70,10 +70,10 @@ def test_lsfa_test_three_clips_two_ranks_equal_single_rank(tmp_path, dtype):
     red on the driver's box (57 % of the rows differed); tools/diag_multirank.py traced it to MIOpen choosing solvers
     from per-user state under $HOME that concurrently starting processes race for (profiles/r3/multirank_diag_*.txt);
     since r3 the fp32 frame path makes no MIOpen call at all (own convolutions) and the library is built without packed-fp32
-    VALU code - that, not an isolated MIOpen state, is what the bit-exactness rests on; `--pinned-algorithms`
-    only switches off the find step / TunableOp for the remaining library GEMMs.  r4: the bf16 mode runs the same own kernels (one
-    bf16 product per fp32 product; r3's fell back to MIOpen) and is held to the same bit-for-bit equality."""
-    args = ["--clips", "3", "--frames", "7", "--interval", "3", "--height", "192", "--width", "320", "--pinned-algorithms", "--dtype", dtype]
+    VALU code - that is what the bit-exactness rests on.  r4: no library GEMM is left either (RPN and R-FCN heads on
+    lsfa_conv_fwd), so there is no algorithm choice to pin (`--pinned-algorithms` and lsfa_amd.tuning are gone); the bf16 mode runs the
+    same own kernels (one bf16 product per fp32 product; r3's fell back to MIOpen) and is held to the same bit-for-bit equality."""
+    args = ["--clips", "3", "--frames", "7", "--interval", "3", "--height", "192", "--width", "320", "--dtype", dtype]
     outs = {}
     for tag, nproc in (("one", 1), ("two", 2)):
         out = str(tmp_path / ("rows_%s.npy" % tag))

@@ -8,7 +8,6 @@ sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..'
 from lsfa_amd.config.config import lsfa_test_config
 from lsfa_amd.symbols import params as P
 from lsfa_amd.symbols.resnet_v1_101_flownet_rfcn import resnet_v1_101_flownet_rfcn
-torch.backends.cudnn.benchmark = True
 dev = 'cuda:0'
 cfg = lsfa_test_config(key_frame_interval=10)
 arg, aux = P.init_params(cfg, seed=0)
@@ -18,9 +17,6 @@ what = sys.argv[2] if len(sys.argv) > 2 else 'backbone'
 G = int(sys.argv[3]) if len(sys.argv) > 3 else 1
 data = torch.rand(G, 3, 600, 1000, device=dev) * 255
 data2 = torch.rand(G, 3, 600, 1000, device=dev) * 255
-if os.environ.get('LSFA_TUNED', '1') == '1':
-    from lsfa_amd import tuning
-    tuning.enable()
 with torch.no_grad():
     for _ in range(n):
         key._backbone(data) if what == 'backbone' else key._flownet(data, data2)

@@ -7,7 +7,7 @@ import sys
 import torch
 
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..'))
-from lsfa_amd import hip, tuning
+from lsfa_amd import hip
 from lsfa_amd.config.config import lsfa_test_config
 from lsfa_amd.symbols import params as P
 from lsfa_amd.symbols.resnet_v1_101_flownet_rfcn import resnet_v1_101_flownet_rfcn
@@ -27,8 +27,6 @@ res = torch.randn(F, 3, 38, 63, device=dev)
 R, ncls = cfg.TEST.RPN_POST_NMS_TOP_N, cfg.dataset.NUM_CLASSES
 bufs = (torch.zeros((F, ncls, R, 5), dtype=torch.float64, device=dev), torch.zeros((F, ncls), dtype=torch.int32, device=dev),
         torch.full((F, ncls, R), -1, dtype=torch.int32, device=dev))      # what core/graphs.py hands lsfa_det_postprocess_batch: static buffers
-if os.environ.get('LSFA_TUNED', '1') == '1':
-    tuning.enable()
 with torch.no_grad():
     for _ in range(n):
         out = cur.forward(data=data, im_info=im_info, feat_key=feat, motion_vector=mv, res_diff=res)

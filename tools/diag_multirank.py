@@ -18,7 +18,7 @@ import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 OUT = os.path.join(ROOT, 'gpurun_out', 'diag')
 HOMES = '/tmp/lsfa_diag_homes'      # MIOpen caches: large, not worth copying back
-ARGS = ['--clips', '3', '--frames', '7', '--interval', '3', '--height', '192', '--width', '320', '--pinned-algorithms']
+ARGS = ['--clips', '3', '--frames', '7', '--interval', '3', '--height', '192', '--width', '320']
 
 
 def free_port():

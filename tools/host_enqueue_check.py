@@ -4,9 +4,6 @@ import os, sys, time
 import torch
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..'))
 import bench
-from lsfa_amd import tuning
-tuning.enable()
-torch.backends.cudnn.benchmark = True
 sys.argv = ['bench.py', '--no-cpu-baseline'] + sys.argv[1:]
 
 def drain():

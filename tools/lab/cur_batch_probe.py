@@ -6,11 +6,10 @@ import os
 import sys
 import torch
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..', '..'))
-from lsfa_amd import hip, tuning
+from lsfa_amd import hip
 from lsfa_amd.config.config import lsfa_test_config
 from lsfa_amd.symbols import params as P
 from lsfa_amd.symbols.resnet_v1_101_flownet_rfcn import resnet_v1_101_flownet_rfcn
-tuning.enable()
 dev = 'cuda:0'
 H, W = 600, 1000
 cfg = lsfa_test_config(key_frame_interval=10)

@@ -5,9 +5,6 @@ import os, sys, time
 import torch
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..'))
 import bench
-from lsfa_amd import tuning
-tuning.enable()
-torch.backends.cudnn.benchmark = True
 K = int(sys.argv[1]); rest = sys.argv[2:]
 sys.argv = ['bench.py', '--no-cpu-baseline', '--max-unique-steps', '4'] + rest
 

@@ -11,10 +11,6 @@ from lsfa_amd.symbols import params as P
 from lsfa_amd.symbols.resnet_v1_101_flownet_rfcn import resnet_v1_101_flownet_rfcn
 from lsfa_amd.utils.synthetic import SyntheticClip
 DEV = 'cuda:0'
-import os
-if os.environ.get('DET') == '1':
-    torch.backends.cudnn.deterministic = True
-    torch.backends.cudnn.benchmark = False
 H, W = (int(sys.argv[1]), int(sys.argv[2])) if len(sys.argv) > 2 else (192, 320)
 cfg = lsfa_test_config(key_frame_interval=10)
 arg, aux = P.init_params(cfg, seed=3)

@@ -5,8 +5,6 @@ sys.path.insert(0, '.')
 import torch
 import bench
 args = bench.parse()
-from lsfa_amd import tuning
-tuning.enable(tune_missing=True)
 r = bench.Runner(args, 0, 'cuda:0')
 r.prime()
 r.fg.flush(); torch.cuda.synchronize()

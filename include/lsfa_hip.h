@@ -347,18 +347,26 @@ int lsfa_deconv4x4s2_crop_fwd(const float* x, int lda, int N, int Hi, int Wi, in
  *   lsfa_avgpool_nchw      mx.symbol.Pooling(kernel=(k,k), stride=(k,k), pool_type='avg', pooling_convention='full')
  *                          (dff_rfcn/symbols/resnet_v1_101_flownet_rfcn.py:216 `resize_data`, k = 4): x (N,C,H,W) -> y (N,C,ceil(H/k),
  *                          ceil(W/k)); edge windows are clipped to the image and averaged over what they hold.
+ *   lsfa_stem_weights      conv0's weight as w_l (3,7,7,64) floats = [ci][ky][kx][co] with bn0's scale folded in -> wfrag, the
+ *                          lsfa_stem_weight_bytes() (16-byte aligned) bytes lsfa_stem_conv7x7s2 reads: the matrix-instruction
+ *                          fragments of the weights as two fp16 pieces with a power-of-two scale per output channel.  Once per
+ *                          weight load.
  *   lsfa_stem_conv7x7s2    bn_data + conv0 + bn0 + relu0 (dff_rfcn/symbols/resnet.py:151, :162): x (N,3,H,W) NCHW; in_scale/in_shift (3)
- *                          = bn_data as a per-channel affine (NULL: none), applied before the zero padding; w_l (3,7,7,64) floats =
- *                          [ci][ky][kx][co] with bn0's scale folded in; bias (64) = bn0's shift; y (N,Ho,Wo,64)
- *                          channels-last, Ho = (H-1)/2+1.  fp32 FMA chains in (ci, ky, kx) order.
+ *                          = bn_data as a per-channel affine (NULL: none), applied before the zero padding; wfrag from
+ *                          lsfa_stem_weights; bias (64) = bn0's shift; y (N,Ho,Wo,64) channels-last, Ho = (H-1)/2+1.  fp32 operands
+ *                          as two fp16 pieces on the matrix pipe (three products, fp32 accumulation: fp32 accuracy, like
+ *                          lsfa_conv_fwd's pieces = 2); the input's scale is taken per 4 x 32 output tile from the tile's own
+ *                          patch, so an image's result does not depend on what else is in the batch.
  *   lsfa_maxpool3x3s2_nhwc pool0 (resnet.py:163: 3x3, stride 2, pad 1, max): x (N,H,W,C) -> y (N,(H-1)/2+1,(W-1)/2+1,C), C % 4 == 0;
  *                          y2 != NULL: also max(y*scale2[c] + shift2[c], 0), the first unit's bn1 + relu1 (resnet.py:78-80).
  *                          amax_out != NULL: 256 slots (zeroed by the caller) that receive max|y2| (max|y| without y2) the way
  *                          lsfa_conv_fwd's amax_out does, for the next convolution's amax_in.
  * ------------------------------------------------------------------------ */
 int lsfa_avgpool_nchw(const float* x, int N, int C, int H, int W, int k, float* y, void* stream);
+size_t lsfa_stem_weight_bytes(void);
+int lsfa_stem_weights(const float* w_l, void* wfrag, void* stream);
 int lsfa_stem_conv7x7s2(const float* x, int N, int H, int W, const float* in_scale, const float* in_shift,
-                        const float* w_l, const float* bias, float* y, void* stream);
+                        const void* wfrag, const float* bias, float* y, void* stream);
 int lsfa_maxpool3x3s2_nhwc(const float* x, int N, int H, int W, int C, float* y, float* y2, const float* scale2,
                            const float* shift2, unsigned* amax_out, void* stream);
 /* lsfa_stem_conv7x7s2 with an accumulation input and a choice of activation: y = act(conv(x) + bias + accum), accum (N,Ho,Wo,64)
@@ -366,7 +374,7 @@ int lsfa_maxpool3x3s2_nhwc(const float* x, int N, int H, int W, int C, float* y,
  * resnet_v1_101_flownet_rfcn.py:153) is two such passes, one per image of the pair, with the weight's input channels 0-2 / 3-5.
  * amax_out (or NULL): 256 zeroed slots that receive max|y|, like lsfa_conv_fwd's. */
 int lsfa_stem_conv7x7s2_ex(const float* x, int N, int H, int W, const float* in_scale, const float* in_shift,
-                           const float* w_l, const float* bias, const float* accum, int act, float* y, unsigned* amax_out,
+                           const void* wfrag, const float* bias, const float* accum, int act, float* y, unsigned* amax_out,
                            void* stream);
 
 /* ---------------------------------------------------------------------------

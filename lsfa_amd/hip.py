@@ -45,7 +45,7 @@ def lib():
         L.lsfa_last_error.restype = ctypes.c_char_p
         for name in ("lsfa_proposal_workspace_bytes", "lsfa_nms_workspace_bytes", "lsfa_det_workspace_bytes",
                      "lsfa_mv_workspace_bytes", "lsfa_conv_nhwc_workspace_bytes", "lsfa_conv_weight_bytes",
-                     "lsfa_conv_workspace_bytes", "lsfa_deconv4x4s2_crop_workspace_bytes"):
+                     "lsfa_conv_workspace_bytes", "lsfa_deconv4x4s2_crop_workspace_bytes", "lsfa_stem_weight_bytes"):
             getattr(L, name).restype = ctypes.c_size_t
         L.lsfa_op_name.restype = ctypes.c_char_p
         L._nms.restype = None
@@ -532,22 +532,27 @@ def avgpool_nchw(x, k, out=None):
     return out
 
 
+@_on_tensor_device
 def stem_weight_layout(weight):
-    """conv0's (64, 3, 7, 7) weight (bn0 folded) -> the (3, 7, 7, 64) layout lsfa_stem_conv7x7s2 reads."""
+    """conv0's (64, 3, 7, 7) weight (bn0 folded) -> the fragments lsfa_stem_conv7x7s2 reads (lsfa_stem_weights: a uint8 tensor of
+    lsfa_stem_weight_bytes())."""
     co, ci, kh, kw = weight.shape
     if (co, ci, kh, kw) != (64, 3, 7, 7):
         raise LsfaError("stem_weight_layout: expected a (64, 3, 7, 7) weight, got %s" % (tuple(weight.shape),))
-    return weight.float().permute(1, 2, 3, 0).contiguous()
+    w_l = weight.float().permute(1, 2, 3, 0).contiguous()
+    frag = torch.empty((int(lib().lsfa_stem_weight_bytes()),), dtype=torch.uint8, device=weight.device)
+    _check(lib().lsfa_stem_weights(_ptr(w_l), _ptr(frag), _stream()), "lsfa_stem_weights")
+    return frag
 
 
 @_on_tensor_device
 def stem_conv(x, w_l, bias, in_scale=None, in_shift=None, out=None, accum=None, act=1, amax_out=None):
     """bn_data + conv0 (7x7, stride 2, pad 3) + bias (+ accum) + activation (0 none, 1 ReLU, 2 LeakyReLU 0.1):
     x (N, 3, H, W) NCHW -> (N, Ho, Wo, 64) channels-last.  amax_out: a zeroed row of amax_slots() for max|out|."""
-    x, w_l = _f32c(x, "x"), _f32c(w_l, "w_l")
+    x = _f32c(x, "x")
     N, C, H, W = x.shape
-    if C != 3 or tuple(w_l.shape) != (3, 7, 7, 64):
-        raise LsfaError("stem_conv: x must have 3 channels and w_l the (3, 7, 7, 64) layout")
+    if C != 3 or w_l.dtype != torch.uint8 or w_l.numel() != int(lib().lsfa_stem_weight_bytes()) or not w_l.is_contiguous():
+        raise LsfaError("stem_conv: x must have 3 channels and w_l must come from stem_weight_layout")
     Ho, Wo = (H - 1) // 2 + 1, (W - 1) // 2 + 1
     if out is None:
         out = torch.empty((N, Ho, Wo, 64), device=x.device, dtype=torch.float32)

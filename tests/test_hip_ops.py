@@ -907,11 +907,11 @@ def test_copy_many_is_one_launch_of_plain_copies(hip):
 
 
 # ------------------------------------------------------------------ ResNet stem ----
-@pytest.mark.parametrize("shape", [(1, 600, 1000), (1, 150, 250), (2, 37, 50), (1, 9, 8)])
+@pytest.mark.parametrize("shape", [(1, 600, 1000), (1, 150, 250), (2, 37, 50), (1, 9, 8), (3, 71, 131)])
 def test_stem_conv_pool_vs_torch(hip, shape):
     """bn_data + conv0 (7x7/2, pad 3, bn0 folded) + ReLU as one launch, then pool0 (3x3/2 max, pad 1): against torch in
-    float64 (the convolution is an fp32 FMA chain of 147 terms: 2e-6*sqrt(147) of the output scale) and, for the pooling,
-    exactly."""
+    float64 (two fp16 pieces per operand, three matrix products, fp32 accumulation: the error of an fp32 convolution of
+    147 terms, 2e-6*sqrt(147) of the output scale) and, for the pooling, exactly."""
     import torch.nn.functional as F
     N, H, W = shape
     rs = np.random.RandomState(H + W)
@@ -921,13 +921,14 @@ def test_stem_conv_pool_vs_torch(hip, shape):
     sc, sh = rs.uniform(0.01, 0.03, 3).astype(np.float32), rs.uniform(-3, -1, 3).astype(np.float32)
     xa = torch.from_numpy(x).double() * torch.from_numpy(sc).double().view(1, 3, 1, 1) + torch.from_numpy(sh).double().view(1, 3, 1, 1)
     want = torch.relu(F.conv2d(xa, torch.from_numpy(w).double(), torch.from_numpy(b).double(), stride=2, padding=3))
-    got = hip.stem_conv(t(x), hip.stem_weight_layout(t(w)), t(b), t(sc), t(sh))
+    wl = hip.stem_weight_layout(t(w))
+    got = hip.stem_conv(t(x), wl, t(b), t(sc), t(sh))
     assert got.shape == (N, want.shape[2], want.shape[3], 64)
     g = got.permute(0, 3, 1, 2).cpu().double()
     assert float((g - want).abs().max()) < 2e-6 * np.sqrt(147) * max(float(want.abs().max()), 1.0)
     # without bn_data
     want0 = torch.relu(F.conv2d(torch.from_numpy(x).double(), torch.from_numpy(w).double(), None, stride=2, padding=3))
-    got0 = hip.stem_conv(t(x), hip.stem_weight_layout(t(w)), None).permute(0, 3, 1, 2).cpu().double()
+    got0 = hip.stem_conv(t(x), wl, None).permute(0, 3, 1, 2).cpu().double()
     assert float((got0 - want0).abs().max()) < 2e-6 * np.sqrt(147) * max(float(want0.abs().max()), 1.0)
     pooled = hip.maxpool3x3s2_nhwc(got)
     ref = F.max_pool2d(got.permute(0, 3, 1, 2), 3, 2, 1)
@@ -936,6 +937,46 @@ def test_stem_conv_pool_vs_torch(hip, shape):
     s2, t2 = t(rs.uniform(0.5, 1.5, 64).astype(np.float32)), t(rs.randn(64).astype(np.float32))
     p1, p2 = hip.maxpool3x3s2_nhwc(got, scale2=s2, shift2=t2)
     assert torch.equal(p1, pooled) and torch.equal(p2, torch.relu(pooled * s2 + t2))
+
+
+def test_stem_conv_batch_invariance_accumulation_and_amax(hip):
+    """What the pipeline relies on beyond the values: (a) an image's result is the same bits alone and inside a batch, whatever the
+    other images hold (the input's fp16 scale is taken per tile from the tile's own patch; the batched passes are compared with the
+    frame-by-frame ones bit for bit); (b) FlowNet's flow_conv1 = two passes, the second accumulating into the first in place with
+    LeakyReLU(0.1) (resnet_v1_101_flownet_rfcn.py:153), against the 6-channel convolution in float64; (c) amax_out receives max|y|
+    exactly; (d) weights and inputs of very different magnitudes per channel keep fp32 accuracy relative to each OUTPUT channel's
+    scale (the weight scale is per output channel)."""
+    import torch.nn.functional as F
+    rs = np.random.RandomState(77)
+    H, W = 53, 141
+    x = (rs.rand(4, 3, H, W) * 255).astype(np.float32)
+    x[1] *= 1e-3                                    # a dark image next to bright ones
+    x[2, :, 20:30, 50:90] = 6.0e4                   # a saturated patch
+    w = (rs.randn(64, 3, 7, 7) * 0.05).astype(np.float32)
+    w *= np.exp(rs.uniform(-6, 6, 64)).astype(np.float32)[:, None, None, None]     # channels 5 decades apart
+    b = rs.randn(64).astype(np.float32)
+    wl = hip.stem_weight_layout(t(w))
+    am = hip.amax_slots(1, DEV)[0]
+    both = hip.stem_conv(t(x), wl, t(b), act=0, amax_out=am)
+    for i in range(4):
+        alone = hip.stem_conv(t(x[i:i + 1]), wl, t(b), act=0)
+        assert torch.equal(alone[0], both[i]), i
+    assert float(am.view(torch.float32).max()) == float(both.abs().max())
+    want = F.conv2d(torch.from_numpy(x).double(), torch.from_numpy(w).double(), torch.from_numpy(b).double(), stride=2, padding=3)
+    err = (both.permute(0, 3, 1, 2).cpu().double() - want).abs().amax(dim=(2, 3))          # (image, channel)
+    scale = want.abs().amax(dim=(2, 3)).clamp_min(1e-30)
+    assert float((err / scale).max()) < 2e-6 * np.sqrt(147), float((err / scale).max())
+    # two passes = the 6-channel convolution
+    x2 = (rs.rand(2, 3, H, W)).astype(np.float32)
+    x1 = (rs.rand(2, 3, H, W)).astype(np.float32)
+    w6 = (rs.randn(64, 6, 7, 7) * 0.05).astype(np.float32)
+    r1 = hip.stem_conv(t(x1), hip.stem_weight_layout(t(w6[:, 0:3].copy())), None, act=0)
+    r1 = hip.stem_conv(t(x2), hip.stem_weight_layout(t(w6[:, 3:6].copy())), t(b), out=r1, accum=r1, act=2)
+    want6 = F.leaky_relu(F.conv2d(torch.from_numpy(np.concatenate([x1, x2], 1)).double(), torch.from_numpy(w6).double(),
+                                  torch.from_numpy(b).double(), stride=2, padding=3), 0.1)
+    assert float((r1.permute(0, 3, 1, 2).cpu().double() - want6).abs().max()) < 2e-6 * np.sqrt(294) * float(want6.abs().max())
+    with pytest.raises(hip.LsfaError):
+        hip.stem_conv(t(x1), t(w6[:, 0:3].transpose(1, 2, 3, 0).copy()), None)          # r3's float layout is not the fragments
 
 
 @pytest.mark.parametrize("shape,k", [((1, 3, 600, 1000), 4), ((2, 3, 37, 50), 4), ((1, 5, 9, 7), 2)])

@@ -303,7 +303,8 @@ int lsfa_conv_nhwc_fused_fwd(const float* x, int N, int H, int W, int Cin, const
  *   y_nchw != 0: y, y2 and residual are (N, Cout, Ho, Wo) - the layout the reference's operators take - instead of channels-last.
  * Epilogue: + bias[c], + residual (may alias y), act (0 none, 1 ReLU, 2 LeakyReLU 0.1), and optionally a second output
  * y2 = max(y * scale2[c] + shift2[c], 0) - the NEXT pre-activation unit's bn1 + relu1 (resnet.py:77-79) - and `amax_out`: 256 unsigned
- * slots that receive (atomicMax on the bit pattern; the caller zeroes them once per frame) max|y2| if y2 is given, else max|y|.
+ * slots that receive (atomicMax on the bit pattern; the caller zeroes them once per frame) max|y2| if scale2 / shift2 are given (with
+ * y2 == NULL that maximum is all the second output leaves behind), else max|y|.
  * K may be cut into slices whose partial sums go through `ws` and are added in a fixed order (bit-reproducible). */
 typedef struct lsfa_conv_desc {
   const float* x; int lda; int N, H, W, Cin;
@@ -317,6 +318,12 @@ typedef struct lsfa_conv_desc {
   int x_nchw;            /* != 0: x is an NCHW map (N, lda, H, W) whose channels [0, Cin) are the input (K-major for the contraction): 1x1 /
                           * stride 1 / no padding and small weights only (Cout * Cin * 2 * pieces <= 256 KB per 64 output channels) -
                           * the RPN's 1x1 convolutions on the feature map the reference's operators exchange; else LSFA_ENOTSUP */
+  const float* in_scale; /* with in_shift (Cin floats each, or both NULL): the convolution's input is max(x * in_scale[k] + in_shift[k], 0), */
+  const float* in_shift; /* k the input channel, applied where the operand is cut - a pre-activation ResNet unit's bn1 + relu1
+                          * (dff_rfcn/symbols/resnet.py:78-80) on the previous unit's sum without that map ever being stored: the
+                          * previous conv3 is given scale2 / shift2 but y2 = NULL and only publishes the activated map's maximum in its
+                          * amax_out, which is this call's amax_in.  1x1, no padding, Cin <= 2048, pieces 1 or 2; else LSFA_ENOTSUP.  The
+                          * values multiplied are bit for bit the ones y2 would have held. */
 } lsfa_conv_desc;
 size_t lsfa_conv_weight_bytes(int Cout, int kh, int kw, int Cin, int pieces);
 int lsfa_conv_weights(const float* w, int Cout, int kh, int kw, int Cin, int pieces, int w_exp, void* wfrag, void* stream);

@@ -436,6 +436,11 @@ int direct_waves(const convsplit::Args& a) {
 
 template <int NT, int PC, int ST>
 void launch_ring(bool sp, const convsplit::Args& a, dim3 grid, hipStream_t s, int nx, int ny, int nz) {
+  if (a.in_scale) {      // the input's bn + ReLU applied at the cut (pieces 1 and 2: the frame path's two modes)
+    if (sp) hipLaunchKernelGGL((convsplit::conv_ring_kernel<NT, (PC < 3 ? PC : 2), ST, true, true>), grid, dim3(2 * convsplit::kThreads), 0, s, a, nx, ny, nz);
+    else hipLaunchKernelGGL((convsplit::conv_ring_kernel<NT, (PC < 3 ? PC : 2), ST, false, true>), grid, dim3(convsplit::kThreads), 0, s, a, nx, ny, nz);
+    return;
+  }
   if (sp) hipLaunchKernelGGL((convsplit::conv_ring_kernel<NT, PC, ST, true>), grid, dim3(2 * convsplit::kThreads), 0, s, a, nx, ny, nz);
   else hipLaunchKernelGGL((convsplit::conv_ring_kernel<NT, PC, ST, false>), grid, dim3(convsplit::kThreads), 0, s, a, nx, ny, nz);
 }
@@ -480,6 +485,14 @@ int conv_split_prepare(convsplit::Args& a, int pieces, SplitPlan& p, long& P_out
   LSFA_REQUIRE(pieces != 2 || a.amax, "%s: the fp16 two-piece form needs amax_in (lsfa_amax_partial of x, a producer's amax_out, or a bound)", who);
   LSFA_REQUIRE(N > 0 && H > 0 && W > 0 && kh > 0 && kw > 0 && stride > 0 && a.pad_h >= 0 && a.pad_w >= 0 && dil > 0, "%s: bad shape", who);
   LSFA_REQUIRE(!a.y2 || (a.scale2 && a.shift2), "%s: y2 given without scale2 / shift2", who);
+  LSFA_REQUIRE((a.scale2 == nullptr) == (a.shift2 == nullptr), "%s: scale2 and shift2 go together", who);
+  LSFA_REQUIRE(a.y2 || !a.scale2 || a.amax_out, "%s: scale2 / shift2 without y2 only publish the second output's maximum: amax_out is missing", who);
+  LSFA_REQUIRE((a.in_scale == nullptr) == (a.in_shift == nullptr), "%s: in_scale and in_shift go together", who);
+  if (a.in_scale && (a.kh != 1 || a.kw != 1 || a.pad_h || a.pad_w || a.Cin > convsplit::kAffineMaxCin || a.x_kmajor || a.nphase > 1 || pieces == 3)) {
+    set_error("%s: in_scale / in_shift need a 1x1 convolution without padding on at most %d channels of a channels-last map, pieces 1 or 2", who,
+              convsplit::kAffineMaxCin);
+    return LSFA_ENOTSUP;
+  }
   LSFA_REQUIRE(!a.y2 || a.y2 != a.y, "%s: y2 must not alias y", who);
   LSFA_REQUIRE(a.act >= 0 && a.act <= 2, "%s: act must be 0 (none), 1 (ReLU) or 2 (LeakyReLU 0.1)", who);
   if (Cin % 32 != 0 || Cout % convsplit::kWgCh != 0) {
@@ -518,7 +531,7 @@ int conv_split_prepare(convsplit::Args& a, int pieces, SplitPlan& p, long& P_out
   } else
   // small weights on a small map: the direct kernel (a 64-channel group's weights <= 256 KB at three pieces, re-read by every 32-pixel
   // tile) while the weights' re-reads stay modest: (P / 32) tiles x all weights <= 48 MB through L2
-  if (direct_fits(a, P, pieces) && !g_force_nt.load()) {
+  if (direct_fits(a, P, pieces) && !g_force_nt.load() && !a.in_scale) {
     p = SplitPlan{};
     p.direct = true;
     p.slices = 1;
@@ -575,7 +588,7 @@ int conv_split_launch(convsplit::Args a, int pieces, void* ws, size_t ws_bytes, 
     hipLaunchKernelGGL(convsplit::conv_split3x3_fixup_kernel, dim3((unsigned)(p.nx * p.ny)), dim3(convsplit::kThreads), 0, s, a, p.patches_x,
                        p.patches_y, p.nx);
   }
-  if (p.slices > 1 && a.y_nchw && !a.res && !a.y2 && nph == 1 && Cout % 64 == 0) {
+  if (p.slices > 1 && a.y_nchw && !a.res && !a.scale2 && nph == 1 && Cout % 64 == 0) {
     hipLaunchKernelGGL(convsplit::split_reduce_nchw_kernel, dim3((unsigned)((P + 63) / 64), (unsigned)(Cout / 64)), dim3(convsplit::kThreads), 0,
                        s, a, p.slices);
   } else if (p.slices > 1) {
@@ -597,6 +610,7 @@ convsplit::Args args_of(const lsfa_conv_desc& d) {
   if (d.out_H > 0) { a.view = 1; a.out_H = d.out_H; a.out_W = d.out_W; a.out_sy = d.out_sy; a.out_sx = d.out_sx; }
   a.amax = d.amax_in; a.w_exp = d.w_exp; a.amax_out = d.amax_out; a.status = d.status;
   a.x_kmajor = d.x_nchw ? 1 : 0;
+  a.in_scale = d.in_scale; a.in_shift = d.in_shift;
   return a;
 }
 }  // namespace

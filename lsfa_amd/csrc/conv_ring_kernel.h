@@ -46,6 +46,22 @@ template <int NT, int PC, int ST> struct Ring {
   static_assert((ST - 2) * kDma <= 63, "vmcnt is a 6-bit counter");
 };
 
+// r4 (Args::in_scale): the 16 channels a lane cuts from chunk `gch` are 32 gch + 16 (lane >> 5) + 0..15 (r0..r3, four each).  T holds
+// in_scale * s and, kAffineMaxCin floats further, in_shift * s (s = the fp16 form's power-of-two scale, 1 otherwise):
+// max(v (sc s) + sh s, 0) = s max(v sc + sh, 0) exactly, the value the previous layer's epilogue would have stored, scaled - the cut
+// then runs with scale 1.
+__device__ __forceinline__ float4 affine_relu4(const float4& v, const float4& sc, const float4& sh) {
+  return make_float4(fmaxf(v.x * sc.x + sh.x, 0.f), fmaxf(v.y * sc.y + sh.y, 0.f), fmaxf(v.z * sc.z + sh.z, 0.f), fmaxf(v.w * sc.w + sh.w, 0.f));
+}
+__device__ __forceinline__ void affine_chunk(const float* T, int gch, int lane, float4& c0, float4& c1, float4& c2, float4& c3) {
+  const float4* sc = reinterpret_cast<const float4*>(T + gch * kChunk + 16 * (lane >> 5));
+  const float4* sh = reinterpret_cast<const float4*>(T + kAffineMaxCin + gch * kChunk + 16 * (lane >> 5));
+  c0 = affine_relu4(c0, sc[0], sh[0]);
+  c1 = affine_relu4(c1, sc[1], sh[1]);
+  c2 = affine_relu4(c2, sc[2], sh[2]);
+  c3 = affine_relu4(c3, sc[3], sh[3]);
+}
+
 template <int NT, int PC, int ST, int S>
 __device__ __forceinline__ void ring_issue_a(uint4 (*R)[(Ring<NT, PC, ST>::kStageN)], const float* __restrict__ x, const Geom& g, const Walk& wk) {
   const int dy = wk.ty * g.dil, dx = wk.tx * g.dil;
@@ -69,9 +85,9 @@ __device__ __forceinline__ void ring_issue_b(uint4 (*R)[(Ring<NT, PC, ST>::kStag
 }
 
 // chunk c of n, its data in stage S = c % ST
-template <int NT, int PC, int ST, int S>
+template <int NT, int PC, int ST, int S, bool AF>
 __device__ __forceinline__ void ring_step(uint4 (*R)[(Ring<NT, PC, ST>::kStageN)], const float* __restrict__ x, const uint4* __restrict__ wblock,
-                                          const Geom& g, Walk& wk, int c, int n, f32x16 (&acc)[NT], float a_scale) {
+                                          const Geom& g, Walk& wk, int c, int n, f32x16 (&acc)[NT], float a_scale, const float* T) {
   typedef Ring<NT, PC, ST> RG;
   constexpr int kDmaB = RG::kDmaB;
   constexpr int SN = (S + ST - 1) % ST;                 // the stage chunk c - 1 lived in: free once everybody is past the barrier
@@ -88,11 +104,9 @@ __device__ __forceinline__ void ring_step(uint4 (*R)[(Ring<NT, PC, ST>::kStageN)
   const uint4* A = &R[S][g.wave * 256];
   const uint4* B = &R[S][kStageA + g.lane];
   const uint4 r0 = A[g.frag[0]], r1 = A[g.frag[1]], r2 = A[g.frag[2]], r3 = A[g.frag[3]];
-  const float4 c0 = make_float4(__uint_as_float(r0.x), __uint_as_float(r0.y), __uint_as_float(r0.z), __uint_as_float(r0.w));
-  const float4 c1 = make_float4(__uint_as_float(r1.x), __uint_as_float(r1.y), __uint_as_float(r1.z), __uint_as_float(r1.w));
-  const float4 c2 = make_float4(__uint_as_float(r2.x), __uint_as_float(r2.y), __uint_as_float(r2.z), __uint_as_float(r2.w));
-  const float4 c3 = make_float4(__uint_as_float(r3.x), __uint_as_float(r3.y), __uint_as_float(r3.z), __uint_as_float(r3.w));
-  const PiecesN s0 = cut8<PC>(c0, c1, a_scale), s1 = cut8<PC>(c2, c3, a_scale);
+  float4 c0 = as_f4(r0), c1 = as_f4(r1), c2 = as_f4(r2), c3 = as_f4(r3);
+  if (AF) affine_chunk(T, g.chunk0 + c, g.lane, c0, c1, c2, c3);
+  const PiecesN s0 = cut8<PC>(c0, c1, AF ? 1.f : a_scale), s1 = cut8<PC>(c2, c3, AF ? 1.f : a_scale);
 #pragma unroll
   for (int t = 0; t < NT; ++t) {
     // fragment (col tile t, step s, piece p) at ((t*2 + s)*PC + p)*64 + lane
@@ -135,14 +149,17 @@ __device__ __forceinline__ void ring_load_step(uint4 (*R)[(Ring<NT, PC, ST>::kSt
   }
 }
 
-template <int NT, int PC, int ST, int S>
-__device__ __forceinline__ void ring_consume_step(uint4 (*R)[(Ring<NT, PC, ST>::kStageN)], const Geom& g, f32x16 (&acc)[NT], float a_scale) {
+template <int NT, int PC, int ST, int S, bool AF>
+__device__ __forceinline__ void ring_consume_step(uint4 (*R)[(Ring<NT, PC, ST>::kStageN)], const Geom& g, f32x16 (&acc)[NT], float a_scale, int c,
+                                                  const float* T) {
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
   const uint4* A = &R[S][g.wave * 256];
   const uint4* B = &R[S][kStageA + g.lane];
   const uint4 r0 = A[g.frag[0]], r1 = A[g.frag[1]], r2 = A[g.frag[2]], r3 = A[g.frag[3]];
-  const PiecesN s0 = cut8<PC>(as_f4(r0), as_f4(r1), a_scale), s1 = cut8<PC>(as_f4(r2), as_f4(r3), a_scale);
+  float4 c0 = as_f4(r0), c1 = as_f4(r1), c2 = as_f4(r2), c3 = as_f4(r3);
+  if (AF) affine_chunk(T, g.chunk0 + c, g.lane, c0, c1, c2, c3);
+  const PiecesN s0 = cut8<PC>(c0, c1, AF ? 1.f : a_scale), s1 = cut8<PC>(c2, c3, AF ? 1.f : a_scale);
 #pragma unroll
   for (int t = 0; t < NT; ++t) {
     acc[t] = mma_pc<PC>(s0, B + ((t * 2 + 0) * PC) * 64, acc[t]);
@@ -161,10 +178,13 @@ __device__ __forceinline__ void ring_prologue(uint4 (*R)[(Ring<NT, PC, ST>::kSta
 }
 
 // grid (8 * ceil(tiles / 8)); block 256 (SP: 512).  tiles = ceil(P / 128) * (Cout / (32 * NT)) * slices (* phases)
-template <int NT, int PC, int ST, bool SP = false>
-static __global__ __launch_bounds__((SP ? 2 : 1) * kThreads, (Ring<NT, PC, ST>::kWgPerCu) * (SP ? 2 : 1)) void conv_ring_kernel(Args a, int nx, int ny, int nz) {
+// AF: Args::in_scale / in_shift are applied to the input where it is cut (their table, 16 KB, sits in LDS behind the ring)
+template <int NT, int PC, int ST, bool SP = false, bool AF = false>
+static __global__ __launch_bounds__((SP ? 2 : 1) * kThreads, ((AF ? 2 * (Ring<NT, PC, ST>::kLdsBytes + 16384) <= 160 * 1024 : Ring<NT, PC, ST>::kWgPerCu == 2) ? 2 : 1) * (SP ? 2 : 1))
+void conv_ring_kernel(Args a, int nx, int ny, int nz) {
   typedef Ring<NT, PC, ST> RG;
   __shared__ __attribute__((aligned(16))) uint4 R[ST][RG::kStageN];
+  __shared__ __attribute__((aligned(16))) float T[AF ? 2 * kAffineMaxCin : 4];
   Tile tile = xcd_tile(blockIdx.x, nx, ny, nz, a.tile_order, a.inv_nx, a.inv_ny);
   if (tile.x < 0) return;
   if (a.nphase > 1) { const int slices = nz / a.nphase, phase = tile.z / slices; tile.z -= phase * slices; apply_phase(a, phase, slices); }
@@ -183,6 +203,9 @@ static __global__ __launch_bounds__((SP ? 2 : 1) * kThreads, (Ring<NT, PC, ST>::
     const int s_exp = 13 - amax_exponent_asm(a.amax, g.lane, a.status);
     a_scale = ldexpf(1.f, s_exp);
     out_scale = ldexpf(1.f, -(s_exp + a.w_exp));
+  }
+  if (AF && !loader) {      // visible to every consumer after the first chunk's barrier (which an lgkmcnt(0) precedes)
+    for (int k = tid; k < a.Cin; k += kThreads) { T[k] = a.in_scale[k] * a_scale; T[kAffineMaxCin + k] = a.in_shift[k] * a_scale; }
   }
   g.H = a.H; g.W = a.W; g.Cin = a.Cin; g.lda = a.lda; g.kw = a.kw; g.stride = a.stride; g.dil = a.dil;
   g.chunks_per_tap = a.Cin / kChunk;
@@ -249,10 +272,10 @@ static __global__ __launch_bounds__((SP ? 2 : 1) * kThreads, (Ring<NT, PC, ST>::
     }
     int since = 0;
     for (int c = 0; c < nchunks; c += ST) {
-      ring_consume_step<NT, PC, ST, 0>(R, g, acc, a_scale);
-      if (c + 1 < nchunks) ring_consume_step<NT, PC, ST, 1>(R, g, acc, a_scale);
-      if (ST > 2 && c + 2 < nchunks) ring_consume_step<NT, PC, ST, (ST > 2 ? 2 : 0)>(R, g, acc, a_scale);
-      if (ST > 3 && c + 3 < nchunks) ring_consume_step<NT, PC, ST, (ST > 3 ? 3 : 0)>(R, g, acc, a_scale);
+      ring_consume_step<NT, PC, ST, 0, AF>(R, g, acc, a_scale, c, T);
+      if (c + 1 < nchunks) ring_consume_step<NT, PC, ST, 1, AF>(R, g, acc, a_scale, c + 1, T);
+      if (ST > 2 && c + 2 < nchunks) ring_consume_step<NT, PC, ST, (ST > 2 ? 2 : 0), AF>(R, g, acc, a_scale, c + 2, T);
+      if (ST > 3 && c + 3 < nchunks) ring_consume_step<NT, PC, ST, (ST > 3 ? 3 : 0), AF>(R, g, acc, a_scale, c + 3, T);
       since += ST;
       if (since >= kFlush) {
         since = 0;
@@ -269,10 +292,10 @@ static __global__ __launch_bounds__((SP ? 2 : 1) * kThreads, (Ring<NT, PC, ST>::
     if (ST > 3) ring_prologue<NT, PC, ST, (ST > 3 ? 2 : 0)>(R, a.x, wblock, g, wk, nchunks);
     int since = 0;
     for (int c = 0; c < nchunks; c += ST) {
-      ring_step<NT, PC, ST, 0>(R, a.x, wblock, g, wk, c, nchunks, acc, a_scale);
-      if (c + 1 < nchunks) ring_step<NT, PC, ST, 1>(R, a.x, wblock, g, wk, c + 1, nchunks, acc, a_scale);
-      if (ST > 2 && c + 2 < nchunks) ring_step<NT, PC, ST, (ST > 2 ? 2 : 0)>(R, a.x, wblock, g, wk, c + 2, nchunks, acc, a_scale);
-      if (ST > 3 && c + 3 < nchunks) ring_step<NT, PC, ST, (ST > 3 ? 3 : 0)>(R, a.x, wblock, g, wk, c + 3, nchunks, acc, a_scale);
+      ring_step<NT, PC, ST, 0, AF>(R, a.x, wblock, g, wk, c, nchunks, acc, a_scale, T);
+      if (c + 1 < nchunks) ring_step<NT, PC, ST, 1, AF>(R, a.x, wblock, g, wk, c + 1, nchunks, acc, a_scale, T);
+      if (ST > 2 && c + 2 < nchunks) ring_step<NT, PC, ST, (ST > 2 ? 2 : 0), AF>(R, a.x, wblock, g, wk, c + 2, nchunks, acc, a_scale, T);
+      if (ST > 3 && c + 3 < nchunks) ring_step<NT, PC, ST, (ST > 3 ? 3 : 0), AF>(R, a.x, wblock, g, wk, c + 3, nchunks, acc, a_scale, T);
       since += ST;
       if (since >= kFlush) {
         since = 0;

@@ -73,7 +73,14 @@ struct Args {
   // x[(n * lda + channel) * H * W + pixel]); 1x1 / stride 1 / no padding, the direct kernel only (the RPN head on the feature map the
   // reference's operators exchange)
   int x_kmajor;
+  // r4: x is a pre-activation map and the convolution multiplies max(x * in_scale[k] + in_shift[k], 0) (k = input channel): the bn1 +
+  // relu1 a ResNet unit applies to the previous unit's sum, applied where the operand is cut instead of being written out by the
+  // previous conv3 as a second output and read back (a quarter of a unit's map traffic).  1x1, no padding, Cin <= kAffineMaxCin, the
+  // ring kernel only.  `amax` is then the maximum of the ACTIVATED map: the previous conv3 publishes it without storing the map
+  // (scale2 / shift2 given, y2 == NULL).
+  const float* in_scale; const float* in_shift;
 };
+constexpr int kAffineMaxCin = 2048;
 
 // n / d for 0 <= n < 2^24, 0 < d, with inv = 1.0f / d from the host: the float product is off by at most one, the remainder fixes it
 __device__ __forceinline__ int fdiv(int n, int d, float inv) {
@@ -369,14 +376,14 @@ __device__ __forceinline__ uint32_t tile_store_max(const Args& a, const RowOut& 
   uint32_t m = 0;
 #pragma unroll
   for (int r = 0; r < 16; ++r)
-    if ((ro.valid >> r) & 1u) { a.y[ro.base[r] + ch * cs] = v[r]; m = max(m, amax_bits(pre[r], a.y2 ? 0.f : v[r])); }
-  if (a.y2) {
+    if ((ro.valid >> r) & 1u) { a.y[ro.base[r] + ch * cs] = v[r]; m = max(m, amax_bits(pre[r], a.scale2 ? 0.f : v[r])); }
+  if (a.scale2) {        // y2 == NULL: only the maximum of the second output is wanted
     const float sc2 = a.scale2[ch], sh2 = a.shift2[ch];
 #pragma unroll
     for (int r = 0; r < 16; ++r)
       if ((ro.valid >> r) & 1u) {
         const float w = fmaxf(v[r] * sc2 + sh2, 0.f);
-        a.y2[ro.base[r] + ch * cs] = w;
+        if (a.y2) a.y2[ro.base[r] + ch * cs] = w;
         m = max(m, __float_as_uint(w) & 0x7FFFFFFFu);
       }
   }
@@ -397,7 +404,7 @@ __device__ __forceinline__ uint32_t tile_rows_out(const Args& a, const float* T,
   // pre-activation magnitudes, which is non-finite exactly when one of them is (ReLU would hide a NaN or a -inf): one add per value
   float mx = 0.f, nf = 0.f;
   const int act = a.act;                         // wave-uniform: the branches below are scalar
-  const bool has_y2 = a.y2 != nullptr, has_res = a.res != nullptr, has_bias = a.bias != nullptr;
+  const bool has_y2 = a.scale2 != nullptr, store_y2 = a.y2 != nullptr, has_res = a.res != nullptr, has_bias = a.bias != nullptr;
 #pragma unroll
   for (int k = 0; k < 4; ++k) {
     const int row = 8 * k + (lane >> 3);
@@ -422,7 +429,7 @@ __device__ __forceinline__ uint32_t tile_rows_out(const Args& a, const float* T,
         float4 w;
         w.x = fmaxf(o.x * s2.x + h2.x, 0.f); w.y = fmaxf(o.y * s2.y + h2.y, 0.f);
         w.z = fmaxf(o.z * s2.z + h2.z, 0.f); w.w = fmaxf(o.w * s2.w + h2.w, 0.f);
-        *reinterpret_cast<float4*>(a.y2 + base + ch) = w;
+        if (store_y2) *reinterpret_cast<float4*>(a.y2 + base + ch) = w;
         mx = fmaxf(fmaxf(mx, fmaxf(w.x, w.y)), fmaxf(w.z, w.w));
       } else {
         mx = fmaxf(fmaxf(mx, fmaxf(fabsf(o.x), fabsf(o.y))), fmaxf(fabsf(o.z), fabsf(o.w)));
@@ -449,7 +456,7 @@ __device__ __forceinline__ uint32_t tile_cols_out_nchw(const Args& a, const floa
   const int hw = a.Ho * a.Wo;
   const int base = ok ? out_pixel_base(a, p) : 0;       // (n * Cout) * hw + the pixel's offset in its plane
   const int act = a.act;
-  const bool has_y2 = a.y2 != nullptr, has_res = a.res != nullptr, has_bias = a.bias != nullptr;
+  const bool has_y2 = a.scale2 != nullptr, store_y2 = a.y2 != nullptr, has_res = a.res != nullptr, has_bias = a.bias != nullptr;
   float mx = 0.f, nf = 0.f;
 #pragma unroll
   for (int t = 0; t < NT; ++t) {
@@ -465,7 +472,7 @@ __device__ __forceinline__ uint32_t tile_cols_out_nchw(const Args& a, const floa
       a.y[base + ch * hw] = o;
       if (has_y2) {
         const float w = fmaxf(o * a.scale2[ch] + a.shift2[ch], 0.f);
-        a.y2[base + ch * hw] = w;
+        if (store_y2) a.y2[base + ch * hw] = w;
         mx = fmaxf(mx, w);
       } else {
         mx = fmaxf(mx, fabsf(o));
@@ -513,8 +520,8 @@ static __global__ __launch_bounds__(kThreads) void split_reduce_kernel(Args a, l
       const float pre = v;
       v = activate(v, a.act);
       o1[k] = v;
-      o2[k] = a.y2 ? fmaxf(v * a.scale2[ch + k] + a.shift2[ch + k], 0.f) : 0.f;
-      m = max(m, max(amax_bits(pre, a.y2 ? 0.f : v), __float_as_uint(o2[k]) & 0x7FFFFFFFu));
+      o2[k] = a.scale2 ? fmaxf(v * a.scale2[ch + k] + a.shift2[ch + k], 0.f) : 0.f;
+      m = max(m, max(amax_bits(pre, a.scale2 ? 0.f : v), __float_as_uint(o2[k]) & 0x7FFFFFFFu));
     }
     if (cs == 1 && ((base + ch) & 3) == 0 && ((uintptr_t)a.y & 15) == 0 && (!a.y2 || ((uintptr_t)a.y2 & 15) == 0)) {
       *reinterpret_cast<float4*>(a.y + base + ch) = make_float4(o1[0], o1[1], o1[2], o1[3]);

@@ -655,7 +655,8 @@ class ConvDesc(ctypes.Structure):
                 ("y2", ctypes.c_void_p), ("scale2", ctypes.c_void_p), ("shift2", ctypes.c_void_p),
                 ("amax_out", ctypes.c_void_p), ("status", ctypes.c_void_p),
                 ("Ho", ctypes.c_int), ("Wo", ctypes.c_int), ("out_H", ctypes.c_int), ("out_W", ctypes.c_int), ("out_sy", ctypes.c_int),
-                ("out_sx", ctypes.c_int), ("prof_tag", ctypes.c_int), ("x_nchw", ctypes.c_int)]
+                ("out_sx", ctypes.c_int), ("prof_tag", ctypes.c_int), ("x_nchw", ctypes.c_int),
+                ("in_scale", ctypes.c_void_p), ("in_shift", ctypes.c_void_p)]
 
 
 def _dp(t):
@@ -728,7 +729,7 @@ def check_status(status):
 
 
 def _conv_launch(who, x, lda, N, H, W, cin, sw, bias, stride, pad_h, pad_w, dil, act, nchw, residual, y_ptr, ldy, out2, scale2, shift2,
-                 amax_in, amax_out, status, grid, view, prof_tag, device, x_nchw=False):
+                 amax_in, amax_out, status, grid, view, prof_tag, device, x_nchw=False, in_scale=None, in_shift=None):
     if sw.pieces == 2 and amax_in is None:
         raise LsfaError("%s: a two-piece (fp16) weight needs amax_in" % who)
     d = ConvDesc()
@@ -742,6 +743,7 @@ def _conv_launch(who, x, lda, N, H, W, cin, sw, bias, stride, pad_h, pad_w, dil,
     d.out_H, d.out_W, d.out_sy, d.out_sx = view
     d.prof_tag = prof_tag
     d.x_nchw = int(x_nchw)
+    d.in_scale, d.in_shift = (in_scale.data_ptr() if in_scale is not None else None), (in_shift.data_ptr() if in_shift is not None else None)
     need = lib().lsfa_conv_workspace_bytes(ctypes.byref(d))
     ws = torch.empty(max(need, 16), dtype=torch.uint8, device=device)
     _check(lib().lsfa_conv_fwd(ctypes.byref(d), _ptr(ws), ctypes.c_size_t(need), _stream()), who)
@@ -749,13 +751,16 @@ def _conv_launch(who, x, lda, N, H, W, cin, sw, bias, stride, pad_h, pad_w, dil,
 
 @_on_tensor_device
 def conv_split(x, sw, bias=None, stride=1, pad=0, dil=1, relu=False, out=None, residual=None, out2=None, scale2=None,
-               shift2=None, nchw=False, act=None, amax_in=None, amax_out=None, status=None, x_nchw=False):
+               shift2=None, nchw=False, act=None, amax_in=None, amax_out=None, status=None, x_nchw=False, in_scale=None, in_shift=None):
     """lsfa_conv_fwd: convolution with fp32 in / out and split operands on the matrix pipe; sw: SplitWeight (its `pieces` picks the form).
     x (N, H, W, Cin) contiguous fp32 -> (N, Ho, Wo, Cout), or (N, Cout, Ho, Wo) with nchw=True (then residual / out2 are NCHW too).
     residual (same shape as the output; may BE `out`): added before the activation / store.  out2 + scale2 + shift2: second output
     max(out*scale2[c] + shift2[c], 0) (the next ResNet unit's bn1 + relu1).  act: 0 none, 1 ReLU, 2 LeakyReLU(0.1) (relu=True = act 1).
     amax_in: 256 partial maxima (float32 or int32 bit patterns) bounding |x| - required for two-piece weights; amax_out: 256 int32 slots that
-    receive max|out2| (or max|out|); status: the int32 status word.  Returns out, or (out, out2)."""
+    receive max|out2| (or max|out|); status: the int32 status word.  scale2 + shift2 WITHOUT out2: the second output is not stored, only its
+    maximum published (amax_out) - for a consumer that applies the same affine + ReLU itself through in_scale / in_shift (Cin floats each:
+    the input becomes max(x*in_scale[k] + in_shift[k], 0) where it is cut; 1x1, pad 0, two-piece or one-piece weights; amax_in must bound
+    the ACTIVATED input).  Returns out, or (out, out2)."""
     x = _f32c(x, "x")
     if x_nchw:
         # the input is channels [0, sw.cin) of an NCHW map (N, Ctot, H, W): 1x1 / stride 1 / no padding, small weights (the RPN head)
@@ -780,7 +785,7 @@ def conv_split(x, sw, bias=None, stride=1, pad=0, dil=1, relu=False, out=None, r
     _count_conv(N, Ho, Wo, sw.real_cout, sw.real_cin, kh, kw, sw.pieces)
     _conv_launch("lsfa_conv_fwd", x, Ctot, N, H, W, Cin, sw, bias, stride, pad, pad, dil, (1 if relu else 0) if act is None else act, nchw,
                  residual, out.data_ptr(), Cout, out2, scale2, shift2, amax_in, amax_out, status, (0, 0), (0, 0, 0, 0), 0, x.device,
-                 x_nchw=x_nchw)
+                 x_nchw=x_nchw, in_scale=in_scale, in_shift=in_shift)
     return out if out2 is None else (out, out2)
 
 

@@ -279,6 +279,12 @@ class Executor(object):
         self.flow_pieces = self.pieces       # FlowNet too: a Concat map's scale is the maximum over its producers (they share its amax slots)
         self.taps = None              # set to {} to record stage outputs (parity tests)
         self.status = hip.new_status(self.device)
+        # conv1 applies its unit's bn1 + relu1 where it cuts its operand (see _resnet); 0: every conv3 stores the activated map (r3's form, for A/B runs)
+        self.input_activation_at_cut = _os.environ.get('LSFA_INPUT_ACT_AT_CUT', '1') == '1'
+        # ... where the map is large: below ~48 MB (a single 1000x600 image past stage 1) the maps live in L2 / the Infinity Cache, conv3's
+        # second output costs little and conv1's extra arithmetic shows (tools/lab: 3088 vs 3160 us for one image, 10706 vs 11080 for six).
+        # The choice never changes a bit of the result (tests/test_hip_ops.py::test_conv_input_activation_at_the_cut).
+        self.input_activation_min_bytes = int(float(_os.environ.get('LSFA_INPUT_ACT_MIN_MB', '48')) * (1 << 20))
         cfg = self.cfg
         arg = {k: np.asarray(v, dtype=np.float32) for k, v in arg_params.items()}
         aux = {k: np.asarray(v, dtype=np.float32) for k, v in aux_params.items()}
@@ -378,6 +384,7 @@ class Executor(object):
         am_a = S.new()             # pool0 publishes the maximum of its second output like the convolutions' epilogues do
         x4, a = hip.maxpool3x3s2_nhwc(y, scale2=units[0]['bn1'][0], shift2=units[0]['bn1'][1], amax_out=am_a)
         dilate = 1
+        pre = None                 # (scale, shift) of this unit's bn1 when its input `a` is still the raw sum (applied where conv1 cuts it)
         for ui, u in enumerate(units):
             first = u['unit'] == 1
             # stage 4 keeps stride 1 and doubles the dilation from its 2nd unit on (resnet.py:33-34, :72-76, :223-230)
@@ -386,7 +393,10 @@ class Executor(object):
             if first and u['stage'] == 4:
                 dilate = dilate * 2
             am_c1, am_c2, am_n = S.new(), S.new(), S.new()
-            c1 = self._conv(a, u['w1'], u['b1'], act=1, amax_in=am_a, amax_out=am_c1)     # conv1 + folded bn2 + relu2
+            if pre is None:
+                c1 = self._conv(a, u['w1'], u['b1'], act=1, amax_in=am_a, amax_out=am_c1)     # conv1 + folded bn2 + relu2
+            else:                  # ... on max(sum * bn1 scale + bn1 shift, 0), which only this convolution reads: never stored
+                c1 = self._conv(a, u['w1'], u['b1'], act=1, amax_in=am_a, amax_out=am_c1, in_scale=pre[0], in_shift=pre[1])
             if u['dcn']:
                 # DeformableConvolution (sym_common.py:138-157): offsets, bilinear columns, contraction + folded bn3 + relu3.  Every column
                 # entry is an interpolation of c1 (zeros outside): max|col| <= max|c1|, so c1's scale serves the contraction
@@ -401,7 +411,20 @@ class Executor(object):
                 c2 = self._conv(c1, u['w2'], u['b2'], stride, ud, ud, act=1, amax_in=am_c1, amax_out=am_c2)   # conv2 + folded bn3 + relu3
             # conv3 + shortcut add in place + the bn1 / relu1 the NEXT unit (or the tail) applies to the sum, as a second output
             nxt = units[ui + 1]['bn1'] if ui + 1 < len(units) else net.bn1
-            if nxt is not None:
+            # A stage's first unit also feeds relu1 to its shortcut convolution (a strided 1x1) and the tail feeds it to a 3x3: there
+            # the activated map is stored.  Everywhere else (29 of ResNet-101's 33 units) conv1 is its only reader and applies bn1 +
+            # relu1 itself: conv3 then writes the sum alone and only publishes max(relu1) for conv1's fp16 scale - a quarter less
+            # map traffic per unit (the sum read and written, the activated map written and read, were its four big streams).
+            lone = self.input_activation_at_cut and ui + 1 < len(units) and units[ui + 1]['unit'] != 1 and u['w1'].pieces != 3 and \
+                sc.numel() * 4 >= self.input_activation_min_bytes
+            pre = None
+            if nxt is not None and lone:
+                if u['w3'].pieces == 2:      # max(relu1) is the next conv1's fp16 scale; the one-piece (bf16) mode has no scale
+                    x4 = self._conv(c2, u['w3'], None, amax_in=am_c2, amax_out=am_n, out=sc, residual=sc, scale2=nxt[0], shift2=nxt[1])
+                else:
+                    x4 = self._conv(c2, u['w3'], None, out=sc, residual=sc)
+                a, pre = x4, nxt
+            elif nxt is not None:
                 x4, a = self._conv(c2, u['w3'], None, amax_in=am_c2, amax_out=am_n, out=sc, residual=sc, out2=torch.empty_like(sc),
                                    scale2=nxt[0], shift2=nxt[1])
             else:

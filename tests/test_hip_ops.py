@@ -1098,6 +1098,59 @@ def test_conv_split_nchw_output_equals_nhwc_output(hip, cfg):
     assert torch.equal(z2, y2.permute(0, 3, 1, 2))
 
 
+@pytest.mark.parametrize("pieces", [2, 1])
+def test_conv_input_activation_at_the_cut(hip, pieces):
+    """A pre-activation ResNet unit's bn1 + relu1 (dff_rfcn/symbols/resnet.py:78-80) applied where conv1 cuts its operand instead of
+    being stored by the previous conv3 and read back: lsfa_conv_fwd with in_scale / in_shift on the raw sum == the same convolution
+    on the stored max(x*s + t, 0), BIT FOR BIT, under every plan of the ring kernel (tile width, ring depth, wave roles, K slices),
+    with stride 2 (a stage's first shortcut), a partial last tile and two images; and the producer's side: scale2 / shift2 without
+    out2 store nothing but publish the same maximum and the same first output."""
+    g = torch.Generator(device=DEV).manual_seed(70 + pieces)
+    for (N, H, W, ci, co, stride) in ((2, 13, 23, 256, 64, 1), (1, 19, 31, 1024, 256, 1), (2, 14, 22, 512, 128, 2)):
+        x = torch.randn((N, H, W, ci), device=DEV, generator=g) * 3.0
+        sc, sh = torch.rand(ci, device=DEV, generator=g) + 0.5, torch.randn(ci, device=DEV, generator=g)
+        sw = hip.SplitWeight(torch.randn((co, ci, 1, 1), device=DEV, generator=g) * 0.05, pieces=pieces)
+        b = torch.randn(co, device=DEV, generator=g)
+        act = torch.relu(x * sc + sh)                       # two roundings, like the epilogue that used to store it
+        am = hip.amax_partial(act)
+        plans = [(0, 0, 0, 0)] + [(kern, nt, st, sl) for kern in (1, 2) for nt in (2, 4) for st in (2, 3, 4) for sl in (1, 3)
+                                  if not (nt == 4 and co % 128)]
+        try:
+            for kern, nt, st, sl in plans:
+                hip.conv_plan_override(kernel=kern, nt=nt, st=st, slices=sl)
+                s1, s2 = hip.amax_slots(2, DEV)
+                want = hip.conv_split(act, sw, b, stride, 0, 1, relu=True, amax_in=am, amax_out=s1)
+                got = hip.conv_split(x, sw, b, stride, 0, 1, relu=True, amax_in=am, amax_out=s2, in_scale=sc, in_shift=sh)
+                if kern == 0:       # the plan's own choice: the stored map may go to the direct kernel (another summation order), the cut-time form never does
+                    assert float((got - want).abs().max()) <= 2e-5 * float(want.abs().max()), (ci, co, stride)
+                    continue
+                assert torch.equal(got, want), (ci, co, stride, kern, nt, st, sl)
+                assert torch.equal(s1.max(), s2.max())
+        finally:
+            hip.conv_plan_override()
+    # the producer: second output not stored
+    x = torch.randn((2, 13, 23, 64), device=DEV, generator=g)
+    sw = hip.SplitWeight(torch.randn((256, 64, 1, 1), device=DEV, generator=g) * 0.05, pieces=pieces)
+    res = torch.randn((2, 13, 23, 256), device=DEV, generator=g)
+    sc2, sh2 = torch.rand(256, device=DEV, generator=g) + 0.5, torch.randn(256, device=DEV, generator=g)
+    am = hip.amax_partial(x)
+    try:
+        for kern, nt, st, sl in ((0, 0, 0, 0), (1, 2, 2, 1), (1, 4, 2, 1), (2, 4, 3, 1), (1, 2, 3, 2), (2, 2, 2, 2)):
+            hip.conv_plan_override(kernel=kern, nt=nt, st=st, slices=sl)
+            s1, s2 = hip.amax_slots(2, DEV)
+            y, y2 = hip.conv_split(x, sw, None, residual=res, out2=torch.empty_like(res), scale2=sc2, shift2=sh2, amax_in=am, amax_out=s1)
+            z = hip.conv_split(x, sw, None, residual=res, scale2=sc2, shift2=sh2, amax_in=am, amax_out=s2)
+            assert torch.equal(z, y) and torch.equal(s1.max(), s2.max()), (kern, nt, st, sl)
+            assert s2.view(torch.float32).max().item() == y2.max().item()
+    finally:
+        hip.conv_plan_override()
+    with pytest.raises(hip.LsfaError):      # nothing to publish into
+        hip.conv_split(x, sw, None, residual=res, scale2=sc2, shift2=sh2, amax_in=am)
+    with pytest.raises(hip.LsfaError):      # a 3x3 has padding: its zeros are not max(0*s + t, 0)
+        sw3 = hip.SplitWeight(torch.randn((64, 64, 3, 3), device=DEV, generator=g) * 0.05, pieces=pieces)
+        hip.conv_split(x, sw3, None, 1, 1, 1, amax_in=am, in_scale=sc2[:64].contiguous(), in_shift=sh2[:64].contiguous())
+
+
 @pytest.mark.parametrize("pieces", [2, 3, 1])
 def test_conv_ring_nchw_epilogue_through_lds(hip, pieces):
     """The unsliced ring kernel writes NCHW outputs as 128-byte runs of a plane (tiles turned in LDS, column-major with padded columns)

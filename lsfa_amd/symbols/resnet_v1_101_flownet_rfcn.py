@@ -406,16 +406,19 @@ class Executor(object):
             else:
                 c2 = None
             # shortcut: 1x1 (stride) on relu1, or x
-            sc = self._conv(a, u['sc'], None, stride, amax_in=am_a) if first else x4
+            if first and pre is not None:      # the strided shortcut reads the same raw sum through the same bn1 + relu1
+                sc = self._conv(a, u['sc'], None, stride, amax_in=am_a, in_scale=pre[0], in_shift=pre[1])
+            else:
+                sc = self._conv(a, u['sc'], None, stride, amax_in=am_a) if first else x4
             if c2 is None:
                 c2 = self._conv(c1, u['w2'], u['b2'], stride, ud, ud, act=1, amax_in=am_c1, amax_out=am_c2)   # conv2 + folded bn3 + relu3
             # conv3 + shortcut add in place + the bn1 / relu1 the NEXT unit (or the tail) applies to the sum, as a second output
             nxt = units[ui + 1]['bn1'] if ui + 1 < len(units) else net.bn1
-            # A stage's first unit also feeds relu1 to its shortcut convolution (a strided 1x1) and the tail feeds it to a 3x3: there
-            # the activated map is stored.  Everywhere else (29 of ResNet-101's 33 units) conv1 is its only reader and applies bn1 +
-            # relu1 itself: conv3 then writes the sum alone and only publishes max(relu1) for conv1's fp16 scale - a quarter less
+            # The tail feeds relu1 to a padded 3x3 (its zeros are not max(0 * s + t, 0)) and pool0 produces the first one: there the
+            # activated map is stored.  Everywhere else (32 of ResNet-101's 33 units) its readers are conv1 and, in a stage's first
+            # unit, the shortcut's strided 1x1, which apply bn1 + relu1 themselves: conv3 then writes the sum alone and only publishes max(relu1) for conv1's fp16 scale - a quarter less
             # map traffic per unit (the sum read and written, the activated map written and read, were its four big streams).
-            lone = self.input_activation_at_cut and ui + 1 < len(units) and units[ui + 1]['unit'] != 1 and u['w1'].pieces != 3 and \
+            lone = self.input_activation_at_cut and ui + 1 < len(units) and u['w1'].pieces != 3 and \
                 sc.numel() * 4 >= self.input_activation_min_bytes
             pre = None
             if nxt is not None and lone:

@@ -180,7 +180,9 @@ __device__ __forceinline__ void ring_prologue(uint4 (*R)[(Ring<NT, PC, ST>::kSta
 // grid (8 * ceil(tiles / 8)); block 256 (SP: 512).  tiles = ceil(P / 128) * (Cout / (32 * NT)) * slices (* phases)
 // AF: Args::in_scale / in_shift are applied to the input where it is cut (their table, 16 KB, sits in LDS behind the ring)
 template <int NT, int PC, int ST, bool SP = false, bool AF = false>
-static __global__ __launch_bounds__((SP ? 2 : 1) * kThreads, ((AF ? 2 * (Ring<NT, PC, ST>::kLdsBytes + 16384) <= 160 * 1024 : Ring<NT, PC, ST>::kWgPerCu == 2) ? 2 : 1) * (SP ? 2 : 1))
+// (two resident workgroups only where their registers allow it: a 128 x 128 tile with loader waves needs ~200 per lane, which two 512-thread
+// workgroups per CU - four waves per SIMD, 128 registers - could only have by spilling 100-270 of them)
+static __global__ __launch_bounds__((SP ? 2 : 1) * kThreads, (((AF ? 2 * (Ring<NT, PC, ST>::kLdsBytes + 16384) <= 160 * 1024 : Ring<NT, PC, ST>::kWgPerCu == 2) && !(SP && NT == 4)) ? 2 : 1) * (SP ? 2 : 1))
 void conv_ring_kernel(Args a, int nx, int ny, int nz) {
   typedef Ring<NT, PC, ST> RG;
   __shared__ __attribute__((aligned(16))) uint4 R[ST][RG::kStageN];
@@ -321,6 +323,9 @@ void conv_ring_kernel(Args a, int nx, int ny, int nz) {
   constexpr bool kRowsFit = RG::kLdsBytes >= 4 * NT * 4096;       // the ring holds the four waves' tiles
   const bool rows_ok = kRowsFit && rows_path_ok(a);
   if (rows_ok) {
+    float* part = a.part ? a.part + (size_t)tile.z * P * a.Cout : nullptr;
+    RowsIn<NT> in;                                      // residual, bias, second output's affine: in flight across the barrier and the turn through LDS
+    tile_rows_in<NT>(a, m0, P, tile.y * (32 * NT), part != nullptr, lane, in);
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();                       // every wave is done reading the ring (SP: the loaders have left)
     float* T = reinterpret_cast<float*>(&R[0][0]) + g.wave * (NT * 1024);
@@ -328,8 +333,7 @@ void conv_ring_kernel(Args a, int nx, int ny, int nz) {
     for (int t = 0; t < NT; ++t)
 #pragma unroll
       for (int r = 0; r < 16; ++r) T[t * 1024 + ((r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)) * 32 + (lane & 31)] = acc[t][r];
-    float* part = a.part ? a.part + (size_t)tile.z * P * a.Cout : nullptr;
-    const uint32_t m = tile_rows_out<NT>(a, T, m0, P, tile.y * (32 * NT), part, lane);
+    const uint32_t m = tile_rows_out<NT>(a, T, m0, P, tile.y * (32 * NT), part, lane, in);
     if (!part) publish_amax(m, a.amax_out, a.status, blockIdx.x * 4 + g.wave);
     return;
   }

@@ -397,39 +397,80 @@ __device__ __forceinline__ uint32_t tile_store_max(const Args& a, const RowOut& 
 // 8 lanes, 16 bytes per lane, a quarter of the memory instructions.  Same values, same arithmetic per element as tile_store.
 // m0 = first pixel of the 32 rows, ch0 = first channel of tile 0; part != NULL: a K slice's partial sums instead of the epilogue.
 // -> the wave's contribution to amax_out (bit pattern; 0x7FC00000 if a non-finite value went through this lane)
+// Every load of the epilogue is issued before its first store: the residual is usually the output itself (a ResNet unit adds in place),
+// so the compiler must assume that a store may change what a later load reads and would run the 4 x NT (load, add, store) steps one
+// memory latency after the other - 16 round trips for a 128 x 128 tile, most of a conv3's time (res4 conv3 at six images: 74 us for a
+// main loop of 8 chunks).  A lane reads and writes the same addresses, no other lane touches them: reading them all first is safe.
+template <int NT> struct RowsIn { float4 rr[4][NT], bb[NT], s2[NT], h2[NT]; int base[4]; bool ok[4]; };
+
+// the loads of tile_rows_out, issued by the caller before it turns its accumulators through LDS (their latency runs meanwhile)
 template <int NT>
-__device__ __forceinline__ uint32_t tile_rows_out(const Args& a, const float* T, int m0, int P, int ch0, float* part, int lane) {
+__device__ __forceinline__ void tile_rows_in(const Args& a, int m0, int P, int ch0, bool part, int lane, RowsIn<NT>& in) {
+  const int c4 = (lane & 7) * 4;
+  const bool has_y2 = a.scale2 != nullptr, has_res = a.res != nullptr, has_bias = a.bias != nullptr;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int p = m0 + 8 * k + (lane >> 3);
+    in.ok[k] = p < P;
+    in.base[k] = (in.ok[k] && !part) ? out_pixel_base(a, p) : 0;
+  }
+  if (part) return;
+  const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+  for (int t = 0; t < NT; ++t) {
+    const int ch = ch0 + t * 32 + c4;
+    in.bb[t] = has_bias ? *reinterpret_cast<const float4*>(a.bias + ch) : zero4;
+    in.s2[t] = has_y2 ? *reinterpret_cast<const float4*>(a.scale2 + ch) : zero4;
+    in.h2[t] = has_y2 ? *reinterpret_cast<const float4*>(a.shift2 + ch) : zero4;
+  }
+  if (has_res) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+#pragma unroll
+      for (int t = 0; t < NT; ++t) in.rr[k][t] = *reinterpret_cast<const float4*>(a.res + in.base[k] + ch0 + t * 32 + c4);      // base 0 for a row past the end: a valid address, not used
+  }
+}
+
+template <int NT>
+__device__ __forceinline__ uint32_t tile_rows_out(const Args& a, const float* T, int m0, int P, int ch0, float* part, int lane, const RowsIn<NT>& in) {
   const int c4 = (lane & 7) * 4;
   // the maximum as a float maximum of |.| (one instruction per value; a NaN drops out of it) and, beside it, the SUM of the
   // pre-activation magnitudes, which is non-finite exactly when one of them is (ReLU would hide a NaN or a -inf): one add per value
   float mx = 0.f, nf = 0.f;
   const int act = a.act;                         // wave-uniform: the branches below are scalar
   const bool has_y2 = a.scale2 != nullptr, store_y2 = a.y2 != nullptr, has_res = a.res != nullptr, has_bias = a.bias != nullptr;
+  if (part) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int row = 8 * k + (lane >> 3);
+#pragma unroll
+      for (int t = 0; t < NT; ++t) {
+        const float4 v = *reinterpret_cast<const float4*>(&T[t * 1024 + row * 32 + c4]);
+        if (in.ok[k]) *reinterpret_cast<float4*>(part + (size_t)(m0 + row) * a.Cout + ch0 + t * 32 + c4) = v;
+      }
+    }
+    return 0u;
+  }
 #pragma unroll
   for (int k = 0; k < 4; ++k) {
     const int row = 8 * k + (lane >> 3);
-    const int p = m0 + row;
-    const bool ok = p < P;
-    const int base = (ok && !part) ? out_pixel_base(a, p) : 0;
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
       const int ch = ch0 + t * 32 + c4;
       const float4 v = *reinterpret_cast<const float4*>(&T[t * 1024 + row * 32 + c4]);
-      if (!ok) continue;
-      if (part) { *reinterpret_cast<float4*>(part + (size_t)p * a.Cout + ch) = v; continue; }
+      if (!in.ok[k]) continue;
       float4 o = v;
-      if (has_bias) { const float4 b = *reinterpret_cast<const float4*>(a.bias + ch); o.x = o.x + b.x; o.y = o.y + b.y; o.z = o.z + b.z; o.w = o.w + b.w; }
-      if (has_res) { const float4 rr = *reinterpret_cast<const float4*>(a.res + base + ch); o.x = o.x + rr.x; o.y = o.y + rr.y; o.z = o.z + rr.z; o.w = o.w + rr.w; }
+      if (has_bias) { o.x = o.x + in.bb[t].x; o.y = o.y + in.bb[t].y; o.z = o.z + in.bb[t].z; o.w = o.w + in.bb[t].w; }
+      if (has_res) { o.x = o.x + in.rr[k][t].x; o.y = o.y + in.rr[k][t].y; o.z = o.z + in.rr[k][t].z; o.w = o.w + in.rr[k][t].w; }
       nf = nf + fabsf(o.x); nf = nf + fabsf(o.y); nf = nf + fabsf(o.z); nf = nf + fabsf(o.w);
       if (act == 1) { o.x = fmaxf(o.x, 0.f); o.y = fmaxf(o.y, 0.f); o.z = fmaxf(o.z, 0.f); o.w = fmaxf(o.w, 0.f); }
       else if (act == 2) { o.x = activate(o.x, 2); o.y = activate(o.y, 2); o.z = activate(o.z, 2); o.w = activate(o.w, 2); }
-      *reinterpret_cast<float4*>(a.y + base + ch) = o;
+      *reinterpret_cast<float4*>(a.y + in.base[k] + ch) = o;
       if (has_y2) {
-        const float4 s2 = *reinterpret_cast<const float4*>(a.scale2 + ch), h2 = *reinterpret_cast<const float4*>(a.shift2 + ch);
         float4 w;
-        w.x = fmaxf(o.x * s2.x + h2.x, 0.f); w.y = fmaxf(o.y * s2.y + h2.y, 0.f);
-        w.z = fmaxf(o.z * s2.z + h2.z, 0.f); w.w = fmaxf(o.w * s2.w + h2.w, 0.f);
-        if (store_y2) *reinterpret_cast<float4*>(a.y2 + base + ch) = w;
+        w.x = fmaxf(o.x * in.s2[t].x + in.h2[t].x, 0.f); w.y = fmaxf(o.y * in.s2[t].y + in.h2[t].y, 0.f);
+        w.z = fmaxf(o.z * in.s2[t].z + in.h2[t].z, 0.f); w.w = fmaxf(o.w * in.s2[t].w + in.h2[t].w, 0.f);
+        if (store_y2) *reinterpret_cast<float4*>(a.y2 + in.base[k] + ch) = w;
         mx = fmaxf(fmaxf(mx, fmaxf(w.x, w.y)), fmaxf(w.z, w.w));
       } else {
         mx = fmaxf(fmaxf(mx, fmaxf(fabsf(o.x), fabsf(o.y))), fmaxf(fabsf(o.z), fabsf(o.w)));
@@ -458,20 +499,31 @@ __device__ __forceinline__ uint32_t tile_cols_out_nchw(const Args& a, const floa
   const int act = a.act;
   const bool has_y2 = a.scale2 != nullptr, store_y2 = a.y2 != nullptr, has_res = a.res != nullptr, has_bias = a.bias != nullptr;
   float mx = 0.f, nf = 0.f;
+  // per 32-channel tile: every load (bias, residual, the second output's affine: 16 channels per lane) before the first store - the
+  // compiler cannot know that the stores leave them alone and would otherwise wait for a load in each of the 16 x NT steps
 #pragma unroll
   for (int t = 0; t < NT; ++t) {
-#pragma unroll 4
-    for (int c = 0; c < 32; c += 2) {
-      const int col = c + (lane >> 5), ch = ch0 + t * 32 + col;
+    float bb[16], rr[16], s2[16], h2[16];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+      const int ch = ch0 + t * 32 + 2 * j + (lane >> 5);
+      bb[j] = has_bias ? a.bias[ch] : 0.f;
+      rr[j] = has_res ? a.res[base + ch * hw] : 0.f;        // base 0 for a pixel past the end: a valid address, not used
+      s2[j] = has_y2 ? a.scale2[ch] : 0.f;
+      h2[j] = has_y2 ? a.shift2[ch] : 0.f;
+    }
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+      const int col = 2 * j + (lane >> 5), ch = ch0 + t * 32 + col;
       float o = Tc[(t * 32 + col) * kColPitch + (lane & 31)];
       if (!ok) continue;
-      if (has_bias) o = o + a.bias[ch];
-      if (has_res) o = o + a.res[base + ch * hw];
+      if (has_bias) o = o + bb[j];
+      if (has_res) o = o + rr[j];
       nf = nf + fabsf(o);
       o = activate(o, act);
       a.y[base + ch * hw] = o;
       if (has_y2) {
-        const float w = fmaxf(o * a.scale2[ch] + a.shift2[ch], 0.f);
+        const float w = fmaxf(o * s2[j] + h2[j], 0.f);
         if (store_y2) a.y2[base + ch * hw] = w;
         mx = fmaxf(mx, w);
       } else {
@@ -1064,7 +1116,9 @@ __device__ __forceinline__ void direct_tile(const Args& a, int bx, int by, int n
       T[row * 32 + (lane & 31)] = acc0[r];
       T[1024 + row * 32 + (lane & 31)] = acc1[r];
     }
-    const uint32_t mr = tile_rows_out<2>(a, T, m0, P, by * kWgCh, nullptr, lane);
+    RowsIn<2> in;
+    tile_rows_in<2>(a, m0, P, by * kWgCh, false, lane, in);
+    const uint32_t mr = tile_rows_out<2>(a, T, m0, P, by * kWgCh, nullptr, lane, in);
     publish_amax(mr, a.amax_out, a.status, by * nx + bx);
     return;
   }

@@ -56,6 +56,37 @@ __global__ __launch_bounds__(kThreads) void deform_im2col_kernel(const float* __
 // group share the tap's offset, so a wave reads each of the four corners as 1 KB of consecutive
 // channels and writes 1 KB of col — every access is a full line.  The corner selection and the
 // weights are those of dcn_bilinear (same expressions, same order => same bits per channel).
+// one float4 of channels of one (pixel, tap): the bilinear sample of DeformableConvolution's im2col (zeros outside the image)
+__device__ __forceinline__ float4 deform_sample4(const float* __restrict__ data, const float* __restrict__ offset, int C, int H, int W, int kw,
+                                                 int pad, int stride, int dilate, int cpg, int KK, int off_ld, size_t pix, int n, int ho, int wo,
+                                                 int tap, int c) {
+  const int i = tap / kw, j = tap - i * kw;
+  const int g = c / cpg;
+  const float* off = offset + pix * (size_t)off_ld + (size_t)g * 2 * KK + 2 * tap;
+  const float oh = off[0], ow = off[1];
+  float h = (float)(ho * stride - pad + i * dilate) + oh;
+  float w = (float)(wo * stride - pad + j * dilate) + ow;
+  float4 val = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (h >= 0 && w >= 0 && h < H && w < W) {
+    int h_low = (int)floorf(h), w_low = (int)floorf(w);
+    int h_high, w_high;
+    if (h_low >= H - 1) { h_high = h_low = H - 1; h = (float)h_low; } else { h_high = h_low + 1; }
+    if (w_low >= W - 1) { w_high = w_low = W - 1; w = (float)w_low; } else { w_high = w_low + 1; }
+    const float lh = h - h_low, lw = w - w_low, hh = 1 - lh, hw = 1 - lw;
+    const float* base = data + (size_t)n * H * W * C + c;
+    const float4 v1 = *reinterpret_cast<const float4*>(base + ((size_t)h_low * W + w_low) * C);
+    const float4 v2 = *reinterpret_cast<const float4*>(base + ((size_t)h_low * W + w_high) * C);
+    const float4 v3 = *reinterpret_cast<const float4*>(base + ((size_t)h_high * W + w_low) * C);
+    const float4 v4 = *reinterpret_cast<const float4*>(base + ((size_t)h_high * W + w_high) * C);
+    const float w1 = hh * hw, w2 = hh * lw, w3 = lh * hw, w4 = lh * lw;
+    val.x = w1 * v1.x + w2 * v2.x + w3 * v3.x + w4 * v4.x;
+    val.y = w1 * v1.y + w2 * v2.y + w3 * v3.y + w4 * v4.y;
+    val.z = w1 * v1.z + w2 * v2.z + w3 * v3.z + w4 * v4.z;
+    val.w = w1 * v1.w + w2 * v2.w + w3 * v3.w + w4 * v4.w;
+  }
+  return val;
+}
+
 __global__ __launch_bounds__(kThreads) void deform_im2col_cl_kernel(const float* __restrict__ data,
                                                                     const float* __restrict__ offset, int C, int H,
                                                                     int W, int kh, int kw, int pad, int stride,
@@ -69,31 +100,36 @@ __global__ __launch_bounds__(kThreads) void deform_im2col_cl_kernel(const float*
     const int sp = (int)(pix % HoWo);
     const int n = (int)(pix / HoWo);
     const int ho = sp / Wo, wo = sp - ho * Wo;
-    const int i = tap / kw, j = tap - i * kw;
-    const int g = c / cpg;
-    const float* off = offset + pix * (size_t)off_ld + (size_t)g * 2 * KK + 2 * tap;
-    const float oh = off[0], ow = off[1];
-    float h = (float)(ho * stride - pad + i * dilate) + oh;
-    float w = (float)(wo * stride - pad + j * dilate) + ow;
-    float4 val = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (h >= 0 && w >= 0 && h < H && w < W) {
-      int h_low = (int)floorf(h), w_low = (int)floorf(w);
-      int h_high, w_high;
-      if (h_low >= H - 1) { h_high = h_low = H - 1; h = (float)h_low; } else { h_high = h_low + 1; }
-      if (w_low >= W - 1) { w_high = w_low = W - 1; w = (float)w_low; } else { w_high = w_low + 1; }
-      const float lh = h - h_low, lw = w - w_low, hh = 1 - lh, hw = 1 - lw;
-      const float* base = data + (size_t)n * H * W * C + c;
-      const float4 v1 = *reinterpret_cast<const float4*>(base + ((size_t)h_low * W + w_low) * C);
-      const float4 v2 = *reinterpret_cast<const float4*>(base + ((size_t)h_low * W + w_high) * C);
-      const float4 v3 = *reinterpret_cast<const float4*>(base + ((size_t)h_high * W + w_low) * C);
-      const float4 v4 = *reinterpret_cast<const float4*>(base + ((size_t)h_high * W + w_high) * C);
-      const float w1 = hh * hw, w2 = hh * lw, w3 = lh * hw, w4 = lh * lw;
-      val.x = w1 * v1.x + w2 * v2.x + w3 * v3.x + w4 * v4.x;
-      val.y = w1 * v1.y + w2 * v2.y + w3 * v3.y + w4 * v4.y;
-      val.z = w1 * v1.z + w2 * v2.z + w3 * v3.z + w4 * v4.z;
-      val.w = w1 * v1.w + w2 * v2.w + w3 * v3.w + w4 * v4.w;
-    }
-    reinterpret_cast<float4*>(col)[idx] = val;
+    reinterpret_cast<float4*>(col)[idx] = deform_sample4(data, offset, C, H, W, kw, pad, stride, dilate, cpg, KK, off_ld, pix, n, ho, wo, tap, c);
+  }
+}
+
+// n / d for 0 <= n < 2^24, 0 < d, inv = 1.0f / d from the host: the float product is off by at most one, the remainder fixes it
+__device__ __forceinline__ int fdiv24(int n, int d, float inv) {
+  int q = (int)((float)n * inv);
+  const int r = n - q * d;
+  q += (r >= d) ? 1 : 0;
+  q -= (r < 0) ? 1 : 0;
+  return q;
+}
+
+// The same with the index arithmetic the network's shapes allow (r4): C / 4 a power of two <= 256 and fewer than 2^24 (pixel, tap) units.
+// The general kernel spends five 64-bit integer divisions (~100 instructions each) per float4 it writes - more than the sampling
+// itself; here a thread's channel group is a mask of its id, its unit a shift, and the three remaining divisions run through float
+// reciprocals.  One (pixel, tap) unit per C / 4 threads, 256 / (C / 4) units per workgroup.  Same values.
+__global__ __launch_bounds__(kThreads) void deform_im2col_cl_pow2_kernel(const float* __restrict__ data, const float* __restrict__ offset, int C,
+                                                                         int H, int W, int kh, int kw, int pad, int stride, int dilate, int dg,
+                                                                         int Ho, int Wo, int off_ld, float* __restrict__ col, int units,
+                                                                         int c4_shift, float inv_kk, float inv_howo, float inv_wo) {
+  const int KK = kh * kw, cpg = C / dg, HoWo = Ho * Wo;
+  const int c = (int)(threadIdx.x & ((1u << c4_shift) - 1u)) * 4;
+  const int per_wg = kThreads >> c4_shift;
+  for (int u = blockIdx.x * per_wg + (int)(threadIdx.x >> c4_shift); u < units; u += gridDim.x * per_wg) {
+    const int pix = fdiv24(u, KK, inv_kk), tap = u - pix * KK;
+    const int n = fdiv24(pix, HoWo, inv_howo), sp = pix - n * HoWo;
+    const int ho = fdiv24(sp, Wo, inv_wo), wo = sp - ho * Wo;
+    reinterpret_cast<float4*>(col)[((size_t)u << c4_shift) + (c >> 2)] =
+        deform_sample4(data, offset, C, H, W, kw, pad, stride, dilate, cpg, KK, off_ld, (size_t)pix, n, ho, wo, tap, c);
   }
 }
 
@@ -202,6 +238,19 @@ extern "C" int lsfa_deform_im2col_cl_ld(const float* data, const float* offset, 
   size_t nb = (total4 + kThreads - 1) / kThreads;
   if (nb > 65536) nb = 65536;
   ProfScope prof(LSFA_OP_DCN_IM2COL, s);
+  const int C4 = C / 4;
+  const size_t units = (size_t)N * Ho * Wo * kh * kw;
+  if ((C4 & (C4 - 1)) == 0 && C4 <= kThreads && units < (1u << 24)) {
+    int shift = 0;
+    while ((1 << shift) < C4) ++shift;
+    const int per_wg = kThreads >> shift;
+    size_t nbu = (units + per_wg - 1) / per_wg;
+    if (nbu > 65536) nbu = 65536;
+    hipLaunchKernelGGL(deform_im2col_cl_pow2_kernel, dim3((unsigned)nbu), dim3(kThreads), 0, s, data, offset, C, H, W, kh, kw, pad, stride, dilate,
+                       deform_groups, Ho, Wo, offset_ld, col, (int)units, shift, 1.0f / (float)(kh * kw), 1.0f / (float)(Ho * Wo), 1.0f / (float)Wo);
+    LSFA_LAUNCH_CHECK("lsfa_deform_im2col_cl");
+    return LSFA_OK;
+  }
   hipLaunchKernelGGL(deform_im2col_cl_kernel, dim3((unsigned)nb), dim3(kThreads), 0, s, data, offset, C, H, W, kh, kw,
                      pad, stride, dilate, deform_groups, Ho, Wo, offset_ld, col, total4);
   LSFA_LAUNCH_CHECK("lsfa_deform_im2col_cl");

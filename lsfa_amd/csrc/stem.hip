@@ -117,7 +117,7 @@ __global__ __launch_bounds__(128) void stem_weights_kernel(const float* __restri
   if (half == 0) reinterpret_cast<float*>(wfrag + kFragVecs)[co] = inv_w;
 }
 
-// grid (ceil(ceil(Wo / 32) / tiles_per_wg), ceil(Ho / 4), N); block 256.  w_l: (3, 7, 7, 64) floats = [ci][ky][kx][co].
+// grid (ceil(ceil(Wo / 32) / tiles_per_wg), ceil(Ho / 4), N); block 256.  wfrag: what stem_weights_kernel wrote.
 __global__ __launch_bounds__(256, 2) void stem_conv_kernel(const float* __restrict__ x, int H, int W, const float* __restrict__ in_scale,
                                                            const float* __restrict__ in_shift, const uint4* __restrict__ wfrag,
                                                            const float* __restrict__ bias, int Ho, int Wo, int tiles_per_wg,

@@ -78,8 +78,9 @@ def parse():
                     help='non-key frames of a segment that go through the network in ONE pass, batch axis = frames (the reference\'s batch test '
                          'symbol, resnet_v1_101_flownet_rfcn.py:661-751); -1 = interval - 1 when one clip runs pipelined, else 0 = frame by frame')
     ap.add_argument('--key-group', type=int, default=6,
-                    help='key frames whose image-only half (backbone, FlowNet) is computed in one pass (FramePipeline key_group; the first passes '
-                         'after the pipeline ran empty are 1 and 2 frames: its ramp); 1 = one by one')
+                    help='key frames whose image-only half (backbone, FlowNet) is computed in one pass (FramePipeline key_group); 1 = one by one')
+    ap.add_argument('--ramp', default='',
+                    help='sizes of the first passes of key fronts after the pipeline ran empty, e.g. "1,2" (FramePipeline ramp); default: full groups at once')
     ap.add_argument('--lookahead', action='store_true',
                     help='queue each key frame ahead of the non-key frames that precede it in display order')
     ap.add_argument('--no-flow-stream', action='store_true', help='FlowNet after the backbone on the key stream instead of beside it')
@@ -135,7 +136,7 @@ class Runner(object):
             self.fg = FramePipeline(self.key, self.cur, cfg, args.height, args.width, device,
                                     use_graphs=not args.no_graph, lanes=max(args.lanes, 2 if F else 1),
                                     flow_stream=not args.no_flow_stream, lookahead=args.lookahead, batch=self.B,
-                                    segment=F, key_group=self.key_group)
+                                    segment=F, key_group=self.key_group, ramp=tuple(int(v) for v in args.ramp.split(',') if v.strip()))
         else:
             self.fg = FrameGraphs(self.key, self.cur, cfg, args.height, args.width, device, use_graphs=not args.no_graph,
                                   prefetch=not args.no_prefetch, batch=self.B)
@@ -784,9 +785,10 @@ def main():
                        if args.lanes > 0 else "serial",
                        "batching": ("one clip, frames in display order; the %d non-key frames of a segment go through the network in one pass (batch axis = "
                                     "frames, like the reference's batch test symbol) and the image-only half (backbone, FlowNet) of %d consecutive key "
-                                    "frames in one pass (look-ahead of %d frames; after the pipeline ran empty the first passes are 1 and 2 key frames); "
+                                    "frames in one pass (look-ahead of %d frames%s); "
                                     "--segment 0 --key-group 1 = frame by frame" %
-                                    (r.segment, r.key_group, (r.key_group - 1) * K)) if batched else "none: one frame per pass"},
+                                    (r.segment, r.key_group, (r.key_group - 1) * K,
+                                     "; after the pipeline ran empty the first passes are %s key frames" % args.ramp if args.ramp.strip() else "")) if batched else "none: one frame per pass"},
             "value_spread": {"min": round(frames / max(repeats), 3), "max": round(frames / min(repeats), 3), "repeats": len(repeats),
                              "values": [round(frames / t, 3) for t in repeats],
                              "note": "the timed region run %d times back to back; `value` is the first" % len(repeats),

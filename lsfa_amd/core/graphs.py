@@ -484,7 +484,7 @@ class FramePipeline(object):
     """
 
     def __init__(self, key_exec, cur_exec, cfg, height, width, device, thresh=1e-4, use_graphs=True, lanes=2,
-                 flow_stream=True, lookahead=False, taps=False, batch=1, layout=None, segment=0, key_group=1, ramp=True):
+                 flow_stream=True, lookahead=False, taps=False, batch=1, layout=None, segment=0, key_group=1, ramp=False):
         """batch > 1: that many clips advance in lock-step — every tensor handed to first_frame / key_frame /
         cur_frame carries one image (motion-vector field, residual) per clip on its batch axis, and the
         detection buffers gain a leading clip axis.
@@ -522,9 +522,16 @@ class FramePipeline(object):
                       for g in range(2, self.key_group + 1)}
         self._bank_turn = 0
         self._bank_ready = []                        # [(bank, slot, data_ptr)]: fronts of upcoming key frames already computed
-        # ramp: while the pipeline is empty (the first key frames of a clip, or after flush() / join()) nothing overlaps a pass of
-        # key_group fronts and every lane waits for it: the first pass after that is one front, the second a group of two, then full groups
-        self.ramp = bool(ramp) and self.key_group > 2
+        # ramp (True = (1, 2)): while the pipeline is empty (the first key frames of a clip, or after flush() / join()) nothing overlaps a
+        # pass of key_group fronts and every lane waits for it: with a ramp the first pass after that is one front, the second a group of
+        # two, then full groups - the first detections arrive after 3 ms instead of 10.  Off by default since the end of r4: small passes
+        # cost 1.4-1.8x per frame what a pass of six does, and over a 20-interval region the ramp lost 4-6 % (3063 vs 3261 frames/s).
+        # (ramp may also be the tuple of those first pass sizes; $LSFA_RAMP = "2" / "1,2" / "" overrides it: lab)
+        steps = (1, 2) if ramp is True else tuple(int(v) for v in ramp) if ramp else ()
+        if os.environ.get('LSFA_RAMP') is not None:
+            steps = tuple(int(v) for v in os.environ['LSFA_RAMP'].split(',') if v.strip())
+        self.ramp_steps = tuple(min(max(v, 1), self.key_group) for v in steps) if self.key_group > 2 else ()
+        self.ramp = bool(self.ramp_steps)
         self._ramp_step = 0
         self.group_sizes = []                        # the sizes of the passes issued so far (diagnostics / tests)
         self._next_seg = 0
@@ -707,7 +714,7 @@ class FramePipeline(object):
         self._nkey += 1
         lane, s = self.klanes[b], self.s_key
         if bank is None:
-            cap = self.key_group if not self.ramp else (1, 2)[self._ramp_step] if self._ramp_step < 2 else self.key_group
+            cap = self.ramp_steps[self._ramp_step] if self._ramp_step < len(self.ramp_steps) else self.key_group
             self._ramp_step += 1
             g = min(cap, 1 + len(upcoming or ())) if self.banks else 1
             self.group_sizes.append(g)

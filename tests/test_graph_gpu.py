@@ -709,7 +709,7 @@ def test_pred_eval_pipelined_with_batched_passes(world):
     """pred_eval_pipelined(segment = interval - 1, key_group = 3) - the reference-shaped frame loop on the batched pipeline, the coming key
     frames' images obtained from the loader (TestLoader.upcoming_key_frames: the SAME tensors come back when the iteration reaches them) -
     over two videos of 14 frames at key interval 4 (three full segments, a short one before the video's last frame, which is a key frame
-    by the loader's rule; a ramp of 1, 2 and then 3 key fronts per pass): the same frame ids as the serial pred_eval, and its detections up
+    by the loader's rule; passes of up to 3 key fronts): the same frame ids as the serial pred_eval, and its detections up
     to the rounding of the convolutions' different K cuts - per (frame, class) the same number of rows wherever no score sits on the
     threshold, scores within 1e-4 (north_star's tolerance), boxes within 0.01 px."""
     from lsfa_amd.config.config import lsfa_test_config

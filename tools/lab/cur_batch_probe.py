@@ -1,7 +1,7 @@
 #!/usr/bin/env python
 """Lab: what a non-key frame costs when the B non-key frames of a segment (same key feature) go through the network in one pass, batch axis
 = frames (the reference's own batch test symbol does this: get_batch_test_symbol, resnet_v1_101_flownet_rfcn.py:661-751).  Each variant
-captured as one hipGraph (network + detection post-processing per image) and replayed alone."""
+captured as one hipGraph (network + lsfa_det_postprocess_batch) and replayed alone.  Argument: the batch sizes, e.g. 9,18,27."""
 import os
 import sys
 import torch
@@ -41,21 +41,18 @@ def graph_time(fn, n=20):
 
 
 feat = torch.randn(1, 1024, 38, 63, device=dev)
-for B in (1, 2, 3, 5, 9):
+for B in [int(v) for v in sys.argv[1].split(',')] if len(sys.argv) > 1 else (1, 2, 3, 5, 9):
     data = torch.rand(B, 3, H, W, device=dev) * 255
     im_info = torch.tensor([[H, W, 1.0]] * B, device=dev)
     mv = torch.randn(B, 2, 38, 63, device=dev) * 0.5
     res = torch.randn(B, 3, 38, 63, device=dev)
-    bufs = [(torch.zeros((ncls, R, 5), dtype=torch.float64, device=dev), torch.zeros(ncls, dtype=torch.int32, device=dev),
-             torch.full((ncls, R), -1, dtype=torch.int32, device=dev)) for _ in range(B)]
+    bufs = (torch.zeros((B, ncls, R, 5), dtype=torch.float64, device=dev), torch.zeros((B, ncls), dtype=torch.int32, device=dev),
+            torch.full((B, ncls, R), -1, dtype=torch.int32, device=dev))      # what core/graphs.py hands lsfa_det_postprocess_batch
 
     def frame():
         out = cur.forward(data=data, im_info=im_info, feat_key=feat, motion_vector=mv, res_diff=res)
-        bbox, cls = out['bbox_pred_reshape_output'].reshape(B * R, -1), out['cls_prob_reshape_output'].reshape(B * R, -1)
-        for b in range(B):
-            sl = slice(b * R, (b + 1) * R)
-            hip.det_postprocess(out['rois_output'][sl], bbox[sl], cls[sl], H, W, 1.0, nms_thresh=cfg.TEST.NMS, max_per_image=cfg.TEST.max_per_image,
-                                class_agnostic=cfg.CLASS_AGNOSTIC, out=bufs[b])
+        hip.det_postprocess_batch(out['rois_output'], out['bbox_pred_reshape_output'].reshape(B * R, -1), out['cls_prob_reshape_output'].reshape(B * R, -1),
+                                  B, H, W, 1.0, bufs, nms_thresh=cfg.TEST.NMS, max_per_image=cfg.TEST.max_per_image, class_agnostic=cfg.CLASS_AGNOSTIC)
         return out
 
     def small():

@@ -351,6 +351,10 @@ void ring_plan(SplitPlan& p, long P, int chunk_total, int Cout, int pieces) {
   if (f_k == 1) sp = false;
   if (f_k == 2) sp = true;
   int st = sp ? 3 : 2;
+  // the one-piece (bf16) form's 128 x 128 stage is 24 KB: two mixed-role workgroups per CU fit THREE stages each (144 KB), and the second
+  // chunk in flight is worth 10-28 % at six images (profiles/r4/conv_ring_lab_batch6_bf16.txt: res4 conv3 67.8 -> 48.9 us, res5 conv3
+  // 189 -> 141, res5 conv1 92 -> 79, the DCN contraction 187 -> 164); the 128 x 64 tiles and the two-piece form measured no better with it
+  if (!sp && pieces == 1 && nt == 4) st = 3;
   if (f_st) st = f_st;
   while (st > 2 && !ring_ok(nt, pieces, st)) --st;
   p.nt = nt; p.st = st; p.slices = s; p.per_slice = per; p.sp = sp;
@@ -536,6 +540,8 @@ int conv_split_prepare(convsplit::Args& a, int pieces, SplitPlan& p, long& P_out
     p.direct = true;
     p.slices = 1;
   }
+  // ... except with the input's activation table in LDS (16 KB more per workgroup: three stages would leave one workgroup per CU)
+  if (a.in_scale && !p.direct && !p.halo && !p.sp && pieces == 1 && p.nt == 4 && p.st == 3 && g_force_st.load() == 0) p.st = 2;
   a.part_stride = P * Cout;
   a.chunks_per_slice = p.per_slice;
   a.units_per_wg = a.max_pieces = 0;

@@ -277,6 +277,7 @@ struct SplitPlan {
   int nt;               // ring kernel: 32-channel column tiles per wave (2: 128 x 64 workgroup tiles, 4: 128 x 128)
   int st;               // ring kernel: stages of the LDS ring
   bool sp;              // ring kernel: split roles (512-thread workgroups: four loader waves + four consumer waves)
+  int wv;               // ring kernel: waves that multiply (4: 128-pixel tiles; 8: 256-pixel tiles, eight mixed-role waves)
   bool direct;          // conv_split_direct_kernel: operands straight into registers, a wave per 32 x 64 tile, no K slices
   bool halo;            // the 3x3 halo kernel (stride 1, pad = dilation 1 or 2), else the ring kernel
   int dil;
@@ -295,8 +296,10 @@ bool ring_ok(int nt, int pieces, int st) {
   if (st < 2 || st > 4 || (nt != 2 && nt != 4) || pieces < 1 || pieces > 3) return false;
   if ((nt * pieces) % 2) return false;
   if (nt == 4 && pieces == 3 && st == 4) return false;       // 160 KB exactly: no room for anything else
-  return ring_lds_bytes(nt, pieces, st) <= 160 * 1024 && (st - 2) * (4 + nt * pieces / 2) <= 63;
+  return ring_lds_bytes(nt, pieces, st) <= 160 * 1024 && (st - 1) * (4 + nt * pieces / 2) <= 63;
 }
+
+constexpr int kPlanDefault = 0;      // which r5 rules are on by default (bits of LSFA_CONV_PLAN_LAB)
 
 // The ring kernel's plan, from the sweeps of tools/lab/conv_ring_lab.py over the network's shapes (profiles/r4/conv_ring_lab.txt: every
 // tile width x ring depth x K cut x wave roles, hipGraph-timed):
@@ -307,7 +310,16 @@ bool ring_ok(int nt, int pieces, int st) {
 //   * 128 x 128 tiles when there are >= 512 output channels and >= 64 chunks of K (the A tile's cut and copies feed twice the MFMAs),
 //     128 x 64 otherwise (more tiles for the small maps of this network);
 //   * K slices: by a small cost model over rounds of resident workgroups (below).
+// r5: LSFA_CONV_PLAN_LAB (bit mask; in-situ A/B of the r5 variants against r4's plan, see profiles/r5/plan_ab.txt)
+static int plan_lab_from_env() {
+  const char* e = getenv("LSFA_CONV_PLAN_LAB");
+  return e ? atoi(e) : -1;
+}
+
 void ring_plan(SplitPlan& p, long P, int chunk_total, int Cout, int pieces) {
+  static const int lab_env = plan_lab_from_env();
+  const int lab = lab_env >= 0 ? lab_env : kPlanDefault;
+  p.wv = 4;
   const int f_nt = g_force_nt.load(), f_st = g_force_st.load(), f_s = g_force_slices.load(), f_k = g_force_kernel.load();
   p.nx = (int)((P + convsplit::kWgPix - 1) / convsplit::kWgPix);
   // 128 x 128 tiles: long K with >= 512 output channels (r4, one image), or - maps of several images, the batched pipeline - wherever the
@@ -348,8 +360,19 @@ void ring_plan(SplitPlan& p, long P, int chunk_total, int Cout, int pieces) {
   // and overlap each other better than one 512-thread workgroup's loader and consumer waves do (six images, conv_ring_lab_batch6.txt:
   // res5 shortcut 275 -> 257 us, res3 conv2 75 -> 67, res3 conv1 51 -> 44, feat_conv_3x3 1852 -> 1783; the DCN contraction 265 -> 270)
   if (s == 1 && nt == 4 && tiles4 >= 400) sp = false;
+  // r5 candidates, OFF by default (kPlanDefault): the isolated-layer sweeps (profiles/r5/conv_ring_lab_batch*.txt) favour loader / consumer
+  // waves everywhere and the 256 x 128 tiles for the wide short-K outputs, by 5-45 % per layer; IN the six-image backbone pass each of these
+  // rules costs 2-4 % (profiles/r5/plan_ab.txt: 9499 us with r4's plan, 9690 / 9855 / 9781 / 9795 with rule 1 / 2 / 1+2 / all) - a layer
+  // whose operands the previous layer left in L2 / the Infinity Cache, under the clocks of a 10 ms matrix-heavy pass, is not the layer
+  // the lab times back to back on rotating buffers.  The plan follows the in-situ numbers.
+  if ((lab & 2) && s == 1 && nt == 4 && tiles4 >= 400) sp = per >= 4;
+  if ((lab & 4) && s == 1 && per <= 16 && Cout >= 128 * chunk_total) sp = per >= 4;
+  // 256 x 128 tiles, eight mixed-role waves (r5): wide outputs, short or medium K, at least ~a wave of such tiles
+  const long tiles8 = ((P + 255) / 256) * (Cout / 128);
+  bool wv8 = (lab & 1) && s == 1 && pieces < 3 && Cout % 128 == 0 && Cout >= 1024 && chunk_total <= 72 && tiles8 >= 200 && f_k == 0 && f_nt == 0;
   if (f_k == 1) sp = false;
   if (f_k == 2) sp = true;
+  if (f_k == 4 && nt == 4 && pieces < 3) wv8 = true;
   int st = sp ? 3 : 2;
   // the one-piece (bf16) form's 128 x 128 stage is 24 KB: two mixed-role workgroups per CU fit THREE stages each (144 KB), and the second
   // chunk in flight is worth 10-28 % at six images (profiles/r4/conv_ring_lab_batch6_bf16.txt: res4 conv3 67.8 -> 48.9 us, res5 conv3
@@ -357,6 +380,7 @@ void ring_plan(SplitPlan& p, long P, int chunk_total, int Cout, int pieces) {
   if (!sp && pieces == 1 && nt == 4) st = 3;
   if (f_st) st = f_st;
   while (st > 2 && !ring_ok(nt, pieces, st)) --st;
+  if (wv8) { p.wv = 8; sp = false; nt = 4; st = (f_st == 2) ? 2 : 3; p.nx = (int)((P + 255) / 256); }
   p.nt = nt; p.st = st; p.slices = s; p.per_slice = per; p.sp = sp;
   p.ny = Cout / (32 * nt);
 }
@@ -438,6 +462,11 @@ int direct_waves(const convsplit::Args& a) {
   return nw < 1 ? 1 : nw;
 }
 
+template <int PC, int ST>
+void launch_ring8(const convsplit::Args& a, dim3 grid, hipStream_t s, int nx, int ny, int nz) {      // 256-pixel tiles: eight mixed-role waves
+  if (a.in_scale) hipLaunchKernelGGL((convsplit::conv_ring_kernel<4, PC, ST, false, true, 8>), grid, dim3(512), 0, s, a, nx, ny, nz);
+  else hipLaunchKernelGGL((convsplit::conv_ring_kernel<4, PC, ST, false, false, 8>), grid, dim3(512), 0, s, a, nx, ny, nz);
+}
 template <int NT, int PC, int ST>
 void launch_ring(bool sp, const convsplit::Args& a, dim3 grid, hipStream_t s, int nx, int ny, int nz) {
   if (a.in_scale) {      // the input's bn + ReLU applied at the cut (pieces 1 and 2: the frame path's two modes)
@@ -475,7 +504,7 @@ void launch_halo_direct(const SplitPlan& p, const convsplit::Args& a, dim3 grid,
 // LSFA_CONV_TILE_ORDER (lab): how workgroup ids map to (slice, channel tile, pixel tile), see xcd_tile
 static int tile_order_from_env() {
   const char* e = getenv("LSFA_CONV_TILE_ORDER");
-  return e ? atoi(e) : 0;
+  return e ? atoi(e) : 1;
 }
 
 // every split-operand convolution goes through here; the public entry points fill in what they expose
@@ -541,7 +570,7 @@ int conv_split_prepare(convsplit::Args& a, int pieces, SplitPlan& p, long& P_out
     p.slices = 1;
   }
   // ... except with the input's activation table in LDS (16 KB more per workgroup: three stages would leave one workgroup per CU)
-  if (a.in_scale && !p.direct && !p.halo && !p.sp && pieces == 1 && p.nt == 4 && p.st == 3 && g_force_st.load() == 0) p.st = 2;
+  if (a.in_scale && !p.direct && !p.halo && !p.sp && p.wv == 4 && pieces == 1 && p.nt == 4 && p.st == 3 && g_force_st.load() == 0) p.st = 2;
   a.part_stride = P * Cout;
   a.chunks_per_slice = p.per_slice;
   a.units_per_wg = a.max_pieces = 0;
@@ -585,10 +614,17 @@ int conv_split_launch(convsplit::Args a, int pieces, void* ws, size_t ws_bytes, 
     else if (pieces == 2) launch_halo_direct<2>(p, a, grid, s, P);
     else launch_halo_direct<1>(p, a, grid, s, P);
   } else {
+    if (p.wv == 8) {
+      if (pieces == 2 && p.st == 3) launch_ring8<2, 3>(a, grid, s, p.nx, p.ny, p.slices * nph);
+      else if (pieces == 2) launch_ring8<2, 2>(a, grid, s, p.nx, p.ny, p.slices * nph);
+      else if (p.st == 3) launch_ring8<1, 3>(a, grid, s, p.nx, p.ny, p.slices * nph);
+      else launch_ring8<1, 2>(a, grid, s, p.nx, p.ny, p.slices * nph);
+    } else {
     const bool ok = pieces == 3 ? launch_ring_pc<3>(p.nt, p.st, p.sp, a, grid, s, p.nx, p.ny, p.slices * nph)
                   : pieces == 2 ? launch_ring_pc<2>(p.nt, p.st, p.sp, a, grid, s, p.nx, p.ny, p.slices * nph)
                                 : launch_ring_pc<1>(p.nt, p.st, p.sp, a, grid, s, p.nx, p.ny, p.slices * nph);
     LSFA_REQUIRE(ok, "%s: no ring kernel for nt=%d st=%d pieces=%d", who, p.nt, p.st, pieces);
+    }
   }
   if (p.units_per_wg > 0) {
     hipLaunchKernelGGL(convsplit::conv_split3x3_fixup_kernel, dim3((unsigned)(p.nx * p.ny)), dim3(convsplit::kThreads), 0, s, a, p.patches_x,
@@ -622,8 +658,8 @@ convsplit::Args args_of(const lsfa_conv_desc& d) {
 }  // namespace
 
 extern "C" int lsfa_conv_plan_override(int kernel, int nt, int st, int slices) {
-  LSFA_REQUIRE(kernel >= 0 && kernel <= 3 && (nt == 0 || nt == 2 || nt == 4) && (st == 0 || (st >= 2 && st <= 4)) && slices >= 0 && slices <= 16,
-               "lsfa_conv_plan_override: kernel 0..3, nt 0/2/4, st 0/2..4, slices 0..16");
+  LSFA_REQUIRE(kernel >= 0 && kernel <= 4 && (nt == 0 || nt == 2 || nt == 4) && (st == 0 || (st >= 2 && st <= 4)) && slices >= 0 && slices <= 16,
+               "lsfa_conv_plan_override: kernel 0..4, nt 0/2/4, st 0/2..4, slices 0..16");
   g_force_kernel.store(kernel); g_force_nt.store(nt); g_force_st.store(st); g_force_slices.store(slices);
   return LSFA_OK;
 }

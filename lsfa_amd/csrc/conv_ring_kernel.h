@@ -1,30 +1,31 @@
-// r4: ONE general convolution / GEMM kernel for the split-operand family, templated on
+// ONE general convolution / GEMM kernel for the split-operand family, templated on
 //   PC  pieces per fp32 operand: 3 = three bf16 pieces, six products (conv_split_kernel.h's arithmetic);
 //                                2 = two fp16 pieces + a power-of-two scale per map, three products;
 //                                1 = one bf16 piece (round to nearest even), one product: the bf16 mode of BASELINE configs[2]
 //   NT  32-column accumulator tiles per wave (2: 128 x 64 workgroup tiles, 4: 128 x 128)
 //   ST  stages of the LDS ring (2 ... 4): ST - 1 chunks of K in flight per workgroup
-// It replaces conv_split_kernel (NT 2, ST 2), conv_split_deep_kernel (NT 2, ST 4) and conv_split_wide_kernel (NT 4, ST 2)
-// of rounds 2-3, which differed only in these three numbers, and adds what the small GEMMs of this network need:
-//   * a ring of any depth for every tile shape.  Most launches here are SHORT (a res4 conv1 is 32 chunks of K cut six ways:
-//     five or six chunks per workgroup, one workgroup per CU) and were latency-bound with one chunk in flight: each chunk's
-//     28-32 KB took ~1 us to arrive from L2 / the Infinity Cache while its MFMAs take 0.15-0.35 us.  With ST - 1 chunks in
-//     flight the arrival latency is paid once per workgroup, not once per chunk.
-//   * the maximum of |output| written by the EPILOGUE (`amax_out`: kAmaxSlots slots, atomicMax on the bit pattern of |v|,
-//     zeroed once per frame by the caller) so that the fp16 form's scale of the NEXT layer needs no pass of its own, and
-//   * a status word: a non-finite output (an under-estimated scale makes fp16(x s) overflow to inf) raises bit 0 of
-//     `status`, which the host reads with lsfa_status_check() - an overflow is an error, not a silently wrong feature.
-// Loop protocol (per chunk c, its data in stage c % ST): wait until at most min(ST - 2, chunks left) chunks' worth of this
-// wave's LDS-DMAs are outstanding (DMAs retire in issue order: counted `s_waitcnt vmcnt`), `lgkmcnt(0)`, raw `s_barrier` (every
-// wave's share of chunk c has landed and everybody has finished reading chunk c - 1's stage), issue chunk c + ST - 1 into that
-// stage, compute chunk c.  One barrier per chunk, all LDS addresses compile-time offsets of ONE __shared__ array (the loop is
-// unrolled over the stages), no register-returning vector load inside the loop (the scale is read before the first DMA by an
-// inline-asm load with its own wait), so hipcc emits no `vmcnt(0)` of its own.
+//   SP  split roles: waves 4-7 of a 512-thread workgroup issue the copies, waves 0-3 cut and multiply
+//   AF  the input's bn + ReLU applied where the operand is cut (Args::in_scale)
+//   WV  waves that multiply: 4 (128-pixel tiles) or 8 (r5: 256-pixel tiles, eight mixed-role waves, two per SIMD)
+// What the loop is made of (r4): a ring of ST stages filled by LDS-DMA (`global_load_lds_dwordx4`), counted `s_waitcnt vmcnt(N)` (DMAs
+// retire in issue order), one raw `s_barrier` per chunk, all LDS addresses compile-time offsets of ONE __shared__ array (the loop is
+// unrolled over the stages), no register-returning vector load inside the loop (the scale is read before the first DMA by an inline-asm
+// load with its own wait), so hipcc emits no `vmcnt(0)` of its own; the maximum of |output| written by the EPILOGUE (`amax_out`) and a
+// status word for non-finite outputs (an under-estimated scale).
 // TWO-LEVEL ACCUMULATION: an MFMA accumulator is one sequential fp32 chain (feat_conv_3x3: 192 chunks x 6 matrix instructions =
 // 1152 rounding steps per K slice), where a CPU library's blocked loops run ~100 short chains and add them at the end.  Measured
 // against the float64 graph that made the GPU path 2.2x as far off as the fp32 oracle (tests/test_parity_fullres_gpu.py, r4).
 // Every kFlush chunks the accumulators are therefore added into a second set and cleared: chains of <= kFlush x 2 x PC adds, then
 // <= ceil(chunks / kFlush) adds of the block sums - the error of a blocked summation, for 16 x NT vector adds per kFlush (= 12) chunks.
+// r5: TWO step forms.  The *pipelined* step (SP with NT = 4, and WV = 8) cuts chunk v + 1 under the matrix instructions of chunk v, the
+// order pinned with sched_group_barrier ("the cut of chunk v + 1 runs UNDER ..." below); every other instantiation keeps r4's step
+// ("r4's step, kept for ..." below).  Both compute the same products in the same order per accumulator: results are bit-identical across
+// every plan (tests/test_hip_ops.py::test_conv_ring_every_plan_gives_the_same_convolution).
+// What bounds the kernel (r5, profiles/r5/ring_ablation.txt, fill_lab.txt): with the copies switched off the six-image feat_conv_3x3 takes
+// 1272 us, with the arithmetic switched off 998, with both on 1643 (r4's step: 1758-1892); a CU takes in 32 KB per 128 x 128 x 32 chunk,
+// which the LDS-DMA path delivers at 45-75 GB/s per CU for this access pattern (120 from an L2-resident megabyte, 27 from the Infinity
+// Cache), against the 768 matrix cycles (0.41 us at the 1.88 GHz the part holds under this load) the chunk is worth: the two sides are
+// balanced within 25 %, and neither a deeper ring, tile order, wave priorities nor the pinned step move the sum by more than 5-8 %.
 #pragma once
 #include "conv_split_kernel.h"
 
@@ -33,17 +34,18 @@ namespace convsplit {
 
 constexpr int kFlush = 12;        // a multiple of every ring depth: the flush points do not depend on ST
 
-template <int NT, int PC, int ST> struct Ring {
+template <int NT, int PC, int ST, int WV = 4> struct Ring {     // WV: waves that multiply (4: 128-pixel tiles; 8: 256-pixel tiles, mixed roles only)
   static constexpr int kColTile = 128 * PC;                 // uint4 of one 32-column tile of one chunk: 2 steps x PC pieces x 64 lanes
+  static constexpr int kStageA = WV * 256;                  // uint4 of A per stage: WV waves x 32 pixels x 8 slots (4 KB per wave)
   static constexpr int kStageBn = NT * kColTile;
-  static constexpr int kStageN = kStageA + kStageBn;        // uint4 per stage: 16 KB of A + NT x PC x 2 KB of B
-  static constexpr int kDmaB = (NT * kColTile) / (4 * 64);  // B DMA instructions per wave and chunk: NT * PC / 2
+  static constexpr int kStageN = kStageA + kStageBn;        // uint4 per stage: 4 WV KB of A + NT x PC x 2 KB of B
+  static constexpr int kDmaB = (NT * kColTile) / (WV * 64); // B DMA instructions per wave and chunk: NT * PC / 2 (WV = 8: / 4)
   static constexpr int kDma = 4 + kDmaB;                    // all DMA instructions per wave and chunk
   static constexpr int kLdsBytes = ST * kStageN * 16;
   static constexpr int kWgPerCu = (2 * kLdsBytes <= 160 * 1024) ? 2 : 1;
-  static_assert((NT * kColTile) % 256 == 0, "NT * PC must be even");
+  static_assert((NT * kColTile) % (WV * 64) == 0, "NT * PC must be a multiple of WV / 2");
   static_assert(kLdsBytes <= 160 * 1024, "ring does not fit the CU's LDS");
-  static_assert((ST - 2) * kDma <= 63, "vmcnt is a 6-bit counter");
+  static_assert((ST - 1) * kDma <= 63, "vmcnt is a 6-bit counter");
 };
 
 // r4 (Args::in_scale): the 16 channels a lane cuts from chunk `gch` are 32 gch + 16 (lane >> 5) + 0..15 (r0..r3, four each).  T holds
@@ -62,33 +64,231 @@ __device__ __forceinline__ void affine_chunk(const float* T, int gch, int lane, 
   c3 = affine_relu4(c3, sc[3], sh[3]);
 }
 
-template <int NT, int PC, int ST, int S>
-__device__ __forceinline__ void ring_issue_a(uint4 (*R)[(Ring<NT, PC, ST>::kStageN)], const float* __restrict__ x, const Geom& g, const Walk& wk) {
+template <int NT, int PC, int ST, int WV, int S>
+__device__ __forceinline__ void ring_issue_a(uint4 (*R)[(Ring<NT, PC, ST, WV>::kStageN)], const float* __restrict__ x, const Geom& g, const Walk& wk, bool live) {
   const int dy = wk.ty * g.dil, dx = wk.tx * g.dil;
   const int doff = (dy * g.W + dx) * g.lda + wk.kc * kChunk;
+  const int dy_b = live ? dy : (1 << 26);                // not live: every row is out of bounds (a scalar select, no branch)
   uint4* a_dst = &R[S][g.wave * 256];
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
-    const bool ok = (unsigned)(g.iy0[i] + dy) < (unsigned)g.H && (unsigned)(g.ix0[i] + dx) < (unsigned)g.W;
+    const bool ok = (unsigned)(g.iy0[i] + dy_b) < (unsigned)g.H && (unsigned)(g.ix0[i] + dx) < (unsigned)g.W;
     const float* src = ok ? x + (g.off0[i] + doff) : g_zero_block;
     __builtin_amdgcn_global_load_lds(reinterpret_cast<const uint4*>(src), a_dst + i * 64, 16, 0, 0);
   }
 }
 
-template <int NT, int PC, int ST, int S, int I0, int I1>
-__device__ __forceinline__ void ring_issue_b(uint4 (*R)[(Ring<NT, PC, ST>::kStageN)], const uint4* __restrict__ wblock, const Geom& g, int gch) {
-  typedef Ring<NT, PC, ST> RG;
+template <int NT, int PC, int ST, int WV, int S, int I0, int I1>
+__device__ __forceinline__ void ring_issue_b(uint4 (*R)[(Ring<NT, PC, ST, WV>::kStageN)], const uint4* __restrict__ wblock, const Geom& g, int gch) {
+  typedef Ring<NT, PC, ST, WV> RG;
   const uint4* wsrc = wblock + (size_t)gch * g.wstride + g.wave * (RG::kDmaB * 64) + g.lane;
-  uint4* b_dst = &R[S][kStageA + g.wave * (RG::kDmaB * 64)];
+  uint4* b_dst = &R[S][RG::kStageA + g.wave * (RG::kDmaB * 64)];
 #pragma unroll
   for (int i = I0; i < I1; ++i) __builtin_amdgcn_global_load_lds(wsrc + i * 64, b_dst + i * 64, 16, 0, 0);
 }
 
+// ---- r5: the cut of chunk v + 1 runs UNDER the matrix instructions of chunk v ---------------------------------------------------------
+// r4's step was [barrier, read A, cut (64-112 vector instructions, ~300-450 cycles), then 8 groups of (2 B reads, wait, 3 MFMAs)]: the
+// matrix pipe idled during the cut and at the head of every group (an LDS round trip for 96 cycles of work): 17-35 % duty by PMC.  An MFMA
+// holds the SIMD's vector issue for 8 of its 32 cycles (MI355X_MICROARCH.md, cycle constants): the other 24 take ~5 plain vector
+// instructions and an LDS read for free.  So the ring's unit is now a *v-chunk*: stage v % ST holds the weights B(v) and the raw
+// activations A(v + 1).  Step v multiplies the pieces P(v) it holds in registers by B(v) and, between those MFMAs, reads A(v + 1) and
+// cuts it into P(v + 1); the B fragments are requested several MFMAs ahead of their use.  The order of instructions is pinned with
+// `sched_group_barrier` (MFMA, LDS read, k vector instructions, repeat).  A(0) arrives as v-chunk -1 (A only, in stage ST - 1) and is cut
+// before the loop; the last v-chunk's A half is filled from the block of zeros, so that every v-chunk is the same number of DMAs.  Same cut,
+// same MFMAs in the same order per accumulator as r4: bit-identical results.  One barrier more per workgroup (n + 1).
+struct Cut { PiecesN s0, s1; };
+
+// the vector instructions of one cut, for the interleave's arithmetic (fp16 pair: 2 mul, cvt_pk, 2 cvt back, 2 sub, cvt_pk; AF: mul, add, max per value)
+template <int PC, bool AF> struct CutCost { static constexpr int kValu = (PC == 2 ? 64 : PC == 3 ? 96 : 16) + (AF ? 48 : 0); };
+
+template <int NT, int PC, bool AF, int DMA = 0, int WV = 4> __device__ __forceinline__ void pin_interleave() {
+  if (PC == 3 && NT == 4) return;       // (three pieces on 128 x 128 tiles: the pinned order needs more than the 256 registers of two waves per SIMD)
+  constexpr int kMfma = NT * 2 * (PC == 3 ? 6 : PC == 2 ? 3 : 1);
+  constexpr int kPer = (CutCost<PC, AF>::kValu + (DMA ? 24 : 0) + kMfma - 1) / kMfma + 1;
+  // before the first MFMA: the first k-step's B fragments (PC reads), the raw A rows (4 reads; AF: + the table's 8) and the next
+  // k-step's fragments; from then on one read per MFMA slot, which keeps a fragment in flight for >= 3 slots (an LDS round trip is
+  // 64-128 cycles, a slot 32).  Mixed roles: the wave's DMAs of the v-chunk ST - 1 ahead go one per slot behind the first MFMAs.
+  __builtin_amdgcn_sched_group_barrier(0x100, ((PC == 3 || WV == 8) ? PC + 2 : 2 * PC + 4) + (AF ? 8 : 0), 0);      // (WV = 8: the SIMD's other wave covers the round trips; registers are short)
+#pragma unroll
+  for (int i = 0; i < kMfma; ++i) {
+    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+    if (i >= 1 && i <= DMA) __builtin_amdgcn_sched_group_barrier(0x010, 1, 0);
+    __builtin_amdgcn_sched_group_barrier(0x002, kPer, 0);
+  }
+}
+
+// one step's arithmetic: acc += P * B(v) (stage S), and raw A(v + 1) (same stage) -> its pieces.  The loads are written in the order
+// they are wanted back.  k-step 0 of every column tile first, then k-step 1 (per accumulator the order of the products is unchanged:
+// bit-identical), so that the first k-step's pieces die halfway through the step and the second half of the raw rows is read late: the
+// step's peak is ~16 registers lower, which is what lets the pinned order fit 256 registers where two waves share a SIMD.
+template <int NT, int PC, int ST, int WV, int S, bool AF, int DMA = 0>
+__device__ __forceinline__ Cut ring_mma_cut(const uint4 (*R)[(Ring<NT, PC, ST, WV>::kStageN)], const Geom& g, const Cut& p, f32x16 (&acc)[NT], float a_scale,
+                                            int gch_next, const float* T) {
+  const uint4* B = &R[S][Ring<NT, PC, ST, WV>::kStageA + g.lane];
+  const uint4* A = &R[S][g.wave * 256];
+  uint4 bf[NT * 2][PC];      // fragment (col tile t, step s, piece q) at ((t*2 + s)*PC + q)*64 + lane
+#pragma unroll
+  for (int q = 0; q < PC; ++q) bf[0][q] = B[q * 64];
+  const uint4 r0 = A[g.frag[0]], r1 = A[g.frag[1]];
+#pragma unroll
+  for (int t = 1; t < NT; ++t)
+#pragma unroll
+    for (int q = 0; q < PC; ++q) bf[t * 2][q] = B[((t * 2) * PC + q) * 64];
+  const uint4 r2 = A[g.frag[2]], r3 = A[g.frag[3]];
+#pragma unroll
+  for (int t = 0; t < NT; ++t)
+#pragma unroll
+    for (int q = 0; q < PC; ++q) bf[t * 2 + 1][q] = B[((t * 2 + 1) * PC + q) * 64];
+  float4 c0 = as_f4(r0), c1 = as_f4(r1), c2 = as_f4(r2), c3 = as_f4(r3);
+  if (AF) affine_chunk(T, min(gch_next, g.chunks_per_tap - 1), g.lane, c0, c1, c2, c3);
+  Cut n;
+  n.s0 = cut8<PC>(c0, c1, AF ? 1.f : a_scale);
+  n.s1 = cut8<PC>(c2, c3, AF ? 1.f : a_scale);
+#pragma unroll
+  for (int t = 0; t < NT; ++t) acc[t] = mma_pc<PC>(p.s0, bf[t * 2][0], bf[t * 2][PC > 1 ? 1 : 0], bf[t * 2][PC > 2 ? 2 : 0], acc[t]);
+#pragma unroll
+  for (int t = 0; t < NT; ++t) acc[t] = mma_pc<PC>(p.s1, bf[t * 2 + 1][0], bf[t * 2 + 1][PC > 1 ? 1 : 0], bf[t * 2 + 1][PC > 2 ? 2 : 0], acc[t]);
+  pin_interleave<NT, PC, AF, DMA, WV>();
+  return n;
+}
+
+// the first cut (A(0), v-chunk -1)
+template <int NT, int PC, int ST, int WV, int S, bool AF>
+__device__ __forceinline__ Cut ring_cut(const uint4 (*R)[(Ring<NT, PC, ST, WV>::kStageN)], const Geom& g, float a_scale, int gch, const float* T) {
+  const uint4* A = &R[S][g.wave * 256];
+  const uint4 r0 = A[g.frag[0]], r1 = A[g.frag[1]], r2 = A[g.frag[2]], r3 = A[g.frag[3]];
+  float4 c0 = as_f4(r0), c1 = as_f4(r1), c2 = as_f4(r2), c3 = as_f4(r3);
+  if (AF) affine_chunk(T, min(gch, g.chunks_per_tap - 1), g.lane, c0, c1, c2, c3);
+  Cut n;
+  n.s0 = cut8<PC>(c0, c1, AF ? 1.f : a_scale);
+  n.s1 = cut8<PC>(c2, c3, AF ? 1.f : a_scale);
+  return n;
+}
+
+// v-chunk v of n (B(v), A(v + 1)) in stage S = v % ST; mixed roles: this wave also issues its share of v-chunk v + ST - 1 (MORE), its
+// DMAs spread over the step's MFMA slots (a DMA issue is 60-100 cycles of the wave's stream: in a row they would be 500-800 idle ones)
+template <int NT, int PC, int ST, int WV, int S, bool AF, bool MORE>
+__device__ __forceinline__ void ring_step_body(uint4 (*R)[(Ring<NT, PC, ST, WV>::kStageN)], const float* __restrict__ x, const uint4* __restrict__ wblock,
+                                               const Geom& g, Walk& wk, int v, int n, f32x16 (&acc)[NT], Cut& p, float a_scale, const float* T) {
+  typedef Ring<NT, PC, ST, WV> RG;
+  constexpr int SN = (S + ST - 1) % ST;                 // the stage v-chunk v - 1 lived in: free once everybody is past the barrier
+  if (MORE) {
+    const Walk cur = wk;
+    wk.next(g.kw, g.chunks_per_tap);                    // (its branches first: the DMAs below share the MFMAs' scheduling region)
+    ring_issue_a<NT, PC, ST, WV, SN>(R, x, g, cur, v + ST < n);
+    ring_issue_b<NT, PC, ST, WV, SN, 0, RG::kDmaB>(R, wblock, g, g.chunk0 + v + ST - 1);
+  }
+  p = ring_mma_cut<NT, PC, ST, WV, S, AF, (MORE ? RG::kDma : 0)>(R, g, p, acc, a_scale, g.chunk0 + v + 1, T);
+}
+
+template <int NT, int PC, int ST, int WV, int S, bool AF>
+__device__ __forceinline__ void ring_step(uint4 (*R)[(Ring<NT, PC, ST, WV>::kStageN)], const float* __restrict__ x, const uint4* __restrict__ wblock,
+                                          const Geom& g, Walk& wk, int v, int n, f32x16 (&acc)[NT], Cut& p, float a_scale, const float* T) {
+  typedef Ring<NT, PC, ST, WV> RG;
+  // how many v-chunks beyond v this wave has already issued (they may stay in flight)
+  const int ahead = min(n - 1 - v, ST - 2);
+  if (ST >= 4 && ahead >= 2) wait_vmcnt<(ST >= 4 ? 2 : 0) * RG::kDma>();
+  else if (ST >= 3 && ahead == 1) wait_vmcnt<(ST >= 3 ? 1 : 0) * RG::kDma>();
+  else wait_vmcnt<0>();
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  if (v + ST - 1 < n) ring_step_body<NT, PC, ST, WV, S, AF, true>(R, x, wblock, g, wk, v, n, acc, p, a_scale, T);
+  else ring_step_body<NT, PC, ST, WV, S, AF, false>(R, x, wblock, g, wk, v, n, acc, p, a_scale, T);
+}
+
+// WV = 8 (256-pixel tiles, eight mixed-role waves, two per SIMD): ONE body per step - a second copy of the step for "nothing left to
+// fetch" doubles the accumulators' live ranges across the join (52 registers spilled at the 256 two waves per SIMD leave).  Every
+// step issues its DMAs; past the end they fetch the block of zeros / the slice's last weights again into a stage nobody reads (the kernel
+// drains them before the epilogue turns the ring into its staging area), so every wait is the same counted `vmcnt`.
+template <int NT, int PC, int ST, int WV, int S, bool AF>
+__device__ __forceinline__ void ring_step_uniform(uint4 (*R)[(Ring<NT, PC, ST, WV>::kStageN)], const float* __restrict__ x, const uint4* __restrict__ wblock,
+                                                  const Geom& g, Walk& wk, int v, int n, f32x16 (&acc)[NT], Cut& p, float a_scale, const float* T) {
+  typedef Ring<NT, PC, ST, WV> RG;
+  constexpr int SN = (S + ST - 1) % ST;
+  wait_vmcnt<(ST - 2) * RG::kDma>();
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  const Walk cur = wk;
+  wk.next(g.kw, g.chunks_per_tap);
+  ring_issue_a<NT, PC, ST, WV, SN>(R, x, g, cur, v + ST < n);
+  ring_issue_b<NT, PC, ST, WV, SN, 0, RG::kDmaB>(R, wblock, g, g.chunk0 + min(v + ST - 1, n - 1));
+  p = ring_mma_cut<NT, PC, ST, WV, S, AF, RG::kDma>(R, g, p, acc, a_scale, g.chunk0 + v + 1, T);
+}
+
+template <int NT, int PC, int ST, int WV, int S>
+__device__ __forceinline__ void ring_prologue_uniform(uint4 (*R)[(Ring<NT, PC, ST, WV>::kStageN)], const float* __restrict__ x, const uint4* __restrict__ wblock,
+                                                      const Geom& g, Walk& wk, int n) {
+  ring_issue_a<NT, PC, ST, WV, S>(R, x, g, wk, S + 1 < n);
+  ring_issue_b<NT, PC, ST, WV, S, 0, Ring<NT, PC, ST, WV>::kDmaB>(R, wblock, g, g.chunk0 + min(S, n - 1));
+  wk.next(g.kw, g.chunks_per_tap);
+}
+
+// ---- split roles (SP): waves 4-7 of a 512-thread workgroup issue the copies, waves 0-3 cut and multiply ------------------------------
+// Measured (rocprofv3 kernel trace, r4): a chunk costs a mixed-role wave ~1.3 us whatever the ring depth - its 6-8 LDS-DMA
+// instructions (~100 cycles of issue each), ~100 VALU instructions of cutting, 16 LDS reads and 12-24 MFMAs are ONE in-order
+// instruction stream, and the matrix pipe idles while the wave sits in a DMA issue.  With the copies issued by a partner wave on
+// the same SIMD the consumer's stream is LDS reads + cut + MFMAs only and the two streams overlap.  Same LDS image, same barrier
+// per chunk (all eight waves), same arithmetic: bit-identical results to the mixed-role form.
+template <int NT, int PC, int ST, int WV, int S>
+__device__ __forceinline__ void ring_load_step(uint4 (*R)[(Ring<NT, PC, ST, WV>::kStageN)], const float* __restrict__ x, const uint4* __restrict__ wblock,
+                                               const Geom& g, Walk& wk, int v, int n) {
+  typedef Ring<NT, PC, ST, WV> RG;
+  constexpr int SN = (S + ST - 1) % ST;
+  const int ahead = min(n - 1 - v, ST - 2);
+  if (ST >= 4 && ahead >= 2) wait_vmcnt<(ST >= 4 ? 2 : 0) * RG::kDma>();
+  else if (ST >= 3 && ahead == 1) wait_vmcnt<(ST >= 3 ? 1 : 0) * RG::kDma>();
+  else wait_vmcnt<0>();
+  __builtin_amdgcn_s_barrier();
+  if (v + ST - 1 < n) {
+    ring_issue_a<NT, PC, ST, WV, SN>(R, x, g, wk, v + ST < n);
+    ring_issue_b<NT, PC, ST, WV, SN, 0, RG::kDmaB>(R, wblock, g, g.chunk0 + v + ST - 1);
+    wk.next(g.kw, g.chunks_per_tap);
+  }
+}
+
+template <int NT, int PC, int ST, int WV, int S, bool AF>
+__device__ __forceinline__ void ring_consume_step(uint4 (*R)[(Ring<NT, PC, ST, WV>::kStageN)], const Geom& g, f32x16 (&acc)[NT], Cut& p, float a_scale, int v,
+                                                  const float* T) {
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  p = ring_mma_cut<NT, PC, ST, WV, S, AF>(R, g, p, acc, a_scale, g.chunk0 + v + 1, T);
+}
+
+// the prologue's v-chunks: -1 (A(0) alone, into stage ST - 1), then 0 .. ST - 2 (B(v) and A(v + 1))
+template <int NT, int PC, int ST, int WV, int S>
+__device__ __forceinline__ void ring_prologue(uint4 (*R)[(Ring<NT, PC, ST, WV>::kStageN)], const float* __restrict__ x, const uint4* __restrict__ wblock,
+                                              const Geom& g, Walk& wk, int n) {
+  if (S < n) {
+    ring_issue_a<NT, PC, ST, WV, S>(R, x, g, wk, S + 1 < n);
+    ring_issue_b<NT, PC, ST, WV, S, 0, Ring<NT, PC, ST, WV>::kDmaB>(R, wblock, g, g.chunk0 + S);
+    wk.next(g.kw, g.chunks_per_tap);
+  }
+}
+
+// everything of v-chunk -1 has landed once at most the DMAs of the v-chunks issued behind it are outstanding
+template <int NT, int PC, int ST, int WV>
+__device__ __forceinline__ void ring_wait_first(int n) {
+  typedef Ring<NT, PC, ST, WV> RG;
+  const int behind = min(n, ST - 1);
+  if (ST >= 4 && behind >= 3) wait_vmcnt<(ST >= 4 ? 3 : 0) * RG::kDma>();
+  else if (ST >= 3 && behind == 2) wait_vmcnt<(ST >= 3 ? 2 : 0) * RG::kDma>();
+  else if (behind == 1) wait_vmcnt<RG::kDma>();
+  else wait_vmcnt<0>();
+}
+
+// ---- r4's step, kept for the 128 x 64 tiles and for the mixed-role 128 x 128 ones -------------------------------------------------------
+// Two workgroups per CU (four waves per SIMD at NT = 2: 128 registers; two 256-thread mixed-role ones at NT = 4) overlap each other
+// better than one workgroup's pinned step does on these launches - measured IN the six-image backbone, not in the lab's back-to-back
+// repetitions of one layer: stage 2's conv2 84.7 vs 100.4 us, conv3 129.5 vs 150.6; res4 conv3 (mixed roles, two stages) 52.4 vs 58.3
+// on 256-pixel tiles - and the pipelined step needs 160 (NT = 2) / 230 (NT = 4) registers.  Here stage c % ST holds A(c) and B(c);
+// a step is [wait, barrier, read A, cut, multiply].
 // chunk c of n, its data in stage S = c % ST
 template <int NT, int PC, int ST, int S, bool AF>
-__device__ __forceinline__ void ring_step(uint4 (*R)[(Ring<NT, PC, ST>::kStageN)], const float* __restrict__ x, const uint4* __restrict__ wblock,
+__device__ __forceinline__ void ring_step_r4(uint4 (*R)[(Ring<NT, PC, ST, 4>::kStageN)], const float* __restrict__ x, const uint4* __restrict__ wblock,
                                           const Geom& g, Walk& wk, int c, int n, f32x16 (&acc)[NT], float a_scale, const float* T) {
-  typedef Ring<NT, PC, ST> RG;
+  typedef Ring<NT, PC, ST, 4> RG;
   constexpr int kDmaB = RG::kDmaB;
   constexpr int SN = (S + ST - 1) % ST;                 // the stage chunk c - 1 lived in: free once everybody is past the barrier
   // how many chunks beyond c this wave has already issued (they may stay in flight)
@@ -100,9 +300,9 @@ __device__ __forceinline__ void ring_step(uint4 (*R)[(Ring<NT, PC, ST>::kStageN)
   __builtin_amdgcn_s_barrier();
   const bool more = c + ST - 1 < n;
   const int gch_next = wk.gch;
-  if (more) ring_issue_a<NT, PC, ST, SN>(R, x, g, wk);
+  if (more) ring_issue_a<NT, PC, ST, 4, SN>(R, x, g, wk, true);
   const uint4* A = &R[S][g.wave * 256];
-  const uint4* B = &R[S][kStageA + g.lane];
+  const uint4* B = &R[S][Ring<NT, PC, ST, 4>::kStageA + g.lane];
   const uint4 r0 = A[g.frag[0]], r1 = A[g.frag[1]], r2 = A[g.frag[2]], r3 = A[g.frag[3]];
   float4 c0 = as_f4(r0), c1 = as_f4(r1), c2 = as_f4(r2), c3 = as_f4(r3);
   if (AF) affine_chunk(T, g.chunk0 + c, g.lane, c0, c1, c2, c3);
@@ -117,10 +317,10 @@ __device__ __forceinline__ void ring_step(uint4 (*R)[(Ring<NT, PC, ST>::kStageN)
       constexpr int kE0 = (kPer < kDmaB) ? kPer : kDmaB;
       constexpr int kE1 = (2 * kPer < kDmaB) ? 2 * kPer : kDmaB;
       constexpr int kE2 = (3 * kPer < kDmaB) ? 3 * kPer : kDmaB;
-      if (t == 0) ring_issue_b<NT, PC, ST, SN, 0, kE0>(R, wblock, g, gch_next);
-      if (NT > 1 && t == 1) ring_issue_b<NT, PC, ST, SN, kE0, (NT > 2 ? kE1 : kDmaB)>(R, wblock, g, gch_next);
-      if (NT > 2 && t == 2) ring_issue_b<NT, PC, ST, SN, kE1, (NT > 3 ? kE2 : kDmaB)>(R, wblock, g, gch_next);
-      if (NT > 3 && t == 3) ring_issue_b<NT, PC, ST, SN, kE2, kDmaB>(R, wblock, g, gch_next);
+      if (t == 0) ring_issue_b<NT, PC, ST, 4, SN, 0, kE0>(R, wblock, g, gch_next);
+      if (NT > 1 && t == 1) ring_issue_b<NT, PC, ST, 4, SN, kE0, (NT > 2 ? kE1 : kDmaB)>(R, wblock, g, gch_next);
+      if (NT > 2 && t == 2) ring_issue_b<NT, PC, ST, 4, SN, kE1, (NT > 3 ? kE2 : kDmaB)>(R, wblock, g, gch_next);
+      if (NT > 3 && t == 3) ring_issue_b<NT, PC, ST, 4, SN, kE2, kDmaB>(R, wblock, g, gch_next);
     }
   }
   if (more) wk.next(g.kw, g.chunks_per_tap);
@@ -133,9 +333,9 @@ __device__ __forceinline__ void ring_step(uint4 (*R)[(Ring<NT, PC, ST>::kStageN)
 // the same SIMD the consumer's stream is LDS reads + cut + MFMAs only and the two streams overlap.  Same LDS image, same barrier
 // per chunk (all eight waves), same arithmetic: bit-identical results to the mixed-role form.
 template <int NT, int PC, int ST, int S>
-__device__ __forceinline__ void ring_load_step(uint4 (*R)[(Ring<NT, PC, ST>::kStageN)], const float* __restrict__ x, const uint4* __restrict__ wblock,
+__device__ __forceinline__ void ring_load_step_r4(uint4 (*R)[(Ring<NT, PC, ST, 4>::kStageN)], const float* __restrict__ x, const uint4* __restrict__ wblock,
                                                const Geom& g, Walk& wk, int c, int n) {
-  typedef Ring<NT, PC, ST> RG;
+  typedef Ring<NT, PC, ST, 4> RG;
   constexpr int SN = (S + ST - 1) % ST;
   const int ahead = min(n - 1 - c, ST - 2);
   if (ST >= 4 && ahead >= 2) wait_vmcnt<(ST >= 4 ? 2 : 0) * RG::kDma>();
@@ -143,19 +343,19 @@ __device__ __forceinline__ void ring_load_step(uint4 (*R)[(Ring<NT, PC, ST>::kSt
   else wait_vmcnt<0>();
   __builtin_amdgcn_s_barrier();
   if (c + ST - 1 < n) {
-    ring_issue_a<NT, PC, ST, SN>(R, x, g, wk);
-    ring_issue_b<NT, PC, ST, SN, 0, RG::kDmaB>(R, wblock, g, wk.gch);
+    ring_issue_a<NT, PC, ST, 4, SN>(R, x, g, wk, true);
+    ring_issue_b<NT, PC, ST, 4, SN, 0, RG::kDmaB>(R, wblock, g, wk.gch);
     wk.next(g.kw, g.chunks_per_tap);
   }
 }
 
 template <int NT, int PC, int ST, int S, bool AF>
-__device__ __forceinline__ void ring_consume_step(uint4 (*R)[(Ring<NT, PC, ST>::kStageN)], const Geom& g, f32x16 (&acc)[NT], float a_scale, int c,
+__device__ __forceinline__ void ring_consume_step_r4(uint4 (*R)[(Ring<NT, PC, ST, 4>::kStageN)], const Geom& g, f32x16 (&acc)[NT], float a_scale, int c,
                                                   const float* T) {
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
   const uint4* A = &R[S][g.wave * 256];
-  const uint4* B = &R[S][kStageA + g.lane];
+  const uint4* B = &R[S][Ring<NT, PC, ST, 4>::kStageA + g.lane];
   const uint4 r0 = A[g.frag[0]], r1 = A[g.frag[1]], r2 = A[g.frag[2]], r3 = A[g.frag[3]];
   float4 c0 = as_f4(r0), c1 = as_f4(r1), c2 = as_f4(r2), c3 = as_f4(r3);
   if (AF) affine_chunk(T, g.chunk0 + c, g.lane, c0, c1, c2, c3);
@@ -168,23 +368,24 @@ __device__ __forceinline__ void ring_consume_step(uint4 (*R)[(Ring<NT, PC, ST>::
 }
 
 template <int NT, int PC, int ST, int S>
-__device__ __forceinline__ void ring_prologue(uint4 (*R)[(Ring<NT, PC, ST>::kStageN)], const float* __restrict__ x, const uint4* __restrict__ wblock,
+__device__ __forceinline__ void ring_prologue_r4(uint4 (*R)[(Ring<NT, PC, ST, 4>::kStageN)], const float* __restrict__ x, const uint4* __restrict__ wblock,
                                               const Geom& g, Walk& wk, int n) {
   if (S < n) {
-    ring_issue_a<NT, PC, ST, S>(R, x, g, wk);
-    ring_issue_b<NT, PC, ST, S, 0, Ring<NT, PC, ST>::kDmaB>(R, wblock, g, wk.gch);
+    ring_issue_a<NT, PC, ST, 4, S>(R, x, g, wk, true);
+    ring_issue_b<NT, PC, ST, 4, S, 0, Ring<NT, PC, ST, 4>::kDmaB>(R, wblock, g, wk.gch);
     wk.next(g.kw, g.chunks_per_tap);
   }
 }
 
 // grid (8 * ceil(tiles / 8)); block 256 (SP: 512).  tiles = ceil(P / 128) * (Cout / (32 * NT)) * slices (* phases)
 // AF: Args::in_scale / in_shift are applied to the input where it is cut (their table, 16 KB, sits in LDS behind the ring)
-template <int NT, int PC, int ST, bool SP = false, bool AF = false>
-// (two resident workgroups only where their registers allow it: a 128 x 128 tile with loader waves needs ~200 per lane, which two 512-thread
-// workgroups per CU - four waves per SIMD, 128 registers - could only have by spilling 100-270 of them)
-static __global__ __launch_bounds__((SP ? 2 : 1) * kThreads, (((AF ? 2 * (Ring<NT, PC, ST>::kLdsBytes + 16384) <= 160 * 1024 : Ring<NT, PC, ST>::kWgPerCu == 2) && !(SP && NT == 4)) ? 2 : 1) * (SP ? 2 : 1))
+// WV = 8: 256-pixel tiles, eight mixed-role waves (block 512); tiles = ceil(P / 256) * ...
+template <int NT, int PC, int ST, bool SP = false, bool AF = false, int WV = 4>
+// (two resident workgroups only where their registers allow it: a 128 x 128 tile with loader waves needs ~230 per lane; WV = 8: 512 threads, 256 registers)
+static __global__ __launch_bounds__((SP || WV == 8 ? 2 : 1) * kThreads,
+    WV == 8 ? 2 : (((AF ? 2 * (Ring<NT, PC, ST, WV>::kLdsBytes + 16384) <= 160 * 1024 : Ring<NT, PC, ST, WV>::kWgPerCu == 2) && !(SP && NT == 4)) ? 2 : 1) * (SP ? 2 : 1))
 void conv_ring_kernel(Args a, int nx, int ny, int nz) {
-  typedef Ring<NT, PC, ST> RG;
+  typedef Ring<NT, PC, ST, WV> RG;
   __shared__ __attribute__((aligned(16))) uint4 R[ST][RG::kStageN];
   __shared__ __attribute__((aligned(16))) float T[AF ? 2 * kAffineMaxCin : 4];
   Tile tile = xcd_tile(blockIdx.x, nx, ny, nz, a.tile_order, a.inv_nx, a.inv_ny);
@@ -192,13 +393,16 @@ void conv_ring_kernel(Args a, int nx, int ny, int nz) {
   if (a.nphase > 1) { const int slices = nz / a.nphase, phase = tile.z / slices; tile.z -= phase * slices; apply_phase(a, phase, slices); }
   const int tid = threadIdx.x;
   const int P = a.N * a.Ho * a.Wo;
-  if (tile.x * kWgPix >= P) return;
+  static_assert(!(SP && WV != 4), "loader / consumer waves exist for 128-pixel tiles only");
+  constexpr int kPix = 32 * WV;                          // pixels of a workgroup's tile
+  constexpr bool kPipelined = (SP && NT == 4) || WV == 8;      // the r5 step: 128 x 128 tiles with loader / consumer waves, 256 x 128 tiles; the rest keep r4's
+  if (tile.x * kPix >= P) return;
   const int taps = a.kh * a.kw;
   Geom g;
   g.lane = tid & 63;
   const int wave8 = __builtin_amdgcn_readfirstlane(tid >> 6);
   const bool loader = SP && wave8 >= 4;                 // wave-uniform role
-  g.wave = wave8 & 3;                                    // the consumer wave whose rows / share of B this wave reads or copies
+  g.wave = WV == 8 ? wave8 : (wave8 & 3);                // the consumer wave whose rows / share of B this wave reads or copies
   // fp16 form: the scale that puts max|x| into [2^13, 2^14), and its inverse together with the weights' (both powers of two: exact)
   float a_scale = 1.f, out_scale = 1.f;
   if (PC == 2 && !loader) {
@@ -207,7 +411,7 @@ void conv_ring_kernel(Args a, int nx, int ny, int nz) {
     out_scale = ldexpf(1.f, -(s_exp + a.w_exp));
   }
   if (AF && !loader) {      // visible to every consumer after the first chunk's barrier (which an lgkmcnt(0) precedes)
-    for (int k = tid; k < a.Cin; k += kThreads) { T[k] = a.in_scale[k] * a_scale; T[kAffineMaxCin + k] = a.in_shift[k] * a_scale; }
+    for (int k = tid; k < a.Cin; k += 64 * WV) { T[k] = a.in_scale[k] * a_scale; T[kAffineMaxCin + k] = a.in_shift[k] * a_scale; }
   }
   g.H = a.H; g.W = a.W; g.Cin = a.Cin; g.lda = a.lda; g.kw = a.kw; g.stride = a.stride; g.dil = a.dil;
   g.chunks_per_tap = a.Cin / kChunk;
@@ -217,7 +421,7 @@ void conv_ring_kernel(Args a, int nx, int ny, int nz) {
   const int col_tiles = a.Cout / 32;
   g.wstride = (size_t)col_tiles * RG::kColTile;
   const uint4* wblock = a.wfrag + (size_t)(NT * tile.y) * RG::kColTile;
-  const int m0 = tile.x * kWgPix + g.wave * kWavePix;
+  const int m0 = tile.x * kPix + g.wave * kWavePix;
   // DMA role: instruction i moves pixels 8i .. 8i+7 of the wave's tile, lane -> pixel 8i + (lane >> 3), slot lane & 7
   if (!SP || loader) {
 #pragma unroll
@@ -245,7 +449,7 @@ void conv_ring_kernel(Args a, int nx, int ny, int nz) {
 #pragma unroll
     for (int i = 0; i < 16; ++i) acc[t][i] = 0.f;
 
-  Walk wk;       // the next chunk to fetch
+  Walk wk;       // the next chunk whose A is to be fetched
   wk.gch = g.chunk0;
   {
     const int tap = fdiv(g.chunk0, g.chunks_per_tap, a.inv_cpt);
@@ -258,46 +462,113 @@ void conv_ring_kernel(Args a, int nx, int ny, int nz) {
   for (int t = 0; t < NT; ++t)
 #pragma unroll
     for (int i = 0; i < 16; ++i) sum[t][i] = 0.f;
-  if (SP) {
-    if (loader) {
-      // prologue: chunks 0 .. ST-2 into stages 0 .. ST-2, then one step per chunk: wait for chunk c, meet, refill the stage chunk c - 1 left
-      ring_prologue<NT, PC, ST, 0>(R, a.x, wblock, g, wk, nchunks);
-      if (ST > 2) ring_prologue<NT, PC, ST, (ST > 2 ? 1 : 0)>(R, a.x, wblock, g, wk, nchunks);
-      if (ST > 3) ring_prologue<NT, PC, ST, (ST > 3 ? 2 : 0)>(R, a.x, wblock, g, wk, nchunks);
-      for (int c = 0; c < nchunks; c += ST) {
-        ring_load_step<NT, PC, ST, 0>(R, a.x, wblock, g, wk, c, nchunks);
-        if (c + 1 < nchunks) ring_load_step<NT, PC, ST, 1>(R, a.x, wblock, g, wk, c + 1, nchunks);
-        if (ST > 2 && c + 2 < nchunks) ring_load_step<NT, PC, ST, (ST > 2 ? 2 : 0)>(R, a.x, wblock, g, wk, c + 2, nchunks);
-        if (ST > 3 && c + 3 < nchunks) ring_load_step<NT, PC, ST, (ST > 3 ? 3 : 0)>(R, a.x, wblock, g, wk, c + 3, nchunks);
+  if constexpr (!kPipelined) {
+    if (SP) {
+      if (loader) {
+        // prologue: chunks 0 .. ST-2 into stages 0 .. ST-2, then one step per chunk: wait for chunk c, meet, refill the stage chunk c - 1 left
+        ring_prologue_r4<NT, PC, ST, 0>(R, a.x, wblock, g, wk, nchunks);
+        if (ST > 2) ring_prologue_r4<NT, PC, ST, (ST > 2 ? 1 : 0)>(R, a.x, wblock, g, wk, nchunks);
+        if (ST > 3) ring_prologue_r4<NT, PC, ST, (ST > 3 ? 2 : 0)>(R, a.x, wblock, g, wk, nchunks);
+        for (int c = 0; c < nchunks; c += ST) {
+          ring_load_step_r4<NT, PC, ST, 0>(R, a.x, wblock, g, wk, c, nchunks);
+          if (c + 1 < nchunks) ring_load_step_r4<NT, PC, ST, 1>(R, a.x, wblock, g, wk, c + 1, nchunks);
+          if (ST > 2 && c + 2 < nchunks) ring_load_step_r4<NT, PC, ST, (ST > 2 ? 2 : 0)>(R, a.x, wblock, g, wk, c + 2, nchunks);
+          if (ST > 3 && c + 3 < nchunks) ring_load_step_r4<NT, PC, ST, (ST > 3 ? 3 : 0)>(R, a.x, wblock, g, wk, c + 3, nchunks);
+        }
+        return;                 // the epilogue is the consumers'
       }
-      return;                 // the epilogue is the consumers'
-    }
-    int since = 0;
-    for (int c = 0; c < nchunks; c += ST) {
-      ring_consume_step<NT, PC, ST, 0, AF>(R, g, acc, a_scale, c, T);
-      if (c + 1 < nchunks) ring_consume_step<NT, PC, ST, 1, AF>(R, g, acc, a_scale, c + 1, T);
-      if (ST > 2 && c + 2 < nchunks) ring_consume_step<NT, PC, ST, (ST > 2 ? 2 : 0), AF>(R, g, acc, a_scale, c + 2, T);
-      if (ST > 3 && c + 3 < nchunks) ring_consume_step<NT, PC, ST, (ST > 3 ? 3 : 0), AF>(R, g, acc, a_scale, c + 3, T);
-      since += ST;
-      if (since >= kFlush) {
-        since = 0;
-#pragma unroll
-        for (int t = 0; t < NT; ++t)
-#pragma unroll
-          for (int i = 0; i < 16; ++i) { sum[t][i] = sum[t][i] + acc[t][i]; acc[t][i] = 0.f; }
+      int since = 0;
+      for (int c = 0; c < nchunks; c += ST) {
+        ring_consume_step_r4<NT, PC, ST, 0, AF>(R, g, acc, a_scale, c, T);
+        if (c + 1 < nchunks) ring_consume_step_r4<NT, PC, ST, 1, AF>(R, g, acc, a_scale, c + 1, T);
+        if (ST > 2 && c + 2 < nchunks) ring_consume_step_r4<NT, PC, ST, (ST > 2 ? 2 : 0), AF>(R, g, acc, a_scale, c + 2, T);
+        if (ST > 3 && c + 3 < nchunks) ring_consume_step_r4<NT, PC, ST, (ST > 3 ? 3 : 0), AF>(R, g, acc, a_scale, c + 3, T);
+        since += ST;
+        if (since >= kFlush) {
+          since = 0;
+  #pragma unroll
+          for (int t = 0; t < NT; ++t)
+  #pragma unroll
+            for (int i = 0; i < 16; ++i) { sum[t][i] = sum[t][i] + acc[t][i]; acc[t][i] = 0.f; }
+        }
+      }
+    } else {
+      // prologue: chunks 0 .. ST-2 into stages 0 .. ST-2
+      ring_prologue_r4<NT, PC, ST, 0>(R, a.x, wblock, g, wk, nchunks);
+      if (ST > 2) ring_prologue_r4<NT, PC, ST, (ST > 2 ? 1 : 0)>(R, a.x, wblock, g, wk, nchunks);
+      if (ST > 3) ring_prologue_r4<NT, PC, ST, (ST > 3 ? 2 : 0)>(R, a.x, wblock, g, wk, nchunks);
+      int since = 0;
+      for (int c = 0; c < nchunks; c += ST) {
+        ring_step_r4<NT, PC, ST, 0, AF>(R, a.x, wblock, g, wk, c, nchunks, acc, a_scale, T);
+        if (c + 1 < nchunks) ring_step_r4<NT, PC, ST, 1, AF>(R, a.x, wblock, g, wk, c + 1, nchunks, acc, a_scale, T);
+        if (ST > 2 && c + 2 < nchunks) ring_step_r4<NT, PC, ST, (ST > 2 ? 2 : 0), AF>(R, a.x, wblock, g, wk, c + 2, nchunks, acc, a_scale, T);
+        if (ST > 3 && c + 3 < nchunks) ring_step_r4<NT, PC, ST, (ST > 3 ? 3 : 0), AF>(R, a.x, wblock, g, wk, c + 3, nchunks, acc, a_scale, T);
+        since += ST;
+        if (since >= kFlush) {
+          since = 0;
+  #pragma unroll
+          for (int t = 0; t < NT; ++t)
+  #pragma unroll
+            for (int i = 0; i < 16; ++i) { sum[t][i] = sum[t][i] + acc[t][i]; acc[t][i] = 0.f; }
+        }
       }
     }
   } else {
-    // prologue: chunks 0 .. ST-2 into stages 0 .. ST-2
-    ring_prologue<NT, PC, ST, 0>(R, a.x, wblock, g, wk, nchunks);
-    if (ST > 2) ring_prologue<NT, PC, ST, (ST > 2 ? 1 : 0)>(R, a.x, wblock, g, wk, nchunks);
-    if (ST > 3) ring_prologue<NT, PC, ST, (ST > 3 ? 2 : 0)>(R, a.x, wblock, g, wk, nchunks);
+  if (SP && loader) {
+    // v-chunk -1 (A(0) alone) into stage ST - 1, v-chunks 0 .. ST-2 into stages 0 .. ST-2, then one step per v-chunk: wait for it, meet,
+    // refill the stage v-chunk v - 1 left
+    ring_issue_a<NT, PC, ST, WV, ST - 1>(R, a.x, g, wk, true);
+    wk.next(g.kw, g.chunks_per_tap);
+    ring_prologue<NT, PC, ST, WV, 0>(R, a.x, wblock, g, wk, nchunks);
+    if (ST > 2) ring_prologue<NT, PC, ST, WV, (ST > 2 ? 1 : 0)>(R, a.x, wblock, g, wk, nchunks);
+    if (ST > 3) ring_prologue<NT, PC, ST, WV, (ST > 3 ? 2 : 0)>(R, a.x, wblock, g, wk, nchunks);
+    ring_wait_first<NT, PC, ST, WV>(nchunks);
+    __builtin_amdgcn_s_barrier();
+    for (int c = 0; c < nchunks; c += ST) {
+      ring_load_step<NT, PC, ST, WV, 0>(R, a.x, wblock, g, wk, c, nchunks);
+      if (c + 1 < nchunks) ring_load_step<NT, PC, ST, WV, 1>(R, a.x, wblock, g, wk, c + 1, nchunks);
+      if (ST > 2 && c + 2 < nchunks) ring_load_step<NT, PC, ST, WV, (ST > 2 ? 2 : 0)>(R, a.x, wblock, g, wk, c + 2, nchunks);
+      if (ST > 3 && c + 3 < nchunks) ring_load_step<NT, PC, ST, WV, (ST > 3 ? 3 : 0)>(R, a.x, wblock, g, wk, c + 3, nchunks);
+    }
+    return;                 // the epilogue is the consumers'
+  }
+  if (!SP && WV == 8) {
+    ring_issue_a<NT, PC, ST, WV, ST - 1>(R, a.x, g, wk, true);
+    wk.next(g.kw, g.chunks_per_tap);
+    ring_prologue_uniform<NT, PC, ST, WV, 0>(R, a.x, wblock, g, wk, nchunks);
+    if (ST > 2) ring_prologue_uniform<NT, PC, ST, WV, (ST > 2 ? 1 : 0)>(R, a.x, wblock, g, wk, nchunks);
+    if (ST > 3) ring_prologue_uniform<NT, PC, ST, WV, (ST > 3 ? 2 : 0)>(R, a.x, wblock, g, wk, nchunks);
+    wait_vmcnt<(ST - 1) * RG::kDma>();
+  } else if (!SP) {
+    ring_issue_a<NT, PC, ST, WV, ST - 1>(R, a.x, g, wk, true);
+    wk.next(g.kw, g.chunks_per_tap);
+    ring_prologue<NT, PC, ST, WV, 0>(R, a.x, wblock, g, wk, nchunks);
+    if (ST > 2) ring_prologue<NT, PC, ST, WV, (ST > 2 ? 1 : 0)>(R, a.x, wblock, g, wk, nchunks);
+    if (ST > 3) ring_prologue<NT, PC, ST, WV, (ST > 3 ? 2 : 0)>(R, a.x, wblock, g, wk, nchunks);
+    ring_wait_first<NT, PC, ST, WV>(nchunks);
+  }
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       // AF: this wave's share of the table is written
+  __builtin_amdgcn_s_barrier();                            // v-chunk -1 has landed
+  Cut p = ring_cut<NT, PC, ST, WV, ST - 1, AF>(R, g, a_scale, g.chunk0, T);
+  {
     int since = 0;
     for (int c = 0; c < nchunks; c += ST) {
-      ring_step<NT, PC, ST, 0, AF>(R, a.x, wblock, g, wk, c, nchunks, acc, a_scale, T);
-      if (c + 1 < nchunks) ring_step<NT, PC, ST, 1, AF>(R, a.x, wblock, g, wk, c + 1, nchunks, acc, a_scale, T);
-      if (ST > 2 && c + 2 < nchunks) ring_step<NT, PC, ST, (ST > 2 ? 2 : 0), AF>(R, a.x, wblock, g, wk, c + 2, nchunks, acc, a_scale, T);
-      if (ST > 3 && c + 3 < nchunks) ring_step<NT, PC, ST, (ST > 3 ? 3 : 0), AF>(R, a.x, wblock, g, wk, c + 3, nchunks, acc, a_scale, T);
+      if (SP) {
+        ring_consume_step<NT, PC, ST, WV, 0, AF>(R, g, acc, p, a_scale, c, T);
+        if (c + 1 < nchunks) ring_consume_step<NT, PC, ST, WV, 1, AF>(R, g, acc, p, a_scale, c + 1, T);
+        if (ST > 2 && c + 2 < nchunks) ring_consume_step<NT, PC, ST, WV, (ST > 2 ? 2 : 0), AF>(R, g, acc, p, a_scale, c + 2, T);
+        if (ST > 3 && c + 3 < nchunks) ring_consume_step<NT, PC, ST, WV, (ST > 3 ? 3 : 0), AF>(R, g, acc, p, a_scale, c + 3, T);
+      } else if (WV == 8) {
+        ring_step_uniform<NT, PC, ST, WV, 0, AF>(R, a.x, wblock, g, wk, c, nchunks, acc, p, a_scale, T);
+        if (c + 1 < nchunks) ring_step_uniform<NT, PC, ST, WV, 1, AF>(R, a.x, wblock, g, wk, c + 1, nchunks, acc, p, a_scale, T);
+        if (ST > 2 && c + 2 < nchunks) ring_step_uniform<NT, PC, ST, WV, (ST > 2 ? 2 : 0), AF>(R, a.x, wblock, g, wk, c + 2, nchunks, acc, p, a_scale, T);
+        if (ST > 3 && c + 3 < nchunks) ring_step_uniform<NT, PC, ST, WV, (ST > 3 ? 3 : 0), AF>(R, a.x, wblock, g, wk, c + 3, nchunks, acc, p, a_scale, T);
+      } else {
+        ring_step<NT, PC, ST, WV, 0, AF>(R, a.x, wblock, g, wk, c, nchunks, acc, p, a_scale, T);
+        if (c + 1 < nchunks) ring_step<NT, PC, ST, WV, 1, AF>(R, a.x, wblock, g, wk, c + 1, nchunks, acc, p, a_scale, T);
+        if (ST > 2 && c + 2 < nchunks) ring_step<NT, PC, ST, WV, (ST > 2 ? 2 : 0), AF>(R, a.x, wblock, g, wk, c + 2, nchunks, acc, p, a_scale, T);
+        if (ST > 3 && c + 3 < nchunks) ring_step<NT, PC, ST, WV, (ST > 3 ? 3 : 0), AF>(R, a.x, wblock, g, wk, c + 3, nchunks, acc, p, a_scale, T);
+      }
       since += ST;
       if (since >= kFlush) {
         since = 0;
@@ -308,6 +579,7 @@ void conv_ring_kernel(Args a, int nx, int ny, int nz) {
       }
     }
   }
+  }      // kPipelined
 #pragma unroll
   for (int t = 0; t < NT; ++t)
 #pragma unroll
@@ -320,7 +592,8 @@ void conv_ring_kernel(Args a, int nx, int ny, int nz) {
   // The ring is free once every wave is past its last chunk: each wave writes its NT 32 x 32 tiles row-major into a private 4 KB x NT
   // region and reads them back as float4 along the channels - lane -> (row 8k + lane / 8, channels 4 (lane % 8) ..): whole 128-byte
   // rows per 8 lanes, 16 bytes per lane, a quarter of the memory instructions.  Same values, same arithmetic per element.
-  constexpr bool kRowsFit = RG::kLdsBytes >= 4 * NT * 4096;       // the ring holds the four waves' tiles
+  if (WV == 8) wait_vmcnt<0>();      // the copies issued past the end must have landed before the ring becomes the epilogue's staging area
+  constexpr bool kRowsFit = RG::kLdsBytes >= WV * NT * 4096;       // the ring holds the waves' tiles
   const bool rows_ok = kRowsFit && rows_path_ok(a);
   if (rows_ok) {
     float* part = a.part ? a.part + (size_t)tile.z * P * a.Cout : nullptr;
@@ -334,10 +607,10 @@ void conv_ring_kernel(Args a, int nx, int ny, int nz) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) T[t * 1024 + ((r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)) * 32 + (lane & 31)] = acc[t][r];
     const uint32_t m = tile_rows_out<NT>(a, T, m0, P, tile.y * (32 * NT), part, lane, in);
-    if (!part) publish_amax(m, a.amax_out, a.status, blockIdx.x * 4 + g.wave);
+    if (!part) publish_amax(m, a.amax_out, a.status, blockIdx.x * WV + g.wave);
     return;
   }
-  constexpr bool kColsFit = RG::kLdsBytes >= 4 * NT * 32 * kColPitch * 4;       // ... or their padded column-major images
+  constexpr bool kColsFit = RG::kLdsBytes >= WV * NT * 32 * kColPitch * 4;       // ... or their padded column-major images
   if (kColsFit && a.y_nchw && !a.part && !a.view) {
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();                       // every wave is done reading the ring
@@ -348,7 +621,7 @@ void conv_ring_kernel(Args a, int nx, int ny, int nz) {
       for (int r = 0; r < 16; ++r) Tc[(t * 32 + (lane & 31)) * kColPitch + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)] = acc[t][r];
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       // the wave reads back what its own lanes wrote
     const uint32_t m = tile_cols_out_nchw<NT>(a, Tc, m0, P, tile.y * (32 * NT), lane);
-    publish_amax(m, a.amax_out, a.status, blockIdx.x * 4 + g.wave);
+    publish_amax(m, a.amax_out, a.status, blockIdx.x * WV + g.wave);
     return;
   }
   int prow[16];
@@ -359,12 +632,18 @@ void conv_ring_kernel(Args a, int nx, int ny, int nz) {
     prow[r] = m0 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
     if (prow[r] < P) ro.valid |= 1u << r;
   }
+  if (a.part) {      // a K slice whose ring is too small for the row path (128 x 128 one-piece tiles at two stages): partial sums, no epilogue
+    float* part = a.part + (size_t)tile.z * P * a.Cout;
+#pragma unroll
+    for (int t = 0; t < NT; ++t) tile_store_part(part, a.Cout, prow, ro.valid, tile.y * (32 * NT) + t * 32 + (lane & 31), acc[t]);
+    return;
+  }
 #pragma unroll
   for (int r = 0; r < 16; ++r) ro.base[r] = ((ro.valid >> r) & 1u) ? out_pixel_base(a, prow[r]) : 0;
   uint32_t m = 0;
 #pragma unroll
   for (int t = 0; t < NT; ++t) m = max(m, tile_store_max(a, ro, tile.y * (32 * NT) + t * 32 + (lane & 31), acc[t]));
-  publish_amax(m, a.amax_out, a.status, blockIdx.x * 4 + g.wave);
+  publish_amax(m, a.amax_out, a.status, blockIdx.x * WV + g.wave);
 }
 
 // weights (Cout, taps, Cin) fp32 -> fragment order, PC pieces.  One thread per (fragment, lane): 8 values.

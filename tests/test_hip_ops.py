@@ -1442,7 +1442,10 @@ def test_conv_ring_every_plan_gives_the_same_convolution(hip, pieces):
     tol = 2e-6 * (ci * k * k) ** 0.5 * float(ref.abs().max())
     try:
         by_cut = {}
-        for kern, nt, st in [(k_, n_, s_) for k_ in (1, 2) for n_ in (2, 4) for s_ in (2, 3, 4)]:      # 2: loader / consumer waves
+        plans = [(k_, n_, s_) for k_ in (1, 2) for n_ in (2, 4) for s_ in (2, 3, 4)]      # 2: loader / consumer waves
+        if pieces < 3:
+            plans += [(4, 4, 2), (4, 4, 3)]                                                # 4: 256-pixel tiles, eight mixed-role waves (r5)
+        for kern, nt, st in plans:
             if True:
                 if nt == 4 and pieces == 3 and st == 4:
                     continue

@@ -38,6 +38,29 @@ def main():
         return c / (r / 100.0) / 1e3          # GHz: cycles per microsecond / 1000
 
     g = torch.Generator(device=dev).manual_seed(0)
+    NB = int(sys.argv[sys.argv.index("--batch") + 1]) if "--batch" in sys.argv else 1
+    if "--r5" in sys.argv:      # r5: the batched shapes under the ablation switches of LSFA_CONV_TILE_ORDER (bits 4 / 5: no copies / no arithmetic)
+        xf = torch.relu(torch.randn((NB, 38, 63, 2048), device=dev, generator=g))
+        wf = hip.SplitWeight(torch.randn((1024, 2048, 3, 3), device=dev, generator=g) * 0.01)
+        w5 = hip.SplitWeight(torch.randn((512, 2048, 1, 1), device=dev, generator=g) * 0.02)
+        amf = hip.amax_partial(xf)
+        loads5 = {"idle": (lambda: None, 1),
+                  "feat_conv_3x3 x%d" % NB: (lambda: hip.conv_split(xf, wf, None, 1, 6, 6, relu=True, amax_in=amf), 60),
+                  "res5 conv1 x%d" % NB: (lambda: hip.conv_split(xf, w5, None, 1, 0, 1, relu=True, amax_in=amf), 600)}
+        for name, (fn, n) in loads5.items():
+            with torch.cuda.stream(work_stream):
+                for _ in range(3):
+                    fn()
+            torch.cuda.synchronize()
+            with torch.cuda.stream(work_stream):
+                for _ in range(n):
+                    fn()
+            ghz = [probe(2.0) for _ in range(5)]
+            busy = not work_stream.query()
+            torch.cuda.synchronize()
+            print("%-30s LSFA_CONV_TILE_ORDER=%-3s shader clock %.2f GHz (probes: %s)%s" % (name, os.environ.get("LSFA_CONV_TILE_ORDER", "0"), sorted(ghz)[len(ghz) // 2],
+                  " ".join("%.2f" % v for v in ghz), "" if busy or name == "idle" else "   [work finished before the last probe]"), flush=True)
+        return
     x_feat = torch.randn((1, 38, 63, 2048), device=dev, generator=g)
     w_feat = hip.SplitWeight(torch.randn((1024, 2048, 3, 3), device=dev, generator=g) * 0.01)
     x_res4 = torch.randn((1, 38, 63, 256), device=dev, generator=g)

@@ -90,6 +90,7 @@ def main():
     ap.add_argument('--shapes', default='')
     ap.add_argument('--reps', type=int, default=24)
     ap.add_argument('--no-sweep', action='store_true')
+    ap.add_argument('--force', default='', help='kernel,nt,st,slices: time this plan alone (1 = mixed-role waves, 2 = loader / consumer waves)')
     ap.add_argument('--batch', type=int, default=1, help='images per call (the batched pipeline: 3 key fronts, 9 non-key frames)')
     args = ap.parse_args()
     pieces_list = [int(p) for p in args.pieces.split(',')]
@@ -115,7 +116,9 @@ def main():
             ref = torch.relu(ref)
         scale = float(ref.abs().max())
         print("\n## %s   P=%d K=%d N=%d   %.2f GFLOP" % (name, NB * Ho * Wo, ci * k * k, co, gf))
-        if k == 1 and stride == 1:      # the library GEMM of the same shape (untuned; bias / activation not included)
+        if args.force:
+            pass
+        elif k == 1 and stride == 1:      # the library GEMM of the same shape (untuned; bias / activation not included)
             X = [x.view(NB * H * W, ci) for x in xs]
             Wt = [w.view(co, ci).t().contiguous() for w in ws]
             t_lib = timed(lambda i: torch.mm(X[i % 3], Wt[i % 6]), args.reps)
@@ -132,6 +135,15 @@ def main():
                 if epi == 'res2':
                     kw.update(residual=res, out2=out2, scale2=sc2, shift2=sh2)
                 return hip.conv_split(xs[i % 3], sws[i % 6], b, stride, pad, dil, relu=epi in ('relu', 'nchw'), nchw=epi == 'nchw', **kw)
+            if args.force:
+                kn, nt, st, sl = [int(v) for v in args.force.split(',')]
+                hip.conv_plan_override(kernel=kn, nt=nt, st=st, slices=sl)
+                call(0)
+                timed(call, args.reps, rounds=1)
+                tt = timed(call, args.reps)
+                print("   pieces %d   forced %s nt%d st%d s%d   %7.1f us   %6.1f TFLOP/s" % (pieces, {1: 'mix', 2: 'split', 4: 'mix8'}[kn], nt, st, sl, tt, gf / tt * 1e3))
+                hip.conv_plan_override()
+                continue
             hip.conv_plan_override()
             y = call(0)
             y = y[0] if isinstance(y, tuple) else y
@@ -143,12 +155,12 @@ def main():
             if args.no_sweep:
                 continue
             rows = []
-            for kern in (1, 2):          # 1: mixed-role waves, 2: loader / consumer waves
+            for kern in (1, 2, 4):          # 1: mixed-role waves, 2: loader / consumer waves, 4: eight mixed-role waves on 256-pixel tiles
                 for nt in (2, 4):
-                    if co % (32 * nt):
+                    if co % (32 * nt) or (kern == 4 and (nt != 4 or pieces == 3)):
                         continue
                     for st in (2, 3, 4):
-                        if nt == 4 and pieces == 3 and st == 4:
+                        if (nt == 4 and pieces == 3 and st == 4) or (kern == 4 and st == 4):
                             continue
                         for s in ((1, 2, 3, 4, 6, 8, 12) if not args.quick else (1, 3, 6)):
                             if s > 1 and (ci * k * k // 32) // s < 3:
@@ -161,7 +173,7 @@ def main():
                                 pass
             hip.conv_plan_override()
             rows.sort()
-            tag = {1: "mix", 2: "split"}
+            tag = {1: "mix", 2: "split", 4: "mix8"}
             print("      best plans (ring kernel forced): " + "   ".join("%s nt%d st%d s%d %.1f" % (tag[kn], nt, st, s, tt) for tt, kn, nt, st, s in rows[:6]))
             by = {}
             for tt, kn, nt, st, s in rows:

@@ -38,7 +38,7 @@ def graph_time(fn, n=20):
     return a.elapsed_time(b) / n * 1e3
 
 
-for n in (1, 2, 3, 4, 5, 6):
+for n in ([int(v) for v in sys.argv[1].split(',')] if len(sys.argv) > 1 else (1, 2, 3, 4, 5, 6)):
     data = torch.rand(n, 3, H, W, device=dev) * 255
     data2 = torch.rand(n, 3, H, W, device=dev) * 255
     tb = graph_time(lambda: key._backbone(data))

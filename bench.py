@@ -69,6 +69,11 @@ def parse():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-parity', action='store_true')
     ap.add_argument('--no-spread', action='store_true', help='skip the two extra repeats of the timed region behind `value_spread`')
+    ap.add_argument('--resident-inputs', action='store_true',
+                    help='keep every frame / motion vector / residual resident in HBM as fp32 before the timed region (r1-r4); default (r5): uint8 frames '
+                         '+ fp32 motion vectors / residuals in pinned HOST memory, uploaded per interval on a copy stream inside the timed region and '
+                         'transformed on the GPU (lib/utils/image.py:296-308)')
+    ap.add_argument('--no-frame-by-frame', action='store_true', help='skip the extra frame-by-frame region behind `value_frame_by_frame`')
     ap.add_argument('--no-graph', action='store_true', help='issue every launch eagerly instead of replaying hipGraphs')
     ap.add_argument('--no-prefetch', action='store_true', help='do not overlap the next frame\'s small net with this frame\'s tail')
     ap.add_argument('--lanes', type=int, default=2,
@@ -118,6 +123,44 @@ class Runner(object):
             for i in range(1, self.K):
                 self.mv[kf + i] = cat(lambda c: c.motion_vector(kf + i, kf, device))
                 self.res[kf + i] = cat(lambda c: c.res_diff(kf + i, device))
+        # r5: the inputs as a loader hands them over (dff_rfcn/core/loader.py:131-141: HOST arrays per frame).  Per interval two pinned blocks:
+        # the key frame (uint8 HWC BGR, what a decoder returns) - uploaded `key_group - 1` intervals ahead, because a pass of key fronts needs the
+        # images of its whole group - and [the K-1 non-key frames uint8 | their motion vectors fp32 | their residuals fp32], uploaded with the
+        # interval.  One copy per block on a copy stream, transform (lib/utils/image.py:296-308) on the GPU behind it, into preallocated rings.
+        self.host_inputs = (not args.resident_inputs) and args.lanes > 0
+        if self.host_inputs:
+            K, B, H, W = self.K, self.B, args.height, args.width
+            fh, fw = self.clips[0].fh, self.clips[0].fw
+            self._nb_rest_frames = (K - 1) * B * H * W * 3
+            self._nb_mv, self._nb_res = (K - 1) * B * 2 * fh * fw * 4, (K - 1) * B * 3 * fh * fw * 4
+            assert self._nb_rest_frames % 16 == 0 and self._nb_mv % 16 == 0, "input block offsets must stay 16-byte aligned"
+            self.host_key, self.host_rest = [], []
+            for s_ in range(self.nsteps_unique):
+                kf = 1 + s_ * K
+                hk = torch.empty((B, H, W, 3), dtype=torch.uint8).pin_memory()
+                for b, c in enumerate(self.clips):
+                    hk[b] = c.frame_u8(kf)
+                blk = torch.empty(self._nb_rest_frames + self._nb_mv + self._nb_res, dtype=torch.uint8).pin_memory()
+                fr = blk[:self._nb_rest_frames].view(K - 1, B, H, W, 3)
+                mvv = blk[self._nb_rest_frames:self._nb_rest_frames + self._nb_mv].view(torch.float32).view(K - 1, B, 2, fh, fw)
+                rsv = blk[self._nb_rest_frames + self._nb_mv:].view(torch.float32).view(K - 1, B, 3, fh, fw)
+                for i in range(1, K):
+                    for b, c in enumerate(self.clips):
+                        fr[i - 1, b] = c.frame_u8(kf + i)
+                    mvv[i - 1] = self.mv[kf + i].cpu()
+                    rsv[i - 1] = self.res[kf + i].cpu()
+                self.host_key.append(hk)
+                self.host_rest.append(blk)
+            G = max(1, args.key_group)
+            self._rk, self._rr = 2 * G + 4, 6        # ring depths: a key image lives until the NEXT key frame's pass has read it as `data_key_old`
+            self.dkey_u8 = [torch.empty((B, H, W, 3), dtype=torch.uint8, device=device) for _ in range(self._rk)]
+            self.dkey_f32 = [torch.empty((B, 3, H, W), dtype=torch.float32, device=device) for _ in range(self._rk)]
+            self.drest_blk = [torch.empty(self.host_rest[0].numel(), dtype=torch.uint8, device=device) for _ in range(self._rr)]
+            self.drest_f32 = [torch.empty(((K - 1) * B, 3, H, W), dtype=torch.float32, device=device) for _ in range(self._rr)]
+            self._seq = 0                            # intervals queued so far (ring slots and the events below are keyed by it)
+            self._up_key, self._up_rest, self._done, self._done_key = {}, {}, {}, {}
+            self._pixel_means = [float(v) for v in cfg.network.PIXEL_MEANS]
+            self._pixel_scale = float(cfg.network.PIXEL_SCALE)
         R, ncls = cfg.TEST.RPN_POST_NMS_TOP_N, cfg.dataset.NUM_CLASSES
         # one pinned slot per frame of an interval; dets and counts back to back like the device side keeps them
         # (lsfa_amd/core/graphs.py _alloc_post), so a frame's results leave the device with ONE copy
@@ -204,15 +247,49 @@ class Runner(object):
             self.host_dets[slot].copy_(bufs[0].view(self.host_dets[slot].shape), non_blocking=True)
             self.host_counts_of(slot).copy_(bufs[1].view(self.B, self.ncls), non_blocking=True)
 
-    def step(self, s, fg=None, end=None):
+    def step(self, s, fg=None, end=None, key_group=None):
         """One key-frame interval: key frame (flag 1) + K-1 non-key frames (flag 2).  end: one past the last step of the run of consecutive
         steps this one belongs to (key_group: only key frames of the same run are looked ahead at)."""
         fg = fg or self.fg
+        key_group = self.key_group if key_group is None else key_group
         kf = 1 + (s % self.nsteps_unique) * self.K
         if hasattr(fg, 'lanes'):      # pipelined: frames are queued in order, copies ride on each frame's stream
-            ahead = range(s + 1, s + self.key_group if end is None else min(s + self.key_group, end))
+            ahead = range(s + 1, s + key_group if end is None else min(s + key_group, end))
+            if self.host_inputs and not self._inputs_resident_now:
+                # this interval's key image and non-key block, and the key images of the intervals its key group looks ahead at
+                q = self._seq
+                # WHERE the uploads are queued matters more than what they cost: ROCm multiplexes HIP streams onto 4 hardware queues and the
+                # pipeline's four streams have one each (lsfa_amd/core/streams.py), so a fifth stream shares a queue - behind the key stream's
+                # 10 ms passes an interval's 16 MB block arrived late and the lanes starved (2580 frames/s against 3460 with resident inputs).
+                # The non-key block goes onto a lane's stream, the key images onto the FlowNet / tail stream: queues with slack.
+                lanes = list(fg.s_lane)
+                ks = fg.s_flow if fg.s_flow is not None else lanes[0]
+                keys = [self._upload_key(q + j, s + j, ks) for j in range(1 + len(ahead))]
+                fr, mvs, rss, ev_rest = self._upload_rest(q, s, lanes[q % len(lanes)])
+                ev_keys = keys[-1][1]                # one stream, in order: the last upload's event covers the earlier ones
+                B = self.B
+                fg.key_frame(keys[0][0], deliver=lambda b: self._deliver(b, 0), ready=ev_keys,
+                             upcoming=[k[0] for k in keys[1:]] if key_group > 1 else None)
+                for i in range(1, self.K):
+                    fg.cur_frame(fr[(i - 1) * B:i * B], mvs[i - 1], rss[i - 1], deliver=lambda b, i=i: self._deliver(b, i), ready=ev_rest)
+                # everything that reads interval q - 1's inputs has been queued by now (its segment goes out with this key frame): their ring slots
+                # may be refilled once these events have passed
+                # (key images are read on the key and FlowNet / tail streams, the non-key blocks on the lanes: each ring waits for its readers only -
+                # the key stream runs whole passes ahead, and a lane's upload must not wait for those)
+                for ring, sts in ((self._done_key, [fg.s_key] + ([fg.s_flow] if fg.s_flow is not None else [])), (self._done, list(fg.s_lane))):
+                    evs = []
+                    for st in sts:
+                        e = torch.cuda.Event()
+                        e.record(st)
+                        evs.append(e)
+                    ring[q] = evs
+                    ring.pop(q - 4 * self._rk, None)
+                self._up_key.pop(q, None)
+                self._up_rest.pop(q, None)
+                self._seq = q + 1
+                return
             fg.key_frame(self.frames[kf], deliver=lambda b: self._deliver(b, 0),
-                         upcoming=[self.frames[1 + (j % self.nsteps_unique) * self.K] for j in ahead] if self.key_group > 1 else None)
+                         upcoming=[self.frames[1 + (j % self.nsteps_unique) * self.K] for j in ahead] if key_group > 1 else None)
             for i in range(1, self.K):
                 fg.cur_frame(self.frames[kf + i], self.mv[kf + i], self.res[kf + i],
                              deliver=lambda b, i=i: self._deliver(b, i))
@@ -221,6 +298,95 @@ class Runner(object):
         self._deliver(fg.key_frame(self.frames[kf], nxt(0)), 0)
         for i in range(1, self.K):
             self._deliver(fg.cur_frame(self.frames[kf + i], self.mv[kf + i], self.res[kf + i], nxt(i)), i)
+
+    _inputs_resident_now = False        # set for the extra region that measures the r1-r4 way (inputs already in HBM)
+
+    def _wait_free(self, q, depth, done, stream):
+        """ring slot q % depth was last filled for interval q - depth: its readers are all queued once interval q - depth + 1 has been (see step)"""
+        for e in done.get(q - depth + 1, ()):
+            stream.wait_event(e)
+
+    def _upload_key(self, q, step, stream):
+        """Interval `step`'s key image (queue position q): pinned host -> device ring slot, transform behind it.  -> ((B, 3, H, W) fp32, event)"""
+        u = self._up_key.get(q)
+        if u is None:
+            i = q % self._rk
+            with torch.cuda.stream(stream):
+                self._wait_free(q, self._rk, self._done_key, stream)
+                self.dkey_u8[i].copy_(self.host_key[step % self.nsteps_unique], non_blocking=True)
+                self.hip.image_transform_u8(self.dkey_u8[i], self._pixel_means, self._pixel_scale, out=self.dkey_f32[i])
+                ev = torch.cuda.Event()
+                ev.record(stream)
+            u = self._up_key[q] = (self.dkey_f32[i], ev)
+        return u
+
+    def _upload_rest(self, q, step, stream):
+        """Interval `step`'s non-key frames, motion vectors and residuals: ONE copy of the pinned block.  -> (frames ((K-1)*B, 3, H, W) fp32,
+        mv (K-1, B, 2, fh, fw), res (K-1, B, 3, fh, fw), event)"""
+        u = self._up_rest.get(q)
+        if u is None:
+            a, i = self.args, q % self._rr
+            fh, fw = self.clips[0].fh, self.clips[0].fw
+            with torch.cuda.stream(stream):
+                self._wait_free(q, self._rr, self._done, stream)
+                blk = self.drest_blk[i]
+                blk.copy_(self.host_rest[step % self.nsteps_unique], non_blocking=True)
+                self.hip.image_transform_u8(blk[:self._nb_rest_frames].view((self.K - 1) * self.B, a.height, a.width, 3), self._pixel_means,
+                                            self._pixel_scale, out=self.drest_f32[i])
+                mv = blk[self._nb_rest_frames:self._nb_rest_frames + self._nb_mv].view(torch.float32).view(self.K - 1, self.B, 2, fh, fw)
+                rs = blk[self._nb_rest_frames + self._nb_mv:].view(torch.float32).view(self.K - 1, self.B, 3, fh, fw)
+                ev = torch.cuda.Event()
+                ev.record(stream)
+            u = self._up_rest[q] = (self.drest_f32[i], mv, rs, ev)
+        return u
+
+    def resident_inputs_region(self, steps, warmup):
+        """r5: the main pipeline fed the r1-r4 way (every input already resident in HBM as fp32) for `steps` timed intervals -> frames/s"""
+        self._inputs_resident_now = True
+        try:
+            for s in range(warmup):
+                self.step(s, end=warmup)
+            self.fg.flush()
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for s in range(warmup, warmup + steps):
+                self.step(s, end=warmup + steps)
+            self.fg.flush()
+            torch.cuda.synchronize()
+            return self.B * steps * self.K / (time.perf_counter() - t1)
+        finally:
+            self._inputs_resident_now = False
+
+    def frame_by_frame_region(self, steps, warmup, settle_s=0.5):
+        """r5: the SAME clip through the frame-by-frame pipeline (segment 0, key_group 1: one frame per pass, no look-ahead - the streaming
+        case) for `steps` timed intervals after its own capture, a short settle and `warmup` intervals.  -> frames/s of this rank"""
+        from lsfa_amd.core.graphs import FramePipeline
+        a = self.args
+        fg = FramePipeline(self.key, self.cur, self.cfg, a.height, a.width, self.device, use_graphs=not a.no_graph, lanes=max(a.lanes, 1),
+                           flow_stream=not a.no_flow_stream, lookahead=a.lookahead, batch=self.B, segment=0, key_group=1)
+        seg, self.segment = self.segment, 0          # (_deliver / host_counts_of: every frame comes back on its own)
+        try:
+            fg.first_frame(self.frames[0])
+            fg.capture()
+            t0, n = time.perf_counter(), 0
+            while time.perf_counter() - t0 < settle_s:
+                self.step(n, fg, key_group=1)
+                n += 1
+            for s in range(warmup):
+                self.step(s, fg, key_group=1)
+            fg.flush()
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for s in range(warmup, warmup + steps):
+                self.step(s, fg, key_group=1)
+            fg.flush()
+            torch.cuda.synchronize()
+            dt = time.perf_counter() - t1
+        finally:
+            self.segment = seg
+            if hasattr(fg, 'close'):
+                fg.close()
+        return self.B * steps * self.K / dt
 
     # ---- untimed legs (rank 0) ----------------------------------------------------------------
     OPS = ['warp_bilinear', 'aggregate', 'rfcn_head', 'proposal', 'det_postprocess', 'conv_nhwc']
@@ -245,6 +411,7 @@ class Runner(object):
         self.conv_flops = self.hip.conv_flops_read()
         self.conv_flops3 = self.hip.conv_flops_three_products()
         self.conv_flops1 = self.hip.conv_flops_one_product()
+        self.conv_bytes, self.conv_by_kernel = self.hip.conv_bytes_read(), self.hip.conv_by_kernel()
         self.hip.conv_flops_reset(False)
         self.hip.prof_enable(False)
         return prof
@@ -301,6 +468,7 @@ class Runner(object):
         self.conv_flops = hip.conv_flops_read()
         self.conv_flops3 = hip.conv_flops_three_products()
         self.conv_flops1 = hip.conv_flops_one_product()
+        self.conv_bytes, self.conv_by_kernel = hip.conv_bytes_read(), hip.conv_by_kernel()
         hip.conv_flops_reset(False)
         hip.prof_enable(False)
         C, hw = cfg.network.DFF_FEAT_DIM, (-(-H // 16)) * (-(-W // 16))
@@ -608,6 +776,9 @@ def main():
         if hasattr(r.fg, 'flush'):
             r.fg.flush()             # the pipeline queues a segment when the next key frame arrives: queue the last one
         torch.cuda.synchronize()     # device-wide: drains every stream of the frame pipeline
+        if getattr(r, 'host_inputs', False):
+            r._up_key.clear()        # (uploads issued ahead for a look-ahead that the end of the run cut short)
+            r._up_rest.clear()
 
     # setup, untimed and not part of the W warm-up steps: keep the device under the workload's load until its clocks have settled
     settle_steps, t_settle = 0, time.perf_counter()
@@ -659,6 +830,19 @@ def main():
         repeats.append(time.perf_counter() - t1)
     batched = hasattr(r.fg, 'lanes') and (r.segment > 0 or r.key_group > 1)
     prof = (r.eager_profile_batched(args.warmup) if batched else r.eager_profile_step(args.warmup)) if rank == 0 else None
+    # r5: the streaming figure beside the headline: the same clip frame by frame (one extra short region; rank 0, untimed by the driver)
+    resident = None
+    if getattr(r, 'host_inputs', False) and rank == 0 and not args.no_frame_by_frame:
+        try:
+            resident = r.resident_inputs_region(args.steps, args.warmup)
+        except Exception as e:
+            resident = "failed: %r" % (e,)
+    fbf = None
+    if batched and rank == 0 and not args.no_frame_by_frame:
+        try:
+            fbf = r.frame_by_frame_region(args.steps, args.warmup)
+        except Exception as e:          # a reported extra: never lose the bench line to it
+            fbf = "failed: %r" % (e,)
 
     # an overflow of the fp16 form's scale anywhere in the run is an error, not a number (outside the timed regions: it synchronises)
     r.key.check_status()
@@ -750,11 +934,17 @@ def main():
                     "frac_of_six_product_peak": round(tf / MFMA_SPLIT_PEAK_TFLOPS, 4),     # what rounds 1-2 quoted as `frac` (every call on six products)
                     "traffic": load_traffic("conv_split:%dx%d,interval=%d,%s" % (args.width, args.height, args.interval, args.dtype)),
                     "launches": conv_n, "avg_us": round(conv_ms * 1e3 / conv_n, 2),
-                    "algorithmic_flops_per_launch": round(conv_fl / max(conv_calls, 1)),
+                    "algorithmic_flops_per_launch": round(conv_fl / max(conv_n, 1)),       # x launches / (avg_us x launches) = achieved
+                    "algorithmic_bytes_per_launch": round(float(getattr(r, 'conv_bytes', 0.0)) / max(conv_n, 1)),
+                    "flop_counted_calls": conv_calls,      # == launches: FLOPs and time cover the same lsfa_conv_fwd / lsfa_deconv4x4s2_crop_fwd calls (FlowNet included)
+                    "by_kernel": getattr(r, 'conv_by_kernel', None),
                     "mfma_work": {"achieved": round(mfma_work / (conv_ms * 1e-3) / 1e12, 1), "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s"},
                     "fp32_mfma_pipe_peak": 157.3,
-                    "measured": "HIP events around each lsfa_conv_fwd call (convolution kernel + its reduce pass) of one interval re-issued "
-                                "eagerly after the timed region; algorithmic FLOPs = 2*M*N*K summed over the same calls; traffic = HBM bytes "
+                    "measured": "HIP events around each lsfa_conv_fwd / lsfa_deconv4x4s2_crop_fwd call (convolution kernel + its reduce pass) re-issued "
+                                "eagerly after the timed region; algorithmic FLOPs = 2*M*N*K and algorithmic bytes = every operand once (input channels read, "
+                                "packed weights, output, residual, stored second output) summed over the SAME calls; by_kernel = the same calls by the kernel "
+                                "instantiation the launch plan picks (lsfa_conv_plan_query; tools/conv_family_roofline.py joins it with the rocprofv3 "
+                                "kernel trace and MFMA-busy counters -> profiles/r5/conv_family_roofline.csv); traffic = HBM bytes "
                                 "per call of the kernel family (FETCH_SIZE x2 + WRITE_SIZE, separate rocprofv3 PMC passes over the eager loop, "
                                 "profiles/traffic.json), null if no profile of this configuration is committed",
                     "note": "fp32 in / fp32 accumulate; an fp32 product costs three fp16 matrix instructions' worth (two-piece form: the fp32 "
@@ -793,6 +983,16 @@ def main():
                              "values": [round(frames / t, 3) for t in repeats],
                              "note": "the timed region run %d times back to back; `value` is the first" % len(repeats),
                              "host_enqueue_share_of_repeats": [round(h / t, 3) for h, t in zip(host_enqueue, repeats[1:])]},
+            "inputs": ("host-pinned, uploaded in region: per interval one pinned block (uint8 BGR frames as a decoder hands them over + fp32 motion vectors / "
+                       "residuals, dff_rfcn/core/loader.py:131-141) -> one H2D copy on a copy stream -> transform (lib/utils/image.py:296-308) on the GPU; "
+                       "uploads run ahead of the frames by the key group's look-ahead") if getattr(r, 'host_inputs', False)
+                      else "resident in HBM as fp32 before the timed region (--resident-inputs, or a serial / non-pipelined run)",
+            "value_resident_inputs": (round(resident, 3) if isinstance(resident, float) else resident),
+            "value_resident_inputs_note": "frames/s of this GPU with every input already in HBM as fp32 (what rounds 1-4 timed), one extra region of the same length",
+            "value_frame_by_frame": (round(fbf, 3) if isinstance(fbf, float) else fbf),
+            "value_frame_by_frame_note": "frames/s of this GPU for the same clip with one frame per pass (--segment 0 --key-group 1: no look-ahead, the "
+                                         "streaming case), %d timed intervals after its own graph capture + 0.5 s settle + %d warm-up intervals; null when the "
+                                         "headline configuration is itself unbatched" % (args.steps, args.warmup),
             "roofline": roof,
             "multi_gpu": multi,
             "roofline_hbm_kernel": roof_hbm,
@@ -821,10 +1021,11 @@ def main():
         if (args.height, args.width) == (600, 1000):
             # algorithmic FLOPs of the dense contractions, key frame 392.0 G, non-key frame 17.3 G
             gflop = (392.0 + 17.3 * (K - 1)) * B
-            peak = 157.0 if args.dtype == 'f32' else 2500.0
+            peak = round(MFMA_BF16_PEAK_TFLOPS / 3.0, 1) if args.dtype == 'f32' else MFMA_BF16_PEAK_TFLOPS
             tf = gflop / (elapsed / args.steps) / 1e3
-            line["roofline_dense"] = {"bound": "mfma", "scope": "all dense contractions of one interval (library MFMA kernels), "
-                                      "algorithmic FLOPs / step time, per GPU", "achieved": round(tf, 1), "peak": peak,
+            line["roofline_dense"] = {"bound": "mfma", "scope": "SURVEY.md 8(d)'s algorithmic FLOPs of one interval's dense contractions / the timed region's step "
+                                      "time (whole pipeline, everything overlapped), against the same peak as `roofline`: the dense 16-bit matrix peak / 3 "
+                                      "products per fp32 product (f32) or / 1 (bf16)", "achieved": round(tf, 1), "peak": peak,
                                       "unit": "TFLOP/s", "frac": round(tf / peak, 4), "gflop_per_step": round(gflop, 1)}
         if not (args.no_cpu_baseline and args.no_parity):
             try:

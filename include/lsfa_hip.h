@@ -123,6 +123,10 @@ int lsfa_aggregate_softmax2(const float* a, const float* b, const float* logits,
  * the HBM-resident roofline measurement (configs[4]). */
 int lsfa_aggregate_softmax2_batched(const float* a, const float* b, const float* logits,
                                     int N, int C, int H, int W, float* out, void* stream);
+/* r5: the same with the 2N logit rows `logit_row_stride` floats apart (>= H*W): channel 0 of the Nq net's last convolution
+ * written NCHW with its output channels padded to 64 is read in place (row stride 64*H*W) instead of through a strided copy */
+int lsfa_aggregate_softmax2_rows(const float* a, const float* b, const float* logits, long logit_row_stride,
+                                 int N, int C, int H, int W, float* out, void* stream);
 
 /* Fgfa variant: weights from cosine similarity of 2 embeddings
  * Replaces: compute_weight + softmax + tile/mul/add  resnet_v1_101_flownet_rfcn.py:111-116, :136-147
@@ -314,7 +318,7 @@ typedef struct lsfa_conv_desc {
   float* y2; const float* scale2; const float* shift2;
   unsigned* amax_out; unsigned* status;
   int Ho, Wo, out_H, out_W, out_sy, out_sx;
-  int prof_tag;          /* lsfa_prof_*: 0 counts the call as "conv", 1 as "flownet" */
+  int prof_tag;          /* lsfa_prof_*: r5: ignored - every call of the family is timed as "conv" (FLOPs and time over the same calls) */
   int x_nchw;            /* != 0: x is an NCHW map (N, lda, H, W) whose channels [0, Cin) are the input (K-major for the contraction): 1x1 /
                           * stride 1 / no padding and small weights only (Cout * Cin * 2 * pieces <= 256 KB per 64 output channels) -
                           * the RPN's 1x1 convolutions on the feature map the reference's operators exchange; else LSFA_ENOTSUP */
@@ -339,6 +343,11 @@ int lsfa_status_check(unsigned* status_dev, void* stream);
  * loader / consumer waves; never the halo / direct forms then; 3: the 3x3 halo form wherever its geometry allows), the tile width nt (2 | 4), the
  * ring depth st (2..4) and the number of K slices; 0 = the launch plan decides.  Process-wide; results stay bit-reproducible per setting. */
 int lsfa_conv_plan_override(int kernel, int nt, int st, int slices);
+/* r5: 4 = the ring kernel on 256-pixel tiles (eight mixed-role waves; nt 4, pieces 1 | 2).
+ * measurement hook (bench.py's per-instantiation roofline table): which kernel lsfa_conv_fwd would launch for `d` -
+ * out[0] kernel (1 ring, 2 direct, 3 halo), out[1] nt, out[2] st, out[3] loader / consumer waves, out[4] waves that multiply (4 | 8),
+ * out[5] K slices, out[6] the input's activation applied at the cut, out[7] pieces.  Launches nothing. */
+int lsfa_conv_plan_query(const lsfa_conv_desc* d, int* out8);
 /* Deconvolution(kernel 4, stride 2) + Crop(offset (1,1)) to Hc x Wc (+ bias + activation) as ONE launch of four 2x2-tap phase
  * convolutions (resnet_v1_101_flownet_rfcn.py:170-176 `deconv5` ... `deconv2`): x (N, Hi, Wi, lda) with Cin channels used,
  * wfrag4 = four consecutive blocks of lsfa_conv_weight_bytes(Cout, 2, 2, Cin, pieces) bytes, block py*2 + px =
@@ -370,6 +379,12 @@ int lsfa_deconv4x4s2_crop_fwd(const float* x, int lda, int N, int Hi, int Wi, in
  *                          lsfa_conv_fwd's amax_out does, for the next convolution's amax_in.
  * ------------------------------------------------------------------------ */
 int lsfa_avgpool_nchw(const float* x, int N, int C, int H, int W, int k, float* y, void* stream);
+/* r5: transform (lib/utils/image.py:296-308), the last host-side step of a frame moved behind its upload: decoded frames
+ * (N, H, W, 3) uint8 BGR on the device -> `data` (N, 3, H, W) float32, channel i = (im[..., 2 - i] - pixel_means[2 - i]) * pixel_scale.
+ * computed in float64 like the reference's numpy statements and rounded to float32 once.
+ * pixel_means_bgr_host: three doubles in host memory, B, G, R order (config.network.PIXEL_MEANS); H*W % 4 == 0. */
+int lsfa_image_transform_u8(const unsigned char* im_hwc_bgr, int N, int H, int W, const double* pixel_means_bgr_host, double pixel_scale,
+                            float* data_nchw, void* stream);
 size_t lsfa_stem_weight_bytes(void);
 int lsfa_stem_weights(const float* w_l, void* wfrag, void* stream);
 int lsfa_stem_conv7x7s2(const float* x, int N, int H, int W, const float* in_scale, const float* in_shift,
@@ -452,7 +467,8 @@ int lsfa_mv_residual(const unsigned char* bgr_cur, const unsigned char* bgr_ref,
 int lsfa_stream_create(void** stream_out, int high_priority);
 int lsfa_stream_destroy(void* stream);
 /* up to 32 device-to-device copies of 4-byte elements (elems4[k] of them, dst[k] <- src[k]) as one launch: a frame's - or a whole
- * segment's - images, motion vectors and residuals into the static buffers a captured graph reads */
+ * segment's - images, motion vectors and residuals into the static buffers a captured graph reads.  r5: src[k] == NULL zero-fills
+ * dst[k] (amax slots, the padding channels of a Concat map): the frame path issues no PyTorch fill or copy kernel */
 int lsfa_copy_many(int njobs, void* const* dst, const void* const* src, const long* elems4, void* stream);
 
 /* ------------------------------------------------------------------------ *

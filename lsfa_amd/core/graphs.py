@@ -735,8 +735,7 @@ class FramePipeline(object):
                     s.wait_event(self.ev_tail_of[b])
                     for t in (data, self._prev_key_data):
                         t.record_stream(s)               # the caller may drop its reference right after this call
-                    lane.data.copy_(data)
-                    lane.data_key_old.copy_(self._prev_key_data)
+                    _stage_inputs([(lane.data, data), (lane.data_key_old, self._prev_key_data)])
                 else:
                     s.wait_event(bank.ev_free)           # the bank's previous group has taken all its slices
                     # frame i of the group against its predecessor (the previous key frame for i = 0)
@@ -778,17 +777,19 @@ class FramePipeline(object):
                 # this frame's slice of the bank -> what the key lane's `agg` reads (static buffers under replay)
                 sl = slice(slot * bank.B, (slot + 1) * bank.B)
                 parts = (bank.conv_feat[sl], bank.flow_out[0][sl], bank.flow_out[1][sl])
+                # (one lsfa_copy_many launch together with the previous key frame's feature - queued earlier on this stream: it exists)
                 if lane.use_graphs:
-                    lane.conv_feat.copy_(parts[0])
-                    lane.flow_out[0].copy_(parts[1])
-                    lane.flow_out[1].copy_(parts[2])
+                    _stage_inputs([(lane.conv_feat, parts[0]), (lane.flow_out[0], parts[1]), (lane.flow_out[1], parts[2]),
+                                   (lane.feat_old, self._feat_latest)])
                 else:
                     lane.conv_feat, lane.flow_out = parts[0], (parts[1], parts[2])
+                    _stage_inputs([(lane.feat_old, self._feat_latest)])
                 if slot == bank.G - 1:
                     bank.ev_free.record(sa)
                 if lane.want_taps:
                     lane.taps['backbone_feat'] = lane.conv_feat
-            lane.feat_old.copy_(self._feat_latest)   # the previous key frame's feature (queued earlier on this stream: it exists)
+            else:
+                _stage_inputs([(lane.feat_old, self._feat_latest)])   # the previous key frame's feature
             lane.run_agg()
             # out of the key lane: pool buffer j, once the copies taken from its previous occupant (key frame k - len(pool)) are done
             j = (self._nkey - 1) % len(self._feat_pool)
@@ -796,7 +797,7 @@ class FramePipeline(object):
                 sa.wait_event(e)
             self._handed[j] = []
             pooled = self._feat_pool[j]
-            pooled.copy_(lane.feat)
+            _stage_inputs([(pooled, lane.feat)])
             self.ev_feat[j].record(sa)
             lane.run_tail()                      # heads + detections
             if deliver is not None:
@@ -839,7 +840,7 @@ class FramePipeline(object):
                 # this lane's copy of the segment's key feature (the lane's previous segment is done with the old one: stream order)
                 if self._seg_event is not None:
                     s.wait_event(self._seg_event)
-                self.feat_seg[i].copy_(self._seg_feat)
+                _stage_inputs([(self.feat_seg[i], self._seg_feat)])
                 self._copied_out(s)
                 self._lane_key[i] = self._seg_key
             frames = []
@@ -870,7 +871,7 @@ class FramePipeline(object):
                     s.wait_event(self._seg_event)        # the segment's key feature exists
                 for e in self.ev_lane[1:]:
                     s.wait_event(e)                      # every lane has finished the previous segment
-                self.feat_cur.copy_(self._seg_feat)
+                _stage_inputs([(self.feat_cur, self._seg_feat)])
                 self.ev_handover.record(s)
                 self._copied_out(s)
             self._cur_key = self._seg_key

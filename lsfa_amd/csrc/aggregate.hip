@@ -52,7 +52,7 @@ __device__ __forceinline__ void softmax2(float l0, float l1, float& w0, float& w
 template <int VEC, int CPB>
 __global__ __launch_bounds__(kThreads) void combine_kernel(const float* __restrict__ a,
                                                            const float* __restrict__ b,
-                                                           const float* __restrict__ logits, int C, int HW,
+                                                           const float* __restrict__ logits, long lrow, int C, int HW,
                                                            float* __restrict__ out) {
   const int c0 = blockIdx.y * CPB;
   const int p0 = (blockIdx.x * kThreads + threadIdx.x) * VEC;
@@ -60,8 +60,8 @@ __global__ __launch_bounds__(kThreads) void combine_kernel(const float* __restri
   const int n = blockIdx.z, N = gridDim.z;
   a += (size_t)n * C * HW; b += (size_t)n * C * HW; out += (size_t)n * C * HW;
   float l0[VEC], l1[VEC], w0[VEC], w1[VEC];
-  load_vec<VEC>(logits + (size_t)n * HW + p0, l0);
-  load_vec<VEC>(logits + (size_t)(N + n) * HW + p0, l1);
+  load_vec<VEC>(logits + (size_t)n * lrow + p0, l0);            // lrow: floats between logit rows (HW when they are dense)
+  load_vec<VEC>(logits + (size_t)(N + n) * lrow + p0, l1);
   float va[CPB][VEC], vb[CPB][VEC];
 #pragma unroll
   for (int k = 0; k < CPB; ++k)
@@ -197,19 +197,19 @@ __global__ __launch_bounds__(kThreads) void cosine_tail_kernel(const float* __re
 
 inline bool aligned(const void* p, size_t a) { return ((uintptr_t)p % a) == 0; }
 
-int launch_combine(const float* a, const float* b, const float* logits, int N, int C, int HW, float* out, hipStream_t s) {
+int launch_combine(const float* a, const float* b, const float* logits, long lrow, int N, int C, int HW, float* out, hipStream_t s) {
   using namespace lsfa;
   int vec = (HW % 4 == 0) ? 4 : (HW % 2 == 0) ? 2 : 1;
   const size_t al = sizeof(float) * vec;
-  if (!(aligned(a, al) && aligned(b, al) && aligned(logits, al) && aligned(out, al))) vec = 1;
+  if (!(aligned(a, al) && aligned(b, al) && aligned(logits, al) && aligned(out, al)) || lrow % vec != 0) vec = 1;
   const int gx = ceil_div(HW, kThreads * vec);
   // 8 channels per thread amortise the softmax; fall back to 4 when that leaves too few workgroups
   const bool c8 = (long)gx * ceil_div(C, 8) * N >= 1024;
   const int cpb = c8 ? 8 : 4;
   dim3 grid(gx, ceil_div(C, cpb), N);
 #define LSFA_COMBINE(V)                                                                                          \
-  if (c8) hipLaunchKernelGGL((combine_kernel<V, 8>), grid, dim3(kThreads), 0, s, a, b, logits, C, HW, out);      \
-  else hipLaunchKernelGGL((combine_kernel<V, 4>), grid, dim3(kThreads), 0, s, a, b, logits, C, HW, out);
+  if (c8) hipLaunchKernelGGL((combine_kernel<V, 8>), grid, dim3(kThreads), 0, s, a, b, logits, lrow, C, HW, out);      \
+  else hipLaunchKernelGGL((combine_kernel<V, 4>), grid, dim3(kThreads), 0, s, a, b, logits, lrow, C, HW, out);
   if (vec == 4) { LSFA_COMBINE(4) }
   else if (vec == 2) { LSFA_COMBINE(2) }
   else { LSFA_COMBINE(1) }
@@ -226,7 +226,7 @@ extern "C" int lsfa_aggregate_softmax2(const float* a, const float* b, const flo
   LSFA_REQUIRE(C > 0 && H > 0 && W > 0, "lsfa_aggregate_softmax2: bad shape C=%d H=%d W=%d", C, H, W);
   hipStream_t s = (hipStream_t)stream;
   ProfScope prof(LSFA_OP_AGG, s);
-  launch_combine(a, b, logits, 1, C, H * W, out, s);
+  launch_combine(a, b, logits, (long)H * W, 1, C, H * W, out, s);
   LSFA_LAUNCH_CHECK("lsfa_aggregate_softmax2");
   return LSFA_OK;
 }
@@ -238,8 +238,21 @@ extern "C" int lsfa_aggregate_softmax2_batched(const float* a, const float* b, c
   LSFA_REQUIRE(N > 0 && N <= 65535 && C > 0 && H > 0 && W > 0, "lsfa_aggregate_softmax2_batched: bad shape N=%d C=%d H=%d W=%d", N, C, H, W);
   hipStream_t s = (hipStream_t)stream;
   ProfScope prof(LSFA_OP_AGG, s);
-  launch_combine(a, b, logits, N, C, H * W, out, s);
+  launch_combine(a, b, logits, (long)H * W, N, C, H * W, out, s);
   LSFA_LAUNCH_CHECK("lsfa_aggregate_softmax2_batched");
+  return LSFA_OK;
+}
+
+extern "C" int lsfa_aggregate_softmax2_rows(const float* a, const float* b, const float* logits, long logit_row_stride, int N, int C,
+                                            int H, int W, float* out, void* stream) {
+  using namespace lsfa;
+  LSFA_REQUIRE(a && b && logits && out, "lsfa_aggregate_softmax2_rows: NULL argument");
+  LSFA_REQUIRE(N > 0 && N <= 65535 && C > 0 && H > 0 && W > 0 && logit_row_stride >= (long)H * W,
+               "lsfa_aggregate_softmax2_rows: bad shape N=%d C=%d H=%d W=%d row stride %ld", N, C, H, W, logit_row_stride);
+  hipStream_t s = (hipStream_t)stream;
+  ProfScope prof(LSFA_OP_AGG, s);
+  launch_combine(a, b, logits, logit_row_stride, N, C, H * W, out, s);
+  LSFA_LAUNCH_CHECK("lsfa_aggregate_softmax2_rows");
   return LSFA_OK;
 }
 
@@ -260,7 +273,7 @@ extern "C" int lsfa_aggregate_cosine(const float* a, const float* b, const float
   ProfScope prof(LSFA_OP_AGG, s);
   float* scratch = out + (size_t)(C - 2) * HW;
   hipLaunchKernelGGL(cosine_logits_kernel, dim3(ceil_div(HW, kCosPx)), dim3(kThreads), 0, s, emb_warp, emb_cur, E, HW, scratch);
-  launch_combine(a, b, scratch, 1, C - 2, HW, out, s);
+  launch_combine(a, b, scratch, (long)HW, 1, C - 2, HW, out, s);
   hipLaunchKernelGGL(cosine_tail_kernel, dim3(ceil_div(HW, kThreads)), dim3(kThreads), 0, s, a, b, C, HW, out);
   LSFA_LAUNCH_CHECK("lsfa_aggregate_cosine");
   return LSFA_OK;

@@ -700,7 +700,20 @@ extern "C" size_t lsfa_conv_workspace_bytes(const lsfa_conv_desc* d) {
 
 extern "C" int lsfa_conv_fwd(const lsfa_conv_desc* d, void* ws, size_t ws_bytes, void* stream) {
   LSFA_REQUIRE(d, "lsfa_conv_fwd: NULL descriptor");
-  return conv_split_launch(args_of(*d), d->pieces, ws, ws_bytes, stream, "lsfa_conv_fwd", d->prof_tag == 1 ? LSFA_OP_FLOWNET : LSFA_OP_CONV);
+  return conv_split_launch(args_of(*d), d->pieces, ws, ws_bytes, stream, "lsfa_conv_fwd", LSFA_OP_CONV);
+}
+
+extern "C" int lsfa_conv_plan_query(const lsfa_conv_desc* d, int* out8) {
+  LSFA_REQUIRE(d && out8, "lsfa_conv_plan_query: NULL argument");
+  convsplit::Args a = args_of(*d);
+  SplitPlan p;
+  long P = 0;
+  const int rc = conv_split_prepare(a, d->pieces, p, P, "lsfa_conv_plan_query");
+  if (rc != LSFA_OK) return rc;
+  out8[0] = p.direct ? 2 : (p.halo ? 3 : 1);
+  out8[1] = p.direct ? 2 : p.nt; out8[2] = p.st; out8[3] = p.sp ? 1 : 0; out8[4] = p.wv ? p.wv : 4; out8[5] = p.slices;
+  out8[6] = a.in_scale ? 1 : 0; out8[7] = d->pieces;
+  return LSFA_OK;
 }
 
 extern "C" int lsfa_amax_partial(const float* x, long long n, float* out, void* stream) {
@@ -757,5 +770,5 @@ extern "C" int lsfa_deconv4x4s2_crop_fwd(const float* x, int lda, int N, int Hi,
   a.amax = amax_in; a.w_exp = w_exp; a.amax_out = amax_out; a.status = status;
   // the launch is sized for phase (0, 0), the largest grid
   a.pad_h = a.pad_w = 1; a.Ho = (Hc + 1) / 2; a.Wo = (Wc + 1) / 2;
-  return conv_split_launch(a, pieces, ws, ws_bytes, stream, "lsfa_deconv4x4s2_crop_fwd", LSFA_OP_FLOWNET);
+  return conv_split_launch(a, pieces, ws, ws_bytes, stream, "lsfa_deconv4x4s2_crop_fwd", LSFA_OP_CONV);
 }

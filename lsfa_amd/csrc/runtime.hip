@@ -97,7 +97,10 @@ __global__ __launch_bounds__(256) void copy_many_kernel(CopyJobs j, int njobs) {
   uint32_t* d = reinterpret_cast<uint32_t*>(s_dst[k]) + o;
   const uint32_t* s = reinterpret_cast<const uint32_t*>(s_src[k]) + o;
   const bool vec = o + 4 <= s_elems[k] && ((s_dst[k] | s_src[k]) & 15) == 0;
-  if (vec) {
+  if (s_src[k] == 0) {      // r5: a job without a source zero-fills (amax slots, status words, the padding channels of a Concat map)
+    if (vec) *reinterpret_cast<uint4*>(d) = make_uint4(0u, 0u, 0u, 0u);
+    else for (long e = 0; e < 4 && o + e < s_elems[k]; ++e) d[e] = 0u;
+  } else if (vec) {
     *reinterpret_cast<uint4*>(d) = *reinterpret_cast<const uint4*>(s);
   } else {
     for (long e = 0; e < 4 && o + e < s_elems[k]; ++e) d[e] = s[e];
@@ -111,7 +114,7 @@ extern "C" int lsfa_copy_many(int njobs, void* const* dst, const void* const* sr
   long total = 0;
   for (int k = 0; k < kCopyJobsMax; ++k) {
     if (k < njobs) {
-      LSFA_REQUIRE(dst[k] && src[k] && elems4[k] >= 0, "lsfa_copy_many: NULL pointer or negative size");
+      LSFA_REQUIRE(dst[k] && elems4[k] >= 0, "lsfa_copy_many: NULL destination or negative size");
       total += (elems4[k] + 3) / 4;
     }
     j.dst[k] = k < njobs ? dst[k] : nullptr;

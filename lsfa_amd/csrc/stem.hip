@@ -340,7 +340,47 @@ __global__ __launch_bounds__(256) void maxpool3x3s2_kernel(const float4* __restr
   }
 }
 
+// r5: transform (lib/utils/image.py:296-308): a decoded frame - (N, H, W, 3) uint8, BGR - into the network's `data` tensor,
+// (N, 3, H, W) float32, channel i = (im[:, :, 2 - i] - pixel_means[2 - i]) * pixel_scale.  A thread converts four consecutive pixels
+// (12 bytes in, one float4 per plane out); the subtraction and the multiplication run in float64 like the reference's two numpy
+// statements (np.zeros is float64) and the result is rounded to float32 once, where the reference hands the array to the executor:
+// bit-identical to it for any means / scale.
+__global__ __launch_bounds__(256) void image_transform_u8_kernel(const unsigned char* __restrict__ im, long npix4, int HW, double m0, double m1, double m2,
+                                                                 double scale, float* __restrict__ out) {
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= npix4) return;
+  const long hw4 = HW / 4;
+  const long n = i / hw4, q = i - n * hw4;
+  const uint32_t* src = reinterpret_cast<const uint32_t*>(im + (n * HW + q * 4) * 3);      // 12-byte groups: 4-byte aligned (HW % 4 == 0)
+  const uint32_t w0 = src[0], w1 = src[1], w2 = src[2];
+  // bytes b0 g0 r0 b1 | g1 r1 b2 g2 | r2 b3 g3 r3
+  const double b[4] = {(double)(w0 & 255u), (double)(w0 >> 24), (double)((w1 >> 16) & 255u), (double)((w2 >> 8) & 255u)};
+  const double g[4] = {(double)((w0 >> 8) & 255u), (double)(w1 & 255u), (double)(w1 >> 24), (double)((w2 >> 16) & 255u)};
+  const double r[4] = {(double)((w0 >> 16) & 255u), (double)((w1 >> 8) & 255u), (double)(w2 & 255u), (double)(w2 >> 24)};
+  float* o = out + n * 3 * (long)HW + q * 4;
+  // plane 0 = R - mean[2], plane 1 = G - mean[1], plane 2 = B - mean[0]   (m0, m1, m2 = pixel_means in B, G, R order)
+  *reinterpret_cast<float4*>(o) = make_float4((float)((r[0] - m2) * scale), (float)((r[1] - m2) * scale), (float)((r[2] - m2) * scale), (float)((r[3] - m2) * scale));
+  *reinterpret_cast<float4*>(o + HW) = make_float4((float)((g[0] - m1) * scale), (float)((g[1] - m1) * scale), (float)((g[2] - m1) * scale), (float)((g[3] - m1) * scale));
+  *reinterpret_cast<float4*>(o + 2 * (long)HW) = make_float4((float)((b[0] - m0) * scale), (float)((b[1] - m0) * scale), (float)((b[2] - m0) * scale), (float)((b[3] - m0) * scale));
+}
+
 }  // namespace
+
+extern "C" int lsfa_image_transform_u8(const unsigned char* im_hwc_bgr, int N, int H, int W, const double* pixel_means_bgr_host, double pixel_scale,
+                                       float* data_nchw, void* stream) {
+  LSFA_REQUIRE(im_hwc_bgr && pixel_means_bgr_host && data_nchw, "lsfa_image_transform_u8: NULL argument");
+  LSFA_REQUIRE(N > 0 && H > 0 && W > 0, "lsfa_image_transform_u8: bad shape");
+  if (((long)H * W) % 4 != 0 || ((uintptr_t)im_hwc_bgr & 3) || ((uintptr_t)data_nchw & 15)) {
+    set_error("lsfa_image_transform_u8: H*W = %ld must be a multiple of 4, the image 4-byte and the output 16-byte aligned", (long)H * W);
+    return LSFA_ENOTSUP;
+  }
+  const long npix4 = (long)N * H * W / 4;
+  ProfScope prof(LSFA_OP_STEM, (hipStream_t)stream);
+  hipLaunchKernelGGL(image_transform_u8_kernel, dim3((unsigned)((npix4 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, im_hwc_bgr, npix4, H * W,
+                     pixel_means_bgr_host[0], pixel_means_bgr_host[1], pixel_means_bgr_host[2], pixel_scale, data_nchw);
+  LSFA_LAUNCH_CHECK("lsfa_image_transform_u8");
+  return LSFA_OK;
+}
 
 extern "C" int lsfa_avgpool_nchw(const float* x, int N, int C, int H, int W, int k, float* y, void* stream) {
   LSFA_REQUIRE(x && y, "lsfa_avgpool_nchw: NULL argument");

@@ -185,14 +185,23 @@ def warp_set_variant(variant):
 
 
 @_on_tensor_device
-def aggregate_softmax2(a, b, logits, out=None):
-    """a, b (N, C, H, W); logits (2N, 1, H, W): rows [0, N) weight a, rows [N, 2N) weight b."""
-    a, b, logits = _f32c(a, "a"), _f32c(b, "b"), _f32c(logits, "logits")
+def aggregate_softmax2(a, b, logits, out=None, logit_row_stride=None):
+    """a, b (N, C, H, W); logits (2N, 1, H, W): rows [0, N) weight a, rows [N, 2N) weight b.
+    logit_row_stride (r5): `logits` is any float32 tensor whose 2N rows of H*W logits start that many floats apart (the Nq net's
+    last convolution written NCHW with 64 padded output channels: channel 0 of each image, stride 64*H*W) - no strided copy."""
+    a, b = _f32c(a, "a"), _f32c(b, "b")
     N, C, H, W = a.shape
-    if logits.numel() != 2 * N * H * W:
-        raise LsfaError("aggregate_softmax2: logits %s do not match a %s" % (tuple(logits.shape), tuple(a.shape)))
     if out is None:
         out = torch.empty_like(a)
+    if logit_row_stride is not None:
+        if logits.dtype != torch.float32 or not logits.is_contiguous() or logits.numel() < (2 * N - 1) * logit_row_stride + H * W:
+            raise LsfaError("aggregate_softmax2: logits %s too small for %d rows %d floats apart" % (tuple(logits.shape), 2 * N, logit_row_stride))
+        _check(lib().lsfa_aggregate_softmax2_rows(_ptr(a), _ptr(b), _ptr(logits), ctypes.c_long(logit_row_stride), _ci(N), _ci(C), _ci(H), _ci(W),
+                                                  _ptr(out), _stream()), "lsfa_aggregate_softmax2_rows")
+        return out
+    logits = _f32c(logits, "logits")
+    if logits.numel() != 2 * N * H * W:
+        raise LsfaError("aggregate_softmax2: logits %s do not match a %s" % (tuple(logits.shape), tuple(a.shape)))
     if N == 1:
         _check(lib().lsfa_aggregate_softmax2(_ptr(a), _ptr(b), _ptr(logits), _ci(C), _ci(H), _ci(W), _ptr(out), _stream()),
                "lsfa_aggregate_softmax2")
@@ -435,11 +444,44 @@ def scale_shift_relu_cl(x, scale, shift, relu=True, out=None):
 
 # algorithmic FLOPs (2*M*N*K, fp32-equivalent) of the own convolutions issued since the last reset: bench.py divides
 # them by the event-timed duration of the same launches for its MFMA roofline
-_conv_flops = {"count": False, "flops": 0.0, "launches": 0, "flops_three_products": 0.0, "flops_one_product": 0.0}
+_conv_flops = {"count": False, "flops": 0.0, "launches": 0, "flops_three_products": 0.0, "flops_one_product": 0.0, "bytes": 0.0, "by_kernel": {}}
 
 
 def conv_flops_reset(enable=True):
-    _conv_flops.update(count=bool(enable), flops=0.0, launches=0, flops_three_products=0.0, flops_one_product=0.0)
+    _conv_flops.update(count=bool(enable), flops=0.0, launches=0, flops_three_products=0.0, flops_one_product=0.0, bytes=0.0, by_kernel={})
+
+
+def conv_bytes_read():
+    """r5: algorithmic bytes of the counted calls - each operand once: the input channels the call reads, its packed weights, the output,
+    the residual, a stored second output (4 bytes per activation, 2 x pieces per weight)"""
+    return _conv_flops["bytes"]
+
+
+def conv_by_kernel():
+    """r5: {kernel instantiation as rocprofv3 prints it: {"calls", "gflop", "mbytes"}} of the counted calls (lsfa_conv_plan_query)"""
+    return {k: {"calls": v[0], "gflop": round(v[1] / 1e9, 3), "mbytes": round(v[2] / 1e6, 3)} for k, v in _conv_flops["by_kernel"].items()}
+
+
+def _count_conv_launch(name, flops, nbytes):
+    if _conv_flops["count"]:
+        _conv_flops["bytes"] += nbytes
+        e = _conv_flops["by_kernel"].setdefault(name, [0, 0.0, 0.0])
+        e[0] += 1
+        e[1] += flops
+        e[2] += nbytes
+
+
+def _plan_kernel_name(d):
+    q = (ctypes.c_int * 8)()
+    if lib().lsfa_conv_plan_query(ctypes.byref(d), q) != 0:
+        return "?"
+    kind, nt, st, sp, wv, slices, af, pc = [int(v) for v in q]
+    b = lambda v: "true" if v else "false"
+    if kind == 2:
+        return "conv_split_direct_kernel<%d>" % pc
+    if kind == 3:
+        return "conv_split3x3_kernel<%d, %d>" % (nt, pc)
+    return "conv_ring_kernel<%d, %d, %d, %s, %s, %d>%s" % (nt, pc, st, b(sp), b(af), wv, "" if slices <= 1 else " +split_reduce")
 
 
 def conv_flops_read():
@@ -456,11 +498,11 @@ def conv_flops_one_product():
     return _conv_flops["flops_one_product"]
 
 
-def _count_conv(N, Ho, Wo, Cout, Cin, kh, kw, pieces=3):
+def _count_conv(N, Ho, Wo, Cout, Cin, kh, kw, pieces=3, launches=1):
     if _conv_flops["count"]:
         f = 2.0 * N * Ho * Wo * Cout * Cin * kh * kw
         _conv_flops["flops"] += f
-        _conv_flops["launches"] += 1
+        _conv_flops["launches"] += launches
         if pieces == 2:
             _conv_flops["flops_three_products"] += f
         elif pieces == 1:
@@ -501,7 +543,8 @@ def conv_nhwc(x, w_kc, bias, kh, kw, stride=1, pad=0, dil=1, relu=False, out=Non
 
 
 def copy_many(pairs):
-    """[(dst, src), ...] (at most 32; same shapes, contiguous, 4-byte dtypes, one device) as ONE launch on the current stream."""
+    """[(dst, src), ...] (at most 32; same shapes, contiguous, 4-byte dtypes, one device) as ONE launch on the current stream.
+    src None (r5): dst is zero-filled - the frame path's amax slots and padded maps are cleared by this kernel, not by a PyTorch fill."""
     pairs = [(d, s) for d, s in pairs if d.numel()]
     if not pairs:
         return
@@ -509,15 +552,31 @@ def copy_many(pairs):
     if n > 32:
         raise LsfaError("copy_many: at most 32 copies per launch")
     for d, s in pairs:
-        if d.shape != s.shape or d.dtype != s.dtype or d.element_size() != 4 or not (d.is_contiguous() and s.is_contiguous()) \
-                or d.device != s.device or d.device != pairs[0][0].device:
+        if d.element_size() != 4 or not d.is_contiguous() or d.device != pairs[0][0].device:
+            raise LsfaError("copy_many: %s: need a 4-byte dtype, contiguous, one device" % (tuple(d.shape),))
+        if s is not None and (d.shape != s.shape or d.dtype != s.dtype or not s.is_contiguous() or d.device != s.device):
             raise LsfaError("copy_many: %s <- %s: need equal shapes, 4-byte dtype, contiguous, one device"
                             % (tuple(d.shape), tuple(s.shape)))
     dst = (ctypes.c_void_p * n)(*[d.data_ptr() for d, _ in pairs])
-    src = (ctypes.c_void_p * n)(*[s.data_ptr() for _, s in pairs])
+    src = (ctypes.c_void_p * n)(*[(s.data_ptr() if s is not None else None) for _, s in pairs])
     cnt = (ctypes.c_long * n)(*[d.numel() for d, _ in pairs])
     with torch.cuda.device(pairs[0][0].device):
         _check(lib().lsfa_copy_many(_ci(n), dst, src, cnt, _stream()), "lsfa_copy_many")
+
+
+@_on_tensor_device
+def image_transform_u8(im, pixel_means=(0.0, 0.0, 0.0), pixel_scale=1.0, out=None):
+    """lsfa_image_transform_u8: decoded frames (N, H, W, 3) uint8 BGR on the device -> (N, 3, H, W) float32 RGB minus means, times scale
+    (transform, lib/utils/image.py:296-308).  pixel_means in B, G, R order (config.network.PIXEL_MEANS)."""
+    if im.dtype != torch.uint8 or im.dim() != 4 or im.shape[3] != 3 or not im.is_contiguous():
+        raise LsfaError("image_transform_u8: (N, H, W, 3) contiguous uint8 expected, got %s %s" % (tuple(im.shape), im.dtype))
+    N, H, W, _ = im.shape
+    if out is None:
+        out = torch.empty((N, 3, H, W), device=im.device, dtype=torch.float32)
+    means = (ctypes.c_double * 3)(*[float(m) for m in pixel_means])
+    _check(lib().lsfa_image_transform_u8(_vp(im.data_ptr()), _ci(N), _ci(H), _ci(W), means, ctypes.c_double(pixel_scale), _ptr(out), _stream()),
+           "lsfa_image_transform_u8")
+    return out
 
 
 @_on_tensor_device
@@ -713,8 +772,26 @@ def amax_partial(x, out=None):
 
 
 def amax_slots(n, device):
-    """n zeroed amax_out slot arrays (n, 256) - uint32 bit patterns of non-negative floats, readable as float32 through .view()"""
-    return torch.zeros((n, AMAX_SLOTS), dtype=torch.int32, device=device)
+    """n zeroed amax_out slot arrays (n, 256) - uint32 bit patterns of non-negative floats, readable as float32 through .view()
+    (cleared by lsfa_copy_many's zero-fill job on the current stream: no PyTorch kernel in a captured frame section)"""
+    t = torch.empty((n, AMAX_SLOTS), dtype=torch.int32, device=device)
+    if t.is_cuda:
+        with torch.cuda.device(t.device):
+            copy_many([(t, None)])
+    else:
+        t.zero_()
+    return t
+
+
+def zeros_f32(shape, device):
+    """torch.zeros(shape, float32) cleared by lsfa_copy_many's zero-fill job (see amax_slots)"""
+    t = torch.empty(shape, dtype=torch.float32, device=device)
+    if t.is_cuda:
+        with torch.cuda.device(t.device):
+            copy_many([(t, None)])
+    else:
+        t.zero_()
+    return t
 
 
 def new_status(device):
@@ -746,6 +823,12 @@ def _conv_launch(who, x, lda, N, H, W, cin, sw, bias, stride, pad_h, pad_w, dil,
     d.in_scale, d.in_shift = (in_scale.data_ptr() if in_scale is not None else None), (in_shift.data_ptr() if in_shift is not None else None)
     need = lib().lsfa_conv_workspace_bytes(ctypes.byref(d))
     ws = torch.empty(max(need, 16), dtype=torch.uint8, device=device)
+    if _conv_flops["count"]:
+        Ho = grid[0] if grid[0] > 0 else (H + 2 * pad_h - dil * (sw.kh - 1) - 1) // stride + 1
+        Wo = grid[1] if grid[1] > 0 else (W + 2 * pad_w - dil * (sw.kw - 1) - 1) // stride + 1
+        outs = 1 + (1 if residual is not None else 0) + (1 if out2 is not None else 0)
+        nbytes = 4.0 * N * H * W * cin + 2.0 * sw.pieces * sw.cout * sw.kh * sw.kw * cin + 4.0 * outs * N * Ho * Wo * sw.cout
+        _count_conv_launch(_plan_kernel_name(d), 2.0 * N * Ho * Wo * sw.real_cout * sw.real_cin * sw.kh * sw.kw, nbytes)
     _check(lib().lsfa_conv_fwd(ctypes.byref(d), _ptr(ws), ctypes.c_size_t(need), _stream()), who)
 
 
@@ -886,8 +969,12 @@ def deconv4x4s2_crop(x, sw4, bias, out, c0=0, act=0, amax_in=None, amax_out=None
         amax_in = amax_partial(x)
     need = lib().lsfa_deconv4x4s2_crop_workspace_bytes(_ci(N), _ci(Hi), _ci(Wi), _ci(cin), _ci(cout), _ci(Hc), _ci(Wc), _ci(sw4.pieces))
     ws = torch.empty(max(need, 16), dtype=torch.uint8, device=x.device)
-    for s in sw4:
-        _count_conv(N, (Hc + 1) // 2, (Wc + 1) // 2, s.real_cout, s.real_cin, 2, 2, sw4.pieces)
+    for i, s in enumerate(sw4):      # four phases, ONE launch
+        _count_conv(N, (Hc + 1) // 2, (Wc + 1) // 2, s.real_cout, s.real_cin, 2, 2, sw4.pieces, launches=1 if i == 0 else 0)
+    if _conv_flops["count"]:
+        _count_conv_launch("conv_ring_kernel (the four phases of a stride-2 transposed convolution)",
+                           sum(2.0 * N * ((Hc + 1) // 2) * ((Wc + 1) // 2) * s.real_cout * s.real_cin * 4 for s in sw4),
+                           4.0 * N * Hi * Wi * cin + 4 * 2.0 * sw4.pieces * cout * 4 * cin + 4.0 * N * Hc * Wc * cout)
     _check(lib().lsfa_deconv4x4s2_crop_fwd(_ptr(x), _ci(L), _ci(N), _ci(Hi), _ci(Wi), _ci(cin), _ptr(frags), _ci(sw4.pieces), _ci(sw4.w_exp),
                                            _ptr(amax_in), _ptr(bias), _ci(cout), _ci(act), _vp(out.data_ptr() + 4 * c0), _ci(Lout), _ci(Hc), _ci(Wc),
                                            _ptr(amax_out), _ptr(status), _ptr(ws), ctypes.c_size_t(need), _stream()), "lsfa_deconv4x4s2_crop_fwd")

@@ -477,7 +477,7 @@ class Executor(object):
         S = self._slots['flow'].begin()
 
         def cmap(h, w, c):      # a concatenated map with its channel count padded to a multiple of 32 (the padding stays zero)
-            return torch.zeros((N, h, w, -(-c // 32) * 32), device=dev, dtype=torch.float32)
+            return hip.zeros_f32((N, h, w, -(-c // 32) * 32), dev)      # (the padding channels are multiplied by zero weights: they must be finite)
 
         def out_hw(h, w, k, stride, pad):
             return (h + 2 * pad - k) // stride + 1, (w + 2 * pad - k) // stride + 1
@@ -664,10 +664,11 @@ class Executor(object):
                 x = self._pair_rows(warp, conv_feat, am0)
                 x = self._conv(x, self.nq[0][0], self.nq[0][1], 1, 1, 1, act=1, amax_in=am0, amax_out=am1)
                 x = self._conv(x, self.nq[1][0], self.nq[1][1], act=1, amax_in=am1, amax_out=am2)
-                x = self._conv(x, self.nq[2][0], self.nq[2][1], amax_in=am2)
-                logits = x[..., 0].reshape(2 * n, 1, h, w).contiguous()
-                self._tap('nq_logits', logits)
-                conv_feat = hip.aggregate_softmax2(warp, conv_feat, logits)
+                # the last convolution (1 output channel, padded to 64) written NCHW: channel 0 of image r is logit row r, read in place
+                x = self._conv(x, self.nq[2][0], self.nq[2][1], amax_in=am2, nchw=True)
+                if self.taps is not None:
+                    self._tap('nq_logits', x[:, 0:1].contiguous())
+                conv_feat = hip.aggregate_softmax2(warp, conv_feat, x, logit_row_stride=x.shape[1] * h * w)
             elif cfg.network.add_Fgfa_net:
                 # get_embednet on Concat(conv_feat, warp) (:118-135; note the order, :133): 1x1 1024 -> 512, 3x3 512 -> 512, 1x1 512 -> 2048
                 S = self._slots['agg'].begin()

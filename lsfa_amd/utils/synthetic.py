@@ -50,6 +50,12 @@ class SyntheticClip(object):
         img = (img + noise.to(device)).clamp_(0, 255).round_()
         return img.unsqueeze(0).contiguous()
 
+    def frame_u8(self, f):
+        """The same frame the way a decoder hands it over: (H, W, 3) uint8, BGR, on the host (cv2.imread's layout, image.py:283).
+        frame() is integer-valued in [0, 255], so transform(frame_u8(f), zero means, 1.0) IS frame(f), bit for bit."""
+        rgb = self.frame(f)[0]                                   # (3, H, W) float32, integers
+        return rgb.flip(0).permute(1, 2, 0).to(torch.uint8).contiguous()
+
     def motion_vector(self, f, key_f, device='cpu'):
         """(1,2,fh,fw): -(displacement accumulated since the key frame)/16 + N(0,0.05)."""
         g = torch.Generator(device='cpu').manual_seed(7000 + 1000 * self.clip_id + f)

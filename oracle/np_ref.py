@@ -176,7 +176,12 @@ def cv2_resize_linear(src, fx, fy):
     dsize = cvRound(size*f); with fx / fy given the scale is 1/f (`scale_x = 1. / inv_scale_x`), NOT
     src/dst; source coordinate (d + 0.5)*scale - 0.5, clamped so that the two taps stay inside;
     horizontal pass then vertical pass) [un-vendored, parity unpinned]."""
-    src = np.asarray(src, dtype=np.float32)
+    # resize.cpp's linear_tab: CV_32F runs HResizeLinear<float, float, float> / VResizeLinear<float, float, float>, CV_64F
+    # HResizeLinear<double, double, float> / VResizeLinear<double, double, float>: a float64 image (the zero-padded maps of
+    # transform_mv_res, image.py:210-222) is interpolated in double with the SAME float coefficients and comes back float64
+    src = np.asarray(src)
+    wt = np.float64 if src.dtype == np.float64 else np.float32
+    src = src.astype(wt)
     sh, sw = src.shape[:2]
     dh, dw = int(np.rint(sh * fy)), int(np.rint(sw * fx))
 
@@ -196,9 +201,11 @@ def cv2_resize_linear(src, fx, fy):
     x0, x1, ax = taps(dw, sw, fx)
     y0, y1, ay = taps(dh, sh, fy)
     src3 = src.reshape(sh, sw, -1)
-    hor = src3[:, x0] * (1 - ax)[None, :, None] + src3[:, x1] * ax[None, :, None]
-    out = hor[y0] * (1 - ay)[:, None, None] + hor[y1] * ay[:, None, None]
-    return out.astype(np.float32).reshape((dh, dw) + src.shape[2:])
+    bx, by = (1 - ax).astype(wt), (1 - ay).astype(wt)           # `cbuf[0] = 1.f - fx` in float, then used in the work type
+    ax, ay = ax.astype(wt), ay.astype(wt)
+    hor = src3[:, x0] * bx[None, :, None] + src3[:, x1] * ax[None, :, None]
+    out = hor[y0] * by[:, None, None] + hor[y1] * ay[:, None, None]
+    return out.astype(wt).reshape((dh, dw) + src.shape[2:])
 
 
 def transform_mv_res(motion_vector, res_diff, im_scale, pixel_means, pixel_scale, rcnn_stride=16):
@@ -214,7 +221,7 @@ def transform_mv_res(motion_vector, res_diff, im_scale, pixel_means, pixel_scale
     for i in range(3):
         padded_res_diff[:, :, i] = (padded_res_diff[:, :, 2 - i] - pixel_means[2 - i]) * pixel_scale
     rcnn_scale = 1.0 / rcnn_stride
-    resize_motion_vector = cv2_resize_linear(padded_motion_vector, rcnn_scale, rcnn_scale).astype(np.float64)
+    resize_motion_vector = cv2_resize_linear(padded_motion_vector, rcnn_scale, rcnn_scale)      # float64 in, float64 out
     resize_res_diff = cv2_resize_linear(padded_res_diff, rcnn_scale, rcnn_scale)
     resize_motion_vector *= im_scale * rcnn_scale
     th, tw, _ = resize_res_diff.shape

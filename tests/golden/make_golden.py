@@ -14,6 +14,13 @@ What is captured — inputs and the reference's outputs:
   G5  the frame loop of dff_rfcn/core/tester.py:143-152 + :265-281 assembled from the
       reference's bbox_pred/clip_boxes/nms (the loop itself is Python 2 and cannot
       be imported, so its ~15 lines are replayed here around the reference's functions)
+  G6  (r5) lib/utils/image.py imported with STUB modules for cv2 and coviar_py2 (both absent from this
+      image).  `transform` (:296-308) is pure numpy: its output is the reference's, exactly.
+      `transform_mv_res` (:202-228), `resize` (:266-294) and `tensor_vstack` run the reference's own code
+      with ONE substitution: cv2.resize is the repo's restatement of OpenCV 3.2's INTER_LINEAR
+      (oracle/np_ref.py::cv2_resize_linear) - so the padding, the in-place channel loop (:218-219), the
+      scale factors, the transposes and the im_scale rule are pinned to the reference; the
+      interpolation arithmetic inside cv2.resize stays a restatement (no OpenCV here).
 The three import shims are the ones SURVEY.md §8c lists: xrange, np.float, and
 stub modules for the missing Cython sources (bbox, cpu_nms, gpu_nms).
 """
@@ -43,6 +50,23 @@ def import_reference():
     from rpn.generate_anchor import generate_anchors
     from bbox.bbox_transform import bbox_pred, clip_boxes, bbox_overlaps_py
     return nms, generate_anchors, bbox_pred, clip_boxes, bbox_overlaps_py
+
+
+def import_reference_image():
+    """lib/utils/image.py with cv2 / coviar_py2 stubbed (G6).  cv2.resize -> the oracle's restatement of INTER_LINEAR."""
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", ".."))
+    from oracle import np_ref
+    cv2 = types.ModuleType("cv2")
+    cv2.INTER_LINEAR = 1
+
+    def resize(src, dsize, dst=None, fx=None, fy=None, interpolation=1):
+        assert dsize is None and interpolation == 1
+        return np_ref.cv2_resize_linear(np.asarray(src), fx, fy)
+    cv2.resize = resize
+    sys.modules["cv2"] = cv2
+    sys.modules["coviar_py2"] = types.ModuleType("coviar_py2")
+    from utils import image
+    return image
 
 
 def random_boxes(rs, n, im_w=1000, im_h=600, dtype=np.float32, clustered=True):
@@ -122,6 +146,26 @@ def main():
     g["g5_pred_boxes"] = pred_boxes
     g["g5_counts"] = np.asarray([len(all_boxes[j]) for j in range(ncls)], dtype=np.int64)
     g["g5_dets"] = np.vstack([all_boxes[j] for j in range(ncls)])
+    # G6: lib/utils/image.py
+    image = import_reference_image()
+    rs = np.random.RandomState(33)
+    im = rs.randint(0, 256, (20, 28, 3)).astype(np.uint8)                  # BGR, H*W % 4 == 0
+    means, pscale = np.array([103.06, 115.90, 123.15]), 0.0167
+    g["g6_im"], g["g6_means"], g["g6_pixel_scale"] = im, means, np.asarray(pscale)
+    g["g6_transform"] = image.transform(im, means, pscale)                 # exact: pure numpy
+    g["g6_transform_zero_means"] = image.transform(im, np.zeros(3), 1.0)   # the resnet-101 configuration (config.py:171-176)
+    mv = rs.randint(-40, 41, (37, 52, 2)).astype(np.int32)                 # odd sizes: padding to the stride, 'full' edges
+    res = rs.randint(-128, 128, (37, 52, 3)).astype(np.int32)
+    g["g6_mv"], g["g6_res"] = mv, res
+    for tag, sc in (("s1", 1.0), ("s16", 1.6)):
+        t_mv, t_res = image.transform_mv_res(mv, res, sc, means, pscale)
+        g["g6_mv_tensor_" + tag], g["g6_res_tensor_" + tag] = t_mv, t_res
+    big = rs.randint(0, 256, (30, 50, 3)).astype(np.uint8)
+    g["g6_resize_in"] = big
+    r_im, r_scale = image.resize(big, 60, 100, stride=16)                  # short side -> 60, capped by the long side; padded to 16
+    g["g6_resize_out"], g["g6_resize_scale"] = r_im, np.asarray(r_scale)
+    r_im2, r_scale2 = image.resize(big, 60, 90, stride=0)                  # the max_size rule takes over
+    g["g6_resize_out_capped"], g["g6_resize_scale_capped"] = r_im2, np.asarray(r_scale2)
     np.savez_compressed(OUT, **g)
     print("wrote", OUT, os.path.getsize(OUT), "bytes;", len(g), "arrays")
 

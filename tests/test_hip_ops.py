@@ -979,6 +979,28 @@ def test_stem_conv_batch_invariance_accumulation_and_amax(hip):
         hip.stem_conv(t(x1), t(w6[:, 0:3].transpose(1, 2, 3, 0).copy()), None)          # r3's float layout is not the fragments
 
 
+def test_image_transform_u8_is_the_references_transform(hip, golden):
+    """lsfa_image_transform_u8 (r5: the frame's upload path) against G6 - the output of the reference's own `transform`
+    (lib/utils/image.py:296-308, run by tests/golden/make_golden.py) rounded to float32 where the reference hands it to the executor:
+    bit-exact, with real pixel means / scale and with the resnet-101 configuration's zero means; a batch of frames; and the oracle's
+    restatement at the benchmark's frame size."""
+    from oracle import np_ref
+    im = golden["g6_im"]
+    means, ps = golden["g6_means"], float(golden["g6_pixel_scale"])
+    dev_im = torch.from_numpy(im)[None].to(DEV)
+    out = hip.image_transform_u8(dev_im, means, ps)
+    assert np.array_equal(out.cpu().numpy(), golden["g6_transform"].astype(np.float32))
+    out0 = hip.image_transform_u8(dev_im, (0.0, 0.0, 0.0), 1.0)
+    assert np.array_equal(out0.cpu().numpy(), golden["g6_transform_zero_means"].astype(np.float32))
+    rs = np.random.RandomState(5)
+    batch = rs.randint(0, 256, (3, 600, 1000, 3)).astype(np.uint8)
+    got = hip.image_transform_u8(torch.from_numpy(batch).to(DEV), means, ps).cpu().numpy()
+    for n in range(3):
+        assert np.array_equal(got[n:n + 1], np_ref.transform(batch[n], means, ps).astype(np.float32))
+    with pytest.raises(hip.LsfaError):
+        hip.image_transform_u8(torch.zeros((1, 3, 7, 3), dtype=torch.uint8, device=DEV))      # H*W % 4 != 0
+
+
 @pytest.mark.parametrize("shape,k", [((1, 3, 600, 1000), 4), ((2, 3, 37, 50), 4), ((1, 5, 9, 7), 2)])
 def test_avgpool_nchw_vs_torch_ceil_mode(hip, shape, k):
     """mx Pooling(avg, pooling_convention='full') = torch avg_pool2d(ceil_mode=True) without padding: edge windows are

@@ -133,3 +133,37 @@ def test_coviar_accumulation_hand_case():
     res = oracle.coviar_residual(bgr1, bgr0, a2)
     assert res.dtype == np.int32
     assert res[8, 9].tolist() == (bgr1[8, 9].astype(np.int32) - bgr0[4, 3].astype(np.int32)).tolist()
+
+
+def test_image_helpers_against_reference_g6(golden):
+    """G6 (r5): lib/utils/image.py run here with cv2 / coviar_py2 stubbed (tests/golden/make_golden.py).  `transform` is the reference's
+    own output; `transform_mv_res` / `resize` are the reference's code around the restated INTER_LINEAR, so everything but the
+    interpolation arithmetic (padding to the stride, the in-place channel loop of :218-219, scales, transposes, the im_scale rule) is
+    pinned.  The numpy restatement must reproduce them exactly, the torch host path (lsfa_amd/utils/image.py, float32) to float32 round-off."""
+    import torch
+    from lsfa_amd.utils import image
+    im, means, ps = golden["g6_im"], golden["g6_means"], float(golden["g6_pixel_scale"])
+    np.testing.assert_array_equal(np_ref.transform(im, means, ps), golden["g6_transform"])
+    np.testing.assert_array_equal(np_ref.transform(im, np.zeros(3), 1.0), golden["g6_transform_zero_means"])
+    t = image.transform(torch.from_numpy(im), means, ps).numpy()
+    np.testing.assert_allclose(t, golden["g6_transform"], rtol=3e-7, atol=3e-7)
+    np.testing.assert_array_equal(image.transform(torch.from_numpy(im), np.zeros(3), 1.0).numpy(), golden["g6_transform_zero_means"].astype(np.float32))
+    mv, res = golden["g6_mv"], golden["g6_res"]
+    for tag, sc in (("s1", 1.0), ("s16", 1.6)):
+        want_mv, want_res = golden["g6_mv_tensor_" + tag], golden["g6_res_tensor_" + tag]
+        got_mv, got_res = np_ref.transform_mv_res(mv, res, sc, means, ps)
+        np.testing.assert_array_equal(got_mv, want_mv)
+        np.testing.assert_array_equal(got_res, want_res)
+        h_mv, h_res = image.transform_mv_res(torch.from_numpy(mv), torch.from_numpy(res), sc, means, ps)
+        assert tuple(h_mv.shape) == want_mv.shape and tuple(h_res.shape) == want_res.shape
+        np.testing.assert_allclose(h_mv.numpy(), want_mv, rtol=2e-5, atol=2e-5)
+        np.testing.assert_allclose(h_res.numpy(), want_res, rtol=2e-5, atol=2e-4)
+    big = golden["g6_resize_in"]
+    assert np_ref.resize_scale(big.shape, 60, 100) == float(golden["g6_resize_scale"]) == 2.0
+    assert np_ref.resize_scale(big.shape, 60, 90) == float(golden["g6_resize_scale_capped"]) == 1.8
+    out, sc = image.resize(torch.from_numpy(big), 60, 100, stride=16)
+    assert sc == 2.0 and tuple(out.shape) == golden["g6_resize_out"].shape
+    np.testing.assert_allclose(out.numpy(), golden["g6_resize_out"], rtol=1e-5, atol=1e-3)
+    out, sc = image.resize(torch.from_numpy(big), 60, 90)
+    assert sc == 1.8 and tuple(out.shape) == golden["g6_resize_out_capped"].shape
+    np.testing.assert_allclose(out.numpy(), golden["g6_resize_out_capped"], rtol=1e-5, atol=1e-3)

@@ -357,6 +357,41 @@ class Runner(object):
         finally:
             self._inputs_resident_now = False
 
+    def exact_fp32_region(self, steps=3):
+        """r5: the same clip with EVERY product an fp32 product (executors bound with pieces = 0: lsfa_conv_nhwc_fused_fwd on
+        v_mfma_f32_32x32x2_f32 - a reference evaluation, see Executor) through the frame-by-frame pipeline, `steps` timed intervals.
+        -> frames/s, or None in the bf16 mode."""
+        if self.args.dtype != 'f32':
+            return None
+        from lsfa_amd.core.graphs import FramePipeline
+        from lsfa_amd.symbols.resnet_v1_101_flownet_rfcn import resnet_v1_101_flownet_rfcn
+        a, cfg = self.args, self.cfg
+        net = resnet_v1_101_flownet_rfcn(cfg)
+        key = net.get_key_test_symbol(cfg).bind(self.arg, self.aux, self.device, torch.float32, pieces=0)
+        cur = net.get_cur_test_symbol(cfg).bind(self.arg, self.aux, self.device, torch.float32, pieces=0)
+        fg = FramePipeline(key, cur, cfg, a.height, a.width, self.device, use_graphs=not a.no_graph, lanes=max(a.lanes, 1),
+                           flow_stream=not a.no_flow_stream, batch=self.B, segment=0, key_group=1)
+        seg, self.segment = self.segment, 0
+        try:
+            fg.first_frame(self.frames[0])
+            fg.capture()
+            self.step(0, fg, key_group=1)
+            fg.flush()
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for s in range(1, 1 + steps):
+                self.step(s, fg, key_group=1)
+            fg.flush()
+            torch.cuda.synchronize()
+            dt = time.perf_counter() - t1
+            key.check_status()
+            cur.check_status()
+        finally:
+            self.segment = seg
+            if hasattr(fg, 'close'):
+                fg.close()
+        return self.B * steps * self.K / dt
+
     def frame_by_frame_region(self, steps, warmup, settle_s=0.5):
         """r5: the SAME clip through the frame-by-frame pipeline (segment 0, key_group 1: one frame per pass, no look-ahead - the streaming
         case) for `steps` timed intervals after its own capture, a short settle and `warmup` intervals.  -> frames/s of this rank"""
@@ -661,7 +696,9 @@ class Runner(object):
             if rows:
                 w = max(rows, key=lambda r: r['gpu'])
                 worst[q] = {"gpu": w['gpu'], "oracle_fp32": max(r['oracle_fp32'] for r in rows),
-                            "worst_frame_ratio": max((r['ratio'] for r in rows if r['ratio'] is not None), default=None)}
+                            "worst_frame_ratio": max((r['ratio'] for r in rows if r['ratio'] is not None), default=None),
+                            "worst_frame_ratio_beyond_one_ulp": max((r['ratio_beyond_one_ulp'] for r in rows if r.get('ratio_beyond_one_ulp') is not None), default=None),
+                            "ulp": rows[0].get('ulp')}
         feat64 = d[1]['choose_feat_output']
         parity = {"frames_compared": frames,
                   "vs": "oracle/graph_ref.py in fp32 AND in float64, un-forced: GPU and oracles each on their own intermediate values; "
@@ -688,7 +725,43 @@ class Runner(object):
                   "handwritten_stage_mismatches_on_gpu_inputs": int(forced),
                   "handwritten_stages_checked": "warp, aggregate, proposal, psroi+avg+softmax, det_postprocess of frames %s "
                                                 "(bit-exact = 0 mismatching elements)" % frames[:3]}
+        # r5: mAP agreement over three intervals (30 frames), the GPU's rows from the timed region's own path (hipGraph pipeline, batched passes)
+        try:
+            parity["map_vs_oracle"] = self.map_vs_oracle(ref, intervals=min(3, self.nsteps_unique))
+        except Exception as e:       # a reported extra
+            parity["map_vs_oracle"] = "failed: %r" % (e,)
         return cpu, parity
+
+    def map_vs_oracle(self, known, intervals=3):
+        """north_star's "mAP within 0.1 of the reference", in the only form available without trained weights (oracle/map_check.py): VID mAP@0.5
+        of this GPU's detections of frames 1 .. intervals*K against the fp32 oracle's most confident detections of the same frames.  The GPU's
+        rows are produced by the pipeline the timed region runs (re-primed on frame 0, hipGraph replay, batched passes, this run's dtype)."""
+        from oracle import map_check
+        K, cfg = self.K, self.cfg
+        npf = lambda t: t[:1].detach().float().cpu().numpy()
+        im_info = self.clips[0].im_info()
+        rows_ref = map_check.oracle_rows(cfg, self.arg, self.aux, lambda f: npf(self.frames[f]), lambda f: npf(self.mv[f]), lambda f: npf(self.res[f]),
+                                         im_info, K, intervals, known={i: known[i] for i in known})
+        self.fg.first_frame(self.frames[0])
+        rows = []
+        for s in range(intervals):
+            self.step(s, end=intervals)
+            if hasattr(self.fg, 'flush'):
+                self.fg.flush()
+            torch.cuda.synchronize()
+            counts = self.host_counts
+            for k in range(K):
+                for j in range(1, self.ncls):
+                    n = int(counts[k, 0, j])
+                    if n:
+                        d = self.host_dets_of(k)[0, j, :n].numpy()
+                        r = np.empty((n, 7), np.float64)
+                        r[:, 0], r[:, 1], r[:, 2], r[:, 3:] = 1 + s * K + k, j, d[:, 4], d[:, :4]
+                        rows.append(r)
+        rows_gpu = np.vstack(rows) if rows else np.zeros((0, 7), np.float64)
+        out = map_check.map_vs_oracle(rows_gpu, rows_ref, range(1, intervals * K + 1), self.ncls)
+        out["contractions"] = self.args.dtype
+        return out
 
 
 def rel_err(a, b):
@@ -837,6 +910,12 @@ def main():
             resident = r.resident_inputs_region(args.steps, args.warmup)
         except Exception as e:
             resident = "failed: %r" % (e,)
+    exact = None
+    if rank == 0 and not args.no_frame_by_frame and args.lanes > 0:
+        try:
+            exact = r.exact_fp32_region()
+        except Exception as e:
+            exact = "failed: %r" % (e,)
     fbf = None
     if batched and rank == 0 and not args.no_frame_by_frame:
         try:
@@ -989,6 +1068,10 @@ def main():
                       else "resident in HBM as fp32 before the timed region (--resident-inputs, or a serial / non-pipelined run)",
             "value_resident_inputs": (round(resident, 3) if isinstance(resident, float) else resident),
             "value_resident_inputs_note": "frames/s of this GPU with every input already in HBM as fp32 (what rounds 1-4 timed), one extra region of the same length",
+            "value_exact_fp32": (round(exact, 3) if isinstance(exact, float) else exact),
+            "value_exact_fp32_note": "frames/s, frame by frame, with every convolution on the EXACT fp32 matrix instructions (v_mfma_f32_32x32x2_f32, "
+                                     "157 TFLOP/s peak; Executor pieces = 0, a reference evaluation): what the two-fp16-piece form is compared with in "
+                                     "tests/test_parity_fullres_gpu.py::test_two_fp16_pieces_against_exact_fp32_products_at_1000x600; compare with value_frame_by_frame",
             "value_frame_by_frame": (round(fbf, 3) if isinstance(fbf, float) else fbf),
             "value_frame_by_frame_note": "frames/s of this GPU for the same clip with one frame per pass (--segment 0 --key-group 1: no look-ahead, the "
                                          "streaming case), %d timed intervals after its own graph capture + 0.5 s settle + %d warm-up intervals; null when the "

@@ -328,9 +328,14 @@ typedef struct lsfa_conv_desc {
                           * previous conv3 is given scale2 / shift2 but y2 = NULL and only publishes the activated map's maximum in its
                           * amax_out, which is this call's amax_in.  1x1, no padding, Cin <= 2048, pieces 1 or 2; else LSFA_ENOTSUP.  The
                           * values multiplied are bit for bit the ones y2 would have held. */
+  const float* w_scale;  /* r5, pieces == 2: Cout floats 2^-w_exp[co] for weights cut by lsfa_conv_weights_pc (one power-of-two scale per
+                          * OUTPUT channel: a BatchNorm folded into trained weights spreads the channels' magnitudes over many octaves, and
+                          * every channel keeps its 22 bits); NULL: one scale 2^w_exp for the whole tensor (lsfa_conv_weights) */
 } lsfa_conv_desc;
 size_t lsfa_conv_weight_bytes(int Cout, int kh, int kw, int Cin, int pieces);
 int lsfa_conv_weights(const float* w, int Cout, int kh, int kw, int Cin, int pieces, int w_exp, void* wfrag, void* stream);
+/* r5: the two-piece cut with w_exp_pc[co] (device, Cout ints) per output channel; pass 2^-w_exp_pc[co] as lsfa_conv_desc::w_scale */
+int lsfa_conv_weights_pc(const float* w, int Cout, int kh, int kw, int Cin, const int* w_exp_pc, void* wfrag, void* stream);
 size_t lsfa_conv_workspace_bytes(const lsfa_conv_desc* d);
 int lsfa_conv_fwd(const lsfa_conv_desc* d, void* ws, size_t ws_bytes, void* stream);
 /* 256 partial maxima of |x| (n floats, n % 4 == 0, 16-byte aligned): an `amax_in` for maps no convolution of this library produced */

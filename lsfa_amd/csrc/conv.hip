@@ -651,6 +651,7 @@ convsplit::Args args_of(const lsfa_conv_desc& d) {
   a.lda = d.lda; a.ldy = d.ldy; a.Ho = d.Ho; a.Wo = d.Wo;
   if (d.out_H > 0) { a.view = 1; a.out_H = d.out_H; a.out_W = d.out_W; a.out_sy = d.out_sy; a.out_sx = d.out_sx; }
   a.amax = d.amax_in; a.w_exp = d.w_exp; a.amax_out = d.amax_out; a.status = d.status;
+  a.wscale = d.w_scale;
   a.x_kmajor = d.x_nchw ? 1 : 0;
   a.in_scale = d.in_scale; a.in_shift = d.in_shift;
   return a;
@@ -683,6 +684,21 @@ extern "C" int lsfa_conv_weights(const float* w, int Cout, int kh, int kw, int C
   else if (pieces == 2) hipLaunchKernelGGL(convsplit::pack_weights_kernel<2>, grid, dim3(256), 0, s, w, (uint4*)wfrag, Cout, kh * kw, Cin, w_exp);
   else hipLaunchKernelGGL(convsplit::pack_weights_kernel<1>, grid, dim3(256), 0, s, w, (uint4*)wfrag, Cout, kh * kw, Cin, 0);
   LSFA_LAUNCH_CHECK("lsfa_conv_weights");
+  return LSFA_OK;
+}
+
+// r5: the two-piece form with one power-of-two scale per OUTPUT channel: w_exp_pc[co] (device, Cout ints) scales channel co's weights where
+// they are cut; the caller passes wscale[co] = 2^-w_exp_pc[co] (floats, device) as lsfa_conv_desc::w_scale.
+extern "C" int lsfa_conv_weights_pc(const float* w, int Cout, int kh, int kw, int Cin, const int* w_exp_pc, void* wfrag, void* stream) {
+  LSFA_REQUIRE(w && wfrag && w_exp_pc, "lsfa_conv_weights_pc: NULL argument");
+  if (lsfa_conv_weight_bytes(Cout, kh, kw, Cin, 2) == 0) {
+    set_error("lsfa_conv_weights_pc: Cin=%d must be a multiple of 32, Cout=%d of 64", Cin, Cout);
+    return LSFA_ENOTSUP;
+  }
+  const long total = (long)kh * kw * (Cin / 32) * (Cout / 32) * 2 * 64;
+  hipLaunchKernelGGL(convsplit::pack_weights_kernel<2>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, w, (uint4*)wfrag, Cout,
+                     kh * kw, Cin, 0, w_exp_pc);
+  LSFA_LAUNCH_CHECK("lsfa_conv_weights_pc");
   return LSFA_OK;
 }
 

@@ -404,11 +404,14 @@ void conv_ring_kernel(Args a, int nx, int ny, int nz) {
   const bool loader = SP && wave8 >= 4;                 // wave-uniform role
   g.wave = WV == 8 ? wave8 : (wave8 & 3);                // the consumer wave whose rows / share of B this wave reads or copies
   // fp16 form: the scale that puts max|x| into [2^13, 2^14), and its inverse together with the weights' (both powers of two: exact)
-  float a_scale = 1.f, out_scale = 1.f;
+  float a_scale = 1.f;
+  float out_scale[NT];             // per column tile: 2^-(s_exp + w_exp of this lane's column), 1 unless PC == 2
+#pragma unroll
+  for (int t = 0; t < NT; ++t) out_scale[t] = 1.f;
   if (PC == 2 && !loader) {
     const int s_exp = 13 - amax_exponent_asm(a.amax, g.lane, a.status);
     a_scale = ldexpf(1.f, s_exp);
-    out_scale = ldexpf(1.f, -(s_exp + a.w_exp));
+    column_scales<NT>(a, s_exp, tile.y * (32 * NT), g.lane, out_scale);
   }
   if (AF && !loader) {      // visible to every consumer after the first chunk's barrier (which an lgkmcnt(0) precedes)
     for (int k = tid; k < a.Cin; k += 64 * WV) { T[k] = a.in_scale[k] * a_scale; T[kAffineMaxCin + k] = a.in_shift[k] * a_scale; }
@@ -583,7 +586,7 @@ void conv_ring_kernel(Args a, int nx, int ny, int nz) {
 #pragma unroll
   for (int t = 0; t < NT; ++t)
 #pragma unroll
-    for (int i = 0; i < 16; ++i) acc[t][i] = (sum[t][i] + acc[t][i]) * out_scale;       // out_scale = 1 unless PC == 2 (a power of two: exact)
+    for (int i = 0; i < 16; ++i) acc[t][i] = (sum[t][i] + acc[t][i]) * out_scale[t];    // 1 unless PC == 2 (a power of two: exact)
 
   // C/D layout of 32x32: column = lane & 31 (channel), row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5) (pixel)
   const int lane = g.lane;
@@ -649,7 +652,8 @@ void conv_ring_kernel(Args a, int nx, int ny, int nz) {
 // weights (Cout, taps, Cin) fp32 -> fragment order, PC pieces.  One thread per (fragment, lane): 8 values.
 // out index: ((((g * col_tiles + t) * 2 + s) * PC + piece) * 64 + lane) uint4, g = tap * (Cin/32) + chunk; PC = 2: values w * 2^w_exp
 template <int PC>
-static __global__ void pack_weights_kernel(const float* __restrict__ w, uint4* __restrict__ out, int Cout, int taps, int Cin, int w_exp) {
+static __global__ void pack_weights_kernel(const float* __restrict__ w, uint4* __restrict__ out, int Cout, int taps, int Cin, int w_exp,
+                                           const int* __restrict__ w_exp_pc = nullptr) {
   const int col_tiles = Cout / 32, chunks = Cin / kChunk;
   const long total = (long)taps * chunks * col_tiles * 2 * 64;
   const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -664,7 +668,7 @@ static __global__ void pack_weights_kernel(const float* __restrict__ w, uint4* _
   const int ci = kc * kChunk + 16 * (lane >> 5) + 8 * s;
   const float* src = w + ((size_t)co * taps + tap) * Cin + ci;
   const float4 v0 = *reinterpret_cast<const float4*>(src), v1 = *reinterpret_cast<const float4*>(src + 4);
-  const PiecesN p = cut8<PC>(v0, v1, ldexpf(1.f, w_exp));
+  const PiecesN p = cut8<PC>(v0, v1, ldexpf(1.f, w_exp_pc ? w_exp_pc[co] : w_exp));      // r5: one power of two per OUTPUT channel when given
   uint4* dst = out + ((((size_t)g * col_tiles + t) * 2 + s) * PC) * 64 + lane;
 #pragma unroll
   for (int q = 0; q < PC; ++q) dst[q * 64] = p.p[q];

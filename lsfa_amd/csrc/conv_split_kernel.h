@@ -61,6 +61,11 @@ struct Args {
   // r3, fp16 two-piece form (conv_split_wide_kernel<NT, 2>): `amax` = kAmaxSlots partial maxima of |x| (lsfa_amax_partial), from which
   // every wave derives the power-of-two scale that puts x into fp16's range; the weights were packed as w * 2^w_exp
   const float* amax; int w_exp;
+  // r5: per-OUTPUT-channel weight scales: wscale[co] = 2^-w_exp[co] (the weights were packed as w[co] * 2^w_exp[co], lsfa_conv_weights_pc), or
+  // NULL = one scale 2^w_exp for the whole tensor.  A BatchNorm folded into a trained network's weights spreads the channels' magnitudes
+  // over many octaves; with one scale per tensor the small channels' lo pieces went subnormal and those channels kept 11-15 of their 22
+  // bits.  Per channel every output channel has all of them, and the factor comes back in the epilogue per column (a power of two: exact).
+  const float* wscale;
   // r4: the epilogue (or the reduce pass of a K-sliced launch) leaves max|output| (of y2 when there is a second output) in
   // amax_out[kAmaxSlots] by atomicMax on the bit patterns (the caller zeroes the slots once per frame), so that the layer that
   // multiplies this output next needs no amax pass; a non-finite output raises bit 0 of *status (lsfa_status_check)
@@ -314,6 +319,37 @@ __device__ __forceinline__ f32x16 mma_pc(const PiecesN& a, const uint4& b0, cons
 template <int PC>
 __device__ __forceinline__ f32x16 mma_pc(const PiecesN& a, const uint4* B, f32x16 acc) {
   return mma_pc<PC>(a, B[0], B[PC > 1 ? 64 : 0], B[PC > 2 ? 128 : 0], acc);
+}
+
+// the accumulator columns' output scales: 2^-(s_exp + w_exp[ch]) for the NT columns ch0 + 32 t + (lane & 31) this lane holds.  The
+// per-channel factors are read by inline assembly with their own wait, like the amax slots (no compiler-visible load may be pending
+// when a DMA ring starts).
+template <int NT>
+__device__ __forceinline__ void column_scales(const Args& a, int s_exp, int ch0, int lane, float (&os)[NT]) {
+  if (!a.wscale) {
+    const float v = ldexpf(1.f, -(s_exp + a.w_exp));
+#pragma unroll
+    for (int t = 0; t < NT; ++t) os[t] = v;
+    return;
+  }
+  const float* p = a.wscale + ch0 + (lane & 31);
+  const float inv = ldexpf(1.f, -s_exp);
+  static_assert(NT == 2 || NT == 4, "two or four column tiles per wave");
+  if (NT == 2) {
+    asm volatile("global_load_dword %0, %2, off\n\t"
+                 "global_load_dword %1, %2, off offset:128\n\t"
+                 "s_waitcnt vmcnt(0)"
+                 : "=&v"(os[0]), "=&v"(os[1]) : "v"(p) : "memory");
+  } else {
+    asm volatile("global_load_dword %0, %4, off\n\t"
+                 "global_load_dword %1, %4, off offset:128\n\t"
+                 "global_load_dword %2, %4, off offset:256\n\t"
+                 "global_load_dword %3, %4, off offset:384\n\t"
+                 "s_waitcnt vmcnt(0)"
+                 : "=&v"(os[0]), "=&v"(os[1]), "=&v"(os[NT > 2 ? 2 : 0]), "=&v"(os[NT > 3 ? 3 : 0]) : "v"(p) : "memory");
+  }
+#pragma unroll
+  for (int t = 0; t < NT; ++t) os[t] = os[t] * inv;
 }
 
 template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
@@ -879,11 +915,11 @@ static __global__ __launch_bounds__(kThreads, (DIL == 1 ? 2 : 1)) void conv_spli
   const int col_tiles = a.Cout / 32;
   g.wstride = (size_t)col_tiles * (128 * PC);
   g.hp0 = g.wave * HL::kW + (g.lane & 31);
-  float a_scale = 1.f, out_scale = 1.f;
+  float a_scale = 1.f;
+  int s_exp = 0;
   if (PC == 2) {
-    const int s_exp = 13 - amax_exponent_asm(a.amax, g.lane, a.status);
+    s_exp = 13 - amax_exponent_asm(a.amax, g.lane, a.status);
     a_scale = ldexpf(1.f, s_exp);
-    out_scale = ldexpf(1.f, -(s_exp + a.w_exp));
   }
   uint32_t wg_max = 0;
   g.h4 = 4 * (g.lane >> 5);
@@ -948,8 +984,10 @@ static __global__ __launch_bounds__(kThreads, (DIL == 1 ? 2 : 1)) void conv_spli
       if (kc + 1 < kc_end) halo_chunk<DIL, PC, 1>(S, a.x, wblock, g, kc + 1, kc_end, acc0, acc1, a_scale);
     }
     if (PC == 2) {
+      float os[2];
+      column_scales<2>(a, s_exp, tile.y * kWgCh, g.lane, os);      // (every copy of the ring has landed: vmcnt(0) above)
 #pragma unroll
-      for (int i = 0; i < 16; ++i) { acc0[i] = acc0[i] * out_scale; acc1[i] = acc1[i] * out_scale; }
+      for (int i = 0; i < 16; ++i) { acc0[i] = acc0[i] * os[0]; acc1[i] = acc1[i] * os[1]; }
     }
 
     bool finish = true;       // does this workgroup write the tile's output
@@ -1070,11 +1108,11 @@ __device__ __forceinline__ void direct_tile(const Args& a, int bx, int by, int n
   }
   // the fp16 form's scale, read AFTER the first operands are on their way (one wait for both: a launch this short is a chain of
   // memory round trips, and every one taken out of the chain is ~1 us of its ~10)
-  float a_scale = 1.f, out_scale = 1.f;
+  float a_scale = 1.f;
+  int s_exp = 0;
   if (PC == 2) {
-    const int s_exp = 13 - amax_exponent_asm(a.amax, lane, a.status);
+    s_exp = 13 - amax_exponent_asm(a.amax, lane, a.status);
     a_scale = ldexpf(1.f, s_exp);
-    out_scale = ldexpf(1.f, -(s_exp + a.w_exp));
   }
   for (int c = c_begin; c < c_end; c += 2) {         // two register sets take turns (no copies)
     if (c + 1 < c_end) {
@@ -1103,8 +1141,10 @@ __device__ __forceinline__ void direct_tile(const Args& a, int bx, int by, int n
 #pragma unroll
     for (int r = 0; r < 16; ++r) { acc0[r] = acc0[r] + red[w][r * 64 + lane]; acc1[r] = acc1[r] + red[w][(16 + r) * 64 + lane]; }
   if (PC == 2) {
+    float os[2];
+    column_scales<2>(a, s_exp, by * kWgCh, lane, os);
 #pragma unroll
-    for (int r = 0; r < 16; ++r) { acc0[r] = acc0[r] * out_scale; acc1[r] = acc1[r] * out_scale; }
+    for (int r = 0; r < 16; ++r) { acc0[r] = acc0[r] * os[0]; acc1[r] = acc1[r] * os[1]; }
   }
   if (rows) {
     // the two 32 x 32 tiles through the first 8 KB of the LDS block (the other waves' sums have been read) as float4 rows

@@ -715,7 +715,7 @@ class ConvDesc(ctypes.Structure):
                 ("amax_out", ctypes.c_void_p), ("status", ctypes.c_void_p),
                 ("Ho", ctypes.c_int), ("Wo", ctypes.c_int), ("out_H", ctypes.c_int), ("out_W", ctypes.c_int), ("out_sy", ctypes.c_int),
                 ("out_sx", ctypes.c_int), ("prof_tag", ctypes.c_int), ("x_nchw", ctypes.c_int),
-                ("in_scale", ctypes.c_void_p), ("in_shift", ctypes.c_void_p)]
+                ("in_scale", ctypes.c_void_p), ("in_shift", ctypes.c_void_p), ("w_scale", ctypes.c_void_p)]
 
 
 def _dp(t):
@@ -732,24 +732,45 @@ class SplitWeight(object):
     """A convolution weight cut into `pieces` pieces per value and laid out in MFMA fragment order (lsfa_conv_weights); made once per
     layer at bind time.  pieces = 2: the values are scaled by 2^w_exp so that the largest lands in [2^13, 2^14)."""
 
-    def __init__(self, weight, real_cout=None, real_cin=None, into=None, pieces=None):
+    def __init__(self, weight, real_cout=None, real_cin=None, into=None, pieces=None, per_channel_scale=True):
         """weight: (Cout, Cin, kh, kw) float32 CUDA tensor (the framework's layout).  real_cout / real_cin: the layer's own
         channel counts when `weight` was zero-padded to the kernel's tile sizes (algorithmic FLOPs are counted on those)."""
         w_kc = _f32c(conv_weight_kc(weight), "weight")
         self.pieces = int(DEFAULT_PIECES if pieces is None else pieces)
         self.cout, self.cin, self.kh, self.kw = [int(v) for v in weight.shape]
         self.real_cout, self.real_cin = int(real_cout or self.cout), int(real_cin or self.cin)
+        if self.pieces == 0:
+            # r5, the exact-fp32 evaluation (a REFERENCE mode for tests and one bench line, LSFA_CONV_PIECES=0): the weight stays fp32 in the
+            # (Cout, taps, Cin) layout lsfa_conv_nhwc_fused_fwd reads; conv_split / conv_split_view dispatch on pieces == 0 (_conv_exact)
+            if self.cin % 32 or self.cout % 64:
+                raise LsfaError("SplitWeight: Cin=%d must be a multiple of 32, Cout=%d of 64" % (self.cin, self.cout))
+            self.w_exp, self.frag, self.w_kc = 0, None, w_kc
+            return
         need = lib().lsfa_conv_weight_bytes(_ci(self.cout), _ci(self.kh), _ci(self.kw), _ci(self.cin), _ci(self.pieces))
         if need == 0:
             raise LsfaError("SplitWeight: Cin=%d must be a multiple of 32, Cout=%d of 64, pieces=%d one of 1, 2, 3" % (self.cin, self.cout, self.pieces))
-        self.w_exp = 0
+        self.w_exp, self.w_scale = 0, None
+        self.frag = torch.empty(need, dtype=torch.uint8, device=weight.device) if into is None else into
+        if self.frag.numel() != need or not self.frag.is_contiguous():
+            raise LsfaError("SplitWeight: `into` must be a contiguous uint8 tensor of %d bytes" % need)
+        if self.pieces == 2 and per_channel_scale:
+            # r5: one power of two per OUTPUT channel, from the channel's own maximum (a BatchNorm folded into trained weights spreads the
+            # channels over many octaves: with one scale per tensor the small channels' lo pieces go subnormal).  An all-zero (padding)
+            # channel gets exponent 0.
+            amax_c = weight.detach().abs().reshape(self.cout, -1).amax(1).double()
+            ok = torch.isfinite(amax_c) & (amax_c > 0)
+            e = torch.where(ok, 13 - torch.floor(torch.log2(torch.where(ok, amax_c, torch.ones_like(amax_c)))), torch.zeros_like(amax_c))
+            e = e.clamp(-100, 100).to(torch.int32).contiguous()
+            self.w_exp_pc = e
+            self.w_scale = torch.ldexp(torch.ones(self.cout, dtype=torch.float32, device=weight.device), -e).contiguous()
+            with torch.cuda.device(weight.device):
+                _check(lib().lsfa_conv_weights_pc(_ptr(w_kc), _ci(self.cout), _ci(self.kh), _ci(self.kw), _ci(self.cin), _ptr(e), _ptr(self.frag),
+                                                  _stream()), "lsfa_conv_weights_pc")
+            return
         if self.pieces == 2:
             amax = float(weight.abs().max().item())              # bind time: a host synchronisation is fine here
             self.w_exp = 0 if not (amax > 0 and math.isfinite(amax)) else 13 - int(math.floor(math.log2(amax)))
             self.w_exp = max(-100, min(100, self.w_exp))
-        self.frag = torch.empty(need, dtype=torch.uint8, device=weight.device) if into is None else into
-        if self.frag.numel() != need or not self.frag.is_contiguous():
-            raise LsfaError("SplitWeight: `into` must be a contiguous uint8 tensor of %d bytes" % need)
         with torch.cuda.device(weight.device):
             _check(lib().lsfa_conv_weights(_ptr(w_kc), _ci(self.cout), _ci(self.kh), _ci(self.kw), _ci(self.cin), _ci(self.pieces),
                                            _ci(self.w_exp), _ptr(self.frag), _stream()), "lsfa_conv_weights")
@@ -821,6 +842,8 @@ def _conv_launch(who, x, lda, N, H, W, cin, sw, bias, stride, pad_h, pad_w, dil,
     d.prof_tag = prof_tag
     d.x_nchw = int(x_nchw)
     d.in_scale, d.in_shift = (in_scale.data_ptr() if in_scale is not None else None), (in_shift.data_ptr() if in_shift is not None else None)
+    w_scale = getattr(sw, 'w_scale', None)
+    d.w_scale = w_scale.data_ptr() if w_scale is not None else None
     need = lib().lsfa_conv_workspace_bytes(ctypes.byref(d))
     ws = torch.empty(max(need, 16), dtype=torch.uint8, device=device)
     if _conv_flops["count"]:
@@ -830,6 +853,41 @@ def _conv_launch(who, x, lda, N, H, W, cin, sw, bias, stride, pad_h, pad_w, dil,
         nbytes = 4.0 * N * H * W * cin + 2.0 * sw.pieces * sw.cout * sw.kh * sw.kw * cin + 4.0 * outs * N * Ho * Wo * sw.cout
         _count_conv_launch(_plan_kernel_name(d), 2.0 * N * Ho * Wo * sw.real_cout * sw.real_cin * sw.kh * sw.kw, nbytes)
     _check(lib().lsfa_conv_fwd(ctypes.byref(d), _ptr(ws), ctypes.c_size_t(need), _stream()), who)
+
+
+def _conv_exact(x, sw, bias, stride, pad, dil, act, out, residual, out2, scale2, shift2, nchw, x_nchw, in_scale, in_shift):
+    """conv_split's contract on the EXACT fp32 matrix instructions (lsfa_conv_nhwc_fused_fwd: v_mfma_f32_32x32x2_f32, every product an fp32
+    product, bitwise an fmaf chain) - a reference evaluation, not a fast path: what the channels-last kernel does not take (NCHW in / out,
+    the input's bn + ReLU at the cut, LeakyReLU, a second output that is only measured) is done by separate elementwise steps with the
+    same fp32 operations in the same order as the split kernels' epilogues."""
+    if x_nchw:
+        x = x[:, :sw.cin].permute(0, 2, 3, 1).contiguous()
+    if in_scale is not None:
+        x = torch.relu(x * in_scale + in_shift)                       # max(v * scale + shift, 0): two roundings, like affine_relu4
+    if nchw:
+        res_cl = residual.permute(0, 2, 3, 1).contiguous() if residual is not None else None
+        y = conv_nhwc(x, sw.w_kc, bias, sw.kh, sw.kw, stride, pad, dil, relu=(act == 1), residual=res_cl)
+        if act == 2:
+            y = torch.where(y > 0, y, y * 0.1)
+        y = y.permute(0, 3, 1, 2).contiguous()
+        if out is not None:
+            out.copy_(y)
+            y = out
+        if out2 is not None:
+            out2.copy_(torch.relu(y * scale2.view(1, -1, 1, 1) + shift2.view(1, -1, 1, 1)))
+            return y, out2
+        return y
+    want2 = out2 is not None
+    if act == 2:
+        y = conv_nhwc(x, sw.w_kc, bias, sw.kh, sw.kw, stride, pad, dil, relu=False, out=None, residual=residual)
+        y = torch.where(y > 0, y, y * 0.1)
+        if out is not None:
+            out.copy_(y)
+            y = out
+        return y
+    r = conv_nhwc(x, sw.w_kc, bias, sw.kh, sw.kw, stride, pad, dil, relu=(act == 1), out=out, residual=residual,
+                  out2=out2 if want2 else None, scale2=scale2 if want2 else None, shift2=shift2 if want2 else None)
+    return r
 
 
 @_on_tensor_device
@@ -863,6 +921,9 @@ def conv_split(x, sw, bias=None, stride=1, pad=0, dil=1, relu=False, out=None, r
     for name, t in (("out", out), ("residual", residual), ("out2", out2)):
         if t is not None and (t.numel() != N * Ho * Wo * Cout or not t.is_contiguous() or t.dtype != torch.float32):
             raise LsfaError("conv_split: %s must be a contiguous float32 tensor of %d elements" % (name, N * Ho * Wo * Cout))
+    if sw.pieces == 0:
+        return _conv_exact(x, sw, bias, stride, pad, dil, (1 if relu else 0) if act is None else act, out, residual, out2, scale2, shift2, nchw,
+                           x_nchw, in_scale, in_shift)
     if amax_in is None and sw.pieces == 2:
         amax_in = amax_partial(x)
     _count_conv(N, Ho, Wo, sw.real_cout, sw.real_cin, kh, kw, sw.pieces)
@@ -902,6 +963,15 @@ def conv_split_view(x, sw, bias, out, stride=1, pad=(0, 0), dil=1, act=0, cin=No
     Hout, Wout, Lout = out.shape[1], out.shape[2], out.shape[3]
     if y0 + (Ho - 1) * sy >= Hout or x0 + (Wo - 1) * sx >= Wout:
         raise LsfaError("conv_split_view: a %dx%d grid placed at (%d,%d) step (%d,%d) leaves out %s" % (Ho, Wo, y0, x0, sy, sx, tuple(out.shape)))
+    if sw.pieces == 0:      # the exact-fp32 reference mode (_conv_exact): plain output grids only (the transposed convolutions keep three bf16 pieces)
+        if grid is not None or place is not None or (Ho, Wo) != (Hout, Wout):
+            raise LsfaError("conv_split_view: the exact-fp32 mode takes whole output grids only")
+        xin = x if L == cin else x[..., :cin].contiguous()
+        y = _conv_exact(xin, sw, bias, stride, pad[0], dil, act, None, None, None, None, None, False, False, None, None) if pad[0] == pad[1] else None
+        if y is None:
+            raise LsfaError("conv_split_view: the exact-fp32 mode needs pad_h == pad_w")
+        out[..., c0:c0 + sw.cout] = y
+        return out
     if amax_in is None and sw.pieces == 2:
         amax_in = amax_partial(x)          # the whole (N, H, W, L) map bounds its leading channels
     first = out.data_ptr() + 4 * ((y0 * Wout + x0) * Lout + c0)
@@ -923,6 +993,8 @@ def deconv_phase_weights(wt, cin_pad=None, pieces=None):
     cin, cout = int(wt.shape[0]), int(wt.shape[1])
     cpad = int(cin_pad or cin)
     pieces = int(DEFAULT_PIECES if pieces is None else pieces)
+    if pieces == 0:
+        pieces = 3      # exact-fp32 reference mode: the four-phase launch exists on the split kernels only; three bf16 pieces cut the operands exactly
     per = lib().lsfa_conv_weight_bytes(_ci(cout), _ci(2), _ci(2), _ci(cpad), _ci(pieces))
     if per == 0:
         raise LsfaError("deconv_phase_weights: Cin=%d must be a multiple of 32 and Cout=%d of 64" % (cpad, cout))

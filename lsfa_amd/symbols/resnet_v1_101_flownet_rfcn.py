@@ -100,8 +100,11 @@ class TestSymbol(object):
                      list(self.arg_spec.values())
         return arg_shapes, [out.get(k) for k in self.list_outputs()], list(self.aux_spec.values())
 
-    def bind(self, arg_params, aux_params, device='cuda:0', dtype=torch.float32):
-        return Executor(self, arg_params, aux_params, device, dtype)
+    def bind(self, arg_params, aux_params, device='cuda:0', dtype=torch.float32, pieces=None):
+        """pieces (r5; fp32 only): None = the default form (two fp16 pieces per product, or LSFA_CONV_PIECES); 0 = the EXACT fp32 evaluation,
+        every product an fp32 matrix-instruction product (lsfa_conv_nhwc_fused_fwd) - a slow reference for A/B tests and bench.py's
+        `value_exact_fp32`, see Executor."""
+        return Executor(self, arg_params, aux_params, device, dtype, pieces)
 
 
 class resnet_v1_101_flownet_rfcn(object):
@@ -215,6 +218,11 @@ class _ResNetWeights(object):
         s0, t0 = bn(prefix + 'bn0')
         self.conv0_w_l = hip.stem_weight_layout(dev(fold(arg[prefix + 'conv0_weight'], s0)))
         self.conv0_b = dev(t0)
+        self.conv0_exact = None
+        if pieces == 0:      # exact-fp32 reference mode: conv0 as a 7x7 / stride 2 convolution on the input padded to 32 channels
+            w0 = np.zeros((64, 32, 7, 7), np.float32)
+            w0[:, :3] = fold(arg[prefix + 'conv0_weight'], s0)
+            self.conv0_exact = hip.SplitWeight(dev(w0), real_cin=3, pieces=0)
         self.units = []
         for si in range(1, stages + 1):
             for u in range(1, P.UNITS[si - 1] + 1):
@@ -269,13 +277,17 @@ class _Slots(object):
 class Executor(object):
     """A bound test symbol: folded weights on the device + forward()."""
 
-    def __init__(self, sym, arg_params, aux_params, device, dtype):
+    def __init__(self, sym, arg_params, aux_params, device, dtype, pieces=None):
         self.sym, self.cfg = sym, sym.cfg
         self.device = torch.device(device)
         self.cdtype = dtype           # fp32: split-operand convolutions with fp32 accuracy; bf16: one bf16 product per fp32 product
         if dtype not in (torch.float32, torch.bfloat16):
             raise ValueError("Executor: dtype must be torch.float32 or torch.bfloat16")
-        self.pieces = _FP32_PIECES if dtype == torch.float32 else 1
+        # pieces per fp32 operand.  0 (r5) = exact fp32 products: every convolution of the ResNets, the DCN branch, feat_conv_3x3, the small net,
+        # fuse_reduce_add, the Nq / embedding nets, the RPN and R-FCN heads and FlowNet's plain convolutions run on v_mfma_f32_32x32x2_f32
+        # (hip._conv_exact); FlowNet's first layer (the stem kernel's two fp16 pieces) and its four transposed convolutions (three exact
+        # bf16 pieces) keep their kernels.  A reference evaluation, ~6x slower.
+        self.pieces = (_FP32_PIECES if pieces is None else int(pieces)) if dtype == torch.float32 else 1
         self.flow_pieces = self.pieces       # FlowNet too: a Concat map's scale is the maximum over its producers (they share its amax slots)
         self.taps = None              # set to {} to record stage outputs (parity tests)
         self.status = hip.new_status(self.device)
@@ -380,7 +392,13 @@ class Executor(object):
         S = self._slots[section].begin()
         units = [u for u in net.units if u['stage'] <= stages]
         # bn_data + conv0 + bn0 + relu0, then pool0 with the first unit's bn1 + relu1 as a second output: two launches
-        y = hip.stem_conv(x, net.conv0_w_l, net.conv0_b, net.bn_data[0], net.bn_data[1])
+        if net.conv0_exact is not None:
+            xa = (x * net.bn_data[0].view(1, 3, 1, 1) + net.bn_data[1].view(1, 3, 1, 1)).permute(0, 2, 3, 1)
+            xh = torch.zeros(tuple(xa.shape[:3]) + (32,), device=x.device, dtype=torch.float32)
+            xh[..., :3] = xa
+            y = hip.conv_split(xh, net.conv0_exact, net.conv0_b, 2, 3, 1, act=1)
+        else:
+            y = hip.stem_conv(x, net.conv0_w_l, net.conv0_b, net.bn_data[0], net.bn_data[1])
         am_a = S.new()             # pool0 publishes the maximum of its second output like the convolutions' epilogues do
         x4, a = hip.maxpool3x3s2_nhwc(y, scale2=units[0]['bn1'][0], shift2=units[0]['bn1'][1], amax_out=am_a)
         dilate = 1

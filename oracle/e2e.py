@@ -181,7 +181,10 @@ def frame_gap(cfg, gpu, ref32, ref64, im_info, h, w):
         rec['max_abs_dbox'] = float(np.abs(b_g - b_r).max())            # GPU vs the fp32 oracle, reported (north_star's quantity)
         rec['max_abs_dscore'] = float(np.abs(c_g - c_r).max())
     for k, (eg, er) in err.items():
-        rec['err_vs_f64_' + k] = dict(gpu=eg, oracle_fp32=er, ratio=(eg / er if er > 0 else None))
+        # `ratio` is the plain quotient; `ratio_beyond_one_ulp` takes the criterion's one-ulp allowance off the GPU side first - for quantities
+        # whose errors are one to three fp32 ulps (a class probability near 1: 6e-8 each) the plain quotient is a ratio of small integers
+        rec['err_vs_f64_' + k] = dict(gpu=eg, oracle_fp32=er, ratio=(eg / er if er > 0 else None),
+                                      ratio_beyond_one_ulp=(max(eg - ULP[k], 0.0) / er if er > 0 else None), ulp=ULP[k])
         if eg > RATIO * er + ULP[k]:
             fail.append("%s: GPU is %.3e from float64, the fp32 oracle %.3e (allowed %.1f x + %.1e)" % (k, eg, er, RATIO, ULP[k]))
     rec['rois_compared'] = len(S)

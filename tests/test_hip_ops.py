@@ -1444,6 +1444,50 @@ def test_conv_fp16_form_with_a_wide_per_channel_weight_range(hip):
     assert errs[2] <= 2.0 * errs[3] + 1e-7, errs
 
 
+def test_conv_fp16_form_takes_one_weight_scale_per_output_channel(hip):
+    """r5 (VERDICT r4, weak point 2): a trained pre-activation ResNet's conv3 / shortcut rows follow its residual stream's channel
+    magnitudes - 2^+-8 per channel with a few channels 2^14 above that (tests/test_parity_fullres_gpu.py::trained_like_batchnorm): 2^25 and
+    more between the largest and the smallest output channel of ONE weight.  With r4's single power-of-two scale per weight tensor
+    (per_channel_scale=False) the small channels' hi pieces keep a few bits and their lo pieces none: those OUTPUT channels come out with
+    errors of 1e-3 ... 1 of their own magnitude.  With one scale per output channel (lsfa_conv_weights_pc + lsfa_conv_desc::w_scale, the
+    default) every channel is as accurate as the three-piece bf16 form, which has no scale.  Checked on a 1x1 (ring kernel, loader /
+    consumer waves), a 3x3 on a small map (direct kernel) and through the K-sliced reduce pass; the per-channel factor costs nothing
+    in exactness (powers of two) - a weight with equal channels gives the same bits under both scalings."""
+    g = torch.Generator(device=DEV).manual_seed(23)
+    for H, W, ci, co, k, slices in ((38, 63, 256, 1024, 1, 0), (19, 32, 64, 64, 3, 0), (38, 63, 512, 256, 1, 2)):
+        f = torch.exp2(torch.empty(co, device=DEV).uniform_(-8.0, 8.0, generator=g))
+        f[torch.rand(co, device=DEV, generator=g) < 0.02] *= 2.0 ** 14
+        f[0], f[1] = f.max() * 2.0, f.min() * 0.5                       # both ends present whatever the seed
+        w = torch.randn((co, ci, k, k), device=DEV, generator=g) * (1.0 / (ci * k * k) ** 0.5) * f.view(-1, 1, 1, 1)
+        x = torch.relu(torch.randn((2, H, W, ci), device=DEV, generator=g)) * 2.0
+        ref = torch.nn.functional.conv2d(x.permute(0, 3, 1, 2).double().cpu(), w.double().cpu(), padding=k // 2).permute(0, 2, 3, 1)
+        own = ref.abs().amax(dim=(0, 1, 2))
+        am = hip.amax_partial(x)
+        err = {}
+        try:
+            if slices:
+                hip.conv_plan_override(kernel=2, nt=4, st=3, slices=slices)
+            for tag, sw in (("per_channel", hip.SplitWeight(w, pieces=2)), ("per_tensor", hip.SplitWeight(w, pieces=2, per_channel_scale=False)),
+                            ("three_bf16", hip.SplitWeight(w, pieces=3))):
+                status = hip.new_status(DEV)
+                y = hip.conv_split(x, sw, None, 1, k // 2, 1, amax_in=am, status=status)
+                hip.check_status(status)
+                err[tag] = float(((y.double().cpu() - ref).abs().amax(dim=(0, 1, 2)) / own).max())
+        finally:
+            hip.conv_plan_override()
+        K = ci * k * k
+        assert err["per_channel"] <= 2e-6 * K ** 0.5 and err["per_channel"] <= 2.0 * err["three_bf16"] + 1e-7, (H, W, ci, co, k, err)
+        assert err["per_tensor"] >= 1e-4, (err, "the premise: one scale per tensor loses these channels")
+    # equal channels: the same bits either way
+    w = torch.randn((128, 64, 3, 3), device=DEV, generator=g) * 0.05
+    w = w * (w.abs().reshape(128, -1).amax(1).max() / w.abs().reshape(128, -1).amax(1)).view(-1, 1, 1, 1) * 0.999      # every channel's maximum in one octave
+    x = torch.randn((1, 20, 33, 64), device=DEV, generator=g)
+    am = hip.amax_partial(x)
+    a = hip.conv_split(x, hip.SplitWeight(w, pieces=2), None, 1, 1, 1, amax_in=am)
+    b = hip.conv_split(x, hip.SplitWeight(w, pieces=2, per_channel_scale=False), None, 1, 1, 1, amax_in=am)
+    assert torch.equal(a, b)
+
+
 @pytest.mark.parametrize("pieces", [2, 3])
 def test_conv_ring_every_plan_gives_the_same_convolution(hip, pieces):
     """lsfa_conv_plan_override: the ring kernel under every tile width x ring depth x K cut the plan may choose computes the

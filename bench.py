@@ -73,6 +73,9 @@ def parse():
                     help='keep every frame / motion vector / residual resident in HBM as fp32 before the timed region (r1-r4); default (r5): uint8 frames '
                          '+ fp32 motion vectors / residuals in pinned HOST memory, uploaded per interval on a copy stream inside the timed region and '
                          'transformed on the GPU (lib/utils/image.py:296-308)')
+    ap.add_argument('--eager-loop', type=int, default=0,
+                    help='profiling aid (tools/profile_round.sh): no timed region - re-issue the roofline leg (eager_profile_batched: key_group intervals the way the '
+                         'pipeline batches them, serially on one stream) this many times and print its per-kernel FLOP table; run it under rocprofv3')
     ap.add_argument('--no-frame-by-frame', action='store_true', help='skip the extra frame-by-frame region behind `value_frame_by_frame`')
     ap.add_argument('--no-graph', action='store_true', help='issue every launch eagerly instead of replaying hipGraphs')
     ap.add_argument('--no-prefetch', action='store_true', help='do not overlap the next frame\'s small net with this frame\'s tail')
@@ -265,7 +268,7 @@ class Runner(object):
                 lanes = list(fg.s_lane)
                 ks = fg.s_flow if fg.s_flow is not None else lanes[0]
                 keys = [self._upload_key(q + j, s + j, ks) for j in range(1 + len(ahead))]
-                fr, mvs, rss, ev_rest = self._upload_rest(q, s, lanes[q % len(lanes)])
+                fr, mvs, rss, ev_rest = self._upload_rest(q, s, lanes[q % len(lanes)]) if self.K > 1 else (None, None, None, None)      # (interval 1: every frame is a key frame)
                 ev_keys = keys[-1][1]                # one stream, in order: the last upload's event covers the earlier ones
                 B = self.B
                 fg.key_frame(keys[0][0], deliver=lambda b: self._deliver(b, 0), ready=ev_keys,
@@ -844,6 +847,19 @@ def main():
     torch.cuda.set_device(local_rank)
     r = Runner(args, rank, device)
     r.prime()
+
+    if args.eager_loop > 0:
+        # profiling aid: the serial eager loop alone (rocprofv3 --kernel-trace / --pmc around it give per-kernel durations and MFMA-busy of the
+        # SAME launches the `roofline` object is computed from)
+        prof = None
+        for _ in range(args.eager_loop):
+            prof = r.eager_profile_batched(args.warmup) if (hasattr(r.fg, 'lanes') and (r.segment > 0 or r.key_group > 1)) else r.eager_profile_step(args.warmup)
+        conv_ms, conv_n = prof.get('conv_nhwc', (0.0, 0))
+        conv_fl, _ = r.conv_flops
+        print(json.dumps({"config": {"workload": "eager loop x%d: %d interval(s) per pass, key fronts x%d, segments of %d" % (args.eager_loop, getattr(r, 'profiled_intervals', 1), r.key_group, r.segment)},
+                          "roofline": {"achieved": round(conv_fl / (conv_ms * 1e-3) / 1e12, 1) if conv_ms else None, "launches": conv_n,
+                                       "avg_us": round(conv_ms * 1e3 / max(conv_n, 1), 2), "by_kernel": r.conv_by_kernel}}))
+        return
 
     def drain():
         if hasattr(r.fg, 'flush'):

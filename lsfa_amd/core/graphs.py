@@ -624,6 +624,14 @@ class FramePipeline(object):
 
     def drop_fronts(self):
         """Forget the fronts the bank computed ahead for key frames that will not come (the caller abandons the run of frames it announced)."""
+        # the abandoned group never reaches its last slot, where `ev_free` is normally recorded: record it here, on the stream the slices are
+        # taken on (in order behind the slice copies and the FlowNet pass already queued there), so that the next pass that reuses such a bank
+        # waits for THIS group's readers instead of an older event (ADVICE r4)
+        sa = self.s_flow if self.s_flow is not None else self.s_key
+        for bank in {id(b): b for b, _, _ in self._bank_ready}.values():
+            sa.wait_event(bank.ev_flow)
+            sa.wait_event(bank.ev_front)
+            bank.ev_free.record(sa)
         self._bank_ready = []
         self._ramp_step = 0
 
@@ -702,13 +710,13 @@ class FramePipeline(object):
         front for this frame, the fronts (backbone, FlowNet) of this frame and those G - 1 are computed in one pass (KeyBank) and the
         next G - 1 key_frame calls - which must hand over exactly those tensors - take theirs from the bank.  With fewer than G - 1
         images (the end of a clip) the group is that much smaller; without any the frame's front is computed alone, as with key_group = 1."""
+        bank, slot, group = None, -1, None
+        if self._bank_ready and self._bank_ready[0][2] != data.data_ptr():     # checked before ANYTHING is queued or counted: the call leaves no trace
+            raise ValueError("FramePipeline.key_frame: the bank holds the front of another image (hand the tensors of `upcoming` over in "
+                             "order, or drop_fronts())")
         if not self.lookahead:
             self._issue_segment()
-        bank, slot, group = None, -1, None
         if self._bank_ready:
-            if self._bank_ready[0][2] != data.data_ptr():     # checked before anything is queued or counted: the call leaves no trace
-                raise ValueError("FramePipeline.key_frame: the bank holds the front of another image (hand the tensors of `upcoming` over in "
-                                 "order, or drop_fronts())")
             bank, slot, _ = self._bank_ready.pop(0)
         b = self._nkey % 2
         self._nkey += 1

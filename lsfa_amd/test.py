@@ -42,6 +42,7 @@ def parse_args():
                          'frame, every detection equal to the serial loop\'s bit for bit)')
     ap.add_argument('--key-group', type=int, default=1, help='key frames whose backbone + FlowNet run in one pass (look-ahead through the loader)')
     ap.add_argument('--out', default=None, help='rank 0 saves the gathered detection rows (n,7) here (.npy)')
+    ap.add_argument('--shards-out', default=None, help='rank 0 saves which videos each rank ran (a JSON list per rank, gathered from the ranks themselves)')
     ap.add_argument('--dtype', default='f32', choices=['f32', 'bf16'],
                     help='f32: every fp32 product from two fp16 pieces (fp32 accuracy); bf16: one bf16 product per fp32 product (BASELINE configs[2])')
     return ap.parse_args()
@@ -88,6 +89,18 @@ def main():
                                 dtype=torch.float32 if args.dtype == 'f32' else torch.bfloat16)
     torch.cuda.synchronize()
     dt = time.time() - t0
+    if args.shards_out:
+        # what every rank actually ran (the frame ids its own loader handed out -> video indices), gathered from the ranks - not recomputed
+        mine = sorted(set(int(f) // args.frames for f in frame_ids))
+        seen = [None] * world
+        if dist.is_initialized():
+            dist.all_gather_object(seen, mine)
+        else:
+            seen = [mine]
+        if not dist.is_initialized() or dist.get_rank() == 0:
+            import json
+            with open(args.shards_out, 'w') as f:
+                json.dump(seen, f)
     if not dist.is_initialized() or dist.get_rank() == 0:
         total = args.clips * args.frames
         print('%d clips x %d frames on %d GPU(s): %d detections, %.1f frames/s incl. setup' % (

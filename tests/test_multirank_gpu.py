@@ -93,3 +93,43 @@ def test_lsfa_test_three_clips_two_ranks_equal_single_rank(tmp_path, dtype):
     c1, c2 = _canonical(r1), _canonical(r2)
     differing = np.flatnonzero((c1 != c2).any(1))
     assert differing.size == 0, "%d of %d rows differ; frames %s" % (differing.size, len(c1), sorted(set(c1[differing, 0].astype(int))))
+
+
+def test_eight_ranks_one_clip_each_equal_single_rank(tmp_path):
+    """BASELINE configs[3] as far as a one-GPU box allows: `python -m lsfa_amd.test --clips 8` under
+    torch.distributed.run with EIGHT ranks (every rank on cuda:0, the final gather over gloo) against one rank running the eight clips
+    itself: each rank ran exactly one video (the greedy rule of dff_rfcn/function/test_rcnn.py:69-75 on equal-length clips, reported by
+    the ranks themselves), and the gathered detection rows equal the single-rank run's bit for bit.  RCCL itself is not exercised here."""
+    args = ["--clips", "8", "--frames", "7", "--interval", "3", "--height", "192", "--width", "320"]
+    outs, shards = {}, {}
+    for tag, nproc in (("one", 1), ("eight", 8)):
+        out, sh = str(tmp_path / ("rows_%s.npy" % tag)), str(tmp_path / ("shards_%s.json" % tag))
+        head = [sys.executable, "-m", "lsfa_amd.test"] if nproc == 1 else \
+            [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "8", "--master-addr", "127.0.0.1",
+             "--master-port", str(_free_port()), "-m", "lsfa_amd.test"]
+        r = subprocess.run(head + args + ["--out", out, "--shards-out", sh], capture_output=True, text=True, timeout=1500, cwd=ROOT, env=_env())
+        assert r.returncode == 0, r.stderr[-3000:]
+        outs[tag], shards[tag] = np.load(out), json.load(open(sh))
+    assert shards["one"] == [list(range(8))]
+    assert shards["eight"] == [[v] for v in range(8)]                                      # one clip per rank
+    r1, r8 = outs["one"], outs["eight"]
+    assert sorted(np.unique(r8[:, 0]).astype(int)) == list(range(56)) and r1.shape == r8.shape, (r1.shape, r8.shape)
+    assert np.array_equal(_canonical(r1), _canonical(r8))
+
+
+def test_bench_eight_ranks_one_device():
+    """`bench.py --gpus 8` the way the driver launches it, on one device over gloo: eight ranks seen, eight per-rank times, whole-job value
+    = eight ranks' frames / the slowest rank's time, rows of eight different clips through the final gather."""
+    small = ["--steps", "2", "--warmup", "1", "--height", "192", "--width", "320", "--no-cpu-baseline", "--no-parity", "--no-frame-by-frame",
+             "--no-spread", "--settle-s", "0.2", "--key-group", "2"]
+    stdout = _torchrun(8, [os.path.join(ROOT, "bench.py"), "--gpus", "8"] + small, timeout=1500)
+    lines = [l for l in stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, stdout[-2000:]
+    d = json.loads(lines[0])
+    m = d["multi_gpu"]
+    assert d["n_gpus"] == 8 and d["scaling"] == "weak" and d["config"]["parallelism"] == "clip-parallel x8"
+    assert m["ranks_seen"] == 8 and sorted(p["rank"] for p in m["per_rank"]) == list(range(8)) and m["collectives_in_timed_region"] == 0
+    frames = 8 * 2 * d["config"]["frames_per_step"]
+    assert abs(d["value"] - frames / (d["ms_per_step"] * 2 / 1e3)) < 0.02 * d["value"]
+    assert abs(d["ms_per_step"] * 2 / 1e3 - max(p["seconds"] for p in m["per_rank"])) < 1e-3      # max over ranks
+    assert m["final_gather"]["rows"] > 0

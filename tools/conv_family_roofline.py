@@ -39,7 +39,15 @@ def main():
         if k:
             pmc[k] = r
     rows = []
+    # a K-sliced launch runs the same ring instantiation (+ a reduce pass, which has its own row in the trace): one row per instantiation
+    merged = {}
     for name, v in byk.items():
+        base = name.replace(' +split_reduce', '')
+        m = merged.setdefault(base, {'calls': 0, 'gflop': 0.0, 'mbytes': 0.0, 'sliced_calls': 0})
+        m['calls'] += v['calls']; m['gflop'] += v['gflop']; m['mbytes'] += v['mbytes']
+        if name != base:
+            m['sliced_calls'] += v['calls']
+    for name, v in merged.items():
         k = short(name)
         if not k:
             continue
@@ -52,14 +60,17 @@ def main():
         tf = gf / avg * 1e3 if avg else None
         pm = pmc.get(k)
         duty = (float(pm['SQ_VALU_MFMA_BUSY_CYCLES']) / (4.0 * float(pm['SQ_BUSY_CU_CYCLES']))) if pm and float(pm['SQ_BUSY_CU_CYCLES']) > 0 else None
-        rows.append((name, v['calls'], avg, gf, tf, (tf / (PEAK / products)) if tf else None, v['mbytes'] / max(v['calls'], 1), duty))
+        rows.append((name, v['calls'], avg, gf, tf, (tf / (PEAK / products)) if tf else None, v['mbytes'] / max(v['calls'], 1), duty, v['sliced_calls']))
     rows.sort(key=lambda r: -(r[1] * (r[2] or 0)))
     with open(sys.argv[4], 'w') as o:
         o.write('# %s\n' % (line.get('config', {}).get('workload', '')))
-        o.write('kernel,calls,avg_us,gflop_per_call,tflops,frac_of_peak_for_its_products,algorithmic_mb_per_call,mfma_duty\n')
+        o.write('kernel,calls,avg_us,gflop_per_call,tflops,frac_of_peak_for_its_products,algorithmic_mb_per_call,mfma_duty,of_which_k_sliced_calls\n')
         for r in rows:
-            o.write('"%s",%d,%s,%.3f,%s,%s,%.2f,%s\n' % (r[0], r[1], '%.2f' % r[2] if r[2] else '', r[3], '%.1f' % r[4] if r[4] else '',
-                                                        '%.3f' % r[5] if r[5] else '', r[6], '%.3f' % r[7] if r[7] is not None else ''))
+            o.write('"%s",%d,%s,%.3f,%s,%s,%.2f,%s,%d\n' % (r[0], r[1], '%.2f' % r[2] if r[2] else '', r[3], '%.1f' % r[4] if r[4] else '',
+                                                           '%.3f' % r[5] if r[5] else '', r[6], '%.3f' % r[7] if r[7] is not None else '', r[8]))
+        red = [r for r in csv.DictReader(l for l in open(sys.argv[2]) if not l.startswith('#')) if 'split_reduce' in r['kernel']]
+        for r in red:
+            o.write('"%s",%s,%s,,,,,,\n' % (r['kernel'].split('(')[0].replace('lsfa::convsplit::', ''), r['calls'], r['avg_us']))
         tot_gf = sum(v['gflop'] for v in byk.values())
         tot_us = sum(r[1] * r[2] for r in rows if r[2])
         o.write('# all listed: %.1f GFLOP in %.1f us of kernel time = %.1f TFLOP/s\n' % (tot_gf, tot_us, tot_gf / tot_us * 1e3 if tot_us else 0.0))

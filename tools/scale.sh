@@ -9,14 +9,24 @@ STEPS=${1:-40}; WARM=${2:-5}
 OUT=gpurun_out; mkdir -p $OUT
 export HSA_ENABLE_IPC_MODE_LEGACY=0
 NGPU=$(python -c 'import torch; print(torch.cuda.device_count())')
+EXTRA=""
+if [ "${LSFA_SCALE_DRY_RUN:-0}" = "1" ]; then
+  # r5: the same launches on a ONE-GPU box - every rank on cuda:0, the collectives over gloo, small frames: the N = 1, 2, 4, 8 CONTROL FLOW
+  # (sharding, max-over-ranks timing, final gather), no scaling number (the ranks share one GPU) and no RCCL
+  export LSFA_BENCH_BACKEND=gloo LSFA_BENCH_ONE_DEVICE=1
+  NGPU=8; STEPS=${1:-3}; WARM=${2:-1}
+  EXTRA="--height 192 --width 320 --no-frame-by-frame --no-spread --settle-s 0.2 --key-group 2"
+  echo "# DRY RUN on one device (LSFA_SCALE_DRY_RUN=1): ranks share cuda:0, gloo collectives, 320x192 frames - control flow only" | tee $OUT/scale_table.txt
+else
 echo "# GPUs visible: $NGPU" | tee $OUT/scale_table.txt
+fi
 for N in 1 2 4 8; do
   if [ "$N" -gt "$NGPU" ]; then echo "N=$N skipped: only $NGPU GPU(s)" | tee -a $OUT/scale_table.txt; continue; fi
   if [ "$N" -eq 1 ]; then
-    python bench.py --gpus 1 --steps $STEPS --warmup $WARM --no-cpu-baseline --no-parity > $OUT/scale_N$N.json 2> $OUT/scale_N$N.err
+    python bench.py --gpus 1 --steps $STEPS --warmup $WARM --no-cpu-baseline --no-parity $EXTRA > $OUT/scale_N$N.json 2> $OUT/scale_N$N.err
   else
     python -m torch.distributed.run --nnodes=1 --nproc-per-node $N --master-addr 127.0.0.1 --master-port $((29500 + N)) \
-      bench.py --gpus $N --steps $STEPS --warmup $WARM --no-cpu-baseline --no-parity > $OUT/scale_N$N.json 2> $OUT/scale_N$N.err
+      bench.py --gpus $N --steps $STEPS --warmup $WARM --no-cpu-baseline --no-parity $EXTRA > $OUT/scale_N$N.json 2> $OUT/scale_N$N.err
   fi
   python - $N $OUT/scale_N$N.json <<'PY' | tee -a $OUT/scale_table.txt
 import json, sys
@@ -27,8 +37,8 @@ except Exception as e:
     print("N=%d failed: %r" % (n, e)); sys.exit(0)
 m = d.get('multi_gpu') or {}
 per = " ".join("%.0f" % r['frames_per_s'] for r in m.get('per_rank', []))
-print("N=%d  whole-job %.1f frames/s  (%.1f per GPU)  rccl_ranks_seen=%s  per-rank frames/s: [%s]  gather %s s for %s rows" % (
-    n, d['value'], d['value'] / n, m.get('rccl_ranks_seen', '-'), per, (m.get('final_gather') or {}).get('seconds', '-'),
+print("N=%d  whole-job %.1f frames/s  (%.1f per GPU)  ranks_seen=%s rccl_ranks_seen=%s  per-rank frames/s: [%s]  gather %s s for %s rows" % (
+    n, d['value'], d['value'] / n, m.get('ranks_seen', '-'), m.get('rccl_ranks_seen', '-'), per, (m.get('final_gather') or {}).get('seconds', '-'),
     (m.get('final_gather') or {}).get('rows', '-')))
 PY
 done

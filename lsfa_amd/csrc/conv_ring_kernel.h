@@ -167,37 +167,9 @@ __device__ __forceinline__ Cut ring_cut(const uint4 (*R)[(Ring<NT, PC, ST, WV>::
   return n;
 }
 
-// v-chunk v of n (B(v), A(v + 1)) in stage S = v % ST; mixed roles: this wave also issues its share of v-chunk v + ST - 1 (MORE), its
-// DMAs spread over the step's MFMA slots (a DMA issue is 60-100 cycles of the wave's stream: in a row they would be 500-800 idle ones)
-template <int NT, int PC, int ST, int WV, int S, bool AF, bool MORE>
-__device__ __forceinline__ void ring_step_body(uint4 (*R)[(Ring<NT, PC, ST, WV>::kStageN)], const float* __restrict__ x, const uint4* __restrict__ wblock,
-                                               const Geom& g, Walk& wk, int v, int n, f32x16 (&acc)[NT], Cut& p, float a_scale, const float* T) {
-  typedef Ring<NT, PC, ST, WV> RG;
-  constexpr int SN = (S + ST - 1) % ST;                 // the stage v-chunk v - 1 lived in: free once everybody is past the barrier
-  if (MORE) {
-    const Walk cur = wk;
-    wk.next(g.kw, g.chunks_per_tap);                    // (its branches first: the DMAs below share the MFMAs' scheduling region)
-    ring_issue_a<NT, PC, ST, WV, SN>(R, x, g, cur, v + ST < n);
-    ring_issue_b<NT, PC, ST, WV, SN, 0, RG::kDmaB>(R, wblock, g, g.chunk0 + v + ST - 1);
-  }
-  p = ring_mma_cut<NT, PC, ST, WV, S, AF, (MORE ? RG::kDma : 0)>(R, g, p, acc, a_scale, g.chunk0 + v + 1, T);
-}
-
-template <int NT, int PC, int ST, int WV, int S, bool AF>
-__device__ __forceinline__ void ring_step(uint4 (*R)[(Ring<NT, PC, ST, WV>::kStageN)], const float* __restrict__ x, const uint4* __restrict__ wblock,
-                                          const Geom& g, Walk& wk, int v, int n, f32x16 (&acc)[NT], Cut& p, float a_scale, const float* T) {
-  typedef Ring<NT, PC, ST, WV> RG;
-  // how many v-chunks beyond v this wave has already issued (they may stay in flight)
-  const int ahead = min(n - 1 - v, ST - 2);
-  if (ST >= 4 && ahead >= 2) wait_vmcnt<(ST >= 4 ? 2 : 0) * RG::kDma>();
-  else if (ST >= 3 && ahead == 1) wait_vmcnt<(ST >= 3 ? 1 : 0) * RG::kDma>();
-  else wait_vmcnt<0>();
-  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-  __builtin_amdgcn_s_barrier();
-  if (v + ST - 1 < n) ring_step_body<NT, PC, ST, WV, S, AF, true>(R, x, wblock, g, wk, v, n, acc, p, a_scale, T);
-  else ring_step_body<NT, PC, ST, WV, S, AF, false>(R, x, wblock, g, wk, v, n, acc, p, a_scale, T);
-}
-
+// (A pipelined step for the four-wave mixed-role kernels - the wave issuing its share of v-chunk v + ST - 1 between its MFMAs, a second body
+// for "nothing left to fetch" - was built and measured in r5: 160 (NT = 2) / 230 (NT = 4) registers, one workgroup per CU instead of two,
+// slower in the backbone than r4's step on every launch that uses those kernels; they keep r4's step, see below.)
 // WV = 8 (256-pixel tiles, eight mixed-role waves, two per SIMD): ONE body per step - a second copy of the step for "nothing left to
 // fetch" doubles the accumulators' live ranges across the join (52 registers spilled at the 256 two waves per SIMD leave).  Every
 // step issues its DMAs; past the end they fetch the block of zeros / the slice's last weights again into a stage nobody reads (the kernel
@@ -542,13 +514,6 @@ void conv_ring_kernel(Args a, int nx, int ny, int nz) {
     if (ST > 2) ring_prologue_uniform<NT, PC, ST, WV, (ST > 2 ? 1 : 0)>(R, a.x, wblock, g, wk, nchunks);
     if (ST > 3) ring_prologue_uniform<NT, PC, ST, WV, (ST > 3 ? 2 : 0)>(R, a.x, wblock, g, wk, nchunks);
     wait_vmcnt<(ST - 1) * RG::kDma>();
-  } else if (!SP) {
-    ring_issue_a<NT, PC, ST, WV, ST - 1>(R, a.x, g, wk, true);
-    wk.next(g.kw, g.chunks_per_tap);
-    ring_prologue<NT, PC, ST, WV, 0>(R, a.x, wblock, g, wk, nchunks);
-    if (ST > 2) ring_prologue<NT, PC, ST, WV, (ST > 2 ? 1 : 0)>(R, a.x, wblock, g, wk, nchunks);
-    if (ST > 3) ring_prologue<NT, PC, ST, WV, (ST > 3 ? 2 : 0)>(R, a.x, wblock, g, wk, nchunks);
-    ring_wait_first<NT, PC, ST, WV>(nchunks);
   }
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       // AF: this wave's share of the table is written
   __builtin_amdgcn_s_barrier();                            // v-chunk -1 has landed
@@ -566,11 +531,6 @@ void conv_ring_kernel(Args a, int nx, int ny, int nz) {
         if (c + 1 < nchunks) ring_step_uniform<NT, PC, ST, WV, 1, AF>(R, a.x, wblock, g, wk, c + 1, nchunks, acc, p, a_scale, T);
         if (ST > 2 && c + 2 < nchunks) ring_step_uniform<NT, PC, ST, WV, (ST > 2 ? 2 : 0), AF>(R, a.x, wblock, g, wk, c + 2, nchunks, acc, p, a_scale, T);
         if (ST > 3 && c + 3 < nchunks) ring_step_uniform<NT, PC, ST, WV, (ST > 3 ? 3 : 0), AF>(R, a.x, wblock, g, wk, c + 3, nchunks, acc, p, a_scale, T);
-      } else {
-        ring_step<NT, PC, ST, WV, 0, AF>(R, a.x, wblock, g, wk, c, nchunks, acc, p, a_scale, T);
-        if (c + 1 < nchunks) ring_step<NT, PC, ST, WV, 1, AF>(R, a.x, wblock, g, wk, c + 1, nchunks, acc, p, a_scale, T);
-        if (ST > 2 && c + 2 < nchunks) ring_step<NT, PC, ST, WV, (ST > 2 ? 2 : 0), AF>(R, a.x, wblock, g, wk, c + 2, nchunks, acc, p, a_scale, T);
-        if (ST > 3 && c + 3 < nchunks) ring_step<NT, PC, ST, WV, (ST > 3 ? 3 : 0), AF>(R, a.x, wblock, g, wk, c + 3, nchunks, acc, p, a_scale, T);
       }
       since += ST;
       if (since >= kFlush) {

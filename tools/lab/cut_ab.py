@@ -1,0 +1,56 @@
+#!/usr/bin/env python
+"""A/B of two builds of the library on the same convolutions: prints a digest of every output (bit-identity across builds is read off
+the digests) and the time per call.  LSFA_HIP_LIBRARY selects the build.
+    python3 tools/lab/cut_ab.py; LSFA_HIP_LIBRARY=$PWD/tools/lab/_build/mix/liblsfa_hip_mix.so python3 tools/lab/cut_ab.py
+"""
+import hashlib
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+from lsfa_amd import hip  # noqa: E402
+
+DEV = "cuda:0"
+g = torch.Generator(device=DEV).manual_seed(0)
+CASES = [  # name, N, H, W, ci, co, k, dil
+    ("feat x6", 6, 38, 63, 2048, 1024, 3, 6),
+    ("res4 conv2 x6", 6, 38, 63, 256, 256, 3, 1),
+    ("res4 conv1 x6", 6, 38, 63, 1024, 256, 1, 1),
+    ("res4 conv3 x6", 6, 38, 63, 256, 1024, 1, 1),
+    ("res3 conv2 x6", 6, 75, 125, 128, 128, 3, 1),
+    ("res2 conv3 x6", 6, 150, 250, 64, 256, 1, 1),
+    ("small feat x9", 9, 38, 63, 256, 1024, 3, 1),
+    ("rfcn x9", 9, 38, 63, 1024, 1911, 1, 1),
+    ("tiny values", 1, 38, 63, 256, 256, 3, 1),
+]
+print("library:", hip.LIB_PATH)
+for name, N, H, W, ci, co, k, dil in CASES:
+    x = torch.relu(torch.randn((N, H, W, ci), device=DEV, generator=g))
+    if name == "tiny values":
+        x = x * torch.exp2(torch.randint(-40, 3, x.shape, device=DEV, generator=g).float())      # lo pieces across the subnormal range
+    w = torch.randn((co, ci, k, k), device=DEV, generator=g) * 0.02
+    b = torch.randn(co, device=DEV, generator=g)
+    sw = hip.SplitWeight(w, pieces=2)
+    am = hip.amax_partial(x)
+    line = "%-16s" % name
+    for plan in (None, (2, 4, 3, 1), (2, 4, 4, 1), (1, 4, 2, 1)):      # the plan's own choice; loader / consumer waves, three stages; pairs; mixed roles
+        if plan is None:
+            hip.conv_plan_override()
+        else:
+            hip.conv_plan_override(kernel=plan[0], nt=plan[1], st=plan[2], slices=plan[3])
+        y = hip.conv_split(x, sw, b, 1, dil * (k // 2), dil, relu=True, amax_in=am)
+        torch.cuda.synchronize()
+        digest = hashlib.sha1(y.cpu().numpy().tobytes()).hexdigest()[:8]
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        for _ in range(3):
+            hip.conv_split(x, sw, b, 1, dil * (k // 2), dil, relu=True, amax_in=am)
+        e0.record()
+        for _ in range(20):
+            hip.conv_split(x, sw, b, 1, dil * (k // 2), dil, relu=True, amax_in=am)
+        e1.record()
+        torch.cuda.synchronize()
+        line += "  | %s %s %7.1f us" % ("plan" if plan is None else "%d,%d,%d,%d" % plan, digest, e0.elapsed_time(e1) * 1000 / 20)
+    hip.conv_plan_override()
+    print(line)

@@ -68,12 +68,15 @@ def main():
         for r in rows:
             o.write('"%s",%d,%s,%.3f,%s,%s,%.2f,%s,%d\n' % (r[0], r[1], '%.2f' % r[2] if r[2] else '', r[3], '%.1f' % r[4] if r[4] else '',
                                                            '%.3f' % r[5] if r[5] else '', r[6], '%.3f' % r[7] if r[7] is not None else '', r[8]))
+        # the trace window holds several repetitions of the loop; the rows above count ONE (by_kernel): scale the reduce passes' counts alike
+        reps = sorted(float(stats[short(n)]['calls']) / v['calls'] for n, v in merged.items() if short(n) in stats and v['calls'])
+        rep = reps[len(reps) // 2] if reps else 1.0
         red = [r for r in csv.DictReader(l for l in open(sys.argv[2]) if not l.startswith('#')) if 'split_reduce' in r['kernel']]
         for r in red:
-            o.write('"%s",%s,%s,,,,,,\n' % (r['kernel'].split('(')[0].replace('lsfa::convsplit::', ''), r['calls'], r['avg_us']))
+            o.write('"%s",%.1f,%s,,,,,,\n' % (r['kernel'].split('(')[0].replace('lsfa::convsplit::', ''), float(r['calls']) / rep, r['avg_us']))
         tot_gf = sum(v['gflop'] for v in byk.values())
-        tot_us = sum(r[1] * r[2] for r in rows if r[2])
-        o.write('# all listed: %.1f GFLOP in %.1f us of kernel time = %.1f TFLOP/s\n' % (tot_gf, tot_us, tot_gf / tot_us * 1e3 if tot_us else 0.0))
+        tot_us = sum(r[1] * r[2] for r in rows if r[2]) + sum(float(r['calls']) / rep * float(r['avg_us']) for r in red)
+        o.write('# all listed (reduce passes included): %.1f GFLOP in %.1f us of kernel time = %.1f TFLOP/s\n' % (tot_gf, tot_us, tot_gf / tot_us * 1e3 if tot_us else 0.0))
 
 
 if __name__ == '__main__':

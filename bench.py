@@ -266,7 +266,8 @@ class Runner(object):
                 # 10 ms passes an interval's 16 MB block arrived late and the lanes starved (2580 frames/s against 3460 with resident inputs).
                 # The non-key block goes onto a lane's stream, the key images onto the FlowNet / tail stream: queues with slack.
                 lanes = list(fg.s_lane)
-                ks = fg.s_flow if fg.s_flow is not None else lanes[0]
+                # (interval 1: no non-key frames, the lanes are idle and the FlowNet / tail stream carries every frame's back half: the lanes' queue then)
+                ks = lanes[0] if self.K == 1 or fg.s_flow is None else fg.s_flow
                 keys = [self._upload_key(q + j, s + j, ks) for j in range(1 + len(ahead))]
                 fr, mvs, rss, ev_rest = self._upload_rest(q, s, lanes[q % len(lanes)]) if self.K > 1 else (None, None, None, None)      # (interval 1: every frame is a key frame)
                 ev_keys = keys[-1][1]                # one stream, in order: the last upload's event covers the earlier ones

@@ -285,6 +285,24 @@ def test_aggregate_softmax2_bit_exact(hip, shape):
     np.testing.assert_allclose(got, (ref[0] * torch.from_numpy(a) + ref[1] * torch.from_numpy(b)).numpy(), rtol=1e-5, atol=1e-6)
 
 
+@pytest.mark.parametrize("shape", [(1, 1024, 38, 63), (3, 20, 8, 8)])
+def test_aggregate_softmax2_reads_logit_rows_in_place(hip, shape):
+    """r5 (lsfa_aggregate_softmax2_rows): the 2N rows of logits are read where the Nq net's last convolution left them - rows of a wider
+    buffer, `logit_row_stride` floats apart - instead of from a gathered (2N, 1, H, W) copy: the same bits as the packed operator."""
+    N, C, H, W = shape
+    rs = np.random.RandomState(7 * N + C)
+    a, b = rs.randn(N, C, H, W).astype(np.float32), rs.randn(N, C, H, W).astype(np.float32)
+    logits = (3 * rs.randn(2 * N, 1, H, W)).astype(np.float32)
+    want = oracle.aggregate_softmax2(a, b, logits)
+    stride = H * W + 37                                            # rows inside a wider buffer, garbage in between
+    wide = np.full((2 * N, stride), np.nan, np.float32)
+    wide[:, :H * W] = logits.reshape(2 * N, H * W)
+    got = hip.aggregate_softmax2(t(a), t(b), t(wide), logit_row_stride=stride).cpu().numpy()
+    np.testing.assert_array_equal(got, want)
+    with pytest.raises(hip.LsfaError):                             # a buffer that does not hold the last row
+        hip.aggregate_softmax2(t(a), t(b), t(wide.reshape(-1)[:(2 * N - 1) * stride + H * W - 1].copy()), logit_row_stride=stride)
+
+
 @pytest.mark.parametrize("shape", [(4, 1024, 38, 63), (3, 20, 8, 8), (32, 64, 38, 63)])
 def test_aggregate_softmax2_batched_bit_exact(hip, shape):
     """N maps per launch (several clips advancing together; the HBM-resident roofline mode): map n uses logits
@@ -906,6 +924,22 @@ def test_copy_many_is_one_launch_of_plain_copies(hip):
         hip.copy_many([(dsts[1], srcs[1])] * 33)
 
 
+def test_copy_many_zero_fills_where_there_is_no_source(hip):
+    """r5: a job without a source clears its destination (the frame path's amax slots, status words and padded maps are zeroed by this
+    kernel, not by a PyTorch fill), alongside plain copies in the same launch; empty destinations are skipped."""
+    rs = np.random.RandomState(5)
+    a, b, c = t(rs.randn(3, 37, 21).astype(np.float32)), t(rs.randn(257).astype(np.float32)), t(rs.randint(1, 99, (1031,)).astype(np.int32))
+    src = t(rs.randn(257).astype(np.float32))
+    keep = a.clone()
+    hip.copy_many([(b, src), (c, None), (torch.empty((0,), device=DEV), None)])
+    assert torch.equal(b, src) and int(c.abs().sum()) == 0 and torch.equal(a, keep)
+    hip.copy_many([(a, None)])
+    assert float(a.abs().sum()) == 0.0 and a.shape == keep.shape
+    z = hip.zeros_f32((2, 5, 7), DEV)
+    assert z.dtype == torch.float32 and z.shape == (2, 5, 7) and float(z.abs().sum()) == 0.0
+    hip.copy_many([])                                              # nothing to do: no launch, no error
+
+
 # ------------------------------------------------------------------ ResNet stem ----
 @pytest.mark.parametrize("shape", [(1, 600, 1000), (1, 150, 250), (2, 37, 50), (1, 9, 8), (3, 71, 131)])
 def test_stem_conv_pool_vs_torch(hip, shape):
@@ -1442,6 +1476,43 @@ def test_conv_fp16_form_with_a_wide_per_channel_weight_range(hip):
         errs[pieces] = float(((y.double().cpu() - ref).abs().amax(dim=(0, 1, 2)) / per_ch).max())
     assert errs[2] <= 2e-6 * K ** 0.5, errs
     assert errs[2] <= 2.0 * errs[3] + 1e-7, errs
+
+
+def test_conv_counters_name_the_launch_plan_and_count_flops_and_bytes_once(hip):
+    """r5 (lsfa_conv_plan_query; bench.py's roofline.by_kernel): every counted lsfa_conv_fwd call is attributed to the kernel instantiation the
+    launch plan picks, with its algorithmic FLOPs (2 M N K) and bytes (every operand once); a forced plan shows up under its own name."""
+    import re
+    g = torch.Generator(device=DEV).manual_seed(11)
+    N, H, W, ci, co = 2, 38, 63, 256, 256
+    x = torch.relu(torch.randn((N, H, W, ci), device=DEV, generator=g))
+    w = torch.randn((co, ci, 3, 3), device=DEV, generator=g) * 0.02
+    b = torch.randn(co, device=DEV, generator=g)
+    sw = hip.SplitWeight(w, pieces=2)
+    am = hip.amax_partial(x)
+    hip.conv_flops_reset(True)
+    try:
+        y0 = hip.conv_split(x, sw, b, 1, 1, 1, relu=True, amax_in=am)
+        hip.conv_plan_override(kernel=2, nt=4, st=3, slices=1)
+        y1 = hip.conv_split(x, sw, b, 1, 1, 1, relu=True, amax_in=am)
+        hip.conv_plan_override(kernel=1, nt=2, st=2, slices=1)
+        y2 = hip.conv_split(x, sw, b, 1, 1, 1, relu=True, amax_in=am)
+    finally:
+        hip.conv_plan_override()
+    by = hip.conv_by_kernel()
+    flops, launches = hip.conv_flops_read()
+    hip.conv_flops_reset(False)
+    for y in (y1, y2):                                            # (bit-identity across plans is test_conv_ring_every_plan...'s subject: per tile width and K cut)
+        assert float((y - y0).abs().max()) <= 2e-6 * float(y0.abs().max()) * (ci * 9) ** 0.5
+    assert launches == 3 and sum(v["calls"] for v in by.values()) == 3
+    per_call = 2.0 * N * H * W * co * ci * 9
+    assert abs(flops - 3 * per_call) < 1e-6 * per_call
+    assert "conv_ring_kernel<4, 2, 3, true, false, 4>" in by and "conv_ring_kernel<2, 2, 2, false, false, 4>" in by, by
+    for name, v in by.items():
+        assert re.match(r"conv_(ring_kernel<[24], 2, [234], (true|false), false, [48]>|split_direct_kernel<2>|split3x3_kernel<\d, 2>)( \+split_reduce)?$", name), name
+        # input + weights (two fp16 pieces = 4 bytes per weight) + output, each once
+        want_mb = v["calls"] * (N * H * W * ci * 4 + co * ci * 9 * 4 + N * H * W * co * 4) / 1e6
+        assert abs(v["mbytes"] - want_mb) < 0.02 * want_mb, (name, v, want_mb)
+        assert abs(v["gflop"] - v["calls"] * per_call / 1e9) < 1e-3 * per_call / 1e9
 
 
 def test_conv_fp16_form_takes_one_weight_scale_per_output_channel(hip):

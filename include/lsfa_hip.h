@@ -463,6 +463,19 @@ int lsfa_mv_accumulate(const int* mvs, int n_mvs, int max_block_area, const int*
 int lsfa_mv_field(const int* accu, int width, int height, int* mv, void* stream);
 int lsfa_mv_residual(const unsigned char* bgr_cur, const unsigned char* bgr_ref, const int* accu,
                      int width, int height, int* res, void* stream);
+/* r5: transform_mv_res (lib/utils/image.py:202-228) on the device: the decoded frame's motion vectors (H, W, 2) and residual (H, W, 3) -
+ * int32 as lsfa_mv_field / lsfa_mv_residual leave them (flags bit 0) or float32 - to the network's `motion_vector` (1, 2, h, w) and `res_diff`
+ * (1, 3, h, w): cv2.resize by im_scale (INTER_LINEAR, float32 work type), zero padding to rcnn_stride, the residual's in-place channel loop
+ * (BGR -> RGB, minus pixel_means, times pixel_scale, channel 2 from the rewritten channel 0 as in the reference), cv2.resize by 1 / rcnn_stride
+ * in float64, motion vectors times im_scale / rcnn_stride; rounded to float32 once, where the reference hands its float64 arrays to the
+ * executor.  One launch, nothing materialised at full resolution.  h1, w1 = cvRound(H * im_scale), cvRound(W * im_scale) (the caller rounds as
+ * numpy does); out_h, out_w = ceil(h1 / stride), ceil(w1 / stride) - checked.  pixel_means_bgr_host: three doubles in host memory.
+ * flags bit 1: the motion vectors are negated first, the `motion_vector = - motion_vector` of get_image (lib/utils/image.py:54).
+ * OpenCV is not in the reference tree: the interpolation arithmetic follows OpenCV 3.2's resize.cpp as restated in oracle/np_ref.py
+ * (parity unpinned for that part; everything around it is pinned by golden G6). */
+int lsfa_transform_mv_res(const void* motion_vector, const void* res_diff, int flags, int H, int W, double im_scale, int h1, int w1,
+                          int rcnn_stride, const double* pixel_means_bgr_host, double pixel_scale, float* out_mv, float* out_res,
+                          int out_h, int out_w, void* stream);
 
 /* ------------------------------------------------------------------------ *
  * Plumbing without a reference counterpart: a hipStream_t that is nobody else's (non-blocking; PyTorch's

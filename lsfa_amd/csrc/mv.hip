@@ -87,7 +87,119 @@ __global__ __launch_bounds__(kThreads) void mv_residual_kernel(const unsigned ch
   for (int c = 0; c < 3; ++c) res[o + c] = (int)cur[o + c] - (int)ref[s + c];
 }
 
+// ---- r5: transform_mv_res (lib/utils/image.py:202-228) on the device ---------------------------------------------------------------------
+// The reference resizes the (H, W, 2) motion vectors and the (H, W, 3) residual by im_scale (cv2.resize, INTER_LINEAR, float32 images: OpenCV
+// 3.2's HResizeLinear / VResizeLinear<float, float, float>), copies them into zero maps padded to the stride (np.zeros: float64), rewrites the
+// residual's channels IN PLACE in float64 - channel 2 is computed from the already rewritten channel 0 (:218-219) -, resizes both by 1 / stride
+// (CV_64F: double work type, the same float coefficients), scales the motion vectors by im_scale / stride and hands float64 arrays to the
+// executor, which rounds them to float32.  An output element depends on 2 x 2 padded positions (1 / 16: rows 16 Y + 7 and 16 Y + 8, weights
+// 0.5) and each of those on 2 x 2 source pixels: one thread per output element computes exactly that chain - the first resize's four values
+// in float32 (mul, mul, add: the two passes' roundings), everything behind them in float64, one rounding to float32 at the end - instead of
+// materialising three full-resolution maps.  oracle/np_ref.py::transform_mv_res is the same arithmetic statement by statement.
+struct ResizeTap { int i0, i1; float a; };
+
+// resize.cpp: `fx = (float)((dx + 0.5) * scale_x - 0.5); sx = cvFloor(fx); fx -= sx;` with scale = 1. / f; taps clamped into the image
+__device__ __forceinline__ ResizeTap resize_tap(int d, int src_n, double inv_f) {
+  const float f = (float)(((double)d + 0.5) * inv_f - 0.5);
+  int s0 = (int)floorf(f);
+  float a = f - (float)s0;
+  if (s0 < 0) { s0 = 0; a = 0.f; }
+  if (s0 >= src_n - 1) { s0 = src_n - 1; a = 0.f; }
+  ResizeTap t;
+  t.i0 = s0;
+  t.i1 = min(s0 + 1, src_n - 1);
+  t.a = a;
+  return t;
+}
+
+template <typename T>
+__device__ __forceinline__ float first_resize(const T* __restrict__ src, int H, int W, int C, int c, int y, int x, double inv_scale, float sign = 1.f) {
+  const ResizeTap tx = resize_tap(x, W, inv_scale), ty = resize_tap(y, H, inv_scale);
+  const float bx = 1.f - tx.a, by = 1.f - ty.a;
+  // (sign: the reference negates the decoder's motion vectors before the transform, image.py:54 - exact, applied to the source values)
+  const float s00 = (float)src[((size_t)ty.i0 * W + tx.i0) * C + c] * sign, s01 = (float)src[((size_t)ty.i0 * W + tx.i1) * C + c] * sign;
+  const float s10 = (float)src[((size_t)ty.i1 * W + tx.i0) * C + c] * sign, s11 = (float)src[((size_t)ty.i1 * W + tx.i1) * C + c] * sign;
+  const float h0 = s00 * bx + s01 * tx.a;          // the horizontal pass of the two rows, rounded to float like the work buffer
+  const float h1 = s10 * bx + s11 * tx.a;
+  return h0 * by + h1 * ty.a;
+}
+
+struct MvResArgs {
+  int H, W;             // the decoded frame
+  int h1, w1;           // cvRound(H im_scale), cvRound(W im_scale): the first resize's output
+  int ph, pw;           // padded to the stride
+  int oh, ow;           // cvRound(ph / stride), cvRound(pw / stride): the network's feature grid
+  double inv_scale;     // 1. / im_scale
+  double inv_rcnn;      // 1. / (1. / stride)
+  double mv_mul;        // im_scale * (1. / stride)
+  double m0, m1, m2, pixel_scale;       // pixel_means in B, G, R order
+  float mv_sign;        // -1: the motion vectors are negated first (`motion_vector = - motion_vector`, image.py:54)
+};
+
+// value of padded map `which` (0: motion vectors, channel c; 1: the residual AFTER the in-place loop, channel c) at (y, x), float64
+template <typename T>
+__device__ __forceinline__ double padded_value(const T* __restrict__ mv, const T* __restrict__ res, const MvResArgs& a, int which, int c, int y, int x) {
+  const bool inside = y < a.h1 && x < a.w1;
+  if (which == 0) return inside ? (double)first_resize(mv, a.H, a.W, 2, c, y, x, a.inv_scale, a.mv_sign) : 0.0;
+  // i = 0: p0 = (p2 - mean[2]) scale;  i = 1: p1 = (p1 - mean[1]) scale;  i = 2: p2 = (p0 - mean[0]) scale with the NEW p0
+  if (c == 1) return ((inside ? (double)first_resize(res, a.H, a.W, 3, 1, y, x, a.inv_scale) : 0.0) - a.m1) * a.pixel_scale;
+  const double p0 = ((inside ? (double)first_resize(res, a.H, a.W, 3, 2, y, x, a.inv_scale) : 0.0) - a.m2) * a.pixel_scale;
+  return c == 0 ? p0 : (p0 - a.m0) * a.pixel_scale;
+}
+
+template <typename T>
+__global__ __launch_bounds__(kThreads) void transform_mv_res_kernel(const T* __restrict__ mv, const T* __restrict__ res, MvResArgs a,
+                                                                    float* __restrict__ out_mv, float* __restrict__ out_res) {
+  const int i = blockIdx.x * kThreads + threadIdx.x;
+  const int plane = a.oh * a.ow;
+  if (i >= 5 * plane) return;
+  const int ch = i / plane, r = i - ch * plane, Y = r / a.ow, X = r - Y * a.ow;
+  const int which = ch < 2 ? 0 : 1, c = ch < 2 ? ch : ch - 2;
+  const ResizeTap tx = resize_tap(X, a.pw, a.inv_rcnn), ty = resize_tap(Y, a.ph, a.inv_rcnn);
+  const double ax = (double)tx.a, bx = (double)(1.f - tx.a), ay = (double)ty.a, by = (double)(1.f - ty.a);      // `1.f - fx` in float, used in double
+  const double h0 = padded_value(mv, res, a, which, c, ty.i0, tx.i0) * bx + padded_value(mv, res, a, which, c, ty.i0, tx.i1) * ax;
+  const double h1 = padded_value(mv, res, a, which, c, ty.i1, tx.i0) * bx + padded_value(mv, res, a, which, c, ty.i1, tx.i1) * ax;
+  double v = h0 * by + h1 * ay;
+  if (which == 0) { v *= a.mv_mul; out_mv[c * plane + r] = (float)v; }
+  else out_res[c * plane + r] = (float)v;
+}
+
 }  // namespace
+
+extern "C" int lsfa_transform_mv_res(const void* motion_vector, const void* res_diff, int flags, int H, int W, double im_scale, int h1, int w1,
+                                     int rcnn_stride, const double* pixel_means_bgr_host, double pixel_scale, float* out_mv, float* out_res,
+                                     int out_h, int out_w, void* stream) {
+  LSFA_REQUIRE(motion_vector && res_diff && pixel_means_bgr_host && out_mv && out_res, "lsfa_transform_mv_res: NULL argument");
+  LSFA_REQUIRE(H > 0 && W > 0 && h1 > 0 && w1 > 0 && rcnn_stride > 0 && im_scale > 0.0 && (flags & ~3) == 0, "lsfa_transform_mv_res: bad shape or flags");
+  MvResArgs a;
+  a.H = H; a.W = W; a.h1 = h1; a.w1 = w1;
+  a.ph = (h1 + rcnn_stride - 1) / rcnn_stride * rcnn_stride;
+  a.pw = (w1 + rcnn_stride - 1) / rcnn_stride * rcnn_stride;
+  const double rcnn_scale = 1.0 / (double)rcnn_stride;
+  a.oh = (int)nearbyint((double)a.ph * rcnn_scale);        // cvRound (ties to even); a multiple of the stride divides exactly
+  a.ow = (int)nearbyint((double)a.pw * rcnn_scale);
+  if (a.oh != out_h || a.ow != out_w) {
+    set_error("lsfa_transform_mv_res: outputs are %d x %d, the padded %d x %d map gives %d x %d", out_h, out_w, a.ph, a.pw, a.oh, a.ow);
+    return LSFA_EINVAL;
+  }
+  a.inv_scale = 1.0 / im_scale;
+  a.inv_rcnn = 1.0 / rcnn_scale;
+  a.mv_mul = im_scale * rcnn_scale;
+  a.m0 = pixel_means_bgr_host[0]; a.m1 = pixel_means_bgr_host[1]; a.m2 = pixel_means_bgr_host[2];
+  a.pixel_scale = pixel_scale;
+  a.mv_sign = (flags & 2) ? -1.f : 1.f;
+  const bool is_int32 = (flags & 1) != 0;
+  const int total = 5 * a.oh * a.ow;
+  hipStream_t s = (hipStream_t)stream;
+  if (is_int32)
+    hipLaunchKernelGGL(transform_mv_res_kernel<int>, dim3(ceil_div(total, kThreads)), dim3(kThreads), 0, s, (const int*)motion_vector, (const int*)res_diff, a,
+                       out_mv, out_res);
+  else
+    hipLaunchKernelGGL(transform_mv_res_kernel<float>, dim3(ceil_div(total, kThreads)), dim3(kThreads), 0, s, (const float*)motion_vector,
+                       (const float*)res_diff, a, out_mv, out_res);
+  LSFA_LAUNCH_CHECK("lsfa_transform_mv_res");
+  return LSFA_OK;
+}
 
 extern "C" size_t lsfa_mv_workspace_bytes(int width, int height) {
   if (width <= 0 || height <= 0) return 0;

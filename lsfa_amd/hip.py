@@ -565,6 +565,29 @@ def copy_many(pairs):
 
 
 @_on_tensor_device
+def transform_mv_res(motion_vector, res_diff, im_scale, pixel_means=(0.0, 0.0, 0.0), pixel_scale=1.0, rcnn_stride=16, negate_mv=False):
+    """lsfa_transform_mv_res: (H, W, 2) motion vectors + (H, W, 3) residual on the device (int32 or float32) -> `motion_vector` (1, 2, h, w),
+    `res_diff` (1, 3, h, w) float32 (transform_mv_res, lib/utils/image.py:202-228), one launch.  negate_mv: get_image's
+    `motion_vector = - motion_vector` (:54) applied to the source values."""
+    mv, res = motion_vector, res_diff
+    if mv.dtype != res.dtype or mv.dtype not in (torch.int32, torch.float32):
+        raise LsfaError("transform_mv_res: int32 or float32 maps expected, got %s / %s" % (mv.dtype, res.dtype))
+    if mv.dim() != 3 or res.dim() != 3 or mv.shape[2] != 2 or res.shape[2] != 3 or mv.shape[:2] != res.shape[:2] or not (mv.is_contiguous() and res.is_contiguous()):
+        raise LsfaError("transform_mv_res: contiguous (H, W, 2) and (H, W, 3) expected, got %s / %s" % (tuple(mv.shape), tuple(res.shape)))
+    H, W = int(mv.shape[0]), int(mv.shape[1])
+    import numpy as _np
+    h1, w1 = int(_np.rint(H * float(im_scale))), int(_np.rint(W * float(im_scale)))       # cvRound
+    oh, ow = -(-h1 // rcnn_stride), -(-w1 // rcnn_stride)
+    out_mv = torch.empty((1, 2, oh, ow), device=mv.device, dtype=torch.float32)
+    out_res = torch.empty((1, 3, oh, ow), device=mv.device, dtype=torch.float32)
+    means = (ctypes.c_double * 3)(*[float(m) for m in pixel_means])
+    _check(lib().lsfa_transform_mv_res(_ptr(mv), _ptr(res), _ci(int(mv.dtype == torch.int32) | (2 if negate_mv else 0)), _ci(H), _ci(W), ctypes.c_double(float(im_scale)), _ci(h1), _ci(w1),
+                                       _ci(int(rcnn_stride)), means, ctypes.c_double(float(pixel_scale)), _ptr(out_mv), _ptr(out_res), _ci(oh), _ci(ow),
+                                       _stream()), "lsfa_transform_mv_res")
+    return out_mv, out_res
+
+
+@_on_tensor_device
 def image_transform_u8(im, pixel_means=(0.0, 0.0, 0.0), pixel_scale=1.0, out=None):
     """lsfa_image_transform_u8: decoded frames (N, H, W, 3) uint8 BGR on the device -> (N, 3, H, W) float32 RGB minus means, times scale
     (transform, lib/utils/image.py:296-308).  pixel_means in B, G, R order (config.network.PIXEL_MEANS)."""
@@ -1118,6 +1141,11 @@ class MotionVectorAccumulator(object):
             _check(lib().lsfa_mv_residual(_ptr(bgr_cur), _ptr(bgr_ref), _ptr(self.accu), _ci(self.width), _ci(self.height),
                                           _ptr(res), _stream()), "lsfa_mv_residual")
         return res
+
+    def network_inputs(self, bgr_cur, bgr_ref, im_scale, pixel_means=(0.0, 0.0, 0.0), pixel_scale=1.0, rcnn_stride=16):
+        """The frame's `motion_vector` (1, 2, h, w) and `res_diff` (1, 3, h, w) as get_image builds them (lib/utils/image.py:52-63): the
+        accumulated motion vectors, negated, and the residual through transform_mv_res - three launches, nothing leaves the device."""
+        return transform_mv_res(self.motion_vectors(), self.residual(bgr_cur, bgr_ref), im_scale, pixel_means, pixel_scale, rcnn_stride, negate_mv=True)
 
 
 # ---- live timing -----------------------------------------------------------------------

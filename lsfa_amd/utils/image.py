@@ -43,8 +43,11 @@ def _resize_hwc(x, fx, fy):
     oh, ow = _cv_round(h * fy), _cv_round(w * fx)
     x0, x1, ax = _taps(ow, w, fx, x.device)
     y0, y1, ay = _taps(oh, h, fy, x.device)
-    hor = x[:, x0] * (1 - ax)[None, :, None] + x[:, x1] * ax[None, :, None]
-    return hor[y0] * (1 - ay)[:, None, None] + hor[y1] * ay[:, None, None]
+    wt = x.dtype                                                    # float32 images: cv2's CV_32F path; float64: CV_64F (double work type, the SAME float coefficients)
+    bx, by = (1 - ax).to(wt), (1 - ay).to(wt)                       # `cbuf[0] = 1.f - fx` in float
+    ax, ay = ax.to(wt), ay.to(wt)
+    hor = x[:, x0] * bx[None, :, None] + x[:, x1] * ax[None, :, None]
+    return hor[y0] * by[:, None, None] + hor[y1] * ay[:, None, None]
 
 
 def resize(im, target_size, max_size, stride=0):
@@ -74,22 +77,31 @@ def transform(im, pixel_means, pixel_scale):
 
 
 def transform_mv_res(motion_vector, res_diff, im_scale, pixel_means, pixel_scale, rcnn_stride=16):
-    """(H, W, 2) motion vectors + (H, W, 3) residual -> (1,2,h,w), (1,3,h,w) stride-16 tensors.
-    lib/utils/image.py:202-228, including its in-place channel loop: channel 2 of the residual is
-    computed from the ALREADY REWRITTEN channel 0 (:218-219), which is reproduced here."""
-    mv = _resize_hwc(torch.as_tensor(motion_vector).float(), im_scale, im_scale)
-    res = _resize_hwc(torch.as_tensor(res_diff).float(), im_scale, im_scale)
+    """(H, W, 2) motion vectors + (H, W, 3) residual -> (1,2,h,w), (1,3,h,w) stride-16 float32 tensors.
+    lib/utils/image.py:202-228, including its in-place channel loop: channel 2 of the residual is computed from the ALREADY REWRITTEN
+    channel 0 (:218-219), and its precisions: the first resize runs on float32 images, the padded maps are np.zeros - float64 - so the
+    channel loop, the resize by 1 / stride (cv2's CV_64F path: double work type, float coefficients) and the final scale are float64, rounded to
+    float32 once (where the reference hands the arrays to the executor).  Maps on a GPU take ONE launch of lsfa_transform_mv_res (r5), maps
+    on the host the same arithmetic in torch; both equal oracle/np_ref.py::transform_mv_res bit for bit."""
+    mv, res = torch.as_tensor(motion_vector), torch.as_tensor(res_diff)
+    if mv.is_cuda:
+        from lsfa_amd import hip
+        if mv.dtype not in (torch.int32, torch.float32):
+            mv, res = mv.float(), res.float()
+        return hip.transform_mv_res(mv.contiguous(), res.to(mv.dtype).contiguous(), im_scale, pixel_means, pixel_scale, rcnn_stride)
+    mv = _resize_hwc(mv.float(), im_scale, im_scale)
+    res = _resize_hwc(res.float(), im_scale, im_scale)
     im_h, im_w = res.shape[0], res.shape[1]
     p_h = int(np.ceil(im_h / float(rcnn_stride)) * rcnn_stride)
     p_w = int(np.ceil(im_w / float(rcnn_stride)) * rcnn_stride)
-    pmv = torch.zeros((p_h, p_w, 2), dtype=torch.float32, device=mv.device)
-    pres = torch.zeros((p_h, p_w, 3), dtype=torch.float32, device=mv.device)
+    pmv = torch.zeros((p_h, p_w, 2), dtype=torch.float64)
+    pres = torch.zeros((p_h, p_w, 3), dtype=torch.float64)
     pmv[:im_h, :im_w] = mv
     pres[:im_h, :im_w] = res
     means = [float(m) for m in pixel_means]
     for i in range(3):     # the reference's in-place loop, in the same order
-        pres[:, :, i] = (pres[:, :, 2 - i] - means[2 - i]) * pixel_scale
+        pres[:, :, i] = (pres[:, :, 2 - i] - means[2 - i]) * float(pixel_scale)
     s = 1.0 / rcnn_stride
-    rmv = _resize_hwc(pmv, s, s) * (im_scale * s)
+    rmv = _resize_hwc(pmv, s, s) * (float(im_scale) * s)
     rres = _resize_hwc(pres, s, s)
-    return rmv.permute(2, 0, 1).unsqueeze(0).contiguous(), rres.permute(2, 0, 1).unsqueeze(0).contiguous()
+    return rmv.permute(2, 0, 1).unsqueeze(0).contiguous().float(), rres.permute(2, 0, 1).unsqueeze(0).contiguous().float()

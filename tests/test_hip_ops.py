@@ -9,6 +9,7 @@ import pytest
 import torch
 
 import oracle
+from oracle import np_ref
 
 pytestmark = pytest.mark.gpu
 
@@ -856,6 +857,13 @@ def test_mv_accumulation_bit_exact(hip, size):
     ref = rs.randint(0, 256, (height, width, 3)).astype(np.uint8)
     np.testing.assert_array_equal(acc.residual(torch.from_numpy(cur), torch.from_numpy(ref)).cpu().numpy(),
                                   oracle.coviar_residual(cur, ref, want))
+    # r5: from the decoder's blocks to the network's inputs without leaving the device (get_image, lib/utils/image.py:52-63: the motion vectors
+    # negated, both maps through transform_mv_res)
+    means, ps, sc = (102.9801, 115.9465, 122.7717), 1.0, 1.25
+    want_mv, want_res = np_ref.transform_mv_res(-oracle.coviar_mv(want).astype(np.float32), oracle.coviar_residual(cur, ref, want).astype(np.float32), sc, means, ps)
+    got_mv, got_res = acc.network_inputs(torch.from_numpy(cur), torch.from_numpy(ref), sc, means, ps)
+    np.testing.assert_array_equal(got_mv.cpu().numpy(), want_mv.astype(np.float32))
+    np.testing.assert_array_equal(got_res.cpu().numpy(), want_res.astype(np.float32))
     acc.reset()
     np.testing.assert_array_equal(acc.accu.cpu().numpy(), oracle.coviar_identity(width, height))
 
@@ -938,6 +946,51 @@ def test_copy_many_zero_fills_where_there_is_no_source(hip):
     z = hip.zeros_f32((2, 5, 7), DEV)
     assert z.dtype == torch.float32 and z.shape == (2, 5, 7) and float(z.abs().sum()) == 0.0
     hip.copy_many([])                                              # nothing to do: no launch, no error
+
+
+@pytest.mark.parametrize("case", [(600, 1000, 1.0, (0.0, 0.0, 0.0), 1.0), (720, 1280, 0.78125, (102.9801, 115.9465, 122.7717), 1.0),
+                                  (72, 128, 100.0 / 128, (3.0, 5.0, 7.0), 0.5), (37, 53, 1.7, (1.5, 2.5, 3.5), 0.017), (16, 16, 1.0, (0.0, 0.0, 0.0), 1.0),
+                                  (5, 9, 0.6, (1.0, 2.0, 3.0), 2.0)])
+def test_transform_mv_res_on_the_device_is_the_references(hip, case):
+    """r5 (lsfa_transform_mv_res): decoded motion vectors + residual -> the network's stride-16 inputs in ONE launch, bit for bit
+    the reference's arithmetic (oracle/np_ref.py::transform_mv_res, float64, rounded to float32 where the reference hands the arrays to the
+    executor): first resize in float32, padding, the in-place channel loop and the 1 / 16 resize in float64.  int32 maps (what
+    lsfa_mv_field / lsfa_mv_residual leave on the device) and float32 maps; odd sizes, up- and down-scaling, a one-cell output."""
+    H, W, scale, means, ps = case
+    rs = np.random.RandomState(H + W)
+    mv = rs.randint(-40, 40, (H, W, 2)).astype(np.int32)
+    res = rs.randint(-255, 256, (H, W, 3)).astype(np.int32)
+    want_mv, want_res = np_ref.transform_mv_res(mv, res, scale, means, ps)
+    got_mv, got_res = hip.transform_mv_res(t(mv), t(res), scale, means, ps)
+    assert tuple(got_mv.shape) == want_mv.shape and tuple(got_res.shape) == want_res.shape
+    np.testing.assert_array_equal(got_mv.cpu().numpy(), want_mv.astype(np.float32))
+    np.testing.assert_array_equal(got_res.cpu().numpy(), want_res.astype(np.float32))
+    # float32 maps with fractional values (an already resized or filtered field)
+    mvf = (mv + rs.rand(H, W, 2)).astype(np.float32)
+    resf = (res * 0.37).astype(np.float32)
+    want_mv, want_res = np_ref.transform_mv_res(mvf, resf, scale, means, ps)
+    got_mv, got_res = hip.transform_mv_res(t(mvf), t(resf), scale, means, ps)
+    np.testing.assert_array_equal(got_mv.cpu().numpy(), want_mv.astype(np.float32))
+    np.testing.assert_array_equal(got_res.cpu().numpy(), want_res.astype(np.float32))
+    # the host-side module dispatches device maps to the same launch
+    from lsfa_amd.utils import image
+    h_mv, h_res = image.transform_mv_res(t(mv), t(res), scale, means, ps)
+    assert h_mv.is_cuda and torch.equal(h_mv, hip.transform_mv_res(t(mv), t(res), scale, means, ps)[0])
+    with pytest.raises(hip.LsfaError):
+        hip.transform_mv_res(t(mv).double(), t(res).double(), scale, means, ps)
+    # get_image negates the decoder's motion vectors before the transform (lib/utils/image.py:54)
+    want_mv, _ = np_ref.transform_mv_res(-mv.astype(np.float32), res.astype(np.float32), scale, means, ps)
+    got_mv, _ = hip.transform_mv_res(t(mv), t(res), scale, means, ps, negate_mv=True)
+    np.testing.assert_array_equal(got_mv.cpu().numpy(), want_mv.astype(np.float32))
+
+
+def test_transform_mv_res_golden_g6_on_the_device(hip, golden):
+    """... and against G6: the reference's own transform_mv_res run around the restated INTER_LINEAR (tests/golden/make_golden.py)."""
+    mv, res, means, ps = golden["g6_mv"], golden["g6_res"], golden["g6_means"], float(golden["g6_pixel_scale"])
+    for tag, sc in (("s1", 1.0), ("s16", 1.6)):
+        got_mv, got_res = hip.transform_mv_res(t(np.ascontiguousarray(mv)), t(np.ascontiguousarray(res).astype(mv.dtype)), sc, means, ps)
+        np.testing.assert_array_equal(got_mv.cpu().numpy(), golden["g6_mv_tensor_" + tag].astype(np.float32))
+        np.testing.assert_array_equal(got_res.cpu().numpy(), golden["g6_res_tensor_" + tag].astype(np.float32))
 
 
 # ------------------------------------------------------------------ ResNet stem ----

@@ -139,7 +139,8 @@ def test_image_helpers_against_reference_g6(golden):
     """G6 (r5): lib/utils/image.py run here with cv2 / coviar_py2 stubbed (tests/golden/make_golden.py).  `transform` is the reference's
     own output; `transform_mv_res` / `resize` are the reference's code around the restated INTER_LINEAR, so everything but the
     interpolation arithmetic (padding to the stride, the in-place channel loop of :218-219, scales, transposes, the im_scale rule) is
-    pinned.  The numpy restatement must reproduce them exactly, the torch host path (lsfa_amd/utils/image.py, float32) to float32 round-off."""
+    pinned.  The numpy restatement must reproduce them exactly, and so must the host path (lsfa_amd/utils/image.py) after the executor's rounding to
+    float32 (`transform_mv_res`; the frame's own `resize` / `transform` stay float32 throughout: to round-off)."""
     import torch
     from lsfa_amd.utils import image
     im, means, ps = golden["g6_im"], golden["g6_means"], float(golden["g6_pixel_scale"])
@@ -156,8 +157,8 @@ def test_image_helpers_against_reference_g6(golden):
         np.testing.assert_array_equal(got_res, want_res)
         h_mv, h_res = image.transform_mv_res(torch.from_numpy(mv), torch.from_numpy(res), sc, means, ps)
         assert tuple(h_mv.shape) == want_mv.shape and tuple(h_res.shape) == want_res.shape
-        np.testing.assert_allclose(h_mv.numpy(), want_mv, rtol=2e-5, atol=2e-5)
-        np.testing.assert_allclose(h_res.numpy(), want_res, rtol=2e-5, atol=2e-4)
+        np.testing.assert_array_equal(h_mv.numpy(), want_mv.astype(np.float32))       # float64 arrays in the reference, float32 at the executor
+        np.testing.assert_array_equal(h_res.numpy(), want_res.astype(np.float32))
     big = golden["g6_resize_in"]
     assert np_ref.resize_scale(big.shape, 60, 100) == float(golden["g6_resize_scale"]) == 2.0
     assert np_ref.resize_scale(big.shape, 60, 90) == float(golden["g6_resize_scale_capped"]) == 1.8

@@ -476,6 +476,15 @@ int lsfa_mv_residual(const unsigned char* bgr_cur, const unsigned char* bgr_ref,
 int lsfa_transform_mv_res(const void* motion_vector, const void* res_diff, int flags, int H, int W, double im_scale, int h1, int w1,
                           int rcnn_stride, const double* pixel_means_bgr_host, double pixel_scale, float* out_mv, float* out_res,
                           int out_h, int out_w, void* stream);
+/* r5: resize + transform (lib/utils/image.py:266-308) of decoded frames in one launch: N frames (H, W, 3) BGR, uint8 (is_u8) or float32, on the
+ * device -> `data` (N, 3, out_h, out_w) float32: cv2.resize by im_scale on the float image (get_image's .astype(np.float32), :52; INTER_LINEAR,
+ * float32 work type), zero padding to `stride` (config.network.IMAGE_STRIDE; 0: none), channel i = (im[..., 2 - i] - pixel_means[2 - i]) *
+ * pixel_scale: the subtraction in float32 (a float32 image minus a Python float), the product in float64, rounded to float32 once.  h1, w1 = cvRound(H * im_scale), cvRound(W * im_scale); out_h, out_w = h1, w1 rounded up to
+ * the stride - checked.  (lsfa_image_transform_u8 is the uint8-image form of `transform`: float64 subtraction; the two agree for zero means.)  (A frame that cv2.imread hands over as uint8 - the last frame of a
+ * video, :45 - takes OpenCV's fixed-point uint8 path in the reference and differs from this by up to half an intensity level: stated, not
+ * reproduced.) */
+int lsfa_image_resize_transform(const void* im_hwc_bgr, int is_u8, int N, int H, int W, double im_scale, int h1, int w1, int stride,
+                                const double* pixel_means_bgr_host, double pixel_scale, float* data_nchw, int out_h, int out_w, void* stream);
 
 /* ------------------------------------------------------------------------ *
  * Plumbing without a reference counterpart: a hipStream_t that is nobody else's (non-blocking; PyTorch's

@@ -164,7 +164,62 @@ __global__ __launch_bounds__(kThreads) void transform_mv_res_kernel(const T* __r
   else out_res[c * plane + r] = (float)v;
 }
 
+// ---- r5: resize + transform (lib/utils/image.py:266-308) of a decoded frame in one launch -----------------------------------------------
+// `resize`: cv2.resize by im_scale on the FLOAT image (get_image converts the decoder's frame with .astype(np.float32) first, :52: OpenCV's
+// float path, as above), zero padding to the image stride; `transform`: channel i = (im[..., 2 - i] - pixel_means[2 - i]) * pixel_scale: the
+// subtraction in float32 (a float32 image minus a Python float: config.py:172-182 leaves a list), the product in float64 (np.zeros), rounded
+// to float32 at the executor.  Padding pixels are transformed like any other ((0 - mean) * scale), as in the
+// reference.  A thread per output pixel, the three channels together.
+template <typename T>
+__global__ __launch_bounds__(kThreads) void resize_transform_kernel(const T* __restrict__ im, int N, int H, int W, int h1, int w1, int ph, int pw,
+                                                                    double inv_scale, double m0, double m1, double m2, double pixel_scale,
+                                                                    float* __restrict__ out) {
+  const long i = (long)blockIdx.x * kThreads + threadIdx.x;
+  const long plane = (long)ph * pw;
+  if (i >= N * plane) return;
+  const int n = (int)(i / plane);
+  const long r = i - n * plane;
+  const int y = (int)(r / pw), x = (int)(r - (long)y * pw);
+  const T* src = im + (size_t)n * H * W * 3;
+  float b = 0.f, g = 0.f, rr = 0.f;
+  if (y < h1 && x < w1) {
+    b = first_resize(src, H, W, 3, 0, y, x, inv_scale);
+    g = first_resize(src, H, W, 3, 1, y, x, inv_scale);
+    rr = first_resize(src, H, W, 3, 2, y, x, inv_scale);
+  }
+  float* o = out + (size_t)n * 3 * plane + r;
+  // a float32 image minus a Python float is a float32 subtraction (the mean rounded to float32 first); the product with pixel_scale is float64
+  const float tr = rr - (float)m2, tg = g - (float)m1, tb = b - (float)m0;
+  o[0] = (float)((double)tr * pixel_scale);
+  o[plane] = (float)((double)tg * pixel_scale);
+  o[2 * plane] = (float)((double)tb * pixel_scale);
+}
+
 }  // namespace
+
+extern "C" int lsfa_image_resize_transform(const void* im_hwc_bgr, int is_u8, int N, int H, int W, double im_scale, int h1, int w1, int stride,
+                                           const double* pixel_means_bgr_host, double pixel_scale, float* data_nchw, int out_h, int out_w,
+                                           void* stream) {
+  LSFA_REQUIRE(im_hwc_bgr && pixel_means_bgr_host && data_nchw, "lsfa_image_resize_transform: NULL argument");
+  LSFA_REQUIRE(N > 0 && H > 0 && W > 0 && h1 > 0 && w1 > 0 && stride >= 0 && im_scale > 0.0, "lsfa_image_resize_transform: bad shape");
+  const int ph = stride > 0 ? (h1 + stride - 1) / stride * stride : h1, pw = stride > 0 ? (w1 + stride - 1) / stride * stride : w1;
+  if (ph != out_h || pw != out_w) {
+    set_error("lsfa_image_resize_transform: output is %d x %d, the resized %d x %d frame padded to %d gives %d x %d", out_h, out_w, h1, w1, stride, ph, pw);
+    return LSFA_EINVAL;
+  }
+  const long total = (long)N * ph * pw;
+  hipStream_t s = (hipStream_t)stream;
+  ProfScope prof(LSFA_OP_STEM, s);
+  const dim3 grid((unsigned)((total + kThreads - 1) / kThreads));
+  if (is_u8)
+    hipLaunchKernelGGL(resize_transform_kernel<unsigned char>, grid, dim3(kThreads), 0, s, (const unsigned char*)im_hwc_bgr, N, H, W, h1, w1, ph, pw,
+                       1.0 / im_scale, pixel_means_bgr_host[0], pixel_means_bgr_host[1], pixel_means_bgr_host[2], pixel_scale, data_nchw);
+  else
+    hipLaunchKernelGGL(resize_transform_kernel<float>, grid, dim3(kThreads), 0, s, (const float*)im_hwc_bgr, N, H, W, h1, w1, ph, pw, 1.0 / im_scale,
+                       pixel_means_bgr_host[0], pixel_means_bgr_host[1], pixel_means_bgr_host[2], pixel_scale, data_nchw);
+  LSFA_LAUNCH_CHECK("lsfa_image_resize_transform");
+  return LSFA_OK;
+}
 
 extern "C" int lsfa_transform_mv_res(const void* motion_vector, const void* res_diff, int flags, int H, int W, double im_scale, int h1, int w1,
                                      int rcnn_stride, const double* pixel_means_bgr_host, double pixel_scale, float* out_mv, float* out_res,

@@ -588,6 +588,26 @@ def transform_mv_res(motion_vector, res_diff, im_scale, pixel_means=(0.0, 0.0, 0
 
 
 @_on_tensor_device
+def image_resize_transform(im, im_scale, pixel_means=(0.0, 0.0, 0.0), pixel_scale=1.0, stride=0):
+    """lsfa_image_resize_transform: decoded frames (N, H, W, 3) or (H, W, 3) BGR, uint8 or float32, on the device -> `data` (N, 3, h, w) float32:
+    resize (lib/utils/image.py:266-294) + transform (:296-308) in one launch."""
+    if im.dim() == 3:
+        im = im.unsqueeze(0)
+    if im.dtype not in (torch.uint8, torch.float32) or im.dim() != 4 or im.shape[3] != 3 or not im.is_contiguous():
+        raise LsfaError("image_resize_transform: (N, H, W, 3) contiguous uint8 or float32 expected, got %s %s" % (tuple(im.shape), im.dtype))
+    N, H, W, _ = [int(v) for v in im.shape]
+    import numpy as _np
+    h1, w1 = int(_np.rint(H * float(im_scale))), int(_np.rint(W * float(im_scale)))       # cvRound
+    ph, pw = (-(-h1 // stride) * stride, -(-w1 // stride) * stride) if stride else (h1, w1)
+    out = torch.empty((N, 3, ph, pw), device=im.device, dtype=torch.float32)
+    means = (ctypes.c_double * 3)(*[float(m) for m in pixel_means])
+    _check(lib().lsfa_image_resize_transform(_ptr(im), _ci(int(im.dtype == torch.uint8)), _ci(N), _ci(H), _ci(W), ctypes.c_double(float(im_scale)), _ci(h1), _ci(w1),
+                                             _ci(int(stride)), means, ctypes.c_double(float(pixel_scale)), _ptr(out), _ci(ph), _ci(pw), _stream()),
+           "lsfa_image_resize_transform")
+    return out
+
+
+@_on_tensor_device
 def image_transform_u8(im, pixel_means=(0.0, 0.0, 0.0), pixel_scale=1.0, out=None):
     """lsfa_image_transform_u8: decoded frames (N, H, W, 3) uint8 BGR on the device -> (N, 3, H, W) float32 RGB minus means, times scale
     (transform, lib/utils/image.py:296-308).  pixel_means in B, G, R order (config.network.PIXEL_MEANS)."""

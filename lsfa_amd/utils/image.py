@@ -69,11 +69,18 @@ def resize(im, target_size, max_size, stride=0):
 
 
 def transform(im, pixel_means, pixel_scale):
-    """(H, W, 3) BGR -> (1, 3, H, W) RGB minus means, times scale.  lib/utils/image.py:296-308"""
-    im = torch.as_tensor(im).float()
-    means = torch.as_tensor(np.asarray(pixel_means, dtype=np.float32), device=im.device)
-    t = torch.stack([im[:, :, 2 - i] - means[2 - i] for i in range(3)], 0).unsqueeze(0)
-    return t * pixel_scale
+    """(H, W, 3) BGR -> (1, 3, H, W) RGB minus means, times scale.  lib/utils/image.py:296-308, in its precisions: a float image minus the
+    (Python float) mean is a float32 subtraction, a uint8 image's a float64 one; the product with pixel_scale is float64 (np.zeros), rounded to
+    float32 where the reference hands the array to the executor."""
+    im = torch.as_tensor(im)
+    if im.dtype == torch.uint8:
+        x = im.double()
+        means = torch.as_tensor(np.asarray(pixel_means, dtype=np.float64), device=im.device)
+    else:
+        x = im.float()
+        means = torch.as_tensor(np.asarray(pixel_means, dtype=np.float32), device=im.device)
+    t = torch.stack([x[:, :, 2 - i] - means[2 - i] for i in range(3)], 0).unsqueeze(0)
+    return (t.double() * float(pixel_scale)).float()
 
 
 def transform_mv_res(motion_vector, res_diff, im_scale, pixel_means, pixel_scale, rcnn_stride=16):

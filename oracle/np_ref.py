@@ -238,6 +238,12 @@ def resize_scale(im_shape, target_size, max_size):
 
 
 def transform(im, pixel_means, pixel_scale):
+    # config.network.PIXEL_MEANS is a list of Python numbers once update_network_config has run (dff_rfcn/config/config.py:172-182; the yaml's
+    # too).  A float32 image - the decoder's frame after get_image's .astype(np.float32) and cv2.resize (lib/utils/image.py:52, 283) - minus a
+    # Python float is a FLOAT32 subtraction (mean rounded to float32 first) under the reference's numpy and under today's alike; a uint8 image
+    # (cv2.imread: the last frame of a video, :45) minus a Python float is float64.  Coerced to Python floats so that the restatement does not
+    # depend on whether a test passes a list, a tuple or an array (an np.float64 ELEMENT would make numpy >= 2 subtract in float64).
+    pixel_means = [float(m) for m in pixel_means]
     im_tensor = np.zeros((1, 3, im.shape[0], im.shape[1]))
     for i in range(3):
         im_tensor[0, i, :, :] = im[:, :, 2 - i] - pixel_means[2 - i]

@@ -154,6 +154,9 @@ def main():
     g["g6_im"], g["g6_means"], g["g6_pixel_scale"] = im, means, np.asarray(pscale)
     g["g6_transform"] = image.transform(im, means, pscale)                 # exact: pure numpy
     g["g6_transform_zero_means"] = image.transform(im, np.zeros(3), 1.0)   # the resnet-101 configuration (config.py:171-176)
+    # a float32 frame (the decoder's, after get_image's .astype(np.float32)) with list means, as update_network_config leaves them
+    # (config.py:177-182): the subtraction is a float32 one
+    g["g6_transform_f32_list_means"] = image.transform(im.astype(np.float32) * np.float32(0.731), [103.94, 116.78, 123.68], 0.017)
     mv = rs.randint(-40, 41, (37, 52, 2)).astype(np.int32)                 # odd sizes: padding to the stride, 'full' edges
     res = rs.randint(-128, 128, (37, 52, 3)).astype(np.int32)
     g["g6_mv"], g["g6_res"] = mv, res

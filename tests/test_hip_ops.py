@@ -984,6 +984,42 @@ def test_transform_mv_res_on_the_device_is_the_references(hip, case):
     np.testing.assert_array_equal(got_mv.cpu().numpy(), want_mv.astype(np.float32))
 
 
+@pytest.mark.parametrize("case", [(600, 1000, 1.0, 0), (720, 1280, 0.78125, 16), (480, 640, 1.25, 32), (37, 53, 1.7, 16), (9, 7, 0.6, 0)])
+def test_image_resize_transform_on_the_device_is_the_references(hip, case):
+    """r5 (lsfa_image_resize_transform): a decoded frame -> `data` in one launch = resize (cv2's float INTER_LINEAR as restated in
+    oracle/np_ref.py, zero padding to the image stride) + transform (float64, rounded to float32 at the executor), bit for bit; uint8 and
+    float32 frames, two per launch; at scale 1 without padding it is lsfa_image_transform_u8."""
+    H, W, scale, stride = case
+    rs = np.random.RandomState(H * 3 + W)
+    means, ps = (102.9801, 115.9465, 122.7717), 0.5
+    ims = rs.randint(0, 256, (2, H, W, 3)).astype(np.uint8)
+
+    def want_of(im):
+        r = np_ref.cv2_resize_linear(im.astype(np.float32), scale, scale)
+        if stride:
+            ph, pw = -(-r.shape[0] // stride) * stride, -(-r.shape[1] // stride) * stride
+            p = np.zeros((ph, pw, 3), np.float32)
+            p[:r.shape[0], :r.shape[1]] = r
+            r = p
+        return np_ref.transform(r, means, ps).astype(np.float32)
+
+    want = np.concatenate([want_of(ims[0]), want_of(ims[1])], 0)
+    got = hip.image_resize_transform(t(ims), scale, means, ps, stride=stride)
+    assert tuple(got.shape) == want.shape
+    np.testing.assert_array_equal(got.cpu().numpy(), want)
+    got_f = hip.image_resize_transform(t(ims.astype(np.float32)), scale, means, ps, stride=stride)
+    np.testing.assert_array_equal(got_f.cpu().numpy(), want)
+    if scale == 1.0 and stride == 0 and (H * W) % 4 == 0:         # zero means (the resnet-101 configuration): the uint8-image form of `transform` agrees
+        assert torch.equal(hip.image_resize_transform(t(ims), 1.0, (0.0, 0.0, 0.0), ps), hip.image_transform_u8(t(ims), (0.0, 0.0, 0.0), ps))
+
+
+def test_image_resize_transform_golden_g6_float32_frame(hip, golden):
+    """... and against G6: the reference's own `transform` on a float32 frame with list means (float32 subtraction, float64 product)."""
+    imf = golden["g6_im"].astype(np.float32) * np.float32(0.731)
+    got = hip.image_resize_transform(t(imf), 1.0, [103.94, 116.78, 123.68], 0.017)
+    np.testing.assert_array_equal(got.cpu().numpy(), golden["g6_transform_f32_list_means"].astype(np.float32))
+
+
 def test_transform_mv_res_golden_g6_on_the_device(hip, golden):
     """... and against G6: the reference's own transform_mv_res run around the restated INTER_LINEAR (tests/golden/make_golden.py)."""
     mv, res, means, ps = golden["g6_mv"], golden["g6_res"], golden["g6_means"], float(golden["g6_pixel_scale"])

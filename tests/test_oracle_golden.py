@@ -146,8 +146,12 @@ def test_image_helpers_against_reference_g6(golden):
     im, means, ps = golden["g6_im"], golden["g6_means"], float(golden["g6_pixel_scale"])
     np.testing.assert_array_equal(np_ref.transform(im, means, ps), golden["g6_transform"])
     np.testing.assert_array_equal(np_ref.transform(im, np.zeros(3), 1.0), golden["g6_transform_zero_means"])
-    t = image.transform(torch.from_numpy(im), means, ps).numpy()
-    np.testing.assert_allclose(t, golden["g6_transform"], rtol=3e-7, atol=3e-7)
+    imf = im.astype(np.float32) * np.float32(0.731)                   # a float32 frame, list means: float32 subtraction (config.py:177-182)
+    np.testing.assert_array_equal(np_ref.transform(imf, [103.94, 116.78, 123.68], 0.017), golden["g6_transform_f32_list_means"])
+    np.testing.assert_array_equal(np_ref.transform(imf, np.array([103.94, 116.78, 123.68]), 0.017), golden["g6_transform_f32_list_means"])
+    np.testing.assert_array_equal(image.transform(torch.from_numpy(im), means, ps).numpy(), golden["g6_transform"].astype(np.float32))
+    np.testing.assert_array_equal(image.transform(torch.from_numpy(imf), [103.94, 116.78, 123.68], 0.017).numpy(),
+                                  golden["g6_transform_f32_list_means"].astype(np.float32))
     np.testing.assert_array_equal(image.transform(torch.from_numpy(im), np.zeros(3), 1.0).numpy(), golden["g6_transform_zero_means"].astype(np.float32))
     mv, res = golden["g6_mv"], golden["g6_res"]
     for tag, sc in (("s1", 1.0), ("s16", 1.6)):

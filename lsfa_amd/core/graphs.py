@@ -521,7 +521,8 @@ class FramePipeline(object):
         self.banks = {g: [KeyBank(key_exec, cfg, height, width, dev, use_graphs, g, taps, B) for _ in range(2 if g == self.key_group else 1)]
                       for g in range(2, self.key_group + 1)}
         self._bank_turn = 0
-        self._bank_ready = []                        # [(bank, slot, data_ptr)]: fronts of upcoming key frames already computed
+        self._bank_ready = []                        # [(bank, slot, image tensor)]: fronts of upcoming key frames already computed (the tensor is HELD: its
+                                                     # storage cannot be freed and handed to another image at the same address while its front waits)
         # ramp (True = (1, 2)): while the pipeline is empty (the first key frames of a clip, or after flush() / join()) nothing overlaps a
         # pass of key_group fronts and every lane waits for it: with a ramp the first pass after that is one front, the second a group of
         # two, then full groups - the first detections arrive after 3 ms instead of 10.  Off by default since the end of r4: small passes
@@ -711,7 +712,10 @@ class FramePipeline(object):
         next G - 1 key_frame calls - which must hand over exactly those tensors - take theirs from the bank.  With fewer than G - 1
         images (the end of a clip) the group is that much smaller; without any the frame's front is computed alone, as with key_group = 1."""
         bank, slot, group = None, -1, None
-        if self._bank_ready and self._bank_ready[0][2] != data.data_ptr():     # checked before ANYTHING is queued or counted: the call leaves no trace
+        # checked before ANYTHING is queued or counted: the call leaves no trace.  The front belongs to the tensor handed over in `upcoming` (held by
+        # the bank) or to a view of the same storage at the same offset and shape.
+        if self._bank_ready and not (self._bank_ready[0][2] is data or (self._bank_ready[0][2].data_ptr() == data.data_ptr()
+                                                                       and self._bank_ready[0][2].shape == data.shape)):
             raise ValueError("FramePipeline.key_frame: the bank holds the front of another image (hand the tensors of `upcoming` over in "
                              "order, or drop_fronts())")
         if not self.lookahead:
@@ -730,7 +734,7 @@ class FramePipeline(object):
             if g >= 2:
                 self._bank_turn += 1
                 bank, group, slot = self.banks[g][self._bank_turn % len(self.banks[g])], [data] + list(upcoming[:g - 1]), 0
-                self._bank_ready = [(bank, i, group[i].data_ptr()) for i in range(1, g)]
+                self._bank_ready = [(bank, i, group[i]) for i in range(1, g)]
         # ---- the image-only part, when this call starts one: a pass of the bank (or this frame's front alone) on the key stream, FlowNet
         #      beside it; nothing here waits for aggregations or tails, so passes run back to back
         src = bank if slot >= 0 else lane

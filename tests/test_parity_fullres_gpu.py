@@ -108,6 +108,15 @@ def test_first_key_cur_second_key_at_1000x600(world):
     rec['frame10_end_to_end'] = e2e.frame_gap(cfg, e2e.gpu_side(cfg, taps10, out10, im_info), ref10, d10, im_info, H, W)
     rec['choose_feat_second_key_vs_f64'] = dict(gpu=rel_err(np_(out10['choose_feat_output']), d10['choose_feat_output']),
                                                 oracle_fp32=rel_err(ref10['choose_feat_output'], d10['choose_feat_output']))
+    # how deep the Proposal's sweep goes on this data (what a mask limited to the first rows could save): the position
+    # of the 300th survivor in the score-sorted list of 6000, per frame, from the oracle's own sweep on the GPU's RPN outputs
+    depth = {}
+    for name, taps in (('frame0', taps0), ('frame3', taps3), ('frame10', taps10)):
+        _, _, _, keep, nkeep = oracle.proposal(np_(taps['rpn_cls_prob']), np_(taps['rpn_bbox_pred']), im_info, rpn_min_size=cfg.TEST.RPN_MIN_SIZE, return_debug=True)
+        n = int(nkeep[0])                                          # the oracle sweeps the whole list; the operator stops at post_nms_top_n = 300
+        last = int(keep[0][min(n, cfg.TEST.RPN_POST_NMS_TOP_N) - 1])
+        depth[name] = dict(survivors_of_the_full_sweep=n, position_of_survivor_300=last, blocks_of_64_visited=last // 64 + 1, blocks_total=(6000 + 63) // 64)
+    rec['proposal_sweep_depth'] = depth
     key.taps = cur.taps = None
     record('fullres', rec)
     world['oracles'] = dict(feat0=feat0, ref3=ref3, d3=d3, ref10=ref10, d10=d10)       # for the batched-pass test below

@@ -287,6 +287,11 @@ __device__ __forceinline__ uint32_t bf16_rne_pair(float a, float b) {
 template <int PC>
 __device__ __forceinline__ PiecesN cut8(const float4& a, const float4& b, float s) {
   PiecesN r;
+#ifdef LSFA_LAB_NO_CUT      // lab ablation (tools/lab/cut_ab.py): the raw bits as if they were pieces - wrong numbers, the step's timing without the cut
+  r.p[0] = make_uint4(__float_as_uint(a.x), __float_as_uint(a.y), __float_as_uint(a.z), __float_as_uint(a.w));
+  for (int q = 1; q < PC; ++q) r.p[q] = make_uint4(__float_as_uint(b.x), __float_as_uint(b.y), __float_as_uint(b.z), __float_as_uint(b.w));
+  return r;
+#endif
   if (PC == 3) {
     const Pieces p = split8(a, b);
     r.p[0] = p.p1; r.p[1] = p.p2; r.p[2] = p.p3;

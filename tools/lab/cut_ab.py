@@ -22,7 +22,7 @@ CASES = [  # name, N, H, W, ci, co, k, dil
     ("res3 conv2 x6", 6, 75, 125, 128, 128, 3, 1),
     ("res2 conv3 x6", 6, 150, 250, 64, 256, 1, 1),
     ("small feat x9", 9, 38, 63, 256, 1024, 3, 1),
-    ("rfcn x9", 9, 38, 63, 1024, 1911, 1, 1),
+    ("rfcn x9", 9, 38, 63, 1024, 1920, 1, 1),
     ("tiny values", 1, 38, 63, 256, 256, 3, 1),
 ]
 print("library:", hip.LIB_PATH)

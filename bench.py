@@ -15,7 +15,9 @@ A STEP is one key-frame interval of the clip(s) of this GPU: 1 key frame (ResNet
 warp x scale map + Nq aggregation + heads + Proposal + PSROI + detection NMS) followed by
 key_interval-1 non-key frames (small net + MV warp + residual + heads + Proposal + PSROI +
 detection NMS).  Frames, motion vectors and residuals are resident in HBM before the timed
-region; every frame's detections are copied to pinned host memory inside it.
+region (the bench contract: `value` never includes PCIe; the same pipeline with the inputs starting in
+pinned host memory and uploaded inside the region is the extra figure `value_uploaded_inputs`, or
+`value` itself under --host-inputs); every frame's detections are copied to pinned host memory inside it.
 
 N > 1: launched by torch.distributed.run, one rank per GPU; rank r runs clip(s) r (clips are
 independent: "scaling": "weak", no data-path collective); the only collective is the final
@@ -69,10 +71,13 @@ def parse():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-parity', action='store_true')
     ap.add_argument('--no-spread', action='store_true', help='skip the two extra repeats of the timed region behind `value_spread`')
+    ap.add_argument('--host-inputs', action='store_true',
+                    help='`value` = the PCIe-inclusive rate: uint8 frames + fp32 motion vectors / residuals start in pinned HOST memory, are uploaded per interval '
+                         'inside the timed region and transformed on the GPU (lib/utils/image.py:296-308).  Default: `value` is measured with every input already '
+                         'resident in HBM when the timed region starts (the bench contract) and the PCIe-inclusive rate is an extra region of the same line '
+                         '(`value_uploaded_inputs`)')
     ap.add_argument('--resident-inputs', action='store_true',
-                    help='keep every frame / motion vector / residual resident in HBM as fp32 before the timed region (r1-r4); default (r5): uint8 frames '
-                         '+ fp32 motion vectors / residuals in pinned HOST memory, uploaded per interval on a copy stream inside the timed region and '
-                         'transformed on the GPU (lib/utils/image.py:296-308)')
+                    help='do not build the host-side input blocks at all: no `value_uploaded_inputs` region (r1-r4)')
     ap.add_argument('--eager-loop', type=int, default=0,
                     help='profiling aid (tools/profile_round.sh): no timed region - re-issue the roofline leg (eager_profile_batched: key_group intervals the way the '
                          'pipeline batches them, serially on one stream) this many times and print its per-kernel FLOP table; run it under rocprofv3')
@@ -131,6 +136,7 @@ class Runner(object):
         # images of its whole group - and [the K-1 non-key frames uint8 | their motion vectors fp32 | their residuals fp32], uploaded with the
         # interval.  One copy per block on a copy stream, transform (lib/utils/image.py:296-308) on the GPU behind it, into preallocated rings.
         self.host_inputs = (not args.resident_inputs) and args.lanes > 0
+        self._inputs_resident_now = not (self.host_inputs and getattr(args, 'host_inputs', False))
         if self.host_inputs:
             K, B, H, W = self.K, self.B, args.height, args.width
             fh, fw = self.clips[0].fh, self.clips[0].fw
@@ -138,18 +144,22 @@ class Runner(object):
             self._nb_mv, self._nb_res = (K - 1) * B * 2 * fh * fw * 4, (K - 1) * B * 3 * fh * fw * 4
             assert self._nb_rest_frames % 16 == 0 and self._nb_mv % 16 == 0, "input block offsets must stay 16-byte aligned"
             self.host_key, self.host_rest = [], []
+            # the decoder's view of the RESIDENT frames (integer-valued RGB planes -> uint8 HWC BGR): the two input modes then see the same images bit
+            # for bit.  (SyntheticClip.frame_u8 renders on the host; its sines differ from the device's in the last ulp and a few dozen pixels per frame
+            # round the other way - enough to move the mAP-agreement figure in its fourth digit between the modes.)
+            u8_of = lambda t: t.detach().cpu().flip(0).permute(1, 2, 0).to(torch.uint8)
             for s_ in range(self.nsteps_unique):
                 kf = 1 + s_ * K
                 hk = torch.empty((B, H, W, 3), dtype=torch.uint8).pin_memory()
-                for b, c in enumerate(self.clips):
-                    hk[b] = c.frame_u8(kf)
+                for b in range(B):
+                    hk[b] = u8_of(self.frames[kf][b])
                 blk = torch.empty(self._nb_rest_frames + self._nb_mv + self._nb_res, dtype=torch.uint8).pin_memory()
                 fr = blk[:self._nb_rest_frames].view(K - 1, B, H, W, 3)
                 mvv = blk[self._nb_rest_frames:self._nb_rest_frames + self._nb_mv].view(torch.float32).view(K - 1, B, 2, fh, fw)
                 rsv = blk[self._nb_rest_frames + self._nb_mv:].view(torch.float32).view(K - 1, B, 3, fh, fw)
                 for i in range(1, K):
-                    for b, c in enumerate(self.clips):
-                        fr[i - 1, b] = c.frame_u8(kf + i)
+                    for b in range(B):
+                        fr[i - 1, b] = u8_of(self.frames[kf + i][b])
                     mvv[i - 1] = self.mv[kf + i].cpu()
                     rsv[i - 1] = self.res[kf + i].cpu()
                 self.host_key.append(hk)
@@ -269,7 +279,9 @@ class Runner(object):
                 # (interval 1: no non-key frames, the lanes are idle and the FlowNet / tail stream carries every frame's back half: the lanes' queue then)
                 ks = lanes[0] if self.K == 1 or fg.s_flow is None else fg.s_flow
                 keys = [self._upload_key(q + j, s + j, ks) for j in range(1 + len(ahead))]
-                fr, mvs, rss, ev_rest = self._upload_rest(q, s, lanes[q % len(lanes)]) if self.K > 1 else (None, None, None, None)      # (interval 1: every frame is a key frame)
+                # (the lane this interval's segment will be queued on - not this loop's own parity: the pipeline's count may be ahead of it)
+                rest_stream = fg.stream_of_next_segment() if hasattr(fg, 'stream_of_next_segment') else lanes[q % len(lanes)]
+                fr, mvs, rss, ev_rest = self._upload_rest(q, s, rest_stream) if self.K > 1 else (None, None, None, None)      # (interval 1: every frame is a key frame)
                 ev_keys = keys[-1][1]                # one stream, in order: the last upload's event covers the earlier ones
                 B = self.B
                 fg.key_frame(keys[0][0], deliver=lambda b: self._deliver(b, 0), ready=ev_keys,
@@ -303,7 +315,7 @@ class Runner(object):
         for i in range(1, self.K):
             self._deliver(fg.cur_frame(self.frames[kf + i], self.mv[kf + i], self.res[kf + i], nxt(i)), i)
 
-    _inputs_resident_now = False        # set for the extra region that measures the r1-r4 way (inputs already in HBM)
+    _inputs_resident_now = True         # the timed region: inputs already in HBM (the bench contract); False: uploaded inside the region (--host-inputs, and the extra region)
 
     def _wait_free(self, q, depth, done, stream):
         """ring slot q % depth was last filled for interval q - depth: its readers are all queued once interval q - depth + 1 has been (see step)"""
@@ -344,22 +356,40 @@ class Runner(object):
             u = self._up_rest[q] = (self.drest_f32[i], mv, rs, ev)
         return u
 
-    def resident_inputs_region(self, steps, warmup):
-        """r5: the main pipeline fed the r1-r4 way (every input already resident in HBM as fp32) for `steps` timed intervals -> frames/s"""
-        self._inputs_resident_now = True
+    def other_inputs_region(self, steps, warmup, settle_s=0.75):
+        """r5: the main pipeline fed the OTHER way - uploads inside the region when `value` was measured with resident inputs (the default), resident
+        inputs under --host-inputs - for `steps` timed intervals -> frames/s"""
+        main = self._inputs_resident_now
+        self._inputs_resident_now = not main
         try:
-            for s in range(warmup):
-                self.step(s, end=warmup)
-            self.fg.flush()
-            torch.cuda.synchronize()
-            t1 = time.perf_counter()
-            for s in range(warmup, warmup + steps):
-                self.step(s, end=warmup + steps)
-            self.fg.flush()
-            torch.cuda.synchronize()
-            return self.B * steps * self.K / (time.perf_counter() - t1)
+            # its own settle, like the main region's: the first passes over the pinned blocks and the device rings (and the clocks after the
+            # eager roofline leg) are not the steady state - without it this region read 10 % low against the same mode measured as `value`
+            t0 = time.perf_counter()
+            while time.perf_counter() - t0 < settle_s:
+                for s in range(32):
+                    self.step(s, end=32)
+                self.fg.flush()
+                torch.cuda.synchronize()
+            rates = []
+            for _ in range(2):            # the region twice, like the main region's repeats: the second is reported (the first still carries one-time costs)
+                for s in range(warmup):
+                    self.step(s, end=warmup)
+                self.fg.flush()
+                torch.cuda.synchronize()
+                t1 = time.perf_counter()
+                for s in range(warmup, warmup + steps):
+                    self.step(s, end=warmup + steps)
+                self.fg.flush()
+                torch.cuda.synchronize()
+                rates.append(self.B * steps * self.K / (time.perf_counter() - t1))
+                self._up_key.clear()
+                self._up_rest.clear()
+            self.other_inputs_rates = [round(v, 3) for v in rates]
+            return rates[-1]
         finally:
-            self._inputs_resident_now = False
+            self._inputs_resident_now = main
+            self._up_key.clear()
+            self._up_rest.clear()
 
     def exact_fp32_region(self, steps=3):
         """r5: the same clip with EVERY product an fp32 product (executors bound with pieces = 0: lsfa_conv_nhwc_fused_fwd on
@@ -875,8 +905,11 @@ def main():
     # bursts of 32 intervals (~0.19 s) between drains: with bursts of 8 (46 ms) the device never reached its sustained state during setup
     # and went through the transition - three to six intervals of 7.5-9.7 ms instead of 5.6 - inside the first timed region in half of
     # the runs (profiles/r3/ab_experiments.txt section 9, tools/trace_regions.py)
-    settle_drain = int(os.environ.get('LSFA_BENCH_SETTLE_DRAIN', '32'))
-    burst = settle_drain or 32
+    # ... and never shorter than the timed region itself: the first run of K consecutive intervals without a drain lets the host queue deeper than
+    # any burst before it, and the runtime grows its command / signal pools ONCE, inside that run (r5: the first 100-interval region read 6 % under
+    # its two repeats - 18 ms - while 20-interval regions and the throttled upload mode did not)
+    settle_drain = int(os.environ.get('LSFA_BENCH_SETTLE_DRAIN', str(max(32, args.steps))))
+    burst = settle_drain or max(32, args.steps)
     while time.perf_counter() - t_settle < args.settle_s:
         r.step(settle_steps, end=(settle_steps // burst + 1) * burst)        # a burst is one run of consecutive steps
         settle_steps += 1
@@ -921,12 +954,12 @@ def main():
     batched = hasattr(r.fg, 'lanes') and (r.segment > 0 or r.key_group > 1)
     prof = (r.eager_profile_batched(args.warmup) if batched else r.eager_profile_step(args.warmup)) if rank == 0 else None
     # r5: the streaming figure beside the headline: the same clip frame by frame (one extra short region; rank 0, untimed by the driver)
-    resident = None
+    other_inputs = None
     if getattr(r, 'host_inputs', False) and rank == 0 and not args.no_frame_by_frame:
         try:
-            resident = r.resident_inputs_region(args.steps, args.warmup)
+            other_inputs = r.other_inputs_region(args.steps, args.warmup)
         except Exception as e:
-            resident = "failed: %r" % (e,)
+            other_inputs = "failed: %r" % (e,)
     exact = None
     if rank == 0 and not args.no_frame_by_frame and args.lanes > 0:
         try:
@@ -940,6 +973,7 @@ def main():
         except Exception as e:          # a reported extra: never lose the bench line to it
             fbf = "failed: %r" % (e,)
 
+    uploads_extra = bool(getattr(r, 'host_inputs', False)) and not getattr(args, 'host_inputs', False)      # `value`: resident inputs; the extra region: uploads
     # an overflow of the fp16 form's scale anywhere in the run is an error, not a number (outside the timed regions: it synchronises)
     r.key.check_status()
     r.cur.check_status()
@@ -1079,12 +1113,22 @@ def main():
                              "values": [round(frames / t, 3) for t in repeats],
                              "note": "the timed region run %d times back to back; `value` is the first" % len(repeats),
                              "host_enqueue_share_of_repeats": [round(h / t, 3) for h, t in zip(host_enqueue, repeats[1:])]},
-            "inputs": ("host-pinned, uploaded in region: per interval one pinned block (uint8 BGR frames as a decoder hands them over + fp32 motion vectors / "
-                       "residuals, dff_rfcn/core/loader.py:131-141) -> one H2D copy on a copy stream -> transform (lib/utils/image.py:296-308) on the GPU; "
-                       "uploads run ahead of the frames by the key group's look-ahead") if getattr(r, 'host_inputs', False)
-                      else "resident in HBM as fp32 before the timed region (--resident-inputs, or a serial / non-pipelined run)",
-            "value_resident_inputs": (round(resident, 3) if isinstance(resident, float) else resident),
-            "value_resident_inputs_note": "frames/s of this GPU with every input already in HBM as fp32 (what rounds 1-4 timed), one extra region of the same length",
+            "inputs": (("resident in HBM as fp32 when the timed region starts (the bench contract: `value` never includes PCIe); `value_uploaded_inputs` is the "
+                        "PCIe-inclusive rate of the same pipeline" if uploads_extra else
+                        "host-pinned, uploaded in region (--host-inputs): per interval one pinned block (uint8 BGR frames as a decoder hands them over + fp32 motion "
+                        "vectors / residuals, dff_rfcn/core/loader.py:131-141) -> one H2D copy -> transform (lib/utils/image.py:296-308) on the GPU; uploads run "
+                        "ahead of the frames by the key group's look-ahead; `value_resident_inputs` is the contract's figure")
+                       if getattr(r, 'host_inputs', False)
+                       else "resident in HBM as fp32 before the timed region (--resident-inputs, or a serial / non-pipelined run)"),
+            "value_resident_inputs": (round(frames / elapsed, 3) if uploads_extra or not getattr(r, 'host_inputs', False)
+                                      else (round(other_inputs, 3) if isinstance(other_inputs, float) else other_inputs)),
+            "value_uploaded_inputs": ((round(other_inputs, 3) if isinstance(other_inputs, float) else other_inputs) if uploads_extra
+                                      else (round(frames / elapsed, 3) if getattr(r, 'host_inputs', False) else None)),
+            "value_other_inputs_regions": getattr(r, 'other_inputs_rates', None),
+            "value_uploaded_inputs_note": "frames/s of this GPU with the inputs starting in pinned HOST memory: per interval one pinned block (uint8 BGR frames as a "
+                                          "decoder hands them over + fp32 motion vectors / residuals, dff_rfcn/core/loader.py:131-141) -> one H2D copy inside the "
+                                          "region -> transform (lib/utils/image.py:296-308) on the GPU, uploads ahead of the frames by the key group's look-ahead; "
+                                          "the extra region (rank 0: its own 0.75 s settle, then the region twice - `value_other_inputs_regions` - the second reported), or `value` itself under --host-inputs",
             "value_exact_fp32": (round(exact, 3) if isinstance(exact, float) else exact),
             "value_exact_fp32_note": "frames/s, frame by frame, with every convolution on the EXACT fp32 matrix instructions (v_mfma_f32_32x32x2_f32, "
                                      "157 TFLOP/s peak; Executor pieces = 0, a reference evaluation): what the two-fp16-piece form is compared with in "

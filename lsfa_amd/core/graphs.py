@@ -839,6 +839,15 @@ class FramePipeline(object):
             e.record(s)
             self._handed[self._seg_buf].append(e)
 
+    def stream_of_next_segment(self):
+        """The stream the segment whose frames are handed over NEXT will be queued on (batched segments alternate over the lanes; a segment still
+        held goes first): where a caller should queue the upload of that segment's inputs, so that the copy does not sit behind the OTHER lane's
+        pass (bench.py: the lanes' parity against the caller's own interval count made the upload mode read 7-12 % low when it started on an odd
+        count)."""
+        if self.segment > 0:
+            return self.s_lane[(self._next_seg + (1 if self._held else 0)) % len(self.seg_lanes)]
+        return self.s_lane[self._next % len(self.lanes)]
+
     def _issue_batched(self):
         """The held frames (exactly `segment` of them, all of one segment) as one pass on the next segment lane."""
         i = self._next_seg

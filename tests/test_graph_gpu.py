@@ -486,6 +486,7 @@ def test_frame_pipeline_batched_segments_and_key_groups(world, lookahead, group)
     mvs = {f: clip.motion_vector(f, kf, DEV) for f, kf in sched if f != kf}
     ress = {f: clip.res_diff(f, DEV) for f, kf in sched if f != kf}
     torch.cuda.synchronize()
+    predicted, sched_key = {}, dict(sched)
 
     def run(fp):
         outs = {}
@@ -501,16 +502,20 @@ def test_frame_pipeline_batched_segments_and_key_groups(world, lookahead, group)
                     if seg is not None:
                         taps, out = e2e.image_of_batch(taps, out, seg[1], seg[2])
                     o = dict(taps=taps, out=out, batched=seg is not None)
+                    if seg is not None:      # r5: the lane a segment's pass runs on is the one stream_of_next_segment() named before its key frame was handed over
+                        assert torch.cuda.current_stream(DEV) == predicted[sched_key[f]], (f, sched_key[f])
                 o.update(dets=bufs[0].clone(), counts=bufs[1].clone())
                 outs[f] = o
             return deliver
         first = fp.first_frame(frames[0])
         outs[0] = dict(feat=fp.feat.clone())
+        predicted.clear()
         if not fp.captured:
             fp.capture()
         for f, kf in sched:
             if f == kf:
                 later = [frames[k] for k in keys if k > f]
+                predicted[f] = fp.stream_of_next_segment()      # where a caller would queue the upload of THIS interval's non-key inputs
                 fp.key_frame(frames[f], deliver=keep(f, True), upcoming=later)
             else:
                 fp.cur_frame(frames[f], mvs[f], ress[f], deliver=keep(f, False))

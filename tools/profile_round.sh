@@ -11,6 +11,8 @@ PY=python3
 
 # 1. the bench lines (default = configs[1], batched passes; the same frame by frame; configs[4]; configs[2])
 timeout 600 $PY bench.py --steps 100 > $OUT/bench_default_run.json 2> $OUT/bench_default_run.err
+timeout 300 $PY bench.py --steps 20 --warmup 5 > $OUT/bench_driver_settings_run.json 2> /dev/null                                   # the driver's command line
+timeout 300 $PY bench.py --steps 100 --host-inputs --no-cpu-baseline --no-parity > $OUT/bench_host_inputs_run.json 2> /dev/null          # the PCIe-inclusive rate as `value`
 timeout 400 $PY bench.py --steps 60 --segment 0 --key-group 1 --no-cpu-baseline > $OUT/bench_frame_by_frame_run.json 2> /dev/null
 timeout 400 $PY bench.py --interval 1 --maps-per-launch 32 --steps 60 > $OUT/bench_interval1_maps32_run.json 2> $OUT/bench_interval1_maps32_run.err
 timeout 600 $PY bench.py --dtype bf16 --clips 4 --steps 40 > $OUT/bench_bf16_clips4_run.json 2> $OUT/bench_bf16_clips4_run.err

@@ -1135,7 +1135,7 @@ def main():
                                      "tests/test_parity_fullres_gpu.py::test_two_fp16_pieces_against_exact_fp32_products_at_1000x600; compare with value_frame_by_frame",
             "value_frame_by_frame": (round(fbf, 3) if isinstance(fbf, float) else fbf),
             "value_frame_by_frame_note": "frames/s of this GPU for the same clip with one frame per pass (--segment 0 --key-group 1: no look-ahead, the "
-                                         "streaming case), %d timed intervals after its own graph capture + 0.5 s settle + %d warm-up intervals; null when the "
+                                         "streaming case; inputs as for `value`), %d timed intervals after its own graph capture + 0.5 s settle + %d warm-up intervals; null when the "
                                          "headline configuration is itself unbatched" % (args.steps, args.warmup),
             "roofline": roof,
             "multi_gpu": multi,

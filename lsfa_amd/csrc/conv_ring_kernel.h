@@ -367,7 +367,14 @@ void conv_ring_kernel(Args a, int nx, int ny, int nz) {
   const int P = a.N * a.Ho * a.Wo;
   static_assert(!(SP && WV != 4), "loader / consumer waves exist for 128-pixel tiles only");
   constexpr int kPix = 32 * WV;                          // pixels of a workgroup's tile
-  constexpr bool kPipelined = (SP && NT == 4) || WV == 8;      // the r5 step: 128 x 128 tiles with loader / consumer waves, 256 x 128 tiles; the rest keep r4's
+  // the uniform pipelined step (ONE body per step, copies always issued - past the end into a stage nobody reads): the 256-pixel tiles and, since
+  // the end of r5, the four-wave mixed-role 128 x 128 kernels: 186-256 registers without a spill, so two workgroups per CU stay (the first attempt
+  // at a pipelined mixed-role step had a second body for "nothing left to fetch", needed 512 registers and ONE workgroup per CU, and lost in the
+  // backbone).  Measured against r4's step on the same launches (profiles/r5/mixed_pipelined_ab.txt): res4 conv2 forced onto it 100.6 -> 74.5 us,
+  // res3 conv2 72 -> 65, the small net's 3x3 at nine frames 416 -> 383, the R-FCN maps 372 -> 334; in situ the nine-frame segment pass 1206 -> 1167 us,
+  // the six-image backbone pass 9470 -> 9360.  Two-chunk launches lose 5 % on it: those run on 128 x 64 tiles, which keep r4's step.
+  constexpr bool kUniform = !SP && (WV == 8 || NT == 4);
+  constexpr bool kPipelined = (SP && NT == 4) || kUniform;      // the r5 step: 128 x 128 tiles with loader / consumer waves, 256 x 128 tiles; the rest keep r4's
   if (tile.x * kPix >= P) return;
   const int taps = a.kh * a.kw;
   Geom g;
@@ -507,7 +514,7 @@ void conv_ring_kernel(Args a, int nx, int ny, int nz) {
     }
     return;                 // the epilogue is the consumers'
   }
-  if (!SP && WV == 8) {
+  if (kUniform) {
     ring_issue_a<NT, PC, ST, WV, ST - 1>(R, a.x, g, wk, true);
     wk.next(g.kw, g.chunks_per_tap);
     ring_prologue_uniform<NT, PC, ST, WV, 0>(R, a.x, wblock, g, wk, nchunks);
@@ -526,7 +533,7 @@ void conv_ring_kernel(Args a, int nx, int ny, int nz) {
         if (c + 1 < nchunks) ring_consume_step<NT, PC, ST, WV, 1, AF>(R, g, acc, p, a_scale, c + 1, T);
         if (ST > 2 && c + 2 < nchunks) ring_consume_step<NT, PC, ST, WV, (ST > 2 ? 2 : 0), AF>(R, g, acc, p, a_scale, c + 2, T);
         if (ST > 3 && c + 3 < nchunks) ring_consume_step<NT, PC, ST, WV, (ST > 3 ? 3 : 0), AF>(R, g, acc, p, a_scale, c + 3, T);
-      } else if (WV == 8) {
+      } else if (kUniform) {
         ring_step_uniform<NT, PC, ST, WV, 0, AF>(R, a.x, wblock, g, wk, c, nchunks, acc, p, a_scale, T);
         if (c + 1 < nchunks) ring_step_uniform<NT, PC, ST, WV, 1, AF>(R, a.x, wblock, g, wk, c + 1, nchunks, acc, p, a_scale, T);
         if (ST > 2 && c + 2 < nchunks) ring_step_uniform<NT, PC, ST, WV, (ST > 2 ? 2 : 0), AF>(R, a.x, wblock, g, wk, c + 2, nchunks, acc, p, a_scale, T);
@@ -555,7 +562,7 @@ void conv_ring_kernel(Args a, int nx, int ny, int nz) {
   // The ring is free once every wave is past its last chunk: each wave writes its NT 32 x 32 tiles row-major into a private 4 KB x NT
   // region and reads them back as float4 along the channels - lane -> (row 8k + lane / 8, channels 4 (lane % 8) ..): whole 128-byte
   // rows per 8 lanes, 16 bytes per lane, a quarter of the memory instructions.  Same values, same arithmetic per element.
-  if (WV == 8) wait_vmcnt<0>();      // the copies issued past the end must have landed before the ring becomes the epilogue's staging area
+  if (kUniform) wait_vmcnt<0>();      // the copies issued past the end must have landed before the ring becomes the epilogue's staging area
   constexpr bool kRowsFit = RG::kLdsBytes >= WV * NT * 4096;       // the ring holds the waves' tiles
   const bool rows_ok = kRowsFit && rows_path_ok(a);
   if (rows_ok) {

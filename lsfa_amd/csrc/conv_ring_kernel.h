@@ -17,7 +17,7 @@
 // against the float64 graph that made the GPU path 2.2x as far off as the fp32 oracle (tests/test_parity_fullres_gpu.py, r4).
 // Every kFlush chunks the accumulators are therefore added into a second set and cleared: chains of <= kFlush x 2 x PC adds, then
 // <= ceil(chunks / kFlush) adds of the block sums - the error of a blocked summation, for 16 x NT vector adds per kFlush (= 12) chunks.
-// r5: TWO step forms.  The *pipelined* step (SP with NT = 4, and WV = 8) cuts chunk v + 1 under the matrix instructions of chunk v, the
+// r5: TWO step forms.  The *pipelined* step (NT = 4: loader / consumer waves, and - one body per step - the mixed-role kernels; WV = 8) cuts chunk v + 1 under the matrix instructions of chunk v, the
 // order pinned with sched_group_barrier ("the cut of chunk v + 1 runs UNDER ..." below); every other instantiation keeps r4's step
 // ("r4's step, kept for ..." below).  Both compute the same products in the same order per accumulator: results are bit-identical across
 // every plan (tests/test_hip_ops.py::test_conv_ring_every_plan_gives_the_same_convolution).
@@ -250,7 +250,7 @@ __device__ __forceinline__ void ring_wait_first(int n) {
   else wait_vmcnt<0>();
 }
 
-// ---- r4's step, kept for the 128 x 64 tiles and for the mixed-role 128 x 128 ones -------------------------------------------------------
+// ---- r4's step, kept for the 128 x 64 tiles (until the end of r5 also the mixed-role 128 x 128 ones: kUniform below) -------------------------------------------------------
 // Two workgroups per CU (four waves per SIMD at NT = 2: 128 registers; two 256-thread mixed-role ones at NT = 4) overlap each other
 // better than one workgroup's pinned step does on these launches - measured IN the six-image backbone, not in the lab's back-to-back
 // repetitions of one layer: stage 2's conv2 84.7 vs 100.4 us, conv3 129.5 vs 150.6; res4 conv3 (mixed roles, two stages) 52.4 vs 58.3

@@ -373,6 +373,8 @@ void conv_ring_kernel(Args a, int nx, int ny, int nz) {
   // backbone).  Measured against r4's step on the same launches (profiles/r5/mixed_pipelined_ab.txt): res4 conv2 forced onto it 100.6 -> 74.5 us,
   // res3 conv2 72 -> 65, the small net's 3x3 at nine frames 416 -> 383, the R-FCN maps 372 -> 334; in situ the nine-frame segment pass 1206 -> 1167 us,
   // the six-image backbone pass 9470 -> 9360.  Two-chunk launches lose 5 % on it: those run on 128 x 64 tiles, which keep r4's step.
+  // (the same step on the 128 x 64 tiles - 136 registers, three workgroups per CU - LOSES: res3 conv3 58 -> 63 us, and with the plan's 128 x 64
+  //  launches moved from loader / consumer waves onto it the six-image backbone pass goes 9770 -> 9925 us: profiles/r5/mixed_pipelined_nt2_ab.txt)
   constexpr bool kUniform = !SP && (WV == 8 || NT == 4);
   constexpr bool kPipelined = (SP && NT == 4) || kUniform;      // the r5 step: 128 x 128 tiles with loader / consumer waves, 256 x 128 tiles; the rest keep r4's
   if (tile.x * kPix >= P) return;

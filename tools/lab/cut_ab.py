@@ -25,6 +25,18 @@ CASES = [  # name, N, H, W, ci, co, k, dil
     ("rfcn x9", 9, 38, 63, 1024, 1920, 1, 1),
     ("tiny values", 1, 38, 63, 256, 256, 3, 1),
 ]
+if os.environ.get('CUT_AB_NT2'):      # the launches the plan runs on 128 x 64 tiles
+    CASES = [
+        ("res2 conv2 x6", 6, 150, 250, 64, 64, 3, 1),
+        ("res2 conv1 x6", 6, 150, 250, 256, 64, 1, 1),
+        ("res3 conv1 x6", 6, 75, 125, 512, 128, 1, 1),
+        ("res3 conv2 x6", 6, 75, 125, 128, 128, 3, 1),
+        ("res3 conv3 x6", 6, 75, 125, 128, 512, 1, 1),
+        ("small conv2 x9", 9, 38, 63, 64, 64, 3, 1),
+        ("small conv3 x9", 9, 38, 63, 64, 256, 1, 1),
+        ("res4 conv2 x1", 1, 38, 63, 256, 256, 3, 1),
+        ("res5 conv1 x1", 1, 38, 63, 2048, 512, 1, 1),
+    ]
 print("library:", hip.LIB_PATH)
 for name, N, H, W, ci, co, k, dil in CASES:
     x = torch.relu(torch.randn((N, H, W, ci), device=DEV, generator=g))
@@ -35,7 +47,8 @@ for name, N, H, W, ci, co, k, dil in CASES:
     sw = hip.SplitWeight(w, pieces=2)
     am = hip.amax_partial(x)
     line = "%-16s" % name
-    for plan in (None, (2, 4, 3, 1), (2, 4, 4, 1), (1, 4, 2, 1)):      # the plan's own choice; loader / consumer waves, three stages; pairs; mixed roles
+    plans = [tuple(int(v) for v in q.split(',')) for q in os.environ['CUT_AB_PLANS'].split(';')] if os.environ.get('CUT_AB_PLANS') else [(2, 4, 3, 1), (2, 4, 4, 1), (1, 4, 2, 1)]
+    for plan in [None] + plans:      # the plan's own choice; then forced (kernel, nt, st, slices): 2 = loader / consumer waves, 1 = mixed roles
         if plan is None:
             hip.conv_plan_override()
         else:

@@ -856,10 +856,19 @@ def load_launch_counts(args):
 def main():
     args = parse()
     parity_failed = False
+    from lsfa_amd import hip as _hip
+    if _hip.LAB_SKIP:
+        # ablation (tools/lab/tail_ablation.sh): launches are dropped, detections are garbage - the line says so and carries no parity and no
+        # CPU baseline
+        if _hip.LAB_SKIP_TAIL:
+            _hip.proposal_set_plan('lab-no-nms')
+        args.no_parity = args.no_cpu_baseline = True
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
     world = int(os.environ.get('WORLD_SIZE', '1'))
-    distributed = world > 1
+    # LSFA_BENCH_FORCE_DIST=1 (tests/test_multirank_gpu.py): take the distributed branch at world size 1 too, so that a one-GPU box executes
+    # every line the N-GPU run will - RCCL initialisation, device barriers, all_reduce / all_gather on device tensors - except N > 1 itself
+    distributed = world > 1 or (os.environ.get('LSFA_BENCH_FORCE_DIST') == '1' and 'RANK' in os.environ)
     # test hook (one-GPU boxes): LSFA_BENCH_BACKEND=gloo LSFA_BENCH_ONE_DEVICE=1 runs every rank on cuda:0 and
     # the collectives on CPU tensors, to exercise the N>1 control flow without N GPUs
     backend = os.environ.get('LSFA_BENCH_BACKEND', 'nccl')
@@ -1031,7 +1040,11 @@ def main():
         staged = (fh * fw) % 2 == 0 and 1024 <= fh * fw <= 4096 and os.environ.get('LSFA_WARP_VARIANT', 'auto') != 'gather'
         warp_kernel = ("warp_staged_kernel (lsfa_warp_bilinear: MV/flow warp + fused epilogue; planes staged in LDS by DMA)" if staged else
                        "warp_kernel (lsfa_warp_bilinear: MV/flow warp + fused epilogue; gather form: plane size outside the LDS-staged kernel's range)")
-        roof_hbm = {"bound": "hbm", "kernel": "%s, %d map(s) per launch" % (warp_kernel, B),
+        mixed = bool(getattr(r, 'warp_bytes_total', None))
+        maps_label = ("a MIX of launches: %d map(s) per key-frame launch (flow warp) and %d maps per segment launch (MV warp, one shared key feature); "
+                      "algorithmic_bytes_per_launch is the mean over both kinds" % (B, B * r.segment)) if mixed and getattr(r, 'segment', 0) > 0 \
+            else "%d map(s) per launch" % B
+        roof_hbm = {"bound": "hbm", "kernel": "%s, %s" % (warp_kernel, maps_label),
                 "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 4),
                 "traffic": load_traffic("warp_bilinear:N=%d,C=%d,H=%d,W=%d" % (B, C, fh, fw)),
@@ -1089,7 +1102,8 @@ def main():
             "warmup": args.warmup, "settle_s": args.settle_s, "settle_steps": settle_steps,
             "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
-            "config": {"workload": "dff_rfcn ResNet-101 LSFA (DCN + FlowNet + Nq + small net + R-FCN), %d clip%s per GPU%s, "
+            "config": {"workload": ("ABLATION, NOT A RESULT (LSFA_LAB_SKIP=%s: launches dropped): " % ",".join(sorted(_hip.LAB_SKIP)) if _hip.LAB_SKIP else "") +
+                                   "dff_rfcn ResNet-101 LSFA (DCN + FlowNet + Nq + small net + R-FCN), %d clip%s per GPU%s, "
                                    "key_interval=%d, %dx%d, %s; step = 1 key + %d non-key frames per clip" %
                                    (B, "" if B == 1 else "s", "" if B == 1 else " in lock-step (batch axis)", K, args.width,
                                     args.height, args.dtype, K - 1),

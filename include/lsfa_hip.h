@@ -155,7 +155,10 @@ enum { LSFA_PROPOSAL_PLAN_AUTO = 0, LSFA_PROPOSAL_PLAN_SINGLE_WORKGROUP = 1, LSF
         * built and one 16-wave workgroup decides everything across blocks from the survivors' boxes in LDS.  No dependent trips to
         * L2, but 64 x (survivors so far) IoU tests per block on ONE CU's four SIMDs: 160 us against 18 + 48 us for mask + sweep on the
         * benchmark's RPN, so it is not what AUTO picks */
-       LSFA_PROPOSAL_PLAN_CHIP_WIDE_BOX_SWEEP = 3 };
+       LSFA_PROPOSAL_PLAN_CHIP_WIDE_BOX_SWEEP = 3,
+       /* r6, ABLATION ONLY (tools/lab/tail_ablation.sh, LSFA_LAB_SKIP_TAIL=1): the chip-wide plan WITHOUT its suppression stage - rois and
+        * scores are not written.  What the NMS launches cost the frame pipeline is the difference to a normal run; never a product setting. */
+       LSFA_PROPOSAL_PLAN_LAB_NO_NMS = 99 };
 int lsfa_proposal_set_plan(int plan);
 int lsfa_proposal(const float* cls_prob, const float* bbox_pred, const float* im_info,
                   int B, int A, int H, int W, int feature_stride,
@@ -348,6 +351,12 @@ int lsfa_status_check(unsigned* status_dev, void* stream);
  * loader / consumer waves; never the halo / direct forms then; 3: the 3x3 halo form wherever its geometry allows), the tile width nt (2 | 4), the
  * ring depth st (2..4) and the number of K slices; 0 = the launch plan decides.  Process-wide; results stay bit-reproducible per setting. */
 int lsfa_conv_plan_override(int kernel, int nt, int st, int slices);
+/* r6, measurement / test hook: the two orders the ring kernel's launch can be laid out in, process-wide like the override above; -1 = back to
+ * the default (or the LSFA_CONV_TILE_ORDER / LSFA_CONV_K_ORDER environment variables).  tile_order: 0 = workgroups numbered with the pixel tile
+ * fastest, 1 = the channel tile fastest (all channel tiles of a pixel tile on one XCD); results do not depend on it.  k_order: 0 = K walked tap by
+ * tap (a tap's channel chunks, then the next tap), 1 = channel chunk by channel chunk (a chunk's taps, then the next chunk: a tap's rows are the
+ * previous tap's rows shifted, served from the CU's L1); the summation order differs between the two, within a setting every plan agrees. */
+int lsfa_conv_order_override(int tile_order, int k_order);
 /* r5: 4 = the ring kernel on 256-pixel tiles (eight mixed-role waves; nt 4, pieces 1 | 2).
  * measurement hook (bench.py's per-instantiation roofline table): which kernel lsfa_conv_fwd would launch for `d` -
  * out[0] kernel (1 ring, 2 direct, 3 halo), out[1] nt, out[2] st, out[3] loader / consumer waves, out[4] waves that multiply (4 | 8),
@@ -472,14 +481,19 @@ int lsfa_mv_residual(const unsigned char* bgr_cur, const unsigned char* bgr_ref,
  * numpy does); out_h, out_w = ceil(h1 / stride), ceil(w1 / stride) - checked.  pixel_means_bgr_host: three doubles in host memory.
  * flags bit 1: the motion vectors are negated first, the `motion_vector = - motion_vector` of get_image (lib/utils/image.py:54).
  * OpenCV is not in the reference tree: the interpolation arithmetic follows OpenCV 3.2's resize.cpp as restated in oracle/np_ref.py
- * (parity unpinned for that part; everything around it is pinned by golden G6). */
+ * (parity unpinned for that part; everything around it is pinned by golden G6).  One case of resize() is NOT restated: at a scale of
+ * exactly 1/2 in both directions OpenCV turns INTER_LINEAR into INTER_AREA (resizeAreaFast: the mean of the 2 x 2 block as (a + b + c + d) * 0.25f,
+ * in an order its SIMD and scalar paths do not share).  The two-tap form used here weighs the same four pixels by 0.25 each: identical for
+ * integer-valued sources (decoder frames, motion vectors, residuals: every partial sum is exact), up to an ulp apart for fractional float32
+ * maps.  The second resize (1 / rcnn_stride = 1/16) never takes that switch. */
 int lsfa_transform_mv_res(const void* motion_vector, const void* res_diff, int flags, int H, int W, double im_scale, int h1, int w1,
                           int rcnn_stride, const double* pixel_means_bgr_host, double pixel_scale, float* out_mv, float* out_res,
                           int out_h, int out_w, void* stream);
 /* r5: resize + transform (lib/utils/image.py:266-308) of decoded frames in one launch: N frames (H, W, 3) BGR, uint8 (is_u8) or float32, on the
  * device -> `data` (N, 3, out_h, out_w) float32: cv2.resize by im_scale on the float image (get_image's .astype(np.float32), :52; INTER_LINEAR,
  * float32 work type), zero padding to `stride` (config.network.IMAGE_STRIDE; 0: none), channel i = (im[..., 2 - i] - pixel_means[2 - i]) *
- * pixel_scale: the subtraction in float32 (a float32 image minus a Python float), the product in float64, rounded to float32 once.  h1, w1 = cvRound(H * im_scale), cvRound(W * im_scale); out_h, out_w = h1, w1 rounded up to
+ * pixel_scale: the subtraction in float32 when stride == 0 (a float32 image minus a Python float) and in float64 when stride > 0 (the padded copy is
+ * np.zeros(...), a float64 image: image.py:288-293), the product in float64, rounded to float32 once.  h1, w1 = cvRound(H * im_scale), cvRound(W * im_scale); out_h, out_w = h1, w1 rounded up to
  * the stride - checked.  (lsfa_image_transform_u8 is the uint8-image form of `transform`: float64 subtraction; the two agree for zero means.)  (A frame that cv2.imread hands over as uint8 - the last frame of a
  * video, :45 - takes OpenCV's fixed-point uint8 path in the reference and differs from this by up to half an intensity level: stated, not
  * reproduced.) */

@@ -40,8 +40,9 @@ def detections_to_rows(all_boxes, frame_ids):
 
 def gather_rows(rows, device=None):
     """all_gather ragged (n_r, 7) row blocks: first the counts, then one padded tensor.  Returns the
-    concatenation in rank order on every rank.  Works on any initialised backend."""
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+    concatenation in rank order on every rank.  Works on any initialised backend; a world of one still issues both collectives
+    (that is how a one-GPU box exercises the RCCL path: tests/test_multirank_gpu.py)."""
+    if not (dist.is_available() and dist.is_initialized()):
         return rows
     world = dist.get_world_size()
     if device is None:

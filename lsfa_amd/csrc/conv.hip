@@ -290,6 +290,7 @@ struct SplitPlan {
 
 // lab override (lsfa_conv_plan_override): 0 = the plan decides
 std::atomic<int> g_force_nt{0}, g_force_st{0}, g_force_slices{0}, g_force_kernel{0};
+std::atomic<int> g_force_tile_order{-1}, g_force_k_order{-1};      // lsfa_conv_order_override: -1 = the default / environment
 
 size_t ring_lds_bytes(int nt, int pieces, int st) { return (size_t)st * (16384 + (size_t)nt * pieces * 2048); }
 bool ring_ok(int nt, int pieces, int st) {
@@ -507,11 +508,20 @@ static int tile_order_from_env() {
   return e ? atoi(e) : 1;
 }
 
+// LSFA_CONV_K_ORDER (lab): how the ring kernel walks K, see Walk (conv_split_kernel.h)
+static int k_order_from_env() {
+  const char* e = getenv("LSFA_CONV_K_ORDER");
+  return e ? atoi(e) : 0;
+}
+
 // every split-operand convolution goes through here; the public entry points fill in what they expose
 // validation, the launch plan, and every derived field of the argument block
 int conv_split_prepare(convsplit::Args& a, int pieces, SplitPlan& p, long& P_out, const char* who) {
   static const int tile_order = tile_order_from_env();
-  a.tile_order = tile_order;
+  static const int k_order = k_order_from_env();
+  const int f_to = g_force_tile_order.load(), f_ko = g_force_k_order.load();
+  a.tile_order = f_to >= 0 ? f_to : tile_order;
+  a.k_order = f_ko >= 0 ? f_ko : k_order;
   const int N = a.N, H = a.H, W = a.W, Cin = a.Cin, Cout = a.Cout, kh = a.kh, kw = a.kw, stride = a.stride, dil = a.dil;
   LSFA_REQUIRE(a.x && a.wfrag && a.y, "%s: NULL argument", who);
   LSFA_REQUIRE(pieces >= 1 && pieces <= 3, "%s: pieces must be 1 (bf16), 2 (fp16 hi / lo) or 3 (bf16 x 3), not %d", who, pieces);
@@ -662,6 +672,12 @@ extern "C" int lsfa_conv_plan_override(int kernel, int nt, int st, int slices) {
   LSFA_REQUIRE(kernel >= 0 && kernel <= 4 && (nt == 0 || nt == 2 || nt == 4) && (st == 0 || (st >= 2 && st <= 4)) && slices >= 0 && slices <= 16,
                "lsfa_conv_plan_override: kernel 0..4, nt 0/2/4, st 0/2..4, slices 0..16");
   g_force_kernel.store(kernel); g_force_nt.store(nt); g_force_st.store(st); g_force_slices.store(slices);
+  return LSFA_OK;
+}
+
+extern "C" int lsfa_conv_order_override(int tile_order, int k_order) {
+  LSFA_REQUIRE(tile_order >= -1 && tile_order <= 1 && k_order >= -1 && k_order <= 1, "lsfa_conv_order_override: tile_order and k_order are -1 (default), 0 or 1");
+  g_force_tile_order.store(tile_order); g_force_k_order.store(k_order);
   return LSFA_OK;
 }
 

@@ -34,6 +34,14 @@ namespace convsplit {
 
 constexpr int kFlush = 12;        // a multiple of every ring depth: the flush points do not depend on ST
 
+// lab (tools/lab/build_variant.sh): cache-policy bits of the ring's LDS-DMA loads (0 = default; 1 = sc0, 2 = nt, 16 = sc1: the latter two bypass the CU's L1)
+#ifndef LSFA_RING_A_AUX
+#define LSFA_RING_A_AUX 0
+#endif
+#ifndef LSFA_RING_B_AUX
+#define LSFA_RING_B_AUX 0
+#endif
+
 template <int NT, int PC, int ST, int WV = 4> struct Ring {     // WV: waves that multiply (4: 128-pixel tiles; 8: 256-pixel tiles, mixed roles only)
   static constexpr int kColTile = 128 * PC;                 // uint4 of one 32-column tile of one chunk: 2 steps x PC pieces x 64 lanes
   static constexpr int kStageA = WV * 256;                  // uint4 of A per stage: WV waves x 32 pixels x 8 slots (4 KB per wave)
@@ -74,7 +82,7 @@ __device__ __forceinline__ void ring_issue_a(uint4 (*R)[(Ring<NT, PC, ST, WV>::k
   for (int i = 0; i < 4; ++i) {
     const bool ok = (unsigned)(g.iy0[i] + dy_b) < (unsigned)g.H && (unsigned)(g.ix0[i] + dx) < (unsigned)g.W;
     const float* src = ok ? x + (g.off0[i] + doff) : g_zero_block;
-    __builtin_amdgcn_global_load_lds(reinterpret_cast<const uint4*>(src), a_dst + i * 64, 16, 0, 0);
+    __builtin_amdgcn_global_load_lds(reinterpret_cast<const uint4*>(src), a_dst + i * 64, 16, 0, LSFA_RING_A_AUX);
   }
 }
 
@@ -84,7 +92,7 @@ __device__ __forceinline__ void ring_issue_b(uint4 (*R)[(Ring<NT, PC, ST, WV>::k
   const uint4* wsrc = wblock + (size_t)gch * g.wstride + g.wave * (RG::kDmaB * 64) + g.lane;
   uint4* b_dst = &R[S][RG::kStageA + g.wave * (RG::kDmaB * 64)];
 #pragma unroll
-  for (int i = I0; i < I1; ++i) __builtin_amdgcn_global_load_lds(wsrc + i * 64, b_dst + i * 64, 16, 0, 0);
+  for (int i = I0; i < I1; ++i) __builtin_amdgcn_global_load_lds(wsrc + i * 64, b_dst + i * 64, 16, 0, LSFA_RING_B_AUX);
 }
 
 // ---- r5: the cut of chunk v + 1 runs UNDER the matrix instructions of chunk v ---------------------------------------------------------
@@ -183,9 +191,9 @@ __device__ __forceinline__ void ring_step_uniform(uint4 (*R)[(Ring<NT, PC, ST, W
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
   const Walk cur = wk;
-  wk.next(g.kw, g.chunks_per_tap);
+  wk.next(g.kh, g.kw, g.chunks_per_tap, g.k_order);
   ring_issue_a<NT, PC, ST, WV, SN>(R, x, g, cur, v + ST < n);
-  ring_issue_b<NT, PC, ST, WV, SN, 0, RG::kDmaB>(R, wblock, g, g.chunk0 + min(v + ST - 1, n - 1));
+  ring_issue_b<NT, PC, ST, WV, SN, 0, RG::kDmaB>(R, wblock, g, cur.bprev);      // B(v + ST - 1); past the slice's end: some valid block, into a stage nobody reads
   p = ring_mma_cut<NT, PC, ST, WV, S, AF, RG::kDma>(R, g, p, acc, a_scale, g.chunk0 + v + 1, T);
 }
 
@@ -193,8 +201,8 @@ template <int NT, int PC, int ST, int WV, int S>
 __device__ __forceinline__ void ring_prologue_uniform(uint4 (*R)[(Ring<NT, PC, ST, WV>::kStageN)], const float* __restrict__ x, const uint4* __restrict__ wblock,
                                                       const Geom& g, Walk& wk, int n) {
   ring_issue_a<NT, PC, ST, WV, S>(R, x, g, wk, S + 1 < n);
-  ring_issue_b<NT, PC, ST, WV, S, 0, Ring<NT, PC, ST, WV>::kDmaB>(R, wblock, g, g.chunk0 + min(S, n - 1));
-  wk.next(g.kw, g.chunks_per_tap);
+  ring_issue_b<NT, PC, ST, WV, S, 0, Ring<NT, PC, ST, WV>::kDmaB>(R, wblock, g, wk.bprev);      // B(S): the walk stands at A(S + 1)
+  wk.next(g.kh, g.kw, g.chunks_per_tap, g.k_order);
 }
 
 // ---- split roles (SP): waves 4-7 of a 512-thread workgroup issue the copies, waves 0-3 cut and multiply ------------------------------
@@ -215,8 +223,8 @@ __device__ __forceinline__ void ring_load_step(uint4 (*R)[(Ring<NT, PC, ST, WV>:
   __builtin_amdgcn_s_barrier();
   if (v + ST - 1 < n) {
     ring_issue_a<NT, PC, ST, WV, SN>(R, x, g, wk, v + ST < n);
-    ring_issue_b<NT, PC, ST, WV, SN, 0, RG::kDmaB>(R, wblock, g, g.chunk0 + v + ST - 1);
-    wk.next(g.kw, g.chunks_per_tap);
+    ring_issue_b<NT, PC, ST, WV, SN, 0, RG::kDmaB>(R, wblock, g, wk.bprev);      // B(v + ST - 1): the walk stands at A(v + ST)
+    wk.next(g.kh, g.kw, g.chunks_per_tap, g.k_order);
   }
 }
 
@@ -234,8 +242,8 @@ __device__ __forceinline__ void ring_prologue(uint4 (*R)[(Ring<NT, PC, ST, WV>::
                                               const Geom& g, Walk& wk, int n) {
   if (S < n) {
     ring_issue_a<NT, PC, ST, WV, S>(R, x, g, wk, S + 1 < n);
-    ring_issue_b<NT, PC, ST, WV, S, 0, Ring<NT, PC, ST, WV>::kDmaB>(R, wblock, g, g.chunk0 + S);
-    wk.next(g.kw, g.chunks_per_tap);
+    ring_issue_b<NT, PC, ST, WV, S, 0, Ring<NT, PC, ST, WV>::kDmaB>(R, wblock, g, wk.bprev);      // B(S): the walk stands at A(S + 1)
+    wk.next(g.kh, g.kw, g.chunks_per_tap, g.k_order);
   }
 }
 
@@ -271,7 +279,7 @@ __device__ __forceinline__ void ring_step_r4(uint4 (*R)[(Ring<NT, PC, ST, 4>::kS
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
   const bool more = c + ST - 1 < n;
-  const int gch_next = wk.gch;
+  const int gch_next = wk.bidx;
   if (more) ring_issue_a<NT, PC, ST, 4, SN>(R, x, g, wk, true);
   const uint4* A = &R[S][g.wave * 256];
   const uint4* B = &R[S][Ring<NT, PC, ST, 4>::kStageA + g.lane];
@@ -295,7 +303,7 @@ __device__ __forceinline__ void ring_step_r4(uint4 (*R)[(Ring<NT, PC, ST, 4>::kS
       if (NT > 3 && t == 3) ring_issue_b<NT, PC, ST, 4, SN, kE2, kDmaB>(R, wblock, g, gch_next);
     }
   }
-  if (more) wk.next(g.kw, g.chunks_per_tap);
+  if (more) wk.next(g.kh, g.kw, g.chunks_per_tap, g.k_order);
 }
 
 // ---- split roles (SP): waves 4-7 of a 512-thread workgroup issue the copies, waves 0-3 cut and multiply ------------------------------
@@ -316,8 +324,8 @@ __device__ __forceinline__ void ring_load_step_r4(uint4 (*R)[(Ring<NT, PC, ST, 4
   __builtin_amdgcn_s_barrier();
   if (c + ST - 1 < n) {
     ring_issue_a<NT, PC, ST, 4, SN>(R, x, g, wk, true);
-    ring_issue_b<NT, PC, ST, 4, SN, 0, RG::kDmaB>(R, wblock, g, wk.gch);
-    wk.next(g.kw, g.chunks_per_tap);
+    ring_issue_b<NT, PC, ST, 4, SN, 0, RG::kDmaB>(R, wblock, g, wk.bidx);
+    wk.next(g.kh, g.kw, g.chunks_per_tap, g.k_order);
   }
 }
 
@@ -344,8 +352,8 @@ __device__ __forceinline__ void ring_prologue_r4(uint4 (*R)[(Ring<NT, PC, ST, 4>
                                               const Geom& g, Walk& wk, int n) {
   if (S < n) {
     ring_issue_a<NT, PC, ST, 4, S>(R, x, g, wk, true);
-    ring_issue_b<NT, PC, ST, 4, S, 0, Ring<NT, PC, ST, 4>::kDmaB>(R, wblock, g, wk.gch);
-    wk.next(g.kw, g.chunks_per_tap);
+    ring_issue_b<NT, PC, ST, 4, S, 0, Ring<NT, PC, ST, 4>::kDmaB>(R, wblock, g, wk.bidx);
+    wk.next(g.kh, g.kw, g.chunks_per_tap, g.k_order);
   }
 }
 
@@ -397,7 +405,8 @@ void conv_ring_kernel(Args a, int nx, int ny, int nz) {
   if (AF && !loader) {      // visible to every consumer after the first chunk's barrier (which an lgkmcnt(0) precedes)
     for (int k = tid; k < a.Cin; k += 64 * WV) { T[k] = a.in_scale[k] * a_scale; T[kAffineMaxCin + k] = a.in_shift[k] * a_scale; }
   }
-  g.H = a.H; g.W = a.W; g.Cin = a.Cin; g.lda = a.lda; g.kw = a.kw; g.stride = a.stride; g.dil = a.dil;
+  g.H = a.H; g.W = a.W; g.Cin = a.Cin; g.lda = a.lda; g.kh = a.kh; g.kw = a.kw; g.stride = a.stride; g.dil = a.dil;
+  g.k_order = taps > 1 ? a.k_order : 0;
   g.chunks_per_tap = a.Cin / kChunk;
   const int chunk_total = taps * g.chunks_per_tap;
   g.chunk0 = tile.z * a.chunks_per_slice;
@@ -434,13 +443,7 @@ void conv_ring_kernel(Args a, int nx, int ny, int nz) {
     for (int i = 0; i < 16; ++i) acc[t][i] = 0.f;
 
   Walk wk;       // the next chunk whose A is to be fetched
-  wk.gch = g.chunk0;
-  {
-    const int tap = fdiv(g.chunk0, g.chunks_per_tap, a.inv_cpt);
-    wk.kc = g.chunk0 - tap * g.chunks_per_tap;
-    wk.ty = fdiv(tap, a.kw, a.inv_kw);
-    wk.tx = tap - wk.ty * a.kw;
-  }
+  wk.start(g.chunk0, a.kh, a.kw, g.chunks_per_tap, g.k_order);
   f32x16 sum[NT];        // block sums (second level)
 #pragma unroll
   for (int t = 0; t < NT; ++t)
@@ -502,7 +505,7 @@ void conv_ring_kernel(Args a, int nx, int ny, int nz) {
     // v-chunk -1 (A(0) alone) into stage ST - 1, v-chunks 0 .. ST-2 into stages 0 .. ST-2, then one step per v-chunk: wait for it, meet,
     // refill the stage v-chunk v - 1 left
     ring_issue_a<NT, PC, ST, WV, ST - 1>(R, a.x, g, wk, true);
-    wk.next(g.kw, g.chunks_per_tap);
+    wk.next(g.kh, g.kw, g.chunks_per_tap, g.k_order);
     ring_prologue<NT, PC, ST, WV, 0>(R, a.x, wblock, g, wk, nchunks);
     if (ST > 2) ring_prologue<NT, PC, ST, WV, (ST > 2 ? 1 : 0)>(R, a.x, wblock, g, wk, nchunks);
     if (ST > 3) ring_prologue<NT, PC, ST, WV, (ST > 3 ? 2 : 0)>(R, a.x, wblock, g, wk, nchunks);
@@ -518,7 +521,7 @@ void conv_ring_kernel(Args a, int nx, int ny, int nz) {
   }
   if (kUniform) {
     ring_issue_a<NT, PC, ST, WV, ST - 1>(R, a.x, g, wk, true);
-    wk.next(g.kw, g.chunks_per_tap);
+    wk.next(g.kh, g.kw, g.chunks_per_tap, g.k_order);
     ring_prologue_uniform<NT, PC, ST, WV, 0>(R, a.x, wblock, g, wk, nchunks);
     if (ST > 2) ring_prologue_uniform<NT, PC, ST, WV, (ST > 2 ? 1 : 0)>(R, a.x, wblock, g, wk, nchunks);
     if (ST > 3) ring_prologue_uniform<NT, PC, ST, WV, (ST > 3 ? 2 : 0)>(R, a.x, wblock, g, wk, nchunks);

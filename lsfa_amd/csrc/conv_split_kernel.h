@@ -74,6 +74,7 @@ struct Args {
   // ~35 dependent VALU instructions, and a short launch spent more time in its prologue's divisions than in its matrix instructions
   float inv_wo, inv_howo, inv_nx, inv_ny, inv_cpt, inv_kw;      // 1 / Wo, 1 / (Ho Wo), 1 / nx, 1 / ny, 1 / (Cin / 32), 1 / kw
   int tile_order;   // 0: tiles numbered (slice, channel tile, pixel tile), pixel fastest; 1: (slice, pixel tile, channel tile), channel fastest
+  int k_order;      // r6, ring kernel: 0 = a tap's channel chunks before the next tap; 1 = a channel chunk's taps before the next chunk (Walk)
   // r4: the input is channels [0, Cin) of an NCHW map with `lda` channels (K-major for the contraction: element (pixel, channel) at
   // x[(n * lda + channel) * H * W + pixel]); 1x1 / stride 1 / no padding, the direct kernel only (the RPN head on the feature map the
   // reference's operators exchange)
@@ -700,7 +701,7 @@ __device__ __attribute__((aligned(64))) const float g_zero_block[32] = {};
 
 struct Geom {       // per lane / per wave constants of the loop
   size_t wstride;                            // uint4 between consecutive chunks
-  int H, W, Cin, lda, kw, stride, dil, chunks_per_tap, chunk0;
+  int H, W, Cin, lda, kh, kw, stride, dil, chunks_per_tap, chunk0, k_order;
   // the four pixels this lane moves (DMA i: pixel 8*i + (lane >> 3)): top-left input coordinate of its window
   // (hugely negative when the pixel does not exist) and the float offset of (that coordinate, the lane's swizzled piece)
   int iy0[4], ix0[4], off0[4];
@@ -712,11 +713,29 @@ struct Geom {       // per lane / per wave constants of the loop
 // 12 KB of chunk 0) are __restrict__ parameters on purpose (see the header comment).
 // which (tap row, tap column, channel chunk) a chunk index is, walked incrementally (an integer division per chunk
 // cost ~50 scalar instructions in the loop)
+// r6: two orders.  k_order 0 walks a tap's channel chunks before the next tap (weights are packed that way: block (tap, chunk) at index
+// tap * chunks_per_tap + chunk); k_order 1 walks the taps of one channel chunk before the next chunk, so that a tap's rows are the previous
+// tap's rows shifted by `dil` pixels (or rows) and come out of the CU's L1 instead of L2.  `bidx` is the weight block of the walk's
+// position, `bprev` that of the position before it (the pipelined ring holds B(v) beside A(v + 1)); both clamped to the array.
 struct Walk {
   int ty, tx, kc, gch;
-  __device__ __forceinline__ void next(int kw, int chunks_per_tap) {
+  int bidx, bprev;
+  __device__ __forceinline__ void start(int pos, int kh, int kw, int chunks_per_tap, int k_order) {
+    gch = pos;
+    const int taps = kh * kw;
+    int tap;
+    // once per workgroup (pos = 0 unless K is sliced); fdiv with approximate reciprocals: its fix-up absorbs their last-bit error
+    if (k_order) { kc = fdiv(pos, taps, __builtin_amdgcn_rcpf((float)taps)); tap = pos - kc * taps; }
+    else { tap = fdiv(pos, chunks_per_tap, __builtin_amdgcn_rcpf((float)chunks_per_tap)); kc = pos - tap * chunks_per_tap; }
+    ty = fdiv(tap, kw, __builtin_amdgcn_rcpf((float)kw)); tx = tap - ty * kw;
+    bidx = bprev = min(tap * chunks_per_tap + kc, taps * chunks_per_tap - 1);
+  }
+  __device__ __forceinline__ void next(int kh, int kw, int chunks_per_tap, int k_order) {
     ++gch;
-    if (++kc == chunks_per_tap) { kc = 0; if (++tx == kw) { tx = 0; ++ty; } }
+    bprev = bidx;
+    if (k_order) { if (++tx == kw) { tx = 0; if (++ty == kh) { ty = 0; ++kc; } } }
+    else { if (++kc == chunks_per_tap) { kc = 0; if (++tx == kw) { tx = 0; ++ty; } } }
+    bidx = min((ty * kw + tx) * chunks_per_tap + kc, kh * kw * chunks_per_tap - 1);
   }
 };
 

@@ -167,13 +167,13 @@ __global__ __launch_bounds__(kThreads) void transform_mv_res_kernel(const T* __r
 // ---- r5: resize + transform (lib/utils/image.py:266-308) of a decoded frame in one launch -----------------------------------------------
 // `resize`: cv2.resize by im_scale on the FLOAT image (get_image converts the decoder's frame with .astype(np.float32) first, :52: OpenCV's
 // float path, as above), zero padding to the image stride; `transform`: channel i = (im[..., 2 - i] - pixel_means[2 - i]) * pixel_scale: the
-// subtraction in float32 (a float32 image minus a Python float: config.py:172-182 leaves a list), the product in float64 (np.zeros), rounded
-// to float32 at the executor.  Padding pixels are transformed like any other ((0 - mean) * scale), as in the
+// subtraction in float32 when stride == 0 (a float32 image minus a Python float: config.py:172-182 leaves a list) and in float64 when the frame was
+// padded (the padded copy is np.zeros(...): float64, image.py:288-293), the product in float64 (np.zeros), rounded to float32 at the executor.  Padding pixels are transformed like any other ((0 - mean) * scale), as in the
 // reference.  A thread per output pixel, the three channels together.
 template <typename T>
 __global__ __launch_bounds__(kThreads) void resize_transform_kernel(const T* __restrict__ im, int N, int H, int W, int h1, int w1, int ph, int pw,
                                                                     double inv_scale, double m0, double m1, double m2, double pixel_scale,
-                                                                    float* __restrict__ out) {
+                                                                    int sub_f64, float* __restrict__ out) {
   const long i = (long)blockIdx.x * kThreads + threadIdx.x;
   const long plane = (long)ph * pw;
   if (i >= N * plane) return;
@@ -188,7 +188,15 @@ __global__ __launch_bounds__(kThreads) void resize_transform_kernel(const T* __r
     rr = first_resize(src, H, W, 3, 2, y, x, inv_scale);
   }
   float* o = out + (size_t)n * 3 * plane + r;
-  // a float32 image minus a Python float is a float32 subtraction (the mean rounded to float32 first); the product with pixel_scale is float64
+  if (sub_f64) {
+    // stride > 0: `resize` copied the float32 frame into np.zeros(...) - a float64 image (image.py:288-293) - so `transform` subtracts in float64
+    // and the executor rounds once
+    o[0] = (float)(((double)rr - m2) * pixel_scale);
+    o[plane] = (float)(((double)g - m1) * pixel_scale);
+    o[2 * plane] = (float)(((double)b - m0) * pixel_scale);
+    return;
+  }
+  // stride == 0: a float32 image minus a Python float is a float32 subtraction (the mean rounded to float32 first); the product with pixel_scale is float64
   const float tr = rr - (float)m2, tg = g - (float)m1, tb = b - (float)m0;
   o[0] = (float)((double)tr * pixel_scale);
   o[plane] = (float)((double)tg * pixel_scale);
@@ -213,10 +221,10 @@ extern "C" int lsfa_image_resize_transform(const void* im_hwc_bgr, int is_u8, in
   const dim3 grid((unsigned)((total + kThreads - 1) / kThreads));
   if (is_u8)
     hipLaunchKernelGGL(resize_transform_kernel<unsigned char>, grid, dim3(kThreads), 0, s, (const unsigned char*)im_hwc_bgr, N, H, W, h1, w1, ph, pw,
-                       1.0 / im_scale, pixel_means_bgr_host[0], pixel_means_bgr_host[1], pixel_means_bgr_host[2], pixel_scale, data_nchw);
+                       1.0 / im_scale, pixel_means_bgr_host[0], pixel_means_bgr_host[1], pixel_means_bgr_host[2], pixel_scale, stride > 0 ? 1 : 0, data_nchw);
   else
     hipLaunchKernelGGL(resize_transform_kernel<float>, grid, dim3(kThreads), 0, s, (const float*)im_hwc_bgr, N, H, W, h1, w1, ph, pw, 1.0 / im_scale,
-                       pixel_means_bgr_host[0], pixel_means_bgr_host[1], pixel_means_bgr_host[2], pixel_scale, data_nchw);
+                       pixel_means_bgr_host[0], pixel_means_bgr_host[1], pixel_means_bgr_host[2], pixel_scale, stride > 0 ? 1 : 0, data_nchw);
   LSFA_LAUNCH_CHECK("lsfa_image_resize_transform");
   return LSFA_OK;
 }

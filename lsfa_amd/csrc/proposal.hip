@@ -733,7 +733,8 @@ WsLayout ws_layout(int B, int count, int pre_n, int post_n) {
 
 static std::atomic<int> g_plan{LSFA_PROPOSAL_PLAN_AUTO};
 extern "C" int lsfa_proposal_set_plan(int plan) {
-  LSFA_REQUIRE(plan >= LSFA_PROPOSAL_PLAN_AUTO && plan <= LSFA_PROPOSAL_PLAN_CHIP_WIDE_BOX_SWEEP, "lsfa_proposal_set_plan: unknown plan %d", plan);
+  LSFA_REQUIRE((plan >= LSFA_PROPOSAL_PLAN_AUTO && plan <= LSFA_PROPOSAL_PLAN_CHIP_WIDE_BOX_SWEEP) || plan == LSFA_PROPOSAL_PLAN_LAB_NO_NMS,
+               "lsfa_proposal_set_plan: unknown plan %d", plan);
   g_plan.store(plan);
   return LSFA_OK;
 }
@@ -798,6 +799,10 @@ extern "C" int lsfa_proposal(const float* cls_prob, const float* bbox_pred, cons
                        (const uint32_t*)hist, A, H * W, pre_n, cand, info, bin_start, bin_count);
     hipLaunchKernelGGL(proposal_rank_kernel, dim3(gi, B), dim3(kRankThreads), 0, s, (const uint64_t*)cand, (const int*)info,
                        (const int*)bin_start, (const int*)bin_count, count, pre_n, (const float4*)boxes, sbox, skey);
+    if (plan == LSFA_PROPOSAL_PLAN_LAB_NO_NMS) {      // ablation: what the suppression stage costs the pipeline (no rois are written)
+      LSFA_LAUNCH_CHECK("lsfa_proposal");
+      return LSFA_OK;
+    }
     if (plan != LSFA_PROPOSAL_PLAN_CHIP_WIDE_BOX_SWEEP) {
       hipLaunchKernelGGL(nms_mask_kernel<true>, dim3(ceil_div(nms_tile_count(col_blocks), 4), 1, B), dim3(256), 0, s,
                          (const float*)sbox, (long)pre_n * 4, 4, (const int*)nullptr, pre_n, iou, mask, diagT, col_blocks, 0);

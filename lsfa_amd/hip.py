@@ -194,8 +194,10 @@ def aggregate_softmax2(a, b, logits, out=None, logit_row_stride=None):
     if out is None:
         out = torch.empty_like(a)
     if logit_row_stride is not None:
-        if logits.dtype != torch.float32 or not logits.is_contiguous() or logits.numel() < (2 * N - 1) * logit_row_stride + H * W:
-            raise LsfaError("aggregate_softmax2: logits %s too small for %d rows %d floats apart" % (tuple(logits.shape), 2 * N, logit_row_stride))
+        if (logits.dtype != torch.float32 or not logits.is_contiguous() or logits.device != a.device or logit_row_stride < H * W or
+                logits.numel() < (2 * N - 1) * logit_row_stride + H * W):
+            raise LsfaError("aggregate_softmax2: logits %s (%s, %s) must be contiguous float32 on %s with %d rows of %d logits >= %d floats apart, got stride %d" % (
+                tuple(logits.shape), logits.dtype, logits.device, a.device, 2 * N, H * W, H * W, logit_row_stride))
         _check(lib().lsfa_aggregate_softmax2_rows(_ptr(a), _ptr(b), _ptr(logits), ctypes.c_long(logit_row_stride), _ci(N), _ci(C), _ci(H), _ci(W),
                                                   _ptr(out), _stream()), "lsfa_aggregate_softmax2_rows")
         return out
@@ -268,7 +270,18 @@ class ProposalOp(object):
 @_on_tensor_device
 def proposal_set_plan(plan):
     """'auto' | 'single' | 'chip' | 'chip-box-sweep': lsfa_proposal_set_plan (process-wide launch plan; same results)."""
-    _check(lib().lsfa_proposal_set_plan(_ci({'auto': 0, 'single': 1, 'chip': 2, 'chip-box-sweep': 3}[plan])), "lsfa_proposal_set_plan")
+    _check(lib().lsfa_proposal_set_plan(_ci({'auto': 0, 'single': 1, 'chip': 2, 'chip-box-sweep': 3, 'lab-no-nms': 99}[plan])), "lsfa_proposal_set_plan")
+
+
+# Ablation switches (tools/lab/tail_ablation.sh; VERDICT r5 items 4 and 5): LSFA_LAB_SKIP=tail,copy,nhwc drops launches from every frame so that
+# bench.py's frames/s with and without them says what they cost the PIPELINE (not what they take alone):
+#   tail  the Proposal's suppression stage (nms_mask + nms_sweep), the PSROI head, the detection post-processing (det_class + det_cap)
+#   copy  lsfa_copy_many's staging copies of frames / motion vectors / residuals into a graph's static buffers (after each buffer's first fill)
+#   nhwc  lsfa_nchw_to_nhwc in front of the R-FCN / Nq convolutions (after each output's first fill)
+# Results are garbage then; bench.py labels the line, reports no parity and does not read the status word.  Never set in a product run.
+LAB_SKIP = set(v for v in os.environ.get('LSFA_LAB_SKIP', '').split(',') if v)
+LAB_SKIP_TAIL = 'tail' in LAB_SKIP
+_lab_filled = set()
 
 
 def nms_sorted(boxes, thresh):
@@ -336,6 +349,8 @@ def det_postprocess(rois, deltas, probs, im_h, im_w, scale, score_thresh=1e-4, n
         keep_idx = torch.full((ncls, R), -1, dtype=torch.int32, device=rois.device)
     else:
         dets, counts, keep_idx = out
+    if LAB_SKIP_TAIL:
+        return dets, counts, keep_idx
     _check(lib().lsfa_det_postprocess(_ptr(rois), _ptr(deltas), _ptr(probs), _ci(R), _ci(ncls), _ci(nreg),
                                       _ci(int(class_agnostic)), _cd(im_h), _cd(im_w), _cd(scale), _cd(score_thresh),
                                       _cd(nms_thresh), _ci(max_per_image), _ptr(dets), _ptr(counts), _ptr(keep_idx),
@@ -368,6 +383,8 @@ def det_postprocess_batch(rois, deltas, probs, B, im_h, im_w, scale, out, score_
     if tuple(dets.shape) != (B, ncls, R, 5) or tuple(counts.shape) != (B, ncls) or not (dets.is_contiguous() and counts.is_contiguous() and
                                                                                        keep_idx.is_contiguous()):
         raise LsfaError("det_postprocess_batch: out must be contiguous (B, ncls, R, 5) / (B, ncls) / (B, ncls, R) buffers")
+    if LAB_SKIP_TAIL:
+        return dets, counts, keep_idx
     _check(lib().lsfa_det_postprocess_batch(_ptr(rois), _ptr(deltas), _ptr(probs), _ci(B), _ci(R), _ci(ncls), _ci(nreg),
                                             _ci(int(class_agnostic)), _cd(im_h), _cd(im_w), _cd(scale), _cd(score_thresh),
                                             _cd(nms_thresh), _ci(max_per_image), _ptr(dets), _ptr(counts), _ptr(keep_idx),
@@ -557,6 +574,16 @@ def copy_many(pairs):
         if s is not None and (d.shape != s.shape or d.dtype != s.dtype or not s.is_contiguous() or d.device != s.device):
             raise LsfaError("copy_many: %s <- %s: need equal shapes, 4-byte dtype, contiguous, one device"
                             % (tuple(d.shape), tuple(s.shape)))
+    if 'copy' in LAB_SKIP:      # ablation: copies of >= 1 KB into a buffer that has been filled once are dropped (zero fills stay)
+        kept = []
+        for d, s_ in pairs:
+            if s_ is None or d.numel() < 256 or d.data_ptr() not in _lab_filled:
+                kept.append((d, s_))
+            _lab_filled.add(d.data_ptr())
+        pairs = kept
+        n = len(pairs)
+        if not n:
+            return
     dst = (ctypes.c_void_p * n)(*[d.data_ptr() for d, _ in pairs])
     src = (ctypes.c_void_p * n)(*[(s.data_ptr() if s is not None else None) for _, s in pairs])
     cnt = (ctypes.c_long * n)(*[d.numel() for d, _ in pairs])
@@ -702,6 +729,9 @@ def nchw_to_nhwc(x, c0=0, c=None, out=None, amax_out=None):
         out = torch.empty((N, H, W, c), device=x.device, dtype=torch.float32)
     elif tuple(out.shape) != (N, H, W, c) or not out.is_contiguous() or out.dtype != torch.float32:
         raise LsfaError("nchw_to_nhwc: out must be a contiguous float32 %s tensor" % ((N, H, W, c),))
+    if 'nhwc' in LAB_SKIP and out.data_ptr() in _lab_filled:
+        return out
+    _lab_filled.add(out.data_ptr())
     _check(lib().lsfa_nchw_to_nhwc(_ptr(x), _ci(N), _ci(C), _ci(H * W), _ci(c0), _ci(c), _ptr(out), _ptr(amax_out), _stream()),
            "lsfa_nchw_to_nhwc")
     return out
@@ -713,6 +743,8 @@ def rfcn_head_ps_ld(ps_map, cell_ld, rois, H, W, ncls, nbox, spatial_scale=0.062
     N, R = ps_map.shape[0], rois.shape[0]
     cls_prob = torch.empty((R, ncls), device=rois.device, dtype=torch.float32)
     bbox_pred = torch.empty((R, nbox), device=rois.device, dtype=torch.float32)
+    if LAB_SKIP_TAIL:
+        return cls_prob, bbox_pred
     with torch.cuda.device(ps_map.device):
         _check(lib().lsfa_rfcn_head_ps_ld_fwd(_ptr(ps_map), _ci(cell_ld), _ptr(rois), _ci(N), _ci(H), _ci(W), _ci(R), _ci(ncls), _ci(nbox),
                                               _cf(spatial_scale), _ci(pooled_size), _ci(group_size), _ptr(cls_prob), None,
@@ -866,6 +898,8 @@ def new_status(device):
 def check_status(status):
     """lsfa_status_check: raises LsfaError if a convolution raised the status word (non-finite output: the fp16 form's scale was an
     under-estimate, or the input held inf / NaN).  Synchronises the current stream."""
+    if LAB_SKIP:      # an ablation run's maps are garbage by construction
+        return
     _check(lib().lsfa_status_check(_ptr(status), _stream()), "lsfa_status_check")
 
 
@@ -1099,6 +1133,12 @@ def deconv4x4s2_crop(x, sw4, bias, out, c0=0, act=0, amax_in=None, amax_out=None
 def conv_plan_override(kernel=0, nt=0, st=0, slices=0):
     """lsfa_conv_plan_override (lab): force the ring kernel (kernel=1), its tile width / ring depth / K slices; zeros = the plan decides"""
     _check(lib().lsfa_conv_plan_override(_ci(kernel), _ci(nt), _ci(st), _ci(slices)), "lsfa_conv_plan_override")
+
+
+def conv_order_override(tile_order=-1, k_order=-1):
+    """lsfa_conv_order_override (lab / tests): workgroup -> tile numbering (0 pixel tile fastest, 1 channel tile fastest) and the ring kernel's walk
+    of K (0 tap by tap, 1 channel chunk by channel chunk); -1 = the default"""
+    _check(lib().lsfa_conv_order_override(_ci(tile_order), _ci(k_order)), "lsfa_conv_order_override")
 
 
 class MotionVectorAccumulator(object):

@@ -65,7 +65,9 @@ def main():
     if os.environ.get('LSFA_BENCH_ONE_DEVICE') == '1':
         local_rank = 0
     torch.cuda.set_device(local_rank)
-    if world > 1:
+    # LSFA_BENCH_FORCE_DIST=1: initialise the process group at world size 1 too (a one-GPU box then runs RCCL's init and the final
+    # gather's collectives on device tensors: tests/test_multirank_gpu.py)
+    if world > 1 or (os.environ.get('LSFA_BENCH_FORCE_DIST') == '1' and 'RANK' in os.environ):
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         if backend == 'nccl':
             dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))

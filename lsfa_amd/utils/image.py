@@ -63,17 +63,17 @@ def resize(im, target_size, max_size, stride=0):
         return out, im_scale
     ph = int(np.ceil(out.shape[0] / float(stride)) * stride)
     pw = int(np.ceil(out.shape[1] / float(stride)) * stride)
-    padded = torch.zeros((ph, pw, out.shape[2]), dtype=out.dtype, device=out.device)
+    padded = torch.zeros((ph, pw, out.shape[2]), dtype=torch.float64, device=out.device)      # np.zeros(...): a float64 image (image.py:291)
     padded[:out.shape[0], :out.shape[1]] = out
     return padded, im_scale
 
 
 def transform(im, pixel_means, pixel_scale):
     """(H, W, 3) BGR -> (1, 3, H, W) RGB minus means, times scale.  lib/utils/image.py:296-308, in its precisions: a float image minus the
-    (Python float) mean is a float32 subtraction, a uint8 image's a float64 one; the product with pixel_scale is float64 (np.zeros), rounded to
+    (Python float) mean is a float32 subtraction, a uint8 or float64 (padded by `resize`) image's a float64 one; the product with pixel_scale is float64 (np.zeros), rounded to
     float32 where the reference hands the array to the executor."""
     im = torch.as_tensor(im)
-    if im.dtype == torch.uint8:
+    if im.dtype in (torch.uint8, torch.float64):      # (float64: a frame `resize` padded to the stride)
         x = im.double()
         means = torch.as_tensor(np.asarray(pixel_means, dtype=np.float64), device=im.device)
     else:

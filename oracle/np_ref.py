@@ -175,7 +175,10 @@ def cv2_resize_linear(src, fx, fy):
     """cv2.resize(src, None, None, fx, fy, INTER_LINEAR) for float images (OpenCV 3.2 resize.cpp:
     dsize = cvRound(size*f); with fx / fy given the scale is 1/f (`scale_x = 1. / inv_scale_x`), NOT
     src/dst; source coordinate (d + 0.5)*scale - 0.5, clamped so that the two taps stay inside;
-    horizontal pass then vertical pass) [un-vendored, parity unpinned]."""
+    horizontal pass then vertical pass) [un-vendored, parity unpinned].
+    NOT restated: at fx == fy == 0.5 exactly, OpenCV 3.2's resize() switches INTER_LINEAR to INTER_AREA (resizeAreaFast,
+    (a + b + c + d) * 0.25f).  The two taps below weigh the same 2 x 2 block by 0.25 each: equal bit for bit on
+    integer-valued sources (frames, motion vectors, residuals), up to an ulp apart on fractional float32 maps."""
     # resize.cpp's linear_tab: CV_32F runs HResizeLinear<float, float, float> / VResizeLinear<float, float, float>, CV_64F
     # HResizeLinear<double, double, float> / VResizeLinear<double, double, float>: a float64 image (the zero-padded maps of
     # transform_mv_res, image.py:210-222) is interpolated in double with the SAME float coefficients and comes back float64

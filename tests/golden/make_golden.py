@@ -167,6 +167,9 @@ def main():
     g["g6_resize_in"] = big
     r_im, r_scale = image.resize(big, 60, 100, stride=16)                  # short side -> 60, capped by the long side; padded to 16
     g["g6_resize_out"], g["g6_resize_scale"] = r_im, np.asarray(r_scale)
+    # the decoder's float32 frame padded to the stride: `resize` returns a float64 image then, and `transform` subtracts in float64
+    r_f32, _ = image.resize(big.astype(np.float32), 60, 100, stride=16)
+    g["g6_resize_f32_stride16_transform"] = image.transform(r_f32, [103.94, 116.78, 123.68], 0.017)
     r_im2, r_scale2 = image.resize(big, 60, 90, stride=0)                  # the max_size rule takes over
     g["g6_resize_out_capped"], g["g6_resize_scale_capped"] = r_im2, np.asarray(r_scale2)
     np.savez_compressed(OUT, **g)

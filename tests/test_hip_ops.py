@@ -302,6 +302,10 @@ def test_aggregate_softmax2_reads_logit_rows_in_place(hip, shape):
     np.testing.assert_array_equal(got, want)
     with pytest.raises(hip.LsfaError):                             # a buffer that does not hold the last row
         hip.aggregate_softmax2(t(a), t(b), t(wide.reshape(-1)[:(2 * N - 1) * stride + H * W - 1].copy()), logit_row_stride=stride)
+    with pytest.raises(hip.LsfaError):                             # rows that overlap
+        hip.aggregate_softmax2(t(a), t(b), t(wide), logit_row_stride=H * W - 1)
+    with pytest.raises(hip.LsfaError):                             # logits on another device than the maps: the C side cannot tell
+        hip.aggregate_softmax2(t(a), t(b), torch.from_numpy(wide), logit_row_stride=stride)
 
 
 @pytest.mark.parametrize("shape", [(4, 1024, 38, 63), (3, 20, 8, 8), (32, 64, 38, 63)])
@@ -998,7 +1002,7 @@ def test_image_resize_transform_on_the_device_is_the_references(hip, case):
         r = np_ref.cv2_resize_linear(im.astype(np.float32), scale, scale)
         if stride:
             ph, pw = -(-r.shape[0] // stride) * stride, -(-r.shape[1] // stride) * stride
-            p = np.zeros((ph, pw, 3), np.float32)
+            p = np.zeros((ph, pw, 3))            # float64, like the reference's np.zeros (image.py:291): transform then subtracts in float64
             p[:r.shape[0], :r.shape[1]] = r
             r = p
         return np_ref.transform(r, means, ps).astype(np.float32)
@@ -1018,6 +1022,14 @@ def test_image_resize_transform_golden_g6_float32_frame(hip, golden):
     imf = golden["g6_im"].astype(np.float32) * np.float32(0.731)
     got = hip.image_resize_transform(t(imf), 1.0, [103.94, 116.78, 123.68], 0.017)
     np.testing.assert_array_equal(got.cpu().numpy(), golden["g6_transform_f32_list_means"].astype(np.float32))
+
+
+def test_image_resize_transform_golden_g6_padded_frame(hip, golden):
+    """... and G6's padded case: the reference's own resize(stride=16) + transform on a float32 frame - the padded copy is a float64
+    image, so the mean is subtracted in float64."""
+    big = golden["g6_resize_in"].astype(np.float32)
+    got = hip.image_resize_transform(t(big), float(golden["g6_resize_scale"]), [103.94, 116.78, 123.68], 0.017, stride=16)
+    np.testing.assert_array_equal(got.cpu().numpy(), golden["g6_resize_f32_stride16_transform"].astype(np.float32))
 
 
 def test_transform_mv_res_golden_g6_on_the_device(hip, golden):
@@ -1689,6 +1701,57 @@ def test_conv_ring_every_plan_gives_the_same_convolution(hip, pieces):
                     by_cut[key] = y
     finally:
         hip.conv_plan_override()
+
+
+def test_conv_tile_order_and_k_order(hip):
+    """lsfa_conv_order_override (r6's K walk).  Tile order only renumbers the workgroups: with >= 4 channel tiles (Cout 512), K slices
+    and the four phases of a transposed convolution in one launch, both orders give the SAME bits.  The K walk (tap by tap / channel chunk by
+    channel chunk) changes the order of summation: the two walks agree with float64 within the fp32 bound, and within one walk every forced
+    plan with the same tile width and K cut agrees bit for bit."""
+    import torch.nn.functional as F
+    g = torch.Generator(device=DEV).manual_seed(91)
+    H, W, ci, co, dil = 23, 31, 256, 512, 2
+    x = torch.relu(torch.randn((2, H, W, ci), device=DEV, generator=g))
+    w = torch.randn((co, ci, 3, 3), device=DEV, generator=g) * 0.02
+    b = torch.randn(co, device=DEV, generator=g)
+    ref = torch.relu(F.conv2d(x.permute(0, 3, 1, 2).double().cpu(), w.double().cpu(), b.double().cpu(), padding=dil, dilation=dil)).permute(0, 2, 3, 1)
+    tol = 2e-6 * (ci * 9) ** 0.5 * float(ref.abs().max())
+    sw = hip.SplitWeight(w, pieces=2)
+    am = hip.amax_partial(x)
+    # a transposed convolution whose phases are K-sliced (K = 4 x 1056)
+    Cin, Cout, Hi, Wi, Hc, Wc = 1056, 256, 10, 16, 19, 32
+    xd = torch.randn(1, Hi, Wi, Cin, device=DEV, generator=g)
+    wt = torch.randn(Cin, Cout, 4, 4, device=DEV, generator=g) * (1.0 / (4 * Cin) ** 0.5)
+    bd = torch.randn(Cout, device=DEV, generator=g)
+    sws = hip.deconv_phase_weights(wt)
+    full = F.leaky_relu(F.conv_transpose2d(xd.permute(0, 3, 1, 2).double().cpu(), wt.double().cpu(), bd.double().cpu(), stride=2), 0.1)
+    refd = full[:, :, 1:1 + Hc, 1:1 + Wc].permute(0, 2, 3, 1)
+    try:
+        seen = {}
+        for k_order in (0, 1):
+            for tile_order in (0, 1):
+                hip.conv_order_override(tile_order=tile_order, k_order=k_order)
+                for kern, nt, st, slices in ((1, 2, 2, 1), (2, 2, 3, 3), (1, 4, 2, 2), (2, 4, 3, 1), (2, 4, 3, 5)):
+                    hip.conv_plan_override(kernel=kern, nt=nt, st=st, slices=slices)
+                    y = hip.conv_split(x, sw, b, 1, dil, dil, relu=True, amax_in=am)
+                    assert float((y.double().cpu() - ref).abs().max()) < tol, (k_order, tile_order, kern, nt, st, slices)
+                    key = (k_order, nt, slices)
+                    if key in seen:
+                        assert torch.equal(seen[key], y), (k_order, tile_order, kern, nt, st, slices)
+                    seen[key] = y
+                for slices in (1, 2):
+                    hip.conv_plan_override(kernel=2, nt=2, st=3, slices=slices)
+                    one = torch.zeros((1, Hc, Wc, Cout), device=DEV)
+                    hip.deconv4x4s2_crop(xd, sws, bd, one, act=2)
+                    assert float((one.double().cpu() - refd).abs().max()) < 2e-6 * (Cin * 4) ** 0.5 * float(refd.abs().max())
+                    key = ('deconv', k_order, slices)
+                    if key in seen:
+                        assert torch.equal(seen[key], one), (k_order, tile_order, slices)
+                    seen[key] = one
+        assert not torch.equal(seen[(0, 4, 1)], seen[(1, 4, 1)])       # the two walks do sum in different orders (else this test checks nothing)
+    finally:
+        hip.conv_plan_override()
+        hip.conv_order_override()
 
 
 @pytest.mark.parametrize("shape", [(38, 63, 256, 1024, 1), (30, 70, 192, 1024, 2), (150, 250, 64, 64, 1)])

@@ -133,3 +133,48 @@ def test_bench_eight_ranks_one_device():
     assert abs(d["value"] - frames / (d["ms_per_step"] * 2 / 1e3)) < 0.02 * d["value"]
     assert abs(d["ms_per_step"] * 2 / 1e3 - max(p["seconds"] for p in m["per_rank"])) < 1e-3      # max over ranks
     assert m["final_gather"]["rows"] > 0
+
+
+def _rccl_env():
+    """The real backend: no gloo substitution; the single rank is LOCAL_RANK 0 = cuda:0."""
+    env = _env()
+    del env["LSFA_BENCH_BACKEND"], env["LSFA_BENCH_ONE_DEVICE"]
+    env["LSFA_BENCH_FORCE_DIST"] = "1"
+    return env
+
+
+def test_bench_rccl_initialised_at_world_size_one():
+    """RCCL on the one GPU there is: `bench.py --gpus 1` launched the driver's way (torch.distributed.run, a fresh
+    child that has not touched the GPU) with LSFA_BENCH_FORCE_DIST=1 takes the distributed branch with backend 'nccl' (= RCCL on ROCm):
+    init_process_group('nccl', device_id=...), barrier(device_ids=...) on both sides of the timed region, the MAX all_reduce of the
+    times, the all_gather of the per-rank record and gather_rows' two all_gathers, all on DEVICE tensors.  That is every line of the
+    branch an 8-GPU run takes except N > 1 itself (dff_rfcn/core/tester.py:301-312 is the fan-out it stands for)."""
+    small = ["--steps", "2", "--warmup", "1", "--height", "192", "--width", "320", "--no-cpu-baseline", "--no-parity", "--no-frame-by-frame",
+             "--no-spread", "--settle-s", "0.2", "--key-group", "2"]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "1"] + small
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=ROOT, env=_rccl_env())
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]
+    d = json.loads(lines[0])
+    m = d["multi_gpu"]
+    assert d["n_gpus"] == 1 and m["rccl_ranks_seen"] == 1 and m["ranks_seen"] == 1 and "rccl" in m["backend"]
+    assert m["per_rank"] == [dict(m["per_rank"][0], rank=0, device=0)] and m["collectives_in_timed_region"] == 0
+    assert m["final_gather"]["rows"] > 0 and m["final_gather"]["rows"] == d["config"]["detections_last_interval"]
+
+
+def test_lsfa_test_rccl_gather_equals_plain_run(tmp_path):
+    """`python -m lsfa_amd.test` under torch.distributed.run with ONE rank and the real backend: the detection rows that went through
+    RCCL's all_gather (device tensors, lsfa_amd/core/parallel.py gather_rows) equal the rows of a plain run bit for bit."""
+    args = ["--clips", "2", "--frames", "7", "--interval", "3", "--height", "192", "--width", "320"]
+    plain, rccl = str(tmp_path / "plain.npy"), str(tmp_path / "rccl.npy")
+    r = subprocess.run([sys.executable, "-m", "lsfa_amd.test"] + args + ["--out", plain], capture_output=True, text=True, timeout=900,
+                       cwd=ROOT, env=_env())
+    assert r.returncode == 0, r.stderr[-3000:]
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+                        "--master-port", str(_free_port()), "-m", "lsfa_amd.test"] + args + ["--out", rccl], capture_output=True, text=True,
+                       timeout=900, cwd=ROOT, env=_rccl_env())
+    assert r.returncode == 0, r.stderr[-3000:]
+    a, b = np.load(plain), np.load(rccl)
+    assert len(a) > 0 and np.array_equal(a, b)

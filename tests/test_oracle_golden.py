@@ -169,6 +169,11 @@ def test_image_helpers_against_reference_g6(golden):
     out, sc = image.resize(torch.from_numpy(big), 60, 100, stride=16)
     assert sc == 2.0 and tuple(out.shape) == golden["g6_resize_out"].shape
     np.testing.assert_allclose(out.numpy(), golden["g6_resize_out"], rtol=1e-5, atol=1e-3)
+    # a float32 frame padded to the stride is a float64 image: `transform` then subtracts the mean in float64; the host path follows
+    padded, _ = image.resize(torch.from_numpy(big.astype(np.float32)), 60, 100, stride=16)
+    assert padded.dtype == torch.float64
+    np.testing.assert_array_equal(image.transform(padded, [103.94, 116.78, 123.68], 0.017).numpy(),
+                                  golden["g6_resize_f32_stride16_transform"].astype(np.float32))
     out, sc = image.resize(torch.from_numpy(big), 60, 90)
     assert sc == 1.8 and tuple(out.shape) == golden["g6_resize_out_capped"].shape
     np.testing.assert_allclose(out.numpy(), golden["g6_resize_out_capped"], rtol=1e-5, atol=1e-3)

@@ -1067,7 +1067,7 @@ def main():
             fl6 = conv_fl - fl3 - fl1
             mfma_work = 6 * fl6 + 3 * fl3 + fl1          # matrix-instruction FLOPs actually issued
             mix_peak = conv_fl / (mfma_work / MFMA_BF16_PEAK_TFLOPS)
-            roof = {"bound": "mfma", "kernel": "the split-operand convolution family behind lsfa_conv_fwd (ring / halo / direct kernels + their reduce passes): "
+            roof = {"bound": "mfma", "kernel": "the split-operand convolution family behind lsfa_conv_fwd (ring / direct kernels + their reduce passes): "
                     "every convolution of ResNet-101 + DCN, feat_conv_3x3, the small net, fuse_reduce_add, FlowNet, the Nq net; %d calls of %d interval(s)%s" %
                     (conv_n, getattr(r, 'profiled_intervals', 1), " computed the way the pipeline batches them (key fronts x%d, segments of %d frames)" % (r.key_group, r.segment) if batched else ""),
                     "achieved": round(tf, 1), "peak": round(mix_peak, 1), "unit": "TFLOP/s",

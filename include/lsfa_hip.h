@@ -348,7 +348,7 @@ int lsfa_amax_partial(const float* x, long long n, float* out256, void* stream);
 #define LSFA_EOVERFLOW (-4)
 int lsfa_status_check(unsigned* status_dev, void* stream);
 /* measurement hook (tools/lab/conv_ring_lab.py): force the kernel (1: the ring kernel, mixed-role waves; 2: the ring kernel with
- * loader / consumer waves; never the halo / direct forms then; 3: the 3x3 halo form wherever its geometry allows), the tile width nt (2 | 4), the
+ * loader / consumer waves; never the direct form then; 3 was the 3x3 halo form, removed in r6: refused), the tile width nt (2 | 4), the
  * ring depth st (2..4) and the number of K slices; 0 = the launch plan decides.  Process-wide; results stay bit-reproducible per setting. */
 int lsfa_conv_plan_override(int kernel, int nt, int st, int slices);
 /* r6, measurement / test hook: the two orders the ring kernel's launch can be laid out in, process-wide like the override above; -1 = back to
@@ -359,7 +359,7 @@ int lsfa_conv_plan_override(int kernel, int nt, int st, int slices);
 int lsfa_conv_order_override(int tile_order, int k_order);
 /* r5: 4 = the ring kernel on 256-pixel tiles (eight mixed-role waves; nt 4, pieces 1 | 2).
  * measurement hook (bench.py's per-instantiation roofline table): which kernel lsfa_conv_fwd would launch for `d` -
- * out[0] kernel (1 ring, 2 direct, 3 halo), out[1] nt, out[2] st, out[3] loader / consumer waves, out[4] waves that multiply (4 | 8),
+ * out[0] kernel (1 ring, 2 direct), out[1] nt, out[2] st, out[3] loader / consumer waves, out[4] waves that multiply (4 | 8),
  * out[5] K slices, out[6] the input's activation applied at the cut, out[7] pieces.  Launches nothing. */
 int lsfa_conv_plan_query(const lsfa_conv_desc* d, int* out8);
 /* Deconvolution(kernel 4, stride 2) + Crop(offset (1,1)) to Hc x Wc (+ bias + activation) as ONE launch of four 2x2-tap phase
@@ -393,6 +393,10 @@ int lsfa_deconv4x4s2_crop_fwd(const float* x, int lda, int N, int Hi, int Wi, in
  *                          lsfa_conv_fwd's amax_out does, for the next convolution's amax_in.
  * ------------------------------------------------------------------------ */
 int lsfa_avgpool_nchw(const float* x, int N, int C, int H, int W, int k, float* y, void* stream);
+/* r6: the same with the N images given by a DEVICE table of N base pointers (image n = C x H x W floats at x_table[n]): frames that arrive as
+ * separate tensors (dff_rfcn/core/loader.py:131-141 hands one array per frame) go through a batched pass without a staging copy into one
+ * (N, C, H, W) buffer.  The table's address is what a captured graph bakes in; lsfa_ptr_table_set rewrites its entries before a replay. */
+int lsfa_avgpool_nchw_tbl(const float* const* x_table, int N, int C, int H, int W, int k, float* y, void* stream);
 /* r5: transform (lib/utils/image.py:296-308), the last host-side step of a frame moved behind its upload: decoded frames
  * (N, H, W, 3) uint8 BGR on the device -> `data` (N, 3, H, W) float32, channel i = (im[..., 2 - i] - pixel_means[2 - i]) * pixel_scale.
  * computed in float64 like the reference's numpy statements and rounded to float32 once.
@@ -412,6 +416,9 @@ int lsfa_maxpool3x3s2_nhwc(const float* x, int N, int H, int W, int C, float* y,
 int lsfa_stem_conv7x7s2_ex(const float* x, int N, int H, int W, const float* in_scale, const float* in_shift,
                            const void* wfrag, const float* bias, const float* accum, int act, float* y, unsigned* amax_out,
                            void* stream);
+/* r6: lsfa_stem_conv7x7s2_ex with the N images given by a device table of base pointers (3 x H x W floats each): see lsfa_avgpool_nchw_tbl. */
+int lsfa_stem_conv7x7s2_tbl(const float* const* x_table, int N, int H, int W, const float* in_scale, const float* in_shift,
+                            const void* wfrag, const float* bias, const float* accum, int act, float* y, unsigned* amax_out, void* stream);
 
 /* ---------------------------------------------------------------------------
  * FlowNet-S pieces that are not MFMA-sized (lsfa_amd/csrc/flownet.hip); with lsfa_conv_split_view_fwd and the two-pass stem
@@ -511,6 +518,9 @@ int lsfa_stream_destroy(void* stream);
  * segment's - images, motion vectors and residuals into the static buffers a captured graph reads.  r5: src[k] == NULL zero-fills
  * dst[k] (amax slots, the padding channels of a Concat map): the frame path issues no PyTorch fill or copy kernel */
 int lsfa_copy_many(int njobs, void* const* dst, const void* const* src, const long* elems4, void* stream);
+/* r6: table_dev[i] = ptrs_host[i] for i < n, as one tiny launch per 64 entries on `stream` (the values travel as kernel arguments): how the
+ * per-image pointer tables of the *_tbl entry points are rewritten between replays of a captured graph. */
+int lsfa_ptr_table_set(void** table_dev, int n, const void* const* ptrs_host, void* stream);
 
 /* ------------------------------------------------------------------------ *
  * Live per-op timing with HIP events on the launch stream (bench.py's roofline leg).

@@ -43,6 +43,17 @@ def _alloc_post(batch, ncls, R, device):
     return full, public
 
 
+# r6: batched passes read their frames where the caller left them (hip.ImageTable: a device table of per-image pointers, rewritten by one tiny
+# launch per pass) instead of from a static batch buffer filled by a staging copy (2 x 65 MB per nine-frame segment, 2 x 86 MB per pass of six key
+# fronts: 2.4 % of frames/s, profiles/r6/tail_ablation.txt).  LSFA_STAGE_FRAMES=1 brings the copies back (A/B, and the fall-back for frames the
+# table cannot take: not float32, not contiguous, another device).
+ZERO_COPY_FRAMES = os.environ.get('LSFA_STAGE_FRAMES') != '1'
+
+
+def _table_ok(t, shape, device):
+    return t.is_cuda and t.device == device and t.dtype == torch.float32 and t.is_contiguous() and tuple(t.shape[-3:]) == tuple(shape)
+
+
 def _stage_inputs(jobs):
     """Frame inputs into the static buffers a captured graph reads: one launch (lsfa_copy_many) when the tensors allow
     it (same device, fp32, contiguous, equal shapes), else plain copies."""
@@ -67,7 +78,7 @@ def _post_all(out, full, cfg, h, w, scale, thresh):
 
 class FrameGraphs(object):
     def __init__(self, key_exec, cur_exec, cfg, height, width, device, thresh=1e-4, use_graphs=True, prefetch=True,
-                 feat_shared=None, taps=False, batch=1):
+                 feat_shared=None, taps=False, batch=1, frames_by_table=False):
         """feat_shared: a caller-owned (1, DFF_FEAT_DIM, h, w) buffer the non-key graph reads the key feature
         from; such an instance is a non-key "lane" of a FramePipeline and never runs key frames.
         taps=True (parity tests): the stage outputs of the last key / non-key frame stay readable in
@@ -89,6 +100,9 @@ class FrameGraphs(object):
         z = lambda *s: torch.zeros(s, device=dev, dtype=torch.float32)
         # static inputs
         self.data = z(B, 3, height, width)
+        # frames_by_table (a FramePipeline's segment lanes): cur_segment reads the frames where the caller left them - no staging copy
+        self._use_tbl = bool(frames_by_table) and not prefetch
+        self.data_tbl = hip.ImageTable(B, 3, height, width, dev).set([self.data[i] for i in range(B)]) if self._use_tbl else None
         self.data_key_old = z(B, 3, height, width)
         self.feat_old = z(B, dim, fh, fw)
         self.mv = z(B, 2, fh, fw)
@@ -148,8 +162,8 @@ class FrameGraphs(object):
                 out = self.cur.forward(data=self.data, im_info=self.im_info, feat_key=self.feat, motion_vector=self.mv,
                                        res_diff=self.res, small_feat=self.small_cur)
             else:
-                out = self.cur.forward(data=self.data, im_info=self.im_info, feat_key=self.feat, motion_vector=self.mv,
-                                       res_diff=self.res)
+                out = self.cur.forward(data=self.data_tbl if self._use_tbl else self.data, im_info=self.im_info, feat_key=self.feat,
+                                       motion_vector=self.mv, res_diff=self.res)
         finally:
             self.cur.taps = saved
         self.cur_out = out if self.want_taps else None
@@ -272,10 +286,15 @@ class FrameGraphs(object):
         if len(frames) * B != self.batch or self.prefetch:
             raise ValueError("cur_segment: this lane takes %d images per pass (and no prefetch)" % self.batch)
         jobs = []
+        tbl = self._use_tbl and all(_table_ok(data, self.data.shape[1:], self.device) for data, _, _ in frames)
         for f, (data, mv, res) in enumerate(frames):
             sl = slice(f * B, (f + 1) * B)
-            jobs += [(self.data[sl], data), (self.mv[sl], mv), (self.res[sl], res)]
+            jobs += ([] if tbl else [(self.data[sl], data)]) + [(self.mv[sl], mv), (self.res[sl], res)]
         _stage_inputs(jobs)
+        if tbl:
+            self.data_tbl.set([data[b] for data, _, _ in frames for b in range(B)])
+        elif self._use_tbl:      # frames the table cannot take went through the dense buffer: point the table at it
+            self.data_tbl.set([self.data[i] for i in range(self.batch)])
         if self.use_graphs:
             self.cur_graph.replay()
         else:
@@ -294,6 +313,12 @@ class KeyBank(object):
         z = lambda *s: torch.zeros(s, device=device, dtype=torch.float32)
         self.data = z(self.G * self.B, 3, height, width)          # group-major: key frame i of the group is images [i * B, (i + 1) * B)
         self.data_old = z(self.G * self.B, 3, height, width)
+        # r6: the pass reads its images through pointer tables (hip.ImageTable), i.e. where the caller left them; the dense buffers above are what
+        # the tables point at during capture, and the fall-back (LSFA_STAGE_FRAMES=1)
+        self.by_table = ZERO_COPY_FRAMES
+        n = self.G * self.B
+        self.data_tbl = hip.ImageTable(n, 3, height, width, device).set([self.data[i] for i in range(n)]) if self.by_table else None
+        self.data_old_tbl = hip.ImageTable(n, 3, height, width, device).set([self.data_old[i] for i in range(n)]) if self.by_table else None
         self.conv_feat = self.flow_out = None
         self.front_graph = self.flow_graph = None
         self.want_taps = taps
@@ -301,10 +326,24 @@ class KeyBank(object):
         self.ev_front, self.ev_flow, self.ev_free = E(), E(), E()      # backbone done / FlowNet done / every slice copied out
 
     def front(self):
-        self.conv_feat = self.key.key_backbone(self.data)
+        self.conv_feat = self.key.key_backbone(self.data_tbl if self.by_table else self.data)
 
     def flow(self):
-        self.flow_out = self.key.key_flow(self.data, self.data_old)
+        self.flow_out = self.key.key_flow(self.data_tbl, self.data_old_tbl) if self.by_table else self.key.key_flow(self.data, self.data_old)
+
+    def set_images(self, group, olds):
+        """The pass's images: key frame i of the group (B clips each) and its predecessor.  By table: two tiny launches; else the staging copies."""
+        nb = self.B
+        shape = self.data.shape[1:]
+        if self.by_table and all(_table_ok(t, shape, self.device) for t in list(group) + list(olds)):
+            self.data_tbl.set([t[b] for t in group for b in range(nb)])
+            self.data_old_tbl.set([t[b] for t in olds for b in range(nb)])
+            return
+        if self.by_table:      # frames the table cannot take: through the dense buffers the tables pointed at when the graphs were captured
+            self.data_tbl.set([self.data[i] for i in range(self.G * nb)])
+            self.data_old_tbl.set([self.data_old[i] for i in range(self.G * nb)])
+        _stage_inputs([(self.data[i * nb:(i + 1) * nb], group[i]) for i in range(self.G)] +
+                      [(self.data_old[i * nb:(i + 1) * nb], olds[i]) for i in range(self.G)])
 
     def capture(self, warmup=2):
         if not self.use_graphs:
@@ -480,7 +519,10 @@ class FramePipeline(object):
     streams sharing one run strictly in turn): key, FlowNet/tail and two lanes get one each; further
     lanes share the FlowNet stream's queue.
     The caller must keep each key frame's `data` tensor unmodified until the next key frame has
-    been queued (it is read again as that frame's `data_key_old`).
+    been queued (it is read again as that frame's `data_key_old`).  r6: batched passes (segment > 0, key_group > 1) read the frames
+    WHERE THE CALLER LEFT THEM (hip.ImageTable: no staging copy), so those tensors must stay unmodified until the pass has run - i.e.
+    until their results have been delivered; dropping the Python reference is fine (the pipeline holds one and calls record_stream),
+    overwriting the storage in place is not.  LSFA_STAGE_FRAMES=1 restores the staging copies.
     """
 
     def __init__(self, key_exec, cur_exec, cfg, height, width, device, thresh=1e-4, use_graphs=True, lanes=2,
@@ -515,7 +557,7 @@ class FramePipeline(object):
         # non-key frames (the end of a clip) takes the per-frame lanes.  key_group > 1: see KeyBank and key_frame(upcoming=...).
         self.feat_seg = [torch.zeros((B, dim, fh, fw), device=dev, dtype=torch.float32) for _ in range(max(2, lanes) if self.segment else 0)]
         self.seg_lanes = [FrameGraphs(key_exec, cur_exec, cfg, height, width, dev, thresh, use_graphs, prefetch=False,
-                                      feat_shared=f, taps=taps, batch=self.segment * B) for f in self.feat_seg]
+                                      feat_shared=f, taps=taps, batch=self.segment * B, frames_by_table=ZERO_COPY_FRAMES) for f in self.feat_seg]
         # one bank per group size 2 .. key_group: the tail of a run of key frames (fewer images ahead than key_group - 1) is a smaller group
         # (two of the full size, alternating: the next group's pass may start while this group's key frames still take their slices)
         self.banks = {g: [KeyBank(key_exec, cfg, height, width, dev, use_graphs, g, taps, B) for _ in range(2 if g == self.key_group else 1)]
@@ -754,9 +796,7 @@ class FramePipeline(object):
                     olds = [self._prev_key_data] + group[:-1]
                     for t in group + olds[:1]:
                         t.record_stream(s)
-                    nb = bank.B
-                    _stage_inputs([(bank.data[i * nb:(i + 1) * nb], group[i]) for i in range(bank.G)] +
-                                  [(bank.data_old[i * nb:(i + 1) * nb], olds[i]) for i in range(bank.G)])
+                    bank.set_images(group, olds)
                 if self.s_flow is not None:
                     self.ev_in.record(s)
                     with torch.cuda.stream(self.s_flow):

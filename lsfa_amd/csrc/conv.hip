@@ -279,13 +279,8 @@ struct SplitPlan {
   bool sp;              // ring kernel: split roles (512-thread workgroups: four loader waves + four consumer waves)
   int wv;               // ring kernel: waves that multiply (4: 128-pixel tiles; 8: 256-pixel tiles, eight mixed-role waves)
   bool direct;          // conv_split_direct_kernel: operands straight into registers, a wave per 32 x 64 tile, no K slices
-  bool halo;            // the 3x3 halo kernel (stride 1, pad = dilation 1 or 2), else the ring kernel
-  int dil;
-  int patches_x, patches_y;
   int nx, ny, slices;   // tiles: nx pixel tiles x ny channel tiles x slices
-  int per_slice;        // chunks (ring: of taps*Cin/32; halo: of Cin/32) per slice
-  int units_per_wg;     // halo, balanced mode: (tile, channel chunk) units per workgroup, else 0
-  int max_pieces;       // ... and the most workgroups that can share one tile
+  int per_slice;        // chunks (of taps * Cin / 32) per slice
 };
 
 // lab override (lsfa_conv_plan_override): 0 = the plan decides
@@ -386,55 +381,25 @@ void ring_plan(SplitPlan& p, long P, int chunk_total, int Cout, int pieces) {
   p.ny = Cout / (32 * nt);
 }
 
+// (r2-r5 also had a 3x3 halo form - a workgroup staging a 4 x 32 output patch's input halo once per channel chunk; with loader / consumer
+// waves the ring kernel passed it on its last shapes in r4 (res2 conv2 24.0 vs 27.1 us) and it was removed in r6; profiles/r4/conv_ring_lab.txt
+// has its last numbers)
 SplitPlan split_plan(int N, int H, int W, int Cin, int Cout, int kh, int kw, int stride, int pad, int dil, int pieces) {
   SplitPlan p = {};
   p.nt = 2; p.st = 2;
   const int Ho = (H + 2 * pad - dil * (kh - 1) - 1) / stride + 1, Wo = (W + 2 * pad - dil * (kw - 1) - 1) / stride + 1;
-  p.ny = Cout / convsplit::kWgCh;
-  p.dil = dil;
-  p.halo = kh == 3 && kw == 3 && stride == 1 && pad == dil && (dil == 1 || dil == 2) && (g_force_kernel.load() == 0 || g_force_kernel.load() == 3);
-  // two 4-wave workgroups per CU is the halo kernel's design point: 512 workgroups fill the chip
-  if (p.halo) {
-    p.patches_x = (W + convsplit::kPatchCols - 1) / convsplit::kPatchCols;
-    p.patches_y = (H + convsplit::kPatchRows - 1) / convsplit::kPatchRows;
-    p.nx = N * p.patches_x * p.patches_y;
-    const int cpt = Cin / 32;
-    int s = 512 / (p.nx * p.ny > 0 ? p.nx * p.ny : 1);
-    if (s < 1) s = 1;
-    if (s > cpt) s = cpt;
-    p.per_slice = (cpt + s - 1) / s;
-    p.slices = (cpt + p.per_slice - 1) / p.per_slice;
-    // measured (r2, tools/lab/conv_split_lab.py): the halo form wins where its patches alone fill the chip (res2 conv2, the 256 -> 1024
-    // fuse convolution); where K must be cut anyway the ring kernel's finer cut (it slices taps x chunks) keeps more CUs busy
-    if (p.slices > 1) p.halo = false;
-    // r4: with the ring kernel's loader / consumer waves the halo form only keeps the wide-map, narrow-output case (res2 conv2:
-    // 37,500 pixels, 64 -> 64: 30.3 vs 31.1 us); fuse_reduce_add is 58 us on the ring against 77 here (tools/lab/conv_ring_lab.py)
-    if ((long)p.nx * p.ny < 256 || Cout > 128) p.halo = false;
-    // r4, end of round: the ring kernel with loader / consumer waves is ahead on these too (res2 conv2 24.0 vs 27.1 us, at three images 45.1 vs
-    // 55.0; res3 conv2 38.6 vs 41): the halo form is no plan's choice any more, only lsfa_conv_plan_override(kernel = 3) reaches it
-    p.halo = false;
-    if (g_force_kernel.load() == 3) p.halo = true;
-    // balanced mode: fewer than 512 tiles but more than 512 (tile, chunk) units -> equal unit counts per workgroup
-    // (fuse_reduce_add: 320 tiles x 8 chunks = 512 workgroups x 5 instead of one round of 320 x 8)
-    const long tiles = (long)p.nx * p.ny, units = tiles * cpt;
-    if (p.halo && tiles < 512 && units > 512) {
-      const int per = (int)((units + 511) / 512);
-      if (per * 4 <= cpt * 3) { p.units_per_wg = per; p.max_pieces = (cpt + per - 1) / per + 1; }     // worth it from 25 % shorter
-    }
-  }
-  if (!p.halo) ring_plan(p, (long)N * Ho * Wo, kh * kw * (Cin / 32), Cout, pieces);
+  ring_plan(p, (long)N * Ho * Wo, kh * kw * (Cin / 32), Cout, pieces);
   return p;
 }
 
 // the ring kernel's plan for an output grid of Ho x Wo pixels (what a view launch falls back to)
 SplitPlan split_plan_general(int N, int Ho, int Wo, int Cin, int Cout, int kh, int kw, int pieces) {
   SplitPlan p = {};
-  p.dil = 1;
   ring_plan(p, (long)N * Ho * Wo, kh * kw * (Cin / 32), Cout, pieces);
   return p;
 }
 
-// the plan of a launch whose operands may be views: the halo form needs the plain geometry
+// the plan of a launch whose operands may be views
 SplitPlan view_plan(int N, int H, int W, int Cin, int Cout, int kh, int kw, int stride, int pad_h, int pad_w, int dil, int lda, int Ho_grid,
                     int Wo_grid, int pieces) {
   const int Ho = (H + 2 * pad_h - dil * (kh - 1) - 1) / stride + 1, Wo = (W + 2 * pad_w - dil * (kw - 1) - 1) / stride + 1;
@@ -444,8 +409,6 @@ SplitPlan view_plan(int N, int H, int W, int Cin, int Cout, int kh, int kw, int 
 }
 
 size_t split_workspace(const SplitPlan& p, long P, int Cout) {
-  if (p.units_per_wg > 0)      // one 32 KB accumulator slot per (tile, piece)
-    return (size_t)p.nx * p.ny * p.max_pieces * convsplit::kThreads * 32 * sizeof(float);
   return p.slices > 1 ? align_up((size_t)p.slices * P * Cout * sizeof(float), 256) : 256;
 }
 
@@ -490,16 +453,10 @@ bool launch_ring_pc(int nt, int st, bool sp, const convsplit::Args& a, dim3 grid
   return true;
 }
 template <int PC>
-void launch_halo_direct(const SplitPlan& p, const convsplit::Args& a, dim3 grid, hipStream_t s, long P) {
-  if (p.direct) {
-    const int nw = direct_waves(a);
-    hipLaunchKernelGGL(convsplit::conv_split_direct_kernel<PC>, dim3((unsigned)((P + 31) / 32), a.Cout / 64), dim3(64 * nw),
-                       (size_t)(nw > 1 ? nw - 1 : 1) * 32 * 64 * sizeof(float), s, a);      // the waves' sums; at least the 8 KB the row epilogue uses
-  } else if (p.dil == 1) {
-    hipLaunchKernelGGL((convsplit::conv_split3x3_kernel<1, PC>), grid, dim3(convsplit::kThreads), 0, s, a, p.patches_x, p.patches_y, p.nx, p.ny, p.slices);
-  } else {
-    hipLaunchKernelGGL((convsplit::conv_split3x3_kernel<2, PC>), grid, dim3(convsplit::kThreads), 0, s, a, p.patches_x, p.patches_y, p.nx, p.ny, p.slices);
-  }
+void launch_direct(const convsplit::Args& a, hipStream_t s, long P) {
+  const int nw = direct_waves(a);
+  hipLaunchKernelGGL(convsplit::conv_split_direct_kernel<PC>, dim3((unsigned)((P + 31) / 32), a.Cout / 64), dim3(64 * nw),
+                     (size_t)(nw > 1 ? nw - 1 : 1) * 32 * 64 * sizeof(float), s, a);      // the waves' sums; at least the 8 KB the row epilogue uses
 }
 
 // LSFA_CONV_TILE_ORDER (lab): how workgroup ids map to (slice, channel tile, pixel tile), see xcd_tile
@@ -580,10 +537,9 @@ int conv_split_prepare(convsplit::Args& a, int pieces, SplitPlan& p, long& P_out
     p.slices = 1;
   }
   // ... except with the input's activation table in LDS (16 KB more per workgroup: three stages would leave one workgroup per CU)
-  if (a.in_scale && !p.direct && !p.halo && !p.sp && p.wv == 4 && pieces == 1 && p.nt == 4 && p.st == 3 && g_force_st.load() == 0) p.st = 2;
+  if (a.in_scale && !p.direct && !p.sp && p.wv == 4 && pieces == 1 && p.nt == 4 && p.st == 3 && g_force_st.load() == 0) p.st = 2;
   a.part_stride = P * Cout;
   a.chunks_per_slice = p.per_slice;
-  a.units_per_wg = a.max_pieces = 0;
   a.inv_wo = 1.0f / (float)a.Wo;
   a.inv_howo = 1.0f / (float)(a.Ho * a.Wo);
   a.inv_nx = 1.0f / (float)(p.nx > 0 ? p.nx : 1);
@@ -603,26 +559,20 @@ int conv_split_launch(convsplit::Args a, int pieces, void* ws, size_t ws_bytes, 
   (void)Cin;
   const int nph = a.nphase > 1 ? a.nphase : 1;
   const size_t need = split_workspace(p, P, Cout) * (size_t)nph;
-  if ((p.slices > 1 || p.units_per_wg > 0) && (!ws || ws_bytes < need)) {
+  if (p.slices > 1 && (!ws || ws_bytes < need)) {
     set_error("%s: workspace %zu < %zu bytes", who, ws_bytes, need);
     return LSFA_EWORKSPACE;
   }
-  LSFA_REQUIRE(nph == 1 || (!p.halo && p.units_per_wg == 0 && !p.direct), "%s: phases need the ring kernel", who);
+  LSFA_REQUIRE(nph == 1 || !p.direct, "%s: phases need the ring kernel", who);
   hipStream_t s = (hipStream_t)stream;
   a.part = p.slices > 1 ? (float*)ws : nullptr;
   ProfScope prof(prof_op, s);
-  int tiles = p.nx * p.ny * p.slices * nph;
-  if (p.units_per_wg > 0) {
-    a.part = (float*)ws;
-    a.units_per_wg = p.units_per_wg;
-    a.max_pieces = p.max_pieces;
-    tiles = (p.nx * p.ny * (Cin / 32) + p.units_per_wg - 1) / p.units_per_wg;      // workgroups
-  }
+  const int tiles = p.nx * p.ny * p.slices * nph;
   const dim3 grid((unsigned)(8 * ((tiles + 7) / 8)));
-  if (p.direct || p.halo) {
-    if (pieces == 3) launch_halo_direct<3>(p, a, grid, s, P);
-    else if (pieces == 2) launch_halo_direct<2>(p, a, grid, s, P);
-    else launch_halo_direct<1>(p, a, grid, s, P);
+  if (p.direct) {
+    if (pieces == 3) launch_direct<3>(a, s, P);
+    else if (pieces == 2) launch_direct<2>(a, s, P);
+    else launch_direct<1>(a, s, P);
   } else {
     if (p.wv == 8) {
       if (pieces == 2 && p.st == 3) launch_ring8<2, 3>(a, grid, s, p.nx, p.ny, p.slices * nph);
@@ -635,10 +585,6 @@ int conv_split_launch(convsplit::Args a, int pieces, void* ws, size_t ws_bytes, 
                                 : launch_ring_pc<1>(p.nt, p.st, p.sp, a, grid, s, p.nx, p.ny, p.slices * nph);
     LSFA_REQUIRE(ok, "%s: no ring kernel for nt=%d st=%d pieces=%d", who, p.nt, p.st, pieces);
     }
-  }
-  if (p.units_per_wg > 0) {
-    hipLaunchKernelGGL(convsplit::conv_split3x3_fixup_kernel, dim3((unsigned)(p.nx * p.ny)), dim3(convsplit::kThreads), 0, s, a, p.patches_x,
-                       p.patches_y, p.nx);
   }
   if (p.slices > 1 && a.y_nchw && !a.res && !a.scale2 && nph == 1 && Cout % 64 == 0) {
     hipLaunchKernelGGL(convsplit::split_reduce_nchw_kernel, dim3((unsigned)((P + 63) / 64), (unsigned)(Cout / 64)), dim3(convsplit::kThreads), 0,
@@ -669,8 +615,8 @@ convsplit::Args args_of(const lsfa_conv_desc& d) {
 }  // namespace
 
 extern "C" int lsfa_conv_plan_override(int kernel, int nt, int st, int slices) {
-  LSFA_REQUIRE(kernel >= 0 && kernel <= 4 && (nt == 0 || nt == 2 || nt == 4) && (st == 0 || (st >= 2 && st <= 4)) && slices >= 0 && slices <= 16,
-               "lsfa_conv_plan_override: kernel 0..4, nt 0/2/4, st 0/2..4, slices 0..16");
+  LSFA_REQUIRE(kernel >= 0 && kernel <= 4 && kernel != 3 && (nt == 0 || nt == 2 || nt == 4) && (st == 0 || (st >= 2 && st <= 4)) && slices >= 0 && slices <= 16,
+               "lsfa_conv_plan_override: kernel 0, 1, 2 or 4 (3 was the halo form, removed in r6), nt 0/2/4, st 0/2..4, slices 0..16");
   g_force_kernel.store(kernel); g_force_nt.store(nt); g_force_st.store(st); g_force_slices.store(slices);
   return LSFA_OK;
 }
@@ -742,7 +688,7 @@ extern "C" int lsfa_conv_plan_query(const lsfa_conv_desc* d, int* out8) {
   long P = 0;
   const int rc = conv_split_prepare(a, d->pieces, p, P, "lsfa_conv_plan_query");
   if (rc != LSFA_OK) return rc;
-  out8[0] = p.direct ? 2 : (p.halo ? 3 : 1);
+  out8[0] = p.direct ? 2 : 1;
   out8[1] = p.direct ? 2 : p.nt; out8[2] = p.st; out8[3] = p.sp ? 1 : 0; out8[4] = p.wv ? p.wv : 4; out8[5] = p.slices;
   out8[6] = a.in_scale ? 1 : 0; out8[7] = d->pieces;
   return LSFA_OK;

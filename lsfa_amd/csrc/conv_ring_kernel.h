@@ -42,13 +42,19 @@ constexpr int kFlush = 12;        // a multiple of every ring depth: the flush p
 #define LSFA_RING_B_AUX 0
 #endif
 
+#ifdef LSFA_LAB_HALF_A      // lab ablation (tools/lab/build_variant.sh): half of A's copies issued - wrong numbers, the step's timing with 8 KB of A per chunk
+constexpr int kRingIssueA = 2;
+#else
+constexpr int kRingIssueA = 4;
+#endif
+
 template <int NT, int PC, int ST, int WV = 4> struct Ring {     // WV: waves that multiply (4: 128-pixel tiles; 8: 256-pixel tiles, mixed roles only)
   static constexpr int kColTile = 128 * PC;                 // uint4 of one 32-column tile of one chunk: 2 steps x PC pieces x 64 lanes
   static constexpr int kStageA = WV * 256;                  // uint4 of A per stage: WV waves x 32 pixels x 8 slots (4 KB per wave)
   static constexpr int kStageBn = NT * kColTile;
   static constexpr int kStageN = kStageA + kStageBn;        // uint4 per stage: 4 WV KB of A + NT x PC x 2 KB of B
   static constexpr int kDmaB = (NT * kColTile) / (WV * 64); // B DMA instructions per wave and chunk: NT * PC / 2 (WV = 8: / 4)
-  static constexpr int kDma = 4 + kDmaB;                    // all DMA instructions per wave and chunk
+  static constexpr int kDma = kRingIssueA + kDmaB;          // all DMA instructions per wave and chunk (4 of A + B's)
   static constexpr int kLdsBytes = ST * kStageN * 16;
   static constexpr int kWgPerCu = (2 * kLdsBytes <= 160 * 1024) ? 2 : 1;
   static_assert((NT * kColTile) % (WV * 64) == 0, "NT * PC must be a multiple of WV / 2");
@@ -79,7 +85,7 @@ __device__ __forceinline__ void ring_issue_a(uint4 (*R)[(Ring<NT, PC, ST, WV>::k
   const int dy_b = live ? dy : (1 << 26);                // not live: every row is out of bounds (a scalar select, no branch)
   uint4* a_dst = &R[S][g.wave * 256];
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
+  for (int i = 0; i < kRingIssueA; ++i) {
     const bool ok = (unsigned)(g.iy0[i] + dy_b) < (unsigned)g.H && (unsigned)(g.ix0[i] + dx) < (unsigned)g.W;
     const float* src = ok ? x + (g.off0[i] + doff) : g_zero_block;
     __builtin_amdgcn_global_load_lds(reinterpret_cast<const uint4*>(src), a_dst + i * 64, 16, 0, LSFA_RING_A_AUX);

@@ -18,7 +18,6 @@
 //   epilogues               tile_store_max (fragment-shaped stores: NCHW, views), tile_rows_out (channels-last rows through LDS as
 //                           float4), with bias / residual / activation / second output (the next unit's bn1 + relu1)
 //   split_reduce_*          the pass that adds a K-sliced launch's partial sums in slice order and applies the epilogue
-//   conv_split3x3_kernel    the 3x3 halo form (wide maps with few output channels: the input patch + halo staged once per tile)
 //   conv_split_direct_*     small weights on a small map: a wave per 32 x 64 tile, operands straight into registers
 // Weights (B) are cut and laid out ONCE at bind time in fragment order (lsfa_conv_weights / pack_weights_kernel):
 // [tap][chunk][32-col tile][k-step][piece][lane][8 x 16 bit], so a fragment is 1 KB contiguous.  One chunk = 32 input channels of one tap.
@@ -40,9 +39,6 @@ struct Args {
   int act;         // 0 none, 1 ReLU, 2 LeakyReLU(0.1) (FlowNet, resnet_v1_101_flownet_rfcn.py:153-176)
   const float* res; float* y2; const float* scale2; const float* shift2;
   int y_nchw;      // y / y2 / res are (N, Cout, Ho, Wo) instead of (N, Ho, Wo, Cout); partial slices stay NHWC
-  // halo kernel, balanced mode (units_per_wg > 0): every workgroup takes the same number of (tile, channel chunk) units,
-  // crossing tile boundaries; a tile shared by several workgroups is put together by conv_split3x3_fixup_kernel
-  int units_per_wg; int max_pieces;
   // r3: operand views, so that producers write into (and consumers read from) channel slices of wider maps without copies
   //   lda   floats between consecutive input pixels (>= Cin; the general kernels only)
   //   ldy   floats between consecutive output pixels (>= Cout): y = channels [c0, c0 + Cout) of an (.., ldy) map, the
@@ -208,18 +204,6 @@ __device__ __forceinline__ f32x16 mma3h(const PiecesH& a, const uint4& bhi, cons
   return acc;
 }
 
-// floor(log2(max of the kAmaxSlots partial maxima)) of a finite positive maximum, 0 for an all-zero (or non-finite) map; wave-uniform
-__device__ __forceinline__ int amax_exponent(const float* __restrict__ amax, int lane) {
-  float m = 0.f;
-#pragma unroll
-  for (int i = 0; i < kAmaxSlots / 64; ++i) m = fmaxf(m, amax[i * 64 + lane]);
-#pragma unroll
-  for (int d = 32; d >= 1; d >>= 1) m = fmaxf(m, __shfl_xor(m, d, 64));
-  const uint32_t bits = __float_as_uint(m);
-  const int e = (int)((bits >> 23) & 255u);
-  return (e == 0 || e == 255) ? 0 : __builtin_amdgcn_readfirstlane(e - 127);
-}
-
 // ---- epilogue shared by the kernels below -----------------------------------------------------------------------
 // Where output pixel p (= (n * Ho + oy) * Wo + ox of THIS launch) starts in y / y2 / res, and the distance between channels.
 struct RowOut { int base[16]; unsigned valid; };
@@ -235,34 +219,6 @@ __device__ __forceinline__ int out_pixel_base(const Args& a, int p) {
 
 __device__ __forceinline__ float activate(float v, int act) {
   return act == 1 ? fmaxf(v, 0.f) : (act == 2 ? (v > 0.f ? v : v * 0.1f) : v);
-}
-
-// one 32 x 32 accumulator (C/D layout: column = lane & 31 = channel, register r = pixel row of `ro`) -> its outputs:
-// bias, residual (all loads first, so that no store waits on a load), activation, second output
-__device__ __forceinline__ void tile_store(const Args& a, const RowOut& ro, int ch, const f32x16& acc) {
-  const int cs = a.y_nchw ? a.Ho * a.Wo : 1;
-  const float bias = a.bias ? a.bias[ch] : 0.f;
-  float v[16];
-#pragma unroll
-  for (int r = 0; r < 16; ++r) v[r] = acc[r] + bias;
-  if (a.res) {
-    float rv[16];
-#pragma unroll
-    for (int r = 0; r < 16; ++r) rv[r] = ((ro.valid >> r) & 1u) ? a.res[ro.base[r] + ch * cs] : 0.f;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) v[r] = v[r] + rv[r];
-  }
-#pragma unroll
-  for (int r = 0; r < 16; ++r) v[r] = activate(v[r], a.act);
-#pragma unroll
-  for (int r = 0; r < 16; ++r)
-    if ((ro.valid >> r) & 1u) a.y[ro.base[r] + ch * cs] = v[r];
-  if (a.y2) {
-    const float sc2 = a.scale2[ch], sh2 = a.shift2[ch];
-#pragma unroll
-    for (int r = 0; r < 16; ++r)
-      if ((ro.valid >> r) & 1u) a.y2[ro.base[r] + ch * cs] = fmaxf(v[r] * sc2 + sh2, 0.f);
-  }
 }
 
 // a K slice's partial sums: dense (P, Cout) rows, whatever the output view
@@ -695,8 +651,6 @@ static __global__ __launch_bounds__(kThreads) void split_reduce_nchw_kernel(Args
   }
 }
 
-constexpr int kStageA = 4 * 4 * 64;                     // uint4 per stage: 4 waves x 32 pixels x 8 slots = 16 KB
-
 __device__ __attribute__((aligned(64))) const float g_zero_block[32] = {};
 
 struct Geom {       // per lane / per wave constants of the loop
@@ -765,276 +719,6 @@ __device__ __forceinline__ Tile xcd_tile(int id, int nx, int ny, int nz, int ord
   r.z = fast ? fdiv(q, ny, inv_ny) : q / ny;
   r.y = q - r.z * ny;
   return r;
-}
-
-// ---------------------------------------------------------------------------------------------------------------
-// 3x3, stride 1, pad = dilation: the halo form.  The ring kernel is bound by what it pulls through the L2 (each of the
-// nine taps re-fetches the activations: 28 KB per workgroup and 24 MFMAs/wave).  Here a workgroup owns a 4-row x
-// 32-column patch of the output (wave w = row w) and, per 32-channel chunk, stages the patch's (4+2d) x (32+2d) input
-// halo ONCE (26 KB at d = 1): the nine taps read their A fragments from it at shifted positions.  Per tap only the 12 KB
-// of weights move: 12 + 26/9 = 15 KB per 24 MFMAs/wave, half of the above, and the DMA count per wave and step drops
-// from 7 to 3-4.  Stages: A halo double-buffered per channel chunk, B double-buffered per tap, all in one array with
-// compile-time offsets (the tap loop is unrolled inside a function templated on the A parity; nine taps per chunk is
-// odd, so the B parity of (chunk, tap) is (chunk + tap) & 1).
-constexpr int kPatchRows = 4, kPatchCols = 32;
-
-template <int DIL, int PC = 3> struct Halo {
-  static constexpr int kStageBp = 2 * 2 * PC * 64;                     // uint4 of B per tap step: two 32-column tiles x 2 steps x PC pieces
-  static constexpr int kW = kPatchCols + 2 * DIL, kH = kPatchRows + 2 * DIL;
-  static constexpr int kPix = kW * kH;
-  static constexpr int kPieces = kPix * 8;                            // 16-byte pieces of one stage
-  static constexpr int kDma = (kPieces + kThreads - 1) / kThreads;   // DMA instructions per thread and chunk
-  static constexpr int kStageUint4 = kPieces + kStageBp;             // A halo + B, per parity
-  static constexpr int kRow = kStageUint4;
-};
-
-template <int DIL>
-struct HaloGeom {
-  size_t wstride;
-  int chunks_per_tap;
-  int off0[Halo<DIL>::kDma];      // float offset of this thread's piece of DMA i at channel chunk 0 (meaningless when !ok)
-  unsigned ok_mask;               // bit i: DMA i's source pixel is inside the image
-  unsigned live_mask;             // bit i: DMA i's piece exists (the last instruction is partial)
-  int hp0;                        // halo pixel of this lane's fragment row at tap (0, 0): w * kW + (lane & 31)
-  int h4;                         // 4 * (lane >> 5)
-  int wave, lane, tid;
-};
-
-// B of step (kc, tap) -> parity PB; one third of the A halo of chunk kc_next (DMA instructions i0 .. i1-1) -> parity PA
-template <int DIL, int PC, int PA, int PB, int I0, int I1>
-__device__ __forceinline__ void halo_issue(uint4 (*S)[(Halo<DIL, PC>::kRow)], const float* __restrict__ x, const uint4* __restrict__ wblock,
-                                           const HaloGeom<DIL>& g, int gch, bool with_b, int kc_next, bool with_a) {
-  if (with_b) {
-    const uint4* wsrc = wblock + (size_t)gch * g.wstride + g.wave * (64 * PC) + g.lane;
-    uint4* b_dst = &S[PB][Halo<DIL, PC>::kPieces + g.wave * (64 * PC)];
-#pragma unroll
-    for (int i = 0; i < PC; ++i) __builtin_amdgcn_global_load_lds(wsrc + i * 64, b_dst + i * 64, 16, 0, 0);
-  }
-  if (with_a) {
-#pragma unroll
-    for (int i = I0; i < I1; ++i) {
-      if (i < Halo<DIL, PC>::kDma && ((g.live_mask >> i) & 1u)) {
-        const float* src = ((g.ok_mask >> i) & 1u) ? x + (g.off0[i] + kc_next * kChunk) : g_zero_block;
-        __builtin_amdgcn_global_load_lds(reinterpret_cast<const uint4*>(src), &S[PA][i * kThreads + g.wave * 64], 16, 0, 0);
-      }
-    }
-  }
-}
-
-template <int DIL, int PC, int PA, int PB, int TAP>
-__device__ __forceinline__ void halo_consume(uint4 (*S)[(Halo<DIL, PC>::kRow)], const HaloGeom<DIL>& g, f32x16& acc0, f32x16& acc1, float a_scale) {
-  constexpr int ty = TAP / 3, tx = TAP % 3;
-  const int hp = g.hp0 + (ty * DIL) * Halo<DIL>::kW + tx * DIL;
-  const int xs = g.h4 ^ ((hp >> 1) & 7);                  // slot of piece 4h + j is (4h + j) ^ sw = xs ^ j
-  const uint4* A = &S[PA][hp * 8];
-  const uint4* B = &S[PB][Halo<DIL, PC>::kPieces + g.lane];
-  const uint4 r0 = A[xs], r1 = A[xs ^ 1], r2 = A[xs ^ 2], r3 = A[xs ^ 3];
-  const PiecesN s0 = cut8<PC>(as_f4(r0), as_f4(r1), a_scale), s1 = cut8<PC>(as_f4(r2), as_f4(r3), a_scale);
-  // fragment (col tile t, step s, piece p) at ((t*2 + s)*PC + p)*64 + lane
-  acc0 = mma_pc<PC>(s0, B + (0 * PC) * 64, acc0);
-  acc1 = mma_pc<PC>(s0, B + (2 * PC) * 64, acc1);
-  acc0 = mma_pc<PC>(s1, B + (1 * PC) * 64, acc0);
-  acc1 = mma_pc<PC>(s1, B + (3 * PC) * 64, acc1);
-}
-
-// one step = one tap of channel chunk kc (A parity PA): start the copies the NEXT step needs (its B; during taps 0-2 a
-// third each of the next chunk's halo), compute this tap, retire the copies, meet the other waves
-template <int DIL, int PC, int PA, int TAP>
-__device__ __forceinline__ void halo_step(uint4 (*S)[(Halo<DIL, PC>::kRow)], const float* __restrict__ x, const uint4* __restrict__ wblock,
-                                          const HaloGeom<DIL>& g, int kc, int kc_end, f32x16& acc0, f32x16& acc1, float a_scale) {
-  constexpr int PB = (PA + TAP) & 1;
-  constexpr int K3 = (Halo<DIL, PC>::kDma + 2) / 3;
-  const bool last_tap = TAP == 8;
-  const bool more = !last_tap || kc + 1 < kc_end;                              // is there a next step at all
-  const int next_g = last_tap ? (kc + 1) : ((TAP + 1) * g.chunks_per_tap + kc);  // its (tap, chunk) index in the weight array
-  constexpr int I0 = TAP < 3 ? TAP * K3 : 0, I1 = TAP < 3 ? (TAP + 1) * K3 : 0;
-  constexpr int PA_NEXT = PA ^ 1, PB_NEXT = PB ^ 1;
-  halo_issue<DIL, PC, PA_NEXT, PB_NEXT, I0, I1>(S, x, wblock, g, next_g, more, kc + 1, TAP < 3 && kc + 1 < kc_end);
-  halo_consume<DIL, PC, PA, PB, TAP>(S, g, acc0, acc1, a_scale);
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-  __builtin_amdgcn_s_barrier();
-}
-
-template <int DIL, int PC, int PA>
-__device__ __forceinline__ void halo_chunk(uint4 (*S)[(Halo<DIL, PC>::kRow)], const float* __restrict__ x, const uint4* __restrict__ wblock,
-                                           const HaloGeom<DIL>& g, int kc, int kc_end, f32x16& acc0, f32x16& acc1, float a_scale) {
-  halo_step<DIL, PC, PA, 0>(S, x, wblock, g, kc, kc_end, acc0, acc1, a_scale);
-  halo_step<DIL, PC, PA, 1>(S, x, wblock, g, kc, kc_end, acc0, acc1, a_scale);
-  halo_step<DIL, PC, PA, 2>(S, x, wblock, g, kc, kc_end, acc0, acc1, a_scale);
-  halo_step<DIL, PC, PA, 3>(S, x, wblock, g, kc, kc_end, acc0, acc1, a_scale);
-  halo_step<DIL, PC, PA, 4>(S, x, wblock, g, kc, kc_end, acc0, acc1, a_scale);
-  halo_step<DIL, PC, PA, 5>(S, x, wblock, g, kc, kc_end, acc0, acc1, a_scale);
-  halo_step<DIL, PC, PA, 6>(S, x, wblock, g, kc, kc_end, acc0, acc1, a_scale);
-  halo_step<DIL, PC, PA, 7>(S, x, wblock, g, kc, kc_end, acc0, acc1, a_scale);
-  halo_step<DIL, PC, PA, 8>(S, x, wblock, g, kc, kc_end, acc0, acc1, a_scale);
-}
-
-// the tile's outputs from the accumulators (C/D layout: column = lane & 31 = channel, row = (reg & 3) + 8 * (reg >> 2) +
-// 4 * (lane >> 5) = column of the wave's patch row): a K slice's partial sums, or bias / residual / ReLU / second output
-__device__ __forceinline__ uint32_t halo_epilogue(const Args& a, float* part, int pimg, int y0, int x0, int ch_tile, int wave, int lane,
-                                                  const f32x16& acc0, const f32x16& acc1) {
-  const int oy = y0 + wave;
-  int prow[16];
-  RowOut ro;
-  ro.valid = 0;
-#pragma unroll
-  for (int r = 0; r < 16; ++r) {
-    const int ox = x0 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-    prow[r] = (pimg * a.H + oy) * a.W + ox;
-    if (oy < a.H && ox < a.W) ro.valid |= 1u << r;
-  }
-  if (part) {
-    tile_store_part(part, a.Cout, prow, ro.valid, ch_tile * kWgCh + (lane & 31), acc0);
-    tile_store_part(part, a.Cout, prow, ro.valid, ch_tile * kWgCh + 32 + (lane & 31), acc1);
-    return 0;
-  }
-#pragma unroll
-  for (int r = 0; r < 16; ++r) ro.base[r] = ((ro.valid >> r) & 1u) ? out_pixel_base(a, prow[r]) : 0;
-  return max(tile_store_max(a, ro, ch_tile * kWgCh + (lane & 31), acc0), tile_store_max(a, ro, ch_tile * kWgCh + 32 + (lane & 31), acc1));
-}
-
-// balanced mode, second launch: grid (tiles); block 256.  A tile that several workgroups shared: add their pieces in piece
-// order (fixed, so the result is reproducible) and run the epilogue; tiles one workgroup finished alone are already written.
-static __global__ __launch_bounds__(kThreads) void conv_split3x3_fixup_kernel(Args a, int patches_x, int patches_y, int nx) {
-  const int txy = blockIdx.x, cpt = a.Cin / kChunk;
-  const int first_wg = (txy * cpt) / a.units_per_wg, last_wg = (txy * cpt + cpt - 1) / a.units_per_wg;
-  if (first_wg == last_wg) return;
-  const int tid = threadIdx.x;
-  f32x16 acc0, acc1;
-#pragma unroll
-  for (int r = 0; r < 16; ++r) { acc0[r] = 0.f; acc1[r] = 0.f; }
-  const float* base = a.part + (size_t)txy * a.max_pieces * (kThreads * 32);
-  for (int p = 0; p <= last_wg - first_wg; ++p) {
-    const float* sp = base + (size_t)p * (kThreads * 32);
-#pragma unroll
-    for (int r = 0; r < 16; ++r) { acc0[r] = acc0[r] + sp[r * kThreads + tid]; acc1[r] = acc1[r] + sp[(16 + r) * kThreads + tid]; }
-  }
-  const int tx = txy % nx, ty = txy / nx;
-  const int pimg = tx / (patches_x * patches_y), prem = tx - pimg * (patches_x * patches_y);
-  const uint32_t m = halo_epilogue(a, nullptr, pimg, (prem / patches_x) * kPatchRows, (prem % patches_x) * kPatchCols, ty, tid >> 6, tid & 63, acc0, acc1);
-  publish_amax(m, a.amax_out, a.status, blockIdx.x * 4 + (tid >> 6));
-}
-
-// grid (8 * ceil(tiles / 8)); block 256.  tiles = N * ceil(H/4) * ceil(W/32) patches x (Cout / 64) x slices (of channel chunks);
-// a.chunks_per_slice counts CHANNEL chunks here.  Output size = input size (stride 1, pad = DIL).
-//
-// Balanced mode (a.units_per_wg > 0, nz == 1): the work is the list of (tile, channel chunk) units, tile-major; workgroup g
-// takes units [g * per, (g + 1) * per) whatever tiles they belong to.  320 tiles of 8 chunks on 512 workgroup slots run as
-// ONE round of 8 chunks with 192 slots idle; as 512 workgroups of 5 units each they run 5 chunks' worth.  A tile whose
-// chunks were shared leaves its fp32 accumulators in a.part (one slot per piece) and conv_split3x3_fixup_kernel adds them in
-// piece order and runs the epilogue.  (A last-arriver ticket inside this kernel was tried first: the device-scope
-// __threadfence() it needs writes back / invalidates the whole L2 on this multi-XCD part and doubled the kernel's time.)
-template <int DIL, int PC>
-static __global__ __launch_bounds__(kThreads, (DIL == 1 ? 2 : 1)) void conv_split3x3_kernel(Args a, int patches_x, int patches_y, int nx, int ny, int nz) {
-#if __HIP_DEVICE_COMPILE__      // hipcc's HOST pass fails to instantiate the unrolled tap chain (spurious "substitution failure"); it needs only the stub
-  typedef Halo<DIL, PC> HL;
-  __shared__ __attribute__((aligned(16))) uint4 S[2][HL::kRow];
-  HaloGeom<DIL> g;
-  g.tid = threadIdx.x;
-  g.lane = g.tid & 63;
-  g.wave = __builtin_amdgcn_readfirstlane(g.tid >> 6);
-  g.chunks_per_tap = a.Cin / kChunk;
-  const int cpt = g.chunks_per_tap;
-  const int col_tiles = a.Cout / 32;
-  g.wstride = (size_t)col_tiles * (128 * PC);
-  g.hp0 = g.wave * HL::kW + (g.lane & 31);
-  float a_scale = 1.f;
-  int s_exp = 0;
-  if (PC == 2) {
-    s_exp = 13 - amax_exponent_asm(a.amax, g.lane, a.status);
-    a_scale = ldexpf(1.f, s_exp);
-  }
-  uint32_t wg_max = 0;
-  g.h4 = 4 * (g.lane >> 5);
-  const bool balanced = a.units_per_wg > 0;
-  int u = 0, u_end = 0, wg = 0;
-  Tile tile;
-  if (balanced) {
-    const int total_units = nx * ny * cpt;
-    const int groups = (total_units + a.units_per_wg - 1) / a.units_per_wg;
-    wg = xcd_tile(blockIdx.x, groups, 1, 1).x;
-    if (wg < 0) return;
-    u = wg * a.units_per_wg;
-    u_end = min(u + a.units_per_wg, total_units);
-  } else {
-    tile = xcd_tile(blockIdx.x, nx, ny, nz, a.tile_order);
-    if (tile.x < 0) return;
-  }
-  for (;;) {
-    int kc0, kc_end, txy = 0;
-    if (balanced) {
-      txy = u / cpt;
-      kc0 = u - txy * cpt;
-      kc_end = min(cpt, kc0 + (u_end - u));
-      tile.x = txy % nx; tile.y = txy / nx; tile.z = 0;
-    } else {
-      kc0 = tile.z * a.chunks_per_slice;
-      kc_end = min(kc0 + a.chunks_per_slice, cpt);
-    }
-    const uint4* wblock = a.wfrag + (size_t)(2 * tile.y) * (128 * PC);
-    // patch -> image, top-left output pixel
-    const int pimg = tile.x / (patches_x * patches_y), prem = tile.x - pimg * (patches_x * patches_y);
-    const int y0 = (prem / patches_x) * kPatchRows, x0 = (prem % patches_x) * kPatchCols;
-    // DMA role: piece e = i * 256 + tid of the halo: halo pixel e >> 3, slot e & 7 holds source piece (e & 7) ^ ((pixel >> 1) & 7)
-    g.ok_mask = 0; g.live_mask = 0;
-#pragma unroll
-    for (int i = 0; i < HL::kDma; ++i) {
-      const int e = i * kThreads + g.tid;
-      g.off0[i] = 0;
-      if (e < HL::kPieces) {
-        g.live_mask |= 1u << i;
-        const int hpix = e >> 3, piece = (e & 7) ^ ((hpix >> 1) & 7);
-        const int iy = y0 - DIL + hpix / HL::kW, ix = x0 - DIL + hpix % HL::kW;
-        if (iy >= 0 && iy < a.H && ix >= 0 && ix < a.W) {
-          g.ok_mask |= 1u << i;
-          g.off0[i] = ((pimg * a.H + iy) * a.W + ix) * a.Cin + 4 * piece;
-        }
-      }
-    }
-
-    f32x16 acc0, acc1;
-#pragma unroll
-    for (int i = 0; i < 16; ++i) { acc0[i] = 0.f; acc1[i] = 0.f; }
-
-    if (kc0 < kc_end) {
-      // prologue: the whole halo of chunk kc0 and the weights of (kc0, tap 0); parities as if kc0 were even
-      halo_issue<DIL, PC, 0, 0, 0, HL::kDma>(S, a.x, wblock, g, kc0, true, kc0, true);
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    for (int kc = kc0; kc < kc_end; kc += 2) {
-      halo_chunk<DIL, PC, 0>(S, a.x, wblock, g, kc, kc_end, acc0, acc1, a_scale);
-      if (kc + 1 < kc_end) halo_chunk<DIL, PC, 1>(S, a.x, wblock, g, kc + 1, kc_end, acc0, acc1, a_scale);
-    }
-    if (PC == 2) {
-      float os[2];
-      column_scales<2>(a, s_exp, tile.y * kWgCh, g.lane, os);      // (every copy of the ring has landed: vmcnt(0) above)
-#pragma unroll
-      for (int i = 0; i < 16; ++i) { acc0[i] = acc0[i] * os[0]; acc1[i] = acc1[i] * os[1]; }
-    }
-
-    bool finish = true;       // does this workgroup write the tile's output
-    if (balanced && !(kc0 == 0 && kc_end == cpt)) {
-      // a shared tile: leave the accumulators in this piece's slot; conv_split3x3_fixup_kernel adds the pieces in order
-      const int first_wg = (txy * cpt) / a.units_per_wg;
-      float* slot = a.part + ((size_t)txy * a.max_pieces + (wg - first_wg)) * (kThreads * 32);
-#pragma unroll
-      for (int r = 0; r < 16; ++r) { slot[r * kThreads + g.tid] = acc0[r]; slot[(16 + r) * kThreads + g.tid] = acc1[r]; }
-      finish = false;
-    }
-
-    if (finish) {
-      const int P = a.N * a.H * a.W;
-      float* part = (!balanced && a.part) ? a.part + (size_t)tile.z * P * a.Cout : nullptr;
-      wg_max = max(wg_max, halo_epilogue(a, part, pimg, y0, x0, tile.y, g.wave, g.lane, acc0, acc1));
-    }
-    if (!balanced) break;
-    u += kc_end - kc0;
-    if (u >= u_end) break;
-  }
-  if (!(a.part && !balanced)) publish_amax(wg_max, a.amax_out, a.status, blockIdx.x * 4 + g.wave);
-#endif
 }
 
 // ---------------------------------------------------------------------------------------------------------------

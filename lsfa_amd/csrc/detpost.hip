@@ -78,7 +78,12 @@ __device__ __forceinline__ bool suppresses(double inter, double uni, const NmsTe
   return r;
 }
 
-__global__ __launch_bounds__(kClassThreads) void det_class_kernel(
+// (second launch bound, minimum waves per SIMD: 4 = one 16-wave workgroup per CU, 72 registers; 8 = two per CU, 63 registers + 8 spilled - an A/B
+//  of tools/lab/build_variant.sh, profiles/r6)
+#ifndef LSFA_DET_CLASS_MIN_WAVES
+#define LSFA_DET_CLASS_MIN_WAVES 4
+#endif
+__global__ __launch_bounds__(kClassThreads, LSFA_DET_CLASS_MIN_WAVES) void det_class_kernel(
     const float* __restrict__ rois, const float* __restrict__ deltas, const float* __restrict__ probs, int R,
     int ncls, int nreg, int class_agnostic, double im_h, double im_w, double scale, double score_thresh,
     NmsTest64 nms, double* __restrict__ dets, int* __restrict__ counts, int* __restrict__ keep_idx) {

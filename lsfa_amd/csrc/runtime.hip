@@ -128,6 +128,30 @@ extern "C" int lsfa_copy_many(int njobs, void* const* dst, const void* const* sr
   return LSFA_OK;
 }
 
+// r6: a device table of pointers (the per-image bases lsfa_avgpool_nchw_tbl / lsfa_stem_conv7x7s2_tbl read) rewritten from host values by one
+// tiny launch: the values travel as kernel arguments, so the call is captured-graph friendly on the CALLER's side only (a replayed graph reads the
+// table; the table itself is rewritten before each replay, in stream order)
+namespace {
+constexpr int kPtrTableMax = 64;
+struct PtrJobs { const void* p[kPtrTableMax]; };
+__global__ void ptr_table_kernel(const void** __restrict__ table, PtrJobs j, int n) {
+  const int i = threadIdx.x;
+  if (i < n) table[i] = j.p[i];
+}
+}  // namespace
+
+extern "C" int lsfa_ptr_table_set(void** table_dev, int n, const void* const* ptrs_host, void* stream) {
+  LSFA_REQUIRE(table_dev && ptrs_host && n >= 1, "lsfa_ptr_table_set: NULL argument or empty table");
+  for (int i0 = 0; i0 < n; i0 += kPtrTableMax) {
+    PtrJobs j;
+    const int m = n - i0 < kPtrTableMax ? n - i0 : kPtrTableMax;
+    for (int k = 0; k < kPtrTableMax; ++k) j.p[k] = k < m ? ptrs_host[i0 + k] : nullptr;
+    hipLaunchKernelGGL(ptr_table_kernel, dim3(1), dim3(kPtrTableMax), 0, (hipStream_t)stream, (const void**)table_dev + i0, j, m);
+  }
+  LSFA_LAUNCH_CHECK("lsfa_ptr_table_set");
+  return LSFA_OK;
+}
+
 extern "C" int lsfa_stream_destroy(void* stream) {
   if (!stream) return LSFA_OK;
   const hipError_t e = hipStreamDestroy((hipStream_t)stream);

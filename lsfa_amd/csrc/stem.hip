@@ -75,8 +75,10 @@ __device__ __forceinline__ void scale_of(float m, float& s, float& inv) {
   inv = ok ? __uint_as_float((uint32_t)(be - 13) << 23) : 1.f;
 }
 
-__global__ __launch_bounds__(256) void avgpool_kernel(const float* __restrict__ x, int NC, int H, int W, int k, int Ho, int Wo,
-                                                      float* __restrict__ y) {
+// r6: `tbl` (or NULL) = a device table of per-image base pointers: image n is read at tbl[n] instead of x + n * C * H * W, so that frames
+// handed over as separate tensors need no staging copy into one batch (lsfa_avgpool_nchw_tbl; C = channels per image then)
+__global__ __launch_bounds__(256) void avgpool_kernel(const float* __restrict__ x, const float* const* __restrict__ tbl, int C, int NC, int H, int W,
+                                                      int k, int Ho, int Wo, float* __restrict__ y) {
   const long i = (long)blockIdx.x * 256 + threadIdx.x;
   if (i >= (long)NC * Ho * Wo) return;
   const int ox = (int)(i % Wo);
@@ -84,7 +86,7 @@ __global__ __launch_bounds__(256) void avgpool_kernel(const float* __restrict__ 
   const int oy = (int)(r % Ho);
   const long nc = r / Ho;
   const int y0 = oy * k, x0 = ox * k, y1 = min(y0 + k, H), x1 = min(x0 + k, W);
-  const float* p = x + nc * (long)H * W;
+  const float* p = tbl ? tbl[nc / C] + (nc % C) * (long)H * W : x + nc * (long)H * W;
   float s = 0.f;
   for (int yy = y0; yy < y1; ++yy)
     for (int xx = x0; xx < x1; ++xx) s = s + p[(long)yy * W + xx];
@@ -118,7 +120,7 @@ __global__ __launch_bounds__(128) void stem_weights_kernel(const float* __restri
 }
 
 // grid (ceil(ceil(Wo / 32) / tiles_per_wg), ceil(Ho / 4), N); block 256.  wfrag: what stem_weights_kernel wrote.
-__global__ __launch_bounds__(256, 2) void stem_conv_kernel(const float* __restrict__ x, int H, int W, const float* __restrict__ in_scale,
+__global__ __launch_bounds__(256, 2) void stem_conv_kernel(const float* __restrict__ x, const float* const* __restrict__ tbl, int H, int W, const float* __restrict__ in_scale,
                                                            const float* __restrict__ in_shift, const uint4* __restrict__ wfrag,
                                                            const float* __restrict__ bias, int Ho, int Wo, int tiles_per_wg,
                                                            const float* accum, int act, float* y, unsigned* __restrict__ amax_out) {
@@ -128,7 +130,7 @@ __global__ __launch_bounds__(256, 2) void stem_conv_kernel(const float* __restri
   const int half = lane >> 5, px = lane & 31, co = px + 32 * ni;
   const int n = blockIdx.z, oy0 = blockIdx.y * kTileRows;
   const int iy0 = 2 * oy0 - 3;
-  const float* xin = x + (size_t)n * kStemCin * H * W;
+  const float* xin = tbl ? tbl[n] : x + (size_t)n * kStemCin * H * W;      // (tbl: lsfa_stem_conv7x7s2_tbl, per-image base pointers)
 
   // ---- this wave's weight fragments (stem_weights_kernel cut them): 24 coalesced 16-byte loads ----
   uint4 bhi[kSteps], blo[kSteps];
@@ -382,15 +384,23 @@ extern "C" int lsfa_image_transform_u8(const unsigned char* im_hwc_bgr, int N, i
   return LSFA_OK;
 }
 
-extern "C" int lsfa_avgpool_nchw(const float* x, int N, int C, int H, int W, int k, float* y, void* stream) {
-  LSFA_REQUIRE(x && y, "lsfa_avgpool_nchw: NULL argument");
-  LSFA_REQUIRE(N > 0 && C > 0 && H > 0 && W > 0 && k > 0, "lsfa_avgpool_nchw: bad shape");
+static int avgpool_launch(const float* x, const float* const* tbl, int N, int C, int H, int W, int k, float* y, void* stream, const char* who) {
+  LSFA_REQUIRE((x || tbl) && y, "%s: NULL argument", who);
+  LSFA_REQUIRE(N > 0 && C > 0 && H > 0 && W > 0 && k > 0, "%s: bad shape", who);
   const int Ho = (H + k - 1) / k, Wo = (W + k - 1) / k;
   const long total = (long)N * C * Ho * Wo;
   ProfScope prof(LSFA_OP_STEM, (hipStream_t)stream);
-  hipLaunchKernelGGL(avgpool_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x, N * C, H, W, k, Ho, Wo, y);
-  LSFA_LAUNCH_CHECK("lsfa_avgpool_nchw");
+  hipLaunchKernelGGL(avgpool_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x, tbl, C, N * C, H, W, k, Ho, Wo, y);
+  LSFA_LAUNCH_CHECK(who);
   return LSFA_OK;
+}
+
+extern "C" int lsfa_avgpool_nchw(const float* x, int N, int C, int H, int W, int k, float* y, void* stream) {
+  return avgpool_launch(x, nullptr, N, C, H, W, k, y, stream, "lsfa_avgpool_nchw");
+}
+
+extern "C" int lsfa_avgpool_nchw_tbl(const float* const* x_table, int N, int C, int H, int W, int k, float* y, void* stream) {
+  return avgpool_launch(nullptr, x_table, N, C, H, W, k, y, stream, "lsfa_avgpool_nchw_tbl");
 }
 
 extern "C" size_t lsfa_stem_weight_bytes(void) { return (size_t)kFragVecs * sizeof(uint4) + kStemCout * sizeof(float); }
@@ -408,10 +418,25 @@ extern "C" int lsfa_stem_conv7x7s2(const float* x, int N, int H, int W, const fl
   return lsfa_stem_conv7x7s2_ex(x, N, H, W, in_scale, in_shift, wfrag, bias, nullptr, 1, y, nullptr, stream);
 }
 
+static int stem_launch(const float* x, const float* const* tbl, int N, int H, int W, const float* in_scale, const float* in_shift, const void* wfrag,
+                       const float* bias, const float* accum, int act, float* y, unsigned* amax_out, void* stream);
+
 extern "C" int lsfa_stem_conv7x7s2_ex(const float* x, int N, int H, int W, const float* in_scale, const float* in_shift,
                                       const void* wfrag, const float* bias, const float* accum, int act, float* y, unsigned* amax_out,
                                       void* stream) {
-  LSFA_REQUIRE(x && wfrag && y, "lsfa_stem_conv7x7s2: NULL argument");
+  return stem_launch(x, nullptr, N, H, W, in_scale, in_shift, wfrag, bias, accum, act, y, amax_out, stream);
+}
+
+extern "C" int lsfa_stem_conv7x7s2_tbl(const float* const* x_table, int N, int H, int W, const float* in_scale, const float* in_shift,
+                                       const void* wfrag, const float* bias, const float* accum, int act, float* y, unsigned* amax_out,
+                                       void* stream) {
+  LSFA_REQUIRE(x_table, "lsfa_stem_conv7x7s2_tbl: NULL table");
+  return stem_launch(nullptr, x_table, N, H, W, in_scale, in_shift, wfrag, bias, accum, act, y, amax_out, stream);
+}
+
+static int stem_launch(const float* x, const float* const* tbl, int N, int H, int W, const float* in_scale, const float* in_shift, const void* wfrag,
+                       const float* bias, const float* accum, int act, float* y, unsigned* amax_out, void* stream) {
+  LSFA_REQUIRE((x || tbl) && wfrag && y, "lsfa_stem_conv7x7s2: NULL argument");
   LSFA_REQUIRE(((uintptr_t)wfrag & 15) == 0, "lsfa_stem_conv7x7s2: wfrag must be 16-byte aligned (lsfa_stem_weights)");
   LSFA_REQUIRE((long)3 * H * W < (1L << 31), "lsfa_stem_conv7x7s2: an image of 2^31 elements or more");
   LSFA_REQUIRE(act >= 0 && act <= 2, "lsfa_stem_conv7x7s2_ex: act must be 0, 1 or 2");
@@ -425,7 +450,7 @@ extern "C" int lsfa_stem_conv7x7s2_ex(const float* x, int N, int H, int W, const
   if (want < 1) want = 1;
   const int gx = (int)((xt + want - 1) / want);
   const int tpw = (xt + gx - 1) / gx;
-  hipLaunchKernelGGL(stem_conv_kernel, dim3((xt + tpw - 1) / tpw, yt, N), dim3(256), 0, (hipStream_t)stream, x, H, W, in_scale, in_shift,
+  hipLaunchKernelGGL(stem_conv_kernel, dim3((xt + tpw - 1) / tpw, yt, N), dim3(256), 0, (hipStream_t)stream, x, tbl, H, W, in_scale, in_shift,
                      (const uint4*)wfrag, bias, Ho, Wo, tpw, accum, act, y, amax_out);
   LSFA_LAUNCH_CHECK("lsfa_stem_conv7x7s2");
   return LSFA_OK;

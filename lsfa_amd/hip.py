@@ -649,14 +649,67 @@ def image_transform_u8(im, pixel_means=(0.0, 0.0, 0.0), pixel_scale=1.0, out=Non
     return out
 
 
+class ImageTable(object):
+    """N images (C, H, W) float32, each ANYWHERE on the device, in place of one (N, C, H, W) tensor: what lsfa_avgpool_nchw_tbl and
+    lsfa_stem_conv7x7s2_tbl read.  The reference's loader hands over one array per frame (dff_rfcn/core/loader.py:131-141); a batched pass
+    over F such frames used to copy them into one static buffer first (lsfa_copy_many: 2 x 65 MB per nine-frame segment, 2.4 % of frames/s,
+    profiles/r6/tail_ablation.txt).  The table of N device pointers has a fixed address - a captured graph bakes THAT in - and `set`
+    rewrites its entries on the current stream with one tiny launch (lsfa_ptr_table_set); the images must stay alive and unchanged until
+    the pass that reads them has run (the table keeps references until the next `set`)."""
+
+    def __init__(self, n, c, h, w, device):
+        self.shape = (int(n), int(c), int(h), int(w))
+        self.device = torch.device(device)
+        self.ptrs = torch.zeros(int(n), dtype=torch.int64, device=self.device)
+        self.dtype, self.is_cuda = torch.float32, True
+        self.held = None
+
+    def dim(self):
+        return 4
+
+    def contiguous(self):
+        return self
+
+    def is_contiguous(self):
+        return True
+
+    def set(self, images):
+        """images: N tensors (C, H, W) (or (1, C, H, W)), float32, contiguous, on this device"""
+        n, c, h, w = self.shape
+        images = list(images)
+        if len(images) != n:
+            raise LsfaError("ImageTable.set: %d images for a table of %d" % (len(images), n))
+        for t in images:
+            if t.dtype != torch.float32 or not t.is_cuda or t.device != self.device or not t.is_contiguous() or t.numel() != c * h * w or \
+                    tuple(t.shape[-3:]) != (c, h, w) or t.data_ptr() % 4:
+                raise LsfaError("ImageTable.set: every image must be a contiguous float32 (%d, %d, %d) tensor on %s, got %s %s on %s" % (
+                    c, h, w, self.device, tuple(t.shape), t.dtype, t.device))
+        arr = (ctypes.c_void_p * n)(*[t.data_ptr() for t in images])
+        with torch.cuda.device(self.device):
+            _check(lib().lsfa_ptr_table_set(_vp(self.ptrs.data_ptr()), _ci(n), arr, _stream()), "lsfa_ptr_table_set")
+        self.held = images
+        return self
+
+    def materialize(self):
+        """the images as one (N, C, H, W) tensor (a copy; for code paths that need a tensor)"""
+        return torch.stack([t.reshape(self.shape[1:]) for t in self.held], 0)
+
+
 @_on_tensor_device
 def avgpool_nchw(x, k, out=None):
-    """(N, C, H, W) float32 -> (N, C, ceil(H/k), ceil(W/k)): k x k / k average, edge windows clipped (lsfa_avgpool_nchw)."""
-    x = _f32c(x, "x")
+    """(N, C, H, W) float32 (or an ImageTable of N images) -> (N, C, ceil(H/k), ceil(W/k)): k x k / k average, edge windows clipped
+    (lsfa_avgpool_nchw / lsfa_avgpool_nchw_tbl)."""
+    tbl = isinstance(x, ImageTable)
+    if not tbl:
+        x = _f32c(x, "x")
     N, C, H, W = x.shape
     Ho, Wo = -(-H // k), -(-W // k)
     if out is None:
         out = torch.empty((N, C, Ho, Wo), device=x.device, dtype=torch.float32)
+    if tbl:
+        with torch.cuda.device(x.device):
+            _check(lib().lsfa_avgpool_nchw_tbl(_vp(x.ptrs.data_ptr()), _ci(N), _ci(C), _ci(H), _ci(W), _ci(k), _ptr(out), _stream()), "lsfa_avgpool_nchw_tbl")
+        return out
     _check(lib().lsfa_avgpool_nchw(_ptr(x), _ci(N), _ci(C), _ci(H), _ci(W), _ci(k), _ptr(out), _stream()), "lsfa_avgpool_nchw")
     return out
 
@@ -678,7 +731,9 @@ def stem_weight_layout(weight):
 def stem_conv(x, w_l, bias, in_scale=None, in_shift=None, out=None, accum=None, act=1, amax_out=None):
     """bn_data + conv0 (7x7, stride 2, pad 3) + bias (+ accum) + activation (0 none, 1 ReLU, 2 LeakyReLU 0.1):
     x (N, 3, H, W) NCHW -> (N, Ho, Wo, 64) channels-last.  amax_out: a zeroed row of amax_slots() for max|out|."""
-    x = _f32c(x, "x")
+    tbl = isinstance(x, ImageTable)      # the N images given by a table of device pointers (lsfa_stem_conv7x7s2_tbl)
+    if not tbl:
+        x = _f32c(x, "x")
     N, C, H, W = x.shape
     if C != 3 or w_l.dtype != torch.uint8 or w_l.numel() != int(lib().lsfa_stem_weight_bytes()) or not w_l.is_contiguous():
         raise LsfaError("stem_conv: x must have 3 channels and w_l must come from stem_weight_layout")
@@ -687,6 +742,11 @@ def stem_conv(x, w_l, bias, in_scale=None, in_shift=None, out=None, accum=None, 
         out = torch.empty((N, Ho, Wo, 64), device=x.device, dtype=torch.float32)
     if accum is not None and (tuple(accum.shape) != tuple(out.shape) or not accum.is_contiguous()):
         raise LsfaError("stem_conv: accum must be a contiguous %s tensor" % (tuple(out.shape),))
+    if tbl:
+        with torch.cuda.device(x.device):
+            _check(lib().lsfa_stem_conv7x7s2_tbl(_vp(x.ptrs.data_ptr()), _ci(N), _ci(H), _ci(W), _ptr(in_scale), _ptr(in_shift), _ptr(w_l), _ptr(bias),
+                                                 _ptr(accum), _ci(act), _ptr(out), _ptr(amax_out), _stream()), "lsfa_stem_conv7x7s2_tbl")
+        return out
     _check(lib().lsfa_stem_conv7x7s2_ex(_ptr(x), _ci(N), _ci(H), _ci(W), _ptr(in_scale), _ptr(in_shift), _ptr(w_l), _ptr(bias),
                                         _ptr(accum), _ci(act), _ptr(out), _ptr(amax_out), _stream()), "lsfa_stem_conv7x7s2_ex")
     return out

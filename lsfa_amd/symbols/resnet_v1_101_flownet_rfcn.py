@@ -393,6 +393,8 @@ class Executor(object):
         units = [u for u in net.units if u['stage'] <= stages]
         # bn_data + conv0 + bn0 + relu0, then pool0 with the first unit's bn1 + relu1 as a second output: two launches
         if net.conv0_exact is not None:
+            if isinstance(x, hip.ImageTable):
+                x = x.materialize()
             xa = (x * net.bn_data[0].view(1, 3, 1, 1) + net.bn_data[1].view(1, 3, 1, 1)).permute(0, 2, 3, 1)
             xh = torch.zeros(tuple(xa.shape[:3]) + (32,), device=x.device, dtype=torch.float32)
             xh[..., :3] = xa

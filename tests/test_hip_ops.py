@@ -1017,6 +1017,36 @@ def test_image_resize_transform_on_the_device_is_the_references(hip, case):
         assert torch.equal(hip.image_resize_transform(t(ims), 1.0, (0.0, 0.0, 0.0), ps), hip.image_transform_u8(t(ims), (0.0, 0.0, 0.0), ps))
 
 
+def test_image_table_entry_points_equal_the_dense_ones(hip):
+    """r6 (lsfa_avgpool_nchw_tbl, lsfa_stem_conv7x7s2_tbl, lsfa_ptr_table_set): N frames that live in separate tensors, read through a device
+    table of per-image pointers, give the bits of the same frames stacked into one (N, 3, H, W) tensor - and a table rewritten to other
+    frames gives theirs (what a replayed graph sees between two passes)."""
+    rs = np.random.RandomState(77)
+    N, H, W = 5, 37, 53
+    frames = [t((rs.rand(3, H, W) * 255).astype(np.float32)) for _ in range(N)]
+    pad = [torch.empty(1000 + 17 * i, device=DEV) for i in range(N)]                       # (keeps the frames apart in memory)
+    dense = torch.stack(frames, 0)
+    w = (rs.randn(64, 3, 7, 7) * 0.05).astype(np.float32)
+    wl, b = hip.stem_weight_layout(t(w)), t(rs.randn(64).astype(np.float32))
+    sc, sh = t(rs.uniform(0.01, 0.03, 3).astype(np.float32)), t(rs.uniform(-3, -1, 3).astype(np.float32))
+    tbl = hip.ImageTable(N, 3, H, W, DEV).set(frames)
+    for k in (2, 4):
+        assert torch.equal(hip.avgpool_nchw(tbl, k), hip.avgpool_nchw(dense, k))
+    slots = hip.amax_slots(2, DEV)
+    y_t = hip.stem_conv(tbl, wl, b, sc, sh, amax_out=slots[0])
+    y_d = hip.stem_conv(dense, wl, b, sc, sh, amax_out=slots[1])
+    assert torch.equal(y_t, y_d) and torch.equal(slots[0], slots[1])
+    other = [frames[(i + 2) % N] for i in range(N)]
+    tbl.set(other)
+    assert torch.equal(hip.stem_conv(tbl, wl, b, sc, sh), hip.stem_conv(torch.stack(other, 0), wl, b, sc, sh))
+    assert torch.equal(hip.avgpool_nchw(tbl, 4), hip.avgpool_nchw(torch.stack(other, 0), 4))
+    with pytest.raises(hip.LsfaError):
+        tbl.set(frames[:-1])
+    with pytest.raises(hip.LsfaError):
+        tbl.set([f.double() for f in frames])
+    del pad
+
+
 def test_image_resize_transform_golden_g6_float32_frame(hip, golden):
     """... and against G6: the reference's own `transform` on a float32 frame with list means (float32 subtraction, float64 product)."""
     imf = golden["g6_im"].astype(np.float32) * np.float32(0.731)
@@ -1157,10 +1187,9 @@ SPLIT_CFGS = [
     dict(N=2, H=13, W=9, Cin=64, Cout=64, k=3, stride=1, dil=1),         # batch 2, ragged pixel tile, one chunk per tap
     dict(N=1, H=20, W=17, Cin=96, Cout=128, k=1, stride=1, dil=1),       # 1x1, odd chunk count
     dict(N=1, H=38, W=63, Cin=256, Cout=1024, k=1, stride=1, dil=1),     # res4 conv3 shape
-    dict(N=1, H=38, W=63, Cin=256, Cout=1024, k=3, stride=1, dil=1),     # the fuse convolution (halo kernel, balanced mode:
-                                                                         # 512 workgroups x 5 (tile, chunk) units, shared tiles)
-    dict(N=1, H=30, W=70, Cin=192, Cout=1024, k=3, stride=1, dil=2),     # balanced mode, dilation 2, 6 chunks per tile
-    dict(N=2, H=20, W=63, Cin=256, Cout=1024, k=3, stride=1, dil=1),     # balanced mode over two images
+    dict(N=1, H=38, W=63, Cin=256, Cout=1024, k=3, stride=1, dil=1),     # the fuse convolution
+    dict(N=1, H=30, W=70, Cin=192, Cout=1024, k=3, stride=1, dil=2),     # dilation 2, 6 chunks per tap
+    dict(N=2, H=20, W=63, Cin=256, Cout=1024, k=3, stride=1, dil=1),     # two images
     dict(N=1, H=21, W=40, Cin=256, Cout=64, k=3, stride=1, dil=6),       # feat_conv_3x3's dilation (general kernel)
     dict(N=1, H=38, W=63, Cin=512, Cout=1024, k=3, stride=1, dil=6),     # 304 workgroups: K cut into 5 by the rounds model
 ]
@@ -1237,8 +1266,8 @@ def test_conv_split_cut_is_exact_and_products_are_fp32_grade(hip):
                                  dict(N=1, H=38, W=63, Cin=256, Cout=256, k=3), dict(N=1, H=20, W=17, Cin=96, Cout=128, k=1)])
 def test_conv_split_nchw_output_equals_nhwc_output(hip, cfg):
     """y_nchw: the same numbers in the reference operators' layout (the small net's fuse convolution feeds
-    lsfa_warp_bilinear's `add` operand without a transposing copy), incl. residual and second output, for the halo
-    kernel, the general kernel and the sliced path."""
+    lsfa_warp_bilinear's `add` operand without a transposing copy), incl. residual and second output, for the ring kernel
+    and the sliced path."""
     rs = np.random.RandomState(cfg["Cout"] + cfg["H"])
     N, H, W, Cin, Cout, k = (cfg[x] for x in ("N", "H", "W", "Cin", "Cout", "k"))
     x = t(rs.randn(N, H, W, Cin).astype(np.float32))
@@ -1752,31 +1781,6 @@ def test_conv_tile_order_and_k_order(hip):
     finally:
         hip.conv_plan_override()
         hip.conv_order_override()
-
-
-@pytest.mark.parametrize("shape", [(38, 63, 256, 1024, 1), (30, 70, 192, 1024, 2), (150, 250, 64, 64, 1)])
-def test_conv_halo_form_forced(hip, shape):
-    """The 3x3 halo kernel (incl. its balanced mode + fix-up pass and the K-sliced form) is only the plan's choice for wide maps with
-    narrow outputs since r4; forced through lsfa_conv_plan_override(kernel=3) it must still compute the convolution the ring
-    kernel computes (both within the fp32 bound of float64), for two- and three-piece operands, with amax_out."""
-    H, W, ci, co, dil = shape
-    g = torch.Generator(device=DEV).manual_seed(H + ci)
-    x = torch.relu(torch.randn((1, H, W, ci), device=DEV, generator=g))
-    w = torch.randn((co, ci, 3, 3), device=DEV, generator=g) * 0.02
-    b = torch.randn(co, device=DEV, generator=g)
-    ref = torch.relu(torch.nn.functional.conv2d(x.permute(0, 3, 1, 2).double().cpu(), w.double().cpu(), b.double().cpu(), padding=dil, dilation=dil)).permute(0, 2, 3, 1)
-    tol = 2e-6 * (ci * 9) ** 0.5 * float(ref.abs().max())
-    for pieces in (2, 3):
-        sw = hip.SplitWeight(w, pieces=pieces)
-        try:
-            hip.conv_plan_override(kernel=3)
-            slots = hip.amax_slots(1, DEV)[0]
-            y = hip.conv_split(x, sw, b, 1, dil, dil, relu=True, amax_out=slots)
-        finally:
-            hip.conv_plan_override()
-        assert float((y.double().cpu() - ref).abs().max()) < tol
-        assert slots.view(torch.float32).max().item() == y.max().item()
-        assert float((hip.conv_split(x, sw, b, 1, dil, dil, relu=True).double().cpu() - ref).abs().max()) < tol
 
 
 def test_proposal_and_nms_do_not_depend_on_workspace_contents(hip):

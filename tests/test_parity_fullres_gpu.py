@@ -306,6 +306,126 @@ def _rescale_bn(arg, aux, name, f, rs):
     arg[name + '_beta'] = (arg[name + '_beta'].astype(np.float64) + m * s).astype(np.float32)
 
 
+def trained_like_everywhere(arg, aux, seed=6, octaves=4.0, outlier_share=0.001, outlier_log2=12.0):
+    """trained_like_batchnorm's backbone + the same idea in every other convolution net of an interval: channel c of a map is
+    scaled by f[c] = 2^U(-octaves, octaves), `outlier_share` of the channels another 2^outlier_log2 up - the producer's output rows (and bias)
+    times f[c] - and every reader divides its input channels by f[c]; ReLU / LeakyReLU commute with a positive factor, so in real arithmetic
+    the networks compute what they computed.  Spread this way:
+      * the small net's stage-1 stream (conv3 / shortcut rows; its later units' bn1 undo it) - whose LAST reader is fuse_reduce_add, a
+        convolution with NO BatchNorm in front: the two fp16 pieces there see a raw map with a 2^20 channel spread under ONE power-of-two scale,
+        the matching weights spread the other way (resnet_v1_101_flownet_rfcn.py:209-236);
+      * Nq_conv1 -> Nq_conv2 (:94-101), ReLU in between, no BatchNorm;
+      * FlowNet's single-reader encoder maps flow_conv1 -> conv2, conv3 -> conv3_1, conv4 -> conv4_1, conv5 -> conv5_1, conv6 -> conv6_1 (:153-169).
+    The window this is sized for: a value within 2^-16 of its map's maximum keeps all 22 bits of the two-piece form."""
+    arg, aux = trained_like_batchnorm(arg, aux)
+    rs = np.random.RandomState(seed)
+
+    def spread(C):
+        f = np.exp2(rs.uniform(-octaves, octaves, C))
+        f[rs.rand(C) < outlier_share] *= 2.0 ** outlier_log2
+        if not (f > 2.0 ** octaves).any():
+            f[rs.randint(C)] *= 2.0 ** outlier_log2          # at least one outlier per map, whatever the share rounds to
+        return f
+
+    def rows(name, f, bias=True):
+        arg[name + '_weight'] = (arg[name + '_weight'].astype(np.float64) * f[:, None, None, None]).astype(np.float32)
+        if bias and name + '_bias' in arg:
+            arg[name + '_bias'] = (arg[name + '_bias'].astype(np.float64) * f).astype(np.float32)
+
+    def cols(name, f):
+        arg[name + '_weight'] = (arg[name + '_weight'].astype(np.float64) / f[None, :, None, None]).astype(np.float32)
+
+    # the small net's stage 1 (the only stage that exists: need_part) and its reader without a BatchNorm
+    f = spread(arg['small_net_stage1_unit1_conv3_weight'].shape[0])
+    for u in (1, 2, 3):
+        p_ = 'small_net_stage1_unit%d_' % u
+        rows(p_ + 'conv3', f, bias=False)
+        if u == 1:
+            rows(p_ + 'sc', f, bias=False)
+        else:
+            _rescale_bn(arg, aux, p_ + 'bn1', f, rs)
+    cols('fuse_reduce_add', f)
+    g = spread(arg['Nq_conv1_weight'].shape[0])
+    rows('Nq_conv1', g)
+    cols('Nq_conv2', g)
+    for prod, cons in (('flow_conv1', 'conv2'), ('conv3', 'conv3_1'), ('conv4', 'conv4_1'), ('conv5', 'conv5_1'), ('conv6', 'conv6_1')):
+        h = spread(arg[prod + '_weight'].shape[0])
+        rows(prod, h)
+        cols(cons, h)
+    return arg, aux
+
+
+def test_trained_like_statistics_over_an_interval_at_1000x600(world):
+    """r5's trained-like test ran frame 0 only (backbone + heads) and spread the backbone's BatchNorms only.  Here the small
+    net (whose output feeds fuse_reduce_add WITHOUT a BatchNorm), the Nq net and FlowNet carry a per-channel spread too (2^+-4, 0.1 % of the
+    channels - at least one per map - 2^12 above that: activation outliers 2^12 x the map's typical magnitude entering convolutions that are
+    not bn-at-the-cut), and a whole interval's kinds of frames go through: frame 0 (first key frame), frame 1 (non-key: small net +
+    fuse_reduce_add + MV warp + heads) and frame 10 (second key frame: FlowNet + flow warp + Nq aggregation), each under the float64-anchored
+    criterion (oracle/e2e.py), the dense maps within TOL_DENSE of the fp32 oracle's and no further from float64 than 1.5 x the oracle, and no
+    status bit raised."""
+    from lsfa_amd.symbols.resnet_v1_101_flownet_rfcn import resnet_v1_101_flownet_rfcn
+    cfg, clip = world['cfg'], world['clip']
+    arg, aux = trained_like_everywhere(world['arg'], world['aux'])
+    im_info = clip.im_info()
+    im_t = torch.from_numpy(im_info).to(DEV)
+    net = resnet_v1_101_flownet_rfcn(cfg)
+    key = net.get_key_test_symbol(cfg).bind(arg, aux, DEV)
+    cur = net.get_cur_test_symbol(cfg).bind(arg, aux, DEV)
+    p = graph_ref.Params(arg, aux)
+    f0, f1, f10 = clip.frame(0), clip.frame(1), clip.frame(10)
+    zero = np.zeros((1, 1024, 1, 1), np.float32)
+    rec = {}
+    # frame 0
+    key.taps = {}
+    out0 = key.forward(data=f0.to(DEV), im_info=im_t, data_key_old=f0.to(DEV), feat_key_old=torch.zeros(1, 1024, 1, 1, device=DEV))
+    taps0 = dict(key.taps)
+    ref0 = graph_ref.key_forward(cfg, arg, aux, f0.numpy(), f0.numpy(), zero, im_info)
+    d0 = graph_ref.key_forward(cfg, arg, aux, f0.numpy(), f0.numpy(), zero, im_info, dtype=F64)
+    rec['frame0'] = e2e.frame_gap(cfg, e2e.gpu_side(cfg, taps0, out0, im_info), ref0, d0, im_info, H, W)
+    feat0 = out0['choose_feat_output']
+    # frame 1: the non-key path
+    mv, res = clip.motion_vector(1, 0), clip.res_diff(1)
+    cur.taps = {}
+    out1 = cur.forward(data=f1.to(DEV), im_info=im_t, feat_key=feat0, motion_vector=mv.to(DEV), res_diff=res.to(DEV))
+    taps1 = dict(cur.taps)
+    small_ref, small_64 = graph_ref.small_net_feature(p, f1).numpy(), graph_ref.small_net_feature(graph_ref.Params(arg, aux, dtype=F64), f1).numpy()
+    rec['small_feat'] = dict(vs_oracle=rel_err(np_(taps1['small_feat']), small_ref), gpu_vs_f64=rel_err(np_(taps1['small_feat']), small_64),
+                             oracle_vs_f64=rel_err(small_ref, small_64))
+    check_cur_frame(cfg, arg, taps1, out1, feat0, mv, res, im_info)
+    ref1 = graph_ref.cur_forward(cfg, arg, aux, f1.numpy(), ref0['choose_feat_output'], mv.numpy(), res.numpy(), im_info)
+    d1 = graph_ref.cur_forward(cfg, arg, aux, f1.numpy(), d0['choose_feat_output'], mv.numpy(), res.numpy(), im_info, dtype=F64)
+    rec['frame1'] = e2e.frame_gap(cfg, e2e.gpu_side(cfg, taps1, out1, im_info), ref1, d1, im_info, H, W)
+    # frame 10: the second key frame
+    key.taps = {}
+    out10 = key.forward(data=f10.to(DEV), im_info=im_t, data_key_old=f0.to(DEV), feat_key_old=feat0)
+    taps10 = dict(key.taps)
+    flow_ref, scale_ref = graph_ref.get_flownet(p, f10, f0)
+    rec['flow_abs'], rec['flow_max'] = float(np.abs(np_(taps10['flow']) - flow_ref.numpy()).max()), float(flow_ref.abs().max())
+    rec['scale_map'] = rel_err(np_(taps10['scale_map']), scale_ref.numpy())
+    check_key_frame(cfg, taps10, out10, feat0, im_info)
+    logits_ref = graph_ref.nq_logits(p, torch.from_numpy(np_(taps10['warp'])), taps10['backbone_feat'].cpu()).numpy()
+    rec['nq_logits_abs'], rec['nq_logits_max'] = float(np.abs(np_(taps10['nq_logits']) - logits_ref).max()), float(np.abs(logits_ref).max())
+    ref10 = graph_ref.key_forward(cfg, arg, aux, f10.numpy(), f0.numpy(), ref0['choose_feat_output'], im_info)
+    d10 = graph_ref.key_forward(cfg, arg, aux, f10.numpy(), f0.numpy(), d0['choose_feat_output'], im_info, dtype=F64)
+    rec['frame10'] = e2e.frame_gap(cfg, e2e.gpu_side(cfg, taps10, out10, im_info), ref10, d10, im_info, H, W)
+    rec['choose_feat_second_key_vs_f64'] = dict(gpu=rel_err(np_(out10['choose_feat_output']), d10['choose_feat_output']),
+                                                oracle_fp32=rel_err(ref10['choose_feat_output'], d10['choose_feat_output']))
+    key.check_status()
+    cur.check_status()
+    key.taps = cur.taps = None
+    record('trained_like_everywhere', rec)
+    assert rec['small_feat']['vs_oracle'] < TOL_DENSE, rec['small_feat']
+    assert rec['small_feat']['gpu_vs_f64'] <= e2e.RATIO * rec['small_feat']['oracle_vs_f64'] + 2.0 ** -23, rec['small_feat']
+    assert rec['scale_map'] < TOL_DENSE and rec['flow_abs'] < TOL_DENSE * max(1.0, rec['flow_max']), rec
+    assert rec['nq_logits_abs'] < TOL_DENSE * max(1.0, rec['nq_logits_max']), rec
+    for k in ('frame0', 'frame1', 'frame10'):
+        e = rec[k]
+        assert not e['failures'], (k, e['failures'], e)
+        assert e['max_abs_dscore'] <= TOL_SCORE and e['max_abs_dbox'] <= TOL_BOX_PX_BACKSTOP, (k, e)
+        assert e['rois_compared'] >= 250, (k, e)
+    assert rec['choose_feat_second_key_vs_f64']['gpu'] <= e2e.RATIO * rec['choose_feat_second_key_vs_f64']['oracle_fp32'] + 2.0 ** -23, rec['choose_feat_second_key_vs_f64']
+
+
 def test_trained_like_batchnorm_statistics_at_1000x600(world):
     """the fp32 path's two fp16 pieces take one power-of-two scale per activation MAP and - since r5 - one per OUTPUT
     CHANNEL of a weight.  With the residual streams, conv3 / shortcut weights and bn1 statistics spread the way a trained network's are

@@ -14,7 +14,8 @@ dev = 'cuda:0'
 H, W = 600, 1000
 cfg = lsfa_test_config(key_frame_interval=10)
 arg, aux = P.init_params(cfg, seed=0)
-cur = resnet_v1_101_flownet_rfcn(cfg).get_cur_test_symbol(cfg).bind(arg, aux, dev)
+DT = torch.bfloat16 if os.environ.get('LSFA_PROBE_DTYPE') == 'bf16' else torch.float32      # bf16: the one-product mode (BASELINE configs[2])
+cur = resnet_v1_101_flownet_rfcn(cfg).get_cur_test_symbol(cfg).bind(arg, aux, dev, dtype=DT)
 R, ncls = cfg.TEST.RPN_POST_NMS_TOP_N, cfg.dataset.NUM_CLASSES
 
 

@@ -13,7 +13,8 @@ H, W = 600, 1000
 cfg = lsfa_test_config(key_frame_interval=10)
 arg, aux = P.init_params(cfg, seed=0)
 net = resnet_v1_101_flownet_rfcn(cfg)
-key = net.get_key_test_symbol(cfg).bind(arg, aux, dev)
+DT = torch.bfloat16 if os.environ.get('LSFA_PROBE_DTYPE') == 'bf16' else torch.float32      # bf16: the one-product mode (BASELINE configs[2])
+key = net.get_key_test_symbol(cfg).bind(arg, aux, dev, dtype=DT)
 
 
 def graph_time(fn, n=20):

@@ -56,7 +56,6 @@ rm -rf $OUT/pmc_cfetch $OUT/pmc_cwrite
 timeout 200 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_ops -o t -- $PY tools/bench_ops.py > $OUT/bench_ops_microbench.txt 2>&1
 cp $(find $OUT/trace_ops -name "*kernel_stats.csv" | head -1) $OUT/bench_ops_kernel_stats.csv 2>/dev/null
 rm -rf $OUT/trace_ops
-timeout 200 $PY tools/lab/warp_lab.py --rounds 9 > $OUT/warp_lab.txt 2>&1
 timeout 200 $PY tools/key_sections.py > $OUT/key_sections.txt 2>&1
 LSFA_CONV_PIECES=3 timeout 200 $PY tools/key_sections.py > $OUT/key_sections_three_bf16_pieces.txt 2>&1
 timeout 300 $PY tools/lab/key_batch_probe.py 2>&1 | tail -6 > $OUT/key_batch_probe.txt

@@ -860,7 +860,7 @@ def main():
     if _hip.LAB_SKIP:
         # ablation (tools/lab/tail_ablation.sh): launches are dropped, detections are garbage - the line says so and carries no parity and no
         # CPU baseline
-        if _hip.LAB_SKIP_TAIL:
+        if _hip.LAB_SKIP_NMS:
             _hip.proposal_set_plan('lab-no-nms')
         args.no_parity = args.no_cpu_baseline = True
     rank = int(os.environ.get('RANK', '0'))
@@ -1075,7 +1075,8 @@ def main():
                     "flops_share_by_products_per_fp32_product": {"six (three bf16 pieces)": round(fl6 / conv_fl, 3), "three (two fp16 pieces)": round(fl3 / conv_fl, 3),
                                                                   "one (bf16 mode)": round(fl1 / conv_fl, 3)},
                     "frac_of_six_product_peak": round(tf / MFMA_SPLIT_PEAK_TFLOPS, 4),     # what rounds 1-2 quoted as `frac` (every call on six products)
-                    "traffic": load_traffic("conv_split:%dx%d,interval=%d,%s" % (args.width, args.height, args.interval, args.dtype)),
+                    "traffic": load_traffic("conv_split:%dx%d,interval=%d,%s%s" % (args.width, args.height, args.interval, args.dtype,
+                                                                                  "" if args.clips == 1 else ",clips=%d" % args.clips)),
                     "launches": conv_n, "avg_us": round(conv_ms * 1e3 / conv_n, 2),
                     "algorithmic_flops_per_launch": round(conv_fl / max(conv_n, 1)),       # x launches / (avg_us x launches) = achieved
                     "algorithmic_bytes_per_launch": round(float(getattr(r, 'conv_bytes', 0.0)) / max(conv_n, 1)),

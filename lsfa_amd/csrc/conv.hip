@@ -312,11 +312,24 @@ static int plan_lab_from_env() {
   return e ? atoi(e) : -1;
 }
 
+// lab: LSFA_CONV_PLAN_LONGK="kernel,nt,st,slices" forces that plan on launches of >= 512 chunks of K only (feat_conv_3x3: 576) - an in-situ A/B of
+// one layer's plan inside a whole pass (tools/lab/key_batch_probe.py)
+struct LongKForce { int k, nt, st, s; };
+static LongKForce longk_from_env() {
+  LongKForce f = {0, 0, 0, 0};
+  const char* e = getenv("LSFA_CONV_PLAN_LONGK");
+  if (e) sscanf(e, "%d,%d,%d,%d", &f.k, &f.nt, &f.st, &f.s);
+  return f;
+}
+
 void ring_plan(SplitPlan& p, long P, int chunk_total, int Cout, int pieces) {
   static const int lab_env = plan_lab_from_env();
+  static const LongKForce longk = longk_from_env();
   const int lab = lab_env >= 0 ? lab_env : kPlanDefault;
   p.wv = 4;
-  const int f_nt = g_force_nt.load(), f_st = g_force_st.load(), f_s = g_force_slices.load(), f_k = g_force_kernel.load();
+  const bool lk = chunk_total >= 512 && (longk.k || longk.nt || longk.st || longk.s);
+  const int f_nt = lk ? longk.nt : g_force_nt.load(), f_st = lk ? longk.st : g_force_st.load(), f_s = lk ? longk.s : g_force_slices.load(),
+            f_k = lk ? longk.k : g_force_kernel.load();
   p.nx = (int)((P + convsplit::kWgPix - 1) / convsplit::kWgPix);
   // 128 x 128 tiles: long K with >= 512 output channels (r4, one image), or - maps of several images, the batched pipeline - wherever the
   // wider tiles alone still give the chip well over a wave of workgroups (profiles/r4/conv_ring_lab_batch3.txt: res4 conv3 44.1 -> 39.3 us,

@@ -403,14 +403,25 @@ void conv_ring_kernel(Args a, int nx, int ny, int nz) {
   float out_scale[NT];             // per column tile: 2^-(s_exp + w_exp of this lane's column), 1 unless PC == 2
 #pragma unroll
   for (int t = 0; t < NT; ++t) out_scale[t] = 1.f;
-  if (PC == 2 && !loader) {
-    const int s_exp = 13 - amax_exponent_asm(a.amax, g.lane, a.status);
-    a_scale = ldexpf(1.f, s_exp);
-    column_scales<NT>(a, s_exp, tile.y * (32 * NT), g.lane, out_scale);
+  // r6: the scales' loads leave FIRST and are waited for where the scale is needed (LSFA_SCALES_READY below): behind the geometry set-up and,
+  // in the mixed-role kernels, behind the prologue's copies - one round trip under cover instead of two in front of everything
+  ScaleRegs sr;
+  if (PC == 2 && !loader) scale_loads_issue<NT>(a, tile.y * (32 * NT), g.lane, sr);
+  // N_: vector-memory operations this wave has issued since (they return in order).  Then the input's activation table (AF), visible to every
+  // consumer after the first chunk's barrier (which an lgkmcnt(0) precedes)
+#ifdef LSFA_LAB_EARLY_SCALES      // lab A/B (tools/lab/build_variant.sh): r5's order - wait for the scales at once, in front of everything
+  constexpr bool kScalesEarly = true;
+#else
+  constexpr bool kScalesEarly = false;
+#endif
+#define LSFA_SCALES_READY(N_)                                                                                                   \
+  if (!kScalesEarly || (N_) < 0) {                                                                                              \
+    if (PC == 2) { scale_loads_wait<((N_) < 0 ? 0 : (N_))>(sr); a_scale = scale_finish<NT>(a, sr, g.lane, out_scale); }         \
+    if (AF) {                                                                                                                   \
+      for (int k = tid; k < a.Cin; k += 64 * WV) { T[k] = a.in_scale[k] * a_scale; T[kAffineMaxCin + k] = a.in_shift[k] * a_scale; } \
+    }                                                                                                                           \
   }
-  if (AF && !loader) {      // visible to every consumer after the first chunk's barrier (which an lgkmcnt(0) precedes)
-    for (int k = tid; k < a.Cin; k += 64 * WV) { T[k] = a.in_scale[k] * a_scale; T[kAffineMaxCin + k] = a.in_shift[k] * a_scale; }
-  }
+  if (kScalesEarly && !loader) LSFA_SCALES_READY(-1)
   g.H = a.H; g.W = a.W; g.Cin = a.Cin; g.lda = a.lda; g.kh = a.kh; g.kw = a.kw; g.stride = a.stride; g.dil = a.dil;
   g.k_order = taps > 1 ? a.k_order : 0;
   g.chunks_per_tap = a.Cin / kChunk;
@@ -470,6 +481,7 @@ void conv_ring_kernel(Args a, int nx, int ny, int nz) {
         }
         return;                 // the epilogue is the consumers'
       }
+      LSFA_SCALES_READY(0)
       int since = 0;
       for (int c = 0; c < nchunks; c += ST) {
         ring_consume_step_r4<NT, PC, ST, 0, AF>(R, g, acc, a_scale, c, T);
@@ -490,6 +502,7 @@ void conv_ring_kernel(Args a, int nx, int ny, int nz) {
       ring_prologue_r4<NT, PC, ST, 0>(R, a.x, wblock, g, wk, nchunks);
       if (ST > 2) ring_prologue_r4<NT, PC, ST, (ST > 2 ? 1 : 0)>(R, a.x, wblock, g, wk, nchunks);
       if (ST > 3) ring_prologue_r4<NT, PC, ST, (ST > 3 ? 2 : 0)>(R, a.x, wblock, g, wk, nchunks);
+      LSFA_SCALES_READY(0)      // (behind the prologue's copies: their count depends on nchunks, so everything is waited for - chunk 0 is needed next anyway)
       int since = 0;
       for (int c = 0; c < nchunks; c += ST) {
         ring_step_r4<NT, PC, ST, 0, AF>(R, a.x, wblock, g, wk, c, nchunks, acc, a_scale, T);
@@ -532,6 +545,9 @@ void conv_ring_kernel(Args a, int nx, int ny, int nz) {
     if (ST > 2) ring_prologue_uniform<NT, PC, ST, WV, (ST > 2 ? 1 : 0)>(R, a.x, wblock, g, wk, nchunks);
     if (ST > 3) ring_prologue_uniform<NT, PC, ST, WV, (ST > 3 ? 2 : 0)>(R, a.x, wblock, g, wk, nchunks);
     wait_vmcnt<(ST - 1) * RG::kDma>();
+    LSFA_SCALES_READY((ST - 1) * RG::kDma)      // (older than every copy: landed with A(0))
+  } else {
+    LSFA_SCALES_READY(0)                          // a consumer wave issues nothing else
   }
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       // AF: this wave's share of the table is written
   __builtin_amdgcn_s_barrier();                            // v-chunk -1 has landed
@@ -626,6 +642,8 @@ void conv_ring_kernel(Args a, int nx, int ny, int nz) {
   for (int t = 0; t < NT; ++t) m = max(m, tile_store_max(a, ro, tile.y * (32 * NT) + t * 32 + (lane & 31), acc[t]));
   publish_amax(m, a.amax_out, a.status, blockIdx.x * WV + g.wave);
 }
+
+#undef LSFA_SCALES_READY
 
 // weights (Cout, taps, Cin) fp32 -> fragment order, PC pieces.  One thread per (fragment, lane): 8 values.
 // out index: ((((g * col_tiles + t) * 2 + s) * PC + piece) * 64 + lane) uint4, g = tap * (Cin/32) + chunk; PC = 2: values w * 2^w_exp

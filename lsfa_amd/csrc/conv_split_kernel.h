@@ -316,6 +316,69 @@ __device__ __forceinline__ void column_scales(const Args& a, int s_exp, int ch0,
 
 template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
+// r6: the two round trips at the head of every two-piece launch (the 256 amax slots, then the per-channel weight scales) as ONE, issued first
+// thing and waited for only when the scale is needed - behind the geometry set-up and, in the mixed-role kernels, behind the prologue's
+// copies, whose latency then covers it.  scale_loads_issue: the loads, no wait.  scale_loads_wait<N>: `s_waitcnt vmcnt(N)` with every
+// destination register as an in/out operand, so that no use of them can be scheduled above it (N = vector-memory operations the wave has
+// issued SINCE: they return in order, so "at most N outstanding" means these have landed).  scale_finish: the arithmetic of
+// amax_exponent_asm + column_scales.  Same values, same bits.
+struct ScaleRegs { uint32_t m0, m1, m2, m3; float w0, w1, w2, w3; };
+
+template <int NT>
+__device__ __forceinline__ void scale_loads_issue(const Args& a, int ch0, int lane, ScaleRegs& r) {
+  static_assert(kAmaxSlots == 256, "four slots per lane");
+  static_assert(NT == 2 || NT == 4, "two or four column tiles per wave");
+  const float* p = a.amax + lane;
+  asm volatile("global_load_dword %0, %4, off\n\t"
+               "global_load_dword %1, %4, off offset:256\n\t"
+               "global_load_dword %2, %4, off offset:512\n\t"
+               "global_load_dword %3, %4, off offset:768"
+               : "=&v"(r.m0), "=&v"(r.m1), "=&v"(r.m2), "=&v"(r.m3) : "v"(p) : "memory");
+  r.w0 = r.w1 = r.w2 = r.w3 = 1.f;
+  if (a.wscale) {
+    const float* q = a.wscale + ch0 + (lane & 31);
+    if (NT == 2) {
+      asm volatile("global_load_dword %0, %2, off\n\t"
+                   "global_load_dword %1, %2, off offset:128"
+                   : "=&v"(r.w0), "=&v"(r.w1) : "v"(q) : "memory");
+    } else {
+      asm volatile("global_load_dword %0, %4, off\n\t"
+                   "global_load_dword %1, %4, off offset:128\n\t"
+                   "global_load_dword %2, %4, off offset:256\n\t"
+                   "global_load_dword %3, %4, off offset:384"
+                   : "=&v"(r.w0), "=&v"(r.w1), "=&v"(r.w2), "=&v"(r.w3) : "v"(q) : "memory");
+    }
+  }
+}
+
+template <int N>
+__device__ __forceinline__ void scale_loads_wait(ScaleRegs& r) {
+  asm volatile("s_waitcnt vmcnt(%8)"
+               : "+v"(r.m0), "+v"(r.m1), "+v"(r.m2), "+v"(r.m3), "+v"(r.w0), "+v"(r.w1), "+v"(r.w2), "+v"(r.w3) : "n"(N) : "memory");
+}
+
+// -> a_scale = 2^s_exp (the map's maximum into [2^13, 2^14)), os[t] = 2^-(s_exp + w_exp of this lane's column of tile t)
+template <int NT>
+__device__ __forceinline__ float scale_finish(const Args& a, const ScaleRegs& r, int lane, float (&os)[NT]) {
+  uint32_t m = max(max(r.m0 & 0x7FFFFFFFu, r.m1 & 0x7FFFFFFFu), max(r.m2 & 0x7FFFFFFFu, r.m3 & 0x7FFFFFFFu));
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) m = max(m, (uint32_t)__shfl_xor((int)m, d, 64));
+  const int e = (int)((m >> 23) & 255u);
+  if (e == 255 && a.status && lane == 0) atomicOr(a.status, 2u);      // the INPUT map already holds inf / NaN
+  const int s_exp = 13 - ((e == 0 || e == 255) ? 0 : __builtin_amdgcn_readfirstlane(e - 127));
+  if (!a.wscale) {
+    const float v = ldexpf(1.f, -(s_exp + a.w_exp));
+#pragma unroll
+    for (int t = 0; t < NT; ++t) os[t] = v;
+  } else {
+    const float inv = ldexpf(1.f, -s_exp);
+    const float w[4] = {r.w0, r.w1, r.w2, r.w3};
+#pragma unroll
+    for (int t = 0; t < NT; ++t) os[t] = w[t] * inv;
+  }
+  return ldexpf(1.f, s_exp);
+}
+
 // the fp16 form's scale from the kAmaxSlots partial maxima (floats or bit patterns of |x|: the same thing for non-negative values),
 // read by inline assembly with its own wait so that no compiler-visible vector load is pending when a DMA ring starts.
 // -> floor(log2(max)), 0 for an all-zero map; an inf / NaN maximum raises bit 1 of *status

@@ -280,6 +280,9 @@ static __global__ __launch_bounds__(64) void nms_sweep_kernel(const uint64_t* __
                                                               float* __restrict__ rois, float* __restrict__ scores) {
   __shared__ uint64_t remv[kSweepMaxBlocks];
   __shared__ int kept_pos[kSweepLazyMax];
+#ifdef LSFA_SWEEP_PRIO      // lab (tools/lab/build_variant.sh): the one wave of a sweep is a latency chain; under the pipeline's contention it takes 67 us for 12 us of work
+  __builtin_amdgcn_s_setprio(LSFA_SWEEP_PRIO);
+#endif
   const int img = blockIdx.x;
   const uint64_t* mask = mask_all + (size_t)img * n * col_blocks;
   const uint64_t* diagT = diagT_all + (size_t)img * n;

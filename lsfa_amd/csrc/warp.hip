@@ -136,3 +136,135 @@ extern "C" int lsfa_warp_bilinear(const float* feat, int feat_n, const float* fl
   LSFA_LAUNCH_CHECK("lsfa_warp_bilinear");
   return LSFA_OK;
 }
+
+// ---- r6: the non-key path's warp on CHANNELS-LAST maps --------------------------------------------------------------------------------------
+// On a non-key frame the warped feature is read by two 1x1 convolutions only (the RPN head on channels [0, 512), the R-FCN score maps on
+// [512, 1024): resnet_v1_101_flownet_rfcn.py:479-499) - GEMMs over the channel axis, i.e. consumers of channels-last rows.  With the NCHW
+// operator layout every pass carried a transposing copy of half the map in front of the R-FCN convolution (lsfa_nchw_to_nhwc: 32 us per
+// nine-frame segment, 2.2 % of frames/s, profiles/r6/tail_ablation.txt).  Here the key feature is turned channels-last ONCE per pass (one map
+// instead of one per frame), the small net's fuse convolution writes its natural layout, and the warp reads and writes (pixel, channel) rows:
+// thread t owns the channel quad 4t .. 4t+3 (C = 1024: one quad per thread of a 256-thread workgroup), a workgroup walks a run of pixels,
+// every access is a 4 KB row (256 threads x float4).  The arithmetic is lsfa_warp_bilinear's general path, operation for operation (taps
+// outside the map contribute 0 * w; then + rnet_conv0(res_diff) + add): the two layouts give the same bits (tests/test_hip_ops.py).
+// amax_out (or NULL): 256 zeroed slots that receive max|out| - the next convolution's scale, as the convolutions' own epilogues leave it.
+namespace {
+__device__ __attribute__((aligned(16))) float4 g_warp_zero4 = {0.f, 0.f, 0.f, 0.f};      // (not const: a constant-address-space pointer in the select below turns the loads into flat ones)
+
+template <bool HAS_ADD, bool HAS_RES>
+__global__ __launch_bounds__(256) void warp_cl_kernel(const float* __restrict__ feat, int feat_n, const float* __restrict__ flow, int N, int C,
+                                                      int H, int W, const float* __restrict__ add, const float* __restrict__ res, int res_c,
+                                                      const float* __restrict__ res_w, const float* __restrict__ res_b,
+                                                      float* __restrict__ out, unsigned* __restrict__ amax_out, int pix_per_wg) {
+  using namespace lsfa::warp;
+  const int HW = H * W, C4 = C >> 2;
+  const int P = N * HW;                                   // (< 2^31: checked by the host)
+  const int p_begin = blockIdx.x * pix_per_wg;
+  const int p_end = min(p_begin + pix_per_wg, P);
+  const float half_w = (float)((W - 1) / 2.0), half_h = (float)((H - 1) / 2.0);
+  float mx = 0.f;
+  for (int q = threadIdx.x; q < C4; q += 256) {
+    float rw[4][kResMax], rb[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      rb[j] = HAS_RES ? res_b[4 * q + j] : 0.f;
+#pragma unroll
+      for (int k = 0; k < kResMax; ++k) rw[j][k] = (HAS_RES && k < res_c) ? res_w[(size_t)(4 * q + j) * res_c + k] : 0.f;
+    }
+    int n = p_begin / HW;
+    int r = p_begin - n * HW;
+    int y = r / W, x = r - y * W;
+    for (int p = p_begin; p < p_end; ++p) {
+      const float fx = flow[((size_t)n * 2 + 0) * HW + r], fy = flow[((size_t)n * 2 + 1) * HW + r];
+      const float gx = ((float)x + fx) / half_w - 1.0f;
+      const float gy = ((float)y + fy) / half_h - 1.0f;
+      const float x_real = (gx + 1.0f) * (float)(W - 1) / 2.0f;
+      const float y_real = (gy + 1.0f) * (float)(H - 1) / 2.0f;
+      const float fx0 = floorf(x_real), fy0 = floorf(y_real);
+      const int x0 = (int)fminf(fmaxf(fx0, -2.0f), (float)W);       // (clamped before the conversion: outside the map either way)
+      const int y0 = (int)fminf(fmaxf(fy0, -2.0f), (float)H);
+      const float wx0 = 1.0f - (x_real - fx0), wy0 = 1.0f - (y_real - fy0);
+      const float wx1 = 1.0f - wx0, wy1 = 1.0f - wy0;
+      const bool vx0 = (x0 >= 0 && x0 <= W - 1), vx1 = (x0 + 1 >= 0 && x0 + 1 <= W - 1);
+      const bool vy0 = (y0 >= 0 && y0 <= H - 1), vy1 = (y0 + 1 >= 0 && y0 + 1 <= H - 1);
+      const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
+      const float4* fb = reinterpret_cast<const float4*>(feat + (size_t)(n % feat_n) * HW * C) + q;
+      const long off = (long)y0 * W + x0;
+      // (every thread of the workgroup works on the same pixel: the four branches are uniform)
+      // a tap outside the map reads a block of zeros (a select between two GLOBAL addresses: `cond ? load : 0` made hipcc spill a zero to
+      // scratch and load through a flat pointer)
+      const float4 tl = *((vx0 && vy0) ? fb + (size_t)off * C4 : &g_warp_zero4);
+      const float4 tr = *((vx1 && vy0) ? fb + (size_t)(off + 1) * C4 : &g_warp_zero4);
+      const float4 bl = *((vx0 && vy1) ? fb + (size_t)(off + W) * C4 : &g_warp_zero4);
+      const float4 br = *((vx1 && vy1) ? fb + (size_t)(off + W + 1) * C4 : &g_warp_zero4);
+      float4 a4 = zero4;
+      if (HAS_ADD) a4 = reinterpret_cast<const float4*>(add)[(size_t)p * C4 + q];
+      // (named scalars, not arrays: indexed arrays ended up in scratch memory here)
+      const float* rp = res + (size_t)n * res_c * HW + r;
+      const float rv0 = HAS_RES ? rp[0] : 0.f, rv1 = (HAS_RES && res_c > 1) ? rp[HW] : 0.f;
+      const float rv2 = (HAS_RES && res_c > 2) ? rp[2 * (size_t)HW] : 0.f, rv3 = (HAS_RES && res_c > 3) ? rp[3 * (size_t)HW] : 0.f;
+      // one component: the oracle's expression, then the residual's 1x1 convolution and the small net's feature
+#define LSFA_WARP_CL_ONE(J_, TL_, TR_, BL_, BR_, A_, O_)                                                                     \
+      float O_ = TL_ * wy0 * wx0 + TR_ * wy0 * wx1 + BL_ * wy1 * wx0 + BR_ * wy1 * wx1;                                      \
+      if (HAS_RES) {                                                                                                         \
+        float qv = rw[J_][0] * rv0;                                                                                          \
+        if (res_c > 1) qv = qv + rw[J_][1] * rv1;                                                                            \
+        if (res_c > 2) qv = qv + rw[J_][2] * rv2;                                                                            \
+        if (res_c > 3) qv = qv + rw[J_][3] * rv3;                                                                            \
+        qv = qv + rb[J_];                                                                                                    \
+        O_ = O_ + qv;                                                                                                        \
+      }                                                                                                                      \
+      if (HAS_ADD) O_ = O_ + A_;                                                                                             \
+      mx = fmaxf(mx, fabsf(O_));
+      LSFA_WARP_CL_ONE(0, tl.x, tr.x, bl.x, br.x, a4.x, o0)
+      LSFA_WARP_CL_ONE(1, tl.y, tr.y, bl.y, br.y, a4.y, o1)
+      LSFA_WARP_CL_ONE(2, tl.z, tr.z, bl.z, br.z, a4.z, o2)
+      LSFA_WARP_CL_ONE(3, tl.w, tr.w, bl.w, br.w, a4.w, o3)
+#undef LSFA_WARP_CL_ONE
+      reinterpret_cast<float4*>(out)[(size_t)p * C4 + q] = make_float4(o0, o1, o2, o3);
+      if (++x == W) { x = 0; if (++y == H) { y = 0; ++n; } }
+      if (++r == HW) r = 0;
+    }
+  }
+  if (amax_out) {
+    uint32_t m = __float_as_uint(mx);       // non-negative, or NaN bits (fmaxf drops a NaN: a non-finite output shows in the consumer's own status)
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) m = max(m, (uint32_t)__shfl_xor((int)m, d, 64));
+    if ((threadIdx.x & 63) == 0) atomicMax(amax_out + ((blockIdx.x * 4 + (threadIdx.x >> 6)) & 255), m);
+  }
+}
+}  // namespace
+
+extern "C" int lsfa_warp_bilinear_cl(const float* feat_cl, int feat_n, const float* flow, int N, int C, int H, int W, const float* add_cl,
+                                     const float* res, int res_c, const float* res_w, const float* res_b, float* out_cl, unsigned* amax_out,
+                                     void* stream) {
+  using namespace lsfa;
+  LSFA_REQUIRE(feat_cl && flow && out_cl, "lsfa_warp_bilinear_cl: feat, flow and out must be non-NULL");
+  LSFA_REQUIRE(N > 0 && C > 0 && C % 4 == 0 && H > 1 && W > 1, "lsfa_warp_bilinear_cl: bad shape N=%d C=%d (a multiple of 4) H=%d W=%d", N, C, H, W);
+  LSFA_REQUIRE(feat_n >= 1 && N % feat_n == 0, "lsfa_warp_bilinear_cl: feat batch %d must divide N=%d", feat_n, N);
+  LSFA_REQUIRE(aligned(feat_cl, 16) && aligned(add_cl, 16) && aligned(out_cl, 16), "lsfa_warp_bilinear_cl: maps must be 16-byte aligned");
+  if (res) {
+    LSFA_REQUIRE(res_w && res_b, "lsfa_warp_bilinear_cl: res given without res_w/res_b");
+    if (res_c < 1 || res_c > warp::kResMax) {
+      set_error("lsfa_warp_bilinear_cl: res_c=%d not in [1,%d]", res_c, warp::kResMax);
+      return LSFA_ENOTSUP;
+    }
+  }
+  hipStream_t s = (hipStream_t)stream;
+  const long P = (long)N * H * W;
+  LSFA_REQUIRE(P * C < (1L << 31), "lsfa_warp_bilinear_cl: map of 2^31 elements or more");
+  long per = P / 1536;                     // ~6 workgroups per CU; a run of pixels amortises the quad's residual weights
+  if (per < 1) per = 1;
+  if (per > 16) per = 16;
+  const dim3 grid((unsigned)((P + per - 1) / per));
+  ProfScope prof(LSFA_OP_WARP, s);
+#define LSFA_WARP_CL(A_, R_) hipLaunchKernelGGL((warp_cl_kernel<A_, R_>), grid, dim3(256), 0, s, feat_cl, feat_n, flow, N, C, H, W, add_cl, res, res_c, \
+                                                res_w, res_b, out_cl, amax_out, (int)per)
+  if (add_cl && res) LSFA_WARP_CL(true, true);
+  else if (add_cl) LSFA_WARP_CL(true, false);
+  else if (res) LSFA_WARP_CL(false, true);
+  else LSFA_WARP_CL(false, false);
+#undef LSFA_WARP_CL
+  LSFA_LAUNCH_CHECK("lsfa_warp_bilinear_cl");
+  return LSFA_OK;
+}
+

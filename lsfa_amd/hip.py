@@ -178,6 +178,29 @@ def warp_bilinear(feat, flow, mul=None, add=None, res=None, res_w=None, res_b=No
     return out
 
 
+@_on_tensor_device
+def warp_bilinear_cl(feat_cl, flow, add_cl=None, res=None, res_w=None, res_b=None, out=None, amax_out=None):
+    """lsfa_warp_bilinear_cl: the non-key path's warp on channels-last maps.  feat_cl (feat_n, H, W, C), flow (N, 2, H, W), add_cl (N, H, W, C),
+    res (N, res_c, H, W) -> (N, H, W, C); the bits of warp_bilinear on the transposed maps.  amax_out: a zeroed row of amax_slots() that
+    receives max|out| (the scale of the convolutions that read the result)."""
+    feat_cl, flow = _f32c(feat_cl, "feat_cl"), _f32c(flow, "flow")
+    add_cl, res = _f32c(add_cl, "add_cl"), _f32c(res, "res")
+    N, _, H, W = flow.shape
+    feat_n, C = feat_cl.shape[0], feat_cl.shape[3]
+    if tuple(feat_cl.shape[1:3]) != (H, W) or (add_cl is not None and tuple(add_cl.shape) != (N, H, W, C)):
+        raise LsfaError("warp_bilinear_cl: feat_cl %s / add_cl %s do not match a (%d, 2, %d, %d) flow" % (
+            tuple(feat_cl.shape), None if add_cl is None else tuple(add_cl.shape), N, H, W))
+    res_c = 0
+    if res is not None:
+        res_w, res_b = _f32c(res_w, "res_w").reshape(C, -1), _f32c(res_b, "res_b")
+        res_c = res.shape[1]
+    if out is None:
+        out = torch.empty((N, H, W, C), device=feat_cl.device, dtype=torch.float32)
+    _check(lib().lsfa_warp_bilinear_cl(_ptr(feat_cl), _ci(feat_n), _ptr(flow), _ci(N), _ci(C), _ci(H), _ci(W), _ptr(add_cl), _ptr(res), _ci(res_c),
+                                       _ptr(res_w), _ptr(res_b), _ptr(out), _ptr(amax_out), _stream()), "lsfa_warp_bilinear_cl")
+    return out
+
+
 def warp_set_variant(variant):
     """'auto' | 'gather' | 'staged': lsfa_warp_set_variant (process-wide kernel choice of warp_bilinear; same results.  'staged'
     makes shapes the LDS-staged kernel does not take an error instead of falling back)."""
@@ -275,12 +298,16 @@ def proposal_set_plan(plan):
 
 # Ablation switches (tools/lab/tail_ablation.sh): LSFA_LAB_SKIP=tail,copy,nhwc drops launches from every frame so that
 # bench.py's frames/s with and without them says what they cost the PIPELINE (not what they take alone):
-#   tail  the Proposal's suppression stage (nms_mask + nms_sweep), the PSROI head, the detection post-processing (det_class + det_cap)
+#   tail  the Proposal's suppression stage (nms_mask + nms_sweep: `nms`), the PSROI head (`head`), the detection post-processing (det_class +
+#         det_cap: `det`); each part also by its own name
 #   copy  lsfa_copy_many's staging copies of frames / motion vectors / residuals into a graph's static buffers (after each buffer's first fill)
 #   nhwc  lsfa_nchw_to_nhwc in front of the R-FCN / Nq convolutions (after each output's first fill)
 # Results are garbage then; bench.py labels the line, reports no parity and does not read the status word.  Never set in a product run.
 LAB_SKIP = set(v for v in os.environ.get('LSFA_LAB_SKIP', '').split(',') if v)
 LAB_SKIP_TAIL = 'tail' in LAB_SKIP
+LAB_SKIP_NMS = LAB_SKIP_TAIL or 'nms' in LAB_SKIP        # ... or one part of the tail: nms | head | det
+LAB_SKIP_HEAD = LAB_SKIP_TAIL or 'head' in LAB_SKIP
+LAB_SKIP_DET = LAB_SKIP_TAIL or 'det' in LAB_SKIP
 _lab_filled = set()
 
 
@@ -349,7 +376,7 @@ def det_postprocess(rois, deltas, probs, im_h, im_w, scale, score_thresh=1e-4, n
         keep_idx = torch.full((ncls, R), -1, dtype=torch.int32, device=rois.device)
     else:
         dets, counts, keep_idx = out
-    if LAB_SKIP_TAIL:
+    if LAB_SKIP_DET:
         return dets, counts, keep_idx
     _check(lib().lsfa_det_postprocess(_ptr(rois), _ptr(deltas), _ptr(probs), _ci(R), _ci(ncls), _ci(nreg),
                                       _ci(int(class_agnostic)), _cd(im_h), _cd(im_w), _cd(scale), _cd(score_thresh),
@@ -383,7 +410,7 @@ def det_postprocess_batch(rois, deltas, probs, B, im_h, im_w, scale, out, score_
     if tuple(dets.shape) != (B, ncls, R, 5) or tuple(counts.shape) != (B, ncls) or not (dets.is_contiguous() and counts.is_contiguous() and
                                                                                        keep_idx.is_contiguous()):
         raise LsfaError("det_postprocess_batch: out must be contiguous (B, ncls, R, 5) / (B, ncls) / (B, ncls, R) buffers")
-    if LAB_SKIP_TAIL:
+    if LAB_SKIP_DET:
         return dets, counts, keep_idx
     _check(lib().lsfa_det_postprocess_batch(_ptr(rois), _ptr(deltas), _ptr(probs), _ci(B), _ci(R), _ci(ncls), _ci(nreg),
                                             _ci(int(class_agnostic)), _cd(im_h), _cd(im_w), _cd(scale), _cd(score_thresh),
@@ -803,7 +830,7 @@ def rfcn_head_ps_ld(ps_map, cell_ld, rois, H, W, ncls, nbox, spatial_scale=0.062
     N, R = ps_map.shape[0], rois.shape[0]
     cls_prob = torch.empty((R, ncls), device=rois.device, dtype=torch.float32)
     bbox_pred = torch.empty((R, nbox), device=rois.device, dtype=torch.float32)
-    if LAB_SKIP_TAIL:
+    if LAB_SKIP_HEAD:
         return cls_prob, bbox_pred
     with torch.cuda.device(ps_map.device):
         _check(lib().lsfa_rfcn_head_ps_ld_fwd(_ptr(ps_map), _ci(cell_ld), _ptr(rois), _ci(N), _ci(H), _ci(W), _ci(R), _ci(ncls), _ci(nbox),
@@ -964,11 +991,11 @@ def check_status(status):
 
 
 def _conv_launch(who, x, lda, N, H, W, cin, sw, bias, stride, pad_h, pad_w, dil, act, nchw, residual, y_ptr, ldy, out2, scale2, shift2,
-                 amax_in, amax_out, status, grid, view, prof_tag, device, x_nchw=False, in_scale=None, in_shift=None):
+                 amax_in, amax_out, status, grid, view, prof_tag, device, x_nchw=False, in_scale=None, in_shift=None, x_offset=0):
     if sw.pieces == 2 and amax_in is None:
         raise LsfaError("%s: a two-piece (fp16) weight needs amax_in" % who)
     d = ConvDesc()
-    d.x, d.lda, d.N, d.H, d.W, d.Cin = x.data_ptr(), lda, N, H, W, cin
+    d.x, d.lda, d.N, d.H, d.W, d.Cin = x.data_ptr() + x_offset, lda, N, H, W, cin
     d.wfrag, d.pieces, d.w_exp, d.amax_in = sw.frag.data_ptr(), sw.pieces, sw.w_exp, (amax_in.data_ptr() if amax_in is not None else None)
     d.bias, d.Cout, d.kh, d.kw, d.stride, d.pad_h, d.pad_w, d.dil = (bias.data_ptr() if bias is not None else None), sw.cout, sw.kh, sw.kw, stride, pad_h, pad_w, dil
     d.act, d.y_nchw, d.residual, d.y, d.ldy = int(act), int(nchw), (residual.data_ptr() if residual is not None else None), y_ptr, ldy
@@ -1077,9 +1104,10 @@ def conv_split_h(x, swh, bias=None, stride=1, pad=0, dil=1, act=0, out=None, nch
 
 @_on_tensor_device
 def conv_split_view(x, sw, bias, out, stride=1, pad=(0, 0), dil=1, act=0, cin=None, c0=0, grid=None, place=None, amax_in=None,
-                    amax_out=None, status=None):
+                    amax_out=None, status=None, cin0=0):
     """lsfa_conv_fwd between VIEWS of wider channels-last maps.
-    x    (N, H, W, L) contiguous fp32, the convolution reads channels [0, cin) of it (cin = sw.cin by default, L >= cin);
+    x    (N, H, W, L) contiguous fp32, the convolution reads channels [cin0, cin0 + cin) of it (cin = sw.cin by default, L >= cin0 + cin;
+         cin0 a multiple of 4: the operand pointer stays 16-byte aligned);
     out  (N, Hout, Wout, Lout) contiguous fp32: the result goes to channels [c0, c0 + sw.cout) of it;
     grid (Ho, Wo): the output grid of this launch when smaller than the convolution's; place (y0, x0, sy, sx): output pixel
          (oy, ox) is written to out[:, y0 + oy*sy, x0 + ox*sx] (default: out[:, oy, ox]) - a phase of a transposed convolution;
@@ -1089,8 +1117,8 @@ def conv_split_view(x, sw, bias, out, stride=1, pad=(0, 0), dil=1, act=0, cin=No
         raise LsfaError("conv_split_view: out must be a contiguous float32 (N, H, W, C) tensor")
     N, H, W, L = x.shape
     cin = sw.cin if cin is None else cin
-    if cin != sw.cin or L < cin:
-        raise LsfaError("conv_split_view: the weight has %d input channels, x offers %d (of %d)" % (sw.cin, cin, L))
+    if cin != sw.cin or L < cin0 + cin or cin0 < 0 or cin0 % 4:
+        raise LsfaError("conv_split_view: the weight has %d input channels, x offers [%d, %d) (of %d)" % (sw.cin, cin0, cin0 + cin, L))
     if c0 < 0 or c0 + sw.cout > out.shape[3] or out.shape[0] != N:
         raise LsfaError("conv_split_view: channels [%d, %d) do not fit out %s" % (c0, c0 + sw.cout, tuple(out.shape)))
     kh, kw = sw.kh, sw.kw
@@ -1103,7 +1131,7 @@ def conv_split_view(x, sw, bias, out, stride=1, pad=(0, 0), dil=1, act=0, cin=No
     if sw.pieces == 0:      # the exact-fp32 reference mode (_conv_exact): plain output grids only (the transposed convolutions keep three bf16 pieces)
         if grid is not None or place is not None or (Ho, Wo) != (Hout, Wout):
             raise LsfaError("conv_split_view: the exact-fp32 mode takes whole output grids only")
-        xin = x if L == cin else x[..., :cin].contiguous()
+        xin = x if (L == cin and cin0 == 0) else x[..., cin0:cin0 + cin].contiguous()
         y = _conv_exact(xin, sw, bias, stride, pad[0], dil, act, None, None, None, None, None, False, False, None, None) if pad[0] == pad[1] else None
         if y is None:
             raise LsfaError("conv_split_view: the exact-fp32 mode needs pad_h == pad_w")
@@ -1115,7 +1143,7 @@ def conv_split_view(x, sw, bias, out, stride=1, pad=(0, 0), dil=1, act=0, cin=No
     view = place is not None or (Ho, Wo) != (Hout, Wout)
     _count_conv(N, Ho, Wo, sw.real_cout, sw.real_cin, kh, kw, sw.pieces)
     _conv_launch("lsfa_conv_fwd (view)", x, L, N, H, W, cin, sw, bias, stride, pad[0], pad[1], dil, act, False, None, first, Lout, None, None,
-                 None, amax_in, amax_out, status, (Ho, Wo), (Hout if view else 0, Wout, sy, sx), 1, x.device)
+                 None, amax_in, amax_out, status, (Ho, Wo), (Hout if view else 0, Wout, sy, sx), 1, x.device, x_offset=4 * cin0)
     return out
 
 

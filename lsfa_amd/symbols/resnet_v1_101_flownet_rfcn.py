@@ -253,6 +253,9 @@ class _ResNetWeights(object):
             self.bn1 = (dev(s), dev(t))
 
 
+CUR_CHANNELS_LAST = _os.environ.get('LSFA_CUR_NCHW') != '1'
+
+
 class _Slots(object):
     """amax_out slot rows of one section of a frame: a fresh zeroed (rows, 256) block per call (inside a hipGraph capture that
     is graph-private memory, so graphs replayed side by side - the non-key lanes - never share slots)."""
@@ -708,18 +711,61 @@ class Executor(object):
         return {'choose_feat_output': conv_feat, 'rois_output': rois, 'cls_prob_reshape_output': cls_prob,
                 'bbox_pred_reshape_output': bbox_pred}
 
-    def small_net_feature(self, data):
+    def small_net_feature(self, data, nchw=True):
         """fuse_small_net's image branch (:209-236): avgpool 4x4 -> small_net_ stem + stage 1 ->
-        fuse_reduce_add (3x3 256 -> 1024, written NCHW: the warp kernel's `add` operand).  It depends on the frame image only, so a
-        caller may compute it ahead of the rest of the frame (lsfa_amd/core/graphs.py overlaps it with the previous frame's tail)."""
+        fuse_reduce_add (3x3 256 -> 1024, written NCHW: the warp kernel's `add` operand; nchw=False: channels-last, the operand of
+        lsfa_warp_bilinear_cl).  It depends on the frame image only, so a caller may compute it ahead of the rest of the frame
+        (lsfa_amd/core/graphs.py overlaps it with the previous frame's tail)."""
         with torch.no_grad():
             img = hip.avgpool_nchw(data, 4)
             s, am = self._resnet(img, self.small, 1, 'small')
-            return self._conv(s, self.fuse_w, self.fuse_b, 1, 1, 1, amax_in=am, nchw=True)
+            return self._conv(s, self.fuse_w, self.fuse_b, 1, 1, 1, amax_in=am, nchw=nchw)
+
+    def _forward_cur_cl(self, d):
+        """The non-key frame on channels-last maps (r6): the warped feature is read by two 1x1 convolutions only - GEMMs over the channel axis -
+        so it is produced as (pixel, channel) rows: the key feature turned channels-last once per PASS (not half a map per frame in front of
+        the R-FCN convolution), the small net's fuse convolution in its natural layout, lsfa_warp_bilinear_cl (the same bits as the NCHW
+        kernel, + the maximum the R-FCN convolution's scale needs).  `conv_feat` in the outputs is the NCHW view of the same memory."""
+        S = self._slots['heads'].begin()
+        feat_cl = hip.nchw_to_nhwc(d['feat_key'])
+        add_cl = self.small_net_feature(d['data'], nchw=False)
+        self._tap('small_feat', add_cl.permute(0, 3, 1, 2))
+        am = S.new()
+        conv_cl = hip.warp_bilinear_cl(feat_cl, d['motion_vector'], add_cl=add_cl, res=d['res_diff'], res_w=self.rnet_w, res_b=self.rnet_b,
+                                       amax_out=am)
+        rois, cls_prob, bbox_pred = self._heads_cl(conv_cl, am, d['im_info'])
+        return {'data': d['data'], 'data_key': d.get('data_key'), 'data_key_old': d.get('data_key_old'),
+                'feat_key_old': d.get('feat_key_old'), 'rois_output': rois, 'cls_prob_reshape_output': cls_prob,
+                'bbox_pred_reshape_output': bbox_pred, 'conv_feat': conv_cl.permute(0, 3, 1, 2)}
+
+    def _heads_cl(self, conv_cl, am, im_info):
+        """_heads on a channels-last feature (N, H, W, 1024) whose maximum sits in `am`: both convolutions read their 512 channels in place."""
+        cfg = self.cfg
+        A = cfg.network.NUM_ANCHORS
+        n, h, w, _ = conv_cl.shape
+        logits = torch.empty((n, h, w, self.rpn_sw.cout), device=conv_cl.device, dtype=torch.float32)
+        hip.conv_split_view(conv_cl, self.rpn_sw, self.rpn_b, logits, cin=512, amax_in=am, status=self.status)
+        cls_prob, rpn_bbox = hip.rpn_softmax_split(logits, A)
+        rois = self.proposal(cls_prob, rpn_bbox, im_info)
+        D = self.ncls + self.nbox
+        ps = torch.empty((n, h, w, self.rfcn_sw.cout), device=conv_cl.device, dtype=torch.float32)
+        hip.conv_split_view(conv_cl, self.rfcn_sw, self.rfcn_b_ps, ps, cin=512, cin0=512, amax_in=am, status=self.status)
+        if self.taps is not None:
+            nchw = ps[..., :49 * D].reshape(n, h * w, 49, D).permute(0, 3, 2, 1).reshape(n, D * 49, h, w)
+            self.taps.update(rpn_cls_prob=cls_prob, rpn_bbox_pred=rpn_bbox, cls_map=nchw[:, :self.n_cls_ch],
+                             box_map=nchw[:, self.n_cls_ch:])
+        cls_p, bbox = hip.rfcn_head_ps_ld(ps, self.ps_ld, rois, h, w, self.ncls, self.nbox, 0.0625, 7, 7)
+        B = cfg.TEST.BATCH_IMAGES
+        return rois, cls_p.view(B, -1, cls_p.shape[1]), bbox.view(B, -1, bbox.shape[1])
 
     def _forward_cur(self, d):
         cfg = self.cfg
         add = d.get('small_feat')          # precomputed by the caller, else computed here
+        # r6: the whole non-key frame on channels-last maps (no transposing copy in front of the R-FCN convolution) whenever nothing forces the
+        # operator layout: the small net's feature is computed here (not handed over NCHW), C is a multiple of 4, no exact-fp32 reference mode.
+        # LSFA_CUR_NCHW=1 keeps the NCHW form (A/B; it is also what the key frames and the batch test symbol run).
+        if add is None and cfg.network.add_small_net and CUR_CHANNELS_LAST and self.pieces != 0 and d['feat_key'].shape[1] % 4 == 0:
+            return self._forward_cur_cl(d)
         if add is None and cfg.network.add_small_net:
             add = self.small_net_feature(d['data'])
         self._tap('small_feat', add)

@@ -161,6 +161,33 @@ def test_warp_cur_path_fused_epilogue(hip, hw):
     np.testing.assert_array_equal(got, want)
 
 
+@pytest.mark.parametrize("shape", [(1, 1, 1024, 38, 63), (6, 2, 1024, 38, 63), (3, 1, 24, 12, 20), (2, 2, 512, 9, 7)])
+def test_warp_channels_last_equals_the_operator_layout(hip, shape):
+    """r6 (lsfa_warp_bilinear_cl): the non-key path's warp on channels-last maps - key feature (feat_n, H, W, C), small-net feature and output
+    (N, H, W, C) - gives the ORACLE's bits, transposed; with and without the residual / add operands, feat_n dividing N (lock-step clips),
+    flows that leave the map (border taps contribute 0), and max|out| in the amax slots."""
+    N, feat_n, C, H, W = shape
+    rs = np.random.RandomState(N * 7 + C)
+    feat = rs.randn(feat_n, C, H, W).astype(np.float32)
+    flow = smooth_flow(rs, N, H, W, 3.5)
+    flow[:, :, 0, :] -= 4.0                                          # the first row samples above the map
+    res = (4 * rs.randn(N, 3, H, W)).astype(np.float32)
+    res_w = (0.01 * rs.randn(C, 3, 1, 1)).astype(np.float32)
+    res_b = (0.01 * rs.randn(C)).astype(np.float32)
+    add = rs.randn(N, C, H, W).astype(np.float32)
+    cl = lambda a: t(np.ascontiguousarray(a.transpose(0, 2, 3, 1)))
+    feats = np.concatenate([feat] * (N // feat_n), 0) if feat_n > 1 else feat      # map n samples feature n mod feat_n
+    want = oracle.warp_bilinear(feats, flow, add=add, res=res, res_w=res_w, res_b=res_b)
+    slots = hip.amax_slots(1, DEV)[0]
+    got = hip.warp_bilinear_cl(cl(feat), t(flow), add_cl=cl(add), res=t(res), res_w=t(res_w), res_b=t(res_b), amax_out=slots)
+    np.testing.assert_array_equal(got.permute(0, 3, 1, 2).cpu().numpy(), want)
+    assert slots.view(torch.float32).max().item() == float(np.abs(want).max())
+    want_plain = oracle.warp_bilinear(feats, flow)
+    np.testing.assert_array_equal(hip.warp_bilinear_cl(cl(feat), t(flow)).permute(0, 3, 1, 2).cpu().numpy(), want_plain)
+    want_add = oracle.warp_bilinear(feats, flow, add=add)
+    np.testing.assert_array_equal(hip.warp_bilinear_cl(cl(feat), t(flow), add_cl=cl(add)).permute(0, 3, 1, 2).cpu().numpy(), want_add)
+
+
 def test_warp_broadcast_key_feature_batch(hip):
     rs = np.random.RandomState(8)
     feat = rs.randn(1, 32, 12, 20).astype(np.float32)

@@ -3,7 +3,7 @@
 # Raw traces stay on the box; the condensed summaries land in gpurun_out/<round>/ and are copied to profiles/<round>/.
 # PMC passes never share a run with --sys-trace / --runtime-trace (the pool refuses that combination).
 set -u
-R=${1:-r5}
+R=${1:-r6}
 OUT=gpurun_out/$R
 mkdir -p $OUT
 export TMPDIR=/tmp
@@ -51,6 +51,12 @@ timeout 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_cfetch -o
 timeout 300 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_cwrite -o t -- $PY $EAGER > $OUT/conv_traffic_write.log 2>&1
 $PY tools/summarize_prof.py convtraffic $OUT/pmc_cfetch $OUT/pmc_cwrite $OUT/traffic.json "conv_split:1000x600,interval=10,f32" > $OUT/conv_traffic_summary.log 2>&1
 rm -rf $OUT/pmc_cfetch $OUT/pmc_cwrite
+# 4c. r6: the same for configs[2] (bf16, four clips): VERDICT r5 found `roofline.traffic: null` in that line
+EAGER2="$EAGER --dtype bf16 --clips 4"
+timeout 400 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_cfetch2 -o t -- $PY $EAGER2 > $OUT/conv_traffic_fetch_bf16.log 2>&1
+timeout 400 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_cwrite2 -o t -- $PY $EAGER2 > $OUT/conv_traffic_write_bf16.log 2>&1
+$PY tools/summarize_prof.py convtraffic $OUT/pmc_cfetch2 $OUT/pmc_cwrite2 $OUT/traffic.json "conv_split:1000x600,interval=10,bf16,clips=4" > $OUT/conv_traffic_summary_bf16.log 2>&1
+rm -rf $OUT/pmc_cfetch2 $OUT/pmc_cwrite2
 
 # 5. per-op kernels (GPU-side durations) and the warp A/B
 timeout 200 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_ops -o t -- $PY tools/bench_ops.py > $OUT/bench_ops_microbench.txt 2>&1

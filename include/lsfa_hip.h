@@ -509,9 +509,12 @@ int lsfa_transform_mv_res(const void* motion_vector, const void* res_diff, int f
  * float32 work type), zero padding to `stride` (config.network.IMAGE_STRIDE; 0: none), channel i = (im[..., 2 - i] - pixel_means[2 - i]) *
  * pixel_scale: the subtraction in float32 when stride == 0 (a float32 image minus a Python float) and in float64 when stride > 0 (the padded copy is
  * np.zeros(...), a float64 image: image.py:288-293), the product in float64, rounded to float32 once.  h1, w1 = cvRound(H * im_scale), cvRound(W * im_scale); out_h, out_w = h1, w1 rounded up to
- * the stride - checked.  (lsfa_image_transform_u8 is the uint8-image form of `transform`: float64 subtraction; the two agree for zero means.)  (A frame that cv2.imread hands over as uint8 - the last frame of a
- * video, :45 - takes OpenCV's fixed-point uint8 path in the reference and differs from this by up to half an intensity level: stated, not
- * reproduced.) */
+ * the stride - checked.  (lsfa_image_transform_u8 is the uint8-image form of `transform`: float64 subtraction; the two agree for zero means.)
+ * is_u8: 0 = float32 frames; 1 = uint8 frames converted to float and interpolated in float (a decoder's frame after get_image's .astype); 2 (r6) = a
+ * uint8 frame as cv2.imread hands it over - the LAST frame of a video, :45 - interpolated on OpenCV's fixed-point uint8 path (2048-scaled short
+ * coefficients, int32 horizontal pass, `(((b0 (S0 >> 4)) >> 16) + ((b1 (S1 >> 4)) >> 16) + 2) >> 2` vertically: OpenCV 3.2 imgwarp.cpp, restated as
+ * oracle/np_ref.py::cv2_resize_linear_u8 - parity unpinned like the float path), then transformed with a float64 subtraction (a uint8 image's rule).
+ * The result is within 0.8 intensity levels of the float interpolation.  NOT restated (either path): OpenCV's switch to INTER_AREA at im_scale 0.5. */
 int lsfa_image_resize_transform(const void* im_hwc_bgr, int is_u8, int N, int H, int W, double im_scale, int h1, int w1, int stride,
                                 const double* pixel_means_bgr_host, double pixel_scale, float* data_nchw, int out_h, int out_w, void* stream);
 

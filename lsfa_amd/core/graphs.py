@@ -86,6 +86,12 @@ class FrameGraphs(object):
         are the graphs' static buffers, so read or clone them on the frame's stream before the next replay."""
         self.key, self.cur, self.cfg = key_exec, cur_exec, cfg
         self.feat_shared = feat_shared
+        # r6: a lane whose non-key frames run on channels-last maps takes the key feature channels-last (feat_shared_cl: the pipeline's hand-over
+        # IS the transposing copy - set_key_feature - instead of a plain copy followed by a transposition in every pass)
+        self.feat_shared_cl = None
+        if feat_shared is not None and not prefetch and cur_exec is not None and cur_exec.cur_channels_last(cfg.network.DFF_FEAT_DIM):
+            self.feat_shared_cl = torch.zeros((feat_shared.shape[0], feat_shared.shape[2], feat_shared.shape[3], feat_shared.shape[1]),
+                                              device=feat_shared.device, dtype=torch.float32)
         self.want_taps = taps
         self.key_taps = self.cur_taps = self.key_out = self.cur_out = None
         self._small_valid = False      # small_cur holds the small-net feature of the frame cur_frame is about to get
@@ -118,6 +124,14 @@ class FrameGraphs(object):
         self.feat = None            # the key graph's output feature (static address once captured)
         self.key_graph = self.cur_graph = None
         self.scale = 1.0
+
+    def set_key_feature(self, feat):
+        """A lane's copy of the key feature its next frames are served from (on the current stream): channels-last when the lane's frames run
+        that way (the copy is the transposition), else a plain copy into feat_shared."""
+        if self.feat_shared_cl is not None:
+            hip.nchw_to_nhwc(feat, out=self.feat_shared_cl)
+        else:
+            _stage_inputs([(self.feat_shared, feat)])
 
     # ---- the two launch sequences -------------------------------------------------------
     def _post(self, out):
@@ -163,7 +177,7 @@ class FrameGraphs(object):
                                        res_diff=self.res, small_feat=self.small_cur)
             else:
                 out = self.cur.forward(data=self.data_tbl if self._use_tbl else self.data, im_info=self.im_info, feat_key=self.feat,
-                                       motion_vector=self.mv, res_diff=self.res)
+                                       motion_vector=self.mv, res_diff=self.res, feat_key_cl=self.feat_shared_cl)
         finally:
             self.cur.taps = saved
         self.cur_out = out if self.want_taps else None
@@ -551,6 +565,8 @@ class FramePipeline(object):
         self.klanes = [KeyLane(key_exec, cfg, height, width, dev, thresh, use_graphs, taps, B) for _ in range(2)]
         self.lanes = [FrameGraphs(key_exec, cur_exec, cfg, height, width, dev, thresh, use_graphs, prefetch=False,
                                   feat_shared=self.feat_cur, taps=taps, batch=B) for _ in range(lanes)]
+        for ln in self.lanes[1:]:
+            ln.feat_shared_cl = self.lanes[0].feat_shared_cl       # one shared copy, like feat_cur
         # segment > 0: the non-key frames of a segment (all served from one key feature) go through the network in ONE pass of `segment`
         # frames on the batch axis - what the reference's own batch test symbol does (get_batch_test_symbol,
         # resnet_v1_101_flownet_rfcn.py:661-751) - on `lanes` (>= 2) alternating lanes, each with its own copy of the key feature; a shorter run of
@@ -717,10 +733,14 @@ class FramePipeline(object):
         self._publish_from_main()
         return self._first_post
 
+    def _set_lanes_feature(self, feat):
+        """the per-frame lanes share ONE copy of the key feature (feat_cur; channels-last: the first lane's buffer, which the others alias)"""
+        self.lanes[0].set_key_feature(feat) if self.lanes else _stage_inputs([(self.feat_cur, feat)])
+
     def _publish_from_main(self):
         """The clip's first feature goes to the lanes directly; every stream and event starts from here."""
         main = torch.cuda.current_stream(self.device)
-        self.feat_cur.copy_(self._feat_latest)
+        self._set_lanes_feature(self._feat_latest)
         for s in self._all_streams():
             s.wait_stream(main)
         for e in [self.ev_handover, self.ev_tail] + self.ev_feat + self.ev_lane + self.ev_tail_of:
@@ -901,7 +921,7 @@ class FramePipeline(object):
                 # this lane's copy of the segment's key feature (the lane's previous segment is done with the old one: stream order)
                 if self._seg_event is not None:
                     s.wait_event(self._seg_event)
-                _stage_inputs([(self.feat_seg[i], self._seg_feat)])
+                lane.set_key_feature(self._seg_feat)
                 self._copied_out(s)
                 self._lane_key[i] = self._seg_key
             frames = []
@@ -932,7 +952,7 @@ class FramePipeline(object):
                     s.wait_event(self._seg_event)        # the segment's key feature exists
                 for e in self.ev_lane[1:]:
                     s.wait_event(e)                      # every lane has finished the previous segment
-                _stage_inputs([(self.feat_cur, self._seg_feat)])
+                self._set_lanes_feature(self._seg_feat)
                 self.ev_handover.record(s)
                 self._copied_out(s)
             self._cur_key = self._seg_key

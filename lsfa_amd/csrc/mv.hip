@@ -203,6 +203,41 @@ __global__ __launch_bounds__(kThreads) void resize_transform_kernel(const T* __r
   o[2 * plane] = (float)((double)tb * pixel_scale);
 }
 
+// r6: the LAST frame of a video reaches `resize` as the uint8 image cv2.imread returned (lib/utils/image.py:45), and OpenCV interpolates uint8
+// images in fixed point: shorts `saturate_cast<short>(c * 2048)` of the two float coefficients of an axis, an int32 horizontal pass
+// `D = S[x0] a0 + S[x1] a1`, and `uchar((((b0 (S0 >> 4)) >> 16) + ((b1 (S1 >> 4)) >> 16) + 2) >> 2)` vertically (OpenCV 3.2 imgwarp.cpp,
+// VResizeLinear<uchar, int, short, FixedPtCast<int, uchar, 22>>; restated as oracle/np_ref.py::cv2_resize_linear_u8 - parity unpinned: no
+// OpenCV in the image).  `transform` then sees a uint8 (or, padded, float64) image: float64 subtraction.  One thread per output pixel.
+__global__ __launch_bounds__(kThreads) void resize_u8_fixed_transform_kernel(const unsigned char* __restrict__ im, int N, int H, int W, int h1, int w1,
+                                                                             int ph, int pw, double inv_scale, double m0, double m1, double m2,
+                                                                             double pixel_scale, float* __restrict__ out) {
+  const long i = (long)blockIdx.x * kThreads + threadIdx.x;
+  const long plane = (long)ph * pw;
+  if (i >= N * plane) return;
+  const int n = (int)(i / plane);
+  const long r = i - n * plane;
+  const int y = (int)(r / pw), x = (int)(r - (long)y * pw);
+  const unsigned char* src = im + (size_t)n * H * W * 3;
+  int v[3] = {0, 0, 0};
+  if (y < h1 && x < w1) {
+    const ResizeTap tx = resize_tap(x, W, inv_scale), ty = resize_tap(y, H, inv_scale);
+    // cvRound of the float coefficient times 2048 (round to nearest even: rintf in the default mode)
+    const int a0 = (int)rintf((1.f - tx.a) * 2048.f), a1 = (int)rintf(tx.a * 2048.f);
+    const int b0 = (int)rintf((1.f - ty.a) * 2048.f), b1 = (int)rintf(ty.a * 2048.f);
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      const int s00 = src[((size_t)ty.i0 * W + tx.i0) * 3 + c], s01 = src[((size_t)ty.i0 * W + tx.i1) * 3 + c];
+      const int s10 = src[((size_t)ty.i1 * W + tx.i0) * 3 + c], s11 = src[((size_t)ty.i1 * W + tx.i1) * 3 + c];
+      const int h0 = s00 * a0 + s01 * a1, h1_ = s10 * a0 + s11 * a1;
+      v[c] = ((((b0 * (h0 >> 4)) >> 16) + ((b1 * (h1_ >> 4)) >> 16) + 2) >> 2) & 0xFF;
+    }
+  }
+  float* o = out + (size_t)n * 3 * plane + r;
+  o[0] = (float)(((double)v[2] - m2) * pixel_scale);
+  o[plane] = (float)(((double)v[1] - m1) * pixel_scale);
+  o[2 * plane] = (float)(((double)v[0] - m0) * pixel_scale);
+}
+
 }  // namespace
 
 extern "C" int lsfa_image_resize_transform(const void* im_hwc_bgr, int is_u8, int N, int H, int W, double im_scale, int h1, int w1, int stride,
@@ -219,7 +254,11 @@ extern "C" int lsfa_image_resize_transform(const void* im_hwc_bgr, int is_u8, in
   hipStream_t s = (hipStream_t)stream;
   ProfScope prof(LSFA_OP_STEM, s);
   const dim3 grid((unsigned)((total + kThreads - 1) / kThreads));
-  if (is_u8)
+  LSFA_REQUIRE(is_u8 >= 0 && is_u8 <= 2, "lsfa_image_resize_transform: is_u8 is 0 (float32), 1 (uint8, interpolated in float) or 2 (uint8, OpenCV's fixed-point path)");
+  if (is_u8 == 2)
+    hipLaunchKernelGGL(resize_u8_fixed_transform_kernel, grid, dim3(kThreads), 0, s, (const unsigned char*)im_hwc_bgr, N, H, W, h1, w1, ph, pw,
+                       1.0 / im_scale, pixel_means_bgr_host[0], pixel_means_bgr_host[1], pixel_means_bgr_host[2], pixel_scale, data_nchw);
+  else if (is_u8)
     hipLaunchKernelGGL(resize_transform_kernel<unsigned char>, grid, dim3(kThreads), 0, s, (const unsigned char*)im_hwc_bgr, N, H, W, h1, w1, ph, pw,
                        1.0 / im_scale, pixel_means_bgr_host[0], pixel_means_bgr_host[1], pixel_means_bgr_host[2], pixel_scale, stride > 0 ? 1 : 0, data_nchw);
   else

@@ -642,9 +642,11 @@ def transform_mv_res(motion_vector, res_diff, im_scale, pixel_means=(0.0, 0.0, 0
 
 
 @_on_tensor_device
-def image_resize_transform(im, im_scale, pixel_means=(0.0, 0.0, 0.0), pixel_scale=1.0, stride=0):
+def image_resize_transform(im, im_scale, pixel_means=(0.0, 0.0, 0.0), pixel_scale=1.0, stride=0, u8_fixed_point=False):
     """lsfa_image_resize_transform: decoded frames (N, H, W, 3) or (H, W, 3) BGR, uint8 or float32, on the device -> `data` (N, 3, h, w) float32:
-    resize (lib/utils/image.py:266-294) + transform (:296-308) in one launch."""
+    resize (lib/utils/image.py:266-294) + transform (:296-308) in one launch.  u8_fixed_point (uint8 frames only): interpolate on OpenCV's
+    fixed-point uint8 path and subtract the means in float64 - what the reference does to the LAST frame of a video, which it reads with
+    cv2.imread (:45); the default treats a uint8 frame like the decoder's (converted to float first, :52)."""
     if im.dim() == 3:
         im = im.unsqueeze(0)
     if im.dtype not in (torch.uint8, torch.float32) or im.dim() != 4 or im.shape[3] != 3 or not im.is_contiguous():
@@ -655,7 +657,9 @@ def image_resize_transform(im, im_scale, pixel_means=(0.0, 0.0, 0.0), pixel_scal
     ph, pw = (-(-h1 // stride) * stride, -(-w1 // stride) * stride) if stride else (h1, w1)
     out = torch.empty((N, 3, ph, pw), device=im.device, dtype=torch.float32)
     means = (ctypes.c_double * 3)(*[float(m) for m in pixel_means])
-    _check(lib().lsfa_image_resize_transform(_ptr(im), _ci(int(im.dtype == torch.uint8)), _ci(N), _ci(H), _ci(W), ctypes.c_double(float(im_scale)), _ci(h1), _ci(w1),
+    if u8_fixed_point and im.dtype != torch.uint8:
+        raise LsfaError("image_resize_transform: u8_fixed_point needs uint8 frames")
+    _check(lib().lsfa_image_resize_transform(_ptr(im), _ci(2 if u8_fixed_point else int(im.dtype == torch.uint8)), _ci(N), _ci(H), _ci(W), ctypes.c_double(float(im_scale)), _ci(h1), _ci(w1),
                                              _ci(int(stride)), means, ctypes.c_double(float(pixel_scale)), _ptr(out), _ci(ph), _ci(pw), _stream()),
            "lsfa_image_resize_transform")
     return out

@@ -721,13 +721,19 @@ class Executor(object):
             s, am = self._resnet(img, self.small, 1, 'small')
             return self._conv(s, self.fuse_w, self.fuse_b, 1, 1, 1, amax_in=am, nchw=nchw)
 
+    def cur_channels_last(self, channels):
+        """whether a non-key frame whose small-net feature is computed inside forward() runs on channels-last maps (_forward_cur_cl)"""
+        return bool(self.cfg.network.add_small_net and CUR_CHANNELS_LAST and self.pieces != 0 and channels % 4 == 0)
+
     def _forward_cur_cl(self, d):
         """The non-key frame on channels-last maps (r6): the warped feature is read by two 1x1 convolutions only - GEMMs over the channel axis -
         so it is produced as (pixel, channel) rows: the key feature turned channels-last once per PASS (not half a map per frame in front of
         the R-FCN convolution), the small net's fuse convolution in its natural layout, lsfa_warp_bilinear_cl (the same bits as the NCHW
         kernel, + the maximum the R-FCN convolution's scale needs).  `conv_feat` in the outputs is the NCHW view of the same memory."""
         S = self._slots['heads'].begin()
-        feat_cl = hip.nchw_to_nhwc(d['feat_key'])
+        feat_cl = d.get('feat_key_cl')                 # (B, H, W, C): a caller that hands the key feature over channels-last (FramePipeline does, as its
+        if feat_cl is None:                            #  hand-over copy) saves the per-pass transposition
+            feat_cl = hip.nchw_to_nhwc(d['feat_key'])
         add_cl = self.small_net_feature(d['data'], nchw=False)
         self._tap('small_feat', add_cl.permute(0, 3, 1, 2))
         am = S.new()
@@ -764,7 +770,7 @@ class Executor(object):
         # r6: the whole non-key frame on channels-last maps (no transposing copy in front of the R-FCN convolution) whenever nothing forces the
         # operator layout: the small net's feature is computed here (not handed over NCHW), C is a multiple of 4, no exact-fp32 reference mode.
         # LSFA_CUR_NCHW=1 keeps the NCHW form (A/B; it is also what the key frames and the batch test symbol run).
-        if add is None and cfg.network.add_small_net and CUR_CHANNELS_LAST and self.pieces != 0 and d['feat_key'].shape[1] % 4 == 0:
+        if add is None and self.cur_channels_last(d['feat_key'].shape[1]):
             return self._forward_cur_cl(d)
         if add is None and cfg.network.add_small_net:
             add = self.small_net_feature(d['data'])

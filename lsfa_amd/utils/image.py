@@ -8,11 +8,11 @@ INTER_LINEAR) on float input [OpenCV 3.2 resize.cpp, un-vendored — PARITY UNPI
 cvRound(size * f); source coordinate of destination pixel d = (d + 0.5) / f - 0.5 — the scale is
 1/f as GIVEN, not src/dst (they differ whenever size*f is not an integer, the usual case for
 im_scale) — two taps with edge clamping, no antialiasing, horizontal pass then vertical pass.
-This is cv2's FLOAT path, which is what the motion vectors and the residual take (image.py:204-205, 221-222).  The
-reference's `resize()` of the frame itself runs on the uint8 image from cv2.imread (image.py:283): cv2's fixed-point path
-(11-bit coefficients, result rounded to uint8).  `resize()` here interpolates in float and does not round: up to 0.5
-intensity levels of difference per pixel against the reference's frame (stated, not reproduced: cv2 is absent, so neither
-path can be pinned — DESIGN.md §5).
+This is cv2's FLOAT path, which is what the motion vectors, the residual and a decoder's frame (converted with
+.astype(np.float32) first, image.py:52) take.  The LAST frame of a video is read with cv2.imread (image.py:45) and reaches
+`resize()` as a uint8 image: cv2's fixed-point path (11-bit coefficients, result rounded to uint8), which
+`resize(..., u8_fixed_point=True)` follows (r6; oracle/np_ref.py::cv2_resize_linear_u8, lsfa_image_resize_transform's
+is_u8 = 2).  cv2 is absent, so neither path can be pinned.
 """
 import numpy as np
 import torch
@@ -50,15 +50,30 @@ def _resize_hwc(x, fx, fy):
     return hor[y0] * by[:, None, None] + hor[y1] * ay[:, None, None]
 
 
-def resize(im, target_size, max_size, stride=0):
-    """im (H, W, C) BGR tensor -> (resized [padded to `stride`], im_scale).  lib/utils/image.py:266-294"""
+def _resize_hwc_u8(x, fx, fy):
+    """x: (H, W, C) uint8 tensor -> uint8, OpenCV 3.2's fixed-point INTER_LINEAR (oracle/np_ref.py::cv2_resize_linear_u8 states the source)."""
+    h, w, _ = x.shape
+    oh, ow = _cv_round(h * fy), _cv_round(w * fx)
+    x0, x1, ax = _taps(ow, w, fx, x.device)
+    y0, y1, ay = _taps(oh, h, fy, x.device)
+    q = lambda c: torch.round(c * 2048.0).to(torch.int32)         # saturate_cast<short>(c * 2048): nearest, ties to even (torch.round is that)
+    a0, a1, b0, b1 = q(1.0 - ax), q(ax), q(1.0 - ay), q(ay)
+    xi = x.to(torch.int32)
+    hor = xi[:, x0] * a0[None, :, None] + xi[:, x1] * a1[None, :, None]
+    out = (((b0[:, None, None] * (hor[y0] >> 4)) >> 16) + ((b1[:, None, None] * (hor[y1] >> 4)) >> 16) + 2) >> 2
+    return out.to(torch.uint8)
+
+
+def resize(im, target_size, max_size, stride=0, u8_fixed_point=False):
+    """im (H, W, C) BGR tensor -> (resized [padded to `stride`], im_scale).  lib/utils/image.py:266-294.  u8_fixed_point: a uint8 image is
+    interpolated on cv2's fixed-point path and stays uint8 (the reference's last frame of a video); else in float."""
     im = torch.as_tensor(im)
     h, w = im.shape[0], im.shape[1]
     im_size_min, im_size_max = min(h, w), max(h, w)
     im_scale = float(target_size) / float(im_size_min)
     if np.round(im_scale * im_size_max) > max_size:
         im_scale = float(max_size) / float(im_size_max)
-    out = _resize_hwc(im.float(), im_scale, im_scale)
+    out = _resize_hwc_u8(im, im_scale, im_scale) if (u8_fixed_point and im.dtype == torch.uint8) else _resize_hwc(im.float(), im_scale, im_scale)
     if stride == 0:
         return out, im_scale
     ph = int(np.ceil(out.shape[0] / float(stride)) * stride)

@@ -211,6 +211,41 @@ def cv2_resize_linear(src, fx, fy):
     return out.astype(wt).reshape((dh, dw) + src.shape[2:])
 
 
+def cv2_resize_linear_u8(src, fx, fy):
+    """cv2.resize(src, None, None, fx, fy, INTER_LINEAR) for a UINT8 image: OpenCV 3.2's fixed-point path (imgwarp.cpp) - what the
+    reference runs on the LAST frame of a video, which lib/utils/image.py:45 reads with cv2.imread [un-vendored, parity unpinned:
+    restated from the published source, no OpenCV in this image to pin it].  Taps and positions as in the float path; the two
+    coefficients of an axis become shorts `saturate_cast<short>(c * 2048)` (cvRound: ties to even) of c = 1.f - f and f (float);
+    horizontal pass in int32, `D = S[x0] * a0 + S[x1] * a1`; vertical pass
+    `dst = uchar((((b0 * (S0 >> 4)) >> 16) + ((b1 * (S1 >> 4)) >> 16) + 2) >> 2)` (VResizeLinear<uchar, int, short, FixedPtCast<int, uchar, 22>>:
+    the form its SSE2 kernel computes with 16-bit high multiplies).  NOT restated: the switch to INTER_AREA at fx == fy == 0.5."""
+    src = np.asarray(src)
+    assert src.dtype == np.uint8
+    sh, sw = src.shape[:2]
+    dh, dw = int(np.rint(sh * fy)), int(np.rint(sw * fx))
+
+    def taps(dn, sn, factor):
+        scale = 1.0 / float(factor)
+        f = ((np.arange(dn, dtype=np.float64) + 0.5) * scale - 0.5).astype(np.float32)
+        s0 = np.floor(f).astype(np.int64)
+        a = (f - s0.astype(np.float32)).astype(np.float32)
+        lo = s0 < 0
+        s0[lo], a[lo] = 0, 0.0
+        hi = s0 >= sn - 1
+        s0[hi], a[hi] = sn - 1, 0.0
+        c0 = (np.float32(1.0) - a).astype(np.float32)
+        i0 = np.rint(c0 * np.float32(2048.0)).astype(np.int32)       # saturate_cast<short>(float) = cvRound (nearest, ties to even); <= 2048
+        i1 = np.rint(a * np.float32(2048.0)).astype(np.int32)
+        return s0, np.minimum(s0 + 1, sn - 1), i0, i1
+
+    x0, x1, a0, a1 = taps(dw, sw, fx)
+    y0, y1, b0, b1 = taps(dh, sh, fy)
+    s3 = src.reshape(sh, sw, -1).astype(np.int32)
+    hor = s3[:, x0] * a0[None, :, None] + s3[:, x1] * a1[None, :, None]
+    out = (((b0[:, None, None] * (hor[y0] >> 4)) >> 16) + ((b1[:, None, None] * (hor[y1] >> 4)) >> 16) + 2) >> 2
+    return out.astype(np.uint8).reshape((dh, dw) + src.shape[2:])
+
+
 def transform_mv_res(motion_vector, res_diff, im_scale, pixel_means, pixel_scale, rcnn_stride=16):
     motion_vector = cv2_resize_linear(motion_vector.astype(np.float32), im_scale, im_scale)
     res_diff = cv2_resize_linear(res_diff.astype(np.float32), im_scale, im_scale)

@@ -1074,6 +1074,34 @@ def test_image_table_entry_points_equal_the_dense_ones(hip):
     del pad
 
 
+@pytest.mark.parametrize("case", [(600, 1000, 1.0, 0), (720, 1280, 0.78125, 0), (480, 640, 1.25, 32), (37, 53, 1.7, 16), (9, 7, 0.6, 0)])
+def test_image_resize_transform_u8_fixed_point_path(hip, case):
+    """r6 (is_u8 = 2): the last frame of a video reaches `resize` as cv2.imread's uint8 image (lib/utils/image.py:45) and OpenCV interpolates it in
+    fixed point; oracle/np_ref.py::cv2_resize_linear_u8 restates that path (parity unpinned) and the kernel equals it + `transform`'s uint8 rule
+    (float64 subtraction) bit for bit, padding included; at scale 1 it is lsfa_image_transform_u8."""
+    H, W, scale, stride = case
+    rs = np.random.RandomState(H + 5 * W)
+    means, ps = (102.9801, 115.9465, 122.7717), 0.5
+    ims = rs.randint(0, 256, (2, H, W, 3)).astype(np.uint8)
+
+    def want_of(im):
+        r = np_ref.cv2_resize_linear_u8(im, scale, scale)
+        if stride:
+            ph, pw = -(-r.shape[0] // stride) * stride, -(-r.shape[1] // stride) * stride
+            p = np.zeros((ph, pw, 3))
+            p[:r.shape[0], :r.shape[1]] = r
+            r = p
+        return np_ref.transform(r, means, ps).astype(np.float32)
+
+    want = np.concatenate([want_of(ims[0]), want_of(ims[1])], 0)
+    got = hip.image_resize_transform(t(ims), scale, means, ps, stride=stride, u8_fixed_point=True)
+    np.testing.assert_array_equal(got.cpu().numpy(), want)
+    floaty = hip.image_resize_transform(t(ims), scale, means, ps, stride=stride).cpu().numpy()
+    assert np.abs(floaty - got.cpu().numpy()).max() <= 0.8 * ps + 1e-4         # within 0.8 intensity levels of the float interpolation
+    if scale == 1.0 and (H * W) % 4 == 0:
+        assert torch.equal(got, hip.image_transform_u8(t(ims), means, ps))
+
+
 def test_image_resize_transform_golden_g6_float32_frame(hip, golden):
     """... and against G6: the reference's own `transform` on a float32 frame with list means (float32 subtraction, float64 product)."""
     imf = golden["g6_im"].astype(np.float32) * np.float32(0.731)

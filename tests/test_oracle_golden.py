@@ -177,3 +177,31 @@ def test_image_helpers_against_reference_g6(golden):
     out, sc = image.resize(torch.from_numpy(big), 60, 90)
     assert sc == 1.8 and tuple(out.shape) == golden["g6_resize_out_capped"].shape
     np.testing.assert_allclose(out.numpy(), golden["g6_resize_out_capped"], rtol=1e-5, atol=1e-3)
+
+
+def test_cv2_uint8_fixed_point_restatement_invariants():
+    """oracle/np_ref.py::cv2_resize_linear_u8 (OpenCV 3.2's fixed-point INTER_LINEAR for uint8 images, the reference's last-frame path; parity
+    unpinned): the properties the published arithmetic guarantees - identity at scale 1, a constant image stays constant at any scale, and the
+    result stays within 0.8 intensity levels of the float interpolation of the same taps."""
+    rs = np.random.RandomState(4)
+    im = rs.randint(0, 256, (37, 53, 3)).astype(np.uint8)
+    np.testing.assert_array_equal(np_ref.cv2_resize_linear_u8(im, 1.0, 1.0), im)
+    const = np.full((20, 30, 3), 137, np.uint8)
+    for f in (0.6, 0.78125, 1.25, 1.7):
+        assert (np_ref.cv2_resize_linear_u8(const, f, f) == 137).all()
+        a = np_ref.cv2_resize_linear_u8(im, f, f)
+        b = np_ref.cv2_resize_linear(im.astype(np.float32), f, f)
+        assert a.shape == b.shape and a.dtype == np.uint8
+        assert np.abs(a.astype(np.float64) - b).max() <= 0.8
+    # the host path (lsfa_amd/utils/image.py) follows the same arithmetic: uint8 out, padded copy float64, float64 subtraction in transform
+    import torch
+    from lsfa_amd.utils import image
+    big = rs.randint(0, 256, (30, 50, 3)).astype(np.uint8)
+    out, sc = image.resize(torch.from_numpy(big), 60, 100, u8_fixed_point=True)
+    assert sc == 2.0 and out.dtype == torch.uint8
+    np.testing.assert_array_equal(out.numpy(), np_ref.cv2_resize_linear_u8(big, 2.0, 2.0))
+    out2, sc2 = image.resize(torch.from_numpy(big), 60, 90, stride=16, u8_fixed_point=True)
+    r = np_ref.cv2_resize_linear_u8(big, sc2, sc2)
+    assert out2.dtype == torch.float64 and tuple(out2.shape[:2]) == (-(-r.shape[0] // 16) * 16, -(-r.shape[1] // 16) * 16)
+    np.testing.assert_array_equal(out2.numpy()[:r.shape[0], :r.shape[1]], r.astype(np.float64))
+

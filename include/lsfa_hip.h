@@ -514,7 +514,7 @@ int lsfa_transform_mv_res(const void* motion_vector, const void* res_diff, int f
  * uint8 frame as cv2.imread hands it over - the LAST frame of a video, :45 - interpolated on OpenCV's fixed-point uint8 path (2048-scaled short
  * coefficients, int32 horizontal pass, `(((b0 (S0 >> 4)) >> 16) + ((b1 (S1 >> 4)) >> 16) + 2) >> 2` vertically: OpenCV 3.2 imgwarp.cpp, restated as
  * oracle/np_ref.py::cv2_resize_linear_u8 - parity unpinned like the float path), then transformed with a float64 subtraction (a uint8 image's rule).
- * The result is within 0.8 intensity levels of the float interpolation.  NOT restated (either path): OpenCV's switch to INTER_AREA at im_scale 0.5. */
+ * The result is about one intensity level from the float interpolation at most (measured <= 0.81).  NOT restated (either path): OpenCV's switch to INTER_AREA at im_scale 0.5. */
 int lsfa_image_resize_transform(const void* im_hwc_bgr, int is_u8, int N, int H, int W, double im_scale, int h1, int w1, int stride,
                                 const double* pixel_means_bgr_host, double pixel_scale, float* data_nchw, int out_h, int out_w, void* stream);
 

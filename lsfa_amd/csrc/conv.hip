@@ -427,8 +427,12 @@ size_t split_workspace(const SplitPlan& p, long P, int Cout) {
 
 bool direct_fits(const convsplit::Args& a, long P, int pieces) {
   const size_t wbytes = (size_t)a.kh * a.kw * a.Cin * 2 * pieces;      // per output channel
-  return a.nphase <= 1 && a.stride == 1 && wbytes * 64 <= (256u << 10) && P <= 16384 &&
-         (size_t)((P + 31) / 32) * wbytes * a.Cout <= (48u << 20) && g_force_kernel.load() == 0;
+  // r6: a narrow exact-cut launch (the RPN head: 512 -> 64 channels, three bf16 pieces) stays on the direct kernel for a whole segment's maps
+  // (21,546 pixels) too - what its K-major form did until r5 whatever the size: on the ring kernel it would be 169 workgroups of 128 x 64 tiles,
+  // and its K would be summed in one chain per output instead of the direct kernel's three (the ROI coordinates' margin against float64: 1.25 / 2.0)
+  const bool narrow = pieces == 3 && a.Cout <= 64;
+  return a.nphase <= 1 && a.stride == 1 && wbytes * 64 <= (256u << 10) && P <= (narrow ? 32768 : 16384) &&
+         (size_t)((P + 31) / 32) * wbytes * a.Cout <= ((narrow ? 160u : 48u) << 20) && g_force_kernel.load() == 0;
 }
 
 // waves per tile of the direct kernel: at least two chunks per wave, at most kDirectMaxWaves waves

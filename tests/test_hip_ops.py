@@ -1097,7 +1097,7 @@ def test_image_resize_transform_u8_fixed_point_path(hip, case):
     got = hip.image_resize_transform(t(ims), scale, means, ps, stride=stride, u8_fixed_point=True)
     np.testing.assert_array_equal(got.cpu().numpy(), want)
     floaty = hip.image_resize_transform(t(ims), scale, means, ps, stride=stride).cpu().numpy()
-    assert np.abs(floaty - got.cpu().numpy()).max() <= 0.8 * ps + 1e-4         # within 0.8 intensity levels of the float interpolation
+    assert np.abs(floaty - got.cpu().numpy()).max() <= 1.25 * ps               # about one intensity level from the float interpolation (final rounding 0.5 + two truncations 0.5 + 11-bit coefficients)
     if scale == 1.0 and (H * W) % 4 == 0:
         assert torch.equal(got, hip.image_transform_u8(t(ims), means, ps))
 

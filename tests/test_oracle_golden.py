@@ -182,7 +182,7 @@ def test_image_helpers_against_reference_g6(golden):
 def test_cv2_uint8_fixed_point_restatement_invariants():
     """oracle/np_ref.py::cv2_resize_linear_u8 (OpenCV 3.2's fixed-point INTER_LINEAR for uint8 images, the reference's last-frame path; parity
     unpinned): the properties the published arithmetic guarantees - identity at scale 1, a constant image stays constant at any scale, and the
-    result stays within 0.8 intensity levels of the float interpolation of the same taps."""
+    result stays about one intensity level from the float interpolation of the same taps."""
     rs = np.random.RandomState(4)
     im = rs.randint(0, 256, (37, 53, 3)).astype(np.uint8)
     np.testing.assert_array_equal(np_ref.cv2_resize_linear_u8(im, 1.0, 1.0), im)
@@ -192,7 +192,7 @@ def test_cv2_uint8_fixed_point_restatement_invariants():
         a = np_ref.cv2_resize_linear_u8(im, f, f)
         b = np_ref.cv2_resize_linear(im.astype(np.float32), f, f)
         assert a.shape == b.shape and a.dtype == np.uint8
-        assert np.abs(a.astype(np.float64) - b).max() <= 0.8
+        assert np.abs(a.astype(np.float64) - b).max() <= 1.25      # final rounding 0.5 + two truncations 0.5 + 11-bit coefficients
     # the host path (lsfa_amd/utils/image.py) follows the same arithmetic: uint8 out, padded copy float64, float64 subtraction in transform
     import torch
     from lsfa_amd.utils import image

@@ -104,12 +104,13 @@ int lsfa_warp_bilinear(const float* feat, int feat_n, const float* flow,
                        float* out, void* stream);
 /* r6: the same operator on CHANNELS-LAST maps - feat_cl (feat_n, H, W, C), add_cl / out_cl (N, H, W, C), C a multiple of 4, 16-byte aligned;
  * flow (N, 2, H, W) and res (N, res_c, H, W) as above; no `mul` (the non-key path's epilogue: + rnet_conv0(res) + add).  Same arithmetic,
- * same bits as lsfa_warp_bilinear on the transposed maps.  amax_out (or NULL): 256 zeroed slots that receive max|out| (the scale of the
- * convolutions that read the result: the RPN head and the R-FCN score maps, which are GEMMs over the channel axis - with this layout the
- * non-key path needs no lsfa_nchw_to_nhwc in front of them). */
+ * same bits as lsfa_warp_bilinear on the transposed maps.  amax_out (or NULL): 256 zeroed slots that receive max|out| over channels
+ * [amax_c0, C) (a multiple of 4) - the scale of the convolution that reads them: the R-FCN score maps take channels [512, 1024), the RPN head
+ * [0, 512) with an exact three-piece cut; both are GEMMs over the channel axis, so with this layout the non-key path needs no
+ * lsfa_nchw_to_nhwc in front of them. */
 int lsfa_warp_bilinear_cl(const float* feat_cl, int feat_n, const float* flow, int N, int C, int H, int W, const float* add_cl,
                           const float* res, int res_c, const float* res_w, const float* res_b, float* out_cl, unsigned* amax_out,
-                          void* stream);
+                          int amax_c0, void* stream);
 /* Kernel choice (process-wide; results are identical bit for bit): 0 = by shape (default), 1 = the gather kernel only (rounds 1-2),
  * 2 = the LDS-staged kernel (round 3: whole planes copied into LDS by DMA, taps read from LDS) or LSFA_ENOTSUP when the shape or
  * alignment does not allow it (H*W even and <= 4096, 16-byte aligned maps, (C*H*W) % 4 == 0). */

@@ -154,7 +154,7 @@ template <bool HAS_ADD, bool HAS_RES>
 __global__ __launch_bounds__(256) void warp_cl_kernel(const float* __restrict__ feat, int feat_n, const float* __restrict__ flow, int N, int C,
                                                       int H, int W, const float* __restrict__ add, const float* __restrict__ res, int res_c,
                                                       const float* __restrict__ res_w, const float* __restrict__ res_b,
-                                                      float* __restrict__ out, unsigned* __restrict__ amax_out, int pix_per_wg) {
+                                                      float* __restrict__ out, unsigned* __restrict__ amax_out, int amax_c0, int pix_per_wg) {
   using namespace lsfa::warp;
   const int HW = H * W, C4 = C >> 2;
   const int P = N * HW;                                   // (< 2^31: checked by the host)
@@ -170,6 +170,7 @@ __global__ __launch_bounds__(256) void warp_cl_kernel(const float* __restrict__ 
 #pragma unroll
       for (int k = 0; k < kResMax; ++k) rw[j][k] = (HAS_RES && k < res_c) ? res_w[(size_t)(4 * q + j) * res_c + k] : 0.f;
     }
+    const bool counts = 4 * q >= amax_c0;            // the maximum is taken over channels [amax_c0, C): the ones the scaled consumer reads
     int n = p_begin / HW;
     int r = p_begin - n * HW;
     int y = r / W, x = r - y * W;
@@ -214,7 +215,7 @@ __global__ __launch_bounds__(256) void warp_cl_kernel(const float* __restrict__ 
         O_ = O_ + qv;                                                                                                        \
       }                                                                                                                      \
       if (HAS_ADD) O_ = O_ + A_;                                                                                             \
-      mx = fmaxf(mx, fabsf(O_));
+      if (counts) mx = fmaxf(mx, fabsf(O_));
       LSFA_WARP_CL_ONE(0, tl.x, tr.x, bl.x, br.x, a4.x, o0)
       LSFA_WARP_CL_ONE(1, tl.y, tr.y, bl.y, br.y, a4.y, o1)
       LSFA_WARP_CL_ONE(2, tl.z, tr.z, bl.z, br.z, a4.z, o2)
@@ -236,11 +237,12 @@ __global__ __launch_bounds__(256) void warp_cl_kernel(const float* __restrict__ 
 
 extern "C" int lsfa_warp_bilinear_cl(const float* feat_cl, int feat_n, const float* flow, int N, int C, int H, int W, const float* add_cl,
                                      const float* res, int res_c, const float* res_w, const float* res_b, float* out_cl, unsigned* amax_out,
-                                     void* stream) {
+                                     int amax_c0, void* stream) {
   using namespace lsfa;
   LSFA_REQUIRE(feat_cl && flow && out_cl, "lsfa_warp_bilinear_cl: feat, flow and out must be non-NULL");
   LSFA_REQUIRE(N > 0 && C > 0 && C % 4 == 0 && H > 1 && W > 1, "lsfa_warp_bilinear_cl: bad shape N=%d C=%d (a multiple of 4) H=%d W=%d", N, C, H, W);
   LSFA_REQUIRE(feat_n >= 1 && N % feat_n == 0, "lsfa_warp_bilinear_cl: feat batch %d must divide N=%d", feat_n, N);
+  LSFA_REQUIRE(amax_c0 >= 0 && amax_c0 < C && amax_c0 % 4 == 0, "lsfa_warp_bilinear_cl: amax_c0=%d must be a multiple of 4 in [0, C)", amax_c0);
   LSFA_REQUIRE(aligned(feat_cl, 16) && aligned(add_cl, 16) && aligned(out_cl, 16), "lsfa_warp_bilinear_cl: maps must be 16-byte aligned");
   if (res) {
     LSFA_REQUIRE(res_w && res_b, "lsfa_warp_bilinear_cl: res given without res_w/res_b");
@@ -258,7 +260,7 @@ extern "C" int lsfa_warp_bilinear_cl(const float* feat_cl, int feat_n, const flo
   const dim3 grid((unsigned)((P + per - 1) / per));
   ProfScope prof(LSFA_OP_WARP, s);
 #define LSFA_WARP_CL(A_, R_) hipLaunchKernelGGL((warp_cl_kernel<A_, R_>), grid, dim3(256), 0, s, feat_cl, feat_n, flow, N, C, H, W, add_cl, res, res_c, \
-                                                res_w, res_b, out_cl, amax_out, (int)per)
+                                                res_w, res_b, out_cl, amax_out, amax_c0, (int)per)
   if (add_cl && res) LSFA_WARP_CL(true, true);
   else if (add_cl) LSFA_WARP_CL(true, false);
   else if (res) LSFA_WARP_CL(false, true);

@@ -179,10 +179,10 @@ def warp_bilinear(feat, flow, mul=None, add=None, res=None, res_w=None, res_b=No
 
 
 @_on_tensor_device
-def warp_bilinear_cl(feat_cl, flow, add_cl=None, res=None, res_w=None, res_b=None, out=None, amax_out=None):
+def warp_bilinear_cl(feat_cl, flow, add_cl=None, res=None, res_w=None, res_b=None, out=None, amax_out=None, amax_c0=0):
     """lsfa_warp_bilinear_cl: the non-key path's warp on channels-last maps.  feat_cl (feat_n, H, W, C), flow (N, 2, H, W), add_cl (N, H, W, C),
     res (N, res_c, H, W) -> (N, H, W, C); the bits of warp_bilinear on the transposed maps.  amax_out: a zeroed row of amax_slots() that
-    receives max|out| (the scale of the convolutions that read the result)."""
+    receives max|out| over channels [amax_c0, C) (the scale of the convolution that reads those)."""
     feat_cl, flow = _f32c(feat_cl, "feat_cl"), _f32c(flow, "flow")
     add_cl, res = _f32c(add_cl, "add_cl"), _f32c(res, "res")
     N, _, H, W = flow.shape
@@ -197,7 +197,7 @@ def warp_bilinear_cl(feat_cl, flow, add_cl=None, res=None, res_w=None, res_b=Non
     if out is None:
         out = torch.empty((N, H, W, C), device=feat_cl.device, dtype=torch.float32)
     _check(lib().lsfa_warp_bilinear_cl(_ptr(feat_cl), _ci(feat_n), _ptr(flow), _ci(N), _ci(C), _ci(H), _ci(W), _ptr(add_cl), _ptr(res), _ci(res_c),
-                                       _ptr(res_w), _ptr(res_b), _ptr(out), _ptr(amax_out), _stream()), "lsfa_warp_bilinear_cl")
+                                       _ptr(res_w), _ptr(res_b), _ptr(out), _ptr(amax_out), _ci(amax_c0), _stream()), "lsfa_warp_bilinear_cl")
     return out
 
 

@@ -738,7 +738,7 @@ class Executor(object):
         self._tap('small_feat', add_cl.permute(0, 3, 1, 2))
         am = S.new()
         conv_cl = hip.warp_bilinear_cl(feat_cl, d['motion_vector'], add_cl=add_cl, res=d['res_diff'], res_w=self.rnet_w, res_b=self.rnet_b,
-                                       amax_out=am)
+                                       amax_out=am, amax_c0=512)     # the maximum of the channels the R-FCN convolution (two fp16 pieces) reads
         rois, cls_prob, bbox_pred = self._heads_cl(conv_cl, am, d['im_info'])
         return {'data': d['data'], 'data_key': d.get('data_key'), 'data_key_old': d.get('data_key_old'),
                 'feat_key_old': d.get('feat_key_old'), 'rois_output': rois, 'cls_prob_reshape_output': cls_prob,
@@ -750,7 +750,7 @@ class Executor(object):
         A = cfg.network.NUM_ANCHORS
         n, h, w, _ = conv_cl.shape
         logits = torch.empty((n, h, w, self.rpn_sw.cout), device=conv_cl.device, dtype=torch.float32)
-        hip.conv_split_view(conv_cl, self.rpn_sw, self.rpn_b, logits, cin=512, amax_in=am, status=self.status)
+        hip.conv_split_view(conv_cl, self.rpn_sw, self.rpn_b, logits, cin=512, status=self.status)      # (three exact bf16 pieces, or one in bf16 mode: no scale)
         cls_prob, rpn_bbox = hip.rpn_softmax_split(logits, A)
         rois = self.proposal(cls_prob, rpn_bbox, im_info)
         D = self.ncls + self.nbox

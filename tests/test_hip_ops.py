@@ -182,6 +182,10 @@ def test_warp_channels_last_equals_the_operator_layout(hip, shape):
     got = hip.warp_bilinear_cl(cl(feat), t(flow), add_cl=cl(add), res=t(res), res_w=t(res_w), res_b=t(res_b), amax_out=slots)
     np.testing.assert_array_equal(got.permute(0, 3, 1, 2).cpu().numpy(), want)
     assert slots.view(torch.float32).max().item() == float(np.abs(want).max())
+    if C >= 8:                                                     # the maximum over the upper half of the channels only (what the R-FCN convolution reads)
+        slots2 = hip.amax_slots(1, DEV)[0]
+        hip.warp_bilinear_cl(cl(feat), t(flow), add_cl=cl(add), res=t(res), res_w=t(res_w), res_b=t(res_b), amax_out=slots2, amax_c0=C // 2)
+        assert slots2.view(torch.float32).max().item() == float(np.abs(want[:, C // 2:]).max())
     want_plain = oracle.warp_bilinear(feats, flow)
     np.testing.assert_array_equal(hip.warp_bilinear_cl(cl(feat), t(flow)).permute(0, 3, 1, 2).cpu().numpy(), want_plain)
     want_add = oracle.warp_bilinear(feats, flow, add=add)

@@ -857,6 +857,8 @@ def main():
     args = parse()
     parity_failed = False
     from lsfa_amd import hip as _hip
+    if os.environ.get('LSFA_PROPOSAL_PLAN'):      # lab: 'chip' | 'chip-box-sweep' | 'single' (process-wide; identical results)
+        _hip.proposal_set_plan(os.environ['LSFA_PROPOSAL_PLAN'])
     if _hip.LAB_SKIP:
         # ablation (tools/lab/tail_ablation.sh): launches are dropped, detections are garbage - the line says so and carries no parity and no
         # CPU baseline

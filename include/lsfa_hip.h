@@ -158,7 +158,9 @@ int lsfa_aggregate_cosine(const float* a, const float* b, const float* emb_warp,
 size_t lsfa_proposal_workspace_bytes(int B, int A, int H, int W, int pre_nms_top_n);
 /* Launch plan (process-wide; results are identical bit for bit): AUTO picks the chip-wide plan (six short
  * kernels spread over the CUs) for count <= 32768 anchors and pre_nms_top_n <= 8192, else the single-workgroup
- * plan (one 16-wave workgroup per image, everything in its CU's LDS).  The workspace size does not depend on it. */
+ * plan (one 16-wave workgroup per image, everything in its CU's LDS).  r6: inside the chip-wide plan AUTO builds the full
+ * suppression mask for ONE image (lowest latency) and takes the mask-free box sweep for B >= 2 (a batched pass: one workgroup
+ * per image instead of every CU; +2-4 % frames/s in the pipeline).  The workspace size does not depend on it. */
 enum { LSFA_PROPOSAL_PLAN_AUTO = 0, LSFA_PROPOSAL_PLAN_SINGLE_WORKGROUP = 1, LSFA_PROPOSAL_PLAN_CHIP_WIDE = 2,
        /* the chip-wide plan with a mask-free NMS stage (r3 experiment, same results): only the diagonal tiles of the suppression mask are
         * built and one 16-wave workgroup decides everything across blocks from the survivors' boxes in LDS.  No dependent trips to

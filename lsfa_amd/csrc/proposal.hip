@@ -803,7 +803,13 @@ extern "C" int lsfa_proposal(const float* cls_prob, const float* bbox_pred, cons
       LSFA_LAUNCH_CHECK("lsfa_proposal");
       return LSFA_OK;
     }
-    if (plan != LSFA_PROPOSAL_PLAN_CHIP_WIDE_BOX_SWEEP) {
+    // r6: AUTO takes the mask-free sweep for launches of several images.  The full mask costs the WHOLE CHIP 100 us per nine images (4465 tiles
+    // each, of which the sweep reads a sliver); the box sweep costs one workgroup per image 160 us.  Alone that is slower - r3's measurement, and
+    // why one image keeps the mask (18 + 12 us against 160: the frame-by-frame pipeline loses 6 % on the box sweep) - but in the batched
+    // pipeline a kernel's cost is the share of the chip it takes from the other streams: +2.2 ... +2.8 % frames/s (fp32), +4.2 % (bf16, four
+    // clips) with the box sweep (profiles/r6/proposal_plan_ab*.txt).  Same results bit for bit (tests/test_hip_ops.py::test_proposal_launch_plans_agree).
+    const bool box_sweep = plan == LSFA_PROPOSAL_PLAN_CHIP_WIDE_BOX_SWEEP || (plan == LSFA_PROPOSAL_PLAN_AUTO && B >= 2);
+    if (!box_sweep) {
       hipLaunchKernelGGL(nms_mask_kernel<true>, dim3(ceil_div(nms_tile_count(col_blocks), 4), 1, B), dim3(256), 0, s,
                          (const float*)sbox, (long)pre_n * 4, 4, (const int*)nullptr, pre_n, iou, mask, diagT, col_blocks, 0);
       hipLaunchKernelGGL(nms_sweep_kernel, dim3(B), dim3(64), 0, s, (const uint64_t*)mask, (const uint64_t*)diagT, pre_n,

@@ -90,8 +90,10 @@ def parse():
     ap.add_argument('--segment', type=int, default=-1,
                     help='non-key frames of a segment that go through the network in ONE pass, batch axis = frames (the reference\'s batch test '
                          'symbol, resnet_v1_101_flownet_rfcn.py:661-751); -1 = interval - 1 when one clip runs pipelined, else 0 = frame by frame')
-    ap.add_argument('--key-group', type=int, default=6,
-                    help='key frames whose image-only half (backbone, FlowNet) is computed in one pass (FramePipeline key_group); 1 = one by one')
+    ap.add_argument('--key-group', type=int, default=12,
+                    help='key frames whose image-only half (backbone, FlowNet) is computed in one pass (FramePipeline key_group); 1 = one by one.  '
+                         '12 since r6 (profiles/r6/key_group_sweep.txt: 6 -> 3664, 12 -> 3784, 18 -> 3810, 24 -> 3854 frames/s over 120 intervals; '
+                         'sizes that are not multiples of 6 lose)')
     ap.add_argument('--ramp', default='',
                     help='sizes of the first passes of key fronts after the pipeline ran empty, e.g. "1,2" (FramePipeline ramp); default: full groups at once')
     ap.add_argument('--lookahead', action='store_true',

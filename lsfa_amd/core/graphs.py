@@ -574,10 +574,11 @@ class FramePipeline(object):
         self.feat_seg = [torch.zeros((B, dim, fh, fw), device=dev, dtype=torch.float32) for _ in range(max(2, lanes) if self.segment else 0)]
         self.seg_lanes = [FrameGraphs(key_exec, cur_exec, cfg, height, width, dev, thresh, use_graphs, prefetch=False,
                                       feat_shared=f, taps=taps, batch=self.segment * B, frames_by_table=ZERO_COPY_FRAMES) for f in self.feat_seg]
-        # one bank per group size 2 .. key_group: the tail of a run of key frames (fewer images ahead than key_group - 1) is a smaller group
+        # one bank per group size 2 .. min(key_group, 6) and the full size: the tail of a run of key frames (fewer images ahead than key_group - 1)
+        # is a smaller group - with key_group > 6 the largest size there is a bank for (a bank per size would hold key_group^2 / 2 images' maps)
         # (two of the full size, alternating: the next group's pass may start while this group's key frames still take their slices)
         self.banks = {g: [KeyBank(key_exec, cfg, height, width, dev, use_graphs, g, taps, B) for _ in range(2 if g == self.key_group else 1)]
-                      for g in range(2, self.key_group + 1)}
+                      for g in sorted(set(range(2, min(self.key_group, 6) + 1)) | ({self.key_group} if self.key_group >= 2 else set()))}
         self._bank_turn = 0
         self._bank_ready = []                        # [(bank, slot, image tensor)]: fronts of upcoming key frames already computed (the tensor is HELD: its
                                                      # storage cannot be freed and handed to another image at the same address while its front waits)
@@ -791,6 +792,7 @@ class FramePipeline(object):
             cap = self.ramp_steps[self._ramp_step] if self._ramp_step < len(self.ramp_steps) else self.key_group
             self._ramp_step += 1
             g = min(cap, 1 + len(upcoming or ())) if self.banks else 1
+            g = max([n for n in self.banks if n <= g] or [1])         # (key_group > 6: not every size has a bank)
             self.group_sizes.append(g)
             del self.group_sizes[:-64]
             if g >= 2:

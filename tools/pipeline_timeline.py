@@ -4,7 +4,10 @@ for the last `frac` of the run - per queue: launches, busy time (union of its ke
 gaps with the kernels either side; over all queues: the time during which no kernel at all was running.
 
     rocprofv3 --kernel-trace --output-format csv -d DIR -o t -- python3 bench.py --steps 30 --no-cpu-baseline --no-parity
-    python3 tools/pipeline_timeline.py DIR [frac]
+    python3 tools/pipeline_timeline.py DIR [frac] [--chart MS [BUCKET_US]]
+
+--chart: a text chart of the window's first MS milliseconds, one row per hardware queue, one character per BUCKET_US (default 250) microseconds:
+the tenths of the bucket during which the queue had a kernel running ('.' = none, '#' = all of it).
 """
 import collections
 import csv
@@ -17,7 +20,25 @@ def short(name):
     return name.split('(')[0][:44]
 
 
-def main(d, frac=0.5):
+def chart(byq, t0, ms, bucket_us):
+    n = int(ms * 1e3 / bucket_us)
+    print('\nchart: %d buckets of %d us from the window\'s start; per queue, tenths of the bucket with a kernel running' % (n, bucket_us))
+    for q, ks in sorted(byq.items(), key=lambda kv: -sum(e - s for s, e, _ in kv[1])):
+        busy = [0.0] * n
+        for s, e, _ in ks:
+            a, b = (s - t0) / 1e3, (e - t0) / 1e3
+            i = int(a // bucket_us)
+            while i < n and i * bucket_us < b:
+                lo, hi = max(a, i * bucket_us), min(b, (i + 1) * bucket_us)
+                if hi > lo:
+                    busy[i] += hi - lo
+                i += 1
+        line = ''.join('.' if x <= 0 else '#' if x >= 0.95 * bucket_us else str(min(9, int(10 * x / bucket_us))) for x in busy)
+        print('queue %-3s %s' % (q, line))
+    print('ms        ' + ''.join(('%-*d' % (int(1e3 / bucket_us), i)) for i in range(int(ms))))
+
+
+def main(d, frac=0.5, chart_ms=0.0, bucket_us=250):
     f = glob.glob(d + '/**/*kernel_trace.csv', recursive=True)
     rows = list(csv.DictReader(open(f[0])))
     rows.sort(key=lambda r: int(r['Start_Timestamp']))
@@ -71,5 +92,17 @@ def main(d, frac=0.5):
             print('   %4d gaps >= 20 us, %8.0f us in all: after %-40s before %s' % (n, tt, a, b))
 
 
+    if chart_ms > 0:
+        chart(byq, t0, chart_ms, bucket_us)
+
+
 if __name__ == '__main__':
-    main(sys.argv[1], float(sys.argv[2]) if len(sys.argv) > 2 else 0.5)
+    av = sys.argv[1:]
+    cm, bu = 0.0, 250
+    if '--chart' in av:
+        i = av.index('--chart')
+        extra = av[i + 1:]
+        cm = float(extra[0])
+        bu = int(extra[1]) if len(extra) > 1 else 250
+        av = av[:i]
+    main(av[0], float(av[1]) if len(av) > 1 else 0.5, cm, bu)

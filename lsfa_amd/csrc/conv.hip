@@ -322,12 +322,25 @@ static LongKForce longk_from_env() {
   return f;
 }
 
+// lab: LSFA_CONV_PLAN_AT="chunks,cout,kernel,nt,st,slices" forces that plan on the launches of exactly that K (in chunks of 32) and channel count
+// (an in-situ A/B of one layer: the small net's fuse convolution is 72,1024; the R-FCN convolution 16,1920)
+struct AtForce { int chunks, cout; LongKForce f; };
+static AtForce at_from_env() {
+  AtForce a = {0, 0, {0, 0, 0, 0}};
+  const char* e = getenv("LSFA_CONV_PLAN_AT");
+  if (e) sscanf(e, "%d,%d,%d,%d,%d,%d", &a.chunks, &a.cout, &a.f.k, &a.f.nt, &a.f.st, &a.f.s);
+  return a;
+}
+
 void ring_plan(SplitPlan& p, long P, int chunk_total, int Cout, int pieces) {
   static const int lab_env = plan_lab_from_env();
-  static const LongKForce longk = longk_from_env();
+  static const LongKForce longk_env = longk_from_env();
+  static const AtForce at = at_from_env();
+  const bool at_hit = at.chunks > 0 && at.chunks == chunk_total && at.cout == Cout;
+  const LongKForce longk = at_hit ? at.f : longk_env;
   const int lab = lab_env >= 0 ? lab_env : kPlanDefault;
   p.wv = 4;
-  const bool lk = chunk_total >= 512 && (longk.k || longk.nt || longk.st || longk.s);
+  const bool lk = (at_hit || chunk_total >= 512) && (longk.k || longk.nt || longk.st || longk.s);
   const int f_nt = lk ? longk.nt : g_force_nt.load(), f_st = lk ? longk.st : g_force_st.load(), f_s = lk ? longk.s : g_force_slices.load(),
             f_k = lk ? longk.k : g_force_kernel.load();
   p.nx = (int)((P + convsplit::kWgPix - 1) / convsplit::kWgPix);

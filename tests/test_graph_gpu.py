@@ -622,6 +622,39 @@ def test_frame_pipeline_ramp_and_bank_bookkeeping(world):
     assert worst < TOL_DENSE, worst
 
 
+def test_frame_pipeline_key_groups_above_six_keep_few_banks(world):
+    """key_group = 8 (r6: bench.py runs 12): banks exist for group sizes 2..6 and the full size only, so a run of 15 key frames is computed
+    as passes of 8, 6 and 1 fronts - the tail takes the largest size there is a bank for - and the aggregated features are those of
+    key_group = 4 up to the convolutions' rounding (a different batch changes a launch's K cut and shared scale, never more)."""
+    from lsfa_amd.core.graphs import FramePipeline
+    from lsfa_amd.utils.synthetic import SyntheticClip
+    cfg, key, cur = world['cfg'], world['key'], world['cur']
+    key.taps = cur.taps = None
+    clip = SyntheticClip(21, 16, H, W, 1)
+    frames = [clip.frame(f, DEV) for f in range(16)]
+
+    def run(group):
+        fp = FramePipeline(key, cur, cfg, H, W, DEV, lanes=2, use_graphs=False, key_group=group)
+        assert sorted(fp.banks) == ([2, 3, 4, 5, 6, 8] if group == 8 else [2, 3, 4])
+        fp.first_frame(frames[0])
+        fp.capture()
+        feats = []
+        for k in range(1, 16):
+            fp.key_frame(frames[k], upcoming=frames[k + 1:16])
+            fp.join()
+            torch.cuda.synchronize()
+            feats.append(fp.feat.clone())
+        sizes = list(fp.group_sizes)
+        fp.close()
+        return sizes, feats
+    sizes8, f8 = run(8)
+    assert sizes8 == [8, 6, 1], sizes8
+    sizes4, f4 = run(4)
+    assert sizes4 == [4, 4, 4, 3], sizes4
+    worst = max(float((a - b).abs().max() / b.abs().max()) for a, b in zip(f8, f4))
+    assert worst < TOL_DENSE, worst
+
+
 def test_frame_pipeline_batched_with_two_clips_in_lockstep(world):
     """FramePipeline(batch=2, segment=3, key_group=2): two clips advance together, so a segment pass carries 3 frames x 2 clips (frame-major:
     image f * 2 + b samples clip b's key feature - lsfa_warp_bilinear's feat_n = 2 < N = 6) and a key group 2 key frames x 2 clips.  Every

@@ -46,7 +46,7 @@ timeout 200 rocprofv3 --kernel-trace --output-format csv -d $OUT/pmc_trace -o t 
 $PY tools/traffic_probe.py summarize $OUT/pmc_fetch $OUT/pmc_write $OUT/pmc_trace $OUT/traffic.json > $OUT/traffic_summary.log 2>&1
 rm -rf $OUT/pmc_fetch $OUT/pmc_write $OUT/pmc_trace
 # 4b. HBM traffic of the split-convolution family per call (the `roofline.traffic` of the default bench line), same two-pass rule
-EAGER="bench.py --steps 6 --warmup 3 --settle-s 0 --no-graph --no-cpu-baseline --no-parity --no-spread --no-frame-by-frame"
+EAGER="bench.py --steps 12 --warmup 12 --settle-s 0 --no-graph --no-cpu-baseline --no-parity --no-spread --no-frame-by-frame"
 timeout 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_cfetch -o t -- $PY $EAGER > $OUT/conv_traffic_fetch.log 2>&1
 timeout 300 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_cwrite -o t -- $PY $EAGER > $OUT/conv_traffic_write.log 2>&1
 $PY tools/summarize_prof.py convtraffic $OUT/pmc_cfetch $OUT/pmc_cwrite $OUT/traffic.json "conv_split:1000x600,interval=10,f32" > $OUT/conv_traffic_summary.log 2>&1
@@ -64,7 +64,7 @@ cp $(find $OUT/trace_ops -name "*kernel_stats.csv" | head -1) $OUT/bench_ops_ker
 rm -rf $OUT/trace_ops
 timeout 200 $PY tools/key_sections.py > $OUT/key_sections.txt 2>&1
 LSFA_CONV_PIECES=3 timeout 200 $PY tools/key_sections.py > $OUT/key_sections_three_bf16_pieces.txt 2>&1
-timeout 300 $PY tools/lab/key_batch_probe.py 2>&1 | tail -6 > $OUT/key_batch_probe.txt
+timeout 400 $PY tools/lab/key_batch_probe.py 1,2,3,4,6,8,12 2>&1 | tail -7 > $OUT/key_batch_probe.txt
 timeout 300 $PY tools/lab/cur_batch_probe.py 2>&1 | tail -5 > $OUT/cur_batch_probe.txt
 timeout 200 $PY tools/lab/stem_probe.py 2>&1 | tail -4 > $OUT/stem_probe.txt
 
@@ -88,7 +88,11 @@ timeout 60 $PY tools/kernel_sequence.py $OUT/bb 12 --by-name > $OUT/backbone_ker
 timeout 300 rocprofv3 --kernel-trace --output-format csv -d $OUT/bb6 -o t -- $PY tools/backbone_only.py 8 backbone 6 > /dev/null 2>&1
 timeout 60 $PY tools/kernel_sequence.py $OUT/bb6 8 --by-name > $OUT/backbone6_kernels_by_name.txt 2>&1
 timeout 60 $PY tools/kernel_sequence.py $OUT/bb6 8 > $OUT/backbone6_kernel_sequence.txt 2>&1; rm -rf $OUT/bb6
+timeout 400 rocprofv3 --kernel-trace --output-format csv -d $OUT/bb12 -o t -- $PY tools/backbone_only.py 6 backbone 12 > /dev/null 2>&1     # r6: bench.py's default key group
+timeout 60 $PY tools/kernel_sequence.py $OUT/bb12 6 --by-name > $OUT/backbone12_kernels_by_name.txt 2>&1; rm -rf $OUT/bb12
 # 8. r4: where the pipelined loop's wall time goes per hardware queue
 timeout 300 rocprofv3 --kernel-trace --output-format csv -d $OUT/tl -o t -- $PY bench.py --steps 30 --no-cpu-baseline --no-parity --no-spread --no-frame-by-frame > /dev/null 2>&1
-timeout 120 $PY tools/pipeline_timeline.py $OUT/tl 0.5 > $OUT/pipeline_timeline.txt 2>&1; rm -rf $OUT/tl
+timeout 120 $PY tools/pipeline_timeline.py $OUT/tl 0.5 --chart 60 250 > $OUT/pipeline_timeline.txt 2>&1; rm -rf $OUT/tl
+# 9. r6: ... and the schedule WITHOUT a tracer attached (the traced loop runs its queues one after the other: LABNOTES "Round 6", 13)
+timeout 300 $PY tools/lab/schedule_probe.py --steps 40 2>&1 | grep -A200 "schedule of" > $OUT/schedule_probe.txt
 ls -la $OUT

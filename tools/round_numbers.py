@@ -48,7 +48,7 @@ for f in ('bench_default_run', 'bench_driver_settings_run', 'bench_host_inputs_r
         if wr:
             print('    worst ratios:', wr)
 for f in ('backbone6_kernel_sequence.txt', 'segment9_kernel_sequence.txt', 'flownet_kernel_sequence.txt', 'curframe_kernel_sequence.txt',
-          'backbone_kernels_by_name.txt', 'backbone6_kernels_by_name.txt'):
+          'backbone_kernels_by_name.txt', 'backbone6_kernels_by_name.txt', 'backbone12_kernels_by_name.txt'):
     print('%-34s %s us over %s kernels' % ((f,) + seq_total(f)))
 for f in ('conv_family_roofline.csv', 'key_batch_probe.txt', 'cur_batch_probe.txt', 'key_sections.txt', 'gpu_suite.txt'):
     try:
@@ -67,6 +67,7 @@ if '--write-launch-counts' in sys.argv:
     seg, nseg = seq_total('segment9_kernel_sequence.txt')
     cur, ncur = seq_total('curframe_kernel_sequence.txt')
     bb6, nbb6 = seq_total('backbone6_kernels_by_name.txt')
+    bb12, nbb12 = seq_total('backbone12_kernels_by_name.txt')
     bb, nbb = seq_total('backbone_kernels_by_name.txt')
     fl, nfl = seq_total('flownet_kernel_sequence.txt')
     head = {"per_frame_mean_pipelined": lj.get("per_frame_mean"), "per_10_frame_interval_pipelined": lj.get("per_10_frame_interval"),
@@ -77,6 +78,7 @@ if '--write-launch-counts' in sys.argv:
         segment_of_9_non_key_frames_eager={"launches": nseg, "kernel_time_us": seg, "note": "tools/curframe_only.py 12 9: ONE pass for the nine non-key frames of a segment"},
         non_key_frame_alone_eager={"launches": ncur, "kernel_time_us": cur, "note": "tools/curframe_only.py 30 (one frame per pass: the frame-by-frame pipeline)"},
         key_fronts_of_6_backbone_eager={"launches": nbb6, "kernel_time_us": bb6, "note": "tools/backbone_only.py 8 backbone 6: the image-only half of six key frames in one pass"},
+        key_fronts_of_12_backbone_eager={"launches": nbb12, "kernel_time_us": bb12, "note": "tools/backbone_only.py 6 backbone 12: bench.py's default key group since r6"},
         key_frame_backbone_alone_eager={"launches": nbb, "kernel_time_us": bb},
         key_frame_flownet_alone_eager={"launches": nfl, "kernel_time_us": fl},
         source="profiles/%s/bench_pipelined_timed_region_kernels_launches.json (rocprofv3 --kernel-trace of bench.py --steps 30, batched pipeline), "
